@@ -1,0 +1,231 @@
+/*
+ * driver.c -- problem setup, the benchmark protocol and the C-ABI accessors.
+ *
+ * Behavioural reference: finite-volume/source/hpgmg-fv.c
+ *   bench_hpgmg :50-99 (warm-up solves, then timed solves, zero_vector(U) first)
+ *   main :103-386 (argument rules :152-205, setup :283-308, the h/2h/4h loop
+ *   :320-345 with its "DOF/s" line :344, Richardson analysis :351-366)
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#include "hpgmg_fv.h"
+
+extern int hpgmg_box_align_jstride, hpgmg_box_align_kstride, hpgmg_box_align_volume, hpgmg_box_align_base_bytes;
+
+static double now(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+#define SAY(rank, ...) do { if ((rank) == 0 && hpgmg_verbose) { fprintf(stdout, __VA_ARGS__); fflush(stdout); } } while (0)
+
+void hpgmg_set_verbose(int v) { hpgmg_verbose = v; }
+void hpgmg_set_box_alignment(int jstride, int kstride, int volume, int base_bytes) {
+  if (jstride > 0) hpgmg_box_align_jstride = jstride;
+  if (kstride > 0) hpgmg_box_align_kstride = kstride;
+  if (volume > 0) hpgmg_box_align_volume = volume;
+  if (base_bytes >= 8) hpgmg_box_align_base_bytes = base_bytes;
+}
+
+int hpgmg_choose_boxes_in_i(int log2_box_dim, int target_boxes_per_rank, int num_ranks) {
+  const long long box_dim = 1LL << log2_box_dim, target = (long long)target_boxes_per_rank * (long long)num_ranks;
+  long long bi, best = -1;
+  for (bi = 1; bi < 1000; bi++) {
+    if (bi * bi * bi > target) continue;
+    long long odd = box_dim * bi;
+    while ((odd & 1) == 0) odd >>= 1;
+    if (odd <= 11) best = bi; /* MAX_COARSE_DIM: the bottom solver must stay small */
+  }
+  return (int)best;
+}
+
+hpgmg_solver *hpgmg_solver_create_explicit(int boxes_in_i, int box_dim, int bc, int my_rank, int num_ranks) {
+  hpgmg_config cfg;
+  hpgmg_get_config(&cfg);
+  hpgmg_solver *s = (hpgmg_solver *)calloc(1, sizeof(*s));
+  s->boxes_in_i = boxes_in_i; s->box_dim = box_dim; s->my_rank = my_rank; s->num_ranks = num_ranks;
+  create_level(&s->level_h, boxes_in_i, box_dim, stencil_get_radius(), hpgmg_vectors_reserved(), bc, my_rank, num_ranks);
+  if (cfg.helmholtz) { s->a = 1.0; s->b = 1.0; SAY(my_rank, "  Creating Helmholtz (a=%f, b=%f) test problem\n", s->a, s->b); }
+  else               { s->a = 0.0; s->b = 1.0; SAY(my_rank, "  Creating Poisson (a=%f, b=%f) test problem\n", s->a, s->b); }
+  s->h = 1.0 / ((double)boxes_in_i * (double)box_dim);
+  initialize_problem(&s->level_h, s->h, s->a, s->b);
+  rebuild_operator(&s->level_h, NULL, s->a, s->b);
+  if (bc == BC_PERIODIC) {
+    double avg = mean(&s->level_h, VECTOR_F);
+    if (avg != 0.0) {
+      if (my_rank == 0) fprintf(stderr, "  WARNING... Periodic boundary conditions, but f does not sum to zero... mean(f)=%e\n", avg);
+      shift_vector(&s->level_h, VECTOR_F, VECTOR_F, -avg);
+    }
+  }
+  MGBuild(&s->mg, &s->level_h, s->a, s->b, bc == BC_PERIODIC ? 2 : 1);
+  return s;
+}
+
+hpgmg_solver *hpgmg_solver_create(int log2_box_dim, int target_boxes_per_rank, int bc, int my_rank, int num_ranks) {
+  int bi = hpgmg_choose_boxes_in_i(log2_box_dim, target_boxes_per_rank, num_ranks);
+  if (bi < 1) { if (my_rank == 0) fprintf(stderr, "failed to find an acceptable problem size\n"); return NULL; }
+  return hpgmg_solver_create_explicit(bi, 1 << log2_box_dim, bc, my_rank, num_ranks);
+}
+
+void hpgmg_solver_destroy(hpgmg_solver *s) {
+  if (!s) return;
+  MGDestroy(&s->mg);
+  destroy_level(&s->level_h);
+  free(s);
+}
+
+int hpgmg_solver_num_levels(const hpgmg_solver *s) { return s->mg.num_levels; }
+level_type *hpgmg_solver_level(hpgmg_solver *s, int l) { return (l >= 0 && l < s->mg.num_levels) ? s->mg.levels[l] : NULL; }
+
+void hpgmg_solver_restrict_rhs(hpgmg_solver *s, int l) {
+  if (l > 0) restriction(s->mg.levels[l], VECTOR_F, s->mg.levels[l - 1], VECTOR_F, RESTRICT_CELL);
+}
+
+double hpgmg_solver_fmg(hpgmg_solver *s, int l) {
+  zero_vector(s->mg.levels[l], VECTOR_U);
+  FMGSolve(&s->mg, l, VECTOR_U, VECTOR_F, s->a, s->b, 1e-10);
+  return hpgmg_last_solve.norm_of_residual;
+}
+
+double hpgmg_solver_bench(hpgmg_solver *s, int l, int warmup, int solves) {
+  int n;
+  for (n = 0; n < warmup; n++) hpgmg_solver_fmg(s, l);
+  MGResetTimers(&s->mg);
+  for (n = 0; n < solves; n++) hpgmg_solver_fmg(s, l);
+  return s->mg.timers.MGSolve / (double)(s->mg.MGSolves_performed ? s->mg.MGSolves_performed : 1);
+}
+
+void hpgmg_solver_richardson(hpgmg_solver *s, double out[2]) {
+  int l;
+  MGResetTimers(&s->mg);
+  for (l = 0; l < 3; l++) {
+    hpgmg_solver_restrict_rhs(s, l);
+    hpgmg_solver_fmg(s, l);
+  }
+  richardson_error(&s->mg, 0, VECTOR_U);
+  out[0] = hpgmg_last_solve.richardson_error;
+  out[1] = hpgmg_last_solve.richardson_order;
+}
+
+/* ------------------------------------------------------------------ CLI */
+static int usage(int rank) {
+  if (rank == 0) fprintf(stderr,
+    "usage: hpgmg-fv [--op 7pt|27pt|fv4|fv2] [--smoother cheby|gsrb|jacobi] [--helmholtz] [--const-coeff]\n"
+    "                [--warmup N] [--solves N] [--rank R --ranks N]  log2_box_dim  target_boxes_per_rank\n");
+  return 0;
+}
+
+int hpgmg_fv_main(int argc, char **argv) {
+  hpgmg_config cfg = { HPGMG_OP_7PT, HPGMG_SMOOTH_CHEBY, 0, 1 };
+  int pos[2], npos = 0, a, my_rank = 0, num_ranks = 1, warmup = 10, solves = 10, test_error_only = 0;
+  const hpgmg_transport *T = hpgmg_get_transport();
+  if (T) { my_rank = T->rank; num_ranks = T->size; }
+  for (a = 1; a < argc; a++) {
+    if (!strcmp(argv[a], "--op") && a + 1 < argc) { a++;
+      if (!strcmp(argv[a], "7pt")) cfg.op = HPGMG_OP_7PT; else if (!strcmp(argv[a], "27pt")) { cfg.op = HPGMG_OP_27PT; cfg.variable_coeff = 0; }
+      else if (!strcmp(argv[a], "fv4")) cfg.op = HPGMG_OP_FV4; else if (!strcmp(argv[a], "fv2")) cfg.op = HPGMG_OP_FV2; else return usage(my_rank);
+    } else if (!strcmp(argv[a], "--smoother") && a + 1 < argc) { a++;
+      if (!strcmp(argv[a], "cheby")) cfg.smoother = HPGMG_SMOOTH_CHEBY; else if (!strcmp(argv[a], "gsrb")) cfg.smoother = HPGMG_SMOOTH_GSRB;
+      else if (!strcmp(argv[a], "jacobi")) cfg.smoother = HPGMG_SMOOTH_JACOBI; else return usage(my_rank);
+    } else if (!strcmp(argv[a], "--helmholtz")) cfg.helmholtz = 1;
+    else if (!strcmp(argv[a], "--const-coeff")) cfg.variable_coeff = 0;
+    else if (!strcmp(argv[a], "--test-error")) test_error_only = 1;
+    else if (!strcmp(argv[a], "--warmup") && a + 1 < argc) warmup = atoi(argv[++a]);
+    else if (!strcmp(argv[a], "--solves") && a + 1 < argc) solves = atoi(argv[++a]);
+    else if (npos < 2 && argv[a][0] != '-') pos[npos++] = atoi(argv[a]);
+    else return usage(my_rank);
+  }
+  if (npos != 2) return usage(my_rank);
+  if (pos[0] > 9) { if (my_rank == 0) fprintf(stderr, "log2_box_dim must be less than 10\n"); return 0; }
+  if (pos[0] < 4) { if (my_rank == 0) fprintf(stderr, "log2_box_dim must be at least 4\n"); return 0; }
+  if (pos[1] < 1) { if (my_rank == 0) fprintf(stderr, "target_boxes_per_rank must be at least 1\n"); return 0; }
+  if (hpgmg_configure(&cfg)) { if (my_rank == 0) fprintf(stderr, "unsupported operator/smoother combination\n"); return 1; }
+
+  SAY(my_rank, "\n\n********************************************************************************\n"
+               "***                            HPGMG-FV Benchmark                            ***\n"
+               "********************************************************************************\n");
+  SAY(my_rank, "%d MPI Tasks of %d threads   [backend: %s]\n", num_ranks, 1, hpgmg_backend_name());
+  SAY(my_rank, "\n\n===== Benchmark setup ==========================================================\n");
+
+  hpgmg_solver *s = hpgmg_solver_create(pos[0], pos[1], BC_DIRICHLET, my_rank, num_ranks);
+  if (!s) return 0;
+
+  enum { DYNAMIC_RANGE = 3 };
+  double avg[DYNAMIC_RANGE];
+  int l, n;
+  if (!test_error_only) {
+    for (l = 0; l < DYNAMIC_RANGE; l++) {
+      hpgmg_solver_restrict_rhs(s, l);
+      SAY(my_rank, "\n\n===== Warming up by running %d solves ==========================================\n", warmup);
+      MGResetTimers(&s->mg);
+      for (n = 0; n < warmup; n++) hpgmg_solver_fmg(s, l);
+      SAY(my_rank, "\n\n===== Running %d solves ========================================================\n", solves);
+      MGResetTimers(&s->mg);
+      for (n = 0; n < solves; n++) hpgmg_solver_fmg(s, l);
+      avg[l] = s->mg.timers.MGSolve / (double)s->mg.MGSolves_performed;
+      SAY(my_rank, "\n\n===== Timing Breakdown =========================================================\n");
+      MGPrintTiming(&s->mg, l);
+    }
+    SAY(my_rank, "\n\n===== Performance Summary ======================================================\n");
+    for (l = 0; l < DYNAMIC_RANGE; l++) {
+      level_type *L = s->mg.levels[l];
+      double dof = (double)L->dim.i * (double)L->dim.j * (double)L->dim.k;
+      SAY(my_rank, "  h=%0.15e  DOF=%0.15e  time=%0.6f  DOF/s=%0.3e  MPI=%d  OMP=%d\n", L->h, dof, avg[l], dof / avg[l], num_ranks, 1);
+    }
+  }
+  SAY(my_rank, "\n\n===== Richardson error analysis ================================================\n");
+  { double out[2]; hpgmg_solver_richardson(s, out); }
+  SAY(my_rank, "\n\n===== Deallocating memory ======================================================\n");
+  hpgmg_solver_destroy(s);
+  SAY(my_rank, "\n\n===== Done =====================================================================\n");
+  (void)now;
+  return 0;
+}
+
+/* ------------------------------------------------------------------ accessors */
+void hpgmg_level_info(const level_type *L, int out[HPGMG_INFO_COUNT]) {
+  out[HPGMG_INFO_DIM] = L->dim.i;            out[HPGMG_INFO_BOX_DIM] = L->box_dim;
+  out[HPGMG_INFO_GHOSTS] = L->box_ghosts;    out[HPGMG_INFO_JSTRIDE] = L->box_jStride;
+  out[HPGMG_INFO_KSTRIDE] = L->box_kStride;  out[HPGMG_INFO_VOLUME] = L->box_volume;
+  out[HPGMG_INFO_NUM_MY_BOXES] = L->num_my_boxes; out[HPGMG_INFO_NUM_VECTORS] = L->numVectors;
+  out[HPGMG_INFO_BOXES_IN_I] = L->boxes_in.i; out[HPGMG_INFO_MY_RANK] = L->my_rank;
+  out[HPGMG_INFO_NUM_RANKS] = L->num_ranks;  out[HPGMG_INFO_NUM_MY_BLOCKS] = L->num_my_blocks;
+  out[HPGMG_INFO_ACTIVE] = L->active;
+}
+double hpgmg_level_h(const level_type *L) { return L->h; }
+double hpgmg_level_eigenvalue(const level_type *L) { return L->dominant_eigenvalue_of_DinvA; }
+void hpgmg_level_box_low(const level_type *L, int box, int out[3]) {
+  out[0] = L->my_boxes[box].low.i; out[1] = L->my_boxes[box].low.j; out[2] = L->my_boxes[box].low.k;
+}
+/* which: 0 exchange_ghosts[shape], 1 restriction[type], 2 interpolation, 3 boundary_condition[shape] (out[0] only) */
+int hpgmg_level_list_counts(const level_type *L, int which, int idx, int out[3]) {
+  const communicator_type *C = NULL;
+  out[0] = out[1] = out[2] = 0;
+  if (which == 0) C = &L->exchange_ghosts[idx]; else if (which == 1) C = &L->restriction[idx]; else if (which == 2) C = &L->interpolation;
+  else { out[0] = L->boundary_condition.num_blocks[idx]; return 0; }
+  out[0] = C->num_blocks[0]; out[1] = C->num_blocks[1]; out[2] = C->num_blocks[2];
+  return C->num_sends + C->num_recvs;
+}
+void hpgmg_level_read_vector(level_type *L, int box, int id, double *host_out) {
+  hpgmg_vector_download(host_out, L->my_boxes[box].vectors[id], (size_t)L->box_volume);
+}
+void hpgmg_level_write_vector(level_type *L, int box, int id, const double *host_in) {
+  hpgmg_vector_upload(L->my_boxes[box].vectors[id], host_in, (size_t)L->box_volume);
+}
+level_type *hpgmg_level_create(int boxes_in_i, int box_dim, int ghosts, int numVectors, int bc, int my_rank, int num_ranks, double h) {
+  level_type *L = (level_type *)malloc(sizeof(level_type));
+  create_level(L, boxes_in_i, box_dim, ghosts, numVectors, bc, my_rank, num_ranks);
+  L->h = h;
+  return L;
+}
+void hpgmg_level_destroy(level_type *L) { if (L) { destroy_level(L); free(L); } }
+mg_type *hpgmg_mg_create(level_type *fine, double a, double b, int minCoarseDim) {
+  mg_type *G = (mg_type *)calloc(1, sizeof(mg_type));
+  MGBuild(G, fine, a, b, minCoarseDim);
+  return G;
+}
+void hpgmg_mg_destroy(mg_type *G) { if (G) { MGDestroy(G); free(G); } }
+level_type *hpgmg_mg_level(mg_type *G, int l) { return (l >= 0 && l < G->num_levels) ? G->levels[l] : NULL; }
+int hpgmg_mg_num_levels(const mg_type *G) { return G->num_levels; }

@@ -1,0 +1,491 @@
+/*
+ * level.c -- builds one multigrid level: box -> rank map, vector storage, the
+ * tile list and the ghost-exchange / boundary-condition "mini programs".
+ *
+ * Behavioural reference: finite-volume/source/level.c
+ *   decompose_level_zmort :240-275   append_block_to_list     :313-361
+ *   build_boundary_conditions :367-465   build_exchange_ghosts :498-922
+ *   create_vectors :929-1068   create_level :1075-1258
+ * Written from scratch; what is kept is the CONTRACT (who owns which box, the
+ * order of data inside a message, the padding rule), because the neighbouring
+ * rank and the operator kernels depend on it.
+ *
+ * Difference that matters on a GPU: all boxes of a level are carved from ONE
+ * allocation (a slab) obtained from the operator plugin (hpgmg_vector_alloc),
+ * so vector bytes are device memory and are never touched from this file.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include "hpgmg_level.h"
+#include "hpgmg_operators.h"
+#include "hpgmg_mg.h"
+
+/* sanctioned tuning knobs of the reference (level.h:46-55), runtime here */
+int hpgmg_box_align_jstride = 4;
+int hpgmg_box_align_kstride = 4;
+int hpgmg_box_align_volume  = 4;
+int hpgmg_box_align_base_bytes = 32; /* alignment of the first interior cell of vector 0 of each box */
+
+#define DIE(...) do { fprintf(stderr, __VA_ARGS__); exit(1); } while (0)
+
+/* ------------------------------------------------------------------ side records */
+static hpgmg_level_ext *ext_head = NULL;
+
+hpgmg_level_ext *hpgmg_level_ext_get(level_type *level) {
+  hpgmg_level_ext *e;
+  for (e = ext_head; e; e = e->next) if (e->level == level) return e;
+  e = (hpgmg_level_ext *)calloc(1, sizeof(*e));
+  e->level = level;
+  e->next = ext_head;
+  ext_head = e;
+  return e;
+}
+
+void hpgmg_level_ext_drop(level_type *level) {
+  hpgmg_level_ext **pp = &ext_head;
+  while (*pp) {
+    if ((*pp)->level == level) {
+      hpgmg_level_ext *dead = *pp;
+      *pp = dead->next;
+      free(dead->active_ranks);
+      free(dead);
+      return;
+    }
+    pp = &(*pp)->next;
+  }
+}
+
+/* ------------------------------------------------------------------ transport */
+static hpgmg_transport the_transport;
+static int have_transport = 0;
+void hpgmg_set_transport(const hpgmg_transport *t) {
+  if (t) { the_transport = *t; have_transport = 1; } else have_transport = 0;
+}
+const hpgmg_transport *hpgmg_get_transport(void) { return have_transport ? &the_transport : NULL; }
+
+/* ------------------------------------------------------------------ box -> rank
+ * Z-Morton walk over the (possibly non power-of-two) box grid; box n along the
+ * curve goes to rank floor(ranks*n/curve_length).  Octants are visited i fastest,
+ * an odd extent gives the smaller half to the low side (reference :240-275). */
+static int zmort_assign(int *rank_of_box, const int nb[3], int lo_i, int lo_j, int lo_k,
+                        int ei, int ej, int ek, int ranks, int pos, int curve_len) {
+  if (ei < 1 || ej < 1 || ek < 1) return pos;
+  if (ei == 1 && ej == 1 && ek == 1) {
+    if (lo_i < nb[0] && lo_j < nb[1] && lo_k < nb[2]) {
+      rank_of_box[lo_i + nb[0] * (lo_j + nb[1] * lo_k)] = (int)(((uint64_t)ranks * (uint64_t)pos) / (uint64_t)curve_len);
+      pos++;
+    }
+    return pos;
+  }
+  int oct;
+  for (oct = 0; oct < 8; oct++) {
+    int hi_i = oct & 1, hi_j = (oct >> 1) & 1, hi_k = (oct >> 2) & 1;
+    pos = zmort_assign(rank_of_box, nb,
+                       hi_i ? lo_i + ei / 2 : lo_i, hi_j ? lo_j + ej / 2 : lo_j, hi_k ? lo_k + ek / 2 : lo_k,
+                       hi_i ? ei - ei / 2 : ei / 2, hi_j ? ej - ej / 2 : ej / 2, hi_k ? ek - ek / 2 : ek / 2,
+                       ranks, pos, curve_len);
+  }
+  return pos;
+}
+
+/* ------------------------------------------------------------------ block lists */
+void append_block_to_list(blockCopy_type **blocks, int *allocated_blocks, int *num_blocks,
+                          int dim_i, int dim_j, int dim_k,
+                          int read_box, double *read_ptr, int read_i, int read_j, int read_k,
+                          int read_jStride, int read_kStride, int read_scale,
+                          int write_box, double *write_ptr, int write_i, int write_j, int write_k,
+                          int write_jStride, int write_kStride, int write_scale,
+                          int tile_i, int tile_j, int tile_k, int subtype) {
+  /* cut the region into tiles; read/write_scale (1 or 2) lets one list entry
+   * describe a restriction (read 2x) or an interpolation (write 2x) */
+  int ti, tj, tk;
+  for (tk = 0; tk < dim_k; tk += tile_k)
+  for (tj = 0; tj < dim_j; tj += tile_j)
+  for (ti = 0; ti < dim_i; ti += tile_i) {
+    if (*num_blocks >= *allocated_blocks) {
+      int want = *allocated_blocks ? 2 * (*allocated_blocks) : 1024;
+      blockCopy_type *grown = NULL;
+      if (posix_memalign((void **)&grown, 64, (size_t)want * sizeof(blockCopy_type))) DIE("append_block_to_list: out of memory\n");
+      if (*blocks) { memcpy(grown, *blocks, (size_t)(*num_blocks) * sizeof(blockCopy_type)); free(*blocks); }
+      *blocks = grown;
+      *allocated_blocks = want;
+    }
+    blockCopy_type *b = &(*blocks)[(*num_blocks)++];
+    memset(b, 0, sizeof(*b));
+    b->subtype = subtype;
+    b->dim.i = (dim_i - ti < tile_i) ? dim_i - ti : tile_i;
+    b->dim.j = (dim_j - tj < tile_j) ? dim_j - tj : tile_j;
+    b->dim.k = (dim_k - tk < tile_k) ? dim_k - tk : tile_k;
+    b->read.box = read_box;   b->read.ptr = read_ptr;
+    b->read.i = read_i + read_scale * ti;
+    b->read.j = read_j + read_scale * tj;
+    b->read.k = read_k + read_scale * tk;
+    b->read.jStride = read_jStride;   b->read.kStride = read_kStride;
+    b->write.box = write_box; b->write.ptr = write_ptr;
+    b->write.i = write_i + write_scale * ti;
+    b->write.j = write_j + write_scale * tj;
+    b->write.k = write_k + write_scale * tk;
+    b->write.jStride = write_jStride; b->write.kStride = write_kStride;
+  }
+}
+
+/* kind of a direction code 13+di+3dj+9dk: 1 face, 2 edge, 3 corner, 0 centre */
+static int dir_kind(int dir) {
+  int di = dir % 3 - 1, dj = (dir / 3) % 3 - 1, dk = dir / 9 - 1;
+  return (di != 0) + (dj != 0) + (dk != 0);
+}
+static int shape_wants(int shape, int dir) {
+  int kind = dir_kind(dir);
+  if (kind == 0) return 0;
+  if (shape == STENCIL_SHAPE_STAR) return kind == 1;
+  if (shape == STENCIL_SHAPE_NO_CORNERS) return kind <= 2;
+  return 1;
+}
+
+/* id of the box at (bi+di, bj+dj, bk+dk), -1 if outside a Dirichlet domain / a hole */
+static int neighbor_box(const level_type *L, int bi, int bj, int bk, int di, int dj, int dk) {
+  int ni = bi + di, nj = bj + dj, nk = bk + dk;
+  if (L->boundary_condition.type == BC_PERIODIC) {
+    ni = (ni + L->boxes_in.i) % L->boxes_in.i;
+    nj = (nj + L->boxes_in.j) % L->boxes_in.j;
+    nk = (nk + L->boxes_in.k) % L->boxes_in.k;
+  } else if (ni < 0 || nj < 0 || nk < 0 || ni >= L->boxes_in.i || nj >= L->boxes_in.j || nk >= L->boxes_in.k) {
+    return -1;
+  }
+  int id = ni + L->boxes_in.i * (nj + L->boxes_in.j * nk);
+  return (L->rank_of_box[id] < 0) ? -1 : id;
+}
+
+static int local_index_of(const level_type *L, int global_id) {
+  int b;
+  for (b = 0; b < L->num_my_boxes; b++) if (L->my_boxes[b].global_box_id == global_id) return b;
+  return -1;
+}
+
+/* For one axis of a send direction d (relative to the SENDER): first interior
+ * cell sent, how many, and where it lands in the receiver's coordinates. */
+static void axis_span(int d, int dim, int g, int *send_lo, int *len, int *recv_lo) {
+  if (d < 0)      { *send_lo = 0;       *len = g;   *recv_lo = dim; }
+  else if (d > 0) { *send_lo = dim - g; *len = g;   *recv_lo = -g;  }
+  else            { *send_lo = 0;       *len = dim; *recv_lo = 0;   }
+}
+
+/* Domain-boundary ghost regions of my boxes, tagged with the DOMAIN normal so a
+ * box corner sitting on a domain face is treated as a face (reference :367-465). */
+static void build_boundary_conditions(level_type *L, int shape) {
+  L->boundary_condition.blocks[shape] = NULL;
+  L->boundary_condition.num_blocks[shape] = 0;
+  L->boundary_condition.allocated_blocks[shape] = 0;
+  if (L->boundary_condition.type == BC_PERIODIC) return;
+  const int g = L->box_ghosts, dim = L->box_dim;
+  const int tile_jk = (16 < g) ? g : 16; /* a BC tile may not be thinner than the ghost depth */
+  int box, dir;
+  for (box = 0; box < L->num_my_boxes; box++) {
+    const box_type *B = &L->my_boxes[box];
+    int bi = B->low.i / dim, bj = B->low.j / dim, bk = B->low.k / dim;
+    for (dir = 0; dir < 27; dir++) {
+      int di = dir % 3 - 1, dj = (dir / 3) % 3 - 1, dk = dir / 9 - 1;
+      if (!shape_wants(shape, dir)) continue;
+      int normal = 13, outside = 0;
+      if (bi + di < 0) { outside = 1; normal -= 1; }  if (bi + di >= L->boxes_in.i) { outside = 1; normal += 1; }
+      if (bj + dj < 0) { outside = 1; normal -= 3; }  if (bj + dj >= L->boxes_in.j) { outside = 1; normal += 3; }
+      if (bk + dk < 0) { outside = 1; normal -= 9; }  if (bk + dk >= L->boxes_in.k) { outside = 1; normal += 9; }
+      if (!outside) continue;
+      int lo_i = di < 0 ? -g : (di > 0 ? dim : 0), len_i = di ? g : dim;
+      int lo_j = dj < 0 ? -g : (dj > 0 ? dim : 0), len_j = dj ? g : dim;
+      int lo_k = dk < 0 ? -g : (dk > 0 ? dim : 0), len_k = dk ? g : dim;
+      append_block_to_list(&L->boundary_condition.blocks[shape], &L->boundary_condition.allocated_blocks[shape],
+                           &L->boundary_condition.num_blocks[shape], len_i, len_j, len_k,
+                           box, NULL, lo_i, lo_j, lo_k, B->jStride, B->kStride, 1,
+                           box, NULL, lo_i, lo_j, lo_k, B->jStride, B->kStride, 1,
+                           BLOCKCOPY_TILE_I < g ? g : BLOCKCOPY_TILE_I, tile_jk, tile_jk, normal);
+    }
+  }
+}
+
+/* ------------------------------------------------------------------ ghost exchange */
+typedef struct { int send_rank, send_id, send_box, dir, recv_rank, recv_id, recv_box; } halo_t;
+
+static int halo_cmp(const void *pa, const void *pb) {
+  const halo_t *a = (const halo_t *)pa, *b = (const halo_t *)pb;
+  if (a->send_rank != b->send_rank) return a->send_rank < b->send_rank ? -1 : 1;
+  if (a->send_id   != b->send_id)   return a->send_id   < b->send_id   ? -1 : 1;
+  if (a->dir       != b->dir)       return a->dir       < b->dir       ? -1 : 1;
+  return 0;
+}
+static int int_cmp(const void *pa, const void *pb) {
+  int a = *(const int *)pa, b = *(const int *)pb;
+  return (a > b) - (a < b);
+}
+static int sort_unique(int *v, int n) {
+  int i, m = 0;
+  qsort(v, (size_t)n, sizeof(int), int_cmp);
+  for (i = 0; i < n; i++) if (m == 0 || v[m - 1] != v[i]) v[m++] = v[i];
+  return m;
+}
+static int find_int(const int *v, int n, int x) { int i; for (i = 0; i < n; i++) if (v[i] == x) return i; return -1; }
+
+static void comm_clear(communicator_type *c) { memset(c, 0, sizeof(*c)); }
+
+/* Message convention (both sides derive it independently, reference :593, :786):
+ * inside the buffer for one (sender,receiver) pair, regions are ordered by the
+ * sender's global box id, then by the direction code seen from the sender. */
+static void build_exchange_ghosts(level_type *L, int shape) {
+  communicator_type *C = &L->exchange_ghosts[shape];
+  comm_clear(C);
+  const int g = L->box_ghosts, dim = L->box_dim, me = L->my_rank;
+  const int nmax = 26 * (L->num_my_boxes > 0 ? L->num_my_boxes : 1);
+  halo_t *out = (halo_t *)malloc((size_t)nmax * sizeof(halo_t));
+  halo_t *in  = (halo_t *)malloc((size_t)nmax * sizeof(halo_t));
+  int *peers  = (int *)malloc((size_t)nmax * sizeof(int));
+  int n_out = 0, n_in = 0, n_peers = 0, box, dir, n, pass;
+
+  /* what I send (to anyone, myself included) and what I receive from others */
+  for (box = 0; box < L->num_my_boxes; box++) {
+    const box_type *B = &L->my_boxes[box];
+    int bi = B->low.i / dim, bj = B->low.j / dim, bk = B->low.k / dim;
+    for (dir = 0; dir < 27; dir++) {
+      if (!shape_wants(shape, dir)) continue;
+      int nb = neighbor_box(L, bi, bj, bk, dir % 3 - 1, (dir / 3) % 3 - 1, dir / 9 - 1);
+      if (nb < 0) continue;
+      int r = L->rank_of_box[nb];
+      halo_t h = { me, B->global_box_id, box, dir, r, nb, (r == me) ? local_index_of(L, nb) : -1 };
+      out[n_out++] = h;
+      if (r != me) {
+        halo_t q = { r, nb, -1, 26 - dir, me, B->global_box_id, box };
+        in[n_in++] = q;
+        peers[n_peers++] = r;
+      }
+    }
+  }
+  qsort(out, (size_t)n_out, sizeof(halo_t), halo_cmp);
+  qsort(in,  (size_t)n_in,  sizeof(halo_t), halo_cmp);
+  n_peers = sort_unique(peers, n_peers); /* halo relation is symmetric: send peers == recv peers */
+
+  C->num_sends = C->num_recvs = n_peers;
+  if (n_peers) {
+    C->send_ranks = (int *)malloc(n_peers * sizeof(int));  C->recv_ranks = (int *)malloc(n_peers * sizeof(int));
+    C->send_sizes = (int *)calloc(n_peers, sizeof(int));   C->recv_sizes = (int *)calloc(n_peers, sizeof(int));
+    C->send_buffers = (double **)calloc(n_peers, sizeof(double *));
+    C->recv_buffers = (double **)calloc(n_peers, sizeof(double *));
+    memcpy(C->send_ranks, peers, n_peers * sizeof(int));
+    memcpy(C->recv_ranks, peers, n_peers * sizeof(int));
+  }
+
+  /* pass 0 sizes the buffers, pass 1 allocates them and emits the lists */
+  for (pass = 0; pass < 2; pass++) {
+    if (pass == 1 && n_peers) {
+      size_t tot_s = 0, tot_r = 0;
+      for (n = 0; n < n_peers; n++) { tot_s += C->send_sizes[n]; tot_r += C->recv_sizes[n]; }
+      double *sb = hpgmg_vector_alloc(tot_s ? tot_s : 1), *rb = hpgmg_vector_alloc(tot_r ? tot_r : 1);
+      for (n = 0; n < n_peers; n++) {
+        C->send_buffers[n] = sb; sb += C->send_sizes[n]; C->send_sizes[n] = 0;
+        C->recv_buffers[n] = rb; rb += C->recv_sizes[n]; C->recv_sizes[n] = 0;
+      }
+    }
+    for (n = 0; n < n_out; n++) {
+      int di = out[n].dir % 3 - 1, dj = (out[n].dir / 3) % 3 - 1, dk = out[n].dir / 9 - 1;
+      int si, sj, sk, li, lj, lk, ri, rj, rk;
+      axis_span(di, dim, g, &si, &li, &ri);
+      axis_span(dj, dim, g, &sj, &lj, &rj);
+      axis_span(dk, dim, g, &sk, &lk, &rk);
+      const box_type *S = &L->my_boxes[out[n].send_box];
+      if (out[n].recv_rank == me) {
+        if (pass == 1) {
+          const box_type *R = &L->my_boxes[out[n].recv_box];
+          append_block_to_list(&C->blocks[1], &C->allocated_blocks[1], &C->num_blocks[1], li, lj, lk,
+                               out[n].send_box, NULL, si, sj, sk, S->jStride, S->kStride, 1,
+                               out[n].recv_box, NULL, ri, rj, rk, R->jStride, R->kStride, 1,
+                               BLOCKCOPY_TILE_I, 16, 16, 0);
+        }
+      } else {
+        int p = find_int(C->send_ranks, n_peers, out[n].recv_rank);
+        if (pass == 1)
+          append_block_to_list(&C->blocks[0], &C->allocated_blocks[0], &C->num_blocks[0], li, lj, lk,
+                               out[n].send_box, NULL, si, sj, sk, S->jStride, S->kStride, 1,
+                               -1, C->send_buffers[p], C->send_sizes[p], 0, 0, li, li * lj, 1,
+                               BLOCKCOPY_TILE_I, 16, 16, 0);
+        C->send_sizes[p] += li * lj * lk;
+      }
+    }
+    for (n = 0; n < n_in; n++) {
+      int di = in[n].dir % 3 - 1, dj = (in[n].dir / 3) % 3 - 1, dk = in[n].dir / 9 - 1;
+      int si, sj, sk, li, lj, lk, ri, rj, rk;
+      axis_span(di, dim, g, &si, &li, &ri);
+      axis_span(dj, dim, g, &sj, &lj, &rj);
+      axis_span(dk, dim, g, &sk, &lk, &rk);
+      int p = find_int(C->recv_ranks, n_peers, in[n].send_rank);
+      if (pass == 1) {
+        const box_type *R = &L->my_boxes[in[n].recv_box];
+        append_block_to_list(&C->blocks[2], &C->allocated_blocks[2], &C->num_blocks[2], li, lj, lk,
+                             -1, C->recv_buffers[p], C->recv_sizes[p], 0, 0, li, li * lj, 1,
+                             in[n].recv_box, NULL, ri, rj, rk, R->jStride, R->kStride, 1,
+                             BLOCKCOPY_TILE_I, 16, 16, 0);
+      }
+      C->recv_sizes[p] += li * lj * lk;
+    }
+  }
+  free(out); free(in); free(peers);
+}
+
+static void comm_free(communicator_type *C) {
+  int n;
+  if (C->num_recvs > 0 && C->recv_buffers) { if (C->recv_buffers[0]) hpgmg_vector_free(C->recv_buffers[0]); }
+  if (C->num_sends > 0 && C->send_buffers) { if (C->send_buffers[0]) hpgmg_vector_free(C->send_buffers[0]); }
+  free(C->recv_buffers); free(C->send_buffers);
+  free(C->recv_ranks); free(C->send_ranks); free(C->recv_sizes); free(C->send_sizes);
+  for (n = 0; n < 3; n++) free(C->blocks[n]);
+  comm_clear(C);
+}
+void hpgmg_communicator_free(communicator_type *C) { comm_free(C); }
+
+/* ------------------------------------------------------------------ vectors */
+static int round_up(int x, int m) { return (m > 1) ? ((x + m - 1) / m) * m : x; }
+
+/* (Re)allocate vector storage for every owned box.  Padding rule = reference
+ * :935-938: jStride = roundup(dim+2g), kStride = jStride*(dim+2g),
+ * volume = kStride*(dim+2g).  All boxes share one slab: box b, vector v starts
+ * at slab_aligned + (b*numVectors + v)*volume. */
+void create_vectors(level_type *L, int numVectors) {
+  if (numVectors <= L->numVectors) return;
+  const int old_nv = L->numVectors, width = L->box_dim + 2 * L->box_ghosts;
+  L->box_jStride = round_up(width, hpgmg_box_align_jstride);
+  L->box_kStride = round_up(L->box_jStride * width, hpgmg_box_align_kstride);
+  L->box_volume  = round_up(L->box_kStride * width, hpgmg_box_align_volume);
+
+  hpgmg_level_ext *X = hpgmg_level_ext_get(L);
+  double *old_slab = X->slab;
+  double **old_v0 = NULL;
+  int b, v;
+  if (old_nv > 0) {
+    old_v0 = (double **)malloc((size_t)(L->num_my_boxes + 1) * sizeof(double *));
+    for (b = 0; b < L->num_my_boxes; b++) old_v0[b] = L->my_boxes[b].vectors[0];
+  }
+  const size_t per_box = (size_t)numVectors * (size_t)L->box_volume;
+  const size_t pad = (size_t)hpgmg_box_align_base_bytes / sizeof(double) + 8;
+  X->slab_doubles = per_box * (size_t)L->num_my_boxes + pad;
+  X->slab = L->num_my_boxes ? hpgmg_vector_alloc(X->slab_doubles) : NULL;
+  double *base = X->slab;
+  if (base) { /* put the first interior cell of (box 0, vector 0) on the requested boundary */
+    size_t first = (size_t)L->box_ghosts * (size_t)(1 + L->box_jStride + L->box_kStride);
+    while (((uintptr_t)(base + first)) % (uintptr_t)hpgmg_box_align_base_bytes) base++;
+  }
+  for (b = 0; b < L->num_my_boxes; b++) {
+    box_type *B = &L->my_boxes[b];
+    if (old_nv > 0) free(B->vectors);
+    B->vectors = (double **)malloc((size_t)numVectors * sizeof(double *));
+    B->fp_base = X->slab;
+    for (v = 0; v < numVectors; v++) B->vectors[v] = base + per_box * (size_t)b + (size_t)v * (size_t)L->box_volume;
+    if (old_nv > 0) hpgmg_vector_copy(B->vectors[0], old_v0[b], (size_t)old_nv * (size_t)L->box_volume);
+  }
+  if (old_nv > 0) { free(old_v0); if (old_slab) hpgmg_vector_free(old_slab); }
+
+  /* box descriptors, in global-id order */
+  b = 0;
+  int i, j, k;
+  for (k = 0; k < L->boxes_in.k; k++)
+  for (j = 0; j < L->boxes_in.j; j++)
+  for (i = 0; i < L->boxes_in.i; i++) {
+    int id = i + L->boxes_in.i * (j + L->boxes_in.j * k);
+    if (L->rank_of_box[id] != L->my_rank) continue;
+    box_type *B = &L->my_boxes[b++];
+    B->numVectors = numVectors;
+    B->dim = L->box_dim;        B->ghosts = L->box_ghosts;
+    B->jStride = L->box_jStride; B->kStride = L->box_kStride; B->volume = L->box_volume;
+    B->low.i = i * L->box_dim;  B->low.j = j * L->box_dim;   B->low.k = k * L->box_dim;
+    B->global_box_id = id;
+  }
+  L->numVectors = numVectors;
+}
+
+/* ------------------------------------------------------------------ level */
+void create_level(level_type *L, int boxes_in_i, int box_dim, int box_ghosts, int numVectors,
+                  int domain_boundary_condition, int my_rank, int num_ranks) {
+  const int total_boxes = boxes_in_i * boxes_in_i * boxes_in_i;
+  int b, shape;
+  if (my_rank == 0 && hpgmg_verbose) {
+    fprintf(stdout, "\nattempting to create a %d^3 level from %d x %d^3 boxes distributed among %d tasks...\n",
+            box_dim * boxes_in_i, total_boxes, box_dim, num_ranks);
+    fprintf(stdout, domain_boundary_condition == BC_DIRICHLET ? "  boundary condition = BC_DIRICHLET\n"
+                                                               : "  boundary condition = BC_PERIODIC\n");
+  }
+  if (box_ghosts < stencil_get_radius())
+    DIE("ghosts(%d) must be >= stencil_get_radius(%d)\n", box_ghosts, stencil_get_radius());
+
+  memset(L, 0, sizeof(*L));
+  L->box_dim = box_dim;  L->box_ghosts = box_ghosts;
+  L->boxes_in.i = L->boxes_in.j = L->boxes_in.k = boxes_in_i;
+  L->dim.i = L->dim.j = L->dim.k = box_dim * boxes_in_i;
+  L->active = 1;  L->my_rank = my_rank;  L->num_ranks = num_ranks;
+  L->boundary_condition.type = domain_boundary_condition;
+  L->must_subtract_mean = -1;
+  L->num_threads = 1;
+  L->tag = (int)log2((double)L->dim.i);
+
+  L->rank_of_box = (int *)malloc((size_t)total_boxes * sizeof(int));
+  for (b = 0; b < total_boxes; b++) L->rank_of_box[b] = -1;
+  { const int nb[3] = { boxes_in_i, boxes_in_i, boxes_in_i };
+    if (my_rank == 0 && hpgmg_verbose) { fprintf(stdout, "  Decomposing level via Z-mort ordering... "); fflush(stdout); }
+    zmort_assign(L->rank_of_box, nb, 0, 0, 0, boxes_in_i, boxes_in_i, boxes_in_i, num_ranks, 0, total_boxes);
+    if (my_rank == 0 && hpgmg_verbose) fprintf(stdout, "done\n"); }
+
+  for (b = 0; b < total_boxes; b++) if (L->rank_of_box[b] == my_rank) L->num_my_boxes++;
+  L->my_boxes = (box_type *)calloc((size_t)(L->num_my_boxes + 1), sizeof(box_type));
+
+  if (my_rank == 0 && hpgmg_verbose) { fprintf(stdout, "  Allocating vectors... "); fflush(stdout); }
+  create_vectors(L, numVectors);
+  if (my_rank == 0 && hpgmg_verbose) fprintf(stdout, "done\n");
+
+  /* flatten boxes into dim x 8 x 8 tiles: the unit every operator iterates over */
+  for (b = 0; b < L->num_my_boxes; b++) {
+    const box_type *B = &L->my_boxes[b];
+    append_block_to_list(&L->my_blocks, &L->allocated_blocks, &L->num_my_blocks, B->dim, B->dim, B->dim,
+                         b, NULL, 0, 0, 0, B->jStride, B->kStride, 1,
+                         b, NULL, 0, 0, 0, B->jStride, B->kStride, 1,
+                         BLOCKCOPY_TILE_I, BLOCKCOPY_TILE_J, BLOCKCOPY_TILE_K, 0);
+  }
+  for (shape = 0; shape < STENCIL_MAX_SHAPES; shape++) build_exchange_ghosts(L, shape);
+  for (shape = 0; shape < STENCIL_MAX_SHAPES; shape++) build_boundary_conditions(L, shape);
+
+  /* every rank can name the ranks owning boxes here without communicating */
+  { hpgmg_level_ext *X = hpgmg_level_ext_get(L);
+    int *owners = (int *)malloc((size_t)total_boxes * sizeof(int)), n = 0;
+    for (b = 0; b < total_boxes; b++) if (L->rank_of_box[b] >= 0) owners[n++] = L->rank_of_box[b];
+    X->num_active_ranks = sort_unique(owners, n);
+    free(X->active_ranks);
+    X->active_ranks = owners; }
+
+  int most = L->num_my_boxes;
+  { const hpgmg_transport *T = hpgmg_get_transport();
+    if (T && T->size > 1) {
+      int r, *all = (int *)malloc((size_t)T->size * sizeof(int));
+      double v = (double)most;
+      for (r = 0; r < T->size; r++) all[r] = r;
+      T->allreduce(T->ctx, &v, 1, HPGMG_REDUCE_MAX, all, T->size);
+      most = (int)v; free(all);
+    } }
+  if (my_rank == 0 && hpgmg_verbose)
+    fprintf(stdout, "  Calculating boxes per process... target=%0.3f, max=%d\n", (double)total_boxes / (double)num_ranks, most);
+}
+
+void reset_level_timers(level_type *L) {
+  memset(&L->timers, 0, sizeof(L->timers));
+  L->Krylov_iterations = 0;
+  L->CAKrylov_formations_of_G = 0;
+  L->vcycles_from_this_level = 0;
+}
+
+void destroy_level(level_type *L) {
+  int i;
+  if (L->my_rank == 0 && hpgmg_verbose) { fprintf(stdout, "attempting to free the %5d^3 level... ", L->dim.i); fflush(stdout); }
+  hpgmg_level_release(L);
+  hpgmg_level_ext *X = hpgmg_level_ext_get(L);
+  if (X->slab) hpgmg_vector_free(X->slab);
+  for (i = 0; i < L->num_my_boxes; i++) free(L->my_boxes[i].vectors);
+  free(L->rank_of_box); free(L->my_boxes); free(L->my_blocks);
+  for (i = 0; i < STENCIL_MAX_SHAPES; i++) { free(L->boundary_condition.blocks[i]); comm_free(&L->exchange_ghosts[i]); }
+  hpgmg_level_ext_drop(L);
+  if (L->my_rank == 0 && hpgmg_verbose) fprintf(stdout, "done\n");
+}

@@ -1,0 +1,81 @@
+/*
+ * hpgmg_fv.h -- C-ABI of the host driver library (libhpgmg_fv.so / liboracle_fv.so).
+ *
+ * Plain pointers, ints and doubles only; this is what ctypes (tests, bench.py)
+ * and any non-C host binds.  It wraps what the reference does in
+ * finite-volume/source/hpgmg-fv.c: main() :103-386 (problem-size selection
+ * :152-205, level creation :283-295, MGBuild :308, the timed loop :320-345,
+ * Richardson analysis :351-366) and bench_hpgmg() :50-99.
+ */
+#ifndef HPGMG_FV_H
+#define HPGMG_FV_H
+
+#include "hpgmg_level.h"
+#include "hpgmg_operators.h"
+#include "hpgmg_mg.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hpgmg_solver {
+  level_type level_h;   /* finest level */
+  mg_type    mg;
+  double a, b, h;
+  int boxes_in_i, box_dim;
+  int my_rank, num_ranks;
+} hpgmg_solver;
+
+/* largest boxes_in_i with boxes_in_i^3 <= boxes_per_rank*ranks whose odd part of
+ * (box_dim*boxes_in_i) is <= 11 (reference hpgmg-fv.c:181-197); -1 if none */
+int hpgmg_choose_boxes_in_i(int log2_box_dim, int target_boxes_per_rank, int num_ranks);
+
+/* create level + problem + operator + hierarchy (hpgmg-fv.c:283-308).
+ * Call hpgmg_configure() first.  bc = BC_DIRICHLET or BC_PERIODIC. */
+hpgmg_solver *hpgmg_solver_create(int log2_box_dim, int target_boxes_per_rank, int bc, int my_rank, int num_ranks);
+/* same, but with an explicit box grid (tests use tiny domains the CLI rejects) */
+hpgmg_solver *hpgmg_solver_create_explicit(int boxes_in_i, int box_dim, int bc, int my_rank, int num_ranks);
+void hpgmg_solver_destroy(hpgmg_solver *s);
+
+int         hpgmg_solver_num_levels(const hpgmg_solver *s);
+level_type *hpgmg_solver_level(hpgmg_solver *s, int l);
+
+/* F(l) = restriction of F(l-1), as the benchmark does before solving on 2h, 4h (hpgmg-fv.c:324) */
+void   hpgmg_solver_restrict_rhs(hpgmg_solver *s, int l);
+/* zero_vector(U); FMGSolve(...) on level l; returns ||F - A u||_inf (hpgmg-fv.c:79-81) */
+double hpgmg_solver_fmg(hpgmg_solver *s, int l);
+/* warmup + timed solves (hpgmg-fv.c:50-99); returns average seconds per solve */
+double hpgmg_solver_bench(hpgmg_solver *s, int l, int warmup, int solves);
+/* solve on l, l+1, l+2 then richardson_error (hpgmg-fv.c:351-366); out[0]=error out[1]=order */
+void   hpgmg_solver_richardson(hpgmg_solver *s, double out[2]);
+
+/* the reference's whole main(): prints the same report; returns 0 */
+int hpgmg_fv_main(int argc, char **argv);
+
+/* ---- small accessors so a ctypes caller never needs the struct layouts ---- */
+enum { HPGMG_INFO_DIM = 0, HPGMG_INFO_BOX_DIM, HPGMG_INFO_GHOSTS, HPGMG_INFO_JSTRIDE, HPGMG_INFO_KSTRIDE,
+       HPGMG_INFO_VOLUME, HPGMG_INFO_NUM_MY_BOXES, HPGMG_INFO_NUM_VECTORS, HPGMG_INFO_BOXES_IN_I,
+       HPGMG_INFO_MY_RANK, HPGMG_INFO_NUM_RANKS, HPGMG_INFO_NUM_MY_BLOCKS, HPGMG_INFO_ACTIVE, HPGMG_INFO_COUNT };
+void   hpgmg_level_info(const level_type *level, int out[HPGMG_INFO_COUNT]);
+double hpgmg_level_h(const level_type *level);
+double hpgmg_level_eigenvalue(const level_type *level);
+void   hpgmg_level_box_low(const level_type *level, int box, int out[3]);
+int    hpgmg_level_list_counts(const level_type *level, int which, int shape_or_type, int out[3]);
+/* whole padded box volume of one vector <-> host array of box_volume doubles */
+void   hpgmg_level_read_vector(level_type *level, int box, int id, double *host_out);
+void   hpgmg_level_write_vector(level_type *level, int box, int id, const double *host_in);
+/* standalone level for operator-level tests */
+level_type *hpgmg_level_create(int boxes_in_i, int box_dim, int ghosts, int numVectors, int bc, int my_rank, int num_ranks, double h);
+void        hpgmg_level_destroy(level_type *level);
+/* two-level hierarchy around an existing fine level (restriction/interpolation tests) */
+mg_type    *hpgmg_mg_create(level_type *fine, double a, double b, int minCoarseDim);
+void        hpgmg_mg_destroy(mg_type *mg);
+level_type *hpgmg_mg_level(mg_type *mg, int l);
+int         hpgmg_mg_num_levels(const mg_type *mg);
+void        hpgmg_set_verbose(int v);
+void        hpgmg_set_box_alignment(int jstride, int kstride, int volume, int base_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,114 @@
+/*
+ * hpgmg_operators.h -- the operator plugin surface (THE drop-in boundary).
+ *
+ * Every prototype below has the same name, argument order and meaning as the
+ * reference's finite-volume/source/operators.h:14-50.  The reference selects
+ * one plugin (operators.7pt.c, .27pt.c, .fv4.c ...) and one smoother at compile
+ * time with -D flags; here the same choices are a process-wide runtime
+ * configuration (hpgmg_configure) because the reference's own
+ * stencil_get_radius()/stencil_get_shape() take no level argument.
+ *
+ * Two implementations of this header exist in the repository:
+ *   hpgmg_amd/csrc/host/operators_hip.c  -- product: forwards to the HIP kernels
+ *                                           behind include/hpgmg_hip.h
+ *   oracle/operators_cpu.c               -- test oracle: plain C restatement
+ * They are never linked into the same binary.
+ */
+#ifndef HPGMG_OPERATORS_H
+#define HPGMG_OPERATORS_H
+
+#include "hpgmg_level.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* vector ids (reference defines.h:12-39).  ALPHA/L1INV exist only when the
+ * configuration is Helmholtz, exactly like -DUSE_HELMHOLTZ in the reference. */
+#define VECTOR_TEMP    0
+#define VECTOR_U       1
+#define VECTOR_F       2
+#define VECTOR_E       3
+#define VECTOR_R       4
+#define VECTOR_DINV    5
+#define VECTOR_BETA_I  6
+#define VECTOR_BETA_J  7
+#define VECTOR_BETA_K  8
+#define VECTOR_ALPHA   9
+#define VECTOR_L1INV  10
+
+/* ---- runtime replacement of the reference's compile-time -D switches ---- */
+enum { HPGMG_OP_7PT = 0, HPGMG_OP_27PT = 1, HPGMG_OP_FV4 = 2, HPGMG_OP_FV2 = 3 };
+enum { HPGMG_SMOOTH_CHEBY = 0, HPGMG_SMOOTH_GSRB = 1, HPGMG_SMOOTH_JACOBI = 2 };
+
+typedef struct {
+  int op;                 /* HPGMG_OP_*          (which operators.X.c)             */
+  int smoother;           /* HPGMG_SMOOTH_*      (-DUSE_CHEBY / -DUSE_GSRB / ...)   */
+  int helmholtz;          /* 1 = -DUSE_HELMHOLTZ (adds VECTOR_ALPHA, VECTOR_L1INV) */
+  int variable_coeff;     /* 1 = STENCIL_VARIABLE_COEFFICIENT (7pt/fv2/fv4)        */
+} hpgmg_config;
+
+/* Returns 0, or -1 for a combination the reference itself rejects with #error
+ * (e.g. 27pt + variable coefficients, operators.27pt.c:53-55). */
+int  hpgmg_configure(const hpgmg_config *cfg);
+void hpgmg_get_config(hpgmg_config *cfg);
+int  hpgmg_vectors_reserved(void); /* VECTORS_RESERVED: 9, or 11 for Helmholtz */
+
+/* ---- operators.h:14-15 ---- */
+int stencil_get_radius(void);
+int stencil_get_shape(void);
+/* ---- operators.h:17-21 ---- */
+void apply_op(level_type *level, int Ax_id, int x_id, double a, double b);
+void residual(level_type *level, int res_id, int x_id, int rhs_id, double a, double b);
+void smooth(level_type *level, int phi_id, int rhs_id, double a, double b);
+void rebuild_operator(level_type *level, level_type *fromLevel, double a, double b);
+void rebuild_operator_blackbox(level_type *level, double a, double b, int colors_in_each_dim);
+/* ---- operators.h:23-25 ---- */
+void restriction(level_type *level_c, int id_c, level_type *level_f, int id_f, int restrictionType);
+void interpolation_vcycle(level_type *level_f, int id_f, double prescale_f, level_type *level_c, int id_c);
+void interpolation_fcycle(level_type *level_f, int id_f, double prescale_f, level_type *level_c, int id_c);
+/* ---- operators.h:27-33 ---- */
+void exchange_boundary(level_type *level, int id_a, int shape);
+void apply_BCs(level_type *level, int x_id, int shape);   /* plugin's dispatch, operators.7pt.c:47 */
+void apply_BCs_p1(level_type *level, int x_id, int shape);
+void apply_BCs_p2(level_type *level, int x_id, int shape);
+void apply_BCs_v1(level_type *level, int x_id, int shape);
+void apply_BCs_v2(level_type *level, int x_id, int shape);
+void apply_BCs_v4(level_type *level, int x_id, int shape);
+void extrapolate_betas(level_type *level);
+/* ---- operators.h:35-45 ---- */
+double dot(level_type *level, int id_a, int id_b);
+double norm(level_type *level, int id_a);
+double mean(level_type *level, int id_a);
+double error(level_type *level, int id_a, int id_b);
+void add_vectors(level_type *level, int id_c, double scale_a, int id_a, double scale_b, int id_b);
+void scale_vector(level_type *level, int id_c, double scale_a, int id_a);
+void zero_vector(level_type *level, int id_a);
+void shift_vector(level_type *level, int id_c, int id_a, double shift_a);
+void mul_vectors(level_type *level, int id_c, double scale, int id_a, int id_b);
+void invert_vector(level_type *level, int id_c, double scale_a, int id_a);
+void init_vector(level_type *level, int id_a, double scalar);
+/* ---- operators.h:47-48 ---- */
+void color_vector(level_type *level, int id, int colors, int icolor, int jcolor, int kcolor);
+void random_vector(level_type *level, int id);
+/* ---- operators.h:50 ---- */
+void initialize_problem(level_type *level, double hLevel, double a, double b);
+
+/* ---- the one hook outside operators.h: who owns vector storage -----------
+ * The reference allocates with MALLOC() in level.c:25-40 and zero-fills on the
+ * host (level.c:976).  The plugin supplies these instead, so level.c never
+ * touches vector bytes: HIP build -> hipMalloc/hipMemset, oracle -> calloc. */
+double *hpgmg_vector_alloc(size_t num_doubles);           /* zero-filled */
+void    hpgmg_vector_free(double *p);
+void    hpgmg_vector_copy(double *dst, const double *src, size_t num_doubles);
+/* host<->plugin staging, used by tests and by initialize_problem */
+void    hpgmg_vector_upload(double *dst_plugin, const double *src_host, size_t num_doubles);
+void    hpgmg_vector_download(double *dst_host, const double *src_plugin, size_t num_doubles);
+/* called by destroy_level / MGDestroy so the plugin can drop device mirrors */
+void    hpgmg_level_release(level_type *level);
+const char *hpgmg_backend_name(void);                      /* "hip" or "oracle-cpu" */
+
+#ifdef __cplusplus
+}
+#endif
+#endif
