@@ -1,0 +1,289 @@
+// blas1.hip -- interior-only vector operations, reductions and the 7-pt operator
+// rebuild (reference finite-volume/source/operators/misc.c and operators.7pt.c:158-227).
+//
+// Work unit = one unit-stride row (j,k) of one box per wave: 64 lanes stride
+// along i, so every load/store instruction of a wave covers 512 contiguous
+// bytes.  All of these are pure streaming kernels (8-24 B per cell), HBM-bound.
+// Sums (dot, mean) reproduce the reference's single-thread order: one partial
+// per dim x 8 x 8 tile accumulated in k,j,i order, partials added in tile-list
+// order (misc.c:261-269).  They are only ever called on the coarsest level
+// (BiCGStab) and in untimed setup, so one lane per tile is enough.
+#include "common.hpp"
+
+namespace hpgmg {
+
+constexpr int kRowsPerBlock = 4;   // 256 threads = 4 waves = 4 rows
+
+struct RowIter {                   // decode "row id" -> box, j, k over a (rows_per_side)^2 * num_boxes space
+  int box, j, k;
+};
+__device__ __forceinline__ bool row_of(int row, int side, int num_boxes, RowIter &r) {
+  const int per_box = side * side;
+  if (row >= per_box * num_boxes) return false;
+  r.box = row / per_box;
+  const int rem = row - r.box * per_box;
+  r.k = rem / side;
+  r.j = rem - r.k * side;
+  return true;
+}
+static inline int rows_grid(int rows) { return (rows + kRowsPerBlock - 1) / kRowsPerBlock; }
+
+enum { OP_AXPBY = 0, OP_MUL, OP_INVERT, OP_SCALE, OP_SHIFT, OP_COLOR, OP_RANDOM };
+struct EwArgs { int id_c, id_a, id_b; double sa, sb; int colors, ic, jc, kc; };
+
+template <int OP>
+__global__ __launch_bounds__(256) void elementwise_kernel(const hpgmg_hip_level L, const EwArgs A) {
+  RowIter r;
+  const int row = blockIdx.x * kRowsPerBlock + threadIdx.x / 64, lane = threadIdx.x % 64;
+  if (!row_of(row, L.dim, L.num_boxes, r)) return;
+  const int base = r.j * L.jStride + r.k * L.kStride;
+  double *c = vec_origin(L, r.box, A.id_c) + base;
+  const double *pa = (OP == OP_COLOR || OP == OP_RANDOM) ? nullptr : vec_origin(L, r.box, A.id_a) + base;
+  const double *pb = (OP == OP_AXPBY || OP == OP_MUL) ? vec_origin(L, r.box, A.id_b) + base : nullptr;
+  for (int i = lane; i < L.dim; i += 64) {
+    double v;
+    if (OP == OP_AXPBY)       v = A.sa * pa[i] + A.sb * pb[i];
+    else if (OP == OP_MUL)    v = A.sa * pa[i] * pb[i];
+    else if (OP == OP_INVERT) v = A.sa / pa[i];
+    else if (OP == OP_SCALE)  v = A.sa * pa[i];
+    else if (OP == OP_SHIFT)  v = pa[i] + A.sa;
+    else if (OP == OP_COLOR) {
+      const double si = ((i + L.box_low[3 * r.box] + A.ic) % A.colors == 0) ? 1.0 : 0.0;
+      const double sj = ((r.j + L.box_low[3 * r.box + 1] + A.jc) % A.colors == 0) ? 1.0 : 0.0;
+      const double sk = ((r.k + L.box_low[3 * r.box + 2] + A.kc) % A.colors == 0) ? 1.0 : 0.0;
+      v = si * sj * sk;
+    } else v = -1.000 + 2.0 * (double)(i ^ r.j ^ r.k ^ 0x1);   // misc.c:500, literally
+    c[i] = v;
+  }
+}
+
+// zero_vector / init_vector: the whole padded box including ghosts; ghosts := 0 (misc.c:26-41, :68-86)
+__global__ __launch_bounds__(256) void fill_kernel(const hpgmg_hip_level L, int id, double inside) {
+  RowIter r;
+  const int side = L.dim + 2 * L.ghosts;
+  const int row = blockIdx.x * kRowsPerBlock + threadIdx.x / 64, lane = threadIdx.x % 64;
+  if (!row_of(row, side, L.num_boxes, r)) return;
+  double *v = L.box_base[r.box] + (size_t)id * (size_t)L.volume + r.j * L.jStride + r.k * L.kStride;
+  const bool ghost_row = (r.j < L.ghosts) || (r.k < L.ghosts) || (r.j >= L.dim + L.ghosts) || (r.k >= L.dim + L.ghosts);
+  for (int i = lane; i < side; i += 64) {
+    const bool ghost = ghost_row || (i < L.ghosts) || (i >= L.dim + L.ghosts);
+    v[i] = ghost ? 0.0 : inside;
+  }
+}
+
+// ---- max reductions ------------------------------------------------------------------
+__device__ __forceinline__ double wave_max(double v) {
+  for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_down(v, off, 64); v = (o > v) ? o : v; }
+  return v;
+}
+__device__ __forceinline__ void block_max_store(double v, double *partials) {
+  __shared__ double smem[kRowsPerBlock];
+  v = wave_max(v);
+  if (threadIdx.x % 64 == 0) smem[threadIdx.x / 64] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double m = smem[0];
+    for (int w = 1; w < kRowsPerBlock; w++) m = (smem[w] > m) ? smem[w] : m;
+    partials[blockIdx.x] = m;
+  }
+}
+
+__global__ __launch_bounds__(256) void absmax_kernel(const hpgmg_hip_level L, int id, double *partials) {
+  RowIter r;
+  const int row = blockIdx.x * kRowsPerBlock + threadIdx.x / 64, lane = threadIdx.x % 64;
+  double m = 0.0;
+  if (row_of(row, L.dim, L.num_boxes, r)) {
+    const double *p = vec_origin(L, r.box, id) + r.j * L.jStride + r.k * L.kStride;
+    for (int i = lane; i < L.dim; i += 64) { const double f = fabs(p[i]); m = (f > m) ? f : m; }
+  }
+  block_max_store(m, partials);
+}
+
+__global__ __launch_bounds__(256) void final_max_kernel(const double *partials, int n, double init, double *result) {
+  __shared__ double smem[4];
+  double m = init;
+  for (int t = threadIdx.x; t < n; t += 256) m = (partials[t] > m) ? partials[t] : m;
+  m = wave_max(m);
+  if (threadIdx.x % 64 == 0) smem[threadIdx.x / 64] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) { for (int w = 1; w < 4; w++) m = (smem[w] > m) ? smem[w] : m; *result = (smem[0] > m) ? smem[0] : m; }
+}
+
+// ---- ordered sums ----------------------------------------------------------------------
+// one lane per dim x 8 x 8 tile, tiles numbered as level.c:1184-1210 builds my_blocks
+__global__ __launch_bounds__(64) void tile_sum_kernel(const hpgmg_hip_level L, int id_a, int id_b, double *partials) {
+  const int tiles_side = (L.dim + BLOCKCOPY_TILE_J - 1) / BLOCKCOPY_TILE_J;
+  const int tiles_per_box = tiles_side * tiles_side;
+  const int t = blockIdx.x * 64 + threadIdx.x;
+  if (t >= tiles_per_box * L.num_boxes) return;
+  const int box = t / tiles_per_box, rem = t % tiles_per_box;
+  const int k0 = (rem / tiles_side) * BLOCKCOPY_TILE_K, j0 = (rem % tiles_side) * BLOCKCOPY_TILE_J;
+  const int k1 = min(k0 + BLOCKCOPY_TILE_K, L.dim), j1 = min(j0 + BLOCKCOPY_TILE_J, L.dim);
+  const double *pa = vec_origin(L, box, id_a);
+  const double *pb = (id_b >= 0) ? vec_origin(L, box, id_b) : nullptr;
+  double acc = 0.0;
+  for (int k = k0; k < k1; k++) for (int j = j0; j < j1; j++) {
+    const int base = j * L.jStride + k * L.kStride;
+    for (int i = 0; i < L.dim; i++) acc += pb ? pa[base + i] * pb[base + i] : pa[base + i];
+  }
+  partials[t] = acc;
+}
+__global__ void ordered_sum_kernel(const double *partials, int n, double *result) {
+  double s = 0.0;
+  for (int t = 0; t < n; t++) s += partials[t];
+  *result = s;
+}
+
+// ---- operators.7pt.c:158-227 --------------------------------------------------------------
+struct RebuildArgs { int variable_coeff, alpha_id, l1inv_id; double a, b, h2inv; };
+__global__ __launch_bounds__(256) void rebuild7_kernel(const hpgmg_hip_level L, const RebuildArgs A, double *partials) {
+  RowIter r;
+  const int row = blockIdx.x * kRowsPerBlock + threadIdx.x / 64, lane = threadIdx.x % 64;
+  double best = -1e9;
+  if (row_of(row, L.dim, L.num_boxes, r)) {
+    const int base = r.j * L.jStride + r.k * L.kStride, jS = L.jStride, kS = L.kStride;
+    const double *beta_i = vec_origin(L, r.box, VECTOR_BETA_I) + base;
+    const double *beta_j = vec_origin(L, r.box, VECTOR_BETA_J) + base;
+    const double *beta_k = vec_origin(L, r.box, VECTOR_BETA_K) + base;
+    const double *alpha = (A.alpha_id >= 0) ? vec_origin(L, r.box, A.alpha_id) + base : nullptr;
+    double *dinv = vec_origin(L, r.box, VECTOR_DINV) + base;
+    double *l1inv = (A.l1inv_id >= 0) ? vec_origin(L, r.box, A.l1inv_id) + base : nullptr;
+    const int gi0 = L.box_low[3 * r.box], gj = L.box_low[3 * r.box + 1] + r.j, gk = L.box_low[3 * r.box + 2] + r.k;
+    double jlo = 1.0, jhi = 1.0, klo = 1.0, khi = 1.0;
+    if (!L.periodic) {
+      if (gj - 1 < 0) jlo = 0.0;  if (gj + 1 >= L.dim_j) jhi = 0.0;
+      if (gk - 1 < 0) klo = 0.0;  if (gk + 1 >= L.dim_k) khi = 0.0;
+    }
+    for (int i = lane; i < L.dim; i += 64) {
+      double ilo = 1.0, ihi = 1.0;
+      if (!L.periodic) { if (gi0 + i - 1 < 0) ilo = 0.0; if (gi0 + i + 1 >= L.dim_i) ihi = 0.0; }
+      double sumAbsAij, Aii;
+      if (A.variable_coeff) {
+        double s = fabs(beta_i[i] * ilo);
+        s = s + fabs(beta_j[i] * jlo);
+        s = s + fabs(beta_k[i] * klo);
+        s = s + fabs(beta_i[i + 1] * ihi);
+        s = s + fabs(beta_j[i + jS] * jhi);
+        s = s + fabs(beta_k[i + kS] * khi);
+        sumAbsAij = fabs(A.b * A.h2inv) * s;
+        double d = beta_i[i] * (ilo - 2.0);
+        d = d + beta_j[i] * (jlo - 2.0);
+        d = d + beta_k[i] * (klo - 2.0);
+        d = d + beta_i[i + 1] * (ihi - 2.0);
+        d = d + beta_j[i + jS] * (jhi - 2.0);
+        d = d + beta_k[i + kS] * (khi - 2.0);
+        Aii = ((-A.b) * A.h2inv) * d;
+        if (alpha) Aii = Aii + A.a * alpha[i];
+      } else {
+        double s = ilo + jlo; s = s + klo; s = s + ihi; s = s + jhi; s = s + khi;
+        sumAbsAij = fabs(A.b * A.h2inv) * s;
+        Aii = A.a - (A.b * A.h2inv) * (s - 12.0);
+      }
+      dinv[i] = 1.0 / Aii;
+      const double Di = (Aii + sumAbsAij) / Aii;
+      best = (Di > best) ? Di : best;
+      if (l1inv) l1inv[i] = (Aii >= 1.5 * sumAbsAij) ? 1.0 / (Aii) : 1.0 / (Aii + 0.5 * sumAbsAij);
+    }
+  }
+  block_max_store(best, partials);
+}
+
+// scratch for partial results + a pinned host word the final kernels write to
+static double *g_scratch = nullptr;  static int g_scratch_len = 0;
+static double *g_result_dev = nullptr;
+static int ensure_scratch(int n) {
+  if (!g_result_dev) { HPGMG_CHECK(hipMalloc((void **)&g_result_dev, 64)); }
+  if (n > g_scratch_len) {
+    if (g_scratch) { hipStreamSynchronize(g_stream); (void)hipFree(g_scratch); }
+    int want = n < 65536 ? 65536 : n;
+    HPGMG_CHECK(hipMalloc((void **)&g_scratch, (size_t)want * sizeof(double)));
+    g_scratch_len = want;
+  }
+  return 0;
+}
+static int fetch_result(double *out) {
+  HPGMG_CHECK(hipMemcpyAsync(out, g_result_dev, sizeof(double), hipMemcpyDeviceToHost, g_stream));
+  HPGMG_CHECK(hipStreamSynchronize(g_stream));
+  return 0;
+}
+
+template <int OP>
+static int launch_ew(const hpgmg_hip_level *L, const EwArgs &A) {
+  if (L->num_boxes <= 0) return 0;
+  const int rows = L->num_boxes * L->dim * L->dim;
+  hipLaunchKernelGGL((elementwise_kernel<OP>), dim3(rows_grid(rows)), dim3(256), 0, g_stream, *L, A);
+  HPGMG_LAUNCH_CHECK("elementwise_kernel");
+  return 0;
+}
+
+}  // namespace hpgmg
+using namespace hpgmg;
+
+extern "C" {
+
+int hpgmg_hip_fill(const hpgmg_hip_level *L, int id, double v) {
+  if (L->num_boxes <= 0) return 0;
+  const int side = L->dim + 2 * L->ghosts, rows = L->num_boxes * side * side;
+  hipLaunchKernelGGL(fill_kernel, dim3(rows_grid(rows)), dim3(256), 0, g_stream, *L, id, v);
+  HPGMG_LAUNCH_CHECK("fill_kernel");
+  return 0;
+}
+int hpgmg_hip_axpby(const hpgmg_hip_level *L, int id_c, double sa, int id_a, double sb, int id_b) {
+  EwArgs A = {}; A.id_c = id_c; A.id_a = id_a; A.id_b = id_b; A.sa = sa; A.sb = sb; return launch_ew<OP_AXPBY>(L, A);
+}
+int hpgmg_hip_mul(const hpgmg_hip_level *L, int id_c, double s, int id_a, int id_b) {
+  EwArgs A = {}; A.id_c = id_c; A.id_a = id_a; A.id_b = id_b; A.sa = s; return launch_ew<OP_MUL>(L, A);
+}
+int hpgmg_hip_invert(const hpgmg_hip_level *L, int id_c, double s, int id_a) {
+  EwArgs A = {}; A.id_c = id_c; A.id_a = id_a; A.sa = s; return launch_ew<OP_INVERT>(L, A);
+}
+int hpgmg_hip_scale(const hpgmg_hip_level *L, int id_c, double s, int id_a) {
+  EwArgs A = {}; A.id_c = id_c; A.id_a = id_a; A.sa = s; return launch_ew<OP_SCALE>(L, A);
+}
+int hpgmg_hip_shift(const hpgmg_hip_level *L, int id_c, int id_a, double shift) {
+  EwArgs A = {}; A.id_c = id_c; A.id_a = id_a; A.sa = shift; return launch_ew<OP_SHIFT>(L, A);
+}
+int hpgmg_hip_color(const hpgmg_hip_level *L, int id, int colors, int ic, int jc, int kc) {
+  EwArgs A = {}; A.id_c = id; A.colors = colors; A.ic = ic; A.jc = jc; A.kc = kc; return launch_ew<OP_COLOR>(L, A);
+}
+int hpgmg_hip_random(const hpgmg_hip_level *L, int id) {
+  EwArgs A = {}; A.id_c = id; return launch_ew<OP_RANDOM>(L, A);
+}
+
+int hpgmg_hip_norm_max(const hpgmg_hip_level *L, int id, double *out) {
+  *out = 0.0;
+  if (L->num_boxes <= 0) return 0;
+  const int nblk = rows_grid(L->num_boxes * L->dim * L->dim);
+  if (int e = ensure_scratch(nblk)) return e;
+  hipLaunchKernelGGL(absmax_kernel, dim3(nblk), dim3(256), 0, g_stream, *L, id, g_scratch);
+  hipLaunchKernelGGL(final_max_kernel, dim3(1), dim3(256), 0, g_stream, (const double *)g_scratch, nblk, 0.0, g_result_dev);
+  HPGMG_LAUNCH_CHECK("norm_max");
+  return fetch_result(out);
+}
+static int ordered_sum(const hpgmg_hip_level *L, int id_a, int id_b, double *out) {
+  *out = 0.0;
+  if (L->num_boxes <= 0) return 0;
+  const int side = (L->dim + BLOCKCOPY_TILE_J - 1) / BLOCKCOPY_TILE_J, ntiles = side * side * L->num_boxes;
+  if (int e = ensure_scratch(ntiles)) return e;
+  hipLaunchKernelGGL(tile_sum_kernel, dim3((ntiles + 63) / 64), dim3(64), 0, g_stream, *L, id_a, id_b, g_scratch);
+  hipLaunchKernelGGL(ordered_sum_kernel, dim3(1), dim3(1), 0, g_stream, (const double *)g_scratch, ntiles, g_result_dev);
+  HPGMG_LAUNCH_CHECK("ordered_sum");
+  return fetch_result(out);
+}
+int hpgmg_hip_dot(const hpgmg_hip_level *L, int id_a, int id_b, double *out) { return ordered_sum(L, id_a, id_b, out); }
+int hpgmg_hip_sum(const hpgmg_hip_level *L, int id, double *out) { return ordered_sum(L, id, -1, out); }
+
+int hpgmg_hip_rebuild_7pt(const hpgmg_hip_level *L, int variable_coeff, int alpha_id, int l1inv_id,
+                          double a, double b, double h2inv, double *lambda_max_out) {
+  *lambda_max_out = -1e9;
+  if (L->num_boxes <= 0) return 0;
+  const int nblk = rows_grid(L->num_boxes * L->dim * L->dim);
+  if (int e = ensure_scratch(nblk)) return e;
+  RebuildArgs A = { variable_coeff, alpha_id, l1inv_id, a, b, h2inv };
+  hipLaunchKernelGGL(rebuild7_kernel, dim3(nblk), dim3(256), 0, g_stream, *L, A, g_scratch);
+  hipLaunchKernelGGL(final_max_kernel, dim3(1), dim3(256), 0, g_stream, (const double *)g_scratch, nblk, -1e9, g_result_dev);
+  HPGMG_LAUNCH_CHECK("rebuild_7pt");
+  return fetch_result(lambda_max_out);
+}
+
+}  // extern "C"

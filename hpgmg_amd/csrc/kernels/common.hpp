@@ -1,0 +1,34 @@
+// common.hpp -- shared device/host helpers of libhpgmg_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "hpgmg_hip.h"
+#include "hpgmg_operators.h"   // VECTOR_* ids
+
+namespace hpgmg {
+
+extern hipStream_t g_stream;          // stream every launcher enqueues on
+int  record_error(hipError_t e, const char *where);
+#define HPGMG_CHECK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return hpgmg::record_error(e_, #call); } while (0)
+#define HPGMG_LAUNCH_CHECK(name) do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return hpgmg::record_error(e_, name); } while (0)
+
+constexpr int kXcds = 8;              // MI355X: 8 XCDs, workgroup b is placed on XCD b % 8
+
+// Physical block id -> logical work id such that each XCD (hence each private L2)
+// owns one CONTIGUOUS range of logical ids.  Logical ids are laid out box-major,
+// then k, j, i, so an XCD works on a compact slab and the planes shared by
+// neighbouring tiles are served by its own L2 instead of being refetched by another.
+__device__ __forceinline__ int xcd_logical_block(int physical, int per_xcd) {
+  return (physical % kXcds) * per_xcd + physical / kXcds;
+}
+inline int grid_for(int logical_blocks, int *per_xcd) {
+  *per_xcd = (logical_blocks + kXcds - 1) / kXcds;
+  return *per_xcd * kXcds;
+}
+
+// pointer to cell (0,0,0) (first interior cell) of vector `id` in box `box`
+__device__ __forceinline__ double *vec_origin(const hpgmg_hip_level &L, int box, int id) {
+  return L.box_base[box] + (size_t)id * (size_t)L.volume + (size_t)L.ghosts * (size_t)(1 + L.jStride + L.kStride);
+}
+
+}  // namespace hpgmg

@@ -1,0 +1,114 @@
+/*
+ * hpgmg_hip.h -- C-ABI of libhpgmg_hip.so: the hand-written gfx950 kernels of the
+ * HPGMG-FV operator layer plus the device-memory hooks.
+ *
+ * Plain C types only (device pointers as double*, ints, doubles, streams as
+ * void*); every launcher returns 0 on success or a hipError_t value.  Each
+ * entry point names the reference routine it replaces (paths relative to
+ * finite-volume/source/).  The host-side plugin hpgmg_amd/csrc/host/operators_hip.c
+ * implements include/hpgmg_operators.h (= the reference's operators.h) on top of
+ * these; tests call them directly through ctypes.
+ *
+ * Geometry of a level is passed as one POD record.  All boxes of a level have
+ * the same dim/ghosts/strides (reference level.c:935-938); box b's vector v
+ * starts at box_base[b] + v*volume and cell (i,j,k) of it sits at
+ * (i+g) + (j+g)*jStride + (k+g)*kStride.
+ */
+#ifndef HPGMG_HIP_H
+#define HPGMG_HIP_H
+
+#include <stddef.h>
+#include "hpgmg_level.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct {
+  double *const *box_base; /* DEVICE array [num_boxes]: vectors[0] of each owned box        */
+  const int *box_low;      /* DEVICE array [3*num_boxes]: global (i,j,k) of first interior cell */
+  int num_boxes;
+  int dim, ghosts, jStride, kStride, volume;
+  int dim_i, dim_j, dim_k; /* global cells per side (Dirichlet masks in rebuild)             */
+  int periodic;
+} hpgmg_hip_level;
+
+/* stencil variants of apply_op_ijk (operators.7pt.c:49-89, operators.27pt.c:60-91, operators.fv4.c:55-134) */
+enum { HPGMG_HIP_7PT_VC_HELMHOLTZ = 0, HPGMG_HIP_7PT_VC_POISSON = 1, HPGMG_HIP_7PT_CC = 2,
+       HPGMG_HIP_27PT_CC = 3, HPGMG_HIP_FV4_VC_HELMHOLTZ = 4, HPGMG_HIP_FV4_VC_POISSON = 5 };
+
+/* ---- runtime / memory (replaces MALLOC of level.c:25-40 for vector data) ---- */
+int    hpgmg_hip_device_count(void);
+int    hpgmg_hip_set_device(int dev);
+void   hpgmg_hip_set_stream(void *hip_stream);     /* stream every launcher below enqueues on (default: null stream) */
+void  *hpgmg_hip_get_stream(void);
+int    hpgmg_hip_sync(void);                        /* hipStreamSynchronize on that stream */
+void  *hpgmg_hip_malloc(size_t bytes);              /* zero-filled device memory, NULL on failure */
+void   hpgmg_hip_free(void *p);
+int    hpgmg_hip_memcpy_h2d(void *dst, const void *src, size_t bytes);
+int    hpgmg_hip_memcpy_d2h(void *dst, const void *src, size_t bytes);
+int    hpgmg_hip_memcpy_d2d(void *dst, const void *src, size_t bytes);
+int    hpgmg_hip_memset0(void *dst, size_t bytes);
+const char *hpgmg_hip_last_error(void);
+/* event timing on the launch stream (bench.py: average kernel time over the timed region) */
+void  *hpgmg_hip_event_create(void);
+void   hpgmg_hip_event_destroy(void *ev);
+int    hpgmg_hip_event_record(void *ev);
+double hpgmg_hip_event_elapsed_ms(void *start, void *stop); /* synchronises on stop */
+/* accumulate the GPU time of every smoother-kernel launch between begin/end (hipEvents around each launch) */
+void   hpgmg_hip_profile_smoother(int enable);
+int    hpgmg_hip_profile_smoother_read(double *total_ms, long long *launches, long long *cells);
+
+/* ---- smoothers: operators/chebyshev.c:43-99, operators/gsrb.c:24-132, operators/jacobi.c:8-65 ----
+ * One sweep over every owned box.  x_n/x_np1/rhs are vector ids.  Chebyshev and
+ * Jacobi read x_n and write x_np1 (x_np1 doubles as x_{n-1} for Chebyshev);
+ * GSRB updates the cells whose global parity (i+j+k+sweep) is even, in place
+ * when xn_id == xnp1_id, otherwise copying the other colour. */
+int hpgmg_hip_smooth_cheby(const hpgmg_hip_level *L, int variant, int xn_id, int xnp1_id, int rhs_id,
+                           double a, double b, double h2inv, double c1, double c2);
+int hpgmg_hip_smooth_gsrb(const hpgmg_hip_level *L, int variant, int xn_id, int xnp1_id, int rhs_id,
+                          double a, double b, double h2inv, int sweep);
+int hpgmg_hip_smooth_jacobi(const hpgmg_hip_level *L, int variant, int xn_id, int xnp1_id, int rhs_id,
+                            double a, double b, double h2inv, double weight);
+/* operators/residual.c:9-51 (rhs_id >= 0: res = rhs - A x) and operators/apply_op.c:9-48 (rhs_id < 0: res = A x) */
+int hpgmg_hip_residual(const hpgmg_hip_level *L, int variant, int res_id, int x_id, int rhs_id,
+                       double a, double b, double h2inv);
+
+/* ---- block lists.  `blocks` is a DEVICE copy of a host blockCopy_type array ---- */
+/* operators/blockCopy.c:6-105 CopyBlock over a list (exchange_boundary pack/local/unpack, restriction unpack) */
+int hpgmg_hip_copy_blocks(const hpgmg_hip_level *L, int id, const blockCopy_type *blocks, int num_blocks);
+/* operators/blockCopy.c:109-156 IncrementBlock (interpolation unpack): w = prescale*w + r */
+int hpgmg_hip_increment_blocks(const hpgmg_hip_level *L, int id, double prescale, const blockCopy_type *blocks, int num_blocks);
+/* operators/boundary_fd.c:6-90 apply_BCs_p1 */
+int hpgmg_hip_apply_bc_p1(const hpgmg_hip_level *L, int id, const blockCopy_type *blocks, int num_blocks);
+/* operators/restriction.c:6-94 restriction_pc_block over a list; type = RESTRICT_* */
+int hpgmg_hip_restrict_blocks(const hpgmg_hip_level *Lc, int id_c, const hpgmg_hip_level *Lf, int id_f,
+                              const blockCopy_type *blocks, int num_blocks, int type);
+/* operators/interpolation_p0.c:6-46 (order 0) and interpolation_p1.c:8-65 (order 1) over a list */
+int hpgmg_hip_interpolate_blocks(const hpgmg_hip_level *Lf, int id_f, double prescale, const hpgmg_hip_level *Lc, int id_c,
+                                 const blockCopy_type *blocks, int num_blocks, int order);
+
+/* ---- BLAS-1: operators/misc.c ---- */
+int hpgmg_hip_fill(const hpgmg_hip_level *L, int id, double interior_value);          /* zero_vector :6 / init_vector :48 (ghosts := 0) */
+int hpgmg_hip_axpby(const hpgmg_hip_level *L, int id_c, double sa, int id_a, double sb, int id_b); /* add_vectors :94 */
+int hpgmg_hip_mul(const hpgmg_hip_level *L, int id_c, double s, int id_a, int id_b);  /* mul_vectors :131 */
+int hpgmg_hip_invert(const hpgmg_hip_level *L, int id_c, double s, int id_a);         /* invert_vector :168 */
+int hpgmg_hip_scale(const hpgmg_hip_level *L, int id_c, double s, int id_a);          /* scale_vector :204 */
+int hpgmg_hip_shift(const hpgmg_hip_level *L, int id_c, int id_a, double shift);      /* shift_vector :386 */
+int hpgmg_hip_color(const hpgmg_hip_level *L, int id, int colors, int ic, int jc, int kc); /* color_vector :441 */
+int hpgmg_hip_random(const hpgmg_hip_level *L, int id);                               /* random_vector :478 */
+/* reductions over interior cells of this rank's boxes; synchronise and return through *out.
+ * max: exact under any order.  sums: one partial per dim x 8 x 8 tile in k,j,i order,
+ * partials added in tile order -- the order of the reference run with one thread. */
+int hpgmg_hip_norm_max(const hpgmg_hip_level *L, int id, double *out);                /* norm :287 */
+int hpgmg_hip_dot(const hpgmg_hip_level *L, int id_a, int id_b, double *out);         /* dot :239 */
+int hpgmg_hip_sum(const hpgmg_hip_level *L, int id, double *out);                     /* mean :336 (before the divide) */
+
+/* ---- operators.7pt.c:158-227: Dinv (+L1inv when l1inv_id >= 0) and the Gershgorin bound of lambda_max(D^-1 A) ---- */
+int hpgmg_hip_rebuild_7pt(const hpgmg_hip_level *L, int variable_coeff, int alpha_id, int l1inv_id,
+                          double a, double b, double h2inv, double *lambda_max_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
