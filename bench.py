@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""bench.py -- the headline measurement: DOF/s of one HPGMG-FV FMG F-cycle on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch of synthetic input: zero_vector(U) +
+one FMG F-cycle (reference bench_hpgmg, finite-volume/source/hpgmg-fv.c:50-99) on
+BASELINE.json config 2: `hpgmg-fv 7 8`, fp64 7-point variable-coefficient Helmholtz,
+Chebyshev smoother, 8 boxes of 128^3 per GPU (256^3 on one GPU).  Inputs (beta, alpha, F) are
+the reference's analytic problem (problem.p6.c), resident in HBM before timing starts.
+
+N > 1: one process per GPU (torch.distributed.run), boxes partitioned over the ranks exactly
+like the reference partitions them over MPI ranks (Z-Morton, `7 8` with N ranks -> the reference
+CLI's weak-scaling series 256^3, 256^3, 384^3, 512^3 for N = 1, 2, 4, 8), ghost zones exchanged
+with RCCL send/recv over xGMI.  value = fine-grid DOF of the whole job / max-over-ranks time.
+
+Extra objects on the JSON line:
+  roofline     fine-level Chebyshev sweep: algorithmic bytes (72 B/cell) / hipEvent-timed launch
+  cpu_baseline the REFERENCE binary (oracle/_ref, built from /root/reference by oracle/Makefile)
+               run on this box's host cores; falls back to the CPU restatement ("port").
+"""
+import argparse
+import ctypes
+import json
+import os
+import re
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+BYTES_PER_CELL_CHEBY_HELMHOLTZ = 72  # x_n, x_nm1, rhs, Dinv, beta_i/j/k, alpha read + x_np1 written
+LOG2_BOX_DIM, BOXES_PER_RANK = 7, 8
+
+
+def host_cores():
+    """CPU threads this container may really use (cgroup quota, not the 256 the box reports)."""
+    n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except Exception:
+        pass
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    return n
+
+
+def cpu_baseline():
+    """Reference (or port) on the host cores, bounded: the benchmark's own 10+10 solves at 256^3, 128^3, 64^3."""
+    cores = host_cores()
+    env = dict(os.environ, OMP_NUM_THREADS=str(cores), OMP_PROC_BIND="close", OMP_PLACES="cores", OMP_WAIT_POLICY="passive")
+    ref = os.path.join(ROOT, "oracle", "_ref", "hpgmg-7pt-cheby-helm")
+    port = os.path.join(ROOT, "oracle", "hpgmg-fv-oracle")
+    if os.path.exists(ref):
+        cmd, kind, sample = [ref, "7", "8"], "reference", "reference binary `hpgmg-fv 7 8` (7pt VC Helmholtz, Chebyshev): its own protocol, 10 warm-up + 10 timed F-cycles at 256^3 (and 128^3, 64^3)"
+    elif os.path.exists(port):
+        cmd, kind, sample = [port, "--helmholtz", "--warmup", "2", "--solves", "5", "7", "8"], "port", "CPU restatement `--helmholtz 7 8`: 2 warm-up + 5 timed F-cycles at 256^3 (and 128^3, 64^3)"
+    else:
+        return None
+    try:
+        out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900).stdout
+        m = re.search(r"h=\S+\s+DOF=\S+\s+time=(\S+)\s+DOF/s=(\S+)", out)
+        return {"value": float(m.group(2)), "unit": "DOF/s", "cores": cores, "kind": kind, "sample": sample,
+                "seconds_per_solve": float(m.group(1))}
+    except Exception as exc:  # report, never fake
+        return {"value": None, "unit": "DOF/s", "cores": cores, "kind": kind, "sample": sample, "error": repr(exc)}
+
+
+def pmc_traffic():
+    """HBM bytes per fine-level Chebyshev launch from the committed rocprofv3 --pmc summary, if any."""
+    best = None
+    pdir = os.path.join(ROOT, "profiles")
+    if os.path.isdir(pdir):
+        for f in sorted(os.listdir(pdir)):
+            if f.endswith("_pmc_summary.json"):
+                try:
+                    best = json.load(open(os.path.join(pdir, f))).get("hbm_bytes_per_launch_cheby_fine")
+                except Exception:
+                    pass
+    return best
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP operator path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+
+    import hpgmg_amd as H
+    K = H.load_kernels()
+    lib = H.load_driver()
+    assert K.hpgmg_hip_set_device(local_rank) == 0
+    lib.hpgmg_set_verbose(0)
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        ident = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            buf = ctypes.create_string_buffer(128)
+            assert K.hpgmg_hip_rccl_unique_id(buf) == 0
+            ident = torch.tensor(list(buf.raw), dtype=torch.uint8, device="cuda")
+        dist.broadcast(ident, src=0)
+        lib.hpgmg_transport_init_rccl.restype = ctypes.c_int
+        lib.hpgmg_transport_init_rccl.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int]
+        assert lib.hpgmg_transport_init_rccl(bytes(ident.cpu().tolist()), rank, world) == 0
+
+    cfg = H.Config(H.OP_7PT, H.SMOOTH_CHEBY, 1, 1)
+    assert lib.hpgmg_configure(ctypes.byref(cfg)) == 0
+    solver = lib.hpgmg_solver_create(LOG2_BOX_DIM, BOXES_PER_RANK, H.BC_DIRICHLET, rank, world)
+    assert solver, "no acceptable problem size"
+    info = (ctypes.c_int * H.INFO_COUNT)()
+    lib.hpgmg_level_info(lib.hpgmg_solver_level(solver, 0), info)
+    dim, box_dim, my_boxes = info[H.INFO_DIM], info[H.INFO_BOX_DIM], info[H.INFO_NUM_MY_BOXES]
+    dof = float(dim) ** 3
+
+    def barrier():
+        torch.cuda.synchronize()
+        K.hpgmg_hip_sync()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        lib.hpgmg_solver_fmg(solver, 0)
+
+    # time only the fine-level smoother launches with hipEvents on the launch stream
+    fine_cells = my_boxes * box_dim ** 3
+    K.hpgmg_hip_profile_smoother_min_cells(max(fine_cells, 1))
+    K.hpgmg_hip_profile_smoother(1)
+    barrier()
+    t0 = time.perf_counter()
+    norm = 0.0
+    for _ in range(args.steps):
+        norm = lib.hpgmg_solver_fmg(solver, 0)      # returns ||F - A u||_inf -> synchronises
+    barrier()
+    elapsed = time.perf_counter() - t0
+    K.hpgmg_hip_profile_smoother(0)
+    ms, launches, cells = ctypes.c_double(), ctypes.c_longlong(), ctypes.c_longlong()
+    K.hpgmg_hip_profile_smoother_read(ctypes.byref(ms), ctypes.byref(launches), ctypes.byref(cells))
+
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        sec_per_step = elapsed / args.steps
+        roof = None
+        if launches.value > 0 and ms.value > 0:
+            avg_s = ms.value * 1e-3 / launches.value
+            bytes_per_launch = BYTES_PER_CELL_CHEBY_HELMHOLTZ * (cells.value / launches.value)
+            achieved = bytes_per_launch / avg_s / 1e9
+            roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(),
+                    "kernel": "hpgmg::stencil7_kernel<VC Helmholtz, Chebyshev> on the finest level",
+                    "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_us": round(avg_s * 1e6, 2),
+                    "launches_timed": launches.value}
+        line = {
+            "metric": "DOF/s (fine-grid) for FMG F-cycle", "value": dof / sec_per_step, "unit": "DOF/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": sec_per_step * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"hpgmg-fv {LOG2_BOX_DIM} {BOXES_PER_RANK}: {dim}^3 fp64 7-pt variable-coefficient Helmholtz, "
+                                   f"Chebyshev smoother, {BOXES_PER_RANK} boxes of {box_dim}^3 per GPU, BiCGStab bottom, Dirichlet",
+                       "fine_grid_dof": dof, "fcycle_residual_norm": norm, "parallelism": f"boxes over {world} GPU(s), RCCL halo exchange"},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+
+    lib.hpgmg_solver_destroy(solver)
+    if dist is not None:
+        lib.hpgmg_transport_finalize_rccl()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

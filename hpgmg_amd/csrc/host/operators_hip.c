@@ -48,6 +48,22 @@ void hpgmg_vector_copy(double *d, const double *s, size_t n) { HIP_OK(hpgmg_hip_
 void hpgmg_vector_upload(double *d, const double *s, size_t n) { HIP_OK(hpgmg_hip_memcpy_h2d(d, s, n * sizeof(double))); }
 void hpgmg_vector_download(double *d, const double *s, size_t n) { HIP_OK(hpgmg_hip_memcpy_d2h(d, s, n * sizeof(double))); }
 
+/* ---------------------------------------------------------------- transport selection
+ * One process per GPU: rank 0 obtains an id with hpgmg_hip_rccl_unique_id(), the launcher
+ * (bench.py via torch.distributed, or any bootstrap) hands it to every rank, and each rank
+ * calls this once before creating levels.  Replaces MPI_Init/MPI_Comm_rank of hpgmg-fv.c:129-136. */
+int hpgmg_transport_init_rccl(const char *id128, int rank, int size) {
+  hpgmg_transport t;
+  int e = hpgmg_hip_rccl_init(id128, rank, size);
+  if (e) return e;
+  t.rank = rank; t.size = size; t.ctx = NULL;
+  t.sendrecv = hpgmg_hip_rccl_sendrecv;
+  t.allreduce = hpgmg_hip_rccl_allreduce;
+  hpgmg_set_transport(&t);
+  return 0;
+}
+void hpgmg_transport_finalize_rccl(void) { hpgmg_set_transport(NULL); hpgmg_hip_rccl_finalize(); }
+
 /* ---------------------------------------------------------------- per-level device record */
 #define MAX_LISTS 32
 typedef struct {

@@ -1,0 +1,95 @@
+// comm_rccl.hip -- the transport that replaces the reference's MPI calls when one process
+// drives one MI355X: RCCL point-to-point over xGMI, enqueued on the SAME stream as the
+// pack / unpack kernels, so a ghost exchange is  pack kernel -> grouped send/recv -> unpack
+// kernel  in stream order with no host synchronisation.
+//
+// Reference call sites replaced (finite-volume/source/operators/):
+//   exchange_boundary.c:33-97, restriction.c:128-192, interpolation_p*.c:74-139
+//     MPI_Irecv* + MPI_Isend* + MPI_Waitall   ->  hpgmg_hip_rccl_sendrecv (one ncclGroup)
+//   misc.c:276,324,373  MPI_Allreduce(1 double, SUM|MAX, sub-communicator)
+//                                              ->  hpgmg_hip_rccl_allreduce over the listed ranks
+// Message sizes are small (a 128^2 face = 128 KiB, 4 faces per neighbour), every neighbour
+// pair has its own xGMI link, so one grouped call per exchange is the right granularity.
+// The scalar reductions involve only the ranks active on that level (the reference's
+// per-level MPI_Comm_split); they are done as an all-to-all of 8-byte messages reduced on
+// the host in rank order, which is deterministic and identical on every rank.
+#include <stdio.h>
+#include <string.h>
+#include <rccl/rccl.h>
+#include "common.hpp"
+
+namespace hpgmg {
+static ncclComm_t g_comm = nullptr;
+static int g_rank = 0, g_size = 1;
+static double *g_red_dev = nullptr;   // [g_size] staging for the scalar all-to-all
+static double *g_red_host = nullptr;  // pinned
+static int nccl_fail(ncclResult_t r, const char *where) {
+  fprintf(stderr, "hpgmg_hip: %s: %s\n", where, ncclGetErrorString(r));
+  return 1000 + (int)r;
+}
+#define NCCL_OK(call) do { ncclResult_t r_ = (call); if (r_ != ncclSuccess) return nccl_fail(r_, #call); } while (0)
+}  // namespace hpgmg
+using namespace hpgmg;
+
+extern "C" {
+
+int hpgmg_hip_rccl_unique_id(char *out128) {
+  ncclUniqueId id;
+  NCCL_OK(ncclGetUniqueId(&id));
+  memcpy(out128, id.internal, NCCL_UNIQUE_ID_BYTES);
+  return 0;
+}
+
+int hpgmg_hip_rccl_init(const char *id128, int rank, int size) {
+  ncclUniqueId id;
+  memcpy(id.internal, id128, NCCL_UNIQUE_ID_BYTES);
+  NCCL_OK(ncclCommInitRank(&g_comm, size, id, rank));
+  g_rank = rank; g_size = size;
+  HPGMG_CHECK(hipMalloc((void **)&g_red_dev, (size_t)size * sizeof(double)));
+  HPGMG_CHECK(hipHostMalloc((void **)&g_red_host, (size_t)size * sizeof(double), hipHostMallocDefault));
+  return 0;
+}
+
+void hpgmg_hip_rccl_finalize(void) {
+  if (g_comm) { hipStreamSynchronize(g_stream); ncclCommDestroy(g_comm); g_comm = nullptr; }
+  if (g_red_dev) { (void)hipFree(g_red_dev); g_red_dev = nullptr; }
+  if (g_red_host) { (void)hipHostFree(g_red_host); g_red_host = nullptr; }
+}
+
+// signature = hpgmg_transport.sendrecv (include/hpgmg_mg.h); buffers are device memory
+void hpgmg_hip_rccl_sendrecv(void *ctx, int nrecv, double *const *rbuf, const int *rsize, const int *rrank,
+                             int nsend, double *const *sbuf, const int *ssize, const int *srank, int tag) {
+  (void)ctx; (void)tag;   // ordering inside one stream + one group per phase makes tags unnecessary
+  if (!g_comm) { fprintf(stderr, "hpgmg_hip: RCCL transport used before hpgmg_hip_rccl_init\n"); abort(); }
+  ncclResult_t r = ncclGroupStart();
+  for (int n = 0; n < nrecv && r == ncclSuccess; n++) r = ncclRecv(rbuf[n], (size_t)rsize[n], ncclDouble, rrank[n], g_comm, g_stream);
+  for (int n = 0; n < nsend && r == ncclSuccess; n++) r = ncclSend(sbuf[n], (size_t)ssize[n], ncclDouble, srank[n], g_comm, g_stream);
+  if (r == ncclSuccess) r = ncclGroupEnd();
+  if (r != ncclSuccess) { nccl_fail(r, "grouped ncclSend/ncclRecv"); abort(); }
+}
+
+// signature = hpgmg_transport.allreduce: n host doubles, in place, over `ranks` (sorted, contains me)
+void hpgmg_hip_rccl_allreduce(void *ctx, double *vals, int n, int op, const int *ranks, int nranks) {
+  (void)ctx;
+  if (nranks <= 1) return;
+  if (!g_comm) { fprintf(stderr, "hpgmg_hip: RCCL transport used before hpgmg_hip_rccl_init\n"); abort(); }
+  for (int v = 0; v < n; v++) {   // n is 1 everywhere on the path; keep the general form simple
+    g_red_host[g_rank] = vals[v];
+    hipMemcpyAsync(g_red_dev + g_rank, g_red_host + g_rank, sizeof(double), hipMemcpyHostToDevice, g_stream);
+    ncclResult_t r = ncclGroupStart();
+    for (int q = 0; q < nranks && r == ncclSuccess; q++) if (ranks[q] != g_rank) r = ncclRecv(g_red_dev + ranks[q], 1, ncclDouble, ranks[q], g_comm, g_stream);
+    for (int q = 0; q < nranks && r == ncclSuccess; q++) if (ranks[q] != g_rank) r = ncclSend(g_red_dev + g_rank, 1, ncclDouble, ranks[q], g_comm, g_stream);
+    if (r == ncclSuccess) r = ncclGroupEnd();
+    if (r != ncclSuccess) { nccl_fail(r, "scalar all-to-all"); abort(); }
+    hipMemcpyAsync(g_red_host, g_red_dev, (size_t)g_size * sizeof(double), hipMemcpyDeviceToHost, g_stream);
+    hipStreamSynchronize(g_stream);
+    double acc = g_red_host[ranks[0]];
+    for (int q = 1; q < nranks; q++) {
+      const double x = g_red_host[ranks[q]];
+      if (op == 0) acc = (x > acc) ? x : acc; else acc += x;   // HPGMG_REDUCE_MAX = 0, HPGMG_REDUCE_SUM = 1
+    }
+    vals[v] = acc;
+  }
+}
+
+}  // extern "C"

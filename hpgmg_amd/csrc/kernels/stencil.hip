@@ -135,6 +135,7 @@ __global__ __launch_bounds__(256) void stencil7_kernel(const hpgmg_hip_level L, 
 
 // ---- smoother-kernel profiling: hipEvent pair around every smoother launch ----
 static bool g_profile = false;
+static long long g_profile_min_cells = 0;   // only launches covering at least this many cells are timed
 static const int kMaxPairs = 8192;
 static hipEvent_t g_ev[2 * kMaxPairs];
 static int g_pairs_alloc = 0, g_pairs_used = 0;
@@ -149,8 +150,8 @@ static void profile_flush() {
   }
   g_pairs_used = 0;
 }
-static int profile_begin() {
-  if (!g_profile) return -1;
+static int profile_begin(long long cells) {
+  if (!g_profile || cells < g_profile_min_cells) return -1;
   if (g_pairs_used == kMaxPairs) profile_flush();
   if (g_pairs_used == g_pairs_alloc) { hipEventCreate(&g_ev[2 * g_pairs_alloc]); hipEventCreate(&g_ev[2 * g_pairs_alloc + 1]); g_pairs_alloc++; }
   int p = g_pairs_used++;
@@ -185,14 +186,15 @@ static int launch(const hpgmg_hip_level *L, int variant, StencilArgs P, bool is_
   if (L->num_boxes <= 0) return 0;
   dim3 block; int grid;
   plan(L, P, block, grid);
-  int prof = is_smoother ? profile_begin() : -1;
+  const long long cells = (long long)L->num_boxes * L->dim * L->dim * L->dim;
+  int prof = is_smoother ? profile_begin(cells) : -1;
   switch (variant) {
     case HPGMG_HIP_7PT_VC_HELMHOLTZ: hipLaunchKernelGGL((stencil7_kernel<HPGMG_HIP_7PT_VC_HELMHOLTZ, MODE>), dim3(grid), block, 0, g_stream, *L, P); break;
     case HPGMG_HIP_7PT_VC_POISSON:   hipLaunchKernelGGL((stencil7_kernel<HPGMG_HIP_7PT_VC_POISSON, MODE>), dim3(grid), block, 0, g_stream, *L, P); break;
     case HPGMG_HIP_7PT_CC:           hipLaunchKernelGGL((stencil7_kernel<HPGMG_HIP_7PT_CC, MODE>), dim3(grid), block, 0, g_stream, *L, P); break;
     default: return record_error(hipErrorInvalidValue, "stencil variant not implemented");
   }
-  profile_end(prof, (long long)L->num_boxes * L->dim * L->dim * L->dim);
+  profile_end(prof, cells);
   HPGMG_LAUNCH_CHECK("stencil7_kernel");
   return 0;
 }
@@ -206,6 +208,7 @@ void hpgmg_hip_profile_smoother(int enable) {
   if (enable) { profile_flush(); g_prof_ms_flushed = 0.0; g_prof_cells = 0; g_prof_launches = 0; }
   g_profile = enable != 0;
 }
+void hpgmg_hip_profile_smoother_min_cells(long long min_cells) { g_profile_min_cells = min_cells; }
 int hpgmg_hip_profile_smoother_read(double *total_ms, long long *launches, long long *cells) {
   profile_flush();
   if (total_ms) *total_ms = g_prof_ms_flushed;

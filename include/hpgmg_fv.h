@@ -73,6 +73,10 @@ void        hpgmg_mg_destroy(mg_type *mg);
 level_type *hpgmg_mg_level(mg_type *mg, int l);
 int         hpgmg_mg_num_levels(const mg_type *mg);
 void        hpgmg_set_verbose(int v);
+/* HIP build only: install the RCCL transport (id from hpgmg_hip_rccl_unique_id on rank 0) */
+int         hpgmg_transport_init_rccl(const char *id128, int rank, int size);
+void        hpgmg_transport_finalize_rccl(void);
+void        hpgmg_set_sync_timers(int on);
 void        hpgmg_set_box_alignment(int jstride, int kstride, int volume, int base_bytes);
 
 #ifdef __cplusplus

@@ -57,6 +57,7 @@ int    hpgmg_hip_event_record(void *ev);
 double hpgmg_hip_event_elapsed_ms(void *start, void *stop); /* synchronises on stop */
 /* accumulate the GPU time of every smoother-kernel launch between begin/end (hipEvents around each launch) */
 void   hpgmg_hip_profile_smoother(int enable);
+void   hpgmg_hip_profile_smoother_min_cells(long long min_cells); /* time only launches over >= this many cells */
 int    hpgmg_hip_profile_smoother_read(double *total_ms, long long *launches, long long *cells);
 
 /* ---- smoothers: operators/chebyshev.c:43-99, operators/gsrb.c:24-132, operators/jacobi.c:8-65 ----
@@ -107,6 +108,17 @@ int hpgmg_hip_sum(const hpgmg_hip_level *L, int id, double *out);               
 /* ---- operators.7pt.c:158-227: Dinv (+L1inv when l1inv_id >= 0) and the Gershgorin bound of lambda_max(D^-1 A) ---- */
 int hpgmg_hip_rebuild_7pt(const hpgmg_hip_level *L, int variable_coeff, int alpha_id, int l1inv_id,
                           double a, double b, double h2inv, double *lambda_max_out);
+
+/* ---- transport over RCCL / xGMI (replaces the MPI calls of exchange_boundary.c:33-97,
+ *      restriction.c:128-192, interpolation_p*.c:74-139 and the MPI_Allreduce of misc.c:276,324,373).
+ *      One process per GPU; rank 0 makes the id, every rank calls init with it.  The two
+ *      functions after init have exactly the hpgmg_transport callback signatures. ---- */
+int  hpgmg_hip_rccl_unique_id(char *out128);
+int  hpgmg_hip_rccl_init(const char *id128, int rank, int size);
+void hpgmg_hip_rccl_finalize(void);
+void hpgmg_hip_rccl_sendrecv(void *ctx, int nrecv, double *const *rbuf, const int *rsize, const int *rrank,
+                             int nsend, double *const *sbuf, const int *ssize, const int *srank, int tag);
+void hpgmg_hip_rccl_allreduce(void *ctx, double *vals, int n, int op, const int *ranks, int nranks);
 
 #ifdef __cplusplus
 }

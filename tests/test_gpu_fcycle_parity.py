@@ -1,0 +1,68 @@
+"""HIP path vs the reference's golden numbers and vs the CPU oracle, whole F-cycles.
+
+Everything goes through the C-ABI libraries (libhpgmg_fv.so -> libhpgmg_hip.so).  The bar is
+bit-exactness of the printed 16-digit max-norms (tolerance stated: 0 ulp on those digits; the
+north_star allows 1e-12 relative, which the last test also asserts explicitly).
+"""
+import pytest
+
+from hpgmg_testlib import VARIANTS, load_golden
+
+pytestmark = pytest.mark.gpu
+GOLD = load_golden("fcycle_norms.json")
+
+
+def fmt(x):
+    return "%1.15e" % x
+
+
+SMALL = [("7pt-cheby", "4 8"), ("7pt-cheby", "5 8"), ("7pt-gsrb", "5 8"), ("7pt-cheby-helm", "5 8"), ("7ptcc-cheby", "5 8"),
+         ("7pt-jacobi", "4 8"), ("7pt-cheby", "4 1"), ("7pt-cheby", "4 27"), ("7pt-cheby-helm", "6 8")]
+
+
+@pytest.mark.parametrize("variant,args", SMALL)
+def test_hip_fcycle_matches_reference_golden(hip, variant, args):
+    gold = GOLD[f"{variant} {args}"]
+    hip.configure(**VARIANTS[variant])
+    log2, per_rank = map(int, args.split())
+    s = hip.solver_cli(log2, per_rank)
+    try:
+        assert [fmt(v) for v in s.three_sizes()] == gold["norms"]
+        assert ["%e" % s.level(l).eigenvalue for l in range(s.num_levels())] == gold["eigenvalue_max"]
+        err, order = s.richardson()
+        assert fmt(err) == gold["richardson_error"]
+        assert "%0.3f" % order == gold["order"]
+    finally:
+        s.destroy()
+
+
+@pytest.mark.parametrize("variant", ["7pt-cheby-helm", "7pt-cheby", "7pt-gsrb", "7ptcc-cheby"])
+def test_hip_fcycle_full_size_256(hip, variant):
+    """BASELINE.json config 2 (`7 8`, 256^3, 8 boxes of 128^3) and its Poisson/GSRB/CC siblings."""
+    gold = GOLD[f"{variant} 7 8"]
+    hip.configure(**VARIANTS[variant])
+    s = hip.solver_cli(7, 8)
+    try:
+        got = s.three_sizes()
+        assert [fmt(v) for v in got] == gold["norms"]
+        for g, r in zip(got, gold["norms"]):
+            assert abs(g - float(r)) <= 1e-12 * float(r)        # the north_star's stated tolerance
+        err, order = s.richardson()
+        assert fmt(err) == gold["richardson_error"] and "%0.3f" % order == gold["order"]
+    finally:
+        s.destroy()
+
+
+def test_hip_equals_oracle_live(hip, oracle):
+    """Same solve on both builds of the host layer, compared as doubles (no formatting)."""
+    for be in (hip, oracle):
+        be.configure(**VARIANTS["7pt-cheby-helm"])
+    sh, so = hip.solver(2, 16), oracle.solver(2, 16)
+    try:
+        assert sh.three_sizes() == so.three_sizes()
+        lh, lo = sh.level(0), so.level(0)
+        import numpy as np
+        for vid in (1, 2, 4, 5, 6, 7, 8, 9):   # U F R DINV BETA_* ALPHA
+            assert np.array_equal(lh.interior(vid), lo.interior(vid)), vid
+    finally:
+        sh.destroy(); so.destroy()

@@ -1,0 +1,164 @@
+"""Operator-by-operator parity: HIP kernels (through the C-ABI) vs the CPU oracle on the same
+seeded inputs, compared byte for byte over the WHOLE padded boxes (interior, ghosts and padding),
+so a kernel writing one cell too many is caught as well.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+
+import hpgmg_amd as H
+from hpgmg_testlib import VARIANTS, seeded_field
+
+pytestmark = pytest.mark.gpu
+
+GEOMS = [(1, 16), (2, 8), (2, 16), (3, 4), (1, 2), (1, 1), (2, 2), (1, 6), (2, 64)]
+
+
+def make_pair(hip, oracle, variant, boxes_in_i, box_dim, seed=0, vectors=None):
+    """Two identical levels (one per backend) with every reserved vector filled with the same seeded data."""
+    levels = []
+    for be in (hip, oracle):
+        be.configure(**VARIANTS[variant])
+        levels.append(be.level(boxes_in_i, box_dim, num_vectors=vectors))
+    lh, lo = levels
+    for vid in range(lh.num_vectors):
+        data = seeded_field(lh, seed * 100 + vid)
+        if vid in (H.VECTOR_DINV, H.VECTOR_BETA_I, H.VECTOR_BETA_J, H.VECTOR_BETA_K, H.VECTOR_ALPHA):
+            data = np.abs(data) + 0.5          # positive coefficients, like the real problem
+        lh.write_all(vid, data); lo.write_all(vid, data)
+    for lv in (lh, lo):
+        lv.b.lib.rebuild_operator  # noqa: B018  (symbol exists on both)
+    return lh, lo
+
+
+def same(lh, lo, vids):
+    for vid in vids:
+        a, b = lh.read_all(vid), lo.read_all(vid)
+        assert np.array_equal(a, b), f"vector {vid}: {np.argwhere(a != b)[:5]} max|d|={np.nanmax(np.abs(a - b))}"
+
+
+def set_eig(lv, value=1.9):
+    # dominant_eigenvalue_of_DinvA is set by rebuild_operator; run it so both sides have the same state
+    lv.b.lib.rebuild_operator(lv.ptr, None, 1.0, 1.0)
+
+
+@pytest.mark.parametrize("geom", GEOMS)
+@pytest.mark.parametrize("variant", ["7pt-cheby", "7pt-cheby-helm", "7ptcc-cheby", "7pt-gsrb", "7pt-jacobi"])
+def test_smooth_residual_apply(hip, oracle, variant, geom):
+    lh, lo = make_pair(hip, oracle, variant, *geom, seed=1)
+    try:
+        a, b = (1.0, 1.0) if "helm" in variant else (0.0, 1.0)
+        for lv in (lh, lo):
+            lv.b.lib.rebuild_operator(lv.ptr, None, a, b)
+        assert lh.eigenvalue == lo.eigenvalue
+        same(lh, lo, [H.VECTOR_DINV])
+        for lv in (lh, lo):
+            lv.b.lib.smooth(lv.ptr, H.VECTOR_U, H.VECTOR_F, a, b)
+        same(lh, lo, [H.VECTOR_U, H.VECTOR_TEMP])
+        for lv in (lh, lo):
+            lv.b.lib.residual(lv.ptr, H.VECTOR_R, H.VECTOR_U, H.VECTOR_F, a, b)
+            lv.b.lib.apply_op(lv.ptr, H.VECTOR_E, H.VECTOR_U, a, b)
+        same(lh, lo, [H.VECTOR_R, H.VECTOR_E, H.VECTOR_U])
+    finally:
+        lh.destroy(); lo.destroy()
+
+
+@pytest.mark.parametrize("geom", GEOMS)
+@pytest.mark.parametrize("shape", [H.STENCIL_SHAPE_BOX, H.STENCIL_SHAPE_STAR, H.STENCIL_SHAPE_NO_CORNERS])
+def test_exchange_and_boundary_conditions(hip, oracle, geom, shape):
+    lh, lo = make_pair(hip, oracle, "7pt-cheby", *geom, seed=2)
+    try:
+        for lv in (lh, lo):
+            lv.b.lib.exchange_boundary(lv.ptr, H.VECTOR_U, shape)
+        same(lh, lo, [H.VECTOR_U])
+        for lv in (lh, lo):
+            lv.b.lib.apply_BCs_p1(lv.ptr, H.VECTOR_U, shape)
+        same(lh, lo, [H.VECTOR_U])
+    finally:
+        lh.destroy(); lo.destroy()
+
+
+@pytest.mark.parametrize("geom", [(2, 16), (2, 8), (4, 8), (1, 8), (1, 2), (3, 4), (2, 32)])
+def test_restriction_and_interpolation(hip, oracle, geom):
+    pairs = []
+    for be in (hip, oracle):
+        be.configure(**VARIANTS["7pt-cheby-helm"])
+        fine = be.level(*geom)
+        for vid in range(fine.num_vectors):
+            d = seeded_field(fine, 300 + vid)
+            if vid >= H.VECTOR_DINV:
+                d = np.abs(d) + 0.5
+            fine.write_all(vid, d)
+        mg = be.lib.hpgmg_mg_create(fine.ptr, 1.0, 1.0, 1)
+        pairs.append((be, fine, mg))
+    try:
+        (bh, fh, mh), (bo, fo, mo) = pairs
+        assert bh.lib.hpgmg_mg_num_levels(mh) == bo.lib.hpgmg_mg_num_levels(mo) >= 2
+        from hpgmg_testlib import Level
+        ch, co = Level(bh, bh.lib.hpgmg_mg_level(mh, 1)), Level(bo, bo.lib.hpgmg_mg_level(mo, 1))
+        # MGBuild already restricted alpha/beta (cell + 3 face types) and rebuilt Dinv on the coarse level
+        same(ch, co, [H.VECTOR_ALPHA, H.VECTOR_BETA_I, H.VECTOR_BETA_J, H.VECTOR_BETA_K, H.VECTOR_DINV])
+        assert ch.eigenvalue == co.eigenvalue
+        for be, f, m in pairs:
+            c = be.lib.hpgmg_mg_level(m, 1)
+            be.lib.restriction(c, H.VECTOR_R, f.ptr, H.VECTOR_F, H.RESTRICT_CELL)
+            be.lib.interpolation_vcycle(f.ptr, H.VECTOR_U, 1.0, c, H.VECTOR_R)     # p0, increment
+            be.lib.interpolation_fcycle(f.ptr, H.VECTOR_E, 0.0, c, H.VECTOR_R)     # p1, overwrite
+        same(ch, co, [H.VECTOR_R])
+        same(fh, fo, [H.VECTOR_U, H.VECTOR_E])
+    finally:
+        for be, f, m in pairs:
+            be.lib.hpgmg_mg_destroy(m); f.destroy()
+
+
+@pytest.mark.parametrize("geom", [(2, 8), (1, 4), (3, 4), (1, 1), (2, 32)])
+def test_blas1_and_reductions(hip, oracle, geom):
+    lh, lo = make_pair(hip, oracle, "7pt-cheby-helm", *geom, seed=4)
+    try:
+        for lv in (lh, lo):
+            L = lv.b.lib
+            L.add_vectors(lv.ptr, 0, 0.75, 1, -1.25, 2)
+            L.mul_vectors(lv.ptr, 3, 2.0, 1, 2)
+            L.invert_vector(lv.ptr, 4, 3.0, 5)
+            L.scale_vector(lv.ptr, 1, -0.5, 2)
+            L.shift_vector(lv.ptr, 2, 2, 0.125)
+        same(lh, lo, range(lh.num_vectors))
+        for name in ("norm", "mean"):
+            assert getattr(lh.b.lib, name)(lh.ptr, 3) == getattr(lo.b.lib, name)(lo.ptr, 3), name
+        assert lh.b.lib.dot(lh.ptr, 3, 4) == lo.b.lib.dot(lo.ptr, 3, 4)
+        assert lh.b.lib.error(lh.ptr, 3, 4) == lo.b.lib.error(lo.ptr, 3, 4)
+        for lv in (lh, lo):
+            L = lv.b.lib
+            L.zero_vector(lv.ptr, 6); L.init_vector(lv.ptr, 7, 2.5)
+            L.color_vector(lv.ptr, 8, 3, 1, 2, 0); L.random_vector(lv.ptr, 9)
+        same(lh, lo, range(lh.num_vectors))
+    finally:
+        lh.destroy(); lo.destroy()
+
+
+def test_cabi_kernel_called_directly(hip):
+    """Call a launcher of include/hpgmg_hip.h straight through ctypes with raw device pointers."""
+    K = H.load_kernels()
+    dim, g = 8, 1
+    jS, kS = 12, 120
+    vol, nv = 1200, 3
+    host = np.zeros(nv * vol)
+    rng = np.random.default_rng(7)
+    host[:] = rng.random(nv * vol)
+    dev = K.hpgmg_hip_malloc(host.nbytes)
+    assert dev and K.hpgmg_hip_memcpy_h2d(dev, host.ctypes.data, host.nbytes) == 0
+    base = np.array([dev], dtype=np.uint64); low = np.zeros(3, dtype=np.int32)
+    d_base, d_low = K.hpgmg_hip_malloc(8), K.hpgmg_hip_malloc(12)
+    K.hpgmg_hip_memcpy_h2d(d_base, base.ctypes.data, 8); K.hpgmg_hip_memcpy_h2d(d_low, low.ctypes.data, 12)
+    lvl = H.HipLevel(d_base, d_low, 1, dim, g, jS, kS, vol, dim, dim, dim, 0)
+    assert K.hpgmg_hip_axpby(ctypes.byref(lvl), 2, 2.0, 0, -3.0, 1) == 0
+    out = ctypes.c_double()
+    assert K.hpgmg_hip_norm_max(ctypes.byref(lvl), 2, ctypes.byref(out)) == 0
+    back = np.empty_like(host); K.hpgmg_hip_memcpy_d2h(back.ctypes.data, dev, host.nbytes)
+    v = host.reshape(nv, 10, 10, 12)
+    expect = 2.0 * v[0, 1:9, 1:9, 1:9] + (-3.0) * v[1, 1:9, 1:9, 1:9]
+    assert np.array_equal(back.reshape(nv, 10, 10, 12)[2, 1:9, 1:9, 1:9], expect)
+    assert out.value == np.abs(expect).max()
+    for p in (dev, d_base, d_low):
+        K.hpgmg_hip_free(p)

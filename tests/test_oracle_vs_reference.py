@@ -1,0 +1,49 @@
+"""Pins the oracle against the REFERENCE ITSELF (only where /root/reference exists).
+
+oracle/Makefile builds (a) the unmodified reference and (b) the reference's own driver
+(level.c, mg.c, solvers.c, hpgmg-fv.c) linked against oracle/operators_cpu.c in place of
+operators.7pt.c.  Both must print identical pinned lines; and our level_type must be
+layout-identical to the reference's (otherwise (b) would not even run).
+"""
+import os
+import re
+import subprocess
+
+import pytest
+
+from hpgmg_testlib import ROOT, have_reference
+
+pytestmark = pytest.mark.skipif(not have_reference(), reason="/root/reference not present on this machine")
+REF = os.path.join(ROOT, "oracle", "_ref")
+
+
+@pytest.fixture(scope="module")
+def ref_build():
+    subprocess.run(["make", "-s", "-j4", "-C", os.path.join(ROOT, "oracle"), "ref"], check=True, stdout=subprocess.DEVNULL)
+    return REF
+
+
+def pinned_lines(binary, args):
+    env = dict(os.environ, OMP_NUM_THREADS="4")
+    out = subprocess.run([binary] + args.split(), capture_output=True, text=True, env=env, check=True).stdout
+    keep = []
+    for line in out.splitlines():
+        m = re.search(r"(f-cycle\s+norm=\S+\s+rel=\S+|\|\|error\|\|=\S+|order=\S+|eigenvalue_max<\S+|attempting to create.*)", line)
+        if m:
+            keep.append(m.group(1))
+    return keep
+
+
+def test_level_type_layout_matches_reference(ref_build):
+    a = subprocess.run([os.path.join(ref_build, "layout_ref")], capture_output=True, text=True, check=True).stdout
+    b = subprocess.run([os.path.join(ref_build, "layout_ours")], capture_output=True, text=True, check=True).stdout
+    assert a == b and "sizeof(level_type)" in a
+
+
+@pytest.mark.parametrize("variant", ["7pt-cheby", "7pt-gsrb", "7pt-cheby-helm", "7ptcc-cheby", "7pt-jacobi"])
+@pytest.mark.parametrize("args", ["4 8", "5 8"])
+def test_reference_driver_with_our_operators_prints_reference_numbers(ref_build, variant, args):
+    ref = pinned_lines(os.path.join(ref_build, "hpgmg-" + variant), args)
+    hyb = pinned_lines(os.path.join(ref_build, "hybrid-" + variant), args)
+    assert len(ref) > 60
+    assert ref == hyb
