@@ -90,6 +90,10 @@ def test_restriction_and_interpolation(hip, oracle, geom):
             if vid >= H.VECTOR_DINV:
                 d = np.abs(d) + 0.5
             fine.write_all(vid, d)
+        # face-centred data is shared by two boxes (high face of one = low face of the next): make the ghost
+        # copies consistent first, as initialize_problem does, or the two writers of a coarse face would race
+        for vid in range(H.VECTOR_DINV, fine.num_vectors):
+            be.lib.exchange_boundary(fine.ptr, vid, H.STENCIL_SHAPE_BOX)
         mg = be.lib.hpgmg_mg_create(fine.ptr, 1.0, 1.0, 1)
         pairs.append((be, fine, mg))
     try:
