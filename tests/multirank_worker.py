@@ -1,0 +1,92 @@
+"""Worker for tests/test_multirank_gloo.py: one rank of a world_size-N CPU job.
+
+Runs the host layer (level/list construction for num_ranks > 1, pack/unpack lists, per-level active
+rank sets, host-driven BiCGStab) with the CPU oracle operators, the MPI replacement being a
+transport whose two callbacks are implemented with torch.distributed (gloo).  The same two
+callbacks are implemented with RCCL in the product (hpgmg_amd/csrc/kernels/comm_rccl.hip).
+Prints one JSON line per rank.
+"""
+import ctypes
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from hpgmg_testlib import Backend, VARIANTS  # noqa: E402
+
+c_int, c_dbl, vp = ctypes.c_int, ctypes.c_double, ctypes.c_void_p
+PD, PI = ctypes.POINTER(c_dbl), ctypes.POINTER(c_int)
+SENDRECV = ctypes.CFUNCTYPE(None, vp, c_int, ctypes.POINTER(PD), PI, PI, c_int, ctypes.POINTER(PD), PI, PI, c_int)
+ALLREDUCE = ctypes.CFUNCTYPE(None, vp, PD, c_int, c_int, PI, c_int)
+
+
+class Transport(ctypes.Structure):
+    _fields_ = [("rank", c_int), ("size", c_int), ("ctx", vp), ("sendrecv", SENDRECV), ("allreduce", ALLREDUCE)]
+
+
+def view(ptr, n):
+    return torch.from_numpy(np.ctypeslib.as_array(ptr, shape=(n,)))
+
+
+def main():
+    variant, log2, per_rank = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+    dist.init_process_group(backend="gloo")
+    rank, size = dist.get_rank(), dist.get_world_size()
+    stats = {"messages": 0, "doubles": 0, "allreduces": 0}
+
+    def sendrecv(ctx, nrecv, rbuf, rsize, rrank, nsend, sbuf, ssize, srank, tag):
+        reqs = []
+        for n in range(nrecv):
+            reqs.append(dist.irecv(view(rbuf[n], rsize[n]), src=rrank[n], tag=tag))
+        for n in range(nsend):
+            reqs.append(dist.isend(view(sbuf[n], ssize[n]), dst=srank[n], tag=tag))
+            stats["messages"] += 1; stats["doubles"] += ssize[n]
+        for r in reqs:
+            r.wait()
+
+    def allreduce(ctx, vals, n, op, ranks, nranks):
+        stats["allreduces"] += 1
+        members = [ranks[q] for q in range(nranks)]
+        mine = torch.tensor([vals[v] for v in range(n)], dtype=torch.float64)
+        got = {rank: mine}
+        reqs = []
+        for r in members:
+            if r != rank:
+                got[r] = torch.empty(n, dtype=torch.float64)
+                reqs.append(dist.irecv(got[r], src=r, tag=9999))
+        for r in members:
+            if r != rank:
+                reqs.append(dist.isend(mine, dst=r, tag=9999))
+        for q in reqs:
+            q.wait()
+        for v in range(n):
+            acc = got[members[0]][v].item()
+            for r in members[1:]:
+                x = got[r][v].item()
+                acc = max(acc, x) if op == 0 else acc + x
+            vals[v] = acc
+
+    be = Backend.oracle()
+    cb = Transport(rank, size, None, SENDRECV(sendrecv), ALLREDUCE(allreduce))
+    be.lib.hpgmg_set_transport(ctypes.byref(cb))
+    be.configure(**VARIANTS[variant])
+    s = be.solver_cli(log2, per_rank, rank=rank, ranks=size)
+    norms = s.three_sizes()
+    err, order = s.richardson()
+    levels = []
+    for l in range(s.num_levels()):
+        lv = s.level(l)
+        levels.append({"dim": lv.dim, "box_dim": lv.box_dim, "my_boxes": lv.num_boxes, "active": lv.info[12]})
+    s.destroy()
+    print("RESULT " + json.dumps({"rank": rank, "norms": ["%1.15e" % v for v in norms], "err": "%1.15e" % err,
+                                  "order": "%0.3f" % order, "levels": levels, "stats": stats}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

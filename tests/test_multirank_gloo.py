@@ -1,0 +1,52 @@
+"""N > 1 path on CPU: world_size-2 (and 4) gloo jobs through the same host layer and transport
+interface the RCCL build uses.  Operator results do not depend on how the domain is cut into
+ranks, so every rank must print the single-rank reference golden numbers."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from hpgmg_testlib import ROOT, build_oracle, load_golden
+
+GOLD = load_golden("fcycle_norms.json")
+
+
+def free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def run_job(world, variant, log2, per_rank):
+    build_oracle()
+    env = dict(os.environ, OMP_NUM_THREADS="2", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.join(ROOT, "tests", "multirank_worker.py"), variant, str(log2), str(per_rank)]
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = [json.loads(line[len("RESULT "):]) for line in out.stdout.splitlines() if line.startswith("RESULT ")]
+    assert len(res) == world
+    return sorted(res, key=lambda r: r["rank"])
+
+
+@pytest.mark.parametrize("world,variant,log2,per_rank,gold_key", [
+    (2, "7pt-cheby", 4, 4, "7pt-cheby 4 8"),          # 2 ranks x 4 boxes of 16^3 = the single-rank `4 8` domain (32^3)
+    (2, "7pt-gsrb", 4, 4, "7pt-gsrb 4 8"),
+    (2, "7pt-cheby-helm", 4, 4, "7pt-cheby-helm 4 8"),
+    (4, "7pt-cheby", 4, 2, "7pt-cheby 4 8"),          # 4 ranks x 2 boxes
+])
+def test_multirank_matches_single_rank_reference(world, variant, log2, per_rank, gold_key):
+    gold = GOLD[gold_key]
+    res = run_job(world, variant, log2, per_rank)
+    # rank 0 owns a box on every level and is the rank whose numbers the reference prints
+    assert res[0]["norms"] == gold["norms"], res[0]
+    assert res[0]["err"] == gold["richardson_error"] and res[0]["order"] == gold["order"]
+    for r in res:   # every rank sees the same reduced norm on the levels where it is active (h and 2h here)
+        assert r["norms"][:2] == gold["norms"][:2], r
+        assert r["err"] == gold["richardson_error"]
+    # the fine level is really distributed, halo messages really flowed, coarse levels collapse onto rank 0
+    assert all(r["levels"][0]["my_boxes"] == 8 // world for r in res)
+    assert all(r["stats"]["messages"] > 50 and r["stats"]["allreduces"] > 5 for r in res)
+    last = [r["levels"][-1] for r in res]
+    assert last[0]["my_boxes"] == 1 and all(l["my_boxes"] == 0 and l["active"] == 0 for l in last[1:])
