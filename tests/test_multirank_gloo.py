@@ -25,7 +25,13 @@ def run_job(world, variant, log2, per_rank):
            "--master-port", str(free_port()), os.path.join(ROOT, "tests", "multirank_worker.py"), variant, str(log2), str(per_rank)]
     out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
-    res = [json.loads(line[len("RESULT "):]) for line in out.stdout.splitlines() if line.startswith("RESULT ")]
+    dec, res, pos = json.JSONDecoder(), [], 0       # ranks share stdout: two records can land on one line
+    while True:
+        pos = out.stdout.find("RESULT ", pos)
+        if pos < 0:
+            break
+        obj, end = dec.raw_decode(out.stdout, pos + len("RESULT "))
+        res.append(obj); pos = end
     assert len(res) == world
     return sorted(res, key=lambda r: r["rank"])
 
