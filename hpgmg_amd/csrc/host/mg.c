@@ -14,6 +14,7 @@
 #include <string.h>
 #include <math.h>
 #include <time.h>
+#include <stdint.h>
 #include "hpgmg_level.h"
 #include "hpgmg_operators.h"
 #include "hpgmg_mg.h"
@@ -361,6 +362,22 @@ void MGResetTimers(mg_type *G) {
   G->MGSolves_performed = 0;
 }
 
+/* ------------------------------------------------------------------ launch-bound segments
+ * Work on levels of <= SEGMENT_MAX_DIM^3 cells is a long chain of tiny launches.  The driver
+ * names each stretch of such work between two host synchronisations (bottom solves, norms) with
+ * a key that is identical in every solve; the plugin may capture and replay it (HIP: hipGraph).
+ * Nothing here changes WHAT is executed or in which order. */
+#define SEGMENT_MAX_DIM 64
+static long long seg_base = 0;   /* identifies (hierarchy, start level) of the running solve */
+static int seg_counter = 0, seg_open_now = 0;
+static int is_small(const mg_type *G, int l) { return G->levels[l]->dim.i <= SEGMENT_MAX_DIM; }
+static void seg_reset(const mg_type *G, int onLevel) {
+  seg_base = ((long long)(uintptr_t)G << 20) ^ ((long long)onLevel << 12);
+  seg_counter = 0; seg_open_now = 0;
+}
+static void seg_open(void) { if (!seg_open_now) { hpgmg_segment_begin(seg_base + (seg_counter++)); seg_open_now = 1; } }
+static void seg_close(void) { if (seg_open_now) { hpgmg_segment_end(); seg_open_now = 0; } }
+
 /* ------------------------------------------------------------------ cycles */
 void richardson_error(mg_type *G, int lh, int u_id) {
   /* || u^2h - R u^h ||_inf estimates the error at h; the ratio of two such
@@ -382,9 +399,24 @@ void MGVCycle(mg_type *G, int e_id, int R_id, double a, double b, int l) {
   double t;
   if (!L->active) return;
   if (l == G->num_levels - 1) {
+    seg_close();                                   /* the Krylov solver synchronises with the host */
     t = now();
     IterativeSolver(L, e_id, R_id, a, b, MG_DEFAULT_BOTTOM_NORM);
     L->timers.Total += now() - t;
+    return;
+  }
+  const int opened_here = is_small(G, l) && !seg_open_now;
+  if (is_small(G, l)) seg_open();
+  /* tiny levels: the plugin may run each leg of the rest of this V-cycle as one fused operation */
+  t = now();
+  if (hpgmg_vcycle_legs_fused(&G->levels[l], G->num_levels - l, e_id, R_id, a, b, 0)) {
+    L->timers.Total += now() - t;
+    MGVCycle(G, e_id, R_id, a, b, G->num_levels - 1);          /* bottom solve (closes the segment) */
+    seg_open();
+    t = now();
+    if (!hpgmg_vcycle_legs_fused(&G->levels[l], G->num_levels - l, e_id, R_id, a, b, 1)) { fprintf(stderr, "fused V-cycle leg refused after being accepted\n"); exit(1); }
+    L->timers.Total += now() - t;
+    if (opened_here) seg_close();
     return;
   }
   t = now();
@@ -394,12 +426,16 @@ void MGVCycle(mg_type *G, int e_id, int R_id, double a, double b, int l) {
   zero_vector(G->levels[l + 1], e_id);
   L->timers.Total += now() - t;
 
+  if (!is_small(G, l) && is_small(G, l + 1)) seg_open();   /* everything below this point is launch bound */
   MGVCycle(G, e_id, R_id, a, b, l + 1);
+  if (is_small(G, l)) seg_open();                           /* re-open after the bottom solve */
+  else seg_close();                                         /* back on a bandwidth-bound level */
 
   t = now();
   interpolation_vcycle(L, e_id, 1.0, G->levels[l + 1], e_id);
   smooth(L, e_id, R_id, a, b);
   L->timers.Total += now() - t;
+  if (opened_here) seg_close();
 }
 
 /* residual check shared by MGSolve and FMGSolve; returns 1 when converged */
@@ -429,12 +465,14 @@ void MGSolve(mg_type *G, int onLevel, int u_id, int F_id, double a, double b, do
   if (!L->active) return;
   SAY(L->my_rank, "MGSolve... ");
   double t0 = now();
+  seg_reset(G, onLevel + 64);
   double norm_of_F = norm(L, F_id);
   zero_vector(L, e_id);
   scale_vector(L, R_id, 1.0, F_id);
   for (v = 0; v < maxVCycles; v++) {
     L->vcycles_from_this_level++;
     MGVCycle(G, e_id, R_id, a, b, onLevel);
+    seg_close();
     snprintf(label, sizeof label, v > 0 ? "\n           v-cycle=%2d" : "v-cycle=%2d", v + 1);
     hpgmg_last_solve.vcycles = v + 1;
     if (check_residual(G, onLevel, e_id, F_id, a, b, norm_of_F, rtol, label)) break;
@@ -456,6 +494,7 @@ void FMGSolve(mg_type *G, int onLevel, int u_id, int F_id, double a, double b, d
   if (!L->active) return;
   SAY(L->my_rank, "FMGSolve... ");
   const double t0 = now();
+  seg_reset(G, onLevel);
 
   t = now();
   double norm_of_F = norm(L, F_id);
@@ -463,6 +502,7 @@ void FMGSolve(mg_type *G, int onLevel, int u_id, int F_id, double a, double b, d
   L->timers.Total += now() - t;
 
   for (l = onLevel; l < bottom; l++) {           /* carry the right-hand side down */
+    if (is_small(G, l)) seg_open();
     t = now();
     restriction(G->levels[l + 1], R_id, G->levels[l], R_id, RESTRICT_CELL);
     G->levels[l]->timers.Total += now() - t;
@@ -470,15 +510,18 @@ void FMGSolve(mg_type *G, int onLevel, int u_id, int F_id, double a, double b, d
 
   t = now();
   if (bottom > onLevel) zero_vector(G->levels[bottom], e_id);
+  seg_close();
   IterativeSolver(G->levels[bottom], e_id, R_id, a, b, MG_DEFAULT_BOTTOM_NORM);
   G->levels[bottom]->timers.Total += now() - t;
 
   for (l = bottom - 1; l >= onLevel; l--) {       /* climb: prolong the solution, then one V-cycle */
+    if (is_small(G, l)) seg_open();
     t = now();
     interpolation_fcycle(G->levels[l], e_id, 0.0, G->levels[l + 1], e_id);
     G->levels[l]->timers.Total += now() - t;
     G->levels[l]->vcycles_from_this_level++;
     MGVCycle(G, e_id, R_id, a, b, l);
+    seg_close();
   }
 
   hpgmg_last_solve.vcycles = 0;

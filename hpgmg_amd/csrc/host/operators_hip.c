@@ -25,11 +25,12 @@
 int hpgmg_smooth_sweeps(void);
 int hpgmg_gsrb_out_of_place(void);
 
-static int sync_timers = 0; /* 1: synchronise around every operator so level->timers are device times */
+static int sync_timers = -1; /* 1: synchronise around every operator so level->timers are device times (HPGMG_SYNC_TIMERS=1) */
 void hpgmg_set_sync_timers(int on) { sync_timers = on; }
 
 static double now(void) {
   struct timespec ts;
+  if (sync_timers < 0) { const char *e = getenv("HPGMG_SYNC_TIMERS"); sync_timers = (e && e[0] == '1'); }
   if (sync_timers) hpgmg_hip_sync();
   clock_gettime(CLOCK_MONOTONIC, &ts);
   return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
@@ -64,11 +65,21 @@ int hpgmg_transport_init_rccl(const char *id128, int rank, int size) {
 }
 void hpgmg_transport_finalize_rccl(void) { hpgmg_set_transport(NULL); hpgmg_hip_rccl_finalize(); }
 
+/* ---------------------------------------------------------------- hipGraph segments (see hpgmg_operators.h) */
+void hpgmg_segment_begin(long long key) {
+  static int graphs = -1;
+  if (graphs < 0) { const char *e = getenv("HPGMG_GRAPH"); graphs = !(e && e[0] == '0'); }
+  if (!graphs || sync_timers > 0) return;       /* HPGMG_GRAPH=0 / per-operator timing: stay eager */
+  if (hpgmg_get_transport()) return;            /* multi-rank: RCCL calls stay eager */
+  if (hpgmg_hip_graph_begin(key) < 0) { fprintf(stderr, "hpgmg: graph segment failed: %s\n", hpgmg_hip_last_error()); abort(); }
+}
+void hpgmg_segment_end(void) { HIP_OK(hpgmg_hip_graph_end()); }
+
 /* ---------------------------------------------------------------- per-level device record */
 #define MAX_LISTS 32
 typedef struct {
   hpgmg_hip_level dev;         /* what the kernels receive */
-  double **d_box_base;  int *d_box_low;
+  double **d_box_base;  int *d_box_low;  int *d_box_nbr;  int all_faces_local;
   double  *seen_v0;     int seen_nv, seen_boxes;  /* detects create_vectors() re-allocation */
   struct { const blockCopy_type *host; int n; blockCopy_type *dev; } lists[MAX_LISTS];
   int num_lists;
@@ -87,14 +98,39 @@ static backend_t *backend_of(level_type *L) {
       base[b] = L->my_boxes[b].vectors[0];
       low[3 * b] = L->my_boxes[b].low.i; low[3 * b + 1] = L->my_boxes[b].low.j; low[3 * b + 2] = L->my_boxes[b].low.k;
     }
+    /* face-neighbour table for the ghost-free stencil: local box index, -1 Dirichlet face, -2 remote box */
+    int *nbr = (int *)calloc((size_t)n * 6, sizeof(int));
+    B->all_faces_local = 1;
+    for (b = 0; b < L->num_my_boxes; b++) {
+      static const int step[6][3] = { {-1,0,0}, {1,0,0}, {0,-1,0}, {0,1,0}, {0,0,-1}, {0,0,1} };
+      const int bi = L->my_boxes[b].low.i / L->box_dim, bj = L->my_boxes[b].low.j / L->box_dim, bk = L->my_boxes[b].low.k / L->box_dim;
+      int d;
+      for (d = 0; d < 6; d++) {
+        int ni = bi + step[d][0], nj = bj + step[d][1], nk = bk + step[d][2], code;
+        if (L->boundary_condition.type == BC_PERIODIC) {
+          ni = (ni + L->boxes_in.i) % L->boxes_in.i; nj = (nj + L->boxes_in.j) % L->boxes_in.j; nk = (nk + L->boxes_in.k) % L->boxes_in.k;
+        }
+        if (ni < 0 || nj < 0 || nk < 0 || ni >= L->boxes_in.i || nj >= L->boxes_in.j || nk >= L->boxes_in.k) code = -1;
+        else {
+          const int id = ni + L->boxes_in.i * (nj + L->boxes_in.j * nk);
+          code = -2;
+          if (L->rank_of_box[id] == L->my_rank) { int q; for (q = 0; q < L->num_my_boxes; q++) if (L->my_boxes[q].global_box_id == id) code = q; }
+          if (code == -2) B->all_faces_local = 0;
+        }
+        nbr[6 * b + d] = code;
+      }
+    }
     if (B->d_box_base) hpgmg_hip_free(B->d_box_base);
     if (B->d_box_low) hpgmg_hip_free(B->d_box_low);
+    if (B->d_box_nbr) hpgmg_hip_free(B->d_box_nbr);
     B->d_box_base = (double **)hpgmg_hip_malloc((size_t)n * sizeof(double *));
     B->d_box_low = (int *)hpgmg_hip_malloc((size_t)n * 3 * sizeof(int));
-    if (!B->d_box_base || !B->d_box_low) { fprintf(stderr, "hpgmg: device allocation failed: %s\n", hpgmg_hip_last_error()); abort(); }
+    B->d_box_nbr = (int *)hpgmg_hip_malloc((size_t)n * 6 * sizeof(int));
+    if (!B->d_box_base || !B->d_box_low || !B->d_box_nbr) { fprintf(stderr, "hpgmg: device allocation failed: %s\n", hpgmg_hip_last_error()); abort(); }
     HIP_OK(hpgmg_hip_memcpy_h2d(B->d_box_base, base, (size_t)n * sizeof(double *)));
     HIP_OK(hpgmg_hip_memcpy_h2d(B->d_box_low, low, (size_t)n * 3 * sizeof(int)));
-    free(base); free(low);
+    HIP_OK(hpgmg_hip_memcpy_h2d(B->d_box_nbr, nbr, (size_t)n * 6 * sizeof(int)));
+    free(base); free(low); free(nbr);
     B->seen_v0 = v0; B->seen_nv = L->numVectors; B->seen_boxes = L->num_my_boxes;
   }
   B->dev.box_base = (double *const *)B->d_box_base;
@@ -104,6 +140,7 @@ static backend_t *backend_of(level_type *L) {
   B->dev.jStride = L->box_jStride; B->dev.kStride = L->box_kStride; B->dev.volume = L->box_volume;
   B->dev.dim_i = L->dim.i; B->dev.dim_j = L->dim.j; B->dev.dim_k = L->dim.k;
   B->dev.periodic = (L->boundary_condition.type == BC_PERIODIC);
+  B->dev.box_nbr = B->d_box_nbr;
   return B;
 }
 
@@ -123,6 +160,7 @@ static const blockCopy_type *mirror(level_type *owner, const blockCopy_type *hos
 }
 
 void hpgmg_level_release(level_type *L) {
+  hpgmg_hip_graph_reset();                       /* cached graphs hold pointers into this level */
   hpgmg_level_ext *X = hpgmg_level_ext_get(L);
   backend_t *B = (backend_t *)X->backend;
   int s;
@@ -130,6 +168,7 @@ void hpgmg_level_release(level_type *L) {
   for (s = 0; s < B->num_lists; s++) hpgmg_hip_free(B->lists[s].dev);
   if (B->d_box_base) hpgmg_hip_free(B->d_box_base);
   if (B->d_box_low) hpgmg_hip_free(B->d_box_low);
+  if (B->d_box_nbr) hpgmg_hip_free(B->d_box_nbr);
   free(B);
   X->backend = NULL;
 }
@@ -164,6 +203,37 @@ void exchange_boundary(level_type *L, int id, int shape) {
   L->timers.ghostZone_total += now() - t0;
 }
 
+/* What the stencil routines call instead of exchange_boundary()+apply_BCs() (chebyshev.c:45-46,
+ * gsrb.c:29-34, residual.c:11-12, apply_op.c:11-12).  In ghost-free mode (default for the 7-pt STAR
+ * stencil; HPGMG_GHOST_FREE=0 restores the reference's three-step form) the kernel reads local
+ * neighbours and the Dirichlet condition itself, so only messages from other ranks still go
+ * through the ghost zone: pack -> send/recv -> unpack, no local copies, no BC launch. */
+static int ghost_free = -1;
+static int ghost_free_mode(void) {
+  if (ghost_free < 0) { const char *e = getenv("HPGMG_GHOST_FREE"); ghost_free = (e && e[0] == '0') ? 0 : 1; hpgmg_hip_set_ghost_free(ghost_free); }
+  return ghost_free;
+}
+void hpgmg_set_ghost_free(int on) { ghost_free = on ? 1 : 0; hpgmg_hip_set_ghost_free(ghost_free); }
+static void ghosts_for_stencil(level_type *L, int id) {
+  const int shape = stencil_get_shape();
+  hpgmg_config c;
+  hpgmg_get_config(&c);
+  if (ghost_free_mode() && c.op == HPGMG_OP_7PT && shape == STENCIL_SHAPE_STAR) {
+    communicator_type *C = &L->exchange_ghosts[shape];
+    if (C->num_sends + C->num_recvs > 0) {
+      const double t0 = now();
+      backend_t *B = backend_of(L);
+      HIP_OK(hpgmg_hip_copy_blocks(&B->dev, id, mirror(L, C->blocks[0], C->num_blocks[0]), C->num_blocks[0]));
+      transport_phase(C, C, (L->tag << 4) | shape);
+      HIP_OK(hpgmg_hip_copy_blocks(&B->dev, id, mirror(L, C->blocks[2], C->num_blocks[2]), C->num_blocks[2]));
+      L->timers.ghostZone_total += now() - t0;
+    }
+    return;
+  }
+  exchange_boundary(L, id, shape);
+  apply_BCs(L, id, shape);
+}
+
 /* ---------------------------------------------------------------- boundary_fd.c / boundary_fv.c */
 void apply_BCs_p1(level_type *L, int x_id, int shape) {
   if (shape >= STENCIL_MAX_SHAPES) shape = STENCIL_SHAPE_BOX;
@@ -193,26 +263,64 @@ void apply_BCs(level_type *L, int x_id, int shape) {
 }
 
 /* ---------------------------------------------------------------- smoothers */
+static void cheby_coefficients(const level_type *L, int degree, double *c1, double *c2) { /* chebyshev.c:22-40 */
+  double beta = 1.000 * L->dominant_eigenvalue_of_DinvA, alpha = 0.125000 * beta;
+  double theta = 0.5 * (beta + alpha), delta = 0.5 * (beta - alpha), sigma = theta / delta, rho_n = 1 / sigma;
+  int s;
+  c1[0] = 0.0; c2[0] = 1 / theta;
+  for (s = 1; s < degree; s++) { double rho_nm1 = rho_n; rho_n = 1.0 / (2.0 * sigma - rho_nm1); c1[s] = rho_n * rho_nm1; c2[s] = rho_n * 2.0 / delta; }
+}
+
+/* Both legs of a V-cycle over a chain of tiny levels in one launch each (kernels/tail.hip). */
+int hpgmg_vcycle_legs_fused(level_type **levels, int n, int e_id, int R_id, double a, double b, int leg) {
+  static int enabled = -1;
+  hpgmg_config cfg;
+  const hpgmg_hip_level *dev[8];
+  const blockCopy_type *rl[8], *il[8];
+  int nr[8], ni[8], l, s;
+  double h2inv[8], c1[64], c2[64];
+  if (enabled < 0) { const char *e = getenv("HPGMG_FUSED_TAIL"); enabled = !(e && e[0] == '0'); }
+  hpgmg_get_config(&cfg);
+  const int sweeps = hpgmg_smooth_sweeps();
+  if (!enabled || !ghost_free_mode() || cfg.op != HPGMG_OP_7PT || n < 2 || n > 8 || n > hpgmg_hip_tail_max_levels() || sweeps > 8) return 0;
+  if (hpgmg_get_transport() && hpgmg_get_transport()->size > 1) return 0;
+  for (l = 0; l < n; l++) {
+    level_type *L = levels[l];
+    backend_t *B = backend_of(L);
+    if (!L->active || L->num_my_boxes < 1) return 0;
+    if (l + 1 < n) {
+      communicator_type *R = &L->restriction[RESTRICT_CELL], *I = &levels[l + 1]->interpolation;
+      if ((long long)L->dim.i * L->dim.j * L->dim.k > hpgmg_hip_tail_max_cells() || !B->all_faces_local) return 0;
+      if (R->num_blocks[0] || R->num_sends || levels[l + 1]->restriction[RESTRICT_CELL].num_blocks[2]) return 0;
+      if (I->num_blocks[0] || I->num_sends || L->interpolation.num_blocks[2]) return 0;
+      rl[l] = mirror(L, R->blocks[1], R->num_blocks[1]);             nr[l] = R->num_blocks[1];
+      il[l] = mirror(levels[l + 1], I->blocks[1], I->num_blocks[1]); ni[l] = I->num_blocks[1];
+      if (L->dominant_eigenvalue_of_DinvA <= 0.0 && cfg.smoother == HPGMG_SMOOTH_CHEBY) return 0;
+      cheby_coefficients(L, sweeps, c1 + l * sweeps, c2 + l * sweeps);
+    } else { rl[l] = il[l] = NULL; nr[l] = ni[l] = 0; for (s = 0; s < sweeps; s++) c1[l * sweeps + s] = c2[l * sweeps + s] = 0.0; }
+    dev[l] = &B->dev;
+    h2inv[l] = 1.0 / (L->h * L->h);
+  }
+  const double t0 = now();
+  HIP_OK(hpgmg_hip_vcycle_tail(n, dev, h2inv, c1, c2, sweeps, rl, nr, il, ni, variant(), cfg.smoother, e_id, R_id, a, b, leg));
+  levels[0]->timers.smooth += now() - t0;
+  return 1;
+}
+
 void smooth(level_type *L, int x_id, int rhs_id, double a, double b) {
   hpgmg_config cfg;
   hpgmg_get_config(&cfg);
-  const int sweeps = hpgmg_smooth_sweeps(), shape = stencil_get_shape(), v = variant();
+  const int sweeps = hpgmg_smooth_sweeps(), v = variant();
   const double h2inv = 1.0 / (L->h * L->h);
   backend_t *B = backend_of(L);
   int s;
   if (cfg.smoother == HPGMG_SMOOTH_CHEBY) {          /* chebyshev.c:8-100 */
     double c1[16], c2[16];
     if (L->dominant_eigenvalue_of_DinvA <= 0.0 && L->my_rank == 0) fprintf(stderr, "dominant_eigenvalue_of_DinvA <= 0.0 !\n");
-    { /* coefficients: chebyshev.c:22-40 */
-      double beta = 1.000 * L->dominant_eigenvalue_of_DinvA, alpha = 0.125000 * beta;
-      double theta = 0.5 * (beta + alpha), delta = 0.5 * (beta - alpha), sigma = theta / delta, rho_n = 1 / sigma;
-      c1[0] = 0.0; c2[0] = 1 / theta;
-      for (s = 1; s < sweeps; s++) { double rho_nm1 = rho_n; rho_n = 1.0 / (2.0 * sigma - rho_nm1); c1[s] = rho_n * rho_nm1; c2[s] = rho_n * 2.0 / delta; }
-    }
+    cheby_coefficients(L, sweeps, c1, c2);
     for (s = 0; s < sweeps; s++) {
       const int src = (s & 1) ? VECTOR_TEMP : x_id, dst = (s & 1) ? x_id : VECTOR_TEMP;
-      exchange_boundary(L, src, shape);
-      apply_BCs(L, src, shape);
+      ghosts_for_stencil(L, src);
       const double t0 = now();
       HIP_OK(hpgmg_hip_smooth_cheby(&B->dev, v, src, dst, rhs_id, a, b, h2inv, c1[s], c2[s]));
       L->timers.smooth += now() - t0;
@@ -221,8 +329,7 @@ void smooth(level_type *L, int x_id, int rhs_id, double a, double b) {
     const int oop = hpgmg_gsrb_out_of_place();
     for (s = 0; s < sweeps; s++) {
       const int src = (oop && (s & 1)) ? VECTOR_TEMP : x_id, dst = oop ? ((s & 1) ? x_id : VECTOR_TEMP) : x_id;
-      exchange_boundary(L, src, shape);
-      apply_BCs(L, src, shape);
+      ghosts_for_stencil(L, src);
       const double t0 = now();
       HIP_OK(hpgmg_hip_smooth_gsrb(&B->dev, v, src, dst, rhs_id, a, b, h2inv, s));
       L->timers.smooth += now() - t0;
@@ -230,8 +337,7 @@ void smooth(level_type *L, int x_id, int rhs_id, double a, double b) {
   } else {                                           /* jacobi.c:8-65 */
     for (s = 0; s < sweeps; s++) {
       const int src = (s & 1) ? VECTOR_TEMP : x_id, dst = (s & 1) ? x_id : VECTOR_TEMP;
-      exchange_boundary(L, src, shape);
-      apply_BCs(L, src, shape);
+      ghosts_for_stencil(L, src);
       const double t0 = now();
       HIP_OK(hpgmg_hip_smooth_jacobi(&B->dev, v, src, dst, rhs_id, a, b, h2inv, 2.0 / 3.0));
       L->timers.smooth += now() - t0;
@@ -240,15 +346,13 @@ void smooth(level_type *L, int x_id, int rhs_id, double a, double b) {
 }
 
 void residual(level_type *L, int res_id, int x_id, int rhs_id, double a, double b) {   /* residual.c:9-51 */
-  exchange_boundary(L, x_id, stencil_get_shape());
-  apply_BCs(L, x_id, stencil_get_shape());
+  ghosts_for_stencil(L, x_id);
   const double t0 = now();
   HIP_OK(hpgmg_hip_residual(&backend_of(L)->dev, variant(), res_id, x_id, rhs_id, a, b, 1.0 / (L->h * L->h)));
   L->timers.residual += now() - t0;
 }
 void apply_op(level_type *L, int Ax_id, int x_id, double a, double b) {               /* apply_op.c:9-48 */
-  exchange_boundary(L, x_id, stencil_get_shape());
-  apply_BCs(L, x_id, stencil_get_shape());
+  ghosts_for_stencil(L, x_id);
   const double t0 = now();
   HIP_OK(hpgmg_hip_residual(&backend_of(L)->dev, variant(), Ax_id, x_id, -1, a, b, 1.0 / (L->h * L->h)));
   L->timers.apply_op += now() - t0;

@@ -99,6 +99,23 @@ __global__ __launch_bounds__(256) void absmax_kernel(const hpgmg_hip_level L, in
   block_max_store(m, partials);
 }
 
+// small levels: one workgroup walks every row and stores the final max itself
+__global__ __launch_bounds__(256) void absmax_small_kernel(const hpgmg_hip_level L, int id, double *result) {
+  __shared__ double smem[4];
+  const int rows = L.num_boxes * L.dim * L.dim, lane = threadIdx.x % 64;
+  double m = 0.0;
+  for (int row = threadIdx.x / 64; row < rows; row += 4) {
+    RowIter r;
+    row_of(row, L.dim, L.num_boxes, r);
+    const double *p = vec_origin(L, r.box, id) + r.j * L.jStride + r.k * L.kStride;
+    for (int i = lane; i < L.dim; i += 64) { const double f = fabs(p[i]); m = (f > m) ? f : m; }
+  }
+  m = wave_max(m);
+  if (lane == 0) smem[threadIdx.x / 64] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) { for (int w = 1; w < 4; w++) m = (smem[w] > m) ? smem[w] : m; *result = m; }
+}
+
 __global__ __launch_bounds__(256) void final_max_kernel(const double *partials, int n, double init, double *result) {
   __shared__ double smem[4];
   double m = init;
@@ -111,11 +128,17 @@ __global__ __launch_bounds__(256) void final_max_kernel(const double *partials, 
 
 // ---- ordered sums ----------------------------------------------------------------------
 // one lane per dim x 8 x 8 tile, tiles numbered as level.c:1184-1210 builds my_blocks
-__global__ __launch_bounds__(64) void tile_sum_kernel(const hpgmg_hip_level L, int id_a, int id_b, double *partials) {
+// kFinish: the whole level fits one 64-lane workgroup, which then also adds the partials in tile
+// order and stores the result (to pinned host memory) -- one launch per reduction on small levels.
+template <bool kFinish>
+__global__ __launch_bounds__(64) void tile_sum_kernel(const hpgmg_hip_level L, int id_a, int id_b, double *partials, double *result) {
+  __shared__ double part[64];
   const int tiles_side = (L.dim + BLOCKCOPY_TILE_J - 1) / BLOCKCOPY_TILE_J;
   const int tiles_per_box = tiles_side * tiles_side;
+  const int ntiles = tiles_per_box * L.num_boxes;
   const int t = blockIdx.x * 64 + threadIdx.x;
-  if (t >= tiles_per_box * L.num_boxes) return;
+  if (kFinish) part[threadIdx.x] = 0.0;
+  if (t >= ntiles) { if (kFinish) __syncthreads(); return; }
   const int box = t / tiles_per_box, rem = t % tiles_per_box;
   const int k0 = (rem / tiles_side) * BLOCKCOPY_TILE_K, j0 = (rem % tiles_side) * BLOCKCOPY_TILE_J;
   const int k1 = min(k0 + BLOCKCOPY_TILE_K, L.dim), j1 = min(j0 + BLOCKCOPY_TILE_J, L.dim);
@@ -126,7 +149,10 @@ __global__ __launch_bounds__(64) void tile_sum_kernel(const hpgmg_hip_level L, i
     const int base = j * L.jStride + k * L.kStride;
     for (int i = 0; i < L.dim; i++) acc += pb ? pa[base + i] * pb[base + i] : pa[base + i];
   }
-  partials[t] = acc;
+  if (!kFinish) { partials[t] = acc; return; }
+  part[threadIdx.x] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) { double s = 0.0; for (int q = 0; q < ntiles; q++) s += part[q]; *result = s; }
 }
 __global__ void ordered_sum_kernel(const double *partials, int n, double *result) {
   double s = 0.0;
@@ -190,9 +216,9 @@ __global__ __launch_bounds__(256) void rebuild7_kernel(const hpgmg_hip_level L, 
 
 // scratch for partial results + a pinned host word the final kernels write to
 static double *g_scratch = nullptr;  static int g_scratch_len = 0;
-static double *g_result_dev = nullptr;
+static double *g_result_dev = nullptr;   // pinned, device-visible host word: kernels store the scalar here directly
 static int ensure_scratch(int n) {
-  if (!g_result_dev) { HPGMG_CHECK(hipMalloc((void **)&g_result_dev, 64)); }
+  if (!g_result_dev) { HPGMG_CHECK(hipHostMalloc((void **)&g_result_dev, 64, hipHostMallocDefault)); }
   if (n > g_scratch_len) {
     if (g_scratch) { hipStreamSynchronize(g_stream); (void)hipFree(g_scratch); }
     int want = n < 65536 ? 65536 : n;
@@ -202,13 +228,14 @@ static int ensure_scratch(int n) {
   return 0;
 }
 static int fetch_result(double *out) {
-  HPGMG_CHECK(hipMemcpyAsync(out, g_result_dev, sizeof(double), hipMemcpyDeviceToHost, g_stream));
   HPGMG_CHECK(hipStreamSynchronize(g_stream));
+  *out = *(volatile double *)g_result_dev;
   return 0;
 }
 
 template <int OP>
 static int launch_ew(const hpgmg_hip_level *L, const EwArgs &A) {
+  HPGMG_SKIP_IF_REPLAY();
   if (L->num_boxes <= 0) return 0;
   const int rows = L->num_boxes * L->dim * L->dim;
   hipLaunchKernelGGL((elementwise_kernel<OP>), dim3(rows_grid(rows)), dim3(256), 0, g_stream, *L, A);
@@ -220,8 +247,10 @@ static int launch_ew(const hpgmg_hip_level *L, const EwArgs &A) {
 using namespace hpgmg;
 
 extern "C" {
+int hpgmg_hip_graph_flush(void);
 
 int hpgmg_hip_fill(const hpgmg_hip_level *L, int id, double v) {
+  HPGMG_SKIP_IF_REPLAY();
   if (L->num_boxes <= 0) return 0;
   const int side = L->dim + 2 * L->ghosts, rows = L->num_boxes * side * side;
   hipLaunchKernelGGL(fill_kernel, dim3(rows_grid(rows)), dim3(256), 0, g_stream, *L, id, v);
@@ -251,22 +280,32 @@ int hpgmg_hip_random(const hpgmg_hip_level *L, int id) {
 }
 
 int hpgmg_hip_norm_max(const hpgmg_hip_level *L, int id, double *out) {
+  if (int e = hpgmg_hip_graph_flush()) return e;
   *out = 0.0;
   if (L->num_boxes <= 0) return 0;
   const int nblk = rows_grid(L->num_boxes * L->dim * L->dim);
   if (int e = ensure_scratch(nblk)) return e;
-  hipLaunchKernelGGL(absmax_kernel, dim3(nblk), dim3(256), 0, g_stream, *L, id, g_scratch);
-  hipLaunchKernelGGL(final_max_kernel, dim3(1), dim3(256), 0, g_stream, (const double *)g_scratch, nblk, 0.0, g_result_dev);
+  if (nblk <= 64) {
+    hipLaunchKernelGGL(absmax_small_kernel, dim3(1), dim3(256), 0, g_stream, *L, id, g_result_dev);
+  } else {
+    hipLaunchKernelGGL(absmax_kernel, dim3(nblk), dim3(256), 0, g_stream, *L, id, g_scratch);
+    hipLaunchKernelGGL(final_max_kernel, dim3(1), dim3(256), 0, g_stream, (const double *)g_scratch, nblk, 0.0, g_result_dev);
+  }
   HPGMG_LAUNCH_CHECK("norm_max");
   return fetch_result(out);
 }
 static int ordered_sum(const hpgmg_hip_level *L, int id_a, int id_b, double *out) {
+  if (int e = hpgmg_hip_graph_flush()) return e;
   *out = 0.0;
   if (L->num_boxes <= 0) return 0;
   const int side = (L->dim + BLOCKCOPY_TILE_J - 1) / BLOCKCOPY_TILE_J, ntiles = side * side * L->num_boxes;
   if (int e = ensure_scratch(ntiles)) return e;
-  hipLaunchKernelGGL(tile_sum_kernel, dim3((ntiles + 63) / 64), dim3(64), 0, g_stream, *L, id_a, id_b, g_scratch);
-  hipLaunchKernelGGL(ordered_sum_kernel, dim3(1), dim3(1), 0, g_stream, (const double *)g_scratch, ntiles, g_result_dev);
+  if (ntiles <= 64) {
+    hipLaunchKernelGGL((tile_sum_kernel<true>), dim3(1), dim3(64), 0, g_stream, *L, id_a, id_b, g_scratch, g_result_dev);
+  } else {
+    hipLaunchKernelGGL((tile_sum_kernel<false>), dim3((ntiles + 63) / 64), dim3(64), 0, g_stream, *L, id_a, id_b, g_scratch, g_result_dev);
+    hipLaunchKernelGGL(ordered_sum_kernel, dim3(1), dim3(1), 0, g_stream, (const double *)g_scratch, ntiles, g_result_dev);
+  }
   HPGMG_LAUNCH_CHECK("ordered_sum");
   return fetch_result(out);
 }
@@ -275,6 +314,7 @@ int hpgmg_hip_sum(const hpgmg_hip_level *L, int id, double *out) { return ordere
 
 int hpgmg_hip_rebuild_7pt(const hpgmg_hip_level *L, int variable_coeff, int alpha_id, int l1inv_id,
                           double a, double b, double h2inv, double *lambda_max_out) {
+  if (int e = hpgmg_hip_graph_flush()) return e;
   *lambda_max_out = -1e9;
   if (L->num_boxes <= 0) return 0;
   const int nblk = rows_grid(L->num_boxes * L->dim * L->dim);

@@ -119,18 +119,21 @@ using namespace hpgmg;
 extern "C" {
 
 int hpgmg_hip_copy_blocks(const hpgmg_hip_level *L, int id, const blockCopy_type *blocks, int n) {
+  HPGMG_SKIP_IF_REPLAY();
   if (n <= 0) return 0;
   hipLaunchKernelGGL((copy_blocks_kernel<false>), dim3(n), dim3(256), 0, g_stream, *L, id, blocks, 0.0);
   HPGMG_LAUNCH_CHECK("copy_blocks_kernel");
   return 0;
 }
 int hpgmg_hip_increment_blocks(const hpgmg_hip_level *L, int id, double prescale, const blockCopy_type *blocks, int n) {
+  HPGMG_SKIP_IF_REPLAY();
   if (n <= 0) return 0;
   hipLaunchKernelGGL((copy_blocks_kernel<true>), dim3(n), dim3(256), 0, g_stream, *L, id, blocks, prescale);
   HPGMG_LAUNCH_CHECK("increment_blocks_kernel");
   return 0;
 }
 int hpgmg_hip_apply_bc_p1(const hpgmg_hip_level *L, int id, const blockCopy_type *blocks, int n) {
+  HPGMG_SKIP_IF_REPLAY();
   if (n <= 0) return 0;
   hipLaunchKernelGGL(bc_p1_kernel, dim3(n), dim3(256), 0, g_stream, *L, id, blocks);
   HPGMG_LAUNCH_CHECK("bc_p1_kernel");
@@ -138,6 +141,7 @@ int hpgmg_hip_apply_bc_p1(const hpgmg_hip_level *L, int id, const blockCopy_type
 }
 int hpgmg_hip_restrict_blocks(const hpgmg_hip_level *Lc, int id_c, const hpgmg_hip_level *Lf, int id_f,
                               const blockCopy_type *blocks, int n, int type) {
+  HPGMG_SKIP_IF_REPLAY();
   if (n <= 0) return 0;
   switch (type) {
     case RESTRICT_CELL:   hipLaunchKernelGGL((restrict_blocks_kernel<RESTRICT_CELL>), dim3(n), dim3(256), 0, g_stream, *Lc, id_c, *Lf, id_f, blocks); break;
@@ -151,6 +155,7 @@ int hpgmg_hip_restrict_blocks(const hpgmg_hip_level *Lc, int id_c, const hpgmg_h
 }
 int hpgmg_hip_interpolate_blocks(const hpgmg_hip_level *Lf, int id_f, double prescale, const hpgmg_hip_level *Lc, int id_c,
                                  const blockCopy_type *blocks, int n, int order) {
+  HPGMG_SKIP_IF_REPLAY();
   if (n <= 0) return 0;
   if (order == 0) hipLaunchKernelGGL((interp_blocks_kernel<0>), dim3(n), dim3(256), 0, g_stream, *Lf, id_f, prescale, *Lc, id_c, blocks);
   else if (order == 1) hipLaunchKernelGGL((interp_blocks_kernel<1>), dim3(n), dim3(256), 0, g_stream, *Lf, id_f, prescale, *Lc, id_c, blocks);

@@ -32,6 +32,7 @@ static int nccl_fail(ncclResult_t r, const char *where) {
 using namespace hpgmg;
 
 extern "C" {
+int hpgmg_hip_graph_flush(void);
 
 int hpgmg_hip_rccl_unique_id(char *out128) {
   ncclUniqueId id;
@@ -59,6 +60,7 @@ void hpgmg_hip_rccl_finalize(void) {
 // signature = hpgmg_transport.sendrecv (include/hpgmg_mg.h); buffers are device memory
 void hpgmg_hip_rccl_sendrecv(void *ctx, int nrecv, double *const *rbuf, const int *rsize, const int *rrank,
                              int nsend, double *const *sbuf, const int *ssize, const int *srank, int tag) {
+  hpgmg_hip_graph_flush();
   (void)ctx; (void)tag;   // ordering inside one stream + one group per phase makes tags unnecessary
   if (!g_comm) { fprintf(stderr, "hpgmg_hip: RCCL transport used before hpgmg_hip_rccl_init\n"); abort(); }
   ncclResult_t r = ncclGroupStart();
@@ -71,6 +73,7 @@ void hpgmg_hip_rccl_sendrecv(void *ctx, int nrecv, double *const *rbuf, const in
 // signature = hpgmg_transport.allreduce: n host doubles, in place, over `ranks` (sorted, contains me)
 void hpgmg_hip_rccl_allreduce(void *ctx, double *vals, int n, int op, const int *ranks, int nranks) {
   (void)ctx;
+  hpgmg_hip_graph_flush();
   if (nranks <= 1) return;
   if (!g_comm) { fprintf(stderr, "hpgmg_hip: RCCL transport used before hpgmg_hip_rccl_init\n"); abort(); }
   for (int v = 0; v < n; v++) {   // n is 1 everywhere on the path; keep the general form simple

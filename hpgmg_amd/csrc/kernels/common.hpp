@@ -8,8 +8,10 @@
 namespace hpgmg {
 
 extern hipStream_t g_stream;          // stream every launcher enqueues on
+extern int g_skip_launches;           // 1 while a hipGraph replay segment is open (graph.hip): launchers do nothing
 int  record_error(hipError_t e, const char *where);
 #define HPGMG_CHECK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return hpgmg::record_error(e_, #call); } while (0)
+#define HPGMG_SKIP_IF_REPLAY() do { if (hpgmg::g_skip_launches) return 0; } while (0)
 #define HPGMG_LAUNCH_CHECK(name) do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return hpgmg::record_error(e_, name); } while (0)
 
 constexpr int kXcds = 8;              // MI355X: 8 XCDs, workgroup b is placed on XCD b % 8

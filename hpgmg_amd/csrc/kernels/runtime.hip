@@ -17,26 +17,28 @@ int record_error(hipError_t e, const char *where) {
 using namespace hpgmg;
 
 extern "C" {
+int hpgmg_hip_graph_flush(void);
 
 int hpgmg_hip_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
 int hpgmg_hip_set_device(int dev) { HPGMG_CHECK(hipSetDevice(dev)); return 0; }
 void hpgmg_hip_set_stream(void *s) { g_stream = (hipStream_t)s; }
 void *hpgmg_hip_get_stream(void) { return (void *)g_stream; }
-int hpgmg_hip_sync(void) { HPGMG_CHECK(hipStreamSynchronize(g_stream)); return 0; }
+int hpgmg_hip_sync(void) { hpgmg_hip_graph_flush(); HPGMG_CHECK(hipStreamSynchronize(g_stream)); return 0; }
 const char *hpgmg_hip_last_error(void) { return g_last_error; }
 
 void *hpgmg_hip_malloc(size_t bytes) {
   void *p = nullptr;
+  hpgmg_hip_graph_flush();
   if (bytes == 0) bytes = 8;
   if (hipMalloc(&p, bytes) != hipSuccess) { record_error(hipGetLastError(), "hipMalloc"); return nullptr; }
   if (hipMemsetAsync(p, 0, bytes, g_stream) != hipSuccess) { record_error(hipGetLastError(), "hipMemsetAsync"); }
   return p;
 }
-void hpgmg_hip_free(void *p) { if (p) { hipStreamSynchronize(g_stream); (void)hipFree(p); } }
-int hpgmg_hip_memcpy_h2d(void *d, const void *s, size_t n) { HPGMG_CHECK(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, g_stream)); HPGMG_CHECK(hipStreamSynchronize(g_stream)); return 0; }
-int hpgmg_hip_memcpy_d2h(void *d, const void *s, size_t n) { HPGMG_CHECK(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, g_stream)); HPGMG_CHECK(hipStreamSynchronize(g_stream)); return 0; }
-int hpgmg_hip_memcpy_d2d(void *d, const void *s, size_t n) { HPGMG_CHECK(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, g_stream)); return 0; }
-int hpgmg_hip_memset0(void *d, size_t n) { HPGMG_CHECK(hipMemsetAsync(d, 0, n, g_stream)); return 0; }
+void hpgmg_hip_free(void *p) { hpgmg_hip_graph_flush(); if (p) { hipStreamSynchronize(g_stream); (void)hipFree(p); } }
+int hpgmg_hip_memcpy_h2d(void *d, const void *s, size_t n) { hpgmg_hip_graph_flush(); HPGMG_CHECK(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, g_stream)); HPGMG_CHECK(hipStreamSynchronize(g_stream)); return 0; }
+int hpgmg_hip_memcpy_d2h(void *d, const void *s, size_t n) { hpgmg_hip_graph_flush(); HPGMG_CHECK(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, g_stream)); HPGMG_CHECK(hipStreamSynchronize(g_stream)); return 0; }
+int hpgmg_hip_memcpy_d2d(void *d, const void *s, size_t n) { hpgmg_hip_graph_flush(); HPGMG_CHECK(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, g_stream)); return 0; }
+int hpgmg_hip_memset0(void *d, size_t n) { hpgmg_hip_graph_flush(); HPGMG_CHECK(hipMemsetAsync(d, 0, n, g_stream)); return 0; }
 
 void *hpgmg_hip_event_create(void) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return nullptr; return (void *)e; }
 void hpgmg_hip_event_destroy(void *e) { if (e) (void)hipEventDestroy((hipEvent_t)e); }

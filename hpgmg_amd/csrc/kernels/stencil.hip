@@ -20,6 +20,7 @@
 //   * logical tiles are ordered box, k, j, i and dealt to XCDs in contiguous
 //     ranges (common.hpp) so halo planes shared by adjacent tiles hit the same L2.
 #include "common.hpp"
+#include "stencil_math.hpp"
 
 namespace hpgmg {
 
@@ -32,32 +33,8 @@ struct StencilArgs {
   int sweep;                    // GSRB colour of this half sweep
   int copy_other_colour;        // GSRB out of place
   int tiles_i, tiles_j, chunks_k, kchunk, per_xcd, total_blocks;
+  int ghost_free;               // read face neighbours from the adjacent box / apply the Dirichlet BC in registers
 };
-
-// A x at one cell, exactly as the reference's macro evaluates it.
-template <int V>
-__device__ __forceinline__ double apply_op_7pt(double xc, double xim, double xip, double xjm, double xjp, double xkm, double xkp,
-                                               double bi0, double bi1, double bj0, double bj1, double bk0, double bk1,
-                                               double alpha, double a, double b, double h2inv) {
-  if (V == HPGMG_HIP_7PT_CC) {
-    double s = xip + xim;
-    s = s + xjp;
-    s = s + xjm;
-    s = s + xkp;
-    s = s + xkm;
-    s = s - xc * 6.0;
-    return a * xc - (b * h2inv) * s;
-  } else {
-    double s = bi1 * (xip - xc);
-    s = s + bi0 * (xim - xc);
-    s = s + bj1 * (xjp - xc);
-    s = s + bj0 * (xjm - xc);
-    s = s + bk1 * (xkp - xc);
-    s = s + bk0 * (xkm - xc);
-    if (V == HPGMG_HIP_7PT_VC_HELMHOLTZ) return (a * alpha) * xc - (b * h2inv) * s;
-    return ((-b) * h2inv) * s;
-  }
-}
 
 // x may alias the output only for in-place GSRB; everywhere else it is restrict-qualified
 // so the loads of plane k+1 can be issued ahead of the store of plane k.
@@ -98,18 +75,32 @@ __global__ __launch_bounds__(256) void stencil7_kernel(const hpgmg_hip_level L, 
   int colour000 = 0;
   if (MODE == MODE_GSRB) colour000 = (L.box_low[3 * box] ^ L.box_low[3 * box + 1] ^ L.box_low[3 * box + 2] ^ P.sweep) & 1;
 
+  // Value of x just outside this box across face `dir` (0..5 = -i,+i,-j,+j,-k,+k): from the
+  // neighbouring local box, from the Dirichlet condition (ghost = -centre), or from the ghost zone.
+  const int last = L.dim - 1;
+  auto outside = [&](int dir, int idx_in_neighbour, int idx_ghost, double centre) -> double {
+    const int nb = L.box_nbr[6 * box + dir];
+    if (nb >= 0) return vec_origin(L, nb, P.xn_id)[idx_in_neighbour];
+    if (nb == -1) return -centre;
+    return x[idx_ghost];
+  };
+  const bool gf = P.ghost_free != 0;
+
   int ijk = i + j * jS + k0 * kS;
-  double xm = x[ijk - kS];
   double xc = x[ijk];
+  double xm = (gf && k0 == 0) ? outside(4, i + j * jS + last * kS, ijk - kS, xc) : x[ijk - kS];
   double bk0 = kVC ? beta_k[ijk] : 0.0;
 
   for (int k = k0; k < k1; k++, ijk += kS) {
-    const double xp = x[ijk + kS];
+    const double xp = (gf && k == last) ? outside(5, i + j * jS, ijk + kS, xc) : x[ijk + kS];
     const double bk1 = kVC ? beta_k[ijk + kS] : 0.0;
     bool update = true;
     if (MODE == MODE_GSRB) update = (((i ^ j ^ k ^ colour000) & 1) == 0);
     if (MODE != MODE_GSRB || update) {
-      const double xim = x[ijk - 1], xip = x[ijk + 1], xjm = x[ijk - jS], xjp = x[ijk + jS];
+      const double xim = (gf && i == 0)    ? outside(0, last + j * jS + k * kS, ijk - 1, xc)  : x[ijk - 1];
+      const double xip = (gf && i == last) ? outside(1, j * jS + k * kS, ijk + 1, xc)          : x[ijk + 1];
+      const double xjm = (gf && j == 0)    ? outside(2, i + last * jS + k * kS, ijk - jS, xc) : x[ijk - jS];
+      const double xjp = (gf && j == last) ? outside(3, i + k * kS, ijk + jS, xc)              : x[ijk + jS];
       double bi0 = 0.0, bi1 = 0.0, bj0 = 0.0, bj1 = 0.0, al = 0.0;
       if (kVC) { bi0 = beta_i[ijk]; bi1 = beta_i[ijk + 1]; bj0 = beta_j[ijk]; bj1 = beta_j[ijk + jS]; }
       if (kHelm) al = alpha[ijk];
@@ -150,8 +141,9 @@ static void profile_flush() {
   }
   g_pairs_used = 0;
 }
+extern "C" int hpgmg_hip_graph_is_open(void);
 static int profile_begin(long long cells) {
-  if (!g_profile || cells < g_profile_min_cells) return -1;
+  if (!g_profile || cells < g_profile_min_cells || hpgmg_hip_graph_is_open()) return -1;
   if (g_pairs_used == kMaxPairs) profile_flush();
   if (g_pairs_used == g_pairs_alloc) { hipEventCreate(&g_ev[2 * g_pairs_alloc]); hipEventCreate(&g_ev[2 * g_pairs_alloc + 1]); g_pairs_alloc++; }
   int p = g_pairs_used++;
@@ -164,7 +156,10 @@ static void profile_end(int p, long long cells) {
   g_prof_cells += cells; g_prof_launches++;
 }
 
+static int g_ghost_free = 0;
+
 static void plan(const hpgmg_hip_level *L, StencilArgs &P, dim3 &block, int &grid) {
+  P.ghost_free = (g_ghost_free && L->box_nbr) ? 1 : 0;
   int tx = 64;
   while (tx > 1 && tx / 2 >= L->dim) tx /= 2;           // smallest power of two >= dim, capped at one wave
   int ty = 256 / tx;
@@ -183,6 +178,7 @@ static void plan(const hpgmg_hip_level *L, StencilArgs &P, dim3 &block, int &gri
 
 template <int MODE>
 static int launch(const hpgmg_hip_level *L, int variant, StencilArgs P, bool is_smoother) {
+  HPGMG_SKIP_IF_REPLAY();
   if (L->num_boxes <= 0) return 0;
   dim3 block; int grid;
   plan(L, P, block, grid);
@@ -203,6 +199,9 @@ static int launch(const hpgmg_hip_level *L, int variant, StencilArgs P, bool is_
 using namespace hpgmg;
 
 extern "C" {
+
+void hpgmg_hip_set_ghost_free(int on) { g_ghost_free = on; }
+int hpgmg_hip_get_ghost_free(void) { return g_ghost_free; }
 
 void hpgmg_hip_profile_smoother(int enable) {
   if (enable) { profile_flush(); g_prof_ms_flushed = 0.0; g_prof_cells = 0; g_prof_launches = 0; }

@@ -31,6 +31,8 @@ typedef struct {
   int dim, ghosts, jStride, kStride, volume;
   int dim_i, dim_j, dim_k; /* global cells per side (Dirichlet masks in rebuild)             */
   int periodic;
+  const int *box_nbr;      /* DEVICE array [6*num_boxes] or NULL: local index of the box across the -i,+i,-j,+j,-k,+k
+                              face; -1 = homogeneous-Dirichlet domain face; -2 = box on another rank (use the ghost zone) */
 } hpgmg_hip_level;
 
 /* stencil variants of apply_op_ijk (operators.7pt.c:49-89, operators.27pt.c:60-91, operators.fv4.c:55-134) */
@@ -59,6 +61,15 @@ double hpgmg_hip_event_elapsed_ms(void *start, void *stop); /* synchronises on s
 void   hpgmg_hip_profile_smoother(int enable);
 void   hpgmg_hip_profile_smoother_min_cells(long long min_cells); /* time only launches over >= this many cells */
 int    hpgmg_hip_profile_smoother_read(double *total_ms, long long *launches, long long *cells);
+
+/* Ghost-free mode of the 7-pt stencil launchers below.  When `on` and L->box_nbr is given, a face
+ * neighbour that lies in another local box is read from that box directly and a Dirichlet face is
+ * evaluated as -x(centre) (= what apply_BCs_p1 would have stored, boundary_fd.c:35-65), so the
+ * caller may skip exchange_boundary()'s local copies and apply_BCs() for STAR-shaped stencils:
+ * one launch per sweep instead of three.  Interior results are bit-identical; ghost cells of the
+ * operand are then simply not refreshed (every consumer refreshes or bypasses them itself). */
+void hpgmg_hip_set_ghost_free(int on);
+int  hpgmg_hip_get_ghost_free(void);
 
 /* ---- smoothers: operators/chebyshev.c:43-99, operators/gsrb.c:24-132, operators/jacobi.c:8-65 ----
  * One sweep over every owned box.  x_n/x_np1/rhs are vector ids.  Chebyshev and
@@ -108,6 +119,31 @@ int hpgmg_hip_sum(const hpgmg_hip_level *L, int id, double *out);               
 /* ---- operators.7pt.c:158-227: Dinv (+L1inv when l1inv_id >= 0) and the Gershgorin bound of lambda_max(D^-1 A) ---- */
 int hpgmg_hip_rebuild_7pt(const hpgmg_hip_level *L, int variable_coeff, int alpha_id, int l1inv_id,
                           double a, double b, double h2inv, double *lambda_max_out);
+
+/* ---- tail.hip: both legs of a V-cycle over a chain of small levels (each <= hpgmg_hip_tail_max_cells()
+ *      cells, all face neighbours local) as ONE single-workgroup launch per leg; the operator sequence
+ *      of mg.c:1147-1163 (smooth, residual, restriction, zero_vector | interpolation_vcycle, smooth)
+ *      with barriers where the driver has kernel boundaries.  levels[n-1] is the bottom level. ---- */
+int hpgmg_hip_tail_max_levels(void);
+int hpgmg_hip_tail_max_cells(void);
+int hpgmg_hip_vcycle_tail(int n, const hpgmg_hip_level *const *levels, const double *h2inv,
+                          const double *c1, const double *c2, int sweeps,
+                          const blockCopy_type *const *restrict_lists, const int *n_restrict,
+                          const blockCopy_type *const *interp_lists, const int *n_interp,
+                          int variant, int smoother, int e_id, int R_id, double a, double b, int leg);
+
+/* ---- hipGraph segments (graph.hip): capture/replay of the launch-bound small-level part of a cycle.
+ *      begin(key): first use of a key runs eagerly, second is captured, later ones are replayed
+ *      (launchers return immediately while a replay segment is open; end() launches the graph).
+ *      Host-synchronising entry points flush an open segment themselves. ---- */
+void hpgmg_hip_graph_enable(int on);
+int  hpgmg_hip_graph_enabled(void);
+int  hpgmg_hip_graph_begin(long long key);
+int  hpgmg_hip_graph_end(void);
+int  hpgmg_hip_graph_is_open(void);
+int  hpgmg_hip_graph_flush(void);
+void hpgmg_hip_graph_reset(void);
+void hpgmg_hip_graph_stats(long long out[3]);   /* eager, captured, replayed segment counts */
 
 /* ---- transport over RCCL / xGMI (replaces the MPI calls of exchange_boundary.c:33-97,
  *      restriction.c:128-192, interpolation_p*.c:74-139 and the MPI_Allreduce of misc.c:276,324,373).

@@ -104,6 +104,19 @@ void    hpgmg_vector_copy(double *dst, const double *src, size_t num_doubles);
 /* host<->plugin staging, used by tests and by initialize_problem */
 void    hpgmg_vector_upload(double *dst_plugin, const double *src_host, size_t num_doubles);
 void    hpgmg_vector_download(double *dst_host, const double *src_plugin, size_t num_doubles);
+/* Launch-bound stretches of a cycle (everything done on levels of <= 64^3 cells between two
+ * bottom solves) are bracketed by the cycle driver as a SEGMENT with a key that repeats every
+ * solve, so the HIP plugin can capture it once into a hipGraph and replay it.  Plugins without
+ * such a mechanism implement these as no-ops.  A reduction (norm/dot/mean) ends an open segment. */
+void    hpgmg_segment_begin(long long key);
+void    hpgmg_segment_end(void);
+/* Optional fused form of MGVCycle's two legs (mg.c:1147-1163) over the chain levels[0..n-1]
+ * (finest first, levels[n-1] = bottom level, untouched except as restriction target /
+ * interpolation source).  leg 0: smooth, residual, restriction, zero_vector per level going
+ * down; leg 1: interpolation_vcycle, smooth per level going up.  Returns 1 when the plugin
+ * executed it (bit-identical to the per-operator sequence), 0 when it cannot -- the driver
+ * then issues the operators one by one. */
+int     hpgmg_vcycle_legs_fused(level_type **levels, int n, int e_id, int R_id, double a, double b, int leg);
 /* called by destroy_level / MGDestroy so the plugin can drop device mirrors */
 void    hpgmg_level_release(level_type *level);
 const char *hpgmg_backend_name(void);                      /* "hip" or "oracle-cpu" */

@@ -53,6 +53,21 @@ def test_hip_fcycle_full_size_256(hip, variant):
         s.destroy()
 
 
+def test_reference_three_launch_mode_gives_the_same_norms(hip):
+    """HPGMG_GHOST_FREE=0 path (exchange_boundary + apply_BCs + stencil, as the reference sequences them)."""
+    import ctypes
+    gold = GOLD["7pt-gsrb 5 8"]
+    hip.lib.hpgmg_set_ghost_free.argtypes = [ctypes.c_int]
+    hip.lib.hpgmg_set_ghost_free(0)
+    try:
+        hip.configure(**VARIANTS["7pt-gsrb"])
+        s = hip.solver_cli(5, 8)
+        assert [fmt(v) for v in s.three_sizes()] == gold["norms"]
+        s.destroy()
+    finally:
+        hip.lib.hpgmg_set_ghost_free(1)
+
+
 def test_hip_equals_oracle_live(hip, oracle):
     """Same solve on both builds of the host layer, compared as doubles (no formatting)."""
     for be in (hip, oracle):
