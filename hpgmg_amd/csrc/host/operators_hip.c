@@ -17,6 +17,7 @@
 #include <string.h>
 #include <math.h>
 #include <time.h>
+#include <stdint.h>
 #include "hpgmg_level.h"
 #include "hpgmg_operators.h"
 #include "hpgmg_mg.h"
@@ -141,6 +142,11 @@ static backend_t *backend_of(level_type *L) {
   B->dev.dim_i = L->dim.i; B->dev.dim_j = L->dim.j; B->dev.dim_k = L->dim.k;
   B->dev.periodic = (L->boundary_condition.type == BC_PERIODIC);
   B->dev.box_nbr = B->d_box_nbr;
+  { /* 16-byte alignment of every (box, vector) interior origin: base aligned and all strides even */
+    int b, ok = (L->box_jStride % 2 == 0) && (L->box_kStride % 2 == 0) && (L->box_volume % 2 == 0);
+    const size_t first = (size_t)L->box_ghosts * (size_t)(1 + L->box_jStride + L->box_kStride);
+    for (b = 0; ok && b < L->num_my_boxes; b++) if (((uintptr_t)(L->my_boxes[b].vectors[0] + first)) % 16) ok = 0;
+    B->dev.flags = ok ? 1 : 0; }
   return B;
 }
 

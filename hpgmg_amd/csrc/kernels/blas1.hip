@@ -99,8 +99,18 @@ __global__ __launch_bounds__(256) void absmax_kernel(const hpgmg_hip_level L, in
   block_max_store(m, partials);
 }
 
+// Scalar results go straight to a pinned host slot {value, sequence}: the last lane stores the value,
+// fences at system scope, then stores the launch's sequence number; the host polls the sequence
+// instead of paying a full stream synchronisation (reductions gate the host-driven BiCGStab).
+struct ResultSlot { double value; unsigned long long seq; };
+__device__ __forceinline__ void publish(ResultSlot *slot, double v, unsigned long long seq) {
+  slot->value = v;
+  __threadfence_system();
+  __hip_atomic_store(&slot->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // small levels: one workgroup walks every row and stores the final max itself
-__global__ __launch_bounds__(256) void absmax_small_kernel(const hpgmg_hip_level L, int id, double *result) {
+__global__ __launch_bounds__(256) void absmax_small_kernel(const hpgmg_hip_level L, int id, ResultSlot *result, unsigned long long seq) {
   __shared__ double smem[4];
   const int rows = L.num_boxes * L.dim * L.dim, lane = threadIdx.x % 64;
   double m = 0.0;
@@ -113,17 +123,17 @@ __global__ __launch_bounds__(256) void absmax_small_kernel(const hpgmg_hip_level
   m = wave_max(m);
   if (lane == 0) smem[threadIdx.x / 64] = m;
   __syncthreads();
-  if (threadIdx.x == 0) { for (int w = 1; w < 4; w++) m = (smem[w] > m) ? smem[w] : m; *result = m; }
+  if (threadIdx.x == 0) { for (int w = 1; w < 4; w++) m = (smem[w] > m) ? smem[w] : m; publish(result, m, seq); }
 }
 
-__global__ __launch_bounds__(256) void final_max_kernel(const double *partials, int n, double init, double *result) {
+__global__ __launch_bounds__(256) void final_max_kernel(const double *partials, int n, double init, ResultSlot *result, unsigned long long seq) {
   __shared__ double smem[4];
   double m = init;
   for (int t = threadIdx.x; t < n; t += 256) m = (partials[t] > m) ? partials[t] : m;
   m = wave_max(m);
   if (threadIdx.x % 64 == 0) smem[threadIdx.x / 64] = m;
   __syncthreads();
-  if (threadIdx.x == 0) { for (int w = 1; w < 4; w++) m = (smem[w] > m) ? smem[w] : m; *result = (smem[0] > m) ? smem[0] : m; }
+  if (threadIdx.x == 0) { for (int w = 1; w < 4; w++) m = (smem[w] > m) ? smem[w] : m; publish(result, (smem[0] > m) ? smem[0] : m, seq); }
 }
 
 // ---- ordered sums ----------------------------------------------------------------------
@@ -131,7 +141,7 @@ __global__ __launch_bounds__(256) void final_max_kernel(const double *partials, 
 // kFinish: the whole level fits one 64-lane workgroup, which then also adds the partials in tile
 // order and stores the result (to pinned host memory) -- one launch per reduction on small levels.
 template <bool kFinish>
-__global__ __launch_bounds__(64) void tile_sum_kernel(const hpgmg_hip_level L, int id_a, int id_b, double *partials, double *result) {
+__global__ __launch_bounds__(64) void tile_sum_kernel(const hpgmg_hip_level L, int id_a, int id_b, double *partials, ResultSlot *result, unsigned long long seq) {
   __shared__ double part[64];
   const int tiles_side = (L.dim + BLOCKCOPY_TILE_J - 1) / BLOCKCOPY_TILE_J;
   const int tiles_per_box = tiles_side * tiles_side;
@@ -152,12 +162,12 @@ __global__ __launch_bounds__(64) void tile_sum_kernel(const hpgmg_hip_level L, i
   if (!kFinish) { partials[t] = acc; return; }
   part[threadIdx.x] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) { double s = 0.0; for (int q = 0; q < ntiles; q++) s += part[q]; *result = s; }
+  if (threadIdx.x == 0) { double s = 0.0; for (int q = 0; q < ntiles; q++) s += part[q]; publish(result, s, seq); }
 }
-__global__ void ordered_sum_kernel(const double *partials, int n, double *result) {
+__global__ void ordered_sum_kernel(const double *partials, int n, ResultSlot *result, unsigned long long seq) {
   double s = 0.0;
   for (int t = 0; t < n; t++) s += partials[t];
-  *result = s;
+  publish(result, s, seq);
 }
 
 // ---- operators.7pt.c:158-227 --------------------------------------------------------------
@@ -216,9 +226,10 @@ __global__ __launch_bounds__(256) void rebuild7_kernel(const hpgmg_hip_level L, 
 
 // scratch for partial results + a pinned host word the final kernels write to
 static double *g_scratch = nullptr;  static int g_scratch_len = 0;
-static double *g_result_dev = nullptr;   // pinned, device-visible host word: kernels store the scalar here directly
+static ResultSlot *g_result_dev = nullptr;   // pinned, device-visible host slot: kernels publish the scalar here directly
+static unsigned long long g_seq = 0;
 static int ensure_scratch(int n) {
-  if (!g_result_dev) { HPGMG_CHECK(hipHostMalloc((void **)&g_result_dev, 64, hipHostMallocDefault)); }
+  if (!g_result_dev) { HPGMG_CHECK(hipHostMalloc((void **)&g_result_dev, 64, hipHostMallocDefault)); g_result_dev->seq = 0; g_result_dev->value = 0.0; }
   if (n > g_scratch_len) {
     if (g_scratch) { hipStreamSynchronize(g_stream); (void)hipFree(g_scratch); }
     int want = n < 65536 ? 65536 : n;
@@ -228,8 +239,13 @@ static int ensure_scratch(int n) {
   return 0;
 }
 static int fetch_result(double *out) {
-  HPGMG_CHECK(hipStreamSynchronize(g_stream));
-  *out = *(volatile double *)g_result_dev;
+  volatile ResultSlot *slot = g_result_dev;
+  for (long spins = 0; slot->seq != g_seq; spins++) {
+    __builtin_ia32_pause();
+    if (spins > 20000000L) { HPGMG_CHECK(hipStreamSynchronize(g_stream)); if (slot->seq != g_seq) return record_error(hipErrorUnknown, "reduction result never arrived"); }
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  *out = slot->value;
   return 0;
 }
 
@@ -286,10 +302,10 @@ int hpgmg_hip_norm_max(const hpgmg_hip_level *L, int id, double *out) {
   const int nblk = rows_grid(L->num_boxes * L->dim * L->dim);
   if (int e = ensure_scratch(nblk)) return e;
   if (nblk <= 64) {
-    hipLaunchKernelGGL(absmax_small_kernel, dim3(1), dim3(256), 0, g_stream, *L, id, g_result_dev);
+    hipLaunchKernelGGL(absmax_small_kernel, dim3(1), dim3(256), 0, g_stream, *L, id, g_result_dev, ++g_seq);
   } else {
     hipLaunchKernelGGL(absmax_kernel, dim3(nblk), dim3(256), 0, g_stream, *L, id, g_scratch);
-    hipLaunchKernelGGL(final_max_kernel, dim3(1), dim3(256), 0, g_stream, (const double *)g_scratch, nblk, 0.0, g_result_dev);
+    hipLaunchKernelGGL(final_max_kernel, dim3(1), dim3(256), 0, g_stream, (const double *)g_scratch, nblk, 0.0, g_result_dev, ++g_seq);
   }
   HPGMG_LAUNCH_CHECK("norm_max");
   return fetch_result(out);
@@ -301,10 +317,10 @@ static int ordered_sum(const hpgmg_hip_level *L, int id_a, int id_b, double *out
   const int side = (L->dim + BLOCKCOPY_TILE_J - 1) / BLOCKCOPY_TILE_J, ntiles = side * side * L->num_boxes;
   if (int e = ensure_scratch(ntiles)) return e;
   if (ntiles <= 64) {
-    hipLaunchKernelGGL((tile_sum_kernel<true>), dim3(1), dim3(64), 0, g_stream, *L, id_a, id_b, g_scratch, g_result_dev);
+    hipLaunchKernelGGL((tile_sum_kernel<true>), dim3(1), dim3(64), 0, g_stream, *L, id_a, id_b, g_scratch, g_result_dev, ++g_seq);
   } else {
-    hipLaunchKernelGGL((tile_sum_kernel<false>), dim3((ntiles + 63) / 64), dim3(64), 0, g_stream, *L, id_a, id_b, g_scratch, g_result_dev);
-    hipLaunchKernelGGL(ordered_sum_kernel, dim3(1), dim3(1), 0, g_stream, (const double *)g_scratch, ntiles, g_result_dev);
+    hipLaunchKernelGGL((tile_sum_kernel<false>), dim3((ntiles + 63) / 64), dim3(64), 0, g_stream, *L, id_a, id_b, g_scratch, g_result_dev, 0ULL);
+    hipLaunchKernelGGL(ordered_sum_kernel, dim3(1), dim3(1), 0, g_stream, (const double *)g_scratch, ntiles, g_result_dev, ++g_seq);
   }
   HPGMG_LAUNCH_CHECK("ordered_sum");
   return fetch_result(out);
@@ -321,7 +337,7 @@ int hpgmg_hip_rebuild_7pt(const hpgmg_hip_level *L, int variable_coeff, int alph
   if (int e = ensure_scratch(nblk)) return e;
   RebuildArgs A = { variable_coeff, alpha_id, l1inv_id, a, b, h2inv };
   hipLaunchKernelGGL(rebuild7_kernel, dim3(nblk), dim3(256), 0, g_stream, *L, A, g_scratch);
-  hipLaunchKernelGGL(final_max_kernel, dim3(1), dim3(256), 0, g_stream, (const double *)g_scratch, nblk, -1e9, g_result_dev);
+  hipLaunchKernelGGL(final_max_kernel, dim3(1), dim3(256), 0, g_stream, (const double *)g_scratch, nblk, -1e9, g_result_dev, ++g_seq);
   HPGMG_LAUNCH_CHECK("rebuild_7pt");
   return fetch_result(lambda_max_out);
 }

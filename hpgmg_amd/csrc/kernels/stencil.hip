@@ -19,6 +19,7 @@
 //     fetch as their own centre values);
 //   * logical tiles are ordered box, k, j, i and dealt to XCDs in contiguous
 //     ranges (common.hpp) so halo planes shared by adjacent tiles hit the same L2.
+#include <stdlib.h>
 #include "common.hpp"
 #include "stencil_math.hpp"
 
@@ -124,6 +125,137 @@ __global__ __launch_bounds__(256) void stencil7_kernel(const hpgmg_hip_level L, 
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Wide kernel for boxes whose side is a multiple of 128 (the bandwidth-critical fine levels).
+// Each lane owns a 2 (i) x 2 (j) patch: a wave covers two full 128-cell rows with 16-byte loads
+// (1 KiB per wave-instruction, the coalescing sweet spot), a 64x4 workgroup covers 8 rows and
+// marches in +k.  Per plane and per 4 cells a lane issues 4 x 16 B of x (the two k+1 centres and
+// the rows above / below the patch; the row in between comes from the partner row's registers)
+// instead of 12 x 8 B, and every coefficient stream as 16-byte loads: half the memory
+// instructions of the generic kernel and a third less L1 traffic for x.  Interior rows are
+// 16-byte aligned because jStride and kStride are even and the first interior cell is 32-byte
+// aligned (create_vectors); the launcher checks this and otherwise uses the generic kernel.
+// GSRB: the two cells of a row always have different colours, so every lane updates exactly one
+// cell per row (no idle lanes) and stores 8 bytes.
+struct alignas(16) d2 { double x, y; };
+__device__ __forceinline__ d2 ld2(const double *p) { return *reinterpret_cast<const d2 *>(p); }
+__device__ __forceinline__ void st2(double *p, d2 v) { *reinterpret_cast<d2 *>(p) = v; }
+
+template <int V, int MODE>
+__global__ __launch_bounds__(256) void stencil7_wide_kernel(const hpgmg_hip_level L, const StencilArgs P) {
+  const int logical = xcd_logical_block((int)blockIdx.x, P.per_xcd);
+  if (logical >= P.total_blocks) return;
+  int t = logical;
+  const int ti = t % P.tiles_i; t /= P.tiles_i;
+  const int tj = t % P.tiles_j; t /= P.tiles_j;
+  const int ck = t % P.chunks_k; t /= P.chunks_k;
+  const int box = t;
+
+  const int i = ti * 128 + 2 * (int)threadIdx.x;            // cells i, i+1
+  const int ja = tj * 8 + 2 * (int)threadIdx.y;             // rows ja, ja+1
+  const int k0 = ck * P.kchunk, k1 = (k0 + P.kchunk < L.dim) ? k0 + P.kchunk : L.dim;
+  const int jS = L.jStride, kS = L.kStride, last = L.dim - 1;
+
+  constexpr bool kVC = (V != HPGMG_HIP_7PT_CC);
+  constexpr bool kHelm = (V == HPGMG_HIP_7PT_VC_HELMHOLTZ);
+  constexpr bool kSmooth = (MODE == MODE_CHEBY || MODE == MODE_GSRB || MODE == MODE_JACOBI);
+
+  typename src_ptr<MODE == MODE_GSRB>::type x = vec_origin(L, box, P.xn_id);
+  double *out = vec_origin(L, box, P.xout_id);
+  const double *__restrict__ rhs = (MODE == MODE_APPLY) ? nullptr : vec_origin(L, box, P.rhs_id);
+  const double *__restrict__ dinv = kSmooth ? vec_origin(L, box, VECTOR_DINV) : nullptr;
+  const double *__restrict__ alpha = kHelm ? vec_origin(L, box, VECTOR_ALPHA) : nullptr;
+  const double *__restrict__ beta_i = kVC ? vec_origin(L, box, VECTOR_BETA_I) : nullptr;
+  const double *__restrict__ beta_j = kVC ? vec_origin(L, box, VECTOR_BETA_J) : nullptr;
+  const double *__restrict__ beta_k = kVC ? vec_origin(L, box, VECTOR_BETA_K) : nullptr;
+
+  const bool gf = P.ghost_free != 0;
+  // pair of values just outside this box across face `dir`, for the pair whose centres are `c`
+  auto outside2 = [&](int dir, int idx_in_neighbour, int idx_ghost, d2 c) -> d2 {
+    const int nb = L.box_nbr[6 * box + dir];
+    if (nb >= 0) return ld2(vec_origin(L, nb, P.xn_id) + idx_in_neighbour);
+    if (nb == -1) return d2{-c.x, -c.y};
+    return ld2(x + idx_ghost);
+  };
+  auto outside1 = [&](int dir, int idx_in_neighbour, int idx_ghost, double c) -> double {
+    const int nb = L.box_nbr[6 * box + dir];
+    if (nb >= 0) return vec_origin(L, nb, P.xn_id)[idx_in_neighbour];
+    if (nb == -1) return -c;
+    return x[idx_ghost];
+  };
+
+  int colour000 = 0;
+  if (MODE == MODE_GSRB) colour000 = (L.box_low[3 * box] ^ L.box_low[3 * box + 1] ^ L.box_low[3 * box + 2] ^ P.sweep) & 1;
+
+  int ia = i + ja * jS + k0 * kS;          // index of (i, ja, k); row b is ia + jS
+  d2 xc_a = ld2(x + ia), xc_b = ld2(x + ia + jS);
+  d2 xm_a = (gf && k0 == 0) ? outside2(4, i + ja * jS + last * kS, ia - kS, xc_a) : ld2(x + ia - kS);
+  d2 xm_b = (gf && k0 == 0) ? outside2(4, i + (ja + 1) * jS + last * kS, ia + jS - kS, xc_b) : ld2(x + ia + jS - kS);
+  d2 bk0_a = {0, 0}, bk0_b = {0, 0};
+  if (kVC) { bk0_a = ld2(beta_k + ia); bk0_b = ld2(beta_k + ia + jS); }
+
+  for (int k = k0; k < k1; k++, ia += kS) {
+    const int ib = ia + jS;
+    const d2 xp_a = (gf && k == last) ? outside2(5, i + ja * jS, ia + kS, xc_a) : ld2(x + ia + kS);
+    const d2 xp_b = (gf && k == last) ? outside2(5, i + (ja + 1) * jS, ib + kS, xc_b) : ld2(x + ib + kS);
+    d2 bk1_a = {0, 0}, bk1_b = {0, 0};
+    if (kVC) { bk1_a = ld2(beta_k + ia + kS); bk1_b = ld2(beta_k + ib + kS); }
+    // rows above and below the 2-row patch; the row between them is the partner row itself
+    const d2 xjm_a = (gf && ja == 0)        ? outside2(2, i + last * jS + k * kS, ia - jS, xc_a) : ld2(x + ia - jS);
+    const d2 xjp_b = (gf && ja + 1 == last) ? outside2(3, i + k * kS, ib + jS, xc_b)             : ld2(x + ib + jS);
+    // i neighbours of the pair: the cell left of .x and the cell right of .y
+    const double xl_a = (gf && i == 0)        ? outside1(0, last + ja * jS + k * kS, ia - 1, xc_a.x)       : x[ia - 1];
+    const double xl_b = (gf && i == 0)        ? outside1(0, last + (ja + 1) * jS + k * kS, ib - 1, xc_b.x) : x[ib - 1];
+    const double xr_a = (gf && i + 1 == last) ? outside1(1, ja * jS + k * kS, ia + 2, xc_a.y)              : x[ia + 2];
+    const double xr_b = (gf && i + 1 == last) ? outside1(1, (ja + 1) * jS + k * kS, ib + 2, xc_b.y)        : x[ib + 2];
+
+#define HPGMG_ROW(ROW, IDX, XC, XM, XP, XJM, XJP, XL, XR, BK0, BK1, JROW)                                                   \
+    {                                                                                                                        \
+      d2 bi = {0, 0}, bjl = {0, 0}, bjh = {0, 0}, al = {0, 0}; double bir = 0;                                               \
+      if (kVC) { bi = ld2(beta_i + IDX); bir = beta_i[IDX + 2]; bjl = ld2(beta_j + IDX); bjh = ld2(beta_j + IDX + jS); }     \
+      if (kHelm) al = ld2(alpha + IDX);                                                                                     \
+      if (MODE == MODE_GSRB) {                                                                                              \
+        const int pp = (JROW ^ k ^ colour000) & 1;              /* the cell of this pair whose colour is swept */           \
+        const double c = pp ? XC.y : XC.x;                                                                                  \
+        const double Ax = apply_op_7pt<V>(c, pp ? XC.x : XL, pp ? XR : XC.y, pp ? XJM.y : XJM.x, pp ? XJP.y : XJP.x,        \
+                                          pp ? XM.y : XM.x, pp ? XP.y : XP.x, pp ? bi.y : bi.x, pp ? bir : bi.y,            \
+                                          pp ? bjl.y : bjl.x, pp ? bjh.y : bjh.x, pp ? BK0.y : BK0.x, pp ? BK1.y : BK1.x,   \
+                                          pp ? al.y : al.x, P.a, P.b, P.h2inv);                                             \
+        const d2 r2 = ld2(rhs + IDX), dv = ld2(dinv + IDX);                                                                 \
+        const double xn = c + (pp ? dv.y : dv.x) * ((pp ? r2.y : r2.x) - Ax);                                              \
+        if (P.copy_other_colour) st2(out + IDX, pp ? d2{XC.x, xn} : d2{xn, XC.y}); else out[IDX + pp] = xn;                 \
+      } else {                                                                                                              \
+        const double Ax0 = apply_op_7pt<V>(XC.x, XL, XC.y, XJM.x, XJP.x, XM.x, XP.x, bi.x, bi.y, bjl.x, bjh.x, BK0.x, BK1.x, al.x, P.a, P.b, P.h2inv); \
+        const double Ax1 = apply_op_7pt<V>(XC.y, XC.x, XR, XJM.y, XJP.y, XM.y, XP.y, bi.y, bir, bjl.y, bjh.y, BK0.y, BK1.y, al.y, P.a, P.b, P.h2inv);  \
+        d2 o;                                                                                                               \
+        if (MODE == MODE_APPLY) { o.x = Ax0; o.y = Ax1; }                                                                   \
+        else {                                                                                                              \
+          const d2 r2 = ld2(rhs + IDX);                                                                                     \
+          if (MODE == MODE_RESIDUAL) { o.x = r2.x - Ax0; o.y = r2.y - Ax1; }                                                \
+          else {                                                                                                            \
+            const d2 dv = ld2(dinv + IDX);                                                                                  \
+            if (MODE == MODE_CHEBY) {                                                                                       \
+              const d2 old = ld2(out + IDX);                                                                                \
+              o.x = XC.x + P.c1 * (XC.x - old.x) + P.c2 * dv.x * (r2.x - Ax0);                                              \
+              o.y = XC.y + P.c1 * (XC.y - old.y) + P.c2 * dv.y * (r2.y - Ax1);                                              \
+            } else {                                                                                                        \
+              o.x = XC.x + P.c2 * dv.x * (r2.x - Ax0);                                                                      \
+              o.y = XC.y + P.c2 * dv.y * (r2.y - Ax1);                                                                      \
+            }                                                                                                               \
+          }                                                                                                                 \
+        }                                                                                                                   \
+        st2(out + IDX, o);                                                                                                  \
+      }                                                                                                                     \
+    }
+    HPGMG_ROW(a, ia, xc_a, xm_a, xp_a, xjm_a, xc_b, xl_a, xr_a, bk0_a, bk1_a, ja)
+    HPGMG_ROW(b, ib, xc_b, xm_b, xp_b, xc_a, xjp_b, xl_b, xr_b, bk0_b, bk1_b, (ja + 1))
+#undef HPGMG_ROW
+    xm_a = xc_a; xc_a = xp_a; bk0_a = bk1_a;
+    xm_b = xc_b; xc_b = xp_b; bk0_b = bk1_b;
+  }
+}
+
 // ---- smoother-kernel profiling: hipEvent pair around every smoother launch ----
 static bool g_profile = false;
 static long long g_profile_min_cells = 0;   // only launches covering at least this many cells are timed
@@ -158,11 +290,15 @@ static void profile_end(int p, long long cells) {
 
 static int g_ghost_free = 0;
 
+static int env_int(const char *name, int dflt) { const char *e = getenv(name); return (e && *e) ? atoi(e) : dflt; }
+
 static void plan(const hpgmg_hip_level *L, StencilArgs &P, dim3 &block, int &grid) {
+  static const int tune_ty = env_int("HPGMG_TUNE_TY", 0), tune_kchunk = env_int("HPGMG_TUNE_KCHUNK", 0);   // experiments only
   P.ghost_free = (g_ghost_free && L->box_nbr) ? 1 : 0;
   int tx = 64;
   while (tx > 1 && tx / 2 >= L->dim) tx /= 2;           // smallest power of two >= dim, capped at one wave
   int ty = 256 / tx;
+  if (tune_ty > 0 && tx == 64) ty = tune_ty;
   while (ty > 1 && ty / 2 >= L->dim) ty /= 2;
   block = dim3(tx, ty, 1);
   P.tiles_i = (L->dim + tx - 1) / tx;
@@ -170,6 +306,7 @@ static void plan(const hpgmg_hip_level *L, StencilArgs &P, dim3 &block, int &gri
   // k chunk: long enough to amortise the two start-up planes, short enough to expose >= ~8 blocks per CU
   int kchunk = L->dim;
   while (kchunk > 16 && (long long)L->num_boxes * P.tiles_i * P.tiles_j * ((L->dim + kchunk - 1) / kchunk) < 2048) kchunk /= 2;
+  if (tune_kchunk > 0 && L->dim >= tune_kchunk) kchunk = tune_kchunk;
   P.kchunk = kchunk;
   P.chunks_k = (L->dim + kchunk - 1) / kchunk;
   P.total_blocks = L->num_boxes * P.chunks_k * P.tiles_j * P.tiles_i;
@@ -184,6 +321,26 @@ static int launch(const hpgmg_hip_level *L, int variant, StencilArgs P, bool is_
   plan(L, P, block, grid);
   const long long cells = (long long)L->num_boxes * L->dim * L->dim * L->dim;
   int prof = is_smoother ? profile_begin(cells) : -1;
+  static const int no_wide = env_int("HPGMG_TUNE_NO_WIDE", 0);
+  // wide kernel: side a multiple of 128, 16-byte aligned interior rows (even strides; the box bases are checked by the host)
+  if (!no_wide && L->dim % 128 == 0 && L->jStride % 2 == 0 && L->kStride % 2 == 0 && L->volume % 2 == 0 && (L->flags & 1)) {
+    block = dim3(64, 4, 1);
+    P.tiles_i = L->dim / 128; P.tiles_j = L->dim / 8;
+    int kchunk = 16;
+    if (env_int("HPGMG_TUNE_KCHUNK", 0) > 0) kchunk = env_int("HPGMG_TUNE_KCHUNK", 0);
+    P.kchunk = kchunk; P.chunks_k = (L->dim + kchunk - 1) / kchunk;
+    P.total_blocks = L->num_boxes * P.chunks_k * P.tiles_j * P.tiles_i;
+    grid = grid_for(P.total_blocks, &P.per_xcd);
+    switch (variant) {
+      case HPGMG_HIP_7PT_VC_HELMHOLTZ: hipLaunchKernelGGL((stencil7_wide_kernel<HPGMG_HIP_7PT_VC_HELMHOLTZ, MODE>), dim3(grid), block, 0, g_stream, *L, P); break;
+      case HPGMG_HIP_7PT_VC_POISSON:   hipLaunchKernelGGL((stencil7_wide_kernel<HPGMG_HIP_7PT_VC_POISSON, MODE>), dim3(grid), block, 0, g_stream, *L, P); break;
+      case HPGMG_HIP_7PT_CC:           hipLaunchKernelGGL((stencil7_wide_kernel<HPGMG_HIP_7PT_CC, MODE>), dim3(grid), block, 0, g_stream, *L, P); break;
+      default: return record_error(hipErrorInvalidValue, "stencil variant not implemented");
+    }
+    profile_end(prof, cells);
+    HPGMG_LAUNCH_CHECK("stencil7_wide_kernel");
+    return 0;
+  }
   switch (variant) {
     case HPGMG_HIP_7PT_VC_HELMHOLTZ: hipLaunchKernelGGL((stencil7_kernel<HPGMG_HIP_7PT_VC_HELMHOLTZ, MODE>), dim3(grid), block, 0, g_stream, *L, P); break;
     case HPGMG_HIP_7PT_VC_POISSON:   hipLaunchKernelGGL((stencil7_kernel<HPGMG_HIP_7PT_VC_POISSON, MODE>), dim3(grid), block, 0, g_stream, *L, P); break;

@@ -33,6 +33,7 @@ typedef struct {
   int periodic;
   const int *box_nbr;      /* DEVICE array [6*num_boxes] or NULL: local index of the box across the -i,+i,-j,+j,-k,+k
                               face; -1 = homogeneous-Dirichlet domain face; -2 = box on another rank (use the ghost zone) */
+  int flags;               /* bit 0: the first interior cell of every box and vector is 16-byte aligned (enables 16-B loads) */
 } hpgmg_hip_level;
 
 /* stencil variants of apply_op_ijk (operators.7pt.c:49-89, operators.27pt.c:60-91, operators.fv4.c:55-134) */
