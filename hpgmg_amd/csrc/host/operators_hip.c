@@ -183,6 +183,7 @@ static int variant(void) {
   hpgmg_config c;
   hpgmg_get_config(&c);
   if (c.op == HPGMG_OP_7PT) return !c.variable_coeff ? HPGMG_HIP_7PT_CC : (c.helmholtz ? HPGMG_HIP_7PT_VC_HELMHOLTZ : HPGMG_HIP_7PT_VC_POISSON);
+  if (c.op == HPGMG_OP_27PT) return HPGMG_HIP_27PT_CC;
   fprintf(stderr, "hpgmg: operator %d has no HIP kernels yet\n", c.op);
   abort();
 }
@@ -251,12 +252,48 @@ void apply_BCs_p1(level_type *L, int x_id, int shape) {
   L->timers.boundary_conditions += now() - t0;
 }
 static void no_kernel(const char *what) { fprintf(stderr, "hpgmg: %s has no HIP kernel yet\n", what); abort(); }
-void apply_BCs_p2(level_type *L, int x_id, int shape) { (void)L; (void)x_id; (void)shape; no_kernel("apply_BCs_p2"); }
+void apply_BCs_p2(level_type *L, int x_id, int shape) {                                /* boundary_fd.c:93-205 */
+  if (shape >= STENCIL_MAX_SHAPES) shape = STENCIL_SHAPE_BOX;
+  if (L->boundary_condition.type == BC_PERIODIC) return;
+  if (L->box_dim < 2) { apply_BCs_p1(L, x_id, shape); return; }
+  const double t0 = now();
+  backend_t *B = backend_of(L);
+  const int n = L->boundary_condition.num_blocks[shape];
+  HIP_OK(hpgmg_hip_apply_bc_p2(&B->dev, x_id, mirror(L, L->boundary_condition.blocks[shape], n), n));
+  L->timers.boundary_conditions += now() - t0;
+}
 void apply_BCs_v1(level_type *L, int x_id, int shape) { (void)L; (void)x_id; (void)shape; no_kernel("apply_BCs_v1"); }
 void apply_BCs_v2(level_type *L, int x_id, int shape) { (void)L; (void)x_id; (void)shape; no_kernel("apply_BCs_v2"); }
 void apply_BCs_v4(level_type *L, int x_id, int shape) { (void)L; (void)x_id; (void)shape; no_kernel("apply_BCs_v4"); }
 void extrapolate_betas(level_type *L) { (void)L; no_kernel("extrapolate_betas"); }
-void rebuild_operator_blackbox(level_type *L, double a, double b, int c) { (void)L; (void)a; (void)b; (void)c; no_kernel("rebuild_operator_blackbox"); }
+static int variant(void);
+/* operators/rebuild.c:47-208: probe with colors^3 0/1 colourings (exchange + BCs each time), accumulate on the device */
+void rebuild_operator_blackbox(level_type *L, double a, double b, int colors) {
+  if (L->dim.i < colors) colors = L->dim.i;
+  if (L->dim.j < colors) colors = L->dim.j;
+  if (L->dim.k < colors) colors = L->dim.k;
+  if (L->my_rank == 0 && hpgmg_verbose) { fprintf(stdout, "  calculating D^{-1} exactly for level h=%e using %3d colors...  ", L->h, colors * colors * colors); fflush(stdout); }
+  const int x_id = VECTOR_TEMP, Aii_id = VECTOR_DINV, sum_id = (hpgmg_vectors_reserved() > VECTOR_L1INV) ? VECTOR_L1INV : VECTOR_E;
+  const double h2inv = 1.0 / (L->h * L->h);
+  int ic, jc, kc;
+  zero_vector(L, Aii_id);
+  zero_vector(L, sum_id);
+  for (kc = 0; kc < colors; kc++) for (jc = 0; jc < colors; jc++) for (ic = 0; ic < colors; ic++) {
+    color_vector(L, x_id, colors, ic, jc, kc);
+    exchange_boundary(L, x_id, stencil_get_shape());
+    apply_BCs(L, x_id, stencil_get_shape());
+    HIP_OK(hpgmg_hip_blackbox_accumulate(&backend_of(L)->dev, variant(), x_id, Aii_id, sum_id, a, b, h2inv));
+  }
+  double lambda = -1e9;
+  HIP_OK(hpgmg_hip_blackbox_finalize(&backend_of(L)->dev, Aii_id, sum_id, a, b, h2inv, &lambda));
+  if (L->my_rank == 0 && hpgmg_verbose) fprintf(stdout, "done\n");
+  { const hpgmg_transport *T = hpgmg_get_transport();
+    if (T && T->size > 1) { int r, *all = (int *)malloc((size_t)T->size * sizeof(int)); for (r = 0; r < T->size; r++) all[r] = r;
+      T->allreduce(T->ctx, &lambda, 1, HPGMG_REDUCE_MAX, all, T->size); free(all); } }
+  { hpgmg_config cfg; hpgmg_get_config(&cfg);
+    if (cfg.smoother == HPGMG_SMOOTH_CHEBY && L->my_rank == 0 && hpgmg_verbose) { fprintf(stdout, "  estimating  lambda_max... <%1.15e\n", lambda); fflush(stdout); } }
+  L->dominant_eigenvalue_of_DinvA = lambda;
+}
 void apply_BCs(level_type *L, int x_id, int shape) {
   hpgmg_config c;
   hpgmg_get_config(&c);
@@ -389,11 +426,18 @@ static void interpolation_lists(level_type *Lf, int id_f, double prescale, level
 }
 void interpolation_vcycle(level_type *Lf, int id_f, double prescale, level_type *Lc, int id_c) {
   hpgmg_config c; hpgmg_get_config(&c);
+  if (c.op == HPGMG_OP_27PT) {                                  /* interpolation_p2.c:228-230 */
+    exchange_boundary(Lc, id_c, STENCIL_SHAPE_BOX);
+    apply_BCs_p2(Lc, id_c, STENCIL_SHAPE_BOX);
+    interpolation_lists(Lf, id_f, prescale, Lc, id_c, 2, 0x7);
+    return;
+  }
   if (c.op != HPGMG_OP_7PT) no_kernel("interpolation_vcycle for this operator");
   interpolation_lists(Lf, id_f, prescale, Lc, id_c, 0, 0x6);
 }
 void interpolation_fcycle(level_type *Lf, int id_f, double prescale, level_type *Lc, int id_c) {
   hpgmg_config c; hpgmg_get_config(&c);
+  if (c.op == HPGMG_OP_27PT) { interpolation_vcycle(Lf, id_f, prescale, Lc, id_c); return; }   /* p2 for both, operators.27pt.c:150-151 */
   if (c.op != HPGMG_OP_7PT) no_kernel("interpolation_fcycle for this operator");
   exchange_boundary(Lc, id_c, STENCIL_SHAPE_BOX);
   apply_BCs_p1(Lc, id_c, STENCIL_SHAPE_BOX);
@@ -493,6 +537,21 @@ void initialize_problem(level_type *L, double h, double a, double b) {
 void rebuild_operator(level_type *L, level_type *from, double a, double b) {
   hpgmg_config cfg;
   hpgmg_get_config(&cfg);
+  if (cfg.op == HPGMG_OP_27PT) {                                /* operators.27pt.c:96-121 */
+    if (from) {
+      if (cfg.helmholtz) restriction(L, VECTOR_ALPHA, from, VECTOR_ALPHA, RESTRICT_CELL);
+      restriction(L, VECTOR_BETA_I, from, VECTOR_BETA_I, RESTRICT_FACE_I);
+      restriction(L, VECTOR_BETA_J, from, VECTOR_BETA_J, RESTRICT_FACE_J);
+      restriction(L, VECTOR_BETA_K, from, VECTOR_BETA_K, RESTRICT_FACE_K);
+    }
+    if (cfg.helmholtz) exchange_boundary(L, VECTOR_ALPHA, STENCIL_SHAPE_BOX);
+    exchange_boundary(L, VECTOR_BETA_I, STENCIL_SHAPE_BOX);
+    exchange_boundary(L, VECTOR_BETA_J, STENCIL_SHAPE_BOX);
+    exchange_boundary(L, VECTOR_BETA_K, STENCIL_SHAPE_BOX);
+    rebuild_operator_blackbox(L, a, b, 2);
+    exchange_boundary(L, VECTOR_DINV, STENCIL_SHAPE_BOX);
+    return;
+  }
   if (cfg.op != HPGMG_OP_7PT) no_kernel("rebuild_operator for this operator");
   if (L->my_rank == 0 && hpgmg_verbose) { fprintf(stdout, "  rebuilding operator for level...  h=%e  ", L->h); fflush(stdout); }
   if (from) {

@@ -224,6 +224,27 @@ __global__ __launch_bounds__(256) void rebuild7_kernel(const hpgmg_hip_level L, 
   block_max_store(best, partials);
 }
 
+// operators/rebuild.c:139-181: from the accumulated Aii and sum|Aij| form Dinv, L1inv and the Gershgorin bound
+__global__ __launch_bounds__(256) void blackbox_finalize_kernel(const hpgmg_hip_level L, int Aii_id, int sum_id, double a, double b, double h2inv, double *partials) {
+  RowIter r;
+  const int row = blockIdx.x * kRowsPerBlock + threadIdx.x / 64, lane = threadIdx.x % 64;
+  double best = -1e9;
+  if (row_of(row, L.dim, L.num_boxes, r)) {
+    const int base = r.j * L.jStride + r.k * L.kStride;
+    double *Aii = vec_origin(L, r.box, Aii_id) + base, *sumAbs = vec_origin(L, r.box, sum_id) + base;
+    for (int i = lane; i < L.dim; i += 64) {
+      double d = Aii[i];
+      if (d == 0.0) d = a + b * h2inv;                       // the reference's "FIX !!!" branch (rebuild.c:160-163)
+      const double sa = sumAbs[i];
+      const double Di = (d + sa) / d;
+      best = (Di > best) ? Di : best;
+      sumAbs[i] = (d >= 1.5 * sa) ? 1.0 / (d) : 1.0 / (d + 0.5 * sa);
+      Aii[i] = 1.0 / d;
+    }
+  }
+  block_max_store(best, partials);
+}
+
 // scratch for partial results + a pinned host word the final kernels write to
 static double *g_scratch = nullptr;  static int g_scratch_len = 0;
 static ResultSlot *g_result_dev = nullptr;   // pinned, device-visible host slot: kernels publish the scalar here directly
@@ -327,6 +348,18 @@ static int ordered_sum(const hpgmg_hip_level *L, int id_a, int id_b, double *out
 }
 int hpgmg_hip_dot(const hpgmg_hip_level *L, int id_a, int id_b, double *out) { return ordered_sum(L, id_a, id_b, out); }
 int hpgmg_hip_sum(const hpgmg_hip_level *L, int id, double *out) { return ordered_sum(L, id, -1, out); }
+
+int hpgmg_hip_blackbox_finalize(const hpgmg_hip_level *L, int Aii_id, int sumAbs_id, double a, double b, double h2inv, double *lambda_max_out) {
+  if (int e = hpgmg_hip_graph_flush()) return e;
+  *lambda_max_out = -1e9;
+  if (L->num_boxes <= 0) return 0;
+  const int nblk = rows_grid(L->num_boxes * L->dim * L->dim);
+  if (int e = ensure_scratch(nblk)) return e;
+  hipLaunchKernelGGL(blackbox_finalize_kernel, dim3(nblk), dim3(256), 0, g_stream, *L, Aii_id, sumAbs_id, a, b, h2inv, g_scratch);
+  hipLaunchKernelGGL(final_max_kernel, dim3(1), dim3(256), 0, g_stream, (const double *)g_scratch, nblk, -1e9, g_result_dev, ++g_seq);
+  HPGMG_LAUNCH_CHECK("blackbox_finalize");
+  return fetch_result(lambda_max_out);
+}
 
 int hpgmg_hip_rebuild_7pt(const hpgmg_hip_level *L, int variable_coeff, int alpha_id, int l1inv_id,
                           double a, double b, double h2inv, double *lambda_max_out) {

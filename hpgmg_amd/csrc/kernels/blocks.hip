@@ -61,6 +61,86 @@ __global__ __launch_bounds__(256) void bc_p1_kernel(const hpgmg_hip_level L, int
   }
 }
 
+// boundary_fd.c:93-205 apply_BCs_p2: quadratic extrapolation through a zero on the boundary face;
+// faces 2 terms, edges 4, corners 8 (decimal literals of the reference)
+__global__ __launch_bounds__(256) void bc_p2_kernel(const hpgmg_hip_level L, int id, const blockCopy_type *__restrict__ list) {
+  const blockCopy_type &e = list[blockIdx.x];
+  const int jS = L.jStride, kS = L.kStride, inward = 26 - e.subtype;
+  const int di = (inward % 3 - 1) * 1, dj = ((inward % 9) / 3 - 1) * jS, dk = (inward / 9 - 1) * kS;
+  const int kind = (di != 0) + (dj != 0) + (dk != 0);
+  double *x = vec_origin(L, e.read.box, id) + e.read.i + e.read.j * jS + e.read.k * kS;
+  const int ni = e.dim.i, nj = e.dim.j, n = ni * nj * e.dim.k;
+  int dr = 0, ds = 0;
+  if (di == 0) { dr = dj; ds = dk; }
+  if (dj == 0) { dr = di; ds = dk; }
+  if (dk == 0) { dr = di; ds = dj; }
+  for (int t = threadIdx.x; t < n; t += blockDim.x) {
+    const int i = t % ni, j = (t / ni) % nj, k = t / (ni * nj);
+    const int ijk = i + j * jS + k * kS;
+    double v;
+    if (kind == 1) {
+      const int s1 = di + dj + dk;
+      v = -2.0 * x[ijk + s1] + 0.333333333333333333 * x[ijk + 2 * s1];
+    } else if (kind == 2) {
+      v = 4.000000000000000000 * x[ijk + dr + ds] - 0.666666666666666667 * x[ijk + 2 * dr + ds];
+      v = v - 0.666666666666666667 * x[ijk + dr + 2 * ds];
+      v = v + 0.111111111111111111 * x[ijk + 2 * dr + 2 * ds];
+    } else {
+      v = -8.000000000000000000 * x[ijk + di + dj + dk] + 1.333333333333333333 * x[ijk + 2 * di + dj + dk];
+      v = v + 1.333333333333333333 * x[ijk + di + 2 * dj + dk];
+      v = v + 1.333333333333333333 * x[ijk + di + dj + 2 * dk];
+      v = v - 0.222222222222222222 * x[ijk + 2 * di + 2 * dj + dk];
+      v = v - 0.222222222222222222 * x[ijk + di + 2 * dj + 2 * dk];
+      v = v - 0.222222222222222222 * x[ijk + 2 * di + dj + 2 * dk];
+      v = v + 0.037037037037037037 * x[ijk + 2 * di + 2 * dj + 2 * dk];
+    }
+    x[ijk] = v;
+  }
+}
+
+// 1-D rules of the tensor-product interpolations (v[] = coarse line, centre at v[R]):
+//   order 2 = p2 interpolation_p2.c:90-92,150-205;  order 3 = v2 interpolation_v2.c:111-113;  order 4 = v4 interpolation_v4.c:96-97,180-240
+template <int ORDER>
+__device__ __forceinline__ double interp_rule(bool odd, const double *v) {
+  if (ORDER == 2) {
+    const double w0 = 5.0 / 32.0, w1 = 30.0 / 32.0, w2 = -3.0 / 32.0;
+    return odd ? (w1 * v[1] + w2 * v[0] + w0 * v[2]) : (w1 * v[1] + w0 * v[0] + w2 * v[2]);
+  } else if (ORDER == 3) {
+    const double c1 = 1.0 / 8.0;
+    return odd ? (v[1] - c1 * (v[0] - v[2])) : (v[1] + c1 * (v[0] - v[2]));
+  } else {
+    const double c1 = 22.0 / 128.0, c2 = -3.0 / 128.0;
+    return odd ? (v[2] - c1 * (v[1] - v[3]) - c2 * (v[0] - v[4])) : (v[2] + c1 * (v[1] - v[3]) + c2 * (v[0] - v[4]));
+  }
+}
+// dimension by dimension (i, then j, then k), one fine cell per lane: the same intermediate values
+// f?c??, f??c?, f??? the reference forms for the 8 children of a coarse cell
+template <int ORDER>
+__global__ __launch_bounds__(256) void interp_tensor_kernel(const hpgmg_hip_level Lf, int id_f, double prescale, const hpgmg_hip_level Lc, int id_c,
+                                                            const blockCopy_type *__restrict__ list) {
+  constexpr int R = (ORDER == 4) ? 2 : 1, W = 2 * R + 1;
+  const blockCopy_type &e = list[blockIdx.x];
+  const Side r = resolve_read(Lc, id_c, e), w = resolve_write(Lf, id_f, e);
+  const int di = 2 * e.dim.i, dj = 2 * e.dim.j, n = di * dj * 2 * e.dim.k, rj = r.jS, rk = r.kS;
+  for (int t = threadIdx.x; t < n; t += blockDim.x) {
+    const int i = t % di, j = (t / di) % dj, k = t / (di * dj);
+    const double *c = r.p + (i >> 1) + (j >> 1) * rj + (k >> 1) * rk;
+    double line[W], tj[W], tk[W];
+#pragma unroll
+    for (int kk = 0; kk < W; kk++) {
+#pragma unroll
+      for (int jj = 0; jj < W; jj++) {
+#pragma unroll
+        for (int ii = 0; ii < W; ii++) line[ii] = c[(ii - R) + (jj - R) * rj + (kk - R) * rk];
+        tj[jj] = interp_rule<ORDER>(i & 1, line);
+      }
+      tk[kk] = interp_rule<ORDER>(j & 1, tj);
+    }
+    double *fw = &w.p[i + j * w.jS + k * w.kS];
+    *fw = prescale * (*fw) + interp_rule<ORDER>(k & 1, tk);
+  }
+}
+
 template <int TYPE>
 __global__ __launch_bounds__(256) void restrict_blocks_kernel(const hpgmg_hip_level Lc, int id_c, const hpgmg_hip_level Lf, int id_f,
                                                               const blockCopy_type *__restrict__ list) {
@@ -139,6 +219,13 @@ int hpgmg_hip_apply_bc_p1(const hpgmg_hip_level *L, int id, const blockCopy_type
   HPGMG_LAUNCH_CHECK("bc_p1_kernel");
   return 0;
 }
+int hpgmg_hip_apply_bc_p2(const hpgmg_hip_level *L, int id, const blockCopy_type *blocks, int n) {
+  HPGMG_SKIP_IF_REPLAY();
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(bc_p2_kernel, dim3(n), dim3(256), 0, g_stream, *L, id, blocks);
+  HPGMG_LAUNCH_CHECK("bc_p2_kernel");
+  return 0;
+}
 int hpgmg_hip_restrict_blocks(const hpgmg_hip_level *Lc, int id_c, const hpgmg_hip_level *Lf, int id_f,
                               const blockCopy_type *blocks, int n, int type) {
   HPGMG_SKIP_IF_REPLAY();
@@ -159,6 +246,9 @@ int hpgmg_hip_interpolate_blocks(const hpgmg_hip_level *Lf, int id_f, double pre
   if (n <= 0) return 0;
   if (order == 0) hipLaunchKernelGGL((interp_blocks_kernel<0>), dim3(n), dim3(256), 0, g_stream, *Lf, id_f, prescale, *Lc, id_c, blocks);
   else if (order == 1) hipLaunchKernelGGL((interp_blocks_kernel<1>), dim3(n), dim3(256), 0, g_stream, *Lf, id_f, prescale, *Lc, id_c, blocks);
+  else if (order == 2) hipLaunchKernelGGL((interp_tensor_kernel<2>), dim3(n), dim3(256), 0, g_stream, *Lf, id_f, prescale, *Lc, id_c, blocks);
+  else if (order == 3) hipLaunchKernelGGL((interp_tensor_kernel<3>), dim3(n), dim3(256), 0, g_stream, *Lf, id_f, prescale, *Lc, id_c, blocks);
+  else if (order == 4) hipLaunchKernelGGL((interp_tensor_kernel<4>), dim3(n), dim3(256), 0, g_stream, *Lf, id_f, prescale, *Lc, id_c, blocks);
   else return record_error(hipErrorInvalidValue, "interpolation order");
   HPGMG_LAUNCH_CHECK("interp_blocks_kernel");
   return 0;

@@ -25,7 +25,7 @@
 
 namespace hpgmg {
 
-enum { MODE_CHEBY = 0, MODE_GSRB = 1, MODE_JACOBI = 2, MODE_RESIDUAL = 3, MODE_APPLY = 4 };
+enum { MODE_CHEBY = 0, MODE_GSRB = 1, MODE_JACOBI = 2, MODE_RESIDUAL = 3, MODE_APPLY = 4, MODE_BLACKBOX = 5 };
 
 struct StencilArgs {
   int xn_id, xout_id, rhs_id;   // xout = x_np1 (smoothers) or res/Ax
@@ -256,6 +256,86 @@ __global__ __launch_bounds__(256) void stencil7_wide_kernel(const hpgmg_hip_leve
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// 27-point constant-coefficient operator (reference operators.27pt.c:48-51,60-91).
+// One lane per (i,j) column marching in +k with the three 3x3 planes around the cell held in
+// registers (27 values, 9 new loads per step instead of 27); streams: x, x_nm1, rhs, Dinv =
+// 40 B per cell for Chebyshev.  The weighted partial sums are formed in the reference's order:
+// ((C3*corners + C2*edges) + C1*faces) + C0*centre, each group summed left to right as listed.
+// MODE_BLACKBOX is the probe of operators/rebuild.c:126-132 (out = Aii, rhs slot = sum|Aij|).
+#define C27_0 (-4.2666666666666666666)
+#define C27_1 ( 0.4666666666666666666)
+#define C27_2 ( 0.1000000000000000000)
+#define C27_3 ( 0.0333333333333333333)
+struct plane9 { double v[3][3]; };   // [dj+1][di+1]
+__device__ __forceinline__ plane9 load_plane(const double *p, int jS) {
+  plane9 q;
+#pragma unroll
+  for (int jj = 0; jj < 3; jj++) {
+#pragma unroll
+    for (int ii = 0; ii < 3; ii++) q.v[jj][ii] = p[(ii - 1) + (jj - 1) * jS];
+  }
+  return q;
+}
+__device__ __forceinline__ double apply_op_27pt(const plane9 &m, const plane9 &c, const plane9 &p, double a, double b, double h2inv) {
+  double s8 = m.v[0][0] + m.v[0][2]; s8 = s8 + m.v[2][0]; s8 = s8 + m.v[2][2];
+  s8 = s8 + p.v[0][0]; s8 = s8 + p.v[0][2]; s8 = s8 + p.v[2][0]; s8 = s8 + p.v[2][2];
+  double s12 = m.v[0][1] + m.v[1][0]; s12 = s12 + m.v[1][2]; s12 = s12 + m.v[2][1];
+  s12 = s12 + c.v[0][0]; s12 = s12 + c.v[0][2]; s12 = s12 + c.v[2][0]; s12 = s12 + c.v[2][2];
+  s12 = s12 + p.v[0][1]; s12 = s12 + p.v[1][0]; s12 = s12 + p.v[1][2]; s12 = s12 + p.v[2][1];
+  double s6 = m.v[1][1] + c.v[0][1]; s6 = s6 + c.v[1][0]; s6 = s6 + c.v[1][2]; s6 = s6 + c.v[2][1]; s6 = s6 + p.v[1][1];
+  double t = C27_3 * s8 + C27_2 * s12;
+  t = t + C27_1 * s6;
+  t = t + C27_0 * c.v[1][1];
+  return a * c.v[1][1] - (b * h2inv) * t;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void stencil27_kernel(const hpgmg_hip_level L, const StencilArgs P) {
+  const int logical = xcd_logical_block((int)blockIdx.x, P.per_xcd);
+  if (logical >= P.total_blocks) return;
+  int t = logical;
+  const int ti = t % P.tiles_i; t /= P.tiles_i;
+  const int tj = t % P.tiles_j; t /= P.tiles_j;
+  const int ck = t % P.chunks_k; t /= P.chunks_k;
+  const int box = t;
+  const int i = ti * (int)blockDim.x + (int)threadIdx.x;
+  const int j = tj * (int)blockDim.y + (int)threadIdx.y;
+  if (i >= L.dim || j >= L.dim) return;
+  const int k0 = ck * P.kchunk, k1 = (k0 + P.kchunk < L.dim) ? k0 + P.kchunk : L.dim;
+  const int jS = L.jStride, kS = L.kStride;
+  constexpr bool kSmooth = (MODE == MODE_CHEBY || MODE == MODE_GSRB || MODE == MODE_JACOBI);
+
+  const double *__restrict__ x = vec_origin(L, box, P.xn_id);      // 27-pt GSRB is always out of place
+  double *__restrict__ out = vec_origin(L, box, P.xout_id);
+  double *rhs = (MODE == MODE_APPLY) ? nullptr : vec_origin(L, box, P.rhs_id);   // BLACKBOX: the sum|Aij| accumulator
+  const double *__restrict__ dinv = kSmooth ? vec_origin(L, box, VECTOR_DINV) : nullptr;
+  int colour000 = 0;
+  if (MODE == MODE_GSRB) colour000 = (L.box_low[3 * box] ^ L.box_low[3 * box + 1] ^ L.box_low[3 * box + 2] ^ P.sweep) & 1;
+
+  int ijk = i + j * jS + k0 * kS;
+  plane9 m = load_plane(x + ijk - kS, jS), c = load_plane(x + ijk, jS);
+  for (int k = k0; k < k1; k++, ijk += kS) {
+    const plane9 p = load_plane(x + ijk + kS, jS);
+    const double xc = c.v[1][1];
+    bool update = true;
+    if (MODE == MODE_GSRB) update = (((i ^ j ^ k ^ colour000) & 1) == 0);
+    if (update) {
+      const double Ax = apply_op_27pt(m, c, p, P.a, P.b, P.h2inv);
+      if (MODE == MODE_CHEBY)         { const double xnm1 = out[ijk]; out[ijk] = xc + P.c1 * (xc - xnm1) + P.c2 * dinv[ijk] * (rhs[ijk] - Ax); }
+      else if (MODE == MODE_GSRB)     { out[ijk] = xc + dinv[ijk] * (rhs[ijk] - Ax); }
+      else if (MODE == MODE_JACOBI)   { out[ijk] = xc + P.c2 * dinv[ijk] * (rhs[ijk] - Ax); }
+      else if (MODE == MODE_RESIDUAL) { out[ijk] = rhs[ijk] - Ax; }
+      else if (MODE == MODE_APPLY)    { out[ijk] = Ax; }
+      else { out[ijk] += (xc) * Ax; rhs[ijk] += fabs((1.0 - xc) * Ax); }
+    } else {
+      out[ijk] = xc;   // out-of-place GSRB copies the other colour (gsrb.c:94-98)
+    }
+    m = c; c = p;
+  }
+}
+
 // ---- smoother-kernel profiling: hipEvent pair around every smoother launch ----
 static bool g_profile = false;
 static long long g_profile_min_cells = 0;   // only launches covering at least this many cells are timed
@@ -314,9 +394,24 @@ static void plan(const hpgmg_hip_level *L, StencilArgs &P, dim3 &block, int &gri
 }
 
 template <int MODE>
+static int launch27(const hpgmg_hip_level *L, StencilArgs P, bool is_smoother) {
+  HPGMG_SKIP_IF_REPLAY();
+  if (L->num_boxes <= 0) return 0;
+  dim3 block; int grid;
+  plan(L, P, block, grid);
+  const long long cells = (long long)L->num_boxes * L->dim * L->dim * L->dim;
+  int prof = is_smoother ? profile_begin(cells) : -1;
+  hipLaunchKernelGGL((stencil27_kernel<MODE>), dim3(grid), block, 0, g_stream, *L, P);
+  profile_end(prof, cells);
+  HPGMG_LAUNCH_CHECK("stencil27_kernel");
+  return 0;
+}
+
+template <int MODE>
 static int launch(const hpgmg_hip_level *L, int variant, StencilArgs P, bool is_smoother) {
   HPGMG_SKIP_IF_REPLAY();
   if (L->num_boxes <= 0) return 0;
+  if (variant == HPGMG_HIP_27PT_CC) return launch27<MODE>(L, P, is_smoother);
   dim3 block; int grid;
   plan(L, P, block, grid);
   const long long cells = (long long)L->num_boxes * L->dim * L->dim * L->dim;
@@ -388,6 +483,11 @@ int hpgmg_hip_smooth_jacobi(const hpgmg_hip_level *L, int variant, int xn_id, in
                             double a, double b, double h2inv, double weight) {
   StencilArgs P = {}; P.xn_id = xn_id; P.xout_id = xnp1_id; P.rhs_id = rhs_id; P.a = a; P.b = b; P.h2inv = h2inv; P.c2 = weight;
   return launch<MODE_JACOBI>(L, variant, P, true);
+}
+int hpgmg_hip_blackbox_accumulate(const hpgmg_hip_level *L, int variant, int x_id, int Aii_id, int sumAbs_id, double a, double b, double h2inv) {
+  StencilArgs P = {}; P.xn_id = x_id; P.xout_id = Aii_id; P.rhs_id = sumAbs_id; P.a = a; P.b = b; P.h2inv = h2inv;
+  if (variant == HPGMG_HIP_27PT_CC) return launch27<MODE_BLACKBOX>(L, P, false);
+  return record_error(hipErrorInvalidValue, "blackbox probe: variant not implemented");
 }
 int hpgmg_hip_residual(const hpgmg_hip_level *L, int variant, int res_id, int x_id, int rhs_id, double a, double b, double h2inv) {
   StencilArgs P = {}; P.xn_id = x_id; P.xout_id = res_id; P.rhs_id = rhs_id; P.a = a; P.b = b; P.h2inv = h2inv;

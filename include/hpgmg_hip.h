@@ -94,10 +94,13 @@ int hpgmg_hip_copy_blocks(const hpgmg_hip_level *L, int id, const blockCopy_type
 int hpgmg_hip_increment_blocks(const hpgmg_hip_level *L, int id, double prescale, const blockCopy_type *blocks, int num_blocks);
 /* operators/boundary_fd.c:6-90 apply_BCs_p1 */
 int hpgmg_hip_apply_bc_p1(const hpgmg_hip_level *L, int id, const blockCopy_type *blocks, int num_blocks);
+/* operators/boundary_fd.c:93-205 apply_BCs_p2 */
+int hpgmg_hip_apply_bc_p2(const hpgmg_hip_level *L, int id, const blockCopy_type *blocks, int num_blocks);
 /* operators/restriction.c:6-94 restriction_pc_block over a list; type = RESTRICT_* */
 int hpgmg_hip_restrict_blocks(const hpgmg_hip_level *Lc, int id_c, const hpgmg_hip_level *Lf, int id_f,
                               const blockCopy_type *blocks, int num_blocks, int type);
-/* operators/interpolation_p0.c:6-46 (order 0) and interpolation_p1.c:8-65 (order 1) over a list */
+/* operators/interpolation_p0.c:6-46 (order 0), interpolation_p1.c:8-65 (order 1), and the tensor-product
+ * interpolation_p2.c (order 2), interpolation_v2.c (order 3), interpolation_v4.c (order 4) over a list */
 int hpgmg_hip_interpolate_blocks(const hpgmg_hip_level *Lf, int id_f, double prescale, const hpgmg_hip_level *Lc, int id_c,
                                  const blockCopy_type *blocks, int num_blocks, int order);
 
@@ -116,6 +119,11 @@ int hpgmg_hip_random(const hpgmg_hip_level *L, int id);                         
 int hpgmg_hip_norm_max(const hpgmg_hip_level *L, int id, double *out);                /* norm :287 */
 int hpgmg_hip_dot(const hpgmg_hip_level *L, int id_a, int id_b, double *out);         /* dot :239 */
 int hpgmg_hip_sum(const hpgmg_hip_level *L, int id, double *out);                     /* mean :336 (before the divide) */
+
+/* ---- operators/rebuild.c:47-208 black-box rebuild: accumulate one colouring (x = 0/1 pattern, ghosts
+ *      already exchanged / BCs applied) into Aii and sum|Aij|, then turn them into Dinv, L1inv, lambda_max ---- */
+int hpgmg_hip_blackbox_accumulate(const hpgmg_hip_level *L, int variant, int x_id, int Aii_id, int sumAbs_id, double a, double b, double h2inv);
+int hpgmg_hip_blackbox_finalize(const hpgmg_hip_level *L, int Aii_id, int sumAbs_id, double a, double b, double h2inv, double *lambda_max_out);
 
 /* ---- operators.7pt.c:158-227: Dinv (+L1inv when l1inv_id >= 0) and the Gershgorin bound of lambda_max(D^-1 A) ---- */
 int hpgmg_hip_rebuild_7pt(const hpgmg_hip_level *L, int variable_coeff, int alpha_id, int l1inv_id,

@@ -38,9 +38,10 @@ def run(variant, args):
     err = re.search(r"\|\|error\|\|=(\S+)", out).group(1)
     order = re.search(r"order=(\S+)", out).group(1)
     eig = re.findall(r"eigenvalue_max<(\S+)", out)
+    lam = re.findall(r"lambda_max\.\.\. <(\S+)", out)          # black-box rebuild (27pt, fv2, fv4 with Chebyshev)
     levels = re.findall(r"attempting to create a (\d+)\^3 level from (\d+) x (\d+)\^3 boxes", out)
     return {"norms": [n for n, _ in last3], "rels": [r for _, r in last3], "richardson_error": err, "order": order,
-            "eigenvalue_max": eig, "levels": [[int(a), int(b), int(c)] for a, b, c in levels]}
+            "eigenvalue_max": eig, "lambda_max": lam, "levels": [[int(a), int(b), int(c)] for a, b, c in levels]}
 def main():
     gold = {"_generated_by": "tests/golden/make_golden.py from oracle/_ref/hpgmg-* (reference built by oracle/Makefile: gcc -O2 -fopenmp, no MPI)"}
     for v, arglist in CASES.items():

@@ -28,7 +28,7 @@ def pinned_lines(binary, args):
     out = subprocess.run([binary] + args.split(), capture_output=True, text=True, env=env, check=True).stdout
     keep = []
     for line in out.splitlines():
-        m = re.search(r"(f-cycle\s+norm=\S+\s+rel=\S+|\|\|error\|\|=\S+|order=\S+|eigenvalue_max<\S+|attempting to create.*)", line)
+        m = re.search(r"(f-cycle\s+norm=\S+\s+rel=\S+|\|\|error\|\|=\S+|order=\S+|eigenvalue_max<\S+|lambda_max\.\.\. <\S+|attempting to create.*)", line)
         if m:
             keep.append(m.group(1))
     return keep
@@ -40,7 +40,7 @@ def test_level_type_layout_matches_reference(ref_build):
     assert a == b and "sizeof(level_type)" in a
 
 
-@pytest.mark.parametrize("variant", ["7pt-cheby", "7pt-gsrb", "7pt-cheby-helm", "7ptcc-cheby", "7pt-jacobi"])
+@pytest.mark.parametrize("variant", ["7pt-cheby", "7pt-gsrb", "7pt-cheby-helm", "7ptcc-cheby", "7pt-jacobi", "27pt-cheby", "27pt-gsrb", "fv4-gsrb", "fv4-cheby", "fv2-cheby"])
 @pytest.mark.parametrize("args", ["4 8", "5 8"])
 def test_reference_driver_with_our_operators_prints_reference_numbers(ref_build, variant, args):
     ref = pinned_lines(os.path.join(ref_build, "hpgmg-" + variant), args)
