@@ -182,8 +182,10 @@ void hpgmg_level_release(level_type *L) {
 static int variant(void) {
   hpgmg_config c;
   hpgmg_get_config(&c);
-  if (c.op == HPGMG_OP_7PT) return !c.variable_coeff ? HPGMG_HIP_7PT_CC : (c.helmholtz ? HPGMG_HIP_7PT_VC_HELMHOLTZ : HPGMG_HIP_7PT_VC_POISSON);
+  if (c.op == HPGMG_OP_7PT || c.op == HPGMG_OP_FV2)   /* operators.fv2.c: the 7-pt stencil with finite-volume BCs/interpolation */
+    return !c.variable_coeff ? HPGMG_HIP_7PT_CC : (c.helmholtz ? HPGMG_HIP_7PT_VC_HELMHOLTZ : HPGMG_HIP_7PT_VC_POISSON);
   if (c.op == HPGMG_OP_27PT) return HPGMG_HIP_27PT_CC;
+  if (c.op == HPGMG_OP_FV4 && c.variable_coeff) return c.helmholtz ? HPGMG_HIP_FV4_VC_HELMHOLTZ : HPGMG_HIP_FV4_VC_POISSON;
   fprintf(stderr, "hpgmg: operator %d has no HIP kernels yet\n", c.op);
   abort();
 }
@@ -225,7 +227,9 @@ static void ghosts_for_stencil(level_type *L, int id) {
   const int shape = stencil_get_shape();
   hpgmg_config c;
   hpgmg_get_config(&c);
-  if (ghost_free_mode() && c.op == HPGMG_OP_7PT && shape == STENCIL_SHAPE_STAR) {
+  const int fuse = ghost_free_mode() && c.op == HPGMG_OP_7PT && shape == STENCIL_SHAPE_STAR;
+  hpgmg_hip_set_ghost_free(fuse);   /* the in-kernel -x(centre) rule IS apply_BCs_p1; other plugins (fv2: v2 BCs) need real ghosts */
+  if (fuse) {
     communicator_type *C = &L->exchange_ghosts[shape];
     if (C->num_sends + C->num_recvs > 0) {
       const double t0 = now();
@@ -262,10 +266,33 @@ void apply_BCs_p2(level_type *L, int x_id, int shape) {                         
   HIP_OK(hpgmg_hip_apply_bc_p2(&B->dev, x_id, mirror(L, L->boundary_condition.blocks[shape], n), n));
   L->timers.boundary_conditions += now() - t0;
 }
-void apply_BCs_v1(level_type *L, int x_id, int shape) { (void)L; (void)x_id; (void)shape; no_kernel("apply_BCs_v1"); }
-void apply_BCs_v2(level_type *L, int x_id, int shape) { (void)L; (void)x_id; (void)shape; no_kernel("apply_BCs_v2"); }
-void apply_BCs_v4(level_type *L, int x_id, int shape) { (void)L; (void)x_id; (void)shape; no_kernel("apply_BCs_v4"); }
-void extrapolate_betas(level_type *L) { (void)L; no_kernel("extrapolate_betas"); }
+void apply_BCs_v1(level_type *L, int x_id, int shape) { apply_BCs_p1(L, x_id, shape); }   /* boundary_fv.c:6-90: same one-point formula */
+void apply_BCs_v2(level_type *L, int x_id, int shape) {                                   /* boundary_fv.c:101-250 */
+  if (shape >= STENCIL_MAX_SHAPES) shape = STENCIL_SHAPE_BOX;
+  if (L->boundary_condition.type == BC_PERIODIC) return;
+  if (L->box_dim < 2) { apply_BCs_v1(L, x_id, shape); return; }
+  const double t0 = now();
+  const int n = L->boundary_condition.num_blocks[shape];
+  HIP_OK(hpgmg_hip_apply_bc_v2(&backend_of(L)->dev, x_id, mirror(L, L->boundary_condition.blocks[shape], n), n));
+  L->timers.boundary_conditions += now() - t0;
+}
+void apply_BCs_v4(level_type *L, int x_id, int shape) {                                   /* boundary_fv.c:262-569 */
+  if (shape >= STENCIL_MAX_SHAPES) shape = STENCIL_SHAPE_BOX;
+  if (L->boundary_condition.type == BC_PERIODIC) return;
+  if (L->box_ghosts < 2) { fprintf(stderr, "called quartic BC's with only 1 ghost zone!!!\n"); abort(); }
+  if (L->box_dim < 4) { apply_BCs_v2(L, x_id, shape); return; }
+  const double t0 = now();
+  const int n = L->boundary_condition.num_blocks[shape];
+  HIP_OK(hpgmg_hip_apply_bc_v4(&backend_of(L)->dev, x_id, mirror(L, L->boundary_condition.blocks[shape], n), n));
+  L->timers.boundary_conditions += now() - t0;
+}
+void extrapolate_betas(level_type *L) {                                                    /* boundary_fv.c:573-681 */
+  if (L->boundary_condition.type == BC_PERIODIC) return;
+  const double t0 = now();
+  const int n = L->boundary_condition.num_blocks[STENCIL_SHAPE_BOX];
+  HIP_OK(hpgmg_hip_extrapolate_betas(&backend_of(L)->dev, mirror(L, L->boundary_condition.blocks[STENCIL_SHAPE_BOX], n), n));
+  L->timers.boundary_conditions += now() - t0;
+}
 static int variant(void);
 /* operators/rebuild.c:47-208: probe with colors^3 0/1 colourings (exchange + BCs each time), accumulate on the device */
 void rebuild_operator_blackbox(level_type *L, double a, double b, int colors) {
@@ -432,12 +459,24 @@ void interpolation_vcycle(level_type *Lf, int id_f, double prescale, level_type 
     interpolation_lists(Lf, id_f, prescale, Lc, id_c, 2, 0x7);
     return;
   }
+  if (c.op == HPGMG_OP_FV2 || c.op == HPGMG_OP_FV4) {           /* interpolation_v2.c:210-212 (V-cycle of fv2 and fv4) */
+    exchange_boundary(Lc, id_c, STENCIL_SHAPE_BOX);
+    apply_BCs_v2(Lc, id_c, STENCIL_SHAPE_BOX);
+    interpolation_lists(Lf, id_f, prescale, Lc, id_c, 3, 0x7);
+    return;
+  }
   if (c.op != HPGMG_OP_7PT) no_kernel("interpolation_vcycle for this operator");
   interpolation_lists(Lf, id_f, prescale, Lc, id_c, 0, 0x6);
 }
 void interpolation_fcycle(level_type *Lf, int id_f, double prescale, level_type *Lc, int id_c) {
   hpgmg_config c; hpgmg_get_config(&c);
-  if (c.op == HPGMG_OP_27PT) { interpolation_vcycle(Lf, id_f, prescale, Lc, id_c); return; }   /* p2 for both, operators.27pt.c:150-151 */
+  if (c.op == HPGMG_OP_27PT || c.op == HPGMG_OP_FV2) { interpolation_vcycle(Lf, id_f, prescale, Lc, id_c); return; } /* operators.27pt.c:150-151, .fv2.c:151-152 */
+  if (c.op == HPGMG_OP_FV4) {                                   /* interpolation_v4.c:276-278 */
+    exchange_boundary(Lc, id_c, STENCIL_SHAPE_BOX);
+    apply_BCs_v4(Lc, id_c, STENCIL_SHAPE_BOX);
+    interpolation_lists(Lf, id_f, prescale, Lc, id_c, 4, 0x7);
+    return;
+  }
   if (c.op != HPGMG_OP_7PT) no_kernel("interpolation_fcycle for this operator");
   exchange_boundary(Lc, id_c, STENCIL_SHAPE_BOX);
   apply_BCs_p1(Lc, id_c, STENCIL_SHAPE_BOX);
@@ -494,10 +533,67 @@ static void eval_poly(double t, double shift, double *P, double *Pt, double *Ptt
   *Pt  = 12.0 * pow(t, 5) -  30.0 * pow(t, 4) + 20.0 * pow(t, 3) - 2.0 * t;
   *Ptt = 60.0 * pow(t, 4) - 120.0 * pow(t, 3) + 60.0 * pow(t, 2) - 2.0;
 }
+/* problem.fv.c:9-28,71-87,90-140: 4th-order cell/face averages = point value + h^2/24 * second derivatives */
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+static double fv_beta(double x, double y, double z, double h, int add_Bxx, int add_Byy, int add_Bzz) {
+  const double b = 0.25, a = 2.0 * M_PI;
+  double B   = 1.0 + b * sin(a * x) * sin(a * y) * sin(a * z);
+  double Bxx = -a * a * b * sin(a * x) * sin(a * y) * sin(a * z);
+  double Byy = -a * a * b * sin(a * x) * sin(a * y) * sin(a * z);
+  double Bzz = -a * a * b * sin(a * x) * sin(a * y) * sin(a * z);
+  if (add_Bxx) B += (h * h / 24.0) * Bxx;
+  if (add_Byy) B += (h * h / 24.0) * Byy;
+  if (add_Bzz) B += (h * h / 24.0) * Bzz;
+  return B;
+}
+static double fv_F(double x, double y, double z, double h) {
+  const double a = 2.0 * M_PI, p = 7.0;
+  double F   = pow(sin(a * x), p) * pow(sin(a * y), p) * pow(sin(a * z), p);
+  double Fxx = -a * a * p * pow(sin(a * x), p) * pow(sin(a * y), p) * pow(sin(a * z), p) + a * a * p * (p - 1) * pow(sin(a * x), p - 2) * pow(sin(a * y), p) * pow(sin(a * z), p) * pow(cos(a * x), 2);
+  double Fyy = -a * a * p * pow(sin(a * x), p) * pow(sin(a * y), p) * pow(sin(a * z), p) + a * a * p * (p - 1) * pow(sin(a * x), p) * pow(sin(a * y), p - 2) * pow(sin(a * z), p) * pow(cos(a * y), 2);
+  double Fzz = -a * a * p * pow(sin(a * x), p) * pow(sin(a * y), p) * pow(sin(a * z), p) + a * a * p * (p - 1) * pow(sin(a * x), p) * pow(sin(a * y), p) * pow(sin(a * z), p - 2) * pow(cos(a * z), 2);
+  F += (h * h / 24.0) * Fxx;
+  F += (h * h / 24.0) * Fyy;
+  F += (h * h / 24.0) * Fzz;
+  return F;
+}
+static void initialize_problem_fv(level_type *L, double h, const hpgmg_config *cfg) {
+  L->h = h;
+  const int jS = L->box_jStride, kS = L->box_kStride, g = L->box_ghosts, dim = L->box_dim;
+  const size_t vol = (size_t)L->box_volume;
+  double *stage = (double *)calloc(5 * vol, sizeof(double));
+  int box, i, j, k;
+  for (box = 0; box < L->num_my_boxes; box++) {
+    const box_type *B = &L->my_boxes[box];
+    memset(stage, 0, 5 * vol * sizeof(double));
+    #pragma omp parallel for private(k, j, i) collapse(2)
+    for (k = 0; k <= dim; k++) for (j = 0; j <= dim; j++) for (i = 0; i <= dim; i++) {
+      const size_t ijk = (size_t)(i + g) + (size_t)(j + g) * jS + (size_t)(k + g) * kS;
+      const double x = h * ((double)(i + B->low.i) + 0.5), y = h * ((double)(j + B->low.j) + 0.5), z = h * ((double)(k + B->low.k) + 0.5);
+      double Bi = 1.0, Bj = 1.0, Bk = 1.0;
+      if (cfg->variable_coeff) {
+        Bi = fv_beta(x - h * 0.5, y, z, h, 0, 1, 1);
+        Bj = fv_beta(x, y - h * 0.5, z, h, 1, 0, 1);
+        Bk = fv_beta(x, y, z - h * 0.5, h, 1, 1, 0);
+      }
+      stage[0 * vol + ijk] = Bi; stage[1 * vol + ijk] = Bj; stage[2 * vol + ijk] = Bk; stage[3 * vol + ijk] = 1.0;
+      stage[4 * vol + ijk] = fv_F(x, y, z, h);
+    }
+    hpgmg_vector_upload(B->vectors[VECTOR_BETA_I], stage + 0 * vol, vol);
+    hpgmg_vector_upload(B->vectors[VECTOR_BETA_J], stage + 1 * vol, vol);
+    hpgmg_vector_upload(B->vectors[VECTOR_BETA_K], stage + 2 * vol, vol);
+    if (cfg->helmholtz) hpgmg_vector_upload(B->vectors[VECTOR_ALPHA], stage + 3 * vol, vol);
+    hpgmg_vector_upload(B->vectors[VECTOR_F], stage + 4 * vol, vol);
+  }
+  free(stage);
+}
+
 void initialize_problem(level_type *L, double h, double a, double b) {
   hpgmg_config cfg;
   hpgmg_get_config(&cfg);
-  if (cfg.op != HPGMG_OP_7PT && cfg.op != HPGMG_OP_27PT) no_kernel("initialize_problem (problem.fv)");
+  if (cfg.op == HPGMG_OP_FV2 || cfg.op == HPGMG_OP_FV4) { initialize_problem_fv(L, h, &cfg); return; }
   L->h = h;
   const int jS = L->box_jStride, kS = L->box_kStride, g = L->box_ghosts, dim = L->box_dim;
   const size_t vol = (size_t)L->box_volume;
@@ -537,18 +633,19 @@ void initialize_problem(level_type *L, double h, double a, double b) {
 void rebuild_operator(level_type *L, level_type *from, double a, double b) {
   hpgmg_config cfg;
   hpgmg_get_config(&cfg);
-  if (cfg.op == HPGMG_OP_27PT) {                                /* operators.27pt.c:96-121 */
+  if (cfg.op != HPGMG_OP_7PT) {                                 /* operators.27pt.c:96-121, .fv2.c:98-124, .fv4.c:145-172 */
     if (from) {
       if (cfg.helmholtz) restriction(L, VECTOR_ALPHA, from, VECTOR_ALPHA, RESTRICT_CELL);
       restriction(L, VECTOR_BETA_I, from, VECTOR_BETA_I, RESTRICT_FACE_I);
       restriction(L, VECTOR_BETA_J, from, VECTOR_BETA_J, RESTRICT_FACE_J);
       restriction(L, VECTOR_BETA_K, from, VECTOR_BETA_K, RESTRICT_FACE_K);
     }
+    if (cfg.op == HPGMG_OP_FV4) extrapolate_betas(L);           /* mixed-derivative terms read beta in the ghost zone */
     if (cfg.helmholtz) exchange_boundary(L, VECTOR_ALPHA, STENCIL_SHAPE_BOX);
     exchange_boundary(L, VECTOR_BETA_I, STENCIL_SHAPE_BOX);
     exchange_boundary(L, VECTOR_BETA_J, STENCIL_SHAPE_BOX);
     exchange_boundary(L, VECTOR_BETA_K, STENCIL_SHAPE_BOX);
-    rebuild_operator_blackbox(L, a, b, 2);
+    rebuild_operator_blackbox(L, a, b, cfg.op == HPGMG_OP_FV4 ? 4 : 2);
     exchange_boundary(L, VECTOR_DINV, STENCIL_SHAPE_BOX);
     return;
   }

@@ -98,6 +98,163 @@ __global__ __launch_bounds__(256) void bc_p2_kernel(const hpgmg_hip_level L, int
   }
 }
 
+
+// ---- finite-volume boundary conditions (reference operators/boundary_fv.c) -------------------
+// Geometry of one BC list entry: axes whose DOMAIN normal component is non-zero (in i<j<k order)
+// sit at ghost index -1 / dim and step inward; the remaining axes run over the entry's extent.
+struct BcGeom { int nn, pos[3], step[3], lo[2], len[2], fstride[2]; };
+__device__ __forceinline__ BcGeom bc_geometry(const hpgmg_hip_level &L, const blockCopy_type &e) {
+  BcGeom g;
+  const int strides[3] = {1, L.jStride, L.kStride}, lo[3] = {e.read.i, e.read.j, e.read.k}, len[3] = {e.dim.i, e.dim.j, e.dim.k};
+  const int d[3] = {e.subtype % 3 - 1, (e.subtype % 9) / 3 - 1, e.subtype / 9 - 1};
+  g.nn = 0; int nf = 0;
+  g.lo[0] = g.lo[1] = 0; g.len[0] = g.len[1] = 1; g.fstride[0] = g.fstride[1] = 0;
+  g.pos[0] = g.pos[1] = g.pos[2] = 0; g.step[0] = g.step[1] = g.step[2] = 0;
+#pragma unroll
+  for (int ax = 0; ax < 3; ax++) {
+    if (d[ax]) { g.pos[g.nn] = (d[ax] < 0 ? -1 : L.dim) * strides[ax]; g.step[g.nn] = -d[ax] * strides[ax]; g.nn++; }
+    else if (nf < 2) { g.lo[nf] = lo[ax]; g.len[nf] = len[ax]; g.fstride[nf] = strides[ax]; nf++; }
+  }
+  return g;
+}
+__device__ __forceinline__ void bc_zero_entry(const hpgmg_hip_level &L, double *x, const blockCopy_type &e) {
+  const int ni = e.dim.i, nj = e.dim.j, n = ni * nj * e.dim.k;
+  for (int t = threadIdx.x; t < n; t += blockDim.x) {
+    const int i = t % ni, j = (t / ni) % nj, k = t / (ni * nj);
+    x[(i + e.read.i) + (j + e.read.j) * L.jStride + (k + e.read.k) * L.kStride] = 0.0;
+  }
+  __syncthreads();
+}
+
+// boundary_fv.c:101-250 apply_BCs_v2: first ghost layer by quadratic extrapolation of cell averages, deeper layers zero
+__global__ __launch_bounds__(256) void bc_v2_kernel(const hpgmg_hip_level L, int id, const blockCopy_type *__restrict__ list) {
+  const blockCopy_type &e = list[blockIdx.x];
+  double *x = vec_origin(L, e.read.box, id);
+  if (L.ghosts > 1) bc_zero_entry(L, x, e);
+  const BcGeom g = bc_geometry(L, e);
+  const int n = g.len[0] * g.len[1];
+  for (int t = threadIdx.x; t < n; t += blockDim.x) {
+    const int r = t % g.len[0], q = t / g.len[0];
+    int ijk = (r + g.lo[0]) * g.fstride[0] + (q + g.lo[1]) * g.fstride[1];
+    double v;
+    if (g.nn == 1) {
+      const int dt = g.step[0]; ijk += g.pos[0];
+      v = -2.5 * x[ijk + dt] + 0.5 * x[ijk + 2 * dt];
+    } else if (g.nn == 2) {
+      const int ds = g.step[0], dt = g.step[1]; ijk += g.pos[0] + g.pos[1];
+      v = 6.25 * x[ijk + ds + dt] - 1.25 * x[ijk + 2 * ds + dt];
+      v = v - 1.25 * x[ijk + ds + 2 * dt];
+      v = v + 0.25 * x[ijk + 2 * ds + 2 * dt];
+    } else {
+      const int di = g.step[0], dj = g.step[1], dk = g.step[2]; ijk += g.pos[0] + g.pos[1] + g.pos[2];
+      v = -15.625 * x[ijk + di + dj + dk] + 3.125 * x[ijk + 2 * di + dj + dk];
+      v = v + 3.125 * x[ijk + di + 2 * dj + dk];
+      v = v + 3.125 * x[ijk + di + dj + 2 * dk];
+      v = v - 0.625 * x[ijk + 2 * di + 2 * dj + dk];
+      v = v - 0.625 * x[ijk + di + 2 * dj + 2 * dk];
+      v = v - 0.625 * x[ijk + 2 * di + dj + 2 * dk];
+      v = v + 0.125 * x[ijk + 2 * di + 2 * dj + 2 * dk];
+    }
+    x[ijk] = v;
+  }
+}
+
+// boundary_fv.c:262-569 apply_BCs_v4: near/far ghost from the four cells next to the boundary,
+// N = (-77 x1 + 43 x2 - 17 x3 + 3 x4)/12, F = (-505 x1 + 335 x2 - 145 x3 + 27 x4)/12, applied axis after axis
+__device__ __forceinline__ double v4_near(double x1, double x2, double x3, double x4) { const double w = 1.0 / 12.0; double s = -77.0 * x1 + 43.0 * x2; s = s - 17.0 * x3; s = s + 3.0 * x4; return w * s; }
+__device__ __forceinline__ double v4_far(double x1, double x2, double x3, double x4)  { const double w = 1.0 / 12.0; double s = -505.0 * x1 + 335.0 * x2; s = s - 145.0 * x3; s = s + 27.0 * x4; return w * s; }
+__global__ __launch_bounds__(256) void bc_v4_kernel(const hpgmg_hip_level L, int id, const blockCopy_type *__restrict__ list) {
+  const blockCopy_type &e = list[blockIdx.x];
+  double *x = vec_origin(L, e.read.box, id);
+  if (L.ghosts > 2) bc_zero_entry(L, x, e);
+  const BcGeom g = bc_geometry(L, e);
+  const int n = g.len[0] * g.len[1];
+  for (int t = threadIdx.x; t < n; t += blockDim.x) {
+    const int r = t % g.len[0], q = t / g.len[0];
+    int ijk = (r + g.lo[0]) * g.fstride[0] + (q + g.lo[1]) * g.fstride[1];
+    if (g.nn == 1) {
+      const int dt = g.step[0]; ijk += g.pos[0];
+      const double x1 = x[ijk + dt], x2 = x[ijk + 2 * dt], x3 = x[ijk + 3 * dt], x4 = x[ijk + 4 * dt];
+      x[ijk] = v4_near(x1, x2, x3, x4);
+      x[ijk - dt] = v4_far(x1, x2, x3, x4);
+    } else if (g.nn == 2) {
+      const int ds = g.step[0], dt = g.step[1]; ijk += g.pos[0] + g.pos[1];
+      double nr[4], fr[4];
+#pragma unroll
+      for (int m = 0; m < 4; m++) {
+        const int o = ijk + (m + 1) * dt;
+        const double a1 = x[o + ds], a2 = x[o + 2 * ds], a3 = x[o + 3 * ds], a4 = x[o + 4 * ds];
+        nr[m] = v4_near(a1, a2, a3, a4); fr[m] = v4_far(a1, a2, a3, a4);
+      }
+      x[ijk]           = v4_near(nr[0], nr[1], nr[2], nr[3]);
+      x[ijk - dt]      = v4_far(nr[0], nr[1], nr[2], nr[3]);
+      x[ijk - ds]      = v4_near(fr[0], fr[1], fr[2], fr[3]);
+      x[ijk - ds - dt] = v4_far(fr[0], fr[1], fr[2], fr[3]);
+    } else {
+      const int di = g.step[0], dj = g.step[1], dk = g.step[2]; ijk += g.pos[0] + g.pos[1] + g.pos[2];
+      double nn[4], nf[4], fn[4], ff[4];
+#pragma unroll
+      for (int p = 0; p < 4; p++) {
+        double nj[4], fj[4];
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+          const int o = ijk + (m + 1) * dj + (p + 1) * dk;
+          const double a1 = x[o + di], a2 = x[o + 2 * di], a3 = x[o + 3 * di], a4 = x[o + 4 * di];
+          nj[m] = v4_near(a1, a2, a3, a4); fj[m] = v4_far(a1, a2, a3, a4);
+        }
+        nn[p] = v4_near(nj[0], nj[1], nj[2], nj[3]); nf[p] = v4_far(nj[0], nj[1], nj[2], nj[3]);
+        fn[p] = v4_near(fj[0], fj[1], fj[2], fj[3]); ff[p] = v4_far(fj[0], fj[1], fj[2], fj[3]);
+      }
+      x[ijk]                = v4_near(nn[0], nn[1], nn[2], nn[3]);
+      x[ijk - dk]           = v4_far(nn[0], nn[1], nn[2], nn[3]);
+      x[ijk - dj]           = v4_near(nf[0], nf[1], nf[2], nf[3]);
+      x[ijk - dj - dk]      = v4_far(nf[0], nf[1], nf[2], nf[3]);
+      x[ijk - di]           = v4_near(fn[0], fn[1], fn[2], fn[3]);
+      x[ijk - di - dk]      = v4_far(fn[0], fn[1], fn[2], fn[3]);
+      x[ijk - di - dj]      = v4_near(ff[0], ff[1], ff[2], ff[3]);
+      x[ijk - di - dj - dk] = v4_far(ff[0], ff[1], ff[2], ff[3]);
+    }
+  }
+}
+
+// boundary_fv.c:573-681 extrapolate_betas.  The reference updates each block IN PLACE in k,j,i order, so a
+// deeper ghost cell may see a shallower one already (high side) or not yet (low side) updated.  One lane per
+// list entry walks its block in exactly that order; entries run in parallel like the reference's OpenMP tasks.
+// Setup only (called from rebuild_operator), never in the timed cycle.
+__global__ __launch_bounds__(64) void extrapolate_betas_kernel(const hpgmg_hip_level L, const blockCopy_type *__restrict__ list, int n) {
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= n) return;
+  const blockCopy_type &e = list[b];
+  const int jS = L.jStride, kS = L.kStride, ilo = e.read.i, jlo = e.read.j, klo = e.read.k;
+  int subtype = 13;
+  if (ilo < 0) subtype -= 1;
+  if (jlo < 0) subtype -= 3;
+  if (klo < 0) subtype -= 9;
+  if (ilo >= L.dim) subtype += 1;
+  if (jlo >= L.dim) subtype += 3;
+  if (klo >= L.dim) subtype += 9;
+  const int normal = 26 - subtype, di = normal % 3 - 1, dj = (normal % 9) / 3 - 1, dk = normal / 9 - 1;
+  const int bs[3] = { dj * jS + dk * kS, di + dk * kS, di + dj * jS };
+  const int skip_lo[3] = {12, 10, 4}, skip_hi[3] = {14, 16, 22};
+  double *beta[3] = { vec_origin(L, e.read.box, VECTOR_BETA_I), vec_origin(L, e.read.box, VECTOR_BETA_J), vec_origin(L, e.read.box, VECTOR_BETA_K) };
+  for (int k = 0; k < e.dim.k; k++) for (int j = 0; j < e.dim.j; j++) for (int i = 0; i < e.dim.i; i++) {
+    const int ijk = (i + ilo) + (j + jlo) * jS + (k + klo) * kS;
+    for (int c = 0; c < 3; c++) {
+      if (subtype == skip_lo[c] || subtype == skip_hi[c]) continue;
+      double *bb = beta[c]; const int st = bs[c];
+      if (L.dim >= 5) {
+        double v = 5.0 * bb[ijk + st] - 10.0 * bb[ijk + 2 * st]; v = v + 10.0 * bb[ijk + 3 * st]; v = v - 5.0 * bb[ijk + 4 * st]; v = v + bb[ijk + 5 * st];
+        bb[ijk] = v;
+      } else if (L.dim >= 4) {
+        double v = 4.0 * bb[ijk + st] - 6.0 * bb[ijk + 2 * st]; v = v + 4.0 * bb[ijk + 3 * st]; v = v - bb[ijk + 4 * st];
+        bb[ijk] = v;
+      } else if (L.dim >= 2) {
+        bb[ijk] = 2.0 * bb[ijk + st] - bb[ijk + 2 * st];
+      }
+    }
+  }
+}
+
 // 1-D rules of the tensor-product interpolations (v[] = coarse line, centre at v[R]):
 //   order 2 = p2 interpolation_p2.c:90-92,150-205;  order 3 = v2 interpolation_v2.c:111-113;  order 4 = v4 interpolation_v4.c:96-97,180-240
 template <int ORDER>
@@ -224,6 +381,27 @@ int hpgmg_hip_apply_bc_p2(const hpgmg_hip_level *L, int id, const blockCopy_type
   if (n <= 0) return 0;
   hipLaunchKernelGGL(bc_p2_kernel, dim3(n), dim3(256), 0, g_stream, *L, id, blocks);
   HPGMG_LAUNCH_CHECK("bc_p2_kernel");
+  return 0;
+}
+int hpgmg_hip_apply_bc_v2(const hpgmg_hip_level *L, int id, const blockCopy_type *blocks, int n) {
+  HPGMG_SKIP_IF_REPLAY();
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(bc_v2_kernel, dim3(n), dim3(256), 0, g_stream, *L, id, blocks);
+  HPGMG_LAUNCH_CHECK("bc_v2_kernel");
+  return 0;
+}
+int hpgmg_hip_apply_bc_v4(const hpgmg_hip_level *L, int id, const blockCopy_type *blocks, int n) {
+  HPGMG_SKIP_IF_REPLAY();
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(bc_v4_kernel, dim3(n), dim3(256), 0, g_stream, *L, id, blocks);
+  HPGMG_LAUNCH_CHECK("bc_v4_kernel");
+  return 0;
+}
+int hpgmg_hip_extrapolate_betas(const hpgmg_hip_level *L, const blockCopy_type *blocks, int n) {
+  HPGMG_SKIP_IF_REPLAY();
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(extrapolate_betas_kernel, dim3((n + 63) / 64), dim3(64), 0, g_stream, *L, blocks, n);
+  HPGMG_LAUNCH_CHECK("extrapolate_betas_kernel");
   return 0;
 }
 int hpgmg_hip_restrict_blocks(const hpgmg_hip_level *Lc, int id_c, const hpgmg_hip_level *Lf, int id_f,

@@ -336,6 +336,99 @@ __global__ __launch_bounds__(256) void stencil27_kernel(const hpgmg_hip_level L,
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Direct-load kernel: one lane per (i,j) column walking +k, every operand read through L1/L2.
+// Used for the 4th-order finite-volume operator (reference operators.fv4.c:55-114: radius 2,
+// 25 x values and 30 coefficient values per cell, so the neighbourhood does not fit a register
+// window worth keeping) and for the black-box probe of the 7-point operator (fv2 rebuild).
+// Expression order is the macro's: T*(six face terms) + (0.25*T)*(twelve mixed terms), each
+// group summed left to right; a mixed term is (beta+ - beta-) * (((x1 - x2) - x3) + x4).
+#define FV4_TWELFTH ( 0.0833333333333333333)
+template <int V>
+__device__ __forceinline__ double apply_op_direct(const double *x, const double *alpha, const double *bi, const double *bj, const double *bk,
+                                                  int ijk, int jS, int kS, double a, double b, double h2inv) {
+  const double xc = x[ijk];
+  if (V == HPGMG_HIP_FV4_VC_HELMHOLTZ || V == HPGMG_HIP_FV4_VC_POISSON) {
+    double s1 = bi[ijk] * (15.0 * (x[ijk - 1] - xc) - (x[ijk - 2] - x[ijk + 1]));
+    s1 = s1 + bi[ijk + 1] * (15.0 * (x[ijk + 1] - xc) - (x[ijk + 2] - x[ijk - 1]));
+    s1 = s1 + bj[ijk] * (15.0 * (x[ijk - jS] - xc) - (x[ijk - 2 * jS] - x[ijk + jS]));
+    s1 = s1 + bj[ijk + jS] * (15.0 * (x[ijk + jS] - xc) - (x[ijk + 2 * jS] - x[ijk - jS]));
+    s1 = s1 + bk[ijk] * (15.0 * (x[ijk - kS] - xc) - (x[ijk - 2 * kS] - x[ijk + kS]));
+    s1 = s1 + bk[ijk + kS] * (15.0 * (x[ijk + kS] - xc) - (x[ijk + 2 * kS] - x[ijk - kS]));
+#define MIX(B, o, t, d) ((B[ijk + (o) + (t)] - B[ijk + (o) - (t)]) * (x[ijk + (d) + (t)] - x[ijk + (t)] - x[ijk + (d) - (t)] + x[ijk - (t)]))
+    double s2 = MIX(bi, 0, jS, -1);
+    s2 = s2 + MIX(bi, 0, kS, -1);
+    s2 = s2 + MIX(bj, 0, 1, -jS);
+    s2 = s2 + MIX(bj, 0, kS, -jS);
+    s2 = s2 + MIX(bk, 0, 1, -kS);
+    s2 = s2 + MIX(bk, 0, jS, -kS);
+    s2 = s2 + MIX(bi, 1, jS, 1);
+    s2 = s2 + MIX(bi, 1, kS, 1);
+    s2 = s2 + MIX(bj, jS, 1, jS);
+    s2 = s2 + MIX(bj, jS, kS, jS);
+    s2 = s2 + MIX(bk, kS, 1, kS);
+    s2 = s2 + MIX(bk, kS, jS, kS);
+#undef MIX
+    const double sum = FV4_TWELFTH * s1 + (0.25 * FV4_TWELFTH) * s2;
+    if (V == HPGMG_HIP_FV4_VC_HELMHOLTZ) return (a * alpha[ijk]) * xc - (b * h2inv) * sum;
+    return ((-b) * h2inv) * sum;
+  } else {
+    constexpr bool kVC = (V != HPGMG_HIP_7PT_CC);
+    return apply_op_7pt<V>(xc, x[ijk - 1], x[ijk + 1], x[ijk - jS], x[ijk + jS], x[ijk - kS], x[ijk + kS],
+                           kVC ? bi[ijk] : 0.0, kVC ? bi[ijk + 1] : 0.0, kVC ? bj[ijk] : 0.0, kVC ? bj[ijk + jS] : 0.0,
+                           kVC ? bk[ijk] : 0.0, kVC ? bk[ijk + kS] : 0.0, (V == HPGMG_HIP_7PT_VC_HELMHOLTZ) ? alpha[ijk] : 0.0, a, b, h2inv);
+  }
+}
+
+template <int V, int MODE>
+__global__ __launch_bounds__(256) void stencil_direct_kernel(const hpgmg_hip_level L, const StencilArgs P) {
+  const int logical = xcd_logical_block((int)blockIdx.x, P.per_xcd);
+  if (logical >= P.total_blocks) return;
+  int t = logical;
+  const int ti = t % P.tiles_i; t /= P.tiles_i;
+  const int tj = t % P.tiles_j; t /= P.tiles_j;
+  const int ck = t % P.chunks_k; t /= P.chunks_k;
+  const int box = t;
+  const int i = ti * (int)blockDim.x + (int)threadIdx.x;
+  const int j = tj * (int)blockDim.y + (int)threadIdx.y;
+  if (i >= L.dim || j >= L.dim) return;
+  const int k0 = ck * P.kchunk, k1 = (k0 + P.kchunk < L.dim) ? k0 + P.kchunk : L.dim;
+  const int jS = L.jStride, kS = L.kStride;
+  constexpr bool kSmooth = (MODE == MODE_CHEBY || MODE == MODE_GSRB || MODE == MODE_JACOBI);
+  constexpr bool kVC = (V != HPGMG_HIP_7PT_CC);
+  constexpr bool kHelm = (V == HPGMG_HIP_7PT_VC_HELMHOLTZ || V == HPGMG_HIP_FV4_VC_HELMHOLTZ);
+
+  const double *x = vec_origin(L, box, P.xn_id);
+  double *out = vec_origin(L, box, P.xout_id);           // in-place GSRB (fv2) aliases x
+  double *rhs = (MODE == MODE_APPLY) ? nullptr : vec_origin(L, box, P.rhs_id);   // BLACKBOX: the sum|Aij| accumulator
+  const double *dinv = kSmooth ? vec_origin(L, box, VECTOR_DINV) : nullptr;
+  const double *alpha = kHelm ? vec_origin(L, box, VECTOR_ALPHA) : nullptr;
+  const double *bi = kVC ? vec_origin(L, box, VECTOR_BETA_I) : nullptr;
+  const double *bj = kVC ? vec_origin(L, box, VECTOR_BETA_J) : nullptr;
+  const double *bk = kVC ? vec_origin(L, box, VECTOR_BETA_K) : nullptr;
+  int colour000 = 0;
+  if (MODE == MODE_GSRB) colour000 = (L.box_low[3 * box] ^ L.box_low[3 * box + 1] ^ L.box_low[3 * box + 2] ^ P.sweep) & 1;
+
+  int ijk = i + j * jS + k0 * kS;
+  for (int k = k0; k < k1; k++, ijk += kS) {
+    bool update = true;
+    if (MODE == MODE_GSRB) update = (((i ^ j ^ k ^ colour000) & 1) == 0);
+    if (update) {
+      const double xc = x[ijk];
+      const double Ax = apply_op_direct<V>(x, alpha, bi, bj, bk, ijk, jS, kS, P.a, P.b, P.h2inv);
+      if (MODE == MODE_CHEBY)         { const double xnm1 = out[ijk]; out[ijk] = xc + P.c1 * (xc - xnm1) + P.c2 * dinv[ijk] * (rhs[ijk] - Ax); }
+      else if (MODE == MODE_GSRB)     { out[ijk] = xc + dinv[ijk] * (rhs[ijk] - Ax); }
+      else if (MODE == MODE_JACOBI)   { out[ijk] = xc + P.c2 * dinv[ijk] * (rhs[ijk] - Ax); }
+      else if (MODE == MODE_RESIDUAL) { out[ijk] = rhs[ijk] - Ax; }
+      else if (MODE == MODE_APPLY)    { out[ijk] = Ax; }
+      else { out[ijk] += (xc) * Ax; rhs[ijk] += fabs((1.0 - xc) * Ax); }
+    } else if (P.copy_other_colour) {
+      out[ijk] = x[ijk];
+    }
+  }
+}
+
 // ---- smoother-kernel profiling: hipEvent pair around every smoother launch ----
 static bool g_profile = false;
 static long long g_profile_min_cells = 0;   // only launches covering at least this many cells are timed
@@ -408,10 +501,33 @@ static int launch27(const hpgmg_hip_level *L, StencilArgs P, bool is_smoother) {
 }
 
 template <int MODE>
+static int launch_direct(const hpgmg_hip_level *L, int variant, StencilArgs P, bool is_smoother) {
+  HPGMG_SKIP_IF_REPLAY();
+  if (L->num_boxes <= 0) return 0;
+  dim3 block; int grid;
+  plan(L, P, block, grid);
+  P.ghost_free = 0;
+  const long long cells = (long long)L->num_boxes * L->dim * L->dim * L->dim;
+  int prof = is_smoother ? profile_begin(cells) : -1;
+  switch (variant) {
+    case HPGMG_HIP_FV4_VC_HELMHOLTZ: hipLaunchKernelGGL((stencil_direct_kernel<HPGMG_HIP_FV4_VC_HELMHOLTZ, MODE>), dim3(grid), block, 0, g_stream, *L, P); break;
+    case HPGMG_HIP_FV4_VC_POISSON:   hipLaunchKernelGGL((stencil_direct_kernel<HPGMG_HIP_FV4_VC_POISSON, MODE>), dim3(grid), block, 0, g_stream, *L, P); break;
+    case HPGMG_HIP_7PT_VC_HELMHOLTZ: hipLaunchKernelGGL((stencil_direct_kernel<HPGMG_HIP_7PT_VC_HELMHOLTZ, MODE>), dim3(grid), block, 0, g_stream, *L, P); break;
+    case HPGMG_HIP_7PT_VC_POISSON:   hipLaunchKernelGGL((stencil_direct_kernel<HPGMG_HIP_7PT_VC_POISSON, MODE>), dim3(grid), block, 0, g_stream, *L, P); break;
+    case HPGMG_HIP_7PT_CC:           hipLaunchKernelGGL((stencil_direct_kernel<HPGMG_HIP_7PT_CC, MODE>), dim3(grid), block, 0, g_stream, *L, P); break;
+    default: return record_error(hipErrorInvalidValue, "stencil variant not implemented");
+  }
+  profile_end(prof, cells);
+  HPGMG_LAUNCH_CHECK("stencil_direct_kernel");
+  return 0;
+}
+
+template <int MODE>
 static int launch(const hpgmg_hip_level *L, int variant, StencilArgs P, bool is_smoother) {
   HPGMG_SKIP_IF_REPLAY();
   if (L->num_boxes <= 0) return 0;
   if (variant == HPGMG_HIP_27PT_CC) return launch27<MODE>(L, P, is_smoother);
+  if (variant == HPGMG_HIP_FV4_VC_HELMHOLTZ || variant == HPGMG_HIP_FV4_VC_POISSON) return launch_direct<MODE>(L, variant, P, is_smoother);
   dim3 block; int grid;
   plan(L, P, block, grid);
   const long long cells = (long long)L->num_boxes * L->dim * L->dim * L->dim;
@@ -487,7 +603,7 @@ int hpgmg_hip_smooth_jacobi(const hpgmg_hip_level *L, int variant, int xn_id, in
 int hpgmg_hip_blackbox_accumulate(const hpgmg_hip_level *L, int variant, int x_id, int Aii_id, int sumAbs_id, double a, double b, double h2inv) {
   StencilArgs P = {}; P.xn_id = x_id; P.xout_id = Aii_id; P.rhs_id = sumAbs_id; P.a = a; P.b = b; P.h2inv = h2inv;
   if (variant == HPGMG_HIP_27PT_CC) return launch27<MODE_BLACKBOX>(L, P, false);
-  return record_error(hipErrorInvalidValue, "blackbox probe: variant not implemented");
+  return launch_direct<MODE_BLACKBOX>(L, variant, P, false);
 }
 int hpgmg_hip_residual(const hpgmg_hip_level *L, int variant, int res_id, int x_id, int rhs_id, double a, double b, double h2inv) {
   StencilArgs P = {}; P.xn_id = x_id; P.xout_id = res_id; P.rhs_id = rhs_id; P.a = a; P.b = b; P.h2inv = h2inv;

@@ -96,6 +96,10 @@ int hpgmg_hip_increment_blocks(const hpgmg_hip_level *L, int id, double prescale
 int hpgmg_hip_apply_bc_p1(const hpgmg_hip_level *L, int id, const blockCopy_type *blocks, int num_blocks);
 /* operators/boundary_fd.c:93-205 apply_BCs_p2 */
 int hpgmg_hip_apply_bc_p2(const hpgmg_hip_level *L, int id, const blockCopy_type *blocks, int num_blocks);
+/* operators/boundary_fv.c:101-250 apply_BCs_v2, :262-569 apply_BCs_v4, :573-681 extrapolate_betas (BOX list) */
+int hpgmg_hip_apply_bc_v2(const hpgmg_hip_level *L, int id, const blockCopy_type *blocks, int num_blocks);
+int hpgmg_hip_apply_bc_v4(const hpgmg_hip_level *L, int id, const blockCopy_type *blocks, int num_blocks);
+int hpgmg_hip_extrapolate_betas(const hpgmg_hip_level *L, const blockCopy_type *blocks, int num_blocks);
 /* operators/restriction.c:6-94 restriction_pc_block over a list; type = RESTRICT_* */
 int hpgmg_hip_restrict_blocks(const hpgmg_hip_level *Lc, int id_c, const hpgmg_hip_level *Lf, int id_f,
                               const blockCopy_type *blocks, int num_blocks, int type);

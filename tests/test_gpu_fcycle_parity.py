@@ -17,7 +17,7 @@ def fmt(x):
 
 
 SMALL = [("7pt-cheby", "4 8"), ("7pt-cheby", "5 8"), ("7pt-gsrb", "5 8"), ("7pt-cheby-helm", "5 8"), ("7ptcc-cheby", "5 8"),
-         ("7pt-jacobi", "4 8"), ("27pt-cheby", "4 8"), ("27pt-cheby", "5 8"), ("27pt-gsrb", "4 8"), ("7pt-cheby", "4 1"), ("7pt-cheby", "4 27"), ("7pt-cheby-helm", "6 8")]
+         ("7pt-jacobi", "4 8"), ("27pt-cheby", "4 8"), ("27pt-cheby", "5 8"), ("27pt-gsrb", "4 8"), ("fv4-gsrb", "4 8"), ("fv4-gsrb", "5 8"), ("fv4-cheby", "4 8"), ("fv2-cheby", "4 8"), ("fv2-cheby", "5 8"), ("7pt-cheby", "4 1"), ("7pt-cheby", "4 27"), ("7pt-cheby-helm", "6 8")]
 
 
 @pytest.mark.parametrize("variant,args", SMALL)
@@ -39,7 +39,7 @@ def test_hip_fcycle_matches_reference_golden(hip, variant, args):
         s.destroy()
 
 
-@pytest.mark.parametrize("variant", ["7pt-cheby-helm", "7pt-cheby", "7pt-gsrb", "7ptcc-cheby", "27pt-cheby"])
+@pytest.mark.parametrize("variant", ["7pt-cheby-helm", "7pt-cheby", "7pt-gsrb", "7ptcc-cheby", "27pt-cheby", "fv4-gsrb"])
 def test_hip_fcycle_full_size_256(hip, variant):
     """BASELINE.json config 2 (`7 8`, 256^3, 8 boxes of 128^3) and its Poisson/GSRB/CC siblings."""
     gold = GOLD[f"{variant} 7 8"]
