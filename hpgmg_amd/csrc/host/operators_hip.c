@@ -358,6 +358,18 @@ int hpgmg_vcycle_legs_fused(level_type **levels, int n, int e_id, int R_id, doub
     level_type *L = levels[l];
     backend_t *B = backend_of(L);
     if (!L->active || L->num_my_boxes < 1) return 0;
+    /* the kernel addresses cells by global coordinate: cubic Dirichlet domain, boxes in lexicographic order, halving per level */
+    if (L->boundary_condition.type != BC_DIRICHLET || L->dim.i != L->dim.j || L->dim.i != L->dim.k || (sweeps & 1)) return 0;
+    if (l > 0 && 2 * L->dim.i != levels[l - 1]->dim.i) return 0;
+    {
+      const int nb = L->dim.i / L->box_dim;
+      int bx;
+      if (L->num_my_boxes != nb * nb * nb) return 0;
+      for (bx = 0; bx < L->num_my_boxes; bx++) {
+        const box_type *X = &L->my_boxes[bx];
+        if (X->low.i != (bx % nb) * L->box_dim || X->low.j != ((bx / nb) % nb) * L->box_dim || X->low.k != (bx / (nb * nb)) * L->box_dim) return 0;
+      }
+    }
     if (l + 1 < n) {
       communicator_type *R = &L->restriction[RESTRICT_CELL], *I = &levels[l + 1]->interpolation;
       if ((long long)L->dim.i * L->dim.j * L->dim.k > hpgmg_hip_tail_max_cells() || !B->all_faces_local) return 0;

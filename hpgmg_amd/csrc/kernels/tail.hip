@@ -12,8 +12,8 @@
 // the chain is the bottom level: it is only the target of the restriction / source of the
 // interpolation; its solve (BiCGStab) stays with the host between the two legs.
 //
-// One workgroup of 1024 lanes walks the cells of a level (<= 4096 cells: <= 4 per lane); all
-// data stays in that CU's L1/L2.  The arithmetic is the same expression tree as the streaming
+// One workgroup of 1024 lanes owns a level (<= 4096 cells: <= 4 per lane); the iterate and TEMP sit
+// in LDS, coefficients in registers.  The arithmetic is the same expression tree as the streaming
 // kernels (stencil_math.hpp, restriction.c:54-57, interpolation_p0.c:43), so results are
 // bit-identical to the per-operator path -- tests/test_gpu_* run both.
 // Ghost handling is the ghost-free form (neighbour box / Dirichlet -x, see stencil.hip), which
@@ -43,131 +43,155 @@ struct TailArgs {
 
 enum { SM_CHEBY = 0, SM_GSRB = 1, SM_JACOBI = 2, SM_RESIDUAL = 3 };
 
-// one sweep (or the residual) over every interior cell of a level, all lanes of the workgroup
-template <int V, int MODE>
-__device__ void tail_sweep(const hpgmg_hip_level &L, int xn_id, int xout_id, int rhs_id,
-                           double a, double b, double h2inv, double c1, double c2, int sweep) {
+// The level being worked on lives in LDS as two dense D^3 arrays in GLOBAL cell order (box boundaries
+// disappear; a Dirichlet face is the in-register rule ghost = -centre, exactly what apply_BCs_p1 stores):
+//   sx = the iterate (e), st = VECTOR_TEMP (Chebyshev/Jacobi ping-pong partner, then the residual).
+// Each lane owns up to kCellsPerLane cells for the whole visit and keeps their coefficients
+// (beta faces, alpha, Dinv, rhs) in registers, so a sweep is LDS reads + arithmetic + one barrier
+// (~0.2 us) instead of a round trip to L2 (~1.3 us).  Global memory is read once and written once per
+// level visit, leaving every vector in the state the per-operator sequence would leave it in.
+constexpr int kCellsPerLane = 4;                    // 4096 cells / 1024 lanes
+constexpr int kTailMaxCells = kCellsPerLane * kTailThreads;
+
+struct CellRef { int box, ijk; };                    // where a global cell lives in the boxed layout
+__device__ __forceinline__ CellRef locate(const hpgmg_hip_level &L, int gi, int gj, int gk) {
+  const int bd = L.dim, nb = L.dim_i / bd;
+  const int bi = gi / bd, bj = gj / bd, bk = gk / bd;
+  CellRef r;
+  r.box = bi + nb * (bj + nb * bk);
+  r.ijk = (gi - bi * bd) + (gj - bj * bd) * L.jStride + (gk - bk * bd) * L.kStride;
+  return r;
+}
+
+template <int V>
+struct CellCoef { double bi0, bi1, bj0, bj1, bk0, bk1, al, dinv, rhs; };
+
+// A x at LDS cell c of a D^3 level; src is the dense iterate
+template <int V>
+__device__ __forceinline__ double tail_apply(const double *src, int c, int gi, int gj, int gk, int D, const CellCoef<V> &q,
+                                             double a, double b, double h2inv) {
+  const double xc = src[c];
+  const int last = D - 1;
+  const double xim = (gi == 0)    ? -xc : src[c - 1];
+  const double xip = (gi == last) ? -xc : src[c + 1];
+  const double xjm = (gj == 0)    ? -xc : src[c - D];
+  const double xjp = (gj == last) ? -xc : src[c + D];
+  const double xkm = (gk == 0)    ? -xc : src[c - D * D];
+  const double xkp = (gk == last) ? -xc : src[c + D * D];
+  return apply_op_7pt<V>(xc, xim, xip, xjm, xjp, xkm, xkp, q.bi0, q.bi1, q.bj0, q.bj1, q.bk0, q.bk1, q.al, a, b, h2inv);
+}
+
+// one visit of a level: load -> (interpolate) -> smooth -> (residual, restrict, zero) -> store
+template <int V, int SM>
+__device__ void tail_level(const TailArgs &A, int l, int leg, double *sx, double *st) {
   constexpr bool kVC = (V != HPGMG_HIP_7PT_CC);
   constexpr bool kHelm = (V == HPGMG_HIP_7PT_VC_HELMHOLTZ);
-  const int dim = L.dim, jS = L.jStride, kS = L.kStride, last = dim - 1;
-  const int per_box = dim * dim * dim, total = per_box * L.num_boxes;
-  for (int c = threadIdx.x; c < total; c += kTailThreads) {
-    const int box = c / per_box, r = c - box * per_box;
-    const int k = r / (dim * dim), j = (r / dim) % dim, i = r % dim;
-    if (MODE == SM_GSRB) {
-      const int colour000 = (L.box_low[3 * box] ^ L.box_low[3 * box + 1] ^ L.box_low[3 * box + 2] ^ sweep) & 1;
-      if (((i ^ j ^ k ^ colour000) & 1) != 0) continue;   // in place: the other colour keeps its value
-    }
-    const double *x = vec_origin(L, box, xn_id);
-    double *out = vec_origin(L, box, xout_id);
-    const int ijk = i + j * jS + k * kS;
-    const double xc = x[ijk];
-    auto outside = [&](int dir, int idx_in_neighbour) -> double {
-      const int nb = L.box_nbr[6 * box + dir];
-      if (nb >= 0) return vec_origin(L, nb, xn_id)[idx_in_neighbour];
-      return -xc;                                          // Dirichlet face (the host guarantees no remote faces)
-    };
-    const double xim = (i == 0)    ? outside(0, last + j * jS + k * kS) : x[ijk - 1];
-    const double xip = (i == last) ? outside(1, j * jS + k * kS)        : x[ijk + 1];
-    const double xjm = (j == 0)    ? outside(2, i + last * jS + k * kS) : x[ijk - jS];
-    const double xjp = (j == last) ? outside(3, i + k * kS)             : x[ijk + jS];
-    const double xkm = (k == 0)    ? outside(4, i + j * jS + last * kS) : x[ijk - kS];
-    const double xkp = (k == last) ? outside(5, i + j * jS)             : x[ijk + kS];
-    double bi0 = 0, bi1 = 0, bj0 = 0, bj1 = 0, bk0 = 0, bk1 = 0, al = 0;
-    if (kVC) {
-      const double *beta_i = vec_origin(L, box, VECTOR_BETA_I), *beta_j = vec_origin(L, box, VECTOR_BETA_J), *beta_k = vec_origin(L, box, VECTOR_BETA_K);
-      bi0 = beta_i[ijk]; bi1 = beta_i[ijk + 1]; bj0 = beta_j[ijk]; bj1 = beta_j[ijk + jS]; bk0 = beta_k[ijk]; bk1 = beta_k[ijk + kS];
-    }
-    if (kHelm) al = vec_origin(L, box, VECTOR_ALPHA)[ijk];
-    const double Ax = apply_op_7pt<V>(xc, xim, xip, xjm, xjp, xkm, xkp, bi0, bi1, bj0, bj1, bk0, bk1, al, a, b, h2inv);
-    if (MODE == SM_RESIDUAL) { out[ijk] = vec_origin(L, box, rhs_id)[ijk] - Ax; continue; }
-    const double rhs = vec_origin(L, box, rhs_id)[ijk], dinv = vec_origin(L, box, VECTOR_DINV)[ijk];
-    if (MODE == SM_CHEBY)      { const double xnm1 = out[ijk]; out[ijk] = xc + c1 * (xc - xnm1) + c2 * dinv * (rhs - Ax); }
-    else if (MODE == SM_GSRB)  { out[ijk] = xc + dinv * (rhs - Ax); }
-    else                       { out[ijk] = xc + c2 * dinv * (rhs - Ax); }
-  }
-  __syncthreads();
-}
+  const TailLevel &T = A.lv[l];
+  const hpgmg_hip_level &L = T.L;
+  const int D = L.dim_i, total = D * D * D;
+  CellCoef<V> q[kCellsPerLane];
+  int gi[kCellsPerLane], gj[kCellsPerLane], gk[kCellsPerLane];
+  CellRef where[kCellsPerLane];
 
-// smooth(): the sweep schedule of chebyshev.c:43-47, gsrb.c:26-34, jacobi.c:17-20 (ping-pong with VECTOR_TEMP)
-template <int V, int SM>
-__device__ void tail_smooth(const TailLevel &T, int x_id, int rhs_id, double a, double b, int sweeps) {
-  for (int s = 0; s < sweeps; s++) {
-    if (SM == SM_GSRB) {
-      tail_sweep<V, SM_GSRB>(T.L, x_id, x_id, rhs_id, a, b, T.h2inv, 0.0, 0.0, s);
-    } else {
-      const int src = (s & 1) ? VECTOR_TEMP : x_id, dst = (s & 1) ? x_id : VECTOR_TEMP;
-      if (SM == SM_CHEBY) tail_sweep<V, SM_CHEBY>(T.L, src, dst, rhs_id, a, b, T.h2inv, T.c1[s], T.c2[s], s);
-      else                tail_sweep<V, SM_JACOBI>(T.L, src, dst, rhs_id, a, b, T.h2inv, 0.0, 2.0 / 3.0, s);
-    }
-  }
-}
-
-__device__ __forceinline__ double *side_ptr(const hpgmg_hip_level &L, int id, int box, int i, int j, int k) {
-  return vec_origin(L, box, id) + i + j * L.jStride + k * L.kStride;
-}
-
-// restriction.c:49-58 over a local list: coarse = 0.125 * sum of 8 fine cells
-__device__ void tail_restrict_cell(const hpgmg_hip_level &Lc, int id_c, const hpgmg_hip_level &Lf, int id_f, const blockCopy_type *list, int n) {
-  for (int e = 0; e < n; e++) {
-    const blockCopy_type &E = list[e];
-    const double *rp = side_ptr(Lf, id_f, E.read.box, E.read.i, E.read.j, E.read.k);
-    double *wp = side_ptr(Lc, id_c, E.write.box, E.write.i, E.write.j, E.write.k);
-    const int di = E.dim.i, dj = E.dim.j, cells = di * dj * E.dim.k, rj = Lf.jStride, rk = Lf.kStride;
-    for (int t = threadIdx.x; t < cells; t += kTailThreads) {
-      const int i = t % di, j = (t / di) % dj, k = t / (di * dj);
-      const double *f = rp + 2 * i + 2 * j * rj + 2 * k * rk;
-      double v = f[0] + f[1]; v = v + f[rj]; v = v + f[1 + rj]; v = v + f[rk]; v = v + f[1 + rk]; v = v + f[rj + rk]; v = v + f[1 + rj + rk];
-      wp[i + j * Lc.jStride + k * Lc.kStride] = v * 0.125;
+#pragma unroll
+  for (int m = 0; m < kCellsPerLane; m++) {
+    const int c = threadIdx.x + m * kTailThreads;
+    if (c < total) {
+      gi[m] = c % D; gj[m] = (c / D) % D; gk[m] = c / (D * D);
+      where[m] = locate(L, gi[m], gj[m], gk[m]);
+      const int box = where[m].box, ijk = where[m].ijk, jS = L.jStride, kS = L.kStride;
+      double e = vec_origin(L, box, A.e_id)[ijk];
+      if (leg == 1) {          // interpolation_vcycle: e = 1.0*e + (coarse parent), interpolation_p0.c:43
+        const hpgmg_hip_level &C = A.lv[l + 1].L;
+        const CellRef p = locate(C, gi[m] >> 1, gj[m] >> 1, gk[m] >> 1);
+        e = 1.0 * e + vec_origin(C, p.box, A.e_id)[p.ijk];
+      }
+      sx[c] = e;
+      st[c] = vec_origin(L, box, VECTOR_TEMP)[ijk];
+      q[m].rhs = vec_origin(L, box, A.R_id)[ijk];
+      q[m].dinv = vec_origin(L, box, VECTOR_DINV)[ijk];
+      q[m].bi0 = q[m].bi1 = q[m].bj0 = q[m].bj1 = q[m].bk0 = q[m].bk1 = q[m].al = 0.0;
+      if (kVC) {
+        const double *bi = vec_origin(L, box, VECTOR_BETA_I), *bj = vec_origin(L, box, VECTOR_BETA_J), *bk = vec_origin(L, box, VECTOR_BETA_K);
+        q[m].bi0 = bi[ijk]; q[m].bi1 = bi[ijk + 1]; q[m].bj0 = bj[ijk]; q[m].bj1 = bj[ijk + jS]; q[m].bk0 = bk[ijk]; q[m].bk1 = bk[ijk + kS];
+      }
+      if (kHelm) q[m].al = vec_origin(L, box, VECTOR_ALPHA)[ijk];
     }
   }
   __syncthreads();
-}
 
-// interpolation_p0.c:43 over a local list: fine = prescale*fine + coarse parent
-__device__ void tail_interp_p0(const hpgmg_hip_level &Lf, int id_f, double prescale, const hpgmg_hip_level &Lc, int id_c, const blockCopy_type *list, int n) {
-  for (int e = 0; e < n; e++) {
-    const blockCopy_type &E = list[e];
-    const double *rp = side_ptr(Lc, id_c, E.read.box, E.read.i, E.read.j, E.read.k);
-    double *wp = side_ptr(Lf, id_f, E.write.box, E.write.i, E.write.j, E.write.k);
-    const int di = 2 * E.dim.i, dj = 2 * E.dim.j, cells = di * dj * 2 * E.dim.k;
-    for (int t = threadIdx.x; t < cells; t += kTailThreads) {
-      const int i = t % di, j = (t / di) % dj, k = t / (di * dj);
-      double *fw = wp + i + j * Lf.jStride + k * Lf.kStride;
-      *fw = prescale * (*fw) + rp[(i >> 1) + (j >> 1) * Lc.jStride + (k >> 1) * Lc.kStride];
+  // smooth(): chebyshev.c:43-99 / gsrb.c:24-132 / jacobi.c:17-62 (even number of sweeps: the result ends in sx)
+  for (int s = 0; s < A.sweeps; s++) {
+    const double *src = (SM != SM_GSRB && (s & 1)) ? st : sx;
+    double *dst = (SM == SM_GSRB) ? sx : ((s & 1) ? sx : st);
+#pragma unroll
+    for (int m = 0; m < kCellsPerLane; m++) {
+      const int c = threadIdx.x + m * kTailThreads;
+      if (c < total) {
+        if (SM == SM_GSRB) {
+          const int colour = (gi[m] ^ gj[m] ^ gk[m] ^ s) & 1;   // global parity: box.low folded in (gsrb.c:55)
+          if (colour != 0) continue;
+        }
+        const double xc = src[c];
+        const double Ax = tail_apply<V>(src, c, gi[m], gj[m], gk[m], D, q[m], A.a, A.b, T.h2inv);
+        if (SM == SM_CHEBY)     { const double xnm1 = dst[c]; dst[c] = xc + T.c1[s] * (xc - xnm1) + T.c2[s] * q[m].dinv * (q[m].rhs - Ax); }
+        else if (SM == SM_GSRB) { dst[c] = xc + q[m].dinv * (q[m].rhs - Ax); }
+        else                    { dst[c] = xc + (2.0 / 3.0) * q[m].dinv * (q[m].rhs - Ax); }
+      }
+    }
+    __syncthreads();
+  }
+
+  if (leg == 0) {                                     // residual -> TEMP (residual.c:42-48)
+#pragma unroll
+    for (int m = 0; m < kCellsPerLane; m++) {
+      const int c = threadIdx.x + m * kTailThreads;
+      if (c < total) {
+        const double Ax = tail_apply<V>(sx, c, gi[m], gj[m], gk[m], D, q[m], A.a, A.b, T.h2inv);
+        st[c] = q[m].rhs - Ax;                        // each lane overwrites only its own TEMP cells: no hazard with the reads of sx
+      }
+    }
+    __syncthreads();
+  }
+
+  // leave e and TEMP in global memory as the per-operator sequence would
+#pragma unroll
+  for (int m = 0; m < kCellsPerLane; m++) {
+    const int c = threadIdx.x + m * kTailThreads;
+    if (c < total) {
+      vec_origin(L, where[m].box, A.e_id)[where[m].ijk] = sx[c];
+      vec_origin(L, where[m].box, VECTOR_TEMP)[where[m].ijk] = st[c];
     }
   }
-  __syncthreads();
-}
 
-// misc.c:6-44 zero_vector: whole padded boxes, ghosts included
-__device__ void tail_zero(const hpgmg_hip_level &L, int id) {
-  const int side = L.dim + 2 * L.ghosts, per_box = side * side * side, total = per_box * L.num_boxes;
-  for (int c = threadIdx.x; c < total; c += kTailThreads) {
-    const int box = c / per_box, r = c - box * per_box;
-    const int k = r / (side * side), j = (r / side) % side, i = r % side;
-    (L.box_base[box] + (size_t)id * (size_t)L.volume)[i + j * L.jStride + k * L.kStride] = 0.0;
+  if (leg == 0) {
+    // restriction(next.R <- TEMP): 0.125 * sum of the 8 children in the reference's order (restriction.c:54-57)
+    const hpgmg_hip_level &C = A.lv[l + 1].L;
+    const int Dc = D / 2, totc = Dc * Dc * Dc;
+    for (int c = threadIdx.x; c < totc; c += kTailThreads) {
+      const int ci = c % Dc, cj = (c / Dc) % Dc, ck = c / (Dc * Dc);
+      const double *f = st + 2 * ci + 2 * cj * D + 2 * ck * D * D;
+      double v = f[0] + f[1]; v = v + f[D]; v = v + f[1 + D]; v = v + f[D * D]; v = v + f[1 + D * D]; v = v + f[D + D * D]; v = v + f[1 + D + D * D];
+      const CellRef p = locate(C, ci, cj, ck);
+      vec_origin(C, p.box, A.R_id)[p.ijk] = v * 0.125;
+    }
+    // zero_vector(next.e): whole padded boxes, ghosts included (misc.c:6-44)
+    const int side = C.dim + 2 * C.ghosts, per_box = side * side * side, all = per_box * C.num_boxes;
+    for (int c = threadIdx.x; c < all; c += kTailThreads) {
+      const int box = c / per_box, r = c - box * per_box;
+      const int k = r / (side * side), j = (r / side) % side, i = r % side;
+      (C.box_base[box] + (size_t)A.e_id * (size_t)C.volume)[i + j * C.jStride + k * C.kStride] = 0.0;
+    }
   }
-  __syncthreads();
+  __syncthreads();                                    // global writes of this level are visible to the next level's loads
 }
 
 template <int V, int SM>
 __global__ __launch_bounds__(kTailThreads) void tail_kernel(const TailArgs A, int leg) {
-  if (leg == 0) {
-    for (int l = 0; l + 1 < A.n; l++) {
-      const TailLevel &T = A.lv[l];
-      tail_smooth<V, SM>(T, A.e_id, A.R_id, A.a, A.b, A.sweeps);
-      tail_sweep<V, SM_RESIDUAL>(T.L, A.e_id, VECTOR_TEMP, A.R_id, A.a, A.b, T.h2inv, 0.0, 0.0, 0);
-      tail_restrict_cell(A.lv[l + 1].L, A.R_id, T.L, VECTOR_TEMP, T.restrict_list, T.n_restrict);
-      tail_zero(A.lv[l + 1].L, A.e_id);
-    }
-  } else {
-    for (int l = A.n - 2; l >= 0; l--) {
-      const TailLevel &T = A.lv[l];
-      tail_interp_p0(T.L, A.e_id, 1.0, A.lv[l + 1].L, A.e_id, T.interp_list, T.n_interp);
-      tail_smooth<V, SM>(T, A.e_id, A.R_id, A.a, A.b, A.sweeps);
-    }
-  }
+  __shared__ double sx[kTailMaxCells];
+  __shared__ double st[kTailMaxCells];
+  if (leg == 0) { for (int l = 0; l + 1 < A.n; l++) tail_level<V, SM>(A, l, 0, sx, st); }
+  else          { for (int l = A.n - 2; l >= 0; l--) tail_level<V, SM>(A, l, 1, sx, st); }
 }
 
 }  // namespace hpgmg
