@@ -357,7 +357,7 @@ void MGDestroy(mg_type *G) {
 
 void MGResetTimers(mg_type *G) {
   int l;
-  for (l = 0; l < G->num_levels; l++) reset_level_timers(G->levels[l]);
+  for (l = 0; l < G->num_levels; l++) { hpgmg_level_sync_counters(G->levels[l]); reset_level_timers(G->levels[l]); }
   G->timers.MGSolve = 0;
   G->MGSolves_performed = 0;
 }
@@ -399,16 +399,23 @@ void MGVCycle(mg_type *G, int e_id, int R_id, double a, double b, int l) {
   double t;
   if (!L->active) return;
   if (l == G->num_levels - 1) {
-    seg_close();                                   /* the Krylov solver synchronises with the host */
     t = now();
-    IterativeSolver(L, e_id, R_id, a, b, MG_DEFAULT_BOTTOM_NORM);
+    if (!hpgmg_vcycle_legs_fused(&G->levels[l], 1, e_id, R_id, a, b, 3)) {
+      seg_close();                                 /* the host-driven Krylov solver synchronises */
+      IterativeSolver(L, e_id, R_id, a, b, MG_DEFAULT_BOTTOM_NORM);
+    }
     L->timers.Total += now() - t;
     return;
   }
   const int opened_here = is_small(G, l) && !seg_open_now;
   if (is_small(G, l)) seg_open();
-  /* tiny levels: the plugin may run each leg of the rest of this V-cycle as one fused operation */
+  /* tiny levels: the plugin may run the rest of this V-cycle (or each of its legs) as one fused operation */
   t = now();
+  if (hpgmg_vcycle_legs_fused(&G->levels[l], G->num_levels - l, e_id, R_id, a, b, 2)) {
+    L->timers.Total += now() - t;
+    if (opened_here) seg_close();
+    return;
+  }
   if (hpgmg_vcycle_legs_fused(&G->levels[l], G->num_levels - l, e_id, R_id, a, b, 0)) {
     L->timers.Total += now() - t;
     MGVCycle(G, e_id, R_id, a, b, G->num_levels - 1);          /* bottom solve (closes the segment) */
@@ -510,8 +517,8 @@ void FMGSolve(mg_type *G, int onLevel, int u_id, int F_id, double a, double b, d
 
   t = now();
   if (bottom > onLevel) zero_vector(G->levels[bottom], e_id);
-  seg_close();
-  IterativeSolver(G->levels[bottom], e_id, R_id, a, b, MG_DEFAULT_BOTTOM_NORM);
+  if (is_small(G, bottom)) seg_open();
+  MGVCycle(G, e_id, R_id, a, b, bottom);          /* the bottom solve */
   G->levels[bottom]->timers.Total += now() - t;
 
   for (l = bottom - 1; l >= onLevel; l--) {       /* climb: prolong the solution, then one V-cycle */
@@ -537,8 +544,9 @@ void FMGSolve(mg_type *G, int onLevel, int u_id, int F_id, double a, double b, d
 
 /* ------------------------------------------------------------------ timing table */
 void MGPrintTiming(mg_type *G, int fromLevel) {
-  if (G->my_rank != 0 || !hpgmg_verbose) return;
   const int nl = G->num_levels;
+  { int c; for (c = 0; c < nl; c++) hpgmg_level_sync_counters(G->levels[c]); }
+  if (G->my_rank != 0 || !hpgmg_verbose) return;
   const double scale = 1.0 / (double)(G->MGSolves_performed ? G->MGSolves_performed : 1);
   int l;
   printf("\n\n");

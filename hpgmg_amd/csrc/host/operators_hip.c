@@ -84,6 +84,7 @@ typedef struct {
   double  *seen_v0;     int seen_nv, seen_boxes;  /* detects create_vectors() re-allocation */
   struct { const blockCopy_type *host; int n; blockCopy_type *dev; } lists[MAX_LISTS];
   int num_lists;
+  int *krylov_pinned;          /* iterations of device-side bottom solves not yet folded into level->Krylov_iterations */
 } backend_t;
 
 static backend_t *backend_of(level_type *L) {
@@ -175,6 +176,7 @@ void hpgmg_level_release(level_type *L) {
   if (B->d_box_base) hpgmg_hip_free(B->d_box_base);
   if (B->d_box_low) hpgmg_hip_free(B->d_box_low);
   if (B->d_box_nbr) hpgmg_hip_free(B->d_box_nbr);
+  if (B->krylov_pinned) hpgmg_hip_host_free(B->krylov_pinned);
   free(B);
   X->backend = NULL;
 }
@@ -342,22 +344,37 @@ static void cheby_coefficients(const level_type *L, int degree, double *c1, doub
 }
 
 /* Both legs of a V-cycle over a chain of tiny levels in one launch each (kernels/tail.hip). */
+/* fold the iteration counts of device-side bottom solves into level->Krylov_iterations (mg.c:156 prints it) */
+void hpgmg_level_sync_counters(level_type *L) {
+  hpgmg_level_ext *X = hpgmg_level_ext_get(L);
+  backend_t *B = (backend_t *)X->backend;
+  if (!B || !B->krylov_pinned) return;
+  HIP_OK(hpgmg_hip_sync());
+  L->Krylov_iterations += *B->krylov_pinned;
+  *B->krylov_pinned = 0;
+}
+
+/* leg 0/1: the legs around a host-driven bottom solve; leg 2: legs + bottom solve; leg 3: bottom solve only (n == 1) */
 int hpgmg_vcycle_legs_fused(level_type **levels, int n, int e_id, int R_id, double a, double b, int leg) {
-  static int enabled = -1;
+  static int enabled = -1, bottom_enabled = -1;
   hpgmg_config cfg;
   const hpgmg_hip_level *dev[8];
-  const blockCopy_type *rl[8], *il[8];
-  int nr[8], ni[8], l, s;
+  int l, s;
   double h2inv[8], c1[64], c2[64];
   if (enabled < 0) { const char *e = getenv("HPGMG_FUSED_TAIL"); enabled = !(e && e[0] == '0'); }
+  if (bottom_enabled < 0) { const char *e = getenv("HPGMG_FUSED_BOTTOM"); bottom_enabled = !(e && e[0] == '0'); }
   hpgmg_get_config(&cfg);
   const int sweeps = hpgmg_smooth_sweeps();
-  if (!enabled || !ghost_free_mode() || cfg.op != HPGMG_OP_7PT || n < 2 || n > 8 || n > hpgmg_hip_tail_max_levels() || sweeps > 8) return 0;
+  const int with_bottom = (leg >= 2);
+  if (!enabled || !ghost_free_mode() || cfg.op != HPGMG_OP_7PT || n > 8 || n > hpgmg_hip_tail_max_levels() || sweeps > 8) return 0;
+  if (with_bottom && !bottom_enabled) return 0;
+  if (n < (leg == 3 ? 1 : 2)) return 0;
   if (hpgmg_get_transport() && hpgmg_get_transport()->size > 1) return 0;
   for (l = 0; l < n; l++) {
     level_type *L = levels[l];
     backend_t *B = backend_of(L);
-    if (!L->active || L->num_my_boxes < 1) return 0;
+    const long long cells = (long long)L->dim.i * L->dim.j * L->dim.k;
+    if (!L->active || L->num_my_boxes < 1 || !B->all_faces_local) return 0;
     /* the kernel addresses cells by global coordinate: cubic Dirichlet domain, boxes in lexicographic order, halving per level */
     if (L->boundary_condition.type != BC_DIRICHLET || L->dim.i != L->dim.j || L->dim.i != L->dim.k || (sweeps & 1)) return 0;
     if (l > 0 && 2 * L->dim.i != levels[l - 1]->dim.i) return 0;
@@ -371,20 +388,26 @@ int hpgmg_vcycle_legs_fused(level_type **levels, int n, int e_id, int R_id, doub
       }
     }
     if (l + 1 < n) {
-      communicator_type *R = &L->restriction[RESTRICT_CELL], *I = &levels[l + 1]->interpolation;
-      if ((long long)L->dim.i * L->dim.j * L->dim.k > hpgmg_hip_tail_max_cells() || !B->all_faces_local) return 0;
-      if (R->num_blocks[0] || R->num_sends || levels[l + 1]->restriction[RESTRICT_CELL].num_blocks[2]) return 0;
-      if (I->num_blocks[0] || I->num_sends || L->interpolation.num_blocks[2]) return 0;
-      rl[l] = mirror(L, R->blocks[1], R->num_blocks[1]);             nr[l] = R->num_blocks[1];
-      il[l] = mirror(levels[l + 1], I->blocks[1], I->num_blocks[1]); ni[l] = I->num_blocks[1];
+      if (cells > hpgmg_hip_tail_max_cells()) return 0;
       if (L->dominant_eigenvalue_of_DinvA <= 0.0 && cfg.smoother == HPGMG_SMOOTH_CHEBY) return 0;
       cheby_coefficients(L, sweeps, c1 + l * sweeps, c2 + l * sweeps);
-    } else { rl[l] = il[l] = NULL; nr[l] = ni[l] = 0; for (s = 0; s < sweeps; s++) c1[l * sweeps + s] = c2[l * sweeps + s] = 0.0; }
+    } else {
+      for (s = 0; s < sweeps; s++) c1[l * sweeps + s] = c2[l * sweeps + s] = 0.0;
+      if (with_bottom) {
+        /* solvers.c:27-95: Dirichlet never subtracts the mean; the Krylov vectors must exist */
+        if (cells > hpgmg_hip_tail_bottom_max_cells() || L->must_subtract_mean == 1) return 0;
+        if (L->numVectors < hpgmg_vectors_reserved() + IterativeSolver_NumVectors()) return 0;
+        L->must_subtract_mean = 0;
+        if (!B->krylov_pinned) B->krylov_pinned = (int *)hpgmg_hip_host_malloc(64);
+        if (!B->krylov_pinned) return 0;
+      }
+    }
     dev[l] = &B->dev;
     h2inv[l] = 1.0 / (L->h * L->h);
   }
   const double t0 = now();
-  HIP_OK(hpgmg_hip_vcycle_tail(n, dev, h2inv, c1, c2, sweeps, rl, nr, il, ni, variant(), cfg.smoother, e_id, R_id, a, b, leg));
+  HIP_OK(hpgmg_hip_vcycle_tail(n, dev, h2inv, c1, c2, sweeps, variant(), cfg.smoother, e_id, R_id, a, b, leg,
+                               hpgmg_vectors_reserved(), MG_DEFAULT_BOTTOM_NORM, with_bottom ? backend_of(levels[n - 1])->krylov_pinned : NULL));
   levels[0]->timers.smooth += now() - t0;
   return 1;
 }

@@ -35,6 +35,13 @@ void *hpgmg_hip_malloc(size_t bytes) {
   return p;
 }
 void hpgmg_hip_free(void *p) { hpgmg_hip_graph_flush(); if (p) { hipStreamSynchronize(g_stream); (void)hipFree(p); } }
+void *hpgmg_hip_host_malloc(size_t bytes) {
+  void *p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 8, hipHostMallocDefault) != hipSuccess) { record_error(hipErrorOutOfMemory, "hpgmg_hip_host_malloc"); return nullptr; }
+  memset(p, 0, bytes);
+  return p;
+}
+void hpgmg_hip_host_free(void *p) { if (p) { hpgmg_hip_graph_flush(); hipStreamSynchronize(g_stream); (void)hipHostFree(p); } }
 int hpgmg_hip_memcpy_h2d(void *d, const void *s, size_t n) { hpgmg_hip_graph_flush(); HPGMG_CHECK(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, g_stream)); HPGMG_CHECK(hipStreamSynchronize(g_stream)); return 0; }
 int hpgmg_hip_memcpy_d2h(void *d, const void *s, size_t n) { hpgmg_hip_graph_flush(); HPGMG_CHECK(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, g_stream)); HPGMG_CHECK(hipStreamSynchronize(g_stream)); return 0; }
 int hpgmg_hip_memcpy_d2d(void *d, const void *s, size_t n) { hpgmg_hip_graph_flush(); HPGMG_CHECK(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, g_stream)); return 0; }

@@ -31,13 +31,14 @@ struct TailLevel {
   hpgmg_hip_level L;
   double h2inv;
   double c1[kTailMaxSweeps], c2[kTailMaxSweeps];   // Chebyshev coefficients of THIS level (its own eigenvalue bound)
-  const blockCopy_type *restrict_list; int n_restrict;  // local list restricting this level into the next one
-  const blockCopy_type *interp_list;   int n_interp;    // local list (owned by the next level) interpolating into this one
 };
 struct TailArgs {
   int n;                       // levels in the chain, the last one is only restriction target / interpolation source
   int e_id, R_id, sweeps;
   double a, b;
+  int krylov_base;             // first of the 8 BiCGStab work vectors on the bottom level (r0,r,p,q,s,t,Ap,As)
+  double bottom_norm;          // desired reduction of the bottom residual norm
+  int *krylov_iterations;      // pinned host counter (+= iterations done), may be null
   TailLevel lv[kTailMaxLevels];
 };
 
@@ -186,12 +187,153 @@ __device__ void tail_level(const TailArgs &A, int l, int leg, double *sx, double
   __syncthreads();                                    // global writes of this level are visible to the next level's loads
 }
 
+// ---- the bottom solve: diagonally preconditioned BiCGStab (solvers/bicgstab.c:14-97) --------------
+// One cell per lane (<= kBottomMaxCells cells), every vector a register; the vector an operator is
+// applied to passes through LDS for its neighbours.  The operation sequence, the expression of every
+// BLAS-1 step (misc.c: c = sa*a + sb*b, c = s*a*b) and the break-down tests are those of the host
+// driver (host/solvers.c), and the sums keep the reference's order -- one partial per dim x 8 x 8
+// tile accumulated k,j,i, partials added in tile order (misc.c:261-269) -- so the iterates, the
+// iteration count and the coarse correction are bit-identical to the host-driven solve.
+constexpr int kBottomMaxCells = kTailThreads;
+struct BottomGeom { int D, total, c, gi, gj, gk, bd, nb, tiles_side, tiles_per_box, ntiles; bool active; };
+
+__device__ double bottom_dot(const BottomGeom &g, double va, double vb, double *scr) {
+  if (g.active) scr[g.c] = va * vb;
+  __syncthreads();
+  const int t = threadIdx.x;
+  if (t < g.ntiles) {
+    const int box = t / g.tiles_per_box, rem = t % g.tiles_per_box;
+    const int k0 = (rem / g.tiles_side) * BLOCKCOPY_TILE_K, j0 = (rem % g.tiles_side) * BLOCKCOPY_TILE_J;
+    const int k1 = min(k0 + BLOCKCOPY_TILE_K, g.bd), j1 = min(j0 + BLOCKCOPY_TILE_J, g.bd);
+    const int oi = (box % g.nb) * g.bd, oj = ((box / g.nb) % g.nb) * g.bd, ok = (box / (g.nb * g.nb)) * g.bd;
+    double acc = 0.0;
+    for (int k = k0; k < k1; k++) for (int j = j0; j < j1; j++) {
+      const double *row = scr + oi + g.D * ((oj + j) + g.D * (ok + k));
+      for (int i = 0; i < g.bd; i++) acc += row[i];
+    }
+    scr[kBottomMaxCells + t] = acc;
+  }
+  __syncthreads();
+  if (t == 0) { double sum = 0.0; for (int q = 0; q < g.ntiles; q++) sum += scr[kBottomMaxCells + q]; scr[2 * kBottomMaxCells] = sum; }
+  __syncthreads();
+  return scr[2 * kBottomMaxCells];
+}
+__device__ double bottom_norm(const BottomGeom &g, double v, double *scr) {          // max |v| (misc.c:303-349)
+  double m = 0.0;
+  if (g.active) { const double f = fabs(v); m = (f > m) ? f : m; }
+  for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_down(m, off, 64); m = (o > m) ? o : m; }
+  double *w = scr + 2 * kBottomMaxCells + 8;
+  if (threadIdx.x % 64 == 0) w[threadIdx.x / 64] = m;
+  __syncthreads();
+  m = w[0];
+  for (int q = 1; q < kTailThreads / 64; q++) m = (w[q] > m) ? w[q] : m;
+  __syncthreads();
+  return m;
+}
+template <int V>
+__device__ double bottom_apply(const BottomGeom &g, double v, const CellCoef<V> &q, double a, double b, double h2inv, double *sx) {
+  if (g.active) sx[g.c] = v;
+  __syncthreads();
+  double Ax = 0.0;
+  if (g.active) Ax = tail_apply<V>(sx, g.c, g.gi, g.gj, g.gk, g.D, q, a, b, h2inv);
+  __syncthreads();
+  return Ax;
+}
+
+template <int V>
+__device__ void tail_bottom(const TailArgs &A, double *sx, double *scr) {
+  constexpr bool kVC = (V != HPGMG_HIP_7PT_CC);
+  constexpr bool kHelm = (V == HPGMG_HIP_7PT_VC_HELMHOLTZ);
+  const TailLevel &T = A.lv[A.n - 1];
+  const hpgmg_hip_level &L = T.L;
+  BottomGeom g;
+  g.D = L.dim_i; g.total = g.D * g.D * g.D; g.c = threadIdx.x; g.active = g.c < g.total;
+  g.gi = g.c % g.D; g.gj = (g.c / g.D) % g.D; g.gk = g.c / (g.D * g.D);
+  g.bd = L.dim; g.nb = g.D / g.bd;
+  g.tiles_side = (g.bd + BLOCKCOPY_TILE_J - 1) / BLOCKCOPY_TILE_J; g.tiles_per_box = g.tiles_side * g.tiles_side;
+  g.ntiles = g.tiles_per_box * L.num_boxes;
+  const int r0_id = A.krylov_base, r_id = r0_id + 1, p_id = r0_id + 2, q_id = r0_id + 3, s_id = r0_id + 4, t_id = r0_id + 5, Ap_id = r0_id + 6, As_id = r0_id + 7;
+
+  CellCoef<V> cf;
+  cf.bi0 = cf.bi1 = cf.bj0 = cf.bj1 = cf.bk0 = cf.bk1 = cf.al = cf.dinv = cf.rhs = 0.0;
+  CellRef at = {0, 0};
+  double x = 0, r0 = 0, r = 0, p = 0, q = 0, sv = 0, tv = 0, Ap = 0, As = 0, tmp = 0;
+  if (g.active) {
+    at = locate(L, g.gi, g.gj, g.gk);
+    const int box = at.box, ijk = at.ijk, jS = L.jStride, kS = L.kStride;
+    x = vec_origin(L, box, A.e_id)[ijk];
+    cf.rhs = vec_origin(L, box, A.R_id)[ijk];
+    cf.dinv = vec_origin(L, box, VECTOR_DINV)[ijk];
+    if (kVC) {
+      const double *bi = vec_origin(L, box, VECTOR_BETA_I), *bj = vec_origin(L, box, VECTOR_BETA_J), *bk = vec_origin(L, box, VECTOR_BETA_K);
+      cf.bi0 = bi[ijk]; cf.bi1 = bi[ijk + 1]; cf.bj0 = bj[ijk]; cf.bj1 = bj[ijk + jS]; cf.bk0 = bk[ijk]; cf.bk1 = bk[ijk + kS];
+    }
+    if (kHelm) cf.al = vec_origin(L, box, VECTOR_ALPHA)[ijk];
+    // work vectors keep whatever an early exit leaves untouched
+    r0 = vec_origin(L, box, r0_id)[ijk]; r = vec_origin(L, box, r_id)[ijk]; p = vec_origin(L, box, p_id)[ijk]; q = vec_origin(L, box, q_id)[ijk];
+    sv = vec_origin(L, box, s_id)[ijk]; tv = vec_origin(L, box, t_id)[ijk]; Ap = vec_origin(L, box, Ap_id)[ijk]; As = vec_origin(L, box, As_id)[ijk];
+    tmp = vec_origin(L, box, VECTOR_TEMP)[ijk];
+  }
+  const double a = A.a, b = A.b, h2inv = T.h2inv, want = A.bottom_norm;
+
+  r0 = cf.rhs - bottom_apply<V>(g, x, cf, a, b, h2inv, sx);          // residual(r0, x, R)
+  r = 1.0 * r0;
+  p = 1.0 * r0;
+  double rho = bottom_dot(g, r, r0, scr);
+  const double r0_norm = bottom_norm(g, r, scr);
+  int it = 0;
+  if (!(rho == 0.0 || r0_norm == 0.0)) {
+    while (it < 200) {
+      it++;
+      q = 1.0 * cf.dinv * p;
+      Ap = bottom_apply<V>(g, q, cf, a, b, h2inv, sx);
+      const double Ap_r0 = bottom_dot(g, Ap, r0, scr);
+      if (Ap_r0 == 0.0) break;
+      const double alpha = rho / Ap_r0;
+      if (__builtin_isinf(alpha)) break;
+      x = 1.0 * x + alpha * q;
+      sv = 1.0 * r + (-alpha) * Ap;
+      const double s_norm = bottom_norm(g, sv, scr);
+      if (s_norm == 0.0 || s_norm < want * r0_norm) break;
+      tv = 1.0 * cf.dinv * sv;
+      As = bottom_apply<V>(g, tv, cf, a, b, h2inv, sx);
+      const double As_As = bottom_dot(g, As, As, scr);
+      const double As_s = bottom_dot(g, As, sv, scr);
+      if (As_As == 0.0) break;
+      const double omega = As_s / As_As;
+      if (omega == 0.0 || __builtin_isinf(omega)) break;
+      x = 1.0 * x + omega * tv;
+      r = 1.0 * sv + (-omega) * As;
+      const double r_norm = bottom_norm(g, r, scr);
+      if (r_norm == 0.0 || r_norm < want * r0_norm) break;
+      const double rho_new = bottom_dot(g, r, r0, scr);
+      if (rho_new == 0.0) break;
+      const double beta = (rho_new / rho) * (alpha / omega);
+      if (__builtin_isinf(beta)) break;
+      tmp = 1.0 * p + (-omega) * Ap;
+      p = 1.0 * r + beta * tmp;
+      rho = rho_new;
+    }
+  }
+  if (g.active) {
+    const int box = at.box, ijk = at.ijk;
+    vec_origin(L, box, A.e_id)[ijk] = x;
+    vec_origin(L, box, r0_id)[ijk] = r0; vec_origin(L, box, r_id)[ijk] = r; vec_origin(L, box, p_id)[ijk] = p; vec_origin(L, box, q_id)[ijk] = q;
+    vec_origin(L, box, s_id)[ijk] = sv; vec_origin(L, box, t_id)[ijk] = tv; vec_origin(L, box, Ap_id)[ijk] = Ap; vec_origin(L, box, As_id)[ijk] = As;
+    vec_origin(L, box, VECTOR_TEMP)[ijk] = tmp;
+  }
+  if (threadIdx.x == 0 && A.krylov_iterations) *A.krylov_iterations += it;
+  __syncthreads();
+}
+
+// leg 0: down legs | leg 1: up legs | leg 2: down, bottom solve, up | leg 3: bottom solve only
 template <int V, int SM>
 __global__ __launch_bounds__(kTailThreads) void tail_kernel(const TailArgs A, int leg) {
   __shared__ double sx[kTailMaxCells];
   __shared__ double st[kTailMaxCells];
-  if (leg == 0) { for (int l = 0; l + 1 < A.n; l++) tail_level<V, SM>(A, l, 0, sx, st); }
-  else          { for (int l = A.n - 2; l >= 0; l--) tail_level<V, SM>(A, l, 1, sx, st); }
+  if (leg == 0 || leg == 2) { for (int l = 0; l + 1 < A.n; l++) tail_level<V, SM>(A, l, 0, sx, st); }
+  if (leg == 2 || leg == 3) tail_bottom<V>(A, sx, st);
+  if (leg == 1 || leg == 2) { for (int l = A.n - 2; l >= 0; l--) tail_level<V, SM>(A, l, 1, sx, st); }
 }
 
 }  // namespace hpgmg
@@ -200,26 +342,29 @@ using namespace hpgmg;
 extern "C" {
 
 int hpgmg_hip_tail_max_levels(void) { return kTailMaxLevels; }
-int hpgmg_hip_tail_max_cells(void) { return 4096; }
+int hpgmg_hip_tail_max_cells(void) { return kTailMaxCells; }
+int hpgmg_hip_tail_bottom_max_cells(void) { return kBottomMaxCells; }
 
-// levels[0..n-1]: finest..coarsest of the chain; per level h2inv, Chebyshev coefficients (sweeps of them),
-// the LOCAL restriction list into the next level and the LOCAL interpolation list from the next level.
+// levels[0..n-1]: finest..coarsest of the chain; per level h2inv and Chebyshev coefficients (sweeps of them).
+// leg 0/1: the two legs around a host-driven bottom solve; leg 2: legs and bottom solve in one launch;
+// leg 3: the bottom solve alone (n may be 1).
 int hpgmg_hip_vcycle_tail(int n, const hpgmg_hip_level *const *levels, const double *h2inv,
                           const double *c1, const double *c2, int sweeps,
-                          const blockCopy_type *const *restrict_lists, const int *n_restrict,
-                          const blockCopy_type *const *interp_lists, const int *n_interp,
-                          int variant, int smoother, int e_id, int R_id, double a, double b, int leg) {
+                          int variant, int smoother, int e_id, int R_id, double a, double b, int leg,
+                          int krylov_base, double bottom_norm, int *krylov_iterations) {
   HPGMG_SKIP_IF_REPLAY();
-  if (n < 2 || n > kTailMaxLevels || sweeps > kTailMaxSweeps) return record_error(hipErrorInvalidValue, "vcycle_tail: chain too long");
+  if (n < 1 || (n < 2 && leg != 3) || n > kTailMaxLevels || sweeps > kTailMaxSweeps || leg < 0 || leg > 3)
+    return record_error(hipErrorInvalidValue, "vcycle_tail: chain length / leg");
   TailArgs A = {};
   A.n = n; A.e_id = e_id; A.R_id = R_id; A.sweeps = sweeps; A.a = a; A.b = b;
+  A.krylov_base = krylov_base; A.bottom_norm = bottom_norm; A.krylov_iterations = krylov_iterations;
   for (int l = 0; l < n; l++) {
     A.lv[l].L = *levels[l];
     A.lv[l].h2inv = h2inv[l];
     for (int s = 0; s < sweeps; s++) { A.lv[l].c1[s] = c1[l * sweeps + s]; A.lv[l].c2[s] = c2[l * sweeps + s]; }
-    A.lv[l].restrict_list = restrict_lists[l]; A.lv[l].n_restrict = n_restrict[l];
-    A.lv[l].interp_list = interp_lists[l];     A.lv[l].n_interp = n_interp[l];
-    if (l + 1 < n && !levels[l]->box_nbr) return record_error(hipErrorInvalidValue, "vcycle_tail: neighbour table missing");
+    const long long cells = (long long)levels[l]->dim_i * levels[l]->dim_j * levels[l]->dim_k;
+    if (l + 1 < n && cells > kTailMaxCells) return record_error(hipErrorInvalidValue, "vcycle_tail: level too large");
+    if (l + 1 == n && leg >= 2 && cells > kBottomMaxCells) return record_error(hipErrorInvalidValue, "vcycle_tail: bottom level too large");
   }
 #define TAIL_CASE(V, SM) hipLaunchKernelGGL((tail_kernel<V, SM>), dim3(1), dim3(kTailThreads), 0, g_stream, A, leg)
   const int key = variant * 3 + smoother;

@@ -48,6 +48,8 @@ void  *hpgmg_hip_get_stream(void);
 int    hpgmg_hip_sync(void);                        /* hipStreamSynchronize on that stream */
 void  *hpgmg_hip_malloc(size_t bytes);              /* zero-filled device memory, NULL on failure */
 void   hpgmg_hip_free(void *p);
+void  *hpgmg_hip_host_malloc(size_t bytes);         /* zero-filled pinned host memory the device can write, NULL on failure */
+void   hpgmg_hip_host_free(void *p);
 int    hpgmg_hip_memcpy_h2d(void *dst, const void *src, size_t bytes);
 int    hpgmg_hip_memcpy_d2h(void *dst, const void *src, size_t bytes);
 int    hpgmg_hip_memcpy_d2d(void *dst, const void *src, size_t bytes);
@@ -138,12 +140,16 @@ int hpgmg_hip_rebuild_7pt(const hpgmg_hip_level *L, int variable_coeff, int alph
  *      of mg.c:1147-1163 (smooth, residual, restriction, zero_vector | interpolation_vcycle, smooth)
  *      with barriers where the driver has kernel boundaries.  levels[n-1] is the bottom level. ---- */
 int hpgmg_hip_tail_max_levels(void);
-int hpgmg_hip_tail_max_cells(void);
+int hpgmg_hip_tail_max_cells(void);          /* per smoothed level of the chain */
+int hpgmg_hip_tail_bottom_max_cells(void);   /* bottom level, when its BiCGStab solve runs on the device (leg 2, 3) */
+/* leg 0 / 1: down / up legs around a host-driven bottom solve;  leg 2: down legs, the bottom solve
+ * (diagonally preconditioned BiCGStab, solvers/bicgstab.c:14-97, work vectors krylov_base..+7, stop at
+ * bottom_norm relative reduction), up legs -- one launch;  leg 3: the bottom solve alone (n >= 1).
+ * krylov_iterations: device-visible host counter the kernel adds its iteration count to, or NULL. */
 int hpgmg_hip_vcycle_tail(int n, const hpgmg_hip_level *const *levels, const double *h2inv,
                           const double *c1, const double *c2, int sweeps,
-                          const blockCopy_type *const *restrict_lists, const int *n_restrict,
-                          const blockCopy_type *const *interp_lists, const int *n_interp,
-                          int variant, int smoother, int e_id, int R_id, double a, double b, int leg);
+                          int variant, int smoother, int e_id, int R_id, double a, double b, int leg,
+                          int krylov_base, double bottom_norm, int *krylov_iterations);
 
 /* ---- hipGraph segments (graph.hip): capture/replay of the launch-bound small-level part of a cycle.
  *      begin(key): first use of a key runs eagerly, second is captured, later ones are replayed

@@ -110,13 +110,16 @@ void    hpgmg_vector_download(double *dst_host, const double *src_plugin, size_t
  * such a mechanism implement these as no-ops.  A reduction (norm/dot/mean) ends an open segment. */
 void    hpgmg_segment_begin(long long key);
 void    hpgmg_segment_end(void);
-/* Optional fused form of MGVCycle's two legs (mg.c:1147-1163) over the chain levels[0..n-1]
- * (finest first, levels[n-1] = bottom level, untouched except as restriction target /
- * interpolation source).  leg 0: smooth, residual, restriction, zero_vector per level going
- * down; leg 1: interpolation_vcycle, smooth per level going up.  Returns 1 when the plugin
- * executed it (bit-identical to the per-operator sequence), 0 when it cannot -- the driver
- * then issues the operators one by one. */
+/* Optional fused form of MGVCycle (mg.c:1147-1163) over the chain levels[0..n-1] (finest first,
+ * levels[n-1] = bottom level).  leg 0: smooth, residual, restriction, zero_vector per level going
+ * down; leg 1: interpolation_vcycle, smooth per level going up (the driver runs IterativeSolver on
+ * the bottom level between the two); leg 2: leg 0, the bottom solve (solvers.c:27-95, BiCGStab to
+ * MG_DEFAULT_BOTTOM_NORM), leg 1; leg 3: the bottom solve alone (n == 1).  Returns 1 when the plugin
+ * executed it (bit-identical to the per-operator sequence), 0 when it cannot -- the driver then
+ * issues the operators one by one. */
 int     hpgmg_vcycle_legs_fused(level_type **levels, int n, int e_id, int R_id, double a, double b, int leg);
+/* bring level->Krylov_iterations up to date with bottom solves the plugin ran asynchronously */
+void    hpgmg_level_sync_counters(level_type *level);
 /* called by destroy_level / MGDestroy so the plugin can drop device mirrors */
 void    hpgmg_level_release(level_type *level);
 const char *hpgmg_backend_name(void);                      /* "hip" or "oracle-cpu" */
