@@ -76,6 +76,17 @@ __device__ __forceinline__ double wave_max(double v) {
   for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_down(v, off, 64); v = (o > v) ? o : v; }
   return v;
 }
+__device__ __forceinline__ void block_max_store_at(double v, double *partials, int slot) {
+  __shared__ double smem[kRowsPerBlock];
+  v = wave_max(v);
+  if (threadIdx.x % 64 == 0) smem[threadIdx.x / 64] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double m = smem[0];
+    for (int w = 1; w < kRowsPerBlock; w++) m = (smem[w] > m) ? smem[w] : m;
+    partials[slot] = m;
+  }
+}
 __device__ __forceinline__ void block_max_store(double v, double *partials) {
   __shared__ double smem[kRowsPerBlock];
   v = wave_max(v);
@@ -88,15 +99,32 @@ __device__ __forceinline__ void block_max_store(double v, double *partials) {
   }
 }
 
-__global__ __launch_bounds__(256) void absmax_kernel(const hpgmg_hip_level L, int id, double *partials) {
-  RowIter r;
-  const int row = blockIdx.x * kRowsPerBlock + threadIdx.x / 64, lane = threadIdx.x % 64;
+// grid = (workgroups per box, boxes); each wave strides over the rows of its box with four rows in flight;
+// block maxima go to `partials` (the last workgroup to finish folds them and publishes the result)
+__device__ __forceinline__ double absmax_rows(const hpgmg_hip_level &L, int id) {
+  const int dim = L.dim, rows = dim * dim, lane = threadIdx.x % 64;
+  const int wave = blockIdx.x * kRowsPerBlock + threadIdx.x / 64, waves = gridDim.x * kRowsPerBlock;
+  const int sh = ((dim & (dim - 1)) == 0) ? __builtin_ctz(dim) : -1;
+  const double *base = vec_origin(L, blockIdx.y, id);
   double m = 0.0;
-  if (row_of(row, L.dim, L.num_boxes, r)) {
-    const double *p = vec_origin(L, r.box, id) + r.j * L.jStride + r.k * L.kStride;
-    for (int i = lane; i < L.dim; i += 64) { const double f = fabs(p[i]); m = (f > m) ? f : m; }
+  for (int row0 = wave; row0 < rows; row0 += 4 * waves) {
+    const double *p[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      int row = row0 + u * waves;
+      row = (row < rows) ? row : row0;                          // a repeated row does not change a maximum
+      const int k = (sh >= 0) ? (row >> sh) : (row / dim), j = row - k * dim;
+      p[u] = base + j * L.jStride + k * L.kStride;
+    }
+    for (int i = lane; i < dim; i += 64) {
+      double f[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) f[u] = fabs(p[u][i]);
+#pragma unroll
+      for (int u = 0; u < 4; u++) m = (f[u] > m) ? f[u] : m;
+    }
   }
-  block_max_store(m, partials);
+  return m;
 }
 
 // Scalar results go straight to a pinned host slot {value, sequence}: the last lane stores the value,
@@ -124,6 +152,12 @@ __global__ __launch_bounds__(256) void absmax_small_kernel(const hpgmg_hip_level
   if (lane == 0) smem[threadIdx.x / 64] = m;
   __syncthreads();
   if (threadIdx.x == 0) { for (int w = 1; w < 4; w++) m = (smem[w] > m) ? smem[w] : m; publish(result, m, seq); }
+}
+
+// (a single-launch "last workgroup folds" variant was measured 4x slower: the agent-scope fence each
+// workgroup needs before signalling costs an L2 write-back on a multi-XCD part; a second tiny launch is cheaper)
+__global__ __launch_bounds__(256) void absmax_kernel(const hpgmg_hip_level L, int id, double *partials) {
+  block_max_store_at(absmax_rows(L, id), partials, blockIdx.x + gridDim.x * blockIdx.y);
 }
 
 __global__ __launch_bounds__(256) void final_max_kernel(const double *partials, int n, double init, ResultSlot *result, unsigned long long seq) {
@@ -325,8 +359,11 @@ int hpgmg_hip_norm_max(const hpgmg_hip_level *L, int id, double *out) {
   if (nblk <= 64) {
     hipLaunchKernelGGL(absmax_small_kernel, dim3(1), dim3(256), 0, g_stream, *L, id, g_result_dev, ++g_seq);
   } else {
-    hipLaunchKernelGGL(absmax_kernel, dim3(nblk), dim3(256), 0, g_stream, *L, id, g_scratch);
-    hipLaunchKernelGGL(final_max_kernel, dim3(1), dim3(256), 0, g_stream, (const double *)g_scratch, nblk, 0.0, g_result_dev, ++g_seq);
+    // ~16 workgroups per CU over the whole level, each wave streaming several rows of one box
+    int per_box = rows_grid(L->dim * L->dim);
+    while (per_box > 1 && (long long)per_box * L->num_boxes > 4096) per_box = (per_box + 1) / 2;
+    hipLaunchKernelGGL(absmax_kernel, dim3(per_box, L->num_boxes), dim3(256), 0, g_stream, *L, id, g_scratch);
+    hipLaunchKernelGGL(final_max_kernel, dim3(1), dim3(256), 0, g_stream, (const double *)g_scratch, per_box * L->num_boxes, 0.0, g_result_dev, ++g_seq);
   }
   HPGMG_LAUNCH_CHECK("norm_max");
   return fetch_result(out);

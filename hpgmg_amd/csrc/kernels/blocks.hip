@@ -322,31 +322,62 @@ __global__ __launch_bounds__(256) void restrict_blocks_kernel(const hpgmg_hip_le
   }
 }
 
+// interpolation_p0.c:43 (ORDER 0, piecewise constant) and interpolation_p1.c:40-70 (ORDER 1, trilinear).
+// One wave per COARSE row of an entry (grid.y strides over the rows), one coarse cell per lane: the lane
+// produces the cell's 2x2x2 children, each fine row as one 16-byte read-modify-write when the layout allows.
+// The per-child expression (prescale*fine + weighted coarse neighbours, in the reference's order) is unchanged.
 template <int ORDER>
 __global__ __launch_bounds__(256) void interp_blocks_kernel(const hpgmg_hip_level Lf, int id_f, double prescale, const hpgmg_hip_level Lc, int id_c,
                                                             const blockCopy_type *__restrict__ list) {
   const blockCopy_type &e = list[blockIdx.x];
   const Side r = resolve_read(Lc, id_c, e), w = resolve_write(Lf, id_f, e);
-  const int di = 2 * e.dim.i, dj = 2 * e.dim.j, n = di * dj * 2 * e.dim.k, rj = r.jS, rk = r.kS;
-  for (int t = threadIdx.x; t < n; t += blockDim.x) {
-    const int i = t % di, j = (t / di) % dj, k = t / (di * dj);
-    double *fw = &w.p[i + j * w.jS + k * w.kS];
-    const double *c = r.p + (i >> 1) + (j >> 1) * rj + (k >> 1) * rk;
-    double v = prescale * (*fw);
-    if (ORDER == 0) {
-      v = v + c[0];
-    } else {  // even fine cell leans on the coarse neighbour behind it, odd on the one ahead
-      const int oi = (i & 1) ? 1 : -1, oj = (j & 1) ? rj : -rj, ok = (k & 1) ? rk : -rk;
-      v = v + 0.421875 * c[0];
-      v = v + 0.140625 * c[ok];
-      v = v + 0.140625 * c[oj];
-      v = v + 0.046875 * c[oj + ok];
-      v = v + 0.140625 * c[oi];
-      v = v + 0.046875 * c[oi + ok];
-      v = v + 0.046875 * c[oi + oj];
-      v = v + 0.015625 * c[oi + oj + ok];
+  const int ci_n = e.dim.i, cj_n = e.dim.j, rows = cj_n * e.dim.k, rj = r.jS, rk = r.kS;
+  const bool pairs = (e.write.box >= 0) && (Lf.flags & 1);      // fine pairs (2ci, 2ci+1) are 16-byte aligned
+  const int lane = threadIdx.x % 64;
+  for (int row = blockIdx.y * 4 + threadIdx.x / 64; row < rows; row += gridDim.y * 4) {
+    const int ck = row / cj_n, cj = row - ck * cj_n;
+    const double *crow = r.p + cj * rj + ck * rk;
+    double *frow = w.p + 2 * cj * w.jS + 2 * ck * w.kS;
+    for (int ci = lane; ci < ci_n; ci += 64) {
+      const double *c = crow + ci;
+      double nb[3][3][3];                                       // [dk][dj][di], offsets -1,0,+1 (ORDER 1 only)
+      if (ORDER == 1) {
+#pragma unroll
+        for (int dk = 0; dk < 3; dk++)
+#pragma unroll
+          for (int dj = 0; dj < 3; dj++)
+#pragma unroll
+            for (int di = 0; di < 3; di++) nb[dk][dj][di] = c[(di - 1) + (dj - 1) * rj + (dk - 1) * rk];
+      } else nb[1][1][1] = c[0];
+#pragma unroll
+      for (int fk = 0; fk < 2; fk++) {
+#pragma unroll
+        for (int fj = 0; fj < 2; fj++) {
+          double *fw = frow + 2 * ci + fj * w.jS + fk * w.kS;
+          double f0, f1;
+          if (pairs) { const double2 t = *reinterpret_cast<const double2 *>(fw); f0 = t.x; f1 = t.y; }
+          else { f0 = fw[0]; f1 = fw[1]; }
+          double v[2] = { prescale * f0, prescale * f1 };
+#pragma unroll
+          for (int fi = 0; fi < 2; fi++) {
+            if (ORDER == 0) v[fi] = v[fi] + nb[1][1][1];
+            else {  // an even fine cell leans on the coarse neighbour behind it, an odd one on the one ahead
+              const int oi = fi ? 2 : 0, oj = fj ? 2 : 0, ok = fk ? 2 : 0;
+              v[fi] = v[fi] + 0.421875 * nb[1][1][1];
+              v[fi] = v[fi] + 0.140625 * nb[ok][1][1];
+              v[fi] = v[fi] + 0.140625 * nb[1][oj][1];
+              v[fi] = v[fi] + 0.046875 * nb[ok][oj][1];
+              v[fi] = v[fi] + 0.140625 * nb[1][1][oi];
+              v[fi] = v[fi] + 0.046875 * nb[ok][1][oi];
+              v[fi] = v[fi] + 0.046875 * nb[1][oj][oi];
+              v[fi] = v[fi] + 0.015625 * nb[ok][oj][oi];
+            }
+          }
+          if (pairs) *reinterpret_cast<double2 *>(fw) = make_double2(v[0], v[1]);
+          else { fw[0] = v[0]; fw[1] = v[1]; }
+        }
+      }
     }
-    *fw = v;
   }
 }
 
@@ -422,8 +453,10 @@ int hpgmg_hip_interpolate_blocks(const hpgmg_hip_level *Lf, int id_f, double pre
                                  const blockCopy_type *blocks, int n, int order) {
   HPGMG_SKIP_IF_REPLAY();
   if (n <= 0) return 0;
-  if (order == 0) hipLaunchKernelGGL((interp_blocks_kernel<0>), dim3(n), dim3(256), 0, g_stream, *Lf, id_f, prescale, *Lc, id_c, blocks);
-  else if (order == 1) hipLaunchKernelGGL((interp_blocks_kernel<1>), dim3(n), dim3(256), 0, g_stream, *Lf, id_f, prescale, *Lc, id_c, blocks);
+  // entries are whole coarse tiles; spread each over enough workgroups to fill the chip (4 coarse rows per workgroup pass)
+  const int slabs = n >= 4096 ? 1 : (4096 / n > 64 ? 64 : 4096 / n);
+  if (order == 0) hipLaunchKernelGGL((interp_blocks_kernel<0>), dim3(n, slabs), dim3(256), 0, g_stream, *Lf, id_f, prescale, *Lc, id_c, blocks);
+  else if (order == 1) hipLaunchKernelGGL((interp_blocks_kernel<1>), dim3(n, slabs), dim3(256), 0, g_stream, *Lf, id_f, prescale, *Lc, id_c, blocks);
   else if (order == 2) hipLaunchKernelGGL((interp_tensor_kernel<2>), dim3(n), dim3(256), 0, g_stream, *Lf, id_f, prescale, *Lc, id_c, blocks);
   else if (order == 3) hipLaunchKernelGGL((interp_tensor_kernel<3>), dim3(n), dim3(256), 0, g_stream, *Lf, id_f, prescale, *Lc, id_c, blocks);
   else if (order == 4) hipLaunchKernelGGL((interp_tensor_kernel<4>), dim3(n), dim3(256), 0, g_stream, *Lf, id_f, prescale, *Lc, id_c, blocks);

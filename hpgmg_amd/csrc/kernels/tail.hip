@@ -54,13 +54,23 @@ enum { SM_CHEBY = 0, SM_GSRB = 1, SM_JACOBI = 2, SM_RESIDUAL = 3 };
 constexpr int kCellsPerLane = 4;                    // 4096 cells / 1024 lanes
 constexpr int kTailMaxCells = kCellsPerLane * kTailThreads;
 
+// dimensions are almost always powers of two: divide by shifting then (a wave-uniform choice), since an
+// integer division costs ~40 instructions and a level visit needs a dozen per cell
+struct IDiv { int d, sh; };
+__device__ __forceinline__ IDiv idiv_of(int d) { IDiv r; r.d = d; r.sh = (d > 0 && (d & (d - 1)) == 0) ? __builtin_ctz(d) : -1; return r; }
+__device__ __forceinline__ int operator/(int x, const IDiv &D) { return D.sh >= 0 ? (x >> D.sh) : (x / D.d); }
+__device__ __forceinline__ int operator%(int x, const IDiv &D) { return D.sh >= 0 ? (x & (D.d - 1)) : (x % D.d); }
+
 struct CellRef { int box, ijk; };                    // where a global cell lives in the boxed layout
-__device__ __forceinline__ CellRef locate(const hpgmg_hip_level &L, int gi, int gj, int gk) {
-  const int bd = L.dim, nb = L.dim_i / bd;
-  const int bi = gi / bd, bj = gj / bd, bk = gk / bd;
+struct LevelGeom { IDiv D, bd, nb; int jS, kS; };
+__device__ __forceinline__ LevelGeom geom_of(const hpgmg_hip_level &L) {
+  LevelGeom G; G.D = idiv_of(L.dim_i); G.bd = idiv_of(L.dim); G.nb = idiv_of(L.dim_i / G.bd); G.jS = L.jStride; G.kS = L.kStride; return G;
+}
+__device__ __forceinline__ CellRef locate(const LevelGeom &G, int gi, int gj, int gk) {
+  const int bi = gi / G.bd, bj = gj / G.bd, bk = gk / G.bd;
   CellRef r;
-  r.box = bi + nb * (bj + nb * bk);
-  r.ijk = (gi - bi * bd) + (gj - bj * bd) * L.jStride + (gk - bk * bd) * L.kStride;
+  r.box = bi + G.nb.d * (bj + G.nb.d * bk);
+  r.ijk = (gi - bi * G.bd.d) + (gj - bj * G.bd.d) * G.jS + (gk - bk * G.bd.d) * G.kS;
   return r;
 }
 
@@ -90,6 +100,7 @@ __device__ void tail_level(const TailArgs &A, int l, int leg, double *sx, double
   const TailLevel &T = A.lv[l];
   const hpgmg_hip_level &L = T.L;
   const int D = L.dim_i, total = D * D * D;
+  const LevelGeom G = geom_of(L);
   CellCoef<V> q[kCellsPerLane];
   int gi[kCellsPerLane], gj[kCellsPerLane], gk[kCellsPerLane];
   CellRef where[kCellsPerLane];
@@ -98,13 +109,13 @@ __device__ void tail_level(const TailArgs &A, int l, int leg, double *sx, double
   for (int m = 0; m < kCellsPerLane; m++) {
     const int c = threadIdx.x + m * kTailThreads;
     if (c < total) {
-      gi[m] = c % D; gj[m] = (c / D) % D; gk[m] = c / (D * D);
-      where[m] = locate(L, gi[m], gj[m], gk[m]);
+      { const int cj = c / G.D; gi[m] = c % G.D; gj[m] = cj % G.D; gk[m] = cj / G.D; }
+      where[m] = locate(G, gi[m], gj[m], gk[m]);
       const int box = where[m].box, ijk = where[m].ijk, jS = L.jStride, kS = L.kStride;
       double e = vec_origin(L, box, A.e_id)[ijk];
       if (leg == 1) {          // interpolation_vcycle: e = 1.0*e + (coarse parent), interpolation_p0.c:43
         const hpgmg_hip_level &C = A.lv[l + 1].L;
-        const CellRef p = locate(C, gi[m] >> 1, gj[m] >> 1, gk[m] >> 1);
+        const CellRef p = locate(geom_of(C), gi[m] >> 1, gj[m] >> 1, gk[m] >> 1);
         e = 1.0 * e + vec_origin(C, p.box, A.e_id)[p.ijk];
       }
       sx[c] = e;
@@ -168,20 +179,20 @@ __device__ void tail_level(const TailArgs &A, int l, int leg, double *sx, double
   if (leg == 0) {
     // restriction(next.R <- TEMP): 0.125 * sum of the 8 children in the reference's order (restriction.c:54-57)
     const hpgmg_hip_level &C = A.lv[l + 1].L;
+    const LevelGeom GC = geom_of(C);
     const int Dc = D / 2, totc = Dc * Dc * Dc;
     for (int c = threadIdx.x; c < totc; c += kTailThreads) {
-      const int ci = c % Dc, cj = (c / Dc) % Dc, ck = c / (Dc * Dc);
+      const int cjk = c / GC.D, ci = c % GC.D, cj = cjk % GC.D, ck = cjk / GC.D;
       const double *f = st + 2 * ci + 2 * cj * D + 2 * ck * D * D;
       double v = f[0] + f[1]; v = v + f[D]; v = v + f[1 + D]; v = v + f[D * D]; v = v + f[1 + D * D]; v = v + f[D + D * D]; v = v + f[1 + D + D * D];
-      const CellRef p = locate(C, ci, cj, ck);
+      const CellRef p = locate(GC, ci, cj, ck);
       vec_origin(C, p.box, A.R_id)[p.ijk] = v * 0.125;
     }
-    // zero_vector(next.e): whole padded boxes, ghosts included (misc.c:6-44)
-    const int side = C.dim + 2 * C.ghosts, per_box = side * side * side, all = per_box * C.num_boxes;
-    for (int c = threadIdx.x; c < all; c += kTailThreads) {
-      const int box = c / per_box, r = c - box * per_box;
-      const int k = r / (side * side), j = (r / side) % side, i = r % side;
-      (C.box_base[box] + (size_t)A.e_id * (size_t)C.volume)[i + j * C.jStride + k * C.kStride] = 0.0;
+    // zero_vector(next.e): the whole padded box, ghosts included (misc.c:6-44); the alignment padding between
+    // rows is never read and was zero-filled at allocation, so the box's slab is cleared as one contiguous run
+    for (int box = 0; box < C.num_boxes; box++) {
+      double *z = C.box_base[box] + (size_t)A.e_id * (size_t)C.volume;
+      for (int c = threadIdx.x; c < C.volume; c += kTailThreads) z[c] = 0.0;
     }
   }
   __syncthreads();                                    // global writes of this level are visible to the next level's loads
@@ -248,8 +259,9 @@ __device__ void tail_bottom(const TailArgs &A, double *sx, double *scr) {
   const hpgmg_hip_level &L = T.L;
   BottomGeom g;
   g.D = L.dim_i; g.total = g.D * g.D * g.D; g.c = threadIdx.x; g.active = g.c < g.total;
-  g.gi = g.c % g.D; g.gj = (g.c / g.D) % g.D; g.gk = g.c / (g.D * g.D);
-  g.bd = L.dim; g.nb = g.D / g.bd;
+  const LevelGeom G = geom_of(L);
+  { const int cj = g.c / G.D; g.gi = g.c % G.D; g.gj = cj % G.D; g.gk = cj / G.D; }
+  g.bd = L.dim; g.nb = G.nb.d;
   g.tiles_side = (g.bd + BLOCKCOPY_TILE_J - 1) / BLOCKCOPY_TILE_J; g.tiles_per_box = g.tiles_side * g.tiles_side;
   g.ntiles = g.tiles_per_box * L.num_boxes;
   const int r0_id = A.krylov_base, r_id = r0_id + 1, p_id = r0_id + 2, q_id = r0_id + 3, s_id = r0_id + 4, t_id = r0_id + 5, Ap_id = r0_id + 6, As_id = r0_id + 7;
@@ -259,7 +271,7 @@ __device__ void tail_bottom(const TailArgs &A, double *sx, double *scr) {
   CellRef at = {0, 0};
   double x = 0, r0 = 0, r = 0, p = 0, q = 0, sv = 0, tv = 0, Ap = 0, As = 0, tmp = 0;
   if (g.active) {
-    at = locate(L, g.gi, g.gj, g.gk);
+    at = locate(G, g.gi, g.gj, g.gk);
     const int box = at.box, ijk = at.ijk, jS = L.jStride, kS = L.kStride;
     x = vec_origin(L, box, A.e_id)[ijk];
     cf.rhs = vec_origin(L, box, A.R_id)[ijk];

@@ -1,6 +1,3 @@
-export OMP_NUM_THREADS=16 OMP_WAIT_POLICY=passive
-timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -5
-for args in "--helmholtz 7 8" "--smoother gsrb 7 8" "--const-coeff 7 8"; do
-  echo "[$args]"; timeout 120 hpgmg_amd/bin/hpgmg-fv $args --warmup 3 --solves 20 2>&1 | grep -E "DOF/s|Bottom solver"
-done
-echo "[bottom off]"; HPGMG_FUSED_BOTTOM=0 timeout 120 hpgmg_amd/bin/hpgmg-fv --helmholtz 7 8 --warmup 3 --solves 20 2>&1 | grep -E "DOF/s|Bottom solver"
+cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
+rm -rf gpurun_out/prof_c; mkdir -p gpurun_out
+timeout 300 rocprofv3 --kernel-trace -d gpurun_out/prof_c -o kt -- hpgmg_amd/bin/hpgmg-fv --helmholtz 7 8 --warmup 2 --solves 10 > gpurun_out/prof_c.log 2>&1 </dev/null
