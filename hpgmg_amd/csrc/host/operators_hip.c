@@ -369,7 +369,8 @@ int hpgmg_vcycle_legs_fused(level_type **levels, int n, int e_id, int R_id, doub
   if (!enabled || !ghost_free_mode() || cfg.op != HPGMG_OP_7PT || n > 8 || n > hpgmg_hip_tail_max_levels() || sweeps > 8) return 0;
   if (with_bottom && !bottom_enabled) return 0;
   if (n < (leg == 3 ? 1 : 2)) return 0;
-  if (hpgmg_get_transport() && hpgmg_get_transport()->size > 1) return 0;
+  /* multi-rank jobs: the chain qualifies when this rank owns every box of every level in it (checked below), which is
+   * how the coarse levels end up after agglomeration onto rank 0 -- no message and no all-reduce is needed then */
   for (l = 0; l < n; l++) {
     level_type *L = levels[l];
     backend_t *B = backend_of(L);

@@ -129,21 +129,27 @@ __global__ __launch_bounds__(256) void stencil7_kernel(const hpgmg_hip_level L, 
 // ---------------------------------------------------------------------------------------------
 // Wide kernel for boxes whose side is a multiple of 128 (the bandwidth-critical fine levels).
 // Each lane owns a 2 (i) x 2 (j) patch: a wave covers two full 128-cell rows with 16-byte loads
-// (1 KiB per wave-instruction, the coalescing sweet spot), a 64x4 workgroup covers 8 rows and
-// marches in +k.  Per plane and per 4 cells a lane issues 4 x 16 B of x (the two k+1 centres and
-// the rows above / below the patch; the row in between comes from the partner row's registers)
-// instead of 12 x 8 B, and every coefficient stream as 16-byte loads: half the memory
-// instructions of the generic kernel and a third less L1 traffic for x.  Interior rows are
-// 16-byte aligned because jStride and kStride are even and the first interior cell is 32-byte
-// aligned (create_vectors); the launcher checks this and otherwise uses the generic kernel.
+// (1 KiB per wave-instruction, the coalescing sweet spot); a 64 x WJ workgroup covers 2*WJ rows
+// and marches in +k.  Every cell of x is fetched from memory ONCE per workgroup:
+//   * k neighbours: the plane k+1 loaded this step is the centre of the next (registers);
+//   * j neighbours: the rows owned by the waves above / below come from an LDS copy of the plane
+//     (each wave deposits the plane k+1 rows it just loaded; double buffered, one barrier per step);
+//     only the two rows outside the workgroup's slab are read from memory;
+//   * i neighbours: the neighbouring lane's registers (wave shuffle); lanes 0 / 63 sit on the tile edge.
+// (Measured on MI355X: re-reading those neighbours through L1/L2, as the first version did, made the
+// L2 miss traffic 10.1 streams per cell instead of 8.4 -- 32 KiB of L1 and 4 MiB of L2 per XCD do not
+// hold a plane step of 128 resident workgroups.)
+// Interior rows are 16-byte aligned because jStride and kStride are even and the first interior cell
+// is 32-byte aligned (create_vectors); the launcher checks this and otherwise uses the generic kernel.
 // GSRB: the two cells of a row always have different colours, so every lane updates exactly one
 // cell per row (no idle lanes) and stores 8 bytes.
 struct alignas(16) d2 { double x, y; };
 __device__ __forceinline__ d2 ld2(const double *p) { return *reinterpret_cast<const d2 *>(p); }
 __device__ __forceinline__ void st2(double *p, d2 v) { *reinterpret_cast<d2 *>(p) = v; }
 
-template <int V, int MODE>
-__global__ __launch_bounds__(256) void stencil7_wide_kernel(const hpgmg_hip_level L, const StencilArgs P) {
+template <int V, int MODE, int WJ>
+__global__ __launch_bounds__(64 * WJ) void stencil7_wide_kernel(const hpgmg_hip_level L, const StencilArgs P) {
+  __shared__ d2 slab[2][2 * WJ][64];                          // plane copy: [buffer][row of the slab][i pair]
   const int logical = xcd_logical_block((int)blockIdx.x, P.per_xcd);
   if (logical >= P.total_blocks) return;
   int t = logical;
@@ -152,8 +158,9 @@ __global__ __launch_bounds__(256) void stencil7_wide_kernel(const hpgmg_hip_leve
   const int ck = t % P.chunks_k; t /= P.chunks_k;
   const int box = t;
 
-  const int i = ti * 128 + 2 * (int)threadIdx.x;            // cells i, i+1
-  const int ja = tj * 8 + 2 * (int)threadIdx.y;             // rows ja, ja+1
+  const int lane = (int)threadIdx.x, ty = (int)threadIdx.y;
+  const int i = ti * 128 + 2 * lane;                         // cells i, i+1
+  const int ja = tj * (2 * WJ) + 2 * ty;                     // rows ja, ja+1
   const int k0 = ck * P.kchunk, k1 = (k0 + P.kchunk < L.dim) ? k0 + P.kchunk : L.dim;
   const int jS = L.jStride, kS = L.kStride, last = L.dim - 1;
 
@@ -194,6 +201,9 @@ __global__ __launch_bounds__(256) void stencil7_wide_kernel(const hpgmg_hip_leve
   d2 xm_b = (gf && k0 == 0) ? outside2(4, i + (ja + 1) * jS + last * kS, ia + jS - kS, xc_b) : ld2(x + ia + jS - kS);
   d2 bk0_a = {0, 0}, bk0_b = {0, 0};
   if (kVC) { bk0_a = ld2(beta_k + ia); bk0_b = ld2(beta_k + ia + jS); }
+  slab[k0 & 1][2 * ty][lane] = xc_a;
+  slab[k0 & 1][2 * ty + 1][lane] = xc_b;
+  __syncthreads();
 
   for (int k = k0; k < k1; k++, ia += kS) {
     const int ib = ia + jS;
@@ -201,33 +211,45 @@ __global__ __launch_bounds__(256) void stencil7_wide_kernel(const hpgmg_hip_leve
     const d2 xp_b = (gf && k == last) ? outside2(5, i + (ja + 1) * jS, ib + kS, xc_b) : ld2(x + ib + kS);
     d2 bk1_a = {0, 0}, bk1_b = {0, 0};
     if (kVC) { bk1_a = ld2(beta_k + ia + kS); bk1_b = ld2(beta_k + ib + kS); }
-    // rows above and below the 2-row patch; the row between them is the partner row itself
-    const d2 xjm_a = (gf && ja == 0)        ? outside2(2, i + last * jS + k * kS, ia - jS, xc_a) : ld2(x + ia - jS);
-    const d2 xjp_b = (gf && ja + 1 == last) ? outside2(3, i + k * kS, ib + jS, xc_b)             : ld2(x + ib + jS);
-    // i neighbours of the pair: the cell left of .x and the cell right of .y
-    const double xl_a = (gf && i == 0)        ? outside1(0, last + ja * jS + k * kS, ia - 1, xc_a.x)       : x[ia - 1];
-    const double xl_b = (gf && i == 0)        ? outside1(0, last + (ja + 1) * jS + k * kS, ib - 1, xc_b.x) : x[ib - 1];
-    const double xr_a = (gf && i + 1 == last) ? outside1(1, ja * jS + k * kS, ia + 2, xc_a.y)              : x[ia + 2];
-    const double xr_b = (gf && i + 1 == last) ? outside1(1, (ja + 1) * jS + k * kS, ib + 2, xc_b.y)        : x[ib + 2];
+    // rows above and below the 2-row patch: the neighbouring wave's rows (LDS) or, at the slab edge, memory
+    d2 xjm_a, xjp_b;
+    if (ty > 0) xjm_a = slab[k & 1][2 * ty - 1][lane];
+    else        xjm_a = (gf && ja == 0) ? outside2(2, i + last * jS + k * kS, ia - jS, xc_a) : ld2(x + ia - jS);
+    if (ty < WJ - 1) xjp_b = slab[k & 1][2 * ty + 2][lane];
+    else             xjp_b = (gf && ja + 1 == last) ? outside2(3, i + k * kS, ib + jS, xc_b) : ld2(x + ib + jS);
+    // i neighbours of the pair: the cell left of .x and the cell right of .y live in the adjacent lanes
+    double xl_a = __shfl_up(xc_a.y, 1, 64), xl_b = __shfl_up(xc_b.y, 1, 64);
+    double xr_a = __shfl_down(xc_a.x, 1, 64), xr_b = __shfl_down(xc_b.x, 1, 64);
+    if (lane == 0) {
+      xl_a = (gf && i == 0) ? outside1(0, last + ja * jS + k * kS, ia - 1, xc_a.x)       : x[ia - 1];
+      xl_b = (gf && i == 0) ? outside1(0, last + (ja + 1) * jS + k * kS, ib - 1, xc_b.x) : x[ib - 1];
+    }
+    if (lane == 63) {
+      xr_a = (gf && i + 1 == last) ? outside1(1, ja * jS + k * kS, ia + 2, xc_a.y)       : x[ia + 2];
+      xr_b = (gf && i + 1 == last) ? outside1(1, (ja + 1) * jS + k * kS, ib + 2, xc_b.y) : x[ib + 2];
+    }
+    // beta_j on the face between the two rows serves both (upper face of row a, lower face of row b)
+    d2 bj_lo = {0, 0}, bj_mid = {0, 0}, bj_hi = {0, 0};
+    if (kVC) { bj_lo = ld2(beta_j + ia); bj_mid = ld2(beta_j + ib); bj_hi = ld2(beta_j + ib + jS); }
 
-#define HPGMG_ROW(ROW, IDX, XC, XM, XP, XJM, XJP, XL, XR, BK0, BK1, JROW)                                                   \
+#define HPGMG_ROW(IDX, XC, XM, XP, XJM, XJP, XL, XR, BK0, BK1, BJL, BJH, JROW)                                              \
     {                                                                                                                        \
-      d2 bi = {0, 0}, bjl = {0, 0}, bjh = {0, 0}, al = {0, 0}; double bir = 0;                                               \
-      if (kVC) { bi = ld2(beta_i + IDX); bir = beta_i[IDX + 2]; bjl = ld2(beta_j + IDX); bjh = ld2(beta_j + IDX + jS); }     \
+      d2 bi = {0, 0}, al = {0, 0}; double bir = 0;                                                                           \
+      if (kVC) { bi = ld2(beta_i + IDX); bir = __shfl_down(bi.x, 1, 64); if (lane == 63) bir = beta_i[IDX + 2]; }            \
       if (kHelm) al = ld2(alpha + IDX);                                                                                     \
       if (MODE == MODE_GSRB) {                                                                                              \
         const int pp = (JROW ^ k ^ colour000) & 1;              /* the cell of this pair whose colour is swept */           \
         const double c = pp ? XC.y : XC.x;                                                                                  \
         const double Ax = apply_op_7pt<V>(c, pp ? XC.x : XL, pp ? XR : XC.y, pp ? XJM.y : XJM.x, pp ? XJP.y : XJP.x,        \
                                           pp ? XM.y : XM.x, pp ? XP.y : XP.x, pp ? bi.y : bi.x, pp ? bir : bi.y,            \
-                                          pp ? bjl.y : bjl.x, pp ? bjh.y : bjh.x, pp ? BK0.y : BK0.x, pp ? BK1.y : BK1.x,   \
+                                          pp ? BJL.y : BJL.x, pp ? BJH.y : BJH.x, pp ? BK0.y : BK0.x, pp ? BK1.y : BK1.x,   \
                                           pp ? al.y : al.x, P.a, P.b, P.h2inv);                                             \
         const d2 r2 = ld2(rhs + IDX), dv = ld2(dinv + IDX);                                                                 \
         const double xn = c + (pp ? dv.y : dv.x) * ((pp ? r2.y : r2.x) - Ax);                                              \
         if (P.copy_other_colour) st2(out + IDX, pp ? d2{XC.x, xn} : d2{xn, XC.y}); else out[IDX + pp] = xn;                 \
       } else {                                                                                                              \
-        const double Ax0 = apply_op_7pt<V>(XC.x, XL, XC.y, XJM.x, XJP.x, XM.x, XP.x, bi.x, bi.y, bjl.x, bjh.x, BK0.x, BK1.x, al.x, P.a, P.b, P.h2inv); \
-        const double Ax1 = apply_op_7pt<V>(XC.y, XC.x, XR, XJM.y, XJP.y, XM.y, XP.y, bi.y, bir, bjl.y, bjh.y, BK0.y, BK1.y, al.y, P.a, P.b, P.h2inv);  \
+        const double Ax0 = apply_op_7pt<V>(XC.x, XL, XC.y, XJM.x, XJP.x, XM.x, XP.x, bi.x, bi.y, BJL.x, BJH.x, BK0.x, BK1.x, al.x, P.a, P.b, P.h2inv); \
+        const double Ax1 = apply_op_7pt<V>(XC.y, XC.x, XR, XJM.y, XJP.y, XM.y, XP.y, bi.y, bir, BJL.y, BJH.y, BK0.y, BK1.y, al.y, P.a, P.b, P.h2inv);  \
         d2 o;                                                                                                               \
         if (MODE == MODE_APPLY) { o.x = Ax0; o.y = Ax1; }                                                                   \
         else {                                                                                                              \
@@ -248,9 +270,13 @@ __global__ __launch_bounds__(256) void stencil7_wide_kernel(const hpgmg_hip_leve
         st2(out + IDX, o);                                                                                                  \
       }                                                                                                                     \
     }
-    HPGMG_ROW(a, ia, xc_a, xm_a, xp_a, xjm_a, xc_b, xl_a, xr_a, bk0_a, bk1_a, ja)
-    HPGMG_ROW(b, ib, xc_b, xm_b, xp_b, xc_a, xjp_b, xl_b, xr_b, bk0_b, bk1_b, (ja + 1))
+    HPGMG_ROW(ia, xc_a, xm_a, xp_a, xjm_a, xc_b, xl_a, xr_a, bk0_a, bk1_a, bj_lo, bj_mid, ja)
+    HPGMG_ROW(ib, xc_b, xm_b, xp_b, xc_a, xjp_b, xl_b, xr_b, bk0_b, bk1_b, bj_mid, bj_hi, (ja + 1))
 #undef HPGMG_ROW
+    // hand the plane k+1 rows to the neighbouring waves for the next step
+    slab[(k + 1) & 1][2 * ty][lane] = xp_a;
+    slab[(k + 1) & 1][2 * ty + 1][lane] = xp_b;
+    __syncthreads();
     xm_a = xc_a; xc_a = xp_a; bk0_a = bk1_a;
     xm_b = xc_b; xc_b = xp_b; bk0_b = bk1_b;
   }
@@ -538,19 +564,24 @@ static int launch(const hpgmg_hip_level *L, int variant, StencilArgs P, bool is_
   static const int no_wide = env_int("HPGMG_TUNE_NO_WIDE", 0);
   // wide kernel: side a multiple of 128, 16-byte aligned interior rows (even strides; the box bases are checked by the host)
   if (!no_wide && L->dim % 128 == 0 && L->jStride % 2 == 0 && L->kStride % 2 == 0 && L->volume % 2 == 0 && (L->flags & 1)) {
-    block = dim3(64, 4, 1);
-    P.tiles_i = L->dim / 128; P.tiles_j = L->dim / 8;
-    int kchunk = 16;
-    if (env_int("HPGMG_TUNE_KCHUNK", 0) > 0) kchunk = env_int("HPGMG_TUNE_KCHUNK", 0);
+    static const int wj = env_int("HPGMG_TUNE_WIDE_WJ", 8), tune_kc = env_int("HPGMG_TUNE_KCHUNK", 0);
+    block = dim3(64, wj, 1);
+    P.tiles_i = L->dim / 128; P.tiles_j = L->dim / (2 * wj);
+    const int kchunk = tune_kc > 0 ? tune_kc : 16;
     P.kchunk = kchunk; P.chunks_k = (L->dim + kchunk - 1) / kchunk;
     P.total_blocks = L->num_boxes * P.chunks_k * P.tiles_j * P.tiles_i;
     grid = grid_for(P.total_blocks, &P.per_xcd);
+#define WIDE_CASE(VAR) case VAR: \
+      if (wj == 8) hipLaunchKernelGGL((stencil7_wide_kernel<VAR, MODE, 8>), dim3(grid), block, 0, g_stream, *L, P); \
+      else         hipLaunchKernelGGL((stencil7_wide_kernel<VAR, MODE, 4>), dim3(grid), block, 0, g_stream, *L, P); \
+      break;
     switch (variant) {
-      case HPGMG_HIP_7PT_VC_HELMHOLTZ: hipLaunchKernelGGL((stencil7_wide_kernel<HPGMG_HIP_7PT_VC_HELMHOLTZ, MODE>), dim3(grid), block, 0, g_stream, *L, P); break;
-      case HPGMG_HIP_7PT_VC_POISSON:   hipLaunchKernelGGL((stencil7_wide_kernel<HPGMG_HIP_7PT_VC_POISSON, MODE>), dim3(grid), block, 0, g_stream, *L, P); break;
-      case HPGMG_HIP_7PT_CC:           hipLaunchKernelGGL((stencil7_wide_kernel<HPGMG_HIP_7PT_CC, MODE>), dim3(grid), block, 0, g_stream, *L, P); break;
+      WIDE_CASE(HPGMG_HIP_7PT_VC_HELMHOLTZ)
+      WIDE_CASE(HPGMG_HIP_7PT_VC_POISSON)
+      WIDE_CASE(HPGMG_HIP_7PT_CC)
       default: return record_error(hipErrorInvalidValue, "stencil variant not implemented");
     }
+#undef WIDE_CASE
     profile_end(prof, cells);
     HPGMG_LAUNCH_CHECK("stencil7_wide_kernel");
     return 0;

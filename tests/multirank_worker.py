@@ -34,19 +34,37 @@ def view(ptr, n):
 
 def main():
     variant, log2, per_rank = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+    backend = sys.argv[4] if len(sys.argv) > 4 else "oracle"
     dist.init_process_group(backend="gloo")
     rank, size = dist.get_rank(), dist.get_world_size()
     stats = {"messages": 0, "doubles": 0, "allreduces": 0}
+    K = None
+    if backend == "hip":        # every rank of the job shares the box's one GPU; message buffers are device memory
+        import hpgmg_amd as H
+        K = H.load_kernels()
+        assert K.hpgmg_hip_set_device(0) == 0
 
     def sendrecv(ctx, nrecv, rbuf, rsize, rrank, nsend, sbuf, ssize, srank, tag):
-        reqs = []
+        reqs, staged = [], []
         for n in range(nrecv):
-            reqs.append(dist.irecv(view(rbuf[n], rsize[n]), src=rrank[n], tag=tag))
+            if K is None:
+                host = view(rbuf[n], rsize[n])
+            else:
+                host = torch.empty(rsize[n], dtype=torch.float64)
+                staged.append((ctypes.cast(rbuf[n], vp), host))
+            reqs.append(dist.irecv(host, src=rrank[n], tag=tag))
         for n in range(nsend):
-            reqs.append(dist.isend(view(sbuf[n], ssize[n]), dst=srank[n], tag=tag))
+            if K is None:
+                host = view(sbuf[n], ssize[n])
+            else:           # stands in for ncclSend on the launch stream: stage the packed device buffer through the host
+                host = torch.empty(ssize[n], dtype=torch.float64)
+                assert K.hpgmg_hip_memcpy_d2h(vp(host.data_ptr()), ctypes.cast(sbuf[n], vp), ssize[n] * 8) == 0
+            reqs.append(dist.isend(host, dst=srank[n], tag=tag))
             stats["messages"] += 1; stats["doubles"] += ssize[n]
         for r in reqs:
             r.wait()
+        for dev, host in staged:
+            assert K.hpgmg_hip_memcpy_h2d(dev, vp(host.data_ptr()), host.numel() * 8) == 0
 
     def allreduce(ctx, vals, n, op, ranks, nranks):
         stats["allreduces"] += 1
@@ -70,7 +88,7 @@ def main():
                 acc = max(acc, x) if op == 0 else acc + x
             vals[v] = acc
 
-    be = Backend.oracle()
+    be = Backend.hip() if backend == "hip" else Backend.oracle()
     cb = Transport(rank, size, None, SENDRECV(sendrecv), ALLREDUCE(allreduce))
     be.lib.hpgmg_set_transport(ctypes.byref(cb))
     be.configure(**VARIANTS[variant])

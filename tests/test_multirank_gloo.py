@@ -18,11 +18,12 @@ def free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def run_job(world, variant, log2, per_rank):
-    build_oracle()
+def run_job(world, variant, log2, per_rank, backend="oracle"):
+    if backend == "oracle":
+        build_oracle()
     env = dict(os.environ, OMP_NUM_THREADS="2", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-           "--master-port", str(free_port()), os.path.join(ROOT, "tests", "multirank_worker.py"), variant, str(log2), str(per_rank)]
+           "--master-port", str(free_port()), os.path.join(ROOT, "tests", "multirank_worker.py"), variant, str(log2), str(per_rank), backend]
     out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     dec, res, pos = json.JSONDecoder(), [], 0       # ranks share stdout: two records can land on one line
