@@ -173,7 +173,7 @@ def main():
             achieved = bytes_per_launch / avg_s / 1e9
             roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(),
-                    "kernel": "hpgmg::stencil7_kernel<VC Helmholtz, Chebyshev> on the finest level",
+                    "kernel": "hpgmg::stencil7_wide_kernel<VC Helmholtz, Chebyshev, 8 waves> on the finest level (8 boxes of 128^3)",
                     "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_us": round(avg_s * 1e6, 2),
                     "launches_timed": launches.value}
         line = {
