@@ -15,7 +15,8 @@ CLI's weak-scaling series 256^3, 256^3, 384^3, 512^3 for N = 1, 2, 4, 8), ghost 
 with RCCL send/recv over xGMI.  value = fine-grid DOF of the whole job / max-over-ranks time.
 
 Extra objects on the JSON line:
-  roofline     fine-level Chebyshev sweep: algorithmic bytes (72 B/cell) / hipEvent-timed launch
+  roofline     fine-level Chebyshev smoother: algorithmic bytes (72 B per cell per sweep x the sweeps a launch performs;
+               the fused kernel does two) / hipEvent-timed launch
   cpu_baseline the REFERENCE binary (oracle/_ref, built from /root/reference by oracle/Makefile)
                run on this box's host cores; falls back to the CPU restatement ("port").
 """
@@ -173,7 +174,8 @@ def main():
             achieved = bytes_per_launch / avg_s / 1e9
             roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(),
-                    "kernel": "hpgmg::stencil7_wide_kernel<VC Helmholtz, Chebyshev, 8 waves> on the finest level (8 boxes of 128^3)",
+                    "kernel": "hpgmg::cheby_pair_kernel<VC Helmholtz> (+ its edge-column pre-pass) on the finest level: one launch = TWO Chebyshev sweeps over 8 boxes of 128^3",
+                    "sweeps_per_launch": round(cells.value / launches.value / fine_cells, 3),
                     "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_us": round(avg_s * 1e6, 2),
                     "launches_timed": launches.value}
         line = {

@@ -85,12 +85,14 @@ typedef struct {
   struct { const blockCopy_type *host; int n; blockCopy_type *dev; } lists[MAX_LISTS];
   int num_lists;
   int *krylov_pinned;          /* iterations of device-side bottom solves not yet folded into level->Krylov_iterations */
+  double *pair_scratch; double **d_pair_base;   /* two private vectors per box for the fused Chebyshev sweep pairs */
+  int lexicographic;           /* -1 unknown, else whether local box b sits at (b % nb, (b / nb) % nb, b / nb^2) and all boxes are local */
 } backend_t;
 
 static backend_t *backend_of(level_type *L) {
   hpgmg_level_ext *X = hpgmg_level_ext_get(L);
   backend_t *B = (backend_t *)X->backend;
-  if (!B) { B = (backend_t *)calloc(1, sizeof(*B)); X->backend = B; }
+  if (!B) { B = (backend_t *)calloc(1, sizeof(*B)); X->backend = B; B->lexicographic = -1; }
   double *v0 = L->num_my_boxes ? L->my_boxes[0].vectors[0] : NULL;
   if (B->seen_v0 != v0 || B->seen_nv != L->numVectors || B->seen_boxes != L->num_my_boxes || !B->d_box_low) {
     int b, n = L->num_my_boxes > 0 ? L->num_my_boxes : 1;
@@ -177,6 +179,8 @@ void hpgmg_level_release(level_type *L) {
   if (B->d_box_low) hpgmg_hip_free(B->d_box_low);
   if (B->d_box_nbr) hpgmg_hip_free(B->d_box_nbr);
   if (B->krylov_pinned) hpgmg_hip_host_free(B->krylov_pinned);
+  if (B->pair_scratch) hpgmg_hip_free(B->pair_scratch);
+  if (B->d_pair_base) hpgmg_hip_free(B->d_pair_base);
   free(B);
   X->backend = NULL;
 }
@@ -413,6 +417,58 @@ int hpgmg_vcycle_legs_fused(level_type **levels, int n, int e_id, int R_id, doub
   return 1;
 }
 
+/* every box of the level is local and local box b sits at lexicographic position b (what the kernels that address
+ * cells by global coordinate assume) */
+static int boxes_lexicographic(level_type *L) {
+  backend_t *B = backend_of(L);
+  if (B->lexicographic < 0) {
+    int bx, ok = (L->num_my_boxes == L->boxes_in.i * L->boxes_in.j * L->boxes_in.k);
+    for (bx = 0; ok && bx < L->num_my_boxes; bx++) {
+      const box_type *X = &L->my_boxes[bx];
+      if (X->low.i != (bx % L->boxes_in.i) * L->box_dim || X->low.j != ((bx / L->boxes_in.i) % L->boxes_in.j) * L->box_dim ||
+          X->low.k != (bx / (L->boxes_in.i * L->boxes_in.j)) * L->box_dim) ok = 0;
+    }
+    B->lexicographic = ok;
+  }
+  return B->lexicographic;
+}
+
+/* Chebyshev smooth() as fused sweep pairs (kernels/cheby_pair.hpp): 4 sweeps = 2 passes of 10 streams instead of
+ * 4 x 9.  x1,x2 of the first pair go to two plugin-private vectors, the second pair brings x3 -> VECTOR_TEMP and
+ * x4 -> x_id, i.e. exactly the state chebyshev.c:43-99 leaves.  Returns 0 when the level does not qualify. */
+static int fused_sweeps = -1;
+void hpgmg_set_fused_sweeps(int on) { fused_sweeps = on ? 1 : 0; }
+static int smooth_cheby_pairs(level_type *L, int x_id, int rhs_id, double a, double b, const double *c1, const double *c2, int sweeps) {
+  if (fused_sweeps < 0) { const char *e = getenv("HPGMG_FUSED_SWEEPS"); fused_sweeps = !(e && e[0] == '0'); }
+  const int enabled = fused_sweeps;
+  hpgmg_config cfg;
+  hpgmg_get_config(&cfg);
+  backend_t *B = backend_of(L);
+  if (!enabled || sweeps != 4 || cfg.op != HPGMG_OP_7PT || !ghost_free_mode() || stencil_get_shape() != STENCIL_SHAPE_STAR) return 0;
+  if (L->boundary_condition.type != BC_DIRICHLET || !B->all_faces_local || x_id == VECTOR_TEMP || rhs_id == VECTOR_TEMP) return 0;
+  if (!hpgmg_hip_smooth_cheby_pair_supported(&B->dev, variant()) || !boxes_lexicographic(L)) return 0;
+  if (!B->pair_scratch) {
+    int bx;
+    double **base = (double **)calloc((size_t)L->num_my_boxes, sizeof(double *));
+    B->pair_scratch = (double *)hpgmg_hip_malloc(((size_t)L->num_my_boxes * 2 * (size_t)L->box_volume + 2) * sizeof(double));
+    B->d_pair_base = (double **)hpgmg_hip_malloc((size_t)L->num_my_boxes * sizeof(double *));
+    if (!B->pair_scratch || !B->d_pair_base) { fprintf(stderr, "hpgmg: no memory for the sweep-pair scratch vectors\n"); abort(); }
+    /* the vector bases share the level's alignment class so the first interior cell is 16-byte aligned here too */
+    const size_t pad = ((uintptr_t)L->my_boxes[0].vectors[0] % 16) / sizeof(double);
+    for (bx = 0; bx < L->num_my_boxes; bx++) base[bx] = B->pair_scratch + pad + (size_t)bx * 2 * (size_t)L->box_volume;
+    HIP_OK(hpgmg_hip_memcpy_h2d(B->d_pair_base, base, (size_t)L->num_my_boxes * sizeof(double *)));
+    free(base);
+  }
+  const double h2inv = 1.0 / (L->h * L->h);
+  const int v = variant();
+  const double t0 = now();
+  hpgmg_hip_set_ghost_free(1);
+  HIP_OK(hpgmg_hip_smooth_cheby_pair(&B->dev, v, (double *const *)B->d_pair_base, 0, x_id, 0, VECTOR_TEMP, 1, 0, 1, 1, rhs_id, a, b, h2inv, c1[0], c2[0], c1[1], c2[1]));
+  HIP_OK(hpgmg_hip_smooth_cheby_pair(&B->dev, v, (double *const *)B->d_pair_base, 1, 1, 1, 0, 0, VECTOR_TEMP, 0, x_id, rhs_id, a, b, h2inv, c1[2], c2[2], c1[3], c2[3]));
+  L->timers.smooth += now() - t0;
+  return 1;
+}
+
 void smooth(level_type *L, int x_id, int rhs_id, double a, double b) {
   hpgmg_config cfg;
   hpgmg_get_config(&cfg);
@@ -424,6 +480,7 @@ void smooth(level_type *L, int x_id, int rhs_id, double a, double b) {
     double c1[16], c2[16];
     if (L->dominant_eigenvalue_of_DinvA <= 0.0 && L->my_rank == 0) fprintf(stderr, "dominant_eigenvalue_of_DinvA <= 0.0 !\n");
     cheby_coefficients(L, sweeps, c1, c2);
+    if (smooth_cheby_pairs(L, x_id, rhs_id, a, b, c1, c2, sweeps)) return;
     for (s = 0; s < sweeps; s++) {
       const int src = (s & 1) ? VECTOR_TEMP : x_id, dst = (s & 1) ? x_id : VECTOR_TEMP;
       ghosts_for_stencil(L, src);

@@ -1,0 +1,255 @@
+// cheby_pair.hpp -- TWO Chebyshev sweeps of the 7-point operator in one pass over the fine level.
+//
+// One sweep of chebyshev.c:43-99 moves 9 streams per cell (x_n, x_nm1, rhs, Dinv, beta_i/j/k, alpha read,
+// x_np1 written); two consecutive sweeps read the same six coefficient streams twice.  This kernel
+// computes  x1 = S_a(x0, xm1)  and  x2 = S_b(x1, x0)  together: x0, xm1 and the coefficients are read once,
+// x1 and x2 are written once -- 10 streams for two sweeps instead of 18.  The arithmetic per cell is the same
+// expression tree as the single-sweep kernels (apply_op_7pt + the update of chebyshev.c:86-95), so the result
+// is bit-identical; only the order in which cells are visited changes.
+//
+// Decomposition (global cell coordinates; boxes are numbered lexicographically, checked by the host):
+//   workgroup = NW waves x 64 lanes;  wave w owns ONE 128-cell row  gj = R-1+w  of a slab of NR = NW-2 output
+//   rows (waves 0 and NW-1 compute x1 on the two halo rows only), a lane owns 2 adjacent cells (16-byte loads,
+//   1 KiB per wave-load); the workgroup marches in +k over KC output planes plus one halo plane at each end.
+//   Per step p it computes x1 on plane p and then x2 on plane p-1.
+//   * k neighbours and the plane-(p-1) coefficients needed again for x2: registers;
+//   * j neighbours of x0 / x1 and the upper beta_j face: the neighbouring wave's row via LDS (x0 and beta_j are
+//     deposited one step ahead; one __syncthreads per step, buffers double-buffered);
+//   * i neighbours: adjacent lane (shuffle).  Across a 128-cell tile edge x0 is read from memory; x1 there was
+//     written beforehand by cheby_pair_edge_kernel (the columns next to interior tile edges, 0.8 % of the cells);
+//   * the domain boundary is the in-register Dirichlet rule ghost = -centre (apply_BCs_p1), applied to x0 for
+//     the first sweep and to x1 for the second, as the reference does between sweeps.
+// x1/x2 go to vectors distinct from x0/xm1 (plugin-private scratch for the first pair of a smooth() call), since
+// neighbouring workgroups still read x0/xm1 on their halo.
+#pragma once
+#include "common.hpp"
+#include "stencil_math.hpp"
+
+namespace hpgmg {
+
+struct VecRef { int scratch, id; };                  // vector `id` of the level, or of the plugin's scratch pair
+struct PairArgs {
+  VecRef x0, xm1, out1, out2;
+  int rhs_id;
+  double a, b, h2inv, c1a, c2a, c1b, c2b;           // Chebyshev coefficients of the two sweeps
+  double *const *scr_base;                          // per box: base of 2 scratch vectors (same padded layout)
+  int nbi, nbj;                                     // boxes per dimension (lexicographic numbering)
+  int Di, Dj, Dk;                                   // global cells
+  int tiles_i, slabs_j, chunks_k, KC, per_xcd, total_blocks;
+};
+
+__device__ __forceinline__ double *pair_vec(const hpgmg_hip_level &L, const PairArgs &A, VecRef r, int box) {
+  double *base = r.scratch ? A.scr_base[box] : L.box_base[box];
+  return base + (size_t)r.id * (size_t)L.volume + (size_t)L.ghosts * (size_t)(1 + L.jStride + L.kStride);
+}
+
+struct alignas(16) p2 { double x, y; };
+__device__ __forceinline__ p2 pld(const double *p) { return *reinterpret_cast<const p2 *>(p); }
+__device__ __forceinline__ void pst(double *p, p2 v) { *reinterpret_cast<p2 *>(p) = v; }
+__device__ __forceinline__ p2 pneg(p2 v) { return p2{-v.x, -v.y}; }
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// coefficients of one plane for a lane's two cells
+template <int V> struct PlaneCoef { p2 rhs, dinv, al, bi, bjlo, bjhi, bk0, bk1; double bir; };
+
+// one Chebyshev update of the pair (c.x, c.y)
+template <int V>
+__device__ __forceinline__ p2 cheby_update(p2 c, double left, double right, p2 jm, p2 jp, p2 km, p2 kp, p2 old,
+                                           const PlaneCoef<V> &q, double a, double b, double h2inv, double c1, double c2) {
+  const double Ax0 = apply_op_7pt<V>(c.x, left, c.y, jm.x, jp.x, km.x, kp.x, q.bi.x, q.bi.y, q.bjlo.x, q.bjhi.x, q.bk0.x, q.bk1.x, q.al.x, a, b, h2inv);
+  const double Ax1 = apply_op_7pt<V>(c.y, c.x, right, jm.y, jp.y, km.y, kp.y, q.bi.y, q.bir, q.bjlo.y, q.bjhi.y, q.bk0.y, q.bk1.y, q.al.y, a, b, h2inv);
+  p2 o;
+  o.x = c.x + c1 * (c.x - old.x) + c2 * q.dinv.x * (q.rhs.x - Ax0);
+  o.y = c.y + c1 * (c.y - old.y) + c2 * q.dinv.y * (q.rhs.y - Ax1);
+  return o;
+}
+
+template <int V, int NW>
+__global__ __launch_bounds__(64 * NW) void cheby_pair_kernel(const hpgmg_hip_level L, const PairArgs A) {
+  constexpr bool kVC = (V != HPGMG_HIP_7PT_CC);
+  constexpr bool kHelm = (V == HPGMG_HIP_7PT_VC_HELMHOLTZ);
+  constexpr int NR = NW - 2;
+  extern __shared__ p2 pair_lds[];                              // 3 x [2 buffers][NW rows][64 pairs] = NW x 6 KiB
+  p2 (*slabX0)[NW][64] = reinterpret_cast<p2 (*)[NW][64]>(pair_lds);
+  p2 (*slabX1)[NW][64] = reinterpret_cast<p2 (*)[NW][64]>(pair_lds + 2 * NW * 64);
+  p2 (*slabBJ)[NW][64] = reinterpret_cast<p2 (*)[NW][64]>(pair_lds + 4 * NW * 64);
+
+  const int logical = xcd_logical_block((int)blockIdx.x, A.per_xcd);
+  if (logical >= A.total_blocks) return;
+  int t = logical;
+  const int ti = t % A.tiles_i; t /= A.tiles_i;
+  const int sj = t % A.slabs_j; t /= A.slabs_j;
+  const int ck = t;
+
+  const int lane = (int)threadIdx.x, w = uni((int)threadIdx.y);
+  const int bd = L.dim, jS = L.jStride, kS = L.kStride;
+  const int gi0 = ti * 128, R = sj * NR, K0 = ck * A.KC;
+  const int NRs = (R + NR <= A.Dj) ? NR : A.Dj - R;          // output rows of this slab
+  const int KCs = (K0 + A.KC <= A.Dk) ? A.KC : A.Dk - K0;    // output planes of this chunk
+  const int gj = R - 1 + w;
+  const bool row_x1 = (gj >= 0 && gj < A.Dj && w <= NRs + 1);  // this wave computes x1 on its row
+  const bool row_out = (w >= 1 && w <= NRs);                   // ... and x2, and stores both
+  const int bi_ = gi0 / bd, li = gi0 - bi_ * bd + 2 * lane;
+  const int gjc = row_x1 ? gj : 0;
+  const int bj_ = gjc / bd, lj = gjc - bj_ * bd;
+  const int row_off = li + lj * jS;                            // offset of this lane's pair inside a plane of its box
+  // neighbours in i across the tile edge (lane 0 / lane 63 only)
+  const bool left_dom = (gi0 == 0), right_dom = (gi0 + 128 == A.Di);
+  const int biL = left_dom ? bi_ : (gi0 - 1) / bd, liL = left_dom ? 0 : (gi0 - 1) - biL * bd;
+  const int biR = right_dom ? bi_ : (gi0 + 128) / bd, liR = right_dom ? 0 : (gi0 + 128) - biR * bd;
+  // far rows of x0 the two halo waves need from memory
+  const bool far_lo = row_x1 && (w == 0) && (gj - 1 >= 0);
+  const bool far_hi = row_x1 && (w == NRs + 1) && (gj + 1 < A.Dj);
+  const int gjf = far_lo ? gj - 1 : (far_hi ? gj + 1 : gjc);
+  const int bjf = gjf / bd, ljf = gjf - bjf * bd;
+
+  // pointers of the current plane (wave-uniform: one box per row and plane)
+  auto box_of = [&](int bi, int bj, int gk) { return uni(bi + A.nbi * (bj + A.nbj * (gk / bd))); };
+  auto plane_off = [&](int gk) { return (gk % bd) * kS; };
+
+  const int P0 = K0 - 1, P1 = K0 + KCs;                         // x1 planes P0..P1 (those inside the domain)
+  auto in_dom = [&](int gk) { return gk >= 0 && gk < A.Dk; };
+
+  p2 x0m = {0, 0}, x0c = {0, 0}, x0p = {0, 0};                  // x0 on planes p-1, p, p+1
+  p2 x1m2 = {0, 0}, x1m1 = {0, 0}, x1c = {0, 0};                // x1 on planes p-2, p-1, p
+  p2 far_c = {0, 0}, far_n = {0, 0};                            // far x0 row on planes p, p+1 (halo waves)
+  p2 bj_c = {0, 0}, bj_n = {0, 0};                              // own beta_j row on planes p, p+1
+  PlaneCoef<V> qc = {}, qp = {};                                // coefficients of planes p and p-1
+
+  // ---- prologue: planes pstart-1 and pstart of x0, beta_j of pstart, into registers / LDS
+  const int pstart = in_dom(P0) ? P0 : P0 + 1;
+  if (row_x1) {
+    const int box = box_of(bi_, bj_, pstart), off = row_off + plane_off(pstart);
+    x0c = pld(pair_vec(L, A, A.x0, box) + off);
+    if (kVC) bj_c = pld(vec_origin(L, box, VECTOR_BETA_J) + off);
+    if (in_dom(pstart - 1)) { const int bm = box_of(bi_, bj_, pstart - 1); x0m = pld(pair_vec(L, A, A.x0, bm) + row_off + plane_off(pstart - 1)); }
+    if (far_lo || far_hi) far_c = pld(pair_vec(L, A, A.x0, box_of(bi_, bjf, pstart)) + li + ljf * jS + plane_off(pstart));
+    slabX0[pstart & 1][w][lane] = x0c;
+    slabBJ[pstart & 1][w][lane] = bj_c;
+  }
+  __syncthreads();
+
+  for (int p = pstart; p <= P1 && p < A.Dk; p++) {
+    const int box = box_of(bi_, bj_, p), off = row_off + plane_off(p);
+    const bool have_next = in_dom(p + 1) && (p + 1 <= P1);     // plane p+1 is needed as a centre later
+    const bool above_in = in_dom(p + 1);
+    // ---- loads: x0 / beta_j / far row one plane ahead, everything else for plane p
+    if (row_x1) {
+      if (above_in) {
+        const int bn = box_of(bi_, bj_, p + 1), offn = row_off + plane_off(p + 1);
+        x0p = pld(pair_vec(L, A, A.x0, bn) + offn);
+        if (have_next) {
+          if (kVC) bj_n = pld(vec_origin(L, bn, VECTOR_BETA_J) + offn);
+          if (far_lo || far_hi) far_n = pld(pair_vec(L, A, A.x0, box_of(bi_, bjf, p + 1)) + li + ljf * jS + plane_off(p + 1));
+        }
+      }
+      qc.rhs = pld(vec_origin(L, box, A.rhs_id) + off);
+      qc.dinv = pld(vec_origin(L, box, VECTOR_DINV) + off);
+      if (kHelm) qc.al = pld(vec_origin(L, box, VECTOR_ALPHA) + off);
+      if (kVC) {
+        const double *bip = vec_origin(L, box, VECTOR_BETA_I) + off;
+        qc.bi = pld(bip);
+        qc.bir = __shfl_down(qc.bi.x, 1, 64);
+        if (lane == 63) qc.bir = bip[2];
+        const double *bkp = vec_origin(L, box, VECTOR_BETA_K) + off;
+        // the lower face is the previous plane's upper face (same address) unless this is the first plane of a box / of the march
+        if (p == pstart || (p % bd) == 0) qc.bk0 = pld(bkp); else qc.bk0 = qp.bk1;
+        qc.bk1 = pld(bkp + kS);                                  // the box's own upper face (ghost plane at the box top)
+        qc.bjlo = bj_c;
+        if (w == NRs + 1 || gj + 1 >= A.Dj || ((lj + 1) == bd)) qc.bjhi = pld(vec_origin(L, box, VECTOR_BETA_J) + off + jS);
+        else qc.bjhi = slabBJ[p & 1][w + 1][lane];
+      }
+      const p2 xm1 = pld(pair_vec(L, A, A.xm1, box) + off);
+
+      // ---- x1 on plane p (first sweep): neighbours of x0
+      p2 jm, jp;
+      if (gj - 1 < 0) jm = pneg(x0c); else if (w == 0) jm = far_c; else jm = slabX0[p & 1][w - 1][lane];
+      if (gj + 1 >= A.Dj) jp = pneg(x0c); else if (w == NRs + 1) jp = far_c; else jp = slabX0[p & 1][w + 1][lane];
+      const p2 km = in_dom(p - 1) ? x0m : pneg(x0c);
+      const p2 kp = above_in ? x0p : pneg(x0c);
+      double left = __shfl_up(x0c.y, 1, 64), right = __shfl_down(x0c.x, 1, 64);
+      if (lane == 0)  left  = left_dom  ? -x0c.x : pair_vec(L, A, A.x0, box_of(biL, bj_, p))[liL + lj * jS + plane_off(p)];
+      if (lane == 63) right = right_dom ? -x0c.y : pair_vec(L, A, A.x0, box_of(biR, bj_, p))[liR + lj * jS + plane_off(p)];
+      x1c = cheby_update<V>(x0c, left, right, jm, jp, km, kp, xm1, qc, A.a, A.b, A.h2inv, A.c1a, A.c2a);
+    }
+
+    // ---- x2 on plane q = p-1 (second sweep): neighbours of x1; x0 is the older iterate
+    const int q = p - 1;
+    if (row_out && q >= K0) {
+      const int boxq = box_of(bi_, bj_, q), offq = row_off + plane_off(q);
+      p2 jm, jp;
+      if (gj - 1 < 0) jm = pneg(x1m1); else jm = slabX1[q & 1][w - 1][lane];
+      if (gj + 1 >= A.Dj) jp = pneg(x1m1); else jp = slabX1[q & 1][w + 1][lane];
+      const p2 km = in_dom(q - 1) ? x1m2 : pneg(x1m1);
+      const p2 kp = x1c;                                         // plane p is inside the domain here
+      double left = __shfl_up(x1m1.y, 1, 64), right = __shfl_down(x1m1.x, 1, 64);
+      if (lane == 0)  left  = left_dom  ? -x1m1.x : pair_vec(L, A, A.out1, box_of(biL, bj_, q))[liL + lj * jS + plane_off(q)];
+      if (lane == 63) right = right_dom ? -x1m1.y : pair_vec(L, A, A.out1, box_of(biR, bj_, q))[liR + lj * jS + plane_off(q)];
+      const p2 x2 = cheby_update<V>(x1m1, left, right, jm, jp, km, kp, x0m, qp, A.a, A.b, A.h2inv, A.c1b, A.c2b);
+      pst(pair_vec(L, A, A.out2, boxq) + offq, x2);
+    }
+    if (row_out && p >= K0 && p < K0 + KCs) pst(pair_vec(L, A, A.out1, box) + off, x1c);
+
+    // ---- hand this plane's x1 and the next plane's x0 / beta_j to the neighbouring waves
+    if (row_x1) {
+      slabX1[p & 1][w][lane] = x1c;
+      if (have_next) { slabX0[(p + 1) & 1][w][lane] = x0p; slabBJ[(p + 1) & 1][w][lane] = bj_n; }
+    }
+    __syncthreads();
+    x0m = x0c; x0c = x0p; x1m2 = x1m1; x1m1 = x1c; far_c = far_n; bj_c = bj_n; qp = qc;
+  }
+
+  // ---- the last output plane when the chunk ends at the top of the domain: x1 above it is the Dirichlet ghost
+  if (P1 >= A.Dk && row_out) {
+    const int q = A.Dk - 1;
+    if (q >= K0) {
+      const int boxq = box_of(bi_, bj_, q), offq = row_off + plane_off(q);
+      p2 jm, jp;
+      if (gj - 1 < 0) jm = pneg(x1m1); else jm = slabX1[q & 1][w - 1][lane];
+      if (gj + 1 >= A.Dj) jp = pneg(x1m1); else jp = slabX1[q & 1][w + 1][lane];
+      const p2 km = in_dom(q - 1) ? x1m2 : pneg(x1m1);
+      const p2 kp = pneg(x1m1);
+      double left = __shfl_up(x1m1.y, 1, 64), right = __shfl_down(x1m1.x, 1, 64);
+      if (lane == 0)  left  = left_dom  ? -x1m1.x : pair_vec(L, A, A.out1, box_of(biL, bj_, q))[liL + lj * jS + plane_off(q)];
+      if (lane == 63) right = right_dom ? -x1m1.y : pair_vec(L, A, A.out1, box_of(biR, bj_, q))[liR + lj * jS + plane_off(q)];
+      const p2 x2 = cheby_update<V>(x1m1, left, right, jm, jp, km, kp, x0m, qp, A.a, A.b, A.h2inv, A.c1b, A.c2b);
+      pst(pair_vec(L, A, A.out2, boxq) + offq, x2);
+    }
+  }
+}
+
+// x1 on the cell columns next to interior 128-cell tile edges (gi = 128 t - 1 and 128 t), which the pair kernel
+// reads as i neighbours of the second sweep.  One lane per cell of those columns (0.8 % of the level), lanes along j.
+template <int V>
+__global__ __launch_bounds__(256) void cheby_pair_edge_kernel(const hpgmg_hip_level L, const PairArgs A) {
+  constexpr bool kVC = (V != HPGMG_HIP_7PT_CC);
+  constexpr bool kHelm = (V == HPGMG_HIP_7PT_VC_HELMHOLTZ);
+  const int gj = blockIdx.x * blockDim.x + threadIdx.x, gk = blockIdx.y, col = blockIdx.z;
+  if (gj >= A.Dj) return;
+  const int gi = 128 * (col / 2 + 1) - 1 + (col & 1);
+  const int bd = L.dim, jS = L.jStride, kS = L.kStride;
+  auto cell = [&](int ci, int cj, int ck, int &box) -> int {
+    const int bi = ci / bd, bj = cj / bd, bk = ck / bd;
+    box = bi + A.nbi * (bj + A.nbj * bk);
+    return (ci - bi * bd) + (cj - bj * bd) * jS + (ck - bk * bd) * kS;
+  };
+  auto x0_at = [&](int ci, int cj, int ck, double centre) -> double {
+    if (ci < 0 || cj < 0 || ck < 0 || ci >= A.Di || cj >= A.Dj || ck >= A.Dk) return -centre;
+    int box; const int idx = cell(ci, cj, ck, box);
+    return pair_vec(L, A, A.x0, box)[idx];
+  };
+  int box; const int idx = cell(gi, gj, gk, box);
+  const double xc = pair_vec(L, A, A.x0, box)[idx];
+  double bi0 = 0, bi1 = 0, bj0 = 0, bj1 = 0, bk0 = 0, bk1 = 0, al = 0;
+  if (kVC) {
+    const double *bi = vec_origin(L, box, VECTOR_BETA_I), *bj = vec_origin(L, box, VECTOR_BETA_J), *bk = vec_origin(L, box, VECTOR_BETA_K);
+    bi0 = bi[idx]; bi1 = bi[idx + 1]; bj0 = bj[idx]; bj1 = bj[idx + jS]; bk0 = bk[idx]; bk1 = bk[idx + kS];
+  }
+  if (kHelm) al = vec_origin(L, box, VECTOR_ALPHA)[idx];
+  const double Ax = apply_op_7pt<V>(xc, x0_at(gi - 1, gj, gk, xc), x0_at(gi + 1, gj, gk, xc), x0_at(gi, gj - 1, gk, xc), x0_at(gi, gj + 1, gk, xc),
+                                    x0_at(gi, gj, gk - 1, xc), x0_at(gi, gj, gk + 1, xc), bi0, bi1, bj0, bj1, bk0, bk1, al, A.a, A.b, A.h2inv);
+  const double xnm1 = pair_vec(L, A, A.xm1, box)[idx];
+  pair_vec(L, A, A.out1, box)[idx] = xc + A.c1a * (xc - xnm1) + A.c2a * vec_origin(L, box, VECTOR_DINV)[idx] * (vec_origin(L, box, A.rhs_id)[idx] - Ax);
+}
+
+}  // namespace hpgmg

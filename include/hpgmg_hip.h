@@ -81,6 +81,15 @@ int  hpgmg_hip_get_ghost_free(void);
  * when xn_id == xnp1_id, otherwise copying the other colour. */
 int hpgmg_hip_smooth_cheby(const hpgmg_hip_level *L, int variant, int xn_id, int xnp1_id, int rhs_id,
                            double a, double b, double h2inv, double c1, double c2);
+/* Two consecutive Chebyshev sweeps (chebyshev.c:43-99 twice) in one pass: x1 = S(x0, xm1; c1a, c2a),
+ * x2 = S(x1, x0; c1b, c2b); bit-identical to two hpgmg_hip_smooth_cheby calls with the Dirichlet ghost rule between
+ * them.  Each vector is (scratch?, id): scratch ids 0/1 are the two extra vectors per box behind scr_base[box]
+ * (same padded layout as the level's vectors).  out1/out2 must differ from x0/xm1.  Needs every face neighbour
+ * local, Dirichlet, box side a multiple of 128, boxes numbered lexicographically (_supported() checks the rest). */
+int hpgmg_hip_smooth_cheby_pair_supported(const hpgmg_hip_level *L, int variant);
+int hpgmg_hip_smooth_cheby_pair(const hpgmg_hip_level *L, int variant, double *const *scr_base,
+                                int x0_scr, int x0_id, int xm1_scr, int xm1_id, int out1_scr, int out1_id, int out2_scr, int out2_id,
+                                int rhs_id, double a, double b, double h2inv, double c1a, double c2a, double c1b, double c2b);
 int hpgmg_hip_smooth_gsrb(const hpgmg_hip_level *L, int variant, int xn_id, int xnp1_id, int rhs_id,
                           double a, double b, double h2inv, int sweep);
 int hpgmg_hip_smooth_jacobi(const hpgmg_hip_level *L, int variant, int xn_id, int xnp1_id, int rhs_id,

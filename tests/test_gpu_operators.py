@@ -80,6 +80,31 @@ def test_smooth_residual_apply(hip, oracle, variant, geom, ghost_free):
         lh.destroy(); lo.destroy()
 
 
+@pytest.mark.parametrize("variant,geom", [("7pt-cheby-helm", (2, 128)), ("7pt-cheby", (1, 128)), ("7ptcc-cheby", (1, 256)), ("7pt-cheby-helm", (3, 128))])
+def test_fused_chebyshev_sweep_pairs(hip, oracle, variant, geom):
+    """Boxes whose side is a multiple of 128 smooth with the fused two-sweeps-per-pass kernel (cheby_pair.hpp): U and
+    VECTOR_TEMP must equal the oracle's four separate sweeps bit for bit, and equal the one-launch-per-sweep HIP path."""
+    hip.lib.hpgmg_set_fused_sweeps.argtypes = [ctypes.c_int]
+    lh, lo = make_pair(hip, oracle, variant, *geom, seed=3)
+    try:
+        a, b = (1.0, 1.0) if "helm" in variant else (0.0, 1.0)
+        for lv in (lh, lo):
+            lv.b.lib.rebuild_operator(lv.ptr, None, a, b)
+        u0 = lh.read_all(H.VECTOR_U); t0 = lh.read_all(H.VECTOR_TEMP)
+        for lv in (lh, lo):
+            lv.b.lib.smooth(lv.ptr, H.VECTOR_U, H.VECTOR_F, a, b)
+        same(lh, lo, [H.VECTOR_U, H.VECTOR_TEMP], interior_only=True)
+        fused_u, fused_t = lh.read_all(H.VECTOR_U), lh.read_all(H.VECTOR_TEMP)
+        hip.lib.hpgmg_set_fused_sweeps(0)
+        lh.write_all(H.VECTOR_U, u0); lh.write_all(H.VECTOR_TEMP, t0)
+        lh.b.lib.smooth(lh.ptr, H.VECTOR_U, H.VECTOR_F, a, b)
+        same(lh, lo, [H.VECTOR_U, H.VECTOR_TEMP], interior_only=True)
+        del fused_u, fused_t
+    finally:
+        hip.lib.hpgmg_set_fused_sweeps(1)
+        lh.destroy(); lo.destroy()
+
+
 @pytest.mark.parametrize("geom", GEOMS)
 @pytest.mark.parametrize("shape", [H.STENCIL_SHAPE_BOX, H.STENCIL_SHAPE_STAR, H.STENCIL_SHAPE_NO_CORNERS])
 def test_exchange_and_boundary_conditions(hip, oracle, geom, shape):
