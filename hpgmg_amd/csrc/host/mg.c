@@ -254,7 +254,22 @@ typedef struct { int procs, dim, boxes, box_dim, ghosts; } plan_t;
 /* Coarsening ladder of the reference's true-V-cycle build (mg.c:895-952):
  * halve boxes while they are bigger than 8^3, then merge 8 boxes into 1, then
  * (non power-of-two domains) collapse onto few ranks, finally halve again. */
+static int plan_next_reference(const plan_t *f, int coarsest_dim, plan_t *c);
+/* MI355X deviation from the reference ladder (rank map only; results do not depend on which rank owns a box):
+ * a level of <= hpgmg_gather_dim^3 cells is owned entirely by rank 0.  The reference keeps such levels spread over
+ * all ranks until its boxes reach 8^3 (e.g. 8 ranks x 8 boxes of 8^3 for a 32^3 level), where every smoother sweep
+ * is a latency-bound message exchange; one GPU runs the whole <= 64^3 tail of a V-cycle in well under a
+ * millisecond with no messages (hipGraph segments, fused tail kernel).  0 = the reference's rank map. */
+int hpgmg_gather_dim = -1;
+void hpgmg_set_gather_dim(int dim) { hpgmg_gather_dim = dim; }
 static int plan_next(const plan_t *f, int coarsest_dim, plan_t *c) {
+  if (hpgmg_gather_dim < 0) { const char *e = getenv("HPGMG_GATHER_DIM"); hpgmg_gather_dim = (e && *e) ? atoi(e) : 64; }
+  if (!plan_next_reference(f, coarsest_dim, c)) return 0;
+  if (f->procs == 1) c->procs = 1;                       /* once gathered, stay gathered */
+  if (hpgmg_gather_dim > 0 && c->dim <= hpgmg_gather_dim) c->procs = 1;
+  return 1;
+}
+static int plan_next_reference(const plan_t *f, int coarsest_dim, plan_t *c) {
   const int r = stencil_get_radius();
   *c = *f;
   c->dim = f->dim / 2;

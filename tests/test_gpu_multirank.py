@@ -33,3 +33,16 @@ def test_hip_multirank_matches_single_rank_reference(world, variant, log2, per_r
     total = int(gold_key.split()[-1])
     assert sum(r["levels"][0]["my_boxes"] for r in res) == total
     assert all(r["stats"]["messages"] > 50 for r in res)
+
+
+@pytest.mark.parametrize("world,variant,log2,per_rank,gold_key,gather", [
+    (2, "7pt-cheby-helm", 4, 4, "7pt-cheby-helm 4 8", 16),
+    (4, "7pt-cheby", 4, 8, "7pt-cheby 4 27", 24),
+    (2, "fv4-gsrb", 4, 4, "fv4-gsrb 4 8", 16),
+])
+def test_hip_gathered_coarse_levels(world, variant, log2, per_rank, gold_key, gather):
+    """Default product rank map (coarse levels gathered on rank 0, where the fused tail kernel runs them) on the HIP path."""
+    gold = GOLD[gold_key]
+    res = run_job(world, variant, log2, per_rank, backend="hip", gather_dim=gather)
+    assert res[0]["norms"] == gold["norms"], res[0]
+    assert res[0]["err"] == gold["richardson_error"] and res[0]["order"] == gold["order"]

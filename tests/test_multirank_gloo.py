@@ -18,10 +18,11 @@ def free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def run_job(world, variant, log2, per_rank, backend="oracle"):
+def run_job(world, variant, log2, per_rank, backend="oracle", gather_dim=0):
+    """gather_dim=0: the reference's rank map on every level; > 0: levels of <= gather_dim^3 cells on rank 0 (the product default is 64)."""
     if backend == "oracle":
         build_oracle()
-    env = dict(os.environ, OMP_NUM_THREADS="2", MASTER_ADDR="127.0.0.1")
+    env = dict(os.environ, OMP_NUM_THREADS="2", MASTER_ADDR="127.0.0.1", HPGMG_GATHER_DIM=str(gather_dim))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), os.path.join(ROOT, "tests", "multirank_worker.py"), variant, str(log2), str(per_rank), backend]
     out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
@@ -59,3 +60,22 @@ def test_multirank_matches_single_rank_reference(world, variant, log2, per_rank,
     assert all(r["stats"]["messages"] > 50 and r["stats"]["allreduces"] > 5 for r in res)
     last = [r["levels"][-1] for r in res]
     assert last[0]["my_boxes"] == 1 and all(l["my_boxes"] == 0 and l["active"] == 0 for l in last[1:])
+
+
+@pytest.mark.parametrize("world,variant,log2,per_rank,gold_key,gather", [
+    (2, "7pt-cheby-helm", 4, 4, "7pt-cheby-helm 4 8", 16),     # 32^3 distributed, 16^3 and below gathered on rank 0
+    (4, "7pt-cheby", 4, 8, "7pt-cheby 4 27", 24),              # 48^3 over 4 ranks (7/7/7/6), 24^3 and below on rank 0
+    (4, "7pt-cheby", 4, 2, "7pt-cheby 4 8", 64),               # the default value: every coarse level of this small problem is on rank 0
+])
+def test_gathered_coarse_levels(world, variant, log2, per_rank, gold_key, gather):
+    """The MI355X rank map (levels <= gather^3 owned by rank 0, hpgmg_set_gather_dim) changes who owns a box,
+    never a number: rank 0 prints the reference's golden values."""
+    gold = GOLD[gold_key]
+    res = run_job(world, variant, log2, per_rank, gather_dim=gather)
+    assert res[0]["norms"] == gold["norms"], res[0]
+    assert res[0]["err"] == gold["richardson_error"] and res[0]["order"] == gold["order"]
+    for lv in range(1, len(res[0]["levels"])):          # the fine level is created by the caller with the reference's map
+        owners = [r["levels"][lv]["my_boxes"] for r in res]
+        if res[0]["levels"][lv]["dim"] <= gather:
+            assert all(n == 0 for n in owners[1:]) and owners[0] > 0, (lv, owners)
+    assert all(r["levels"][0]["my_boxes"] > 0 for r in res)
