@@ -71,7 +71,9 @@ void hpgmg_segment_begin(long long key) {
   static int graphs = -1;
   if (graphs < 0) { const char *e = getenv("HPGMG_GRAPH"); graphs = !(e && e[0] == '0'); }
   if (!graphs || sync_timers > 0) return;       /* HPGMG_GRAPH=0 / per-operator timing: stay eager */
-  if (hpgmg_get_transport()) return;            /* multi-rank: RCCL calls stay eager */
+  /* multi-rank: segments cover levels of <= 64^3 cells; they are message-free (capturable) only when the rank map
+   * gathers those levels on rank 0 (mg.c: hpgmg_gather_dim, the default) */
+  { extern int hpgmg_gather_dim; const hpgmg_transport *T = hpgmg_get_transport(); if (T && T->size > 1 && hpgmg_gather_dim < 64) return; }
   if (hpgmg_hip_graph_begin(key) < 0) { fprintf(stderr, "hpgmg: graph segment failed: %s\n", hpgmg_hip_last_error()); abort(); }
 }
 void hpgmg_segment_end(void) { HIP_OK(hpgmg_hip_graph_end()); }

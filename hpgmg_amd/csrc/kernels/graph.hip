@@ -38,6 +38,14 @@ int hpgmg_hip_graph_end(void) {
   if (state == SEG_CAPTURE) {
     hipGraph_t graph = nullptr;
     HPGMG_CHECK(hipStreamEndCapture(g_stream, &graph));
+    size_t nodes = 0;
+    if (graph) HPGMG_CHECK(hipGraphGetNodes(graph, nullptr, &nodes));
+    if (!graph || nodes == 0) {                      // nothing was launched (a rank that owns no box of these levels): stay eager
+      if (graph) HPGMG_CHECK(hipGraphDestroy(graph));
+      g_cache[g_key].seen = 2;
+      g_stats[0]++;
+      return 0;
+    }
     hipGraphExec_t exec = nullptr;
     HPGMG_CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
     HPGMG_CHECK(hipGraphDestroy(graph));
@@ -60,6 +68,7 @@ int hpgmg_hip_graph_begin(long long key) {
   Entry &e = g_cache[key];
   g_key = key;
   if (e.exec) { g_state = SEG_REPLAY; g_skip_launches = 1; }
+  else if (e.seen == 2) g_state = SEG_EAGER;          // known to be empty
   else if (e.seen) {
     if (hipStreamBeginCapture(g_stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); g_state = SEG_EAGER; }
     else g_state = SEG_CAPTURE;

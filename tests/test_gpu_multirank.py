@@ -28,6 +28,7 @@ def test_hip_multirank_matches_single_rank_reference(world, variant, log2, per_r
     res = run_job(world, variant, log2, per_rank, backend="hip")
     assert res[0]["norms"] == gold["norms"], res[0]
     assert res[0]["err"] == gold["richardson_error"] and res[0]["order"] == gold["order"]
+    assert res[0]["repeat"] == [gold["norms"][0]] * 3, res[0]["repeat"]
     for r in res:
         assert r["norms"][:2] == gold["norms"][:2], r
     total = int(gold_key.split()[-1])
@@ -39,6 +40,8 @@ def test_hip_multirank_matches_single_rank_reference(world, variant, log2, per_r
     (2, "7pt-cheby-helm", 4, 4, "7pt-cheby-helm 4 8", 16),
     (4, "7pt-cheby", 4, 8, "7pt-cheby 4 27", 24),
     (2, "fv4-gsrb", 4, 4, "fv4-gsrb 4 8", 16),
+    (4, "7pt-cheby-helm", 4, 2, "7pt-cheby-helm 4 8", 64),     # product default: hipGraph segments on rank 0, empty segments elsewhere
+    (2, "7pt-gsrb", 5, 4, "7pt-gsrb 5 8", 64),
 ])
 def test_hip_gathered_coarse_levels(world, variant, log2, per_rank, gold_key, gather):
     """Default product rank map (coarse levels gathered on rank 0, where the fused tail kernel runs them) on the HIP path."""
@@ -46,3 +49,4 @@ def test_hip_gathered_coarse_levels(world, variant, log2, per_rank, gold_key, ga
     res = run_job(world, variant, log2, per_rank, backend="hip", gather_dim=gather)
     assert res[0]["norms"] == gold["norms"], res[0]
     assert res[0]["err"] == gold["richardson_error"] and res[0]["order"] == gold["order"]
+    assert res[0]["repeat"] == [gold["norms"][0]] * 3, res[0]["repeat"]

@@ -51,6 +51,7 @@ def test_multirank_matches_single_rank_reference(world, variant, log2, per_rank,
     # rank 0 owns a box on every level and is the rank whose numbers the reference prints
     assert res[0]["norms"] == gold["norms"], res[0]
     assert res[0]["err"] == gold["richardson_error"] and res[0]["order"] == gold["order"]
+    assert res[0]["repeat"] == [gold["norms"][0]] * 3, res[0]["repeat"]
     for r in res:   # every rank sees the same reduced norm on the levels where it is active (h and 2h here)
         assert r["norms"][:2] == gold["norms"][:2], r
         assert r["err"] == gold["richardson_error"]
@@ -74,6 +75,7 @@ def test_gathered_coarse_levels(world, variant, log2, per_rank, gold_key, gather
     res = run_job(world, variant, log2, per_rank, gather_dim=gather)
     assert res[0]["norms"] == gold["norms"], res[0]
     assert res[0]["err"] == gold["richardson_error"] and res[0]["order"] == gold["order"]
+    assert res[0]["repeat"] == [gold["norms"][0]] * 3, res[0]["repeat"]
     for lv in range(1, len(res[0]["levels"])):          # the fine level is created by the caller with the reference's map
         owners = [r["levels"][lv]["my_boxes"] for r in res]
         if res[0]["levels"][lv]["dim"] <= gather:
