@@ -253,6 +253,64 @@ static void ghosts_for_stencil(level_type *L, int id) {
   apply_BCs(L, id, shape);
 }
 
+/* Halo exchange overlapped with the stencil launch that consumes it (north_star: "ghost-zone exchange on RCCL over
+ * xGMI overlapped with interior smoothing"; the reference only overlaps local copies with MPI latency,
+ * exchange_boundary.c:81-90).  Ghost-free 7-point path with faces owned by other ranks:
+ *     launch stream:  pack | stencil on every cell whose neighbours are local or Dirichlet  | wait | shell cells
+ *     comm stream:         | wait pack, grouped ncclSend/ncclRecv, unpack into ghost zones |
+ * overlap_begin() returns 0 when the level does not qualify (then the caller uses ghosts_for_stencil()). */
+static void *comm_stream = NULL, *ev_packed = NULL, *ev_landed = NULL;
+static int overlap_mode = -1;
+static long long overlap_count = 0;
+long long hpgmg_overlap_count(void) { return overlap_count; }   /* overlapped exchanges so far (tests) */
+void hpgmg_set_overlap(int on) { overlap_mode = on ? 1 : 0; }
+static int overlap_begin(level_type *L, int id) {
+  const int shape = stencil_get_shape();
+  const hpgmg_transport *T = hpgmg_get_transport();
+  hpgmg_config c;
+  if (overlap_mode < 0) { const char *e = getenv("HPGMG_OVERLAP"); overlap_mode = (e && e[0] == '0') ? 0 : 1; }
+  if (!overlap_mode || !T || T->size < 2) return 0;
+  hpgmg_get_config(&c);
+  if (!(ghost_free_mode() && c.op == HPGMG_OP_7PT && shape == STENCIL_SHAPE_STAR) || L->box_dim < 8) return 0;
+  communicator_type *C = &L->exchange_ghosts[shape];
+  if (C->num_sends + C->num_recvs == 0 || L->num_my_boxes < 1) return 0;
+  if (!comm_stream) {
+    comm_stream = hpgmg_hip_stream_create(); ev_packed = hpgmg_hip_event_create(); ev_landed = hpgmg_hip_event_create();
+    if (!comm_stream || !ev_packed || !ev_landed) { fprintf(stderr, "hpgmg: cannot create the exchange stream\n"); abort(); }
+  }
+  const double t0 = now();
+  backend_t *B = backend_of(L);
+  void *launch_stream = hpgmg_hip_get_stream();
+  hpgmg_hip_set_ghost_free(1);
+  HIP_OK(hpgmg_hip_copy_blocks(&B->dev, id, mirror(L, C->blocks[0], C->num_blocks[0]), C->num_blocks[0]));          /* pack */
+  const blockCopy_type *unpack = mirror(L, C->blocks[2], C->num_blocks[2]);
+  HIP_OK(hpgmg_hip_event_record(ev_packed));
+  hpgmg_hip_set_stream(comm_stream);
+  HIP_OK(hpgmg_hip_stream_wait_event(ev_packed));
+  transport_phase(C, C, (L->tag << 4) | shape);
+  HIP_OK(hpgmg_hip_copy_blocks(&B->dev, id, unpack, C->num_blocks[2]));                                              /* unpack */
+  HIP_OK(hpgmg_hip_event_record(ev_landed));
+  hpgmg_hip_set_stream(launch_stream);
+  L->timers.ghostZone_total += now() - t0;
+  overlap_count++;
+  return 1;
+}
+static void overlap_end(void) { HIP_OK(hpgmg_hip_stream_wait_event(ev_landed)); }
+/* run a stencil launch with its operand's ghost zones: overlapped (two launches: all but the shell, then the shell) or plain */
+#define STENCIL_WITH_GHOSTS(L, id, TIMER, CALL) do {                                                     \
+    if (overlap_begin(L, id)) {                                                                          \
+      const double t0_ = now();                                                                          \
+      hpgmg_hip_set_defer_mode(1); HIP_OK(CALL);                                                         \
+      overlap_end();                                                                                     \
+      hpgmg_hip_set_defer_mode(2); HIP_OK(CALL); hpgmg_hip_set_defer_mode(0);                            \
+      (L)->timers.TIMER += now() - t0_;                                                                  \
+    } else {                                                                                             \
+      ghosts_for_stencil(L, id);                                                                         \
+      const double t0_ = now();                                                                          \
+      HIP_OK(CALL);                                                                                      \
+      (L)->timers.TIMER += now() - t0_;                                                                  \
+    } } while (0)
+
 /* ---------------------------------------------------------------- boundary_fd.c / boundary_fv.c */
 void apply_BCs_p1(level_type *L, int x_id, int shape) {
   if (shape >= STENCIL_MAX_SHAPES) shape = STENCIL_SHAPE_BOX;
@@ -485,42 +543,27 @@ void smooth(level_type *L, int x_id, int rhs_id, double a, double b) {
     if (smooth_cheby_pairs(L, x_id, rhs_id, a, b, c1, c2, sweeps)) return;
     for (s = 0; s < sweeps; s++) {
       const int src = (s & 1) ? VECTOR_TEMP : x_id, dst = (s & 1) ? x_id : VECTOR_TEMP;
-      ghosts_for_stencil(L, src);
-      const double t0 = now();
-      HIP_OK(hpgmg_hip_smooth_cheby(&B->dev, v, src, dst, rhs_id, a, b, h2inv, c1[s], c2[s]));
-      L->timers.smooth += now() - t0;
+      STENCIL_WITH_GHOSTS(L, src, smooth, hpgmg_hip_smooth_cheby(&B->dev, v, src, dst, rhs_id, a, b, h2inv, c1[s], c2[s]));
     }
   } else if (cfg.smoother == HPGMG_SMOOTH_GSRB) {    /* gsrb.c:24-132 */
     const int oop = hpgmg_gsrb_out_of_place();
     for (s = 0; s < sweeps; s++) {
       const int src = (oop && (s & 1)) ? VECTOR_TEMP : x_id, dst = oop ? ((s & 1) ? x_id : VECTOR_TEMP) : x_id;
-      ghosts_for_stencil(L, src);
-      const double t0 = now();
-      HIP_OK(hpgmg_hip_smooth_gsrb(&B->dev, v, src, dst, rhs_id, a, b, h2inv, s));
-      L->timers.smooth += now() - t0;
+      STENCIL_WITH_GHOSTS(L, src, smooth, hpgmg_hip_smooth_gsrb(&B->dev, v, src, dst, rhs_id, a, b, h2inv, s));
     }
   } else {                                           /* jacobi.c:8-65 */
     for (s = 0; s < sweeps; s++) {
       const int src = (s & 1) ? VECTOR_TEMP : x_id, dst = (s & 1) ? x_id : VECTOR_TEMP;
-      ghosts_for_stencil(L, src);
-      const double t0 = now();
-      HIP_OK(hpgmg_hip_smooth_jacobi(&B->dev, v, src, dst, rhs_id, a, b, h2inv, 2.0 / 3.0));
-      L->timers.smooth += now() - t0;
+      STENCIL_WITH_GHOSTS(L, src, smooth, hpgmg_hip_smooth_jacobi(&B->dev, v, src, dst, rhs_id, a, b, h2inv, 2.0 / 3.0));
     }
   }
 }
 
 void residual(level_type *L, int res_id, int x_id, int rhs_id, double a, double b) {   /* residual.c:9-51 */
-  ghosts_for_stencil(L, x_id);
-  const double t0 = now();
-  HIP_OK(hpgmg_hip_residual(&backend_of(L)->dev, variant(), res_id, x_id, rhs_id, a, b, 1.0 / (L->h * L->h)));
-  L->timers.residual += now() - t0;
+  STENCIL_WITH_GHOSTS(L, x_id, residual, hpgmg_hip_residual(&backend_of(L)->dev, variant(), res_id, x_id, rhs_id, a, b, 1.0 / (L->h * L->h)));
 }
 void apply_op(level_type *L, int Ax_id, int x_id, double a, double b) {               /* apply_op.c:9-48 */
-  ghosts_for_stencil(L, x_id);
-  const double t0 = now();
-  HIP_OK(hpgmg_hip_residual(&backend_of(L)->dev, variant(), Ax_id, x_id, -1, a, b, 1.0 / (L->h * L->h)));
-  L->timers.apply_op += now() - t0;
+  STENCIL_WITH_GHOSTS(L, x_id, apply_op, hpgmg_hip_residual(&backend_of(L)->dev, variant(), Ax_id, x_id, -1, a, b, 1.0 / (L->h * L->h)));
 }
 
 /* ---------------------------------------------------------------- restriction.c:104-212 */

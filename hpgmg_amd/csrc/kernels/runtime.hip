@@ -47,6 +47,9 @@ int hpgmg_hip_memcpy_d2h(void *d, const void *s, size_t n) { hpgmg_hip_graph_flu
 int hpgmg_hip_memcpy_d2d(void *d, const void *s, size_t n) { hpgmg_hip_graph_flush(); HPGMG_CHECK(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, g_stream)); return 0; }
 int hpgmg_hip_memset0(void *d, size_t n) { hpgmg_hip_graph_flush(); HPGMG_CHECK(hipMemsetAsync(d, 0, n, g_stream)); return 0; }
 
+void *hpgmg_hip_stream_create(void) { hipStream_t s; if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return nullptr; return (void *)s; }
+void hpgmg_hip_stream_destroy(void *s) { if (s) (void)hipStreamDestroy((hipStream_t)s); }
+int hpgmg_hip_stream_wait_event(void *e) { HPGMG_CHECK(hipStreamWaitEvent(g_stream, (hipEvent_t)e, 0)); return 0; }
 void *hpgmg_hip_event_create(void) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return nullptr; return (void *)e; }
 void hpgmg_hip_event_destroy(void *e) { if (e) (void)hipEventDestroy((hipEvent_t)e); }
 int hpgmg_hip_event_record(void *e) { HPGMG_CHECK(hipEventRecord((hipEvent_t)e, g_stream)); return 0; }

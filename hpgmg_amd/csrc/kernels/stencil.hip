@@ -36,6 +36,8 @@ struct StencilArgs {
   int copy_other_colour;        // GSRB out of place
   int tiles_i, tiles_j, chunks_k, kchunk, per_xcd, total_blocks;
   int ghost_free;               // read face neighbours from the adjacent box / apply the Dirichlet BC in registers
+  int defer;                    // 1: leave the cells next to a face owned by another rank untouched (their ghost values are still
+                                //    in flight); stencil7_shell_kernel computes them once the exchange has landed
 };
 
 // x may alias the output only for in-place GSRB; everywhere else it is restrict-qualified
@@ -87,6 +89,13 @@ __global__ __launch_bounds__(256) void stencil7_kernel(const hpgmg_hip_level L, 
     return x[idx_ghost];
   };
   const bool gf = P.ghost_free != 0;
+  // cells whose stencil reaches into a ghost zone another rank fills (box_nbr == -2)
+  bool defer_ij = false, defer_klo = false, defer_khi = false;
+  if (P.defer) {
+    const int *nb = L.box_nbr + 6 * box;
+    defer_ij = (i == 0 && nb[0] == -2) || (i == last && nb[1] == -2) || (j == 0 && nb[2] == -2) || (j == last && nb[3] == -2);
+    defer_klo = (nb[4] == -2); defer_khi = (nb[5] == -2);
+  }
 
   int ijk = i + j * jS + k0 * kS;
   double xc = x[ijk];
@@ -98,7 +107,8 @@ __global__ __launch_bounds__(256) void stencil7_kernel(const hpgmg_hip_level L, 
     const double bk1 = kVC ? beta_k[ijk + kS] : 0.0;
     bool update = true;
     if (MODE == MODE_GSRB) update = (((i ^ j ^ k ^ colour000) & 1) == 0);
-    if (MODE != MODE_GSRB || update) {
+    if (P.defer && (defer_ij || (k == 0 && defer_klo) || (k == last && defer_khi))) update = false;
+    if (update) {
       const double xim = (gf && i == 0)    ? outside(0, last + j * jS + k * kS, ijk - 1, xc)  : x[ijk - 1];
       const double xip = (gf && i == last) ? outside(1, j * jS + k * kS, ijk + 1, xc)          : x[ijk + 1];
       const double xjm = (gf && j == 0)    ? outside(2, i + last * jS + k * kS, ijk - jS, xc) : x[ijk - jS];
@@ -196,6 +206,16 @@ __global__ __launch_bounds__(64 * WJ) void stencil7_wide_kernel(const hpgmg_hip_
   int colour000 = 0;
   if (MODE == MODE_GSRB) colour000 = (L.box_low[3 * box] ^ L.box_low[3 * box + 1] ^ L.box_low[3 * box + 2] ^ P.sweep) & 1;
 
+  // cells next to a face another rank owns (P.defer): bit 0 = the pair's first cell, bit 1 = its second cell
+  int dm_a = 0, dm_b = 0; bool defer_klo = false, defer_khi = false;
+  if (P.defer) {
+    const int *nb = L.box_nbr + 6 * box;
+    const int di = ((i == 0 && nb[0] == -2) ? 1 : 0) | ((i + 1 == last && nb[1] == -2) ? 2 : 0);
+    dm_a = (ja == 0 && nb[2] == -2) ? 3 : di;
+    dm_b = (ja + 1 == last && nb[3] == -2) ? 3 : di;
+    defer_klo = (nb[4] == -2); defer_khi = (nb[5] == -2);
+  }
+
   int ia = i + ja * jS + k0 * kS;          // index of (i, ja, k); row b is ia + jS
   d2 xc_a = ld2(x + ia), xc_b = ld2(x + ia + jS);
   d2 xm_a = (gf && k0 == 0) ? outside2(4, i + ja * jS + last * kS, ia - kS, xc_a) : ld2(x + ia - kS);
@@ -233,8 +253,10 @@ __global__ __launch_bounds__(64 * WJ) void stencil7_wide_kernel(const hpgmg_hip_
     d2 bj_lo = {0, 0}, bj_mid = {0, 0}, bj_hi = {0, 0};
     if (kVC) { bj_lo = ld2(beta_j + ia); bj_mid = ld2(beta_j + ib); bj_hi = ld2(beta_j + ib + jS); }
 
-#define HPGMG_ROW(IDX, XC, XM, XP, XJM, XJP, XL, XR, BK0, BK1, BJL, BJH, JROW)                                              \
+    const bool defer_plane = P.defer && ((k == 0 && defer_klo) || (k == last && defer_khi));
+#define HPGMG_ROW(IDX, XC, XM, XP, XJM, XJP, XL, XR, BK0, BK1, BJL, BJH, JROW, DM)                                          \
     {                                                                                                                        \
+      const int dm = defer_plane ? 3 : DM;                                                                                   \
       d2 bi = {0, 0}, al = {0, 0}; double bir = 0;                                                                           \
       if (kVC) { bi = ld2(beta_i + IDX); bir = __shfl_down(bi.x, 1, 64); if (lane == 63) bir = beta_i[IDX + 2]; }            \
       if (kHelm) al = ld2(alpha + IDX);                                                                                     \
@@ -247,7 +269,7 @@ __global__ __launch_bounds__(64 * WJ) void stencil7_wide_kernel(const hpgmg_hip_
                                           pp ? al.y : al.x, P.a, P.b, P.h2inv);                                             \
         const d2 r2 = ld2(rhs + IDX), dv = ld2(dinv + IDX);                                                                 \
         const double xn = c + (pp ? dv.y : dv.x) * ((pp ? r2.y : r2.x) - Ax);                                              \
-        if (P.copy_other_colour) st2(out + IDX, pp ? d2{XC.x, xn} : d2{xn, XC.y}); else out[IDX + pp] = xn;                 \
+        if (P.copy_other_colour) st2(out + IDX, pp ? d2{XC.x, xn} : d2{xn, XC.y}); else if (!((dm >> pp) & 1)) out[IDX + pp] = xn; \
       } else {                                                                                                              \
         const double Ax0 = apply_op_7pt<V>(XC.x, XL, XC.y, XJM.x, XJP.x, XM.x, XP.x, bi.x, bi.y, BJL.x, BJH.x, BK0.x, BK1.x, al.x, P.a, P.b, P.h2inv); \
         const double Ax1 = apply_op_7pt<V>(XC.y, XC.x, XR, XJM.y, XJP.y, XM.y, XP.y, bi.y, bir, BJL.y, BJH.y, BK0.y, BK1.y, al.y, P.a, P.b, P.h2inv);  \
@@ -268,11 +290,12 @@ __global__ __launch_bounds__(64 * WJ) void stencil7_wide_kernel(const hpgmg_hip_
             }                                                                                                               \
           }                                                                                                                 \
         }                                                                                                                   \
-        st2(out + IDX, o);                                                                                                  \
+        if (dm == 0) st2(out + IDX, o);                                                                                     \
+        else { if (!(dm & 1)) out[IDX] = o.x; if (!(dm & 2)) out[IDX + 1] = o.y; }                                          \
       }                                                                                                                     \
     }
-    HPGMG_ROW(ia, xc_a, xm_a, xp_a, xjm_a, xc_b, xl_a, xr_a, bk0_a, bk1_a, bj_lo, bj_mid, ja)
-    HPGMG_ROW(ib, xc_b, xm_b, xp_b, xc_a, xjp_b, xl_b, xr_b, bk0_b, bk1_b, bj_mid, bj_hi, (ja + 1))
+    HPGMG_ROW(ia, xc_a, xm_a, xp_a, xjm_a, xc_b, xl_a, xr_a, bk0_a, bk1_a, bj_lo, bj_mid, ja, dm_a)
+    HPGMG_ROW(ib, xc_b, xm_b, xp_b, xc_a, xjp_b, xl_b, xr_b, bk0_b, bk1_b, bj_mid, bj_hi, (ja + 1), dm_b)
 #undef HPGMG_ROW
     // hand the plane k+1 rows to the neighbouring waves for the next step
     slab[(k + 1) & 1][2 * ty][lane] = xp_a;
@@ -283,6 +306,61 @@ __global__ __launch_bounds__(64 * WJ) void stencil7_wide_kernel(const hpgmg_hip_
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// The cells a deferred launch (StencilArgs.defer) skipped: one lane per cell of every box face whose neighbour
+// box lives on another rank, run after that rank's ghost data has been unpacked.  A cell on an edge or corner
+// shared by several such faces is computed by the lowest-numbered face only (in-place GSRB must not update twice).
+template <int V, int MODE>
+__global__ __launch_bounds__(256) void stencil7_shell_kernel(const hpgmg_hip_level L, const StencilArgs P) {
+  const int box = blockIdx.y / 6, dir = blockIdx.y % 6;
+  const int *nb = L.box_nbr + 6 * box;
+  if (nb[dir] != -2) return;
+  const int dim = L.dim, last = dim - 1, t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= dim * dim) return;
+  const int u = t % dim, v = t / dim, side = (dir & 1) ? last : 0;
+  int i, j, k;
+  if (dir < 2) { i = side; j = u; k = v; } else if (dir < 4) { j = side; i = u; k = v; } else { k = side; i = u; j = v; }
+  const int on_face[6] = { i == 0, i == last, j == 0, j == last, k == 0, k == last };
+  for (int d = 0; d < dir; d++) if (on_face[d] && nb[d] == -2) return;
+  constexpr bool kVC = (V != HPGMG_HIP_7PT_CC);
+  constexpr bool kHelm = (V == HPGMG_HIP_7PT_VC_HELMHOLTZ);
+  const int jS = L.jStride, kS = L.kStride, ijk = i + j * jS + k * kS;
+  if (MODE == MODE_GSRB) {
+    const int colour000 = (L.box_low[3 * box] ^ L.box_low[3 * box + 1] ^ L.box_low[3 * box + 2] ^ P.sweep) & 1;
+    if (((i ^ j ^ k ^ colour000) & 1) != 0) return;
+  }
+  const double *x = vec_origin(L, box, P.xn_id);
+  double *out = vec_origin(L, box, P.xout_id);
+  const double xc = x[ijk];
+  auto outside = [&](int d, int idx_in_neighbour, int idx_ghost) -> double {
+    const int n = nb[d];
+    if (n >= 0) return vec_origin(L, n, P.xn_id)[idx_in_neighbour];
+    if (n == -1) return -xc;
+    return x[idx_ghost];
+  };
+  const bool gf = P.ghost_free != 0;
+  const double xim = (gf && i == 0)    ? outside(0, last + j * jS + k * kS, ijk - 1)  : x[ijk - 1];
+  const double xip = (gf && i == last) ? outside(1, j * jS + k * kS, ijk + 1)          : x[ijk + 1];
+  const double xjm = (gf && j == 0)    ? outside(2, i + last * jS + k * kS, ijk - jS) : x[ijk - jS];
+  const double xjp = (gf && j == last) ? outside(3, i + k * kS, ijk + jS)              : x[ijk + jS];
+  const double xkm = (gf && k == 0)    ? outside(4, i + j * jS + last * kS, ijk - kS) : x[ijk - kS];
+  const double xkp = (gf && k == last) ? outside(5, i + j * jS, ijk + kS)              : x[ijk + kS];
+  double bi0 = 0, bi1 = 0, bj0 = 0, bj1 = 0, bk0 = 0, bk1 = 0, al = 0;
+  if (kVC) {
+    const double *bi = vec_origin(L, box, VECTOR_BETA_I), *bj = vec_origin(L, box, VECTOR_BETA_J), *bk = vec_origin(L, box, VECTOR_BETA_K);
+    bi0 = bi[ijk]; bi1 = bi[ijk + 1]; bj0 = bj[ijk]; bj1 = bj[ijk + jS]; bk0 = bk[ijk]; bk1 = bk[ijk + kS];
+  }
+  if (kHelm) al = vec_origin(L, box, VECTOR_ALPHA)[ijk];
+  const double Ax = apply_op_7pt<V>(xc, xim, xip, xjm, xjp, xkm, xkp, bi0, bi1, bj0, bj1, bk0, bk1, al, P.a, P.b, P.h2inv);
+  if (MODE == MODE_APPLY) { out[ijk] = Ax; return; }
+  const double rhs = vec_origin(L, box, P.rhs_id)[ijk];
+  if (MODE == MODE_RESIDUAL) { out[ijk] = rhs - Ax; return; }
+  const double dinv = vec_origin(L, box, VECTOR_DINV)[ijk];
+  if (MODE == MODE_CHEBY)      { const double xnm1 = out[ijk]; out[ijk] = xc + P.c1 * (xc - xnm1) + P.c2 * dinv * (rhs - Ax); }
+  else if (MODE == MODE_GSRB)  { out[ijk] = xc + dinv * (rhs - Ax); }
+  else                         { out[ijk] = xc + P.c2 * dinv * (rhs - Ax); }
+}
 
 // ---------------------------------------------------------------------------------------------
 // 27-point constant-coefficient operator (reference operators.27pt.c:48-51,60-91).
@@ -489,6 +567,7 @@ static void profile_end(int p, long long cells) {
 }
 
 static int g_ghost_free = 0;
+static int g_defer_mode = 0;   // 0: whole boxes; 1: skip the cells next to remote faces; 2: only those cells (stencil7_shell_kernel)
 
 static int env_int(const char *name, int dflt) { const char *e = getenv(name); return (e && *e) ? atoi(e) : dflt; }
 
@@ -560,6 +639,22 @@ static int launch(const hpgmg_hip_level *L, int variant, StencilArgs P, bool is_
   if (variant == HPGMG_HIP_FV4_VC_HELMHOLTZ || variant == HPGMG_HIP_FV4_VC_POISSON) return launch_direct<MODE>(L, variant, P, is_smoother);
   dim3 block; int grid;
   plan(L, P, block, grid);
+  if (g_defer_mode) {
+    if (!P.ghost_free || P.copy_other_colour || MODE == MODE_BLACKBOX) return record_error(hipErrorInvalidValue, "deferred stencil launch needs the ghost-free 7-point path");
+    if (g_defer_mode == 2) {
+      if (L->dim < 2) return record_error(hipErrorInvalidValue, "deferred stencil launch needs boxes of at least 2^3");
+      dim3 sgrid((L->dim * L->dim + 255) / 256, L->num_boxes * 6);
+      switch (variant) {
+        case HPGMG_HIP_7PT_VC_HELMHOLTZ: hipLaunchKernelGGL((stencil7_shell_kernel<HPGMG_HIP_7PT_VC_HELMHOLTZ, MODE>), sgrid, dim3(256), 0, g_stream, *L, P); break;
+        case HPGMG_HIP_7PT_VC_POISSON:   hipLaunchKernelGGL((stencil7_shell_kernel<HPGMG_HIP_7PT_VC_POISSON, MODE>), sgrid, dim3(256), 0, g_stream, *L, P); break;
+        case HPGMG_HIP_7PT_CC:           hipLaunchKernelGGL((stencil7_shell_kernel<HPGMG_HIP_7PT_CC, MODE>), sgrid, dim3(256), 0, g_stream, *L, P); break;
+        default: return record_error(hipErrorInvalidValue, "stencil variant not implemented");
+      }
+      HPGMG_LAUNCH_CHECK("stencil7_shell_kernel");
+      return 0;
+    }
+    P.defer = 1;
+  }
   const long long cells = (long long)L->num_boxes * L->dim * L->dim * L->dim;
   int prof = is_smoother ? profile_begin(cells) : -1;
   static const int no_wide = env_int("HPGMG_TUNE_NO_WIDE", 0);
@@ -604,6 +699,7 @@ using namespace hpgmg;
 extern "C" {
 
 void hpgmg_hip_set_ghost_free(int on) { g_ghost_free = on; }
+void hpgmg_hip_set_defer_mode(int mode) { g_defer_mode = mode; }
 int hpgmg_hip_get_ghost_free(void) { return g_ghost_free; }
 
 void hpgmg_hip_profile_smoother(int enable) {

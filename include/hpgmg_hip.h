@@ -59,6 +59,9 @@ const char *hpgmg_hip_last_error(void);
 void  *hpgmg_hip_event_create(void);
 void   hpgmg_hip_event_destroy(void *ev);
 int    hpgmg_hip_event_record(void *ev);
+void  *hpgmg_hip_stream_create(void);               /* a second (non-blocking) stream, e.g. for the halo exchange */
+void   hpgmg_hip_stream_destroy(void *stream);
+int    hpgmg_hip_stream_wait_event(void *ev);       /* the CURRENT launch stream waits for ev */
 double hpgmg_hip_event_elapsed_ms(void *start, void *stop); /* synchronises on stop */
 /* accumulate the GPU time of every smoother-kernel launch between begin/end (hipEvents around each launch) */
 void   hpgmg_hip_profile_smoother(int enable);
@@ -79,6 +82,10 @@ int  hpgmg_hip_get_ghost_free(void);
  * Jacobi read x_n and write x_np1 (x_np1 doubles as x_{n-1} for Chebyshev);
  * GSRB updates the cells whose global parity (i+j+k+sweep) is even, in place
  * when xn_id == xnp1_id, otherwise copying the other colour. */
+/* Overlap of the halo exchange with the stencil launches below (ghost-free 7-point path only): mode 1 = the next
+ * launches leave the cells next to a face owned by another rank (box_nbr == -2) untouched, mode 2 = the next launches
+ * compute exactly those cells (one lane per cell), mode 0 = whole boxes. */
+void hpgmg_hip_set_defer_mode(int mode);
 int hpgmg_hip_smooth_cheby(const hpgmg_hip_level *L, int variant, int xn_id, int xnp1_id, int rhs_id,
                            double a, double b, double h2inv, double c1, double c2);
 /* Two consecutive Chebyshev sweeps (chebyshev.c:43-99 twice) in one pass: x1 = S(x0, xm1; c1a, c2a),

@@ -100,6 +100,9 @@ def main():
     for l in range(s.num_levels()):
         lv = s.level(l)
         levels.append({"dim": lv.dim, "box_dim": lv.box_dim, "my_boxes": lv.num_boxes, "active": lv.info[12]})
+    if backend == "hip":
+        be.lib.hpgmg_overlap_count.restype = ctypes.c_longlong
+        stats["overlapped_exchanges"] = be.lib.hpgmg_overlap_count()
     s.destroy()
     print("RESULT " + json.dumps({"rank": rank, "norms": ["%1.15e" % v for v in norms], "err": "%1.15e" % err,
                                   "order": "%0.3f" % order, "levels": levels, "stats": stats, "repeat": repeat}), flush=True)

@@ -17,6 +17,7 @@ GOLD = load_golden("fcycle_norms.json")
     (2, "7pt-cheby-helm", 4, 4, "7pt-cheby-helm 4 8"),
     (2, "7pt-gsrb", 4, 4, "7pt-gsrb 4 8"),
     (4, "7pt-cheby", 4, 2, "7pt-cheby 4 8"),
+    (2, "7pt-cheby-helm", 7, 4, "7pt-cheby-helm 7 8"),    # bench.py --gpus 2 at full size: 2 x 4 boxes of 128^3 (wide kernel + shell launches)
     (4, "7pt-cheby", 4, 8, "7pt-cheby 4 27"),          # bench.py --gpus 4 in small: 27 boxes over 4 ranks (7/7/7/6), 48^3
     (2, "27pt-cheby", 4, 4, "27pt-cheby 4 8"),
     (2, "fv4-gsrb", 4, 4, "fv4-gsrb 4 8"),
@@ -34,6 +35,8 @@ def test_hip_multirank_matches_single_rank_reference(world, variant, log2, per_r
     total = int(gold_key.split()[-1])
     assert sum(r["levels"][0]["my_boxes"] for r in res) == total
     assert all(r["stats"]["messages"] > 50 for r in res)
+    if variant.startswith("7pt"):     # the 7-point path overlaps its halo exchanges with the stencil launches
+        assert all(r["stats"]["overlapped_exchanges"] > 20 for r in res), [r["stats"] for r in res]
 
 
 @pytest.mark.parametrize("world,variant,log2,per_rank,gold_key,gather", [
