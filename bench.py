@@ -94,6 +94,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", choices=["fp64", "fp32"], default="fp64",
+                    help="fp32 = BASELINE.json config 5: mixed-precision Chebyshev smoother (fp32 coefficient streams), tolerance-gated; default fp64 = config 2, bit-exact")
     args = ap.parse_args()
 
     import torch
@@ -126,6 +128,9 @@ def main():
         lib.hpgmg_transport_init_rccl.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int]
         assert lib.hpgmg_transport_init_rccl(bytes(ident.cpu().tolist()), rank, world) == 0
 
+    mixed = args.precision == "fp32"
+    lib.hpgmg_set_smoother_precision.argtypes = [ctypes.c_int]
+    lib.hpgmg_set_smoother_precision(32 if mixed else 64)
     cfg = H.Config(H.OP_7PT, H.SMOOTH_CHEBY, 1, 1)
     assert lib.hpgmg_configure(ctypes.byref(cfg)) == 0
     solver = lib.hpgmg_solver_create(LOG2_BOX_DIM, BOXES_PER_RANK, H.BC_DIRICHLET, rank, world)
@@ -170,10 +175,11 @@ def main():
         roof = None
         if launches.value > 0 and ms.value > 0:
             avg_s = ms.value * 1e-3 / launches.value
-            bytes_per_launch = BYTES_PER_CELL_CHEBY_HELMHOLTZ * (cells.value / launches.value)
+            # mixed precision: Dinv, alpha, beta_i/j/k are 4-byte streams -> 72 - 5*4 = 52 B per cell per sweep
+            bytes_per_launch = (52 if mixed else BYTES_PER_CELL_CHEBY_HELMHOLTZ) * (cells.value / launches.value)
             achieved = bytes_per_launch / avg_s / 1e9
             roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(),
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None if mixed else pmc_traffic(),
                     "kernel": "hpgmg::cheby_pair_kernel<VC Helmholtz> (+ its edge-column pre-pass) on the finest level: one launch = TWO Chebyshev sweeps over 8 boxes of 128^3",
                     "sweeps_per_launch": round(cells.value / launches.value / fine_cells, 3),
                     "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_us": round(avg_s * 1e6, 2),
@@ -181,9 +187,10 @@ def main():
         line = {
             "metric": "DOF/s (fine-grid) for FMG F-cycle", "value": dof / sec_per_step, "unit": "DOF/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": sec_per_step * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64 arithmetic and iterate, f32 coefficient streams in the smoother" if mixed else "f64", "data": "synthetic",
             "config": {"workload": f"hpgmg-fv {LOG2_BOX_DIM} {BOXES_PER_RANK}: {dim}^3 fp64 7-pt variable-coefficient Helmholtz, "
-                                   f"Chebyshev smoother, {BOXES_PER_RANK} boxes of {box_dim}^3 per GPU, BiCGStab bottom, Dirichlet",
+                                   f"Chebyshev smoother{' (mixed precision, BASELINE config 5)' if mixed else ''}, {BOXES_PER_RANK} boxes of {box_dim}^3 per GPU, BiCGStab bottom, Dirichlet",
                        "fine_grid_dof": dof, "fcycle_residual_norm": norm, "parallelism": f"boxes over {world} GPU(s), RCCL halo exchange"},
             "roofline": roof,
         }

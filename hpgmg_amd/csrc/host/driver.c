@@ -112,7 +112,7 @@ void hpgmg_solver_richardson(hpgmg_solver *s, double out[2]) {
 /* ------------------------------------------------------------------ CLI */
 static int usage(int rank) {
   if (rank == 0) fprintf(stderr,
-    "usage: hpgmg-fv [--op 7pt|27pt|fv4|fv2] [--smoother cheby|gsrb|jacobi] [--helmholtz] [--const-coeff]\n"
+    "usage: hpgmg-fv [--op 7pt|27pt|fv4|fv2] [--smoother cheby|gsrb|jacobi] [--helmholtz] [--const-coeff] [--fp32-smoother]\n"
     "                [--warmup N] [--solves N] [--rank R --ranks N]  log2_box_dim  target_boxes_per_rank\n");
   return 0;
 }
@@ -131,6 +131,7 @@ int hpgmg_fv_main(int argc, char **argv) {
       else if (!strcmp(argv[a], "jacobi")) cfg.smoother = HPGMG_SMOOTH_JACOBI; else return usage(my_rank);
     } else if (!strcmp(argv[a], "--helmholtz")) cfg.helmholtz = 1;
     else if (!strcmp(argv[a], "--const-coeff")) cfg.variable_coeff = 0;
+    else if (!strcmp(argv[a], "--fp32-smoother")) hpgmg_set_smoother_precision(32);
     else if (!strcmp(argv[a], "--test-error")) test_error_only = 1;
     else if (!strcmp(argv[a], "--warmup") && a + 1 < argc) warmup = atoi(argv[++a]);
     else if (!strcmp(argv[a], "--solves") && a + 1 < argc) solves = atoi(argv[++a]);

@@ -88,9 +88,11 @@ typedef struct {
   int num_lists;
   int *krylov_pinned;          /* iterations of device-side bottom solves not yet folded into level->Krylov_iterations */
   double *pair_scratch; double **d_pair_base;   /* two private vectors per box for the fused Chebyshev sweep pairs */
+  float *coef32; float **d_coef32_base; int coef32_valid;   /* fp32 copies of Dinv, alpha, beta_* for the mixed-precision smoother */
   int lexicographic;           /* -1 unknown, else whether local box b sits at (b % nb, (b / nb) % nb, b / nb^2) and all boxes are local */
 } backend_t;
 
+static void coef32_invalidate(level_type *L);
 static backend_t *backend_of(level_type *L) {
   hpgmg_level_ext *X = hpgmg_level_ext_get(L);
   backend_t *B = (backend_t *)X->backend;
@@ -182,6 +184,8 @@ void hpgmg_level_release(level_type *L) {
   if (B->d_box_nbr) hpgmg_hip_free(B->d_box_nbr);
   if (B->krylov_pinned) hpgmg_hip_host_free(B->krylov_pinned);
   if (B->pair_scratch) hpgmg_hip_free(B->pair_scratch);
+  if (B->coef32) hpgmg_hip_free(B->coef32);
+  if (B->d_coef32_base) hpgmg_hip_free(B->d_coef32_base);
   if (B->d_pair_base) hpgmg_hip_free(B->d_pair_base);
   free(B);
   X->backend = NULL;
@@ -362,6 +366,7 @@ void extrapolate_betas(level_type *L) {                                         
 static int variant(void);
 /* operators/rebuild.c:47-208: probe with colors^3 0/1 colourings (exchange + BCs each time), accumulate on the device */
 void rebuild_operator_blackbox(level_type *L, double a, double b, int colors) {
+  coef32_invalidate(L);
   if (L->dim.i < colors) colors = L->dim.i;
   if (L->dim.j < colors) colors = L->dim.j;
   if (L->dim.k < colors) colors = L->dim.k;
@@ -496,6 +501,36 @@ static int boxes_lexicographic(level_type *L) {
 /* Chebyshev smooth() as fused sweep pairs (kernels/cheby_pair.hpp): 4 sweeps = 2 passes of 10 streams instead of
  * 4 x 9.  x1,x2 of the first pair go to two plugin-private vectors, the second pair brings x3 -> VECTOR_TEMP and
  * x4 -> x_id, i.e. exactly the state chebyshev.c:43-99 leaves.  Returns 0 when the level does not qualify. */
+/* BASELINE config 5: mixed-precision Chebyshev smoother.  32 = the fused sweep pairs read fp32 copies of the five
+ * coefficient vectors (the iterate, the right-hand side and all arithmetic stay fp64; residual, restriction,
+ * interpolation and every level the pair kernel does not cover are unchanged).  64 (default) = bit-exact fp64. */
+static int smoother_bits = 0;
+void hpgmg_set_smoother_precision(int bits) { smoother_bits = (bits == 32) ? 32 : 64; }
+int hpgmg_get_smoother_precision(void) {
+  if (!smoother_bits) { const char *e = getenv("HPGMG_SMOOTHER_PRECISION"); smoother_bits = (e && atoi(e) == 32) ? 32 : 64; }
+  return smoother_bits;
+}
+static const float *const *coef32_of(level_type *L) {
+  backend_t *B = backend_of(L);
+  if (hpgmg_get_smoother_precision() != 32) return NULL;
+  if (!B->coef32) {
+    int bx;
+    float **base = (float **)calloc((size_t)L->num_my_boxes, sizeof(float *));
+    B->coef32 = (float *)hpgmg_hip_malloc(((size_t)L->num_my_boxes * 5 * (size_t)L->box_volume + 4) * sizeof(float));
+    B->d_coef32_base = (float **)hpgmg_hip_malloc((size_t)L->num_my_boxes * sizeof(float *));
+    if (!B->coef32 || !B->d_coef32_base) { fprintf(stderr, "hpgmg: no memory for the fp32 coefficient copies\n"); abort(); }
+    /* pairs (2 floats) must be 8-byte aligned where the fp64 pairs are 16-byte aligned: same parity of the first interior cell */
+    const size_t pad = ((uintptr_t)L->my_boxes[0].vectors[0] % 16) / sizeof(double);
+    for (bx = 0; bx < L->num_my_boxes; bx++) base[bx] = B->coef32 + pad + (size_t)bx * 5 * (size_t)L->box_volume;
+    HIP_OK(hpgmg_hip_memcpy_h2d(B->d_coef32_base, base, (size_t)L->num_my_boxes * sizeof(float *)));
+    free(base);
+    B->coef32_valid = 0;
+  }
+  if (!B->coef32_valid) { HIP_OK(hpgmg_hip_coef32_refresh(&B->dev, (float *const *)B->d_coef32_base, L->numVectors)); B->coef32_valid = 1; }
+  return (const float *const *)B->d_coef32_base;
+}
+static void coef32_invalidate(level_type *L) { backend_t *B = backend_of(L); B->coef32_valid = 0; }
+
 static int fused_sweeps = -1;
 void hpgmg_set_fused_sweeps(int on) { fused_sweeps = on ? 1 : 0; }
 static int smooth_cheby_pairs(level_type *L, int x_id, int rhs_id, double a, double b, const double *c1, const double *c2, int sweeps) {
@@ -523,8 +558,9 @@ static int smooth_cheby_pairs(level_type *L, int x_id, int rhs_id, double a, dou
   const int v = variant();
   const double t0 = now();
   hpgmg_hip_set_ghost_free(1);
-  HIP_OK(hpgmg_hip_smooth_cheby_pair(&B->dev, v, (double *const *)B->d_pair_base, 0, x_id, 0, VECTOR_TEMP, 1, 0, 1, 1, rhs_id, a, b, h2inv, c1[0], c2[0], c1[1], c2[1]));
-  HIP_OK(hpgmg_hip_smooth_cheby_pair(&B->dev, v, (double *const *)B->d_pair_base, 1, 1, 1, 0, 0, VECTOR_TEMP, 0, x_id, rhs_id, a, b, h2inv, c1[2], c2[2], c1[3], c2[3]));
+  const float *const *c32 = coef32_of(L);
+  HIP_OK(hpgmg_hip_smooth_cheby_pair(&B->dev, v, (double *const *)B->d_pair_base, c32, 0, x_id, 0, VECTOR_TEMP, 1, 0, 1, 1, rhs_id, a, b, h2inv, c1[0], c2[0], c1[1], c2[1]));
+  HIP_OK(hpgmg_hip_smooth_cheby_pair(&B->dev, v, (double *const *)B->d_pair_base, c32, 1, 1, 1, 0, 0, VECTOR_TEMP, 0, x_id, rhs_id, a, b, h2inv, c1[2], c2[2], c1[3], c2[3]));
   L->timers.smooth += now() - t0;
   return 1;
 }
@@ -729,6 +765,7 @@ static void initialize_problem_fv(level_type *L, double h, const hpgmg_config *c
 }
 
 void initialize_problem(level_type *L, double h, double a, double b) {
+  coef32_invalidate(L);
   hpgmg_config cfg;
   hpgmg_get_config(&cfg);
   if (cfg.op == HPGMG_OP_FV2 || cfg.op == HPGMG_OP_FV4) { initialize_problem_fv(L, h, &cfg); return; }
@@ -769,6 +806,7 @@ void initialize_problem(level_type *L, double h, double a, double b) {
 
 /* ---------------------------------------------------------------- operators.7pt.c:95-252 */
 void rebuild_operator(level_type *L, level_type *from, double a, double b) {
+  coef32_invalidate(L);
   hpgmg_config cfg;
   hpgmg_get_config(&cfg);
   if (cfg.op != HPGMG_OP_7PT) {                                 /* operators.27pt.c:96-121, .fv2.c:98-124, .fv4.c:145-172 */

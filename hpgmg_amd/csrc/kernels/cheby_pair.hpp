@@ -33,6 +33,8 @@ struct PairArgs {
   int rhs_id;
   double a, b, h2inv, c1a, c2a, c1b, c2b;           // Chebyshev coefficients of the two sweeps
   double *const *scr_base;                          // per box: base of 2 scratch vectors (same padded layout)
+  const float *const *c32_base;                     // mixed-precision mode: per box, fp32 copies of Dinv, alpha, beta_i, beta_j, beta_k
+                                                    // (5 x volume floats, same padded indexing); null in fp64 mode
   int nbi, nbj;                                     // boxes per dimension (lexicographic numbering)
   int Di, Dj, Dk;                                   // global cells
   int tiles_i, slabs_j, chunks_k, KC, per_xcd, total_blocks;
@@ -49,6 +51,25 @@ __device__ __forceinline__ void pst(double *p, p2 v) { *reinterpret_cast<p2 *>(p
 __device__ __forceinline__ p2 pneg(p2 v) { return p2{-v.x, -v.y}; }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// Coefficient streams.  fp64 mode reads the level's own vectors; the mixed-precision smoother (BASELINE config 5) reads
+// fp32 copies -- 4 instead of 8 bytes per value on 5 of the 8 input streams -- and widens them to double, so all
+// arithmetic and the iterate stay fp64 (the rounding of a coefficient perturbs the operator by <= 6e-8 relative, and
+// only inside the smoother: residual, restriction and interpolation keep the fp64 coefficients).
+enum { C32_DINV = 0, C32_ALPHA, C32_BETA_I, C32_BETA_J, C32_BETA_K, C32_COUNT };
+template <bool C32> struct CoefStream {
+  const double *p64; const float *p32;
+  __device__ __forceinline__ CoefStream(const hpgmg_hip_level &L, const PairArgs &A, int box, int vec_id, int slot) {
+    const size_t first = (size_t)L.ghosts * (size_t)(1 + L.jStride + L.kStride);
+    if (C32) { p32 = A.c32_base[box] + (size_t)slot * (size_t)L.volume + first; p64 = nullptr; }
+    else     { p64 = L.box_base[box] + (size_t)vec_id * (size_t)L.volume + first; p32 = nullptr; }
+  }
+  __device__ __forceinline__ p2 pair(int off) const {
+    if (C32) { const float2 f = *reinterpret_cast<const float2 *>(p32 + off); return p2{(double)f.x, (double)f.y}; }
+    return pld(p64 + off);
+  }
+  __device__ __forceinline__ double one(int off) const { return C32 ? (double)p32[off] : p64[off]; }
+};
+
 // coefficients of one plane for a lane's two cells
 template <int V> struct PlaneCoef { p2 rhs, dinv, al, bi, bjlo, bjhi, bk0, bk1; double bir; };
 
@@ -64,7 +85,7 @@ __device__ __forceinline__ p2 cheby_update(p2 c, double left, double right, p2 j
   return o;
 }
 
-template <int V, int NW>
+template <int V, int NW, bool C32>
 __global__ __launch_bounds__(64 * NW) void cheby_pair_kernel(const hpgmg_hip_level L, const PairArgs A) {
   constexpr bool kVC = (V != HPGMG_HIP_7PT_CC);
   constexpr bool kHelm = (V == HPGMG_HIP_7PT_VC_HELMHOLTZ);
@@ -121,7 +142,7 @@ __global__ __launch_bounds__(64 * NW) void cheby_pair_kernel(const hpgmg_hip_lev
   if (row_x1) {
     const int box = box_of(bi_, bj_, pstart), off = row_off + plane_off(pstart);
     x0c = pld(pair_vec(L, A, A.x0, box) + off);
-    if (kVC) bj_c = pld(vec_origin(L, box, VECTOR_BETA_J) + off);
+    if (kVC) bj_c = CoefStream<C32>(L, A, box, VECTOR_BETA_J, C32_BETA_J).pair(off);
     if (in_dom(pstart - 1)) { const int bm = box_of(bi_, bj_, pstart - 1); x0m = pld(pair_vec(L, A, A.x0, bm) + row_off + plane_off(pstart - 1)); }
     if (far_lo || far_hi) far_c = pld(pair_vec(L, A, A.x0, box_of(bi_, bjf, pstart)) + li + ljf * jS + plane_off(pstart));
     slabX0[pstart & 1][w][lane] = x0c;
@@ -139,24 +160,23 @@ __global__ __launch_bounds__(64 * NW) void cheby_pair_kernel(const hpgmg_hip_lev
         const int bn = box_of(bi_, bj_, p + 1), offn = row_off + plane_off(p + 1);
         x0p = pld(pair_vec(L, A, A.x0, bn) + offn);
         if (have_next) {
-          if (kVC) bj_n = pld(vec_origin(L, bn, VECTOR_BETA_J) + offn);
+          if (kVC) bj_n = CoefStream<C32>(L, A, bn, VECTOR_BETA_J, C32_BETA_J).pair(offn);
           if (far_lo || far_hi) far_n = pld(pair_vec(L, A, A.x0, box_of(bi_, bjf, p + 1)) + li + ljf * jS + plane_off(p + 1));
         }
       }
       qc.rhs = pld(vec_origin(L, box, A.rhs_id) + off);
-      qc.dinv = pld(vec_origin(L, box, VECTOR_DINV) + off);
-      if (kHelm) qc.al = pld(vec_origin(L, box, VECTOR_ALPHA) + off);
+      qc.dinv = CoefStream<C32>(L, A, box, VECTOR_DINV, C32_DINV).pair(off);
+      if (kHelm) qc.al = CoefStream<C32>(L, A, box, VECTOR_ALPHA, C32_ALPHA).pair(off);
       if (kVC) {
-        const double *bip = vec_origin(L, box, VECTOR_BETA_I) + off;
-        qc.bi = pld(bip);
+        const CoefStream<C32> bis(L, A, box, VECTOR_BETA_I, C32_BETA_I), bks(L, A, box, VECTOR_BETA_K, C32_BETA_K);
+        qc.bi = bis.pair(off);
         qc.bir = __shfl_down(qc.bi.x, 1, 64);
-        if (lane == 63) qc.bir = bip[2];
-        const double *bkp = vec_origin(L, box, VECTOR_BETA_K) + off;
+        if (lane == 63) qc.bir = bis.one(off + 2);
         // the lower face is the previous plane's upper face (same address) unless this is the first plane of a box / of the march
-        if (p == pstart || (p % bd) == 0) qc.bk0 = pld(bkp); else qc.bk0 = qp.bk1;
-        qc.bk1 = pld(bkp + kS);                                  // the box's own upper face (ghost plane at the box top)
+        if (p == pstart || (p % bd) == 0) qc.bk0 = bks.pair(off); else qc.bk0 = qp.bk1;
+        qc.bk1 = bks.pair(off + kS);                             // the box's own upper face (ghost plane at the box top)
         qc.bjlo = bj_c;
-        if (w == NRs + 1 || gj + 1 >= A.Dj || ((lj + 1) == bd)) qc.bjhi = pld(vec_origin(L, box, VECTOR_BETA_J) + off + jS);
+        if (w == NRs + 1 || gj + 1 >= A.Dj || ((lj + 1) == bd)) qc.bjhi = CoefStream<C32>(L, A, box, VECTOR_BETA_J, C32_BETA_J).pair(off + jS);
         else qc.bjhi = slabBJ[p & 1][w + 1][lane];
       }
       const p2 xm1 = pld(pair_vec(L, A, A.xm1, box) + off);
@@ -220,7 +240,7 @@ __global__ __launch_bounds__(64 * NW) void cheby_pair_kernel(const hpgmg_hip_lev
 
 // x1 on the cell columns next to interior 128-cell tile edges (gi = 128 t - 1 and 128 t), which the pair kernel
 // reads as i neighbours of the second sweep.  One lane per cell of those columns (0.8 % of the level), lanes along j.
-template <int V>
+template <int V, bool C32>
 __global__ __launch_bounds__(256) void cheby_pair_edge_kernel(const hpgmg_hip_level L, const PairArgs A) {
   constexpr bool kVC = (V != HPGMG_HIP_7PT_CC);
   constexpr bool kHelm = (V == HPGMG_HIP_7PT_VC_HELMHOLTZ);
@@ -242,14 +262,26 @@ __global__ __launch_bounds__(256) void cheby_pair_edge_kernel(const hpgmg_hip_le
   const double xc = pair_vec(L, A, A.x0, box)[idx];
   double bi0 = 0, bi1 = 0, bj0 = 0, bj1 = 0, bk0 = 0, bk1 = 0, al = 0;
   if (kVC) {
-    const double *bi = vec_origin(L, box, VECTOR_BETA_I), *bj = vec_origin(L, box, VECTOR_BETA_J), *bk = vec_origin(L, box, VECTOR_BETA_K);
-    bi0 = bi[idx]; bi1 = bi[idx + 1]; bj0 = bj[idx]; bj1 = bj[idx + jS]; bk0 = bk[idx]; bk1 = bk[idx + kS];
+    const CoefStream<C32> bi(L, A, box, VECTOR_BETA_I, C32_BETA_I), bj(L, A, box, VECTOR_BETA_J, C32_BETA_J), bk(L, A, box, VECTOR_BETA_K, C32_BETA_K);
+    bi0 = bi.one(idx); bi1 = bi.one(idx + 1); bj0 = bj.one(idx); bj1 = bj.one(idx + jS); bk0 = bk.one(idx); bk1 = bk.one(idx + kS);
   }
-  if (kHelm) al = vec_origin(L, box, VECTOR_ALPHA)[idx];
+  if (kHelm) al = CoefStream<C32>(L, A, box, VECTOR_ALPHA, C32_ALPHA).one(idx);
   const double Ax = apply_op_7pt<V>(xc, x0_at(gi - 1, gj, gk, xc), x0_at(gi + 1, gj, gk, xc), x0_at(gi, gj - 1, gk, xc), x0_at(gi, gj + 1, gk, xc),
                                     x0_at(gi, gj, gk - 1, xc), x0_at(gi, gj, gk + 1, xc), bi0, bi1, bj0, bj1, bk0, bk1, al, A.a, A.b, A.h2inv);
   const double xnm1 = pair_vec(L, A, A.xm1, box)[idx];
-  pair_vec(L, A, A.out1, box)[idx] = xc + A.c1a * (xc - xnm1) + A.c2a * vec_origin(L, box, VECTOR_DINV)[idx] * (vec_origin(L, box, A.rhs_id)[idx] - Ax);
+  pair_vec(L, A, A.out1, box)[idx] = xc + A.c1a * (xc - xnm1) + A.c2a * CoefStream<C32>(L, A, box, VECTOR_DINV, C32_DINV).one(idx) * (vec_origin(L, box, A.rhs_id)[idx] - Ax);
+}
+
+// fp32 copies of the five coefficient vectors (whole padded boxes: the kernels read ghost faces of the betas)
+__global__ __launch_bounds__(256) void coef32_convert_kernel(const hpgmg_hip_level L, float *const *c32_base, int num_vectors) {
+  const int box = blockIdx.y;
+  const int ids[C32_COUNT] = { VECTOR_DINV, VECTOR_ALPHA, VECTOR_BETA_I, VECTOR_BETA_J, VECTOR_BETA_K };
+  const long long n = (long long)C32_COUNT * L.volume;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
+    const int slot = (int)(t / L.volume), idx = (int)(t - (long long)slot * L.volume);
+    if (ids[slot] < num_vectors)      // Poisson / constant-coefficient builds carry no alpha (no beta) vectors
+      c32_base[box][(size_t)slot * (size_t)L.volume + idx] = (float)L.box_base[box][(size_t)ids[slot] * (size_t)L.volume + idx];
+  }
 }
 
 }  // namespace hpgmg

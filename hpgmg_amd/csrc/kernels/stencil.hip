@@ -731,17 +731,25 @@ int hpgmg_hip_smooth_cheby_pair_supported(const hpgmg_hip_level *L, int variant)
   if ((long long)(L->dim_i / L->dim) * (L->dim_j / L->dim) * (L->dim_k / L->dim) != L->num_boxes) return 0;
   return 1;
 }
-int hpgmg_hip_smooth_cheby_pair(const hpgmg_hip_level *L, int variant, double *const *scr_base,
+int hpgmg_hip_coef32_refresh(const hpgmg_hip_level *L, float *const *c32_base, int num_vectors) {
+  HPGMG_SKIP_IF_REPLAY();
+  if (L->num_boxes <= 0) return 0;
+  hipLaunchKernelGGL(coef32_convert_kernel, dim3(512, L->num_boxes), dim3(256), 0, g_stream, *L, c32_base, num_vectors);
+  HPGMG_LAUNCH_CHECK("coef32_convert_kernel");
+  return 0;
+}
+int hpgmg_hip_smooth_cheby_pair(const hpgmg_hip_level *L, int variant, double *const *scr_base, const float *const *c32_base,
                                 int x0_scr, int x0_id, int xm1_scr, int xm1_id, int out1_scr, int out1_id, int out2_scr, int out2_id,
                                 int rhs_id, double a, double b, double h2inv, double c1a, double c2a, double c1b, double c2b) {
   HPGMG_SKIP_IF_REPLAY();
   if (!hpgmg_hip_smooth_cheby_pair_supported(L, variant)) return record_error(hipErrorInvalidValue, "smooth_cheby_pair: level not supported");
-  static const int nw = env_int("HPGMG_TUNE_PAIR_NW", 16) == 8 ? 8 : 16, tune_kc = env_int("HPGMG_TUNE_PAIR_KC", 0);
+  static const int tune_kc = env_int("HPGMG_TUNE_PAIR_KC", 0);
+  constexpr int nw = 16;
   // k chunk: every workgroup costs KC+2 plane steps and (at 128 VGPRs, 16 waves) one workgroup occupies a CU, so the
   // launch takes ceil(workgroups / 256) rounds of KC+2 steps: pick the KC that minimises that product
   int kc = tune_kc;
   if (kc <= 0) {
-    const int per_plane = (L->dim_i / 128) * ((L->dim_j + (nw - 2) - 1) / (nw - 2)), slots = 256 * (nw == 16 ? 1 : 2);
+    const int per_plane = (L->dim_i / 128) * ((L->dim_j + (nw - 2) - 1) / (nw - 2)), slots = 256;
     long long best = -1;
     for (int c = 8; c <= 64 && c <= L->dim_k; c++) {
       const long long wgs = (long long)per_plane * ((L->dim_k + c - 1) / c), cost = ((wgs + slots - 1) / slots) * (c + 2);
@@ -751,7 +759,7 @@ int hpgmg_hip_smooth_cheby_pair(const hpgmg_hip_level *L, int variant, double *c
   PairArgs A = {};
   A.x0 = VecRef{x0_scr, x0_id}; A.xm1 = VecRef{xm1_scr, xm1_id}; A.out1 = VecRef{out1_scr, out1_id}; A.out2 = VecRef{out2_scr, out2_id};
   A.rhs_id = rhs_id; A.a = a; A.b = b; A.h2inv = h2inv; A.c1a = c1a; A.c2a = c2a; A.c1b = c1b; A.c2b = c2b;
-  A.scr_base = scr_base;
+  A.scr_base = scr_base; A.c32_base = c32_base;
   A.nbi = L->dim_i / L->dim; A.nbj = L->dim_j / L->dim;
   A.Di = L->dim_i; A.Dj = L->dim_j; A.Dk = L->dim_k;
   A.tiles_i = A.Di / 128; A.slabs_j = (A.Dj + (nw - 2) - 1) / (nw - 2); A.KC = kc; A.chunks_k = (A.Dk + kc - 1) / kc;
@@ -760,12 +768,11 @@ int hpgmg_hip_smooth_cheby_pair(const hpgmg_hip_level *L, int variant, double *c
   const long long cells = (long long)A.Di * A.Dj * A.Dk;
   const size_t lds = (size_t)nw * 6 * 64 * sizeof(p2);
   const int prof = profile_begin(cells);
-#define PAIR_CASE(VAR) case VAR: { \
-      if (A.tiles_i > 1) hipLaunchKernelGGL((cheby_pair_edge_kernel<VAR>), dim3((A.Dj + 63) / 64, A.Dk, 2 * (A.tiles_i - 1)), dim3(64), 0, g_stream, *L, A); \
-      if (nw == 16) { static bool once16 = false; if (!once16) { HPGMG_CHECK(hipFuncSetAttribute((const void *)cheby_pair_kernel<VAR, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once16 = true; } \
-                      hipLaunchKernelGGL((cheby_pair_kernel<VAR, 16>), dim3(grid), dim3(64, 16), lds, g_stream, *L, A); } \
-      else          { hipLaunchKernelGGL((cheby_pair_kernel<VAR, 8>), dim3(grid), dim3(64, 8), lds, g_stream, *L, A); } \
-    } break;
+#define PAIR_LAUNCH(VAR, C32) { \
+      if (A.tiles_i > 1) hipLaunchKernelGGL((cheby_pair_edge_kernel<VAR, C32>), dim3((A.Dj + 63) / 64, A.Dk, 2 * (A.tiles_i - 1)), dim3(64), 0, g_stream, *L, A); \
+      static bool once = false; if (!once) { HPGMG_CHECK(hipFuncSetAttribute((const void *)cheby_pair_kernel<VAR, nw, C32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once = true; } \
+      hipLaunchKernelGGL((cheby_pair_kernel<VAR, nw, C32>), dim3(grid), dim3(64, nw), lds, g_stream, *L, A); }
+#define PAIR_CASE(VAR) case VAR: if (c32_base) PAIR_LAUNCH(VAR, true) else PAIR_LAUNCH(VAR, false) break;
   switch (variant) {
     PAIR_CASE(HPGMG_HIP_7PT_VC_HELMHOLTZ)
     PAIR_CASE(HPGMG_HIP_7PT_VC_POISSON)
@@ -773,6 +780,7 @@ int hpgmg_hip_smooth_cheby_pair(const hpgmg_hip_level *L, int variant, double *c
     default: return record_error(hipErrorInvalidValue, "smooth_cheby_pair: variant");
   }
 #undef PAIR_CASE
+#undef PAIR_LAUNCH
   profile_end(prof, 2 * cells);                      // one launch = two sweeps over every cell
   HPGMG_LAUNCH_CHECK("cheby_pair_kernel");
   return 0;

@@ -94,9 +94,14 @@ int hpgmg_hip_smooth_cheby(const hpgmg_hip_level *L, int variant, int xn_id, int
  * (same padded layout as the level's vectors).  out1/out2 must differ from x0/xm1.  Needs every face neighbour
  * local, Dirichlet, box side a multiple of 128, boxes numbered lexicographically (_supported() checks the rest). */
 int hpgmg_hip_smooth_cheby_pair_supported(const hpgmg_hip_level *L, int variant);
-int hpgmg_hip_smooth_cheby_pair(const hpgmg_hip_level *L, int variant, double *const *scr_base,
+int hpgmg_hip_smooth_cheby_pair(const hpgmg_hip_level *L, int variant, double *const *scr_base, const float *const *c32_base,
                                 int x0_scr, int x0_id, int xm1_scr, int xm1_id, int out1_scr, int out1_id, int out2_scr, int out2_id,
                                 int rhs_id, double a, double b, double h2inv, double c1a, double c2a, double c1b, double c2b);
+/* Mixed-precision smoother (BASELINE config 5): c32_base[box] = 5 x volume floats holding fp32 copies of Dinv, alpha,
+ * beta_i, beta_j, beta_k (whole padded vectors, same indexing).  hpgmg_hip_coef32_refresh fills them from the level's
+ * vectors; passing them to hpgmg_hip_smooth_cheby_pair makes the sweep pair read 4-byte coefficients (iterate, right-hand
+ * side and all arithmetic stay fp64).  c32_base == NULL is the bit-exact fp64 smoother. */
+int hpgmg_hip_coef32_refresh(const hpgmg_hip_level *L, float *const *c32_base, int num_vectors /* of the level: absent coefficient vectors are skipped */);
 int hpgmg_hip_smooth_gsrb(const hpgmg_hip_level *L, int variant, int xn_id, int xnp1_id, int rhs_id,
                           double a, double b, double h2inv, int sweep);
 int hpgmg_hip_smooth_jacobi(const hpgmg_hip_level *L, int variant, int xn_id, int xnp1_id, int rhs_id,
