@@ -11,6 +11,17 @@
 #include <string.h>
 #include <time.h>
 #include "hpgmg_fv.h"
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+/* OpenMP threads of the host build (hpgmg-fv.c:137-147 prints omp_get_max_threads()); the HIP build has one host thread */
+static int host_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
 
 extern int hpgmg_box_align_jstride, hpgmg_box_align_kstride, hpgmg_box_align_volume, hpgmg_box_align_base_bytes;
 
@@ -147,7 +158,7 @@ int hpgmg_fv_main(int argc, char **argv) {
   SAY(my_rank, "\n\n********************************************************************************\n"
                "***                            HPGMG-FV Benchmark                            ***\n"
                "********************************************************************************\n");
-  SAY(my_rank, "%d MPI Tasks of %d threads   [backend: %s]\n", num_ranks, 1, hpgmg_backend_name());
+  SAY(my_rank, "%d MPI Tasks of %d threads   [backend: %s]\n", num_ranks, host_threads(), hpgmg_backend_name());
   SAY(my_rank, "\n\n===== Benchmark setup ==========================================================\n");
 
   hpgmg_solver *s = hpgmg_solver_create(pos[0], pos[1], BC_DIRICHLET, my_rank, num_ranks);
@@ -173,7 +184,7 @@ int hpgmg_fv_main(int argc, char **argv) {
     for (l = 0; l < DYNAMIC_RANGE; l++) {
       level_type *L = s->mg.levels[l];
       double dof = (double)L->dim.i * (double)L->dim.j * (double)L->dim.k;
-      SAY(my_rank, "  h=%0.15e  DOF=%0.15e  time=%0.6f  DOF/s=%0.3e  MPI=%d  OMP=%d\n", L->h, dof, avg[l], dof / avg[l], num_ranks, 1);
+      SAY(my_rank, "  h=%0.15e  DOF=%0.15e  time=%0.6f  DOF/s=%0.3e  MPI=%d  OMP=%d\n", L->h, dof, avg[l], dof / avg[l], num_ranks, host_threads());
     }
   }
   SAY(my_rank, "\n\n===== Richardson error analysis ================================================\n");

@@ -47,3 +47,36 @@ def test_reference_driver_with_our_operators_prints_reference_numbers(ref_build,
     hyb = pinned_lines(os.path.join(ref_build, "hybrid-" + variant), args)
     assert len(ref) > 60
     assert ref == hyb
+
+
+def _masked(text):
+    """stdout with every timing figure (and the one line naming threads / backend) replaced: what a log parser keys on stays"""
+    import re
+    out = []
+    for line in text.splitlines():
+        if "MPI Tasks of" in line:
+            line = "N MPI Tasks of M threads"
+        line = re.sub(r"done \([0-9.]+ seconds\)", "done (T seconds)", line)
+        line = re.sub(r"\(([0-9.]+) seconds\)", "(T seconds)", line)
+        line = re.sub(r"time=\s*[0-9.]+\s+DOF/s=\s*[0-9.e+]+", "time=T DOF/s=R", line)
+        if re.match(r"^(smooth|  max|  min|residual|applyOp|BLAS1|Boundary Conditions|Restriction|  local restriction|  pack MPI buffers|  unpack MPI buffers|"
+                    r"  MPI_Isend|  MPI_Irecv|  MPI_Waitall|Interpolation|  local interpolation|Ghost Zone Exchange|  local exchange|MPI_collectives|"
+                    r"Total by level|   Total time in MGBuild|   Total time in MGSolve|      number of v-cycles|Bottom solver iterations|"
+                    r"            Performance|calculating D\^\{-1\}|\s+rebuilding operator)", line):
+            line = re.sub(r"[0-9]+\.[0-9]+(e[+-][0-9]+)?", "T", line)
+        out.append(line.rstrip())
+    return out
+
+
+@pytest.mark.parametrize("variant,flags,args", [("7pt-cheby", [], "4 8"), ("7pt-cheby-helm", ["--helmholtz"], "4 8"), ("7pt-gsrb", ["--smoother", "gsrb"], "5 8")])
+def test_cli_stdout_has_the_reference_layout(ref_build, variant, flags, args):
+    """our driver prints the reference's report line for line -- level creation, operator rebuild,
+    the 10+10 f-cycle lines per size, the timing table, DOF/s, Richardson error -- so HPGMG log parsers work unchanged.
+    Only timing figures (masked here) and the thread/backend banner differ; every pinned number is identical."""
+    env = dict(os.environ, OMP_NUM_THREADS="4")
+    ref = subprocess.run([os.path.join(ref_build, "hpgmg-" + variant)] + args.split(), capture_output=True, text=True, env=env, check=True).stdout
+    ours = subprocess.run([os.path.join(ROOT, "oracle", "hpgmg-fv-oracle")] + flags + args.split(), capture_output=True, text=True, env=env, check=True).stdout
+    a, b = _masked(ref), _masked(ours)
+    assert len(a) == len(b), (len(a), len(b))
+    diff = [(i, x, y) for i, (x, y) in enumerate(zip(a, b)) if x != y]
+    assert not diff, diff[:5]

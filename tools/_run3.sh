@@ -1,8 +1,8 @@
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
-mkdir -p gpurun_out/sweep
-for cfg in "16 0" "16 13" "16 43" "8 0"; do
-  set -- $cfg; export HPGMG_TUNE_PAIR_NW=$1 HPGMG_TUNE_PAIR_KC=$2; tag=p$1k$2
-  rm -rf gpurun_out/sweep/kt$tag gpurun_out/sweep/pmc$tag
-  echo "[$tag]"; timeout 120 hpgmg_amd/bin/hpgmg-fv --helmholtz 7 8 --warmup 3 --solves 20 2>&1 | grep -E "DOF/s|f-cycle" | sort | uniq | head -3
-  timeout 200 rocprofv3 --kernel-trace -d gpurun_out/sweep/kt$tag -o r -- hpgmg_amd/bin/hpgmg-fv --helmholtz 7 8 --warmup 1 --solves 3 > /dev/null 2>&1 </dev/null
+for cfg in "fv4:--op fv4 --smoother gsrb" "27pt:--op 27pt"; do
+  tag=${cfg%%:*}; args=${cfg#*:}
+  rm -rf gpurun_out/prof_$tag
+  timeout 300 rocprofv3 --kernel-trace -d gpurun_out/prof_$tag -o kt -- hpgmg_amd/bin/hpgmg-fv $args 7 8 --warmup 1 --solves 3 > /dev/null 2>&1 </dev/null
+  db=$(find gpurun_out/prof_$tag -name '*.db' | head -1)
+  echo "== $tag"; python3 tools/rocprof_summary.py "$db" </dev/null | head -16
 done
