@@ -123,13 +123,14 @@ void hpgmg_solver_richardson(hpgmg_solver *s, double out[2]) {
 /* ------------------------------------------------------------------ CLI */
 static int usage(int rank) {
   if (rank == 0) fprintf(stderr,
-    "usage: hpgmg-fv [--op 7pt|27pt|fv4|fv2] [--smoother cheby|gsrb|jacobi] [--helmholtz] [--const-coeff] [--fp32-smoother]\n"
+    "usage: hpgmg-fv [--op 7pt|27pt|fv4|fv2] [--smoother cheby|gsrb|jacobi] [--helmholtz] [--const-coeff] [--fp32-smoother] [--periodic]\n"
     "                [--warmup N] [--solves N] [--rank R --ranks N]  log2_box_dim  target_boxes_per_rank\n");
   return 0;
 }
 
 int hpgmg_fv_main(int argc, char **argv) {
   hpgmg_config cfg = { HPGMG_OP_7PT, HPGMG_SMOOTH_CHEBY, 0, 1 };
+  int bc = BC_DIRICHLET;
   int pos[2], npos = 0, a, my_rank = 0, num_ranks = 1, warmup = 10, solves = 10, test_error_only = 0;
   const hpgmg_transport *T = hpgmg_get_transport();
   if (T) { my_rank = T->rank; num_ranks = T->size; }
@@ -143,6 +144,7 @@ int hpgmg_fv_main(int argc, char **argv) {
     } else if (!strcmp(argv[a], "--helmholtz")) cfg.helmholtz = 1;
     else if (!strcmp(argv[a], "--const-coeff")) cfg.variable_coeff = 0;
     else if (!strcmp(argv[a], "--fp32-smoother")) hpgmg_set_smoother_precision(32);
+    else if (!strcmp(argv[a], "--periodic")) bc = BC_PERIODIC;                       /* the reference's -DUSE_PERIODIC_BC */
     else if (!strcmp(argv[a], "--test-error")) test_error_only = 1;
     else if (!strcmp(argv[a], "--warmup") && a + 1 < argc) warmup = atoi(argv[++a]);
     else if (!strcmp(argv[a], "--solves") && a + 1 < argc) solves = atoi(argv[++a]);
@@ -161,7 +163,7 @@ int hpgmg_fv_main(int argc, char **argv) {
   SAY(my_rank, "%d MPI Tasks of %d threads   [backend: %s]\n", num_ranks, host_threads(), hpgmg_backend_name());
   SAY(my_rank, "\n\n===== Benchmark setup ==========================================================\n");
 
-  hpgmg_solver *s = hpgmg_solver_create(pos[0], pos[1], BC_DIRICHLET, my_rank, num_ranks);
+  hpgmg_solver *s = hpgmg_solver_create(pos[0], pos[1], bc, my_rank, num_ranks);
   if (!s) return 0;
 
   enum { DYNAMIC_RANGE = 3 };

@@ -137,8 +137,8 @@ class Backend:
     def solver(self, boxes_in_i, box_dim, bc=H.BC_DIRICHLET, rank=0, ranks=1):
         return Solver(self, self.lib.hpgmg_solver_create_explicit(boxes_in_i, box_dim, bc, rank, ranks))
 
-    def solver_cli(self, log2_box_dim, boxes_per_rank, rank=0, ranks=1):
-        ptr = self.lib.hpgmg_solver_create(log2_box_dim, boxes_per_rank, H.BC_DIRICHLET, rank, ranks)
+    def solver_cli(self, log2_box_dim, boxes_per_rank, rank=0, ranks=1, bc=H.BC_DIRICHLET):
+        ptr = self.lib.hpgmg_solver_create(log2_box_dim, boxes_per_rank, bc, rank, ranks)
         assert ptr, "no acceptable problem size"
         return Solver(self, ptr)
 
@@ -185,6 +185,13 @@ def seeded_field(level, seed, scale=1.0):
     """Deterministic pseudo-random padded boxes (ghosts included), one array per box."""
     rng = np.random.default_rng(seed)
     return scale * (rng.random((level.num_boxes, level.volume)) * 2.0 - 1.0)
+
+
+def split_variant(name):
+    """'7pt-cheby-periodic' -> (VARIANTS key, boundary condition)"""
+    if name.endswith("-periodic"):
+        return name[:-len("-periodic")], H.BC_PERIODIC
+    return name, H.BC_DIRICHLET
 
 
 VARIANTS = {

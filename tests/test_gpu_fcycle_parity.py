@@ -6,7 +6,7 @@ north_star allows 1e-12 relative, which the last test also asserts explicitly).
 """
 import pytest
 
-from hpgmg_testlib import VARIANTS, load_golden
+from hpgmg_testlib import VARIANTS, load_golden, split_variant
 
 pytestmark = pytest.mark.gpu
 GOLD = load_golden("fcycle_norms.json")
@@ -17,15 +17,17 @@ def fmt(x):
 
 
 SMALL = [("7pt-cheby", "4 8"), ("7pt-cheby", "5 8"), ("7pt-gsrb", "5 8"), ("7pt-cheby-helm", "5 8"), ("7ptcc-cheby", "5 8"),
-         ("7pt-jacobi", "4 8"), ("27pt-cheby", "4 8"), ("27pt-cheby", "5 8"), ("27pt-gsrb", "4 8"), ("fv4-gsrb", "4 8"), ("fv4-gsrb", "5 8"), ("fv4-cheby", "4 8"), ("fv2-cheby", "4 8"), ("fv2-cheby", "5 8"), ("7pt-cheby", "4 1"), ("7pt-cheby", "4 27"), ("7pt-cheby-helm", "6 8")]
+         ("7pt-jacobi", "4 8"), ("27pt-cheby", "4 8"), ("27pt-cheby", "5 8"), ("27pt-gsrb", "4 8"), ("fv4-gsrb", "4 8"), ("fv4-gsrb", "5 8"), ("fv4-cheby", "4 8"), ("fv2-cheby", "4 8"), ("fv2-cheby", "5 8"), ("7pt-cheby", "4 1"), ("7pt-cheby", "4 27"), ("7pt-cheby-helm", "6 8"),
+         ("7pt-cheby-periodic", "4 8"), ("7pt-cheby-periodic", "5 8"), ("7pt-cheby-helm-periodic", "4 8"), ("7pt-gsrb-periodic", "4 8")]
 
 
 @pytest.mark.parametrize("variant,args", SMALL)
 def test_hip_fcycle_matches_reference_golden(hip, variant, args):
     gold = GOLD[f"{variant} {args}"]
-    hip.configure(**VARIANTS[variant])
+    base, bc = split_variant(variant)
+    hip.configure(**VARIANTS[base])
     log2, per_rank = map(int, args.split())
-    s = hip.solver_cli(log2, per_rank)
+    s = hip.solver_cli(log2, per_rank, bc=bc)
     try:
         assert [fmt(v) for v in s.three_sizes()] == gold["norms"]
         if gold["eigenvalue_max"]:
