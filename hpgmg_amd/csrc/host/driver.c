@@ -17,10 +17,9 @@
 /* OpenMP threads of the host build (hpgmg-fv.c:137-147 prints omp_get_max_threads()); the HIP build has one host thread */
 static int host_threads(void) {
 #ifdef _OPENMP
-  return omp_get_max_threads();
-#else
-  return 1;
+  if (strcmp(hpgmg_backend_name(), "hip") != 0) return omp_get_max_threads();
 #endif
+  return 1;
 }
 
 extern int hpgmg_box_align_jstride, hpgmg_box_align_kstride, hpgmg_box_align_volume, hpgmg_box_align_base_bytes;

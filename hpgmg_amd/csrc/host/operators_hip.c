@@ -533,13 +533,13 @@ static void coef32_invalidate(level_type *L) { backend_t *B = backend_of(L); B->
 
 static int fused_sweeps = -1;
 void hpgmg_set_fused_sweeps(int on) { fused_sweeps = on ? 1 : 0; }
-static int smooth_cheby_pairs(level_type *L, int x_id, int rhs_id, double a, double b, const double *c1, const double *c2, int sweeps) {
+/* common part: does the level qualify for the sweep-pair kernel, and are its two private vectors there? */
+static int pair_kernel_ready(level_type *L, int x_id, int rhs_id, int sweeps) {
   if (fused_sweeps < 0) { const char *e = getenv("HPGMG_FUSED_SWEEPS"); fused_sweeps = !(e && e[0] == '0'); }
-  const int enabled = fused_sweeps;
   hpgmg_config cfg;
   hpgmg_get_config(&cfg);
   backend_t *B = backend_of(L);
-  if (!enabled || sweeps != 4 || cfg.op != HPGMG_OP_7PT || !ghost_free_mode() || stencil_get_shape() != STENCIL_SHAPE_STAR) return 0;
+  if (!fused_sweeps || sweeps != 4 || cfg.op != HPGMG_OP_7PT || !ghost_free_mode() || stencil_get_shape() != STENCIL_SHAPE_STAR) return 0;
   if (L->boundary_condition.type != BC_DIRICHLET || !B->all_faces_local || x_id == VECTOR_TEMP || rhs_id == VECTOR_TEMP) return 0;
   if (!hpgmg_hip_smooth_cheby_pair_supported(&B->dev, variant()) || !boxes_lexicographic(L)) return 0;
   if (!B->pair_scratch) {
@@ -554,13 +554,35 @@ static int smooth_cheby_pairs(level_type *L, int x_id, int rhs_id, double a, dou
     HIP_OK(hpgmg_hip_memcpy_h2d(B->d_pair_base, base, (size_t)L->num_my_boxes * sizeof(double *)));
     free(base);
   }
+  hpgmg_hip_set_ghost_free(1);
+  return 1;
+}
+
+/* Chebyshev smooth() as fused sweep pairs (kernels/cheby_pair.hpp): 4 sweeps = 2 passes of 10 streams instead of
+ * 4 x 9.  x1,x2 of the first pair go to two plugin-private vectors, the second pair brings x3 -> VECTOR_TEMP and
+ * x4 -> x_id, i.e. exactly the state chebyshev.c:43-99 leaves.  Returns 0 when the level does not qualify. */
+static int smooth_cheby_pairs(level_type *L, int x_id, int rhs_id, double a, double b, const double *c1, const double *c2, int sweeps) {
+  if (!pair_kernel_ready(L, x_id, rhs_id, sweeps)) return 0;
+  backend_t *B = backend_of(L);
   const double h2inv = 1.0 / (L->h * L->h);
   const int v = variant();
   const double t0 = now();
-  hpgmg_hip_set_ghost_free(1);
   const float *const *c32 = coef32_of(L);
   HIP_OK(hpgmg_hip_smooth_cheby_pair(&B->dev, v, (double *const *)B->d_pair_base, c32, 0, x_id, 0, VECTOR_TEMP, 1, 0, 1, 1, rhs_id, a, b, h2inv, c1[0], c2[0], c1[1], c2[1]));
   HIP_OK(hpgmg_hip_smooth_cheby_pair(&B->dev, v, (double *const *)B->d_pair_base, c32, 1, 1, 1, 0, 0, VECTOR_TEMP, 0, x_id, rhs_id, a, b, h2inv, c1[2], c2[2], c1[3], c2[3]));
+  L->timers.smooth += now() - t0;
+  return 1;
+}
+/* in-place GSRB smooth() (gsrb.c:24-132, 4 coloured half sweeps) as two passes of two half sweeps each:
+ * x_id -> private vector -> x_id; VECTOR_TEMP is not touched, as in the reference's in-place form */
+static int smooth_gsrb_pairs(level_type *L, int x_id, int rhs_id, double a, double b, int sweeps) {
+  if (hpgmg_gsrb_out_of_place() || !pair_kernel_ready(L, x_id, rhs_id, sweeps)) return 0;
+  backend_t *B = backend_of(L);
+  const double h2inv = 1.0 / (L->h * L->h);
+  const int v = variant();
+  const double t0 = now();
+  HIP_OK(hpgmg_hip_smooth_gsrb_pair(&B->dev, v, (double *const *)B->d_pair_base, NULL, 0, x_id, 0, 1, 1, rhs_id, a, b, h2inv, 0));
+  HIP_OK(hpgmg_hip_smooth_gsrb_pair(&B->dev, v, (double *const *)B->d_pair_base, NULL, 1, 1, 0, 0, x_id, rhs_id, a, b, h2inv, 2));
   L->timers.smooth += now() - t0;
   return 1;
 }
@@ -583,6 +605,7 @@ void smooth(level_type *L, int x_id, int rhs_id, double a, double b) {
     }
   } else if (cfg.smoother == HPGMG_SMOOTH_GSRB) {    /* gsrb.c:24-132 */
     const int oop = hpgmg_gsrb_out_of_place();
+    if (smooth_gsrb_pairs(L, x_id, rhs_id, a, b, sweeps)) return;
     for (s = 0; s < sweeps; s++) {
       const int src = (oop && (s & 1)) ? VECTOR_TEMP : x_id, dst = oop ? ((s & 1) ? x_id : VECTOR_TEMP) : x_id;
       STENCIL_WITH_GHOSTS(L, src, smooth, hpgmg_hip_smooth_gsrb(&B->dev, v, src, dst, rhs_id, a, b, h2inv, s));

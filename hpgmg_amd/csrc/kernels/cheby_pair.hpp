@@ -32,6 +32,7 @@ struct PairArgs {
   VecRef x0, xm1, out1, out2;
   int rhs_id;
   double a, b, h2inv, c1a, c2a, c1b, c2b;           // Chebyshev coefficients of the two sweeps
+  int sweep_a;                                      // GSRB: number of the first half sweep (its colour; the second is sweep_a + 1)
   double *const *scr_base;                          // per box: base of 2 scratch vectors (same padded layout)
   const float *const *c32_base;                     // mixed-precision mode: per box, fp32 copies of Dinv, alpha, beta_i, beta_j, beta_k
                                                     // (5 x volume floats, same padded indexing); null in fp64 mode
@@ -73,19 +74,28 @@ template <bool C32> struct CoefStream {
 // coefficients of one plane for a lane's two cells
 template <int V> struct PlaneCoef { p2 rhs, dinv, al, bi, bjlo, bjhi, bk0, bk1; double bir; };
 
-// one Chebyshev update of the pair (c.x, c.y)
-template <int V>
-__device__ __forceinline__ p2 cheby_update(p2 c, double left, double right, p2 jm, p2 jp, p2 km, p2 kp, p2 old,
-                                           const PlaneCoef<V> &q, double a, double b, double h2inv, double c1, double c2) {
+enum { PAIR_CHEBY = 0, PAIR_GSRB = 1 };
+// one smoother update of the pair (c.x, c.y).  PAIR_CHEBY: chebyshev.c:86-95 with `old` = x_{n-1}.  PAIR_GSRB: one
+// coloured half sweep of gsrb.c:90-105 -- the cell of the pair whose colour is swept (`first_is_swept` says whether
+// that is c.x) becomes c + Dinv (rhs - A c), the other one keeps its value.
+template <int V, int SM>
+__device__ __forceinline__ p2 pair_update(p2 c, double left, double right, p2 jm, p2 jp, p2 km, p2 kp, p2 old,
+                                          const PlaneCoef<V> &q, double a, double b, double h2inv, double c1, double c2, bool first_is_swept) {
   const double Ax0 = apply_op_7pt<V>(c.x, left, c.y, jm.x, jp.x, km.x, kp.x, q.bi.x, q.bi.y, q.bjlo.x, q.bjhi.x, q.bk0.x, q.bk1.x, q.al.x, a, b, h2inv);
   const double Ax1 = apply_op_7pt<V>(c.y, c.x, right, jm.y, jp.y, km.y, kp.y, q.bi.y, q.bir, q.bjlo.y, q.bjhi.y, q.bk0.y, q.bk1.y, q.al.y, a, b, h2inv);
   p2 o;
-  o.x = c.x + c1 * (c.x - old.x) + c2 * q.dinv.x * (q.rhs.x - Ax0);
-  o.y = c.y + c1 * (c.y - old.y) + c2 * q.dinv.y * (q.rhs.y - Ax1);
+  if (SM == PAIR_CHEBY) {
+    o.x = c.x + c1 * (c.x - old.x) + c2 * q.dinv.x * (q.rhs.x - Ax0);
+    o.y = c.y + c1 * (c.y - old.y) + c2 * q.dinv.y * (q.rhs.y - Ax1);
+  } else {
+    const double nx = c.x + q.dinv.x * (q.rhs.x - Ax0), ny = c.y + q.dinv.y * (q.rhs.y - Ax1);
+    o.x = first_is_swept ? nx : c.x;
+    o.y = first_is_swept ? c.y : ny;
+  }
   return o;
 }
 
-template <int V, int NW, bool C32>
+template <int V, int NW, bool C32, int SM>
 __global__ __launch_bounds__(64 * NW) void cheby_pair_kernel(const hpgmg_hip_level L, const PairArgs A) {
   constexpr bool kVC = (V != HPGMG_HIP_7PT_CC);
   constexpr bool kHelm = (V == HPGMG_HIP_7PT_VC_HELMHOLTZ);
@@ -179,7 +189,8 @@ __global__ __launch_bounds__(64 * NW) void cheby_pair_kernel(const hpgmg_hip_lev
         if (w == NRs + 1 || gj + 1 >= A.Dj || ((lj + 1) == bd)) qc.bjhi = CoefStream<C32>(L, A, box, VECTOR_BETA_J, C32_BETA_J).pair(off + jS);
         else qc.bjhi = slabBJ[p & 1][w + 1][lane];
       }
-      const p2 xm1 = pld(pair_vec(L, A, A.xm1, box) + off);
+      p2 xm1 = {0, 0};
+      if (SM == PAIR_CHEBY) xm1 = pld(pair_vec(L, A, A.xm1, box) + off);
 
       // ---- x1 on plane p (first sweep): neighbours of x0
       p2 jm, jp;
@@ -190,7 +201,8 @@ __global__ __launch_bounds__(64 * NW) void cheby_pair_kernel(const hpgmg_hip_lev
       double left = __shfl_up(x0c.y, 1, 64), right = __shfl_down(x0c.x, 1, 64);
       if (lane == 0)  left  = left_dom  ? -x0c.x : pair_vec(L, A, A.x0, box_of(biL, bj_, p))[liL + lj * jS + plane_off(p)];
       if (lane == 63) right = right_dom ? -x0c.y : pair_vec(L, A, A.x0, box_of(biR, bj_, p))[liR + lj * jS + plane_off(p)];
-      x1c = cheby_update<V>(x0c, left, right, jm, jp, km, kp, xm1, qc, A.a, A.b, A.h2inv, A.c1a, A.c2a);
+      // GSRB: cell (gi, gj, gk) is swept in half sweep s when (gi ^ gj ^ gk ^ s) is even; a pair starts at an even gi
+      x1c = pair_update<V, SM>(x0c, left, right, jm, jp, km, kp, xm1, qc, A.a, A.b, A.h2inv, A.c1a, A.c2a, ((gj ^ p ^ A.sweep_a) & 1) == 0);
     }
 
     // ---- x2 on plane q = p-1 (second sweep): neighbours of x1; x0 is the older iterate
@@ -205,10 +217,10 @@ __global__ __launch_bounds__(64 * NW) void cheby_pair_kernel(const hpgmg_hip_lev
       double left = __shfl_up(x1m1.y, 1, 64), right = __shfl_down(x1m1.x, 1, 64);
       if (lane == 0)  left  = left_dom  ? -x1m1.x : pair_vec(L, A, A.out1, box_of(biL, bj_, q))[liL + lj * jS + plane_off(q)];
       if (lane == 63) right = right_dom ? -x1m1.y : pair_vec(L, A, A.out1, box_of(biR, bj_, q))[liR + lj * jS + plane_off(q)];
-      const p2 x2 = cheby_update<V>(x1m1, left, right, jm, jp, km, kp, x0m, qp, A.a, A.b, A.h2inv, A.c1b, A.c2b);
+      const p2 x2 = pair_update<V, SM>(x1m1, left, right, jm, jp, km, kp, x0m, qp, A.a, A.b, A.h2inv, A.c1b, A.c2b, ((gj ^ q ^ (A.sweep_a + 1)) & 1) == 0);
       pst(pair_vec(L, A, A.out2, boxq) + offq, x2);
     }
-    if (row_out && p >= K0 && p < K0 + KCs) pst(pair_vec(L, A, A.out1, box) + off, x1c);
+    if (SM == PAIR_CHEBY && row_out && p >= K0 && p < K0 + KCs) pst(pair_vec(L, A, A.out1, box) + off, x1c);   // GSRB keeps no x1
 
     // ---- hand this plane's x1 and the next plane's x0 / beta_j to the neighbouring waves
     if (row_x1) {
@@ -232,7 +244,7 @@ __global__ __launch_bounds__(64 * NW) void cheby_pair_kernel(const hpgmg_hip_lev
       double left = __shfl_up(x1m1.y, 1, 64), right = __shfl_down(x1m1.x, 1, 64);
       if (lane == 0)  left  = left_dom  ? -x1m1.x : pair_vec(L, A, A.out1, box_of(biL, bj_, q))[liL + lj * jS + plane_off(q)];
       if (lane == 63) right = right_dom ? -x1m1.y : pair_vec(L, A, A.out1, box_of(biR, bj_, q))[liR + lj * jS + plane_off(q)];
-      const p2 x2 = cheby_update<V>(x1m1, left, right, jm, jp, km, kp, x0m, qp, A.a, A.b, A.h2inv, A.c1b, A.c2b);
+      const p2 x2 = pair_update<V, SM>(x1m1, left, right, jm, jp, km, kp, x0m, qp, A.a, A.b, A.h2inv, A.c1b, A.c2b, ((gj ^ q ^ (A.sweep_a + 1)) & 1) == 0);
       pst(pair_vec(L, A, A.out2, boxq) + offq, x2);
     }
   }
@@ -240,7 +252,7 @@ __global__ __launch_bounds__(64 * NW) void cheby_pair_kernel(const hpgmg_hip_lev
 
 // x1 on the cell columns next to interior 128-cell tile edges (gi = 128 t - 1 and 128 t), which the pair kernel
 // reads as i neighbours of the second sweep.  One lane per cell of those columns (0.8 % of the level), lanes along j.
-template <int V, bool C32>
+template <int V, bool C32, int SM>
 __global__ __launch_bounds__(256) void cheby_pair_edge_kernel(const hpgmg_hip_level L, const PairArgs A) {
   constexpr bool kVC = (V != HPGMG_HIP_7PT_CC);
   constexpr bool kHelm = (V == HPGMG_HIP_7PT_VC_HELMHOLTZ);
@@ -268,8 +280,13 @@ __global__ __launch_bounds__(256) void cheby_pair_edge_kernel(const hpgmg_hip_le
   if (kHelm) al = CoefStream<C32>(L, A, box, VECTOR_ALPHA, C32_ALPHA).one(idx);
   const double Ax = apply_op_7pt<V>(xc, x0_at(gi - 1, gj, gk, xc), x0_at(gi + 1, gj, gk, xc), x0_at(gi, gj - 1, gk, xc), x0_at(gi, gj + 1, gk, xc),
                                     x0_at(gi, gj, gk - 1, xc), x0_at(gi, gj, gk + 1, xc), bi0, bi1, bj0, bj1, bk0, bk1, al, A.a, A.b, A.h2inv);
-  const double xnm1 = pair_vec(L, A, A.xm1, box)[idx];
-  pair_vec(L, A, A.out1, box)[idx] = xc + A.c1a * (xc - xnm1) + A.c2a * CoefStream<C32>(L, A, box, VECTOR_DINV, C32_DINV).one(idx) * (vec_origin(L, box, A.rhs_id)[idx] - Ax);
+  const double dinv = CoefStream<C32>(L, A, box, VECTOR_DINV, C32_DINV).one(idx), rhs = vec_origin(L, box, A.rhs_id)[idx];
+  if (SM == PAIR_CHEBY) {
+    const double xnm1 = pair_vec(L, A, A.xm1, box)[idx];
+    pair_vec(L, A, A.out1, box)[idx] = xc + A.c1a * (xc - xnm1) + A.c2a * dinv * (rhs - Ax);
+  } else {
+    pair_vec(L, A, A.out1, box)[idx] = (((gi ^ gj ^ gk ^ A.sweep_a) & 1) == 0) ? xc + dinv * (rhs - Ax) : xc;
+  }
 }
 
 // fp32 copies of the five coefficient vectors (whole padded boxes: the kernels read ghost faces of the betas)

@@ -738,9 +738,9 @@ int hpgmg_hip_coef32_refresh(const hpgmg_hip_level *L, float *const *c32_base, i
   HPGMG_LAUNCH_CHECK("coef32_convert_kernel");
   return 0;
 }
-int hpgmg_hip_smooth_cheby_pair(const hpgmg_hip_level *L, int variant, double *const *scr_base, const float *const *c32_base,
-                                int x0_scr, int x0_id, int xm1_scr, int xm1_id, int out1_scr, int out1_id, int out2_scr, int out2_id,
-                                int rhs_id, double a, double b, double h2inv, double c1a, double c2a, double c1b, double c2b) {
+static int smooth_pair(const hpgmg_hip_level *L, int variant, int gsrb, int sweep_a, double *const *scr_base, const float *const *c32_base,
+                       int x0_scr, int x0_id, int xm1_scr, int xm1_id, int out1_scr, int out1_id, int out2_scr, int out2_id,
+                       int rhs_id, double a, double b, double h2inv, double c1a, double c2a, double c1b, double c2b) {
   HPGMG_SKIP_IF_REPLAY();
   if (!hpgmg_hip_smooth_cheby_pair_supported(L, variant)) return record_error(hipErrorInvalidValue, "smooth_cheby_pair: level not supported");
   static const int tune_kc = env_int("HPGMG_TUNE_PAIR_KC", 0);
@@ -759,7 +759,7 @@ int hpgmg_hip_smooth_cheby_pair(const hpgmg_hip_level *L, int variant, double *c
   PairArgs A = {};
   A.x0 = VecRef{x0_scr, x0_id}; A.xm1 = VecRef{xm1_scr, xm1_id}; A.out1 = VecRef{out1_scr, out1_id}; A.out2 = VecRef{out2_scr, out2_id};
   A.rhs_id = rhs_id; A.a = a; A.b = b; A.h2inv = h2inv; A.c1a = c1a; A.c2a = c2a; A.c1b = c1b; A.c2b = c2b;
-  A.scr_base = scr_base; A.c32_base = c32_base;
+  A.scr_base = scr_base; A.c32_base = c32_base; A.sweep_a = sweep_a;
   A.nbi = L->dim_i / L->dim; A.nbj = L->dim_j / L->dim;
   A.Di = L->dim_i; A.Dj = L->dim_j; A.Dk = L->dim_k;
   A.tiles_i = A.Di / 128; A.slabs_j = (A.Dj + (nw - 2) - 1) / (nw - 2); A.KC = kc; A.chunks_k = (A.Dk + kc - 1) / kc;
@@ -768,11 +768,13 @@ int hpgmg_hip_smooth_cheby_pair(const hpgmg_hip_level *L, int variant, double *c
   const long long cells = (long long)A.Di * A.Dj * A.Dk;
   const size_t lds = (size_t)nw * 6 * 64 * sizeof(p2);
   const int prof = profile_begin(cells);
-#define PAIR_LAUNCH(VAR, C32) { \
-      if (A.tiles_i > 1) hipLaunchKernelGGL((cheby_pair_edge_kernel<VAR, C32>), dim3((A.Dj + 63) / 64, A.Dk, 2 * (A.tiles_i - 1)), dim3(64), 0, g_stream, *L, A); \
-      static bool once = false; if (!once) { HPGMG_CHECK(hipFuncSetAttribute((const void *)cheby_pair_kernel<VAR, nw, C32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once = true; } \
-      hipLaunchKernelGGL((cheby_pair_kernel<VAR, nw, C32>), dim3(grid), dim3(64, nw), lds, g_stream, *L, A); }
-#define PAIR_CASE(VAR) case VAR: if (c32_base) PAIR_LAUNCH(VAR, true) else PAIR_LAUNCH(VAR, false) break;
+#define PAIR_LAUNCH(VAR, C32, SM) { \
+      if (A.tiles_i > 1) hipLaunchKernelGGL((cheby_pair_edge_kernel<VAR, C32, SM>), dim3((A.Dj + 63) / 64, A.Dk, 2 * (A.tiles_i - 1)), dim3(64), 0, g_stream, *L, A); \
+      static bool once = false; if (!once) { HPGMG_CHECK(hipFuncSetAttribute((const void *)cheby_pair_kernel<VAR, nw, C32, SM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once = true; } \
+      hipLaunchKernelGGL((cheby_pair_kernel<VAR, nw, C32, SM>), dim3(grid), dim3(64, nw), lds, g_stream, *L, A); }
+#define PAIR_CASE(VAR) case VAR: \
+    if (gsrb) { if (c32_base) PAIR_LAUNCH(VAR, true, PAIR_GSRB) else PAIR_LAUNCH(VAR, false, PAIR_GSRB) } \
+    else      { if (c32_base) PAIR_LAUNCH(VAR, true, PAIR_CHEBY) else PAIR_LAUNCH(VAR, false, PAIR_CHEBY) } break;
   switch (variant) {
     PAIR_CASE(HPGMG_HIP_7PT_VC_HELMHOLTZ)
     PAIR_CASE(HPGMG_HIP_7PT_VC_POISSON)
@@ -784,6 +786,18 @@ int hpgmg_hip_smooth_cheby_pair(const hpgmg_hip_level *L, int variant, double *c
   profile_end(prof, 2 * cells);                      // one launch = two sweeps over every cell
   HPGMG_LAUNCH_CHECK("cheby_pair_kernel");
   return 0;
+}
+int hpgmg_hip_smooth_cheby_pair(const hpgmg_hip_level *L, int variant, double *const *scr_base, const float *const *c32_base,
+                                int x0_scr, int x0_id, int xm1_scr, int xm1_id, int out1_scr, int out1_id, int out2_scr, int out2_id,
+                                int rhs_id, double a, double b, double h2inv, double c1a, double c2a, double c1b, double c2b) {
+  return smooth_pair(L, variant, 0, 0, scr_base, c32_base, x0_scr, x0_id, xm1_scr, xm1_id, out1_scr, out1_id, out2_scr, out2_id, rhs_id, a, b, h2inv, c1a, c2a, c1b, c2b);
+}
+// two consecutive in-place GSRB half sweeps (sweep, sweep + 1): x2 -> out2; the scratch vector `edge_scr_id` receives the
+// few x1 values the kernel exchanges across 128-cell tile edges
+int hpgmg_hip_smooth_gsrb_pair(const hpgmg_hip_level *L, int variant, double *const *scr_base, const float *const *c32_base,
+                               int x0_scr, int x0_id, int edge_scr_id, int out2_scr, int out2_id, int rhs_id,
+                               double a, double b, double h2inv, int sweep) {
+  return smooth_pair(L, variant, 1, sweep, scr_base, c32_base, x0_scr, x0_id, x0_scr, x0_id, 1, edge_scr_id, out2_scr, out2_id, rhs_id, a, b, h2inv, 0.0, 0.0, 0.0, 0.0);
 }
 int hpgmg_hip_smooth_gsrb(const hpgmg_hip_level *L, int variant, int xn_id, int xnp1_id, int rhs_id,
                           double a, double b, double h2inv, int sweep) {

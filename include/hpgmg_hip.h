@@ -97,6 +97,11 @@ int hpgmg_hip_smooth_cheby_pair_supported(const hpgmg_hip_level *L, int variant)
 int hpgmg_hip_smooth_cheby_pair(const hpgmg_hip_level *L, int variant, double *const *scr_base, const float *const *c32_base,
                                 int x0_scr, int x0_id, int xm1_scr, int xm1_id, int out1_scr, int out1_id, int out2_scr, int out2_id,
                                 int rhs_id, double a, double b, double h2inv, double c1a, double c2a, double c1b, double c2b);
+/* Two consecutive in-place GSRB half sweeps (gsrb.c:24-132, colours `sweep` and `sweep + 1`) in one pass: reads x0, writes the
+ * result to out2 (which must differ from x0); scratch vector edge_scr_id (0/1 behind scr_base) is clobbered. */
+int hpgmg_hip_smooth_gsrb_pair(const hpgmg_hip_level *L, int variant, double *const *scr_base, const float *const *c32_base,
+                               int x0_scr, int x0_id, int edge_scr_id, int out2_scr, int out2_id, int rhs_id,
+                               double a, double b, double h2inv, int sweep);
 /* Mixed-precision smoother (BASELINE config 5): c32_base[box] = 5 x volume floats holding fp32 copies of Dinv, alpha,
  * beta_i, beta_j, beta_k (whole padded vectors, same indexing).  hpgmg_hip_coef32_refresh fills them from the level's
  * vectors; passing them to hpgmg_hip_smooth_cheby_pair makes the sweep pair read 4-byte coefficients (iterate, right-hand
