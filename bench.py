@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-transport", action="store_true", help="initialise torch.distributed + the RCCL transport even with one rank (smoke test of the N>1 bootstrap)")
     ap.add_argument("--precision", choices=["fp64", "fp32"], default="fp64",
                     help="fp32 = BASELINE.json config 5: mixed-precision Chebyshev smoother (fp32 coefficient streams), tolerance-gated; default fp64 = config 2, bit-exact")
     args = ap.parse_args()
@@ -115,7 +116,7 @@ def main():
     lib.hpgmg_set_verbose(0)
 
     dist = None
-    if world > 1:
+    if world > 1 or args.force_transport:
         import torch.distributed as dist
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         ident = torch.zeros(128, dtype=torch.uint8, device="cuda")
@@ -127,6 +128,7 @@ def main():
         lib.hpgmg_transport_init_rccl.restype = ctypes.c_int
         lib.hpgmg_transport_init_rccl.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int]
         assert lib.hpgmg_transport_init_rccl(bytes(ident.cpu().tolist()), rank, world) == 0
+        ctypes.CDLL(None).fflush(None)      # RCCL prints a version banner through C stdio: get it out now, not after the JSON line
 
     mixed = args.precision == "fp32"
     lib.hpgmg_set_smoother_precision.argtypes = [ctypes.c_int]
@@ -170,6 +172,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    ctypes.CDLL(None).fflush(None)
+    if dist is not None:
+        dist.barrier()                       # every rank has flushed its C-level output before rank 0 prints the result
     if rank == 0:
         sec_per_step = elapsed / args.steps
         roof = None
@@ -196,6 +201,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
+        ctypes.CDLL(None).fflush(None)      # anything C code buffered on stdout goes first: the JSON line is the last line
         print(json.dumps(line), flush=True)
 
     lib.hpgmg_solver_destroy(solver)
