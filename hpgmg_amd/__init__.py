@@ -42,7 +42,7 @@ class HipLevel(ctypes.Structure):
     _fields_ = [("box_base", ctypes.c_void_p), ("box_low", ctypes.c_void_p), ("num_boxes", ctypes.c_int),
                 ("dim", ctypes.c_int), ("ghosts", ctypes.c_int), ("jStride", ctypes.c_int), ("kStride", ctypes.c_int),
                 ("volume", ctypes.c_int), ("dim_i", ctypes.c_int), ("dim_j", ctypes.c_int), ("dim_k", ctypes.c_int),
-                ("periodic", ctypes.c_int), ("box_nbr", ctypes.c_void_p), ("flags", ctypes.c_int)]
+                ("periodic", ctypes.c_int), ("box_nbr", ctypes.c_void_p), ("flags", ctypes.c_int), ("box_stride", ctypes.c_longlong)]
 
 
 def _declare_driver_api(lib):

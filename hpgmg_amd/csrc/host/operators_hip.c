@@ -153,7 +153,13 @@ static backend_t *backend_of(level_type *L) {
     int b, ok = (L->box_jStride % 2 == 0) && (L->box_kStride % 2 == 0) && (L->box_volume % 2 == 0);
     const size_t first = (size_t)L->box_ghosts * (size_t)(1 + L->box_jStride + L->box_kStride);
     for (b = 0; ok && b < L->num_my_boxes; b++) if (((uintptr_t)(L->my_boxes[b].vectors[0] + first)) % 16) ok = 0;
-    B->dev.flags = ok ? 1 : 0; }
+    B->dev.flags = ok ? 1 : 0;
+    B->dev.box_stride = 0;
+    if (L->num_my_boxes > 1) {
+      const long long d = (long long)(L->my_boxes[1].vectors[0] - L->my_boxes[0].vectors[0]);
+      for (b = 1; b < L->num_my_boxes && (long long)(L->my_boxes[b].vectors[0] - L->my_boxes[b - 1].vectors[0]) == d; b++) ;
+      if (b == L->num_my_boxes && d > 0) B->dev.box_stride = d;
+    } }
   return B;
 }
 
@@ -542,6 +548,12 @@ static int pair_kernel_ready(level_type *L, int x_id, int rhs_id, int sweeps) {
   if (!fused_sweeps || sweeps != 4 || cfg.op != HPGMG_OP_7PT || !ghost_free_mode() || stencil_get_shape() != STENCIL_SHAPE_STAR) return 0;
   if (L->boundary_condition.type != BC_DIRICHLET || !B->all_faces_local || x_id == VECTOR_TEMP || rhs_id == VECTOR_TEMP) return 0;
   if (!hpgmg_hip_smooth_cheby_pair_supported(&B->dev, variant()) || !boxes_lexicographic(L)) return 0;
+  { /* the pass structure pays when the level is bandwidth bound; a cache-resident level (128^3 and smaller) is latency
+     * bound and faster with many small single-sweep workgroups (measured: 128^3 pair 80 us vs 2 x 27 us) */
+    static long long min_cells = -1;
+    if (min_cells < 0) { const char *e = getenv("HPGMG_PAIR_MIN_CELLS"); min_cells = (e && *e) ? atoll(e) : 4000000; }
+    if ((long long)L->dim.i * L->dim.j * L->dim.k < min_cells) return 0;
+  }
   if (!B->pair_scratch) {
     int bx;
     double **base = (double **)calloc((size_t)L->num_my_boxes, sizeof(double *));

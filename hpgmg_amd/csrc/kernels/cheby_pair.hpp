@@ -45,6 +45,10 @@ __device__ __forceinline__ double *pair_vec(const hpgmg_hip_level &L, const Pair
   double *base = r.scratch ? A.scr_base[box] : L.box_base[box];
   return base + (size_t)r.id * (size_t)L.volume + (size_t)L.ghosts * (size_t)(1 + L.jStride + L.kStride);
 }
+// Boxes narrower than a 128-cell row: the row spans 128/dim boxes that are consecutive in the level's slab, so lane l
+// reaches ITS box by adding (l / lanes_per_box) box strides to the address computed for the row's first box.
+struct LaneShift { long long lvl, scr, c32; };   // element offsets for level vectors / scratch vectors / fp32 copies
+__device__ __forceinline__ long long shift_of(const LaneShift &s, VecRef r) { return r.scratch ? s.scr : s.lvl; }
 
 struct alignas(16) p2 { double x, y; };
 __device__ __forceinline__ p2 pld(const double *p) { return *reinterpret_cast<const p2 *>(p); }
@@ -59,10 +63,10 @@ __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlan
 enum { C32_DINV = 0, C32_ALPHA, C32_BETA_I, C32_BETA_J, C32_BETA_K, C32_COUNT };
 template <bool C32> struct CoefStream {
   const double *p64; const float *p32;
-  __device__ __forceinline__ CoefStream(const hpgmg_hip_level &L, const PairArgs &A, int box, int vec_id, int slot) {
+  __device__ __forceinline__ CoefStream(const hpgmg_hip_level &L, const PairArgs &A, int box, int vec_id, int slot, const LaneShift &sh = LaneShift{0, 0, 0}) {
     const size_t first = (size_t)L.ghosts * (size_t)(1 + L.jStride + L.kStride);
-    if (C32) { p32 = A.c32_base[box] + (size_t)slot * (size_t)L.volume + first; p64 = nullptr; }
-    else     { p64 = L.box_base[box] + (size_t)vec_id * (size_t)L.volume + first; p32 = nullptr; }
+    if (C32) { p32 = A.c32_base[box] + (size_t)slot * (size_t)L.volume + first + sh.c32; p64 = nullptr; }
+    else     { p64 = L.box_base[box] + (size_t)vec_id * (size_t)L.volume + first + sh.lvl; p32 = nullptr; }
   }
   __device__ __forceinline__ p2 pair(int off) const {
     if (C32) { const float2 f = *reinterpret_cast<const float2 *>(p32 + off); return p2{(double)f.x, (double)f.y}; }
@@ -95,7 +99,7 @@ __device__ __forceinline__ p2 pair_update(p2 c, double left, double right, p2 jm
   return o;
 }
 
-template <int V, int NW, bool C32, int SM>
+template <int V, int NW, bool C32, int SM, bool NARROW>
 __global__ __launch_bounds__(64 * NW) void cheby_pair_kernel(const hpgmg_hip_level L, const PairArgs A) {
   constexpr bool kVC = (V != HPGMG_HIP_7PT_CC);
   constexpr bool kHelm = (V == HPGMG_HIP_7PT_VC_HELMHOLTZ);
@@ -120,7 +124,11 @@ __global__ __launch_bounds__(64 * NW) void cheby_pair_kernel(const hpgmg_hip_lev
   const int gj = R - 1 + w;
   const bool row_x1 = (gj >= 0 && gj < A.Dj && w <= NRs + 1);  // this wave computes x1 on its row
   const bool row_out = (w >= 1 && w <= NRs);                   // ... and x2, and stores both
-  const int bi_ = gi0 / bd, li = gi0 - bi_ * bd + 2 * lane;
+  // NARROW (boxes of 64, 32 or 16 cells): hop = which of the row's boxes this lane is in; otherwise the shifts fold to zero
+  const int lanes_per_box = NARROW ? bd / 2 : 64, hop = NARROW ? lane / lanes_per_box : 0;
+  const int bi_ = gi0 / bd, li = NARROW ? 2 * (lane - hop * lanes_per_box) : gi0 - bi_ * bd + 2 * lane;
+  LaneShift sh = {0, 0, 0};
+  if (NARROW) { sh.lvl = (long long)hop * L.box_stride; sh.scr = (long long)hop * 2 * L.volume; sh.c32 = (long long)hop * C32_COUNT * L.volume; }
   const int gjc = row_x1 ? gj : 0;
   const int bj_ = gjc / bd, lj = gjc - bj_ * bd;
   const int row_off = li + lj * jS;                            // offset of this lane's pair inside a plane of its box
@@ -151,10 +159,10 @@ __global__ __launch_bounds__(64 * NW) void cheby_pair_kernel(const hpgmg_hip_lev
   const int pstart = in_dom(P0) ? P0 : P0 + 1;
   if (row_x1) {
     const int box = box_of(bi_, bj_, pstart), off = row_off + plane_off(pstart);
-    x0c = pld(pair_vec(L, A, A.x0, box) + off);
-    if (kVC) bj_c = CoefStream<C32>(L, A, box, VECTOR_BETA_J, C32_BETA_J).pair(off);
-    if (in_dom(pstart - 1)) { const int bm = box_of(bi_, bj_, pstart - 1); x0m = pld(pair_vec(L, A, A.x0, bm) + row_off + plane_off(pstart - 1)); }
-    if (far_lo || far_hi) far_c = pld(pair_vec(L, A, A.x0, box_of(bi_, bjf, pstart)) + li + ljf * jS + plane_off(pstart));
+    x0c = pld(pair_vec(L, A, A.x0, box) + shift_of(sh, A.x0) + off);
+    if (kVC) bj_c = CoefStream<C32>(L, A, box, VECTOR_BETA_J, C32_BETA_J, sh).pair(off);
+    if (in_dom(pstart - 1)) { const int bm = box_of(bi_, bj_, pstart - 1); x0m = pld(pair_vec(L, A, A.x0, bm) + shift_of(sh, A.x0) + row_off + plane_off(pstart - 1)); }
+    if (far_lo || far_hi) far_c = pld(pair_vec(L, A, A.x0, box_of(bi_, bjf, pstart)) + shift_of(sh, A.x0) + li + ljf * jS + plane_off(pstart));
     slabX0[pstart & 1][w][lane] = x0c;
     slabBJ[pstart & 1][w][lane] = bj_c;
   }
@@ -168,17 +176,17 @@ __global__ __launch_bounds__(64 * NW) void cheby_pair_kernel(const hpgmg_hip_lev
     if (row_x1) {
       if (above_in) {
         const int bn = box_of(bi_, bj_, p + 1), offn = row_off + plane_off(p + 1);
-        x0p = pld(pair_vec(L, A, A.x0, bn) + offn);
+        x0p = pld(pair_vec(L, A, A.x0, bn) + shift_of(sh, A.x0) + offn);
         if (have_next) {
-          if (kVC) bj_n = CoefStream<C32>(L, A, bn, VECTOR_BETA_J, C32_BETA_J).pair(offn);
-          if (far_lo || far_hi) far_n = pld(pair_vec(L, A, A.x0, box_of(bi_, bjf, p + 1)) + li + ljf * jS + plane_off(p + 1));
+          if (kVC) bj_n = CoefStream<C32>(L, A, bn, VECTOR_BETA_J, C32_BETA_J, sh).pair(offn);
+          if (far_lo || far_hi) far_n = pld(pair_vec(L, A, A.x0, box_of(bi_, bjf, p + 1)) + shift_of(sh, A.x0) + li + ljf * jS + plane_off(p + 1));
         }
       }
-      qc.rhs = pld(vec_origin(L, box, A.rhs_id) + off);
-      qc.dinv = CoefStream<C32>(L, A, box, VECTOR_DINV, C32_DINV).pair(off);
-      if (kHelm) qc.al = CoefStream<C32>(L, A, box, VECTOR_ALPHA, C32_ALPHA).pair(off);
+      qc.rhs = pld(vec_origin(L, box, A.rhs_id) + sh.lvl + off);
+      qc.dinv = CoefStream<C32>(L, A, box, VECTOR_DINV, C32_DINV, sh).pair(off);
+      if (kHelm) qc.al = CoefStream<C32>(L, A, box, VECTOR_ALPHA, C32_ALPHA, sh).pair(off);
       if (kVC) {
-        const CoefStream<C32> bis(L, A, box, VECTOR_BETA_I, C32_BETA_I), bks(L, A, box, VECTOR_BETA_K, C32_BETA_K);
+        const CoefStream<C32> bis(L, A, box, VECTOR_BETA_I, C32_BETA_I, sh), bks(L, A, box, VECTOR_BETA_K, C32_BETA_K, sh);
         qc.bi = bis.pair(off);
         qc.bir = __shfl_down(qc.bi.x, 1, 64);
         if (lane == 63) qc.bir = bis.one(off + 2);
@@ -186,11 +194,11 @@ __global__ __launch_bounds__(64 * NW) void cheby_pair_kernel(const hpgmg_hip_lev
         if (p == pstart || (p % bd) == 0) qc.bk0 = bks.pair(off); else qc.bk0 = qp.bk1;
         qc.bk1 = bks.pair(off + kS);                             // the box's own upper face (ghost plane at the box top)
         qc.bjlo = bj_c;
-        if (w == NRs + 1 || gj + 1 >= A.Dj || ((lj + 1) == bd)) qc.bjhi = CoefStream<C32>(L, A, box, VECTOR_BETA_J, C32_BETA_J).pair(off + jS);
+        if (w == NRs + 1 || gj + 1 >= A.Dj || ((lj + 1) == bd)) qc.bjhi = CoefStream<C32>(L, A, box, VECTOR_BETA_J, C32_BETA_J, sh).pair(off + jS);
         else qc.bjhi = slabBJ[p & 1][w + 1][lane];
       }
       p2 xm1 = {0, 0};
-      if (SM == PAIR_CHEBY) xm1 = pld(pair_vec(L, A, A.xm1, box) + off);
+      if (SM == PAIR_CHEBY) xm1 = pld(pair_vec(L, A, A.xm1, box) + shift_of(sh, A.xm1) + off);
 
       // ---- x1 on plane p (first sweep): neighbours of x0
       p2 jm, jp;
@@ -218,9 +226,9 @@ __global__ __launch_bounds__(64 * NW) void cheby_pair_kernel(const hpgmg_hip_lev
       if (lane == 0)  left  = left_dom  ? -x1m1.x : pair_vec(L, A, A.out1, box_of(biL, bj_, q))[liL + lj * jS + plane_off(q)];
       if (lane == 63) right = right_dom ? -x1m1.y : pair_vec(L, A, A.out1, box_of(biR, bj_, q))[liR + lj * jS + plane_off(q)];
       const p2 x2 = pair_update<V, SM>(x1m1, left, right, jm, jp, km, kp, x0m, qp, A.a, A.b, A.h2inv, A.c1b, A.c2b, ((gj ^ q ^ (A.sweep_a + 1)) & 1) == 0);
-      pst(pair_vec(L, A, A.out2, boxq) + offq, x2);
+      pst(pair_vec(L, A, A.out2, boxq) + shift_of(sh, A.out2) + offq, x2);
     }
-    if (SM == PAIR_CHEBY && row_out && p >= K0 && p < K0 + KCs) pst(pair_vec(L, A, A.out1, box) + off, x1c);   // GSRB keeps no x1
+    if (SM == PAIR_CHEBY && row_out && p >= K0 && p < K0 + KCs) pst(pair_vec(L, A, A.out1, box) + shift_of(sh, A.out1) + off, x1c);   // GSRB keeps no x1
 
     // ---- hand this plane's x1 and the next plane's x0 / beta_j to the neighbouring waves
     if (row_x1) {
@@ -245,7 +253,7 @@ __global__ __launch_bounds__(64 * NW) void cheby_pair_kernel(const hpgmg_hip_lev
       if (lane == 0)  left  = left_dom  ? -x1m1.x : pair_vec(L, A, A.out1, box_of(biL, bj_, q))[liL + lj * jS + plane_off(q)];
       if (lane == 63) right = right_dom ? -x1m1.y : pair_vec(L, A, A.out1, box_of(biR, bj_, q))[liR + lj * jS + plane_off(q)];
       const p2 x2 = pair_update<V, SM>(x1m1, left, right, jm, jp, km, kp, x0m, qp, A.a, A.b, A.h2inv, A.c1b, A.c2b, ((gj ^ q ^ (A.sweep_a + 1)) & 1) == 0);
-      pst(pair_vec(L, A, A.out2, boxq) + offq, x2);
+      pst(pair_vec(L, A, A.out2, boxq) + shift_of(sh, A.out2) + offq, x2);
     }
   }
 }

@@ -725,7 +725,9 @@ int hpgmg_hip_smooth_cheby(const hpgmg_hip_level *L, int variant, int xn_id, int
 // no error recorded) when the level does not fit the kernel's assumptions, so the caller can fall back.
 int hpgmg_hip_smooth_cheby_pair_supported(const hpgmg_hip_level *L, int variant) {
   if (variant != HPGMG_HIP_7PT_VC_HELMHOLTZ && variant != HPGMG_HIP_7PT_VC_POISSON && variant != HPGMG_HIP_7PT_CC) return 0;
-  if (L->num_boxes <= 0 || L->periodic || L->dim % 128 != 0 || !(L->flags & 1) || L->ghosts < 1) return 0;
+  if (L->num_boxes <= 0 || L->periodic || !(L->flags & 1) || L->ghosts < 1 || L->dim_i % 128 != 0) return 0;
+  // a wave owns a 128-cell row: whole multiples of 128 per box, or several boxes (consecutive in one slab) per row
+  if (L->dim % 128 != 0 && !(128 % L->dim == 0 && L->dim >= 16 && (L->box_stride > 0 || L->num_boxes == 1))) return 0;
   if (L->jStride % 2 || L->kStride % 2 || L->volume % 2) return 0;
   if (L->dim_i % L->dim || L->dim_j % L->dim || L->dim_k % L->dim) return 0;
   if ((long long)(L->dim_i / L->dim) * (L->dim_j / L->dim) * (L->dim_k / L->dim) != L->num_boxes) return 0;
@@ -768,10 +770,12 @@ static int smooth_pair(const hpgmg_hip_level *L, int variant, int gsrb, int swee
   const long long cells = (long long)A.Di * A.Dj * A.Dk;
   const size_t lds = (size_t)nw * 6 * 64 * sizeof(p2);
   const int prof = profile_begin(cells);
+#define PAIR_LAUNCH2(VAR, C32, SM, NARROW) { \
+      static bool once = false; if (!once) { HPGMG_CHECK(hipFuncSetAttribute((const void *)cheby_pair_kernel<VAR, nw, C32, SM, NARROW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once = true; } \
+      hipLaunchKernelGGL((cheby_pair_kernel<VAR, nw, C32, SM, NARROW>), dim3(grid), dim3(64, nw), lds, g_stream, *L, A); }
 #define PAIR_LAUNCH(VAR, C32, SM) { \
       if (A.tiles_i > 1) hipLaunchKernelGGL((cheby_pair_edge_kernel<VAR, C32, SM>), dim3((A.Dj + 63) / 64, A.Dk, 2 * (A.tiles_i - 1)), dim3(64), 0, g_stream, *L, A); \
-      static bool once = false; if (!once) { HPGMG_CHECK(hipFuncSetAttribute((const void *)cheby_pair_kernel<VAR, nw, C32, SM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once = true; } \
-      hipLaunchKernelGGL((cheby_pair_kernel<VAR, nw, C32, SM>), dim3(grid), dim3(64, nw), lds, g_stream, *L, A); }
+      if (L->dim % 128 == 0) PAIR_LAUNCH2(VAR, C32, SM, false) else PAIR_LAUNCH2(VAR, C32, SM, true) }
 #define PAIR_CASE(VAR) case VAR: \
     if (gsrb) { if (c32_base) PAIR_LAUNCH(VAR, true, PAIR_GSRB) else PAIR_LAUNCH(VAR, false, PAIR_GSRB) } \
     else      { if (c32_base) PAIR_LAUNCH(VAR, true, PAIR_CHEBY) else PAIR_LAUNCH(VAR, false, PAIR_CHEBY) } break;
@@ -783,6 +787,7 @@ static int smooth_pair(const hpgmg_hip_level *L, int variant, int gsrb, int swee
   }
 #undef PAIR_CASE
 #undef PAIR_LAUNCH
+#undef PAIR_LAUNCH2
   profile_end(prof, 2 * cells);                      // one launch = two sweeps over every cell
   HPGMG_LAUNCH_CHECK("cheby_pair_kernel");
   return 0;

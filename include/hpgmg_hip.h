@@ -34,6 +34,7 @@ typedef struct {
   const int *box_nbr;      /* DEVICE array [6*num_boxes] or NULL: local index of the box across the -i,+i,-j,+j,-k,+k
                               face; -1 = homogeneous-Dirichlet domain face; -2 = box on another rank (use the ghost zone) */
   int flags;               /* bit 0: the first interior cell of every box and vector is 16-byte aligned (enables 16-B loads) */
+  long long box_stride;    /* doubles between the bases of consecutive boxes when that distance is the same for all boxes (one slab), else 0 */
 } hpgmg_hip_level;
 
 /* stencil variants of apply_op_ijk (operators.7pt.c:49-89, operators.27pt.c:60-91, operators.fv4.c:55-134) */
@@ -92,7 +93,8 @@ int hpgmg_hip_smooth_cheby(const hpgmg_hip_level *L, int variant, int xn_id, int
  * x2 = S(x1, x0; c1b, c2b); bit-identical to two hpgmg_hip_smooth_cheby calls with the Dirichlet ghost rule between
  * them.  Each vector is (scratch?, id): scratch ids 0/1 are the two extra vectors per box behind scr_base[box]
  * (same padded layout as the level's vectors).  out1/out2 must differ from x0/xm1.  Needs every face neighbour
- * local, Dirichlet, box side a multiple of 128, boxes numbered lexicographically (_supported() checks the rest). */
+ * local, Dirichlet, rows of 128 cells (box side a multiple of 128, or a divisor of 128 with the boxes in one slab), boxes
+ * numbered lexicographically (_supported() checks the rest). */
 int hpgmg_hip_smooth_cheby_pair_supported(const hpgmg_hip_level *L, int variant);
 int hpgmg_hip_smooth_cheby_pair(const hpgmg_hip_level *L, int variant, double *const *scr_base, const float *const *c32_base,
                                 int x0_scr, int x0_id, int xm1_scr, int xm1_id, int out1_scr, int out1_id, int out2_scr, int out2_id,

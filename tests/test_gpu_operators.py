@@ -81,7 +81,8 @@ def test_smooth_residual_apply(hip, oracle, variant, geom, ghost_free):
 
 
 @pytest.mark.parametrize("variant,geom", [("7pt-cheby-helm", (2, 128)), ("7pt-cheby", (1, 128)), ("7ptcc-cheby", (1, 256)), ("7pt-cheby-helm", (3, 128)),
-                                          ("7pt-gsrb", (2, 128)), ("7pt-gsrb", (1, 256))])
+                                          ("7pt-gsrb", (2, 128)), ("7pt-gsrb", (1, 256)),
+                                          ("7pt-cheby-helm", (4, 64)), ("7pt-gsrb", (8, 32))])    # rows of 128 cells spanning 2 / 4 boxes
 def test_fused_chebyshev_sweep_pairs(hip, oracle, variant, geom):
     """Boxes whose side is a multiple of 128 smooth with the fused two-sweeps-per-pass kernel (cheby_pair.hpp): U and
     VECTOR_TEMP must equal the oracle's four separate sweeps bit for bit, and equal the one-launch-per-sweep HIP path."""
