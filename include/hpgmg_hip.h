@@ -83,12 +83,21 @@ int  hpgmg_hip_get_ghost_free(void);
  * Jacobi read x_n and write x_np1 (x_np1 doubles as x_{n-1} for Chebyshev);
  * GSRB updates the cells whose global parity (i+j+k+sweep) is even, in place
  * when xn_id == xnp1_id, otherwise copying the other colour. */
+int hpgmg_hip_smooth_cheby(const hpgmg_hip_level *L, int variant, int xn_id, int xnp1_id, int rhs_id,
+                           double a, double b, double h2inv, double c1, double c2);
+int hpgmg_hip_smooth_gsrb(const hpgmg_hip_level *L, int variant, int xn_id, int xnp1_id, int rhs_id,
+                          double a, double b, double h2inv, int sweep);
+int hpgmg_hip_smooth_jacobi(const hpgmg_hip_level *L, int variant, int xn_id, int xnp1_id, int rhs_id,
+                            double a, double b, double h2inv, double weight);
+/* operators/residual.c:9-51 (rhs_id >= 0: res = rhs - A x) and operators/apply_op.c:9-48 (rhs_id < 0: res = A x) */
+int hpgmg_hip_residual(const hpgmg_hip_level *L, int variant, int res_id, int x_id, int rhs_id,
+                       double a, double b, double h2inv);
 /* Overlap of the halo exchange with the stencil launches below (ghost-free 7-point path only): mode 1 = the next
  * launches leave the cells next to a face owned by another rank (box_nbr == -2) untouched, mode 2 = the next launches
  * compute exactly those cells (one lane per cell), mode 0 = whole boxes. */
 void hpgmg_hip_set_defer_mode(int mode);
-int hpgmg_hip_smooth_cheby(const hpgmg_hip_level *L, int variant, int xn_id, int xnp1_id, int rhs_id,
-                           double a, double b, double h2inv, double c1, double c2);
+
+/* ---- fused forms of smooth() for bandwidth-bound levels (kernels/cheby_pair.hpp) ---- */
 /* Two consecutive Chebyshev sweeps (chebyshev.c:43-99 twice) in one pass: x1 = S(x0, xm1; c1a, c2a),
  * x2 = S(x1, x0; c1b, c2b); bit-identical to two hpgmg_hip_smooth_cheby calls with the Dirichlet ghost rule between
  * them.  Each vector is (scratch?, id): scratch ids 0/1 are the two extra vectors per box behind scr_base[box]
@@ -109,13 +118,6 @@ int hpgmg_hip_smooth_gsrb_pair(const hpgmg_hip_level *L, int variant, double *co
  * vectors; passing them to hpgmg_hip_smooth_cheby_pair makes the sweep pair read 4-byte coefficients (iterate, right-hand
  * side and all arithmetic stay fp64).  c32_base == NULL is the bit-exact fp64 smoother. */
 int hpgmg_hip_coef32_refresh(const hpgmg_hip_level *L, float *const *c32_base, int num_vectors /* of the level: absent coefficient vectors are skipped */);
-int hpgmg_hip_smooth_gsrb(const hpgmg_hip_level *L, int variant, int xn_id, int xnp1_id, int rhs_id,
-                          double a, double b, double h2inv, int sweep);
-int hpgmg_hip_smooth_jacobi(const hpgmg_hip_level *L, int variant, int xn_id, int xnp1_id, int rhs_id,
-                            double a, double b, double h2inv, double weight);
-/* operators/residual.c:9-51 (rhs_id >= 0: res = rhs - A x) and operators/apply_op.c:9-48 (rhs_id < 0: res = A x) */
-int hpgmg_hip_residual(const hpgmg_hip_level *L, int variant, int res_id, int x_id, int rhs_id,
-                       double a, double b, double h2inv);
 
 /* ---- block lists.  `blocks` is a DEVICE copy of a host blockCopy_type array ---- */
 /* operators/blockCopy.c:6-105 CopyBlock over a list (exchange_boundary pack/local/unpack, restriction unpack) */
@@ -163,10 +165,10 @@ int hpgmg_hip_blackbox_finalize(const hpgmg_hip_level *L, int Aii_id, int sumAbs
 int hpgmg_hip_rebuild_7pt(const hpgmg_hip_level *L, int variable_coeff, int alpha_id, int l1inv_id,
                           double a, double b, double h2inv, double *lambda_max_out);
 
-/* ---- tail.hip: both legs of a V-cycle over a chain of small levels (each <= hpgmg_hip_tail_max_cells()
- *      cells, all face neighbours local) as ONE single-workgroup launch per leg; the operator sequence
- *      of mg.c:1147-1163 (smooth, residual, restriction, zero_vector | interpolation_vcycle, smooth)
- *      with barriers where the driver has kernel boundaries.  levels[n-1] is the bottom level. ---- */
+/* ---- tail.hip: the part of a V-cycle below a small level -- a chain of levels of <= hpgmg_hip_tail_max_cells()
+ *      cells each, all face neighbours local -- as ONE single-workgroup launch (or one per leg): the operator
+ *      sequence of mg.c:1147-1163 (smooth, residual, restriction, zero_vector | interpolation_vcycle, smooth) with
+ *      barriers where the driver has kernel boundaries, and optionally the bottom solve.  levels[n-1] is the bottom level. ---- */
 int hpgmg_hip_tail_max_levels(void);
 int hpgmg_hip_tail_max_cells(void);          /* per smoothed level of the chain */
 int hpgmg_hip_tail_bottom_max_cells(void);   /* bottom level, when its BiCGStab solve runs on the device (leg 2, 3) */
