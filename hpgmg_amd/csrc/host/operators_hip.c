@@ -67,10 +67,15 @@ int hpgmg_transport_init_rccl(const char *id128, int rank, int size) {
 void hpgmg_transport_finalize_rccl(void) { hpgmg_set_transport(NULL); hpgmg_hip_rccl_finalize(); }
 
 /* ---------------------------------------------------------------- hipGraph segments (see hpgmg_operators.h) */
+/* hipGraph capture/replay of the launch-bound segments is available but OFF by default: with the launch stream
+ * kept full by asynchronous eager launches the GPU is already 99 % busy, and on ROCm 7 replaying the segments as graphs
+ * measured 2-5 % slower (3.88 vs 3.81 ms per 256^3 F-cycle, 0.574 vs 0.548 ms at 64^3).  HPGMG_GRAPH=1 or
+ * hpgmg_set_graphs(1) turns it on (useful when the host thread is the bottleneck). */
+static int graphs = -1;
+void hpgmg_set_graphs(int on) { graphs = on ? 1 : 0; }
 void hpgmg_segment_begin(long long key) {
-  static int graphs = -1;
-  if (graphs < 0) { const char *e = getenv("HPGMG_GRAPH"); graphs = !(e && e[0] == '0'); }
-  if (!graphs || sync_timers > 0) return;       /* HPGMG_GRAPH=0 / per-operator timing: stay eager */
+  if (graphs < 0) { const char *e = getenv("HPGMG_GRAPH"); graphs = (e && e[0] == '1'); }
+  if (!graphs || sync_timers > 0) return;       /* per-operator timing: stay eager */
   /* multi-rank: segments cover levels of <= 64^3 cells; they are message-free (capturable) only when the rank map
    * gathers those levels on rank 0 (mg.c: hpgmg_gather_dim, the default) */
   { extern int hpgmg_gather_dim; const hpgmg_transport *T = hpgmg_get_transport(); if (T && T->size > 1 && hpgmg_gather_dim < 64) return; }

@@ -11,6 +11,8 @@
 // vector ids and coefficients are fixed after MGBuild; the cache is dropped whenever a level is
 // released or the configuration changes.  Reductions / copies that synchronise with the host
 // close the open segment first (they cannot be part of a graph).
+#include <stdio.h>
+#include <stdlib.h>
 #include <unordered_map>
 #include "common.hpp"
 
@@ -70,7 +72,12 @@ int hpgmg_hip_graph_begin(long long key) {
   if (e.exec) { g_state = SEG_REPLAY; g_skip_launches = 1; }
   else if (e.seen == 2) g_state = SEG_EAGER;          // known to be empty
   else if (e.seen) {
-    if (hipStreamBeginCapture(g_stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); g_state = SEG_EAGER; }
+    const hipError_t ce = hipStreamBeginCapture(g_stream, hipStreamCaptureModeThreadLocal);
+    if (ce != hipSuccess) {
+      static bool told = false;
+      if (!told && getenv("HPGMG_GRAPH_DEBUG")) { fprintf(stderr, "hpgmg_hip: hipStreamBeginCapture failed: %s (stream %p)\n", hipGetErrorString(ce), (void *)g_stream); told = true; }
+      (void)hipGetLastError(); g_state = SEG_EAGER;
+    }
     else g_state = SEG_CAPTURE;
   } else { e.seen = 1; g_state = SEG_EAGER; }
   return g_state;

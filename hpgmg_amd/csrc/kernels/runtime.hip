@@ -20,13 +20,25 @@ extern "C" {
 int hpgmg_hip_graph_flush(void);
 
 int hpgmg_hip_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
-int hpgmg_hip_set_device(int dev) { HPGMG_CHECK(hipSetDevice(dev)); return 0; }
-void hpgmg_hip_set_stream(void *s) { g_stream = (hipStream_t)s; }
-void *hpgmg_hip_get_stream(void) { return (void *)g_stream; }
+// The launch stream.  Unless the caller chose one, the library creates its own on first use: the legacy null stream
+// cannot be captured into a hipGraph (hipErrorStreamCaptureUnsupported), and it would serialise against every other
+// blocking stream of the process (e.g. a framework's).
+static bool g_stream_chosen = false;
+static void ensure_stream() {
+  if (g_stream_chosen) return;
+  g_stream_chosen = true;
+  hipStream_t s = nullptr;
+  (void)hipDeviceSynchronize();
+  if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess) g_stream = s; else (void)hipGetLastError();
+}
+int hpgmg_hip_set_device(int dev) { HPGMG_CHECK(hipSetDevice(dev)); ensure_stream(); return 0; }
+void hpgmg_hip_set_stream(void *s) { g_stream = (hipStream_t)s; g_stream_chosen = true; }
+void *hpgmg_hip_get_stream(void) { ensure_stream(); return (void *)g_stream; }
 int hpgmg_hip_sync(void) { hpgmg_hip_graph_flush(); HPGMG_CHECK(hipStreamSynchronize(g_stream)); return 0; }
 const char *hpgmg_hip_last_error(void) { return g_last_error; }
 
 void *hpgmg_hip_malloc(size_t bytes) {
+  ensure_stream();
   void *p = nullptr;
   hpgmg_hip_graph_flush();
   if (bytes == 0) bytes = 8;

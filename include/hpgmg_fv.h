@@ -82,6 +82,7 @@ long long   hpgmg_overlap_count(void);      /* number of overlapped exchanges pe
 void        hpgmg_set_overlap(int on);      /* multi-rank: 1 (default) overlaps the halo exchange with the stencil launch that consumes it */
 void        hpgmg_set_smoother_precision(int bits); /* 64 (default, bit-exact) or 32: mixed-precision Chebyshev smoother, BASELINE config 5 */
 int         hpgmg_get_smoother_precision(void);
+void        hpgmg_set_graphs(int on);       /* 1: replay the launch-bound segments of a cycle as hipGraphs (default 0: eager launches measured faster) */
 void        hpgmg_set_fused_sweeps(int on); /* 1 (default): Chebyshev smooth() on boxes of side 128k runs as fused sweep pairs; 0: one launch per sweep */
 void        hpgmg_set_ghost_free(int on);   /* 1 (default): fused ghost handling in the 7-pt stencil launches; 0: exchange + BC + stencil */
 void        hpgmg_set_box_alignment(int jstride, int kstride, int volume, int base_bytes);

@@ -84,6 +84,28 @@ def test_fp32_smoother_is_tolerance_gated_against_fp64(hip, variant):
         hip.lib.hpgmg_set_smoother_precision(64)
 
 
+def test_hipgraph_segments_replay_the_same_numbers(hip):
+    """hpgmg_set_graphs(1): the <= 64^3 part of the cycle is captured on the second solve and replayed afterwards."""
+    import ctypes
+    import hpgmg_amd as H
+    K = H.load_kernels()
+    gold = GOLD["7pt-cheby-helm 6 8"]
+    stats = (ctypes.c_longlong * 3)()
+    hip.lib.hpgmg_set_graphs.argtypes = [ctypes.c_int]
+    hip.lib.hpgmg_set_graphs(1)
+    try:
+        hip.configure(**VARIANTS["7pt-cheby-helm"])
+        s = hip.solver_cli(6, 8)
+        K.hpgmg_hip_graph_stats(stats); before = list(stats)
+        for _ in range(4):
+            assert fmt(s.fmg(0)) == gold["norms"][0]
+        K.hpgmg_hip_graph_stats(stats)
+        assert stats[1] > before[1] and stats[2] > before[2], (before, list(stats))     # captured, then replayed
+        s.destroy()
+    finally:
+        hip.lib.hpgmg_set_graphs(0)
+
+
 def test_reference_three_launch_mode_gives_the_same_norms(hip):
     """HPGMG_GHOST_FREE=0 path (exchange_boundary + apply_BCs + stencil, as the reference sequences them)."""
     import ctypes
