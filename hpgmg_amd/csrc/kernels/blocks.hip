@@ -272,29 +272,56 @@ __device__ __forceinline__ double interp_rule(bool odd, const double *v) {
 }
 // dimension by dimension (i, then j, then k), one fine cell per lane: the same intermediate values
 // f?c??, f??c?, f??? the reference forms for the 8 children of a coarse cell
+// Tensor-product interpolations (interpolation_p2.c, _v2.c, _v4.c): the 1-D rule is applied along i, then j, then k.
+// One lane per COARSE cell (a wave per coarse row, grid.y strides over the rows): the (2R+1)^3 coarse neighbourhood is
+// read once, plane by plane, and serves the cell's 8 children -- the i-pass results depend only on the child's i parity,
+// the j-pass results on its (i, j) parities -- instead of once per fine cell; each child is the same expression tree
+// (rule_k(rule_j(rule_i(coarse)))) as before.  Children are written as 16-byte pairs when the layout allows.
 template <int ORDER>
 __global__ __launch_bounds__(256) void interp_tensor_kernel(const hpgmg_hip_level Lf, int id_f, double prescale, const hpgmg_hip_level Lc, int id_c,
                                                             const blockCopy_type *__restrict__ list) {
   constexpr int R = (ORDER == 4) ? 2 : 1, W = 2 * R + 1;
   const blockCopy_type &e = list[blockIdx.x];
   const Side r = resolve_read(Lc, id_c, e), w = resolve_write(Lf, id_f, e);
-  const int di = 2 * e.dim.i, dj = 2 * e.dim.j, n = di * dj * 2 * e.dim.k, rj = r.jS, rk = r.kS;
-  for (int t = threadIdx.x; t < n; t += blockDim.x) {
-    const int i = t % di, j = (t / di) % dj, k = t / (di * dj);
-    const double *c = r.p + (i >> 1) + (j >> 1) * rj + (k >> 1) * rk;
-    double line[W], tj[W], tk[W];
+  const int ci_n = e.dim.i, cj_n = e.dim.j, rows = cj_n * e.dim.k, rj = r.jS, rk = r.kS;
+  const bool pairs = (e.write.box >= 0) && (Lf.flags & 1);
+  const int lane = threadIdx.x % 64;
+  for (int row = blockIdx.y * 4 + threadIdx.x / 64; row < rows; row += gridDim.y * 4) {
+    const int ck = row / cj_n, cj = row - ck * cj_n;
+    const double *crow = r.p + cj * rj + ck * rk;
+    double *frow = w.p + 2 * cj * w.jS + 2 * ck * w.kS;
+    for (int ci = lane; ci < ci_n; ci += 64) {
+      const double *c = crow + ci;
+      double tk[2][2][W];                                       // [child i parity][child j parity][coarse plane]
 #pragma unroll
-    for (int kk = 0; kk < W; kk++) {
+      for (int kk = 0; kk < W; kk++) {
+        double tj[2][W];                                        // [child i parity][coarse row]
 #pragma unroll
-      for (int jj = 0; jj < W; jj++) {
+        for (int jj = 0; jj < W; jj++) {
+          double line[W];
 #pragma unroll
-        for (int ii = 0; ii < W; ii++) line[ii] = c[(ii - R) + (jj - R) * rj + (kk - R) * rk];
-        tj[jj] = interp_rule<ORDER>(i & 1, line);
+          for (int ii = 0; ii < W; ii++) line[ii] = c[(ii - R) + (jj - R) * rj + (kk - R) * rk];
+          tj[0][jj] = interp_rule<ORDER>(false, line);
+          tj[1][jj] = interp_rule<ORDER>(true, line);
+        }
+#pragma unroll
+        for (int fi = 0; fi < 2; fi++) { tk[fi][0][kk] = interp_rule<ORDER>(false, tj[fi]); tk[fi][1][kk] = interp_rule<ORDER>(true, tj[fi]); }
       }
-      tk[kk] = interp_rule<ORDER>(j & 1, tj);
+#pragma unroll
+      for (int fk = 0; fk < 2; fk++) {
+#pragma unroll
+        for (int fj = 0; fj < 2; fj++) {
+          double *fw = frow + 2 * ci + fj * w.jS + fk * w.kS;
+          double f0, f1;
+          if (pairs) { const double2 t = *reinterpret_cast<const double2 *>(fw); f0 = t.x; f1 = t.y; }
+          else { f0 = fw[0]; f1 = fw[1]; }
+          const double v0 = prescale * f0 + interp_rule<ORDER>(fk != 0, tk[0][fj]);
+          const double v1 = prescale * f1 + interp_rule<ORDER>(fk != 0, tk[1][fj]);
+          if (pairs) *reinterpret_cast<double2 *>(fw) = make_double2(v0, v1);
+          else { fw[0] = v0; fw[1] = v1; }
+        }
+      }
     }
-    double *fw = &w.p[i + j * w.jS + k * w.kS];
-    *fw = prescale * (*fw) + interp_rule<ORDER>(k & 1, tk);
   }
 }
 
@@ -457,9 +484,9 @@ int hpgmg_hip_interpolate_blocks(const hpgmg_hip_level *Lf, int id_f, double pre
   const int slabs = n >= 4096 ? 1 : (4096 / n > 64 ? 64 : 4096 / n);
   if (order == 0) hipLaunchKernelGGL((interp_blocks_kernel<0>), dim3(n, slabs), dim3(256), 0, g_stream, *Lf, id_f, prescale, *Lc, id_c, blocks);
   else if (order == 1) hipLaunchKernelGGL((interp_blocks_kernel<1>), dim3(n, slabs), dim3(256), 0, g_stream, *Lf, id_f, prescale, *Lc, id_c, blocks);
-  else if (order == 2) hipLaunchKernelGGL((interp_tensor_kernel<2>), dim3(n), dim3(256), 0, g_stream, *Lf, id_f, prescale, *Lc, id_c, blocks);
-  else if (order == 3) hipLaunchKernelGGL((interp_tensor_kernel<3>), dim3(n), dim3(256), 0, g_stream, *Lf, id_f, prescale, *Lc, id_c, blocks);
-  else if (order == 4) hipLaunchKernelGGL((interp_tensor_kernel<4>), dim3(n), dim3(256), 0, g_stream, *Lf, id_f, prescale, *Lc, id_c, blocks);
+  else if (order == 2) hipLaunchKernelGGL((interp_tensor_kernel<2>), dim3(n, slabs), dim3(256), 0, g_stream, *Lf, id_f, prescale, *Lc, id_c, blocks);
+  else if (order == 3) hipLaunchKernelGGL((interp_tensor_kernel<3>), dim3(n, slabs), dim3(256), 0, g_stream, *Lf, id_f, prescale, *Lc, id_c, blocks);
+  else if (order == 4) hipLaunchKernelGGL((interp_tensor_kernel<4>), dim3(n, slabs), dim3(256), 0, g_stream, *Lf, id_f, prescale, *Lc, id_c, blocks);
   else return record_error(hipErrorInvalidValue, "interpolation order");
   HPGMG_LAUNCH_CHECK("interp_blocks_kernel");
   return 0;
