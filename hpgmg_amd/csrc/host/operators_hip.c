@@ -509,9 +509,6 @@ static int boxes_lexicographic(level_type *L) {
   return B->lexicographic;
 }
 
-/* Chebyshev smooth() as fused sweep pairs (kernels/cheby_pair.hpp): 4 sweeps = 2 passes of 10 streams instead of
- * 4 x 9.  x1,x2 of the first pair go to two plugin-private vectors, the second pair brings x3 -> VECTOR_TEMP and
- * x4 -> x_id, i.e. exactly the state chebyshev.c:43-99 leaves.  Returns 0 when the level does not qualify. */
 /* BASELINE config 5: mixed-precision Chebyshev smoother.  32 = the fused sweep pairs read fp32 copies of the five
  * coefficient vectors (the iterate, the right-hand side and all arithmetic stay fp64; residual, restriction,
  * interpolation and every level the pair kernel does not cover are unchanged).  64 (default) = bit-exact fp64. */
