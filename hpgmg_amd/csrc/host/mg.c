@@ -387,7 +387,7 @@ static long long seg_base = 0;   /* identifies (hierarchy, start level) of the r
 static int seg_counter = 0, seg_open_now = 0;
 static int is_small(const mg_type *G, int l) { return G->levels[l]->dim.i <= SEGMENT_MAX_DIM; }
 static void seg_reset(const mg_type *G, int onLevel) {
-  seg_base = ((long long)(uintptr_t)G << 20) ^ ((long long)onLevel << 12);
+  seg_base = (long long)((((unsigned long long)(uintptr_t)G) << 20) ^ ((unsigned long long)onLevel << 12));   /* unsigned: the shift may wrap */
   seg_counter = 0; seg_open_now = 0;
 }
 static void seg_open(void) { if (!seg_open_now) { hpgmg_segment_begin(seg_base + (seg_counter++)); seg_open_now = 1; } }
