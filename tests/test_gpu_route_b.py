@@ -1,0 +1,48 @@
+"""INTEGRATION.md Route B, executed: the REFERENCE's own driver (hpgmg-fv.c, mg.c, solvers.c, timers.c and level.c with the
+three storage lines patched -- compiled from /root/reference by `make -C oracle ref` into oracle/_ref/routeb-*) linked
+against the PRODUCT plugin (hpgmg_amd/csrc/host/operators_hip.c + libhpgmg_hip.so) must print the reference's golden
+numbers on the MI355X.  This is the drop-in claim itself: nothing of this repository's driver is in that binary.
+The binaries are built where /root/reference exists and travel to the GPU box with the snapshot."""
+import os
+import re
+import subprocess
+
+import pytest
+
+from hpgmg_testlib import ROOT, load_golden
+
+pytestmark = pytest.mark.gpu
+GOLD = load_golden("fcycle_norms.json")
+
+
+def pinned(out):
+    keep = []
+    for line in out.splitlines():
+        m = re.search(r"(f-cycle\s+norm=\S+\s+rel=\S+|\|\|error\|\|=\S+|order=\S+|eigenvalue_max<\S+)", line)
+        if m:
+            keep.append(m.group(1))
+    return keep
+
+
+@pytest.mark.parametrize("variant,args", [("7pt-cheby-helm", "5 8"), ("7pt-cheby-helm", "7 8"), ("7pt-gsrb", "5 8"), ("7pt-gsrb", "7 8"),
+                                          ("7ptcc-cheby", "5 8"), ("7ptcc-cheby", "7 8")])
+def test_reference_driver_runs_on_the_hip_plugin(variant, args):
+    binary = os.path.join(ROOT, "oracle", "_ref", "routeb-" + variant)
+    if not os.path.exists(binary):
+        pytest.skip("oracle/_ref/routeb-* not built (needs /root/reference: make -C oracle ref)")
+    gold = GOLD[f"{variant} {args}"]
+    env = dict(os.environ, OMP_NUM_THREADS="4")
+    out = subprocess.run([binary] + args.split(), capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = pinned(out.stdout)
+    norms = []
+    for l in lines:
+        m = re.match(r"f-cycle\s+norm=(\S+)", l)
+        if m and (not norms or norms[-1] != m.group(1)):
+            norms.append(m.group(1))
+    # timed section h, 2h, 4h (20 solves each) then the Richardson section h, 2h, 4h once more
+    assert norms[:3] == gold["norms"] and norms[-3:] == gold["norms"], norms
+    assert [l.split("<")[1] for l in lines if l.startswith("eigenvalue_max")] == gold["eigenvalue_max"]
+    assert [l for l in lines if l.startswith("||error||")] == ["||error||=" + gold["richardson_error"]]
+    assert [l for l in lines if l.startswith("order=")] == ["order=" + gold["order"]]
+    assert "DOF/s=" in out.stdout
