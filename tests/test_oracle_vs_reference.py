@@ -19,6 +19,8 @@ REF = os.path.join(ROOT, "oracle", "_ref")
 
 @pytest.fixture(scope="module")
 def ref_build():
+    # the Route-B binaries of the `ref` target link the product's kernel library: make sure it exists first
+    subprocess.run(["make", "-s", "-j4", "-C", os.path.join(ROOT, "hpgmg_amd", "csrc")], check=True, stdout=subprocess.DEVNULL)
     subprocess.run(["make", "-s", "-j4", "-C", os.path.join(ROOT, "oracle"), "ref"], check=True, stdout=subprocess.DEVNULL)
     return REF
 
