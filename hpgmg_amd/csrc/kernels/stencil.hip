@@ -495,7 +495,10 @@ __global__ __launch_bounds__(256) void stencil_direct_kernel(const hpgmg_hip_lev
   const int tj = t % P.tiles_j; t /= P.tiles_j;
   const int ck = t % P.chunks_k; t /= P.chunks_k;
   const int box = t;
-  const int i = ti * (int)blockDim.x + (int)threadIdx.x;
+  // GSRB: a lane owns the PAIR of cells (2 ip, 2 ip + 1) and sweeps whichever of the two has this half sweep's colour, so no
+  // lane idles on the other colour (the launcher halves the tiles along i); every other mode: one cell per lane
+  const int ip = ti * (int)blockDim.x + (int)threadIdx.x;
+  const int i = (MODE == MODE_GSRB) ? 2 * ip : ip;
   const int j = tj * (int)blockDim.y + (int)threadIdx.y;
   if (i >= L.dim || j >= L.dim) return;
   const int k0 = ck * P.kchunk, k1 = (k0 + P.kchunk < L.dim) ? k0 + P.kchunk : L.dim;
@@ -515,21 +518,27 @@ __global__ __launch_bounds__(256) void stencil_direct_kernel(const hpgmg_hip_lev
   int colour000 = 0;
   if (MODE == MODE_GSRB) colour000 = (L.box_low[3 * box] ^ L.box_low[3 * box + 1] ^ L.box_low[3 * box + 2] ^ P.sweep) & 1;
 
-  int ijk = i + j * jS + k0 * kS;
-  for (int k = k0; k < k1; k++, ijk += kS) {
-    bool update = true;
-    if (MODE == MODE_GSRB) update = (((i ^ j ^ k ^ colour000) & 1) == 0);
-    if (update) {
+  int row = j * jS + k0 * kS;                            // (0, j, k)
+  for (int k = k0; k < k1; k++, row += kS) {
+    if (MODE == MODE_GSRB) {
+      const int sel = (j ^ k ^ colour000) & 1;             // cell i is swept when (i ^ j ^ k ^ colour000) is even: of the pair, the one with i & 1 == sel
+      const int iu = i + sel, io = i + 1 - sel;
+      if (iu < L.dim) {
+        const int ijk = iu + row;
+        const double xc = x[ijk];
+        const double Ax = apply_op_direct<V>(x, alpha, bi, bj, bk, ijk, jS, kS, P.a, P.b, P.h2inv);
+        out[ijk] = xc + dinv[ijk] * (rhs[ijk] - Ax);
+      }
+      if (P.copy_other_colour && io < L.dim) out[io + row] = x[io + row];
+    } else {
+      const int ijk = i + row;
       const double xc = x[ijk];
       const double Ax = apply_op_direct<V>(x, alpha, bi, bj, bk, ijk, jS, kS, P.a, P.b, P.h2inv);
       if (MODE == MODE_CHEBY)         { const double xnm1 = out[ijk]; out[ijk] = xc + P.c1 * (xc - xnm1) + P.c2 * dinv[ijk] * (rhs[ijk] - Ax); }
-      else if (MODE == MODE_GSRB)     { out[ijk] = xc + dinv[ijk] * (rhs[ijk] - Ax); }
       else if (MODE == MODE_JACOBI)   { out[ijk] = xc + P.c2 * dinv[ijk] * (rhs[ijk] - Ax); }
       else if (MODE == MODE_RESIDUAL) { out[ijk] = rhs[ijk] - Ax; }
       else if (MODE == MODE_APPLY)    { out[ijk] = Ax; }
       else { out[ijk] += (xc) * Ax; rhs[ijk] += fabs((1.0 - xc) * Ax); }
-    } else if (P.copy_other_colour) {
-      out[ijk] = x[ijk];
     }
   }
 }
@@ -616,6 +625,11 @@ static int launch_direct(const hpgmg_hip_level *L, int variant, StencilArgs P, b
   dim3 block; int grid;
   plan(L, P, block, grid);
   P.ghost_free = 0;
+  if (MODE == MODE_GSRB) {                       // a lane owns two cells along i (see the kernel)
+    P.tiles_i = ((L->dim + 1) / 2 + (int)block.x - 1) / (int)block.x;
+    P.total_blocks = L->num_boxes * P.chunks_k * P.tiles_j * P.tiles_i;
+    grid = grid_for(P.total_blocks, &P.per_xcd);
+  }
   const long long cells = (long long)L->num_boxes * L->dim * L->dim * L->dim;
   int prof = is_smoother ? profile_begin(cells) : -1;
   switch (variant) {
