@@ -9,16 +9,18 @@
 // file is compiled with -ffp-contract=off, so results are bit-identical to the
 // reference's gcc -O2 build (no FMA, no reassociation): see DESIGN.md "parity".
 //
-// Bound: HBM bandwidth (about 25 flop per 64-72 B per cell).  Design:
-//   * one lane per (i,j) column, 64 lanes along the unit-stride i direction so a
-//     wave reads 512 contiguous bytes per stream; the block marches in +k and
-//     keeps x[k-1], x[k], x[k+1] and beta_k[k], beta_k[k+1] in registers, so each
-//     of the 8-9 streams is read from HBM once per sweep;
-//   * the +-i / +-j neighbours of x are re-read through the vector L1 (they are
-//     the same 128-B lines the neighbouring lanes / waves of the workgroup
-//     fetch as their own centre values);
-//   * logical tiles are ordered box, k, j, i and dealt to XCDs in contiguous
-//     ranges (common.hpp) so halo planes shared by adjacent tiles hit the same L2.
+// Bound: HBM bandwidth (about 25 flop per 64-72 B per cell).  Kernels in this file:
+//   * stencil7_kernel (any box size; the mid-size, cache-resident levels): one lane per (i,j) column, 64 lanes
+//     along the unit-stride i direction, the block marches in +k and keeps x[k-1], x[k], x[k+1] and beta_k[k],
+//     beta_k[k+1] in registers; the +-i / +-j neighbours of x are re-read through the vector L1;
+//   * stencil7_wide_kernel (boxes of side 128 m; the bandwidth-bound fine level): 2 x 2 cells per lane with
+//     16-byte loads, j neighbours through an LDS copy of the plane, i neighbours by wave shuffle -- every cell
+//     of every stream is fetched from memory once per workgroup;
+//   * cheby_pair_kernel (cheby_pair.hpp, included below): two sweeps per pass on the fine level;
+//   * stencil7_shell_kernel: the cells next to faces owned by another rank, after the overlapped exchange;
+//   * stencil27_kernel (27-point) and stencil_direct_kernel (4th-order fv4, black-box probes);
+//   * logical tiles are ordered box, k, j, i and dealt to XCDs in contiguous ranges (common.hpp) so halo
+//     planes shared by adjacent tiles hit the same L2.
 #include <stdlib.h>
 #include "common.hpp"
 #include "stencil_math.hpp"
