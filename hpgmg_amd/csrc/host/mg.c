@@ -454,8 +454,10 @@ void MGVCycle(mg_type *G, int e_id, int R_id, double a, double b, int l) {
   else seg_close();                                         /* back on a bandwidth-bound level */
 
   t = now();
-  interpolation_vcycle(L, e_id, 1.0, G->levels[l + 1], e_id);
-  smooth(L, e_id, R_id, a, b);
+  if (!hpgmg_interp_smooth_fused(L, e_id, R_id, G->levels[l + 1], a, b)) {
+    interpolation_vcycle(L, e_id, 1.0, G->levels[l + 1], e_id);
+    smooth(L, e_id, R_id, a, b);
+  }
   L->timers.Total += now() - t;
   if (opened_here) seg_close();
 }

@@ -601,6 +601,29 @@ static int smooth_gsrb_pairs(level_type *L, int x_id, int rhs_id, double a, doub
   return 1;
 }
 
+/* interpolation_vcycle(Lf, e, 1.0, Lc, e) followed by smooth(Lf, e, R) -- the up-leg of MGVCycle (mg.c:1160-1161) -- with the
+ * piecewise-constant interpolation folded into the first sweep pair: the interpolated e is never written or re-read.
+ * Same numbers and same final state (e = x4, VECTOR_TEMP = x3) as the two separate operators.  0 = not applicable. */
+int hpgmg_interp_smooth_fused(level_type *Lf, int e_id, int R_id, level_type *Lc, double a, double b) {
+  hpgmg_config cfg;
+  hpgmg_get_config(&cfg);
+  const int sweeps = hpgmg_smooth_sweeps();
+  communicator_type *S = &Lc->interpolation, *Rv = &Lf->interpolation;
+  if (cfg.op != HPGMG_OP_7PT || !Lf->active || !Lc->active) return 0;
+  if (cfg.smoother != HPGMG_SMOOTH_CHEBY && !(cfg.smoother == HPGMG_SMOOTH_GSRB && !hpgmg_gsrb_out_of_place())) return 0;
+  if (S->num_sends || S->num_recvs || Rv->num_sends || Rv->num_recvs || S->num_blocks[0] || Rv->num_blocks[2]) return 0;   /* all parents local */
+  if (Lf->box_dim % 128 != 0 || Lc->box_dim * 2 != Lf->box_dim || Lc->num_my_boxes != Lf->num_my_boxes || !boxes_lexicographic(Lc)) return 0;
+  if (!pair_kernel_ready(Lf, e_id, R_id, sweeps)) return 0;
+  if (cfg.smoother == HPGMG_SMOOTH_CHEBY && Lf->dominant_eigenvalue_of_DinvA <= 0.0) return 0;
+  hpgmg_hip_pair_fold_interpolation(&backend_of(Lc)->dev, e_id, 1.0);
+  if (cfg.smoother == HPGMG_SMOOTH_CHEBY) {
+    double c1[16], c2[16];
+    cheby_coefficients(Lf, sweeps, c1, c2);
+    if (!smooth_cheby_pairs(Lf, e_id, R_id, a, b, c1, c2, sweeps)) { fprintf(stderr, "hpgmg: fused interpolation+smooth refused after being accepted\n"); abort(); }
+  } else if (!smooth_gsrb_pairs(Lf, e_id, R_id, a, b, sweeps)) { fprintf(stderr, "hpgmg: fused interpolation+smooth refused after being accepted\n"); abort(); }
+  return 1;
+}
+
 void smooth(level_type *L, int x_id, int rhs_id, double a, double b) {
   hpgmg_config cfg;
   hpgmg_get_config(&cfg);

@@ -33,6 +33,9 @@ struct PairArgs {
   int rhs_id;
   double a, b, h2inv, c1a, c2a, c1b, c2b;           // Chebyshev coefficients of the two sweeps
   int sweep_a;                                      // GSRB: number of the first half sweep (its colour; the second is sweep_a + 1)
+  // INTERP variants: x0 is not read as stored but as  prescale * x0 + (coarse parent)  -- interpolation_vcycle
+  // (interpolation_p0.c:43) folded into the first sweep pair of the smooth() that follows it in MGVCycle (mg.c:1160-1161)
+  hpgmg_hip_level Lc; int coarse_id; double prescale;
   double *const *scr_base;                          // per box: base of 2 scratch vectors (same padded layout)
   const float *const *c32_base;                     // mixed-precision mode: per box, fp32 copies of Dinv, alpha, beta_i, beta_j, beta_k
                                                     // (5 x volume floats, same padded indexing); null in fp64 mode
@@ -100,7 +103,7 @@ __device__ __forceinline__ p2 pair_update(p2 c, double left, double right, p2 jm
   return o;
 }
 
-template <int V, int NW, bool C32, int SM, bool NARROW>
+template <int V, int NW, bool C32, int SM, bool NARROW, bool INTERP>
 __global__ __launch_bounds__(64 * NW) void cheby_pair_kernel(const hpgmg_hip_level L, const PairArgs A) {
   constexpr bool kVC = (V != HPGMG_HIP_7PT_CC);
   constexpr bool kHelm = (V == HPGMG_HIP_7PT_VC_HELMHOLTZ);
@@ -146,6 +149,21 @@ __global__ __launch_bounds__(64 * NW) void cheby_pair_kernel(const hpgmg_hip_lev
   // pointers of the current plane (wave-uniform: one box per row and plane)
   auto box_of = [&](int bi, int bj, int gk) { return uni(bi + A.nbi * (bj + A.nbj * (gk / bd))); };
   auto plane_off = [&](int gk) { return (gk % bd) * kS; };
+  // x0 for the pair starting at local (l_i, l_j) of `box` on global plane gk (INTERP: plus the coarse parent, which the two
+  // cells of a pair share), and for a single cell
+  auto x0_pair = [&](int box, int l_i, int l_j, int gk) -> p2 {
+    p2 v = pld(pair_vec(L, A, A.x0, box) + shift_of(sh, A.x0) + l_i + l_j * jS + plane_off(gk));
+    if (INTERP) {
+      const double c = vec_origin(A.Lc, box, A.coarse_id)[(l_i >> 1) + (l_j >> 1) * A.Lc.jStride + ((gk % bd) >> 1) * A.Lc.kStride];
+      v.x = A.prescale * v.x + c; v.y = A.prescale * v.y + c;
+    }
+    return v;
+  };
+  auto x0_one = [&](int box, int l_i, int l_j, int gk) -> double {
+    double v = pair_vec(L, A, A.x0, box)[l_i + l_j * jS + plane_off(gk)];
+    if (INTERP) v = A.prescale * v + vec_origin(A.Lc, box, A.coarse_id)[(l_i >> 1) + (l_j >> 1) * A.Lc.jStride + ((gk % bd) >> 1) * A.Lc.kStride];
+    return v;
+  };
 
   const int P0 = K0 - 1, P1 = K0 + KCs;                         // x1 planes P0..P1 (those inside the domain)
   auto in_dom = [&](int gk) { return gk >= 0 && gk < A.Dk; };
@@ -160,10 +178,10 @@ __global__ __launch_bounds__(64 * NW) void cheby_pair_kernel(const hpgmg_hip_lev
   const int pstart = in_dom(P0) ? P0 : P0 + 1;
   if (row_x1) {
     const int box = box_of(bi_, bj_, pstart), off = row_off + plane_off(pstart);
-    x0c = pld(pair_vec(L, A, A.x0, box) + shift_of(sh, A.x0) + off);
+    x0c = x0_pair(box, li, lj, pstart);
     if (kVC) bj_c = CoefStream<C32>(L, A, box, VECTOR_BETA_J, C32_BETA_J, sh).pair(off);
-    if (in_dom(pstart - 1)) { const int bm = box_of(bi_, bj_, pstart - 1); x0m = pld(pair_vec(L, A, A.x0, bm) + shift_of(sh, A.x0) + row_off + plane_off(pstart - 1)); }
-    if (far_lo || far_hi) far_c = pld(pair_vec(L, A, A.x0, box_of(bi_, bjf, pstart)) + shift_of(sh, A.x0) + li + ljf * jS + plane_off(pstart));
+    if (in_dom(pstart - 1)) x0m = x0_pair(box_of(bi_, bj_, pstart - 1), li, lj, pstart - 1);
+    if (far_lo || far_hi) far_c = x0_pair(box_of(bi_, bjf, pstart), li, ljf, pstart);
     slabX0[pstart & 1][w][lane] = x0c;
     slabBJ[pstart & 1][w][lane] = bj_c;
   }
@@ -177,10 +195,10 @@ __global__ __launch_bounds__(64 * NW) void cheby_pair_kernel(const hpgmg_hip_lev
     if (row_x1) {
       if (above_in) {
         const int bn = box_of(bi_, bj_, p + 1), offn = row_off + plane_off(p + 1);
-        x0p = pld(pair_vec(L, A, A.x0, bn) + shift_of(sh, A.x0) + offn);
+        x0p = x0_pair(bn, li, lj, p + 1);
         if (have_next) {
           if (kVC) bj_n = CoefStream<C32>(L, A, bn, VECTOR_BETA_J, C32_BETA_J, sh).pair(offn);
-          if (far_lo || far_hi) far_n = pld(pair_vec(L, A, A.x0, box_of(bi_, bjf, p + 1)) + shift_of(sh, A.x0) + li + ljf * jS + plane_off(p + 1));
+          if (far_lo || far_hi) far_n = x0_pair(box_of(bi_, bjf, p + 1), li, ljf, p + 1);
         }
       }
       qc.rhs = pld(vec_origin(L, box, A.rhs_id) + sh.lvl + off);
@@ -208,8 +226,8 @@ __global__ __launch_bounds__(64 * NW) void cheby_pair_kernel(const hpgmg_hip_lev
       const p2 km = in_dom(p - 1) ? x0m : pneg(x0c);
       const p2 kp = above_in ? x0p : pneg(x0c);
       double left = __shfl_up(x0c.y, 1, 64), right = __shfl_down(x0c.x, 1, 64);
-      if (lane == 0)  left  = left_dom  ? -x0c.x : pair_vec(L, A, A.x0, box_of(biL, bj_, p))[liL + lj * jS + plane_off(p)];
-      if (lane == 63) right = right_dom ? -x0c.y : pair_vec(L, A, A.x0, box_of(biR, bj_, p))[liR + lj * jS + plane_off(p)];
+      if (lane == 0)  left  = left_dom  ? -x0c.x : x0_one(box_of(biL, bj_, p), liL, lj, p);
+      if (lane == 63) right = right_dom ? -x0c.y : x0_one(box_of(biR, bj_, p), liR, lj, p);
       // GSRB: cell (gi, gj, gk) is swept in half sweep s when (gi ^ gj ^ gk ^ s) is even; a pair starts at an even gi
       x1c = pair_update<V, SM>(x0c, left, right, jm, jp, km, kp, xm1, qc, A.a, A.b, A.h2inv, A.c1a, A.c2a, ((gj ^ p ^ A.sweep_a) & 1) == 0);
     }
@@ -261,7 +279,7 @@ __global__ __launch_bounds__(64 * NW) void cheby_pair_kernel(const hpgmg_hip_lev
 
 // x1 on the cell columns next to interior 128-cell tile edges (gi = 128 t - 1 and 128 t), which the pair kernel
 // reads as i neighbours of the second sweep.  One lane per cell of those columns (0.8 % of the level), lanes along j.
-template <int V, bool C32, int SM>
+template <int V, bool C32, int SM, bool INTERP>
 __global__ __launch_bounds__(256) void cheby_pair_edge_kernel(const hpgmg_hip_level L, const PairArgs A) {
   constexpr bool kVC = (V != HPGMG_HIP_7PT_CC);
   constexpr bool kHelm = (V == HPGMG_HIP_7PT_VC_HELMHOLTZ);
@@ -277,10 +295,12 @@ __global__ __launch_bounds__(256) void cheby_pair_edge_kernel(const hpgmg_hip_le
   auto x0_at = [&](int ci, int cj, int ck, double centre) -> double {
     if (ci < 0 || cj < 0 || ck < 0 || ci >= A.Di || cj >= A.Dj || ck >= A.Dk) return -centre;
     int box; const int idx = cell(ci, cj, ck, box);
-    return pair_vec(L, A, A.x0, box)[idx];
+    double v = pair_vec(L, A, A.x0, box)[idx];
+    if (INTERP) v = A.prescale * v + vec_origin(A.Lc, box, A.coarse_id)[((ci % bd) >> 1) + ((cj % bd) >> 1) * A.Lc.jStride + ((ck % bd) >> 1) * A.Lc.kStride];
+    return v;
   };
   int box; const int idx = cell(gi, gj, gk, box);
-  const double xc = pair_vec(L, A, A.x0, box)[idx];
+  const double xc = x0_at(gi, gj, gk, 0.0);
   double bi0 = 0, bi1 = 0, bj0 = 0, bj1 = 0, bk0 = 0, bk1 = 0, al = 0;
   if (kVC) {
     const CoefStream<C32> bi(L, A, box, VECTOR_BETA_I, C32_BETA_I), bj(L, A, box, VECTOR_BETA_J, C32_BETA_J), bk(L, A, box, VECTOR_BETA_K, C32_BETA_K);

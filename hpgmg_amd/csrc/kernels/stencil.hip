@@ -756,6 +756,10 @@ int hpgmg_hip_coef32_refresh(const hpgmg_hip_level *L, float *const *c32_base, i
   HPGMG_LAUNCH_CHECK("coef32_convert_kernel");
   return 0;
 }
+// interpolation_vcycle folded into the NEXT sweep-pair launch (consumed by it): x0 := prescale * x0 + parent(coarse_id of Lc)
+static const hpgmg_hip_level *g_pair_interp_level = nullptr;
+static int g_pair_interp_id = 0;
+static double g_pair_interp_prescale = 1.0;
 static int smooth_pair(const hpgmg_hip_level *L, int variant, int gsrb, int sweep_a, double *const *scr_base, const float *const *c32_base,
                        int x0_scr, int x0_id, int xm1_scr, int xm1_id, int out1_scr, int out1_id, int out2_scr, int out2_id,
                        int rhs_id, double a, double b, double h2inv, double c1a, double c2a, double c1b, double c2b) {
@@ -778,6 +782,13 @@ static int smooth_pair(const hpgmg_hip_level *L, int variant, int gsrb, int swee
   A.x0 = VecRef{x0_scr, x0_id}; A.xm1 = VecRef{xm1_scr, xm1_id}; A.out1 = VecRef{out1_scr, out1_id}; A.out2 = VecRef{out2_scr, out2_id};
   A.rhs_id = rhs_id; A.a = a; A.b = b; A.h2inv = h2inv; A.c1a = c1a; A.c2a = c2a; A.c1b = c1b; A.c2b = c2b;
   A.scr_base = scr_base; A.c32_base = c32_base; A.sweep_a = sweep_a;
+  const bool interp = (g_pair_interp_level != nullptr);
+  if (interp) {
+    const hpgmg_hip_level *C = g_pair_interp_level;
+    g_pair_interp_level = nullptr;
+    if (L->dim % 128 != 0 || C->num_boxes != L->num_boxes || 2 * C->dim != L->dim) return record_error(hipErrorInvalidValue, "smooth pair with interpolation: level pair not supported");
+    A.Lc = *C; A.coarse_id = g_pair_interp_id; A.prescale = g_pair_interp_prescale;
+  }
   A.nbi = L->dim_i / L->dim; A.nbj = L->dim_j / L->dim;
   A.Di = L->dim_i; A.Dj = L->dim_j; A.Dk = L->dim_k;
   A.tiles_i = A.Di / 128; A.slabs_j = (A.Dj + (nw - 2) - 1) / (nw - 2); A.KC = kc; A.chunks_k = (A.Dk + kc - 1) / kc;
@@ -786,12 +797,18 @@ static int smooth_pair(const hpgmg_hip_level *L, int variant, int gsrb, int swee
   const long long cells = (long long)A.Di * A.Dj * A.Dk;
   const size_t lds = (size_t)nw * 6 * 64 * sizeof(p2);
   const int prof = profile_begin(cells);
-#define PAIR_LAUNCH2(VAR, C32, SM, NARROW) { \
-      static bool once = false; if (!once) { HPGMG_CHECK(hipFuncSetAttribute((const void *)cheby_pair_kernel<VAR, nw, C32, SM, NARROW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once = true; } \
-      hipLaunchKernelGGL((cheby_pair_kernel<VAR, nw, C32, SM, NARROW>), dim3(grid), dim3(64, nw), lds, g_stream, *L, A); }
+#define PAIR_LAUNCH2(VAR, C32, SM, NARROW, INTERP) { \
+      static bool once = false; if (!once) { HPGMG_CHECK(hipFuncSetAttribute((const void *)cheby_pair_kernel<VAR, nw, C32, SM, NARROW, INTERP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once = true; } \
+      hipLaunchKernelGGL((cheby_pair_kernel<VAR, nw, C32, SM, NARROW, INTERP>), dim3(grid), dim3(64, nw), lds, g_stream, *L, A); }
 #define PAIR_LAUNCH(VAR, C32, SM) { \
-      if (A.tiles_i > 1) hipLaunchKernelGGL((cheby_pair_edge_kernel<VAR, C32, SM>), dim3((A.Dj + 63) / 64, A.Dk, 2 * (A.tiles_i - 1)), dim3(64), 0, g_stream, *L, A); \
-      if (L->dim % 128 == 0) PAIR_LAUNCH2(VAR, C32, SM, false) else PAIR_LAUNCH2(VAR, C32, SM, true) }
+      const dim3 egrid((A.Dj + 63) / 64, A.Dk, 2 * (A.tiles_i - 1)); \
+      if (interp) { \
+        if (A.tiles_i > 1) hipLaunchKernelGGL((cheby_pair_edge_kernel<VAR, C32, SM, true>), egrid, dim3(64), 0, g_stream, *L, A); \
+        PAIR_LAUNCH2(VAR, C32, SM, false, true) \
+      } else { \
+        if (A.tiles_i > 1) hipLaunchKernelGGL((cheby_pair_edge_kernel<VAR, C32, SM, false>), egrid, dim3(64), 0, g_stream, *L, A); \
+        if (L->dim % 128 == 0) PAIR_LAUNCH2(VAR, C32, SM, false, false) else PAIR_LAUNCH2(VAR, C32, SM, true, false) \
+      } }
 #define PAIR_CASE(VAR) case VAR: \
     if (gsrb) { if (c32_base) PAIR_LAUNCH(VAR, true, PAIR_GSRB) else PAIR_LAUNCH(VAR, false, PAIR_GSRB) } \
     else      { if (c32_base) PAIR_LAUNCH(VAR, true, PAIR_CHEBY) else PAIR_LAUNCH(VAR, false, PAIR_CHEBY) } break;
@@ -812,6 +829,9 @@ int hpgmg_hip_smooth_cheby_pair(const hpgmg_hip_level *L, int variant, double *c
                                 int x0_scr, int x0_id, int xm1_scr, int xm1_id, int out1_scr, int out1_id, int out2_scr, int out2_id,
                                 int rhs_id, double a, double b, double h2inv, double c1a, double c2a, double c1b, double c2b) {
   return smooth_pair(L, variant, 0, 0, scr_base, c32_base, x0_scr, x0_id, xm1_scr, xm1_id, out1_scr, out1_id, out2_scr, out2_id, rhs_id, a, b, h2inv, c1a, c2a, c1b, c2b);
+}
+void hpgmg_hip_pair_fold_interpolation(const hpgmg_hip_level *Lc, int coarse_id, double prescale) {
+  g_pair_interp_level = Lc; g_pair_interp_id = coarse_id; g_pair_interp_prescale = prescale;
 }
 // two consecutive in-place GSRB half sweeps (sweep, sweep + 1): x2 -> out2; the scratch vector `edge_scr_id` receives the
 // few x1 values the kernel exchanges across 128-cell tile edges

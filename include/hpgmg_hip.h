@@ -113,6 +113,11 @@ int hpgmg_hip_smooth_cheby_pair(const hpgmg_hip_level *L, int variant, double *c
 int hpgmg_hip_smooth_gsrb_pair(const hpgmg_hip_level *L, int variant, double *const *scr_base, const float *const *c32_base,
                                int x0_scr, int x0_id, int edge_scr_id, int out2_scr, int out2_id, int rhs_id,
                                double a, double b, double h2inv, int sweep);
+/* Fold interpolation_vcycle (interpolation_p0.c:43, f = prescale*f + parent) into the NEXT hpgmg_hip_smooth_cheby_pair /
+ * _gsrb_pair launch: that launch reads its x0 as prescale*x0 + coarse parent (vector coarse_id of Lc, same box numbering,
+ * boxes half the size) instead of x0 as stored, which is never materialised.  Consumed by that one launch.
+ * Lc must stay valid until the launch has been issued. */
+void hpgmg_hip_pair_fold_interpolation(const hpgmg_hip_level *Lc, int coarse_id, double prescale);
 /* Mixed-precision smoother (BASELINE config 5): c32_base[box] = 5 x volume floats holding fp32 copies of Dinv, alpha,
  * beta_i, beta_j, beta_k (whole padded vectors, same indexing).  hpgmg_hip_coef32_refresh fills them from the level's
  * vectors; passing them to hpgmg_hip_smooth_cheby_pair makes the sweep pair read 4-byte coefficients (iterate, right-hand

@@ -118,6 +118,9 @@ void    hpgmg_segment_end(void);
  * executed it (bit-identical to the per-operator sequence), 0 when it cannot -- the driver then
  * issues the operators one by one. */
 int     hpgmg_vcycle_legs_fused(level_type **levels, int n, int e_id, int R_id, double a, double b, int leg);
+/* Optional fused form of  interpolation_vcycle(fine, e, 1.0, coarse, e); smooth(fine, e, R)  (mg.c:1160-1161): returns 1 when the
+ * plugin executed both (same result and final state), 0 when the driver must call the two operators. */
+int     hpgmg_interp_smooth_fused(level_type *fine, int e_id, int R_id, level_type *coarse, double a, double b);
 /* bring level->Krylov_iterations up to date with bottom solves the plugin ran asynchronously */
 void    hpgmg_level_sync_counters(level_type *level);
 /* called by destroy_level / MGDestroy so the plugin can drop device mirrors */

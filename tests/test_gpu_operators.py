@@ -159,6 +159,43 @@ def test_restriction_and_interpolation(hip, oracle, geom):
             be.lib.hpgmg_mg_destroy(m); f.destroy()
 
 
+@pytest.mark.parametrize("variant,geom", [("7pt-cheby-helm", (2, 128)), ("7pt-gsrb", (2, 128)), ("7ptcc-cheby", (1, 256))])
+def test_interpolation_folded_into_the_first_sweep_pair(hip, oracle, variant, geom):
+    """hpgmg_interp_smooth_fused (the up-leg of MGVCycle on the fine level): interpolation_vcycle + smooth() as sweep pairs whose
+    first pass reads e + P(coarse e) without ever storing it.  Must equal the oracle's two separate operators bit for bit."""
+    pairs = []
+    for be in (hip, oracle):
+        be.configure(**VARIANTS[variant])
+        fine = be.level(*geom)
+        for vid in range(fine.num_vectors):
+            d = seeded_field(fine, 700 + vid)
+            if vid >= H.VECTOR_DINV:
+                d = np.abs(d) + 0.5
+            fine.write_all(vid, d)
+        for vid in range(H.VECTOR_DINV, fine.num_vectors):
+            be.lib.exchange_boundary(fine.ptr, vid, H.STENCIL_SHAPE_BOX)
+        a, b = (1.0, 1.0) if "helm" in variant else (0.0, 1.0)
+        mg = be.lib.hpgmg_mg_create(fine.ptr, a, b, 1)
+        be.lib.rebuild_operator(fine.ptr, None, a, b)
+        pairs.append((be, fine, mg, a, b))
+    try:
+        from hpgmg_testlib import Level
+        (bh, fh, mh, a, b), (bo, fo, mo, _, _) = pairs
+        hip.lib.hpgmg_interp_smooth_fused.restype = ctypes.c_int
+        hip.lib.hpgmg_interp_smooth_fused.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_double, ctypes.c_double]
+        ch, co = Level(bh, bh.lib.hpgmg_mg_level(mh, 1)), Level(bo, bo.lib.hpgmg_mg_level(mo, 1))
+        coarse_e = seeded_field(ch, 777)
+        ch.write_all(H.VECTOR_U, coarse_e); co.write_all(H.VECTOR_U, coarse_e)
+        assert hip.lib.hpgmg_interp_smooth_fused(fh.ptr, H.VECTOR_U, H.VECTOR_F, ch.ptr, a, b) == 1
+        bo.lib.interpolation_vcycle(fo.ptr, H.VECTOR_U, 1.0, co.ptr, H.VECTOR_U)
+        bo.lib.smooth(fo.ptr, H.VECTOR_U, H.VECTOR_F, a, b)
+        vids = [H.VECTOR_U] if "gsrb" in variant else [H.VECTOR_U, H.VECTOR_TEMP]
+        same(fh, fo, vids, interior_only=True)
+    finally:
+        for be, f, m, _, _ in pairs:
+            be.lib.hpgmg_mg_destroy(m); f.destroy()
+
+
 @pytest.mark.parametrize("geom", [(2, 8), (1, 4), (3, 4), (1, 1), (2, 32)])
 def test_blas1_and_reductions(hip, oracle, geom):
     lh, lo = make_pair(hip, oracle, "7pt-cheby-helm", *geom, seed=4)
