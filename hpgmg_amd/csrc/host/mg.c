@@ -444,8 +444,10 @@ void MGVCycle(mg_type *G, int e_id, int R_id, double a, double b, int l) {
   t = now();
   smooth(L, e_id, R_id, a, b);
   residual(L, VECTOR_TEMP, e_id, R_id, a, b);
-  restriction(G->levels[l + 1], R_id, L, VECTOR_TEMP, RESTRICT_CELL);
-  zero_vector(G->levels[l + 1], e_id);
+  if (!hpgmg_restrict_zero_fused(G->levels[l + 1], R_id, L, VECTOR_TEMP, e_id)) {
+    restriction(G->levels[l + 1], R_id, L, VECTOR_TEMP, RESTRICT_CELL);
+    zero_vector(G->levels[l + 1], e_id);
+  }
   L->timers.Total += now() - t;
 
   if (!is_small(G, l) && is_small(G, l + 1)) seg_open();   /* everything below this point is launch bound */

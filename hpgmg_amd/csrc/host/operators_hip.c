@@ -674,6 +674,19 @@ void restriction(level_type *Lc, int id_c, level_type *Lf, int id_f, int type) {
   Lf->timers.restriction_total += now() - t0;
 }
 
+/* restriction(Lc, id_c, Lf, id_f, RESTRICT_CELL) followed by zero_vector(Lc, zero_id) -- the end of MGVCycle's down-leg
+ * (mg.c:1152-1153) -- as one launch when every contribution is local.  0 = the driver calls the two operators. */
+int hpgmg_restrict_zero_fused(level_type *Lc, int id_c, level_type *Lf, int id_f, int zero_id) {
+  communicator_type *S = &Lf->restriction[RESTRICT_CELL], *R = &Lc->restriction[RESTRICT_CELL];
+  if (!Lf->active || !Lc->active || Lc->num_my_boxes < 1 || zero_id == id_c) return 0;
+  if (S->num_sends || R->num_recvs || S->num_blocks[0] || R->num_blocks[2] || S->num_blocks[1] < 1) return 0;
+  const double t0 = now();
+  backend_t *Bc = backend_of(Lc), *Bf = backend_of(Lf);
+  HIP_OK(hpgmg_hip_restrict_cell_and_zero(&Bc->dev, id_c, &Bf->dev, id_f, mirror(Lf, S->blocks[1], S->num_blocks[1]), S->num_blocks[1], zero_id));
+  Lf->timers.restriction_total += now() - t0;
+  return 1;
+}
+
 /* ---------------------------------------------------------------- interpolation_p0.c:52-159, interpolation_p1.c:70-180 */
 static void interpolation_lists(level_type *Lf, int id_f, double prescale, level_type *Lc, int id_c, int order, int tagbits) {
   const double t0 = now();

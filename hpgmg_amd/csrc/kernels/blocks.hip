@@ -325,10 +325,10 @@ __global__ __launch_bounds__(256) void interp_tensor_kernel(const hpgmg_hip_leve
   }
 }
 
+// restriction.c:49-91 for one list entry (one workgroup)
 template <int TYPE>
-__global__ __launch_bounds__(256) void restrict_blocks_kernel(const hpgmg_hip_level Lc, int id_c, const hpgmg_hip_level Lf, int id_f,
-                                                              const blockCopy_type *__restrict__ list) {
-  const blockCopy_type &e = list[blockIdx.x];
+__device__ __forceinline__ void restrict_entry(const hpgmg_hip_level &Lc, int id_c, const hpgmg_hip_level &Lf, int id_f, const blockCopy_type &e) {
+
   const Side r = resolve_read(Lf, id_f, e), w = resolve_write(Lc, id_c, e);
   const int di = e.dim.i, dj = e.dim.j, n = di * dj * e.dim.k, rj = r.jS, rk = r.kS;
   for (int t = threadIdx.x; t < n; t += blockDim.x) {
@@ -347,6 +347,23 @@ __global__ __launch_bounds__(256) void restrict_blocks_kernel(const hpgmg_hip_le
     }
     w.p[i + j * w.jS + k * w.kS] = v;
   }
+}
+template <int TYPE>
+__global__ __launch_bounds__(256) void restrict_blocks_kernel(const hpgmg_hip_level Lc, int id_c, const hpgmg_hip_level Lf, int id_f,
+                                                              const blockCopy_type *__restrict__ list) {
+  restrict_entry<TYPE>(Lc, id_c, Lf, id_f, list[blockIdx.x]);
+}
+// restriction of a list + zero_vector(coarse, zero_id) in one launch (the down-leg of MGVCycle does both, mg.c:1152-1153):
+// workgroups [0, n) take the list entries, the rest clear the coarse vector -- whole padded boxes, ghosts included
+// (misc.c:6-44; the alignment padding between rows is never read and already zero, so each box is one contiguous run)
+__global__ __launch_bounds__(256) void restrict_cell_zero_kernel(const hpgmg_hip_level Lc, int id_c, const hpgmg_hip_level Lf, int id_f,
+                                                                 const blockCopy_type *__restrict__ list, int n, int zero_id, int chunks_per_box) {
+  if ((int)blockIdx.x < n) { restrict_entry<RESTRICT_CELL>(Lc, id_c, Lf, id_f, list[blockIdx.x]); return; }
+  const int z = (int)blockIdx.x - n, box = z / chunks_per_box, chunk = z - box * chunks_per_box;
+  if (box >= Lc.num_boxes) return;
+  double *v = Lc.box_base[box] + (size_t)zero_id * (size_t)Lc.volume;
+  const int lo = chunk * 4096, hi = (lo + 4096 < Lc.volume) ? lo + 4096 : Lc.volume;
+  for (int t = lo + (int)threadIdx.x; t < hi; t += 256) v[t] = 0.0;
 }
 
 // interpolation_p0.c:43 (ORDER 0, piecewise constant) and interpolation_p1.c:40-70 (ORDER 1, trilinear).
@@ -474,6 +491,15 @@ int hpgmg_hip_restrict_blocks(const hpgmg_hip_level *Lc, int id_c, const hpgmg_h
     default: return record_error(hipErrorInvalidValue, "restriction type");
   }
   HPGMG_LAUNCH_CHECK("restrict_blocks_kernel");
+  return 0;
+}
+int hpgmg_hip_restrict_cell_and_zero(const hpgmg_hip_level *Lc, int id_c, const hpgmg_hip_level *Lf, int id_f,
+                                     const blockCopy_type *blocks, int n, int zero_id) {
+  HPGMG_SKIP_IF_REPLAY();
+  if (n <= 0 || Lc->num_boxes <= 0) return record_error(hipErrorInvalidValue, "restrict_cell_and_zero: empty list or level");
+  const int chunks = (Lc->volume + 4095) / 4096;
+  hipLaunchKernelGGL(restrict_cell_zero_kernel, dim3(n + chunks * Lc->num_boxes), dim3(256), 0, g_stream, *Lc, id_c, *Lf, id_f, blocks, n, zero_id, chunks);
+  HPGMG_LAUNCH_CHECK("restrict_cell_zero_kernel");
   return 0;
 }
 int hpgmg_hip_interpolate_blocks(const hpgmg_hip_level *Lf, int id_f, double prescale, const hpgmg_hip_level *Lc, int id_c,

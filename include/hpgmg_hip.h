@@ -140,6 +140,9 @@ int hpgmg_hip_extrapolate_betas(const hpgmg_hip_level *L, const blockCopy_type *
 /* operators/restriction.c:6-94 restriction_pc_block over a list; type = RESTRICT_* */
 int hpgmg_hip_restrict_blocks(const hpgmg_hip_level *Lc, int id_c, const hpgmg_hip_level *Lf, int id_f,
                               const blockCopy_type *blocks, int num_blocks, int type);
+/* restriction (cell) of a LOCAL list and zero_vector(coarse, zero_id) -- misc.c:6-44, whole padded boxes -- in one launch */
+int hpgmg_hip_restrict_cell_and_zero(const hpgmg_hip_level *Lc, int id_c, const hpgmg_hip_level *Lf, int id_f,
+                                     const blockCopy_type *blocks, int num_blocks, int zero_id);
 /* operators/interpolation_p0.c:6-46 (order 0), interpolation_p1.c:8-65 (order 1), and the tensor-product
  * interpolation_p2.c (order 2), interpolation_v2.c (order 3), interpolation_v4.c (order 4) over a list */
 int hpgmg_hip_interpolate_blocks(const hpgmg_hip_level *Lf, int id_f, double prescale, const hpgmg_hip_level *Lc, int id_c,

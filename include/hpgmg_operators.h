@@ -121,6 +121,8 @@ int     hpgmg_vcycle_legs_fused(level_type **levels, int n, int e_id, int R_id, 
 /* Optional fused form of  interpolation_vcycle(fine, e, 1.0, coarse, e); smooth(fine, e, R)  (mg.c:1160-1161): returns 1 when the
  * plugin executed both (same result and final state), 0 when the driver must call the two operators. */
 int     hpgmg_interp_smooth_fused(level_type *fine, int e_id, int R_id, level_type *coarse, double a, double b);
+/* Optional fused form of  restriction(coarse, id_c, fine, id_f, RESTRICT_CELL); zero_vector(coarse, zero_id)  (mg.c:1152-1153) */
+int     hpgmg_restrict_zero_fused(level_type *coarse, int id_c, level_type *fine, int id_f, int zero_id);
 /* bring level->Krylov_iterations up to date with bottom solves the plugin ran asynchronously */
 void    hpgmg_level_sync_counters(level_type *level);
 /* called by destroy_level / MGDestroy so the plugin can drop device mirrors */

@@ -50,6 +50,7 @@ void hpgmg_vector_upload(double *d, const double *s, size_t n) { memcpy(d, s, n 
 void hpgmg_vector_download(double *d, const double *s, size_t n) { memcpy(d, s, n * sizeof(double)); }
 void hpgmg_level_release(level_type *level) { (void)level; }
 void hpgmg_level_sync_counters(level_type *level) { (void)level; }
+int hpgmg_restrict_zero_fused(level_type *c, int ic, level_type *f, int i_f, int z) { (void)c; (void)ic; (void)f; (void)i_f; (void)z; return 0; }
 int hpgmg_interp_smooth_fused(level_type *f, int e, int R, level_type *c, double a, double b) { (void)f; (void)e; (void)R; (void)c; (void)a; (void)b; return 0; }
 void hpgmg_set_graphs(int on) { (void)on; }
 void hpgmg_set_smoother_precision(int bits) { (void)bits; }   /* the oracle is fp64 only */
