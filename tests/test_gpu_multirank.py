@@ -4,6 +4,8 @@ and moves them with gloo (RCCL refuses two ranks on one device); everything else
 ghost-free stencils reading remote faces from the ghost zone, active-rank sets on coarse levels, host-driven
 BiCGStab with all-reduced dot products -- is the code the RCCL transport drives on a multi-GPU node.
 Results must equal the single-rank reference golden numbers."""
+import os
+
 import pytest
 
 from hpgmg_testlib import load_golden
@@ -35,7 +37,7 @@ def test_hip_multirank_matches_single_rank_reference(world, variant, log2, per_r
     total = int(gold_key.split()[-1])
     assert sum(r["levels"][0]["my_boxes"] for r in res) == total
     assert all(r["stats"]["messages"] > 50 for r in res)
-    if variant.startswith("7pt"):     # the 7-point path overlaps its halo exchanges with the stencil launches
+    if variant.startswith("7pt") and os.environ.get("HPGMG_OVERLAP", "1") != "0":     # the 7-point path overlaps its halo exchanges with the stencil launches
         assert all(r["stats"]["overlapped_exchanges"] > 20 for r in res), [r["stats"] for r in res]
 
 
