@@ -94,6 +94,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=["config1", "config2", "config3-fv4", "config3-27pt", "config4", "config5"], default="config2",
+                    help="BASELINE.json configs; default config2 = the one the metric is quoted on.  config3 (`7 64`) and config4 (`8 8`) are the 8-GPU "
+                         "configurations: with --gpus 1 they run their single-rank reading (512^3 on one GPU).  config5 = config2 with --precision fp32")
     ap.add_argument("--force-transport", action="store_true", help="initialise torch.distributed + the RCCL transport even with one rank (smoke test of the N>1 bootstrap)")
     ap.add_argument("--precision", choices=["fp64", "fp32"], default="fp64",
                     help="fp32 = BASELINE.json config 5: mixed-precision Chebyshev smoother (fp32 coefficient streams), tolerance-gated; default fp64 = config 2, bit-exact")
@@ -130,12 +133,22 @@ def main():
         assert lib.hpgmg_transport_init_rccl(bytes(ident.cpu().tolist()), rank, world) == 0
         ctypes.CDLL(None).fflush(None)      # RCCL prints a version banner through C stdio: get it out now, not after the JSON line
 
+    if args.workload == "config5":
+        args.precision = "fp32"
     mixed = args.precision == "fp32"
+    # (operator, smoother, helmholtz, variable coefficients, log2 box dim, boxes per rank, description)
+    table = {"config1": (H.OP_7PT, H.SMOOTH_CHEBY, 0, 0, 5, 8, "7-pt constant-coefficient Poisson, Chebyshev"),
+             "config2": (H.OP_7PT, H.SMOOTH_CHEBY, 1, 1, 7, 8, "7-pt variable-coefficient Helmholtz, Chebyshev"),
+             "config3-fv4": (H.OP_FV4, H.SMOOTH_GSRB, 0, 1, 7, 64, "4th-order fv4 variable-coefficient Poisson, GSRB"),
+             "config3-27pt": (H.OP_27PT, H.SMOOTH_GSRB, 0, 0, 7, 64, "27-pt constant-coefficient Poisson, GSRB"),
+             "config4": (H.OP_7PT, H.SMOOTH_CHEBY, 1, 1, 8, 8, "7-pt variable-coefficient Helmholtz, Chebyshev"),
+             "config5": (H.OP_7PT, H.SMOOTH_CHEBY, 1, 1, 7, 8, "7-pt variable-coefficient Helmholtz, Chebyshev")}
+    w_op, w_sm, w_helm, w_vc, w_log2, w_boxes, w_text = table[args.workload]
     lib.hpgmg_set_smoother_precision.argtypes = [ctypes.c_int]
     lib.hpgmg_set_smoother_precision(32 if mixed else 64)
-    cfg = H.Config(H.OP_7PT, H.SMOOTH_CHEBY, 1, 1)
+    cfg = H.Config(w_op, w_sm, w_helm, w_vc)
     assert lib.hpgmg_configure(ctypes.byref(cfg)) == 0
-    solver = lib.hpgmg_solver_create(LOG2_BOX_DIM, BOXES_PER_RANK, H.BC_DIRICHLET, rank, world)
+    solver = lib.hpgmg_solver_create(w_log2, w_boxes, H.BC_DIRICHLET, rank, world)
     assert solver, "no acceptable problem size"
     info = (ctypes.c_int * H.INFO_COUNT)()
     lib.hpgmg_level_info(lib.hpgmg_solver_level(solver, 0), info)
@@ -178,7 +191,7 @@ def main():
     if rank == 0:
         sec_per_step = elapsed / args.steps
         roof = None
-        if launches.value > 0 and ms.value > 0:
+        if launches.value > 0 and ms.value > 0 and args.workload in ("config2", "config4", "config5"):
             avg_s = ms.value * 1e-3 / launches.value
             # mixed precision: Dinv, alpha, beta_i/j/k are 4-byte streams -> 72 - 5*4 = 52 B per cell per sweep
             bytes_per_launch = (52 if mixed else BYTES_PER_CELL_CHEBY_HELMHOLTZ) * (cells.value / launches.value)
@@ -194,12 +207,13 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": sec_per_step * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64 arithmetic and iterate, f32 coefficient streams in the smoother" if mixed else "f64", "data": "synthetic",
-            "config": {"workload": f"hpgmg-fv {LOG2_BOX_DIM} {BOXES_PER_RANK}: {dim}^3 fp64 7-pt variable-coefficient Helmholtz, "
-                                   f"Chebyshev smoother{' (mixed precision, BASELINE config 5)' if mixed else ''}, {BOXES_PER_RANK} boxes of {box_dim}^3 per GPU, BiCGStab bottom, Dirichlet",
+            "config": {"workload": f"hpgmg-fv {w_log2} {w_boxes}: {dim}^3 fp64 {w_text} smoother"
+                                   f"{' (mixed precision, BASELINE config 5)' if mixed else ''}, {w_boxes} boxes of {box_dim}^3 per GPU, BiCGStab bottom, Dirichlet",
+                       "baseline_config": args.workload,
                        "fine_grid_dof": dof, "fcycle_residual_norm": norm, "parallelism": f"boxes over {world} GPU(s), RCCL halo exchange"},
             "roofline": roof,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload in ("config2", "config5"):
             line["cpu_baseline"] = cpu_baseline()
         ctypes.CDLL(None).fflush(None)      # anything C code buffered on stdout goes first: the JSON line is the last line
         print(json.dumps(line), flush=True)
