@@ -100,14 +100,40 @@ def main():
     ap.add_argument("--force-transport", action="store_true", help="initialise torch.distributed + the RCCL transport even with one rank (smoke test of the N>1 bootstrap)")
     ap.add_argument("--precision", choices=["fp64", "fp32"], default="fp64",
                     help="fp32 = BASELINE.json config 5: mixed-precision Chebyshev smoother (fp32 coefficient streams), tolerance-gated; default fp64 = config 2, bit-exact")
+    ap.add_argument("--series", choices=["strong", "weak"], default="strong",
+                    help="what N > 1 runs (config2): strong = the north_star series, the SAME 256^3 problem cut over N GPUs (`hpgmg-fv 7 8/N`: 8/4/2/1 boxes of "
+                         "128^3 per GPU); weak = the reference CLI's own `7 8` with N ranks (256^3, 256^3, 384^3, 512^3 for N = 1, 2, 4, 8; hpgmg-fv.c:184-197)")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` outside torchrun: start the N ranks ourselves, as a CHILD process (this parent has not touched the
+    # GPU and never does), relay the child's JSON line and exit with its code.  Never measure one GPU and call it N.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+                   OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", str(max(1, host_cores() // args.gpus))))
+        child = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+        lines = [l for l in child.stdout.splitlines() if l.strip()]
+        result = next((l for l in reversed(lines) if l.startswith("{") and '"metric"' in l), None)
+        for l in lines:
+            if l is not result:
+                print(l, file=sys.stderr)
+        if result is not None:
+            print(result, flush=True)
+        raise SystemExit(child.returncode if child.returncode or result is not None else 1)
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a {world}-rank run as {args.gpus} GPUs")
+    if world > 1 and torch.cuda.device_count() < world:
+        raise SystemExit(f"--gpus {world} but only {torch.cuda.device_count()} device(s) visible")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP operator path has no CPU fallback")
     torch.cuda.set_device(local_rank)

@@ -22,6 +22,35 @@ static int host_threads(void) {
   return 1;
 }
 
+/* CPU threads this process may really use: a container reports every core of the machine (256 on the GPU boxes) but is
+ * scheduled on a cgroup quota (16 there); an OpenMP team of 256 spinning threads on 16 CPUs makes every parallel
+ * region crawl.  Unless the user set OMP_NUM_THREADS, cap the team at min(quota, affinity mask) when the library loads. */
+int hpgmg_usable_cpus(void) {
+  long n = -1;
+#ifdef _OPENMP
+  n = omp_get_num_procs();
+#endif
+  if (n < 1) n = 1;
+  FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r");
+  if (f) {
+    char quota[32]; long period = 0;
+    if (fscanf(f, "%31s %ld", quota, &period) == 2 && strcmp(quota, "max") != 0 && period > 0) {
+      long q = atol(quota) / period;
+      if (q < 1) q = 1;
+      if (q < n) n = q;
+    }
+    fclose(f);
+  }
+  return (int)n;
+}
+#ifdef _OPENMP
+__attribute__((constructor)) static void cap_openmp_team(void) {
+  if (getenv("OMP_NUM_THREADS")) return;
+  int n = hpgmg_usable_cpus();
+  if (n < omp_get_max_threads()) omp_set_num_threads(n);
+}
+#endif
+
 extern int hpgmg_box_align_jstride, hpgmg_box_align_kstride, hpgmg_box_align_volume, hpgmg_box_align_base_bytes;
 
 static double now(void) {

@@ -1,7 +1,31 @@
 import os
 import sys
 
-import pytest
+
+def _usable_cpus():
+    """CPU threads this container may really use: the cgroup quota / affinity mask, not the 256 cores a GPU box reports."""
+    n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except Exception:
+        pass
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    return n
+
+
+# Before ANY OpenMP runtime is loaded (numpy, torch, the oracle, the host layer): a team sized to the quota and no
+# spin-waiting.  Round 1's driver run died at its 1200 s limit with 256 spinning libgomp threads on a 16-CPU quota.
+os.environ.setdefault("OMP_NUM_THREADS", str(min(_usable_cpus(), 16)))
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+os.environ.setdefault("OMP_PROC_BIND", "false")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import pytest  # noqa: E402
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
