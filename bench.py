@@ -9,10 +9,13 @@ BASELINE.json config 2: `hpgmg-fv 7 8`, fp64 7-point variable-coefficient Helmho
 Chebyshev smoother, 8 boxes of 128^3 per GPU (256^3 on one GPU).  Inputs (beta, alpha, F) are
 the reference's analytic problem (problem.p6.c), resident in HBM before timing starts.
 
-N > 1: one process per GPU (torch.distributed.run), boxes partitioned over the ranks exactly
-like the reference partitions them over MPI ranks (Z-Morton, `7 8` with N ranks -> the reference
-CLI's weak-scaling series 256^3, 256^3, 384^3, 512^3 for N = 1, 2, 4, 8), ghost zones exchanged
-with RCCL send/recv over xGMI.  value = fine-grid DOF of the whole job / max-over-ranks time.
+N > 1: one process per GPU (started by torch.distributed.run, or by bench.py itself as a child
+process when it is called bare), boxes partitioned over the ranks exactly like the reference
+partitions them over MPI ranks (Z-Morton), ghost zones exchanged with RCCL send/recv over xGMI.
+Default series = north_star's STRONG scaling: the same 256^3 problem on 1, 2, 4, 8 GPUs
+(`hpgmg-fv 7 8/N`, i.e. 8/4/2/1 boxes of 128^3 per GPU; "scaling": "strong").  --series weak =
+the reference CLI's `7 8` with N ranks (256^3, 256^3, 384^3, 512^3).
+value = fine-grid DOF of the whole job / max-over-ranks time.
 
 Extra objects on the JSON line:
   roofline     fine-level Chebyshev smoother: algorithmic bytes (72 B per cell per sweep x the sweeps a launch performs;
@@ -170,11 +173,18 @@ def main():
              "config4": (H.OP_7PT, H.SMOOTH_CHEBY, 1, 1, 8, 8, "7-pt variable-coefficient Helmholtz, Chebyshev"),
              "config5": (H.OP_7PT, H.SMOOTH_CHEBY, 1, 1, 7, 8, "7-pt variable-coefficient Helmholtz, Chebyshev")}
     w_op, w_sm, w_helm, w_vc, w_log2, w_boxes, w_text = table[args.workload]
+    # N > 1.  strong (default): the SAME problem on N GPUs -- north_star's "256^3 at 1, 2, 4 and 8 GPUs" = `hpgmg-fv 7 8/N` (SURVEY 8e:
+    # `7 8`, `7 4`, `7 2`, `7 1`); weak: the reference CLI's reading of `7 8` with N ranks (the domain grows: hpgmg-fv.c:184-197).
+    boxes_per_rank = w_boxes
+    if world > 1 and args.series == "strong":
+        if w_boxes % world:
+            raise SystemExit(f"strong scaling of `{w_log2} {w_boxes}` needs a rank count that divides {w_boxes}, got {world}")
+        boxes_per_rank = w_boxes // world
     lib.hpgmg_set_smoother_precision.argtypes = [ctypes.c_int]
     lib.hpgmg_set_smoother_precision(32 if mixed else 64)
     cfg = H.Config(w_op, w_sm, w_helm, w_vc)
     assert lib.hpgmg_configure(ctypes.byref(cfg)) == 0
-    solver = lib.hpgmg_solver_create(w_log2, w_boxes, H.BC_DIRICHLET, rank, world)
+    solver = lib.hpgmg_solver_create(w_log2, boxes_per_rank, H.BC_DIRICHLET, rank, world)
     assert solver, "no acceptable problem size"
     info = (ctypes.c_int * H.INFO_COUNT)()
     lib.hpgmg_level_info(lib.hpgmg_solver_level(solver, 0), info)
@@ -231,10 +241,12 @@ def main():
         line = {
             "metric": "DOF/s (fine-grid) for FMG F-cycle", "value": dof / sec_per_step, "unit": "DOF/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": sec_per_step * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.series if world > 1 else "strong", "vs_baseline": None,
             "dtype": "f64 arithmetic and iterate, f32 coefficient streams in the smoother" if mixed else "f64", "data": "synthetic",
-            "config": {"workload": f"hpgmg-fv {w_log2} {w_boxes}: {dim}^3 fp64 {w_text} smoother"
-                                   f"{' (mixed precision, BASELINE config 5)' if mixed else ''}, {w_boxes} boxes of {box_dim}^3 per GPU, BiCGStab bottom, Dirichlet",
+            "config": {"workload": f"hpgmg-fv {w_log2} {boxes_per_rank}{f' x {world} ranks' if world > 1 else ''}: {dim}^3 fp64 {w_text} smoother"
+                                   f"{' (mixed precision, BASELINE config 5)' if mixed else ''}, {my_boxes} boxes of {box_dim}^3 per GPU, BiCGStab bottom, Dirichlet",
+                       "series": (f"{args.series} scaling: " + ("same problem on every N (north_star series)" if args.series == "strong" else "reference CLI `7 8` with N ranks (domain grows with N)")) if world > 1 else "single GPU",
+                       "rccl_ranks": world if dist is not None else 0,
                        "baseline_config": args.workload,
                        "fine_grid_dof": dof, "fcycle_residual_norm": norm, "parallelism": f"boxes over {world} GPU(s), RCCL halo exchange"},
             "roofline": roof,

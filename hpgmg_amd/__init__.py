@@ -68,6 +68,9 @@ def _declare_driver_api(lib):
         "hpgmg_solver_richardson": (None, [vp, P(c_dbl)]),
         "hpgmg_level_info": (None, [vp, P(c_int)]),
         "hpgmg_level_h": (c_dbl, [vp]),
+        "hpgmg_level_timers": (None, [vp, P(c_dbl)]),
+        "hpgmg_set_timer_mode": (None, [c_int]),
+        "hpgmg_get_timer_mode": (c_int, []),
         "hpgmg_level_eigenvalue": (c_dbl, [vp]),
         "hpgmg_level_box_low": (None, [vp, c_int, P(c_int)]),
         "hpgmg_level_list_counts": (c_int, [vp, c_int, c_int, P(c_int)]),

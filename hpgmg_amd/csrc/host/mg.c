@@ -411,56 +411,58 @@ void richardson_error(mg_type *G, int lh, int u_id) {
 
 void MGVCycle(mg_type *G, int e_id, int R_id, double a, double b, int l) {
   level_type *L = G->levels[l];
-  double t;
+  hpgmg_tick t;
   if (!L->active) return;
   if (l == G->num_levels - 1) {
-    t = now();
+    t = hpgmg_tick_begin(L, &L->timers.Total, "bottom solve");
     if (!hpgmg_vcycle_legs_fused(&G->levels[l], 1, e_id, R_id, a, b, 3)) {
       seg_close();                                 /* the host-driven Krylov solver synchronises */
       IterativeSolver(L, e_id, R_id, a, b, MG_DEFAULT_BOTTOM_NORM);
     }
-    L->timers.Total += now() - t;
+    hpgmg_tick_end(t);
     return;
   }
   const int opened_here = is_small(G, l) && !seg_open_now;
   if (is_small(G, l)) seg_open();
   /* tiny levels: the plugin may run the rest of this V-cycle (or each of its legs) as one fused operation */
-  t = now();
-  if (hpgmg_vcycle_legs_fused(&G->levels[l], G->num_levels - l, e_id, R_id, a, b, 2)) {
-    L->timers.Total += now() - t;
+  const int maybe_tail = is_small(G, l);         /* only small levels can be fused: do not pay for a tick around a refusal on the big ones */
+  if (maybe_tail) t = hpgmg_tick_begin(L, &L->timers.Total, "V-cycle tail (fused)");
+  if (maybe_tail && hpgmg_vcycle_legs_fused(&G->levels[l], G->num_levels - l, e_id, R_id, a, b, 2)) {
+    hpgmg_tick_end(t);
     if (opened_here) seg_close();
     return;
   }
-  if (hpgmg_vcycle_legs_fused(&G->levels[l], G->num_levels - l, e_id, R_id, a, b, 0)) {
-    L->timers.Total += now() - t;
+  if (maybe_tail && hpgmg_vcycle_legs_fused(&G->levels[l], G->num_levels - l, e_id, R_id, a, b, 0)) {
+    hpgmg_tick_end(t);
     MGVCycle(G, e_id, R_id, a, b, G->num_levels - 1);          /* bottom solve (closes the segment) */
     seg_open();
-    t = now();
+    t = hpgmg_tick_begin(L, &L->timers.Total, "V-cycle tail, up leg (fused)");
     if (!hpgmg_vcycle_legs_fused(&G->levels[l], G->num_levels - l, e_id, R_id, a, b, 1)) { fprintf(stderr, "fused V-cycle leg refused after being accepted\n"); exit(1); }
-    L->timers.Total += now() - t;
+    hpgmg_tick_end(t);
     if (opened_here) seg_close();
     return;
   }
-  t = now();
+  if (maybe_tail) hpgmg_tick_end(t);          /* nothing was launched: adds (next to) nothing */
+  t = hpgmg_tick_begin(L, &L->timers.Total, "V-cycle down leg");
   smooth(L, e_id, R_id, a, b);
   residual(L, VECTOR_TEMP, e_id, R_id, a, b);
   if (!hpgmg_restrict_zero_fused(G->levels[l + 1], R_id, L, VECTOR_TEMP, e_id)) {
     restriction(G->levels[l + 1], R_id, L, VECTOR_TEMP, RESTRICT_CELL);
     zero_vector(G->levels[l + 1], e_id);
   }
-  L->timers.Total += now() - t;
+  hpgmg_tick_end(t);
 
   if (!is_small(G, l) && is_small(G, l + 1)) seg_open();   /* everything below this point is launch bound */
   MGVCycle(G, e_id, R_id, a, b, l + 1);
   if (is_small(G, l)) seg_open();                           /* re-open after the bottom solve */
   else seg_close();                                         /* back on a bandwidth-bound level */
 
-  t = now();
+  t = hpgmg_tick_begin(L, &L->timers.Total, "V-cycle up leg");
   if (!hpgmg_interp_smooth_fused(L, e_id, R_id, G->levels[l + 1], a, b)) {
     interpolation_vcycle(L, e_id, 1.0, G->levels[l + 1], e_id);
     smooth(L, e_id, R_id, a, b);
   }
-  L->timers.Total += now() - t;
+  hpgmg_tick_end(t);
   if (opened_here) seg_close();
 }
 
@@ -468,14 +470,14 @@ void MGVCycle(mg_type *G, int e_id, int R_id, double a, double b, int l) {
 static int check_residual(mg_type *G, int l, int e_id, int F_id, double a, double b, double norm_of_F,
                           double rtol, const char *label) {
   level_type *L = G->levels[l];
-  double t = now();
+  hpgmg_tick t = hpgmg_tick_begin(L, &L->timers.Total, "residual check");
   if (L->must_subtract_mean == 1) {
     double m = mean(L, e_id);
     shift_vector(L, e_id, e_id, -m);
   }
   residual(L, VECTOR_TEMP, e_id, F_id, a, b);
   double r = norm(L, VECTOR_TEMP);
-  L->timers.Total += now() - t;
+  hpgmg_tick_end(t);
   hpgmg_last_solve.norm_of_F = norm_of_F;
   hpgmg_last_solve.norm_of_residual = r;
   SAY(L->my_rank, "%s  norm=%1.15e  rel=%1.15e  ", label, r, r / norm_of_F);
@@ -515,36 +517,34 @@ void FMGSolve(mg_type *G, int onLevel, int u_id, int F_id, double a, double b, d
   level_type *L = G->levels[onLevel];
   char label[64];
   int l, v;
-  double t;
+  hpgmg_tick t;
   G->MGSolves_performed++;
   if (!L->active) return;
   SAY(L->my_rank, "FMGSolve... ");
   const double t0 = now();
   seg_reset(G, onLevel);
 
-  t = now();
+  t = hpgmg_tick_begin(L, &L->timers.Total, "norm(F), R = F");
   double norm_of_F = norm(L, F_id);
   scale_vector(L, R_id, 1.0, F_id);
-  L->timers.Total += now() - t;
+  hpgmg_tick_end(t);
 
   for (l = onLevel; l < bottom; l++) {           /* carry the right-hand side down */
     if (is_small(G, l)) seg_open();
-    t = now();
+    t = hpgmg_tick_begin(G->levels[l], &G->levels[l]->timers.Total, "restrict R");
     restriction(G->levels[l + 1], R_id, G->levels[l], R_id, RESTRICT_CELL);
-    G->levels[l]->timers.Total += now() - t;
+    hpgmg_tick_end(t);
   }
 
-  t = now();
-  if (bottom > onLevel) zero_vector(G->levels[bottom], e_id);
+  if (bottom > onLevel) { t = hpgmg_tick_begin(G->levels[bottom], &G->levels[bottom]->timers.Total, "zero e (bottom)"); zero_vector(G->levels[bottom], e_id); hpgmg_tick_end(t); }
   if (is_small(G, bottom)) seg_open();
-  MGVCycle(G, e_id, R_id, a, b, bottom);          /* the bottom solve */
-  G->levels[bottom]->timers.Total += now() - t;
+  MGVCycle(G, e_id, R_id, a, b, bottom);          /* the bottom solve (times itself) */
 
   for (l = bottom - 1; l >= onLevel; l--) {       /* climb: prolong the solution, then one V-cycle */
     if (is_small(G, l)) seg_open();
-    t = now();
+    t = hpgmg_tick_begin(G->levels[l], &G->levels[l]->timers.Total, "interpolation_fcycle");
     interpolation_fcycle(G->levels[l], e_id, 0.0, G->levels[l + 1], e_id);
-    G->levels[l]->timers.Total += now() - t;
+    hpgmg_tick_end(t);
     G->levels[l]->vcycles_from_this_level++;
     MGVCycle(G, e_id, R_id, a, b, l);
     seg_close();

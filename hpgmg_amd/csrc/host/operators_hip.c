@@ -26,16 +26,54 @@
 int hpgmg_smooth_sweeps(void);
 int hpgmg_gsrb_out_of_place(void);
 
-static int sync_timers = -1; /* 1: synchronise around every operator so level->timers are device times (HPGMG_SYNC_TIMERS=1) */
-void hpgmg_set_sync_timers(int on) { sync_timers = on; }
-
+/* Timers of level->timers (reference level.h:162-196; printed by MGPrintTiming, mg.c:54-161).  Launches are asynchronous, so
+ * there are three ways to fill them:
+ *   HPGMG_TIMERS=host   (default for library users / bench.py) host clock around the launch calls: costs nothing, but the rows only
+ *                       say where the HOST thread spent its time;
+ *   HPGMG_TIMERS=device (default of the hpgmg-fv executable, hpgmg_set_timer_mode(1)) a hipEvent pair on the launch stream around
+ *                       every operator: device time per operator class and level, settled when the table is printed or reset;
+ *   HPGMG_TIMERS=sync   (or HPGMG_SYNC_TIMERS=1) synchronise around every operator: exact wall time, serialises host and device.
+ * With HPGMG_ROCTX=1 every timed operator is also a roctx range "<dim>^3 <operator>" (rocprofv3 --marker-trace). */
+enum { TIMERS_HOST = 0, TIMERS_DEVICE = 1, TIMERS_SYNC = 2 };
+static int timer_mode = -1;
+void hpgmg_set_timer_mode(int mode) { timer_mode = (mode >= 0 && mode <= 2) ? mode : 0; }
+void hpgmg_set_sync_timers(int on) { timer_mode = on ? TIMERS_SYNC : TIMERS_HOST; }
+int hpgmg_get_timer_mode(void) {
+  if (timer_mode < 0) {
+    const char *e = getenv("HPGMG_TIMERS"), *s = getenv("HPGMG_SYNC_TIMERS");
+    timer_mode = TIMERS_HOST;
+    if (e && !strcmp(e, "device")) timer_mode = TIMERS_DEVICE;
+    if ((e && !strcmp(e, "sync")) || (s && s[0] == '1')) timer_mode = TIMERS_SYNC;
+  }
+  return timer_mode;
+}
 static double now(void) {
   struct timespec ts;
-  if (sync_timers < 0) { const char *e = getenv("HPGMG_SYNC_TIMERS"); sync_timers = (e && e[0] == '1'); }
-  if (sync_timers) hpgmg_hip_sync();
+  if (hpgmg_get_timer_mode() == TIMERS_SYNC) hpgmg_hip_sync();
   clock_gettime(CLOCK_MONOTONIC, &ts);
   return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
 }
+hpgmg_tick hpgmg_tick_begin(level_type *L, double *acc, const char *what) {
+  hpgmg_tick t;
+  t.acc = acc; t.slot = -1; t.t0 = 0.0; t.range = 0;
+  if (hpgmg_hip_range_enabled()) {
+    char label[96];
+    snprintf(label, sizeof label, "%d^3 %s", L ? L->dim.i : 0, what);
+    hpgmg_hip_range_push(label);
+    t.range = 1;
+  }
+  if (hpgmg_get_timer_mode() == TIMERS_DEVICE) { t.slot = hpgmg_hip_timer_begin(acc); if (t.slot < 0) t.acc = NULL; }
+  else t.t0 = now();
+  return t;
+}
+void hpgmg_tick_end(hpgmg_tick t) {
+  if (hpgmg_get_timer_mode() == TIMERS_DEVICE) hpgmg_hip_timer_end(t.slot);
+  else if (t.acc) *t.acc += now() - t.t0;
+  if (t.range) hpgmg_hip_range_pop();
+}
+void hpgmg_timers_settle(void) { hpgmg_hip_timer_flush(); }
+#define TICK(L, FIELD, WHAT) const hpgmg_tick tick_ = hpgmg_tick_begin((L), &(L)->timers.FIELD, WHAT)
+#define TOCK() hpgmg_tick_end(tick_)
 #define HIP_OK(call) do { int e_ = (call); if (e_) { fprintf(stderr, "hpgmg: %s failed (%d): %s\n", #call, e_, hpgmg_hip_last_error()); abort(); } } while (0)
 
 /* ---------------------------------------------------------------- storage hooks */
@@ -75,7 +113,7 @@ static int graphs = -1;
 void hpgmg_set_graphs(int on) { graphs = on ? 1 : 0; }
 void hpgmg_segment_begin(long long key) {
   if (graphs < 0) { const char *e = getenv("HPGMG_GRAPH"); graphs = (e && e[0] == '1'); }
-  if (!graphs || sync_timers > 0) return;       /* per-operator timing: stay eager */
+  if (!graphs || hpgmg_get_timer_mode() == TIMERS_SYNC) return;       /* per-operator synchronisation: stay eager */
   /* multi-rank: segments cover levels of <= 64^3 cells; they are message-free (capturable) only when the rank map
    * gathers those levels on rank 0 (mg.c: hpgmg_gather_dim, the default) */
   { extern int hpgmg_gather_dim; const hpgmg_transport *T = hpgmg_get_transport(); if (T && T->size > 1 && hpgmg_gather_dim < 64) return; }
@@ -185,6 +223,7 @@ static const blockCopy_type *mirror(level_type *owner, const blockCopy_type *hos
 
 void hpgmg_level_release(level_type *L) {
   hpgmg_hip_graph_reset();                       /* cached graphs hold pointers into this level */
+  hpgmg_hip_timer_forget(&L->timers, &L->timers + 1);   /* pending device timers point into this level */
   hpgmg_level_ext *X = hpgmg_level_ext_get(L);
   backend_t *B = (backend_t *)X->backend;
   int s;
@@ -224,7 +263,7 @@ static void transport_phase(const communicator_type *recv_side, const communicat
 
 /* ---------------------------------------------------------------- exchange_boundary.c:12-117 */
 void exchange_boundary(level_type *L, int id, int shape) {
-  const double t0 = now();
+  TICK(L, ghostZone_total, "exchange_boundary");
   if (shape >= STENCIL_MAX_SHAPES) shape = STENCIL_SHAPE_BOX;
   communicator_type *C = &L->exchange_ghosts[shape];
   backend_t *B = backend_of(L);
@@ -232,7 +271,7 @@ void exchange_boundary(level_type *L, int id, int shape) {
   transport_phase(C, C, (L->tag << 4) | shape);
   HIP_OK(hpgmg_hip_copy_blocks(&B->dev, id, mirror(L, C->blocks[1], C->num_blocks[1]), C->num_blocks[1]));   /* box -> box */
   HIP_OK(hpgmg_hip_copy_blocks(&B->dev, id, mirror(L, C->blocks[2], C->num_blocks[2]), C->num_blocks[2]));   /* unpack */
-  L->timers.ghostZone_total += now() - t0;
+  TOCK();
 }
 
 /* What the stencil routines call instead of exchange_boundary()+apply_BCs() (chebyshev.c:45-46,
@@ -255,12 +294,12 @@ static void ghosts_for_stencil(level_type *L, int id) {
   if (fuse) {
     communicator_type *C = &L->exchange_ghosts[shape];
     if (C->num_sends + C->num_recvs > 0) {
-      const double t0 = now();
+      TICK(L, ghostZone_total, "exchange_boundary (remote faces)");
       backend_t *B = backend_of(L);
       HIP_OK(hpgmg_hip_copy_blocks(&B->dev, id, mirror(L, C->blocks[0], C->num_blocks[0]), C->num_blocks[0]));
       transport_phase(C, C, (L->tag << 4) | shape);
       HIP_OK(hpgmg_hip_copy_blocks(&B->dev, id, mirror(L, C->blocks[2], C->num_blocks[2]), C->num_blocks[2]));
-      L->timers.ghostZone_total += now() - t0;
+      TOCK();
     }
     return;
   }
@@ -293,7 +332,7 @@ static int overlap_begin(level_type *L, int id) {
     comm_stream = hpgmg_hip_stream_create(); ev_packed = hpgmg_hip_event_create(); ev_landed = hpgmg_hip_event_create();
     if (!comm_stream || !ev_packed || !ev_landed) { fprintf(stderr, "hpgmg: cannot create the exchange stream\n"); abort(); }
   }
-  const double t0 = now();
+  const double t0 = (hpgmg_get_timer_mode() == TIMERS_DEVICE) ? 0.0 : now();   /* two streams: the exchange is hidden behind the stencil launch by design, only the host modes time it */
   backend_t *B = backend_of(L);
   void *launch_stream = hpgmg_hip_get_stream();
   hpgmg_hip_set_ghost_free(1);
@@ -306,7 +345,7 @@ static int overlap_begin(level_type *L, int id) {
   HIP_OK(hpgmg_hip_copy_blocks(&B->dev, id, unpack, C->num_blocks[2]));                                              /* unpack */
   HIP_OK(hpgmg_hip_event_record(ev_landed));
   hpgmg_hip_set_stream(launch_stream);
-  L->timers.ghostZone_total += now() - t0;
+  if (hpgmg_get_timer_mode() != TIMERS_DEVICE) L->timers.ghostZone_total += now() - t0;
   overlap_count++;
   return 1;
 }
@@ -314,65 +353,65 @@ static void overlap_end(void) { HIP_OK(hpgmg_hip_stream_wait_event(ev_landed)); 
 /* run a stencil launch with its operand's ghost zones: overlapped (two launches: all but the shell, then the shell) or plain */
 #define STENCIL_WITH_GHOSTS(L, id, TIMER, CALL) do {                                                     \
     if (overlap_begin(L, id)) {                                                                          \
-      const double t0_ = now();                                                                          \
+      TICK(L, TIMER, #TIMER " (overlapped with the halo exchange)");                                     \
       hpgmg_hip_set_defer_mode(1); HIP_OK(CALL);                                                         \
       overlap_end();                                                                                     \
       hpgmg_hip_set_defer_mode(2); HIP_OK(CALL); hpgmg_hip_set_defer_mode(0);                            \
-      (L)->timers.TIMER += now() - t0_;                                                                  \
+      TOCK();                                                                                            \
     } else {                                                                                             \
       ghosts_for_stencil(L, id);                                                                         \
-      const double t0_ = now();                                                                          \
+      TICK(L, TIMER, #TIMER);                                                                            \
       HIP_OK(CALL);                                                                                      \
-      (L)->timers.TIMER += now() - t0_;                                                                  \
+      TOCK();                                                                                            \
     } } while (0)
 
 /* ---------------------------------------------------------------- boundary_fd.c / boundary_fv.c */
 void apply_BCs_p1(level_type *L, int x_id, int shape) {
   if (shape >= STENCIL_MAX_SHAPES) shape = STENCIL_SHAPE_BOX;
   if (L->boundary_condition.type == BC_PERIODIC) return;
-  const double t0 = now();
+  TICK(L, boundary_conditions, "apply_BCs_p1");
   backend_t *B = backend_of(L);
   const int n = L->boundary_condition.num_blocks[shape];
   HIP_OK(hpgmg_hip_apply_bc_p1(&B->dev, x_id, mirror(L, L->boundary_condition.blocks[shape], n), n));
-  L->timers.boundary_conditions += now() - t0;
+  TOCK();
 }
 static void no_kernel(const char *what) { fprintf(stderr, "hpgmg: %s has no HIP kernel yet\n", what); abort(); }
 void apply_BCs_p2(level_type *L, int x_id, int shape) {                                /* boundary_fd.c:93-205 */
   if (shape >= STENCIL_MAX_SHAPES) shape = STENCIL_SHAPE_BOX;
   if (L->boundary_condition.type == BC_PERIODIC) return;
   if (L->box_dim < 2) { apply_BCs_p1(L, x_id, shape); return; }
-  const double t0 = now();
+  TICK(L, boundary_conditions, "apply_BCs_p2");
   backend_t *B = backend_of(L);
   const int n = L->boundary_condition.num_blocks[shape];
   HIP_OK(hpgmg_hip_apply_bc_p2(&B->dev, x_id, mirror(L, L->boundary_condition.blocks[shape], n), n));
-  L->timers.boundary_conditions += now() - t0;
+  TOCK();
 }
 void apply_BCs_v1(level_type *L, int x_id, int shape) { apply_BCs_p1(L, x_id, shape); }   /* boundary_fv.c:6-90: same one-point formula */
 void apply_BCs_v2(level_type *L, int x_id, int shape) {                                   /* boundary_fv.c:101-250 */
   if (shape >= STENCIL_MAX_SHAPES) shape = STENCIL_SHAPE_BOX;
   if (L->boundary_condition.type == BC_PERIODIC) return;
   if (L->box_dim < 2) { apply_BCs_v1(L, x_id, shape); return; }
-  const double t0 = now();
+  TICK(L, boundary_conditions, "apply_BCs_v2");
   const int n = L->boundary_condition.num_blocks[shape];
   HIP_OK(hpgmg_hip_apply_bc_v2(&backend_of(L)->dev, x_id, mirror(L, L->boundary_condition.blocks[shape], n), n));
-  L->timers.boundary_conditions += now() - t0;
+  TOCK();
 }
 void apply_BCs_v4(level_type *L, int x_id, int shape) {                                   /* boundary_fv.c:262-569 */
   if (shape >= STENCIL_MAX_SHAPES) shape = STENCIL_SHAPE_BOX;
   if (L->boundary_condition.type == BC_PERIODIC) return;
   if (L->box_ghosts < 2) { fprintf(stderr, "called quartic BC's with only 1 ghost zone!!!\n"); abort(); }
   if (L->box_dim < 4) { apply_BCs_v2(L, x_id, shape); return; }
-  const double t0 = now();
+  TICK(L, boundary_conditions, "apply_BCs_v4");
   const int n = L->boundary_condition.num_blocks[shape];
   HIP_OK(hpgmg_hip_apply_bc_v4(&backend_of(L)->dev, x_id, mirror(L, L->boundary_condition.blocks[shape], n), n));
-  L->timers.boundary_conditions += now() - t0;
+  TOCK();
 }
 void extrapolate_betas(level_type *L) {                                                    /* boundary_fv.c:573-681 */
   if (L->boundary_condition.type == BC_PERIODIC) return;
-  const double t0 = now();
+  TICK(L, boundary_conditions, "extrapolate_betas");
   const int n = L->boundary_condition.num_blocks[STENCIL_SHAPE_BOX];
   HIP_OK(hpgmg_hip_extrapolate_betas(&backend_of(L)->dev, mirror(L, L->boundary_condition.blocks[STENCIL_SHAPE_BOX], n), n));
-  L->timers.boundary_conditions += now() - t0;
+  TOCK();
 }
 static int variant(void);
 /* operators/rebuild.c:47-208: probe with colors^3 0/1 colourings (exchange + BCs each time), accumulate on the device */
@@ -426,6 +465,7 @@ static void cheby_coefficients(const level_type *L, int degree, double *c1, doub
 /* Both legs of a V-cycle over a chain of tiny levels in one launch each (kernels/tail.hip). */
 /* fold the iteration counts of device-side bottom solves into level->Krylov_iterations (mg.c:156 prints it) */
 void hpgmg_level_sync_counters(level_type *L) {
+  hpgmg_hip_timer_flush();                       /* pending device timers land in level->timers before they are read or reset */
   hpgmg_level_ext *X = hpgmg_level_ext_get(L);
   backend_t *B = (backend_t *)X->backend;
   if (!B || !B->krylov_pinned) return;
@@ -486,10 +526,10 @@ int hpgmg_vcycle_legs_fused(level_type **levels, int n, int e_id, int R_id, doub
     dev[l] = &B->dev;
     h2inv[l] = 1.0 / (L->h * L->h);
   }
-  const double t0 = now();
+  TICK(levels[0], smooth, leg == 3 ? "bottom solve (device BiCGStab)" : "fused V-cycle tail");
   HIP_OK(hpgmg_hip_vcycle_tail(n, dev, h2inv, c1, c2, sweeps, variant(), cfg.smoother, e_id, R_id, a, b, leg,
                                hpgmg_vectors_reserved(), MG_DEFAULT_BOTTOM_NORM, with_bottom ? backend_of(levels[n - 1])->krylov_pinned : NULL));
-  levels[0]->timers.smooth += now() - t0;
+  TOCK();
   return 1;
 }
 
@@ -580,11 +620,11 @@ static int smooth_cheby_pairs(level_type *L, int x_id, int rhs_id, double a, dou
   backend_t *B = backend_of(L);
   const double h2inv = 1.0 / (L->h * L->h);
   const int v = variant();
-  const double t0 = now();
   const float *const *c32 = coef32_of(L);
+  TICK(L, smooth, "smooth (2 Chebyshev sweep pairs)");
   HIP_OK(hpgmg_hip_smooth_cheby_pair(&B->dev, v, (double *const *)B->d_pair_base, c32, 0, x_id, 0, VECTOR_TEMP, 1, 0, 1, 1, rhs_id, a, b, h2inv, c1[0], c2[0], c1[1], c2[1]));
   HIP_OK(hpgmg_hip_smooth_cheby_pair(&B->dev, v, (double *const *)B->d_pair_base, c32, 1, 1, 1, 0, 0, VECTOR_TEMP, 0, x_id, rhs_id, a, b, h2inv, c1[2], c2[2], c1[3], c2[3]));
-  L->timers.smooth += now() - t0;
+  TOCK();
   return 1;
 }
 /* in-place GSRB smooth() (gsrb.c:24-132, 4 coloured half sweeps) as two passes of two half sweeps each:
@@ -594,10 +634,10 @@ static int smooth_gsrb_pairs(level_type *L, int x_id, int rhs_id, double a, doub
   backend_t *B = backend_of(L);
   const double h2inv = 1.0 / (L->h * L->h);
   const int v = variant();
-  const double t0 = now();
+  TICK(L, smooth, "smooth (2 GSRB half-sweep pairs)");
   HIP_OK(hpgmg_hip_smooth_gsrb_pair(&B->dev, v, (double *const *)B->d_pair_base, NULL, 0, x_id, 0, 1, 1, rhs_id, a, b, h2inv, 0));
   HIP_OK(hpgmg_hip_smooth_gsrb_pair(&B->dev, v, (double *const *)B->d_pair_base, NULL, 1, 1, 0, 0, x_id, rhs_id, a, b, h2inv, 2));
-  L->timers.smooth += now() - t0;
+  TOCK();
   return 1;
 }
 
@@ -664,14 +704,14 @@ void apply_op(level_type *L, int Ax_id, int x_id, double a, double b) {         
 
 /* ---------------------------------------------------------------- restriction.c:104-212 */
 void restriction(level_type *Lc, int id_c, level_type *Lf, int id_f, int type) {
-  const double t0 = now();
+  TICK(Lf, restriction_total, "restriction");
   communicator_type *S = &Lf->restriction[type], *R = &Lc->restriction[type];
   backend_t *Bc = backend_of(Lc), *Bf = backend_of(Lf);
   HIP_OK(hpgmg_hip_restrict_blocks(&Bc->dev, id_c, &Bf->dev, id_f, mirror(Lf, S->blocks[0], S->num_blocks[0]), S->num_blocks[0], type));
   transport_phase(R, S, (Lf->tag << 4) | 0x5);
   HIP_OK(hpgmg_hip_restrict_blocks(&Bc->dev, id_c, &Bf->dev, id_f, mirror(Lf, S->blocks[1], S->num_blocks[1]), S->num_blocks[1], type));
   HIP_OK(hpgmg_hip_copy_blocks(&Bc->dev, id_c, mirror(Lc, R->blocks[2], R->num_blocks[2]), R->num_blocks[2]));
-  Lf->timers.restriction_total += now() - t0;
+  TOCK();
 }
 
 /* restriction(Lc, id_c, Lf, id_f, RESTRICT_CELL) followed by zero_vector(Lc, zero_id) -- the end of MGVCycle's down-leg
@@ -680,23 +720,23 @@ int hpgmg_restrict_zero_fused(level_type *Lc, int id_c, level_type *Lf, int id_f
   communicator_type *S = &Lf->restriction[RESTRICT_CELL], *R = &Lc->restriction[RESTRICT_CELL];
   if (!Lf->active || !Lc->active || Lc->num_my_boxes < 1 || zero_id == id_c) return 0;
   if (S->num_sends || R->num_recvs || S->num_blocks[0] || R->num_blocks[2] || S->num_blocks[1] < 1) return 0;
-  const double t0 = now();
+  TICK(Lf, restriction_total, "restriction + zero_vector");
   backend_t *Bc = backend_of(Lc), *Bf = backend_of(Lf);
   HIP_OK(hpgmg_hip_restrict_cell_and_zero(&Bc->dev, id_c, &Bf->dev, id_f, mirror(Lf, S->blocks[1], S->num_blocks[1]), S->num_blocks[1], zero_id));
-  Lf->timers.restriction_total += now() - t0;
+  TOCK();
   return 1;
 }
 
 /* ---------------------------------------------------------------- interpolation_p0.c:52-159, interpolation_p1.c:70-180 */
 static void interpolation_lists(level_type *Lf, int id_f, double prescale, level_type *Lc, int id_c, int order, int tagbits) {
-  const double t0 = now();
+  TICK(Lf, interpolation_total, "interpolation");
   communicator_type *S = &Lc->interpolation, *R = &Lf->interpolation;
   backend_t *Bc = backend_of(Lc), *Bf = backend_of(Lf);
   HIP_OK(hpgmg_hip_interpolate_blocks(&Bf->dev, id_f, 0.0, &Bc->dev, id_c, mirror(Lc, S->blocks[0], S->num_blocks[0]), S->num_blocks[0], order));
   transport_phase(R, S, (Lf->tag << 4) | tagbits);
   HIP_OK(hpgmg_hip_interpolate_blocks(&Bf->dev, id_f, prescale, &Bc->dev, id_c, mirror(Lc, S->blocks[1], S->num_blocks[1]), S->num_blocks[1], order));
   HIP_OK(hpgmg_hip_increment_blocks(&Bf->dev, id_f, prescale, mirror(Lf, R->blocks[2], R->num_blocks[2]), R->num_blocks[2]));
-  Lf->timers.interpolation_total += now() - t0;
+  TOCK();
 }
 void interpolation_vcycle(level_type *Lf, int id_f, double prescale, level_type *Lc, int id_c) {
   hpgmg_config c; hpgmg_get_config(&c);
@@ -731,7 +771,7 @@ void interpolation_fcycle(level_type *Lf, int id_f, double prescale, level_type 
 }
 
 /* ---------------------------------------------------------------- misc.c */
-#define BLAS1(call) do { const double t0_ = now(); HIP_OK(call); L->timers.blas1 += now() - t0_; } while (0)
+#define BLAS1(call) do { TICK(L, blas1, "BLAS1"); HIP_OK(call); TOCK(); } while (0)
 void zero_vector(level_type *L, int id) { BLAS1(hpgmg_hip_fill(&backend_of(L)->dev, id, 0.0)); }
 void init_vector(level_type *L, int id, double s) { BLAS1(hpgmg_hip_fill(&backend_of(L)->dev, id, s)); }
 void add_vectors(level_type *L, int c, double sa, int a, double sb, int b) { BLAS1(hpgmg_hip_axpby(&backend_of(L)->dev, c, sa, a, sb, b)); }
@@ -746,7 +786,7 @@ static double allreduce_scalar(level_type *L, double v, int op) {
   const hpgmg_transport *T = hpgmg_get_transport();
   if (T && T->size > 1) {
     hpgmg_level_ext *X = hpgmg_level_ext_get(L);
-    if (X->num_active_ranks > 1) { const double t0 = now(); T->allreduce(T->ctx, &v, 1, op, X->active_ranks, X->num_active_ranks); L->timers.collectives += now() - t0; }
+    if (X->num_active_ranks > 1) { const double t0 = now(); T->allreduce(T->ctx, &v, 1, op, X->active_ranks, X->num_active_ranks); L->timers.collectives += now() - t0; }   /* host-synchronous by nature: host clock in every mode */
   }
   return v;
 }

@@ -3,6 +3,8 @@
 // replacement of MALLOC()/FREE() in the reference's level.c:25-40.
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
+#include <dlfcn.h>
 #include "common.hpp"
 
 namespace hpgmg {
@@ -71,5 +73,74 @@ double hpgmg_hip_event_elapsed_ms(void *a, void *b) {
   if (hipEventElapsedTime(&ms, (hipEvent_t)a, (hipEvent_t)b) != hipSuccess) return -1.0;
   return (double)ms;
 }
+
+
+// ---- device-time attribution (reference level.h:162-196, mg.c:54-161: the per-level timing table) ----------------
+// Launches are asynchronous, so host clocks around them say nothing about where the DEVICE spent its time.  A timer here is
+// a hipEvent pair recorded on the launch stream around an operator; the elapsed device time is added to the caller's
+// accumulator (seconds) when the pool is flushed -- at the latest when it is full, normally when the table is printed or
+// reset.  Inside a hipGraph capture nothing is recorded (-1).
+static const int kTimerPool = 8192;
+static hipEvent_t g_tev[2 * kTimerPool];
+static double *g_tacc[kTimerPool];
+static int g_tev_alloc = 0, g_tev_used = 0;
+int hpgmg_hip_graph_is_open(void);
+int hpgmg_hip_timer_flush(void) {
+  for (int p = 0; p < g_tev_used; p++) {
+    float ms = 0.f;
+    if (hipEventSynchronize(g_tev[2 * p + 1]) == hipSuccess && hipEventElapsedTime(&ms, g_tev[2 * p], g_tev[2 * p + 1]) == hipSuccess && g_tacc[p]) *g_tacc[p] += 1e-3 * (double)ms;
+    else (void)hipGetLastError();
+  }
+  g_tev_used = 0;
+  return 0;
+}
+int hpgmg_hip_timer_begin(double *acc_seconds) {
+  if (hpgmg_hip_graph_is_open()) return -1;
+  ensure_stream();
+  if (g_tev_used == kTimerPool) hpgmg_hip_timer_flush();
+  if (g_tev_used == g_tev_alloc) {
+    if (hipEventCreate(&g_tev[2 * g_tev_alloc]) != hipSuccess || hipEventCreate(&g_tev[2 * g_tev_alloc + 1]) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    g_tev_alloc++;
+  }
+  const int p = g_tev_used++;
+  g_tacc[p] = acc_seconds;
+  (void)hipEventRecord(g_tev[2 * p], g_stream);
+  return p;
+}
+void hpgmg_hip_timer_end(int slot) {
+  if (slot < 0 || slot >= g_tev_used) return;
+  if (hipEventRecord(g_tev[2 * slot + 1], g_stream) != hipSuccess) { (void)hipGetLastError(); g_tacc[slot] = nullptr; }
+}
+// an accumulator is going away (level destroyed): settle what is pending
+void hpgmg_hip_timer_forget(const void *lo, const void *hi) {
+  bool any = false;
+  for (int p = 0; p < g_tev_used; p++) if ((const void *)g_tacc[p] >= lo && (const void *)g_tacc[p] < hi) any = true;
+  if (any) hpgmg_hip_timer_flush();
+}
+
+// ---- roctx ranges (per level / operator markers for rocprofv3 --marker-trace), resolved at run time so the
+// library has no hard dependency on the profiler's marker library; HPGMG_ROCTX=1 turns them on ----
+typedef int (*roctx_push_t)(const char *);
+typedef int (*roctx_pop_t)(void);
+static roctx_push_t g_roctx_push = nullptr;
+static roctx_pop_t g_roctx_pop = nullptr;
+static int g_roctx_state = -1;   // -1 unknown, 0 off, 1 on
+static int roctx_ready() {
+  if (g_roctx_state < 0) {
+    g_roctx_state = 0;
+    const char *e = getenv("HPGMG_ROCTX");
+    if (e && e[0] == '1') {
+      void *h = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+      if (!h) h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+      if (h) { g_roctx_push = (roctx_push_t)dlsym(h, "roctxRangePushA"); g_roctx_pop = (roctx_pop_t)dlsym(h, "roctxRangePop"); }
+      if (g_roctx_push && g_roctx_pop) g_roctx_state = 1;
+      else fprintf(stderr, "hpgmg_hip: HPGMG_ROCTX=1 but no roctx library could be loaded\n");
+    }
+  }
+  return g_roctx_state;
+}
+int hpgmg_hip_range_enabled(void) { return roctx_ready(); }
+void hpgmg_hip_range_push(const char *name) { if (roctx_ready()) g_roctx_push(name); }
+void hpgmg_hip_range_pop(void) { if (roctx_ready()) g_roctx_pop(); }
 
 }  // extern "C"

@@ -77,6 +77,9 @@ void        hpgmg_set_verbose(int v);
 int         hpgmg_transport_init_rccl(const char *id128, int rank, int size);
 void        hpgmg_transport_finalize_rccl(void);
 void        hpgmg_set_sync_timers(int on);
+/* level->timers after settling pending device timers: smooth, residual, apply_op, blas1, boundary_conditions, restriction_total,
+ * interpolation_total, ghostZone_total, Total (seconds since MGResetTimers; reference level.h:162-196) */
+void        hpgmg_level_timers(level_type *level, double out[9]);
 void        hpgmg_set_gather_dim(int dim);  /* multi-rank: levels of <= dim^3 cells live entirely on rank 0 (default 64; 0 = the reference's rank map); call before MGBuild */
 long long   hpgmg_overlap_count(void);      /* number of overlapped exchanges performed so far */
 void        hpgmg_set_overlap(int on);      /* multi-rank: 1 (default) overlaps the halo exchange with the stencil launch that consumes it */

@@ -64,6 +64,18 @@ void  *hpgmg_hip_stream_create(void);               /* a second (non-blocking) s
 void   hpgmg_hip_stream_destroy(void *stream);
 int    hpgmg_hip_stream_wait_event(void *ev);       /* the CURRENT launch stream waits for ev */
 double hpgmg_hip_event_elapsed_ms(void *start, void *stop); /* synchronises on stop */
+/* Device-time attribution for the per-level timing table (reference level.h:162-196, mg.c:54-161): a hipEvent pair on the
+ * launch stream around an operator.  begin() returns a slot (-1: not recorded, e.g. inside a graph capture); the elapsed
+ * device time is ADDED to *acc_seconds by flush() (called by the plugin before the table is printed / reset; also when the
+ * pool of 8192 pairs is full).  forget(lo, hi): accumulators in [lo, hi) are about to be freed -- settle them now. */
+int    hpgmg_hip_timer_begin(double *acc_seconds);
+void   hpgmg_hip_timer_end(int slot);
+int    hpgmg_hip_timer_flush(void);
+void   hpgmg_hip_timer_forget(const void *lo, const void *hi);
+/* roctx ranges around operators (rocprofv3 --marker-trace); active only with HPGMG_ROCTX=1 (library resolved with dlopen) */
+int    hpgmg_hip_range_enabled(void);
+void   hpgmg_hip_range_push(const char *name);
+void   hpgmg_hip_range_pop(void);
 /* accumulate the GPU time of every smoother-kernel launch between begin/end (hipEvents around each launch) */
 void   hpgmg_hip_profile_smoother(int enable);
 void   hpgmg_hip_profile_smoother_min_cells(long long min_cells); /* time only launches over >= this many cells */

@@ -123,6 +123,18 @@ int     hpgmg_vcycle_legs_fused(level_type **levels, int n, int e_id, int R_id, 
 int     hpgmg_interp_smooth_fused(level_type *fine, int e_id, int R_id, level_type *coarse, double a, double b);
 /* Optional fused form of  restriction(coarse, id_c, fine, id_f, RESTRICT_CELL); zero_vector(coarse, zero_id)  (mg.c:1152-1153) */
 int     hpgmg_restrict_zero_fused(level_type *coarse, int id_c, level_type *fine, int id_f, int zero_id);
+/* Timing hooks for the cycle driver's per-level "Total" rows (mg.c:54-161).  The plugin decides what a tick measures: the
+ * CPU oracle reads the host clock; the HIP plugin, whose launches are asynchronous, can record a hipEvent pair instead and
+ * add the elapsed DEVICE time to *acc later -- hpgmg_timers_settle() (also done by hpgmg_level_sync_counters) makes every
+ * pending tick land in its accumulator.  `what` names the range for profilers (roctx). */
+typedef struct { double t0; double *acc; int slot, range; } hpgmg_tick;
+hpgmg_tick hpgmg_tick_begin(level_type *level, double *acc_seconds, const char *what);
+void    hpgmg_tick_end(hpgmg_tick t);
+void    hpgmg_timers_settle(void);
+/* 0 host clock around (asynchronous) operator calls, 1 device time per operator (hipEvent pairs), 2 synchronise around every
+ * operator; the CPU oracle ignores it.  Environment: HPGMG_TIMERS=host|device|sync. */
+void    hpgmg_set_timer_mode(int mode);
+int     hpgmg_get_timer_mode(void);
 /* bring level->Krylov_iterations up to date with bottom solves the plugin ran asynchronously */
 void    hpgmg_level_sync_counters(level_type *level);
 /* called by destroy_level / MGDestroy so the plugin can drop device mirrors */

@@ -49,6 +49,12 @@ void hpgmg_vector_copy(double *d, const double *s, size_t n) { memcpy(d, s, n * 
 void hpgmg_vector_upload(double *d, const double *s, size_t n) { memcpy(d, s, n * sizeof(double)); }
 void hpgmg_vector_download(double *d, const double *s, size_t n) { memcpy(d, s, n * sizeof(double)); }
 void hpgmg_level_release(level_type *level) { (void)level; }
+/* timing hooks: the oracle is synchronous, so a tick is the host clock */
+hpgmg_tick hpgmg_tick_begin(level_type *L, double *acc, const char *what) { hpgmg_tick t; (void)L; (void)what; t.t0 = now(); t.acc = acc; t.slot = -1; t.range = 0; return t; }
+void hpgmg_tick_end(hpgmg_tick t) { if (t.acc) *t.acc += now() - t.t0; }
+void hpgmg_timers_settle(void) {}
+void hpgmg_set_timer_mode(int mode) { (void)mode; }
+int hpgmg_get_timer_mode(void) { return 0; }
 void hpgmg_level_sync_counters(level_type *level) { (void)level; }
 int hpgmg_restrict_zero_fused(level_type *c, int ic, level_type *f, int i_f, int z) { (void)c; (void)ic; (void)f; (void)i_f; (void)z; return 0; }
 int hpgmg_interp_smooth_fused(level_type *f, int e, int R, level_type *c, double a, double b) { (void)f; (void)e; (void)R; (void)c; (void)a; (void)b; return 0; }

@@ -13,14 +13,15 @@ import json, os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 REF = os.path.join(ROOT, "oracle", "_ref")
 CASES = {
-    "7pt-cheby": ["4 8", "5 8", "6 8", "7 8", "4 1", "5 1", "4 27"],
+    # `8 8` (512^3 in 8 boxes of 256^3) = BASELINE config 4 at its stated size; `7 64` (512^3 in 64 boxes of 128^3) = config 3's
+    "7pt-cheby": ["4 8", "5 8", "6 8", "7 8", "4 1", "5 1", "4 27", "8 8"],
     "7pt-gsrb": ["4 8", "5 8", "6 8", "7 8"],
-    "7pt-cheby-helm": ["4 8", "5 8", "6 8", "7 8"],
+    "7pt-cheby-helm": ["4 8", "5 8", "6 8", "7 8", "8 8"],
     "7ptcc-cheby": ["4 8", "5 8", "6 8", "7 8"],
     "7pt-jacobi": ["4 8", "5 8"],
     "27pt-cheby": ["4 8", "5 8", "6 8", "7 8"],
-    "27pt-gsrb": ["4 8", "5 8"],
-    "fv4-gsrb": ["4 8", "5 8", "6 8", "7 8"],
+    "27pt-gsrb": ["4 8", "5 8", "7 8", "7 64"],
+    "fv4-gsrb": ["4 8", "5 8", "6 8", "7 8", "7 64"],
     "fv4-cheby": ["4 8", "5 8"],
     "fv2-cheby": ["4 8", "5 8"],
     "7pt-cheby-periodic": ["4 8", "5 8"],          # -DUSE_PERIODIC_BC: Poisson, the mean is removed (mg.c, solvers.c)
@@ -48,7 +49,8 @@ def run(variant, args):
     return {"norms": [n for n, _ in last3], "rels": [r for _, r in last3], "richardson_error": err, "order": order,
             "eigenvalue_max": eig, "lambda_max": lam, "levels": [[int(a), int(b), int(c)] for a, b, c in levels]}
 def main():
-    """no arguments: regenerate everything; `--only SUBSTR`: (re)run the cases whose key contains SUBSTR and merge them into the file"""
+    """no arguments: regenerate everything; `--only SUBSTR`: (re)run the cases whose key contains SUBSTR and merge them into the file
+    (`--missing`: of those, only the ones the file does not hold yet)"""
     path = os.path.join(ROOT, "tests", "golden", "fcycle_norms.json")
     only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else None
     gold = {"_generated_by": "tests/golden/make_golden.py from oracle/_ref/hpgmg-* (reference built by oracle/Makefile: gcc -O2 -fopenmp, no MPI)"}
@@ -57,7 +59,7 @@ def main():
     for v, arglist in CASES.items():
         for a in arglist:
             key = f"{v} {a}"
-            if only and only not in key:
+            if only and only not in key or (only and key in gold and "--missing" in sys.argv):
                 continue
             print("running", key, file=sys.stderr)
             gold[key] = run(v, a)

@@ -134,3 +134,33 @@ def test_hip_equals_oracle_live(hip, oracle):
             assert np.array_equal(lh.interior(vid), lo.interior(vid)), vid
     finally:
         sh.destroy(); so.destroy()
+
+
+def test_timing_table_is_device_time(hip):
+    """Per-level 'Total' rows filled from hipEvent pairs (HPGMG_TIMERS=device): they must account for the solve --
+    the sum over levels within 10 % of the wall time of the timed solves (reference table: mg.c:54-161), every
+    operator-class row no larger than its level's Total, and the numbers unchanged by the instrumentation."""
+    import ctypes
+    hip.configure(**VARIANTS["7pt-cheby-helm"])
+    s = hip.solver_cli(7, 8)
+    prev = hip.lib.hpgmg_get_timer_mode()
+    try:
+        hip.lib.hpgmg_set_timer_mode(1)
+        solves = 8
+        per_solve = s.bench(0, 3, solves)                 # MGResetTimers after the warm-up, like the reference protocol
+        assert fmt(hip.lib.hpgmg_solver_fmg(s.ptr, 0)) == GOLD["7pt-cheby-helm 7 8"]["norms"][0]
+        solves += 1
+        rows = []
+        for l in range(s.num_levels()):
+            out = (ctypes.c_double * 9)()
+            hip.lib.hpgmg_level_timers(s.level(l).ptr, out)
+            rows.append(list(out))
+        total = sum(r[8] for r in rows) / solves
+        assert 0.90 * per_solve <= total <= 1.02 * per_solve, (total, per_solve, rows)
+        for r in rows:
+            assert all(v >= 0.0 for v in r)
+            assert sum(r[:8]) <= 1.05 * r[8] + 1e-4, r
+        assert rows[0][0] > 0.25 * rows[0][8]             # the fine level is dominated by the smoother
+    finally:
+        hip.lib.hpgmg_set_timer_mode(prev)
+        s.destroy()
