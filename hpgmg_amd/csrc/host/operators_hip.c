@@ -133,7 +133,30 @@ typedef struct {
   double *pair_scratch; double **d_pair_base;   /* two private vectors per box for the fused Chebyshev sweep pairs */
   float *coef32; float **d_coef32_base; int coef32_valid;   /* fp32 copies of Dinv, alpha, beta_* for the mixed-precision smoother */
   int lexicographic;           /* -1 unknown, else whether local box b sits at (b % nb, (b / nb) % nb, b / nb^2) and all boxes are local */
+  struct pair_halo *halo;      /* sweep pairs across rank boundaries: brick shape, message plans, deep halos (NULL: not built / not applicable) */
+  int halo_state;              /* 0 not examined, 1 usable, -1 this level cannot use it */
 } backend_t;
+
+/* ---- halo of a sweep pair (kernels/cheby_pair.hpp, REMOTE variants) ----------------------------------------------------------
+ * One message per neighbouring rank per sweep PAIR instead of one per sweep (reference: exchange_boundary before every sweep,
+ * chebyshev.c:45-46).  Plan FIRST (first pair of a smooth()): x0 two cells deep on faces + one cell on the brick's edges, xm1 and the
+ * right-hand side one cell deep; plan NEXT: the same without the right-hand side; plan COEF (once per operator rebuild): the normal
+ * beta component one index beyond the ghost zone on the high faces.  Inside a message regions are ordered by the sender's global box
+ * id, then the direction seen from the sender, then the item -- both sides derive that order independently, like level.c does. */
+enum { HALO_FIRST = 0, HALO_NEXT = 1, HALO_COEF = 2, HALO_PLANS = 3 };
+typedef struct {
+  int n_send, n_recv;                           /* regions */
+  hpgmg_hip_halo_entry *d_send, *d_recv;        /* device copies of the region lists */
+  int n_sp, n_rp;                               /* messages: peers this rank sends to / receives from */
+  int *sp_rank, *rp_rank, *sp_size, *rp_size;   /* doubles per message */
+  double **sp_ptr, **rp_ptr;                    /* start of each message inside the rank's send / receive buffer */
+} halo_plan;
+typedef struct pair_halo {
+  int brick[3], rem[6];
+  halo_plan plan[HALO_PLANS];
+  double *sendbuf, *recvbuf, *deep, *deep_beta;
+  int coef_valid;
+} pair_halo;
 
 static void coef32_invalidate(level_type *L);
 static backend_t *backend_of(level_type *L) {
@@ -237,6 +260,20 @@ void hpgmg_level_release(level_type *L) {
   if (B->coef32) hpgmg_hip_free(B->coef32);
   if (B->d_coef32_base) hpgmg_hip_free(B->d_coef32_base);
   if (B->d_pair_base) hpgmg_hip_free(B->d_pair_base);
+  if (B->halo) {
+    int q;
+    for (q = 0; q < HALO_PLANS; q++) {
+      halo_plan *P = &B->halo->plan[q];
+      if (P->d_send) hpgmg_hip_free(P->d_send);
+      if (P->d_recv) hpgmg_hip_free(P->d_recv);
+      free(P->sp_rank); free(P->rp_rank); free(P->sp_size); free(P->rp_size); free(P->sp_ptr); free(P->rp_ptr);
+    }
+    if (B->halo->sendbuf) hpgmg_hip_free(B->halo->sendbuf);
+    if (B->halo->recvbuf) hpgmg_hip_free(B->halo->recvbuf);
+    if (B->halo->deep) hpgmg_hip_free(B->halo->deep);
+    if (B->halo->deep_beta) hpgmg_hip_free(B->halo->deep_beta);
+    free(B->halo);
+  }
   free(B);
   X->backend = NULL;
 }
@@ -577,7 +614,221 @@ static const float *const *coef32_of(level_type *L) {
   if (!B->coef32_valid) { HIP_OK(hpgmg_hip_coef32_refresh(&B->dev, (float *const *)B->d_coef32_base, L->numVectors)); B->coef32_valid = 1; }
   return (const float *const *)B->d_coef32_base;
 }
-static void coef32_invalidate(level_type *L) { backend_t *B = backend_of(L); B->coef32_valid = 0; }
+static void coef32_invalidate(level_type *L) { backend_t *B = backend_of(L); B->coef32_valid = 0; if (B->halo) B->halo->coef_valid = 0; }
+
+/* ---------------------------------------------------------------- sweep pairs across rank boundaries: halo plans */
+static int pair_remote_enabled(void) {
+  static int on = -1;
+  if (on < 0) { const char *e = getenv("HPGMG_PAIR_REMOTE"); on = !(e && e[0] == '0'); }
+  return on;
+}
+static int box_rank_at(const level_type *L, int bi, int bj, int bk) {           /* -1 outside the (non-periodic) domain */
+  if (bi < 0 || bj < 0 || bk < 0 || bi >= L->boxes_in.i || bj >= L->boxes_in.j || bk >= L->boxes_in.k) return -1;
+  return L->rank_of_box[bi + L->boxes_in.i * (bj + L->boxes_in.j * bk)];
+}
+/* Every rank's boxes form a brick (a box-aligned sub-block of the domain)?  Decided from the global box -> rank table, so all
+ * ranks reach the same answer (they must: the message pattern of a smooth() depends on it).  Returns my brick in lo/n. */
+static int every_rank_owns_a_brick(const level_type *L, int lo[3], int n[3]) {
+  const hpgmg_transport *T = hpgmg_get_transport();
+  const int nr = T ? T->size : 1;
+  int *mn = (int *)malloc((size_t)nr * 3 * sizeof(int)), *mx = (int *)malloc((size_t)nr * 3 * sizeof(int)), *cnt = (int *)calloc((size_t)nr, sizeof(int));
+  int r, bi, bj, bk, ok = 1;
+  for (r = 0; r < 3 * nr; r++) { mn[r] = 1 << 30; mx[r] = -1; }
+  for (bk = 0; bk < L->boxes_in.k; bk++) for (bj = 0; bj < L->boxes_in.j; bj++) for (bi = 0; bi < L->boxes_in.i; bi++) {
+    const int c[3] = { bi, bj, bk };
+    int a;
+    r = box_rank_at(L, bi, bj, bk);
+    if (r < 0 || r >= nr) { ok = 0; continue; }
+    cnt[r]++;
+    for (a = 0; a < 3; a++) { if (c[a] < mn[3 * r + a]) mn[3 * r + a] = c[a]; if (c[a] > mx[3 * r + a]) mx[3 * r + a] = c[a]; }
+  }
+  for (r = 0; r < nr && ok; r++)
+    if (cnt[r] > 0 && cnt[r] != (mx[3 * r] - mn[3 * r] + 1) * (mx[3 * r + 1] - mn[3 * r + 1] + 1) * (mx[3 * r + 2] - mn[3 * r + 2] + 1)) ok = 0;
+  if (ok && L->my_rank < nr && cnt[L->my_rank] > 0) { int a; for (a = 0; a < 3; a++) { lo[a] = mn[3 * L->my_rank + a]; n[a] = mx[3 * L->my_rank + a] - mn[3 * L->my_rank + a] + 1; } }
+  else ok = 0;
+  free(mn); free(mx); free(cnt);
+  return ok;
+}
+
+typedef struct { int send_id, sdir, item; hpgmg_hip_halo_entry e; int peer; } halo_rec;
+static int halo_rec_cmp(const void *pa, const void *pb) {
+  const halo_rec *a = (const halo_rec *)pa, *b = (const halo_rec *)pb;
+  if (a->peer != b->peer) return a->peer < b->peer ? -1 : 1;
+  if (a->send_id != b->send_id) return a->send_id < b->send_id ? -1 : 1;
+  if (a->sdir != b->sdir) return a->sdir < b->sdir ? -1 : 1;
+  return (a->item > b->item) - (a->item < b->item);
+}
+static int local_box_of(const level_type *L, int gid) { int b; for (b = 0; b < L->num_my_boxes; b++) if (L->my_boxes[b].global_box_id == gid) return b; return -1; }
+
+/* turn sorted records into a plan: per-peer message sizes / offsets and the device region lists */
+static size_t halo_finish_side(halo_rec *rec, int n, hpgmg_hip_halo_entry **d_list, int *n_msg, int **ranks, int **sizes, long long **offs) {
+  int q, m = 0;
+  size_t total = 0;
+  qsort(rec, (size_t)n, sizeof(halo_rec), halo_rec_cmp);
+  *ranks = (int *)malloc((size_t)(n + 1) * sizeof(int)); *sizes = (int *)calloc((size_t)(n + 1), sizeof(int)); *offs = (long long *)calloc((size_t)(n + 1), sizeof(long long));
+  hpgmg_hip_halo_entry *host = (hpgmg_hip_halo_entry *)malloc((size_t)(n + 1) * sizeof(*host));
+  for (q = 0; q < n; q++) {
+    if (m == 0 || (*ranks)[m - 1] != rec[q].peer) { (*ranks)[m] = rec[q].peer; (*offs)[m] = (long long)total; m++; }
+    rec[q].e.off = (long long)total;
+    const int len = rec[q].e.ni * rec[q].e.nj * rec[q].e.nk;
+    (*sizes)[m - 1] += len; total += (size_t)len;
+    host[q] = rec[q].e;
+  }
+  *n_msg = m;
+  *d_list = NULL;
+  if (n > 0) {
+    *d_list = (hpgmg_hip_halo_entry *)hpgmg_hip_malloc((size_t)n * sizeof(*host));
+    if (!*d_list) { fprintf(stderr, "hpgmg: device allocation failed: %s\n", hpgmg_hip_last_error()); abort(); }
+    HIP_OK(hpgmg_hip_memcpy_h2d(*d_list, host, (size_t)n * sizeof(*host)));
+  }
+  free(host);
+  return total;
+}
+
+static pair_halo *pair_halo_build(level_type *L, const int lo[3], const int n[3]) {
+  const int me = L->my_rank, dim = L->box_dim;
+  pair_halo *H = (pair_halo *)calloc(1, sizeof(*H));
+  int a, which, bi, bj, bk, dir;
+  for (a = 0; a < 3; a++) H->brick[a] = n[a];
+  { /* a brick face is the domain boundary or belongs to another rank (never to me: the brick is my whole share) */
+    const int bl[3] = { L->boxes_in.i, L->boxes_in.j, L->boxes_in.k };
+    for (a = 0; a < 3; a++) { H->rem[2 * a] = (lo[a] > 0); H->rem[2 * a + 1] = (lo[a] + n[a] < bl[a]); }
+  }
+  const int max_rec = L->boxes_in.i * L->boxes_in.j * L->boxes_in.k * 18 * 4 + 4;
+  size_t need_send = 0, need_recv = 0;
+  long long **soffs = NULL; (void)soffs;
+  for (which = 0; which < HALO_PLANS; which++) {
+    halo_plan *P = &H->plan[which];
+    halo_rec *snd = (halo_rec *)malloc((size_t)max_rec * sizeof(halo_rec)), *rcv = (halo_rec *)malloc((size_t)max_rec * sizeof(halo_rec));
+    int ns = 0, nrv = 0;
+    /* every (receiving box, direction) of the level; both sides evaluate the same rule from the global box -> rank table */
+    for (bk = 0; bk < L->boxes_in.k; bk++) for (bj = 0; bj < L->boxes_in.j; bj++) for (bi = 0; bi < L->boxes_in.i; bi++) for (dir = 0; dir < 27; dir++) {
+      const int d[3] = { dir % 3 - 1, (dir / 3) % 3 - 1, dir / 9 - 1 };
+      const int order = (d[0] != 0) + (d[1] != 0) + (d[2] != 0);
+      if (order != 1 && order != 2) continue;
+      if (which == HALO_COEF && order != 1) continue;
+      const int M = box_rank_at(L, bi, bj, bk), S = box_rank_at(L, bi + d[0], bj + d[1], bk + d[2]);
+      if (M < 0 || S < 0 || M == S || (M != me && S != me)) continue;
+      if (order == 2) {   /* an edge value is read only where BOTH faces it touches belong to other ranks (a Dirichlet face overrides it) */
+        int need = 1;
+        for (a = 0; a < 3; a++) if (d[a]) { const int r = box_rank_at(L, bi + (a == 0 ? d[0] : 0), bj + (a == 1 ? d[1] : 0), bk + (a == 2 ? d[2] : 0)); if (r < 0 || r == M) need = 0; }
+        if (!need) continue;
+      }
+      const int recv_id = bi + L->boxes_in.i * (bj + L->boxes_in.j * bk);
+      const int send_id = (bi + d[0]) + L->boxes_in.i * ((bj + d[1]) + L->boxes_in.j * (bk + d[2]));
+      const int sdir = 26 - dir;
+      int face = -1;
+      if (order == 1) face = d[0] ? (d[0] < 0 ? 0 : 1) : (d[1] ? (d[1] < 0 ? 2 : 3) : (d[2] < 0 ? 4 : 5));
+      /* items: (vector, depth).  depth 1 / 2: the region one / two cells beyond the face; depth 10 + t (coefficients only): the line of
+       * HIGH-face values of beta_t (index dim along the tangential axis t) on the ghost layer -- the ghost cells' own upper faces, which
+       * the BOX exchange of rebuild_operator only delivers where a diagonal neighbour box exists, i.e. not along the domain boundary */
+      int items[4][2], nitems = 0;
+      if (which == HALO_COEF) {
+        const int beta_of[3] = { VECTOR_BETA_I, VECTOR_BETA_J, VECTOR_BETA_K };
+        if (d[0] + d[1] + d[2] > 0) { items[nitems][0] = 16 + (d[0] ? VECTOR_BETA_I : (d[1] ? VECTOR_BETA_J : VECTOR_BETA_K)); items[nitems++][1] = 2; }
+        for (a = 0; a < 3; a++) if (!d[a]) { items[nitems][0] = 16 + beta_of[a]; items[nitems++][1] = 10 + a; }
+      } else {
+        items[nitems][0] = 0; items[nitems++][1] = 1;
+        if (order == 1) {
+          items[nitems][0] = 0; items[nitems++][1] = 2;
+          items[nitems][0] = 1; items[nitems++][1] = 1;
+          if (which == HALO_FIRST) { items[nitems][0] = 2; items[nitems++][1] = 1; }
+        }
+      }
+      int it;
+      for (it = 0; it < nitems; it++) {
+        const int depth = items[it][1];
+        halo_rec R;
+        memset(&R, 0, sizeof(R));
+        R.send_id = send_id; R.sdir = sdir; R.item = it;
+        R.e.vec = items[it][0]; R.e.deep = -1;
+        int lo3[3], len3[3];
+        if (M == me) {                                  /* what I receive: the ghost region (depth 1) or a deep plane (depth 2) */
+          for (a = 0; a < 3; a++) { lo3[a] = d[a] < 0 ? -1 : (d[a] > 0 ? dim : 0); len3[a] = d[a] ? 1 : dim; }
+          if (depth >= 10) { lo3[depth - 10] = dim; len3[depth - 10] = 1; }
+          R.e.box = local_box_of(L, recv_id);
+          if (depth == 2) R.e.deep = (which == HALO_COEF) ? 8 + face / 2 : face;
+          R.e.i = lo3[0]; R.e.j = lo3[1]; R.e.k = lo3[2]; R.e.ni = len3[0]; R.e.nj = len3[1]; R.e.nk = len3[2];
+          R.peer = S;
+          rcv[nrv++] = R;
+        }
+        if (S == me) {                                  /* what I send: my cells next to (depth 1) / one further from (depth 2) that face */
+          for (a = 0; a < 3; a++) {
+            /* seen from the sender the receiver lies in direction -d: d > 0 means the sender is on the receiver's high side and sends its LOW cells */
+            if (depth == 2 && which == HALO_COEF) lo3[a] = d[a] ? 1 : 0;        /* beta face index 1 of the sender = index dim + 1 of the receiver */
+            else { const int dd = depth >= 10 ? 1 : depth; lo3[a] = d[a] > 0 ? (dd - 1) : (d[a] < 0 ? dim - dd : 0); }
+            len3[a] = d[a] ? 1 : dim;
+          }
+          if (depth >= 10) { lo3[depth - 10] = dim; len3[depth - 10] = 1; }
+          R.e.box = local_box_of(L, send_id);
+          R.e.deep = -1;
+          R.e.i = lo3[0]; R.e.j = lo3[1]; R.e.k = lo3[2]; R.e.ni = len3[0]; R.e.nj = len3[1]; R.e.nk = len3[2];
+          R.peer = M;
+          snd[ns++] = R;
+        }
+      }
+    }
+    long long *so = NULL, *ro = NULL;
+    const size_t ts = halo_finish_side(snd, ns, &P->d_send, &P->n_sp, &P->sp_rank, &P->sp_size, &so);
+    const size_t tr = halo_finish_side(rcv, nrv, &P->d_recv, &P->n_rp, &P->rp_rank, &P->rp_size, &ro);
+    P->n_send = ns; P->n_recv = nrv;
+    P->sp_ptr = (double **)calloc((size_t)(P->n_sp + 1), sizeof(double *)); P->rp_ptr = (double **)calloc((size_t)(P->n_rp + 1), sizeof(double *));
+    { int q; for (q = 0; q < P->n_sp; q++) P->sp_ptr[q] = (double *)(uintptr_t)so[q]; for (q = 0; q < P->n_rp; q++) P->rp_ptr[q] = (double *)(uintptr_t)ro[q]; }   /* offsets for now */
+    free(so); free(ro); free(snd); free(rcv);
+    if (ts > need_send) need_send = ts;
+    if (tr > need_recv) need_recv = tr;
+  }
+  H->sendbuf = hpgmg_vector_alloc(need_send + 2);
+  H->recvbuf = hpgmg_vector_alloc(need_recv + 2);
+  H->deep = hpgmg_vector_alloc((size_t)L->num_my_boxes * 6 * (size_t)dim * dim + 2);
+  H->deep_beta = hpgmg_vector_alloc((size_t)L->num_my_boxes * 3 * (size_t)dim * dim + 2);
+  for (which = 0; which < HALO_PLANS; which++) {
+    halo_plan *P = &H->plan[which];
+    int q;
+    for (q = 0; q < P->n_sp; q++) P->sp_ptr[q] = H->sendbuf + (size_t)(uintptr_t)P->sp_ptr[q];
+    for (q = 0; q < P->n_rp; q++) P->rp_ptr[q] = H->recvbuf + (size_t)(uintptr_t)P->rp_ptr[q];
+  }
+  return H;
+}
+
+/* may smooth() on this level run as sweep pairs although some faces belong to other ranks?  (same answer on every rank) */
+static int pair_halo_ready(level_type *L, backend_t *B) {
+  if (B->halo_state == 0) {
+    const hpgmg_transport *T = hpgmg_get_transport();
+    int lo[3], n[3], b, ok;
+    B->halo_state = -1;
+    ok = pair_remote_enabled() && T && T->size > 1 && L->boundary_condition.type == BC_DIRICHLET && L->box_dim % 128 == 0 && L->num_my_boxes > 0;
+    if (ok) ok = every_rank_owns_a_brick(L, lo, n);
+    for (b = 0; ok && b < L->num_my_boxes; b++) {     /* local numbering = lexicographic inside the brick */
+      const box_type *X = &L->my_boxes[b];
+      const int ci = X->low.i / L->box_dim - lo[0], cj = X->low.j / L->box_dim - lo[1], ck = X->low.k / L->box_dim - lo[2];
+      if (ci + n[0] * (cj + n[1] * ck) != b) ok = 0;
+    }
+    if (ok && !hpgmg_hip_smooth_cheby_pair_supported_brick(&B->dev, variant(), n[0], n[1], n[2])) ok = 0;
+    if (ok) { B->halo = pair_halo_build(L, lo, n); B->halo_state = 1; }
+  }
+  return B->halo_state > 0;
+}
+static void pair_halo_exchange(level_type *L, backend_t *B, int which, int x0_scr, int x0_id, int xm1_scr, int xm1_id, int rhs_id) {
+  const hpgmg_transport *T = hpgmg_get_transport();
+  pair_halo *H = B->halo;
+  halo_plan *P = &H->plan[which];
+  if (P->n_send + P->n_recv == 0) return;
+  TICK(L, ghostZone_total, which == HALO_COEF ? "coefficient halo (sweep pairs)" : "sweep-pair halo exchange");
+  HIP_OK(hpgmg_hip_pair_halo_pack(&B->dev, (double *const *)B->d_pair_base, x0_scr, x0_id, xm1_scr, xm1_id, rhs_id, P->d_send, P->n_send, H->sendbuf));
+  T->sendrecv(T->ctx, P->n_rp, P->rp_ptr, P->rp_size, P->rp_rank, P->n_sp, P->sp_ptr, P->sp_size, P->sp_rank, (L->tag << 4) | 0x8 | which);
+  HIP_OK(hpgmg_hip_pair_halo_unpack(&B->dev, (double *const *)B->d_pair_base, x0_scr, x0_id, xm1_scr, xm1_id, rhs_id, P->d_recv, P->n_recv, H->recvbuf, H->deep, H->deep_beta));
+  TOCK();
+}
+/* everything a remote sweep pair needs before its launch: (once per operator rebuild) the deep coefficient planes, then the halo of this pair */
+static void pair_halo_before_launch(level_type *L, backend_t *B, int first, int x0_scr, int x0_id, int xm1_scr, int xm1_id, int rhs_id) {
+  pair_halo *H = B->halo;
+  if (!H->coef_valid) { pair_halo_exchange(L, B, HALO_COEF, 0, 0, 0, 0, 0); H->coef_valid = 1; }
+  pair_halo_exchange(L, B, first ? HALO_FIRST : HALO_NEXT, x0_scr, x0_id, xm1_scr, xm1_id, rhs_id);
+  hpgmg_hip_pair_set_halo(H->brick, H->rem, H->deep, H->deep_beta);
+}
+static long long pair_remote_smooths = 0;
+long long hpgmg_pair_remote_smooths(void) { return pair_remote_smooths; }   /* smooth() calls done as sweep pairs with remote faces (tests) */
 
 static int fused_sweeps = -1;
 void hpgmg_set_fused_sweeps(int on) { fused_sweeps = on ? 1 : 0; }
@@ -588,8 +839,9 @@ static int pair_kernel_ready(level_type *L, int x_id, int rhs_id, int sweeps) {
   hpgmg_get_config(&cfg);
   backend_t *B = backend_of(L);
   if (!fused_sweeps || sweeps != 4 || cfg.op != HPGMG_OP_7PT || !ghost_free_mode() || stencil_get_shape() != STENCIL_SHAPE_STAR) return 0;
-  if (L->boundary_condition.type != BC_DIRICHLET || !B->all_faces_local || x_id == VECTOR_TEMP || rhs_id == VECTOR_TEMP) return 0;
-  if (!hpgmg_hip_smooth_cheby_pair_supported(&B->dev, variant()) || !boxes_lexicographic(L)) return 0;
+  if (L->boundary_condition.type != BC_DIRICHLET || x_id == VECTOR_TEMP || rhs_id == VECTOR_TEMP) return 0;
+  if (B->all_faces_local) { if (!hpgmg_hip_smooth_cheby_pair_supported(&B->dev, variant()) || !boxes_lexicographic(L)) return 0; }
+  else if (!pair_halo_ready(L, B)) return 0;          /* faces owned by other ranks: two-deep halo, one exchange per pair */
   { /* the pass structure pays when the level is bandwidth bound; a cache-resident level (128^3 and smaller) is latency
      * bound and faster with many small single-sweep workgroups (measured: 128^3 pair 80 us vs 2 x 27 us) */
     static long long min_cells = -1;
@@ -620,11 +872,16 @@ static int smooth_cheby_pairs(level_type *L, int x_id, int rhs_id, double a, dou
   backend_t *B = backend_of(L);
   const double h2inv = 1.0 / (L->h * L->h);
   const int v = variant();
-  const float *const *c32 = coef32_of(L);
-  TICK(L, smooth, "smooth (2 Chebyshev sweep pairs)");
-  HIP_OK(hpgmg_hip_smooth_cheby_pair(&B->dev, v, (double *const *)B->d_pair_base, c32, 0, x_id, 0, VECTOR_TEMP, 1, 0, 1, 1, rhs_id, a, b, h2inv, c1[0], c2[0], c1[1], c2[1]));
-  HIP_OK(hpgmg_hip_smooth_cheby_pair(&B->dev, v, (double *const *)B->d_pair_base, c32, 1, 1, 1, 0, 0, VECTOR_TEMP, 0, x_id, rhs_id, a, b, h2inv, c1[2], c2[2], c1[3], c2[3]));
-  TOCK();
+  const int remote = !B->all_faces_local;
+  const float *const *c32 = remote ? NULL : coef32_of(L);      /* across ranks the coefficient streams stay fp64 */
+  if (remote) { pair_remote_smooths++; pair_halo_before_launch(L, B, 1, 0, x_id, 0, VECTOR_TEMP, rhs_id); }
+  { TICK(L, smooth, "smooth (Chebyshev sweeps 1+2)");
+    HIP_OK(hpgmg_hip_smooth_cheby_pair(&B->dev, v, (double *const *)B->d_pair_base, c32, 0, x_id, 0, VECTOR_TEMP, 1, 0, 1, 1, rhs_id, a, b, h2inv, c1[0], c2[0], c1[1], c2[1]));
+    TOCK(); }
+  if (remote) pair_halo_before_launch(L, B, 0, 1, 1, 1, 0, rhs_id);
+  { TICK(L, smooth, "smooth (Chebyshev sweeps 3+4)");
+    HIP_OK(hpgmg_hip_smooth_cheby_pair(&B->dev, v, (double *const *)B->d_pair_base, c32, 1, 1, 1, 0, 0, VECTOR_TEMP, 0, x_id, rhs_id, a, b, h2inv, c1[2], c2[2], c1[3], c2[3]));
+    TOCK(); }
   return 1;
 }
 /* in-place GSRB smooth() (gsrb.c:24-132, 4 coloured half sweeps) as two passes of two half sweeps each:
@@ -634,10 +891,15 @@ static int smooth_gsrb_pairs(level_type *L, int x_id, int rhs_id, double a, doub
   backend_t *B = backend_of(L);
   const double h2inv = 1.0 / (L->h * L->h);
   const int v = variant();
-  TICK(L, smooth, "smooth (2 GSRB half-sweep pairs)");
-  HIP_OK(hpgmg_hip_smooth_gsrb_pair(&B->dev, v, (double *const *)B->d_pair_base, NULL, 0, x_id, 0, 1, 1, rhs_id, a, b, h2inv, 0));
-  HIP_OK(hpgmg_hip_smooth_gsrb_pair(&B->dev, v, (double *const *)B->d_pair_base, NULL, 1, 1, 0, 0, x_id, rhs_id, a, b, h2inv, 2));
-  TOCK();
+  const int remote = !B->all_faces_local;
+  if (remote) { pair_remote_smooths++; pair_halo_before_launch(L, B, 1, 0, x_id, 0, x_id, rhs_id); }
+  { TICK(L, smooth, "smooth (GSRB half sweeps 1+2)");
+    HIP_OK(hpgmg_hip_smooth_gsrb_pair(&B->dev, v, (double *const *)B->d_pair_base, NULL, 0, x_id, 0, 1, 1, rhs_id, a, b, h2inv, 0));
+    TOCK(); }
+  if (remote) pair_halo_before_launch(L, B, 0, 1, 1, 1, 1, rhs_id);
+  { TICK(L, smooth, "smooth (GSRB half sweeps 3+4)");
+    HIP_OK(hpgmg_hip_smooth_gsrb_pair(&B->dev, v, (double *const *)B->d_pair_base, NULL, 1, 1, 0, 0, x_id, rhs_id, a, b, h2inv, 2));
+    TOCK(); }
   return 1;
 }
 
@@ -653,6 +915,7 @@ int hpgmg_interp_smooth_fused(level_type *Lf, int e_id, int R_id, level_type *Lc
   if (cfg.smoother != HPGMG_SMOOTH_CHEBY && !(cfg.smoother == HPGMG_SMOOTH_GSRB && !hpgmg_gsrb_out_of_place())) return 0;
   if (S->num_sends || S->num_recvs || Rv->num_sends || Rv->num_recvs || S->num_blocks[0] || Rv->num_blocks[2]) return 0;   /* all parents local */
   if (Lf->box_dim % 128 != 0 || Lc->box_dim * 2 != Lf->box_dim || Lc->num_my_boxes != Lf->num_my_boxes || !boxes_lexicographic(Lc)) return 0;
+  if (!backend_of(Lf)->all_faces_local) return 0;       /* across ranks the pair kernel takes x0 as stored (interpolation stays its own launch) */
   if (!pair_kernel_ready(Lf, e_id, R_id, sweeps)) return 0;
   if (cfg.smoother == HPGMG_SMOOTH_CHEBY && Lf->dominant_eigenvalue_of_DinvA <= 0.0) return 0;
   hpgmg_hip_pair_fold_interpolation(&backend_of(Lc)->dev, e_id, 1.0);

@@ -40,7 +40,14 @@ struct PairArgs {
   const float *const *c32_base;                     // mixed-precision mode: per box, fp32 copies of Dinv, alpha, beta_i, beta_j, beta_k
                                                     // (5 x volume floats, same padded indexing); null in fp64 mode
   int nbi, nbj;                                     // boxes per dimension (lexicographic numbering)
-  int Di, Dj, Dk;                                   // global cells
+  int Di, Dj, Dk;                                   // cells of the brick this rank owns (= the whole domain on one rank)
+  // REMOTE variants (several ranks): faces -i,+i,-j,+j,-k,+k of the brick: 0 = domain boundary (Dirichlet), 1 = owned by another
+  // rank.  Across a remote face x0 is known TWO cells deep -- the ghost zone plus `deep` -- and xm1, rhs and the coefficients one
+  // cell deep (ghost zone; the normal beta of a high-side ghost cell's far face comes from `deep_beta`), so x1 can be formed on
+  // the ghost layer here exactly as the owning rank forms it, and one halo exchange serves both sweeps.
+  int rem[6];
+  const double *deep;                               // [box][face 0..5][v][u]: x0 two cells outside face f (u, v = the in-face axes in i<j<k order)
+  const double *deep_beta;                          // [box][face 1,3,5 -> 0..2][v][u]: beta_i / beta_j / beta_k at local index dim+1
   int tiles_i, slabs_j, chunks_k, KC, per_xcd, total_blocks;
 };
 
@@ -103,8 +110,9 @@ __device__ __forceinline__ p2 pair_update(p2 c, double left, double right, p2 jm
   return o;
 }
 
-template <int V, int NW, bool C32, int SM, bool NARROW, bool INTERP>
+template <int V, int NW, bool C32, int SM, bool NARROW, bool INTERP, bool REMOTE = false>
 __global__ __launch_bounds__(64 * NW) void cheby_pair_kernel(const hpgmg_hip_level L, const PairArgs A) {
+  static_assert(!(REMOTE && (NARROW || INTERP || C32)), "the multi-rank variant is built for whole-row boxes, fp64 coefficients, no folded interpolation");
   constexpr bool kVC = (V != HPGMG_HIP_7PT_CC);
   constexpr bool kHelm = (V == HPGMG_HIP_7PT_VC_HELMHOLTZ);
   constexpr int NR = NW - 2;
@@ -126,7 +134,12 @@ __global__ __launch_bounds__(64 * NW) void cheby_pair_kernel(const hpgmg_hip_lev
   const int NRs = (R + NR <= A.Dj) ? NR : A.Dj - R;          // output rows of this slab
   const int KCs = (K0 + A.KC <= A.Dk) ? A.KC : A.Dk - K0;    // output planes of this chunk
   const int gj = R - 1 + w;
-  const bool row_x1 = (gj >= 0 && gj < A.Dj && w <= NRs + 1);  // this wave computes x1 on its row
+  // rows / planes on which x1 is formed, and on which x0 is known: the brick, plus one (two) layers across a remote face
+  const int jlo = (REMOTE && A.rem[2]) ? -1 : 0, jhi = (REMOTE && A.rem[3]) ? A.Dj + 1 : A.Dj;
+  const int klo = (REMOTE && A.rem[4]) ? -1 : 0, khi = (REMOTE && A.rem[5]) ? A.Dk + 1 : A.Dk;
+  auto x0row = [&](int r) { return r >= ((REMOTE && A.rem[2]) ? -2 : 0) && r < ((REMOTE && A.rem[3]) ? A.Dj + 2 : A.Dj); };
+  auto x0plane = [&](int g) { return g >= ((REMOTE && A.rem[4]) ? -2 : 0) && g < ((REMOTE && A.rem[5]) ? A.Dk + 2 : A.Dk); };
+  const bool row_x1 = (gj >= jlo && gj < jhi && w <= NRs + 1);  // this wave computes x1 on its row
   const bool row_out = (w >= 1 && w <= NRs);                   // ... and x2, and stores both
   // NARROW (boxes of 64, 32 or 16 cells): hop = which of the row's boxes this lane is in; otherwise the shifts fold to zero
   const int lanes_per_box = NARROW ? bd / 2 : 64, hop = NARROW ? lane / lanes_per_box : 0;
@@ -134,21 +147,28 @@ __global__ __launch_bounds__(64 * NW) void cheby_pair_kernel(const hpgmg_hip_lev
   LaneShift sh = {0, 0, 0};
   if (NARROW) { sh.lvl = (long long)hop * L.box_stride; sh.scr = (long long)hop * 2 * L.volume; sh.c32 = (long long)hop * C32_COUNT * L.volume; }
   const int gjc = row_x1 ? gj : 0;
-  const int bj_ = gjc / bd, lj = gjc - bj_ * bd;
+  // box row and local row; a ghost row (REMOTE: gj = -1 or Dj) is row -1 / bd of the brick's first / last box row
+  const int nbj_ = A.Dj / bd, nbk_ = A.Dk / bd;
+  auto jbox = [&](int r) { return !REMOTE ? r / bd : (r < 0 ? 0 : (r >= A.Dj ? nbj_ - 1 : r / bd)); };
+  auto kbox = [&](int g) { return !REMOTE ? g / bd : (g < 0 ? 0 : (g >= A.Dk ? nbk_ - 1 : g / bd)); };
+  const int bj_ = jbox(gjc), lj = gjc - bj_ * bd;
+  const bool ghost_row = REMOTE && (gjc < 0 || gjc >= A.Dj);
   const int row_off = li + lj * jS;                            // offset of this lane's pair inside a plane of its box
   // neighbours in i across the tile edge (lane 0 / lane 63 only)
   const bool left_dom = (gi0 == 0), right_dom = (gi0 + 128 == A.Di);
-  const int biL = left_dom ? bi_ : (gi0 - 1) / bd, liL = left_dom ? 0 : (gi0 - 1) - biL * bd;
-  const int biR = right_dom ? bi_ : (gi0 + 128) / bd, liR = right_dom ? 0 : (gi0 + 128) - biR * bd;
-  // far rows of x0 the two halo waves need from memory
-  const bool far_lo = row_x1 && (w == 0) && (gj - 1 >= 0);
-  const bool far_hi = row_x1 && (w == NRs + 1) && (gj + 1 < A.Dj);
+  const int biL = left_dom ? bi_ : (gi0 - 1) / bd, liL = left_dom ? (REMOTE ? -1 : 0) : (gi0 - 1) - biL * bd;
+  const int biR = right_dom ? bi_ : (gi0 + 128) / bd, liR = right_dom ? (REMOTE ? bd : 0) : (gi0 + 128) - biR * bd;
+  const bool left_ghost = REMOTE && left_dom && A.rem[0], right_ghost = REMOTE && right_dom && A.rem[1];   // read the ghost column instead of -centre
+  // far rows of x0 the two halo waves need from memory (REMOTE: two rows outside the brick = the deep halo)
+  const bool far_lo = row_x1 && (w == 0) && x0row(gj - 1);
+  const bool far_hi = row_x1 && (w == NRs + 1) && x0row(gj + 1);
   const int gjf = far_lo ? gj - 1 : (far_hi ? gj + 1 : gjc);
-  const int bjf = gjf / bd, ljf = gjf - bjf * bd;
+  const bool far_deep = REMOTE && (gjf < -1 || gjf > A.Dj);
+  const int bjf = jbox(gjf), ljf = gjf - bjf * bd;
 
   // pointers of the current plane (wave-uniform: one box per row and plane)
-  auto box_of = [&](int bi, int bj, int gk) { return uni(bi + A.nbi * (bj + A.nbj * (gk / bd))); };
-  auto plane_off = [&](int gk) { return (gk % bd) * kS; };
+  auto box_of = [&](int bi, int bj, int gk) { return uni(bi + A.nbi * (bj + A.nbj * kbox(gk))); };
+  auto plane_off = [&](int gk) { return !REMOTE ? (gk % bd) * kS : (gk - kbox(gk) * bd) * kS; };
   // x0 for the pair starting at local (l_i, l_j) of `box` on global plane gk (INTERP: plus the coarse parent, which the two
   // cells of a pair share), and for a single cell
   auto x0_pair = [&](int box, int l_i, int l_j, int gk) -> p2 {
@@ -164,9 +184,28 @@ __global__ __launch_bounds__(64 * NW) void cheby_pair_kernel(const hpgmg_hip_lev
     if (INTERP) v = A.prescale * v + vec_origin(A.Lc, box, A.coarse_id)[(l_i >> 1) + (l_j >> 1) * A.Lc.jStride + ((gk % bd) >> 1) * A.Lc.kStride];
     return v;
   };
+  // REMOTE: the same pair on ANY plane x0 is known on -- inside, ghost (-1, Dk) or deep (-2, Dk+1).  A deep plane of a ghost row
+  // would be a brick corner: nobody needs it, zeros stand in.
+  auto x0_row = [&](int bj, int l_j, int gk) -> p2 {
+    if (REMOTE && (gk < -1 || gk > A.Dk)) {
+      if (l_j < 0 || l_j >= bd) return p2{0, 0};
+      const int box = box_of(bi_, bj, gk);
+      return pld(A.deep + (((size_t)box * 6 + (gk < 0 ? 4 : 5)) * bd + l_j) * bd + li);
+    }
+    return x0_pair(box_of(bi_, bj, gk), li, l_j, gk);
+  };
+  // the far row of a halo wave on plane gk: memory, or (REMOTE, two rows outside the brick) the deep halo of the j face
+  auto far_row = [&](int gk) -> p2 {
+    if (REMOTE && far_deep) {
+      if (gk < 0 || gk >= A.Dk) return p2{0, 0};               // corner again
+      const int box = box_of(bi_, bjf, gk);
+      return pld(A.deep + (((size_t)box * 6 + (gjf < 0 ? 2 : 3)) * bd + (gk - kbox(gk) * bd)) * bd + li);
+    }
+    return REMOTE ? x0_row(bjf, ljf, gk) : x0_pair(box_of(bi_, bjf, gk), li, ljf, gk);
+  };
 
-  const int P0 = K0 - 1, P1 = K0 + KCs;                         // x1 planes P0..P1 (those inside the domain)
-  auto in_dom = [&](int gk) { return gk >= 0 && gk < A.Dk; };
+  const int P0 = K0 - 1, P1 = K0 + KCs;                         // x1 planes P0..P1 (those x1 is formed on)
+  auto in_dom = [&](int gk) { return gk >= klo && gk < khi; };
 
   p2 x0m = {0, 0}, x0c = {0, 0}, x0p = {0, 0};                  // x0 on planes p-1, p, p+1
   p2 x1m2 = {0, 0}, x1m1 = {0, 0}, x1c = {0, 0};                // x1 on planes p-2, p-1, p
@@ -178,27 +217,28 @@ __global__ __launch_bounds__(64 * NW) void cheby_pair_kernel(const hpgmg_hip_lev
   const int pstart = in_dom(P0) ? P0 : P0 + 1;
   if (row_x1) {
     const int box = box_of(bi_, bj_, pstart), off = row_off + plane_off(pstart);
-    x0c = x0_pair(box, li, lj, pstart);
+    x0c = REMOTE ? x0_row(bj_, lj, pstart) : x0_pair(box, li, lj, pstart);
     if (kVC) bj_c = CoefStream<C32>(L, A, box, VECTOR_BETA_J, C32_BETA_J, sh).pair(off);
-    if (in_dom(pstart - 1)) x0m = x0_pair(box_of(bi_, bj_, pstart - 1), li, lj, pstart - 1);
-    if (far_lo || far_hi) far_c = x0_pair(box_of(bi_, bjf, pstart), li, ljf, pstart);
+    if (x0plane(pstart - 1)) x0m = REMOTE ? x0_row(bj_, lj, pstart - 1) : x0_pair(box_of(bi_, bj_, pstart - 1), li, lj, pstart - 1);
+    if (far_lo || far_hi) far_c = far_row(pstart);
     slabX0[pstart & 1][w][lane] = x0c;
     slabBJ[pstart & 1][w][lane] = bj_c;
   }
   __syncthreads();
 
-  for (int p = pstart; p <= P1 && p < A.Dk; p++) {
+  for (int p = pstart; p <= P1 && p < khi; p++) {
     const int box = box_of(bi_, bj_, p), off = row_off + plane_off(p);
     const bool have_next = in_dom(p + 1) && (p + 1 <= P1);     // plane p+1 is needed as a centre later
-    const bool above_in = in_dom(p + 1);
+    const bool above_in = x0plane(p + 1);
+    const bool ghost_plane = REMOTE && (p < 0 || p >= A.Dk);
     // ---- loads: x0 / beta_j / far row one plane ahead, everything else for plane p
     if (row_x1) {
       if (above_in) {
         const int bn = box_of(bi_, bj_, p + 1), offn = row_off + plane_off(p + 1);
-        x0p = x0_pair(bn, li, lj, p + 1);
+        x0p = REMOTE ? x0_row(bj_, lj, p + 1) : x0_pair(bn, li, lj, p + 1);
         if (have_next) {
           if (kVC) bj_n = CoefStream<C32>(L, A, bn, VECTOR_BETA_J, C32_BETA_J, sh).pair(offn);
-          if (far_lo || far_hi) far_n = x0_pair(box_of(bi_, bjf, p + 1), li, ljf, p + 1);
+          if (far_lo || far_hi) far_n = far_row(p + 1);
         }
       }
       qc.rhs = pld(vec_origin(L, box, A.rhs_id) + sh.lvl + off);
@@ -211,9 +251,13 @@ __global__ __launch_bounds__(64 * NW) void cheby_pair_kernel(const hpgmg_hip_lev
         if (lane == 63) qc.bir = bis.one(off + 2);
         // the lower face is the previous plane's upper face (same address) unless this is the first plane of a box / of the march
         if (p == pstart || (p % bd) == 0) qc.bk0 = bks.pair(off); else qc.bk0 = qp.bk1;
-        qc.bk1 = bks.pair(off + kS);                             // the box's own upper face (ghost plane at the box top)
+        // the box's own upper face (ghost plane at the box top); REMOTE: the far face of a ghost cell above the brick is one
+        // index beyond the ghost zone and comes from the deep coefficient halo
+        if (REMOTE && p >= A.Dk) qc.bk1 = ghost_row ? p2{0, 0} : pld(A.deep_beta + (((size_t)box * 3 + 2) * bd + lj) * bd + li);
+        else qc.bk1 = bks.pair(off + kS);
         qc.bjlo = bj_c;
-        if (w == NRs + 1 || gj + 1 >= A.Dj || ((lj + 1) == bd)) qc.bjhi = CoefStream<C32>(L, A, box, VECTOR_BETA_J, C32_BETA_J, sh).pair(off + jS);
+        if (REMOTE && gj >= A.Dj) qc.bjhi = ghost_plane ? p2{0, 0} : pld(A.deep_beta + (((size_t)box * 3 + 1) * bd + (p - kbox(p) * bd)) * bd + li);
+        else if (w == NRs + 1 || gj + 1 >= jhi || ((lj + 1) == bd)) qc.bjhi = CoefStream<C32>(L, A, box, VECTOR_BETA_J, C32_BETA_J, sh).pair(off + jS);
         else qc.bjhi = slabBJ[p & 1][w + 1][lane];
       }
       p2 xm1 = {0, 0};
@@ -221,15 +265,17 @@ __global__ __launch_bounds__(64 * NW) void cheby_pair_kernel(const hpgmg_hip_lev
 
       // ---- x1 on plane p (first sweep): neighbours of x0
       p2 jm, jp;
-      if (gj - 1 < 0) jm = pneg(x0c); else if (w == 0) jm = far_c; else jm = slabX0[p & 1][w - 1][lane];
-      if (gj + 1 >= A.Dj) jp = pneg(x0c); else if (w == NRs + 1) jp = far_c; else jp = slabX0[p & 1][w + 1][lane];
-      const p2 km = in_dom(p - 1) ? x0m : pneg(x0c);
+      if (!x0row(gj - 1)) jm = pneg(x0c); else if (w == 0) jm = far_c; else jm = slabX0[p & 1][w - 1][lane];
+      if (!x0row(gj + 1)) jp = pneg(x0c); else if (w == NRs + 1) jp = far_c; else jp = slabX0[p & 1][w + 1][lane];
+      const p2 km = x0plane(p - 1) ? x0m : pneg(x0c);
       const p2 kp = above_in ? x0p : pneg(x0c);
       double left = __shfl_up(x0c.y, 1, 64), right = __shfl_down(x0c.x, 1, 64);
-      if (lane == 0)  left  = left_dom  ? -x0c.x : x0_one(box_of(biL, bj_, p), liL, lj, p);
-      if (lane == 63) right = right_dom ? -x0c.y : x0_one(box_of(biR, bj_, p), liR, lj, p);
+      if (lane == 0)  left  = (left_dom && !left_ghost)   ? -x0c.x : x0_one(box_of(biL, bj_, p), liL, lj, p);
+      if (lane == 63) right = (right_dom && !right_ghost) ? -x0c.y : x0_one(box_of(biR, bj_, p), liR, lj, p);
       // GSRB: cell (gi, gj, gk) is swept in half sweep s when (gi ^ gj ^ gk ^ s) is even; a pair starts at an even gi
-      x1c = pair_update<V, SM>(x0c, left, right, jm, jp, km, kp, xm1, qc, A.a, A.b, A.h2inv, A.c1a, A.c2a, ((gj ^ p ^ A.sweep_a) & 1) == 0);
+      // (brick origins are multiples of the box size, so brick-local and global parities agree)
+      if (!(ghost_row && ghost_plane))                          // a ghost row on a ghost plane is a brick edge: x1 there is never read
+        x1c = pair_update<V, SM>(x0c, left, right, jm, jp, km, kp, xm1, qc, A.a, A.b, A.h2inv, A.c1a, A.c2a, ((gj ^ p ^ A.sweep_a) & 1) == 0);
     }
 
     // ---- x2 on plane q = p-1 (second sweep): neighbours of x1; x0 is the older iterate
@@ -237,13 +283,14 @@ __global__ __launch_bounds__(64 * NW) void cheby_pair_kernel(const hpgmg_hip_lev
     if (row_out && q >= K0) {
       const int boxq = box_of(bi_, bj_, q), offq = row_off + plane_off(q);
       p2 jm, jp;
-      if (gj - 1 < 0) jm = pneg(x1m1); else jm = slabX1[q & 1][w - 1][lane];
-      if (gj + 1 >= A.Dj) jp = pneg(x1m1); else jp = slabX1[q & 1][w + 1][lane];
+      if (gj - 1 < jlo) jm = pneg(x1m1); else jm = slabX1[q & 1][w - 1][lane];
+      if (gj + 1 >= jhi) jp = pneg(x1m1); else jp = slabX1[q & 1][w + 1][lane];
       const p2 km = in_dom(q - 1) ? x1m2 : pneg(x1m1);
-      const p2 kp = x1c;                                         // plane p is inside the domain here
+      const p2 kp = x1c;                                         // x1 was formed on plane p
       double left = __shfl_up(x1m1.y, 1, 64), right = __shfl_down(x1m1.x, 1, 64);
-      if (lane == 0)  left  = left_dom  ? -x1m1.x : pair_vec(L, A, A.out1, box_of(biL, bj_, q))[liL + lj * jS + plane_off(q)];
-      if (lane == 63) right = right_dom ? -x1m1.y : pair_vec(L, A, A.out1, box_of(biR, bj_, q))[liR + lj * jS + plane_off(q)];
+      // across a tile edge -- and, REMOTE, across a remote i face -- x1 was written beforehand by cheby_pair_edge_kernel
+      if (lane == 0)  left  = (left_dom && !left_ghost)   ? -x1m1.x : pair_vec(L, A, A.out1, box_of(biL, bj_, q))[liL + lj * jS + plane_off(q)];
+      if (lane == 63) right = (right_dom && !right_ghost) ? -x1m1.y : pair_vec(L, A, A.out1, box_of(biR, bj_, q))[liR + lj * jS + plane_off(q)];
       const p2 x2 = pair_update<V, SM>(x1m1, left, right, jm, jp, km, kp, x0m, qp, A.a, A.b, A.h2inv, A.c1b, A.c2b, ((gj ^ q ^ (A.sweep_a + 1)) & 1) == 0);
       pst(pair_vec(L, A, A.out2, boxq) + shift_of(sh, A.out2) + offq, x2);
     }
@@ -259,18 +306,18 @@ __global__ __launch_bounds__(64 * NW) void cheby_pair_kernel(const hpgmg_hip_lev
   }
 
   // ---- the last output plane when the chunk ends at the top of the domain: x1 above it is the Dirichlet ghost
-  if (P1 >= A.Dk && row_out) {
+  if (P1 >= khi && row_out) {
     const int q = A.Dk - 1;
     if (q >= K0) {
       const int boxq = box_of(bi_, bj_, q), offq = row_off + plane_off(q);
       p2 jm, jp;
-      if (gj - 1 < 0) jm = pneg(x1m1); else jm = slabX1[q & 1][w - 1][lane];
-      if (gj + 1 >= A.Dj) jp = pneg(x1m1); else jp = slabX1[q & 1][w + 1][lane];
+      if (gj - 1 < jlo) jm = pneg(x1m1); else jm = slabX1[q & 1][w - 1][lane];
+      if (gj + 1 >= jhi) jp = pneg(x1m1); else jp = slabX1[q & 1][w + 1][lane];
       const p2 km = in_dom(q - 1) ? x1m2 : pneg(x1m1);
       const p2 kp = pneg(x1m1);
       double left = __shfl_up(x1m1.y, 1, 64), right = __shfl_down(x1m1.x, 1, 64);
-      if (lane == 0)  left  = left_dom  ? -x1m1.x : pair_vec(L, A, A.out1, box_of(biL, bj_, q))[liL + lj * jS + plane_off(q)];
-      if (lane == 63) right = right_dom ? -x1m1.y : pair_vec(L, A, A.out1, box_of(biR, bj_, q))[liR + lj * jS + plane_off(q)];
+      if (lane == 0)  left  = (left_dom && !left_ghost)   ? -x1m1.x : pair_vec(L, A, A.out1, box_of(biL, bj_, q))[liL + lj * jS + plane_off(q)];
+      if (lane == 63) right = (right_dom && !right_ghost) ? -x1m1.y : pair_vec(L, A, A.out1, box_of(biR, bj_, q))[liR + lj * jS + plane_off(q)];
       const p2 x2 = pair_update<V, SM>(x1m1, left, right, jm, jp, km, kp, x0m, qp, A.a, A.b, A.h2inv, A.c1b, A.c2b, ((gj ^ q ^ (A.sweep_a + 1)) & 1) == 0);
       pst(pair_vec(L, A, A.out2, boxq) + shift_of(sh, A.out2) + offq, x2);
     }
@@ -279,21 +326,38 @@ __global__ __launch_bounds__(64 * NW) void cheby_pair_kernel(const hpgmg_hip_lev
 
 // x1 on the cell columns next to interior 128-cell tile edges (gi = 128 t - 1 and 128 t), which the pair kernel
 // reads as i neighbours of the second sweep.  One lane per cell of those columns (0.8 % of the level), lanes along j.
-template <int V, bool C32, int SM, bool INTERP>
+// REMOTE: also on the ghost columns gi = -1 / Di of remote i faces (columns 2 (tiles_i - 1) and + 1), formed from the ghost
+// zone and the deep halo exactly as the owning rank forms its own cells; neighbours across remote j / k faces come from the ghost zone.
+template <int V, bool C32, int SM, bool INTERP, bool REMOTE = false>
 __global__ __launch_bounds__(256) void cheby_pair_edge_kernel(const hpgmg_hip_level L, const PairArgs A) {
   constexpr bool kVC = (V != HPGMG_HIP_7PT_CC);
   constexpr bool kHelm = (V == HPGMG_HIP_7PT_VC_HELMHOLTZ);
   const int gj = blockIdx.x * blockDim.x + threadIdx.x, gk = blockIdx.y, col = blockIdx.z;
   if (gj >= A.Dj) return;
-  const int gi = 128 * (col / 2 + 1) - 1 + (col & 1);
+  const int ncol_in = 2 * (A.tiles_i - 1);
+  int gi;
+  if (col < ncol_in) gi = 128 * (col / 2 + 1) - 1 + (col & 1);
+  else if (REMOTE) { const int which = (col - ncol_in == 0 && A.rem[0]) ? 0 : 1; gi = which ? A.Di : -1; }
+  else return;
   const int bd = L.dim, jS = L.jStride, kS = L.kStride;
+  const int nbi_ = A.Di / bd, nbj_ = A.Dj / bd, nbk_ = A.Dk / bd;
+  auto clampbox = [&](int c, int D, int nb) { return !REMOTE ? c / bd : (c < 0 ? 0 : (c >= D ? nb - 1 : c / bd)); };
   auto cell = [&](int ci, int cj, int ck, int &box) -> int {
-    const int bi = ci / bd, bj = cj / bd, bk = ck / bd;
+    const int bi = clampbox(ci, A.Di, nbi_), bj = clampbox(cj, A.Dj, nbj_), bk = clampbox(ck, A.Dk, nbk_);
     box = bi + A.nbi * (bj + A.nbj * bk);
     return (ci - bi * bd) + (cj - bj * bd) * jS + (ck - bk * bd) * kS;
   };
+  // x0 at a cell that may lie outside the brick: a Dirichlet face gives -centre (apply_BCs_p1); REMOTE: one cell outside a
+  // remote face is the ghost zone, two cells outside (only along i, for the ghost columns) the deep halo
   auto x0_at = [&](int ci, int cj, int ck, double centre) -> double {
-    if (ci < 0 || cj < 0 || ck < 0 || ci >= A.Di || cj >= A.Dj || ck >= A.Dk) return -centre;
+    if (!REMOTE) { if (ci < 0 || cj < 0 || ck < 0 || ci >= A.Di || cj >= A.Dj || ck >= A.Dk) return -centre; }
+    else {
+      if ((ci < 0 && !A.rem[0]) || (ci >= A.Di && !A.rem[1]) || (cj < 0 && !A.rem[2]) || (cj >= A.Dj && !A.rem[3]) || (ck < 0 && !A.rem[4]) || (ck >= A.Dk && !A.rem[5])) return -centre;
+      if (ci < -1 || ci > A.Di) {
+        const int bj = cj / bd, bk = ck / bd, box = ((ci < 0) ? 0 : nbi_ - 1) + A.nbi * (bj + A.nbj * bk);
+        return A.deep[(((size_t)box * 6 + (ci < 0 ? 0 : 1)) * bd + (ck - bk * bd)) * bd + (cj - bj * bd)];
+      }
+    }
     int box; const int idx = cell(ci, cj, ck, box);
     double v = pair_vec(L, A, A.x0, box)[idx];
     if (INTERP) v = A.prescale * v + vec_origin(A.Lc, box, A.coarse_id)[((ci % bd) >> 1) + ((cj % bd) >> 1) * A.Lc.jStride + ((ck % bd) >> 1) * A.Lc.kStride];
@@ -304,7 +368,10 @@ __global__ __launch_bounds__(256) void cheby_pair_edge_kernel(const hpgmg_hip_le
   double bi0 = 0, bi1 = 0, bj0 = 0, bj1 = 0, bk0 = 0, bk1 = 0, al = 0;
   if (kVC) {
     const CoefStream<C32> bi(L, A, box, VECTOR_BETA_I, C32_BETA_I), bj(L, A, box, VECTOR_BETA_J, C32_BETA_J), bk(L, A, box, VECTOR_BETA_K, C32_BETA_K);
-    bi0 = bi.one(idx); bi1 = bi.one(idx + 1); bj0 = bj.one(idx); bj1 = bj.one(idx + jS); bk0 = bk.one(idx); bk1 = bk.one(idx + kS);
+    bi0 = bi.one(idx); bj0 = bj.one(idx); bj1 = bj.one(idx + jS); bk0 = bk.one(idx); bk1 = bk.one(idx + kS);
+    // the far face of a ghost cell beyond the high i face is one index past the ghost zone: deep coefficient halo
+    if (REMOTE && gi >= A.Di) bi1 = A.deep_beta[(((size_t)box * 3 + 0) * bd + (gk % bd)) * bd + (gj % bd)];
+    else bi1 = bi.one(idx + 1);
   }
   if (kHelm) al = CoefStream<C32>(L, A, box, VECTOR_ALPHA, C32_ALPHA).one(idx);
   const double Ax = apply_op_7pt<V>(xc, x0_at(gi - 1, gj, gk, xc), x0_at(gi + 1, gj, gk, xc), x0_at(gi, gj - 1, gk, xc), x0_at(gi, gj + 1, gk, xc),

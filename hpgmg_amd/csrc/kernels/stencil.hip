@@ -709,6 +709,32 @@ static int launch(const hpgmg_hip_level *L, int variant, StencilArgs P, bool is_
   return 0;
 }
 
+// ---- halo of a sweep pair across rank boundaries: regions of x0 / xm1 / rhs (or a level vector) <-> one message buffer ----
+struct HaloRefs { VecRef x0, xm1; int rhs_id; double *const *scr_base; };
+__device__ __forceinline__ double *halo_vec(const hpgmg_hip_level &L, const HaloRefs &R, int vec, int box) {
+  const size_t first = (size_t)L.ghosts * (size_t)(1 + L.jStride + L.kStride);
+  if (vec >= 16) return L.box_base[box] + (size_t)(vec - 16) * (size_t)L.volume + first;
+  if (vec == 2) return L.box_base[box] + (size_t)R.rhs_id * (size_t)L.volume + first;
+  const VecRef r = (vec == 0) ? R.x0 : R.xm1;
+  return (r.scratch ? R.scr_base[box] : L.box_base[box]) + (size_t)r.id * (size_t)L.volume + first;
+}
+template <bool kUnpack>
+__global__ __launch_bounds__(256) void pair_halo_kernel(const hpgmg_hip_level L, const HaloRefs R, const hpgmg_hip_halo_entry *__restrict__ list,
+                                                        double *buf, double *deep, double *deep_beta) {
+  const hpgmg_hip_halo_entry e = list[blockIdx.x];
+  const int n = e.ni * e.nj * e.nk, jS = L.jStride, kS = L.kStride;
+  double *v = halo_vec(L, R, e.vec, e.box) + e.i + e.j * jS + e.k * kS;
+  double *b = buf + e.off;
+  double *plane = nullptr;
+  if (kUnpack && e.deep >= 8) plane = deep_beta + ((size_t)e.box * 3 + (e.deep - 8)) * (size_t)L.dim * L.dim;
+  else if (kUnpack && e.deep >= 0) plane = deep + ((size_t)e.box * 6 + e.deep) * (size_t)L.dim * L.dim;
+  for (int t = blockIdx.y * 256 + threadIdx.x; t < n; t += gridDim.y * 256) {
+    const int ti = t % e.ni, tj = (t / e.ni) % e.nj, tk = t / (e.ni * e.nj);
+    if (!kUnpack) b[t] = v[ti + tj * jS + tk * kS];
+    else if (plane) plane[t] = b[t];
+    else v[ti + tj * jS + tk * kS] = b[t];
+  }
+}
 }  // namespace hpgmg
 using namespace hpgmg;
 
@@ -739,15 +765,21 @@ int hpgmg_hip_smooth_cheby(const hpgmg_hip_level *L, int variant, int xn_id, int
 // Two Chebyshev sweeps in one pass (cheby_pair.hpp).  Vector references are (scratch?, id) pairs: scratch ids 0/1
 // address the two plugin-private vectors behind scr_base.  Returns hipErrorNotSupported-like status 1 (no launch,
 // no error recorded) when the level does not fit the kernel's assumptions, so the caller can fall back.
-int hpgmg_hip_smooth_cheby_pair_supported(const hpgmg_hip_level *L, int variant) {
+static int pair_supported_dims(const hpgmg_hip_level *L, int variant, int Di, int Dj, int Dk) {
   if (variant != HPGMG_HIP_7PT_VC_HELMHOLTZ && variant != HPGMG_HIP_7PT_VC_POISSON && variant != HPGMG_HIP_7PT_CC) return 0;
-  if (L->num_boxes <= 0 || L->periodic || !(L->flags & 1) || L->ghosts < 1 || L->dim_i % 128 != 0) return 0;
+  if (L->num_boxes <= 0 || L->periodic || !(L->flags & 1) || L->ghosts < 1 || Di % 128 != 0) return 0;
   // a wave owns a 128-cell row: whole multiples of 128 per box, or several boxes (consecutive in one slab) per row
   if (L->dim % 128 != 0 && !(128 % L->dim == 0 && L->dim >= 16 && (L->box_stride > 0 || L->num_boxes == 1))) return 0;
   if (L->jStride % 2 || L->kStride % 2 || L->volume % 2) return 0;
-  if (L->dim_i % L->dim || L->dim_j % L->dim || L->dim_k % L->dim) return 0;
-  if ((long long)(L->dim_i / L->dim) * (L->dim_j / L->dim) * (L->dim_k / L->dim) != L->num_boxes) return 0;
+  if (Di % L->dim || Dj % L->dim || Dk % L->dim) return 0;
+  if ((long long)(Di / L->dim) * (Dj / L->dim) * (Dk / L->dim) != L->num_boxes) return 0;
   return 1;
+}
+int hpgmg_hip_smooth_cheby_pair_supported(const hpgmg_hip_level *L, int variant) { return pair_supported_dims(L, variant, L->dim_i, L->dim_j, L->dim_k); }
+// several ranks: this rank's boxes form a brick of nbi x nbj x nbk boxes (numbered lexicographically inside it)
+int hpgmg_hip_smooth_cheby_pair_supported_brick(const hpgmg_hip_level *L, int variant, int nbi, int nbj, int nbk) {
+  if (L->dim % 128 != 0) return 0;
+  return pair_supported_dims(L, variant, nbi * L->dim, nbj * L->dim, nbk * L->dim);
 }
 int hpgmg_hip_coef32_refresh(const hpgmg_hip_level *L, float *const *c32_base, int num_vectors) {
   HPGMG_SKIP_IF_REPLAY();
@@ -757,6 +789,11 @@ int hpgmg_hip_coef32_refresh(const hpgmg_hip_level *L, float *const *c32_base, i
   return 0;
 }
 // interpolation_vcycle folded into the NEXT sweep-pair launch (consumed by it): x0 := prescale * x0 + parent(coarse_id of Lc)
+// remote faces of the NEXT sweep-pair launch (consumed by it): see hpgmg_hip_pair_set_halo
+static bool g_pair_halo_set = false;
+static int g_pair_rem[6], g_pair_brick[3];
+static const double *g_pair_deep = nullptr, *g_pair_deep_beta = nullptr;
+static long long g_pair_launches = 0, g_pair_remote_launches = 0;
 static const hpgmg_hip_level *g_pair_interp_level = nullptr;
 static int g_pair_interp_id = 0;
 static double g_pair_interp_prescale = 1.0;
@@ -764,17 +801,21 @@ static int smooth_pair(const hpgmg_hip_level *L, int variant, int gsrb, int swee
                        int x0_scr, int x0_id, int xm1_scr, int xm1_id, int out1_scr, int out1_id, int out2_scr, int out2_id,
                        int rhs_id, double a, double b, double h2inv, double c1a, double c2a, double c1b, double c2b) {
   HPGMG_SKIP_IF_REPLAY();
-  if (!hpgmg_hip_smooth_cheby_pair_supported(L, variant)) return record_error(hipErrorInvalidValue, "smooth_cheby_pair: level not supported");
+  const bool remote = g_pair_halo_set;
+  g_pair_halo_set = false;
+  const int Di = remote ? g_pair_brick[0] * L->dim : L->dim_i, Dj = remote ? g_pair_brick[1] * L->dim : L->dim_j, Dk = remote ? g_pair_brick[2] * L->dim : L->dim_k;
+  if (!pair_supported_dims(L, variant, Di, Dj, Dk)) return record_error(hipErrorInvalidValue, "smooth_cheby_pair: level not supported");
+  if (remote && (L->dim % 128 != 0 || c32_base || g_pair_interp_level)) return record_error(hipErrorInvalidValue, "smooth_cheby_pair: remote faces need whole-row boxes, fp64 coefficients, no folded interpolation");
   static const int tune_kc = env_int("HPGMG_TUNE_PAIR_KC", 0);
   constexpr int nw = 16;
   // k chunk: every workgroup costs KC+2 plane steps and (at 128 VGPRs, 16 waves) one workgroup occupies a CU, so the
   // launch takes ceil(workgroups / 256) rounds of KC+2 steps: pick the KC that minimises that product
   int kc = tune_kc;
   if (kc <= 0) {
-    const int per_plane = (L->dim_i / 128) * ((L->dim_j + (nw - 2) - 1) / (nw - 2)), slots = 256;
+    const int per_plane = (Di / 128) * ((Dj + (nw - 2) - 1) / (nw - 2)), slots = 256;
     long long best = -1;
-    for (int c = 8; c <= 64 && c <= L->dim_k; c++) {
-      const long long wgs = (long long)per_plane * ((L->dim_k + c - 1) / c), cost = ((wgs + slots - 1) / slots) * (c + 2);
+    for (int c = 8; c <= 64 && c <= Dk; c++) {
+      const long long wgs = (long long)per_plane * ((Dk + c - 1) / c), cost = ((wgs + slots - 1) / slots) * (c + 2);
       if (best < 0 || cost < best) { best = cost; kc = c; }
     }
   }
@@ -789,8 +830,9 @@ static int smooth_pair(const hpgmg_hip_level *L, int variant, int gsrb, int swee
     if (L->dim % 128 != 0 || C->num_boxes != L->num_boxes || 2 * C->dim != L->dim) return record_error(hipErrorInvalidValue, "smooth pair with interpolation: level pair not supported");
     A.Lc = *C; A.coarse_id = g_pair_interp_id; A.prescale = g_pair_interp_prescale;
   }
-  A.nbi = L->dim_i / L->dim; A.nbj = L->dim_j / L->dim;
-  A.Di = L->dim_i; A.Dj = L->dim_j; A.Dk = L->dim_k;
+  A.nbi = Di / L->dim; A.nbj = Dj / L->dim;
+  A.Di = Di; A.Dj = Dj; A.Dk = Dk;
+  if (remote) { for (int d = 0; d < 6; d++) A.rem[d] = g_pair_rem[d]; A.deep = g_pair_deep; A.deep_beta = g_pair_deep_beta; }
   A.tiles_i = A.Di / 128; A.slabs_j = (A.Dj + (nw - 2) - 1) / (nw - 2); A.KC = kc; A.chunks_k = (A.Dk + kc - 1) / kc;
   A.total_blocks = A.tiles_i * A.slabs_j * A.chunks_k;
   const int grid = grid_for(A.total_blocks, &A.per_xcd);
@@ -800,9 +842,15 @@ static int smooth_pair(const hpgmg_hip_level *L, int variant, int gsrb, int swee
 #define PAIR_LAUNCH2(VAR, C32, SM, NARROW, INTERP) { \
       static bool once = false; if (!once) { HPGMG_CHECK(hipFuncSetAttribute((const void *)cheby_pair_kernel<VAR, nw, C32, SM, NARROW, INTERP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once = true; } \
       hipLaunchKernelGGL((cheby_pair_kernel<VAR, nw, C32, SM, NARROW, INTERP>), dim3(grid), dim3(64, nw), lds, g_stream, *L, A); }
+#define PAIR_LAUNCH_REMOTE(VAR, SM) { \
+      static bool once = false; if (!once) { HPGMG_CHECK(hipFuncSetAttribute((const void *)cheby_pair_kernel<VAR, nw, false, SM, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once = true; } \
+      const int ecols = 2 * (A.tiles_i - 1) + (A.rem[0] ? 1 : 0) + (A.rem[1] ? 1 : 0); \
+      if (ecols > 0) hipLaunchKernelGGL((cheby_pair_edge_kernel<VAR, false, SM, false, true>), dim3((A.Dj + 63) / 64, A.Dk, ecols), dim3(64), 0, g_stream, *L, A); \
+      hipLaunchKernelGGL((cheby_pair_kernel<VAR, nw, false, SM, false, false, true>), dim3(grid), dim3(64, nw), lds, g_stream, *L, A); }
 #define PAIR_LAUNCH(VAR, C32, SM) { \
       const dim3 egrid((A.Dj + 63) / 64, A.Dk, 2 * (A.tiles_i - 1)); \
-      if (interp) { \
+      if (remote) PAIR_LAUNCH_REMOTE(VAR, SM) \
+      else if (interp) { \
         if (A.tiles_i > 1) hipLaunchKernelGGL((cheby_pair_edge_kernel<VAR, C32, SM, true>), egrid, dim3(64), 0, g_stream, *L, A); \
         PAIR_LAUNCH2(VAR, C32, SM, false, true) \
       } else { \
@@ -821,6 +869,8 @@ static int smooth_pair(const hpgmg_hip_level *L, int variant, int gsrb, int swee
 #undef PAIR_CASE
 #undef PAIR_LAUNCH
 #undef PAIR_LAUNCH2
+#undef PAIR_LAUNCH_REMOTE
+  g_pair_launches++; if (remote) g_pair_remote_launches++;
   profile_end(prof, 2 * cells);                      // one launch = two sweeps over every cell
   HPGMG_LAUNCH_CHECK("cheby_pair_kernel");
   return 0;
@@ -833,6 +883,34 @@ int hpgmg_hip_smooth_cheby_pair(const hpgmg_hip_level *L, int variant, double *c
 void hpgmg_hip_pair_fold_interpolation(const hpgmg_hip_level *Lc, int coarse_id, double prescale) {
   g_pair_interp_level = Lc; g_pair_interp_id = coarse_id; g_pair_interp_prescale = prescale;
 }
+void hpgmg_hip_pair_set_halo(const int brick_boxes[3], const int remote_face[6], const double *deep, const double *deep_beta) {
+  for (int d = 0; d < 3; d++) g_pair_brick[d] = brick_boxes[d];
+  for (int d = 0; d < 6; d++) g_pair_rem[d] = remote_face[d];
+  g_pair_deep = deep; g_pair_deep_beta = deep_beta; g_pair_halo_set = true;
+}
+void hpgmg_hip_pair_launch_counts(long long out[2]) { out[0] = g_pair_launches; out[1] = g_pair_remote_launches; }
+
+// ---- the halo of a sweep pair across rank boundaries: one pack launch, one grouped send/recv, one unpack launch ----
+static int pair_halo_move(bool unpack, const hpgmg_hip_level *L, double *const *scr_base, int x0_scr, int x0_id, int xm1_scr, int xm1_id, int rhs_id,
+                          const hpgmg_hip_halo_entry *entries, int n, double *buf, double *deep, double *deep_beta) {
+  HPGMG_SKIP_IF_REPLAY();
+  if (n <= 0) return 0;
+  HaloRefs R; R.x0 = VecRef{x0_scr, x0_id}; R.xm1 = VecRef{xm1_scr, xm1_id}; R.rhs_id = rhs_id; R.scr_base = scr_base;
+  const int slabs = (L->dim * L->dim + 4095) / 4096;                 // a face of dim^2 values: 16 values per lane
+  if (unpack) hipLaunchKernelGGL((pair_halo_kernel<true>), dim3(n, slabs), dim3(256), 0, g_stream, *L, R, entries, buf, deep, deep_beta);
+  else        hipLaunchKernelGGL((pair_halo_kernel<false>), dim3(n, slabs), dim3(256), 0, g_stream, *L, R, entries, buf, deep, deep_beta);
+  HPGMG_LAUNCH_CHECK("pair_halo_kernel");
+  return 0;
+}
+int hpgmg_hip_pair_halo_pack(const hpgmg_hip_level *L, double *const *scr_base, int x0_scr, int x0_id, int xm1_scr, int xm1_id, int rhs_id,
+                             const hpgmg_hip_halo_entry *entries, int n, double *sendbuf) {
+  return pair_halo_move(false, L, scr_base, x0_scr, x0_id, xm1_scr, xm1_id, rhs_id, entries, n, sendbuf, nullptr, nullptr);
+}
+int hpgmg_hip_pair_halo_unpack(const hpgmg_hip_level *L, double *const *scr_base, int x0_scr, int x0_id, int xm1_scr, int xm1_id, int rhs_id,
+                               const hpgmg_hip_halo_entry *entries, int n, double *recvbuf, double *deep, double *deep_beta) {
+  return pair_halo_move(true, L, scr_base, x0_scr, x0_id, xm1_scr, xm1_id, rhs_id, entries, n, recvbuf, deep, deep_beta);
+}
+
 // two consecutive in-place GSRB half sweeps (sweep, sweep + 1): x2 -> out2; the scratch vector `edge_scr_id` receives the
 // few x1 values the kernel exchanges across 128-cell tile edges
 int hpgmg_hip_smooth_gsrb_pair(const hpgmg_hip_level *L, int variant, double *const *scr_base, const float *const *c32_base,

@@ -120,6 +120,26 @@ int hpgmg_hip_smooth_cheby_pair_supported(const hpgmg_hip_level *L, int variant)
 int hpgmg_hip_smooth_cheby_pair(const hpgmg_hip_level *L, int variant, double *const *scr_base, const float *const *c32_base,
                                 int x0_scr, int x0_id, int xm1_scr, int xm1_id, int out1_scr, int out1_id, int out2_scr, int out2_id,
                                 int rhs_id, double a, double b, double h2inv, double c1a, double c2a, double c1b, double c2b);
+/* Sweep pairs across rank boundaries (boxes over the GPUs of a node, halo exchange over RCCL).  This rank's boxes form a
+ * brick of brick_boxes[0..2] boxes (numbered lexicographically inside it); remote_face[f] (f = -i,+i,-j,+j,-k,+k) is 1 where the
+ * brick face belongs to another rank, 0 where it is the (Dirichlet) domain boundary.  Before the launch the caller must have
+ * brought, across every remote face: x0 two cells deep (ghost zone + `deep`), xm1, the right-hand side and every coefficient
+ * vector one cell deep (ghost zones; x0 also on the brick's edges), and `deep_beta` = the normal beta component at index dim+1 on
+ * the high faces.  The kernel then forms x1 on the ghost layer itself -- the same expression the owning rank evaluates -- so ONE
+ * exchange serves TWO sweeps (reference: one exchange_boundary per sweep, chebyshev.c:45-46).  Consumed by the next
+ * hpgmg_hip_smooth_cheby_pair / _gsrb_pair launch.  Layouts: deep[box][face 0..5][v][u], deep_beta[box][0..2 = +i,+j,+k][v][u],
+ * planes of dim x dim values, (u, v) = the two in-face axes in i < j < k order. */
+int  hpgmg_hip_smooth_cheby_pair_supported_brick(const hpgmg_hip_level *L, int variant, int nbi, int nbj, int nbk);
+void hpgmg_hip_pair_set_halo(const int brick_boxes[3], const int remote_face[6], const double *deep, const double *deep_beta);
+void hpgmg_hip_pair_launch_counts(long long out[2]);      /* sweep-pair launches so far: all, and those with remote faces (tests) */
+/* One region of a sweep-pair halo message.  vec: 0 = the pair's x0, 1 = its xm1, 2 = its right-hand side, 16 + id = level vector id.
+ * Pack copies the region (i fastest) to sendbuf + off; unpack copies recvbuf + off into the region (deep = -1: ghost cells at
+ * (i,j,k)), into deep plane `deep` (0..5) or into deep_beta plane deep - 8 (8..10) of the box. */
+typedef struct { int box, vec, i, j, k, ni, nj, nk, deep, pad_; long long off; } hpgmg_hip_halo_entry;
+int  hpgmg_hip_pair_halo_pack(const hpgmg_hip_level *L, double *const *scr_base, int x0_scr, int x0_id, int xm1_scr, int xm1_id, int rhs_id,
+                              const hpgmg_hip_halo_entry *entries, int n, double *sendbuf);
+int  hpgmg_hip_pair_halo_unpack(const hpgmg_hip_level *L, double *const *scr_base, int x0_scr, int x0_id, int xm1_scr, int xm1_id, int rhs_id,
+                                const hpgmg_hip_halo_entry *entries, int n, double *recvbuf, double *deep, double *deep_beta);
 /* Two consecutive in-place GSRB half sweeps (gsrb.c:24-132, colours `sweep` and `sweep + 1`) in one pass: reads x0, writes the
  * result to out2 (which must differ from x0); scratch vector edge_scr_id (0/1 behind scr_base) is clobbered. */
 int hpgmg_hip_smooth_gsrb_pair(const hpgmg_hip_level *L, int variant, double *const *scr_base, const float *const *c32_base,

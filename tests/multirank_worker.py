@@ -103,6 +103,11 @@ def main():
     if backend == "hip":
         be.lib.hpgmg_overlap_count.restype = ctypes.c_longlong
         stats["overlapped_exchanges"] = be.lib.hpgmg_overlap_count()
+        be.lib.hpgmg_pair_remote_smooths.restype = ctypes.c_longlong
+        stats["pair_remote_smooths"] = be.lib.hpgmg_pair_remote_smooths()      # smooth() calls run as sweep pairs across rank boundaries
+        counts = (ctypes.c_longlong * 2)()
+        K.hpgmg_hip_pair_launch_counts(counts)
+        stats["pair_launches"], stats["pair_remote_launches"] = counts[0], counts[1]
     s.destroy()
     print("RESULT " + json.dumps({"rank": rank, "norms": ["%1.15e" % v for v in norms], "err": "%1.15e" % err,
                                   "order": "%0.3f" % order, "levels": levels, "stats": stats, "repeat": repeat}), flush=True)

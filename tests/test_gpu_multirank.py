@@ -41,6 +41,28 @@ def test_hip_multirank_matches_single_rank_reference(world, variant, log2, per_r
         assert all(r["stats"]["overlapped_exchanges"] > 20 for r in res), [r["stats"] for r in res]
 
 
+@pytest.mark.parametrize("world,variant,log2,per_rank,gold_key", [
+    (2, "7pt-cheby-helm", 7, 4, "7pt-cheby-helm 7 8"),     # bench.py --gpus 2: bricks of 2 x 2 x 1 boxes, one remote k face
+    (4, "7pt-cheby-helm", 7, 2, "7pt-cheby-helm 7 8"),     # bench.py --gpus 4: bricks of 2 x 1 x 1 boxes, remote j and k faces + the edge between them
+    (8, "7pt-cheby-helm", 7, 1, "7pt-cheby-helm 7 8"),     # bench.py --gpus 8: one box per rank, three remote faces and three edges each
+    (2, "7pt-gsrb", 7, 4, "7pt-gsrb 7 8"),
+    (4, "7pt-cheby", 7, 2, "7pt-cheby 7 8"),
+])
+def test_sweep_pairs_across_rank_boundaries(world, variant, log2, per_rank, gold_key):
+    """north_star's strong-scaling series (256^3 on 2 / 4 / 8 ranks): the fine-level smoother must stay the two-sweeps-per-pass
+    kernel when faces belong to other ranks -- x0 exchanged two cells deep ONCE per sweep pair (chebyshev.c:45-46 exchanges once per
+    sweep), x1 on the ghost layer recomputed locally -- and still reproduce the single-rank reference numbers to the last digit."""
+    gold = GOLD[gold_key]
+    res = run_job(world, variant, log2, per_rank, backend="hip")
+    assert res[0]["norms"] == gold["norms"], res[0]
+    assert res[0]["err"] == gold["richardson_error"] and res[0]["order"] == gold["order"]
+    assert res[0]["repeat"] == [gold["norms"][0]] * 3, res[0]["repeat"]
+    for r in res:
+        # 4 timed f-cycles at h (three_sizes, richardson, 3 repeats - 1) x 2 smooth() calls on the fine level, at least
+        assert r["stats"]["pair_remote_smooths"] >= 8, r["stats"]
+        assert r["stats"]["pair_remote_launches"] == 2 * r["stats"]["pair_remote_smooths"], r["stats"]
+
+
 @pytest.mark.parametrize("world,variant,log2,per_rank,gold_key,gather", [
     (2, "7pt-cheby-helm", 4, 4, "7pt-cheby-helm 4 8", 16),
     (4, "7pt-cheby", 4, 8, "7pt-cheby 4 27", 24),
