@@ -136,6 +136,23 @@ def test_hip_equals_oracle_live(hip, oracle):
         sh.destroy(); so.destroy()
 
 
+@pytest.mark.parametrize("variant,args", [("7pt-cheby-helm", "8 8"), ("7pt-cheby", "8 8"), ("27pt-gsrb", "7 8"), ("27pt-gsrb", "7 64"), ("fv4-gsrb", "7 64")])
+def test_hip_fcycle_at_the_stated_sizes_of_configs_3_and_4(hip, variant, args):
+    """BASELINE.json config 4 (`8 8`: 512^3 in 8 boxes of 256^3) and config 3 (`7 64`: 512^3 in 64 boxes of 128^3, GSRB, 4th-order fv4
+    and 27-point operators) as whole F-cycles at h, 2h, 4h + Richardson, against what the reference binary printed for exactly these
+    arguments (tests/golden/make_golden.py; single-rank reading of the 8-GPU configurations: one MI355X holds the 512^3 problem)."""
+    gold = GOLD[f"{variant} {args}"]
+    hip.configure(**VARIANTS[variant])
+    log2, per_rank = map(int, args.split())
+    s = hip.solver_cli(log2, per_rank)
+    try:
+        assert [fmt(v) for v in s.three_sizes()] == gold["norms"]
+        err, order = s.richardson()
+        assert fmt(err) == gold["richardson_error"] and "%0.3f" % order == gold["order"]
+    finally:
+        s.destroy()
+
+
 def test_timing_table_is_device_time(hip):
     """Per-level 'Total' rows filled from hipEvent pairs (HPGMG_TIMERS=device): they must account for the solve --
     the sum over levels within 10 % of the wall time of the timed solves (reference table: mg.c:54-161), every
