@@ -227,17 +227,27 @@ def main():
     if rank == 0:
         sec_per_step = elapsed / args.steps
         roof = None
-        if launches.value > 0 and ms.value > 0 and args.workload in ("config2", "config4", "config5"):
+        # SURVEY 8(d) algorithmic bytes per cell per sweep of the fine-level smoother kernel each workload spends most of its time in
+        smoother = {"config1": (40, "7-pt constant-coefficient Chebyshev sweep (stencil7_kernel): x_n, x_nm1, rhs, Dinv read + x_np1 written"),
+                    "config2": (BYTES_PER_CELL_CHEBY_HELMHOLTZ, "hpgmg::cheby_pair_kernel<VC Helmholtz> (+ its edge-column pre-pass): one launch = TWO Chebyshev sweeps"),
+                    "config4": (BYTES_PER_CELL_CHEBY_HELMHOLTZ, "hpgmg::cheby_pair_kernel<VC Helmholtz> (+ its edge-column pre-pass): one launch = TWO Chebyshev sweeps"),
+                    "config5": (52, "hpgmg::cheby_pair_kernel<VC Helmholtz, fp32 coefficient streams> (+ pre-pass): one launch = TWO Chebyshev sweeps"),
+                    "config3-fv4": (56, "hpgmg::fv4_tile_kernel<VC Poisson, GSRB>: one out-of-place coloured half sweep (x, rhs, Dinv, beta_i/j/k read + x written)"),
+                    "config3-27pt": (32, "hpgmg::stencil27_kernel<GSRB>: one out-of-place coloured half sweep (x, rhs, Dinv read + x written)")}[args.workload]
+        if launches.value > 0 and ms.value > 0:
             avg_s = ms.value * 1e-3 / launches.value
-            # mixed precision: Dinv, alpha, beta_i/j/k are 4-byte streams -> 72 - 5*4 = 52 B per cell per sweep
-            bytes_per_launch = (52 if mixed else BYTES_PER_CELL_CHEBY_HELMHOLTZ) * (cells.value / launches.value)
+            # cells.value counts cell-sweeps: the sweep-pair kernel reports two sweeps per launch
+            bytes_per_launch = smoother[0] * (cells.value / launches.value)
             achieved = bytes_per_launch / avg_s / 1e9
+            traffic = pmc_traffic() if args.workload == "config2" and world == 1 else None
             roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None if mixed else pmc_traffic(),
-                    "kernel": "hpgmg::cheby_pair_kernel<VC Helmholtz> (+ its edge-column pre-pass) on the finest level: one launch = TWO Chebyshev sweeps over 8 boxes of 128^3",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "kernel": smoother[1] + f" over the {my_boxes} finest-level boxes of {box_dim}^3 of this rank",
                     "sweeps_per_launch": round(cells.value / launches.value / fine_cells, 3),
                     "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_us": round(avg_s * 1e6, 2),
-                    "launches_timed": launches.value}
+                    "launches_timed": launches.value,
+                    # what the launch really moves (rocprofv3 PMC, profiles/*_pmc_summary.json): DRAM-level rate, next to the algorithmic one above
+                    "dram_GBs_from_pmc": round(traffic / avg_s / 1e9, 1) if traffic else None}
         line = {
             "metric": "DOF/s (fine-grid) for FMG F-cycle", "value": dof / sec_per_step, "unit": "DOF/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": sec_per_step * 1e3,

@@ -1,0 +1,169 @@
+// fv4_tile.hpp -- the 4th-order finite-volume operator (reference operators.fv4.c:55-134) as an LDS-tiled, k-marching kernel.
+//
+// The 25-point variable-coefficient stencil reads, per updated cell, 25 values of x and 30 face coefficients.  Read through
+// the vector L1 (stencil_direct_kernel, the first version) that is ~58 eight-byte loads per update and the kernel is bound by
+// the L1 / texture-address path at ~9 TB/s of cache traffic (3.3 ms per half sweep at 512^3 = 28 % of the HBM roofline).
+// Here a workgroup owns a 64 (i) x TJ (j) tile of one box and marches in +k:
+//   * planes k-1, k, k+1 of x, beta_i, beta_j and faces k, k+1 of beta_k live in LDS with a 2-cell halo (ring buffers;
+//     11 tiles of (TJ+4) x 68 doubles = 72 KB for TJ = 8, two workgroups per CU);
+//   * every value enters LDS ONCE per workgroup: a lane brings its own column (the x value from a register it loaded three
+//     steps earlier -- x[k-2..k+3] of its own column slide through registers, which also serve the +-2 k neighbours) and at
+//     most one halo cell per array; all global loads are issued one step before they are stored (their latency overlaps the
+//     arithmetic of the current plane);
+//   * the update reads its 50 neighbours from LDS (conflict free: a wave reads 64 consecutive doubles).
+// Arithmetic: the expression tree of the reference macro, term by term (T * (6 face terms) + (0.25 T) * (12 mixed terms),
+// every group summed left to right, a mixed term = (beta+ - beta-) * (((x1 - x2) - x3) + x4)), so results are bit-identical
+// to the direct kernel and to the reference (tests/test_gpu_operators.py, tests/test_gpu_fcycle_parity.py).
+// Ghost cells (depth 2) and the extrapolated coefficient ghosts are read exactly where the reference reads them; the caller has
+// run exchange_boundary + apply_BCs_v4 (NO_CORNERS) before, as smooth()/residual() of operators.fv4.c do.
+#pragma once
+#include "common.hpp"
+
+namespace hpgmg {
+
+#ifndef FV4_TWELFTH
+#define FV4_TWELFTH ( 0.0833333333333333333)
+#endif
+
+struct Fv4TileArgs {
+  int xn_id, xout_id, rhs_id;
+  double a, b, h2inv, c1, c2;
+  int sweep, copy_other_colour;
+  int tiles_i, tiles_j, chunks_k, kchunk, per_xcd, total_blocks;
+};
+enum { FV4_CHEBY = 0, FV4_GSRB = 1, FV4_JACOBI = 2, FV4_RESIDUAL = 3, FV4_APPLY = 4 };
+
+template <int V, int MODE, int TJ>
+__global__ __launch_bounds__(64 * TJ) void fv4_tile_kernel(const hpgmg_hip_level L, const Fv4TileArgs P) {
+  constexpr int TI = 64, W = TI + 4, H = TJ + 4, NT = 64 * TJ, PLANE = W * H;
+  constexpr int NH = 4 * W + 4 * TJ;                           // halo cells of one plane tile (two rows above and below, two columns left and right)
+  static_assert(NH <= NT, "one halo cell per lane at most");
+  constexpr bool kHelm = (V == HPGMG_HIP_FV4_VC_HELMHOLTZ);
+  constexpr bool kSmooth = (MODE == FV4_CHEBY || MODE == FV4_GSRB || MODE == FV4_JACOBI);
+  extern __shared__ double fv4_lds[];
+  double *sX = fv4_lds, *sBI = fv4_lds + 3 * PLANE, *sBJ = fv4_lds + 6 * PLANE, *sBK = fv4_lds + 9 * PLANE;   // rings of 3, 3, 3, 2 plane tiles
+
+  const int logical = xcd_logical_block((int)blockIdx.x, P.per_xcd);
+  if (logical >= P.total_blocks) return;
+  int t = logical;
+  const int ti = t % P.tiles_i; t /= P.tiles_i;
+  const int tj = t % P.tiles_j; t /= P.tiles_j;
+  const int ck = t % P.chunks_k; t /= P.chunks_k;
+  const int box = t;
+  const int li = (int)threadIdx.x, lj = (int)threadIdx.y, tid = lj * 64 + li;
+  const int i0 = ti * TI, j0 = tj * TJ, i = i0 + li, j = j0 + lj;
+  const int k0 = ck * P.kchunk, k1 = (k0 + P.kchunk < L.dim) ? k0 + P.kchunk : L.dim;
+  const int jS = L.jStride, kS = L.kStride;
+
+  const double *__restrict__ x = vec_origin(L, box, P.xn_id);
+  double *__restrict__ out = vec_origin(L, box, P.xout_id);
+  const double *__restrict__ rhs = (MODE == FV4_APPLY) ? nullptr : vec_origin(L, box, P.rhs_id);
+  const double *__restrict__ dinv = kSmooth ? vec_origin(L, box, VECTOR_DINV) : nullptr;
+  const double *__restrict__ alpha = kHelm ? vec_origin(L, box, VECTOR_ALPHA) : nullptr;
+  const double *__restrict__ gbi = vec_origin(L, box, VECTOR_BETA_I);
+  const double *__restrict__ gbj = vec_origin(L, box, VECTOR_BETA_J);
+  const double *__restrict__ gbk = vec_origin(L, box, VECTOR_BETA_K);
+  int colour000 = 0;
+  if (MODE == FV4_GSRB) colour000 = (L.box_low[3 * box] ^ L.box_low[3 * box + 1] ^ L.box_low[3 * box + 2] ^ P.sweep) & 1;
+
+  // this lane's own cell and (at most one) halo cell: offsets inside a plane of the box and inside a plane tile
+  const int own_g = i + j * jS, own_s = (lj + 2) * W + (li + 2);
+  int halo_g = 0, halo_s = 0;
+  const bool has_halo = tid < NH;
+  if (has_halo) {
+    int hi, hj;
+    if (tid < 2 * W)      { hj = -2 + tid / W; hi = -2 + tid % W; }
+    else if (tid < 4 * W) { const int h = tid - 2 * W; hj = TJ + h / W; hi = -2 + h % W; }
+    else                  { const int h = tid - 4 * W, c = h % 4; hj = h / 4; hi = (c < 2) ? c - 2 : TI + (c - 2); }
+    halo_g = (i0 + hi) + (j0 + hj) * jS;
+    halo_s = (hj + 2) * W + (hi + 2);
+  }
+  auto slot3 = [](int p) { return ((p % 3) + 3) % 3; };
+
+  // ---- prologue: planes k0-1 and k0 of x / beta_i / beta_j and face k0 of beta_k into LDS; x[k0-2 .. k0+2] of the own column into registers
+  double xm2 = x[own_g + (k0 - 2) * kS], xm1 = x[own_g + (k0 - 1) * kS], xc = x[own_g + k0 * kS];
+  double xp1 = x[own_g + (k0 + 1) * kS], xp2 = x[own_g + (k0 + 2) * kS], xp3 = 0.0;
+  for (int p = k0 - 1; p <= k0; p++) {
+    const int s = slot3(p) * PLANE, pg = p * kS;
+    sX[s + own_s] = (p == k0) ? xc : xm1;
+    sBI[s + own_s] = gbi[own_g + pg];
+    sBJ[s + own_s] = gbj[own_g + pg];
+    if (has_halo) { sX[s + halo_s] = x[halo_g + pg]; sBI[s + halo_s] = gbi[halo_g + pg]; sBJ[s + halo_s] = gbj[halo_g + pg]; }
+  }
+  sBK[(k0 & 1) * PLANE + own_s] = gbk[own_g + k0 * kS];
+  if (has_halo) sBK[(k0 & 1) * PLANE + halo_s] = gbk[halo_g + k0 * kS];
+  // values in flight: plane k+1 (stored to LDS at the start of step k) and the per-cell streams of plane k
+  double n_bi = gbi[own_g + (k0 + 1) * kS], n_bj = gbj[own_g + (k0 + 1) * kS], n_bk = gbk[own_g + (k0 + 1) * kS];
+  double h_x = 0, h_bi = 0, h_bj = 0, h_bk = 0;
+  if (has_halo) { const int pg = (k0 + 1) * kS; h_x = x[halo_g + pg]; h_bi = gbi[halo_g + pg]; h_bj = gbj[halo_g + pg]; h_bk = gbk[halo_g + pg]; }
+  double c_rhs = (MODE == FV4_APPLY) ? 0.0 : rhs[own_g + k0 * kS], c_dinv = kSmooth ? dinv[own_g + k0 * kS] : 0.0;
+  double c_al = kHelm ? alpha[own_g + k0 * kS] : 0.0, c_old = (MODE == FV4_CHEBY) ? out[own_g + k0 * kS] : 0.0;
+
+  for (int k = k0; k < k1; k++) {
+    const int pg = k * kS;
+    __syncthreads();                                            // every wave is done reading the slots that plane k+1 overwrites
+    { // plane k+1 (loaded during the previous step) -> LDS
+      const int s = slot3(k + 1) * PLANE, sk = ((k + 1) & 1) * PLANE;
+      sX[s + own_s] = xp1; sBI[s + own_s] = n_bi; sBJ[s + own_s] = n_bj; sBK[sk + own_s] = n_bk;
+      if (has_halo) { sX[s + halo_s] = h_x; sBI[s + halo_s] = h_bi; sBJ[s + halo_s] = h_bj; sBK[sk + halo_s] = h_bk; }
+    }
+    // issue the loads of the next step: plane k+2, own x three planes ahead, the per-cell streams of plane k+1
+    double nn_rhs = 0, nn_dinv = 0, nn_al = 0, nn_old = 0;
+    if (k + 1 < k1) {
+      const int ng = (k + 2) * kS;
+      n_bi = gbi[own_g + ng]; n_bj = gbj[own_g + ng]; n_bk = gbk[own_g + ng];
+      if (has_halo) { h_x = x[halo_g + ng]; h_bi = gbi[halo_g + ng]; h_bj = gbj[halo_g + ng]; h_bk = gbk[halo_g + ng]; }
+      xp3 = x[own_g + (k + 3) * kS];
+      const int cg = own_g + (k + 1) * kS;
+      if (MODE != FV4_APPLY) nn_rhs = rhs[cg];
+      if (kSmooth) nn_dinv = dinv[cg];
+      if (kHelm) nn_al = alpha[cg];
+      if (MODE == FV4_CHEBY) nn_old = out[cg];
+    }
+    __syncthreads();
+
+    bool update = true;
+    if (MODE == FV4_GSRB) update = (((i ^ j ^ k ^ colour000) & 1) == 0);
+    if (update) {
+      const double *X0 = sX + slot3(k) * PLANE + own_s, *Xm = sX + slot3(k - 1) * PLANE + own_s, *Xp = sX + slot3(k + 1) * PLANE + own_s;
+      const double *I0 = sBI + slot3(k) * PLANE + own_s, *Im = sBI + slot3(k - 1) * PLANE + own_s, *Ip = sBI + slot3(k + 1) * PLANE + own_s;
+      const double *J0 = sBJ + slot3(k) * PLANE + own_s, *Jm = sBJ + slot3(k - 1) * PLANE + own_s, *Jp = sBJ + slot3(k + 1) * PLANE + own_s;
+      const double *K0 = sBK + (k & 1) * PLANE + own_s, *K1 = sBK + ((k + 1) & 1) * PLANE + own_s;
+      // operators.fv4.c:87-93: six face terms
+      double s1 = I0[0] * (15.0 * (X0[-1] - xc) - (X0[-2] - X0[1]));
+      s1 = s1 + I0[1] * (15.0 * (X0[1] - xc) - (X0[2] - X0[-1]));
+      s1 = s1 + J0[0] * (15.0 * (X0[-W] - xc) - (X0[-2 * W] - X0[W]));
+      s1 = s1 + J0[W] * (15.0 * (X0[W] - xc) - (X0[2 * W] - X0[-W]));
+      s1 = s1 + K0[0] * (15.0 * (xm1 - xc) - (xm2 - xp1));
+      s1 = s1 + K1[0] * (15.0 * (xp1 - xc) - (xp2 - xm1));
+      // operators.fv4.c:95-108: twelve mixed terms, (beta+ - beta-) * (((x1 - x2) - x3) + x4)
+      double s2 = (I0[W] - I0[-W]) * (X0[-1 + W] - X0[W] - X0[-1 - W] + X0[-W]);
+      s2 = s2 + (Ip[0] - Im[0]) * (Xp[-1] - xp1 - Xm[-1] + xm1);
+      s2 = s2 + (J0[1] - J0[-1]) * (X0[-W + 1] - X0[1] - X0[-W - 1] + X0[-1]);
+      s2 = s2 + (Jp[0] - Jm[0]) * (Xp[-W] - xp1 - Xm[-W] + xm1);
+      s2 = s2 + (K0[1] - K0[-1]) * (Xm[1] - X0[1] - Xm[-1] + X0[-1]);
+      s2 = s2 + (K0[W] - K0[-W]) * (Xm[W] - X0[W] - Xm[-W] + X0[-W]);
+      s2 = s2 + (I0[1 + W] - I0[1 - W]) * (X0[1 + W] - X0[W] - X0[1 - W] + X0[-W]);
+      s2 = s2 + (Ip[1] - Im[1]) * (Xp[1] - xp1 - Xm[1] + xm1);
+      s2 = s2 + (J0[W + 1] - J0[W - 1]) * (X0[W + 1] - X0[1] - X0[W - 1] + X0[-1]);
+      s2 = s2 + (Jp[W] - Jm[W]) * (Xp[W] - xp1 - Xm[W] + xm1);
+      s2 = s2 + (K1[1] - K1[-1]) * (Xp[1] - X0[1] - Xp[-1] + X0[-1]);
+      s2 = s2 + (K1[W] - K1[-W]) * (Xp[W] - X0[W] - Xp[-W] + X0[-W]);
+      const double sum = FV4_TWELFTH * s1 + (0.25 * FV4_TWELFTH) * s2;
+      const double Ax = kHelm ? (P.a * c_al) * xc - (P.b * P.h2inv) * sum : ((-P.b) * P.h2inv) * sum;
+      double o;
+      if (MODE == FV4_CHEBY)         o = xc + P.c1 * (xc - c_old) + P.c2 * c_dinv * (c_rhs - Ax);
+      else if (MODE == FV4_GSRB)     o = xc + c_dinv * (c_rhs - Ax);
+      else if (MODE == FV4_JACOBI)   o = xc + P.c2 * c_dinv * (c_rhs - Ax);
+      else if (MODE == FV4_RESIDUAL) o = c_rhs - Ax;
+      else                           o = Ax;
+      out[own_g + pg] = o;
+    } else if (P.copy_other_colour) {
+      out[own_g + pg] = xc;                                     // out-of-place GSRB copies the other colour (gsrb.c:94-98)
+    }
+    xm2 = xm1; xm1 = xc; xc = xp1; xp1 = xp2; xp2 = xp3;
+    c_rhs = nn_rhs; c_dinv = nn_dinv; c_al = nn_al; c_old = nn_old;
+  }
+}
+
+}  // namespace hpgmg

@@ -25,6 +25,7 @@
 #include "common.hpp"
 #include "stencil_math.hpp"
 #include "cheby_pair.hpp"
+#include "fv4_tile.hpp"
 
 namespace hpgmg {
 
@@ -620,10 +621,43 @@ static int launch27(const hpgmg_hip_level *L, StencilArgs P, bool is_smoother) {
   return 0;
 }
 
+// the LDS-tiled 4th-order kernel (fv4_tile.hpp): boxes whose side is a multiple of 64, out of place
+template <int MODE>
+static int launch_fv4_tile(const hpgmg_hip_level *L, int variant, const StencilArgs &S, bool is_smoother) {
+  constexpr int TJ = 8;
+  Fv4TileArgs P = {};
+  P.xn_id = S.xn_id; P.xout_id = S.xout_id; P.rhs_id = S.rhs_id; P.a = S.a; P.b = S.b; P.h2inv = S.h2inv; P.c1 = S.c1; P.c2 = S.c2;
+  P.sweep = S.sweep; P.copy_other_colour = S.copy_other_colour;
+  P.tiles_i = L->dim / 64; P.tiles_j = L->dim / TJ;
+  int kchunk = L->dim;                                   // enough workgroups for two per CU, as few chunk prologues as possible
+  while (kchunk > 16 && (long long)L->num_boxes * P.tiles_i * P.tiles_j * (L->dim / kchunk) < 1024) kchunk /= 2;
+  static const int tune_kc = env_int("HPGMG_TUNE_FV4_KCHUNK", 0);
+  if (tune_kc > 0 && L->dim % tune_kc == 0) kchunk = tune_kc;
+  P.kchunk = kchunk; P.chunks_k = (L->dim + kchunk - 1) / kchunk;
+  P.total_blocks = L->num_boxes * P.chunks_k * P.tiles_j * P.tiles_i;
+  const int grid = grid_for(P.total_blocks, &P.per_xcd);
+  const size_t lds = (size_t)11 * (64 + 4) * (TJ + 4) * sizeof(double);
+  const long long cells = (long long)L->num_boxes * L->dim * L->dim * L->dim;
+  const int prof = is_smoother ? profile_begin(cells) : -1;
+#define FV4_TILE_CASE(VAR) { \
+    static bool once = false; if (!once) { HPGMG_CHECK(hipFuncSetAttribute((const void *)fv4_tile_kernel<VAR, MODE, TJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once = true; } \
+    hipLaunchKernelGGL((fv4_tile_kernel<VAR, MODE, TJ>), dim3(grid), dim3(64, TJ), lds, g_stream, *L, P); }
+  if (variant == HPGMG_HIP_FV4_VC_HELMHOLTZ) FV4_TILE_CASE(HPGMG_HIP_FV4_VC_HELMHOLTZ)
+  else FV4_TILE_CASE(HPGMG_HIP_FV4_VC_POISSON)
+#undef FV4_TILE_CASE
+  profile_end(prof, cells);
+  HPGMG_LAUNCH_CHECK("fv4_tile_kernel");
+  return 0;
+}
+
 template <int MODE>
 static int launch_direct(const hpgmg_hip_level *L, int variant, StencilArgs P, bool is_smoother) {
   HPGMG_SKIP_IF_REPLAY();
   if (L->num_boxes <= 0) return 0;
+  if (MODE != MODE_BLACKBOX && (variant == HPGMG_HIP_FV4_VC_HELMHOLTZ || variant == HPGMG_HIP_FV4_VC_POISSON)) {
+    static const int no_tile = env_int("HPGMG_TUNE_FV4_DIRECT", 0);
+    if (!no_tile && L->dim % 64 == 0 && L->ghosts >= 2 && P.xn_id != P.xout_id) return launch_fv4_tile<(MODE == MODE_BLACKBOX) ? MODE_APPLY : MODE>(L, variant, P, is_smoother);
+  }
   dim3 block; int grid;
   plan(L, P, block, grid);
   P.ghost_free = 0;
