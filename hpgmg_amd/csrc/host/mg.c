@@ -445,10 +445,12 @@ void MGVCycle(mg_type *G, int e_id, int R_id, double a, double b, int l) {
   if (maybe_tail) hpgmg_tick_end(t);          /* nothing was launched: adds (next to) nothing */
   t = hpgmg_tick_begin(L, &L->timers.Total, "V-cycle down leg");
   smooth(L, e_id, R_id, a, b);
-  residual(L, VECTOR_TEMP, e_id, R_id, a, b);
-  if (!hpgmg_restrict_zero_fused(G->levels[l + 1], R_id, L, VECTOR_TEMP, e_id)) {
-    restriction(G->levels[l + 1], R_id, L, VECTOR_TEMP, RESTRICT_CELL);
-    zero_vector(G->levels[l + 1], e_id);
+  if (!hpgmg_residual_restrict_zero_fused(G->levels[l + 1], R_id, L, e_id, R_id, a, b, e_id)) {
+    residual(L, VECTOR_TEMP, e_id, R_id, a, b);
+    if (!hpgmg_restrict_zero_fused(G->levels[l + 1], R_id, L, VECTOR_TEMP, e_id)) {
+      restriction(G->levels[l + 1], R_id, L, VECTOR_TEMP, RESTRICT_CELL);
+      zero_vector(G->levels[l + 1], e_id);
+    }
   }
   hpgmg_tick_end(t);
 
@@ -475,8 +477,11 @@ static int check_residual(mg_type *G, int l, int e_id, int F_id, double a, doubl
     double m = mean(L, e_id);
     shift_vector(L, e_id, e_id, -m);
   }
-  residual(L, VECTOR_TEMP, e_id, F_id, a, b);
-  double r = norm(L, VECTOR_TEMP);
+  double r;
+  if (!hpgmg_residual_norm_fused(L, VECTOR_TEMP, e_id, F_id, a, b, &r)) {
+    residual(L, VECTOR_TEMP, e_id, F_id, a, b);
+    r = norm(L, VECTOR_TEMP);
+  }
   hpgmg_tick_end(t);
   hpgmg_last_solve.norm_of_F = norm_of_F;
   hpgmg_last_solve.norm_of_residual = r;
@@ -525,11 +530,16 @@ void FMGSolve(mg_type *G, int onLevel, int u_id, int F_id, double a, double b, d
   seg_reset(G, onLevel);
 
   t = hpgmg_tick_begin(L, &L->timers.Total, "norm(F), R = F");
-  double norm_of_F = norm(L, F_id);
-  scale_vector(L, R_id, 1.0, F_id);
+  double norm_of_F = 0.0;
+  int first_restriction = onLevel;               /* the plugin may do norm, copy and the first restriction in one pass over F */
+  if (onLevel < bottom && hpgmg_norm_scale_restrict_fused(L, F_id, R_id, G->levels[onLevel + 1], &norm_of_F)) first_restriction = onLevel + 1;
+  else {
+    norm_of_F = norm(L, F_id);
+    scale_vector(L, R_id, 1.0, F_id);
+  }
   hpgmg_tick_end(t);
 
-  for (l = onLevel; l < bottom; l++) {           /* carry the right-hand side down */
+  for (l = first_restriction; l < bottom; l++) {           /* carry the right-hand side down */
     if (is_small(G, l)) seg_open();
     t = hpgmg_tick_begin(G->levels[l], &G->levels[l]->timers.Total, "restrict R");
     restriction(G->levels[l + 1], R_id, G->levels[l], R_id, RESTRICT_CELL);

@@ -133,6 +133,7 @@ typedef struct {
   double *pair_scratch; double **d_pair_base;   /* two private vectors per box for the fused Chebyshev sweep pairs */
   float *coef32; float **d_coef32_base; int coef32_valid;   /* fp32 copies of Dinv, alpha, beta_* for the mixed-precision smoother */
   int lexicographic;           /* -1 unknown, else whether local box b sits at (b % nb, (b / nb) % nb, b / nb^2) and all boxes are local */
+  int *d_restrict_map;         /* fused residual + restriction: per fine box the coarse box and the coarse cell under its first cell (device) */
   struct pair_halo *halo;      /* sweep pairs across rank boundaries: brick shape, message plans, deep halos (NULL: not built / not applicable) */
   int halo_state;              /* 0 not examined, 1 usable, -1 this level cannot use it */
 } backend_t;
@@ -260,6 +261,7 @@ void hpgmg_level_release(level_type *L) {
   if (B->coef32) hpgmg_hip_free(B->coef32);
   if (B->d_coef32_base) hpgmg_hip_free(B->d_coef32_base);
   if (B->d_pair_base) hpgmg_hip_free(B->d_pair_base);
+  if (B->d_restrict_map) hpgmg_hip_free(B->d_restrict_map);
   if (B->halo) {
     int q;
     for (q = 0; q < HALO_PLANS; q++) {
@@ -987,6 +989,87 @@ int hpgmg_restrict_zero_fused(level_type *Lc, int id_c, level_type *Lf, int id_f
   backend_t *Bc = backend_of(Lc), *Bf = backend_of(Lf);
   HIP_OK(hpgmg_hip_restrict_cell_and_zero(&Bc->dev, id_c, &Bf->dev, id_f, mirror(Lf, S->blocks[1], S->num_blocks[1]), S->num_blocks[1], zero_id));
   TOCK();
+  return 1;
+}
+
+/* residual(Lf, TEMP, x, rhs) ; restriction(Lc, id_c, Lf, TEMP, RESTRICT_CELL) ; zero_vector(Lc, zero_id) -- the end of MGVCycle's down
+ * leg (mg.c:1150-1153) -- as ONE pass over the fine level: the residual is restricted on the fly and never stored (VECTOR_TEMP of the
+ * fine level keeps its previous content; nothing reads it before the up leg's smooth() overwrites it).  0 = not applicable. */
+static double allreduce_scalar(level_type *L, double v, int op);
+/* per fine box: the coarse box it restricts into and the coarse cell under its first cell -- read off the local restriction list */
+static const int *restrict_map_of(level_type *Lf, backend_t *Bf) {
+  communicator_type *S = &Lf->restriction[RESTRICT_CELL];
+  if (!Bf->d_restrict_map) {
+    int *map = (int *)malloc((size_t)Lf->num_my_boxes * 4 * sizeof(int)), n, b;
+    for (b = 0; b < 4 * Lf->num_my_boxes; b++) map[b] = -1;
+    for (n = 0; n < S->num_blocks[1]; n++) {
+      const blockCopy_type *e = &S->blocks[1][n];
+      if (e->read.box < 0 || e->write.box < 0 || map[4 * e->read.box] >= 0) continue;
+      map[4 * e->read.box] = e->write.box;
+      map[4 * e->read.box + 1] = e->write.i - e->read.i / 2; map[4 * e->read.box + 2] = e->write.j - e->read.j / 2; map[4 * e->read.box + 3] = e->write.k - e->read.k / 2;
+    }
+    for (b = 0; b < Lf->num_my_boxes; b++) if (map[4 * b] < 0) { free(map); return NULL; }
+    Bf->d_restrict_map = (int *)hpgmg_hip_malloc((size_t)Lf->num_my_boxes * 4 * sizeof(int));
+    if (!Bf->d_restrict_map) { fprintf(stderr, "hpgmg: device allocation failed: %s\n", hpgmg_hip_last_error()); abort(); }
+    HIP_OK(hpgmg_hip_memcpy_h2d(Bf->d_restrict_map, map, (size_t)Lf->num_my_boxes * 4 * sizeof(int)));
+    free(map);
+  }
+  return Bf->d_restrict_map;
+}
+static int fused_residual = -1;
+static int fused_residual_on(void) {
+  if (fused_residual < 0) { const char *e = getenv("HPGMG_FUSED_RESIDUAL"); fused_residual = !(e && e[0] == '0'); }
+  return fused_residual;
+}
+int hpgmg_residual_restrict_zero_fused(level_type *Lc, int id_c, level_type *Lf, int x_id, int rhs_id, double a, double b, int zero_id) {
+  communicator_type *S = &Lf->restriction[RESTRICT_CELL], *R = &Lc->restriction[RESTRICT_CELL];
+  hpgmg_config cfg;
+  hpgmg_get_config(&cfg);
+  if (!fused_residual_on() || cfg.op != HPGMG_OP_7PT || !ghost_free_mode() || stencil_get_shape() != STENCIL_SHAPE_STAR) return 0;
+  if (!Lf->active || !Lc->active || Lc->num_my_boxes < 1 || Lf->num_my_boxes < 1 || zero_id == id_c || Lf->boundary_condition.type == BC_PERIODIC) return 0;
+  if (S->num_sends || R->num_recvs || S->num_blocks[0] || R->num_blocks[2] || S->num_blocks[1] < 1) return 0;
+  backend_t *Bc = backend_of(Lc), *Bf = backend_of(Lf);
+  if (!Bf->all_faces_local) return 0;
+  hpgmg_hip_set_ghost_free(1);
+  if (!hpgmg_hip_residual_fused_supported(&Bf->dev, variant())) return 0;
+  if (!restrict_map_of(Lf, Bf)) return 0;
+  TICK(Lf, residual, "residual + restriction + zero_vector (fused)");
+  HIP_OK(hpgmg_hip_residual_restrict(&Bf->dev, variant(), x_id, rhs_id, a, b, 1.0 / (Lf->h * Lf->h), &Bc->dev, id_c, Bf->d_restrict_map, zero_id));
+  TOCK();
+  return 1;
+}
+/* norm(L, F) ; scale_vector(L, R, 1.0, F) ; restriction(Lc, R, L, R, RESTRICT_CELL) -- how FMGSolve starts (mg.c:1262-1270) -- in one pass over F.
+ * Every rank's share of the restriction must be local.  0 = not applicable. */
+int hpgmg_norm_scale_restrict_fused(level_type *L, int F_id, int R_id, level_type *Lc, double *norm_out) {
+  communicator_type *S = &L->restriction[RESTRICT_CELL], *R = &Lc->restriction[RESTRICT_CELL];
+  if (!fused_residual_on() || !L->active || !Lc->active || L->num_my_boxes < 1 || Lc->num_my_boxes < 1 || F_id == R_id) return 0;
+  if (S->num_sends || R->num_recvs || S->num_blocks[0] || R->num_blocks[2] || S->num_blocks[1] < 1) return 0;
+  backend_t *Bc = backend_of(Lc), *B = backend_of(L);
+  if ((L->box_dim & 1) || !(B->dev.flags & 1) || (L->box_jStride & 1) || (L->box_kStride & 1) || (L->box_volume & 1) || L->box_dim < 16) return 0;
+  if (!restrict_map_of(L, B)) return 0;
+  double v = 0.0;
+  { TICK(L, blas1, "norm(F) + R = F + restriction (fused)");
+    HIP_OK(hpgmg_hip_norm_copy_restrict(&B->dev, F_id, R_id, &Bc->dev, R_id, B->d_restrict_map, &v));
+    TOCK(); }
+  *norm_out = allreduce_scalar(L, v, HPGMG_REDUCE_MAX);
+  return 1;
+}
+/* residual(L, res, x, rhs) ; norm(L, res) -- the convergence check of MGSolve / FMGSolve (mg.c:1321-1323) -- in one pass: the residual is
+ * stored as usual and its max-abs comes out of the same kernel.  0 = not applicable. */
+int hpgmg_residual_norm_fused(level_type *L, int res_id, int x_id, int rhs_id, double a, double b, double *norm_out) {
+  hpgmg_config cfg;
+  hpgmg_get_config(&cfg);
+  if (!fused_residual_on() || cfg.op != HPGMG_OP_7PT || !ghost_free_mode() || stencil_get_shape() != STENCIL_SHAPE_STAR) return 0;
+  if (!L->active || L->num_my_boxes < 1 || L->boundary_condition.type == BC_PERIODIC) return 0;
+  backend_t *B = backend_of(L);
+  if (!B->all_faces_local) return 0;
+  hpgmg_hip_set_ghost_free(1);
+  if (!hpgmg_hip_residual_fused_supported(&B->dev, variant())) return 0;
+  double v = 0.0;
+  { TICK(L, residual, "residual + norm (fused)");
+    HIP_OK(hpgmg_hip_residual_norm(&B->dev, variant(), res_id, x_id, rhs_id, a, b, 1.0 / (L->h * L->h), &v));
+    TOCK(); }
+  *norm_out = allreduce_scalar(L, v, HPGMG_REDUCE_MAX);
   return 1;
 }
 

@@ -170,6 +170,38 @@ __global__ __launch_bounds__(256) void final_max_kernel(const double *partials, 
   if (threadIdx.x == 0) { for (int w = 1; w < 4; w++) m = (smem[w] > m) ? smem[w] : m; publish(result, (smem[0] > m) ? smem[0] : m, seq); }
 }
 
+// norm(F) ; scale_vector(R, 1.0, F) ; restriction(coarse R <- R, RESTRICT_CELL) -- the first three operators of FMGSolve (mg.c:1262-1270)
+// -- as one pass over F: a wave owns one COARSE row of a box (its four fine rows, a lane the 2 x 2 x 2 children of a coarse cell,
+// 16-byte accesses), stores R = 1.0 * F, forms the restricted value in the reference's order (restriction.c:54-57) and the maximum of |F|.
+__global__ __launch_bounds__(256) void norm_copy_restrict_kernel(const hpgmg_hip_level L, int f_id, int r_id, const hpgmg_hip_level Lc, int rc_id,
+                                                                 const int *__restrict__ map, double *partials) {
+  const int half = L.dim >> 1, rows_per_box = half * half, lane = threadIdx.x % 64;
+  const int row = blockIdx.x * kRowsPerBlock + threadIdx.x / 64;
+  double m = 0.0;
+  if (row < rows_per_box * L.num_boxes) {
+    const int box = row / rows_per_box, rem = row - box * rows_per_box, ck = rem / half, cj = rem - ck * half;
+    const int jS = L.jStride, kS = L.kStride, base = 2 * cj * jS + 2 * ck * kS;
+    const double *f = vec_origin(L, box, f_id) + base;
+    double *r = vec_origin(L, box, r_id) + base;
+    const int *mp = map + 4 * box;
+    double *c = vec_origin(Lc, mp[0], rc_id) + mp[1] + (mp[2] + cj) * Lc.jStride + (mp[3] + ck) * Lc.kStride;
+    for (int ci = lane; ci < half; ci += 64) {
+      const double2 a = *reinterpret_cast<const double2 *>(f + 2 * ci), b = *reinterpret_cast<const double2 *>(f + 2 * ci + jS);
+      const double2 cc = *reinterpret_cast<const double2 *>(f + 2 * ci + kS), d = *reinterpret_cast<const double2 *>(f + 2 * ci + jS + kS);
+      const double2 ra = make_double2(1.0 * a.x, 1.0 * a.y), rb = make_double2(1.0 * b.x, 1.0 * b.y);
+      const double2 rc = make_double2(1.0 * cc.x, 1.0 * cc.y), rd = make_double2(1.0 * d.x, 1.0 * d.y);
+      *reinterpret_cast<double2 *>(r + 2 * ci) = ra; *reinterpret_cast<double2 *>(r + 2 * ci + jS) = rb;
+      *reinterpret_cast<double2 *>(r + 2 * ci + kS) = rc; *reinterpret_cast<double2 *>(r + 2 * ci + jS + kS) = rd;
+      double v = ra.x + ra.y; v = v + rb.x; v = v + rb.y; v = v + rc.x; v = v + rc.y; v = v + rd.x; v = v + rd.y;
+      c[ci] = v * 0.125;
+      double q;
+      q = fabs(a.x); m = (q > m) ? q : m;  q = fabs(a.y); m = (q > m) ? q : m;  q = fabs(b.x); m = (q > m) ? q : m;  q = fabs(b.y); m = (q > m) ? q : m;
+      q = fabs(cc.x); m = (q > m) ? q : m; q = fabs(cc.y); m = (q > m) ? q : m; q = fabs(d.x); m = (q > m) ? q : m;  q = fabs(d.y); m = (q > m) ? q : m;
+    }
+  }
+  block_max_store(m, partials);
+}
+
 // ---- ordered sums ----------------------------------------------------------------------
 // one lane per dim x 8 x 8 tile, tiles numbered as level.c:1184-1210 builds my_blocks
 // kFinish: the whole level fits one 64-lane workgroup, which then also adds the partials in tile
@@ -304,6 +336,14 @@ static int fetch_result(double *out) {
   return 0;
 }
 
+// for kernels of other translation units that leave one partial maximum per workgroup (stencil.hip: residual + norm fused)
+double *reduction_scratch(int n) { return ensure_scratch(n) ? nullptr : g_scratch; }
+int finish_max_reduction(int n, double init, double *out) {
+  hipLaunchKernelGGL(final_max_kernel, dim3(1), dim3(256), 0, g_stream, (const double *)g_scratch, n, init, g_result_dev, ++g_seq);
+  HPGMG_LAUNCH_CHECK("final_max_kernel");
+  return fetch_result(out);
+}
+
 template <int OP>
 static int launch_ew(const hpgmg_hip_level *L, const EwArgs &A) {
   HPGMG_SKIP_IF_REPLAY();
@@ -350,6 +390,18 @@ int hpgmg_hip_random(const hpgmg_hip_level *L, int id) {
   EwArgs A = {}; A.id_c = id; return launch_ew<OP_RANDOM>(L, A);
 }
 
+int hpgmg_hip_norm_copy_restrict(const hpgmg_hip_level *L, int f_id, int r_id, const hpgmg_hip_level *Lc, int rc_id, const int *map, double *norm_out) {
+  if (int e = hpgmg_hip_graph_flush()) return e;
+  *norm_out = 0.0;
+  if (L->num_boxes <= 0 || Lc->num_boxes <= 0 || (L->dim & 1) || !(L->flags & 1) || (L->jStride & 1) || (L->kStride & 1) || (L->volume & 1) || f_id == r_id)
+    return record_error(hipErrorInvalidValue, "norm_copy_restrict: level not supported");
+  const int nblk = rows_grid(L->num_boxes * (L->dim / 2) * (L->dim / 2));
+  if (int e = ensure_scratch(nblk)) return e;
+  hipLaunchKernelGGL(norm_copy_restrict_kernel, dim3(nblk), dim3(256), 0, g_stream, *L, f_id, r_id, *Lc, rc_id, map, g_scratch);
+  hipLaunchKernelGGL(final_max_kernel, dim3(1), dim3(256), 0, g_stream, (const double *)g_scratch, nblk, 0.0, g_result_dev, ++g_seq);
+  HPGMG_LAUNCH_CHECK("norm_copy_restrict");
+  return fetch_result(norm_out);
+}
 int hpgmg_hip_norm_max(const hpgmg_hip_level *L, int id, double *out) {
   if (int e = hpgmg_hip_graph_flush()) return e;
   *out = 0.0;

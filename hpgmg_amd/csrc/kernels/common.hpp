@@ -14,6 +14,9 @@ int  record_error(hipError_t e, const char *where);
 #define HPGMG_SKIP_IF_REPLAY() do { if (hpgmg::g_skip_launches) return 0; } while (0)
 #define HPGMG_LAUNCH_CHECK(name) do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return hpgmg::record_error(e_, name); } while (0)
 
+double *reduction_scratch(int n);                       // blas1.hip: device scratch of >= n doubles for per-workgroup partial results
+int finish_max_reduction(int n, double init, double *out);   // blas1.hip: fold n partial maxima, publish to the host, wait for the value
+
 constexpr int kXcds = 8;              // MI355X: 8 XCDs, workgroup b is placed on XCD b % 8
 
 // Physical block id -> logical work id such that each XCD (hence each private L2)

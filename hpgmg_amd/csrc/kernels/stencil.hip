@@ -29,7 +29,18 @@
 
 namespace hpgmg {
 
-enum { MODE_CHEBY = 0, MODE_GSRB = 1, MODE_JACOBI = 2, MODE_RESIDUAL = 3, MODE_APPLY = 4, MODE_BLACKBOX = 5 };
+enum { MODE_CHEBY = 0, MODE_GSRB = 1, MODE_JACOBI = 2, MODE_RESIDUAL = 3, MODE_APPLY = 4, MODE_BLACKBOX = 5,
+       MODE_RESIDUAL_RESTRICT = 6,   // wide kernel only: the residual is not stored but restricted (restriction.c:54-57) into the coarse level
+       MODE_RESIDUAL_NORM = 7 };     // wide kernel only: the residual is stored and its max-abs (misc.c:287-329) reduced per workgroup
+
+// second kernel argument of the fused residual forms (unused by the plain modes)
+struct FusedArgs {
+  hpgmg_hip_level Lc;           // coarse level of MODE_RESIDUAL_RESTRICT
+  int coarse_id, zero_id;       // restricted residual goes to vector coarse_id; zero_id >= 0: extra workgroups clear that coarse vector (zero_vector, misc.c:6-44)
+  const int *map;               // per fine box: coarse box, and the (i, j, k) of the coarse cell under the fine box's first cell
+  int zero_chunks_per_box, compute_blocks;
+  double *partials;             // MODE_RESIDUAL_NORM: one max per workgroup
+};
 
 struct StencilArgs {
   int xn_id, xout_id, rhs_id;   // xout = x_np1 (smoothers) or res/Ax
@@ -162,8 +173,19 @@ __device__ __forceinline__ d2 ld2(const double *p) { return *reinterpret_cast<co
 __device__ __forceinline__ void st2(double *p, d2 v) { *reinterpret_cast<d2 *>(p) = v; }
 
 template <int V, int MODE, int WJ>
-__global__ __launch_bounds__(64 * WJ) void stencil7_wide_kernel(const hpgmg_hip_level L, const StencilArgs P) {
+__global__ __launch_bounds__(64 * WJ) void stencil7_wide_kernel(const hpgmg_hip_level L, const StencilArgs P, const FusedArgs F) {
   __shared__ d2 slab[2][2 * WJ][64];                          // plane copy: [buffer][row of the slab][i pair]
+  __shared__ double wg_max[WJ];
+  // zero_vector(coarse, zero_id) -- whole padded boxes, ghosts included -- by the workgroups appended after the stencil grid (physical
+  // order, so they spread over all XCDs instead of landing on the last ones)
+  if (MODE == MODE_RESIDUAL_RESTRICT && (int)blockIdx.x >= kXcds * P.per_xcd) {
+    const int z = (int)blockIdx.x - kXcds * P.per_xcd, zbox = z / F.zero_chunks_per_box, chunk = z - zbox * F.zero_chunks_per_box;
+    if (zbox >= F.Lc.num_boxes) return;
+    double *v = F.Lc.box_base[zbox] + (size_t)F.zero_id * (size_t)F.Lc.volume;
+    const int lo = chunk * 4096, hi = (lo + 4096 < F.Lc.volume) ? lo + 4096 : F.Lc.volume;
+    for (int q = lo + (int)(threadIdx.y * 64 + threadIdx.x); q < hi; q += 64 * WJ) v[q] = 0.0;
+    return;
+  }
   const int logical = xcd_logical_block((int)blockIdx.x, P.per_xcd);
   if (logical >= P.total_blocks) return;
   int t = logical;
@@ -181,15 +203,22 @@ __global__ __launch_bounds__(64 * WJ) void stencil7_wide_kernel(const hpgmg_hip_
   constexpr bool kVC = (V != HPGMG_HIP_7PT_CC);
   constexpr bool kHelm = (V == HPGMG_HIP_7PT_VC_HELMHOLTZ);
   constexpr bool kSmooth = (MODE == MODE_CHEBY || MODE == MODE_GSRB || MODE == MODE_JACOBI);
+  constexpr bool kRestrict = (MODE == MODE_RESIDUAL_RESTRICT), kNorm = (MODE == MODE_RESIDUAL_NORM);
 
   typename src_ptr<MODE == MODE_GSRB>::type x = vec_origin(L, box, P.xn_id);
-  double *out = vec_origin(L, box, P.xout_id);
+  double *out = kRestrict ? nullptr : vec_origin(L, box, P.xout_id);
   const double *__restrict__ rhs = (MODE == MODE_APPLY) ? nullptr : vec_origin(L, box, P.rhs_id);
   const double *__restrict__ dinv = kSmooth ? vec_origin(L, box, VECTOR_DINV) : nullptr;
   const double *__restrict__ alpha = kHelm ? vec_origin(L, box, VECTOR_ALPHA) : nullptr;
   const double *__restrict__ beta_i = kVC ? vec_origin(L, box, VECTOR_BETA_I) : nullptr;
   const double *__restrict__ beta_j = kVC ? vec_origin(L, box, VECTOR_BETA_J) : nullptr;
   const double *__restrict__ beta_k = kVC ? vec_origin(L, box, VECTOR_BETA_K) : nullptr;
+  // fused forms: where this lane's 2 x 2 (x 2 planes) patch lands in the coarse level; running sum / maximum
+  double *coarse = nullptr; double racc = 0.0, lane_max = 0.0;
+  if (kRestrict) {
+    const int *m = F.map + 4 * box;
+    coarse = vec_origin(F.Lc, m[0], F.coarse_id) + (m[1] + (i >> 1)) + (m[2] + (ja >> 1)) * F.Lc.jStride + (m[3] + (k0 >> 1)) * F.Lc.kStride;
+  }
 
   const bool gf = P.ghost_free != 0;
   // pair of values just outside this box across face `dir`, for the pair whose centres are `c`
@@ -280,7 +309,7 @@ __global__ __launch_bounds__(64 * WJ) void stencil7_wide_kernel(const hpgmg_hip_
         if (MODE == MODE_APPLY) { o.x = Ax0; o.y = Ax1; }                                                                   \
         else {                                                                                                              \
           const d2 r2 = ld2(rhs + IDX);                                                                                     \
-          if (MODE == MODE_RESIDUAL) { o.x = r2.x - Ax0; o.y = r2.y - Ax1; }                                                \
+          if (MODE == MODE_RESIDUAL || kRestrict || kNorm) { o.x = r2.x - Ax0; o.y = r2.y - Ax1; }                          \
           else {                                                                                                            \
             const d2 dv = ld2(dinv + IDX);                                                                                  \
             if (MODE == MODE_CHEBY) {                                                                                       \
@@ -293,19 +322,44 @@ __global__ __launch_bounds__(64 * WJ) void stencil7_wide_kernel(const hpgmg_hip_
             }                                                                                                               \
           }                                                                                                                 \
         }                                                                                                                   \
-        if (dm == 0) st2(out + IDX, o);                                                                                     \
+        RES = o;                                                                                                            \
+        if (kRestrict) { }                                                                                                  \
+        else if (dm == 0) st2(out + IDX, o);                                                                                \
         else { if (!(dm & 1)) out[IDX] = o.x; if (!(dm & 2)) out[IDX + 1] = o.y; }                                          \
       }                                                                                                                     \
     }
+    d2 res_a = {0, 0}, res_b = {0, 0};
+#define RES res_a
     HPGMG_ROW(ia, xc_a, xm_a, xp_a, xjm_a, xc_b, xl_a, xr_a, bk0_a, bk1_a, bj_lo, bj_mid, ja, dm_a)
+#undef RES
+#define RES res_b
     HPGMG_ROW(ib, xc_b, xm_b, xp_b, xc_a, xjp_b, xl_b, xr_b, bk0_b, bk1_b, bj_mid, bj_hi, (ja + 1), dm_b)
+#undef RES
 #undef HPGMG_ROW
+    if (kRestrict) {      // restriction.c:54-57: the eight children in the order (i, i+1) of rows j, j+1 of plane k, then of plane k+1; times 0.125
+      if (((k - k0) & 1) == 0) { racc = res_a.x + res_a.y; racc = racc + res_b.x; racc = racc + res_b.y; }
+      else {
+        racc = racc + res_a.x; racc = racc + res_a.y; racc = racc + res_b.x; racc = racc + res_b.y;
+        coarse[((k - k0) >> 1) * F.Lc.kStride] = racc * 0.125;
+      }
+    }
+    if (kNorm) {
+      double f;
+      f = fabs(res_a.x); lane_max = (f > lane_max) ? f : lane_max;  f = fabs(res_a.y); lane_max = (f > lane_max) ? f : lane_max;
+      f = fabs(res_b.x); lane_max = (f > lane_max) ? f : lane_max;  f = fabs(res_b.y); lane_max = (f > lane_max) ? f : lane_max;
+    }
     // hand the plane k+1 rows to the neighbouring waves for the next step
     slab[(k + 1) & 1][2 * ty][lane] = xp_a;
     slab[(k + 1) & 1][2 * ty + 1][lane] = xp_b;
     __syncthreads();
     xm_a = xc_a; xc_a = xp_a; bk0_a = bk1_a;
     xm_b = xc_b; xc_b = xp_b; bk0_b = bk1_b;
+  }
+  if (kNorm) {                                                 // a maximum is exact under any order (misc.c:307-317)
+    for (int off = 32; off > 0; off >>= 1) { const double o2 = __shfl_down(lane_max, off, 64); lane_max = (o2 > lane_max) ? o2 : lane_max; }
+    if (lane == 0) wg_max[ty] = lane_max;
+    __syncthreads();
+    if (lane == 0 && ty == 0) { double m = wg_max[0]; for (int q = 1; q < WJ; q++) m = (wg_max[q] > m) ? wg_max[q] : m; F.partials[logical] = m; }
   }
 }
 
@@ -564,6 +618,7 @@ static void profile_flush() {
   g_pairs_used = 0;
 }
 extern "C" int hpgmg_hip_graph_is_open(void);
+extern "C" int hpgmg_hip_graph_flush(void);
 static int profile_begin(long long cells) {
   if (!g_profile || cells < g_profile_min_cells || hpgmg_hip_graph_is_open()) return -1;
   if (g_pairs_used == kMaxPairs) profile_flush();
@@ -718,8 +773,8 @@ static int launch(const hpgmg_hip_level *L, int variant, StencilArgs P, bool is_
     P.total_blocks = L->num_boxes * P.chunks_k * P.tiles_j * P.tiles_i;
     grid = grid_for(P.total_blocks, &P.per_xcd);
 #define WIDE_CASE(VAR) case VAR: \
-      if (wj == 8) hipLaunchKernelGGL((stencil7_wide_kernel<VAR, MODE, 8>), dim3(grid), block, 0, g_stream, *L, P); \
-      else         hipLaunchKernelGGL((stencil7_wide_kernel<VAR, MODE, 4>), dim3(grid), block, 0, g_stream, *L, P); \
+      if (wj == 8) hipLaunchKernelGGL((stencil7_wide_kernel<VAR, MODE, 8>), dim3(grid), block, 0, g_stream, *L, P, FusedArgs{}); \
+      else         hipLaunchKernelGGL((stencil7_wide_kernel<VAR, MODE, 4>), dim3(grid), block, 0, g_stream, *L, P, FusedArgs{}); \
       break;
     switch (variant) {
       WIDE_CASE(HPGMG_HIP_7PT_VC_HELMHOLTZ)
@@ -768,6 +823,27 @@ __global__ __launch_bounds__(256) void pair_halo_kernel(const hpgmg_hip_level L,
     else if (plane) plane[t] = b[t];
     else v[ti + tj * jS + tk * kS] = b[t];
   }
+}
+// ---- fused forms of residual() on the bandwidth-bound fine level (stencil7_wide_kernel, ghost-free, every face local) ----
+static int wide_fused_ok(const hpgmg_hip_level *L, int variant) {
+  if (variant != HPGMG_HIP_7PT_VC_HELMHOLTZ && variant != HPGMG_HIP_7PT_VC_POISSON && variant != HPGMG_HIP_7PT_CC) return 0;
+  return L->num_boxes > 0 && g_ghost_free && L->box_nbr && !g_defer_mode && L->dim % 128 == 0 && L->jStride % 2 == 0 && L->kStride % 2 == 0 && L->volume % 2 == 0 && (L->flags & 1);
+}
+template <int MODE>
+static int launch_wide_fused(const hpgmg_hip_level *L, int variant, StencilArgs P, FusedArgs F, int extra_blocks) {
+  constexpr int wj = 8;
+  P.ghost_free = 1;
+  P.tiles_i = L->dim / 128; P.tiles_j = L->dim / (2 * wj); P.kchunk = 16; P.chunks_k = (L->dim + 15) / 16;
+  F.compute_blocks = L->num_boxes * P.chunks_k * P.tiles_j * P.tiles_i;
+  P.total_blocks = F.compute_blocks;
+  const int grid = grid_for(P.total_blocks, &P.per_xcd) + extra_blocks;      // the extra (zeroing) workgroups follow the stencil grid
+  switch (variant) {
+    case HPGMG_HIP_7PT_VC_HELMHOLTZ: hipLaunchKernelGGL((stencil7_wide_kernel<HPGMG_HIP_7PT_VC_HELMHOLTZ, MODE, wj>), dim3(grid), dim3(64, wj), 0, g_stream, *L, P, F); break;
+    case HPGMG_HIP_7PT_VC_POISSON:   hipLaunchKernelGGL((stencil7_wide_kernel<HPGMG_HIP_7PT_VC_POISSON, MODE, wj>), dim3(grid), dim3(64, wj), 0, g_stream, *L, P, F); break;
+    default:                         hipLaunchKernelGGL((stencil7_wide_kernel<HPGMG_HIP_7PT_CC, MODE, wj>), dim3(grid), dim3(64, wj), 0, g_stream, *L, P, F); break;
+  }
+  HPGMG_LAUNCH_CHECK("stencil7_wide_kernel (fused residual)");
+  return 0;
 }
 }  // namespace hpgmg
 using namespace hpgmg;
@@ -968,6 +1044,31 @@ int hpgmg_hip_blackbox_accumulate(const hpgmg_hip_level *L, int variant, int x_i
   if (variant == HPGMG_HIP_27PT_CC) return launch27<MODE_BLACKBOX>(L, P, false);
   return launch_direct<MODE_BLACKBOX>(L, variant, P, false);
 }
+int hpgmg_hip_residual_fused_supported(const hpgmg_hip_level *L, int variant) { return wide_fused_ok(L, variant); }
+// residual (never stored) -> restriction into vector coarse_id of Lc, plus zero_vector(Lc, zero_id) when zero_id >= 0: the end of
+// MGVCycle's down leg (mg.c:1150-1153) in one pass over the fine level.  map[4 b .. 4 b + 3] = coarse box and coarse (i, j, k) under fine box b's first cell.
+int hpgmg_hip_residual_restrict(const hpgmg_hip_level *L, int variant, int x_id, int rhs_id, double a, double b, double h2inv,
+                                const hpgmg_hip_level *Lc, int coarse_id, const int *map, int zero_id) {
+  HPGMG_SKIP_IF_REPLAY();
+  if (!wide_fused_ok(L, variant) || Lc->num_boxes <= 0) return record_error(hipErrorInvalidValue, "residual_restrict: level not supported");
+  StencilArgs P = {}; P.xn_id = x_id; P.xout_id = x_id; P.rhs_id = rhs_id; P.a = a; P.b = b; P.h2inv = h2inv;
+  FusedArgs F = {}; F.Lc = *Lc; F.coarse_id = coarse_id; F.zero_id = zero_id; F.map = map;
+  F.zero_chunks_per_box = (Lc->volume + 4095) / 4096;
+  return launch_wide_fused<MODE_RESIDUAL_RESTRICT>(L, variant, P, F, zero_id >= 0 ? F.zero_chunks_per_box * Lc->num_boxes : 0);
+}
+// residual stored to res_id AND its max-abs: residual() + norm() of the convergence check (mg.c:1321-1323) in one pass
+int hpgmg_hip_residual_norm(const hpgmg_hip_level *L, int variant, int res_id, int x_id, int rhs_id, double a, double b, double h2inv, double *norm_out) {
+  if (int e = hpgmg_hip_graph_flush()) return e;
+  *norm_out = 0.0;
+  if (!wide_fused_ok(L, variant)) return record_error(hipErrorInvalidValue, "residual_norm: level not supported");
+  StencilArgs P = {}; P.xn_id = x_id; P.xout_id = res_id; P.rhs_id = rhs_id; P.a = a; P.b = b; P.h2inv = h2inv;
+  const int blocks = L->num_boxes * ((L->dim + 15) / 16) * (L->dim / 16) * (L->dim / 128);
+  FusedArgs F = {}; F.partials = reduction_scratch(blocks);
+  if (!F.partials) return record_error(hipErrorOutOfMemory, "residual_norm: scratch");
+  if (int e = launch_wide_fused<MODE_RESIDUAL_NORM>(L, variant, P, F, 0)) return e;
+  return finish_max_reduction(blocks, 0.0, norm_out);
+}
+
 int hpgmg_hip_residual(const hpgmg_hip_level *L, int variant, int res_id, int x_id, int rhs_id, double a, double b, double h2inv) {
   StencilArgs P = {}; P.xn_id = x_id; P.xout_id = res_id; P.rhs_id = rhs_id; P.a = a; P.b = b; P.h2inv = h2inv;
   if (rhs_id < 0) return launch<MODE_APPLY>(L, variant, P, false);

@@ -104,6 +104,17 @@ int hpgmg_hip_smooth_jacobi(const hpgmg_hip_level *L, int variant, int xn_id, in
 /* operators/residual.c:9-51 (rhs_id >= 0: res = rhs - A x) and operators/apply_op.c:9-48 (rhs_id < 0: res = A x) */
 int hpgmg_hip_residual(const hpgmg_hip_level *L, int variant, int res_id, int x_id, int rhs_id,
                        double a, double b, double h2inv);
+/* Fused forms of residual() for the bandwidth-bound fine level (ghost-free 7-point path, every face neighbour local, box side a
+ * multiple of 128; _supported() says whether a level qualifies):
+ *   _restrict: res = rhs - A x is not stored but restricted (restriction.c:54-57, same summation order) into vector coarse_id of Lc,
+ *              and, when zero_id >= 0, zero_vector(Lc, zero_id) runs in the same launch -- residual + restriction + zero_vector of
+ *              MGVCycle's down leg (mg.c:1150-1153) as one pass: 58 instead of 74 B per fine cell.  map = DEVICE array, 4 ints per fine
+ *              box: coarse box index and the coarse (i, j, k) under the fine box's first cell.
+ *   _norm:     res is stored AND max |res| is returned (residual + norm of the convergence check, mg.c:1321-1323). */
+int hpgmg_hip_residual_fused_supported(const hpgmg_hip_level *L, int variant);
+int hpgmg_hip_residual_restrict(const hpgmg_hip_level *L, int variant, int x_id, int rhs_id, double a, double b, double h2inv,
+                                const hpgmg_hip_level *Lc, int coarse_id, const int *map, int zero_id);
+int hpgmg_hip_residual_norm(const hpgmg_hip_level *L, int variant, int res_id, int x_id, int rhs_id, double a, double b, double h2inv, double *norm_out);
 /* Overlap of the halo exchange with the stencil launches below (ghost-free 7-point path only): mode 1 = the next
  * launches leave the cells next to a face owned by another rank (box_nbr == -2) untouched, mode 2 = the next launches
  * compute exactly those cells (one lane per cell), mode 0 = whole boxes. */
@@ -194,6 +205,9 @@ int hpgmg_hip_random(const hpgmg_hip_level *L, int id);                         
  * partials added in tile order -- the order of the reference run with one thread. */
 int hpgmg_hip_norm_max(const hpgmg_hip_level *L, int id, double *out);                /* norm :287 */
 int hpgmg_hip_dot(const hpgmg_hip_level *L, int id_a, int id_b, double *out);         /* dot :239 */
+/* norm(F), scale_vector(R, 1.0, F) and restriction(coarse rc_id <- R, RESTRICT_CELL) -- the opening of FMGSolve, mg.c:1262-1270 -- in one pass
+ * over F (even box side, 16-byte aligned rows; map as for hpgmg_hip_residual_restrict): 25 instead of 41 B per fine cell */
+int hpgmg_hip_norm_copy_restrict(const hpgmg_hip_level *L, int f_id, int r_id, const hpgmg_hip_level *Lc, int rc_id, const int *map, double *norm_out);
 int hpgmg_hip_sum(const hpgmg_hip_level *L, int id, double *out);                     /* mean :336 (before the divide) */
 
 /* ---- operators/rebuild.c:47-208 black-box rebuild: accumulate one colouring (x = 0/1 pattern, ghosts

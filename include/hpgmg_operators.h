@@ -135,6 +135,14 @@ void    hpgmg_timers_settle(void);
  * operator; the CPU oracle ignores it.  Environment: HPGMG_TIMERS=host|device|sync. */
 void    hpgmg_set_timer_mode(int mode);
 int     hpgmg_get_timer_mode(void);
+/* Optional fused forms around residual() (return 1 when executed, 0 when the driver must issue the operators one by one):
+ *   residual(fine, TEMP, x, rhs); restriction(coarse, id_c, fine, TEMP, RESTRICT_CELL); zero_vector(coarse, zero_id)   (mg.c:1150-1153)
+ *     -- same coarse result; the fine level's VECTOR_TEMP is left untouched (the residual is never stored);
+ *   residual(level, res, x, rhs); *norm_out = norm(level, res)                                                          (mg.c:1321-1323) */
+int     hpgmg_residual_restrict_zero_fused(level_type *coarse, int id_c, level_type *fine, int x_id, int rhs_id, double a, double b, int zero_id);
+int     hpgmg_residual_norm_fused(level_type *level, int res_id, int x_id, int rhs_id, double a, double b, double *norm_out);
+/*   *norm_out = norm(level, F); scale_vector(level, R, 1.0, F); restriction(coarse, R, level, R, RESTRICT_CELL)                        (mg.c:1262-1270) */
+int     hpgmg_norm_scale_restrict_fused(level_type *level, int F_id, int R_id, level_type *coarse, double *norm_out);
 /* bring level->Krylov_iterations up to date with bottom solves the plugin ran asynchronously */
 void    hpgmg_level_sync_counters(level_type *level);
 /* called by destroy_level / MGDestroy so the plugin can drop device mirrors */

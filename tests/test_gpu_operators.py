@@ -196,6 +196,66 @@ def test_interpolation_folded_into_the_first_sweep_pair(hip, oracle, variant, ge
             be.lib.hpgmg_mg_destroy(m); f.destroy()
 
 
+@pytest.mark.parametrize("variant,geom", [("7pt-cheby-helm", (2, 128)), ("7pt-gsrb", (1, 128)), ("7ptcc-cheby", (1, 256))])
+def test_fused_residual_forms(hip, oracle, variant, geom):
+    """The three fused passes of the cycle driver on the fine level against the oracle's separate operators, bit for bit:
+    residual + restriction + zero_vector (MGVCycle's down leg, mg.c:1150-1153; the residual itself is never stored),
+    residual + norm (the convergence check, mg.c:1321-1323) and norm(F) + R = F + restriction (FMGSolve's opening, mg.c:1262-1270)."""
+    set_mode(hip, 1)
+    pairs = []
+    for be in (hip, oracle):
+        be.configure(**VARIANTS[variant])
+        fine = be.level(*geom)
+        for vid in range(fine.num_vectors):
+            d = seeded_field(fine, 900 + vid)
+            if vid >= H.VECTOR_DINV:
+                d = np.abs(d) + 0.5
+            fine.write_all(vid, d)
+        for vid in range(H.VECTOR_DINV, fine.num_vectors):
+            be.lib.exchange_boundary(fine.ptr, vid, H.STENCIL_SHAPE_BOX)
+        a, b = (1.0, 1.0) if "helm" in variant else (0.0, 1.0)
+        mg = be.lib.hpgmg_mg_create(fine.ptr, a, b, 1)
+        pairs.append((be, fine, mg, a, b))
+    try:
+        from hpgmg_testlib import Level
+        (bh, fh, mh, a, b), (bo, fo, mo, _, _) = pairs
+        c_int, c_dbl, vp = ctypes.c_int, ctypes.c_double, ctypes.c_void_p
+        L = hip.lib
+        L.hpgmg_residual_restrict_zero_fused.restype = c_int
+        L.hpgmg_residual_restrict_zero_fused.argtypes = [vp, c_int, vp, c_int, c_int, c_dbl, c_dbl, c_int]
+        L.hpgmg_residual_norm_fused.restype = c_int
+        L.hpgmg_residual_norm_fused.argtypes = [vp, c_int, c_int, c_int, c_dbl, c_dbl, ctypes.POINTER(c_dbl)]
+        L.hpgmg_norm_scale_restrict_fused.restype = c_int
+        L.hpgmg_norm_scale_restrict_fused.argtypes = [vp, c_int, c_int, vp, ctypes.POINTER(c_dbl)]
+        ch, co = Level(bh, bh.lib.hpgmg_mg_level(mh, 1)), Level(bo, bo.lib.hpgmg_mg_level(mo, 1))
+        junk = seeded_field(ch, 901)
+        for c in (ch, co):
+            c.write_all(H.VECTOR_U, junk); c.write_all(H.VECTOR_R, junk)
+        # 1. down leg
+        assert L.hpgmg_residual_restrict_zero_fused(ch.ptr, H.VECTOR_R, fh.ptr, H.VECTOR_U, H.VECTOR_F, a, b, H.VECTOR_U) == 1
+        bo.lib.residual(fo.ptr, H.VECTOR_TEMP, H.VECTOR_U, H.VECTOR_F, a, b)
+        bo.lib.restriction(co.ptr, H.VECTOR_R, fo.ptr, H.VECTOR_TEMP, H.RESTRICT_CELL)
+        bo.lib.zero_vector(co.ptr, H.VECTOR_U)
+        same(ch, co, [H.VECTOR_R, H.VECTOR_U])
+        # 2. convergence check
+        out = c_dbl(0.0)
+        assert L.hpgmg_residual_norm_fused(fh.ptr, H.VECTOR_TEMP, H.VECTOR_U, H.VECTOR_F, a, b, ctypes.byref(out)) == 1
+        same(fh, fo, [H.VECTOR_TEMP], interior_only=True)
+        assert out.value == bo.lib.norm(fo.ptr, H.VECTOR_TEMP)
+        # 3. opening of FMGSolve
+        for c in (ch, co):
+            c.write_all(H.VECTOR_R, junk)
+        assert L.hpgmg_norm_scale_restrict_fused(fh.ptr, H.VECTOR_F, H.VECTOR_R, ch.ptr, ctypes.byref(out)) == 1
+        assert out.value == bo.lib.norm(fo.ptr, H.VECTOR_F)
+        bo.lib.scale_vector(fo.ptr, H.VECTOR_R, 1.0, H.VECTOR_F)
+        bo.lib.restriction(co.ptr, H.VECTOR_R, fo.ptr, H.VECTOR_R, H.RESTRICT_CELL)
+        same(fh, fo, [H.VECTOR_R], interior_only=True)
+        same(ch, co, [H.VECTOR_R])
+    finally:
+        for be, f, m, _, _ in pairs:
+            be.lib.hpgmg_mg_destroy(m); f.destroy()
+
+
 @pytest.mark.parametrize("geom", [(2, 8), (1, 4), (3, 4), (1, 1), (2, 32)])
 def test_blas1_and_reductions(hip, oracle, geom):
     lh, lo = make_pair(hip, oracle, "7pt-cheby-helm", *geom, seed=4)
