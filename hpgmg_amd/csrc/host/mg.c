@@ -539,18 +539,32 @@ void FMGSolve(mg_type *G, int onLevel, int u_id, int F_id, double a, double b, d
   }
   hpgmg_tick_end(t);
 
-  for (l = first_restriction; l < bottom; l++) {           /* carry the right-hand side down */
+  /* the plugin may run everything below some small level -- the rest of the restrictions, the bottom solve and the climb back up to
+   * that level, interpolation_fcycle + V-cycle per level -- as one fused operation */
+  int ftail = bottom;
+  for (l = onLevel; l < bottom; l++) if (is_small(G, l) && hpgmg_vcycle_legs_fused(&G->levels[l], G->num_levels - l, e_id, R_id, a, b, 5)) { ftail = l; break; }
+
+  for (l = first_restriction; l < ftail; l++) {           /* carry the right-hand side down */
     if (is_small(G, l)) seg_open();
     t = hpgmg_tick_begin(G->levels[l], &G->levels[l]->timers.Total, "restrict R");
     restriction(G->levels[l + 1], R_id, G->levels[l], R_id, RESTRICT_CELL);
     hpgmg_tick_end(t);
   }
 
-  if (bottom > onLevel) { t = hpgmg_tick_begin(G->levels[bottom], &G->levels[bottom]->timers.Total, "zero e (bottom)"); zero_vector(G->levels[bottom], e_id); hpgmg_tick_end(t); }
-  if (is_small(G, bottom)) seg_open();
-  MGVCycle(G, e_id, R_id, a, b, bottom);          /* the bottom solve (times itself) */
+  if (ftail < bottom) {
+    if (is_small(G, ftail)) seg_open();
+    t = hpgmg_tick_begin(G->levels[ftail], &G->levels[ftail]->timers.Total, "F-cycle tail (fused)");
+    if (!hpgmg_vcycle_legs_fused(&G->levels[ftail], G->num_levels - ftail, e_id, R_id, a, b, 4)) { fprintf(stderr, "fused F-cycle tail refused after being accepted\n"); exit(1); }
+    hpgmg_tick_end(t);
+    for (l = bottom - 1; l >= ftail; l--) G->levels[l]->vcycles_from_this_level++;
+    seg_close();
+  } else {
+    if (bottom > onLevel) { t = hpgmg_tick_begin(G->levels[bottom], &G->levels[bottom]->timers.Total, "zero e (bottom)"); zero_vector(G->levels[bottom], e_id); hpgmg_tick_end(t); }
+    if (is_small(G, bottom)) seg_open();
+    MGVCycle(G, e_id, R_id, a, b, bottom);          /* the bottom solve (times itself) */
+  }
 
-  for (l = bottom - 1; l >= onLevel; l--) {       /* climb: prolong the solution, then one V-cycle */
+  for (l = ftail - 1; l >= onLevel; l--) {       /* climb: prolong the solution, then one V-cycle */
     if (is_small(G, l)) seg_open();
     t = hpgmg_tick_begin(G->levels[l], &G->levels[l]->timers.Total, "interpolation_fcycle");
     interpolation_fcycle(G->levels[l], e_id, 0.0, G->levels[l + 1], e_id);

@@ -513,7 +513,9 @@ void hpgmg_level_sync_counters(level_type *L) {
   *B->krylov_pinned = 0;
 }
 
-/* leg 0/1: the legs around a host-driven bottom solve; leg 2: legs + bottom solve; leg 3: bottom solve only (n == 1) */
+/* leg 0/1: the legs around a host-driven bottom solve; leg 2: legs + bottom solve; leg 3: bottom solve only (n == 1);
+ * leg 4: the whole F-cycle below levels[0] (right-hand side restricted down the chain, bottom solve, interpolation_fcycle + V-cycle per
+ * level upwards); leg 5: only answer whether leg 4 would be accepted */
 int hpgmg_vcycle_legs_fused(level_type **levels, int n, int e_id, int R_id, double a, double b, int leg) {
   static int enabled = -1, bottom_enabled = -1;
   hpgmg_config cfg;
@@ -528,6 +530,7 @@ int hpgmg_vcycle_legs_fused(level_type **levels, int n, int e_id, int R_id, doub
   if (!enabled || !ghost_free_mode() || cfg.op != HPGMG_OP_7PT || n > 8 || n > hpgmg_hip_tail_max_levels() || sweeps > 8) return 0;
   if (with_bottom && !bottom_enabled) return 0;
   if (n < (leg == 3 ? 1 : 2)) return 0;
+  if (leg >= 4) { static int ftail = -1; if (ftail < 0) { const char *e = getenv("HPGMG_FUSED_FTAIL"); ftail = !(e && e[0] == '0'); } if (!ftail) return 0; }
   /* multi-rank jobs: the chain qualifies when this rank owns every box of every level in it (checked below), which is
    * how the coarse levels end up after agglomeration onto rank 0 -- no message and no all-reduce is needed then */
   for (l = 0; l < n; l++) {
@@ -565,7 +568,8 @@ int hpgmg_vcycle_legs_fused(level_type **levels, int n, int e_id, int R_id, doub
     dev[l] = &B->dev;
     h2inv[l] = 1.0 / (L->h * L->h);
   }
-  TICK(levels[0], smooth, leg == 3 ? "bottom solve (device BiCGStab)" : "fused V-cycle tail");
+  if (leg == 5) return 1;
+  TICK(levels[0], smooth, leg == 3 ? "bottom solve (device BiCGStab)" : (leg == 4 ? "fused F-cycle tail" : "fused V-cycle tail"));
   HIP_OK(hpgmg_hip_vcycle_tail(n, dev, h2inv, c1, c2, sweeps, variant(), cfg.smoother, e_id, R_id, a, b, leg,
                                hpgmg_vectors_reserved(), MG_DEFAULT_BOTTOM_NORM, with_bottom ? backend_of(levels[n - 1])->krylov_pinned : NULL));
   TOCK();

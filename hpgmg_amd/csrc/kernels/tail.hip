@@ -40,7 +40,10 @@ struct TailArgs {
   double bottom_norm;          // desired reduction of the bottom residual norm
   int *krylov_iterations;      // pinned host counter (+= iterations done), may be null
   TailLevel lv[kTailMaxLevels];
+  int nops;                    // ftail_kernel: the operation sequence of the F-cycle, one byte each: kind << 4 | level
+  unsigned char ops[112];
 };
+enum { FT_DOWN = 0, FT_UP = 1, FT_BOTTOM = 2, FT_RESTRICT_RHS = 3, FT_ZERO_BOTTOM = 4, FT_INTERP_F = 5 };
 
 enum { SM_CHEBY = 0, SM_GSRB = 1, SM_JACOBI = 2, SM_RESIDUAL = 3 };
 
@@ -338,6 +341,58 @@ __device__ void tail_bottom(const TailArgs &A, double *sx, double *scr) {
   __syncthreads();
 }
 
+// ---- the F-cycle on the chain (leg 4): what FMGSolve does below the chain's first level (mg.c:1270-1300) ----
+// restriction(next.R <- R, RESTRICT_CELL) of the right-hand side, level by level (restriction.c:54-57)
+__device__ void tail_restrict_rhs(const TailArgs &A, int l) {
+  const hpgmg_hip_level &F = A.lv[l].L, &C = A.lv[l + 1].L;
+  const LevelGeom GF = geom_of(F), GC = geom_of(C);
+  const int Dc = C.dim_i, totc = Dc * Dc * Dc;
+  for (int c = threadIdx.x; c < totc; c += kTailThreads) {
+    const int cjk = c / GC.D, ci = c % GC.D, cj = cjk % GC.D, ck = cjk / GC.D;
+    double f[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) { const CellRef r = locate(GF, 2 * ci + (q & 1), 2 * cj + ((q >> 1) & 1), 2 * ck + (q >> 2)); f[q] = vec_origin(F, r.box, A.R_id)[r.ijk]; }
+    double v = f[0] + f[1]; v = v + f[2]; v = v + f[3]; v = v + f[4]; v = v + f[5]; v = v + f[6]; v = v + f[7];
+    const CellRef p = locate(GC, ci, cj, ck);
+    vec_origin(C, p.box, A.R_id)[p.ijk] = v * 0.125;
+  }
+  __syncthreads();
+}
+// interpolation_fcycle(level l <- level l+1), piecewise linear (interpolation_p1.c:40-70): f = 0.0 * f + 27/64 c + 9/64 (3 face
+// neighbours) + 3/64 (3 edge neighbours) + 1/64 corner, an even fine cell leaning on the coarse neighbour behind it, an odd one on the
+// one ahead.  The reference first fills the coarse ghost cells (exchange_boundary + apply_BCs_p1, BOX shape: a ghost cell is
+// -, +, - its mirror image for 1, 2, 3 directions leaving the domain, boundary_fd.c:35-38); here the same value is formed on the fly.
+__device__ void tail_interp_fcycle(const TailArgs &A, int l) {
+  const hpgmg_hip_level &F = A.lv[l].L, &C = A.lv[l + 1].L;
+  const LevelGeom GF = geom_of(F), GC = geom_of(C);
+  const int D = F.dim_i, total = D * D * D, Dc = C.dim_i;
+  auto coarse = [&](int ci, int cj, int ck) -> double {
+    double s = 1.0;
+    if (ci < 0) { ci = 0; s = -s; } else if (ci >= Dc) { ci = Dc - 1; s = -s; }
+    if (cj < 0) { cj = 0; s = -s; } else if (cj >= Dc) { cj = Dc - 1; s = -s; }
+    if (ck < 0) { ck = 0; s = -s; } else if (ck >= Dc) { ck = Dc - 1; s = -s; }
+    const CellRef r = locate(GC, ci, cj, ck);
+    return s * vec_origin(C, r.box, A.e_id)[r.ijk];
+  };
+  for (int c = threadIdx.x; c < total; c += kTailThreads) {
+    const int cj_ = c / GF.D, gi = c % GF.D, gj = cj_ % GF.D, gk = cj_ / GF.D;
+    const int ci = gi >> 1, cj = gj >> 1, ck = gk >> 1, di = (gi & 1) ? 1 : -1, dj = (gj & 1) ? 1 : -1, dk = (gk & 1) ? 1 : -1;
+    const CellRef w = locate(GF, gi, gj, gk);
+    double *fp = vec_origin(F, w.box, A.e_id) + w.ijk;
+    double v = 0.0 * (*fp);
+    v = v + 0.421875 * coarse(ci, cj, ck);
+    v = v + 0.140625 * coarse(ci, cj, ck + dk);
+    v = v + 0.140625 * coarse(ci, cj + dj, ck);
+    v = v + 0.046875 * coarse(ci, cj + dj, ck + dk);
+    v = v + 0.140625 * coarse(ci + di, cj, ck);
+    v = v + 0.046875 * coarse(ci + di, cj, ck + dk);
+    v = v + 0.046875 * coarse(ci + di, cj + dj, ck);
+    v = v + 0.015625 * coarse(ci + di, cj + dj, ck + dk);
+    *fp = v;
+  }
+  __syncthreads();
+}
+
 // leg 0: down legs | leg 1: up legs | leg 2: down, bottom solve, up | leg 3: bottom solve only
 template <int V, int SM>
 __global__ __launch_bounds__(kTailThreads) void tail_kernel(const TailArgs A, int leg) {
@@ -346,6 +401,27 @@ __global__ __launch_bounds__(kTailThreads) void tail_kernel(const TailArgs A, in
   if (leg == 0 || leg == 2) { for (int l = 0; l + 1 < A.n; l++) tail_level<V, SM>(A, l, 0, sx, st); }
   if (leg == 2 || leg == 3) tail_bottom<V>(A, sx, st);
   if (leg == 1 || leg == 2) { for (int l = A.n - 2; l >= 0; l--) tail_level<V, SM>(A, l, 1, sx, st); }
+}
+// leg 4: the F-cycle on the chain: right-hand side restricted down, bottom solve, then per level upwards interpolation_fcycle + a V-cycle.
+// (Its own kernel: folded into tail_kernel the extra code cost every V-cycle launch registers -- 48 -> 130 us per launch.)
+template <int V, int SM>
+__global__ __launch_bounds__(kTailThreads) void ftail_kernel(const TailArgs A) {
+  __shared__ double sx[kTailMaxCells];
+  __shared__ double st[kTailMaxCells];
+  // the host wrote the sequence out (hpgmg_hip_vcycle_tail); interpreting it keeps ONE call site per routine, so everything inlines
+  // and TailArgs stays in the kernel-argument segment (several call sites made the compiler copy it to scratch: 3x slower)
+  for (int i = 0; i < A.nops; i++) {
+    const int kind = A.ops[i] >> 4, l = A.ops[i] & 15;
+    if (kind == FT_DOWN || kind == FT_UP) tail_level<V, SM>(A, l, kind, sx, st);
+    else if (kind == FT_BOTTOM) tail_bottom<V>(A, sx, st);
+    else if (kind == FT_RESTRICT_RHS) tail_restrict_rhs(A, l);
+    else if (kind == FT_INTERP_F) tail_interp_fcycle(A, l);
+    else { // zero_vector(bottom, e): whole padded boxes (misc.c:6-44)
+      const hpgmg_hip_level &B = A.lv[A.n - 1].L;
+      for (int box = 0; box < B.num_boxes; box++) { double *z = B.box_base[box] + (size_t)A.e_id * (size_t)B.volume; for (int c = threadIdx.x; c < B.volume; c += kTailThreads) z[c] = 0.0; }
+      __syncthreads();
+    }
+  }
 }
 
 }  // namespace hpgmg
@@ -365,7 +441,7 @@ int hpgmg_hip_vcycle_tail(int n, const hpgmg_hip_level *const *levels, const dou
                           int variant, int smoother, int e_id, int R_id, double a, double b, int leg,
                           int krylov_base, double bottom_norm, int *krylov_iterations) {
   HPGMG_SKIP_IF_REPLAY();
-  if (n < 1 || (n < 2 && leg != 3) || n > kTailMaxLevels || sweeps > kTailMaxSweeps || leg < 0 || leg > 3)
+  if (n < 1 || (n < 2 && leg != 3) || n > kTailMaxLevels || sweeps > kTailMaxSweeps || leg < 0 || leg > 4)
     return record_error(hipErrorInvalidValue, "vcycle_tail: chain length / leg");
   TailArgs A = {};
   A.n = n; A.e_id = e_id; A.R_id = R_id; A.sweeps = sweeps; A.a = a; A.b = b;
@@ -378,7 +454,22 @@ int hpgmg_hip_vcycle_tail(int n, const hpgmg_hip_level *const *levels, const dou
     if (l + 1 < n && cells > kTailMaxCells) return record_error(hipErrorInvalidValue, "vcycle_tail: level too large");
     if (l + 1 == n && leg >= 2 && cells > kBottomMaxCells) return record_error(hipErrorInvalidValue, "vcycle_tail: bottom level too large");
   }
-#define TAIL_CASE(V, SM) hipLaunchKernelGGL((tail_kernel<V, SM>), dim3(1), dim3(kTailThreads), 0, g_stream, A, leg)
+  if (leg == 4) {   // FMGSolve below levels[0] (mg.c:1270-1300), written out as a sequence
+    int q = 0;
+    for (int l = 0; l + 1 < n; l++) A.ops[q++] = (unsigned char)((FT_RESTRICT_RHS << 4) | l);
+    A.ops[q++] = (unsigned char)(FT_ZERO_BOTTOM << 4);
+    A.ops[q++] = (unsigned char)(FT_BOTTOM << 4);
+    for (int top = n - 2; top >= 0; top--) {
+      A.ops[q++] = (unsigned char)((FT_INTERP_F << 4) | top);
+      for (int l = top; l + 1 < n; l++) A.ops[q++] = (unsigned char)((FT_DOWN << 4) | l);
+      A.ops[q++] = (unsigned char)(FT_BOTTOM << 4);
+      for (int l = n - 2; l >= top; l--) A.ops[q++] = (unsigned char)((FT_UP << 4) | l);
+    }
+    if (q > (int)sizeof(A.ops)) return record_error(hipErrorInvalidValue, "vcycle_tail: F-cycle sequence too long");
+    A.nops = q;
+  }
+#define TAIL_CASE(V, SM) do { if (leg == 4) hipLaunchKernelGGL((ftail_kernel<V, SM>), dim3(1), dim3(kTailThreads), 0, g_stream, A); \
+                              else hipLaunchKernelGGL((tail_kernel<V, SM>), dim3(1), dim3(kTailThreads), 0, g_stream, A, leg); } while (0)
   const int key = variant * 3 + smoother;
   switch (key) {
     case HPGMG_HIP_7PT_VC_HELMHOLTZ * 3 + SM_CHEBY:  TAIL_CASE(HPGMG_HIP_7PT_VC_HELMHOLTZ, SM_CHEBY); break;

@@ -228,7 +228,9 @@ int hpgmg_hip_tail_max_cells(void);          /* per smoothed level of the chain 
 int hpgmg_hip_tail_bottom_max_cells(void);   /* bottom level, when its BiCGStab solve runs on the device (leg 2, 3) */
 /* leg 0 / 1: down / up legs around a host-driven bottom solve;  leg 2: down legs, the bottom solve
  * (diagonally preconditioned BiCGStab, solvers/bicgstab.c:14-97, work vectors krylov_base..+7, stop at
- * bottom_norm relative reduction), up legs -- one launch;  leg 3: the bottom solve alone (n >= 1).
+ * bottom_norm relative reduction), up legs -- one launch;  leg 3: the bottom solve alone (n >= 1);
+ * leg 4: the F-cycle below levels[0] (FMGSolve, mg.c:1270-1300): restriction of the right-hand side R_id down the chain, zero_vector
+ * + bottom solve, then for every level upwards interpolation_fcycle (interpolation_p1.c, coarse ghosts by apply_BCs_p1) and a V-cycle.
  * krylov_iterations: device-visible host counter the kernel adds its iteration count to, or NULL. */
 int hpgmg_hip_vcycle_tail(int n, const hpgmg_hip_level *const *levels, const double *h2inv,
                           const double *c1, const double *c2, int sweeps,

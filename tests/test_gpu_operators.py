@@ -236,7 +236,11 @@ def test_fused_residual_forms(hip, oracle, variant, geom):
         bo.lib.residual(fo.ptr, H.VECTOR_TEMP, H.VECTOR_U, H.VECTOR_F, a, b)
         bo.lib.restriction(co.ptr, H.VECTOR_R, fo.ptr, H.VECTOR_TEMP, H.RESTRICT_CELL)
         bo.lib.zero_vector(co.ptr, H.VECTOR_U)
-        same(ch, co, [H.VECTOR_R, H.VECTOR_U])
+        same(ch, co, [H.VECTOR_R])
+        # zero_vector clears the padded box, ghosts included; the alignment padding at the end of each row is nobody's (the fused launch clears it too)
+        w = ch.box_dim + 2 * ch.ghosts
+        cells = lambda x: x[:, : w * ch.kStride].reshape(-1, w, ch.kStride)[:, :, : w * ch.jStride].reshape(-1, w, w, ch.jStride)[:, :, :, :w]
+        assert np.array_equal(cells(ch.read_all(H.VECTOR_U)), cells(co.read_all(H.VECTOR_U)))
         # 2. convergence check
         out = c_dbl(0.0)
         assert L.hpgmg_residual_norm_fused(fh.ptr, H.VECTOR_TEMP, H.VECTOR_U, H.VECTOR_F, a, b, ctypes.byref(out)) == 1
