@@ -106,6 +106,7 @@ def main():
     ap.add_argument("--series", choices=["strong", "weak"], default="strong",
                     help="what N > 1 runs (config2): strong = the north_star series, the SAME 256^3 problem cut over N GPUs (`hpgmg-fv 7 8/N`: 8/4/2/1 boxes of "
                          "128^3 per GPU); weak = the reference CLI's own `7 8` with N ranks (256^3, 256^3, 384^3, 512^3 for N = 1, 2, 4, 8; hpgmg-fv.c:184-197)")
+    ap.add_argument("--watchdog", type=int, default=900, help="seconds after which a rank that has not finished reports where it is stuck and exits 124 (0 = off)")
     args = ap.parse_args()
 
     # `python bench.py --gpus N` outside torchrun: start the N ranks ourselves, as a CHILD process (this parent has not touched the
@@ -133,6 +134,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    stage = ["start"]
+    if args.watchdog > 0:      # a multi-rank job that hangs (a peer died, a mismatched exchange) must fail loudly, not sit until the driver's limit
+        import threading
+
+        def _expired():
+            sys.stderr.write(f"bench.py: rank {rank}/{world} still in stage '{stage[0]}' after {args.watchdog} s -- giving up "
+                             f"(HPGMG_OVERLAP=0 serialises the halo exchange, HPGMG_PAIR_REMOTE=0 exchanges once per sweep)\n")
+            sys.stderr.flush()
+            os._exit(124)
+        dog = threading.Timer(args.watchdog, _expired)
+        dog.daemon = True
+        dog.start()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a {world}-rank run as {args.gpus} GPUs")
     if world > 1 and torch.cuda.device_count() < world:
@@ -148,8 +161,15 @@ def main():
     lib.hpgmg_set_verbose(0)
 
     dist = None
+    stage[0] = "transport bootstrap (torch.distributed + RCCL communicator)"
     if world > 1 or args.force_transport:
         import torch.distributed as dist
+        if world == 1 and "RANK" not in os.environ:      # --force-transport outside torchrun: a one-rank job on this machine
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                free = sk.getsockname()[1]
+            os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free))
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         ident = torch.zeros(128, dtype=torch.uint8, device="cuda")
         if rank == 0:
@@ -184,6 +204,7 @@ def main():
     lib.hpgmg_set_smoother_precision(32 if mixed else 64)
     cfg = H.Config(w_op, w_sm, w_helm, w_vc)
     assert lib.hpgmg_configure(ctypes.byref(cfg)) == 0
+    stage[0] = "problem setup (levels, operators, MGBuild)"
     solver = lib.hpgmg_solver_create(w_log2, boxes_per_rank, H.BC_DIRICHLET, rank, world)
     assert solver, "no acceptable problem size"
     info = (ctypes.c_int * H.INFO_COUNT)()
@@ -198,8 +219,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    stage[0] = "warm-up solves"
     for _ in range(args.warmup):
         lib.hpgmg_solver_fmg(solver, 0)
+    stage[0] = "timed solves"
 
     # time only the fine-level smoother launches with hipEvents on the launch stream
     fine_cells = my_boxes * box_dim ** 3
@@ -216,6 +239,10 @@ def main():
     ms, launches, cells = ctypes.c_double(), ctypes.c_longlong(), ctypes.c_longlong()
     K.hpgmg_hip_profile_smoother_read(ctypes.byref(ms), ctypes.byref(launches), ctypes.byref(cells))
 
+    lib.hpgmg_pair_remote_smooths.restype = ctypes.c_longlong
+    lib.hpgmg_overlap_count.restype = ctypes.c_longlong
+    remote_smooths, overlapped = lib.hpgmg_pair_remote_smooths(), lib.hpgmg_overlap_count()
+    stage[0] = "result reduction"
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -257,6 +284,9 @@ def main():
                                    f"{' (mixed precision, BASELINE config 5)' if mixed else ''}, {my_boxes} boxes of {box_dim}^3 per GPU, BiCGStab bottom, Dirichlet",
                        "series": (f"{args.series} scaling: " + ("same problem on every N (north_star series)" if args.series == "strong" else "reference CLI `7 8` with N ranks (domain grows with N)")) if world > 1 else "single GPU",
                        "rccl_ranks": world if dist is not None else 0,
+                       "halo": ({"smooths_as_sweep_pairs_with_remote_faces": remote_smooths, "exchanges_overlapped_with_stencil_launches": overlapped,
+                                 "note": "fine-level smoother: ONE two-cell-deep halo exchange per sweep pair; residual and coarser sweeps: exchange overlapped with the interior launch"}
+                                if world > 1 else None),
                        "baseline_config": args.workload,
                        "fine_grid_dof": dof, "fcycle_residual_norm": norm, "parallelism": f"boxes over {world} GPU(s), RCCL halo exchange"},
             "roofline": roof,
