@@ -116,6 +116,8 @@ void hpgmg_solver_destroy(hpgmg_solver *s) {
 }
 
 int hpgmg_solver_num_levels(const hpgmg_solver *s) { return s->mg.num_levels; }
+mg_type *hpgmg_solver_mg(hpgmg_solver *s) { return &s->mg; }
+void hpgmg_solver_coefficients(const hpgmg_solver *s, double ab[2]) { ab[0] = s->a; ab[1] = s->b; }
 level_type *hpgmg_solver_level(hpgmg_solver *s, int l) { return (l >= 0 && l < s->mg.num_levels) ? s->mg.levels[l] : NULL; }
 
 void hpgmg_solver_restrict_rhs(hpgmg_solver *s, int l) {

@@ -386,8 +386,16 @@ void MGResetTimers(mg_type *G) {
 static long long seg_base = 0;   /* identifies (hierarchy, start level) of the running solve */
 static int seg_counter = 0, seg_open_now = 0;
 static int is_small(const mg_type *G, int l) { return G->levels[l]->dim.i <= SEGMENT_MAX_DIM; }
-static void seg_reset(const mg_type *G, int onLevel) {
-  seg_base = (long long)((((unsigned long long)(uintptr_t)G) << 20) ^ ((unsigned long long)onLevel << 12));   /* unsigned: the shift may wrap */
+/* A captured segment bakes in the vector ids, a, b and (through the Chebyshev coefficients) every level's eigenvalue bound: all of them
+ * are part of the key, so another solve on the same hierarchy with other vectors or a rebuilt operator never replays a stale graph. */
+static void seg_reset(const mg_type *G, int onLevel, int u_id, int F_id, double a, double b) {
+  unsigned long long h = 1469598103934665603ULL;   /* FNV-1a over the configuration */
+  int l;
+#define MIX(v) do { unsigned long long t_; double d_ = (double)(v); memcpy(&t_, &d_, sizeof t_); h = (h ^ t_) * 1099511628211ULL; } while (0)
+  MIX(u_id); MIX(F_id); MIX(a); MIX(b); MIX(onLevel);
+  for (l = 0; l < G->num_levels; l++) MIX(G->levels[l]->dominant_eigenvalue_of_DinvA);
+#undef MIX
+  seg_base = (long long)(((((unsigned long long)(uintptr_t)G) << 20) ^ (h << 12)) & ~0xfffULL);   /* low 12 bits: the segment counter */
   seg_counter = 0; seg_open_now = 0;
 }
 static void seg_open(void) { if (!seg_open_now) { hpgmg_segment_begin(seg_base + (seg_counter++)); seg_open_now = 1; } }
@@ -498,7 +506,7 @@ void MGSolve(mg_type *G, int onLevel, int u_id, int F_id, double a, double b, do
   if (!L->active) return;
   SAY(L->my_rank, "MGSolve... ");
   double t0 = now();
-  seg_reset(G, onLevel + 64);
+  seg_reset(G, onLevel + 64, u_id, F_id, a, b);
   double norm_of_F = norm(L, F_id);
   zero_vector(L, e_id);
   scale_vector(L, R_id, 1.0, F_id);
@@ -527,7 +535,7 @@ void FMGSolve(mg_type *G, int onLevel, int u_id, int F_id, double a, double b, d
   if (!L->active) return;
   SAY(L->my_rank, "FMGSolve... ");
   const double t0 = now();
-  seg_reset(G, onLevel);
+  seg_reset(G, onLevel, u_id, F_id, a, b);
 
   t = hpgmg_tick_begin(L, &L->timers.Total, "norm(F), R = F");
   double norm_of_F = 0.0;

@@ -46,6 +46,8 @@ void   hpgmg_solver_restrict_rhs(hpgmg_solver *s, int l);
 double hpgmg_solver_fmg(hpgmg_solver *s, int l);
 /* warmup + timed solves (hpgmg-fv.c:50-99); returns average seconds per solve */
 double hpgmg_solver_bench(hpgmg_solver *s, int l, int warmup, int solves);
+mg_type *hpgmg_solver_mg(hpgmg_solver *s);                               /* the hierarchy, for callers of MGSolve / FMGSolve (hpgmg_mg.h) */
+void   hpgmg_solver_coefficients(const hpgmg_solver *s, double ab[2]);   /* the a, b of the test problem */
 /* solve on l, l+1, l+2 then richardson_error (hpgmg-fv.c:351-366); out[0]=error out[1]=order */
 void   hpgmg_solver_richardson(hpgmg_solver *s, double out[2]);
 

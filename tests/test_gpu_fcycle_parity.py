@@ -62,7 +62,7 @@ def test_hip_fcycle_full_size_256(hip, variant):
 def test_fp32_smoother_is_tolerance_gated_against_fp64(hip, variant):
     """BASELINE.json config 5 (`7 8`, mixed-precision Chebyshev smoother: fp32 coefficient streams, fp64 iterate and
     arithmetic).  Not bit-exact by construction; gated against the fp64 reference numbers:
-    F-cycle residual norm within 1e-3 relative, discretisation error (the quantity the solver is for) within 1e-6
+    F-cycle residual norm within 2e-4 relative (measured 8e-5), discretisation error (the quantity the solver is for) within 1e-7 (measured 5e-9)
     relative, same convergence order.  Measured on MI355X: 8e-5 and 5e-9."""
     import ctypes
     gold = GOLD[f"{variant} 7 8"]
@@ -73,11 +73,11 @@ def test_fp32_smoother_is_tolerance_gated_against_fp64(hip, variant):
         s = hip.solver_cli(7, 8)
         got = s.three_sizes()
         ref = [float(r) for r in gold["norms"]]
-        assert abs(got[0] - ref[0]) <= 1e-3 * ref[0], (got[0], ref[0])
+        assert abs(got[0] - ref[0]) <= 2e-4 * ref[0], (got[0], ref[0])
         assert got[0] != ref[0] or variant == "7ptcc-cheby"     # the fp32 streams were really used (CC has only Dinv)
         assert [fmt(v) for v in got[1:]] == gold["norms"][1:]   # 128^3 and 64^3: boxes of 64^3 / 32^3 smooth in fp64
         err, order = s.richardson()
-        assert abs(err - float(gold["richardson_error"])) <= 1e-6 * float(gold["richardson_error"])
+        assert abs(err - float(gold["richardson_error"])) <= 1e-7 * float(gold["richardson_error"])
         assert "%0.3f" % order == gold["order"]
         s.destroy()
     finally:
@@ -101,6 +101,21 @@ def test_hipgraph_segments_replay_the_same_numbers(hip):
             assert fmt(s.fmg(0)) == gold["norms"][0]
         K.hpgmg_hip_graph_stats(stats)
         assert stats[1] > before[1] and stats[2] > before[2], (before, list(stats))     # captured, then replayed
+        # the same hierarchy solved into ANOTHER vector: the cached graphs bake vector ids in, so the key must change with them
+        import numpy as np
+        import hpgmg_amd as Hh
+        L = hip.lib
+        L.hpgmg_solver_mg.restype = ctypes.c_void_p; L.hpgmg_solver_mg.argtypes = [ctypes.c_void_p]
+        L.FMGSolve.restype = None
+        L.FMGSolve.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double]
+        ab = (ctypes.c_double * 2)(); L.hpgmg_solver_coefficients.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)]; L.hpgmg_solver_coefficients(s.ptr, ab)
+        lv = s.level(0)
+        want = lv.interior(Hh.VECTOR_U)
+        for _ in range(3):                       # eager, captured, replayed -- with E in place of U
+            L.zero_vector(lv.ptr, Hh.VECTOR_E)
+            L.FMGSolve(L.hpgmg_solver_mg(s.ptr), 0, Hh.VECTOR_E, Hh.VECTOR_F, ab[0], ab[1], 1e-10)
+            assert np.array_equal(lv.interior(Hh.VECTOR_E), want)
+        assert fmt(s.fmg(0)) == gold["norms"][0]
         s.destroy()
     finally:
         hip.lib.hpgmg_set_graphs(0)
