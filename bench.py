@@ -85,7 +85,8 @@ def pmc_traffic():
         for f in sorted(os.listdir(pdir)):
             if f.endswith("_pmc_summary.json"):
                 try:
-                    best = json.load(open(os.path.join(pdir, f))).get("hbm_bytes_per_launch_cheby_fine")
+                    got = json.load(open(os.path.join(pdir, f))).get("hbm_bytes_per_launch_cheby_fine")
+                    best = got if got else best          # the newest summary of the config-2 smoother (files sort by round tag)
                 except Exception:
                     pass
     return best

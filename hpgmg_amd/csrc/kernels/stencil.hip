@@ -677,15 +677,15 @@ static int launch27(const hpgmg_hip_level *L, StencilArgs P, bool is_smoother) {
 }
 
 // the LDS-tiled 4th-order kernel (fv4_tile.hpp): boxes whose side is a multiple of 64, out of place
-template <int MODE>
-static int launch_fv4_tile(const hpgmg_hip_level *L, int variant, const StencilArgs &S, bool is_smoother) {
-  constexpr int TJ = 8;
+template <int MODE, int TJ>
+static int launch_fv4_tile_tj(const hpgmg_hip_level *L, int variant, const StencilArgs &S, bool is_smoother) {
   Fv4TileArgs P = {};
   P.xn_id = S.xn_id; P.xout_id = S.xout_id; P.rhs_id = S.rhs_id; P.a = S.a; P.b = S.b; P.h2inv = S.h2inv; P.c1 = S.c1; P.c2 = S.c2;
   P.sweep = S.sweep; P.copy_other_colour = S.copy_other_colour;
   P.tiles_i = L->dim / 64; P.tiles_j = L->dim / TJ;
-  int kchunk = L->dim;                                   // enough workgroups for two per CU, as few chunk prologues as possible
-  while (kchunk > 16 && (long long)L->num_boxes * P.tiles_i * P.tiles_j * (L->dim / kchunk) < 1024) kchunk /= 2;
+  int kchunk = L->dim;                                   // enough workgroups to fill the chip, as few chunk prologues as possible
+  const int want = (TJ >= 16) ? 512 : 1024;
+  while (kchunk > 16 && (long long)L->num_boxes * P.tiles_i * P.tiles_j * (L->dim / kchunk) < want) kchunk /= 2;
   static const int tune_kc = env_int("HPGMG_TUNE_FV4_KCHUNK", 0);
   if (tune_kc > 0 && L->dim % tune_kc == 0) kchunk = tune_kc;
   P.kchunk = kchunk; P.chunks_k = (L->dim + kchunk - 1) / kchunk;
@@ -703,6 +703,15 @@ static int launch_fv4_tile(const hpgmg_hip_level *L, int variant, const StencilA
   profile_end(prof, cells);
   HPGMG_LAUNCH_CHECK("fv4_tile_kernel");
   return 0;
+}
+// the LDS-tiled 4th-order kernel (fv4_tile.hpp): boxes whose side is a multiple of 64, out of place.  Tile height 8 (two workgroups
+// per CU; 1.59 values loaded per cell and array) measured 1.85 ms per half sweep at 512^3, height 16 (one workgroup of 16 waves and
+// 120 KB of LDS per CU; 1.33 values) 1.92 ms: the second resident workgroup hides more latency than the smaller halo saves
+template <int MODE>
+static int launch_fv4_tile(const hpgmg_hip_level *L, int variant, const StencilArgs &S, bool is_smoother) {
+  static const int tj = env_int("HPGMG_TUNE_FV4_TJ", 8);
+  if (tj == 8) return launch_fv4_tile_tj<MODE, 8>(L, variant, S, is_smoother);
+  return launch_fv4_tile_tj<MODE, 16>(L, variant, S, is_smoother);
 }
 
 template <int MODE>

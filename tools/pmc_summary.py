@@ -38,6 +38,8 @@ def main():
     fetch, write, out = per_kernel(sys.argv[1]), per_kernel(sys.argv[2]), sys.argv[3]
     cells = int(sys.argv[sys.argv.index("--cells") + 1]) if "--cells" in sys.argv else 256 ** 3
     rows = {"cheby_pair_fine": ("cheby_pair_kernel", 144), "cheby_pair_edge_columns": ("cheby_pair_edge_kernel", 0), "cheby_fine": ("stencil7_wide_kernelILi0ELi0", 72), "residual_fine": ("stencil7_wide_kernelILi0ELi3", 56),
+            "residual_restrict_zero_fine": ("stencil7_wide_kernelILi0ELi6", 58), "residual_norm_fine": ("stencil7_wide_kernelILi0ELi7", 56),
+            "norm_copy_restrict_fine": ("norm_copy_restrict_kernel", 17), "fv4_gsrb_fine": ("fv4_tile_kernelILi5ELi1", 56), "stencil27_gsrb_fine": ("stencil27_kernelILi1", 32),
             "scale_fine": ("elementwise_kernelILi3", 16), "interp_p0_fine": ("interp_blocks_kernelILi0", 17),
             "interp_p1_fine": ("interp_blocks_kernelILi1", 17), "restrict_fine": ("restrict_blocks_kernelILi0", 9), "norm_fine": ("absmax_kernel", 8)}
     res = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), MI355X",
@@ -54,6 +56,10 @@ def main():
     if "cheby_pair_fine" in k:      # the smoother launch bench.py times = edge-column pre-pass + pair kernel (two sweeps)
         res["hbm_bytes_per_launch_cheby_fine"] = k["cheby_pair_fine"]["hbm_bytes_per_launch"] + k.get("cheby_pair_edge_columns", {}).get("hbm_bytes_per_launch", 0.0)
         res["sweeps_per_launch"] = 2
+    elif "fv4_gsrb_fine" in k:
+        res["hbm_bytes_per_launch_smoother_fine"] = k["fv4_gsrb_fine"]["hbm_bytes_per_launch"]; res["sweeps_per_launch"] = 1
+    elif "stencil27_gsrb_fine" in k:
+        res["hbm_bytes_per_launch_smoother_fine"] = k["stencil27_gsrb_fine"]["hbm_bytes_per_launch"]; res["sweeps_per_launch"] = 1
     elif "cheby_fine" in k:
         res["hbm_bytes_per_launch_cheby_fine"] = k["cheby_fine"]["hbm_bytes_per_launch"]
         res["sweeps_per_launch"] = 1
