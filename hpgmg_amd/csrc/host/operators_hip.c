@@ -933,6 +933,50 @@ int hpgmg_interp_smooth_fused(level_type *Lf, int e_id, int R_id, level_type *Lc
   return 1;
 }
 
+/* Small levels of the 27-point / fv2 / fv4 plugins: smooth(), residual() or apply_op() with their exchange_boundary + apply_BCs steps as
+ * ONE single-workgroup launch (kernels/stencil.hip: small_level_kernel).  mode: 0 Chebyshev, 1 GSRB, 2 Jacobi, 3 residual, 4 apply_op.
+ * Returns 0 when the level does not qualify (too large, messages needed, 7-point plugin: that one has the LDS-resident tail kernel).
+ * OFF by default (HPGMG_SMALL_FUSED=1 enables; bit-identical, covered by the GPU tests): measured on MI355X it is SLOWER than the
+ * launches it replaces -- fv4 GSRB `7 8` 17.1 vs 12.7 ms, 27-pt GSRB 9.9 vs 6.2 ms per F-cycle -- because a 16^3 level in 8 boxes has
+ * ~160 copy / boundary list entries whose dependent load chains run 16 at a time on one CU, while separate launches spread them over
+ * the chip; the launch overhead saved (~5 us each) is smaller than that serialisation. */
+static int small_fused = -1;
+void hpgmg_set_small_fused(int on) { small_fused = on ? 1 : 0; }
+static int small_level_try(level_type *L, int mode, int x_id, int rhs_id, int res_id, double a, double b) {
+  hpgmg_config cfg;
+  if (small_fused < 0) { const char *e = getenv("HPGMG_SMALL_FUSED"); small_fused = (e && e[0] == '1'); }
+  const int enabled = small_fused;
+  hpgmg_get_config(&cfg);
+  if (!enabled || cfg.op == HPGMG_OP_7PT || L->num_my_boxes < 1) return 0;
+  if ((long long)L->dim.i * L->dim.j * L->dim.k > hpgmg_hip_small_level_max_cells()) return 0;
+  if (L->num_my_boxes != L->boxes_in.i * L->boxes_in.j * L->boxes_in.k) return 0;
+  const int shape = stencil_get_shape();
+  communicator_type *C = &L->exchange_ghosts[shape];
+  if (C->num_sends + C->num_recvs > 0 || C->num_blocks[0] || C->num_blocks[2]) return 0;
+  int bc_kind = 0, zero_first = 0, n_bc = 0;
+  if (L->boundary_condition.type != BC_PERIODIC) {
+    n_bc = L->boundary_condition.num_blocks[shape];
+    if (cfg.op == HPGMG_OP_27PT) bc_kind = (L->box_dim < 2) ? 1 : 2;                                    /* apply_BCs_p2, boundary_fd.c:93-205 */
+    else if (cfg.op == HPGMG_OP_FV2 || L->box_dim < 4) { bc_kind = (L->box_dim < 2) ? 1 : 3; zero_first = (bc_kind == 3 && L->box_ghosts > 1); }   /* apply_BCs_v2 (v4 falls back to it below 4^3) */
+    else { bc_kind = 4; zero_first = (L->box_ghosts > 2); }                                            /* apply_BCs_v4 */
+  }
+  const int sweeps = (mode <= 2) ? hpgmg_smooth_sweeps() : 1;
+  double c1[16], c2[16];
+  int q;
+  for (q = 0; q < 16; q++) c1[q] = c2[q] = 0.0;
+  if (mode == 0) cheby_coefficients(L, sweeps, c1, c2);
+  if (mode == 2) for (q = 0; q < sweeps; q++) c2[q] = 2.0 / 3.0;
+  if (sweeps > 8) return 0;
+  backend_t *B = backend_of(L);
+  const double t_h2inv = 1.0 / (L->h * L->h);
+  hpgmg_tick tk = hpgmg_tick_begin(L, mode <= 2 ? &L->timers.smooth : (mode == 3 ? &L->timers.residual : &L->timers.apply_op), "small level, one launch");
+  HIP_OK(hpgmg_hip_small_level_op(&B->dev, variant(), mode, sweeps, x_id, rhs_id, res_id, mode == 1 ? hpgmg_gsrb_out_of_place() : 0, a, b, t_h2inv, c1, c2,
+                                  mirror(L, C->blocks[1], C->num_blocks[1]), C->num_blocks[1],
+                                  n_bc ? mirror(L, L->boundary_condition.blocks[shape], n_bc) : NULL, n_bc, bc_kind, zero_first));
+  hpgmg_tick_end(tk);
+  return 1;
+}
+
 void smooth(level_type *L, int x_id, int rhs_id, double a, double b) {
   hpgmg_config cfg;
   hpgmg_get_config(&cfg);
@@ -940,6 +984,7 @@ void smooth(level_type *L, int x_id, int rhs_id, double a, double b) {
   const double h2inv = 1.0 / (L->h * L->h);
   backend_t *B = backend_of(L);
   int s;
+  if (cfg.op != HPGMG_OP_7PT && small_level_try(L, cfg.smoother == HPGMG_SMOOTH_CHEBY ? 0 : (cfg.smoother == HPGMG_SMOOTH_GSRB ? 1 : 2), x_id, rhs_id, x_id, a, b)) return;
   if (cfg.smoother == HPGMG_SMOOTH_CHEBY) {          /* chebyshev.c:8-100 */
     double c1[16], c2[16];
     if (L->dominant_eigenvalue_of_DinvA <= 0.0 && L->my_rank == 0) fprintf(stderr, "dominant_eigenvalue_of_DinvA <= 0.0 !\n");
@@ -965,9 +1010,11 @@ void smooth(level_type *L, int x_id, int rhs_id, double a, double b) {
 }
 
 void residual(level_type *L, int res_id, int x_id, int rhs_id, double a, double b) {   /* residual.c:9-51 */
+  if (small_level_try(L, 3, x_id, rhs_id, res_id, a, b)) return;
   STENCIL_WITH_GHOSTS(L, x_id, residual, hpgmg_hip_residual(&backend_of(L)->dev, variant(), res_id, x_id, rhs_id, a, b, 1.0 / (L->h * L->h)));
 }
 void apply_op(level_type *L, int Ax_id, int x_id, double a, double b) {               /* apply_op.c:9-48 */
+  if (small_level_try(L, 4, x_id, -1, Ax_id, a, b)) return;
   STENCIL_WITH_GHOSTS(L, x_id, apply_op, hpgmg_hip_residual(&backend_of(L)->dev, variant(), Ax_id, x_id, -1, a, b, 1.0 / (L->h * L->h)));
 }
 

@@ -1,0 +1,210 @@
+// block_ops.hpp -- entry routines of the block-list executors (ghost-exchange copies and the boundary conditions), shared by the
+// streaming kernels of blocks.hip (one workgroup per list entry) and the single-workgroup small-level kernels of stencil.hip (one
+// wave per entry).  Reference semantics per entry: operators/blockCopy.c:6-156, boundary_fd.c:6-205, boundary_fv.c:101-569.
+#pragma once
+#include "common.hpp"
+
+namespace hpgmg {
+
+struct Side { double *p; int jS, kS; };
+
+// resolve one side of an entry to a pointer at its (i,j,k) start plus strides
+__device__ __forceinline__ Side resolve_read(const hpgmg_hip_level &L, int id, const blockCopy_type &e) {
+  Side s;
+  if (e.read.box >= 0) { s.jS = L.jStride; s.kS = L.kStride; s.p = vec_origin(L, e.read.box, id); }
+  else { s.jS = e.read.jStride; s.kS = e.read.kStride; s.p = e.read.ptr; }
+  s.p += e.read.i + e.read.j * s.jS + e.read.k * s.kS;
+  return s;
+}
+__device__ __forceinline__ Side resolve_write(const hpgmg_hip_level &L, int id, const blockCopy_type &e) {
+  Side s;
+  if (e.write.box >= 0) { s.jS = L.jStride; s.kS = L.kStride; s.p = vec_origin(L, e.write.box, id); }
+  else { s.jS = e.write.jStride; s.kS = e.write.kStride; s.p = e.write.ptr; }
+  s.p += e.write.i + e.write.j * s.jS + e.write.k * s.kS;
+  return s;
+}
+
+// Every list executor below is an ENTRY routine: lanes tid, tid + nth, ... of the caller work through entry e.  The streaming kernels
+// (blocks.hip) give one workgroup to an entry; the single-workgroup small-level kernels (stencil.hip) give a wave to an entry.
+template <bool kIncrement>
+__device__ __forceinline__ void copy_entry(const hpgmg_hip_level &L, int id, const blockCopy_type &e, double prescale, int tid, int nth) {
+  const Side r = resolve_read(L, id, e), w = resolve_write(L, id, e);
+  const int di = e.dim.i, dj = e.dim.j, n = di * dj * e.dim.k;
+  for (int t = tid; t < n; t += nth) {
+    const int i = t % di, j = (t / di) % dj, k = t / (di * dj);
+    const double v = r.p[i + j * r.jS + k * r.kS];
+    double *dst = &w.p[i + j * w.jS + k * w.kS];
+    if (kIncrement) *dst = prescale * (*dst) + v; else *dst = v;
+  }
+}
+
+__device__ __forceinline__ void bc_p1_entry(const hpgmg_hip_level &L, int id, const blockCopy_type &e, int tid, int nth) {
+  const int inward = 26 - e.subtype;                       // direction pointing back into the domain
+  const int ni = inward % 3 - 1, nj = (inward % 9) / 3 - 1, nk = inward / 9 - 1;
+  const int kind = (ni != 0) + (nj != 0) + (nk != 0);      // 1 face, 2 edge, 3 corner
+  const double scale = (kind == 2) ? 1.0 : -1.0;
+  const int jS = L.jStride, kS = L.kStride, step = ni + nj * jS + nk * kS;
+  double *x = vec_origin(L, e.read.box, id) + e.read.i + e.read.j * jS + e.read.k * kS;
+  const int di = e.dim.i, dj = e.dim.j, n = di * dj * e.dim.k;
+  for (int t = tid; t < n; t += nth) {
+    const int i = t % di, j = (t / di) % dj, k = t / (di * dj);
+    const int ijk = i + j * jS + k * kS;
+    x[ijk] = scale * x[ijk + step];
+  }
+}
+
+// boundary_fd.c:93-205 apply_BCs_p2: quadratic extrapolation through a zero on the boundary face;
+// faces 2 terms, edges 4, corners 8 (decimal literals of the reference)
+__device__ __forceinline__ void bc_p2_entry(const hpgmg_hip_level &L, int id, const blockCopy_type &e, int tid, int nth) {
+  const int jS = L.jStride, kS = L.kStride, inward = 26 - e.subtype;
+  const int di = (inward % 3 - 1) * 1, dj = ((inward % 9) / 3 - 1) * jS, dk = (inward / 9 - 1) * kS;
+  const int kind = (di != 0) + (dj != 0) + (dk != 0);
+  double *x = vec_origin(L, e.read.box, id) + e.read.i + e.read.j * jS + e.read.k * kS;
+  const int ni = e.dim.i, nj = e.dim.j, n = ni * nj * e.dim.k;
+  int dr = 0, ds = 0;
+  if (di == 0) { dr = dj; ds = dk; }
+  if (dj == 0) { dr = di; ds = dk; }
+  if (dk == 0) { dr = di; ds = dj; }
+  for (int t = tid; t < n; t += nth) {
+    const int i = t % ni, j = (t / ni) % nj, k = t / (ni * nj);
+    const int ijk = i + j * jS + k * kS;
+    double v;
+    if (kind == 1) {
+      const int s1 = di + dj + dk;
+      v = -2.0 * x[ijk + s1] + 0.333333333333333333 * x[ijk + 2 * s1];
+    } else if (kind == 2) {
+      v = 4.000000000000000000 * x[ijk + dr + ds] - 0.666666666666666667 * x[ijk + 2 * dr + ds];
+      v = v - 0.666666666666666667 * x[ijk + dr + 2 * ds];
+      v = v + 0.111111111111111111 * x[ijk + 2 * dr + 2 * ds];
+    } else {
+      v = -8.000000000000000000 * x[ijk + di + dj + dk] + 1.333333333333333333 * x[ijk + 2 * di + dj + dk];
+      v = v + 1.333333333333333333 * x[ijk + di + 2 * dj + dk];
+      v = v + 1.333333333333333333 * x[ijk + di + dj + 2 * dk];
+      v = v - 0.222222222222222222 * x[ijk + 2 * di + 2 * dj + dk];
+      v = v - 0.222222222222222222 * x[ijk + di + 2 * dj + 2 * dk];
+      v = v - 0.222222222222222222 * x[ijk + 2 * di + dj + 2 * dk];
+      v = v + 0.037037037037037037 * x[ijk + 2 * di + 2 * dj + 2 * dk];
+    }
+    x[ijk] = v;
+  }
+}
+
+
+// ---- finite-volume boundary conditions (reference operators/boundary_fv.c) -------------------
+// Geometry of one BC list entry: axes whose DOMAIN normal component is non-zero (in i<j<k order)
+// sit at ghost index -1 / dim and step inward; the remaining axes run over the entry's extent.
+struct BcGeom { int nn, pos[3], step[3], lo[2], len[2], fstride[2]; };
+__device__ __forceinline__ BcGeom bc_geometry(const hpgmg_hip_level &L, const blockCopy_type &e) {
+  BcGeom g;
+  const int strides[3] = {1, L.jStride, L.kStride}, lo[3] = {e.read.i, e.read.j, e.read.k}, len[3] = {e.dim.i, e.dim.j, e.dim.k};
+  const int d[3] = {e.subtype % 3 - 1, (e.subtype % 9) / 3 - 1, e.subtype / 9 - 1};
+  g.nn = 0; int nf = 0;
+  g.lo[0] = g.lo[1] = 0; g.len[0] = g.len[1] = 1; g.fstride[0] = g.fstride[1] = 0;
+  g.pos[0] = g.pos[1] = g.pos[2] = 0; g.step[0] = g.step[1] = g.step[2] = 0;
+#pragma unroll
+  for (int ax = 0; ax < 3; ax++) {
+    if (d[ax]) { g.pos[g.nn] = (d[ax] < 0 ? -1 : L.dim) * strides[ax]; g.step[g.nn] = -d[ax] * strides[ax]; g.nn++; }
+    else if (nf < 2) { g.lo[nf] = lo[ax]; g.len[nf] = len[ax]; g.fstride[nf] = strides[ax]; nf++; }
+  }
+  return g;
+}
+// first pass of the v2 / v4 conditions when the ghost zone is deeper than the condition fills: clear the whole region.  The caller
+// puts a barrier between this pass and the extrapolation pass (bc_v2_entry / bc_v4_entry) -- the two touch the same cells.
+__device__ __forceinline__ void bc_zero_entry(const hpgmg_hip_level &L, int id, const blockCopy_type &e, int tid, int nth) {
+  double *x = vec_origin(L, e.read.box, id);
+  const int ni = e.dim.i, nj = e.dim.j, n = ni * nj * e.dim.k;
+  for (int t = tid; t < n; t += nth) {
+    const int i = t % ni, j = (t / ni) % nj, k = t / (ni * nj);
+    x[(i + e.read.i) + (j + e.read.j) * L.jStride + (k + e.read.k) * L.kStride] = 0.0;
+  }
+}
+
+// boundary_fv.c:101-250 apply_BCs_v2: first ghost layer by quadratic extrapolation of cell averages, deeper layers zero
+__device__ __forceinline__ void bc_v2_entry(const hpgmg_hip_level &L, int id, const blockCopy_type &e, int tid, int nth) {
+  double *x = vec_origin(L, e.read.box, id);
+  const BcGeom g = bc_geometry(L, e);
+  const int n = g.len[0] * g.len[1];
+  for (int t = tid; t < n; t += nth) {
+    const int r = t % g.len[0], q = t / g.len[0];
+    int ijk = (r + g.lo[0]) * g.fstride[0] + (q + g.lo[1]) * g.fstride[1];
+    double v;
+    if (g.nn == 1) {
+      const int dt = g.step[0]; ijk += g.pos[0];
+      v = -2.5 * x[ijk + dt] + 0.5 * x[ijk + 2 * dt];
+    } else if (g.nn == 2) {
+      const int ds = g.step[0], dt = g.step[1]; ijk += g.pos[0] + g.pos[1];
+      v = 6.25 * x[ijk + ds + dt] - 1.25 * x[ijk + 2 * ds + dt];
+      v = v - 1.25 * x[ijk + ds + 2 * dt];
+      v = v + 0.25 * x[ijk + 2 * ds + 2 * dt];
+    } else {
+      const int di = g.step[0], dj = g.step[1], dk = g.step[2]; ijk += g.pos[0] + g.pos[1] + g.pos[2];
+      v = -15.625 * x[ijk + di + dj + dk] + 3.125 * x[ijk + 2 * di + dj + dk];
+      v = v + 3.125 * x[ijk + di + 2 * dj + dk];
+      v = v + 3.125 * x[ijk + di + dj + 2 * dk];
+      v = v - 0.625 * x[ijk + 2 * di + 2 * dj + dk];
+      v = v - 0.625 * x[ijk + di + 2 * dj + 2 * dk];
+      v = v - 0.625 * x[ijk + 2 * di + dj + 2 * dk];
+      v = v + 0.125 * x[ijk + 2 * di + 2 * dj + 2 * dk];
+    }
+    x[ijk] = v;
+  }
+}
+
+// boundary_fv.c:262-569 apply_BCs_v4: near/far ghost from the four cells next to the boundary,
+// N = (-77 x1 + 43 x2 - 17 x3 + 3 x4)/12, F = (-505 x1 + 335 x2 - 145 x3 + 27 x4)/12, applied axis after axis
+__device__ __forceinline__ double v4_near(double x1, double x2, double x3, double x4) { const double w = 1.0 / 12.0; double s = -77.0 * x1 + 43.0 * x2; s = s - 17.0 * x3; s = s + 3.0 * x4; return w * s; }
+__device__ __forceinline__ double v4_far(double x1, double x2, double x3, double x4)  { const double w = 1.0 / 12.0; double s = -505.0 * x1 + 335.0 * x2; s = s - 145.0 * x3; s = s + 27.0 * x4; return w * s; }
+__device__ __forceinline__ void bc_v4_entry(const hpgmg_hip_level &L, int id, const blockCopy_type &e, int tid, int nth) {
+  double *x = vec_origin(L, e.read.box, id);
+  const BcGeom g = bc_geometry(L, e);
+  const int n = g.len[0] * g.len[1];
+  for (int t = tid; t < n; t += nth) {
+    const int r = t % g.len[0], q = t / g.len[0];
+    int ijk = (r + g.lo[0]) * g.fstride[0] + (q + g.lo[1]) * g.fstride[1];
+    if (g.nn == 1) {
+      const int dt = g.step[0]; ijk += g.pos[0];
+      const double x1 = x[ijk + dt], x2 = x[ijk + 2 * dt], x3 = x[ijk + 3 * dt], x4 = x[ijk + 4 * dt];
+      x[ijk] = v4_near(x1, x2, x3, x4);
+      x[ijk - dt] = v4_far(x1, x2, x3, x4);
+    } else if (g.nn == 2) {
+      const int ds = g.step[0], dt = g.step[1]; ijk += g.pos[0] + g.pos[1];
+      double nr[4], fr[4];
+#pragma unroll
+      for (int m = 0; m < 4; m++) {
+        const int o = ijk + (m + 1) * dt;
+        const double a1 = x[o + ds], a2 = x[o + 2 * ds], a3 = x[o + 3 * ds], a4 = x[o + 4 * ds];
+        nr[m] = v4_near(a1, a2, a3, a4); fr[m] = v4_far(a1, a2, a3, a4);
+      }
+      x[ijk]           = v4_near(nr[0], nr[1], nr[2], nr[3]);
+      x[ijk - dt]      = v4_far(nr[0], nr[1], nr[2], nr[3]);
+      x[ijk - ds]      = v4_near(fr[0], fr[1], fr[2], fr[3]);
+      x[ijk - ds - dt] = v4_far(fr[0], fr[1], fr[2], fr[3]);
+    } else {
+      const int di = g.step[0], dj = g.step[1], dk = g.step[2]; ijk += g.pos[0] + g.pos[1] + g.pos[2];
+      double nn[4], nf[4], fn[4], ff[4];
+#pragma unroll
+      for (int p = 0; p < 4; p++) {
+        double nj[4], fj[4];
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+          const int o = ijk + (m + 1) * dj + (p + 1) * dk;
+          const double a1 = x[o + di], a2 = x[o + 2 * di], a3 = x[o + 3 * di], a4 = x[o + 4 * di];
+          nj[m] = v4_near(a1, a2, a3, a4); fj[m] = v4_far(a1, a2, a3, a4);
+        }
+        nn[p] = v4_near(nj[0], nj[1], nj[2], nj[3]); nf[p] = v4_far(nj[0], nj[1], nj[2], nj[3]);
+        fn[p] = v4_near(fj[0], fj[1], fj[2], fj[3]); ff[p] = v4_far(fj[0], fj[1], fj[2], fj[3]);
+      }
+      x[ijk]                = v4_near(nn[0], nn[1], nn[2], nn[3]);
+      x[ijk - dk]           = v4_far(nn[0], nn[1], nn[2], nn[3]);
+      x[ijk - dj]           = v4_near(nf[0], nf[1], nf[2], nf[3]);
+      x[ijk - dj - dk]      = v4_far(nf[0], nf[1], nf[2], nf[3]);
+      x[ijk - di]           = v4_near(fn[0], fn[1], fn[2], fn[3]);
+      x[ijk - di - dk]      = v4_far(fn[0], fn[1], fn[2], fn[3]);
+      x[ijk - di - dj]      = v4_near(ff[0], ff[1], ff[2], ff[3]);
+      x[ijk - di - dj - dk] = v4_far(ff[0], ff[1], ff[2], ff[3]);
+    }
+  }
+}
+
+
+}  // namespace hpgmg

@@ -26,6 +26,7 @@
 #include "stencil_math.hpp"
 #include "cheby_pair.hpp"
 #include "fv4_tile.hpp"
+#include "block_ops.hpp"
 
 namespace hpgmg {
 
@@ -600,6 +601,73 @@ __global__ __launch_bounds__(256) void stencil_direct_kernel(const hpgmg_hip_lev
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Small levels (<= 4096 cells) of the 27-point / fv2 / fv4 plugins: a whole smooth() -- per sweep exchange_boundary (local copies),
+// apply_BCs and the stencil, the three launches operators.27pt.c / .fv2.c / .fv4.c sequence per sweep -- or a whole residual() /
+// apply_op() as ONE single-workgroup launch, with barriers where the per-operator path has kernel boundaries.  On these levels a
+// launch costs more than the work (fv4: 18 launches of ~6 us per smooth()); the arithmetic is the same entry routines and the same
+// per-cell expressions as the streaming kernels, so results stay bit-identical.  (The 7-point plugin has its own, LDS-resident form
+// of this idea: tail.hip.)
+struct SmallArgs {
+  int mode, sweeps, x_id, rhs_id, res_id, out_of_place, bc_kind, zero_first;   // bc_kind: 0 none (periodic), 1 p1, 2 p2, 3 v2, 4 v4
+  double a, b, h2inv, c1[8], c2[8];
+  const blockCopy_type *copy_list; int n_copy;
+  const blockCopy_type *bc_list; int n_bc;
+};
+template <int V>
+__global__ __launch_bounds__(1024) void small_level_kernel(const hpgmg_hip_level L, const SmallArgs A) {
+  constexpr bool kFv4 = (V == HPGMG_HIP_FV4_VC_HELMHOLTZ || V == HPGMG_HIP_FV4_VC_POISSON), k27 = (V == HPGMG_HIP_27PT_CC);
+  constexpr bool kVC = (V != HPGMG_HIP_7PT_CC && !k27);
+  constexpr bool kHelm = (V == HPGMG_HIP_7PT_VC_HELMHOLTZ || V == HPGMG_HIP_FV4_VC_HELMHOLTZ);
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = (int)blockDim.x >> 6;
+  const int dim = L.dim, jS = L.jStride, kS = L.kStride, per_box = dim * dim * dim, total = per_box * L.num_boxes;
+  for (int s = 0; s < A.sweeps; s++) {
+    int src = A.x_id, dst = A.res_id;
+    if (A.mode == MODE_CHEBY || A.mode == MODE_JACOBI || (A.mode == MODE_GSRB && A.out_of_place)) { src = (s & 1) ? VECTOR_TEMP : A.x_id; dst = (s & 1) ? A.x_id : VECTOR_TEMP; }
+    else if (A.mode == MODE_GSRB) { src = A.x_id; dst = A.x_id; }
+    // exchange_boundary(src): box -> box copies (blockCopy.c:6-105)
+    for (int e = wave; e < A.n_copy; e += nwaves) copy_entry<false>(L, src, A.copy_list[e], 0.0, lane, 64);
+    __syncthreads();
+    // apply_BCs(src)
+    if (A.bc_kind && A.zero_first) { for (int e = wave; e < A.n_bc; e += nwaves) bc_zero_entry(L, src, A.bc_list[e], lane, 64); __syncthreads(); }
+    for (int e = wave; e < A.n_bc; e += nwaves) {
+      if (A.bc_kind == 1) bc_p1_entry(L, src, A.bc_list[e], lane, 64);
+      else if (A.bc_kind == 2) bc_p2_entry(L, src, A.bc_list[e], lane, 64);
+      else if (A.bc_kind == 3) bc_v2_entry(L, src, A.bc_list[e], lane, 64);
+      else if (A.bc_kind == 4) bc_v4_entry(L, src, A.bc_list[e], lane, 64);
+    }
+    __syncthreads();
+    // the stencil over every cell (same expressions as stencil_direct_kernel / stencil27_kernel)
+    for (int t = tid; t < total; t += (int)blockDim.x) {
+      const int box = t / per_box, r = t - box * per_box, k = r / (dim * dim), j = (r / dim) % dim, i = r % dim;
+      const int ijk = i + j * jS + k * kS;
+      const double *x = vec_origin(L, box, src);
+      double *out = vec_origin(L, box, dst);
+      const double xc = x[ijk];
+      bool update = true;
+      if (A.mode == MODE_GSRB) update = (((i ^ j ^ k ^ L.box_low[3 * box] ^ L.box_low[3 * box + 1] ^ L.box_low[3 * box + 2] ^ s) & 1) == 0);
+      if (!update) { if (A.out_of_place) out[ijk] = xc; continue; }
+      double Ax;
+      if (k27) {
+        const plane9 m = load_plane(x + ijk - kS, jS), c = load_plane(x + ijk, jS), p = load_plane(x + ijk + kS, jS);
+        Ax = apply_op_27pt(m, c, p, A.a, A.b, A.h2inv);
+      } else {
+        Ax = apply_op_direct<V>(x, kHelm ? vec_origin(L, box, VECTOR_ALPHA) : nullptr, kVC ? vec_origin(L, box, VECTOR_BETA_I) : nullptr,
+                                kVC ? vec_origin(L, box, VECTOR_BETA_J) : nullptr, kVC ? vec_origin(L, box, VECTOR_BETA_K) : nullptr, ijk, jS, kS, A.a, A.b, A.h2inv);
+      }
+      if (A.mode == MODE_APPLY) { out[ijk] = Ax; continue; }
+      const double rhs = vec_origin(L, box, A.rhs_id)[ijk];
+      if (A.mode == MODE_RESIDUAL) { out[ijk] = rhs - Ax; continue; }
+      const double dinv = vec_origin(L, box, VECTOR_DINV)[ijk];
+      if (A.mode == MODE_CHEBY)      { const double xnm1 = out[ijk]; out[ijk] = xc + A.c1[s] * (xc - xnm1) + A.c2[s] * dinv * (rhs - Ax); }
+      else if (A.mode == MODE_GSRB)  { out[ijk] = xc + dinv * (rhs - Ax); }
+      else                           { out[ijk] = xc + A.c2[s] * dinv * (rhs - Ax); }
+    }
+    __syncthreads();
+  }
+  (void)kFv4;
+}
+
 // ---- smoother-kernel profiling: hipEvent pair around every smoother launch ----
 static bool g_profile = false;
 static long long g_profile_min_cells = 0;   // only launches covering at least this many cells are timed
@@ -1036,6 +1104,35 @@ int hpgmg_hip_smooth_gsrb_pair(const hpgmg_hip_level *L, int variant, double *co
                                int x0_scr, int x0_id, int edge_scr_id, int out2_scr, int out2_id, int rhs_id,
                                double a, double b, double h2inv, int sweep) {
   return smooth_pair(L, variant, 1, sweep, scr_base, c32_base, x0_scr, x0_id, x0_scr, x0_id, 1, edge_scr_id, out2_scr, out2_id, rhs_id, a, b, h2inv, 0.0, 0.0, 0.0, 0.0);
+}
+int hpgmg_hip_small_level_max_cells(void) { return 4096; }
+// mode: 0 Chebyshev, 1 GSRB, 2 Jacobi (x_id <-> VECTOR_TEMP ping-pong as smooth() does; GSRB in place unless out_of_place), 3 residual
+// (res_id = rhs - A x), 4 apply_op (res_id = A x); c1 / c2: per-sweep Chebyshev coefficients (Jacobi: c2 = the weight)
+int hpgmg_hip_small_level_op(const hpgmg_hip_level *L, int variant, int mode, int sweeps, int x_id, int rhs_id, int res_id, int out_of_place,
+                             double a, double b, double h2inv, const double *c1, const double *c2,
+                             const blockCopy_type *copy_list, int n_copy, const blockCopy_type *bc_list, int n_bc, int bc_kind, int zero_first) {
+  HPGMG_SKIP_IF_REPLAY();
+  if (L->num_boxes <= 0) return 0;
+  if (sweeps < 1 || sweeps > 8 || mode < MODE_CHEBY || mode > MODE_APPLY || (long long)L->num_boxes * L->dim * L->dim * L->dim > 4096)
+    return record_error(hipErrorInvalidValue, "small_level_op: arguments");
+  SmallArgs A = {};
+  A.mode = mode; A.sweeps = sweeps; A.x_id = x_id; A.rhs_id = rhs_id; A.res_id = res_id; A.out_of_place = out_of_place;
+  A.bc_kind = n_bc > 0 ? bc_kind : 0; A.zero_first = zero_first; A.a = a; A.b = b; A.h2inv = h2inv;
+  for (int q = 0; q < sweeps; q++) { A.c1[q] = c1 ? c1[q] : 0.0; A.c2[q] = c2 ? c2[q] : 0.0; }
+  A.copy_list = copy_list; A.n_copy = copy_list ? n_copy : 0; A.bc_list = bc_list; A.n_bc = bc_list ? n_bc : 0;
+  const long long cells = (long long)L->num_boxes * L->dim * L->dim * L->dim;
+  const int threads = cells >= 1024 ? 1024 : (cells >= 256 ? 256 : 64);
+  switch (variant) {
+    case HPGMG_HIP_27PT_CC:          hipLaunchKernelGGL((small_level_kernel<HPGMG_HIP_27PT_CC>), dim3(1), dim3(threads), 0, g_stream, *L, A); break;
+    case HPGMG_HIP_FV4_VC_HELMHOLTZ: hipLaunchKernelGGL((small_level_kernel<HPGMG_HIP_FV4_VC_HELMHOLTZ>), dim3(1), dim3(threads), 0, g_stream, *L, A); break;
+    case HPGMG_HIP_FV4_VC_POISSON:   hipLaunchKernelGGL((small_level_kernel<HPGMG_HIP_FV4_VC_POISSON>), dim3(1), dim3(threads), 0, g_stream, *L, A); break;
+    case HPGMG_HIP_7PT_VC_HELMHOLTZ: hipLaunchKernelGGL((small_level_kernel<HPGMG_HIP_7PT_VC_HELMHOLTZ>), dim3(1), dim3(threads), 0, g_stream, *L, A); break;
+    case HPGMG_HIP_7PT_VC_POISSON:   hipLaunchKernelGGL((small_level_kernel<HPGMG_HIP_7PT_VC_POISSON>), dim3(1), dim3(threads), 0, g_stream, *L, A); break;
+    case HPGMG_HIP_7PT_CC:           hipLaunchKernelGGL((small_level_kernel<HPGMG_HIP_7PT_CC>), dim3(1), dim3(threads), 0, g_stream, *L, A); break;
+    default: return record_error(hipErrorInvalidValue, "small_level_op: variant");
+  }
+  HPGMG_LAUNCH_CHECK("small_level_kernel");
+  return 0;
 }
 int hpgmg_hip_smooth_gsrb(const hpgmg_hip_level *L, int variant, int xn_id, int xnp1_id, int rhs_id,
                           double a, double b, double h2inv, int sweep) {

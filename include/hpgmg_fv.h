@@ -79,6 +79,7 @@ void        hpgmg_set_verbose(int v);
 int         hpgmg_transport_init_rccl(const char *id128, int rank, int size);
 void        hpgmg_transport_finalize_rccl(void);
 void        hpgmg_set_sync_timers(int on);
+void        hpgmg_set_small_fused(int on);     /* 27-pt / fv2 / fv4: smooth(), residual() on levels of <= 4096 cells as one single-workgroup launch (off by default: measured slower) */
 long long   hpgmg_pair_remote_smooths(void);   /* smooth() calls executed as sweep pairs with faces owned by other ranks (tests) */
 /* level->timers after settling pending device timers: smooth, residual, apply_op, blas1, boundary_conditions, restriction_total,
  * interpolation_total, ghostZone_total, Total (seconds since MGResetTimers; reference level.h:162-196) */

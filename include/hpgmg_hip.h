@@ -115,6 +115,15 @@ int hpgmg_hip_residual_fused_supported(const hpgmg_hip_level *L, int variant);
 int hpgmg_hip_residual_restrict(const hpgmg_hip_level *L, int variant, int x_id, int rhs_id, double a, double b, double h2inv,
                                 const hpgmg_hip_level *Lc, int coarse_id, const int *map, int zero_id);
 int hpgmg_hip_residual_norm(const hpgmg_hip_level *L, int variant, int res_id, int x_id, int rhs_id, double a, double b, double h2inv, double *norm_out);
+/* Small levels (<= hpgmg_hip_small_level_max_cells() cells, every exchange copy local) of the 27-point / fv2 / fv4 plugins: a whole
+ * smooth() -- per sweep exchange_boundary (local copy list), apply_BCs (list + kind: 1 p1, 2 p2, 3 v2, 4 v4; zero_first = clear the
+ * regions before extrapolating, boundary_fv.c:133-140) and the stencil -- or a residual() / apply_op() in ONE single-workgroup launch.
+ * mode: 0 Chebyshev (c1, c2 per sweep), 1 GSRB (in place, or via VECTOR_TEMP when out_of_place), 2 Jacobi (c2 = weight), 3 residual
+ * (res_id = rhs - A x), 4 apply_op (res_id = A x).  Same entry routines and per-cell expressions as the streaming kernels. */
+int hpgmg_hip_small_level_max_cells(void);
+int hpgmg_hip_small_level_op(const hpgmg_hip_level *L, int variant, int mode, int sweeps, int x_id, int rhs_id, int res_id, int out_of_place,
+                             double a, double b, double h2inv, const double *c1, const double *c2,
+                             const blockCopy_type *copy_list, int n_copy, const blockCopy_type *bc_list, int n_bc, int bc_kind, int zero_first);
 /* Overlap of the halo exchange with the stencil launches below (ghost-free 7-point path only): mode 1 = the next
  * launches leave the cells next to a face owned by another rank (box_nbr == -2) untouched, mode 2 = the next launches
  * compute exactly those cells (one lane per cell), mode 0 = whole boxes. */

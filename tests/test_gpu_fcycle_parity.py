@@ -121,6 +121,26 @@ def test_hipgraph_segments_replay_the_same_numbers(hip):
         hip.lib.hpgmg_set_graphs(0)
 
 
+@pytest.mark.parametrize("variant,args", [("fv4-gsrb", "4 8"), ("27pt-gsrb", "4 8"), ("27pt-cheby", "5 8"), ("fv2-cheby", "4 8"), ("fv4-cheby", "4 8")])
+def test_small_levels_as_single_launches_give_the_same_norms(hip, variant, args):
+    """hpgmg_set_small_fused(1): smooth() / residual() of the non-7-point plugins on levels of <= 16^3 cells as one single-workgroup
+    launch each (exchange copies + boundary conditions + stencil per sweep inside).  Opt-in (measured slower than separate launches),
+    but it must be the same numbers."""
+    import ctypes
+    gold = GOLD[f"{variant} {args}"]
+    hip.lib.hpgmg_set_small_fused.argtypes = [ctypes.c_int]
+    hip.lib.hpgmg_set_small_fused(1)
+    try:
+        hip.configure(**VARIANTS[variant])
+        s = hip.solver_cli(*map(int, args.split()))
+        assert [fmt(v) for v in s.three_sizes()] == gold["norms"]
+        err, order = s.richardson()
+        assert fmt(err) == gold["richardson_error"]
+        s.destroy()
+    finally:
+        hip.lib.hpgmg_set_small_fused(0)
+
+
 def test_reference_three_launch_mode_gives_the_same_norms(hip):
     """HPGMG_GHOST_FREE=0 path (exchange_boundary + apply_BCs + stencil, as the reference sequences them)."""
     import ctypes
