@@ -427,10 +427,9 @@ __global__ __launch_bounds__(256) void stencil7_shell_kernel(const hpgmg_hip_lev
 // 40 B per cell for Chebyshev.  The weighted partial sums are formed in the reference's order:
 // ((C3*corners + C2*edges) + C1*faces) + C0*centre, each group summed left to right as listed.
 // MODE_BLACKBOX is the probe of operators/rebuild.c:126-132 (out = Aii, rhs slot = sum|Aij|).
-#define C27_0 (-4.2666666666666666666)
-#define C27_1 ( 0.4666666666666666666)
-#define C27_2 ( 0.1000000000000000000)
-#define C27_3 ( 0.0333333333333333333)
+}  // namespace hpgmg
+#include "stencil27_tile.hpp"   // C27_* constants + the LDS-staged kernel for boxes of side 64 m
+namespace hpgmg {
 struct plane9 { double v[3][3]; };   // [dj+1][di+1]
 __device__ __forceinline__ plane9 load_plane(const double *p, int jS) {
   plane9 q;
@@ -734,6 +733,26 @@ template <int MODE>
 static int launch27(const hpgmg_hip_level *L, StencilArgs P, bool is_smoother) {
   HPGMG_SKIP_IF_REPLAY();
   if (L->num_boxes <= 0) return 0;
+  static const int no_tile27 = env_int("HPGMG_TUNE_27PT_DIRECT", 0);
+  if (MODE != MODE_BLACKBOX && !no_tile27 && L->dim % 64 == 0 && P.xn_id != P.xout_id) {       // LDS-staged kernel (stencil27_tile.hpp)
+    constexpr int TJ = 8, TM = (MODE == MODE_BLACKBOX) ? MODE_APPLY : MODE;
+    S27TileArgs A = {};
+    A.xn_id = P.xn_id; A.xout_id = P.xout_id; A.rhs_id = P.rhs_id; A.mode = TM; A.a = P.a; A.b = P.b; A.h2inv = P.h2inv; A.c1 = P.c1; A.c2 = P.c2; A.sweep = P.sweep;
+    A.tiles_i = L->dim / 64; A.tiles_j = L->dim / TJ;
+    int kchunk = L->dim;
+    while (kchunk > 32 && (long long)L->num_boxes * A.tiles_i * A.tiles_j * (L->dim / kchunk) < 8192) kchunk /= 2;   // measured at 512^3: 32-plane chunks 929 us, whole boxes 952
+    static const int tune_kc = env_int("HPGMG_TUNE_27PT_KCHUNK", 0);
+    if (tune_kc > 0 && L->dim % tune_kc == 0) kchunk = tune_kc;
+    A.kchunk = kchunk; A.chunks_k = (L->dim + kchunk - 1) / kchunk;
+    A.total_blocks = L->num_boxes * A.chunks_k * A.tiles_j * A.tiles_i;
+    const int tgrid = grid_for(A.total_blocks, &A.per_xcd);
+    const long long tcells = (long long)L->num_boxes * L->dim * L->dim * L->dim;
+    const int tprof = is_smoother ? profile_begin(tcells) : -1;
+    hipLaunchKernelGGL((stencil27_tile_kernel<TM, TJ>), dim3(tgrid), dim3(64, TJ), 0, g_stream, *L, A);
+    profile_end(tprof, tcells);
+    HPGMG_LAUNCH_CHECK("stencil27_tile_kernel");
+    return 0;
+  }
   dim3 block; int grid;
   plan(L, P, block, grid);
   const long long cells = (long long)L->num_boxes * L->dim * L->dim * L->dim;

@@ -1,0 +1,125 @@
+// stencil27_tile.hpp -- the 27-point constant-coefficient operator (reference operators.27pt.c:48-51,60-91) as an LDS-staged,
+// k-marching kernel for boxes whose side is a multiple of 64.
+//
+// stencil27_kernel (stencil.hip) keeps the three 3 x 3 planes around a cell in registers and re-reads 9 values per step through
+// the vector L1: 72 B of L1 traffic per cell and step, which bounds it (8.8 TB/s of L1 traffic at 1.10 ms per coloured half sweep of
+// 512^3).  Here a 64 x TJ workgroup owns a 64 (i) x TJ (j) tile of a box and marches in +k with planes k-1, k, k+1 of x in LDS
+// (ring of three (TJ+2) x 66 tiles): a lane stores its own value (loaded one step earlier into a register) and at most one halo
+// cell, so x enters LDS once per workgroup, and the update reads its 26 neighbours from LDS (a wave reads 64 consecutive doubles:
+// conflict free).  The weighted sums are formed exactly as apply_op_27pt forms them -- ((C3*corners + C2*edges) + C1*faces) + C0*centre,
+// each group summed left to right in the listed order -- so results are bit-identical to the register kernel and to the reference.
+#pragma once
+#include "common.hpp"
+
+#ifndef C27_0
+#define C27_0 (-4.2666666666666666666)
+#define C27_1 ( 0.4666666666666666666)
+#define C27_2 ( 0.1000000000000000000)
+#define C27_3 ( 0.0333333333333333333)
+#endif
+
+namespace hpgmg {
+
+struct S27TileArgs {
+  int xn_id, xout_id, rhs_id, mode;     // mode: MODE_* of stencil.hip (Chebyshev, GSRB, Jacobi, residual, apply_op)
+  double a, b, h2inv, c1, c2;
+  int sweep;
+  int tiles_i, tiles_j, chunks_k, kchunk, per_xcd, total_blocks;
+};
+
+template <int MODE, int TJ>
+__global__ __launch_bounds__(64 * TJ) void stencil27_tile_kernel(const hpgmg_hip_level L, const S27TileArgs P) {
+  constexpr int TI = 64, W = TI + 2, H = TJ + 2, NT = 64 * TJ, PLANE = W * H;
+  constexpr int NH = 2 * W + 2 * TJ;                            // halo cells of one plane tile
+  static_assert(NH <= NT, "one halo cell per lane at most");
+  constexpr bool kSmooth = (MODE == 0 || MODE == 1 || MODE == 2);
+  __shared__ double sX[3 * PLANE];
+
+  const int logical = xcd_logical_block((int)blockIdx.x, P.per_xcd);
+  if (logical >= P.total_blocks) return;
+  int t = logical;
+  const int ti = t % P.tiles_i; t /= P.tiles_i;
+  const int tj = t % P.tiles_j; t /= P.tiles_j;
+  const int ck = t % P.chunks_k; t /= P.chunks_k;
+  const int box = t;
+  const int li = (int)threadIdx.x, lj = (int)threadIdx.y, tid = lj * 64 + li;
+  const int i0 = ti * TI, j0 = tj * TJ, i = i0 + li, j = j0 + lj;
+  const int k0 = ck * P.kchunk, k1 = (k0 + P.kchunk < L.dim) ? k0 + P.kchunk : L.dim;
+  const int jS = L.jStride, kS = L.kStride;
+
+  const double *__restrict__ x = vec_origin(L, box, P.xn_id);
+  double *__restrict__ out = vec_origin(L, box, P.xout_id);      // 27-pt GSRB is out of place, Chebyshev / Jacobi ping-pong: never aliases x
+  const double *__restrict__ rhs = (MODE == 4) ? nullptr : vec_origin(L, box, P.rhs_id);
+  const double *__restrict__ dinv = kSmooth ? vec_origin(L, box, VECTOR_DINV) : nullptr;
+  int colour000 = 0;
+  if (MODE == 1) colour000 = (L.box_low[3 * box] ^ L.box_low[3 * box + 1] ^ L.box_low[3 * box + 2] ^ P.sweep) & 1;
+
+  const int own_g = i + j * jS, own_s = (lj + 1) * W + (li + 1);
+  int halo_g = 0, halo_s = 0;
+  const bool has_halo = tid < NH;
+  if (has_halo) {
+    int hi, hj;
+    if (tid < W)          { hj = -1; hi = -1 + tid; }
+    else if (tid < 2 * W) { hj = TJ; hi = -1 + (tid - W); }
+    else                  { const int h = tid - 2 * W; hj = h >> 1; hi = (h & 1) ? TI : -1; }
+    halo_g = (i0 + hi) + (j0 + hj) * jS;
+    halo_s = (hj + 1) * W + (hi + 1);
+  }
+  auto slot3 = [](int p) { return ((p % 3) + 3) % 3; };
+
+  // prologue: planes k0-1 and k0 into LDS; the plane k0+1 values and the per-cell streams of plane k0 in flight
+  for (int p = k0 - 1; p <= k0; p++) {
+    const int s = slot3(p) * PLANE, pg = p * kS;
+    sX[s + own_s] = x[own_g + pg];
+    if (has_halo) sX[s + halo_s] = x[halo_g + pg];
+  }
+  double n_x = x[own_g + (k0 + 1) * kS], h_x = has_halo ? x[halo_g + (k0 + 1) * kS] : 0.0;
+  double c_rhs = (MODE == 4) ? 0.0 : rhs[own_g + k0 * kS], c_dinv = kSmooth ? dinv[own_g + k0 * kS] : 0.0;
+  double c_old = (MODE == 0) ? out[own_g + k0 * kS] : 0.0;
+
+  for (int k = k0; k < k1; k++) {
+    const int pg = k * kS;
+    __syncthreads();                                            // every wave is done reading the slot that plane k+1 overwrites
+    { const int s = slot3(k + 1) * PLANE; sX[s + own_s] = n_x; if (has_halo) sX[s + halo_s] = h_x; }
+    double nn_rhs = 0, nn_dinv = 0, nn_old = 0;
+    if (k + 1 < k1) {                                           // loads of the next step
+      const int ng = (k + 2) * kS, cg = own_g + (k + 1) * kS;
+      n_x = x[own_g + ng];
+      if (has_halo) h_x = x[halo_g + ng];
+      if (MODE != 4) nn_rhs = rhs[cg];
+      if (kSmooth) nn_dinv = dinv[cg];
+      if (MODE == 0) nn_old = out[cg];
+    }
+    __syncthreads();
+
+    const double *c = sX + slot3(k) * PLANE + own_s, *m = sX + slot3(k - 1) * PLANE + own_s, *p = sX + slot3(k + 1) * PLANE + own_s;
+    const double xc = c[0];
+    bool update = true;
+    if (MODE == 1) update = (((i ^ j ^ k ^ colour000) & 1) == 0);
+    if (update) {
+      // operators.27pt.c:60-91 in apply_op_27pt's order: 8 corners, 12 edges, 6 faces, centre
+      double s8 = m[-W - 1] + m[-W + 1]; s8 = s8 + m[W - 1]; s8 = s8 + m[W + 1];
+      s8 = s8 + p[-W - 1]; s8 = s8 + p[-W + 1]; s8 = s8 + p[W - 1]; s8 = s8 + p[W + 1];
+      double s12 = m[-W] + m[-1]; s12 = s12 + m[1]; s12 = s12 + m[W];
+      s12 = s12 + c[-W - 1]; s12 = s12 + c[-W + 1]; s12 = s12 + c[W - 1]; s12 = s12 + c[W + 1];
+      s12 = s12 + p[-W]; s12 = s12 + p[-1]; s12 = s12 + p[1]; s12 = s12 + p[W];
+      double s6 = m[0] + c[-W]; s6 = s6 + c[-1]; s6 = s6 + c[1]; s6 = s6 + c[W]; s6 = s6 + p[0];
+      double tt = C27_3 * s8 + C27_2 * s12;
+      tt = tt + C27_1 * s6;
+      tt = tt + C27_0 * xc;
+      const double Ax = P.a * xc - (P.b * P.h2inv) * tt;
+      double o;
+      if (MODE == 0)      o = xc + P.c1 * (xc - c_old) + P.c2 * c_dinv * (c_rhs - Ax);
+      else if (MODE == 1) o = xc + c_dinv * (c_rhs - Ax);
+      else if (MODE == 2) o = xc + P.c2 * c_dinv * (c_rhs - Ax);
+      else if (MODE == 3) o = c_rhs - Ax;
+      else                o = Ax;
+      out[own_g + pg] = o;
+    } else {
+      out[own_g + pg] = xc;                                     // out-of-place GSRB copies the other colour (gsrb.c:94-98)
+    }
+    c_rhs = nn_rhs; c_dinv = nn_dinv; c_old = nn_old;
+  }
+}
+
+}  // namespace hpgmg

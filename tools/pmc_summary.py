@@ -39,7 +39,7 @@ def main():
     cells = int(sys.argv[sys.argv.index("--cells") + 1]) if "--cells" in sys.argv else 256 ** 3
     rows = {"cheby_pair_fine": ("cheby_pair_kernel", 144), "cheby_pair_edge_columns": ("cheby_pair_edge_kernel", 0), "cheby_fine": ("stencil7_wide_kernelILi0ELi0", 72), "residual_fine": ("stencil7_wide_kernelILi0ELi3", 56),
             "residual_restrict_zero_fine": ("stencil7_wide_kernelILi0ELi6", 58), "residual_norm_fine": ("stencil7_wide_kernelILi0ELi7", 56),
-            "norm_copy_restrict_fine": ("norm_copy_restrict_kernel", 17), "fv4_gsrb_fine": ("fv4_tile_kernelILi5ELi1", 56), "stencil27_gsrb_fine": ("stencil27_kernelILi1", 32),
+            "norm_copy_restrict_fine": ("norm_copy_restrict_kernel", 17), "fv4_gsrb_fine": ("fv4_tile_kernelILi5ELi1", 56), "stencil27_gsrb_fine": ("stencil27_tile_kernelILi1", 32),
             "scale_fine": ("elementwise_kernelILi3", 16), "interp_p0_fine": ("interp_blocks_kernelILi0", 17),
             "interp_p1_fine": ("interp_blocks_kernelILi1", 17), "restrict_fine": ("restrict_blocks_kernelILi0", 9), "norm_fine": ("absmax_kernel", 8)}
     res = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), MI355X",
