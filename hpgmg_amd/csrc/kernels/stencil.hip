@@ -26,6 +26,7 @@
 #include "stencil_math.hpp"
 #include "cheby_pair.hpp"
 #include "fv4_tile.hpp"
+#include "stencil7_tile.hpp"
 #include "block_ops.hpp"
 
 namespace hpgmg {
@@ -881,6 +882,27 @@ static int launch(const hpgmg_hip_level *L, int variant, StencilArgs P, bool is_
 #undef WIDE_CASE
     profile_end(prof, cells);
     HPGMG_LAUNCH_CHECK("stencil7_wide_kernel");
+    return 0;
+  }
+  // boxes of side 64 m (the 128^3 level of config 2): LDS-staged tile kernel (stencil7_tile.hpp)
+  static const int no_tile7 = env_int("HPGMG_TUNE_7PT_NO_TILE", 0), tile7_kc = env_int("HPGMG_TUNE_7PT_TILE_KCHUNK", 8);
+  if (!no_tile7 && !g_defer_mode && MODE != MODE_BLACKBOX && L->dim % 64 == 0) {
+    constexpr int TJ = 8, TM = (MODE == MODE_BLACKBOX) ? MODE_APPLY : MODE;
+    S7TileArgs A = {};
+    A.xn_id = P.xn_id; A.xout_id = P.xout_id; A.rhs_id = P.rhs_id; A.a = P.a; A.b = P.b; A.h2inv = P.h2inv; A.c1 = P.c1; A.c2 = P.c2; A.sweep = P.sweep;
+    A.ghost_free = P.ghost_free;
+    A.tiles_i = L->dim / 64; A.tiles_j = L->dim / TJ;
+    A.kchunk = (tile7_kc > 0 && L->dim % tile7_kc == 0) ? tile7_kc : 8; A.chunks_k = L->dim / A.kchunk;
+    A.total_blocks = L->num_boxes * A.chunks_k * A.tiles_j * A.tiles_i;
+    const int tgrid = grid_for(A.total_blocks, &A.per_xcd);
+    switch (variant) {
+      case HPGMG_HIP_7PT_VC_HELMHOLTZ: hipLaunchKernelGGL((stencil7_tile_kernel<HPGMG_HIP_7PT_VC_HELMHOLTZ, TM, TJ>), dim3(tgrid), dim3(64, TJ), 0, g_stream, *L, A); break;
+      case HPGMG_HIP_7PT_VC_POISSON:   hipLaunchKernelGGL((stencil7_tile_kernel<HPGMG_HIP_7PT_VC_POISSON, TM, TJ>), dim3(tgrid), dim3(64, TJ), 0, g_stream, *L, A); break;
+      case HPGMG_HIP_7PT_CC:           hipLaunchKernelGGL((stencil7_tile_kernel<HPGMG_HIP_7PT_CC, TM, TJ>), dim3(tgrid), dim3(64, TJ), 0, g_stream, *L, A); break;
+      default: return record_error(hipErrorInvalidValue, "stencil variant not implemented");
+    }
+    profile_end(prof, cells);
+    HPGMG_LAUNCH_CHECK("stencil7_tile_kernel");
     return 0;
   }
   switch (variant) {

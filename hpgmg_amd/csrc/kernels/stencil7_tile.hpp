@@ -1,0 +1,142 @@
+// stencil7_tile.hpp -- one sweep of the 7-point operator for boxes whose side is a multiple of 64 but not of 128 (the 128^3 level of
+// config 2: 8 boxes of 64^3), LDS-staged.
+//
+// stencil7_kernel re-reads the +-i / +-j neighbours of x through the vector L1: 14 eight-byte accesses per cell and step, 8.7 TB/s of L1
+// traffic at 27 us per Chebyshev sweep of the 128^3 level -- the same L1 ceiling the first fv4 / 27-point kernels sat at.  Here a 64 x TJ
+// workgroup owns a 64 (i) x TJ (j) tile and marches in +k with plane k of x in LDS (double buffered, one barrier per step): a lane stores
+// its own value and at most one halo cell, reads its four in-plane neighbours from LDS, keeps x[k-1], x[k+1] and beta_k[k] of its column in
+// registers and gets beta_i's high face from the next lane -- 10 accesses per cell instead of 14, all issued one step ahead.
+// Same expression (apply_op_7pt + the smoother updates) and the same ghost-free face rules as stencil7_kernel: a face neighbour in
+// another local box is read from that box, a Dirichlet face is ghost = -centre, a face of another rank comes from the ghost zone.
+#pragma once
+#include "common.hpp"
+#include "stencil_math.hpp"
+
+namespace hpgmg {
+
+struct S7TileArgs {
+  int xn_id, xout_id, rhs_id;
+  double a, b, h2inv, c1, c2;
+  int sweep, ghost_free;
+  int tiles_i, tiles_j, chunks_k, kchunk, per_xcd, total_blocks;
+};
+
+template <int V, int MODE, int TJ>
+__global__ __launch_bounds__(64 * TJ) void stencil7_tile_kernel(const hpgmg_hip_level L, const S7TileArgs P) {
+  constexpr int TI = 64, W = TI + 2, H = TJ + 2, NT = 64 * TJ, PLANE = W * H;
+  constexpr int NH = 2 * TI + 2 * TJ;                           // halo cells of a plane tile: a row above and below, a column left and right (no corners: star stencil)
+  static_assert(NH <= NT, "one halo cell per lane at most");
+  constexpr bool kVC = (V != HPGMG_HIP_7PT_CC);
+  constexpr bool kHelm = (V == HPGMG_HIP_7PT_VC_HELMHOLTZ);
+  constexpr bool kSmooth = (MODE == 0 || MODE == 1 || MODE == 2);  // Chebyshev, GSRB, Jacobi | 3 residual, 4 apply_op
+  __shared__ double sX[2 * PLANE];
+
+  const int logical = xcd_logical_block((int)blockIdx.x, P.per_xcd);
+  if (logical >= P.total_blocks) return;
+  int t = logical;
+  const int ti = t % P.tiles_i; t /= P.tiles_i;
+  const int tj = t % P.tiles_j; t /= P.tiles_j;
+  const int ck = t % P.chunks_k; t /= P.chunks_k;
+  const int box = t;
+  const int li = (int)threadIdx.x, lj = (int)threadIdx.y, tid = lj * 64 + li;
+  const int i0 = ti * TI, j0 = tj * TJ, i = i0 + li, j = j0 + lj;
+  const int k0 = ck * P.kchunk, k1 = (k0 + P.kchunk < L.dim) ? k0 + P.kchunk : L.dim;
+  const int jS = L.jStride, kS = L.kStride, last = L.dim - 1;
+  const bool gf = P.ghost_free != 0;
+
+  const double *x = vec_origin(L, box, P.xn_id);                  // may alias out (in-place GSRB): a swept cell's neighbours all have the other colour
+  double *out = vec_origin(L, box, P.xout_id);
+  const double *__restrict__ rhs = (MODE == 4) ? nullptr : vec_origin(L, box, P.rhs_id);
+  const double *__restrict__ dinv = kSmooth ? vec_origin(L, box, VECTOR_DINV) : nullptr;
+  const double *__restrict__ alpha = kHelm ? vec_origin(L, box, VECTOR_ALPHA) : nullptr;
+  const double *__restrict__ beta_i = kVC ? vec_origin(L, box, VECTOR_BETA_I) : nullptr;
+  const double *__restrict__ beta_j = kVC ? vec_origin(L, box, VECTOR_BETA_J) : nullptr;
+  const double *__restrict__ beta_k = kVC ? vec_origin(L, box, VECTOR_BETA_K) : nullptr;
+  int colour000 = 0;
+  if (MODE == 1) colour000 = (L.box_low[3 * box] ^ L.box_low[3 * box + 1] ^ L.box_low[3 * box + 2] ^ P.sweep) & 1;
+
+  const int own_g = i + j * jS, own_s = (lj + 1) * W + (li + 1);
+  // this lane's halo cell (if any): where it sits in the tile, and how its value is obtained on plane k:
+  //   kind 0: plain load (inside the box, or the ghost zone);  1: from the neighbouring local box;  2: Dirichlet, minus the adjacent interior cell
+  const bool has_halo = tid < NH;
+  int halo_s = 0, halo_g = 0, halo_kind = 0;
+  const double *halo_x = x;
+  if (has_halo) {
+    int hi, hj;
+    if (tid < TI)          { hj = -1; hi = tid; }
+    else if (tid < 2 * TI) { hj = TJ; hi = tid - TI; }
+    else                   { const int h = tid - 2 * TI; hj = h >> 1; hi = (h & 1) ? TI : -1; }
+    halo_s = (hj + 1) * W + (hi + 1);
+    int ci = i0 + hi, cj = j0 + hj;
+    int dir = -1;
+    if (ci < 0) dir = 0; else if (ci > last) dir = 1; else if (cj < 0) dir = 2; else if (cj > last) dir = 3;
+    if (dir >= 0 && gf) {
+      const int nb = L.box_nbr[6 * box + dir];
+      if (nb >= 0) { halo_kind = 1; halo_x = vec_origin(L, nb, P.xn_id); if (dir == 0) ci = last; else if (dir == 1) ci = 0; else if (dir == 2) cj = last; else cj = 0; }
+      else if (nb == -1) { halo_kind = 2; if (dir == 0) ci = 0; else if (dir == 1) ci = last; else if (dir == 2) cj = 0; else cj = last; }
+    }
+    halo_g = ci + cj * jS;
+  }
+  auto halo_at = [&](int k) -> double { const double v = halo_x[halo_g + k * kS]; return halo_kind == 2 ? -v : v; };
+  // value of x just below / above the box on this lane's column (k faces)
+  auto outside_k = [&](int dir, double centre, int kk) -> double {
+    const int nb = L.box_nbr[6 * box + dir];
+    if (nb >= 0) return vec_origin(L, nb, P.xn_id)[own_g + (dir == 4 ? last : 0) * kS];
+    if (nb == -1) return -centre;
+    return x[own_g + kk * kS];
+  };
+
+  // registers: x[k-1], x[k], x[k+1] of the own column, the halo value of plane k, beta_k[k]; the streams of plane k in flight
+  double xc = x[own_g + k0 * kS];
+  double xm = (gf && k0 == 0) ? outside_k(4, xc, -1) : x[own_g + (k0 - 1) * kS];
+  double xp = (gf && k0 == last) ? outside_k(5, xc, k0 + 1) : x[own_g + (k0 + 1) * kS];
+  double h_c = has_halo ? halo_at(k0) : 0.0;
+  double bk0 = kVC ? beta_k[own_g + k0 * kS] : 0.0;
+  double c_bi = 0, c_bir = 0, c_bj0 = 0, c_bj1 = 0, c_bk1 = 0, c_al = 0, c_dinv = 0, c_rhs = 0, c_old = 0;
+  auto load_streams = [&](int k, double &bi, double &bir, double &bj0, double &bj1, double &bk1, double &al, double &dv, double &rh, double &old) {
+    const int g = own_g + k * kS;
+    if (kVC) { bi = beta_i[g]; bir = (li == 63) ? beta_i[g + 1] : 0.0; bj0 = beta_j[g]; bj1 = beta_j[g + jS]; bk1 = beta_k[g + kS]; }
+    if (kHelm) al = alpha[g];
+    if (kSmooth) dv = dinv[g];
+    if (MODE != 4) rh = rhs[g];
+    if (MODE == 0) old = out[g];
+  };
+  load_streams(k0, c_bi, c_bir, c_bj0, c_bj1, c_bk1, c_al, c_dinv, c_rhs, c_old);
+
+  for (int k = k0; k < k1; k++) {
+    double *s = sX + (k & 1) * PLANE;
+    s[own_s] = xc;
+    if (has_halo) s[halo_s] = h_c;
+    // next step's loads (their latency overlaps this step's barrier and arithmetic)
+    double n_xp = 0, n_h = 0, n_bi = 0, n_bir = 0, n_bj0 = 0, n_bj1 = 0, n_bk1 = 0, n_al = 0, n_dinv = 0, n_rhs = 0, n_old = 0;
+    if (k + 1 < k1) {
+      n_xp = (gf && k + 1 == last) ? 0.0 : x[own_g + (k + 2) * kS];
+      if (has_halo) n_h = halo_at(k + 1);
+      load_streams(k + 1, n_bi, n_bir, n_bj0, n_bj1, n_bk1, n_al, n_dinv, n_rhs, n_old);
+    }
+    __syncthreads();
+    bool update = true;
+    if (MODE == 1) update = (((i ^ j ^ k ^ colour000) & 1) == 0);
+    // beta_i's high face = the next lane's low face (lane 63 loaded it)
+    double bi1 = __shfl_down(c_bi, 1, 64);
+    if (li == 63) bi1 = c_bir;
+    if (update) {
+      const double *c = s + own_s;
+      const double Ax = apply_op_7pt<V>(xc, c[-1], c[1], c[-W], c[W], xm, xp, c_bi, bi1, c_bj0, c_bj1, bk0, c_bk1, c_al, P.a, P.b, P.h2inv);
+      double o;
+      if (MODE == 0)      o = xc + P.c1 * (xc - c_old) + P.c2 * c_dinv * (c_rhs - Ax);
+      else if (MODE == 1) o = xc + c_dinv * (c_rhs - Ax);
+      else if (MODE == 2) o = xc + P.c2 * c_dinv * (c_rhs - Ax);
+      else if (MODE == 3) o = c_rhs - Ax;
+      else                o = Ax;
+      out[own_g + k * kS] = o;
+    }
+    // rotate; at the top of the box the plane above is the face rule applied to the new centre
+    xm = xc; xc = xp;
+    xp = (gf && k + 1 == last) ? outside_k(5, xc, k + 2) : n_xp;
+    h_c = n_h; bk0 = c_bk1;
+    c_bi = n_bi; c_bir = n_bir; c_bj0 = n_bj0; c_bj1 = n_bj1; c_bk1 = n_bk1; c_al = n_al; c_dinv = n_dinv; c_rhs = n_rhs; c_old = n_old;
+  }
+}
+
+}  // namespace hpgmg
