@@ -452,7 +452,7 @@ void MGVCycle(mg_type *G, int e_id, int R_id, double a, double b, int l) {
   }
   if (maybe_tail) hpgmg_tick_end(t);          /* nothing was launched: adds (next to) nothing */
   t = hpgmg_tick_begin(L, &L->timers.Total, "V-cycle down leg");
-  smooth(L, e_id, R_id, a, b);
+  if (!hpgmg_smooth_in_cycle(L, e_id, R_id, a, b)) smooth(L, e_id, R_id, a, b);
   if (!hpgmg_residual_restrict_zero_fused(G->levels[l + 1], R_id, L, e_id, R_id, a, b, e_id)) {
     residual(L, VECTOR_TEMP, e_id, R_id, a, b);
     if (!hpgmg_restrict_zero_fused(G->levels[l + 1], R_id, L, VECTOR_TEMP, e_id)) {
@@ -470,7 +470,7 @@ void MGVCycle(mg_type *G, int e_id, int R_id, double a, double b, int l) {
   t = hpgmg_tick_begin(L, &L->timers.Total, "V-cycle up leg");
   if (!hpgmg_interp_smooth_fused(L, e_id, R_id, G->levels[l + 1], a, b)) {
     interpolation_vcycle(L, e_id, 1.0, G->levels[l + 1], e_id);
-    smooth(L, e_id, R_id, a, b);
+    if (!hpgmg_smooth_in_cycle(L, e_id, R_id, a, b)) smooth(L, e_id, R_id, a, b);
   }
   hpgmg_tick_end(t);
   if (opened_here) seg_close();

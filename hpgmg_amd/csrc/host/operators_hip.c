@@ -873,6 +873,9 @@ static int pair_kernel_ready(level_type *L, int x_id, int rhs_id, int sweeps) {
 /* Chebyshev smooth() as fused sweep pairs (kernels/cheby_pair.hpp): 4 sweeps = 2 passes of 10 streams instead of
  * 4 x 9.  x1,x2 of the first pair go to two plugin-private vectors, the second pair brings x3 -> VECTOR_TEMP and
  * x4 -> x_id, i.e. exactly the state chebyshev.c:43-99 leaves.  Returns 0 when the level does not qualify. */
+/* smooth() called by the cycle driver through hpgmg_smooth_in_cycle(): VECTOR_TEMP (x3 of the four sweeps) is dead after it, so the second
+ * pair does not store it */
+static int temp_is_scratch = 0;
 static int smooth_cheby_pairs(level_type *L, int x_id, int rhs_id, double a, double b, const double *c1, const double *c2, int sweeps) {
   if (!pair_kernel_ready(L, x_id, rhs_id, sweeps)) return 0;
   backend_t *B = backend_of(L);
@@ -886,6 +889,7 @@ static int smooth_cheby_pairs(level_type *L, int x_id, int rhs_id, double a, dou
     TOCK(); }
   if (remote) pair_halo_before_launch(L, B, 0, 1, 1, 1, 0, rhs_id);
   { TICK(L, smooth, "smooth (Chebyshev sweeps 3+4)");
+    if (temp_is_scratch) hpgmg_hip_pair_discard_x1();
     HIP_OK(hpgmg_hip_smooth_cheby_pair(&B->dev, v, (double *const *)B->d_pair_base, c32, 1, 1, 1, 0, 0, VECTOR_TEMP, 0, x_id, rhs_id, a, b, h2inv, c1[2], c2[2], c1[3], c2[3]));
     TOCK(); }
   return 1;
@@ -911,7 +915,8 @@ static int smooth_gsrb_pairs(level_type *L, int x_id, int rhs_id, double a, doub
 
 /* interpolation_vcycle(Lf, e, 1.0, Lc, e) followed by smooth(Lf, e, R) -- the up-leg of MGVCycle (mg.c:1160-1161) -- with the
  * piecewise-constant interpolation folded into the first sweep pair: the interpolated e is never written or re-read.
- * Same numbers and same final state (e = x4, VECTOR_TEMP = x3) as the two separate operators.  0 = not applicable. */
+ * Same iterate (e = x4) as the two separate operators; VECTOR_TEMP (their x3) is left unspecified -- nothing in a cycle reads it
+ * (HPGMG_TEMP_SCRATCH=0 stores it as smooth() does).  0 = not applicable. */
 int hpgmg_interp_smooth_fused(level_type *Lf, int e_id, int R_id, level_type *Lc, double a, double b) {
   hpgmg_config cfg;
   hpgmg_get_config(&cfg);
@@ -928,7 +933,10 @@ int hpgmg_interp_smooth_fused(level_type *Lf, int e_id, int R_id, level_type *Lc
   if (cfg.smoother == HPGMG_SMOOTH_CHEBY) {
     double c1[16], c2[16];
     cheby_coefficients(Lf, sweeps, c1, c2);
-    if (!smooth_cheby_pairs(Lf, e_id, R_id, a, b, c1, c2, sweeps)) { fprintf(stderr, "hpgmg: fused interpolation+smooth refused after being accepted\n"); abort(); }
+    { const char *e = getenv("HPGMG_TEMP_SCRATCH"); temp_is_scratch = !(e && e[0] == '0'); }      /* a cycle-only hook: VECTOR_TEMP is dead afterwards */
+    const int done = smooth_cheby_pairs(Lf, e_id, R_id, a, b, c1, c2, sweeps);
+    temp_is_scratch = 0;
+    if (!done) { fprintf(stderr, "hpgmg: fused interpolation+smooth refused after being accepted\n"); abort(); }
   } else if (!smooth_gsrb_pairs(Lf, e_id, R_id, a, b, sweeps)) { fprintf(stderr, "hpgmg: fused interpolation+smooth refused after being accepted\n"); abort(); }
   return 1;
 }
@@ -977,6 +985,17 @@ static int small_level_try(level_type *L, int mode, int x_id, int rhs_id, int re
   return 1;
 }
 
+/* smooth() as the cycle driver uses it (mg.c:1148,1161): same iterate, but VECTOR_TEMP is left unspecified -- the next operator of a
+ * cycle overwrites or ignores it.  Always returns 1 (the hook exists so that the reference's own driver, which never calls it, keeps
+ * the exact state of smooth()). */
+int hpgmg_smooth_in_cycle(level_type *L, int x_id, int rhs_id, double a, double b) {
+  static int on = -1;
+  if (on < 0) { const char *e = getenv("HPGMG_TEMP_SCRATCH"); on = !(e && e[0] == '0'); }
+  temp_is_scratch = on;
+  smooth(L, x_id, rhs_id, a, b);
+  temp_is_scratch = 0;
+  return 1;
+}
 void smooth(level_type *L, int x_id, int rhs_id, double a, double b) {
   hpgmg_config cfg;
   hpgmg_get_config(&cfg);

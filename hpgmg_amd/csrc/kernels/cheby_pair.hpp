@@ -33,6 +33,7 @@ struct PairArgs {
   int rhs_id;
   double a, b, h2inv, c1a, c2a, c1b, c2b;           // Chebyshev coefficients of the two sweeps
   int sweep_a;                                      // GSRB: number of the first half sweep (its colour; the second is sweep_a + 1)
+  int keep_x1;                                      // 0: x1 is not stored (only its tile-edge columns exist, from the pre-pass): the caller declared out1 scratch
   // INTERP variants: x0 is not read as stored but as  prescale * x0 + (coarse parent)  -- interpolation_vcycle
   // (interpolation_p0.c:43) folded into the first sweep pair of the smooth() that follows it in MGVCycle (mg.c:1160-1161)
   hpgmg_hip_level Lc; int coarse_id; double prescale;
@@ -298,7 +299,7 @@ __global__ __launch_bounds__(64 * NW) void cheby_pair_kernel(const hpgmg_hip_lev
       const p2 x2 = pair_update<V, SM>(x1m1, left, right, jm, jp, km, kp, x0m, qp, A.a, A.b, A.h2inv, A.c1b, A.c2b, ((gj ^ q ^ (A.sweep_a + 1)) & 1) == 0);
       pst(pair_vec(L, A, A.out2, boxq) + shift_of(sh, A.out2) + offq, x2);
     }
-    if (SM == PAIR_CHEBY && row_out && p >= K0 && p < K0 + KCs) pst(pair_vec(L, A, A.out1, box) + shift_of(sh, A.out1) + off, x1c);   // GSRB keeps no x1
+    if (SM == PAIR_CHEBY && A.keep_x1 && row_out && p >= K0 && p < K0 + KCs) pst(pair_vec(L, A, A.out1, box) + shift_of(sh, A.out1) + off, x1c);   // GSRB keeps no x1
 
     // ---- hand this plane's x1 and the next plane's x0 / beta_j to the neighbouring waves
     if (row_x1) {

@@ -1022,6 +1022,7 @@ static bool g_pair_halo_set = false;
 static int g_pair_rem[6], g_pair_brick[3];
 static const double *g_pair_deep = nullptr, *g_pair_deep_beta = nullptr;
 static long long g_pair_launches = 0, g_pair_remote_launches = 0;
+static int g_pair_discard_x1 = 0;     // consumed by the next Chebyshev pair launch: its out1 vector is scratch, do not store x1
 static const hpgmg_hip_level *g_pair_interp_level = nullptr;
 static int g_pair_interp_id = 0;
 static double g_pair_interp_prescale = 1.0;
@@ -1051,6 +1052,7 @@ static int smooth_pair(const hpgmg_hip_level *L, int variant, int gsrb, int swee
   A.x0 = VecRef{x0_scr, x0_id}; A.xm1 = VecRef{xm1_scr, xm1_id}; A.out1 = VecRef{out1_scr, out1_id}; A.out2 = VecRef{out2_scr, out2_id};
   A.rhs_id = rhs_id; A.a = a; A.b = b; A.h2inv = h2inv; A.c1a = c1a; A.c2a = c2a; A.c1b = c1b; A.c2b = c2b;
   A.scr_base = scr_base; A.c32_base = c32_base; A.sweep_a = sweep_a;
+  A.keep_x1 = g_pair_discard_x1 ? 0 : 1; g_pair_discard_x1 = 0;
   const bool interp = (g_pair_interp_level != nullptr);
   if (interp) {
     const hpgmg_hip_level *C = g_pair_interp_level;
@@ -1116,6 +1118,7 @@ void hpgmg_hip_pair_set_halo(const int brick_boxes[3], const int remote_face[6],
   for (int d = 0; d < 6; d++) g_pair_rem[d] = remote_face[d];
   g_pair_deep = deep; g_pair_deep_beta = deep_beta; g_pair_halo_set = true;
 }
+void hpgmg_hip_pair_discard_x1(void) { g_pair_discard_x1 = 1; }
 void hpgmg_hip_pair_launch_counts(long long out[2]) { out[0] = g_pair_launches; out[1] = g_pair_remote_launches; }
 
 // ---- the halo of a sweep pair across rank boundaries: one pack launch, one grouped send/recv, one unpack launch ----

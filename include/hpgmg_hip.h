@@ -151,6 +151,9 @@ int hpgmg_hip_smooth_cheby_pair(const hpgmg_hip_level *L, int variant, double *c
  * planes of dim x dim values, (u, v) = the two in-face axes in i < j < k order. */
 int  hpgmg_hip_smooth_cheby_pair_supported_brick(const hpgmg_hip_level *L, int variant, int nbi, int nbj, int nbk);
 void hpgmg_hip_pair_set_halo(const int brick_boxes[3], const int remote_face[6], const double *deep, const double *deep_beta);
+/* The NEXT hpgmg_hip_smooth_cheby_pair launch need not store x1: its out1 vector is scratch to the caller (the cycle driver's
+ * smooth(): nothing reads VECTOR_TEMP after it).  Saves one of the launch's ten streams; x2 (out2) is unaffected. */
+void hpgmg_hip_pair_discard_x1(void);
 void hpgmg_hip_pair_launch_counts(long long out[2]);      /* sweep-pair launches so far: all, and those with remote faces (tests) */
 /* One region of a sweep-pair halo message.  vec: 0 = the pair's x0, 1 = its xm1, 2 = its right-hand side, 16 + id = level vector id.
  * Pack copies the region (i fastest) to sendbuf + off; unpack copies recvbuf + off into the region (deep = -1: ghost cells at

@@ -121,7 +121,7 @@ void    hpgmg_segment_end(void);
  * issues the operators one by one. */
 int     hpgmg_vcycle_legs_fused(level_type **levels, int n, int e_id, int R_id, double a, double b, int leg);
 /* Optional fused form of  interpolation_vcycle(fine, e, 1.0, coarse, e); smooth(fine, e, R)  (mg.c:1160-1161): returns 1 when the
- * plugin executed both (same result and final state), 0 when the driver must call the two operators. */
+ * plugin executed both (same iterate; VECTOR_TEMP unspecified, as with hpgmg_smooth_in_cycle), 0 when the driver must call the two operators. */
 int     hpgmg_interp_smooth_fused(level_type *fine, int e_id, int R_id, level_type *coarse, double a, double b);
 /* Optional fused form of  restriction(coarse, id_c, fine, id_f, RESTRICT_CELL); zero_vector(coarse, zero_id)  (mg.c:1152-1153) */
 int     hpgmg_restrict_zero_fused(level_type *coarse, int id_c, level_type *fine, int id_f, int zero_id);
@@ -145,6 +145,9 @@ int     hpgmg_residual_restrict_zero_fused(level_type *coarse, int id_c, level_t
 int     hpgmg_residual_norm_fused(level_type *level, int res_id, int x_id, int rhs_id, double a, double b, double *norm_out);
 /*   *norm_out = norm(level, F); scale_vector(level, R, 1.0, F); restriction(coarse, R, level, R, RESTRICT_CELL)                        (mg.c:1262-1270) */
 int     hpgmg_norm_scale_restrict_fused(level_type *level, int F_id, int R_id, level_type *coarse, double *norm_out);
+/* smooth() for callers to whom VECTOR_TEMP is scratch afterwards (MGVCycle: the operator that follows a smooth() overwrites or ignores
+ * it): same iterate in phi_id, VECTOR_TEMP unspecified.  Returns 1 when executed, 0 when the caller must call smooth(). */
+int     hpgmg_smooth_in_cycle(level_type *level, int phi_id, int rhs_id, double a, double b);
 /* bring level->Krylov_iterations up to date with bottom solves the plugin ran asynchronously */
 void    hpgmg_level_sync_counters(level_type *level);
 /* called by destroy_level / MGDestroy so the plugin can drop device mirrors */
