@@ -261,8 +261,11 @@ __global__ __launch_bounds__(64 * NW) void cheby_pair_kernel(const hpgmg_hip_lev
         else if (w == NRs + 1 || gj + 1 >= jhi || ((lj + 1) == bd)) qc.bjhi = CoefStream<C32>(L, A, box, VECTOR_BETA_J, C32_BETA_J, sh).pair(off + jS);
         else qc.bjhi = slabBJ[p & 1][w + 1][lane];
       }
-      p2 xm1 = {0, 0};
-      if (SM == PAIR_CHEBY) xm1 = pld(pair_vec(L, A, A.xm1, box) + shift_of(sh, A.xm1) + off);
+      // x_{n-1} of the first sweep.  When its coefficient c1a is exactly 0 (the first Chebyshev sweep of every smooth(), chebyshev.c:30) the
+      // stream is not read: x0 stands in, the term is c1a * 0 = +0, and x0 + (+0) = x0 as with any finite x_{n-1} (the one representable
+      // difference: an x0 of exactly -0.0 could come out as +0.0)
+      p2 xm1 = x0c;
+      if (SM == PAIR_CHEBY && A.c1a != 0.0) xm1 = pld(pair_vec(L, A, A.xm1, box) + shift_of(sh, A.xm1) + off);
 
       // ---- x1 on plane p (first sweep): neighbours of x0
       p2 jm, jp;
