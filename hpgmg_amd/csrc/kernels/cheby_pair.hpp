@@ -227,8 +227,18 @@ __global__ __launch_bounds__(64 * NW) void cheby_pair_kernel(const hpgmg_hip_lev
   }
   __syncthreads();
 
+#ifdef HPGMG_EXP_TIMELINE
+  // experiment build: wave 1 of the first workgroup records the 100 MHz clock at five points of every step into A.deep (as raw 64-bit counts)
+  unsigned long long *tl = (unsigned long long *)A.deep;
+  const bool probe = !REMOTE && tl && logical == 0 && w == 1 && lane == 0;
+  int tl_n = 0;
+#define TL_MARK() do { if (probe && tl_n < 4000) tl[tl_n++] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define TL_MARK() do { } while (0)
+#endif
   for (int p = pstart; p <= P1 && p < khi; p++) {
     const int box = box_of(bi_, bj_, p), off = row_off + plane_off(p);
+    TL_MARK();                                                   // 0: step begins
     const bool have_next = in_dom(p + 1) && (p + 1 <= P1);     // plane p+1 is needed as a centre later
     const bool above_in = x0plane(p + 1);
     const bool ghost_plane = REMOTE && (p < 0 || p >= A.Dk);
@@ -266,6 +276,10 @@ __global__ __launch_bounds__(64 * NW) void cheby_pair_kernel(const hpgmg_hip_lev
       // difference: an x0 of exactly -0.0 could come out as +0.0)
       p2 xm1 = x0c;
       if (SM == PAIR_CHEBY && A.c1a != 0.0) xm1 = pld(pair_vec(L, A, A.xm1, box) + shift_of(sh, A.xm1) + off);
+#ifdef HPGMG_EXP_TIMELINE
+      if (probe) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+      TL_MARK();                                                 // 1: every load of the step has arrived
+#endif
 
       // ---- x1 on plane p (first sweep): neighbours of x0
       p2 jm, jp;
@@ -283,6 +297,10 @@ __global__ __launch_bounds__(64 * NW) void cheby_pair_kernel(const hpgmg_hip_lev
       if (!(ghost_row && ghost_plane))                          // a ghost row on a ghost plane is a brick edge: x1 there is never read
         x1c = pair_update<V, SM>(x0c, left, right, jm, jp, km, kp, xm1, qc, A.a, A.b, A.h2inv, A.c1a, A.c2a, ((gj ^ p ^ A.sweep_a) & 1) == 0);
     }
+#ifdef HPGMG_EXP_TIMELINE
+    if (probe) { asm volatile("" :: "v"(x1c.x)); }
+    TL_MARK();                                                   // 2: x1 formed
+#endif
 
     // ---- x2 on plane q = p-1 (second sweep): neighbours of x1; x0 is the older iterate
     const int q = p - 1;
@@ -304,14 +322,20 @@ __global__ __launch_bounds__(64 * NW) void cheby_pair_kernel(const hpgmg_hip_lev
     }
     if (SM == PAIR_CHEBY && A.keep_x1 && row_out && p >= K0 && p < K0 + KCs) pst(pair_vec(L, A, A.out1, box) + shift_of(sh, A.out1) + off, x1c);   // GSRB keeps no x1
 
+    TL_MARK();                                                   // 3: x2 formed and stored
     // ---- hand this plane's x1 and the next plane's x0 / beta_j to the neighbouring waves
     if (row_x1) {
       slabX1[p & 1][w][lane] = x1c;
       if (have_next) { slabX0[(p + 1) & 1][w][lane] = x0p; slabBJ[(p + 1) & 1][w][lane] = bj_n; }
     }
     __syncthreads();
+    TL_MARK();                                                   // 4: barrier passed
     x0m = x0c; x0c = x0p; x1m2 = x1m1; x1m1 = x1c; far_c = far_n; bj_c = bj_n; qp = qc;
   }
+#ifdef HPGMG_EXP_TIMELINE
+  if (probe) tl[4095] = (unsigned long long)tl_n;
+#endif
+#undef TL_MARK
 
   // ---- the last output plane when the chunk ends at the top of the domain: x1 above it is the Dirichlet ghost
   if (P1 >= khi && row_out) {

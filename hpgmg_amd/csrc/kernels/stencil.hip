@@ -1022,6 +1022,9 @@ static bool g_pair_halo_set = false;
 static int g_pair_rem[6], g_pair_brick[3];
 static const double *g_pair_deep = nullptr, *g_pair_deep_beta = nullptr;
 static long long g_pair_launches = 0, g_pair_remote_launches = 0;
+#ifdef HPGMG_EXP_TIMELINE
+static double *g_exp_timeline = nullptr;     // experiment build: where the pair kernel's first workgroup records its step timeline
+#endif
 static int g_pair_discard_x1 = 0;     // consumed by the next Chebyshev pair launch: its out1 vector is scratch, do not store x1
 static const hpgmg_hip_level *g_pair_interp_level = nullptr;
 static int g_pair_interp_id = 0;
@@ -1063,6 +1066,9 @@ static int smooth_pair(const hpgmg_hip_level *L, int variant, int gsrb, int swee
   A.nbi = Di / L->dim; A.nbj = Dj / L->dim;
   A.Di = Di; A.Dj = Dj; A.Dk = Dk;
   if (remote) { for (int d = 0; d < 6; d++) A.rem[d] = g_pair_rem[d]; A.deep = g_pair_deep; A.deep_beta = g_pair_deep_beta; }
+#ifdef HPGMG_EXP_TIMELINE
+  else A.deep = g_exp_timeline;
+#endif
   A.tiles_i = A.Di / 128; A.slabs_j = (A.Dj + (nw - 2) - 1) / (nw - 2); A.KC = kc; A.chunks_k = (A.Dk + kc - 1) / kc;
   A.total_blocks = A.tiles_i * A.slabs_j * A.chunks_k;
   const int grid = grid_for(A.total_blocks, &A.per_xcd);
@@ -1119,6 +1125,9 @@ void hpgmg_hip_pair_set_halo(const int brick_boxes[3], const int remote_face[6],
   g_pair_deep = deep; g_pair_deep_beta = deep_beta; g_pair_halo_set = true;
 }
 void hpgmg_hip_pair_discard_x1(void) { g_pair_discard_x1 = 1; }
+#ifdef HPGMG_EXP_TIMELINE
+void hpgmg_hip_exp_timeline(void *buf) { g_exp_timeline = (double *)buf; }
+#endif
 void hpgmg_hip_pair_launch_counts(long long out[2]) { out[0] = g_pair_launches; out[1] = g_pair_remote_launches; }
 
 // ---- the halo of a sweep pair across rank boundaries: one pack launch, one grouped send/recv, one unpack launch ----

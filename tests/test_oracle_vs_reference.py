@@ -85,8 +85,8 @@ def test_cli_stdout_has_the_reference_layout(ref_build, variant, flags, args):
 
 
 @pytest.mark.parametrize("variant,flags,args", [
-    ("7pt-cheby", [], "4 125"), ("7pt-cheby", [], "4 343"), ("7pt-gsrb", ["--smoother", "gsrb"], "4 216"), ("7pt-cheby-helm", ["--helmholtz"], "4 729"),
-    ("7pt-cheby-helm", ["--helmholtz"], "5 27"), ("fv4-gsrb", ["--op", "fv4", "--smoother", "gsrb"], "4 125"), ("27pt-cheby", ["--op", "27pt"], "4 343"),
+    ("7pt-cheby", [], "4 125"), ("7pt-cheby", [], "4 343"), ("7pt-gsrb", ["--smoother", "gsrb"], "4 216"),
+    ("7pt-cheby-helm", ["--helmholtz"], "5 27"), ("fv4-gsrb", ["--op", "fv4", "--smoother", "gsrb"], "4 125"), ("27pt-cheby", ["--op", "27pt"], "4 125"),
     ("7pt-cheby", [], "4 2"), ("7pt-cheby", [], "4 7"), ("7pt-cheby", [], "5 1"),
 ])
 def test_our_host_layer_and_oracle_against_the_reference_binary_on_odd_decompositions(ref_build, variant, flags, args):
