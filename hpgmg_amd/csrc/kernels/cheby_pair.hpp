@@ -50,6 +50,7 @@ struct PairArgs {
   const double *deep;                               // [box][face 0..5][v][u]: x0 two cells outside face f (u, v = the in-face axes in i<j<k order)
   const double *deep_beta;                          // [box][face 1,3,5 -> 0..2][v][u]: beta_i / beta_j / beta_k at local index dim+1
   int tiles_i, slabs_j, chunks_k, KC, per_xcd, total_blocks;
+  int edge_blocks, edge_per_xcd;                    // the pre-pass grid (cheby_pair_edge_kernel)
 };
 
 __device__ __forceinline__ double *pair_vec(const hpgmg_hip_level &L, const PairArgs &A, VecRef r, int box) {
@@ -364,7 +365,13 @@ template <int V, bool C32, int SM, bool INTERP, bool REMOTE = false>
 __global__ __launch_bounds__(256) void cheby_pair_edge_kernel(const hpgmg_hip_level L, const PairArgs A) {
   constexpr bool kVC = (V != HPGMG_HIP_7PT_CC);
   constexpr bool kHelm = (V == HPGMG_HIP_7PT_VC_HELMHOLTZ);
-  const int gj = blockIdx.x * blockDim.x + threadIdx.x, gk = blockIdx.y, col = blockIdx.z;
+  // logical workgroup order: column, then plane, then block of 64 rows -- dealt to the XCDs in contiguous ranges (common.hpp), so the
+  // planes k-1, k, k+1 a cell needs were fetched into the SAME L2 by the neighbouring workgroups (dealt round robin, every plane was
+  // fetched by three XCDs)
+  const int logical = xcd_logical_block((int)blockIdx.x, A.edge_per_xcd);
+  if (logical >= A.edge_blocks) return;
+  const int jblocks = (A.Dj + 63) / 64;
+  const int gj = (logical % jblocks) * 64 + (int)threadIdx.x, gk = (logical / jblocks) % A.Dk, col = logical / (jblocks * A.Dk);
   if (gj >= A.Dj) return;
   const int ncol_in = 2 * (A.tiles_i - 1);
   int gi;
@@ -410,7 +417,7 @@ __global__ __launch_bounds__(256) void cheby_pair_edge_kernel(const hpgmg_hip_le
                                     x0_at(gi, gj, gk - 1, xc), x0_at(gi, gj, gk + 1, xc), bi0, bi1, bj0, bj1, bk0, bk1, al, A.a, A.b, A.h2inv);
   const double dinv = CoefStream<C32>(L, A, box, VECTOR_DINV, C32_DINV).one(idx), rhs = vec_origin(L, box, A.rhs_id)[idx];
   if (SM == PAIR_CHEBY) {
-    const double xnm1 = pair_vec(L, A, A.xm1, box)[idx];
+    const double xnm1 = (A.c1a != 0.0) ? pair_vec(L, A, A.xm1, box)[idx] : xc;     // as in the main kernel: not read when its coefficient is 0
     pair_vec(L, A, A.out1, box)[idx] = xc + A.c1a * (xc - xnm1) + A.c2a * dinv * (rhs - Ax);
   } else {
     pair_vec(L, A, A.out1, box)[idx] = (((gi ^ gj ^ gk ^ A.sweep_a) & 1) == 0) ? xc + dinv * (rhs - Ax) : xc;

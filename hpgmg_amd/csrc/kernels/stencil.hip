@@ -1081,10 +1081,11 @@ static int smooth_pair(const hpgmg_hip_level *L, int variant, int gsrb, int swee
 #define PAIR_LAUNCH_REMOTE(VAR, SM) { \
       static bool once = false; if (!once) { HPGMG_CHECK(hipFuncSetAttribute((const void *)cheby_pair_kernel<VAR, nw, false, SM, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once = true; } \
       const int ecols = 2 * (A.tiles_i - 1) + (A.rem[0] ? 1 : 0) + (A.rem[1] ? 1 : 0); \
-      if (ecols > 0) hipLaunchKernelGGL((cheby_pair_edge_kernel<VAR, false, SM, false, true>), dim3((A.Dj + 63) / 64, A.Dk, ecols), dim3(64), 0, g_stream, *L, A); \
+      A.edge_blocks = ((A.Dj + 63) / 64) * A.Dk * ecols; const int egrid_r = grid_for(A.edge_blocks, &A.edge_per_xcd); \
+      if (ecols > 0) hipLaunchKernelGGL((cheby_pair_edge_kernel<VAR, false, SM, false, true>), dim3(egrid_r), dim3(64), 0, g_stream, *L, A); \
       hipLaunchKernelGGL((cheby_pair_kernel<VAR, nw, false, SM, false, false, true>), dim3(grid), dim3(64, nw), lds, g_stream, *L, A); }
 #define PAIR_LAUNCH(VAR, C32, SM) { \
-      const dim3 egrid((A.Dj + 63) / 64, A.Dk, 2 * (A.tiles_i - 1)); \
+      A.edge_blocks = ((A.Dj + 63) / 64) * A.Dk * 2 * (A.tiles_i - 1); const dim3 egrid(A.edge_blocks > 0 ? grid_for(A.edge_blocks, &A.edge_per_xcd) : 1); \
       if (remote) PAIR_LAUNCH_REMOTE(VAR, SM) \
       else if (interp) { \
         if (A.tiles_i > 1) hipLaunchKernelGGL((cheby_pair_edge_kernel<VAR, C32, SM, true>), egrid, dim3(64), 0, g_stream, *L, A); \
