@@ -389,9 +389,12 @@ static int is_small(const mg_type *G, int l) { return G->levels[l]->dim.i <= SEG
 /* A captured segment bakes in the vector ids, a, b and (through the Chebyshev coefficients) every level's eigenvalue bound: all of them
  * are part of the key, so another solve on the same hierarchy with other vectors or a rebuilt operator never replays a stale graph. */
 static void seg_reset(const mg_type *G, int onLevel, int u_id, int F_id, double a, double b) {
-  unsigned long long h = 1469598103934665603ULL;   /* FNV-1a over the configuration */
+  unsigned long long h = 1469598103934665603ULL;
   int l;
-#define MIX(v) do { unsigned long long t_; double d_ = (double)(v); memcpy(&t_, &d_, sizeof t_); h = (h ^ t_) * 1099511628211ULL; } while (0)
+  /* every value goes through a full 64-bit avalanche (splitmix64 finaliser): small integers as doubles differ only in their top 12 bits,
+   * which a multiplicative hash never carries downwards -- and the top bits are the ones the key drops below */
+#define MIX(v) do { unsigned long long t_; double d_ = (double)(v); memcpy(&t_, &d_, sizeof t_); h ^= t_; \
+    h ^= h >> 30; h *= 0xbf58476d1ce4e5b9ULL; h ^= h >> 27; h *= 0x94d049bb133111ebULL; h ^= h >> 31; } while (0)
   MIX(u_id); MIX(F_id); MIX(a); MIX(b); MIX(onLevel);
   for (l = 0; l < G->num_levels; l++) MIX(G->levels[l]->dominant_eigenvalue_of_DinvA);
 #undef MIX

@@ -116,6 +116,12 @@ def test_hipgraph_segments_replay_the_same_numbers(hip):
             L.FMGSolve(L.hpgmg_solver_mg(s.ptr), 0, Hh.VECTOR_E, Hh.VECTOR_F, ab[0], ab[1], 1e-10)
             assert np.array_equal(lv.interior(Hh.VECTOR_E), want)
         assert fmt(s.fmg(0)) == gold["norms"][0]
+        # solves started from different levels must not share segment keys (a key hash that ignored the start level once made a solve
+        # from 2h replay the graphs captured for the solve from h)
+        for l in range(3):
+            s.restrict_rhs(l)
+        for l in (1, 1, 2, 0, 0, 2, 1, 2):
+            assert fmt(s.fmg(l)) == gold["norms"][l], l
         s.destroy()
     finally:
         hip.lib.hpgmg_set_graphs(0)
