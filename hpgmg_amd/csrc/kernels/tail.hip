@@ -290,46 +290,69 @@ __device__ void tail_bottom(const TailArgs &A, double *sx, double *scr) {
     tmp = vec_origin(L, box, VECTOR_TEMP)[ijk];
   }
   const double a = A.a, b = A.b, h2inv = T.h2inv, want = A.bottom_norm;
-
-  r0 = cf.rhs - bottom_apply<V>(g, x, cf, a, b, h2inv, sx);          // residual(r0, x, R)
-  r = 1.0 * r0;
-  p = 1.0 * r0;
-  double rho = bottom_dot(g, r, r0, scr);
-  const double r0_norm = bottom_norm(g, r, scr);
   int it = 0;
-  if (!(rho == 0.0 || r0_norm == 0.0)) {
-    while (it < 200) {
-      it++;
-      q = 1.0 * cf.dinv * p;
-      Ap = bottom_apply<V>(g, q, cf, a, b, h2inv, sx);
-      const double Ap_r0 = bottom_dot(g, Ap, r0, scr);
-      if (Ap_r0 == 0.0) break;
-      const double alpha = rho / Ap_r0;
-      if (__builtin_isinf(alpha)) break;
-      x = 1.0 * x + alpha * q;
-      sv = 1.0 * r + (-alpha) * Ap;
-      const double s_norm = bottom_norm(g, sv, scr);
-      if (s_norm == 0.0 || s_norm < want * r0_norm) break;
-      tv = 1.0 * cf.dinv * sv;
-      As = bottom_apply<V>(g, tv, cf, a, b, h2inv, sx);
-      const double As_As = bottom_dot(g, As, As, scr);
-      const double As_s = bottom_dot(g, As, sv, scr);
-      if (As_As == 0.0) break;
-      const double omega = As_s / As_As;
-      if (omega == 0.0 || __builtin_isinf(omega)) break;
-      x = 1.0 * x + omega * tv;
-      r = 1.0 * sv + (-omega) * As;
-      const double r_norm = bottom_norm(g, r, scr);
-      if (r_norm == 0.0 || r_norm < want * r0_norm) break;
-      const double rho_new = bottom_dot(g, r, r0, scr);
-      if (rho_new == 0.0) break;
-      const double beta = (rho_new / rho) * (alpha / omega);
-      if (__builtin_isinf(beta)) break;
-      tmp = 1.0 * p + (-omega) * Ap;
-      p = 1.0 * r + beta * tmp;
-      rho = rho_new;
-    }
+
+  // the solver (solvers/bicgstab.c:14-97) written once over three primitives -- operator, dot product, max norm -- so the general form
+  // (one cell per lane, block-wide reductions) and the one-cell form below run literally the same sequence of operations
+#define HPGMG_BICGSTAB(APPLY, DOT, NORM)                                                                   \
+  r0 = cf.rhs - APPLY(x);                                            /* residual(r0, x, R) */               \
+  r = 1.0 * r0;                                                                                            \
+  p = 1.0 * r0;                                                                                            \
+  {                                                                                                        \
+    double rho = DOT(r, r0);                                                                               \
+    const double r0_norm = NORM(r);                                                                        \
+    if (!(rho == 0.0 || r0_norm == 0.0)) {                                                                 \
+      while (it < 200) {                                                                                   \
+        it++;                                                                                              \
+        q = 1.0 * cf.dinv * p;                                                                             \
+        Ap = APPLY(q);                                                                                     \
+        const double Ap_r0 = DOT(Ap, r0);                                                                  \
+        if (Ap_r0 == 0.0) break;                                                                           \
+        const double alpha = rho / Ap_r0;                                                                  \
+        if (__builtin_isinf(alpha)) break;                                                                 \
+        x = 1.0 * x + alpha * q;                                                                           \
+        sv = 1.0 * r + (-alpha) * Ap;                                                                      \
+        const double s_norm = NORM(sv);                                                                    \
+        if (s_norm == 0.0 || s_norm < want * r0_norm) break;                                               \
+        tv = 1.0 * cf.dinv * sv;                                                                           \
+        As = APPLY(tv);                                                                                    \
+        const double As_As = DOT(As, As);                                                                  \
+        const double As_s = DOT(As, sv);                                                                   \
+        if (As_As == 0.0) break;                                                                           \
+        const double omega = As_s / As_As;                                                                 \
+        if (omega == 0.0 || __builtin_isinf(omega)) break;                                                 \
+        x = 1.0 * x + omega * tv;                                                                          \
+        r = 1.0 * sv + (-omega) * As;                                                                      \
+        const double r_norm = NORM(r);                                                                     \
+        if (r_norm == 0.0 || r_norm < want * r0_norm) break;                                               \
+        const double rho_new = DOT(r, r0);                                                                 \
+        if (rho_new == 0.0) break;                                                                         \
+        const double beta = (rho_new / rho) * (alpha / omega);                                             \
+        if (__builtin_isinf(beta)) break;                                                                  \
+        tmp = 1.0 * p + (-omega) * Ap;                                                                     \
+        p = 1.0 * r + beta * tmp;                                                                          \
+        rho = rho_new;                                                                                     \
+      }                                                                                                    \
+    }                                                                                                      \
   }
+
+  if (g.total == 1) {
+    // a 1^3 bottom level (config 2: 256^3 -> ... -> 1^3): lane 0 solves alone, every "reduction" is over one cell.  Same expressions:
+    // the operator with all six neighbours = the Dirichlet ghost -v (tail_apply with D = 1); the ordered sum of one product, 0.0 + (0.0 + a b)
+    // as bottom_dot forms it; max(0, |v|).  No barriers instead of ~25 block-wide ones per solve.
+    if (threadIdx.x == 0) {
+      auto apply1 = [&](double v) { return apply_op_7pt<V>(v, -v, -v, -v, -v, -v, -v, cf.bi0, cf.bi1, cf.bj0, cf.bj1, cf.bk0, cf.bk1, cf.al, a, b, h2inv); };
+      auto dot1 = [&](double va, double vb) { double acc = 0.0; acc += va * vb; double sum = 0.0; sum += acc; return sum; };
+      auto norm1 = [&](double v) { double m = 0.0; const double f = fabs(v); m = (f > m) ? f : m; return m; };
+      HPGMG_BICGSTAB(apply1, dot1, norm1)
+    }
+  } else {
+    auto applyN = [&](double v) { return bottom_apply<V>(g, v, cf, a, b, h2inv, sx); };
+    auto dotN = [&](double va, double vb) { return bottom_dot(g, va, vb, scr); };
+    auto normN = [&](double v) { return bottom_norm(g, v, scr); };
+    HPGMG_BICGSTAB(applyN, dotN, normN)
+  }
+#undef HPGMG_BICGSTAB
   if (g.active) {
     const int box = at.box, ijk = at.ijk;
     vec_origin(L, box, A.e_id)[ijk] = x;
@@ -394,13 +417,26 @@ __device__ void tail_interp_fcycle(const TailArgs &A, int l) {
 }
 
 // leg 0: down legs | leg 1: up legs | leg 2: down, bottom solve, up | leg 3: bottom solve only
+#ifdef HPGMG_EXP_TIMELINE
+__device__ unsigned long long *g_tail_tl = nullptr;
+#define TAIL_MARK() do { if (threadIdx.x == 0 && g_tail_tl && tl_n < 60) g_tail_tl[tl_n++] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define TAIL_MARK() do { } while (0)
+#endif
 template <int V, int SM>
 __global__ __launch_bounds__(kTailThreads) void tail_kernel(const TailArgs A, int leg) {
   __shared__ double sx[kTailMaxCells];
   __shared__ double st[kTailMaxCells];
-  if (leg == 0 || leg == 2) { for (int l = 0; l + 1 < A.n; l++) tail_level<V, SM>(A, l, 0, sx, st); }
-  if (leg == 2 || leg == 3) tail_bottom<V>(A, sx, st);
-  if (leg == 1 || leg == 2) { for (int l = A.n - 2; l >= 0; l--) tail_level<V, SM>(A, l, 1, sx, st); }
+#ifdef HPGMG_EXP_TIMELINE
+  int tl_n = 0;
+#endif
+  TAIL_MARK();
+  if (leg == 0 || leg == 2) { for (int l = 0; l + 1 < A.n; l++) { tail_level<V, SM>(A, l, 0, sx, st); TAIL_MARK(); } }
+  if (leg == 2 || leg == 3) { tail_bottom<V>(A, sx, st); TAIL_MARK(); }
+  if (leg == 1 || leg == 2) { for (int l = A.n - 2; l >= 0; l--) { tail_level<V, SM>(A, l, 1, sx, st); TAIL_MARK(); } }
+#ifdef HPGMG_EXP_TIMELINE
+  if (threadIdx.x == 0 && g_tail_tl) g_tail_tl[63] = (unsigned long long)tl_n;
+#endif
 }
 // leg 4: the F-cycle on the chain: right-hand side restricted down, bottom solve, then per level upwards interpolation_fcycle + a V-cycle.
 // (Its own kernel: folded into tail_kernel the extra code cost every V-cycle launch registers -- 48 -> 130 us per launch.)
@@ -429,6 +465,9 @@ using namespace hpgmg;
 
 extern "C" {
 
+#ifdef HPGMG_EXP_TIMELINE
+void hpgmg_hip_exp_tail_timeline(void *buf) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tail_tl), &buf, sizeof(buf)); }
+#endif
 int hpgmg_hip_tail_max_levels(void) { return kTailMaxLevels; }
 int hpgmg_hip_tail_max_cells(void) { return kTailMaxCells; }
 int hpgmg_hip_tail_bottom_max_cells(void) { return kBottomMaxCells; }
