@@ -489,7 +489,7 @@ static int check_residual(mg_type *G, int l, int e_id, int F_id, double a, doubl
     shift_vector(L, e_id, e_id, -m);
   }
   double r;
-  if (!hpgmg_residual_norm_fused(L, VECTOR_TEMP, e_id, F_id, a, b, &r)) {
+  if (!hpgmg_residual_norm_fused(L, -1, e_id, F_id, a, b, &r)) {   /* -1: VECTOR_TEMP is scratch here, nothing reads the residual after its norm */
     residual(L, VECTOR_TEMP, e_id, F_id, a, b);
     r = norm(L, VECTOR_TEMP);
   }

@@ -1125,7 +1125,8 @@ int hpgmg_norm_scale_restrict_fused(level_type *L, int F_id, int R_id, level_typ
   return 1;
 }
 /* residual(L, res, x, rhs) ; norm(L, res) -- the convergence check of MGSolve / FMGSolve (mg.c:1321-1323) -- in one pass: the residual is
- * stored as usual and its max-abs comes out of the same kernel.  0 = not applicable. */
+ * stored as usual (res_id < 0: not stored -- the cycle driver's check, after which VECTOR_TEMP is dead) and its max-abs comes out of the
+ * same kernel.  0 = not applicable. */
 int hpgmg_residual_norm_fused(level_type *L, int res_id, int x_id, int rhs_id, double a, double b, double *norm_out) {
   hpgmg_config cfg;
   hpgmg_get_config(&cfg);

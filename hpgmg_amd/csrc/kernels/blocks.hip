@@ -215,25 +215,35 @@ __global__ __launch_bounds__(256) void interp_blocks_kernel(const hpgmg_hip_leve
 #pragma unroll
         for (int fj = 0; fj < 2; fj++) {
           double *fw = frow + 2 * ci + fj * w.jS + fk * w.kS;
-          double f0, f1;
-          if (pairs) { const double2 t = *reinterpret_cast<const double2 *>(fw); f0 = t.x; f1 = t.y; }
-          else { f0 = fw[0]; f1 = fw[1]; }
-          double v[2] = { prescale * f0, prescale * f1 };
+          double v[2];
+          auto blend = [&](double f0, double f1) {
+            v[0] = prescale * f0; v[1] = prescale * f1;
 #pragma unroll
-          for (int fi = 0; fi < 2; fi++) {
-            if (ORDER == 0) v[fi] = v[fi] + nb[1][1][1];
-            else {  // an even fine cell leans on the coarse neighbour behind it, an odd one on the one ahead
-              const int oi = fi ? 2 : 0, oj = fj ? 2 : 0, ok = fk ? 2 : 0;
-              v[fi] = v[fi] + 0.421875 * nb[1][1][1];
-              v[fi] = v[fi] + 0.140625 * nb[ok][1][1];
-              v[fi] = v[fi] + 0.140625 * nb[1][oj][1];
-              v[fi] = v[fi] + 0.046875 * nb[ok][oj][1];
-              v[fi] = v[fi] + 0.140625 * nb[1][1][oi];
-              v[fi] = v[fi] + 0.046875 * nb[ok][1][oi];
-              v[fi] = v[fi] + 0.046875 * nb[1][oj][oi];
-              v[fi] = v[fi] + 0.015625 * nb[ok][oj][oi];
+            for (int fi = 0; fi < 2; fi++) {
+              if (ORDER == 0) v[fi] = v[fi] + nb[1][1][1];
+              else {  // an even fine cell leans on the coarse neighbour behind it, an odd one on the one ahead
+                const int oi = fi ? 2 : 0, oj = fj ? 2 : 0, ok = fk ? 2 : 0;
+                v[fi] = v[fi] + 0.421875 * nb[1][1][1];
+                v[fi] = v[fi] + 0.140625 * nb[ok][1][1];
+                v[fi] = v[fi] + 0.140625 * nb[1][oj][1];
+                v[fi] = v[fi] + 0.046875 * nb[ok][oj][1];
+                v[fi] = v[fi] + 0.140625 * nb[1][1][oi];
+                v[fi] = v[fi] + 0.046875 * nb[ok][1][oi];
+                v[fi] = v[fi] + 0.046875 * nb[1][oj][oi];
+                v[fi] = v[fi] + 0.015625 * nb[ok][oj][oi];
+              }
             }
-          }
+          };
+          auto load_fine = [&](double &f0, double &f1) {
+            if (pairs) { const double2 t = *reinterpret_cast<const double2 *>(fw); f0 = t.x; f1 = t.y; }
+            else { f0 = fw[0]; f1 = fw[1]; }
+          };
+          // prescale == 0 (interpolation_fcycle, and the send buffers): 0 * old + y == y for every finite old value unless y is a
+          // zero, whose sign then follows old's -- so the old value is fetched only for results that are zeros
+          double f0 = 0.0, f1 = 0.0;
+          if (prescale != 0.0) load_fine(f0, f1);
+          blend(f0, f1);
+          if (prescale == 0.0 && (v[0] == 0.0 || v[1] == 0.0)) { load_fine(f0, f1); blend(f0, f1); }
           if (pairs) *reinterpret_cast<double2 *>(fw) = make_double2(v[0], v[1]);
           else { fw[0] = v[0]; fw[1] = v[1]; }
         }

@@ -42,6 +42,7 @@ struct FusedArgs {
   const int *map;               // per fine box: coarse box, and the (i, j, k) of the coarse cell under the fine box's first cell
   int zero_chunks_per_box, compute_blocks;
   double *partials;             // MODE_RESIDUAL_NORM: one max per workgroup
+  int no_store;                 // MODE_RESIDUAL_NORM: the residual itself is not wanted, only its norm
 };
 
 struct StencilArgs {
@@ -208,7 +209,7 @@ __global__ __launch_bounds__(64 * WJ) void stencil7_wide_kernel(const hpgmg_hip_
   constexpr bool kRestrict = (MODE == MODE_RESIDUAL_RESTRICT), kNorm = (MODE == MODE_RESIDUAL_NORM);
 
   typename src_ptr<MODE == MODE_GSRB>::type x = vec_origin(L, box, P.xn_id);
-  double *out = kRestrict ? nullptr : vec_origin(L, box, P.xout_id);
+  double *out = (kRestrict || (kNorm && F.no_store)) ? nullptr : vec_origin(L, box, P.xout_id);
   const double *__restrict__ rhs = (MODE == MODE_APPLY) ? nullptr : vec_origin(L, box, P.rhs_id);
   const double *__restrict__ dinv = kSmooth ? vec_origin(L, box, VECTOR_DINV) : nullptr;
   const double *__restrict__ alpha = kHelm ? vec_origin(L, box, VECTOR_ALPHA) : nullptr;
@@ -325,7 +326,7 @@ __global__ __launch_bounds__(64 * WJ) void stencil7_wide_kernel(const hpgmg_hip_
           }                                                                                                                 \
         }                                                                                                                   \
         RES = o;                                                                                                            \
-        if (kRestrict) { }                                                                                                  \
+        if (kRestrict || (kNorm && F.no_store)) { }                                                                         \
         else if (dm == 0) st2(out + IDX, o);                                                                                \
         else { if (!(dm & 1)) out[IDX] = o.x; if (!(dm & 2)) out[IDX + 1] = o.y; }                                          \
       }                                                                                                                     \
@@ -1216,14 +1217,15 @@ int hpgmg_hip_residual_restrict(const hpgmg_hip_level *L, int variant, int x_id,
   F.zero_chunks_per_box = (Lc->volume + 4095) / 4096;
   return launch_wide_fused<MODE_RESIDUAL_RESTRICT>(L, variant, P, F, zero_id >= 0 ? F.zero_chunks_per_box * Lc->num_boxes : 0);
 }
-// residual stored to res_id AND its max-abs: residual() + norm() of the convergence check (mg.c:1321-1323) in one pass
+// residual stored to res_id (not stored when res_id < 0) AND its max-abs: residual() + norm() of the convergence check (mg.c:1321-1323) in one pass
 int hpgmg_hip_residual_norm(const hpgmg_hip_level *L, int variant, int res_id, int x_id, int rhs_id, double a, double b, double h2inv, double *norm_out) {
   if (int e = hpgmg_hip_graph_flush()) return e;
   *norm_out = 0.0;
   if (!wide_fused_ok(L, variant)) return record_error(hipErrorInvalidValue, "residual_norm: level not supported");
   StencilArgs P = {}; P.xn_id = x_id; P.xout_id = res_id; P.rhs_id = rhs_id; P.a = a; P.b = b; P.h2inv = h2inv;
   const int blocks = L->num_boxes * ((L->dim + 15) / 16) * (L->dim / 16) * (L->dim / 128);
-  FusedArgs F = {}; F.partials = reduction_scratch(blocks);
+  FusedArgs F = {}; F.partials = reduction_scratch(blocks); F.no_store = (res_id < 0);
+  if (res_id < 0) P.xout_id = x_id;
   if (!F.partials) return record_error(hipErrorOutOfMemory, "residual_norm: scratch");
   if (int e = launch_wide_fused<MODE_RESIDUAL_NORM>(L, variant, P, F, 0)) return e;
   return finish_max_reduction(blocks, 0.0, norm_out);

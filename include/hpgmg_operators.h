@@ -140,7 +140,8 @@ int     hpgmg_get_timer_mode(void);
 /* Optional fused forms around residual() (return 1 when executed, 0 when the driver must issue the operators one by one):
  *   residual(fine, TEMP, x, rhs); restriction(coarse, id_c, fine, TEMP, RESTRICT_CELL); zero_vector(coarse, zero_id)   (mg.c:1150-1153)
  *     -- same coarse result; the fine level's VECTOR_TEMP is left untouched (the residual is never stored);
- *   residual(level, res, x, rhs); *norm_out = norm(level, res)                                                          (mg.c:1321-1323) */
+ *   residual(level, res, x, rhs); *norm_out = norm(level, res)                                                          (mg.c:1321-1323)
+ *     -- res_id < 0: only the norm is wanted (the cycle driver's convergence check: nothing reads the residual afterwards) */
 int     hpgmg_residual_restrict_zero_fused(level_type *coarse, int id_c, level_type *fine, int x_id, int rhs_id, double a, double b, int zero_id);
 int     hpgmg_residual_norm_fused(level_type *level, int res_id, int x_id, int rhs_id, double a, double b, double *norm_out);
 /*   *norm_out = norm(level, F); scale_vector(level, R, 1.0, F); restriction(coarse, R, level, R, RESTRICT_CELL)                        (mg.c:1262-1270) */

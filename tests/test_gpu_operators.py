@@ -245,6 +245,13 @@ def test_fused_residual_forms(hip, oracle, variant, geom):
         assert L.hpgmg_residual_norm_fused(fh.ptr, H.VECTOR_TEMP, H.VECTOR_U, H.VECTOR_F, a, b, ctypes.byref(out)) == 1
         same(fh, fo, [H.VECTOR_TEMP], interior_only=True)
         assert out.value == bo.lib.norm(fo.ptr, H.VECTOR_TEMP)
+        # the form the cycle driver uses: only the norm, VECTOR_TEMP untouched
+        fine_junk = seeded_field(fh, 902)
+        fh.write_all(H.VECTOR_TEMP, fine_junk)
+        out2 = c_dbl(0.0)
+        assert L.hpgmg_residual_norm_fused(fh.ptr, -1, H.VECTOR_U, H.VECTOR_F, a, b, ctypes.byref(out2)) == 1
+        assert out2.value == out.value
+        assert np.array_equal(fh.read_all(H.VECTOR_TEMP), fine_junk)
         # 3. opening of FMGSolve
         for c in (ch, co):
             c.write_all(H.VECTOR_R, junk)
