@@ -129,6 +129,7 @@ typedef struct {
   double  *seen_v0;     int seen_nv, seen_boxes;  /* detects create_vectors() re-allocation */
   struct { const blockCopy_type *host; int n; blockCopy_type *dev; } lists[MAX_LISTS];
   int num_lists;
+  hpgmg_hip_bc_entry *d_bc[STENCIL_MAX_SHAPES]; int n_bc[STENCIL_MAX_SHAPES];   /* boundary-condition blocks with their geometry worked out */
   int *krylov_pinned;          /* iterations of device-side bottom solves not yet folded into level->Krylov_iterations */
   double *pair_scratch; double **d_pair_base;   /* two private vectors per box for the fused Chebyshev sweep pairs */
   float *coef32; float **d_coef32_base; int coef32_valid;   /* fp32 copies of Dinv, alpha, beta_* for the mixed-precision smoother */
@@ -253,6 +254,7 @@ void hpgmg_level_release(level_type *L) {
   int s;
   if (!B) return;
   for (s = 0; s < B->num_lists; s++) hpgmg_hip_free(B->lists[s].dev);
+  for (s = 0; s < STENCIL_MAX_SHAPES; s++) if (B->d_bc[s]) hpgmg_hip_free(B->d_bc[s]);
   if (B->d_box_base) hpgmg_hip_free(B->d_box_base);
   if (B->d_box_low) hpgmg_hip_free(B->d_box_low);
   if (B->d_box_nbr) hpgmg_hip_free(B->d_box_nbr);
@@ -415,24 +417,63 @@ void apply_BCs_p1(level_type *L, int x_id, int shape) {
   TOCK();
 }
 static void no_kernel(const char *what) { fprintf(stderr, "hpgmg: %s has no HIP kernel yet\n", what); abort(); }
+static const hpgmg_hip_bc_entry *bc_entries(level_type *L, int shape, int *n_out);
 void apply_BCs_p2(level_type *L, int x_id, int shape) {                                /* boundary_fd.c:93-205 */
   if (shape >= STENCIL_MAX_SHAPES) shape = STENCIL_SHAPE_BOX;
   if (L->boundary_condition.type == BC_PERIODIC) return;
   if (L->box_dim < 2) { apply_BCs_p1(L, x_id, shape); return; }
   TICK(L, boundary_conditions, "apply_BCs_p2");
   backend_t *B = backend_of(L);
-  const int n = L->boundary_condition.num_blocks[shape];
-  HIP_OK(hpgmg_hip_apply_bc_p2(&B->dev, x_id, mirror(L, L->boundary_condition.blocks[shape], n), n));
+  int n = L->boundary_condition.num_blocks[shape];
+  if (L->box_ghosts == 1) { const hpgmg_hip_bc_entry *e = bc_entries(L, shape, &n); HIP_OK(hpgmg_hip_apply_bc_fv(&B->dev, x_id, e, n, 12)); }
+  else HIP_OK(hpgmg_hip_apply_bc_p2(&B->dev, x_id, mirror(L, L->boundary_condition.blocks[shape], n), n));
   TOCK();
 }
 void apply_BCs_v1(level_type *L, int x_id, int shape) { apply_BCs_p1(L, x_id, shape); }   /* boundary_fv.c:6-90: same one-point formula */
+/* The finite-volume conditions work on a block's DOMAIN normal (its subtype): the axes leaving the domain sit at ghost index -1 / dim and
+ * step inward, the others run over the block's extent.  That geometry is fixed per block, so it is worked out here once; the kernel
+ * then only loads it (faces first: they are the long entries). */
+static const hpgmg_hip_bc_entry *bc_entries(level_type *L, int shape, int *n_out) {
+  backend_t *B = backend_of(L);
+  const int n = L->boundary_condition.num_blocks[shape];
+  *n_out = n;
+  if (n <= 0) return NULL;
+  if (B->d_bc[shape] && B->n_bc[shape] == n) return B->d_bc[shape];
+  if (B->d_bc[shape]) hpgmg_hip_free(B->d_bc[shape]);
+  const blockCopy_type *blocks = L->boundary_condition.blocks[shape];
+  hpgmg_hip_bc_entry *h = (hpgmg_hip_bc_entry *)calloc((size_t)n, sizeof *h);
+  const int strides[3] = {1, L->my_boxes[0].jStride, L->my_boxes[0].kStride};
+  int kind, q, m = 0;
+  for (kind = 1; kind <= 3; kind++) for (q = 0; q < n; q++) {
+    const blockCopy_type *e = &blocks[q];
+    const int d[3] = {e->subtype % 3 - 1, (e->subtype % 9) / 3 - 1, e->subtype / 9 - 1};
+    const int lo[3] = {e->read.i, e->read.j, e->read.k}, len[3] = {e->dim.i, e->dim.j, e->dim.k};
+    if ((d[0] != 0) + (d[1] != 0) + (d[2] != 0) != kind) continue;
+    hpgmg_hip_bc_entry *o = &h[m++];
+    int ax, nf = 0;
+    o->box = e->read.box; o->nn = 0; o->base = 0; o->len0 = o->len1 = 1; o->fs0 = o->fs1 = 0;
+    for (ax = 0; ax < 3; ax++) {
+      if (d[ax]) { o->base += (d[ax] < 0 ? -1 : L->box_dim) * strides[ax]; o->step[o->nn++] = -d[ax] * strides[ax]; }
+      else if (nf == 0) { o->base += lo[ax] * strides[ax]; o->len0 = len[ax]; o->fs0 = strides[ax]; nf++; }
+      else if (nf == 1) { o->base += lo[ax] * strides[ax]; o->len1 = len[ax]; o->fs1 = strides[ax]; nf++; }
+    }
+  }
+  if (m != n) { fprintf(stderr, "hpgmg: boundary-condition block without a domain normal\n"); abort(); }
+  B->d_bc[shape] = (hpgmg_hip_bc_entry *)hpgmg_hip_malloc((size_t)n * sizeof *h);
+  if (!B->d_bc[shape]) { fprintf(stderr, "hpgmg: device allocation failed: %s\n", hpgmg_hip_last_error()); abort(); }
+  HIP_OK(hpgmg_hip_memcpy_h2d(B->d_bc[shape], h, (size_t)n * sizeof *h));
+  B->n_bc[shape] = n;
+  free(h);
+  return B->d_bc[shape];
+}
 void apply_BCs_v2(level_type *L, int x_id, int shape) {                                   /* boundary_fv.c:101-250 */
   if (shape >= STENCIL_MAX_SHAPES) shape = STENCIL_SHAPE_BOX;
   if (L->boundary_condition.type == BC_PERIODIC) return;
   if (L->box_dim < 2) { apply_BCs_v1(L, x_id, shape); return; }
   TICK(L, boundary_conditions, "apply_BCs_v2");
-  const int n = L->boundary_condition.num_blocks[shape];
-  HIP_OK(hpgmg_hip_apply_bc_v2(&backend_of(L)->dev, x_id, mirror(L, L->boundary_condition.blocks[shape], n), n));
+  int n = L->boundary_condition.num_blocks[shape];
+  if (L->box_ghosts <= 1) { const hpgmg_hip_bc_entry *e = bc_entries(L, shape, &n); HIP_OK(hpgmg_hip_apply_bc_fv(&backend_of(L)->dev, x_id, e, n, 2)); }
+  else HIP_OK(hpgmg_hip_apply_bc_v2(&backend_of(L)->dev, x_id, mirror(L, L->boundary_condition.blocks[shape], n), n));   /* clears the deeper layers first */
   TOCK();
 }
 void apply_BCs_v4(level_type *L, int x_id, int shape) {                                   /* boundary_fv.c:262-569 */
@@ -441,8 +482,9 @@ void apply_BCs_v4(level_type *L, int x_id, int shape) {                         
   if (L->box_ghosts < 2) { fprintf(stderr, "called quartic BC's with only 1 ghost zone!!!\n"); abort(); }
   if (L->box_dim < 4) { apply_BCs_v2(L, x_id, shape); return; }
   TICK(L, boundary_conditions, "apply_BCs_v4");
-  const int n = L->boundary_condition.num_blocks[shape];
-  HIP_OK(hpgmg_hip_apply_bc_v4(&backend_of(L)->dev, x_id, mirror(L, L->boundary_condition.blocks[shape], n), n));
+  int n = L->boundary_condition.num_blocks[shape];
+  if (L->box_ghosts <= 2) { const hpgmg_hip_bc_entry *e = bc_entries(L, shape, &n); HIP_OK(hpgmg_hip_apply_bc_fv(&backend_of(L)->dev, x_id, e, n, 4)); }
+  else HIP_OK(hpgmg_hip_apply_bc_v4(&backend_of(L)->dev, x_id, mirror(L, L->boundary_condition.blocks[shape], n), n));   /* clears the deeper layers first */
   TOCK();
 }
 void extrapolate_betas(level_type *L) {                                                    /* boundary_fv.c:573-681 */

@@ -33,6 +33,10 @@ __global__ __launch_bounds__(256) void bc_v4_kernel(const hpgmg_hip_level L, int
   if (L.ghosts > 2) { bc_zero_entry(L, id, list[blockIdx.x], (int)threadIdx.x, (int)blockDim.x); __syncthreads(); }
   bc_v4_entry(L, id, list[blockIdx.x], (int)threadIdx.x, (int)blockDim.x);
 }
+template <int ORDER>
+__global__ __launch_bounds__(256) void bc_fv_kernel(const hpgmg_hip_level L, int id, const hpgmg_hip_bc_entry *__restrict__ list) {
+  bc_fv_compact_entry<ORDER>(L, id, list[blockIdx.x], (int)threadIdx.x, 256);
+}
 
 // boundary_fv.c:573-681 extrapolate_betas.  The reference updates each block IN PLACE in k,j,i order, so a
 // deeper ghost cell may see a shallower one already (high side) or not yet (low side) updated.  One lane per
@@ -297,6 +301,17 @@ int hpgmg_hip_apply_bc_v4(const hpgmg_hip_level *L, int id, const blockCopy_type
   if (n <= 0) return 0;
   hipLaunchKernelGGL(bc_v4_kernel, dim3(n), dim3(256), 0, g_stream, *L, id, blocks);
   HPGMG_LAUNCH_CHECK("bc_v4_kernel");
+  return 0;
+}
+int hpgmg_hip_apply_bc_fv(const hpgmg_hip_level *L, int id, const hpgmg_hip_bc_entry *entries, int n, int order) {
+  HPGMG_SKIP_IF_REPLAY();
+  if (n <= 0) return 0;
+  const int fills = (order == 4) ? 2 : 1;
+  if (L->ghosts > fills || (order != 2 && order != 4 && order != 12)) return record_error(hipErrorInvalidValue, "apply_bc_fv: ghost zone deeper than the condition fills");
+  if (order == 4)      hipLaunchKernelGGL(bc_fv_kernel<4>, dim3(n), dim3(256), 0, g_stream, *L, id, entries);
+  else if (order == 2) hipLaunchKernelGGL(bc_fv_kernel<2>, dim3(n), dim3(256), 0, g_stream, *L, id, entries);
+  else                 hipLaunchKernelGGL(bc_fv_kernel<12>, dim3(n), dim3(256), 0, g_stream, *L, id, entries);
+  HPGMG_LAUNCH_CHECK("bc_fv_kernel");
   return 0;
 }
 int hpgmg_hip_extrapolate_betas(const hpgmg_hip_level *L, const blockCopy_type *blocks, int n) {
