@@ -72,6 +72,7 @@ def _declare_driver_api(lib):
         "hpgmg_set_timer_mode": (None, [c_int]),
         "hpgmg_get_timer_mode": (c_int, []),
         "hpgmg_level_eigenvalue": (c_dbl, [vp]),
+        "hpgmg_level_set_eigenvalue": (None, [vp, c_dbl]),
         "hpgmg_level_box_low": (None, [vp, c_int, P(c_int)]),
         "hpgmg_level_list_counts": (c_int, [vp, c_int, c_int, P(c_int)]),
         "hpgmg_level_read_vector": (None, [vp, c_int, c_int, vp]),

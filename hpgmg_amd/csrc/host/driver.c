@@ -261,6 +261,7 @@ void hpgmg_level_timers(level_type *L, double out[9]) {
 }
 double hpgmg_level_h(const level_type *L) { return L->h; }
 double hpgmg_level_eigenvalue(const level_type *L) { return L->dominant_eigenvalue_of_DinvA; }
+void hpgmg_level_set_eigenvalue(level_type *L, double v) { L->dominant_eigenvalue_of_DinvA = v; }
 void hpgmg_level_box_low(const level_type *L, int box, int out[3]) {
   out[0] = L->my_boxes[box].low.i; out[1] = L->my_boxes[box].low.j; out[2] = L->my_boxes[box].low.k;
 }

@@ -326,12 +326,14 @@ static int ghost_free_mode(void) {
   return ghost_free;
 }
 void hpgmg_set_ghost_free(int on) { ghost_free = on ? 1 : 0; hpgmg_hip_set_ghost_free(ghost_free); }
-static void ghosts_for_stencil(level_type *L, int id) {
+static int variant(void);
+static void ghosts_for_stencil(level_type *L, int id, int out_id) {
   const int shape = stencil_get_shape();
   hpgmg_config c;
   hpgmg_get_config(&c);
   const int fuse = ghost_free_mode() && c.op == HPGMG_OP_7PT && shape == STENCIL_SHAPE_STAR;
   hpgmg_hip_set_ghost_free(fuse);   /* the in-kernel -x(centre) rule IS apply_BCs_p1; other plugins (fv2: v2 BCs) need real ghosts */
+  hpgmg_hip_set_tile_ghost_free(0);
   if (fuse) {
     communicator_type *C = &L->exchange_ghosts[shape];
     if (C->num_sends + C->num_recvs > 0) {
@@ -343,6 +345,16 @@ static void ghosts_for_stencil(level_type *L, int id) {
       TOCK();
     }
     return;
+  }
+  /* 27-point and fv4 on a level whose boxes are all local, about to run the LDS-tiled kernel: it reads a neighbouring box's cells
+   * where they live, so only the domain-boundary ghost cells are needed (each box's own, from its own interior) */
+  if (ghost_free_mode() && (c.op == HPGMG_OP_27PT || c.op == HPGMG_OP_FV4) && L->num_my_boxes > 0) {
+    backend_t *B = backend_of(L);
+    if (B->all_faces_local && hpgmg_hip_tile_kernel_applies(&B->dev, variant(), id != out_id)) {
+      hpgmg_hip_set_tile_ghost_free(1);
+      apply_BCs(L, id, shape);
+      return;
+    }
   }
   exchange_boundary(L, id, shape);
   apply_BCs(L, id, shape);
@@ -392,7 +404,7 @@ static int overlap_begin(level_type *L, int id) {
 }
 static void overlap_end(void) { HIP_OK(hpgmg_hip_stream_wait_event(ev_landed)); }
 /* run a stencil launch with its operand's ghost zones: overlapped (two launches: all but the shell, then the shell) or plain */
-#define STENCIL_WITH_GHOSTS(L, id, TIMER, CALL) do {                                                     \
+#define STENCIL_WITH_GHOSTS(L, id, out_id, TIMER, CALL) do {                                                     \
     if (overlap_begin(L, id)) {                                                                          \
       TICK(L, TIMER, #TIMER " (overlapped with the halo exchange)");                                     \
       hpgmg_hip_set_defer_mode(1); HIP_OK(CALL);                                                         \
@@ -400,7 +412,7 @@ static void overlap_end(void) { HIP_OK(hpgmg_hip_stream_wait_event(ev_landed)); 
       hpgmg_hip_set_defer_mode(2); HIP_OK(CALL); hpgmg_hip_set_defer_mode(0);                            \
       TOCK();                                                                                            \
     } else {                                                                                             \
-      ghosts_for_stencil(L, id);                                                                         \
+      ghosts_for_stencil(L, id, out_id);                                                                 \
       TICK(L, TIMER, #TIMER);                                                                            \
       HIP_OK(CALL);                                                                                      \
       TOCK();                                                                                            \
@@ -1053,30 +1065,30 @@ void smooth(level_type *L, int x_id, int rhs_id, double a, double b) {
     if (smooth_cheby_pairs(L, x_id, rhs_id, a, b, c1, c2, sweeps)) return;
     for (s = 0; s < sweeps; s++) {
       const int src = (s & 1) ? VECTOR_TEMP : x_id, dst = (s & 1) ? x_id : VECTOR_TEMP;
-      STENCIL_WITH_GHOSTS(L, src, smooth, hpgmg_hip_smooth_cheby(&B->dev, v, src, dst, rhs_id, a, b, h2inv, c1[s], c2[s]));
+      STENCIL_WITH_GHOSTS(L, src, dst, smooth, hpgmg_hip_smooth_cheby(&B->dev, v, src, dst, rhs_id, a, b, h2inv, c1[s], c2[s]));
     }
   } else if (cfg.smoother == HPGMG_SMOOTH_GSRB) {    /* gsrb.c:24-132 */
     const int oop = hpgmg_gsrb_out_of_place();
     if (smooth_gsrb_pairs(L, x_id, rhs_id, a, b, sweeps)) return;
     for (s = 0; s < sweeps; s++) {
       const int src = (oop && (s & 1)) ? VECTOR_TEMP : x_id, dst = oop ? ((s & 1) ? x_id : VECTOR_TEMP) : x_id;
-      STENCIL_WITH_GHOSTS(L, src, smooth, hpgmg_hip_smooth_gsrb(&B->dev, v, src, dst, rhs_id, a, b, h2inv, s));
+      STENCIL_WITH_GHOSTS(L, src, dst, smooth, hpgmg_hip_smooth_gsrb(&B->dev, v, src, dst, rhs_id, a, b, h2inv, s));
     }
   } else {                                           /* jacobi.c:8-65 */
     for (s = 0; s < sweeps; s++) {
       const int src = (s & 1) ? VECTOR_TEMP : x_id, dst = (s & 1) ? x_id : VECTOR_TEMP;
-      STENCIL_WITH_GHOSTS(L, src, smooth, hpgmg_hip_smooth_jacobi(&B->dev, v, src, dst, rhs_id, a, b, h2inv, 2.0 / 3.0));
+      STENCIL_WITH_GHOSTS(L, src, dst, smooth, hpgmg_hip_smooth_jacobi(&B->dev, v, src, dst, rhs_id, a, b, h2inv, 2.0 / 3.0));
     }
   }
 }
 
 void residual(level_type *L, int res_id, int x_id, int rhs_id, double a, double b) {   /* residual.c:9-51 */
   if (small_level_try(L, 3, x_id, rhs_id, res_id, a, b)) return;
-  STENCIL_WITH_GHOSTS(L, x_id, residual, hpgmg_hip_residual(&backend_of(L)->dev, variant(), res_id, x_id, rhs_id, a, b, 1.0 / (L->h * L->h)));
+  STENCIL_WITH_GHOSTS(L, x_id, res_id, residual, hpgmg_hip_residual(&backend_of(L)->dev, variant(), res_id, x_id, rhs_id, a, b, 1.0 / (L->h * L->h)));
 }
 void apply_op(level_type *L, int Ax_id, int x_id, double a, double b) {               /* apply_op.c:9-48 */
   if (small_level_try(L, 4, x_id, -1, Ax_id, a, b)) return;
-  STENCIL_WITH_GHOSTS(L, x_id, apply_op, hpgmg_hip_residual(&backend_of(L)->dev, variant(), Ax_id, x_id, -1, a, b, 1.0 / (L->h * L->h)));
+  STENCIL_WITH_GHOSTS(L, x_id, Ax_id, apply_op, hpgmg_hip_residual(&backend_of(L)->dev, variant(), Ax_id, x_id, -1, a, b, 1.0 / (L->h * L->h)));
 }
 
 /* ---------------------------------------------------------------- restriction.c:104-212 */

@@ -91,55 +91,72 @@ __device__ __forceinline__ double interp_rule(bool odd, const double *v) {
     return odd ? (v[2] - c1 * (v[1] - v[3]) - c2 * (v[0] - v[4])) : (v[2] + c1 * (v[1] - v[3]) + c2 * (v[0] - v[4]));
   }
 }
-// dimension by dimension (i, then j, then k), one fine cell per lane: the same intermediate values
-// f?c??, f??c?, f??? the reference forms for the 8 children of a coarse cell
 // Tensor-product interpolations (interpolation_p2.c, _v2.c, _v4.c): the 1-D rule is applied along i, then j, then k.
-// One lane per COARSE cell (a wave per coarse row, grid.y strides over the rows): the (2R+1)^3 coarse neighbourhood is
-// read once, plane by plane, and serves the cell's 8 children -- the i-pass results depend only on the child's i parity,
-// the j-pass results on its (i, j) parities -- instead of once per fine cell; each child is the same expression tree
-// (rule_k(rule_j(rule_i(coarse)))) as before.  Children are written as 16-byte pairs when the layout allows.
+// One lane per COARSE column, marching in k over a chunk of the entry (a wave per coarse row and chunk; grid.y strides over them):
+// the i- and j-passes of one coarse plane depend only on that plane -- their four results (child i parity x child j parity) are
+// computed once per plane from its (2R+1)^2 neighbourhood and kept in a sliding window of 2R+1 planes, the k-pass then serves the
+// cell's 8 children.  (2R+1)^2 loads per coarse cell instead of (2R+1)^3 (the first version was bound by the L1 at 125 loads per
+// cell); each child is the same expression tree rule_k(rule_j(rule_i(coarse))) as in the reference.  Children are written as
+// 16-byte pairs when the layout allows.
 template <int ORDER>
 __global__ __launch_bounds__(256) void interp_tensor_kernel(const hpgmg_hip_level Lf, int id_f, double prescale, const hpgmg_hip_level Lc, int id_c,
                                                             const blockCopy_type *__restrict__ list) {
-  constexpr int R = (ORDER == 4) ? 2 : 1, W = 2 * R + 1;
+  constexpr int R = (ORDER == 4) ? 2 : 1, W = 2 * R + 1, KC = 8;
   const blockCopy_type &e = list[blockIdx.x];
   const Side r = resolve_read(Lc, id_c, e), w = resolve_write(Lf, id_f, e);
-  const int ci_n = e.dim.i, cj_n = e.dim.j, rows = cj_n * e.dim.k, rj = r.jS, rk = r.kS;
+  const int ci_n = e.dim.i, cj_n = e.dim.j, ck_n = e.dim.k, rj = r.jS, rk = r.kS;
+  const int nkc = (ck_n + KC - 1) / KC, units = cj_n * nkc;
   const bool pairs = (e.write.box >= 0) && (Lf.flags & 1);
   const int lane = threadIdx.x % 64;
-  for (int row = blockIdx.y * 4 + threadIdx.x / 64; row < rows; row += gridDim.y * 4) {
-    const int ck = row / cj_n, cj = row - ck * cj_n;
-    const double *crow = r.p + cj * rj + ck * rk;
-    double *frow = w.p + 2 * cj * w.jS + 2 * ck * w.kS;
+  for (int u = blockIdx.y * 4 + threadIdx.x / 64; u < units; u += gridDim.y * 4) {
+    const int kc = u / cj_n, cj = u - kc * cj_n, k0 = kc * KC, k1 = (k0 + KC < ck_n) ? k0 + KC : ck_n;
     for (int ci = lane; ci < ci_n; ci += 64) {
-      const double *c = crow + ci;
-      double tk[2][2][W];                                       // [child i parity][child j parity][coarse plane]
-#pragma unroll
-      for (int kk = 0; kk < W; kk++) {
+      const double *c = r.p + ci + cj * rj;
+      double tk[2][2][W];                                       // [child i parity][child j parity][coarse plane ck-R .. ck+R]
+      auto plane = [&](int ck, int slot) {                      // i-pass and j-pass of coarse plane ck
+        const double *cp = c + ck * rk;
         double tj[2][W];                                        // [child i parity][coarse row]
 #pragma unroll
         for (int jj = 0; jj < W; jj++) {
           double line[W];
 #pragma unroll
-          for (int ii = 0; ii < W; ii++) line[ii] = c[(ii - R) + (jj - R) * rj + (kk - R) * rk];
+          for (int ii = 0; ii < W; ii++) line[ii] = cp[(ii - R) + (jj - R) * rj];
           tj[0][jj] = interp_rule<ORDER>(false, line);
           tj[1][jj] = interp_rule<ORDER>(true, line);
         }
 #pragma unroll
-        for (int fi = 0; fi < 2; fi++) { tk[fi][0][kk] = interp_rule<ORDER>(false, tj[fi]); tk[fi][1][kk] = interp_rule<ORDER>(true, tj[fi]); }
-      }
+        for (int fi = 0; fi < 2; fi++) { tk[fi][0][slot] = interp_rule<ORDER>(false, tj[fi]); tk[fi][1][slot] = interp_rule<ORDER>(true, tj[fi]); }
+      };
 #pragma unroll
-      for (int fk = 0; fk < 2; fk++) {
+      for (int kk = 0; kk < W - 1; kk++) plane(k0 - R + kk, kk + 1);   // planes k0-R .. k0+R-1 wait one slot up: the loop shifts first
+      for (int ck = k0; ck < k1; ck++) {
 #pragma unroll
-        for (int fj = 0; fj < 2; fj++) {
-          double *fw = frow + 2 * ci + fj * w.jS + fk * w.kS;
-          double f0, f1;
-          if (pairs) { const double2 t = *reinterpret_cast<const double2 *>(fw); f0 = t.x; f1 = t.y; }
-          else { f0 = fw[0]; f1 = fw[1]; }
-          const double v0 = prescale * f0 + interp_rule<ORDER>(fk != 0, tk[0][fj]);
-          const double v1 = prescale * f1 + interp_rule<ORDER>(fk != 0, tk[1][fj]);
-          if (pairs) *reinterpret_cast<double2 *>(fw) = make_double2(v0, v1);
-          else { fw[0] = v0; fw[1] = v1; }
+        for (int fi = 0; fi < 2; fi++)
+#pragma unroll
+          for (int fj = 0; fj < 2; fj++)
+#pragma unroll
+            for (int kk = 0; kk < W - 1; kk++) tk[fi][fj][kk] = tk[fi][fj][kk + 1];
+        plane(ck + R, W - 1);
+        double *frow = w.p + 2 * cj * w.jS + 2 * ck * w.kS;
+#pragma unroll
+        for (int fk = 0; fk < 2; fk++) {
+#pragma unroll
+          for (int fj = 0; fj < 2; fj++) {
+            double *fw = frow + 2 * ci + fj * w.jS + fk * w.kS;
+            const double a0 = interp_rule<ORDER>(fk != 0, tk[0][fj]), a1 = interp_rule<ORDER>(fk != 0, tk[1][fj]);
+            double f0 = 0.0, f1 = 0.0;
+            auto load_fine = [&]() {
+              if (pairs) { const double2 t = *reinterpret_cast<const double2 *>(fw); f0 = t.x; f1 = t.y; }
+              else { f0 = fw[0]; f1 = fw[1]; }
+            };
+            // prescale == 0 (interpolation_fcycle): 0 * old + y == y for every finite old value unless y is a zero, whose sign then
+            // follows old's -- the old value is fetched only for results that are zeros
+            if (prescale != 0.0) load_fine();
+            double v0 = prescale * f0 + a0, v1 = prescale * f1 + a1;
+            if (prescale == 0.0 && (v0 == 0.0 || v1 == 0.0)) { load_fine(); v0 = prescale * f0 + a0; v1 = prescale * f1 + a1; }
+            if (pairs) *reinterpret_cast<double2 *>(fw) = make_double2(v0, v1);
+            else { fw[0] = v0; fw[1] = v1; }
+          }
         }
       }
     }

@@ -36,4 +36,26 @@ __device__ __forceinline__ double *vec_origin(const hpgmg_hip_level &L, int box,
   return L.box_base[box] + (size_t)id * (size_t)L.volume + (size_t)L.ghosts * (size_t)(1 + L.jStride + L.kStride);
 }
 
+
+// Ghost-free reading on levels whose boxes are all local (L.box_nbr codes >= 0 or -1): a cell up to `ghosts` cells outside box
+// `box` is read where it LIVES -- in the interior of the neighbouring box -- instead of from this box's ghost zone, so no
+// exchange_boundary copy is needed before a stencil launch.  Only directions that leave the DOMAIN stay in a ghost zone: that of the
+// box reached through the in-domain directions, which apply_BCs fills from that box's interior with the same formula and inputs as the
+// reference fills this box's copy of the cell.
+struct GfColumn { int box, off; };   // a column (all k) of a box: off = i + j * jStride relative to its first interior cell
+__device__ __forceinline__ GfColumn gf_column(const hpgmg_hip_level &L, int box, int gi, int gj) {
+  if (gi < 0)           { const int n = L.box_nbr[6 * box + 0]; if (n >= 0) { box = n; gi += L.dim; } }
+  else if (gi >= L.dim) { const int n = L.box_nbr[6 * box + 1]; if (n >= 0) { box = n; gi -= L.dim; } }
+  if (gj < 0)           { const int n = L.box_nbr[6 * box + 2]; if (n >= 0) { box = n; gj += L.dim; } }
+  else if (gj >= L.dim) { const int n = L.box_nbr[6 * box + 3]; if (n >= 0) { box = n; gj -= L.dim; } }
+  return GfColumn{box, gi + gj * L.jStride};
+}
+// plane p (p < 0 or p >= dim) of that column
+__device__ __forceinline__ double gf_load_outside(const hpgmg_hip_level &L, int id, GfColumn c, int p) {
+  int box = c.box;
+  if (p < 0) { const int n = L.box_nbr[6 * box + 4]; if (n >= 0) { box = n; p += L.dim; } }
+  else       { const int n = L.box_nbr[6 * box + 5]; if (n >= 0) { box = n; p -= L.dim; } }
+  return vec_origin(L, box, id)[c.off + p * L.kStride];
+}
+
 }  // namespace hpgmg

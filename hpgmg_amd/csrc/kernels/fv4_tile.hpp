@@ -15,7 +15,8 @@
 // every group summed left to right, a mixed term = (beta+ - beta-) * (((x1 - x2) - x3) + x4)), so results are bit-identical
 // to the direct kernel and to the reference (tests/test_gpu_operators.py, tests/test_gpu_fcycle_parity.py).
 // Ghost cells (depth 2) and the extrapolated coefficient ghosts are read exactly where the reference reads them; the caller has
-// run exchange_boundary + apply_BCs_v4 (NO_CORNERS) before, as smooth()/residual() of operators.fv4.c do.
+// run exchange_boundary + apply_BCs_v4 (NO_CORNERS) before, as smooth()/residual() of operators.fv4.c do -- or, with P.ghost_free
+// (all boxes local), only apply_BCs_v4: x outside the box is then read from the neighbouring box itself (common.hpp gf_column).
 #pragma once
 #include "common.hpp"
 
@@ -28,7 +29,7 @@ namespace hpgmg {
 struct Fv4TileArgs {
   int xn_id, xout_id, rhs_id;
   double a, b, h2inv, c1, c2;
-  int sweep, copy_other_colour;
+  int sweep, copy_other_colour, ghost_free;
   int tiles_i, tiles_j, chunks_k, kchunk, per_xcd, total_blocks;
 };
 enum { FV4_CHEBY = 0, FV4_GSRB = 1, FV4_JACOBI = 2, FV4_RESIDUAL = 3, FV4_APPLY = 4 };
@@ -69,6 +70,7 @@ __global__ __launch_bounds__(64 * TJ) void fv4_tile_kernel(const hpgmg_hip_level
   // this lane's own cell and (at most one) halo cell: offsets inside a plane of the box and inside a plane tile
   const int own_g = i + j * jS, own_s = (lj + 2) * W + (li + 2);
   int halo_g = 0, halo_s = 0;
+  GfColumn hcol = {box, 0};
   const bool has_halo = tid < NH;
   if (has_halo) {
     int hi, hj;
@@ -77,25 +79,48 @@ __global__ __launch_bounds__(64 * TJ) void fv4_tile_kernel(const hpgmg_hip_level
     else                  { const int h = tid - 4 * W, c = h % 4; hj = h / 4; hi = (c < 2) ? c - 2 : TI + (c - 2); }
     halo_g = (i0 + hi) + (j0 + hj) * jS;
     halo_s = (hj + 2) * W + (hi + 2);
+    if (P.ghost_free) hcol = gf_column(L, box, i0 + hi, j0 + hj);
   }
+  // x of the own column / the halo column on plane p (any p the stencil reaches): inside the box's k range a plain load
+  const double *__restrict__ xh = (has_halo && P.ghost_free) ? vec_origin(L, hcol.box, P.xn_id) + hcol.off : x + halo_g;
+  const bool gf = P.ghost_free != 0;
+  const int dim = L.dim;
+  // planes below the box (p < 0) are only met in the prologue of the first chunk: looked up there.  Planes above it (p >= dim) are met
+  // in the last steps of the last chunk: one alternative base pointer per column, selected by p, keeps the marching loop free of branches
+  const double *__restrict__ xo_hi = x + own_g, *__restrict__ xh_hi = xh;
+  if (gf && k1 == dim) {
+    const int n = L.box_nbr[6 * box + 5];
+    if (n >= 0) xo_hi = vec_origin(L, n, P.xn_id) + own_g - (long long)dim * kS;
+    if (has_halo) { const int m = L.box_nbr[6 * hcol.box + 5]; if (m >= 0) xh_hi = vec_origin(L, m, P.xn_id) + hcol.off - (long long)dim * kS; }
+  }
+  auto x_own = [&](int p) -> double {
+    if (gf && p < 0) return gf_load_outside(L, P.xn_id, GfColumn{box, own_g}, p);
+    return ((p >= dim) ? xo_hi : x + own_g)[p * kS];
+  };
+  auto x_halo = [&](int p) -> double {
+    if (gf && p < 0) return gf_load_outside(L, P.xn_id, hcol, p);
+    return ((p >= dim) ? xh_hi : xh)[p * kS];
+  };
+  auto x_own_fwd = [&](int p) -> double { return ((p >= dim) ? xo_hi : x + own_g)[p * kS]; };     // p >= 0: the marching loop
+  auto x_halo_fwd = [&](int p) -> double { return ((p >= dim) ? xh_hi : xh)[p * kS]; };
   auto slot3 = [](int p) { return ((p % 3) + 3) % 3; };
 
   // ---- prologue: planes k0-1 and k0 of x / beta_i / beta_j and face k0 of beta_k into LDS; x[k0-2 .. k0+2] of the own column into registers
-  double xm2 = x[own_g + (k0 - 2) * kS], xm1 = x[own_g + (k0 - 1) * kS], xc = x[own_g + k0 * kS];
-  double xp1 = x[own_g + (k0 + 1) * kS], xp2 = x[own_g + (k0 + 2) * kS], xp3 = 0.0;
+  double xm2 = x_own(k0 - 2), xm1 = x_own(k0 - 1), xc = x[own_g + k0 * kS];
+  double xp1 = x_own(k0 + 1), xp2 = x_own(k0 + 2), xp3 = 0.0;
   for (int p = k0 - 1; p <= k0; p++) {
     const int s = slot3(p) * PLANE, pg = p * kS;
     sX[s + own_s] = (p == k0) ? xc : xm1;
     sBI[s + own_s] = gbi[own_g + pg];
     sBJ[s + own_s] = gbj[own_g + pg];
-    if (has_halo) { sX[s + halo_s] = x[halo_g + pg]; sBI[s + halo_s] = gbi[halo_g + pg]; sBJ[s + halo_s] = gbj[halo_g + pg]; }
+    if (has_halo) { sX[s + halo_s] = x_halo(p); sBI[s + halo_s] = gbi[halo_g + pg]; sBJ[s + halo_s] = gbj[halo_g + pg]; }
   }
   sBK[(k0 & 1) * PLANE + own_s] = gbk[own_g + k0 * kS];
   if (has_halo) sBK[(k0 & 1) * PLANE + halo_s] = gbk[halo_g + k0 * kS];
   // values in flight: plane k+1 (stored to LDS at the start of step k) and the per-cell streams of plane k
   double n_bi = gbi[own_g + (k0 + 1) * kS], n_bj = gbj[own_g + (k0 + 1) * kS], n_bk = gbk[own_g + (k0 + 1) * kS];
   double h_x = 0, h_bi = 0, h_bj = 0, h_bk = 0;
-  if (has_halo) { const int pg = (k0 + 1) * kS; h_x = x[halo_g + pg]; h_bi = gbi[halo_g + pg]; h_bj = gbj[halo_g + pg]; h_bk = gbk[halo_g + pg]; }
+  if (has_halo) { const int pg = (k0 + 1) * kS; h_x = x_halo(k0 + 1); h_bi = gbi[halo_g + pg]; h_bj = gbj[halo_g + pg]; h_bk = gbk[halo_g + pg]; }
   double c_rhs = (MODE == FV4_APPLY) ? 0.0 : rhs[own_g + k0 * kS], c_dinv = kSmooth ? dinv[own_g + k0 * kS] : 0.0;
   double c_al = kHelm ? alpha[own_g + k0 * kS] : 0.0, c_old = (MODE == FV4_CHEBY) ? out[own_g + k0 * kS] : 0.0;
 
@@ -112,8 +137,8 @@ __global__ __launch_bounds__(64 * TJ) void fv4_tile_kernel(const hpgmg_hip_level
     if (k + 1 < k1) {
       const int ng = (k + 2) * kS;
       n_bi = gbi[own_g + ng]; n_bj = gbj[own_g + ng]; n_bk = gbk[own_g + ng];
-      if (has_halo) { h_x = x[halo_g + ng]; h_bi = gbi[halo_g + ng]; h_bj = gbj[halo_g + ng]; h_bk = gbk[halo_g + ng]; }
-      xp3 = x[own_g + (k + 3) * kS];
+      if (has_halo) { h_x = x_halo_fwd(k + 2); h_bi = gbi[halo_g + ng]; h_bj = gbj[halo_g + ng]; h_bk = gbk[halo_g + ng]; }
+      xp3 = x_own_fwd(k + 3);
       const int cg = own_g + (k + 1) * kS;
       if (MODE != FV4_APPLY) nn_rhs = rhs[cg];
       if (kSmooth) nn_dinv = dinv[cg];

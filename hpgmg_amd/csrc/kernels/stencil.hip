@@ -703,6 +703,7 @@ static void profile_end(int p, long long cells) {
 }
 
 static int g_ghost_free = 0;
+static int g_tile_ghost_free = 0;   // the LDS-tiled fv4 / 27-point kernels read x outside a box from the neighbouring box (all boxes local)
 static int g_defer_mode = 0;   // 0: whole boxes; 1: skip the cells next to remote faces; 2: only those cells (stencil7_shell_kernel)
 
 static int env_int(const char *name, int dflt) { const char *e = getenv(name); return (e && *e) ? atoi(e) : dflt; }
@@ -740,6 +741,7 @@ static int launch27(const hpgmg_hip_level *L, StencilArgs P, bool is_smoother) {
     constexpr int TJ = 8, TM = (MODE == MODE_BLACKBOX) ? MODE_APPLY : MODE;
     S27TileArgs A = {};
     A.xn_id = P.xn_id; A.xout_id = P.xout_id; A.rhs_id = P.rhs_id; A.mode = TM; A.a = P.a; A.b = P.b; A.h2inv = P.h2inv; A.c1 = P.c1; A.c2 = P.c2; A.sweep = P.sweep;
+    A.ghost_free = (g_tile_ghost_free && L->box_nbr) ? 1 : 0;
     A.tiles_i = L->dim / 64; A.tiles_j = L->dim / TJ;
     int kchunk = L->dim;
     while (kchunk > 32 && (long long)L->num_boxes * A.tiles_i * A.tiles_j * (L->dim / kchunk) < 8192) kchunk /= 2;   // measured at 512^3: 32-plane chunks 929 us, whole boxes 952
@@ -770,7 +772,7 @@ template <int MODE, int TJ>
 static int launch_fv4_tile_tj(const hpgmg_hip_level *L, int variant, const StencilArgs &S, bool is_smoother) {
   Fv4TileArgs P = {};
   P.xn_id = S.xn_id; P.xout_id = S.xout_id; P.rhs_id = S.rhs_id; P.a = S.a; P.b = S.b; P.h2inv = S.h2inv; P.c1 = S.c1; P.c2 = S.c2;
-  P.sweep = S.sweep; P.copy_other_colour = S.copy_other_colour;
+  P.sweep = S.sweep; P.copy_other_colour = S.copy_other_colour; P.ghost_free = (g_tile_ghost_free && L->box_nbr) ? 1 : 0;
   P.tiles_i = L->dim / 64; P.tiles_j = L->dim / TJ;
   int kchunk = L->dim;                                   // enough workgroups to fill the chip, as few chunk prologues as possible
   const int want = (TJ >= 16) ? 512 : 1024;
@@ -971,6 +973,15 @@ extern "C" {
 
 void hpgmg_hip_set_ghost_free(int on) { g_ghost_free = on; }
 void hpgmg_hip_set_defer_mode(int mode) { g_defer_mode = mode; }
+void hpgmg_hip_set_tile_ghost_free(int on) { g_tile_ghost_free = on; }
+// would smooth / residual / apply_op of this variant run the LDS-tiled kernel on this level (out of place)?
+int hpgmg_hip_tile_kernel_applies(const hpgmg_hip_level *L, int variant, int out_of_place) {
+  static const int no_fv4 = env_int("HPGMG_TUNE_FV4_DIRECT", 0), no_27 = env_int("HPGMG_TUNE_27PT_DIRECT", 0);
+  if (L->num_boxes <= 0 || !out_of_place || L->dim % 64 != 0) return 0;
+  if (variant == HPGMG_HIP_27PT_CC) return !no_27;
+  if (variant == HPGMG_HIP_FV4_VC_HELMHOLTZ || variant == HPGMG_HIP_FV4_VC_POISSON) return !no_fv4 && L->ghosts >= 2;
+  return 0;
+}
 int hpgmg_hip_get_ghost_free(void) { return g_ghost_free; }
 
 void hpgmg_hip_profile_smoother(int enable) {

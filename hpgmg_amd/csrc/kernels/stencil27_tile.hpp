@@ -8,6 +8,8 @@
 // cell, so x enters LDS once per workgroup, and the update reads its 26 neighbours from LDS (a wave reads 64 consecutive doubles:
 // conflict free).  The weighted sums are formed exactly as apply_op_27pt forms them -- ((C3*corners + C2*edges) + C1*faces) + C0*centre,
 // each group summed left to right in the listed order -- so results are bit-identical to the register kernel and to the reference.
+// P.ghost_free (all boxes local): x outside the box is read from the neighbouring box itself (common.hpp gf_column), the caller then
+// runs only apply_BCs_p2 before the launch, no exchange_boundary.
 #pragma once
 #include "common.hpp"
 
@@ -23,7 +25,7 @@ namespace hpgmg {
 struct S27TileArgs {
   int xn_id, xout_id, rhs_id, mode;     // mode: MODE_* of stencil.hip (Chebyshev, GSRB, Jacobi, residual, apply_op)
   double a, b, h2inv, c1, c2;
-  int sweep;
+  int sweep, ghost_free;
   int tiles_i, tiles_j, chunks_k, kchunk, per_xcd, total_blocks;
 };
 
@@ -56,6 +58,7 @@ __global__ __launch_bounds__(64 * TJ) void stencil27_tile_kernel(const hpgmg_hip
 
   const int own_g = i + j * jS, own_s = (lj + 1) * W + (li + 1);
   int halo_g = 0, halo_s = 0;
+  GfColumn hcol = {box, 0};
   const bool has_halo = tid < NH;
   if (has_halo) {
     int hi, hj;
@@ -64,16 +67,38 @@ __global__ __launch_bounds__(64 * TJ) void stencil27_tile_kernel(const hpgmg_hip
     else                  { const int h = tid - 2 * W; hj = h >> 1; hi = (h & 1) ? TI : -1; }
     halo_g = (i0 + hi) + (j0 + hj) * jS;
     halo_s = (hj + 1) * W + (hi + 1);
+    if (P.ghost_free) hcol = gf_column(L, box, i0 + hi, j0 + hj);
   }
+  const double *__restrict__ xh = (has_halo && P.ghost_free) ? vec_origin(L, hcol.box, P.xn_id) + hcol.off : x + halo_g;
+  const bool gf = P.ghost_free != 0;
+  const int dim = L.dim;
+  // planes below the box (p < 0) are only met in the prologue of the first chunk: looked up there.  Planes above it (p >= dim) are met
+  // in the last steps of the last chunk: one alternative base pointer per column, selected by p, keeps the marching loop free of branches
+  const double *__restrict__ xo_hi = x + own_g, *__restrict__ xh_hi = xh;
+  if (gf && k1 == dim) {
+    const int n = L.box_nbr[6 * box + 5];
+    if (n >= 0) xo_hi = vec_origin(L, n, P.xn_id) + own_g - (long long)dim * kS;
+    if (has_halo) { const int m = L.box_nbr[6 * hcol.box + 5]; if (m >= 0) xh_hi = vec_origin(L, m, P.xn_id) + hcol.off - (long long)dim * kS; }
+  }
+  auto x_own = [&](int p) -> double {
+    if (gf && p < 0) return gf_load_outside(L, P.xn_id, GfColumn{box, own_g}, p);
+    return ((p >= dim) ? xo_hi : x + own_g)[p * kS];
+  };
+  auto x_halo = [&](int p) -> double {
+    if (gf && p < 0) return gf_load_outside(L, P.xn_id, hcol, p);
+    return ((p >= dim) ? xh_hi : xh)[p * kS];
+  };
+  auto x_own_fwd = [&](int p) -> double { return ((p >= dim) ? xo_hi : x + own_g)[p * kS]; };     // p >= 0: the marching loop
+  auto x_halo_fwd = [&](int p) -> double { return ((p >= dim) ? xh_hi : xh)[p * kS]; };
   auto slot3 = [](int p) { return ((p % 3) + 3) % 3; };
 
   // prologue: planes k0-1 and k0 into LDS; the plane k0+1 values and the per-cell streams of plane k0 in flight
   for (int p = k0 - 1; p <= k0; p++) {
-    const int s = slot3(p) * PLANE, pg = p * kS;
-    sX[s + own_s] = x[own_g + pg];
-    if (has_halo) sX[s + halo_s] = x[halo_g + pg];
+    const int s = slot3(p) * PLANE;
+    sX[s + own_s] = x_own(p);
+    if (has_halo) sX[s + halo_s] = x_halo(p);
   }
-  double n_x = x[own_g + (k0 + 1) * kS], h_x = has_halo ? x[halo_g + (k0 + 1) * kS] : 0.0;
+  double n_x = x_own(k0 + 1), h_x = has_halo ? x_halo(k0 + 1) : 0.0;
   double c_rhs = (MODE == 4) ? 0.0 : rhs[own_g + k0 * kS], c_dinv = kSmooth ? dinv[own_g + k0 * kS] : 0.0;
   double c_old = (MODE == 0) ? out[own_g + k0 * kS] : 0.0;
 
@@ -83,9 +108,9 @@ __global__ __launch_bounds__(64 * TJ) void stencil27_tile_kernel(const hpgmg_hip
     { const int s = slot3(k + 1) * PLANE; sX[s + own_s] = n_x; if (has_halo) sX[s + halo_s] = h_x; }
     double nn_rhs = 0, nn_dinv = 0, nn_old = 0;
     if (k + 1 < k1) {                                           // loads of the next step
-      const int ng = (k + 2) * kS, cg = own_g + (k + 1) * kS;
-      n_x = x[own_g + ng];
-      if (has_halo) h_x = x[halo_g + ng];
+      const int cg = own_g + (k + 1) * kS;
+      n_x = x_own_fwd(k + 2);
+      if (has_halo) h_x = x_halo_fwd(k + 2);
       if (MODE != 4) nn_rhs = rhs[cg];
       if (kSmooth) nn_dinv = dinv[cg];
       if (MODE == 0) nn_old = out[cg];

@@ -61,6 +61,7 @@ enum { HPGMG_INFO_DIM = 0, HPGMG_INFO_BOX_DIM, HPGMG_INFO_GHOSTS, HPGMG_INFO_JST
 void   hpgmg_level_info(const level_type *level, int out[HPGMG_INFO_COUNT]);
 double hpgmg_level_h(const level_type *level);
 double hpgmg_level_eigenvalue(const level_type *level);
+void   hpgmg_level_set_eigenvalue(level_type *level, double dominant_eigenvalue_of_DinvA);   /* what rebuild_operator would have left (tests of a Chebyshev smoother on given coefficients) */
 void   hpgmg_level_box_low(const level_type *level, int box, int out[3]);
 int    hpgmg_level_list_counts(const level_type *level, int which, int shape_or_type, int out[3]);
 /* whole padded box volume of one vector <-> host array of box_volume doubles */

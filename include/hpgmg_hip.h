@@ -128,6 +128,11 @@ int hpgmg_hip_small_level_op(const hpgmg_hip_level *L, int variant, int mode, in
  * launches leave the cells next to a face owned by another rank (box_nbr == -2) untouched, mode 2 = the next launches
  * compute exactly those cells (one lane per cell), mode 0 = whole boxes. */
 void hpgmg_hip_set_defer_mode(int mode);
+/* The LDS-tiled 27-point and fv4 kernels (boxes whose side is a multiple of 64, out of place) can read x outside a box from the
+ * neighbouring box itself when every box of the level is local: the caller then runs only apply_BCs before the launch, not
+ * exchange_boundary.  applies() tells whether the next smooth / residual / apply_op launch of `variant` would be such a kernel. */
+void hpgmg_hip_set_tile_ghost_free(int on);
+int  hpgmg_hip_tile_kernel_applies(const hpgmg_hip_level *L, int variant, int out_of_place);
 
 /* ---- fused forms of smooth() for bandwidth-bound levels (kernels/cheby_pair.hpp) ---- */
 /* Two consecutive Chebyshev sweeps (chebyshev.c:43-99 twice) in one pass: x1 = S(x0, xm1; c1a, c2a),

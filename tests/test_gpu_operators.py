@@ -319,6 +319,31 @@ def test_higher_order_boundary_conditions(hip, oracle, variant, geom, bc, shape)
         lh.destroy(); lo.destroy()
 
 
+@pytest.mark.parametrize("ghost_free", [1, 0])
+@pytest.mark.parametrize("variant,geom", [("fv4-gsrb", (2, 64)), ("27pt-gsrb", (2, 64)), ("fv4-cheby", (1, 64)), ("27pt-cheby", (3, 64))])
+def test_lds_tiled_kernels_of_the_27pt_and_fv4_plugins(hip, oracle, variant, geom, ghost_free):
+    """Boxes of 64^3 and more run the LDS-tiled kernels (fv4_tile.hpp, stencil27_tile.hpp): smooth, residual and apply_op against the
+    oracle, bit for bit.  ghost_free=1 (default): x outside a box is read from the neighbouring box, only apply_BCs runs before a
+    launch, so the operand's ghost zones are scratch and interiors are compared; ghost_free=0: exchange + BCs as the reference does."""
+    set_mode(hip, ghost_free)
+    lh, lo = make_pair(hip, oracle, variant, *geom, seed=11)
+    try:
+        for lv in (lh, lo):
+            declare_extra(lv.b)
+            for vid in (H.VECTOR_BETA_I, H.VECTOR_BETA_J, H.VECTOR_BETA_K, H.VECTOR_ALPHA, H.VECTOR_DINV):
+                if vid < lv.num_vectors:          # the constant-coefficient 27-point plugin reserves no alpha
+                    lv.b.lib.exchange_boundary(lv.ptr, vid, H.STENCIL_SHAPE_BOX)
+        for lv in (lh, lo):
+            lv.b.lib.hpgmg_level_set_eigenvalue(lv.ptr, 1.7)
+            lv.b.lib.smooth(lv.ptr, H.VECTOR_U, H.VECTOR_F, 0.0, 1.0)
+            lv.b.lib.residual(lv.ptr, H.VECTOR_R, H.VECTOR_U, H.VECTOR_F, 0.0, 1.0)
+            lv.b.lib.apply_op(lv.ptr, H.VECTOR_E, H.VECTOR_U, 0.0, 1.0)
+        same(lh, lo, [H.VECTOR_U, H.VECTOR_TEMP, H.VECTOR_R, H.VECTOR_E], interior_only=True)
+    finally:
+        set_mode(hip, 1)
+        lh.destroy(); lo.destroy()
+
+
 @pytest.mark.parametrize("variant,geom", [("27pt-cheby", (2, 8)), ("27pt-gsrb", (1, 4)), ("fv4-gsrb", (2, 8)), ("fv4-gsrb", (2, 16)), ("fv4-cheby", (1, 8)),
                                            ("fv2-cheby", (2, 8)), ("fv4-gsrb", (1, 2)), ("27pt-cheby", (1, 2)), ("fv4-gsrb", (2, 32))])
 def test_other_plugins_operator_by_operator(hip, oracle, variant, geom):
