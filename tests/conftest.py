@@ -21,7 +21,8 @@ def _usable_cpus():
 # Before ANY OpenMP runtime is loaded (numpy, torch, the oracle, the host layer): a team sized to the quota and no
 # spin-waiting.  Round 1's driver run died at its 1200 s limit with 256 spinning libgomp threads on a 16-CPU quota.
 os.environ.setdefault("OMP_NUM_THREADS", str(min(_usable_cpus(), 16)))
-os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+if _usable_cpus() < (os.cpu_count() or 1):          # a quota below the visible cores (the GPU box): spinning threads starve each other
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")
 os.environ.setdefault("OMP_PROC_BIND", "false")
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 

@@ -25,8 +25,17 @@ def ref_build():
     return REF
 
 
-def pinned_lines(binary, args, threads="4"):
+def cli_env(threads="4"):
+    """Environment of a reference / oracle CLI run: a few threads that SPIN between the thousands of tiny parallel regions of the coarse
+    levels (the suite-wide OMP_WAIT_POLICY=passive of conftest.py, meant for the in-process oracle next to a GPU, makes the reference
+    binary ten to fifty times slower)."""
     env = dict(os.environ, OMP_NUM_THREADS=threads)
+    env.pop("OMP_WAIT_POLICY", None)
+    return env
+
+
+def pinned_lines(binary, args, threads="4"):
+    env = cli_env(threads)
     out = subprocess.run([binary] + args.split(), capture_output=True, text=True, env=env, check=True).stdout
     keep = []
     for line in out.splitlines():
@@ -75,7 +84,7 @@ def test_cli_stdout_has_the_reference_layout(ref_build, variant, flags, args):
     """our driver prints the reference's report line for line -- level creation, operator rebuild,
     the 10+10 f-cycle lines per size, the timing table, DOF/s, Richardson error -- so HPGMG log parsers work unchanged.
     Only timing figures (masked here) and the thread/backend banner differ; every pinned number is identical."""
-    env = dict(os.environ, OMP_NUM_THREADS="4")
+    env = cli_env()
     ref = subprocess.run([os.path.join(ref_build, "hpgmg-" + variant)] + args.split(), capture_output=True, text=True, env=env, check=True).stdout
     ours = subprocess.run([os.path.join(ROOT, "oracle", "hpgmg-fv-oracle")] + flags + args.split(), capture_output=True, text=True, env=env, check=True).stdout
     a, b = _masked(ref), _masked(ours)
