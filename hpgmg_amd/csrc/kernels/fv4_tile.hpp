@@ -3,7 +3,7 @@
 // The 25-point variable-coefficient stencil reads, per updated cell, 25 values of x and 30 face coefficients.  Read through
 // the vector L1 (stencil_direct_kernel, the first version) that is ~58 eight-byte loads per update and the kernel is bound by
 // the L1 / texture-address path at ~9 TB/s of cache traffic (3.3 ms per half sweep at 512^3 = 28 % of the HBM roofline).
-// Here a workgroup owns a 64 (i) x TJ (j) tile of one box and marches in +k:
+// Here a workgroup owns a TI (i; 64, or 32 for boxes of 32^3) x TJ (j) tile of one box and marches in +k:
 //   * planes k-1, k, k+1 of x, beta_i, beta_j and faces k, k+1 of beta_k live in LDS with a 2-cell halo (ring buffers;
 //     11 tiles of (TJ+4) x 68 doubles = 72 KB for TJ = 8, two workgroups per CU);
 //   * every value enters LDS ONCE per workgroup: a lane brings its own column (the x value from a register it loaded three
@@ -34,9 +34,9 @@ struct Fv4TileArgs {
 };
 enum { FV4_CHEBY = 0, FV4_GSRB = 1, FV4_JACOBI = 2, FV4_RESIDUAL = 3, FV4_APPLY = 4 };
 
-template <int V, int MODE, int TJ>
-__global__ __launch_bounds__(64 * TJ) void fv4_tile_kernel(const hpgmg_hip_level L, const Fv4TileArgs P) {
-  constexpr int TI = 64, W = TI + 4, H = TJ + 4, NT = 64 * TJ, PLANE = W * H;
+template <int V, int MODE, int TJ, int TI = 64>
+__global__ __launch_bounds__(TI * TJ) void fv4_tile_kernel(const hpgmg_hip_level L, const Fv4TileArgs P) {
+  constexpr int W = TI + 4, H = TJ + 4, NT = TI * TJ, PLANE = W * H;
   constexpr int NH = 4 * W + 4 * TJ;                           // halo cells of one plane tile (two rows above and below, two columns left and right)
   static_assert(NH <= NT, "one halo cell per lane at most");
   constexpr bool kHelm = (V == HPGMG_HIP_FV4_VC_HELMHOLTZ);
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(64 * TJ) void fv4_tile_kernel(const hpgmg_hip_level
   const int tj = t % P.tiles_j; t /= P.tiles_j;
   const int ck = t % P.chunks_k; t /= P.chunks_k;
   const int box = t;
-  const int li = (int)threadIdx.x, lj = (int)threadIdx.y, tid = lj * 64 + li;
+  const int li = (int)threadIdx.x, lj = (int)threadIdx.y, tid = lj * TI + li;
   const int i0 = ti * TI, j0 = tj * TJ, i = i0 + li, j = j0 + lj;
   const int k0 = ck * P.kchunk, k1 = (k0 + P.kchunk < L.dim) ? k0 + P.kchunk : L.dim;
   const int jS = L.jStride, kS = L.kStride;

@@ -767,27 +767,28 @@ static int launch27(const hpgmg_hip_level *L, StencilArgs P, bool is_smoother) {
   return 0;
 }
 
-// the LDS-tiled 4th-order kernel (fv4_tile.hpp): boxes whose side is a multiple of 64, out of place
-template <int MODE, int TJ>
+static int fv4_tile_granule() { static const int g = env_int("HPGMG_TUNE_FV4_TILE32", 1) ? 32 : 64; return g; }   // smallest box side the tiled fv4 kernel takes
+// the LDS-tiled 4th-order kernel (fv4_tile.hpp): boxes whose side is a multiple of 32, out of place
+template <int MODE, int TJ, int TI>
 static int launch_fv4_tile_tj(const hpgmg_hip_level *L, int variant, const StencilArgs &S, bool is_smoother) {
   Fv4TileArgs P = {};
   P.xn_id = S.xn_id; P.xout_id = S.xout_id; P.rhs_id = S.rhs_id; P.a = S.a; P.b = S.b; P.h2inv = S.h2inv; P.c1 = S.c1; P.c2 = S.c2;
   P.sweep = S.sweep; P.copy_other_colour = S.copy_other_colour; P.ghost_free = (g_tile_ghost_free && L->box_nbr) ? 1 : 0;
-  P.tiles_i = L->dim / 64; P.tiles_j = L->dim / TJ;
+  P.tiles_i = L->dim / TI; P.tiles_j = L->dim / TJ;
   int kchunk = L->dim;                                   // enough workgroups to fill the chip, as few chunk prologues as possible
-  const int want = (TJ >= 16) ? 512 : 1024;
+  const int want = (TJ * TI >= 1024) ? 512 : 1024;
   while (kchunk > 16 && (long long)L->num_boxes * P.tiles_i * P.tiles_j * (L->dim / kchunk) < want) kchunk /= 2;
   static const int tune_kc = env_int("HPGMG_TUNE_FV4_KCHUNK", 0);
   if (tune_kc > 0 && L->dim % tune_kc == 0) kchunk = tune_kc;
   P.kchunk = kchunk; P.chunks_k = (L->dim + kchunk - 1) / kchunk;
   P.total_blocks = L->num_boxes * P.chunks_k * P.tiles_j * P.tiles_i;
   const int grid = grid_for(P.total_blocks, &P.per_xcd);
-  const size_t lds = (size_t)11 * (64 + 4) * (TJ + 4) * sizeof(double);
+  const size_t lds = (size_t)11 * (TI + 4) * (TJ + 4) * sizeof(double);
   const long long cells = (long long)L->num_boxes * L->dim * L->dim * L->dim;
   const int prof = is_smoother ? profile_begin(cells) : -1;
 #define FV4_TILE_CASE(VAR) { \
-    static bool once = false; if (!once) { HPGMG_CHECK(hipFuncSetAttribute((const void *)fv4_tile_kernel<VAR, MODE, TJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once = true; } \
-    hipLaunchKernelGGL((fv4_tile_kernel<VAR, MODE, TJ>), dim3(grid), dim3(64, TJ), lds, g_stream, *L, P); }
+    static bool once = false; if (!once) { HPGMG_CHECK(hipFuncSetAttribute((const void *)fv4_tile_kernel<VAR, MODE, TJ, TI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once = true; } \
+    hipLaunchKernelGGL((fv4_tile_kernel<VAR, MODE, TJ, TI>), dim3(grid), dim3(TI, TJ), lds, g_stream, *L, P); }
   if (variant == HPGMG_HIP_FV4_VC_HELMHOLTZ) FV4_TILE_CASE(HPGMG_HIP_FV4_VC_HELMHOLTZ)
   else FV4_TILE_CASE(HPGMG_HIP_FV4_VC_POISSON)
 #undef FV4_TILE_CASE
@@ -795,14 +796,15 @@ static int launch_fv4_tile_tj(const hpgmg_hip_level *L, int variant, const Stenc
   HPGMG_LAUNCH_CHECK("fv4_tile_kernel");
   return 0;
 }
-// the LDS-tiled 4th-order kernel (fv4_tile.hpp): boxes whose side is a multiple of 64, out of place.  Tile height 8 (two workgroups
-// per CU; 1.59 values loaded per cell and array) measured 1.85 ms per half sweep at 512^3, height 16 (one workgroup of 16 waves and
-// 120 KB of LDS per CU; 1.33 values) 1.92 ms: the second resident workgroup hides more latency than the smaller halo saves
+// Tile height 8 (two workgroups per CU; 1.59 values loaded per cell and array) measured 1.85 ms per half sweep at 512^3, height 16 (one
+// workgroup of 16 waves and 120 KB of LDS per CU; 1.33 values) 1.92 ms: the second resident workgroup hides more latency than the smaller
+// halo saves.  Boxes of 32^3 (the 128^3 level of `7 64`): 32 x 16 tiles (a wave = two rows of 32 cells, still conflict free in LDS).
 template <int MODE>
 static int launch_fv4_tile(const hpgmg_hip_level *L, int variant, const StencilArgs &S, bool is_smoother) {
   static const int tj = env_int("HPGMG_TUNE_FV4_TJ", 8);
-  if (tj == 8) return launch_fv4_tile_tj<MODE, 8>(L, variant, S, is_smoother);
-  return launch_fv4_tile_tj<MODE, 16>(L, variant, S, is_smoother);
+  if (L->dim % 64 != 0) return launch_fv4_tile_tj<MODE, 16, 32>(L, variant, S, is_smoother);
+  if (tj == 8) return launch_fv4_tile_tj<MODE, 8, 64>(L, variant, S, is_smoother);
+  return launch_fv4_tile_tj<MODE, 16, 64>(L, variant, S, is_smoother);
 }
 
 template <int MODE>
@@ -811,7 +813,7 @@ static int launch_direct(const hpgmg_hip_level *L, int variant, StencilArgs P, b
   if (L->num_boxes <= 0) return 0;
   if (MODE != MODE_BLACKBOX && (variant == HPGMG_HIP_FV4_VC_HELMHOLTZ || variant == HPGMG_HIP_FV4_VC_POISSON)) {
     static const int no_tile = env_int("HPGMG_TUNE_FV4_DIRECT", 0);
-    if (!no_tile && L->dim % 64 == 0 && L->ghosts >= 2 && P.xn_id != P.xout_id) return launch_fv4_tile<(MODE == MODE_BLACKBOX) ? MODE_APPLY : MODE>(L, variant, P, is_smoother);
+    if (!no_tile && L->dim % fv4_tile_granule() == 0 && L->ghosts >= 2 && P.xn_id != P.xout_id) return launch_fv4_tile<(MODE == MODE_BLACKBOX) ? MODE_APPLY : MODE>(L, variant, P, is_smoother);
   }
   dim3 block; int grid;
   plan(L, P, block, grid);
@@ -977,9 +979,9 @@ void hpgmg_hip_set_tile_ghost_free(int on) { g_tile_ghost_free = on; }
 // would smooth / residual / apply_op of this variant run the LDS-tiled kernel on this level (out of place)?
 int hpgmg_hip_tile_kernel_applies(const hpgmg_hip_level *L, int variant, int out_of_place) {
   static const int no_fv4 = env_int("HPGMG_TUNE_FV4_DIRECT", 0), no_27 = env_int("HPGMG_TUNE_27PT_DIRECT", 0);
-  if (L->num_boxes <= 0 || !out_of_place || L->dim % 64 != 0) return 0;
-  if (variant == HPGMG_HIP_27PT_CC) return !no_27;
-  if (variant == HPGMG_HIP_FV4_VC_HELMHOLTZ || variant == HPGMG_HIP_FV4_VC_POISSON) return !no_fv4 && L->ghosts >= 2;
+  if (L->num_boxes <= 0 || !out_of_place) return 0;
+  if (variant == HPGMG_HIP_27PT_CC) return !no_27 && L->dim % 64 == 0;
+  if (variant == HPGMG_HIP_FV4_VC_HELMHOLTZ || variant == HPGMG_HIP_FV4_VC_POISSON) return !no_fv4 && L->ghosts >= 2 && L->dim % fv4_tile_granule() == 0;
   return 0;
 }
 int hpgmg_hip_get_ghost_free(void) { return g_ghost_free; }

@@ -320,9 +320,9 @@ def test_higher_order_boundary_conditions(hip, oracle, variant, geom, bc, shape)
 
 
 @pytest.mark.parametrize("ghost_free", [1, 0])
-@pytest.mark.parametrize("variant,geom", [("fv4-gsrb", (2, 64)), ("27pt-gsrb", (2, 64)), ("fv4-cheby", (1, 64)), ("27pt-cheby", (3, 64))])
+@pytest.mark.parametrize("variant,geom", [("fv4-gsrb", (2, 64)), ("27pt-gsrb", (2, 64)), ("fv4-cheby", (1, 64)), ("27pt-cheby", (3, 64)), ("fv4-gsrb", (4, 32)), ("fv4-cheby", (1, 32))])
 def test_lds_tiled_kernels_of_the_27pt_and_fv4_plugins(hip, oracle, variant, geom, ghost_free):
-    """Boxes of 64^3 and more run the LDS-tiled kernels (fv4_tile.hpp, stencil27_tile.hpp): smooth, residual and apply_op against the
+    """Boxes of 64^3 and more (fv4: 32^3 and more) run the LDS-tiled kernels (fv4_tile.hpp, stencil27_tile.hpp): smooth, residual and apply_op against the
     oracle, bit for bit.  ghost_free=1 (default): x outside a box is read from the neighbouring box, only apply_BCs runs before a
     launch, so the operand's ghost zones are scratch and interiors are compared; ghost_free=0: exchange + BCs as the reference does."""
     set_mode(hip, ghost_free)
@@ -348,7 +348,9 @@ def test_lds_tiled_kernels_of_the_27pt_and_fv4_plugins(hip, oracle, variant, geo
                                            ("fv2-cheby", (2, 8)), ("fv4-gsrb", (1, 2)), ("27pt-cheby", (1, 2)), ("fv4-gsrb", (2, 32))])
 def test_other_plugins_operator_by_operator(hip, oracle, variant, geom):
     """27pt / fv2 / fv4: black-box rebuild (with extrapolate_betas for fv4), smooth, residual, and the tensor-product
-    interpolations, compared over whole padded boxes."""
+    interpolations, compared over whole padded boxes (so with the reference's exchange + BCs before every stencil launch: the default
+    ghost-free reading of the tiled kernels leaves the operand's ghost zones as scratch, see the test above)."""
+    set_mode(hip, 0)
     pairs = []
     for be in (hip, oracle):
         be.configure(**VARIANTS[variant]); declare_extra(be)
@@ -391,6 +393,7 @@ def test_other_plugins_operator_by_operator(hip, oracle, variant, geom):
             same(ch, co, [H.VECTOR_R, H.VECTOR_DINV])
             same(ch, co, [H.VECTOR_BETA_I, H.VECTOR_BETA_J, H.VECTOR_BETA_K], interior_only=True)
     finally:
+        set_mode(hip, 1)
         for be, f, m in pairs:
             be.lib.hpgmg_mg_destroy(m); f.destroy()
 
