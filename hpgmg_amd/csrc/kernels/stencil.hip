@@ -732,17 +732,23 @@ static void plan(const hpgmg_hip_level *L, StencilArgs &P, dim3 &block, int &gri
   grid = grid_for(P.total_blocks, &P.per_xcd);
 }
 
+// smallest box side the tiled 27-point kernel takes: 64.  The 32 x 16 tiles for boxes of 32^3 work (HPGMG_TUNE_27PT_TILE32=1, covered by the
+// tests) but measured 0.35 ms per `7 64` F-cycle SLOWER than the register kernel on that level (the 128^3 level is cache resident)
+static int g_s27_tile32 = -1;
+static int s27_tile_granule() { if (g_s27_tile32 < 0) g_s27_tile32 = env_int("HPGMG_TUNE_27PT_TILE32", 0) ? 1 : 0; return g_s27_tile32 ? 32 : 64; }
 template <int MODE>
 static int launch27(const hpgmg_hip_level *L, StencilArgs P, bool is_smoother) {
   HPGMG_SKIP_IF_REPLAY();
   if (L->num_boxes <= 0) return 0;
   static const int no_tile27 = env_int("HPGMG_TUNE_27PT_DIRECT", 0);
-  if (MODE != MODE_BLACKBOX && !no_tile27 && L->dim % 64 == 0 && P.xn_id != P.xout_id) {       // LDS-staged kernel (stencil27_tile.hpp)
-    constexpr int TJ = 8, TM = (MODE == MODE_BLACKBOX) ? MODE_APPLY : MODE;
+  if (MODE != MODE_BLACKBOX && !no_tile27 && L->dim % s27_tile_granule() == 0 && P.xn_id != P.xout_id) {       // LDS-staged kernel (stencil27_tile.hpp)
+    constexpr int TM = (MODE == MODE_BLACKBOX) ? MODE_APPLY : MODE;
+    const bool narrow = (L->dim % 64 != 0);               // boxes of 32^3: 32 x 16 tiles
+    const int TI = narrow ? 32 : 64, TJ = narrow ? 16 : 8;
     S27TileArgs A = {};
     A.xn_id = P.xn_id; A.xout_id = P.xout_id; A.rhs_id = P.rhs_id; A.mode = TM; A.a = P.a; A.b = P.b; A.h2inv = P.h2inv; A.c1 = P.c1; A.c2 = P.c2; A.sweep = P.sweep;
     A.ghost_free = (g_tile_ghost_free && L->box_nbr) ? 1 : 0;
-    A.tiles_i = L->dim / 64; A.tiles_j = L->dim / TJ;
+    A.tiles_i = L->dim / TI; A.tiles_j = L->dim / TJ;
     int kchunk = L->dim;
     while (kchunk > 32 && (long long)L->num_boxes * A.tiles_i * A.tiles_j * (L->dim / kchunk) < 8192) kchunk /= 2;   // measured at 512^3: 32-plane chunks 929 us, whole boxes 952
     static const int tune_kc = env_int("HPGMG_TUNE_27PT_KCHUNK", 0);
@@ -752,7 +758,8 @@ static int launch27(const hpgmg_hip_level *L, StencilArgs P, bool is_smoother) {
     const int tgrid = grid_for(A.total_blocks, &A.per_xcd);
     const long long tcells = (long long)L->num_boxes * L->dim * L->dim * L->dim;
     const int tprof = is_smoother ? profile_begin(tcells) : -1;
-    hipLaunchKernelGGL((stencil27_tile_kernel<TM, TJ>), dim3(tgrid), dim3(64, TJ), 0, g_stream, *L, A);
+    if (narrow) hipLaunchKernelGGL((stencil27_tile_kernel<TM, 16, 32>), dim3(tgrid), dim3(32, 16), 0, g_stream, *L, A);
+    else        hipLaunchKernelGGL((stencil27_tile_kernel<TM, 8, 64>), dim3(tgrid), dim3(64, 8), 0, g_stream, *L, A);
     profile_end(tprof, tcells);
     HPGMG_LAUNCH_CHECK("stencil27_tile_kernel");
     return 0;
@@ -976,11 +983,12 @@ extern "C" {
 void hpgmg_hip_set_ghost_free(int on) { g_ghost_free = on; }
 void hpgmg_hip_set_defer_mode(int mode) { g_defer_mode = mode; }
 void hpgmg_hip_set_tile_ghost_free(int on) { g_tile_ghost_free = on; }
+void hpgmg_hip_set_27pt_tile32(int on) { g_s27_tile32 = on ? 1 : 0; }
 // would smooth / residual / apply_op of this variant run the LDS-tiled kernel on this level (out of place)?
 int hpgmg_hip_tile_kernel_applies(const hpgmg_hip_level *L, int variant, int out_of_place) {
   static const int no_fv4 = env_int("HPGMG_TUNE_FV4_DIRECT", 0), no_27 = env_int("HPGMG_TUNE_27PT_DIRECT", 0);
   if (L->num_boxes <= 0 || !out_of_place) return 0;
-  if (variant == HPGMG_HIP_27PT_CC) return !no_27 && L->dim % 64 == 0;
+  if (variant == HPGMG_HIP_27PT_CC) return !no_27 && L->dim % s27_tile_granule() == 0;
   if (variant == HPGMG_HIP_FV4_VC_HELMHOLTZ || variant == HPGMG_HIP_FV4_VC_POISSON) return !no_fv4 && L->ghosts >= 2 && L->dim % fv4_tile_granule() == 0;
   return 0;
 }

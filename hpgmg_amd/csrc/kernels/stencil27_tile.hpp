@@ -1,5 +1,5 @@
 // stencil27_tile.hpp -- the 27-point constant-coefficient operator (reference operators.27pt.c:48-51,60-91) as an LDS-staged,
-// k-marching kernel for boxes whose side is a multiple of 64.
+// k-marching kernel for boxes whose side is a multiple of 64 (TI = 64) or of 32 (TI = 32: a wave is two rows of a 32 x TJ tile).
 //
 // stencil27_kernel (stencil.hip) keeps the three 3 x 3 planes around a cell in registers and re-reads 9 values per step through
 // the vector L1: 72 B of L1 traffic per cell and step, which bounds it (8.8 TB/s of L1 traffic at 1.10 ms per coloured half sweep of
@@ -29,9 +29,9 @@ struct S27TileArgs {
   int tiles_i, tiles_j, chunks_k, kchunk, per_xcd, total_blocks;
 };
 
-template <int MODE, int TJ>
-__global__ __launch_bounds__(64 * TJ) void stencil27_tile_kernel(const hpgmg_hip_level L, const S27TileArgs P) {
-  constexpr int TI = 64, W = TI + 2, H = TJ + 2, NT = 64 * TJ, PLANE = W * H;
+template <int MODE, int TJ, int TI = 64>
+__global__ __launch_bounds__(TI * TJ) void stencil27_tile_kernel(const hpgmg_hip_level L, const S27TileArgs P) {
+  constexpr int W = TI + 2, H = TJ + 2, NT = TI * TJ, PLANE = W * H;
   constexpr int NH = 2 * W + 2 * TJ;                            // halo cells of one plane tile
   static_assert(NH <= NT, "one halo cell per lane at most");
   constexpr bool kSmooth = (MODE == 0 || MODE == 1 || MODE == 2);
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(64 * TJ) void stencil27_tile_kernel(const hpgmg_hip
   const int tj = t % P.tiles_j; t /= P.tiles_j;
   const int ck = t % P.chunks_k; t /= P.chunks_k;
   const int box = t;
-  const int li = (int)threadIdx.x, lj = (int)threadIdx.y, tid = lj * 64 + li;
+  const int li = (int)threadIdx.x, lj = (int)threadIdx.y, tid = lj * TI + li;
   const int i0 = ti * TI, j0 = tj * TJ, i = i0 + li, j = j0 + lj;
   const int k0 = ck * P.kchunk, k1 = (k0 + P.kchunk < L.dim) ? k0 + P.kchunk : L.dim;
   const int jS = L.jStride, kS = L.kStride;

@@ -132,6 +132,7 @@ void hpgmg_hip_set_defer_mode(int mode);
  * neighbouring box itself when every box of the level is local: the caller then runs only apply_BCs before the launch, not
  * exchange_boundary.  applies() tells whether the next smooth / residual / apply_op launch of `variant` would be such a kernel. */
 void hpgmg_hip_set_tile_ghost_free(int on);
+void hpgmg_hip_set_27pt_tile32(int on);   /* tiled 27-point kernel also for boxes of 32^3 (off by default: slower than the register kernel there; HPGMG_TUNE_27PT_TILE32=1) */
 int  hpgmg_hip_tile_kernel_applies(const hpgmg_hip_level *L, int variant, int out_of_place);
 
 /* ---- fused forms of smooth() for bandwidth-bound levels (kernels/cheby_pair.hpp) ---- */

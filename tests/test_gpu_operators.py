@@ -320,12 +320,15 @@ def test_higher_order_boundary_conditions(hip, oracle, variant, geom, bc, shape)
 
 
 @pytest.mark.parametrize("ghost_free", [1, 0])
-@pytest.mark.parametrize("variant,geom", [("fv4-gsrb", (2, 64)), ("27pt-gsrb", (2, 64)), ("fv4-cheby", (1, 64)), ("27pt-cheby", (3, 64)), ("fv4-gsrb", (4, 32)), ("fv4-cheby", (1, 32))])
+@pytest.mark.parametrize("variant,geom", [("fv4-gsrb", (2, 64)), ("27pt-gsrb", (2, 64)), ("fv4-cheby", (1, 64)), ("27pt-cheby", (3, 64)), ("fv4-gsrb", (4, 32)), ("fv4-cheby", (1, 32)), ("27pt-gsrb", (4, 32)), ("27pt-cheby", (2, 32))])
 def test_lds_tiled_kernels_of_the_27pt_and_fv4_plugins(hip, oracle, variant, geom, ghost_free):
-    """Boxes of 64^3 and more (fv4: 32^3 and more) run the LDS-tiled kernels (fv4_tile.hpp, stencil27_tile.hpp): smooth, residual and apply_op against the
+    """Boxes of 64^3 and more (32^3 in narrower tiles) run the LDS-tiled kernels (fv4_tile.hpp, stencil27_tile.hpp): smooth, residual and apply_op against the
     oracle, bit for bit.  ghost_free=1 (default): x outside a box is read from the neighbouring box, only apply_BCs runs before a
     launch, so the operand's ghost zones are scratch and interiors are compared; ghost_free=0: exchange + BCs as the reference does."""
     set_mode(hip, ghost_free)
+    K = H.load_kernels()
+    K.hpgmg_hip_set_27pt_tile32.argtypes = [ctypes.c_int]
+    K.hpgmg_hip_set_27pt_tile32(1)        # the 32-wide tiles of the 27-point kernel are opt-in (slower than the register kernel): test them all the same
     lh, lo = make_pair(hip, oracle, variant, *geom, seed=11)
     try:
         for lv in (lh, lo):
@@ -341,6 +344,7 @@ def test_lds_tiled_kernels_of_the_27pt_and_fv4_plugins(hip, oracle, variant, geo
         same(lh, lo, [H.VECTOR_U, H.VECTOR_TEMP, H.VECTOR_R, H.VECTOR_E], interior_only=True)
     finally:
         set_mode(hip, 1)
+        K.hpgmg_hip_set_27pt_tile32(0)
         lh.destroy(); lo.destroy()
 
 
