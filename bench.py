@@ -80,18 +80,24 @@ def cpu_baseline():
         return {"value": None, "unit": "DOF/s", "cores": cores, "kind": kind, "sample": sample, "error": repr(exc)}
 
 
-def pmc_traffic():
-    """HBM bytes per fine-level Chebyshev launch from the committed rocprofv3 --pmc summary, if any."""
+def pmc_traffic(workload="config2", fine_cells=None):
+    """HBM bytes per fine-level smoother launch from the committed rocprofv3 --pmc summary of this workload, if any (the newest: files sort
+    by round tag).  config 2: the sweep-pair launch with its pre-pass; config 3: the tiled kernel's coloured half sweep at the same size."""
     best = None
     pdir = os.path.join(ROOT, "profiles")
-    if os.path.isdir(pdir):
+    want = {"config2": ("_pmc_summary.json", "hbm_bytes_per_launch_cheby_fine"), "config3-fv4": ("_fv4_pmc_summary.json", "hbm_bytes_per_launch_smoother_fine"),
+            "config3-27pt": ("_27pt_pmc_summary.json", "hbm_bytes_per_launch_smoother_fine")}.get(workload)
+    if want and os.path.isdir(pdir):
         for f in sorted(os.listdir(pdir)):
-            if f.endswith("_pmc_summary.json"):
-                try:
-                    got = json.load(open(os.path.join(pdir, f))).get("hbm_bytes_per_launch_cheby_fine")
-                    best = got if got else best          # the newest summary of the config-2 smoother (files sort by round tag)
-                except Exception:
-                    pass
+            if not f.endswith(want[0]) or (workload == "config2" and ("_fv4_" in f or "_27pt_" in f)):
+                continue
+            try:
+                d = json.load(open(os.path.join(pdir, f)))
+                got = d.get(want[1])
+                if got and (fine_cells is None or workload == "config2" or d.get("cells") == fine_cells):
+                    best = got
+            except Exception:
+                pass
     return best
 
 
@@ -270,7 +276,7 @@ def main():
             # cells.value counts cell-sweeps: the sweep-pair kernel reports two sweeps per launch
             bytes_per_launch = smoother[0] * (cells.value / launches.value)
             achieved = bytes_per_launch / avg_s / 1e9
-            traffic = pmc_traffic() if args.workload == "config2" and world == 1 else None
+            traffic = pmc_traffic(args.workload, int(fine_cells)) if world == 1 else None
             roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "kernel": smoother[1] + f" over the {my_boxes} finest-level boxes of {box_dim}^3 of this rank",

@@ -51,7 +51,9 @@ def main():
         alg = bpc * cells if bpc else fb + wb
         res["kernels"][key] = {"kernel": f[3], "launches_averaged": f[2], "FETCH_SIZE_bytes_raw": f[1] * 1024, "FETCH_bytes_corrected_x2": fb,
                                "WRITE_SIZE_bytes": wb, "hbm_bytes_per_launch": fb + wb, "algorithmic_bytes": alg, "ratio": (fb + wb) / alg}
-    if "scale_fine" in res["kernels"]: res["calibration_scale_vector_ratio"] = res["kernels"]["scale_fine"]["ratio"]
+    if "scale_fine" in res["kernels"]:
+        if 0.5 < res["kernels"]["scale_fine"]["ratio"] < 2.0: res["calibration_scale_vector_ratio"] = res["kernels"]["scale_fine"]["ratio"]
+        else: del res["kernels"]["scale_fine"]      # this workload never runs scale_vector on the fine level: the row would describe a small level
     k = res["kernels"]
     if "cheby_pair_fine" in k:      # the smoother launch bench.py times = edge-column pre-pass + pair kernel (two sweeps)
         res["hbm_bytes_per_launch_cheby_fine"] = k["cheby_pair_fine"]["hbm_bytes_per_launch"] + k.get("cheby_pair_edge_columns", {}).get("hbm_bytes_per_launch", 0.0)
