@@ -130,6 +130,7 @@ typedef struct {
   struct { const blockCopy_type *host; int n; blockCopy_type *dev; } lists[MAX_LISTS];
   int num_lists;
   hpgmg_hip_bc_entry *d_bc[STENCIL_MAX_SHAPES]; int n_bc[STENCIL_MAX_SHAPES];   /* boundary-condition blocks with their geometry worked out */
+  int bc_sources_local[STENCIL_MAX_SHAPES];    /* 1: every entry reads cells of local boxes' interiors only (no exchange needed before the conditions) */
   int *krylov_pinned;          /* iterations of device-side bottom solves not yet folded into level->Krylov_iterations */
   double *pair_scratch; double **d_pair_base;   /* two private vectors per box for the fused Chebyshev sweep pairs */
   float *coef32; float **d_coef32_base; int coef32_valid;   /* fp32 copies of Dinv, alpha, beta_* for the mixed-precision smoother */
@@ -326,6 +327,28 @@ static int ghost_free_mode(void) {
   return ghost_free;
 }
 void hpgmg_set_ghost_free(int on) { ghost_free = on ? 1 : 0; hpgmg_hip_set_ghost_free(ghost_free); }
+/* exchange_boundary(L, id, shape) + apply_BCs_p2 / v2 / v4 (order 12 / 2 / 4) as ONE launch, when the level has no messages and every
+ * boundary-condition block can read its sources from the box that owns them (then the box-to-box copies and the conditions are
+ * independent of each other).  Returns 0 when the caller must issue the two operators. */
+static const hpgmg_hip_bc_entry *bc_entries(level_type *L, int shape, int *n_out);
+static int exchange_and_bcs_one_launch(level_type *L, int id, int shape, int order) {
+  static int merge = -1;
+  if (merge < 0) { const char *e = getenv("HPGMG_ONE_LAUNCH_GHOSTS"); merge = !(e && e[0] == '0'); }
+  if (!merge || !ghost_free_mode() || L->num_my_boxes < 1 || L->boundary_condition.type == BC_PERIODIC) return 0;
+  if (order == 12 && !(L->box_dim >= 2 && L->box_ghosts == 1)) return 0;      /* below: the fall-backs of apply_BCs_p2 / v2 / v4 for tiny boxes, */
+  if (order == 2 && !(L->box_dim >= 2 && L->box_ghosts <= 1)) return 0;       /* and ghost zones deeper than the condition fills (cleared first) */
+  if (order == 4 && !(L->box_dim >= 4 && L->box_ghosts <= 2)) return 0;
+  communicator_type *C = &L->exchange_ghosts[shape];
+  if (C->num_sends + C->num_recvs > 0 || C->num_blocks[0] || C->num_blocks[2]) return 0;
+  backend_t *B = backend_of(L);
+  int n = 0;
+  const hpgmg_hip_bc_entry *e = bc_entries(L, shape, &n);
+  if (!B->bc_sources_local[shape]) return 0;
+  TICK(L, ghostZone_total, "exchange_boundary + apply_BCs (one launch)");
+  HIP_OK(hpgmg_hip_exchange_and_bc(&B->dev, id, mirror(L, C->blocks[1], C->num_blocks[1]), C->num_blocks[1], e, n, order));
+  TOCK();
+  return 1;
+}
 static int variant(void);
 static void ghosts_for_stencil(level_type *L, int id, int out_id) {
   const int shape = stencil_get_shape();
@@ -355,6 +378,11 @@ static void ghosts_for_stencil(level_type *L, int id, int out_id) {
       apply_BCs(L, id, shape);
       return;
     }
+  }
+  {
+    int order = 0;
+    if (c.op == HPGMG_OP_27PT) order = 12; else if (c.op == HPGMG_OP_FV2) order = 2; else if (c.op == HPGMG_OP_FV4) order = 4;
+    if (order && exchange_and_bcs_one_launch(L, id, shape, order)) return;
   }
   exchange_boundary(L, id, shape);
   apply_BCs(L, id, shape);
@@ -455,7 +483,7 @@ static const hpgmg_hip_bc_entry *bc_entries(level_type *L, int shape, int *n_out
   const blockCopy_type *blocks = L->boundary_condition.blocks[shape];
   hpgmg_hip_bc_entry *h = (hpgmg_hip_bc_entry *)calloc((size_t)n, sizeof *h);
   const int strides[3] = {1, L->my_boxes[0].jStride, L->my_boxes[0].kStride};
-  int kind, q, m = 0;
+  int kind, q, m = 0, all_local = 1;
   for (kind = 1; kind <= 3; kind++) for (q = 0; q < n; q++) {
     const blockCopy_type *e = &blocks[q];
     const int d[3] = {e->subtype % 3 - 1, (e->subtype % 9) / 3 - 1, e->subtype / 9 - 1};
@@ -464,12 +492,30 @@ static const hpgmg_hip_bc_entry *bc_entries(level_type *L, int shape, int *n_out
     hpgmg_hip_bc_entry *o = &h[m++];
     int ax, nf = 0;
     o->box = e->read.box; o->nn = 0; o->base = 0; o->len0 = o->len1 = 1; o->fs0 = o->fs1 = 0;
+    int nbr[3] = {0, 0, 0};                  /* in-face axes whose range lies in the ghost zone: the block runs along that neighbour's face */
     for (ax = 0; ax < 3; ax++) {
       if (d[ax]) { o->base += (d[ax] < 0 ? -1 : L->box_dim) * strides[ax]; o->step[o->nn++] = -d[ax] * strides[ax]; }
-      else if (nf == 0) { o->base += lo[ax] * strides[ax]; o->len0 = len[ax]; o->fs0 = strides[ax]; nf++; }
-      else if (nf == 1) { o->base += lo[ax] * strides[ax]; o->len1 = len[ax]; o->fs1 = strides[ax]; nf++; }
+      else {
+        if (nf == 0) { o->base += lo[ax] * strides[ax]; o->len0 = len[ax]; o->fs0 = strides[ax]; nf++; }
+        else if (nf == 1) { o->base += lo[ax] * strides[ax]; o->len1 = len[ax]; o->fs1 = strides[ax]; nf++; }
+        if (lo[ax] < 0) nbr[ax] = -1; else if (lo[ax] >= L->box_dim) nbr[ax] = 1;
+      }
+    }
+    /* read the cells the condition is formed from where they live: the box that owns them (same offsets, shifted by a box length) */
+    o->src_box = o->box; o->src_base = o->base;
+    if (nbr[0] || nbr[1] || nbr[2]) {
+      const box_type *bx = &L->my_boxes[o->box];
+      const int ni = bx->low.i / L->box_dim + nbr[0], nj = bx->low.j / L->box_dim + nbr[1], nk = bx->low.k / L->box_dim + nbr[2];
+      int src = -1, q2;
+      if (ni >= 0 && nj >= 0 && nk >= 0 && ni < L->boxes_in.i && nj < L->boxes_in.j && nk < L->boxes_in.k) {
+        const int gid = ni + L->boxes_in.i * (nj + L->boxes_in.j * nk);
+        if (L->rank_of_box[gid] == L->my_rank) for (q2 = 0; q2 < L->num_my_boxes; q2++) if (L->my_boxes[q2].global_box_id == gid) src = q2;
+      }
+      if (src >= 0) { o->src_box = src; for (ax = 0; ax < 3; ax++) o->src_base -= nbr[ax] * L->box_dim * strides[ax]; }
+      else all_local = 0;                    /* owned by another rank: that block keeps reading the ghost zone an exchange has filled */
     }
   }
+  B->bc_sources_local[shape] = all_local;
   if (m != n) { fprintf(stderr, "hpgmg: boundary-condition block without a domain normal\n"); abort(); }
   B->d_bc[shape] = (hpgmg_hip_bc_entry *)hpgmg_hip_malloc((size_t)n * sizeof *h);
   if (!B->d_bc[shape]) { fprintf(stderr, "hpgmg: device allocation failed: %s\n", hpgmg_hip_last_error()); abort(); }
@@ -1212,14 +1258,12 @@ static void interpolation_lists(level_type *Lf, int id_f, double prescale, level
 void interpolation_vcycle(level_type *Lf, int id_f, double prescale, level_type *Lc, int id_c) {
   hpgmg_config c; hpgmg_get_config(&c);
   if (c.op == HPGMG_OP_27PT) {                                  /* interpolation_p2.c:228-230 */
-    exchange_boundary(Lc, id_c, STENCIL_SHAPE_BOX);
-    apply_BCs_p2(Lc, id_c, STENCIL_SHAPE_BOX);
+    if (!exchange_and_bcs_one_launch(Lc, id_c, STENCIL_SHAPE_BOX, 12)) { exchange_boundary(Lc, id_c, STENCIL_SHAPE_BOX); apply_BCs_p2(Lc, id_c, STENCIL_SHAPE_BOX); }
     interpolation_lists(Lf, id_f, prescale, Lc, id_c, 2, 0x7);
     return;
   }
   if (c.op == HPGMG_OP_FV2 || c.op == HPGMG_OP_FV4) {           /* interpolation_v2.c:210-212 (V-cycle of fv2 and fv4) */
-    exchange_boundary(Lc, id_c, STENCIL_SHAPE_BOX);
-    apply_BCs_v2(Lc, id_c, STENCIL_SHAPE_BOX);
+    if (!exchange_and_bcs_one_launch(Lc, id_c, STENCIL_SHAPE_BOX, 2)) { exchange_boundary(Lc, id_c, STENCIL_SHAPE_BOX); apply_BCs_v2(Lc, id_c, STENCIL_SHAPE_BOX); }
     interpolation_lists(Lf, id_f, prescale, Lc, id_c, 3, 0x7);
     return;
   }
@@ -1230,8 +1274,7 @@ void interpolation_fcycle(level_type *Lf, int id_f, double prescale, level_type 
   hpgmg_config c; hpgmg_get_config(&c);
   if (c.op == HPGMG_OP_27PT || c.op == HPGMG_OP_FV2) { interpolation_vcycle(Lf, id_f, prescale, Lc, id_c); return; } /* operators.27pt.c:150-151, .fv2.c:151-152 */
   if (c.op == HPGMG_OP_FV4) {                                   /* interpolation_v4.c:276-278 */
-    exchange_boundary(Lc, id_c, STENCIL_SHAPE_BOX);
-    apply_BCs_v4(Lc, id_c, STENCIL_SHAPE_BOX);
+    if (!exchange_and_bcs_one_launch(Lc, id_c, STENCIL_SHAPE_BOX, 4)) { exchange_boundary(Lc, id_c, STENCIL_SHAPE_BOX); apply_BCs_v4(Lc, id_c, STENCIL_SHAPE_BOX); }
     interpolation_lists(Lf, id_f, prescale, Lc, id_c, 4, 0x7);
     return;
   }

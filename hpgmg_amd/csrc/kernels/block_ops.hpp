@@ -56,7 +56,7 @@ __device__ __forceinline__ void bc_p1_entry(const hpgmg_hip_level &L, int id, co
 // boundary_fd.c:93-205 apply_BCs_p2: quadratic extrapolation through a zero on the boundary face;
 // faces 2 terms, edges 4, corners 8 (decimal literals of the reference).  One ghost cell x[ijk]; the steps lead back into the domain.
 template <int NN>
-__device__ __forceinline__ void bc_p2_cell(double *x, int ijk, int s0, int s1, int s2) {
+__device__ __forceinline__ void bc_p2_cell(const double *x, double *xw, int ijk, int s0, int s1, int s2) {
   double v;
   if (NN == 1) {
     v = -2.0 * x[ijk + s0] + 0.333333333333333333 * x[ijk + 2 * s0];
@@ -75,7 +75,7 @@ __device__ __forceinline__ void bc_p2_cell(double *x, int ijk, int s0, int s1, i
     v = v - 0.222222222222222222 * x[ijk + 2 * di + dj + 2 * dk];
     v = v + 0.037037037037037037 * x[ijk + 2 * di + 2 * dj + 2 * dk];
   }
-  x[ijk] = v;
+  xw[ijk] = v;
 }
 __device__ __forceinline__ void bc_p2_entry(const hpgmg_hip_level &L, int id, const blockCopy_type &e, int tid, int nth) {
   const int jS = L.jStride, kS = L.kStride, inward = 26 - e.subtype;
@@ -90,9 +90,9 @@ __device__ __forceinline__ void bc_p2_entry(const hpgmg_hip_level &L, int id, co
   for (int t = tid; t < n; t += nth) {
     const int i = t % ni, j = (t / ni) % nj, k = t / (ni * nj);
     const int ijk = i + j * jS + k * kS;
-    if (kind == 1)      bc_p2_cell<1>(x, ijk, di + dj + dk, 0, 0);
-    else if (kind == 2) bc_p2_cell<2>(x, ijk, dr, ds, 0);
-    else                bc_p2_cell<3>(x, ijk, di, dj, dk);
+    if (kind == 1)      bc_p2_cell<1>(x, x, ijk, di + dj + dk, 0, 0);
+    else if (kind == 2) bc_p2_cell<2>(x, x, ijk, dr, ds, 0);
+    else                bc_p2_cell<3>(x, x, ijk, di, dj, dk);
   }
 }
 
@@ -129,7 +129,7 @@ __device__ __forceinline__ void bc_zero_entry(const hpgmg_hip_level &L, int id, 
 // boundary_fv.c:101-250 apply_BCs_v2: first ghost layer by quadratic extrapolation of cell averages, deeper layers zero.
 // One ghost cell x[ijk] where NN axes leave the domain; steps lead back into it.
 template <int NN>
-__device__ __forceinline__ void bc_v2_cell(double *x, int ijk, int s0, int s1, int s2) {
+__device__ __forceinline__ void bc_v2_cell(const double *x, double *xw, int ijk, int s0, int s1, int s2) {
   double v;
   if (NN == 1) {
     v = -2.5 * x[ijk + s0] + 0.5 * x[ijk + 2 * s0];
@@ -148,7 +148,7 @@ __device__ __forceinline__ void bc_v2_cell(double *x, int ijk, int s0, int s1, i
     v = v - 0.625 * x[ijk + 2 * di + dj + 2 * dk];
     v = v + 0.125 * x[ijk + 2 * di + 2 * dj + 2 * dk];
   }
-  x[ijk] = v;
+  xw[ijk] = v;
 }
 __device__ __forceinline__ void bc_v2_entry(const hpgmg_hip_level &L, int id, const blockCopy_type &e, int tid, int nth) {
   double *x = vec_origin(L, e.read.box, id);
@@ -157,9 +157,9 @@ __device__ __forceinline__ void bc_v2_entry(const hpgmg_hip_level &L, int id, co
   for (int t = tid; t < n; t += nth) {
     const int r = t % g.len[0], q = t / g.len[0];
     const int ijk = (r + g.lo[0]) * g.fstride[0] + (q + g.lo[1]) * g.fstride[1];
-    if (g.nn == 1)      bc_v2_cell<1>(x, ijk + g.pos[0], g.step[0], 0, 0);
-    else if (g.nn == 2) bc_v2_cell<2>(x, ijk + g.pos[0] + g.pos[1], g.step[0], g.step[1], 0);
-    else                bc_v2_cell<3>(x, ijk + g.pos[0] + g.pos[1] + g.pos[2], g.step[0], g.step[1], g.step[2]);
+    if (g.nn == 1)      bc_v2_cell<1>(x, x, ijk + g.pos[0], g.step[0], 0, 0);
+    else if (g.nn == 2) bc_v2_cell<2>(x, x, ijk + g.pos[0] + g.pos[1], g.step[0], g.step[1], 0);
+    else                bc_v2_cell<3>(x, x, ijk + g.pos[0] + g.pos[1] + g.pos[2], g.step[0], g.step[1], g.step[2]);
   }
 }
 
@@ -169,12 +169,12 @@ __device__ __forceinline__ double v4_near(double x1, double x2, double x3, doubl
 __device__ __forceinline__ double v4_far(double x1, double x2, double x3, double x4)  { const double w = 1.0 / 12.0; double s = -505.0 * x1 + 335.0 * x2; s = s - 145.0 * x3; s = s + 27.0 * x4; return w * s; }
 // the ghost cells behind x[ijk] (the near one on every leaving axis): 2 for a face, 4 for an edge, 8 for a corner
 template <int NN>
-__device__ __forceinline__ void bc_v4_cell(double *x, int ijk, int s0, int s1, int s2) {
+__device__ __forceinline__ void bc_v4_cell(const double *x, double *xw, int ijk, int s0, int s1, int s2) {
   if (NN == 1) {
     const int dt = s0;
     const double x1 = x[ijk + dt], x2 = x[ijk + 2 * dt], x3 = x[ijk + 3 * dt], x4 = x[ijk + 4 * dt];
-    x[ijk] = v4_near(x1, x2, x3, x4);
-    x[ijk - dt] = v4_far(x1, x2, x3, x4);
+    xw[ijk] = v4_near(x1, x2, x3, x4);
+    xw[ijk - dt] = v4_far(x1, x2, x3, x4);
   } else if (NN == 2) {
     const int ds = s0, dt = s1;
     double nr[4], fr[4];
@@ -184,10 +184,10 @@ __device__ __forceinline__ void bc_v4_cell(double *x, int ijk, int s0, int s1, i
       const double a1 = x[o + ds], a2 = x[o + 2 * ds], a3 = x[o + 3 * ds], a4 = x[o + 4 * ds];
       nr[m] = v4_near(a1, a2, a3, a4); fr[m] = v4_far(a1, a2, a3, a4);
     }
-    x[ijk]           = v4_near(nr[0], nr[1], nr[2], nr[3]);
-    x[ijk - dt]      = v4_far(nr[0], nr[1], nr[2], nr[3]);
-    x[ijk - ds]      = v4_near(fr[0], fr[1], fr[2], fr[3]);
-    x[ijk - ds - dt] = v4_far(fr[0], fr[1], fr[2], fr[3]);
+    xw[ijk]           = v4_near(nr[0], nr[1], nr[2], nr[3]);
+    xw[ijk - dt]      = v4_far(nr[0], nr[1], nr[2], nr[3]);
+    xw[ijk - ds]      = v4_near(fr[0], fr[1], fr[2], fr[3]);
+    xw[ijk - ds - dt] = v4_far(fr[0], fr[1], fr[2], fr[3]);
   } else {
     const int di = s0, dj = s1, dk = s2;
     double nn[4], nf[4], fn[4], ff[4];
@@ -203,14 +203,14 @@ __device__ __forceinline__ void bc_v4_cell(double *x, int ijk, int s0, int s1, i
       nn[p] = v4_near(nj[0], nj[1], nj[2], nj[3]); nf[p] = v4_far(nj[0], nj[1], nj[2], nj[3]);
       fn[p] = v4_near(fj[0], fj[1], fj[2], fj[3]); ff[p] = v4_far(fj[0], fj[1], fj[2], fj[3]);
     }
-    x[ijk]                = v4_near(nn[0], nn[1], nn[2], nn[3]);
-    x[ijk - dk]           = v4_far(nn[0], nn[1], nn[2], nn[3]);
-    x[ijk - dj]           = v4_near(nf[0], nf[1], nf[2], nf[3]);
-    x[ijk - dj - dk]      = v4_far(nf[0], nf[1], nf[2], nf[3]);
-    x[ijk - di]           = v4_near(fn[0], fn[1], fn[2], fn[3]);
-    x[ijk - di - dk]      = v4_far(fn[0], fn[1], fn[2], fn[3]);
-    x[ijk - di - dj]      = v4_near(ff[0], ff[1], ff[2], ff[3]);
-    x[ijk - di - dj - dk] = v4_far(ff[0], ff[1], ff[2], ff[3]);
+    xw[ijk]                = v4_near(nn[0], nn[1], nn[2], nn[3]);
+    xw[ijk - dk]           = v4_far(nn[0], nn[1], nn[2], nn[3]);
+    xw[ijk - dj]           = v4_near(nf[0], nf[1], nf[2], nf[3]);
+    xw[ijk - dj - dk]      = v4_far(nf[0], nf[1], nf[2], nf[3]);
+    xw[ijk - di]           = v4_near(fn[0], fn[1], fn[2], fn[3]);
+    xw[ijk - di - dk]      = v4_far(fn[0], fn[1], fn[2], fn[3]);
+    xw[ijk - di - dj]      = v4_near(ff[0], ff[1], ff[2], ff[3]);
+    xw[ijk - di - dj - dk] = v4_far(ff[0], ff[1], ff[2], ff[3]);
   }
 }
 __device__ __forceinline__ void bc_v4_entry(const hpgmg_hip_level &L, int id, const blockCopy_type &e, int tid, int nth) {
@@ -220,34 +220,35 @@ __device__ __forceinline__ void bc_v4_entry(const hpgmg_hip_level &L, int id, co
   for (int t = tid; t < n; t += nth) {
     const int r = t % g.len[0], q = t / g.len[0];
     const int ijk = (r + g.lo[0]) * g.fstride[0] + (q + g.lo[1]) * g.fstride[1];
-    if (g.nn == 1)      bc_v4_cell<1>(x, ijk + g.pos[0], g.step[0], 0, 0);
-    else if (g.nn == 2) bc_v4_cell<2>(x, ijk + g.pos[0] + g.pos[1], g.step[0], g.step[1], 0);
-    else                bc_v4_cell<3>(x, ijk + g.pos[0] + g.pos[1] + g.pos[2], g.step[0], g.step[1], g.step[2]);
+    if (g.nn == 1)      bc_v4_cell<1>(x, x, ijk + g.pos[0], g.step[0], 0, 0);
+    else if (g.nn == 2) bc_v4_cell<2>(x, x, ijk + g.pos[0] + g.pos[1], g.step[0], g.step[1], 0);
+    else                bc_v4_cell<3>(x, x, ijk + g.pos[0] + g.pos[1] + g.pos[2], g.step[0], g.step[1], g.step[2]);
   }
 }
 
 // the same conditions over entries whose geometry the host worked out (hpgmg_hip_bc_entry): one loop per kind, so the
 // instructions a workgroup executes are few and contiguous.  ORDER: 2 = v2, 4 = v4, 12 = p2
 template <int ORDER, int NN>
-__device__ __forceinline__ void bc_compact_cell(double *x, int ijk, int s0, int s1, int s2) {
-  if (ORDER == 4) bc_v4_cell<NN>(x, ijk, s0, s1, s2); else if (ORDER == 2) bc_v2_cell<NN>(x, ijk, s0, s1, s2); else bc_p2_cell<NN>(x, ijk, s0, s1, s2);
+__device__ __forceinline__ void bc_compact_cell(const double *x, double *xw, int ijk, int s0, int s1, int s2) {
+  if (ORDER == 4) bc_v4_cell<NN>(x, xw, ijk, s0, s1, s2); else if (ORDER == 2) bc_v2_cell<NN>(x, xw, ijk, s0, s1, s2); else bc_p2_cell<NN>(x, xw, ijk, s0, s1, s2);
 }
 template <int ORDER>
 __device__ __forceinline__ void bc_fv_compact_entry(const hpgmg_hip_level &L, int id, const hpgmg_hip_bc_entry &e, int tid, int nth) {
-  double *x = vec_origin(L, e.box, id) + e.base;
+  double *xw = vec_origin(L, e.box, id) + e.base;                                  // where the ghost cells are
+  const double *x = vec_origin(L, e.src_box, id) + e.src_base;                     // where the cells they are formed from are read (same offsets)
   const int n = e.len0 * e.len1;
   if (e.nn == 1) {
     for (int t = tid; t < n; t += nth) {
       const int q = t / e.len0, r = t - q * e.len0, ijk = r * e.fs0 + q * e.fs1;
-      bc_compact_cell<ORDER, 1>(x, ijk, e.step[0], 0, 0);
+      bc_compact_cell<ORDER, 1>(x, xw, ijk, e.step[0], 0, 0);
     }
   } else if (e.nn == 2) {
     for (int t = tid; t < n; t += nth) {
       const int ijk = t * e.fs0;                             // an edge runs along one axis
-      bc_compact_cell<ORDER, 2>(x, ijk, e.step[0], e.step[1], 0);
+      bc_compact_cell<ORDER, 2>(x, xw, ijk, e.step[0], e.step[1], 0);
     }
   } else if (tid == 0) {
-    bc_compact_cell<ORDER, 3>(x, 0, e.step[0], e.step[1], e.step[2]);
+    bc_compact_cell<ORDER, 3>(x, xw, 0, e.step[0], e.step[1], e.step[2]);
   }
 }
 

@@ -37,6 +37,15 @@ template <int ORDER>
 __global__ __launch_bounds__(256) void bc_fv_kernel(const hpgmg_hip_level L, int id, const hpgmg_hip_bc_entry *__restrict__ list) {
   bc_fv_compact_entry<ORDER>(L, id, list[blockIdx.x], (int)threadIdx.x, 256);
 }
+// exchange_boundary's box-to-box copies and the boundary conditions of the same vector in one launch: the first n_copy workgroups run
+// a copy entry each, the others a condition entry.  The two touch disjoint ghost cells and read interior cells only (the host has
+// redirected the conditions that run along another box's face to that box, see hpgmg_hip_bc_entry), so no order is needed between them.
+template <int ORDER>
+__global__ __launch_bounds__(256) void ghost_fill_kernel(const hpgmg_hip_level L, int id, const blockCopy_type *__restrict__ copies, int n_copy,
+                                                         const hpgmg_hip_bc_entry *__restrict__ list) {
+  if ((int)blockIdx.x < n_copy) copy_entry<false>(L, id, copies[blockIdx.x], 0.0, (int)threadIdx.x, 256);
+  else bc_fv_compact_entry<ORDER>(L, id, list[(int)blockIdx.x - n_copy], (int)threadIdx.x, 256);
+}
 
 // boundary_fv.c:573-681 extrapolate_betas.  The reference updates each block IN PLACE in k,j,i order, so a
 // deeper ghost cell may see a shallower one already (high side) or not yet (low side) updated.  One lane per
@@ -329,6 +338,18 @@ int hpgmg_hip_apply_bc_fv(const hpgmg_hip_level *L, int id, const hpgmg_hip_bc_e
   else if (order == 2) hipLaunchKernelGGL(bc_fv_kernel<2>, dim3(n), dim3(256), 0, g_stream, *L, id, entries);
   else                 hipLaunchKernelGGL(bc_fv_kernel<12>, dim3(n), dim3(256), 0, g_stream, *L, id, entries);
   HPGMG_LAUNCH_CHECK("bc_fv_kernel");
+  return 0;
+}
+int hpgmg_hip_exchange_and_bc(const hpgmg_hip_level *L, int id, const blockCopy_type *copies, int n_copy, const hpgmg_hip_bc_entry *entries, int n, int order) {
+  HPGMG_SKIP_IF_REPLAY();
+  if (n_copy <= 0) return hpgmg_hip_apply_bc_fv(L, id, entries, n, order);
+  if (n <= 0) return hpgmg_hip_copy_blocks(L, id, copies, n_copy);
+  const int fills = (order == 4) ? 2 : 1;
+  if (L->ghosts > fills || (order != 2 && order != 4 && order != 12)) return record_error(hipErrorInvalidValue, "exchange_and_bc: ghost zone deeper than the condition fills");
+  if (order == 4)      hipLaunchKernelGGL(ghost_fill_kernel<4>, dim3(n_copy + n), dim3(256), 0, g_stream, *L, id, copies, n_copy, entries);
+  else if (order == 2) hipLaunchKernelGGL(ghost_fill_kernel<2>, dim3(n_copy + n), dim3(256), 0, g_stream, *L, id, copies, n_copy, entries);
+  else                 hipLaunchKernelGGL(ghost_fill_kernel<12>, dim3(n_copy + n), dim3(256), 0, g_stream, *L, id, copies, n_copy, entries);
+  HPGMG_LAUNCH_CHECK("ghost_fill_kernel");
   return 0;
 }
 int hpgmg_hip_extrapolate_betas(const hpgmg_hip_level *L, const blockCopy_type *blocks, int n) {

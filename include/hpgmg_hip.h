@@ -200,10 +200,18 @@ int hpgmg_hip_apply_bc_v4(const hpgmg_hip_level *L, int id, const blockCopy_type
 int hpgmg_hip_extrapolate_betas(const hpgmg_hip_level *L, const blockCopy_type *blocks, int num_blocks);
 /* apply_BCs_v2 / apply_BCs_v4 / apply_BCs_p2 from entries whose geometry the host has worked out (one per boundary_condition block, any order):
  * cell (r, q) of the entry is x[base + r fs0 + q fs1] in vector `id` of box `box`, 0 <= r < len0, 0 <= q < len1; `nn` axes (1 face, 2 edge,
- * 3 corner) leave the domain there and step[0..nn-1] lead back into it.  Short kernels: on the small levels a launch lasts as long as
- * its instruction fetch.  order = 2 (v2) | 4 (v4) | 12 (p2); only for ghost zones no deeper than the condition fills (v4: 2, else 1). */
-typedef struct { int box, nn, base, len0, len1, fs0, fs1, step[3], pad_[2]; } hpgmg_hip_bc_entry;
+ * 3 corner) leave the domain there and step[0..nn-1] lead back into it.  The values the condition READS are taken at the same offsets
+ * from (src_box, src_base): normally the entry's own box; for a block that runs along another box's face (its in-face coordinates lie in
+ * this box's ghost zone) the host may name that neighbouring box instead -- the cells are the same, but then the condition no longer
+ * depends on a preceding exchange_boundary, and hpgmg_hip_exchange_and_bc() runs both as one launch.
+ * Short kernels: on the small levels a launch lasts as long as its instruction fetch.  order = 2 (v2) | 4 (v4) | 12 (p2); only for
+ * ghost zones no deeper than the condition fills (v4: 2, else 1). */
+typedef struct { int box, nn, base, len0, len1, fs0, fs1, step[3], src_box, src_base; } hpgmg_hip_bc_entry;
 int hpgmg_hip_apply_bc_fv(const hpgmg_hip_level *L, int id, const hpgmg_hip_bc_entry *entries, int num_entries, int order);
+/* exchange_boundary's box-to-box copies (a `copy` list, operators/exchange_boundary.c:81-90) and the boundary conditions in ONE launch:
+ * only for entries whose sources do not depend on the copies (see above) and levels without messages */
+int hpgmg_hip_exchange_and_bc(const hpgmg_hip_level *L, int id, const blockCopy_type *copies, int num_copies,
+                              const hpgmg_hip_bc_entry *entries, int num_entries, int order);
 /* operators/restriction.c:6-94 restriction_pc_block over a list; type = RESTRICT_* */
 int hpgmg_hip_restrict_blocks(const hpgmg_hip_level *Lc, int id_c, const hpgmg_hip_level *Lf, int id_f,
                               const blockCopy_type *blocks, int num_blocks, int type);
