@@ -329,9 +329,10 @@ static int ghost_free_mode(void) {
 void hpgmg_set_ghost_free(int on) { ghost_free = on ? 1 : 0; hpgmg_hip_set_ghost_free(ghost_free); }
 /* exchange_boundary(L, id, shape) + apply_BCs_p2 / v2 / v4 (order 12 / 2 / 4) as ONE launch, when the level has no messages and every
  * boundary-condition block can read its sources from the box that owns them (then the box-to-box copies and the conditions are
- * independent of each other).  Returns 0 when the caller must issue the two operators. */
+ * independent of each other).  with_copies = 0: only the conditions (the caller's kernel reads neighbouring boxes itself).  Returns 0 when the
+ * caller must issue the two operators. */
 static const hpgmg_hip_bc_entry *bc_entries(level_type *L, int shape, int *n_out);
-static int exchange_and_bcs_one_launch(level_type *L, int id, int shape, int order) {
+static int exchange_and_bcs_one_launch(level_type *L, int id, int shape, int order, int with_copies) {
   static int merge = -1;
   if (merge < 0) { const char *e = getenv("HPGMG_ONE_LAUNCH_GHOSTS"); merge = !(e && e[0] == '0'); }
   if (!merge || !ghost_free_mode() || L->num_my_boxes < 1 || L->boundary_condition.type == BC_PERIODIC) return 0;
@@ -345,7 +346,7 @@ static int exchange_and_bcs_one_launch(level_type *L, int id, int shape, int ord
   const hpgmg_hip_bc_entry *e = bc_entries(L, shape, &n);
   if (!B->bc_sources_local[shape]) return 0;
   TICK(L, ghostZone_total, "exchange_boundary + apply_BCs (one launch)");
-  HIP_OK(hpgmg_hip_exchange_and_bc(&B->dev, id, mirror(L, C->blocks[1], C->num_blocks[1]), C->num_blocks[1], e, n, order));
+  HIP_OK(hpgmg_hip_exchange_and_bc(&B->dev, id, with_copies ? mirror(L, C->blocks[1], C->num_blocks[1]) : NULL, with_copies ? C->num_blocks[1] : 0, e, n, order));
   TOCK();
   return 1;
 }
@@ -375,14 +376,14 @@ static void ghosts_for_stencil(level_type *L, int id, int out_id) {
     backend_t *B = backend_of(L);
     if (B->all_faces_local && hpgmg_hip_tile_kernel_applies(&B->dev, variant(), id != out_id)) {
       hpgmg_hip_set_tile_ghost_free(1);
-      apply_BCs(L, id, shape);
+      if (!exchange_and_bcs_one_launch(L, id, shape, c.op == HPGMG_OP_27PT ? 12 : 4, 0)) apply_BCs(L, id, shape);
       return;
     }
   }
   {
     int order = 0;
     if (c.op == HPGMG_OP_27PT) order = 12; else if (c.op == HPGMG_OP_FV2) order = 2; else if (c.op == HPGMG_OP_FV4) order = 4;
-    if (order && exchange_and_bcs_one_launch(L, id, shape, order)) return;
+    if (order && exchange_and_bcs_one_launch(L, id, shape, order, 1)) return;
   }
   exchange_boundary(L, id, shape);
   apply_BCs(L, id, shape);
@@ -1258,12 +1259,12 @@ static void interpolation_lists(level_type *Lf, int id_f, double prescale, level
 void interpolation_vcycle(level_type *Lf, int id_f, double prescale, level_type *Lc, int id_c) {
   hpgmg_config c; hpgmg_get_config(&c);
   if (c.op == HPGMG_OP_27PT) {                                  /* interpolation_p2.c:228-230 */
-    if (!exchange_and_bcs_one_launch(Lc, id_c, STENCIL_SHAPE_BOX, 12)) { exchange_boundary(Lc, id_c, STENCIL_SHAPE_BOX); apply_BCs_p2(Lc, id_c, STENCIL_SHAPE_BOX); }
+    if (!exchange_and_bcs_one_launch(Lc, id_c, STENCIL_SHAPE_BOX, 12, 1)) { exchange_boundary(Lc, id_c, STENCIL_SHAPE_BOX); apply_BCs_p2(Lc, id_c, STENCIL_SHAPE_BOX); }
     interpolation_lists(Lf, id_f, prescale, Lc, id_c, 2, 0x7);
     return;
   }
   if (c.op == HPGMG_OP_FV2 || c.op == HPGMG_OP_FV4) {           /* interpolation_v2.c:210-212 (V-cycle of fv2 and fv4) */
-    if (!exchange_and_bcs_one_launch(Lc, id_c, STENCIL_SHAPE_BOX, 2)) { exchange_boundary(Lc, id_c, STENCIL_SHAPE_BOX); apply_BCs_v2(Lc, id_c, STENCIL_SHAPE_BOX); }
+    if (!exchange_and_bcs_one_launch(Lc, id_c, STENCIL_SHAPE_BOX, 2, 1)) { exchange_boundary(Lc, id_c, STENCIL_SHAPE_BOX); apply_BCs_v2(Lc, id_c, STENCIL_SHAPE_BOX); }
     interpolation_lists(Lf, id_f, prescale, Lc, id_c, 3, 0x7);
     return;
   }
@@ -1274,7 +1275,7 @@ void interpolation_fcycle(level_type *Lf, int id_f, double prescale, level_type 
   hpgmg_config c; hpgmg_get_config(&c);
   if (c.op == HPGMG_OP_27PT || c.op == HPGMG_OP_FV2) { interpolation_vcycle(Lf, id_f, prescale, Lc, id_c); return; } /* operators.27pt.c:150-151, .fv2.c:151-152 */
   if (c.op == HPGMG_OP_FV4) {                                   /* interpolation_v4.c:276-278 */
-    if (!exchange_and_bcs_one_launch(Lc, id_c, STENCIL_SHAPE_BOX, 4)) { exchange_boundary(Lc, id_c, STENCIL_SHAPE_BOX); apply_BCs_v4(Lc, id_c, STENCIL_SHAPE_BOX); }
+    if (!exchange_and_bcs_one_launch(Lc, id_c, STENCIL_SHAPE_BOX, 4, 1)) { exchange_boundary(Lc, id_c, STENCIL_SHAPE_BOX); apply_BCs_v4(Lc, id_c, STENCIL_SHAPE_BOX); }
     interpolation_lists(Lf, id_f, prescale, Lc, id_c, 4, 0x7);
     return;
   }

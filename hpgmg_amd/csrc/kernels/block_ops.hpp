@@ -232,10 +232,12 @@ template <int ORDER, int NN>
 __device__ __forceinline__ void bc_compact_cell(const double *x, double *xw, int ijk, int s0, int s1, int s2) {
   if (ORDER == 4) bc_v4_cell<NN>(x, xw, ijk, s0, s1, s2); else if (ORDER == 2) bc_v2_cell<NN>(x, xw, ijk, s0, s1, s2); else bc_p2_cell<NN>(x, xw, ijk, s0, s1, s2);
 }
-template <int ORDER>
+template <int ORDER, bool REDIRECT>
 __device__ __forceinline__ void bc_fv_compact_entry(const hpgmg_hip_level &L, int id, const hpgmg_hip_bc_entry &e, int tid, int nth) {
   double *xw = vec_origin(L, e.box, id) + e.base;                                  // where the ghost cells are
-  const double *x = vec_origin(L, e.src_box, id) + e.src_base;                     // where the cells they are formed from are read (same offsets)
+  // where the cells they are formed from are read (same offsets): the entry's own box as apply_BCs does, or -- REDIRECT, the one-launch
+  // form that does not wait for the exchange -- the box that owns them
+  const double *x = REDIRECT ? vec_origin(L, e.src_box, id) + e.src_base : xw;
   const int n = e.len0 * e.len1;
   if (e.nn == 1) {
     for (int t = tid; t < n; t += nth) {

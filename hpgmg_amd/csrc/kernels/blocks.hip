@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void bc_v4_kernel(const hpgmg_hip_level L, int
 }
 template <int ORDER>
 __global__ __launch_bounds__(256) void bc_fv_kernel(const hpgmg_hip_level L, int id, const hpgmg_hip_bc_entry *__restrict__ list) {
-  bc_fv_compact_entry<ORDER>(L, id, list[blockIdx.x], (int)threadIdx.x, 256);
+  bc_fv_compact_entry<ORDER, false>(L, id, list[blockIdx.x], (int)threadIdx.x, 256);
 }
 // exchange_boundary's box-to-box copies and the boundary conditions of the same vector in one launch: the first n_copy workgroups run
 // a copy entry each, the others a condition entry.  The two touch disjoint ghost cells and read interior cells only (the host has
@@ -44,7 +44,7 @@ template <int ORDER>
 __global__ __launch_bounds__(256) void ghost_fill_kernel(const hpgmg_hip_level L, int id, const blockCopy_type *__restrict__ copies, int n_copy,
                                                          const hpgmg_hip_bc_entry *__restrict__ list) {
   if ((int)blockIdx.x < n_copy) copy_entry<false>(L, id, copies[blockIdx.x], 0.0, (int)threadIdx.x, 256);
-  else bc_fv_compact_entry<ORDER>(L, id, list[(int)blockIdx.x - n_copy], (int)threadIdx.x, 256);
+  else bc_fv_compact_entry<ORDER, true>(L, id, list[(int)blockIdx.x - n_copy], (int)threadIdx.x, 256);
 }
 
 // boundary_fv.c:573-681 extrapolate_betas.  The reference updates each block IN PLACE in k,j,i order, so a
@@ -342,7 +342,6 @@ int hpgmg_hip_apply_bc_fv(const hpgmg_hip_level *L, int id, const hpgmg_hip_bc_e
 }
 int hpgmg_hip_exchange_and_bc(const hpgmg_hip_level *L, int id, const blockCopy_type *copies, int n_copy, const hpgmg_hip_bc_entry *entries, int n, int order) {
   HPGMG_SKIP_IF_REPLAY();
-  if (n_copy <= 0) return hpgmg_hip_apply_bc_fv(L, id, entries, n, order);
   if (n <= 0) return hpgmg_hip_copy_blocks(L, id, copies, n_copy);
   const int fills = (order == 4) ? 2 : 1;
   if (L->ghosts > fills || (order != 2 && order != 4 && order != 12)) return record_error(hipErrorInvalidValue, "exchange_and_bc: ghost zone deeper than the condition fills");

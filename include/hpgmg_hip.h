@@ -202,8 +202,9 @@ int hpgmg_hip_extrapolate_betas(const hpgmg_hip_level *L, const blockCopy_type *
  * cell (r, q) of the entry is x[base + r fs0 + q fs1] in vector `id` of box `box`, 0 <= r < len0, 0 <= q < len1; `nn` axes (1 face, 2 edge,
  * 3 corner) leave the domain there and step[0..nn-1] lead back into it.  The values the condition READS are taken at the same offsets
  * from (src_box, src_base): normally the entry's own box; for a block that runs along another box's face (its in-face coordinates lie in
- * this box's ghost zone) the host may name that neighbouring box instead -- the cells are the same, but then the condition no longer
- * depends on a preceding exchange_boundary, and hpgmg_hip_exchange_and_bc() runs both as one launch.
+ * this box's ghost zone) the host may name that neighbouring box instead -- after an exchange the values are the same, but read there the
+ * condition does not depend on the exchange: hpgmg_hip_exchange_and_bc() uses the sources and runs both as one launch, while
+ * hpgmg_hip_apply_bc_fv() (= apply_BCs on its own) reads the entry's own box like the reference.
  * Short kernels: on the small levels a launch lasts as long as its instruction fetch.  order = 2 (v2) | 4 (v4) | 12 (p2); only for
  * ghost zones no deeper than the condition fills (v4: 2, else 1). */
 typedef struct { int box, nn, base, len0, len1, fs0, fs1, step[3], src_box, src_base; } hpgmg_hip_bc_entry;
