@@ -1117,6 +1117,19 @@ void smooth(level_type *L, int x_id, int rhs_id, double a, double b) {
   } else if (cfg.smoother == HPGMG_SMOOTH_GSRB) {    /* gsrb.c:24-132 */
     const int oop = hpgmg_gsrb_out_of_place();
     if (smooth_gsrb_pairs(L, x_id, rhs_id, a, b, sweeps)) return;
+    /* 27-point, inside a cycle (VECTOR_TEMP is scratch afterwards): each red + black pair of half sweeps as one pass, x -> TEMP -> x.
+     * The state the exported smooth() must leave in VECTOR_TEMP (the iterate before the last half sweep) never exists in this form. */
+    if (cfg.op == HPGMG_OP_27PT && oop && temp_is_scratch && sweeps % 4 == 0 && L->num_my_boxes > 0 && B->all_faces_local &&
+        x_id != VECTOR_TEMP && rhs_id != VECTOR_TEMP && hpgmg_hip_smooth_gsrb27_rb_supported(&B->dev)) {
+      for (s = 0; s < sweeps; s += 2) {
+        const int src = (s & 2) ? VECTOR_TEMP : x_id, dst = (s & 2) ? x_id : VECTOR_TEMP;
+        if (!exchange_and_bcs_one_launch(L, src, stencil_get_shape(), 12, 0)) apply_BCs(L, src, stencil_get_shape());
+        TICK(L, smooth, "smooth (27-point GSRB, red + black half sweeps in one pass)");
+        HIP_OK(hpgmg_hip_smooth_gsrb27_rb(&B->dev, src, dst, rhs_id, a, b, h2inv, s));
+        TOCK();
+      }
+      return;
+    }
     for (s = 0; s < sweeps; s++) {
       const int src = (oop && (s & 1)) ? VECTOR_TEMP : x_id, dst = oop ? ((s & 1) ? x_id : VECTOR_TEMP) : x_id;
       STENCIL_WITH_GHOSTS(L, src, dst, smooth, hpgmg_hip_smooth_gsrb(&B->dev, v, src, dst, rhs_id, a, b, h2inv, s));

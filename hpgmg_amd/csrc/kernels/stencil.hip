@@ -26,6 +26,7 @@
 #include "stencil_math.hpp"
 #include "cheby_pair.hpp"
 #include "fv4_tile.hpp"
+#include "stencil27_rb.hpp"
 #include "stencil7_tile.hpp"
 #include "block_ops.hpp"
 
@@ -1215,6 +1216,37 @@ int hpgmg_hip_smooth_gsrb(const hpgmg_hip_level *L, int variant, int xn_id, int 
   StencilArgs P = {}; P.xn_id = xn_id; P.xout_id = xnp1_id; P.rhs_id = rhs_id; P.a = a; P.b = b; P.h2inv = h2inv; P.sweep = sweep;
   P.copy_other_colour = (xn_id != xnp1_id);
   return launch<MODE_GSRB>(L, variant, P, true);
+}
+// Both coloured half sweeps (sweep, sweep + 1; sweep even) of an out-of-place 27-point GSRB sweep in one pass (stencil27_rb.hpp):
+// x_id -> out_id, the intermediate vector never stored.  Needs boxes of side 64 m, all of them local, apply_BCs_p2 done on x_id.
+static long long g_rb27_launches = 0;
+long long hpgmg_hip_rb27_launch_count(void) { return g_rb27_launches; }   // launches of the one-pass red + black kernel so far (tests)
+int hpgmg_hip_smooth_gsrb27_rb_supported(const hpgmg_hip_level *L) {
+  static const int off = env_int("HPGMG_TUNE_27PT_NO_RB", 0);
+  return !off && L->num_boxes > 0 && L->dim % 64 == 0 && L->box_nbr != nullptr && L->ghosts >= 1;
+}
+int hpgmg_hip_smooth_gsrb27_rb(const hpgmg_hip_level *L, int x_id, int out_id, int rhs_id, double a, double b, double h2inv, int sweep) {
+  HPGMG_SKIP_IF_REPLAY();
+  if (!hpgmg_hip_smooth_gsrb27_rb_supported(L) || x_id == out_id || (sweep & 1)) return record_error(hipErrorInvalidValue, "smooth_gsrb27_rb: level / arguments not supported");
+  static const int TJ = env_int("HPGMG_TUNE_27PT_RB_TJ", 8);
+  S27RbArgs A = {};
+  A.xn_id = x_id; A.xout_id = out_id; A.rhs_id = rhs_id; A.a = a; A.b = b; A.h2inv = h2inv; A.sweep = sweep;
+  A.tiles_i = L->dim / 64; A.tiles_j = L->dim / TJ;
+  int kchunk = L->dim;
+  while (kchunk > 32 && (long long)L->num_boxes * A.tiles_i * A.tiles_j * (L->dim / kchunk) < 4096) kchunk /= 2;
+  static const int tune_kc = env_int("HPGMG_TUNE_27PT_RB_KCHUNK", 0);
+  if (tune_kc > 0 && L->dim % tune_kc == 0) kchunk = tune_kc;
+  A.kchunk = kchunk; A.chunks_k = (L->dim + kchunk - 1) / kchunk;
+  A.total_blocks = L->num_boxes * A.chunks_k * A.tiles_j * A.tiles_i;
+  const int grid = grid_for(A.total_blocks, &A.per_xcd);
+  const long long cells = (long long)L->num_boxes * L->dim * L->dim * L->dim;
+  const int prof = profile_begin(cells);
+  if (TJ == 16) hipLaunchKernelGGL((stencil27_rb_kernel<16>), dim3(grid), dim3(64, 16), 0, g_stream, *L, A);
+  else          hipLaunchKernelGGL((stencil27_rb_kernel<8>), dim3(grid), dim3(64, 8), 0, g_stream, *L, A);
+  g_rb27_launches++;
+  profile_end(prof, 2 * cells);                       // one launch = two half sweeps over every cell
+  HPGMG_LAUNCH_CHECK("stencil27_rb_kernel");
+  return 0;
 }
 int hpgmg_hip_smooth_jacobi(const hpgmg_hip_level *L, int variant, int xn_id, int xnp1_id, int rhs_id,
                             double a, double b, double h2inv, double weight) {

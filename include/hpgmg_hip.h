@@ -132,7 +132,13 @@ void hpgmg_hip_set_defer_mode(int mode);
  * neighbouring box itself when every box of the level is local: the caller then runs only apply_BCs before the launch, not
  * exchange_boundary.  applies() tells whether the next smooth / residual / apply_op launch of `variant` would be such a kernel. */
 void hpgmg_hip_set_tile_ghost_free(int on);
-void hpgmg_hip_set_27pt_tile32(int on);   /* tiled 27-point kernel also for boxes of 32^3 (off by default: slower than the register kernel there; HPGMG_TUNE_27PT_TILE32=1) */
+void hpgmg_hip_set_27pt_tile32(int on);
+/* Both coloured half sweeps (sweep, sweep + 1; sweep even) of one out-of-place GSRB sweep of the 27-point operator in one pass
+ * (gsrb.c:24-132 twice; kernels/stencil27_rb.hpp): x_id -> out_id, the intermediate vector and its boundary conditions live in LDS.
+ * Boxes of side 64 m, every box local; the caller has run apply_BCs_p2 on x_id (no exchange_boundary needed). */
+int  hpgmg_hip_smooth_gsrb27_rb_supported(const hpgmg_hip_level *L);
+int  hpgmg_hip_smooth_gsrb27_rb(const hpgmg_hip_level *L, int x_id, int out_id, int rhs_id, double a, double b, double h2inv, int sweep);
+long long hpgmg_hip_rb27_launch_count(void);   /* launches of that kernel so far (tests) */   /* tiled 27-point kernel also for boxes of 32^3 (off by default: slower than the register kernel there; HPGMG_TUNE_27PT_TILE32=1) */
 int  hpgmg_hip_tile_kernel_applies(const hpgmg_hip_level *L, int variant, int out_of_place);
 
 /* ---- fused forms of smooth() for bandwidth-bound levels (kernels/cheby_pair.hpp) ---- */

@@ -349,6 +349,35 @@ def test_lds_tiled_kernels_of_the_27pt_and_fv4_plugins(hip, oracle, variant, geo
         lh.destroy(); lo.destroy()
 
 
+@pytest.mark.parametrize("geom", [(2, 64), (1, 64), (3, 64), (1, 128), (1, 64, "periodic"), (2, 64, "periodic")])
+def test_27pt_red_and_black_half_sweeps_in_one_pass(hip, oracle, geom):
+    """Inside a cycle (hpgmg_smooth_in_cycle: VECTOR_TEMP is scratch afterwards) the 27-point GSRB smoother runs each red + black pair of
+    half sweeps as ONE pass (stencil27_rb.hpp): the intermediate vector, its exchange and its quadratic boundary extrapolation live in LDS.
+    The iterate must equal the oracle's four separate half sweeps bit for bit, and the kernel must really have been the one launched."""
+    set_mode(hip, 1)
+    lh, lo = make_pair(hip, oracle, "27pt-gsrb", geom[0], geom[1], seed=13, bc=H.BC_PERIODIC if len(geom) > 2 else H.BC_DIRICHLET)
+    try:
+        for lv in (lh, lo):
+            lv.b.lib.exchange_boundary(lv.ptr, H.VECTOR_DINV, H.STENCIL_SHAPE_BOX)
+        K = H.load_kernels()
+        K.hpgmg_hip_profile_smoother.argtypes = [ctypes.c_int]
+        hip.lib.hpgmg_smooth_in_cycle.restype = ctypes.c_int
+        hip.lib.hpgmg_smooth_in_cycle.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double]
+        before = (ctypes.c_longlong * 2)()
+        K.hpgmg_hip_rb27_launch_count.restype = ctypes.c_longlong
+        n0 = K.hpgmg_hip_rb27_launch_count()
+        assert hip.lib.hpgmg_smooth_in_cycle(lh.ptr, H.VECTOR_U, H.VECTOR_F, 0.0, 1.0) == 1
+        assert K.hpgmg_hip_rb27_launch_count() - n0 == 2          # four half sweeps = two passes
+        lo.b.lib.smooth(lo.ptr, H.VECTOR_U, H.VECTOR_F, 0.0, 1.0)
+        same(lh, lo, [H.VECTOR_U], interior_only=True)
+        # and again from the new iterate (the second call starts from ghost zones the first one left as scratch)
+        assert hip.lib.hpgmg_smooth_in_cycle(lh.ptr, H.VECTOR_U, H.VECTOR_F, 0.0, 1.0) == 1
+        lo.b.lib.smooth(lo.ptr, H.VECTOR_U, H.VECTOR_F, 0.0, 1.0)
+        same(lh, lo, [H.VECTOR_U], interior_only=True)
+    finally:
+        lh.destroy(); lo.destroy()
+
+
 @pytest.mark.parametrize("variant,geom", [("27pt-cheby", (2, 8)), ("27pt-gsrb", (1, 4)), ("fv4-gsrb", (2, 8)), ("fv4-gsrb", (2, 16)), ("fv4-cheby", (1, 8)),
                                            ("fv2-cheby", (2, 8)), ("fv4-gsrb", (1, 2)), ("27pt-cheby", (1, 2)), ("fv4-gsrb", (2, 32))])
 def test_other_plugins_operator_by_operator(hip, oracle, variant, geom):
