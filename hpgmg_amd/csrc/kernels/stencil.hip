@@ -1228,7 +1228,7 @@ int hpgmg_hip_smooth_gsrb27_rb_supported(const hpgmg_hip_level *L) {
 int hpgmg_hip_smooth_gsrb27_rb(const hpgmg_hip_level *L, int x_id, int out_id, int rhs_id, double a, double b, double h2inv, int sweep) {
   HPGMG_SKIP_IF_REPLAY();
   if (!hpgmg_hip_smooth_gsrb27_rb_supported(L) || x_id == out_id || (sweep & 1)) return record_error(hipErrorInvalidValue, "smooth_gsrb27_rb: level / arguments not supported");
-  static const int TJ = env_int("HPGMG_TUNE_27PT_RB_TJ", 8);
+  constexpr int TJ = 16;                                // rows of a tile; a lane owns two of them
   S27RbArgs A = {};
   A.xn_id = x_id; A.xout_id = out_id; A.rhs_id = rhs_id; A.a = a; A.b = b; A.h2inv = h2inv; A.sweep = sweep;
   A.tiles_i = L->dim / 64; A.tiles_j = L->dim / TJ;
@@ -1241,8 +1241,7 @@ int hpgmg_hip_smooth_gsrb27_rb(const hpgmg_hip_level *L, int x_id, int out_id, i
   const int grid = grid_for(A.total_blocks, &A.per_xcd);
   const long long cells = (long long)L->num_boxes * L->dim * L->dim * L->dim;
   const int prof = profile_begin(cells);
-  if (TJ == 16) hipLaunchKernelGGL((stencil27_rb_kernel<16>), dim3(grid), dim3(64, 16), 0, g_stream, *L, A);
-  else          hipLaunchKernelGGL((stencil27_rb_kernel<8>), dim3(grid), dim3(64, 8), 0, g_stream, *L, A);
+  hipLaunchKernelGGL((stencil27_rb_kernel<TJ>), dim3(grid), dim3(64, TJ / 2), 0, g_stream, *L, A);
   g_rb27_launches++;
   profile_end(prof, 2 * cells);                       // one launch = two half sweeps over every cell
   HPGMG_LAUNCH_CHECK("stencil27_rb_kernel");

@@ -3,7 +3,9 @@
 //
 // The reference runs   exchange + apply_BCs_p2(x);  t = red half sweep of x;  exchange + apply_BCs_p2(t);  x' = black half sweep of t
 // -- two passes of 32 B per cell each (x, rhs, Dinv read; the other vector written in full: the colour not swept is copied).  Here a
-// 64 x TJ workgroup owns a 64 (i) x TJ (j) tile of a box and marches in +k with two stages per step:
+// workgroup of 64 x TJ/2 lanes owns a 64 (i) x TJ (j) tile of a box -- a lane owns two cells, one above the other, hence always one of
+// each colour: every lane has work in both stages, and (the row stride of the LDS planes being 4 mod 16 doubles) the lanes of a wave, which
+// then alternate between two rows, still hit distinct banks -- and marches in +k with two stages per step:
 //   R(q): the red half sweep on plane q, on the tile EXTENDED by one cell in i and j (cells of neighbouring tiles / boxes are recomputed
 //         rather than exchanged), from planes q-1, q, q+1 of x held in LDS with a two-cell halo; the result -- red cells updated, black
 //         cells copied, i.e. the reference's intermediate vector t -- goes to a second LDS ring, never to memory;
@@ -44,13 +46,13 @@ __device__ __forceinline__ double apply27_lds(const double *m, const double *c, 
 }
 
 template <int TJ>
-__global__ __launch_bounds__(64 * TJ) __attribute__((amdgpu_waves_per_eu(4, 8))) void stencil27_rb_kernel(const hpgmg_hip_level L, const S27RbArgs P) {
-  constexpr int TI = 64, NT = TI * TJ;
+__global__ __launch_bounds__(32 * TJ) __attribute__((amdgpu_waves_per_eu(4, 8))) void stencil27_rb_kernel(const hpgmg_hip_level L, const S27RbArgs P) {
+  constexpr int TI = 64, NT = TI * TJ / 2;                        // lanes: one per PAIR of vertically adjacent cells
   constexpr int WO = TI + 4, HO = TJ + 4, PO = WO * HO;          // planes of x: two-cell halo
   constexpr int WP = TI + 2, HP = TJ + 2, PP = WP * HP;          // planes of t: one-cell halo
   constexpr int NHO = 4 * WO + 4 * TJ;                            // halo cells of an x plane (one per lane at most)
   constexpr int NE = 2 * WP + 2 * TJ;                             // ring cells of a t plane (one per lane at most)
-  static_assert(NHO <= NT && NE <= NT, "one extra cell per lane at most");
+  static_assert(NHO <= NT && NE <= NT && TJ % 2 == 0, "one extra cell per lane at most");
   __shared__ double sO[3 * PO];
   __shared__ double sP[3 * PP];
 
@@ -61,7 +63,7 @@ __global__ __launch_bounds__(64 * TJ) __attribute__((amdgpu_waves_per_eu(4, 8)))
   const int tj = t % P.tiles_j; t /= P.tiles_j;
   const int ck = t % P.chunks_k; t /= P.chunks_k;
   const int box = t;
-  const int li = (int)threadIdx.x, lj = (int)threadIdx.y, tid = lj * TI + li;
+  const int li = (int)threadIdx.x, lj = (int)threadIdx.y, tid = lj * TI + li;     // lj: pair of rows 2 lj, 2 lj + 1
   const int i0 = ti * TI, j0 = tj * TJ;
   const int dim = L.dim, jS = L.jStride, kS = L.kStride;
   const int k0 = ck * P.kchunk, k1 = (k0 + P.kchunk < dim) ? k0 + P.kchunk : dim;
@@ -74,16 +76,17 @@ __global__ __launch_bounds__(64 * TJ) __attribute__((amdgpu_waves_per_eu(4, 8)))
   auto side = [&](int c, bool wall_lo, bool wall_hi) { return (c < 0 && wall_lo) ? -1 : ((c >= dim && wall_hi) ? 1 : 0); };
   auto dist = [&](int c) { return c < 0 ? -c : c - dim + 1; };
   const int par0 = (L.box_low[3 * box] ^ L.box_low[3 * box + 1] ^ L.box_low[3 * box + 2] ^ P.sweep) & 1;   // parity offset: cell (i,j,k) of the box is red when ((i^j^k^par0)&1) == 0
-  auto is_red = [&](int gi, int gj, int gk) { return (((gi ^ gj ^ gk ^ par0) & 1) == 0); };
+  auto is_red = [&](int ci, int cj, int ck2) { return (((ci ^ cj ^ ck2 ^ par0) & 1) == 0); };
 
   const double *__restrict__ x = vec_origin(L, box, P.xn_id);
   double *__restrict__ out = vec_origin(L, box, P.xout_id);
   const double *__restrict__ rhs = vec_origin(L, box, P.rhs_id);
   const double *__restrict__ dinv = vec_origin(L, box, VECTOR_DINV);
 
-  // ---- this lane's cells.  (1) its own cell of the tile; (2) at most one halo cell of the x planes; (3) at most one ring cell of the t planes
-  const int gi = i0 + li, gj = j0 + lj, own_g = gi + gj * jS;
-  const int ownO = (lj + 2) * WO + (li + 2), ownP = (lj + 1) * WP + (li + 1);
+  // ---- this lane's cells.  (1) its own two cells (gi, gj) and (gi, gj + 1); (2) at most one halo cell of the x planes; (3) at most one
+  // ring cell of the t planes
+  const int gi = i0 + li, gj = j0 + 2 * lj, own_g = gi + gj * jS;
+  const int ownO = (2 * lj + 2) * WO + (li + 2), ownP = (2 * lj + 1) * WP + (li + 1);     // the upper cell is one row (WO / WP) further
   // (2) halo cell of the x planes
   const bool has_h = tid < NHO;
   int hO = 0, hgi = 0, hgj = 0; bool h_ok = false; GfColumn hcol = {box, 0};
@@ -112,16 +115,21 @@ __global__ __launch_bounds__(64 * TJ) __attribute__((amdgpu_waves_per_eu(4, 8)))
   const bool e_in = has_e && !e_si && !e_sj;                      // ring cell inside the domain (in i and j): R computes it; else it is a ghost of t
 
   auto slot3 = [](int p) { return ((p % 3) + 3) % 3; };
-  // x on plane p (box-relative, -2 <= p <= dim+1) of the own column / the halo column; 0 where nothing is defined
+  // x on plane p (box-relative, -2 <= p <= dim+1) of the own columns / the halo column; 0 where nothing is defined
   auto k_ok = [&](int p) { const int s = side(p, wall_klo, wall_khi); return !(s && dist(p) > 1); };
-  auto x_col = [&](GfColumn c, const double *inbox, int p) -> double {
-    if (p >= 0 && p < dim) return inbox[p * kS];
-    return gf_load_outside(L, P.xn_id, c, p);
-  };
   const double *__restrict__ xo = x + own_g;
   const double *__restrict__ xh = (has_h && h_ok) ? vec_origin(L, hcol.box, P.xn_id) + hcol.off : xo;
-  auto load_x_own = [&](int p) -> double { return k_ok(p) ? x_col(GfColumn{box, own_g}, xo, p) : 0.0; };
-  auto load_x_halo = [&](int p) -> double { return (h_ok && k_ok(p)) ? x_col(hcol, xh, p) : 0.0; };
+  // own column pair on plane p of vector `id` whose in-box pointer (at the lower cell) is `inbox`
+  auto load_own2 = [&](const double *inbox, int id, int p, double &lo, double &hi) {
+    if (p >= 0 && p < dim) { lo = inbox[p * kS]; hi = inbox[p * kS + jS]; }
+    else { lo = gf_load_outside(L, id, GfColumn{box, own_g}, p); hi = gf_load_outside(L, id, GfColumn{box, own_g + jS}, p); }
+  };
+  auto load_x_own2 = [&](int p, double &lo, double &hi) { if (k_ok(p)) load_own2(xo, P.xn_id, p, lo, hi); else { lo = 0.0; hi = 0.0; } };
+  auto load_x_halo = [&](int p) -> double {
+    if (!(h_ok && k_ok(p))) return 0.0;
+    if (p >= 0 && p < dim) return xh[p * kS];
+    return gf_load_outside(L, P.xn_id, hcol, p);
+  };
   // rhs / Dinv of the ring cell on plane p (inside the domain)
   const double *__restrict__ rhs_e = e_in ? vec_origin(L, ecol.box, P.rhs_id) + ecol.off : rhs;
   const double *__restrict__ dinv_e = e_in ? vec_origin(L, ecol.box, VECTOR_DINV) + ecol.off : dinv;
@@ -130,7 +138,7 @@ __global__ __launch_bounds__(64 * TJ) __attribute__((amdgpu_waves_per_eu(4, 8)))
     return gf_load_outside(L, id, ecol, p);
   };
 
-  // apply_BCs_p2 for a ghost cell of t at LDS position `pos` of plane slot ring: (oi, oj, ok) = -1 / 0 / +1 per axis, steps lead back in
+  // apply_BCs_p2 for a ghost cell of t at LDS position `pos` of plane q: (oi, oj, ok) = -1 / 0 / +1 per axis, steps lead back in
   auto t_at = [&](int q, int pos) -> double { return sP[slot3(q) * PP + pos]; };
   auto bc_p2 = [&](int q, int pos, int oi, int oj, int ok) -> double {
     const int di = -oi, dj = -oj * WP, dk = -ok;                   // inward steps: i and j inside a plane, k between planes
@@ -159,72 +167,82 @@ __global__ __launch_bounds__(64 * TJ) __attribute__((amdgpu_waves_per_eu(4, 8)))
 
   // ---- the march.  R works on planes qlo .. qhi (those of t that B needs and that lie inside the domain), B on k0 .. k1-1.
   const int qlo = (k0 == 0 && wall_klo) ? 0 : k0 - 1, qhi = (k1 == dim && wall_khi) ? dim - 1 : k1;
-  // prologue: planes qlo-1 and qlo of x into LDS, plane qlo+1 and the per-cell streams of plane qlo in flight
-  for (int p = qlo - 1; p <= qlo; p++) {
-    sO[slot3(p) * PO + ownO] = load_x_own(p);
+  // prologue: planes qlo-1, qlo, qlo+1 of x into LDS, the per-cell streams of plane qlo in flight
+  for (int p = qlo - 1; p <= qlo + 1; p++) {
+    double lo, hi; load_x_own2(p, lo, hi);
+    sO[slot3(p) * PO + ownO] = lo; sO[slot3(p) * PO + ownO + WO] = hi;
     if (has_h) sO[slot3(p) * PO + hO] = load_x_halo(p);
   }
-  double n_x = load_x_own(qlo + 1), n_h = has_h ? load_x_halo(qlo + 1) : 0.0;
-  double c_rhs = rhs[own_g + (qlo >= 0 && qlo < dim ? qlo * kS : 0)], c_dinv = dinv[own_g + (qlo >= 0 && qlo < dim ? qlo * kS : 0)];
-  if (qlo < 0) { c_rhs = gf_load_outside(L, P.rhs_id, GfColumn{box, own_g}, qlo); c_dinv = gf_load_outside(L, VECTOR_DINV, GfColumn{box, own_g}, qlo); }
-  double e_rhs = e_in ? load_e(rhs_e, P.rhs_id, qlo) : 0.0, e_dinv = e_in ? load_e(dinv_e, VECTOR_DINV, qlo) : 0.0;
-  double b_rhs = 0.0, b_dinv = 0.0;                                // own cell, one plane behind (for B)
+  double b_rhs = 0.0, b_dinv = 0.0;                                // the black cell of the own pair on the plane behind (for B)
+  // does the extended tile reach outside the domain in i or j (then t has ghost cells to be formed on every plane)?  Uniform per workgroup.
+  const bool wall_ij = (wall_ilo && i0 == 0) || (wall_ihi && i0 + TI == dim) || (wall_jlo && j0 == 0) || (wall_jhi && j0 + TJ == dim);
 
+  // Per step three barriers at most: [A] planes q-1 .. q+1 of x are in LDS and B(q-2) is done with the slot R(q) overwrites; [B] t on plane
+  // q is complete inside the domain; [C] (only next to the domain boundary) its ghost cells are formed.
   for (int q = qlo; q <= qhi; q++) {
-    __syncthreads();                                              // everybody is done with the slots plane q+1 of x (and of t) overwrite
-    sO[slot3(q + 1) * PO + ownO] = n_x;
-    if (has_h) sO[slot3(q + 1) * PO + hO] = n_h;
-    // loads of the next step
-    double nn_rhs = 0.0, nn_dinv = 0.0, ne_rhs = 0.0, ne_dinv = 0.0;
-    if (q < qhi) {
-      n_x = load_x_own(q + 2);
-      if (has_h) n_h = load_x_halo(q + 2);
-      const int r = q + 1;
-      if (r >= 0 && r < dim) { nn_rhs = rhs[own_g + r * kS]; nn_dinv = dinv[own_g + r * kS]; }
-      else { nn_rhs = gf_load_outside(L, P.rhs_id, GfColumn{box, own_g}, r); nn_dinv = gf_load_outside(L, VECTOR_DINV, GfColumn{box, own_g}, r); }
-      if (e_in) { ne_rhs = load_e(rhs_e, P.rhs_id, r); ne_dinv = load_e(dinv_e, VECTOR_DINV, r); }
-    }
-    __syncthreads();
+    __syncthreads();                                              // [A]
+    // loads of this step, all consumed at its end or after the 27-point sums: plane q+2 of x (stored into LDS after B, into the slot of plane
+    // q-1) and rhs / Dinv of plane q (the red cell needs them at the end of R(q), the black one a step later in B(q))
+    double n_lo = 0.0, n_hi = 0.0, n_h = 0.0, c_rhs_lo, c_rhs_hi, c_dinv_lo, c_dinv_hi, e_rhs = 0.0, e_dinv = 0.0;
+    if (q < qhi) { load_x_own2(q + 2, n_lo, n_hi); if (has_h) n_h = load_x_halo(q + 2); }
+    load_own2(rhs + own_g, P.rhs_id, q, c_rhs_lo, c_rhs_hi); load_own2(dinv + own_g, VECTOR_DINV, q, c_dinv_lo, c_dinv_hi);
+    if (e_in) { e_rhs = load_e(rhs_e, P.rhs_id, q); e_dinv = load_e(dinv_e, VECTOR_DINV, q); }
 
-    // ---- R(q): t on plane q -- the red cells updated (gsrb.c:90-105), the black ones copied -- own cell and ring cell
+    // ---- R(q): t on plane q -- the red cell of the own pair updated (gsrb.c:90-105), the black one copied -- and the ring cell
+    const int up = is_red(gi, gj, q) ? 0 : 1;                     // 0: the lower cell of the pair is the red one, 1: the upper
     {
       const double *c = sO + slot3(q) * PO, *m = sO + slot3(q - 1) * PO, *pp = sO + slot3(q + 1) * PO;
-      double v = c[ownO];
-      if (is_red(gi, gj, q)) v = v + c_dinv * (c_rhs - apply27_lds<WO>(m + ownO, c + ownO, pp + ownO, P.a, bh2inv));
-      sP[slot3(q) * PP + ownP] = v;
+      const int oR = ownO + up * WO, oB = ownO + (1 - up) * WO;
+      const double r_rhs = up ? c_rhs_hi : c_rhs_lo, r_dinv = up ? c_dinv_hi : c_dinv_lo;
+      const double v = c[oR] + r_dinv * (r_rhs - apply27_lds<WO>(m + oR, c + oR, pp + oR, P.a, bh2inv));
+      sP[slot3(q) * PP + ownP + up * WP] = v;
+      sP[slot3(q) * PP + ownP + (1 - up) * WP] = c[oB];
       if (e_in) {
         double w = c[eO];
         if (is_red(egi, egj, q)) w = w + e_dinv * (e_rhs - apply27_lds<WO>(m + eO, c + eO, pp + eO, P.a, bh2inv));
         sP[slot3(q) * PP + eP] = w;
       }
     }
-    __syncthreads();
-    // ---- ghost cells of t on plane q that lie outside the domain in i and / or j: apply_BCs_p2 from t itself
-    if (has_e && !e_in) sP[slot3(q) * PP + eP] = bc_p2(q, eP, e_si, e_sj, 0);
-    // ---- the ghost PLANE of t below the domain, once planes 0 and 1 exist (its slot is free: plane 2 of t comes later)
-    if (wall_klo && k0 == 0 && q == 1) {
-      sP[slot3(-1) * PP + ownP] = bc_p2(-1, ownP, 0, 0, -1);
-      if (has_e) sP[slot3(-1) * PP + eP] = bc_p2(-1, eP, e_si, e_sj, -1);
+    __syncthreads();                                              // [B]
+    const bool ghost_below = (wall_klo && k0 == 0 && q == 1);
+    if (wall_ij || ghost_below) {
+      // ---- ghost cells of t on plane q that lie outside the domain in i and / or j: apply_BCs_p2 from t itself
+      if (has_e && !e_in) sP[slot3(q) * PP + eP] = bc_p2(q, eP, e_si, e_sj, 0);
+      // ---- the ghost PLANE of t below the domain, once planes 0 and 1 exist (its slot is free: plane 2 of t comes later)
+      if (ghost_below) {
+        sP[slot3(-1) * PP + ownP] = bc_p2(-1, ownP, 0, 0, -1);
+        sP[slot3(-1) * PP + ownP + WP] = bc_p2(-1, ownP + WP, 0, 0, -1);
+        if (has_e) sP[slot3(-1) * PP + eP] = bc_p2(-1, eP, e_si, e_sj, -1);
+      }
+      __syncthreads();                                            // [C]
     }
-    __syncthreads();
 
-    // ---- B(q-1): the black half sweep on the tile proper, from planes q-2, q-1, q of t
-    auto black = [&](int r, double r_rhs, double r_dinv) {
+    // ---- B(r): the black half sweep on the tile proper, from planes r-1, r, r+1 of t: the black cell of the pair updated, the red one stored as it is
+    auto black = [&](int r, double k_rhs, double k_dinv) {
       const double *c = sP + slot3(r) * PP, *m = sP + slot3(r - 1) * PP, *pp = sP + slot3(r + 1) * PP;
-      double v = c[ownP];
-      if (!is_red(gi, gj, r)) v = v + r_dinv * (r_rhs - apply27_lds<WP>(m + ownP, c + ownP, pp + ownP, P.a, bh2inv));
-      out[own_g + r * kS] = v;
+      const int upb = is_red(gi, gj, r) ? 1 : 0;                  // 1: the upper cell of the pair is the black one
+      const int oB = ownP + upb * WP, oR = ownP + (1 - upb) * WP;
+      const double v = c[oB] + k_dinv * (k_rhs - apply27_lds<WP>(m + oB, c + oB, pp + oB, P.a, bh2inv));
+      out[own_g + r * kS + upb * jS] = v;
+      out[own_g + r * kS + (1 - upb) * jS] = c[oR];
     };
     if (q - 1 >= k0 && q - 1 < k1) black(q - 1, b_rhs, b_dinv);
+    // the black cell of plane q is the one R(q) did not use
+    const double kb_rhs = up ? c_rhs_lo : c_rhs_hi, kb_dinv = up ? c_dinv_lo : c_dinv_hi;
     // ---- the top of the domain: the ghost plane above it takes the slot of plane dim-3, which B(dim-2) has just read; then B(dim-1)
     if (wall_khi && k1 == dim && q == dim - 1) {
       __syncthreads();
       sP[slot3(dim) * PP + ownP] = bc_p2(dim, ownP, 0, 0, 1);
+      sP[slot3(dim) * PP + ownP + WP] = bc_p2(dim, ownP + WP, 0, 0, 1);
       if (has_e) sP[slot3(dim) * PP + eP] = bc_p2(dim, eP, e_si, e_sj, 1);
       __syncthreads();
-      black(q, c_rhs, c_dinv);
+      black(q, kb_rhs, kb_dinv);
     }
-    b_rhs = c_rhs; b_dinv = c_dinv; c_rhs = nn_rhs; c_dinv = nn_dinv; e_rhs = ne_rhs; e_dinv = ne_dinv;
+    b_rhs = kb_rhs; b_dinv = kb_dinv;
+    if (q < qhi) {                                                // plane q+2 of x takes the slot of plane q-1, which R(q) read before [B]
+      sO[slot3(q + 2) * PO + ownO] = n_lo; sO[slot3(q + 2) * PO + ownO + WO] = n_hi;
+      if (has_h) sO[slot3(q + 2) * PO + hO] = n_h;
+    }
   }
 }
 
