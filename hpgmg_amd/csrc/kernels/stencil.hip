@@ -1233,7 +1233,9 @@ int hpgmg_hip_smooth_gsrb27_rb(const hpgmg_hip_level *L, int x_id, int out_id, i
   A.xn_id = x_id; A.xout_id = out_id; A.rhs_id = rhs_id; A.a = a; A.b = b; A.h2inv = h2inv; A.sweep = sweep;
   A.tiles_i = L->dim / 64; A.tiles_j = L->dim / TJ;
   int kchunk = L->dim;
-  while (kchunk > 32 && (long long)L->num_boxes * A.tiles_i * A.tiles_j * (L->dim / kchunk) < 4096) kchunk /= 2;
+  // two workgroups fit a CU: 512 workgroups fill the chip, and every k chunk costs three extra planes of loads and a red stage more
+  // (measured at 512^3: whole boxes 1.09 ms, chunks of 64 planes 1.19, of 32 planes 1.27)
+  while (kchunk > 16 && (long long)L->num_boxes * A.tiles_i * A.tiles_j * (L->dim / kchunk) < 512) kchunk /= 2;
   static const int tune_kc = env_int("HPGMG_TUNE_27PT_RB_KCHUNK", 0);
   if (tune_kc > 0 && L->dim % tune_kc == 0) kchunk = tune_kc;
   A.kchunk = kchunk; A.chunks_k = (L->dim + kchunk - 1) / kchunk;
