@@ -270,7 +270,7 @@ def main():
                     "config4": (BYTES_PER_CELL_CHEBY_HELMHOLTZ, "hpgmg::cheby_pair_kernel<VC Helmholtz> (+ its edge-column pre-pass): one launch = TWO Chebyshev sweeps"),
                     "config5": (52, "hpgmg::cheby_pair_kernel<VC Helmholtz, fp32 coefficient streams> (+ pre-pass): one launch = TWO Chebyshev sweeps"),
                     "config3-fv4": (56, "hpgmg::fv4_tile_kernel<VC Poisson, GSRB>: one out-of-place coloured half sweep (x, rhs, Dinv, beta_i/j/k read + x written)"),
-                    "config3-27pt": (32, "hpgmg::stencil27_tile_kernel<GSRB>: one out-of-place coloured half sweep (x, rhs, Dinv read + x written)")}[args.workload]
+                    "config3-27pt": (32, "hpgmg::stencil27_rb_kernel: one launch = BOTH coloured half sweeps of an out-of-place GSRB sweep (each, done separately: x, rhs, Dinv read + x written; the intermediate vector stays in LDS)")}[args.workload]
         if launches.value > 0 and ms.value > 0:
             avg_s = ms.value * 1e-3 / launches.value
             # cells.value counts cell-sweeps: the sweep-pair kernel reports two sweeps per launch

@@ -39,7 +39,7 @@ def main():
     cells = int(sys.argv[sys.argv.index("--cells") + 1]) if "--cells" in sys.argv else 256 ** 3
     rows = {"cheby_pair_fine": ("cheby_pair_kernel", 144), "cheby_pair_edge_columns": ("cheby_pair_edge_kernel", 0), "cheby_fine": ("stencil7_wide_kernelILi0ELi0", 72), "residual_fine": ("stencil7_wide_kernelILi0ELi3", 56),
             "residual_restrict_zero_fine": ("stencil7_wide_kernelILi0ELi6", 58), "residual_norm_fine": ("stencil7_wide_kernelILi0ELi7", 56),
-            "norm_copy_restrict_fine": ("norm_copy_restrict_kernel", 17), "fv4_gsrb_fine": ("fv4_tile_kernelILi5ELi1", 56), "stencil27_gsrb_fine": ("stencil27_tile_kernelILi1", 32),
+            "norm_copy_restrict_fine": ("norm_copy_restrict_kernel", 17), "fv4_gsrb_fine": ("fv4_tile_kernelILi5ELi1", 56), "stencil27_gsrb_fine": ("stencil27_tile_kernelILi1", 32), "stencil27_rb_fine": ("stencil27_rb_kernel", 64),
             "scale_fine": ("elementwise_kernelILi3", 16), "interp_p0_fine": ("interp_blocks_kernelILi0", 17),
             "interp_p1_fine": ("interp_blocks_kernelILi1", 17), "restrict_fine": ("restrict_blocks_kernelILi0", 9), "norm_fine": ("absmax_kernel", 8)}
     res = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), MI355X",
@@ -60,6 +60,8 @@ def main():
         res["sweeps_per_launch"] = 2
     elif "fv4_gsrb_fine" in k:
         res["hbm_bytes_per_launch_smoother_fine"] = k["fv4_gsrb_fine"]["hbm_bytes_per_launch"]; res["sweeps_per_launch"] = 1
+    elif "stencil27_rb_fine" in k:      # one launch = both coloured half sweeps
+        res["hbm_bytes_per_launch_smoother_fine"] = k["stencil27_rb_fine"]["hbm_bytes_per_launch"]; res["sweeps_per_launch"] = 2
     elif "stencil27_gsrb_fine" in k:
         res["hbm_bytes_per_launch_smoother_fine"] = k["stencil27_gsrb_fine"]["hbm_bytes_per_launch"]; res["sweeps_per_launch"] = 1
     elif "cheby_fine" in k:
