@@ -937,6 +937,21 @@ static void pair_halo_before_launch(level_type *L, backend_t *B, int first, int 
 static long long pair_remote_smooths = 0;
 long long hpgmg_pair_remote_smooths(void) { return pair_remote_smooths; }   /* smooth() calls done as sweep pairs with remote faces (tests) */
 
+/* the two plugin-private vectors per box that hold x1, x2 of the first sweep pair of a smooth() */
+static void ensure_pair_scratch(level_type *L, backend_t *B) {
+  if (!B->pair_scratch) {
+    int bx;
+    double **base = (double **)calloc((size_t)L->num_my_boxes, sizeof(double *));
+    B->pair_scratch = (double *)hpgmg_hip_malloc(((size_t)L->num_my_boxes * 2 * (size_t)L->box_volume + 2) * sizeof(double));
+    B->d_pair_base = (double **)hpgmg_hip_malloc((size_t)L->num_my_boxes * sizeof(double *));
+    if (!B->pair_scratch || !B->d_pair_base) { fprintf(stderr, "hpgmg: no memory for the sweep-pair scratch vectors\n"); abort(); }
+    /* the vector bases share the level's alignment class so the first interior cell is 16-byte aligned here too */
+    const size_t pad = ((uintptr_t)L->my_boxes[0].vectors[0] % 16) / sizeof(double);
+    for (bx = 0; bx < L->num_my_boxes; bx++) base[bx] = B->pair_scratch + pad + (size_t)bx * 2 * (size_t)L->box_volume;
+    HIP_OK(hpgmg_hip_memcpy_h2d(B->d_pair_base, base, (size_t)L->num_my_boxes * sizeof(double *)));
+    free(base);
+  }
+}
 static int fused_sweeps = -1;
 void hpgmg_set_fused_sweeps(int on) { fused_sweeps = on ? 1 : 0; }
 /* common part: does the level qualify for the sweep-pair kernel, and are its two private vectors there? */
@@ -955,19 +970,32 @@ static int pair_kernel_ready(level_type *L, int x_id, int rhs_id, int sweeps) {
     if (min_cells < 0) { const char *e = getenv("HPGMG_PAIR_MIN_CELLS"); min_cells = (e && *e) ? atoll(e) : 4000000; }
     if ((long long)L->dim.i * L->dim.j * L->dim.k < min_cells) return 0;
   }
-  if (!B->pair_scratch) {
-    int bx;
-    double **base = (double **)calloc((size_t)L->num_my_boxes, sizeof(double *));
-    B->pair_scratch = (double *)hpgmg_hip_malloc(((size_t)L->num_my_boxes * 2 * (size_t)L->box_volume + 2) * sizeof(double));
-    B->d_pair_base = (double **)hpgmg_hip_malloc((size_t)L->num_my_boxes * sizeof(double *));
-    if (!B->pair_scratch || !B->d_pair_base) { fprintf(stderr, "hpgmg: no memory for the sweep-pair scratch vectors\n"); abort(); }
-    /* the vector bases share the level's alignment class so the first interior cell is 16-byte aligned here too */
-    const size_t pad = ((uintptr_t)L->my_boxes[0].vectors[0] % 16) / sizeof(double);
-    for (bx = 0; bx < L->num_my_boxes; bx++) base[bx] = B->pair_scratch + pad + (size_t)bx * 2 * (size_t)L->box_volume;
-    HIP_OK(hpgmg_hip_memcpy_h2d(B->d_pair_base, base, (size_t)L->num_my_boxes * sizeof(double *)));
-    free(base);
-  }
+  ensure_pair_scratch(L, B);
   hpgmg_hip_set_ghost_free(1);
+  return 1;
+}
+
+/* The same two-sweeps-per-launch scheme on cache-resident levels (boxes of side 64 m on one rank; kernels/stencil7_pair_tile.hpp): small
+ * tiles that recompute x1 on a one-cell rim.  Vector traffic and states as in smooth_cheby_pairs() below.  0 = not applicable. */
+static int temp_is_scratch = 0;
+static int smooth_cheby_tile_pairs(level_type *L, int x_id, int rhs_id, double a, double b, const double *c1, const double *c2, int sweeps) {
+  hpgmg_config cfg;
+  hpgmg_get_config(&cfg);
+  if (fused_sweeps < 0) { const char *e = getenv("HPGMG_FUSED_SWEEPS"); fused_sweeps = !(e && e[0] == '0'); }
+  if (!fused_sweeps || sweeps != 4 || cfg.op != HPGMG_OP_7PT || !ghost_free_mode() || stencil_get_shape() != STENCIL_SHAPE_STAR) return 0;
+  if (L->boundary_condition.type != BC_DIRICHLET || x_id == VECTOR_TEMP || rhs_id == VECTOR_TEMP || L->num_my_boxes < 1) return 0;
+  backend_t *B = backend_of(L);
+  if (!B->all_faces_local || !hpgmg_hip_smooth_cheby_pair_tile_supported(&B->dev, variant())) return 0;
+  ensure_pair_scratch(L, B);
+  hpgmg_hip_set_ghost_free(1);
+  const double h2inv = 1.0 / (L->h * L->h);
+  const int v = variant();
+  { TICK(L, smooth, "smooth (Chebyshev sweeps 1+2, tiles)");
+    HIP_OK(hpgmg_hip_smooth_cheby_pair_tile(&B->dev, v, (double *const *)B->d_pair_base, 0, x_id, 0, VECTOR_TEMP, 1, 0, 1, 1, rhs_id, a, b, h2inv, c1[0], c2[0], c1[1], c2[1], 1));
+    TOCK(); }
+  { TICK(L, smooth, "smooth (Chebyshev sweeps 3+4, tiles)");
+    HIP_OK(hpgmg_hip_smooth_cheby_pair_tile(&B->dev, v, (double *const *)B->d_pair_base, 1, 1, 1, 0, 0, VECTOR_TEMP, 0, x_id, rhs_id, a, b, h2inv, c1[2], c2[2], c1[3], c2[3], temp_is_scratch ? 0 : 1));
+    TOCK(); }
   return 1;
 }
 
@@ -976,7 +1004,6 @@ static int pair_kernel_ready(level_type *L, int x_id, int rhs_id, int sweeps) {
  * x4 -> x_id, i.e. exactly the state chebyshev.c:43-99 leaves.  Returns 0 when the level does not qualify. */
 /* smooth() called by the cycle driver through hpgmg_smooth_in_cycle(): VECTOR_TEMP (x3 of the four sweeps) is dead after it, so the second
  * pair does not store it */
-static int temp_is_scratch = 0;
 static int smooth_cheby_pairs(level_type *L, int x_id, int rhs_id, double a, double b, const double *c1, const double *c2, int sweeps) {
   if (!pair_kernel_ready(L, x_id, rhs_id, sweeps)) return 0;
   backend_t *B = backend_of(L);
@@ -1110,6 +1137,7 @@ void smooth(level_type *L, int x_id, int rhs_id, double a, double b) {
     if (L->dominant_eigenvalue_of_DinvA <= 0.0 && L->my_rank == 0) fprintf(stderr, "dominant_eigenvalue_of_DinvA <= 0.0 !\n");
     cheby_coefficients(L, sweeps, c1, c2);
     if (smooth_cheby_pairs(L, x_id, rhs_id, a, b, c1, c2, sweeps)) return;
+    if (smooth_cheby_tile_pairs(L, x_id, rhs_id, a, b, c1, c2, sweeps)) return;
     for (s = 0; s < sweeps; s++) {
       const int src = (s & 1) ? VECTOR_TEMP : x_id, dst = (s & 1) ? x_id : VECTOR_TEMP;
       STENCIL_WITH_GHOSTS(L, src, dst, smooth, hpgmg_hip_smooth_cheby(&B->dev, v, src, dst, rhs_id, a, b, h2inv, c1[s], c2[s]));

@@ -27,6 +27,7 @@
 #include "cheby_pair.hpp"
 #include "fv4_tile.hpp"
 #include "stencil27_rb.hpp"
+#include "stencil7_pair_tile.hpp"
 #include "stencil7_tile.hpp"
 #include "block_ops.hpp"
 
@@ -1139,6 +1140,51 @@ int hpgmg_hip_smooth_cheby_pair(const hpgmg_hip_level *L, int variant, double *c
                                 int x0_scr, int x0_id, int xm1_scr, int xm1_id, int out1_scr, int out1_id, int out2_scr, int out2_id,
                                 int rhs_id, double a, double b, double h2inv, double c1a, double c2a, double c1b, double c2b) {
   return smooth_pair(L, variant, 0, 0, scr_base, c32_base, x0_scr, x0_id, xm1_scr, xm1_id, out1_scr, out1_id, out2_scr, out2_id, rhs_id, a, b, h2inv, c1a, c2a, c1b, c2b);
+}
+// Two Chebyshev sweeps in one launch on a cache-resident level (stencil7_pair_tile.hpp): boxes of side 64 m, every box local, Dirichlet.
+// Same arguments as hpgmg_hip_smooth_cheby_pair (fp64 coefficients); keep_x1 = 0 when the caller declared out1 scratch.
+static long long g_pair_tile_launches = 0;
+long long hpgmg_hip_pair_tile_launch_count(void) { return g_pair_tile_launches; }
+// OFF by default: measured on the 128^3 level of config 2 a pair launch takes 63 us against 2 x 26 us for the single-sweep tiled kernel
+// (3.45 vs 3.32 ms per F-cycle; longer k chunks are worse still: 3.65 / 4.19 / 5.26 ms at 16 / 32 / 64 planes) -- that level is cache
+// resident and latency bound, and a pair step issues twice the loads of a single-sweep step before its first barrier.
+// HPGMG_TUNE_7PT_PAIR_TILE=1 or hpgmg_hip_set_pair_tile(1) enables it (bit-identical; the tests do).
+static int g_pair_tile_on = -1;
+void hpgmg_hip_set_pair_tile(int on) { g_pair_tile_on = on ? 1 : 0; }
+int hpgmg_hip_smooth_cheby_pair_tile_supported(const hpgmg_hip_level *L, int variant) {
+  if (g_pair_tile_on < 0) g_pair_tile_on = env_int("HPGMG_TUNE_7PT_PAIR_TILE", 0) ? 1 : 0;
+  const int off = !g_pair_tile_on;
+  if (variant != HPGMG_HIP_7PT_VC_HELMHOLTZ && variant != HPGMG_HIP_7PT_VC_POISSON && variant != HPGMG_HIP_7PT_CC) return 0;
+  return !off && L->num_boxes > 0 && L->dim % 64 == 0 && L->box_nbr != nullptr && !L->periodic && L->ghosts >= 1;
+}
+int hpgmg_hip_smooth_cheby_pair_tile(const hpgmg_hip_level *L, int variant, double *const *scr_base,
+                                     int x0_scr, int x0_id, int xm1_scr, int xm1_id, int out1_scr, int out1_id, int out2_scr, int out2_id,
+                                     int rhs_id, double a, double b, double h2inv, double c1a, double c2a, double c1b, double c2b, int keep_x1) {
+  HPGMG_SKIP_IF_REPLAY();
+  if (!hpgmg_hip_smooth_cheby_pair_tile_supported(L, variant)) return record_error(hipErrorInvalidValue, "smooth_cheby_pair_tile: level not supported");
+  constexpr int TJ = 8;
+  S7PairTileArgs A = {};
+  A.x0 = VecRef{x0_scr, x0_id}; A.xm1 = VecRef{xm1_scr, xm1_id}; A.out1 = VecRef{out1_scr, out1_id}; A.out2 = VecRef{out2_scr, out2_id};
+  A.rhs_id = rhs_id; A.keep_x1 = keep_x1; A.a = a; A.b = b; A.h2inv = h2inv; A.c1a = c1a; A.c2a = c2a; A.c1b = c1b; A.c2b = c2b; A.scr_base = scr_base;
+  A.tiles_i = L->dim / 64; A.tiles_j = L->dim / TJ;
+  static const int tune_kc = env_int("HPGMG_TUNE_7PT_PAIR_TILE_KCHUNK", 0);
+  int kchunk = L->dim;
+  while (kchunk > 8 && (long long)L->num_boxes * A.tiles_i * A.tiles_j * (L->dim / kchunk) < 512) kchunk /= 2;
+  if (tune_kc > 0 && L->dim % tune_kc == 0) kchunk = tune_kc;
+  A.kchunk = kchunk; A.chunks_k = (L->dim + kchunk - 1) / kchunk;
+  A.total_blocks = L->num_boxes * A.chunks_k * A.tiles_j * A.tiles_i;
+  const int grid = grid_for(A.total_blocks, &A.per_xcd);
+  const long long cells = (long long)L->num_boxes * L->dim * L->dim * L->dim;
+  const int prof = profile_begin(cells);
+  switch (variant) {
+    case HPGMG_HIP_7PT_VC_HELMHOLTZ: hipLaunchKernelGGL((stencil7_pair_tile_kernel<HPGMG_HIP_7PT_VC_HELMHOLTZ, TJ>), dim3(grid), dim3(64, TJ), 0, g_stream, *L, A); break;
+    case HPGMG_HIP_7PT_VC_POISSON:   hipLaunchKernelGGL((stencil7_pair_tile_kernel<HPGMG_HIP_7PT_VC_POISSON, TJ>), dim3(grid), dim3(64, TJ), 0, g_stream, *L, A); break;
+    default:                         hipLaunchKernelGGL((stencil7_pair_tile_kernel<HPGMG_HIP_7PT_CC, TJ>), dim3(grid), dim3(64, TJ), 0, g_stream, *L, A); break;
+  }
+  g_pair_tile_launches++;
+  profile_end(prof, 2 * cells);
+  HPGMG_LAUNCH_CHECK("stencil7_pair_tile_kernel");
+  return 0;
 }
 void hpgmg_hip_pair_fold_interpolation(const hpgmg_hip_level *Lc, int coarse_id, double prescale) {
   g_pair_interp_level = Lc; g_pair_interp_id = coarse_id; g_pair_interp_prescale = prescale;

@@ -152,6 +152,15 @@ int hpgmg_hip_smooth_cheby_pair_supported(const hpgmg_hip_level *L, int variant)
 int hpgmg_hip_smooth_cheby_pair(const hpgmg_hip_level *L, int variant, double *const *scr_base, const float *const *c32_base,
                                 int x0_scr, int x0_id, int xm1_scr, int xm1_id, int out1_scr, int out1_id, int out2_scr, int out2_id,
                                 int rhs_id, double a, double b, double h2inv, double c1a, double c2a, double c1b, double c2b);
+/* The same two sweeps for cache-resident levels (boxes of side 64 m, every box local, Dirichlet; kernels/stencil7_pair_tile.hpp): small
+ * tiles that recompute x1 on a one-cell rim instead of exchanging it.  keep_x1 = 0: out1 is scratch, x1 is not stored.  Off by default
+ * (slower than two single-sweep launches on the 128^3 level it was written for); supported() is 0 until set_pair_tile(1). */
+void hpgmg_hip_set_pair_tile(int on);
+int hpgmg_hip_smooth_cheby_pair_tile_supported(const hpgmg_hip_level *L, int variant);
+int hpgmg_hip_smooth_cheby_pair_tile(const hpgmg_hip_level *L, int variant, double *const *scr_base,
+                                     int x0_scr, int x0_id, int xm1_scr, int xm1_id, int out1_scr, int out1_id, int out2_scr, int out2_id,
+                                     int rhs_id, double a, double b, double h2inv, double c1a, double c2a, double c1b, double c2b, int keep_x1);
+long long hpgmg_hip_pair_tile_launch_count(void);   /* launches of that kernel so far (tests) */
 /* Sweep pairs across rank boundaries (boxes over the GPUs of a node, halo exchange over RCCL).  This rank's boxes form a
  * brick of brick_boxes[0..2] boxes (numbered lexicographically inside it); remote_face[f] (f = -i,+i,-j,+j,-k,+k) is 1 where the
  * brick face belongs to another rank, 0 where it is the (Dirichlet) domain boundary.  Before the launch the caller must have

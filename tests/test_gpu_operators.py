@@ -107,6 +107,36 @@ def test_fused_chebyshev_sweep_pairs(hip, oracle, variant, geom):
         lh.destroy(); lo.destroy()
 
 
+@pytest.mark.parametrize("variant,geom", [("7pt-cheby-helm", (2, 64)), ("7pt-cheby", (1, 64)), ("7ptcc-cheby", (2, 64)), ("7pt-cheby-helm", (3, 64)),
+                                          ("7pt-cheby-helm", (1, 128)), ("7pt-cheby", (3, 64))])
+def test_chebyshev_sweep_pairs_on_cache_resident_levels(hip, oracle, variant, geom):
+    """Levels too small for the row-wise sweep-pair kernel (below 4 M cells, or rows that are no multiple of 128 cells) but made of boxes of
+    side 64 m run their Chebyshev smooth() as two launches of two sweeps each in tile form (stencil7_pair_tile.hpp): U and VECTOR_TEMP must
+    equal the oracle's four separate sweeps bit for bit; the in-cycle form (x3 not stored) must give the same iterate."""
+    K = H.load_kernels()
+    K.hpgmg_hip_pair_tile_launch_count.restype = ctypes.c_longlong
+    K.hpgmg_hip_set_pair_tile.argtypes = [ctypes.c_int]
+    K.hpgmg_hip_set_pair_tile(1)          # opt-in: on the 128^3 level of config 2 it measured slower than two single-sweep launches
+    hip.lib.hpgmg_smooth_in_cycle.restype = ctypes.c_int
+    hip.lib.hpgmg_smooth_in_cycle.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double]
+    lh, lo = make_pair(hip, oracle, variant, *geom, seed=17)
+    try:
+        a, b = (1.0, 1.0) if "helm" in variant else (0.0, 1.0)
+        for lv in (lh, lo):
+            lv.b.lib.rebuild_operator(lv.ptr, None, a, b)
+        n0 = K.hpgmg_hip_pair_tile_launch_count()
+        for lv in (lh, lo):
+            lv.b.lib.smooth(lv.ptr, H.VECTOR_U, H.VECTOR_F, a, b)
+        assert K.hpgmg_hip_pair_tile_launch_count() - n0 == 2
+        same(lh, lo, [H.VECTOR_U, H.VECTOR_TEMP], interior_only=True)
+        assert hip.lib.hpgmg_smooth_in_cycle(lh.ptr, H.VECTOR_U, H.VECTOR_F, a, b) == 1
+        lo.b.lib.smooth(lo.ptr, H.VECTOR_U, H.VECTOR_F, a, b)
+        same(lh, lo, [H.VECTOR_U], interior_only=True)
+    finally:
+        K.hpgmg_hip_set_pair_tile(0)
+        lh.destroy(); lo.destroy()
+
+
 @pytest.mark.parametrize("geom", GEOMS)
 @pytest.mark.parametrize("shape", [H.STENCIL_SHAPE_BOX, H.STENCIL_SHAPE_STAR, H.STENCIL_SHAPE_NO_CORNERS])
 def test_exchange_and_boundary_conditions(hip, oracle, geom, shape):
