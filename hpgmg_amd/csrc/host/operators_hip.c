@@ -336,9 +336,9 @@ static int exchange_and_bcs_one_launch(level_type *L, int id, int shape, int ord
   static int merge = -1;
   if (merge < 0) { const char *e = getenv("HPGMG_ONE_LAUNCH_GHOSTS"); merge = !(e && e[0] == '0'); }
   if (!merge || !ghost_free_mode() || L->num_my_boxes < 1 || L->boundary_condition.type == BC_PERIODIC) return 0;
-  if (order == 12 && !(L->box_dim >= 2 && L->box_ghosts == 1)) return 0;      /* below: the fall-backs of apply_BCs_p2 / v2 / v4 for tiny boxes, */
-  if (order == 2 && !(L->box_dim >= 2 && L->box_ghosts <= 1)) return 0;       /* and ghost zones deeper than the condition fills (cleared first) */
-  if (order == 4 && !(L->box_dim >= 4 && L->box_ghosts <= 2)) return 0;
+  if (order == 12 && !(L->box_dim >= 2 && L->box_ghosts == 1)) return 0;      /* the fall-backs of apply_BCs_p2 / v2 / v4 for tiny boxes stay separate launches */
+  if (order == 2 && !(L->box_dim >= 2)) return 0;
+  if (order == 4 && !(L->box_dim >= 4)) return 0;
   communicator_type *C = &L->exchange_ghosts[shape];
   if (C->num_sends + C->num_recvs > 0 || C->num_blocks[0] || C->num_blocks[2]) return 0;
   backend_t *B = backend_of(L);
@@ -493,6 +493,7 @@ static const hpgmg_hip_bc_entry *bc_entries(level_type *L, int shape, int *n_out
     hpgmg_hip_bc_entry *o = &h[m++];
     int ax, nf = 0;
     o->box = e->read.box; o->nn = 0; o->base = 0; o->len0 = o->len1 = 1; o->fs0 = o->fs1 = 0;
+    o->zbase = lo[0] * strides[0] + lo[1] * strides[1] + lo[2] * strides[2]; o->zi = len[0]; o->zj = len[1]; o->zk = len[2];
     int nbr[3] = {0, 0, 0};                  /* in-face axes whose range lies in the ghost zone: the block runs along that neighbour's face */
     for (ax = 0; ax < 3; ax++) {
       if (d[ax]) { o->base += (d[ax] < 0 ? -1 : L->box_dim) * strides[ax]; o->step[o->nn++] = -d[ax] * strides[ax]; }
@@ -531,8 +532,7 @@ void apply_BCs_v2(level_type *L, int x_id, int shape) {                         
   if (L->box_dim < 2) { apply_BCs_v1(L, x_id, shape); return; }
   TICK(L, boundary_conditions, "apply_BCs_v2");
   int n = L->boundary_condition.num_blocks[shape];
-  if (L->box_ghosts <= 1) { const hpgmg_hip_bc_entry *e = bc_entries(L, shape, &n); HIP_OK(hpgmg_hip_apply_bc_fv(&backend_of(L)->dev, x_id, e, n, 2)); }
-  else HIP_OK(hpgmg_hip_apply_bc_v2(&backend_of(L)->dev, x_id, mirror(L, L->boundary_condition.blocks[shape], n), n));   /* clears the deeper layers first */
+  { const hpgmg_hip_bc_entry *e = bc_entries(L, shape, &n); HIP_OK(hpgmg_hip_apply_bc_fv(&backend_of(L)->dev, x_id, e, n, 2)); }   /* clears the deeper layers first when there are any */
   TOCK();
 }
 void apply_BCs_v4(level_type *L, int x_id, int shape) {                                   /* boundary_fv.c:262-569 */
@@ -542,8 +542,7 @@ void apply_BCs_v4(level_type *L, int x_id, int shape) {                         
   if (L->box_dim < 4) { apply_BCs_v2(L, x_id, shape); return; }
   TICK(L, boundary_conditions, "apply_BCs_v4");
   int n = L->boundary_condition.num_blocks[shape];
-  if (L->box_ghosts <= 2) { const hpgmg_hip_bc_entry *e = bc_entries(L, shape, &n); HIP_OK(hpgmg_hip_apply_bc_fv(&backend_of(L)->dev, x_id, e, n, 4)); }
-  else HIP_OK(hpgmg_hip_apply_bc_v4(&backend_of(L)->dev, x_id, mirror(L, L->boundary_condition.blocks[shape], n), n));   /* clears the deeper layers first */
+  { const hpgmg_hip_bc_entry *e = bc_entries(L, shape, &n); HIP_OK(hpgmg_hip_apply_bc_fv(&backend_of(L)->dev, x_id, e, n, 4)); }   /* clears the deeper layers first when there are any */
   TOCK();
 }
 void extrapolate_betas(level_type *L) {                                                    /* boundary_fv.c:573-681 */

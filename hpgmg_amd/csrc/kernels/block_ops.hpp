@@ -232,8 +232,17 @@ template <int ORDER, int NN>
 __device__ __forceinline__ void bc_compact_cell(const double *x, double *xw, int ijk, int s0, int s1, int s2) {
   if (ORDER == 4) bc_v4_cell<NN>(x, xw, ijk, s0, s1, s2); else if (ORDER == 2) bc_v2_cell<NN>(x, xw, ijk, s0, s1, s2); else bc_p2_cell<NN>(x, xw, ijk, s0, s1, s2);
 }
-template <int ORDER, bool REDIRECT>
+template <int ORDER, bool REDIRECT, bool CLEAR = false>
 __device__ __forceinline__ void bc_fv_compact_entry(const hpgmg_hip_level &L, int id, const hpgmg_hip_bc_entry &e, int tid, int nth) {
+  if (CLEAR) {   // boundary_fv.c: the deeper ghost layers of the block are zero; the whole workgroup works on one entry, so a barrier orders the two passes
+    double *z = vec_origin(L, e.box, id) + e.zbase;
+    const int nz = e.zi * e.zj * e.zk;
+    for (int t = tid; t < nz; t += nth) {
+      const int i = t % e.zi, j = (t / e.zi) % e.zj, k = t / (e.zi * e.zj);
+      z[i + j * L.jStride + k * L.kStride] = 0.0;
+    }
+    __syncthreads();
+  }
   double *xw = vec_origin(L, e.box, id) + e.base;                                  // where the ghost cells are
   // where the cells they are formed from are read (same offsets): the entry's own box as apply_BCs does, or -- REDIRECT, the one-launch
   // form that does not wait for the exchange -- the box that owns them

@@ -33,18 +33,18 @@ __global__ __launch_bounds__(256) void bc_v4_kernel(const hpgmg_hip_level L, int
   if (L.ghosts > 2) { bc_zero_entry(L, id, list[blockIdx.x], (int)threadIdx.x, (int)blockDim.x); __syncthreads(); }
   bc_v4_entry(L, id, list[blockIdx.x], (int)threadIdx.x, (int)blockDim.x);
 }
-template <int ORDER>
+template <int ORDER, bool CLEAR>
 __global__ __launch_bounds__(256) void bc_fv_kernel(const hpgmg_hip_level L, int id, const hpgmg_hip_bc_entry *__restrict__ list) {
-  bc_fv_compact_entry<ORDER, false>(L, id, list[blockIdx.x], (int)threadIdx.x, 256);
+  bc_fv_compact_entry<ORDER, false, CLEAR>(L, id, list[blockIdx.x], (int)threadIdx.x, 256);
 }
 // exchange_boundary's box-to-box copies and the boundary conditions of the same vector in one launch: the first n_copy workgroups run
 // a copy entry each, the others a condition entry.  The two touch disjoint ghost cells and read interior cells only (the host has
 // redirected the conditions that run along another box's face to that box, see hpgmg_hip_bc_entry), so no order is needed between them.
-template <int ORDER>
+template <int ORDER, bool CLEAR>
 __global__ __launch_bounds__(256) void ghost_fill_kernel(const hpgmg_hip_level L, int id, const blockCopy_type *__restrict__ copies, int n_copy,
                                                          const hpgmg_hip_bc_entry *__restrict__ list) {
   if ((int)blockIdx.x < n_copy) copy_entry<false>(L, id, copies[blockIdx.x], 0.0, (int)threadIdx.x, 256);
-  else bc_fv_compact_entry<ORDER, true>(L, id, list[(int)blockIdx.x - n_copy], (int)threadIdx.x, 256);
+  else bc_fv_compact_entry<ORDER, true, CLEAR>(L, id, list[(int)blockIdx.x - n_copy], (int)threadIdx.x, 256);
 }
 
 // boundary_fv.c:573-681 extrapolate_betas.  The reference updates each block IN PLACE in k,j,i order, so a
@@ -329,25 +329,37 @@ int hpgmg_hip_apply_bc_v4(const hpgmg_hip_level *L, int id, const blockCopy_type
   HPGMG_LAUNCH_CHECK("bc_v4_kernel");
   return 0;
 }
+// 0: launch without clearing, 1: with, -1: not supported (p2 is defined for one ghost layer only)
+static int bc_fv_clear_mode(const hpgmg_hip_level *L, int order) {
+  if (order != 2 && order != 4 && order != 12) return -1;
+  const int fills = (order == 4) ? 2 : 1;
+  if (L->ghosts <= fills) return 0;
+  return (order == 12) ? -1 : 1;
+}
 int hpgmg_hip_apply_bc_fv(const hpgmg_hip_level *L, int id, const hpgmg_hip_bc_entry *entries, int n, int order) {
   HPGMG_SKIP_IF_REPLAY();
   if (n <= 0) return 0;
-  const int fills = (order == 4) ? 2 : 1;
-  if (L->ghosts > fills || (order != 2 && order != 4 && order != 12)) return record_error(hipErrorInvalidValue, "apply_bc_fv: ghost zone deeper than the condition fills");
-  if (order == 4)      hipLaunchKernelGGL(bc_fv_kernel<4>, dim3(n), dim3(256), 0, g_stream, *L, id, entries);
-  else if (order == 2) hipLaunchKernelGGL(bc_fv_kernel<2>, dim3(n), dim3(256), 0, g_stream, *L, id, entries);
-  else                 hipLaunchKernelGGL(bc_fv_kernel<12>, dim3(n), dim3(256), 0, g_stream, *L, id, entries);
+  const int clear = bc_fv_clear_mode(L, order);
+  if (clear < 0) return record_error(hipErrorInvalidValue, "apply_bc_fv: order / ghost depth not supported");
+  if (order == 4 && clear)      hipLaunchKernelGGL((bc_fv_kernel<4, true>), dim3(n), dim3(256), 0, g_stream, *L, id, entries);
+  else if (order == 4)          hipLaunchKernelGGL((bc_fv_kernel<4, false>), dim3(n), dim3(256), 0, g_stream, *L, id, entries);
+  else if (order == 2 && clear) hipLaunchKernelGGL((bc_fv_kernel<2, true>), dim3(n), dim3(256), 0, g_stream, *L, id, entries);
+  else if (order == 2)          hipLaunchKernelGGL((bc_fv_kernel<2, false>), dim3(n), dim3(256), 0, g_stream, *L, id, entries);
+  else                          hipLaunchKernelGGL((bc_fv_kernel<12, false>), dim3(n), dim3(256), 0, g_stream, *L, id, entries);
   HPGMG_LAUNCH_CHECK("bc_fv_kernel");
   return 0;
 }
 int hpgmg_hip_exchange_and_bc(const hpgmg_hip_level *L, int id, const blockCopy_type *copies, int n_copy, const hpgmg_hip_bc_entry *entries, int n, int order) {
   HPGMG_SKIP_IF_REPLAY();
   if (n <= 0) return hpgmg_hip_copy_blocks(L, id, copies, n_copy);
-  const int fills = (order == 4) ? 2 : 1;
-  if (L->ghosts > fills || (order != 2 && order != 4 && order != 12)) return record_error(hipErrorInvalidValue, "exchange_and_bc: ghost zone deeper than the condition fills");
-  if (order == 4)      hipLaunchKernelGGL(ghost_fill_kernel<4>, dim3(n_copy + n), dim3(256), 0, g_stream, *L, id, copies, n_copy, entries);
-  else if (order == 2) hipLaunchKernelGGL(ghost_fill_kernel<2>, dim3(n_copy + n), dim3(256), 0, g_stream, *L, id, copies, n_copy, entries);
-  else                 hipLaunchKernelGGL(ghost_fill_kernel<12>, dim3(n_copy + n), dim3(256), 0, g_stream, *L, id, copies, n_copy, entries);
+  const int clear = bc_fv_clear_mode(L, order);
+  if (clear < 0) return record_error(hipErrorInvalidValue, "exchange_and_bc: order / ghost depth not supported");
+  const dim3 grid(n_copy + n);
+  if (order == 4 && clear)      hipLaunchKernelGGL((ghost_fill_kernel<4, true>), grid, dim3(256), 0, g_stream, *L, id, copies, n_copy, entries);
+  else if (order == 4)          hipLaunchKernelGGL((ghost_fill_kernel<4, false>), grid, dim3(256), 0, g_stream, *L, id, copies, n_copy, entries);
+  else if (order == 2 && clear) hipLaunchKernelGGL((ghost_fill_kernel<2, true>), grid, dim3(256), 0, g_stream, *L, id, copies, n_copy, entries);
+  else if (order == 2)          hipLaunchKernelGGL((ghost_fill_kernel<2, false>), grid, dim3(256), 0, g_stream, *L, id, copies, n_copy, entries);
+  else                          hipLaunchKernelGGL((ghost_fill_kernel<12, false>), grid, dim3(256), 0, g_stream, *L, id, copies, n_copy, entries);
   HPGMG_LAUNCH_CHECK("ghost_fill_kernel");
   return 0;
 }

@@ -220,9 +220,11 @@ int hpgmg_hip_extrapolate_betas(const hpgmg_hip_level *L, const blockCopy_type *
  * this box's ghost zone) the host may name that neighbouring box instead -- after an exchange the values are the same, but read there the
  * condition does not depend on the exchange: hpgmg_hip_exchange_and_bc() uses the sources and runs both as one launch, while
  * hpgmg_hip_apply_bc_fv() (= apply_BCs on its own) reads the entry's own box like the reference.
- * Short kernels: on the small levels a launch lasts as long as its instruction fetch.  order = 2 (v2) | 4 (v4) | 12 (p2); only for
- * ghost zones no deeper than the condition fills (v4: 2, else 1). */
-typedef struct { int box, nn, base, len0, len1, fs0, fs1, step[3], src_box, src_base; } hpgmg_hip_bc_entry;
+ * Short kernels: on the small levels a launch lasts as long as its instruction fetch.  order = 2 (v2) | 4 (v4) | 12 (p2).  A ghost zone
+ * deeper than the condition fills (v4: 2 layers, v2: 1) is cleared first, block by block, as the reference does; p2 needs ghosts == 1. */
+typedef struct { int box, nn, base, len0, len1, fs0, fs1, step[3], src_box, src_base;
+                 int zbase, zi, zj, zk;   /* the whole block (offset of its first cell, extents): cleared first when the ghost zone is deeper than the condition fills */
+} hpgmg_hip_bc_entry;
 int hpgmg_hip_apply_bc_fv(const hpgmg_hip_level *L, int id, const hpgmg_hip_bc_entry *entries, int num_entries, int order);
 /* exchange_boundary's box-to-box copies (a `copy` list, operators/exchange_boundary.c:81-90) and the boundary conditions in ONE launch:
  * only for entries whose sources do not depend on the copies (see above) and levels without messages */
