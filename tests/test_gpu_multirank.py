@@ -23,6 +23,8 @@ GOLD = load_golden("fcycle_norms.json")
     (4, "7pt-cheby", 4, 8, "7pt-cheby 4 27"),          # bench.py --gpus 4 in small: 27 boxes over 4 ranks (7/7/7/6), 48^3
     (2, "27pt-cheby", 4, 4, "27pt-cheby 4 8"),
     (2, "fv4-gsrb", 4, 4, "fv4-gsrb 4 8"),
+    (2, "27pt-gsrb", 7, 4, "27pt-gsrb 7 8"),           # boxes of 128^3 with a remote k face: tiled kernels on exchanged ghost zones, boundary-condition
+    (2, "fv4-gsrb", 7, 4, "fv4-gsrb 7 8"),             # entries that read local neighbours directly and remote ones from the ghost zone; gathered levels on rank 0
 ])
 def test_hip_multirank_matches_single_rank_reference(world, variant, log2, per_rank, gold_key):
     if gold_key not in GOLD:
