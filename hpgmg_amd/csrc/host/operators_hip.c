@@ -1232,18 +1232,32 @@ static int fused_residual_on(void) {
   if (fused_residual < 0) { const char *e = getenv("HPGMG_FUSED_RESIDUAL"); fused_residual = !(e && e[0] == '0'); }
   return fused_residual;
 }
-int hpgmg_residual_restrict_zero_fused(level_type *Lc, int id_c, level_type *Lf, int x_id, int rhs_id, double a, double b, int zero_id) {
-  communicator_type *S = &Lf->restriction[RESTRICT_CELL], *R = &Lc->restriction[RESTRICT_CELL];
+/* the operand of a fused residual form is made ready: 7-point -- nothing (the kernel applies the Dirichlet rule and reads neighbouring boxes);
+ * 27-point / fv4 -- the domain-boundary ghost cells (the tiled kernel reads neighbouring boxes itself).  0 = the level does not qualify. */
+static int fused_residual_operand(level_type *L, backend_t *B, int x_id) {
   hpgmg_config cfg;
   hpgmg_get_config(&cfg);
-  if (!fused_residual_on() || cfg.op != HPGMG_OP_7PT || !ghost_free_mode() || stencil_get_shape() != STENCIL_SHAPE_STAR) return 0;
-  if (!Lf->active || !Lc->active || Lc->num_my_boxes < 1 || Lf->num_my_boxes < 1 || zero_id == id_c || Lf->boundary_condition.type == BC_PERIODIC) return 0;
+  const int shape = stencil_get_shape();
+  if (!fused_residual_on() || !ghost_free_mode() || !L->active || L->num_my_boxes < 1 || L->boundary_condition.type == BC_PERIODIC || !B->all_faces_local) return 0;
+  if (cfg.op == HPGMG_OP_7PT) {
+    if (shape != STENCIL_SHAPE_STAR) return 0;
+    hpgmg_hip_set_ghost_free(1);
+    return hpgmg_hip_residual_fused_supported(&B->dev, variant());
+  }
+  if (cfg.op != HPGMG_OP_27PT && cfg.op != HPGMG_OP_FV4) return 0;
+  if (!hpgmg_hip_residual_fused_supported(&B->dev, variant())) return 0;
+  hpgmg_hip_set_ghost_free(0);
+  hpgmg_hip_set_tile_ghost_free(1);
+  if (!exchange_and_bcs_one_launch(L, x_id, shape, cfg.op == HPGMG_OP_27PT ? 12 : 4, 0)) apply_BCs(L, x_id, shape);
+  return 1;
+}
+int hpgmg_residual_restrict_zero_fused(level_type *Lc, int id_c, level_type *Lf, int x_id, int rhs_id, double a, double b, int zero_id) {
+  communicator_type *S = &Lf->restriction[RESTRICT_CELL], *R = &Lc->restriction[RESTRICT_CELL];
+  if (!Lf->active || !Lc->active || Lc->num_my_boxes < 1 || Lf->num_my_boxes < 1 || zero_id == id_c) return 0;
   if (S->num_sends || R->num_recvs || S->num_blocks[0] || R->num_blocks[2] || S->num_blocks[1] < 1) return 0;
   backend_t *Bc = backend_of(Lc), *Bf = backend_of(Lf);
-  if (!Bf->all_faces_local) return 0;
-  hpgmg_hip_set_ghost_free(1);
-  if (!hpgmg_hip_residual_fused_supported(&Bf->dev, variant())) return 0;
   if (!restrict_map_of(Lf, Bf)) return 0;
+  if (!fused_residual_operand(Lf, Bf, x_id)) return 0;
   TICK(Lf, residual, "residual + restriction + zero_vector (fused)");
   HIP_OK(hpgmg_hip_residual_restrict(&Bf->dev, variant(), x_id, rhs_id, a, b, 1.0 / (Lf->h * Lf->h), &Bc->dev, id_c, Bf->d_restrict_map, zero_id));
   TOCK();
@@ -1271,12 +1285,10 @@ int hpgmg_norm_scale_restrict_fused(level_type *L, int F_id, int R_id, level_typ
 int hpgmg_residual_norm_fused(level_type *L, int res_id, int x_id, int rhs_id, double a, double b, double *norm_out) {
   hpgmg_config cfg;
   hpgmg_get_config(&cfg);
-  if (!fused_residual_on() || cfg.op != HPGMG_OP_7PT || !ghost_free_mode() || stencil_get_shape() != STENCIL_SHAPE_STAR) return 0;
-  if (!L->active || L->num_my_boxes < 1 || L->boundary_condition.type == BC_PERIODIC) return 0;
+  if (cfg.op != HPGMG_OP_7PT && res_id >= 0) return 0;          /* the tiled kernels of the other plugins only carry the norm-only form */
+  if (!L->active || L->num_my_boxes < 1) return 0;
   backend_t *B = backend_of(L);
-  if (!B->all_faces_local) return 0;
-  hpgmg_hip_set_ghost_free(1);
-  if (!hpgmg_hip_residual_fused_supported(&B->dev, variant())) return 0;
+  if (!fused_residual_operand(L, B, x_id)) return 0;
   double v = 0.0;
   { TICK(L, residual, "residual + norm (fused)");
     HIP_OK(hpgmg_hip_residual_norm(&B->dev, variant(), res_id, x_id, rhs_id, a, b, 1.0 / (L->h * L->h), &v));

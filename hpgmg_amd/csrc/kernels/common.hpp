@@ -58,4 +58,27 @@ __device__ __forceinline__ double gf_load_outside(const hpgmg_hip_level &L, int 
   return vec_origin(L, box, id)[c.off + p * L.kStride];
 }
 
+
+// Fused forms of residual() for the tiled kernels (one cell per lane, TI x TJ lanes, marching in +k): the residual is not stored but
+//   kind 1: reduced to its max-abs (norm(), misc.c:287-329) -- one partial per workgroup;
+//   kind 2: restricted into the coarse level (restriction.c:54-57: the eight children in the order (i, i+1) of rows j, j+1 of plane k,
+//           then of plane k+1; times 0.125).  A plane of residuals passes through an LDS tile; the lane of a child (even i, even j)
+//           gathers its 2 x 2 patch one step later and carries the sum over the plane pair.
+struct TileFused {
+  int kind;                    // 0 plain store, 1 norm, 2 restrict
+  double *partials;            // kind 1: [logical workgroup]
+  hpgmg_hip_level Lc; int coarse_id; const int *map;   // kind 2: map[4 b .. 4 b + 3] = coarse box and coarse (i, j, k) under fine box b's first cell
+};
+template <int TI, int TJ>
+struct TileFusedState {
+  double lane_max = 0.0, racc = 0.0;
+  // called once per plane step AFTER the step's first barrier with the residual of the PREVIOUS plane in sR[(k-1)&1] (k > k0)
+  __device__ __forceinline__ void gather(const TileFused &F, const double *sR, int li, int lj, int kprev, int k0, double *coarse) {
+    if ((li | lj) & 1) return;
+    const double *r = sR + ((kprev & 1) * TJ + lj) * TI + li;
+    if (((kprev - k0) & 1) == 0) { racc = r[0] + r[1]; racc = racc + r[TI]; racc = racc + r[TI + 1]; }
+    else { racc = racc + r[0]; racc = racc + r[1]; racc = racc + r[TI]; racc = racc + r[TI + 1]; coarse[((kprev - k0) >> 1) * F.Lc.kStride] = racc * 0.125; }
+  }
+};
+
 }  // namespace hpgmg

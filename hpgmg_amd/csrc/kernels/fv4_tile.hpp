@@ -30,6 +30,7 @@ struct Fv4TileArgs {
   int xn_id, xout_id, rhs_id;
   double a, b, h2inv, c1, c2;
   int sweep, copy_other_colour, ghost_free;
+  TileFused fused;                      // FV4_RESIDUAL only: what becomes of the residual (common.hpp)
   int tiles_i, tiles_j, chunks_k, kchunk, per_xcd, total_blocks;
 };
 enum { FV4_CHEBY = 0, FV4_GSRB = 1, FV4_JACOBI = 2, FV4_RESIDUAL = 3, FV4_APPLY = 4 };
@@ -42,6 +43,7 @@ __global__ __launch_bounds__(TI * TJ) void fv4_tile_kernel(const hpgmg_hip_level
   constexpr bool kHelm = (V == HPGMG_HIP_FV4_VC_HELMHOLTZ);
   constexpr bool kSmooth = (MODE == FV4_CHEBY || MODE == FV4_GSRB || MODE == FV4_JACOBI);
   extern __shared__ double fv4_lds[];
+  __shared__ double sR[(MODE == FV4_RESIDUAL) ? 2 * TJ * TI : 1];   // fused residual forms: a plane of residuals / the workgroup's partial maxima
   double *sX = fv4_lds, *sBI = fv4_lds + 3 * PLANE, *sBJ = fv4_lds + 6 * PLANE, *sBK = fv4_lds + 9 * PLANE;   // rings of 3, 3, 3, 2 plane tiles
 
   const int logical = xcd_logical_block((int)blockIdx.x, P.per_xcd);
@@ -124,9 +126,18 @@ __global__ __launch_bounds__(TI * TJ) void fv4_tile_kernel(const hpgmg_hip_level
   double c_rhs = (MODE == FV4_APPLY) ? 0.0 : rhs[own_g + k0 * kS], c_dinv = kSmooth ? dinv[own_g + k0 * kS] : 0.0;
   double c_al = kHelm ? alpha[own_g + k0 * kS] : 0.0, c_old = (MODE == FV4_CHEBY) ? out[own_g + k0 * kS] : 0.0;
 
+  const TileFused &F = P.fused;
+  TileFusedState<TI, TJ> fs;
+  double *coarse = nullptr;
+  if (MODE == FV4_RESIDUAL && F.kind == 2) {
+    const int *mp = F.map + 4 * box;
+    coarse = vec_origin(F.Lc, mp[0], F.coarse_id) + (mp[1] + (i >> 1)) + (mp[2] + (j >> 1)) * F.Lc.jStride + (mp[3] + (k0 >> 1)) * F.Lc.kStride;
+  }
+
   for (int k = k0; k < k1; k++) {
     const int pg = k * kS;
     __syncthreads();                                            // every wave is done reading the slots that plane k+1 overwrites
+    if (MODE == FV4_RESIDUAL && F.kind == 2 && k > k0) fs.gather(F, sR, li, lj, k - 1, k0, coarse);
     { // plane k+1 (loaded during the previous step) -> LDS
       const int s = slot3(k + 1) * PLANE, sk = ((k + 1) & 1) * PLANE;
       sX[s + own_s] = xp1; sBI[s + own_s] = n_bi; sBJ[s + own_s] = n_bj; sBK[sk + own_s] = n_bk;
@@ -182,12 +193,23 @@ __global__ __launch_bounds__(TI * TJ) void fv4_tile_kernel(const hpgmg_hip_level
       else if (MODE == FV4_JACOBI)   o = xc + P.c2 * c_dinv * (c_rhs - Ax);
       else if (MODE == FV4_RESIDUAL) o = c_rhs - Ax;
       else                           o = Ax;
-      out[own_g + pg] = o;
+      if (MODE == FV4_RESIDUAL && F.kind == 1) { const double f = fabs(o); fs.lane_max = (f > fs.lane_max) ? f : fs.lane_max; }
+      else if (MODE == FV4_RESIDUAL && F.kind == 2) sR[((k & 1) * TJ + lj) * TI + li] = o;
+      else out[own_g + pg] = o;
     } else if (P.copy_other_colour) {
       out[own_g + pg] = xc;                                     // out-of-place GSRB copies the other colour (gsrb.c:94-98)
     }
     xm2 = xm1; xm1 = xc; xc = xp1; xp1 = xp2; xp2 = xp3;
     c_rhs = nn_rhs; c_dinv = nn_dinv; c_al = nn_al; c_old = nn_old;
+  }
+  if (MODE == FV4_RESIDUAL && F.kind == 2) { __syncthreads(); fs.gather(F, sR, li, lj, k1 - 1, k0, coarse); }
+  if (MODE == FV4_RESIDUAL && F.kind == 1) {                      // a maximum is exact under any order (misc.c:307-317)
+    double mx = fs.lane_max;
+    for (int off = 32; off > 0; off >>= 1) { const double o2 = __shfl_down(mx, off, 64); mx = (o2 > mx) ? o2 : mx; }
+    __syncthreads();
+    if ((tid & 63) == 0) sR[tid >> 6] = mx;
+    __syncthreads();
+    if (tid == 0) { double m2 = sR[0]; for (int q = 1; q < NT / 64; q++) m2 = (sR[q] > m2) ? sR[q] : m2; F.partials[logical] = m2; }
   }
 }
 

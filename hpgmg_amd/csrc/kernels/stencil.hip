@@ -705,7 +705,9 @@ static void profile_end(int p, long long cells) {
 }
 
 static int g_ghost_free = 0;
-static int g_tile_ghost_free = 0;   // the LDS-tiled fv4 / 27-point kernels read x outside a box from the neighbouring box (all boxes local)
+static int g_tile_ghost_free = 0;
+static TileFused g_tile_fused = {};      // consumed by the next tiled residual launch (27-point / fv4): what becomes of the residual
+static int g_tile_last_blocks = 0;       // workgroups of that launch (= partial maxima written)   // the LDS-tiled fv4 / 27-point kernels read x outside a box from the neighbouring box (all boxes local)
 static int g_defer_mode = 0;   // 0: whole boxes; 1: skip the cells next to remote faces; 2: only those cells (stencil7_shell_kernel)
 
 static int env_int(const char *name, int dflt) { const char *e = getenv(name); return (e && *e) ? atoi(e) : dflt; }
@@ -750,6 +752,7 @@ static int launch27(const hpgmg_hip_level *L, StencilArgs P, bool is_smoother) {
     S27TileArgs A = {};
     A.xn_id = P.xn_id; A.xout_id = P.xout_id; A.rhs_id = P.rhs_id; A.mode = TM; A.a = P.a; A.b = P.b; A.h2inv = P.h2inv; A.c1 = P.c1; A.c2 = P.c2; A.sweep = P.sweep;
     A.ghost_free = (g_tile_ghost_free && L->box_nbr) ? 1 : 0;
+    A.fused = g_tile_fused; g_tile_fused = TileFused{};
     A.tiles_i = L->dim / TI; A.tiles_j = L->dim / TJ;
     int kchunk = L->dim;
     while (kchunk > 32 && (long long)L->num_boxes * A.tiles_i * A.tiles_j * (L->dim / kchunk) < 8192) kchunk /= 2;   // measured at 512^3: 32-plane chunks 929 us, whole boxes 952
@@ -757,6 +760,7 @@ static int launch27(const hpgmg_hip_level *L, StencilArgs P, bool is_smoother) {
     if (tune_kc > 0 && L->dim % tune_kc == 0) kchunk = tune_kc;
     A.kchunk = kchunk; A.chunks_k = (L->dim + kchunk - 1) / kchunk;
     A.total_blocks = L->num_boxes * A.chunks_k * A.tiles_j * A.tiles_i;
+    g_tile_last_blocks = A.total_blocks;
     const int tgrid = grid_for(A.total_blocks, &A.per_xcd);
     const long long tcells = (long long)L->num_boxes * L->dim * L->dim * L->dim;
     const int tprof = is_smoother ? profile_begin(tcells) : -1;
@@ -783,6 +787,7 @@ static int launch_fv4_tile_tj(const hpgmg_hip_level *L, int variant, const Stenc
   Fv4TileArgs P = {};
   P.xn_id = S.xn_id; P.xout_id = S.xout_id; P.rhs_id = S.rhs_id; P.a = S.a; P.b = S.b; P.h2inv = S.h2inv; P.c1 = S.c1; P.c2 = S.c2;
   P.sweep = S.sweep; P.copy_other_colour = S.copy_other_colour; P.ghost_free = (g_tile_ghost_free && L->box_nbr) ? 1 : 0;
+  P.fused = g_tile_fused; g_tile_fused = TileFused{};
   P.tiles_i = L->dim / TI; P.tiles_j = L->dim / TJ;
   int kchunk = L->dim;                                   // enough workgroups to fill the chip, as few chunk prologues as possible
   const int want = (TJ * TI >= 1024) ? 512 : 1024;
@@ -791,6 +796,7 @@ static int launch_fv4_tile_tj(const hpgmg_hip_level *L, int variant, const Stenc
   if (tune_kc > 0 && L->dim % tune_kc == 0) kchunk = tune_kc;
   P.kchunk = kchunk; P.chunks_k = (L->dim + kchunk - 1) / kchunk;
   P.total_blocks = L->num_boxes * P.chunks_k * P.tiles_j * P.tiles_i;
+  g_tile_last_blocks = P.total_blocks;
   const int grid = grid_for(P.total_blocks, &P.per_xcd);
   const size_t lds = (size_t)11 * (TI + 4) * (TJ + 4) * sizeof(double);
   const long long cells = (long long)L->num_boxes * L->dim * L->dim * L->dim;
@@ -1305,12 +1311,23 @@ int hpgmg_hip_blackbox_accumulate(const hpgmg_hip_level *L, int variant, int x_i
   if (variant == HPGMG_HIP_27PT_CC) return launch27<MODE_BLACKBOX>(L, P, false);
   return launch_direct<MODE_BLACKBOX>(L, variant, P, false);
 }
-int hpgmg_hip_residual_fused_supported(const hpgmg_hip_level *L, int variant) { return wide_fused_ok(L, variant); }
+static bool tiled_variant(int variant) { return variant == HPGMG_HIP_27PT_CC || variant == HPGMG_HIP_FV4_VC_HELMHOLTZ || variant == HPGMG_HIP_FV4_VC_POISSON; }
+int hpgmg_hip_residual_fused_supported(const hpgmg_hip_level *L, int variant) {
+  if (tiled_variant(variant)) return hpgmg_hip_tile_kernel_applies(L, variant, 1) && L->dim % 2 == 0;   // the tiled kernels carry the fused forms (27-point, fv4)
+  return wide_fused_ok(L, variant);
+}
 // residual (never stored) -> restriction into vector coarse_id of Lc, plus zero_vector(Lc, zero_id) when zero_id >= 0: the end of
 // MGVCycle's down leg (mg.c:1150-1153) in one pass over the fine level.  map[4 b .. 4 b + 3] = coarse box and coarse (i, j, k) under fine box b's first cell.
 int hpgmg_hip_residual_restrict(const hpgmg_hip_level *L, int variant, int x_id, int rhs_id, double a, double b, double h2inv,
                                 const hpgmg_hip_level *Lc, int coarse_id, const int *map, int zero_id) {
   HPGMG_SKIP_IF_REPLAY();
+  if (tiled_variant(variant)) {
+    if (!hpgmg_hip_residual_fused_supported(L, variant) || Lc->num_boxes <= 0) return record_error(hipErrorInvalidValue, "residual_restrict: level not supported");
+    g_tile_fused = TileFused{}; g_tile_fused.kind = 2; g_tile_fused.Lc = *Lc; g_tile_fused.coarse_id = coarse_id; g_tile_fused.map = map;
+    StencilArgs T = {}; T.xn_id = x_id; T.xout_id = rhs_id; T.rhs_id = rhs_id; T.a = a; T.b = b; T.h2inv = h2inv;    // xout only has to differ from xn: nothing is stored
+    if (int e = launch<MODE_RESIDUAL>(L, variant, T, false)) return e;
+    return zero_id >= 0 ? hpgmg_hip_fill(Lc, zero_id, 0.0) : 0;
+  }
   if (!wide_fused_ok(L, variant) || Lc->num_boxes <= 0) return record_error(hipErrorInvalidValue, "residual_restrict: level not supported");
   StencilArgs P = {}; P.xn_id = x_id; P.xout_id = x_id; P.rhs_id = rhs_id; P.a = a; P.b = b; P.h2inv = h2inv;
   FusedArgs F = {}; F.Lc = *Lc; F.coarse_id = coarse_id; F.zero_id = zero_id; F.map = map;
@@ -1321,6 +1338,16 @@ int hpgmg_hip_residual_restrict(const hpgmg_hip_level *L, int variant, int x_id,
 int hpgmg_hip_residual_norm(const hpgmg_hip_level *L, int variant, int res_id, int x_id, int rhs_id, double a, double b, double h2inv, double *norm_out) {
   if (int e = hpgmg_hip_graph_flush()) return e;
   *norm_out = 0.0;
+  if (tiled_variant(variant)) {
+    if (!hpgmg_hip_residual_fused_supported(L, variant) || res_id >= 0) return record_error(hipErrorInvalidValue, "residual_norm: level not supported (27-point / fv4: norm only, res_id < 0)");
+    const long long cells = (long long)L->num_boxes * L->dim * L->dim * L->dim;
+    double *part = reduction_scratch((int)(cells / 4096 + 1024));
+    if (!part) return record_error(hipErrorOutOfMemory, "residual_norm: scratch");
+    g_tile_fused = TileFused{}; g_tile_fused.kind = 1; g_tile_fused.partials = part;
+    StencilArgs T = {}; T.xn_id = x_id; T.xout_id = rhs_id; T.rhs_id = rhs_id; T.a = a; T.b = b; T.h2inv = h2inv;
+    if (int e = launch<MODE_RESIDUAL>(L, variant, T, false)) return e;
+    return finish_max_reduction(g_tile_last_blocks, 0.0, norm_out);
+  }
   if (!wide_fused_ok(L, variant)) return record_error(hipErrorInvalidValue, "residual_norm: level not supported");
   StencilArgs P = {}; P.xn_id = x_id; P.xout_id = res_id; P.rhs_id = rhs_id; P.a = a; P.b = b; P.h2inv = h2inv;
   const int blocks = L->num_boxes * ((L->dim + 15) / 16) * (L->dim / 16) * (L->dim / 128);

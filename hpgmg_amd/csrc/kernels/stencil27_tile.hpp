@@ -26,6 +26,7 @@ struct S27TileArgs {
   int xn_id, xout_id, rhs_id, mode;     // mode: MODE_* of stencil.hip (Chebyshev, GSRB, Jacobi, residual, apply_op)
   double a, b, h2inv, c1, c2;
   int sweep, ghost_free;
+  TileFused fused;                      // MODE 3 only: what becomes of the residual (common.hpp)
   int tiles_i, tiles_j, chunks_k, kchunk, per_xcd, total_blocks;
 };
 
@@ -36,6 +37,7 @@ __global__ __launch_bounds__(TI * TJ) void stencil27_tile_kernel(const hpgmg_hip
   static_assert(NH <= NT, "one halo cell per lane at most");
   constexpr bool kSmooth = (MODE == 0 || MODE == 1 || MODE == 2);
   __shared__ double sX[3 * PLANE];
+  __shared__ double sR[(MODE == 3) ? 2 * TJ * TI : 1];           // fused residual forms: a plane of residuals / the workgroup's partial maxima
 
   const int logical = xcd_logical_block((int)blockIdx.x, P.per_xcd);
   if (logical >= P.total_blocks) return;
@@ -101,10 +103,18 @@ __global__ __launch_bounds__(TI * TJ) void stencil27_tile_kernel(const hpgmg_hip
   double n_x = x_own(k0 + 1), h_x = has_halo ? x_halo(k0 + 1) : 0.0;
   double c_rhs = (MODE == 4) ? 0.0 : rhs[own_g + k0 * kS], c_dinv = kSmooth ? dinv[own_g + k0 * kS] : 0.0;
   double c_old = (MODE == 0) ? out[own_g + k0 * kS] : 0.0;
+  const TileFused &F = P.fused;
+  TileFusedState<TI, TJ> fs;
+  double *coarse = nullptr;
+  if (MODE == 3 && F.kind == 2) {
+    const int *mp = F.map + 4 * box;
+    coarse = vec_origin(F.Lc, mp[0], F.coarse_id) + (mp[1] + (i >> 1)) + (mp[2] + (j >> 1)) * F.Lc.jStride + (mp[3] + (k0 >> 1)) * F.Lc.kStride;
+  }
 
   for (int k = k0; k < k1; k++) {
     const int pg = k * kS;
     __syncthreads();                                            // every wave is done reading the slot that plane k+1 overwrites
+    if (MODE == 3 && F.kind == 2 && k > k0) fs.gather(F, sR, li, lj, k - 1, k0, coarse);
     { const int s = slot3(k + 1) * PLANE; sX[s + own_s] = n_x; if (has_halo) sX[s + halo_s] = h_x; }
     double nn_rhs = 0, nn_dinv = 0, nn_old = 0;
     if (k + 1 < k1) {                                           // loads of the next step
@@ -139,11 +149,22 @@ __global__ __launch_bounds__(TI * TJ) void stencil27_tile_kernel(const hpgmg_hip
       else if (MODE == 2) o = xc + P.c2 * c_dinv * (c_rhs - Ax);
       else if (MODE == 3) o = c_rhs - Ax;
       else                o = Ax;
-      out[own_g + pg] = o;
+      if (MODE == 3 && F.kind == 1) { const double f = fabs(o); fs.lane_max = (f > fs.lane_max) ? f : fs.lane_max; }
+      else if (MODE == 3 && F.kind == 2) sR[((k & 1) * TJ + lj) * TI + li] = o;
+      else out[own_g + pg] = o;
     } else {
       out[own_g + pg] = xc;                                     // out-of-place GSRB copies the other colour (gsrb.c:94-98)
     }
     c_rhs = nn_rhs; c_dinv = nn_dinv; c_old = nn_old;
+  }
+  if (MODE == 3 && F.kind == 2) { __syncthreads(); fs.gather(F, sR, li, lj, k1 - 1, k0, coarse); }
+  if (MODE == 3 && F.kind == 1) {                                 // a maximum is exact under any order (misc.c:307-317)
+    double mx = fs.lane_max;
+    for (int off = 32; off > 0; off >>= 1) { const double o2 = __shfl_down(mx, off, 64); mx = (o2 > mx) ? o2 : mx; }
+    __syncthreads();
+    if ((tid & 63) == 0) sR[tid >> 6] = mx;
+    __syncthreads();
+    if (tid == 0) { double m2 = sR[0]; for (int q = 1; q < NT / 64; q++) m2 = (sR[q] > m2) ? sR[q] : m2; F.partials[logical] = m2; }
   }
 }
 
