@@ -1146,16 +1146,21 @@ void smooth(level_type *L, int x_id, int rhs_id, double a, double b) {
     if (smooth_gsrb_pairs(L, x_id, rhs_id, a, b, sweeps)) return;
     /* 27-point, inside a cycle (VECTOR_TEMP is scratch afterwards): each red + black pair of half sweeps as one pass, x -> TEMP -> x.
      * The state the exported smooth() must leave in VECTOR_TEMP (the iterate before the last half sweep) never exists in this form. */
-    if (cfg.op == HPGMG_OP_27PT && oop && temp_is_scratch && sweeps % 4 == 0 && L->num_my_boxes > 0 && B->all_faces_local &&
-        x_id != VECTOR_TEMP && rhs_id != VECTOR_TEMP && hpgmg_hip_smooth_gsrb27_rb_supported(&B->dev)) {
-      for (s = 0; s < sweeps; s += 2) {
-        const int src = (s & 2) ? VECTOR_TEMP : x_id, dst = (s & 2) ? x_id : VECTOR_TEMP;
-        if (!exchange_and_bcs_one_launch(L, src, stencil_get_shape(), 12, 0)) apply_BCs(L, src, stencil_get_shape());
-        TICK(L, smooth, "smooth (27-point GSRB, red + black half sweeps in one pass)");
-        HIP_OK(hpgmg_hip_smooth_gsrb27_rb(&B->dev, src, dst, rhs_id, a, b, h2inv, s));
-        TOCK();
+    if (cfg.op == HPGMG_OP_27PT && oop && temp_is_scratch && ghost_free_mode() && sweeps % 4 == 0 && L->num_my_boxes > 0 && B->all_faces_local &&
+        x_id != VECTOR_TEMP && rhs_id != VECTOR_TEMP) {
+      const int tiled = hpgmg_hip_smooth_gsrb27_rb_supported(&B->dev);                          /* boxes of side 64 m: marching tiles */
+      const int boxed = !tiled && hpgmg_hip_smooth_gsrb27_rb_box_supported(&B->dev);   /* boxes of 2^3 ... 16^3: one workgroup per box */
+      if (tiled || boxed) {
+        for (s = 0; s < sweeps; s += 2) {
+          const int src = (s & 2) ? VECTOR_TEMP : x_id, dst = (s & 2) ? x_id : VECTOR_TEMP;
+          if (tiled && !exchange_and_bcs_one_launch(L, src, stencil_get_shape(), 12, 0)) apply_BCs(L, src, stencil_get_shape());
+          TICK(L, smooth, "smooth (27-point GSRB, red + black half sweeps in one pass)");
+          if (tiled) HIP_OK(hpgmg_hip_smooth_gsrb27_rb(&B->dev, src, dst, rhs_id, a, b, h2inv, s));
+          else       HIP_OK(hpgmg_hip_smooth_gsrb27_rb_box(&B->dev, src, dst, rhs_id, a, b, h2inv, s));
+          TOCK();
+        }
+        return;
       }
-      return;
     }
     for (s = 0; s < sweeps; s++) {
       const int src = (oop && (s & 1)) ? VECTOR_TEMP : x_id, dst = oop ? ((s & 1) ? x_id : VECTOR_TEMP) : x_id;
