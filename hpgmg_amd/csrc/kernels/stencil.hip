@@ -1304,26 +1304,26 @@ int hpgmg_hip_smooth_gsrb27_rb(const hpgmg_hip_level *L, int x_id, int out_id, i
 }
 // The same on small levels: one workgroup per box of 2^3 ... 16^3 cells (stencil27_rb_box.hpp); forms the boundary ghost cells of x_id itself,
 // so the caller runs neither exchange_boundary nor apply_BCs_p2.  Every box local.
-static int g_rb_box16 = -1;
-void hpgmg_hip_set_27pt_rb_box16(int on) { g_rb_box16 = on ? 1 : 0; }
+// Largest box side it takes.  Boxes of 16^3 and 32^3 are handled as cubes of 8^3 (bit-identical, tested) but measure no faster (16^3) or
+// slower (32^3: 14.3 vs 14.2 ms per `7 64` F-cycle) than the launches they replace -- every cube re-reads a two-cell rim, 3.4 values per cell.
+static int g_rb_box_maxdim = -1;
+void hpgmg_hip_set_27pt_rb_box_maxdim(int dim) { g_rb_box_maxdim = dim; }
 int hpgmg_hip_smooth_gsrb27_rb_box_supported(const hpgmg_hip_level *L) {
   static const int off = env_int("HPGMG_TUNE_27PT_NO_RB_BOX", 0);
-  // boxes of 16^3 work too (tested) but one launch of 1024 lanes per box takes 33 us against 4 x 5 us for the launches it replaces; below that
-  // it wins: 8^3 9-13 us, 4^3 5 us, 2^3 7 us against 16-18 us
-  if (g_rb_box16 < 0) g_rb_box16 = env_int("HPGMG_TUNE_27PT_RB_BOX16", 0) ? 1 : 0;
-  const int with16 = g_rb_box16;
-  return !off && L->num_boxes > 0 && L->box_nbr != nullptr && L->ghosts >= 1 && (L->dim == 2 || L->dim == 4 || L->dim == 8 || (with16 && L->dim == 16));
+  if (g_rb_box_maxdim < 0) g_rb_box_maxdim = env_int("HPGMG_TUNE_27PT_RB_BOX_MAXDIM", 8);
+  const int maxdim = g_rb_box_maxdim;
+  return !off && L->num_boxes > 0 && L->box_nbr != nullptr && L->ghosts >= 1 && L->dim <= maxdim && (L->dim == 2 || L->dim == 4 || L->dim == 8 || L->dim == 16 || L->dim == 32);
 }
 int hpgmg_hip_smooth_gsrb27_rb_box(const hpgmg_hip_level *L, int x_id, int out_id, int rhs_id, double a, double b, double h2inv, int sweep) {
   HPGMG_SKIP_IF_REPLAY();
   if (!hpgmg_hip_smooth_gsrb27_rb_box_supported(L) || x_id == out_id || (sweep & 1)) return record_error(hipErrorInvalidValue, "smooth_gsrb27_rb_box: level / arguments not supported");
   S27RbBoxArgs A = {}; A.xn_id = x_id; A.xout_id = out_id; A.rhs_id = rhs_id; A.a = a; A.b = b; A.h2inv = h2inv; A.sweep = sweep;
+  // cubes of 8^3 for boxes of 8^3 and more (a whole box of 16^3 in one workgroup measured 33 us, slower than the four launches it replaces)
 #define RB_BOX_CASE(DD, NTT) { \
+    A.cubes = L->dim / DD; \
     const size_t lds = (size_t)((DD + 4) * (DD + 4) * (DD + 4) + (DD + 2) * (DD + 2) * (DD + 2)) * sizeof(double); \
-    static bool once = false; if (!once) { HPGMG_CHECK(hipFuncSetAttribute((const void *)stencil27_rb_box_kernel<DD, NTT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once = true; } \
-    hipLaunchKernelGGL((stencil27_rb_box_kernel<DD, NTT>), dim3(L->num_boxes), dim3(NTT), lds, g_stream, *L, A); }
-  if (L->dim == 16) RB_BOX_CASE(16, 1024)
-  else if (L->dim == 8) RB_BOX_CASE(8, 512)
+    hipLaunchKernelGGL((stencil27_rb_box_kernel<DD, NTT>), dim3(L->num_boxes * A.cubes * A.cubes * A.cubes), dim3(NTT), lds, g_stream, *L, A); }
+  if (L->dim >= 8) RB_BOX_CASE(8, 512)
   else if (L->dim == 4) RB_BOX_CASE(4, 256)
   else RB_BOX_CASE(2, 64)
 #undef RB_BOX_CASE

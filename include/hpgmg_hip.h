@@ -138,10 +138,10 @@ void hpgmg_hip_set_27pt_tile32(int on);
  * Boxes of side 64 m, every box local; the caller has run apply_BCs_p2 on x_id (no exchange_boundary needed). */
 int  hpgmg_hip_smooth_gsrb27_rb_supported(const hpgmg_hip_level *L);
 int  hpgmg_hip_smooth_gsrb27_rb(const hpgmg_hip_level *L, int x_id, int out_id, int rhs_id, double a, double b, double h2inv, int sweep);
-/* The same on small levels, one workgroup per box of 2^3 ... 16^3 cells, the box in LDS (kernels/stencil27_rb_box.hpp): forms the
- * domain-boundary ghost cells of x_id itself -- the caller runs neither exchange_boundary nor apply_BCs_p2.  Every box local. */
+/* The same on small levels (boxes of 2^3 ... 32^3), one workgroup per cube of at most 8^3 cells held in LDS (kernels/stencil27_rb_box.hpp):
+ * forms the domain-boundary ghost cells of x_id itself -- the caller runs neither exchange_boundary nor apply_BCs_p2.  Every box local. */
 int  hpgmg_hip_smooth_gsrb27_rb_box_supported(const hpgmg_hip_level *L);
-void hpgmg_hip_set_27pt_rb_box16(int on);    /* boxes of 16^3 too (off by default: slower than the launches it replaces; HPGMG_TUNE_27PT_RB_BOX16=1) */
+void hpgmg_hip_set_27pt_rb_box_maxdim(int dim);   /* largest box side taken (default 8; 16 and 32 work as cubes of 8^3 but are not faster) */
 int  hpgmg_hip_smooth_gsrb27_rb_box(const hpgmg_hip_level *L, int x_id, int out_id, int rhs_id, double a, double b, double h2inv, int sweep);
 long long hpgmg_hip_rb27_launch_count(void);   /* launches of either kernel so far (tests) */   /* tiled 27-point kernel also for boxes of 32^3 (off by default: slower than the register kernel there; HPGMG_TUNE_27PT_TILE32=1) */
 int  hpgmg_hip_tile_kernel_applies(const hpgmg_hip_level *L, int variant, int out_of_place);

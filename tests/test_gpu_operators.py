@@ -385,7 +385,7 @@ def test_lds_tiled_kernels_of_the_27pt_and_fv4_plugins(hip, oracle, variant, geo
 
 
 @pytest.mark.parametrize("geom", [(2, 64), (1, 64), (3, 64), (1, 128), (1, 64, "periodic"), (2, 64, "periodic"),
-                                  (2, 16), (4, 8), (3, 4), (4, 2), (1, 16), (1, 8), (1, 4), (2, 8, "periodic"), (1, 16, "periodic")])   # small boxes: one workgroup per box
+                                  (2, 16), (4, 8), (3, 4), (4, 2), (1, 16), (1, 8), (1, 4), (2, 8, "periodic"), (1, 16, "periodic"), (2, 32), (1, 32), (3, 32)])   # small boxes: one workgroup per cube of at most 8^3
 def test_27pt_red_and_black_half_sweeps_in_one_pass(hip, oracle, geom):
     """Inside a cycle (hpgmg_smooth_in_cycle: VECTOR_TEMP is scratch afterwards) the 27-point GSRB smoother runs each red + black pair of
     half sweeps as ONE pass (stencil27_rb.hpp; boxes of 2^3 ... 16^3: stencil27_rb_box.hpp): the intermediate vector, its exchange and its
@@ -393,8 +393,8 @@ def test_27pt_red_and_black_half_sweeps_in_one_pass(hip, oracle, geom):
     The iterate must equal the oracle's four separate half sweeps bit for bit, and the kernel must really have been the one launched."""
     set_mode(hip, 1)
     K = H.load_kernels()
-    K.hpgmg_hip_set_27pt_rb_box16.argtypes = [ctypes.c_int]
-    K.hpgmg_hip_set_27pt_rb_box16(1)      # boxes of 16^3: correct but slower than the launches it replaces, off by default; tested all the same
+    K.hpgmg_hip_set_27pt_rb_box_maxdim.argtypes = [ctypes.c_int]
+    K.hpgmg_hip_set_27pt_rb_box_maxdim(32)        # boxes of 16^3 / 32^3 as cubes of 8^3: not faster than separate launches, so off by default; tested all the same
     lh, lo = make_pair(hip, oracle, "27pt-gsrb", geom[0], geom[1], seed=13, bc=H.BC_PERIODIC if len(geom) > 2 else H.BC_DIRICHLET)
     try:
         for lv in (lh, lo):
@@ -414,7 +414,7 @@ def test_27pt_red_and_black_half_sweeps_in_one_pass(hip, oracle, geom):
         lo.b.lib.smooth(lo.ptr, H.VECTOR_U, H.VECTOR_F, 0.0, 1.0)
         same(lh, lo, [H.VECTOR_U], interior_only=True)
     finally:
-        K.hpgmg_hip_set_27pt_rb_box16(0)
+        K.hpgmg_hip_set_27pt_rb_box_maxdim(8)
         lh.destroy(); lo.destroy()
 
 
