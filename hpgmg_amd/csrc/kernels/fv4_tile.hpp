@@ -74,6 +74,10 @@ __global__ __launch_bounds__(TI * TJ) void fv4_tile_kernel(const hpgmg_hip_level
   int halo_g = 0, halo_s = 0;
   GfColumn hcol = {box, 0};
   const bool has_halo = tid < NH;
+  // which coefficient arrays the stencil reads at this lane's halo cell (operators.fv4.c:87-108): none on the outer ring (only x reaches two
+  // cells out); beta_i on rows -1 .. TJ of columns 0 .. TI, beta_j on rows 0 .. TJ of columns -1 .. TI, beta_k on the whole inner ring.
+  // The rows never read are not fetched: 2 (beta_i, beta_k) or 3 (beta_j) of the 12 rows a tile of 8 would otherwise stream per plane.
+  bool nb_i = false, nb_j = false, nb_k = false;
   if (has_halo) {
     int hi, hj;
     if (tid < 2 * W)      { hj = -2 + tid / W; hi = -2 + tid % W; }
@@ -81,6 +85,7 @@ __global__ __launch_bounds__(TI * TJ) void fv4_tile_kernel(const hpgmg_hip_level
     else                  { const int h = tid - 4 * W, c = h % 4; hj = h / 4; hi = (c < 2) ? c - 2 : TI + (c - 2); }
     halo_g = (i0 + hi) + (j0 + hj) * jS;
     halo_s = (hj + 2) * W + (hi + 2);
+    nb_k = hi >= -1 && hi <= TI && hj >= -1 && hj <= TJ; nb_i = nb_k && hi >= 0; nb_j = nb_k && hj >= 0;
     if (P.ghost_free) hcol = gf_column(L, box, i0 + hi, j0 + hj);
   }
   // x of the own column / the halo column on plane p (any p the stencil reaches): inside the box's k range a plain load
@@ -115,14 +120,14 @@ __global__ __launch_bounds__(TI * TJ) void fv4_tile_kernel(const hpgmg_hip_level
     sX[s + own_s] = (p == k0) ? xc : xm1;
     sBI[s + own_s] = gbi[own_g + pg];
     sBJ[s + own_s] = gbj[own_g + pg];
-    if (has_halo) { sX[s + halo_s] = x_halo(p); sBI[s + halo_s] = gbi[halo_g + pg]; sBJ[s + halo_s] = gbj[halo_g + pg]; }
+    if (has_halo) { sX[s + halo_s] = x_halo(p); sBI[s + halo_s] = nb_i ? gbi[halo_g + pg] : 0.0; sBJ[s + halo_s] = nb_j ? gbj[halo_g + pg] : 0.0; }
   }
   sBK[(k0 & 1) * PLANE + own_s] = gbk[own_g + k0 * kS];
-  if (has_halo) sBK[(k0 & 1) * PLANE + halo_s] = gbk[halo_g + k0 * kS];
+  if (has_halo) sBK[(k0 & 1) * PLANE + halo_s] = nb_k ? gbk[halo_g + k0 * kS] : 0.0;
   // values in flight: plane k+1 (stored to LDS at the start of step k) and the per-cell streams of plane k
   double n_bi = gbi[own_g + (k0 + 1) * kS], n_bj = gbj[own_g + (k0 + 1) * kS], n_bk = gbk[own_g + (k0 + 1) * kS];
   double h_x = 0, h_bi = 0, h_bj = 0, h_bk = 0;
-  if (has_halo) { const int pg = (k0 + 1) * kS; h_x = x_halo(k0 + 1); h_bi = gbi[halo_g + pg]; h_bj = gbj[halo_g + pg]; h_bk = gbk[halo_g + pg]; }
+  if (has_halo) { const int pg = (k0 + 1) * kS; h_x = x_halo(k0 + 1); if (nb_i) h_bi = gbi[halo_g + pg]; if (nb_j) h_bj = gbj[halo_g + pg]; if (nb_k) h_bk = gbk[halo_g + pg]; }
   double c_rhs = (MODE == FV4_APPLY) ? 0.0 : rhs[own_g + k0 * kS], c_dinv = kSmooth ? dinv[own_g + k0 * kS] : 0.0;
   double c_al = kHelm ? alpha[own_g + k0 * kS] : 0.0, c_old = (MODE == FV4_CHEBY) ? out[own_g + k0 * kS] : 0.0;
 
@@ -148,7 +153,7 @@ __global__ __launch_bounds__(TI * TJ) void fv4_tile_kernel(const hpgmg_hip_level
     if (k + 1 < k1) {
       const int ng = (k + 2) * kS;
       n_bi = gbi[own_g + ng]; n_bj = gbj[own_g + ng]; n_bk = gbk[own_g + ng];
-      if (has_halo) { h_x = x_halo_fwd(k + 2); h_bi = gbi[halo_g + ng]; h_bj = gbj[halo_g + ng]; h_bk = gbk[halo_g + ng]; }
+      if (has_halo) { h_x = x_halo_fwd(k + 2); if (nb_i) h_bi = gbi[halo_g + ng]; if (nb_j) h_bj = gbj[halo_g + ng]; if (nb_k) h_bk = gbk[halo_g + ng]; }
       xp3 = x_own_fwd(k + 3);
       const int cg = own_g + (k + 1) * kS;
       if (MODE != FV4_APPLY) nn_rhs = rhs[cg];
