@@ -35,7 +35,10 @@ int stencil_get_shape(void) {
 
 /* sweeps per smooth() call: Chebyshev degree x NUM_SMOOTHS, 2 x NUM_SMOOTHS colour
  * sweeps for GSRB, NUM_SMOOTHS for Jacobi */
+static int sweeps_override = 0;
+void hpgmg_set_smooth_sweeps(int n) { sweeps_override = n > 0 ? n : 0; }   /* experiments / tests only: the reference fixes the count at compile time */
 int hpgmg_smooth_sweeps(void) {
+  if (sweeps_override) return sweeps_override;
   const int fv = (the_cfg.op == HPGMG_OP_FV4 || the_cfg.op == HPGMG_OP_FV2);
   switch (the_cfg.smoother) {
     case HPGMG_SMOOTH_CHEBY:  return fv ? 6 : 4;  /* CHEBYSHEV_DEGREE 6 (fv2/fv4) or 4, NUM_SMOOTHS 1 */

@@ -130,6 +130,7 @@ typedef struct {
   struct { const blockCopy_type *host; int n; blockCopy_type *dev; } lists[MAX_LISTS];
   int num_lists;
   hpgmg_hip_bc_entry *d_bc[STENCIL_MAX_SHAPES]; int n_bc[STENCIL_MAX_SHAPES];   /* boundary-condition blocks with their geometry worked out */
+  hpgmg_hip_bc_entry *d_bc_k; int n_bc_k, bc_k_local;      /* the blocks of the stencil's shape whose domain normal has a k component (fv4 red + black pre-pass); n_bc_k < 0: not built */
   int bc_sources_local[STENCIL_MAX_SHAPES];    /* 1: every entry reads cells of local boxes' interiors only (no exchange needed before the conditions) */
   int *krylov_pinned;          /* iterations of device-side bottom solves not yet folded into level->Krylov_iterations */
   double *pair_scratch; double **d_pair_base;   /* two private vectors per box for the fused Chebyshev sweep pairs */
@@ -165,7 +166,7 @@ static void coef32_invalidate(level_type *L);
 static backend_t *backend_of(level_type *L) {
   hpgmg_level_ext *X = hpgmg_level_ext_get(L);
   backend_t *B = (backend_t *)X->backend;
-  if (!B) { B = (backend_t *)calloc(1, sizeof(*B)); X->backend = B; B->lexicographic = -1; }
+  if (!B) { B = (backend_t *)calloc(1, sizeof(*B)); X->backend = B; B->lexicographic = -1; B->n_bc_k = -1; }
   double *v0 = L->num_my_boxes ? L->my_boxes[0].vectors[0] : NULL;
   if (B->seen_v0 != v0 || B->seen_nv != L->numVectors || B->seen_boxes != L->num_my_boxes || !B->d_box_low) {
     int b, n = L->num_my_boxes > 0 ? L->num_my_boxes : 1;
@@ -256,6 +257,7 @@ void hpgmg_level_release(level_type *L) {
   if (!B) return;
   for (s = 0; s < B->num_lists; s++) hpgmg_hip_free(B->lists[s].dev);
   for (s = 0; s < STENCIL_MAX_SHAPES; s++) if (B->d_bc[s]) hpgmg_hip_free(B->d_bc[s]);
+  if (B->d_bc_k) hpgmg_hip_free(B->d_bc_k);
   if (B->d_box_base) hpgmg_hip_free(B->d_box_base);
   if (B->d_box_low) hpgmg_hip_free(B->d_box_low);
   if (B->d_box_nbr) hpgmg_hip_free(B->d_box_nbr);
@@ -474,22 +476,19 @@ void apply_BCs_v1(level_type *L, int x_id, int shape) { apply_BCs_p1(L, x_id, sh
 /* The finite-volume conditions work on a block's DOMAIN normal (its subtype): the axes leaving the domain sit at ghost index -1 / dim and
  * step inward, the others run over the block's extent.  That geometry is fixed per block, so it is worked out here once; the kernel
  * then only loads it (faces first: they are the long entries). */
-static const hpgmg_hip_bc_entry *bc_entries(level_type *L, int shape, int *n_out) {
-  backend_t *B = backend_of(L);
+/* host list of the entries of boundary_condition.blocks[shape] (k_only: only those whose domain normal has a k component) */
+static hpgmg_hip_bc_entry *bc_entries_host(level_type *L, int shape, int k_only, int *n_out, int *all_local_out) {
   const int n = L->boundary_condition.num_blocks[shape];
-  *n_out = n;
-  if (n <= 0) return NULL;
-  if (B->d_bc[shape] && B->n_bc[shape] == n) return B->d_bc[shape];
-  if (B->d_bc[shape]) hpgmg_hip_free(B->d_bc[shape]);
   const blockCopy_type *blocks = L->boundary_condition.blocks[shape];
-  hpgmg_hip_bc_entry *h = (hpgmg_hip_bc_entry *)calloc((size_t)n, sizeof *h);
+  hpgmg_hip_bc_entry *h = (hpgmg_hip_bc_entry *)calloc((size_t)(n > 0 ? n : 1), sizeof *h);
   const int strides[3] = {1, L->my_boxes[0].jStride, L->my_boxes[0].kStride};
-  int kind, q, m = 0, all_local = 1;
+  int kind, q, m = 0, all_local = 1, skipped = 0;
   for (kind = 1; kind <= 3; kind++) for (q = 0; q < n; q++) {
     const blockCopy_type *e = &blocks[q];
     const int d[3] = {e->subtype % 3 - 1, (e->subtype % 9) / 3 - 1, e->subtype / 9 - 1};
     const int lo[3] = {e->read.i, e->read.j, e->read.k}, len[3] = {e->dim.i, e->dim.j, e->dim.k};
     if ((d[0] != 0) + (d[1] != 0) + (d[2] != 0) != kind) continue;
+    if (k_only && !d[2]) { skipped++; continue; }
     hpgmg_hip_bc_entry *o = &h[m++];
     int ax, nf = 0;
     o->box = e->read.box; o->nn = 0; o->base = 0; o->len0 = o->len1 = 1; o->fs0 = o->fs1 = 0;
@@ -517,14 +516,42 @@ static const hpgmg_hip_bc_entry *bc_entries(level_type *L, int shape, int *n_out
       else all_local = 0;                    /* owned by another rank: that block keeps reading the ghost zone an exchange has filled */
     }
   }
-  B->bc_sources_local[shape] = all_local;
-  if (m != n) { fprintf(stderr, "hpgmg: boundary-condition block without a domain normal\n"); abort(); }
-  B->d_bc[shape] = (hpgmg_hip_bc_entry *)hpgmg_hip_malloc((size_t)n * sizeof *h);
-  if (!B->d_bc[shape]) { fprintf(stderr, "hpgmg: device allocation failed: %s\n", hpgmg_hip_last_error()); abort(); }
-  HIP_OK(hpgmg_hip_memcpy_h2d(B->d_bc[shape], h, (size_t)n * sizeof *h));
-  B->n_bc[shape] = n;
+  if (m + skipped != n) { fprintf(stderr, "hpgmg: boundary-condition block without a domain normal\n"); abort(); }
+  *n_out = m; *all_local_out = all_local;
+  return h;
+}
+static hpgmg_hip_bc_entry *bc_entries_upload(hpgmg_hip_bc_entry *h, int n) {
+  hpgmg_hip_bc_entry *d = (hpgmg_hip_bc_entry *)hpgmg_hip_malloc((size_t)(n > 0 ? n : 1) * sizeof *h);
+  if (!d) { fprintf(stderr, "hpgmg: device allocation failed: %s\n", hpgmg_hip_last_error()); abort(); }
+  if (n > 0) HIP_OK(hpgmg_hip_memcpy_h2d(d, h, (size_t)n * sizeof *h));
   free(h);
+  return d;
+}
+static const hpgmg_hip_bc_entry *bc_entries(level_type *L, int shape, int *n_out) {
+  backend_t *B = backend_of(L);
+  const int n = L->boundary_condition.num_blocks[shape];
+  *n_out = n;
+  if (n <= 0) return NULL;
+  if (B->d_bc[shape] && B->n_bc[shape] == n) return B->d_bc[shape];
+  if (B->d_bc[shape]) hpgmg_hip_free(B->d_bc[shape]);
+  int m = 0, all_local = 1;
+  hpgmg_hip_bc_entry *h = bc_entries_host(L, shape, 0, &m, &all_local);
+  B->bc_sources_local[shape] = all_local;
+  B->d_bc[shape] = bc_entries_upload(h, n);
+  B->n_bc[shape] = n;
   return B->d_bc[shape];
+}
+/* the blocks of the stencil's shape whose domain normal has a k component (faces below / above the domain, i-k and j-k edges) */
+static const hpgmg_hip_bc_entry *bc_entries_k(level_type *L, int *n_out, int *all_local_out) {
+  backend_t *B = backend_of(L);
+  if (B->n_bc_k < 0) {
+    int m = 0;
+    hpgmg_hip_bc_entry *h = bc_entries_host(L, stencil_get_shape(), 1, &m, &B->bc_k_local);
+    B->d_bc_k = bc_entries_upload(h, m);
+    B->n_bc_k = m;
+  }
+  *n_out = B->n_bc_k; *all_local_out = B->bc_k_local;
+  return B->d_bc_k;
 }
 void apply_BCs_v2(level_type *L, int x_id, int shape) {                                   /* boundary_fv.c:101-250 */
   if (shape >= STENCIL_MAX_SHAPES) shape = STENCIL_SHAPE_BOX;
@@ -1123,6 +1150,62 @@ int hpgmg_smooth_in_cycle(level_type *L, int x_id, int rhs_id, double a, double 
   temp_is_scratch = 0;
   return 1;
 }
+/* 4th-order operator, GSRB, inside a cycle (VECTOR_TEMP is scratch afterwards): each red + black pair of half sweeps as ONE pass
+ * (kernels/fv4_rb.hpp) instead of gsrb.c:24-132's two.  The passes go x -> TEMP -> private vector 0 -> x (an odd number of passes cannot
+ * ping-pong between two vectors); private vector 1 lends its k ghost planes to the intermediate vector's boundary values (the pre-pass).
+ * 0 = not applicable, the caller runs the half sweeps one by one. */
+static long long fv4_rb_smooths = 0;
+long long hpgmg_fv4_rb_smooths(void) { return fv4_rb_smooths; }
+static void fv4_rb_bcs(level_type *L, backend_t *B, int scratch, int id) {           /* apply_BCs_v4 on the pass's input (neighbouring boxes are read where they live) */
+  const int shape = stencil_get_shape();
+  if (L->boundary_condition.type == BC_PERIODIC) return;
+  if (!scratch) { if (!exchange_and_bcs_one_launch(L, id, shape, 4, 0)) apply_BCs(L, id, shape); return; }
+  int n = 0;
+  const hpgmg_hip_bc_entry *e = bc_entries(L, shape, &n);
+  hpgmg_hip_level Ls = B->dev;
+  Ls.box_base = (double *const *)B->d_pair_base;
+  TICK(L, boundary_conditions, "apply_BCs_v4 (private vector)");
+  HIP_OK(hpgmg_hip_exchange_and_bc(&Ls, id, NULL, 0, e, n, 4));
+  TOCK();
+}
+static int smooth_fv4_rb(level_type *L, int x_id, int rhs_id, double a, double b, int sweeps) {
+  hpgmg_config cfg;
+  hpgmg_get_config(&cfg);
+  backend_t *B = backend_of(L);
+  const int passes = sweeps / 2, v = variant();
+  if (cfg.op != HPGMG_OP_FV4 || !hpgmg_gsrb_out_of_place() || !temp_is_scratch || !ghost_free_mode() || (sweeps & 1) || passes < 1) return 0;
+  if (L->num_my_boxes < 1 || !B->all_faces_local || x_id == VECTOR_TEMP || rhs_id == VECTOR_TEMP || L->box_dim < 8) return 0;
+  if (!hpgmg_hip_smooth_gsrb_fv4_rb_supported(&B->dev, v)) return 0;
+  int n_k = 0, k_local = 1, n_all = 0, p;
+  const hpgmg_hip_bc_entry *e_k = NULL;
+  if (L->boundary_condition.type != BC_PERIODIC) {
+    e_k = bc_entries_k(L, &n_k, &k_local);
+    (void)bc_entries(L, stencil_get_shape(), &n_all);
+    if (!k_local || !B->bc_sources_local[stencil_get_shape()]) return 0;
+  }
+  ensure_pair_scratch(L, B);
+  hpgmg_hip_set_tile_ghost_free(1);
+  const double h2inv = 1.0 / (L->h * L->h);
+  /* (scratch, id) of the iterate before pass p: x, then TEMP / x alternately; an odd count routes its second pass through private vector 0 */
+  int src_s = 0, src_id = x_id;
+  for (p = 0; p < passes; p++) {
+    int dst_s = 0, dst_id;
+    const int left = passes - p;                   /* passes still to do, this one included */
+    if (left == 1) dst_id = (passes == 1) ? VECTOR_TEMP : x_id;
+    else if (left == 2 && !(src_s == 0 && src_id == x_id)) { dst_s = 1; dst_id = 0; }    /* two to go and not standing on x: step aside so that the last pass can land on x */
+    else dst_id = (src_s == 0 && src_id == VECTOR_TEMP) ? x_id : VECTOR_TEMP;
+    if (left == 2 && src_s == 0 && src_id == x_id) dst_id = VECTOR_TEMP;
+    fv4_rb_bcs(L, B, src_s, src_id);
+    TICK(L, smooth, "smooth (fv4 GSRB, red + black half sweeps in one pass)");
+    HIP_OK(hpgmg_hip_fv4_rb_prepass(&B->dev, v, (double *const *)B->d_pair_base, src_s, src_id, 1, rhs_id, a, b, h2inv, 2 * p, e_k, n_k));
+    HIP_OK(hpgmg_hip_smooth_gsrb_fv4_rb(&B->dev, v, (double *const *)B->d_pair_base, src_s, src_id, dst_s, dst_id, 1, rhs_id, a, b, h2inv, 2 * p));
+    TOCK();
+    src_s = dst_s; src_id = dst_id;
+  }
+  if (passes == 1) scale_vector(L, x_id, 1.0, VECTOR_TEMP);      /* a single pass cannot land on its own input (never the case with the reference's counts) */
+  fv4_rb_smooths++;
+  return 1;
+}
 void smooth(level_type *L, int x_id, int rhs_id, double a, double b) {
   hpgmg_config cfg;
   hpgmg_get_config(&cfg);
@@ -1162,6 +1245,7 @@ void smooth(level_type *L, int x_id, int rhs_id, double a, double b) {
         return;
       }
     }
+    if (smooth_fv4_rb(L, x_id, rhs_id, a, b, sweeps)) return;
     for (s = 0; s < sweeps; s++) {
       const int src = (oop && (s & 1)) ? VECTOR_TEMP : x_id, dst = oop ? ((s & 1) ? x_id : VECTOR_TEMP) : x_id;
       STENCIL_WITH_GHOSTS(L, src, dst, smooth, hpgmg_hip_smooth_gsrb(&B->dev, v, src, dst, rhs_id, a, b, h2inv, s));

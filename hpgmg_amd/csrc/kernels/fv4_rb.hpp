@@ -1,0 +1,482 @@
+// fv4_rb.hpp -- the two coloured half sweeps of one out-of-place GSRB sweep of the 4th-order operator (reference gsrb.c:24-132 with
+// operators.fv4.c:55-134, GSRB_OOP, and apply_BCs_v4 boundary_fv.c:262-569 between the half sweeps) in ONE pass over the level.
+//
+// The reference runs   exchange + apply_BCs_v4(x);  t = red half sweep of x;  exchange + apply_BCs_v4(t);  x' = black half sweep of t
+// -- two passes of 56 B per cell each (x, rhs, Dinv, beta_i/j/k read; the other vector written in full).  Here a workgroup of 64 x 8
+// lanes owns a 64 (i) x 16 (j) tile of a box -- a lane owns two vertically adjacent cells, hence one of each colour on every plane --
+// and marches in +k with two stages per step:
+//   R(q):   the red half sweep on plane q of the tile and of the cells FACE-adjacent to it (a black cell's only red neighbours are its six
+//           face neighbours, so nothing further out has to be recomputed: 80 ring cells per plane, done by 80 lanes that each own a red /
+//           black pair of them).  Inputs: planes q-1, q, q+1 of x in LDS with a three-cell halo, planes q-1 .. q+1 of beta_i / beta_j and
+//           faces q, q+1 of beta_k with a two-cell halo, x[q-2], x[q+2] of the own column in registers.  The result goes to a compact
+//           LDS ring that holds ONLY the red cells of t (a black cell of t is the cell of x, which is still in the x ring);
+//   B(q-1): the black half sweep on plane q-1 of the tile proper: red neighbours from the t ring, everything else from the x ring; x'
+//           is stored (both cells of the pair: the red one is the value R formed a step earlier).
+// LDS: x ring 4 planes x 70 x 22, beta rings (3 + 3 + 2) planes x 68 x 20, t ring 3 planes x 18 x 34 doubles = 151 008 B of the CU's
+// 160 KiB -- one workgroup per CU.  What makes it fit: the 30 coefficient values B(q) needs (6 face values, 12 differences) are formed one
+// step EARLY, while the planes they come from are in the rings for R(q) anyway, and wait in registers; otherwise every coefficient ring
+// would need a fourth plane.
+// Ghost cells of t outside the domain (the reference's second apply_BCs_v4):
+//   * in i and j they are formed in LDS, plane by plane, from t itself (v4_near / v4_far over the four cells next to the wall; the k-edge
+//     cell diagonal to a tile corner by the reference's two passes, i then j) and written where B reads them: red-parity positions into
+//     the t ring, black-parity positions OVER the x ring's ghost values (R is done with those by then);
+//   * in k they are read from the ghost planes of vector P.tg, which a small pre-pass has filled: the existing tiled kernel forms t on
+//     the four planes next to the bottom / top of the domain and the existing boundary kernel extrapolates them (faces and the i-k /
+//     j-k edges).  Registers and LDS positions of black parity on those planes take the value of P.tg, red-parity ones that of x.
+// Cells outside the box but inside the domain are read from the box that owns them (common.hpp gf_column) -- coefficients too: a ring
+// cell belongs to the neighbouring box, whose ghost coefficients differ from this box's where a third direction leaves the domain.
+// Every update is the expression tree of fv4_tile.hpp (= the reference macro), so x' is bit-identical to the two separate half sweeps;
+// the intermediate vector is never materialised: 56 B per cell per SWEEP.  x' must not alias x.
+#pragma once
+#include "common.hpp"
+#include "fv4_tile.hpp"
+#include "block_ops.hpp"
+
+namespace hpgmg {
+
+struct VecSel { double *const *base; int id; };      // vector `id` behind a table of box bases: a level vector or a plugin-private scratch vector
+__device__ __forceinline__ double *sel_origin(const hpgmg_hip_level &L, const VecSel &S, int box) {
+  return S.base[box] + (size_t)S.id * (size_t)L.volume + (size_t)L.ghosts * (size_t)(1 + L.jStride + L.kStride);
+}
+
+struct Fv4RbArgs {
+  VecSel x, out, tg;
+  int rhs_id;
+  double a, b, h2inv;
+  int sweep;                            // number of the first (even) half sweep: its colour is (i ^ j ^ k ^ sweep) & 1 == 0
+  int tiles_i, tiles_j, chunks_k, kchunk, per_xcd, total_blocks;
+};
+
+namespace fv4rb {
+constexpr int TI = 64, TJ = 16, NT = 512;
+constexpr int WX = TI + 6, HX = TJ + 6, PX = WX * HX;          // x planes: three-cell halo
+constexpr int WB = TI + 4, HB = TJ + 4, PB = WB * HB;          // coefficient planes: two-cell halo
+constexpr int ST = 34, HT = TJ + 2, PT = ST * HT;              // red cells of t on the tile + 1: column c = i + 1 -> c >> 1
+constexpr int LDS_DOUBLES = 4 * PX + 8 * PB + 3 * PT;
+constexpr size_t LDS_BYTES = (size_t)LDS_DOUBLES * sizeof(double);
+__device__ __forceinline__ constexpr int posX(int ci, int cj) { return (cj + 3) * WX + (ci + 3); }
+__device__ __forceinline__ constexpr int posB(int ci, int cj) { return (cj + 2) * WB + (ci + 2); }
+__device__ __forceinline__ int posT(int ci, int cj) { return (cj + 1) * ST + ((ci + 1) >> 1); }
+__device__ __forceinline__ int slot4(int p) { return p & 3; }
+__device__ __forceinline__ int slot3(int p) { return ((p % 3) + 3) % 3; }
+__device__ __forceinline__ int slot2(int p) { return p & 1; }
+
+struct B18 { double f[6], d[12]; };    // what the stencil takes from the coefficients at one cell: six face values, twelve differences
+// operators.fv4.c:87-108 read at a cell of three beta_i / beta_j planes and two beta_k faces (row stride WB)
+__device__ __forceinline__ void beta18(B18 &o, const double *I0, const double *Im, const double *Ip, const double *J0, const double *Jm, const double *Jp,
+                                       const double *K0, const double *K1) {
+  constexpr int W = WB;
+  o.f[0] = I0[0]; o.f[1] = I0[1]; o.f[2] = J0[0]; o.f[3] = J0[W]; o.f[4] = K0[0]; o.f[5] = K1[0];
+  o.d[0] = I0[W] - I0[-W];         o.d[1] = Ip[0] - Im[0];
+  o.d[2] = J0[1] - J0[-1];         o.d[3] = Jp[0] - Jm[0];
+  o.d[4] = K0[1] - K0[-1];         o.d[5] = K0[W] - K0[-W];
+  o.d[6] = I0[1 + W] - I0[1 - W];  o.d[7] = Ip[1] - Im[1];
+  o.d[8] = J0[W + 1] - J0[W - 1];  o.d[9] = Jp[W] - Jm[W];
+  o.d[10] = K1[1] - K1[-1];        o.d[11] = K1[W] - K1[-W];
+}
+// the same read at a cell of a box's own arrays in memory (p: the cell in the box's level vectors): what the reference reads for a cell of that box
+__device__ __forceinline__ void beta18_global(B18 &o, const double *p, size_t vol, int jS, int kS) {
+  const double *I = p + (size_t)VECTOR_BETA_I * vol, *J = p + (size_t)VECTOR_BETA_J * vol, *K = p + (size_t)VECTOR_BETA_K * vol;
+  o.f[0] = I[0]; o.f[1] = I[1]; o.f[2] = J[0]; o.f[3] = J[jS]; o.f[4] = K[0]; o.f[5] = K[kS];
+  o.d[0] = I[jS] - I[-jS];          o.d[1] = I[kS] - I[-kS];
+  o.d[2] = J[1] - J[-1];            o.d[3] = J[kS] - J[-kS];
+  o.d[4] = K[1] - K[-1];            o.d[5] = K[jS] - K[-jS];
+  o.d[6] = I[1 + jS] - I[1 - jS];   o.d[7] = I[1 + kS] - I[1 - kS];
+  o.d[8] = J[jS + 1] - J[jS - 1];   o.d[9] = J[jS + kS] - J[jS - kS];
+  o.d[10] = K[kS + 1] - K[kS - 1];  o.d[11] = K[kS + jS] - K[kS - jS];
+}
+// the 25 values of the iterate the stencil reads: centre, +-1 / +-2 along each axis, the four in-plane diagonals, the four in-plane
+// neighbours on the planes below (m_) and above (p_)
+struct X25 { double c, im1, ip1, im2, ip2, jm1, jp1, jm2, jp2, km1, kp1, km2, kp2, mm, pm, mp, pp, m_im, m_ip, m_jm, m_jp, p_im, p_ip, p_jm, p_jp; };
+// the bracket of operators.fv4.c:87-108 in fv4_tile.hpp's (= the reference's) order: T * (six face terms) + (0.25 T) * (twelve mixed terms)
+__device__ __forceinline__ double fv4_sum(const X25 &x, const B18 &b) {
+  double s1 = b.f[0] * (15.0 * (x.im1 - x.c) - (x.im2 - x.ip1));
+  s1 = s1 + b.f[1] * (15.0 * (x.ip1 - x.c) - (x.ip2 - x.im1));
+  s1 = s1 + b.f[2] * (15.0 * (x.jm1 - x.c) - (x.jm2 - x.jp1));
+  s1 = s1 + b.f[3] * (15.0 * (x.jp1 - x.c) - (x.jp2 - x.jm1));
+  s1 = s1 + b.f[4] * (15.0 * (x.km1 - x.c) - (x.km2 - x.kp1));
+  s1 = s1 + b.f[5] * (15.0 * (x.kp1 - x.c) - (x.kp2 - x.km1));
+  double s2 = b.d[0] * (x.mp - x.jp1 - x.mm + x.jm1);
+  s2 = s2 + b.d[1] * (x.p_im - x.kp1 - x.m_im + x.km1);
+  s2 = s2 + b.d[2] * (x.pm - x.ip1 - x.mm + x.im1);
+  s2 = s2 + b.d[3] * (x.p_jm - x.kp1 - x.m_jm + x.km1);
+  s2 = s2 + b.d[4] * (x.m_ip - x.ip1 - x.m_im + x.im1);
+  s2 = s2 + b.d[5] * (x.m_jp - x.jp1 - x.m_jm + x.jm1);
+  s2 = s2 + b.d[6] * (x.pp - x.jp1 - x.pm + x.jm1);
+  s2 = s2 + b.d[7] * (x.p_ip - x.kp1 - x.m_ip + x.km1);
+  s2 = s2 + b.d[8] * (x.pp - x.ip1 - x.mp + x.im1);
+  s2 = s2 + b.d[9] * (x.p_jp - x.kp1 - x.m_jp + x.km1);
+  s2 = s2 + b.d[10] * (x.p_ip - x.ip1 - x.p_im + x.im1);
+  s2 = s2 + b.d[11] * (x.p_jp - x.jp1 - x.p_jm + x.jm1);
+  return FV4_TWELFTH * s1 + (0.25 * FV4_TWELFTH) * s2;
+}
+}  // namespace fv4rb
+
+template <int V>
+__global__ __launch_bounds__(512) void fv4_rb_kernel(const hpgmg_hip_level L, const Fv4RbArgs P) {
+  using namespace fv4rb;
+  constexpr bool kHelm = (V == HPGMG_HIP_FV4_VC_HELMHOLTZ);
+  extern __shared__ double fv4rb_lds[];
+  double *sX = fv4rb_lds, *sBI = sX + 4 * PX, *sBJ = sBI + 3 * PB, *sBK = sBJ + 3 * PB, *sT = sBK + 2 * PB;
+
+  const int logical = xcd_logical_block((int)blockIdx.x, P.per_xcd);
+  if (logical >= P.total_blocks) return;
+  int t = logical;
+  const int ti = t % P.tiles_i; t /= P.tiles_i;
+  const int tj = t % P.tiles_j; t /= P.tiles_j;
+  const int ck = t % P.chunks_k; t /= P.chunks_k;
+  const int box = t;
+  const int li = (int)threadIdx.x, lj = (int)threadIdx.y, tid = lj * TI + li;     // lj: the pair of rows 2 lj, 2 lj + 1
+  const int i0 = ti * TI, j0 = tj * TJ;
+  const int dim = L.dim, jS = L.jStride, kS = L.kStride;
+  const int k0 = ck * P.kchunk, k1 = (k0 + P.kchunk < dim) ? k0 + P.kchunk : dim;
+  const size_t vol = (size_t)L.volume, first = (size_t)L.ghosts * (size_t)(1 + jS + kS);
+
+  const int *nb = L.box_nbr + 6 * box;
+  const bool wall_ilo = nb[0] == -1, wall_ihi = nb[1] == -1, wall_jlo = nb[2] == -1, wall_jhi = nb[3] == -1, wall_klo = nb[4] == -1, wall_khi = nb[5] == -1;
+  const bool t_ilo = wall_ilo && i0 == 0, t_ihi = wall_ihi && i0 + TI == dim, t_jlo = wall_jlo && j0 == 0, t_jhi = wall_jhi && j0 + TJ == dim;
+  const bool bottom = wall_klo && k0 == 0, top = wall_khi && k1 == dim;      // this chunk starts / ends at the domain boundary
+  // how far box-relative coordinate c lies outside the DOMAIN (0: inside)
+  auto out_i = [&](int c) { return (c < 0 && wall_ilo) ? -c : ((c >= dim && wall_ihi) ? c - dim + 1 : 0); };
+  auto out_j = [&](int c) { return (c < 0 && wall_jlo) ? -c : ((c >= dim && wall_jhi) ? c - dim + 1 : 0); };
+  const int par0 = (L.box_low[3 * box] ^ L.box_low[3 * box + 1] ^ L.box_low[3 * box + 2] ^ P.sweep) & 1;
+  auto is_red = [&](int ci, int cj, int ck2) { return (((ci ^ cj ^ ck2 ^ par0) & 1) == 0); };    // box-relative cell coordinates
+
+  // ---- (1) the own pair of cells (gi, gj), (gi, gj + 1).  Every vector of the own box is reached from one uniform base with the
+  // lane's 32-bit offset own_g; planes p >= dim through the base of the box above (or the own ghost zone)
+  const int gi = i0 + li, gj = j0 + 2 * lj, own_g = gi + gj * jS;
+  const int ownX = posX(li, 2 * lj), ownB = posB(li, 2 * lj), ownT = posT(li, 2 * lj);
+  const double *lvb = L.box_base[box] + first, *lvb_hi = lvb;                       // level vectors: lvb[id * vol + own_g + p * kS (+ jS)]
+  const double *xb = sel_origin(L, P.x, box), *xb_hi = xb;
+  const double *tgb = sel_origin(L, P.tg, box);                                     // its k ghost planes: boundary values of t
+  double *outb = sel_origin(L, P.out, box);
+  if (nb[5] >= 0) { lvb_hi = L.box_base[nb[5]] + first - (long long)dim * kS; xb_hi = sel_origin(L, P.x, nb[5]) - (long long)dim * kS; }
+
+  // ---- (2) one halo cell of the x planes (the cells within three steps of the tile: 492)
+  const bool has_h = tid < 492;
+  int hi = 0, hj = 0;
+  if (has_h) {
+    if (tid < 64)       { hj = -3; hi = tid; }
+    else if (tid < 128) { hj = TJ + 2; hi = tid - 64; }
+    else if (tid < 194) { hj = -2; hi = -1 + (tid - 128); }
+    else if (tid < 260) { hj = TJ + 1; hi = -1 + (tid - 194); }
+    else if (tid < 328) { hj = -1; hi = -2 + (tid - 260); }
+    else if (tid < 396) { hj = TJ; hi = -2 + (tid - 328); }
+    else                { const int h = tid - 396, c = h % 6; hj = h / 6; hi = (c < 3) ? c - 3 : TI + (c - 3); }
+  }
+  const int hX = posX(hi, hj);
+  const bool h_ok = has_h && out_i(i0 + hi) <= 2 && out_j(j0 + hj) <= 2;          // further out nothing is defined (and nothing is needed)
+  GfColumn hcol = {box, 0};
+  if (h_ok) hcol = gf_column(L, box, i0 + hi, j0 + hj);
+  // a halo cell face-adjacent to the tile: a position B reads on the planes r - 1, r + 1 (the k ghost planes of t need it)
+  const bool h_face = h_ok && ((hi >= 0 && hi < TI && (hj == -1 || hj == TJ)) || (hj >= 0 && hj < TJ && (hi == -1 || hi == TI)));
+  const double *__restrict__ xh = sel_origin(L, P.x, hcol.box) + hcol.off, *__restrict__ xh_hi = xh;
+  { const int m = L.box_nbr[6 * hcol.box + 5]; if (h_ok && m >= 0) xh_hi = sel_origin(L, P.x, m) + hcol.off - (long long)dim * kS; }
+
+  // ---- (3) lanes 0 .. 331: one halo cell of the coefficient planes (what the stencils of the tile and of its face-adjacent ring reach), read
+  //      from the OWN box's ghost zone like the reference does: inside the domain that is the neighbour's value (rebuild_operator exchanged
+  //      it), outside the domain it is this box's own extrapolation -- which differs from what the neighbouring box holds for the same
+  //      place (extrapolate_betas works with box-relative normals), see "special" below
+  // ---- (4) lanes 432 .. 511: a red / black pair of ring cells e0 = (ei, ej), e1 = e0 + (edx, edy), in the box that owns them
+  const bool has_b = tid < 332, has_e = tid >= 432;
+  int bhi = 0, bhj = 0, ei = 0, ej = 0, edx = 0, edy = 0;
+  if (has_b) {
+    if (tid < 66)       { bhj = -2; bhi = -1 + tid; }
+    else if (tid < 132) { bhj = TJ + 1; bhi = -1 + (tid - 66); }
+    else if (tid < 200) { bhj = -1; bhi = -2 + (tid - 132); }
+    else if (tid < 268) { bhj = TJ; bhi = -2 + (tid - 200); }
+    else                { const int h = tid - 268, c = h % 4; bhj = h / 4; bhi = (c < 2) ? c - 2 : TI + (c - 2); }
+  }
+  if (has_e) {
+    const int e = tid - 432;
+    if (e < 32)      { ej = -1; ei = 2 * e; edx = 1; }
+    else if (e < 64) { ej = TJ; ei = 2 * (e - 32); edx = 1; }
+    else if (e < 72) { ei = -1; ej = 2 * (e - 64); edy = 1; }
+    else             { ei = TI; ej = 2 * (e - 72); edy = 1; }
+  }
+  const int bB = posB(bhi, bhj), b_g = (i0 + bhi) + (j0 + bhj) * jS;              // the coefficient halo cell: in LDS, in the own box
+  const bool e_in = has_e && out_i(i0 + ei) == 0 && out_j(j0 + ej) == 0;          // inside the domain: R forms its red cell
+  const bool e_other = e_in && (i0 + ei < 0 || i0 + ei >= dim || j0 + ej < 0 || j0 + ej >= dim);     // ... which belongs to another box
+  GfColumn acol = {box, 0};
+  if (e_in)  acol = gf_column(L, box, i0 + ei, j0 + ej);
+  const int e_step = edx + edy * jS;                                              // second cell of the ring pair, in memory (same box: pairs are aligned)
+  const double *__restrict__ al = L.box_base[acol.box] + first + acol.off, *__restrict__ al_hi = al;
+  const double *__restrict__ xe = sel_origin(L, P.x, acol.box) + acol.off, *__restrict__ xe_hi = xe;
+  { const int m = L.box_nbr[6 * acol.box + 5];
+    if (e_in && m >= 0) { al_hi = L.box_base[m] + first + acol.off - (long long)dim * kS; xe_hi = sel_origin(L, P.x, m) + acol.off - (long long)dim * kS; } }
+
+  // ---- (5) lanes 0 .. 331: one ghost cell of t outside the domain in i and / or j: kind 1 near, 2 far, 3 the k-edge cell diagonal to a tile corner
+  const bool tile_wall = t_ilo || t_ihi || t_jlo || t_jhi;
+  int bc_kind = 0, bc_i = 0, bc_j = 0, bc_si = 0, bc_sj = 0;                      // position, inward step(s)
+  if (tile_wall) {
+    int n = tid;
+    // i walls: near cells of rows -1 .. TJ (a row outside the domain makes it the k-edge cell), far cells of rows 0 .. TJ-1
+    for (int side = 0; side < 2 && n >= 0; side++) {
+      if (!(side ? t_ihi : t_ilo)) continue;
+      if (n < 34) {
+        const int col = side ? TI : -1, s = side ? -1 : 1;
+        if (n < 18) { const int r = -1 + n; const int oj = out_j(j0 + r);
+                      bc_i = col; bc_j = r; bc_si = s;
+                      if (oj) { bc_kind = 3; bc_sj = (r < 0) ? 1 : -1; } else bc_kind = 1; }
+        else        { bc_kind = 2; bc_i = side ? TI + 1 : -2; bc_j = n - 18; bc_si = s; }
+        n = -1;
+      } else n -= 34;
+    }
+    // j walls: near cells of columns -1 .. TI inside the domain, far cells of columns 0 .. TI-1
+    for (int side = 0; side < 2 && n >= 0; side++) {
+      if (!(side ? t_jhi : t_jlo)) continue;
+      if (n < 130) {
+        const int row = side ? TJ : -1, s = side ? -1 : 1;
+        if (n < 66) { const int c = -1 + n; if (!out_i(i0 + c)) { bc_kind = 1; bc_i = c; bc_j = row; bc_sj = s; } }
+        else        { bc_kind = 2; bc_i = n - 66; bc_j = side ? TJ + 1 : -2; bc_sj = s; }
+        n = -1;
+      } else n -= 130;
+    }
+  }
+
+  // t on plane q at a tile / ring cell inside the domain: a red cell from the t ring, a black one is the cell of x
+  auto t_at = [&](int ci, int cj, int q) -> double {
+    return is_red(i0 + ci, j0 + cj, q) ? sT[slot3(q) * PT + posT(ci, cj)] : sX[slot4(q) * PX + posX(ci, cj)];
+  };
+
+  // ---- loaders.  Inside the marching loop only planes >= 0 are fetched (one select between the in-box base and the one for planes
+  // >= dim); planes below the box are only met in the prologue of the first chunk and looked up there.
+  const int qlo = bottom ? 0 : k0 - 1, qhi = top ? dim - 1 : k1;                  // planes R works on
+  auto x_own_any = [&](int cell, int p) -> double {                               // x at the own column, cell 0 / 1 of the pair
+    if (p >= 0) return (p > dim + 1 && wall_khi) ? 0.0 : ((p >= dim) ? xb_hi : xb)[own_g + cell * jS + p * kS];
+    if (nb[4] >= 0) return sel_origin(L, P.x, nb[4])[own_g + cell * jS + (p + dim) * kS];
+    return (p < -2) ? 0.0 : xb[own_g + cell * jS + p * kS];
+  };
+  auto lv_any = [&](int id, int cell, int p) -> double {                          // a level vector at the own column, any plane the box or its k neighbours hold
+    if (p >= 0) return ((p >= dim) ? lvb_hi : lvb)[(size_t)id * vol + own_g + cell * jS + p * kS];
+    if (nb[4] >= 0) return (L.box_base[nb[4]] + first)[(size_t)id * vol + own_g + cell * jS + (p + dim) * kS];
+    return lvb[(size_t)id * vol + own_g + cell * jS + p * kS];
+  };
+  auto xh_fwd = [&](int p) -> double { return ((p >= dim) ? xh_hi : xh)[p * kS]; };
+  auto xh_any = [&](int p) -> double {
+    if (!h_ok) return 0.0;
+    if (p >= 0) return (p > dim + 1 && L.box_nbr[6 * hcol.box + 5] < 0) ? 0.0 : xh_fwd(p);
+    const int m = L.box_nbr[6 * hcol.box + 4];
+    if (m >= 0) return sel_origin(L, P.x, m)[hcol.off + (p + dim) * kS];
+    return (p < -2) ? 0.0 : xh[p * kS];
+  };
+  auto al_fwd = [&](int id, int cell, int p) -> double { return ((p >= dim) ? al_hi : al)[(size_t)id * vol + cell * e_step + p * kS]; };
+  auto al_any = [&](int id, int cell, int p) -> double {
+    if (p >= 0) return al_fwd(id, cell, p);
+    const int m = L.box_nbr[6 * acol.box + 4];
+    if (m >= 0) return (L.box_base[m] + first)[(size_t)id * vol + acol.off + cell * e_step + (p + dim) * kS];
+    return al[(size_t)id * vol + cell * e_step + p * kS];
+  };
+  auto xe_fwd = [&](int cell, int p) -> double { return ((p >= dim) ? xe_hi : xe)[cell * e_step + p * kS]; };
+  auto e_red = [&](int q) { return is_red(i0 + ei, j0 + ej, q) ? 0 : 1; };         // which cell of the ring pair is red on plane q
+
+  // ---- prologue: planes qlo-2 .. qlo+1 of x, planes qlo-1 .. qlo+1 of beta_i / beta_j, faces qlo, qlo+1 of beta_k into LDS; x[qlo+2] of
+  // the own columns and the per-cell streams of plane qlo into registers
+  for (int p = qlo - 2; p <= qlo + 1; p++) {
+    const int s = slot4(p) * PX;
+    sX[s + ownX] = x_own_any(0, p); sX[s + ownX + WX] = x_own_any(1, p);
+    if (has_h) sX[s + hX] = xh_any(p);
+  }
+  for (int p = qlo - 1; p <= qlo + 1; p++) {
+    const int s = slot3(p) * PB;
+    sBI[s + ownB] = lvb[(size_t)VECTOR_BETA_I * vol + own_g + p * kS]; sBI[s + ownB + WB] = lvb[(size_t)VECTOR_BETA_I * vol + own_g + jS + p * kS];
+    sBJ[s + ownB] = lvb[(size_t)VECTOR_BETA_J * vol + own_g + p * kS]; sBJ[s + ownB + WB] = lvb[(size_t)VECTOR_BETA_J * vol + own_g + jS + p * kS];
+    if (has_b) { sBI[s + bB] = lvb[(size_t)VECTOR_BETA_I * vol + b_g + p * kS]; sBJ[s + bB] = lvb[(size_t)VECTOR_BETA_J * vol + b_g + p * kS]; }
+    if (p >= qlo) {
+      const int s2 = slot2(p) * PB;
+      sBK[s2 + ownB] = lvb[(size_t)VECTOR_BETA_K * vol + own_g + p * kS]; sBK[s2 + ownB + WB] = lvb[(size_t)VECTOR_BETA_K * vol + own_g + jS + p * kS];
+      if (has_b) sBK[s2 + bB] = lvb[(size_t)VECTOR_BETA_K * vol + b_g + p * kS];
+    }
+  }
+  double kp2_0 = x_own_any(0, qlo + 2), kp2_1 = x_own_any(1, qlo + 2);           // x two planes above the current one, both cells of the pair
+  double c_rhs0 = lv_any(P.rhs_id, 0, qlo), c_rhs1 = lv_any(P.rhs_id, 1, qlo), c_dinv0 = lv_any(VECTOR_DINV, 0, qlo), c_dinv1 = lv_any(VECTOR_DINV, 1, qlo);
+  double c_al0 = kHelm ? lv_any(VECTOR_ALPHA, 0, qlo) : 0.0, c_al1 = kHelm ? lv_any(VECTOR_ALPHA, 1, qlo) : 0.0;
+  double e_rhs = 0.0, e_dinv = 0.0, e_al = 0.0, e_xp2 = 0.0;                       // ring: the streams of the cell that is red on the current plane, its x two planes up
+  if (e_in) {
+    const int c = e_red(qlo);
+    e_rhs = al_any(P.rhs_id, c, qlo); e_dinv = al_any(VECTOR_DINV, c, qlo); if (kHelm) e_al = al_any(VECTOR_ALPHA, c, qlo);
+    e_xp2 = xe_fwd(c, qlo + 2);
+  }
+  // what B(q) needs from the coefficient planes that will have left the rings by then (beta_i / beta_j plane q-1, beta_k face q), formed a step early
+  double pd1 = 0.0, pd3 = 0.0, pd7 = 0.0, pd9 = 0.0, pf4 = 0.0, pd4 = 0.0, pd5 = 0.0;
+  double b_rhs = 0.0, b_dinv = 0.0, b_al = 0.0, r_prev = 0.0, kmB = 0.0;           // kmB: t three planes below the current one at the cell B works on
+  const double bh2inv = P.b * P.h2inv, nbh2inv = (-P.b) * P.h2inv;
+
+  const int qend = top ? dim : qhi;                                                 // at the top of the domain one more step: B(dim-1) after t's ghost plane
+  for (int q = qlo; q <= qend; q++) {
+    __syncthreads();                                                                // [A] the planes stored at the end of the previous step are in place
+    const bool do_r = q <= qhi, more = q + 1 <= qhi;                                // more: there is an R(q+1)
+    // ---- loads of this step (consumed at its end or in the next step)
+    double n_x0 = 0.0, n_x1 = 0.0, n_hx = 0.0, n_bi0 = 0.0, n_bi1 = 0.0, n_bj0 = 0.0, n_bj1 = 0.0, n_bk0 = 0.0, n_bk1 = 0.0, h_bi = 0.0, h_bj = 0.0, h_bk = 0.0;
+    double n_rhs0 = 0.0, n_rhs1 = 0.0, n_dinv0 = 0.0, n_dinv1 = 0.0, n_al0 = 0.0, n_al1 = 0.0, ne_rhs = 0.0, ne_dinv = 0.0, ne_al = 0.0, ne_xp2 = 0.0;
+    if (more) {
+      const int p2 = q + 2, p3 = q + 3, p1 = q + 1;
+      if (h_ok) n_hx = xh_fwd(p2);
+      { const double *b = lvb + own_g + p2 * kS;                                    // coefficients: always the own box's arrays, ghost planes included
+        n_bi0 = b[(size_t)VECTOR_BETA_I * vol]; n_bi1 = b[(size_t)VECTOR_BETA_I * vol + jS];
+        n_bj0 = b[(size_t)VECTOR_BETA_J * vol]; n_bj1 = b[(size_t)VECTOR_BETA_J * vol + jS];
+        n_bk0 = b[(size_t)VECTOR_BETA_K * vol]; n_bk1 = b[(size_t)VECTOR_BETA_K * vol + jS]; }
+      if (has_b) { const double *b = lvb + b_g + p2 * kS; h_bi = b[(size_t)VECTOR_BETA_I * vol]; h_bj = b[(size_t)VECTOR_BETA_J * vol]; h_bk = b[(size_t)VECTOR_BETA_K * vol]; }
+      if (!(wall_khi && p3 > dim + 1)) { const double *b = ((p3 >= dim) ? xb_hi : xb) + own_g + p3 * kS; n_x0 = b[0]; n_x1 = b[jS]; }
+      { const double *b = ((p1 >= dim) ? lvb_hi : lvb) + own_g + p1 * kS;
+        n_rhs0 = b[(size_t)P.rhs_id * vol]; n_rhs1 = b[(size_t)P.rhs_id * vol + jS];
+        n_dinv0 = b[(size_t)VECTOR_DINV * vol]; n_dinv1 = b[(size_t)VECTOR_DINV * vol + jS];
+        if (kHelm) { n_al0 = b[(size_t)VECTOR_ALPHA * vol]; n_al1 = b[(size_t)VECTOR_ALPHA * vol + jS]; } }
+      if (e_in) {
+        const int c = e_red(p1);
+        ne_rhs = al_fwd(P.rhs_id, c, p1); ne_dinv = al_fwd(VECTOR_DINV, c, p1); if (kHelm) ne_al = al_fwd(VECTOR_ALPHA, c, p1);
+        ne_xp2 = xe_fwd(c, p3);
+      }
+    }
+
+    const int up = is_red(gi, gj, q) ? 0 : 1;                                      // the red cell of the own pair on plane q: 0 lower, 1 upper
+    double r_new = 0.0;
+    if (do_r) {
+      const double *X0 = sX + slot4(q) * PX, *Xm = sX + slot4(q - 1) * PX, *Xp = sX + slot4(q + 1) * PX, *Xmm = sX + slot4(q - 2) * PX;
+      const double *I0 = sBI + slot3(q) * PB, *Im = sBI + slot3(q - 1) * PB, *Ip = sBI + slot3(q + 1) * PB;
+      const double *J0 = sBJ + slot3(q) * PB, *Jm = sBJ + slot3(q - 1) * PB, *Jp = sBJ + slot3(q + 1) * PB;
+      const double *K0 = sBK + slot2(q) * PB, *K1 = sBK + slot2(q + 1) * PB;
+      auto gather = [&](X25 &x, int o, double kp2) {                               // the 25 values around position o of the x planes
+        constexpr int W = WX;
+        x.c = X0[o]; x.im1 = X0[o - 1]; x.ip1 = X0[o + 1]; x.im2 = X0[o - 2]; x.ip2 = X0[o + 2];
+        x.jm1 = X0[o - W]; x.jp1 = X0[o + W]; x.jm2 = X0[o - 2 * W]; x.jp2 = X0[o + 2 * W];
+        x.km1 = Xm[o]; x.kp1 = Xp[o]; x.km2 = Xmm[o]; x.kp2 = kp2;
+        x.mm = X0[o - 1 - W]; x.pm = X0[o + 1 - W]; x.mp = X0[o - 1 + W]; x.pp = X0[o + 1 + W];
+        x.m_im = Xm[o - 1]; x.m_ip = Xm[o + 1]; x.m_jm = Xm[o - W]; x.m_jp = Xm[o + W];
+        x.p_im = Xp[o - 1]; x.p_ip = Xp[o + 1]; x.p_jm = Xp[o - W]; x.p_jp = Xp[o + W];
+      };
+      { // ---- R(q) at the red cell of the own pair (gsrb.c:100-104)
+        X25 x; B18 bt;
+        const int oX = ownX + up * WX, oB = ownB + up * WB;
+        gather(x, oX, up ? kp2_1 : kp2_0);
+        // "special": a cell of ANOTHER box (here: a plane below / above this box) whose stencil reaches outside the domain must see that
+        // box's own extrapolated coefficients there, not this box's: read them where the reference reads them
+        const int row = 2 * lj + up;
+        const bool sp = (q < 0 || q >= dim) && ((t_ilo && li == 0) || (t_ihi && li == TI - 1) || (t_jlo && row == 0) || (t_jhi && row == TJ - 1));
+        if (sp) {
+          const double *pc = (q >= dim) ? lvb_hi + own_g + up * jS + q * kS : L.box_base[nb[4]] + first + own_g + up * jS + (q + dim) * kS;
+          beta18_global(bt, pc, vol, jS, kS);
+        } else beta18(bt, I0 + oB, Im + oB, Ip + oB, J0 + oB, Jm + oB, Jp + oB, K0 + oB, K1 + oB);
+        const double sum = fv4_sum(x, bt);
+        const double alv = up ? c_al1 : c_al0, rhs = up ? c_rhs1 : c_rhs0, dinv = up ? c_dinv1 : c_dinv0;
+        const double Ax = kHelm ? (P.a * alv) * x.c - bh2inv * sum : nbh2inv * sum;
+        r_new = x.c + dinv * (rhs - Ax);
+        sT[slot3(q) * PT + ownT + up * ST] = r_new;
+      }
+      if (e_in) { // ---- R(q) at the red cell of the ring pair
+        X25 x; B18 bt;
+        const int c = e_red(q), ci = ei + c * edx, cj = ej + c * edy;
+        const int oX = posX(ci, cj), oB = posB(ci, cj);
+        gather(x, oX, e_xp2);
+        const int ci_g = i0 + ci, cj_g = j0 + cj;
+        const bool sp = (e_other || q < 0 || q >= dim) &&
+                        (out_i(ci_g - 1) || out_i(ci_g + 1) || out_j(cj_g - 1) || out_j(cj_g + 1) || (wall_klo && q == 0) || (wall_khi && q == dim - 1));
+        if (sp) {
+          const double *pc;
+          if (q >= 0) pc = ((q >= dim) ? al_hi : al) + c * e_step + q * kS;
+          else { const int m = L.box_nbr[6 * acol.box + 4]; pc = L.box_base[m] + first + acol.off + c * e_step + (q + dim) * kS; }
+          beta18_global(bt, pc, vol, jS, kS);
+        } else beta18(bt, I0 + oB, Im + oB, Ip + oB, J0 + oB, Jm + oB, Jp + oB, K0 + oB, K1 + oB);
+        const double sum = fv4_sum(x, bt);
+        const double Ax = kHelm ? (P.a * e_al) * x.c - bh2inv * sum : nbh2inv * sum;
+        sT[slot3(q) * PT + posT(ci, cj)] = x.c + e_dinv * (e_rhs - Ax);
+      }
+    }
+    __syncthreads();                                                                // [B] t on plane q is complete inside the domain
+    // ghost values of t: in i / j on plane q (tiles at a wall); below the domain after R(0); above it after R(dim-1) (the x ring's part:
+    // B(dim-2) reads it in this step) and in the extra step (the t ring's part, whose slot B(dim-2) still needed)
+    const int kfill = (bottom && q == 0) ? 1 : ((top && q == dim - 1) ? 2 : ((top && q == dim) ? 3 : 0));
+    if ((tile_wall && do_r) || kfill) {
+      if (tile_wall && do_r && bc_kind) {
+        // ---- ghost cells of t on plane q outside the domain in i / j: apply_BCs_v4 (boundary_fv.c:262-425) from t itself
+        const bool red = is_red(i0 + bc_i, j0 + bc_j, q);
+        if (bc_kind == 3) {
+          if (!red) {                                                               // read by the diagonal black cell only
+            double n4[4];
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+              const int cj = bc_j + (m + 1) * bc_sj;
+              n4[m] = v4_near(t_at(bc_i + bc_si, cj, q), t_at(bc_i + 2 * bc_si, cj, q), t_at(bc_i + 3 * bc_si, cj, q), t_at(bc_i + 4 * bc_si, cj, q));
+            }
+            sX[slot4(q) * PX + posX(bc_i, bc_j)] = v4_near(n4[0], n4[1], n4[2], n4[3]);
+          }
+        } else {
+          const int d = bc_kind;                                                    // the first cell inside the domain is d steps away
+          const int wi = bc_i + d * bc_si, wj = bc_j + d * bc_sj;
+          const double x1 = t_at(wi, wj, q), x2 = t_at(wi + bc_si, wj + bc_sj, q), x3 = t_at(wi + 2 * bc_si, wj + 2 * bc_sj, q), x4 = t_at(wi + 3 * bc_si, wj + 3 * bc_sj, q);
+          if (bc_kind == 1) { const double v = v4_near(x1, x2, x3, x4); if (red) sT[slot3(q) * PT + posT(bc_i, bc_j)] = v; else sX[slot4(q) * PX + posX(bc_i, bc_j)] = v; }
+          else if (!red)    sX[slot4(q) * PX + posX(bc_i, bc_j)] = v4_far(x1, x2, x3, x4);
+        }
+      }
+      if (kfill) {
+        // ---- the ghost plane of t below / above the domain (P.tg): red-parity own cells into the t ring, black-parity positions over x's
+        const int pg = (kfill == 1) ? -1 : dim;
+        const double t0 = tgb[own_g + pg * kS], t1 = tgb[own_g + jS + pg * kS];
+        const bool red0 = is_red(gi, gj, pg);
+        if (kfill != 3) {
+          sX[slot4(pg) * PX + ownX + (red0 ? WX : 0)] = red0 ? t1 : t0;
+          if (h_face && !is_red(i0 + hi, j0 + hj, pg)) sX[slot4(pg) * PX + hX] = (sel_origin(L, P.tg, hcol.box) + hcol.off)[pg * kS];
+        }
+        if (kfill != 2) sT[slot3(pg) * PT + ownT + (red0 ? 0 : ST)] = red0 ? t0 : t1;
+        if (kfill == 1) sX[slot4(-2) * PX + ownX + (red0 ? 0 : WX)] = tgb[own_g + (red0 ? 0 : jS) - 2 * kS];   // two below: black parity where plane -1 is red
+      }
+      __syncthreads();                                                              // [C]
+    }
+
+    // ---- B(r), r = q - 1: the black half sweep at the cell of the own pair that is red on plane q (black on plane r)
+    const int r = q - 1;
+    if (r >= k0 && r < k1) {
+      X25 x; B18 bt;
+      const double *X0 = sX + slot4(r) * PX, *Xm = sX + slot4(r - 1) * PX, *Xp = sX + slot4(r + 1) * PX;
+      const double *T0 = sT + slot3(r) * PT, *Tm = sT + slot3(r - 1) * PT, *Tp = sT + slot3(r + 1) * PT;
+      const int row = 2 * lj + up;
+      const int o = posX(li, row), oB = posB(li, row);
+      constexpr int W = WX, V2 = WB;
+      x.c = X0[o];
+      x.km2 = kmB;
+      x.kp2 = (top && q == dim) ? tgb[own_g + up * jS + (dim + 1) * kS] : sX[slot4(q + 1) * PX + o];
+      x.im1 = T0[posT(li - 1, row)]; x.ip1 = T0[posT(li + 1, row)]; x.jm1 = T0[posT(li, row - 1)]; x.jp1 = T0[posT(li, row + 1)];
+      x.km1 = Tm[posT(li, row)]; x.kp1 = Tp[posT(li, row)];
+      x.im2 = X0[o - 2]; x.ip2 = X0[o + 2]; x.jm2 = X0[o - 2 * W]; x.jp2 = X0[o + 2 * W];
+      x.mm = X0[o - 1 - W]; x.pm = X0[o + 1 - W]; x.mp = X0[o - 1 + W]; x.pp = X0[o + 1 + W];
+      x.m_im = Xm[o - 1]; x.m_ip = Xm[o + 1]; x.m_jm = Xm[o - W]; x.m_jp = Xm[o + W];
+      x.p_im = Xp[o - 1]; x.p_ip = Xp[o + 1]; x.p_jm = Xp[o - W]; x.p_jp = Xp[o + W];
+      // coefficients: beta_i / beta_j plane r and beta_k face r+1 are still in the rings, the rest was formed in the previous step
+      const double *I0 = sBI + slot3(r) * PB + oB, *J0 = sBJ + slot3(r) * PB + oB, *K1 = sBK + slot2(r + 1) * PB + oB;
+      bt.f[0] = I0[0]; bt.f[1] = I0[1]; bt.f[2] = J0[0]; bt.f[3] = J0[V2]; bt.f[4] = pf4; bt.f[5] = K1[0];
+      bt.d[0] = I0[V2] - I0[-V2]; bt.d[1] = pd1; bt.d[2] = J0[1] - J0[-1]; bt.d[3] = pd3; bt.d[4] = pd4; bt.d[5] = pd5;
+      bt.d[6] = I0[1 + V2] - I0[1 - V2]; bt.d[7] = pd7; bt.d[8] = J0[V2 + 1] - J0[V2 - 1]; bt.d[9] = pd9;
+      bt.d[10] = K1[1] - K1[-1]; bt.d[11] = K1[V2] - K1[-V2];
+      const double sum = fv4_sum(x, bt);
+      const double Ax = kHelm ? (P.a * b_al) * x.c - bh2inv * sum : nbh2inv * sum;
+      outb[own_g + up * jS + r * kS] = x.c + b_dinv * (b_rhs - Ax);
+      outb[own_g + (1 - up) * jS + r * kS] = r_prev;                                // the pair's red cell on plane r: what R(r) formed
+    }
+    if (do_r) {
+      // for B(q) in the next step, at the OTHER cell of the pair (black on plane q): the terms whose planes will have left the rings by then
+      // (after B(q-1), which has just used the previous set)
+      const double *Im = sBI + slot3(q - 1) * PB, *Ip = sBI + slot3(q + 1) * PB, *Jm = sBJ + slot3(q - 1) * PB, *Jp = sBJ + slot3(q + 1) * PB, *K0 = sBK + slot2(q) * PB;
+      const int o2 = ownB + (1 - up) * WB;
+      pd1 = Ip[o2] - Im[o2]; pd7 = Ip[o2 + 1] - Im[o2 + 1]; pd3 = Jp[o2] - Jm[o2]; pd9 = Jp[o2 + WB] - Jm[o2 + WB];
+      pf4 = K0[o2]; pd4 = K0[o2 + 1] - K0[o2 - 1]; pd5 = K0[o2 + WB] - K0[o2 - WB];
+    }
+    __syncthreads();                                                                // [D] B is done with the plane that is overwritten now
+    // t three planes below the NEXT plane at the cell B works on then (the other cell of the pair): still in the x ring, in a slot this lane itself overwrites next
+    kmB = sX[slot4(q - 2) * PX + ownX + (1 - up) * WX];
+    if (more) {
+      const int p2 = q + 2, s = slot4(p2) * PX, sb = slot3(p2) * PB, sk = slot2(p2) * PB;
+      sX[s + ownX] = kp2_0; sX[s + ownX + WX] = kp2_1;
+      if (has_h) sX[s + hX] = n_hx;
+      sBI[sb + ownB] = n_bi0; sBI[sb + ownB + WB] = n_bi1; sBJ[sb + ownB] = n_bj0; sBJ[sb + ownB + WB] = n_bj1; sBK[sk + ownB] = n_bk0; sBK[sk + ownB + WB] = n_bk1;
+      if (has_b) { sBI[sb + bB] = h_bi; sBJ[sb + bB] = h_bj; sBK[sk + bB] = h_bk; }
+    }
+    // ---- next plane
+    r_prev = r_new;
+    b_rhs = up ? c_rhs0 : c_rhs1; b_dinv = up ? c_dinv0 : c_dinv1; b_al = up ? c_al0 : c_al1;      // the black cell of plane q: B(q) in the next step
+    kp2_0 = n_x0; kp2_1 = n_x1;
+    c_rhs0 = n_rhs0; c_rhs1 = n_rhs1; c_dinv0 = n_dinv0; c_dinv1 = n_dinv1; c_al0 = n_al0; c_al1 = n_al1;
+    e_rhs = ne_rhs; e_dinv = ne_dinv; e_al = ne_al; e_xp2 = ne_xp2;
+  }
+}
+
+}  // namespace hpgmg

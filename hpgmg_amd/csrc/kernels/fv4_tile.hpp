@@ -32,6 +32,11 @@ struct Fv4TileArgs {
   int sweep, copy_other_colour, ghost_free;
   TileFused fused;                      // FV4_RESIDUAL only: what becomes of the residual (common.hpp)
   int tiles_i, tiles_j, chunks_k, kchunk, per_xcd, total_blocks;
+  // the pre-pass of the one-pass red + black kernel (fv4_rb.hpp) runs a half sweep on a few planes only: chunk ck starts at plane
+  // k_origin + ck * k_step (0 / 0: at ck * kchunk); wall_only: chunk 0 / 1 only in boxes whose low / high k face is the domain boundary;
+  // x_base / out_base: box-base tables of the vectors xn_id / xout_id when they are plugin-private scratch vectors (NULL: level vectors)
+  int k_origin, k_step, wall_only;
+  double *const *x_base, *const *out_base;
 };
 enum { FV4_CHEBY = 0, FV4_GSRB = 1, FV4_JACOBI = 2, FV4_RESIDUAL = 3, FV4_APPLY = 4 };
 
@@ -55,11 +60,15 @@ __global__ __launch_bounds__(TI * TJ) void fv4_tile_kernel(const hpgmg_hip_level
   const int box = t;
   const int li = (int)threadIdx.x, lj = (int)threadIdx.y, tid = lj * TI + li;
   const int i0 = ti * TI, j0 = tj * TJ, i = i0 + li, j = j0 + lj;
-  const int k0 = ck * P.kchunk, k1 = (k0 + P.kchunk < L.dim) ? k0 + P.kchunk : L.dim;
+  const int k0 = P.k_origin + ck * (P.k_step ? P.k_step : P.kchunk), k1 = (k0 + P.kchunk < L.dim) ? k0 + P.kchunk : L.dim;
   const int jS = L.jStride, kS = L.kStride;
+  if (P.wall_only && L.box_nbr[6 * box + (ck ? 5 : 4)] != -1) return;
+  hpgmg_hip_level Lx = L, Lo = L;                                  // where the iterate is read / written (a scratch table, or the level)
+  if (P.x_base) Lx.box_base = P.x_base;
+  if (P.out_base) Lo.box_base = P.out_base;
 
-  const double *__restrict__ x = vec_origin(L, box, P.xn_id);
-  double *__restrict__ out = vec_origin(L, box, P.xout_id);
+  const double *__restrict__ x = vec_origin(Lx, box, P.xn_id);
+  double *__restrict__ out = vec_origin(Lo, box, P.xout_id);
   const double *__restrict__ rhs = (MODE == FV4_APPLY) ? nullptr : vec_origin(L, box, P.rhs_id);
   const double *__restrict__ dinv = kSmooth ? vec_origin(L, box, VECTOR_DINV) : nullptr;
   const double *__restrict__ alpha = kHelm ? vec_origin(L, box, VECTOR_ALPHA) : nullptr;
@@ -89,7 +98,7 @@ __global__ __launch_bounds__(TI * TJ) void fv4_tile_kernel(const hpgmg_hip_level
     if (P.ghost_free) hcol = gf_column(L, box, i0 + hi, j0 + hj);
   }
   // x of the own column / the halo column on plane p (any p the stencil reaches): inside the box's k range a plain load
-  const double *__restrict__ xh = (has_halo && P.ghost_free) ? vec_origin(L, hcol.box, P.xn_id) + hcol.off : x + halo_g;
+  const double *__restrict__ xh = (has_halo && P.ghost_free) ? vec_origin(Lx, hcol.box, P.xn_id) + hcol.off : x + halo_g;
   const bool gf = P.ghost_free != 0;
   const int dim = L.dim;
   // planes below the box (p < 0) are only met in the prologue of the first chunk: looked up there.  Planes above it (p >= dim) are met
@@ -97,15 +106,15 @@ __global__ __launch_bounds__(TI * TJ) void fv4_tile_kernel(const hpgmg_hip_level
   const double *__restrict__ xo_hi = x + own_g, *__restrict__ xh_hi = xh;
   if (gf && k1 == dim) {
     const int n = L.box_nbr[6 * box + 5];
-    if (n >= 0) xo_hi = vec_origin(L, n, P.xn_id) + own_g - (long long)dim * kS;
-    if (has_halo) { const int m = L.box_nbr[6 * hcol.box + 5]; if (m >= 0) xh_hi = vec_origin(L, m, P.xn_id) + hcol.off - (long long)dim * kS; }
+    if (n >= 0) xo_hi = vec_origin(Lx, n, P.xn_id) + own_g - (long long)dim * kS;
+    if (has_halo) { const int m = L.box_nbr[6 * hcol.box + 5]; if (m >= 0) xh_hi = vec_origin(Lx, m, P.xn_id) + hcol.off - (long long)dim * kS; }
   }
   auto x_own = [&](int p) -> double {
-    if (gf && p < 0) return gf_load_outside(L, P.xn_id, GfColumn{box, own_g}, p);
+    if (gf && p < 0) return gf_load_outside(Lx, P.xn_id, GfColumn{box, own_g}, p);
     return ((p >= dim) ? xo_hi : x + own_g)[p * kS];
   };
   auto x_halo = [&](int p) -> double {
-    if (gf && p < 0) return gf_load_outside(L, P.xn_id, hcol, p);
+    if (gf && p < 0) return gf_load_outside(Lx, P.xn_id, hcol, p);
     return ((p >= dim) ? xh_hi : xh)[p * kS];
   };
   auto x_own_fwd = [&](int p) -> double { return ((p >= dim) ? xo_hi : x + own_g)[p * kS]; };     // p >= 0: the marching loop

@@ -235,6 +235,18 @@ int hpgmg_hip_apply_bc_fv(const hpgmg_hip_level *L, int id, const hpgmg_hip_bc_e
  * only for entries whose sources do not depend on the copies (see above) and levels without messages */
 int hpgmg_hip_exchange_and_bc(const hpgmg_hip_level *L, int id, const blockCopy_type *copies, int num_copies,
                               const hpgmg_hip_bc_entry *entries, int num_entries, int order);
+
+/* Both coloured half sweeps of one out-of-place GSRB sweep of the 4th-order operator (operators.fv4.c:55-134 with GSRB_OOP,
+ * gsrb.c:24-132 twice, apply_BCs_v4 boundary_fv.c:262-569 in between) in one pass: kernels/fv4_rb.hpp.  Vectors are (scratch, id) pairs;
+ * scratch = 1 addresses the plugin-private vectors behind scr_base (same box layout as the level's).  The intermediate vector lives in
+ * LDS; its ghost planes below / above the domain are read from the k ghost zone of scratch vector tg_id, which _prepass fills first
+ * (entries_k: the geometry of the boundary blocks whose domain normal has a k component).  sweep = number of the first (even) half sweep. */
+int  hpgmg_hip_smooth_gsrb_fv4_rb_supported(const hpgmg_hip_level *L, int variant);
+int  hpgmg_hip_fv4_rb_prepass(const hpgmg_hip_level *L, int variant, double *const *scr_base, int x_scratch, int x_id, int tg_id, int rhs_id,
+                              double a, double b, double h2inv, int sweep, const hpgmg_hip_bc_entry *entries_k, int n_k);
+int  hpgmg_hip_smooth_gsrb_fv4_rb(const hpgmg_hip_level *L, int variant, double *const *scr_base, int x_scratch, int x_id, int out_scratch, int out_id,
+                                  int tg_id, int rhs_id, double a, double b, double h2inv, int sweep);
+long long hpgmg_hip_rb_fv4_launch_count(void);   /* launches of the one-pass kernel so far (tests) */
 /* operators/restriction.c:6-94 restriction_pc_block over a list; type = RESTRICT_* */
 int hpgmg_hip_restrict_blocks(const hpgmg_hip_level *Lc, int id_c, const hpgmg_hip_level *Lf, int id_f,
                               const blockCopy_type *blocks, int num_blocks, int type);

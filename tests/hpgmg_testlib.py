@@ -203,6 +203,7 @@ VARIANTS = {
     "27pt-cheby": dict(op=H.OP_27PT, smoother=H.SMOOTH_CHEBY, helmholtz=0, variable_coeff=0),
     "27pt-gsrb": dict(op=H.OP_27PT, smoother=H.SMOOTH_GSRB, helmholtz=0, variable_coeff=0),
     "fv4-gsrb": dict(op=H.OP_FV4, smoother=H.SMOOTH_GSRB, helmholtz=0, variable_coeff=1),
+    "fv4-gsrb-helm": dict(op=H.OP_FV4, smoother=H.SMOOTH_GSRB, helmholtz=1, variable_coeff=1),
     "fv4-cheby": dict(op=H.OP_FV4, smoother=H.SMOOTH_CHEBY, helmholtz=0, variable_coeff=1),
     "fv2-cheby": dict(op=H.OP_FV2, smoother=H.SMOOTH_CHEBY, helmholtz=0, variable_coeff=1),
 }

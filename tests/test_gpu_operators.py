@@ -418,6 +418,41 @@ def test_27pt_red_and_black_half_sweeps_in_one_pass(hip, oracle, geom):
         lh.destroy(); lo.destroy()
 
 
+@pytest.mark.parametrize("variant,geom", [("fv4-gsrb", (2, 64)), ("fv4-gsrb", (1, 64)), ("fv4-gsrb", (3, 64)), ("fv4-gsrb", (1, 128)), ("fv4-gsrb-helm", (2, 64)),
+                                          ("fv4-gsrb", (1, 64, "periodic")), ("fv4-gsrb", (2, 64, "periodic")), ("fv4-gsrb-helm", (1, 128)), ("fv4-gsrb", (2, 128))])
+def test_fv4_red_and_black_half_sweeps_in_one_pass(hip, oracle, variant, geom):
+    """Inside a cycle (hpgmg_smooth_in_cycle: VECTOR_TEMP is scratch afterwards) the 4th-order GSRB smoother runs each red + black pair of its
+    six half sweeps as ONE pass (fv4_rb.hpp): the intermediate vector lives in LDS, its quartic boundary extrapolation (apply_BCs_v4) is formed
+    in LDS in i / j and by a pre-pass in k.  The iterate must equal the oracle's six separate half sweeps bit for bit -- 1, 8 and 27 boxes
+    (every combination of domain walls and neighbouring boxes around a tile), Dirichlet and periodic, Poisson and Helmholtz, whole-box and
+    chunked k marches -- and the kernel must really have been the one launched."""
+    set_mode(hip, 1)
+    K = H.load_kernels()
+    lh, lo = make_pair(hip, oracle, variant, geom[0], geom[1], seed=17, bc=H.BC_PERIODIC if len(geom) > 2 else H.BC_DIRICHLET)
+    try:
+        for lv in (lh, lo):
+            for vid in (H.VECTOR_BETA_I, H.VECTOR_BETA_J, H.VECTOR_BETA_K, H.VECTOR_ALPHA, H.VECTOR_DINV):
+                if vid < lv.num_vectors and (vid != H.VECTOR_ALPHA or "helm" in variant):
+                    lv.b.lib.exchange_boundary(lv.ptr, vid, H.STENCIL_SHAPE_BOX)
+        hip.lib.hpgmg_smooth_in_cycle.restype = ctypes.c_int
+        hip.lib.hpgmg_smooth_in_cycle.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double]
+        K.hpgmg_hip_rb_fv4_launch_count.restype = ctypes.c_longlong
+        a = 1.0 if "helm" in variant else 0.0
+        n0 = K.hpgmg_hip_rb_fv4_launch_count()
+        assert hip.lib.hpgmg_smooth_in_cycle(lh.ptr, H.VECTOR_U, H.VECTOR_F, a, 1.0) == 1
+        assert K.hpgmg_hip_rb_fv4_launch_count() - n0 == 3          # six half sweeps = three passes
+        lo.b.lib.smooth(lo.ptr, H.VECTOR_U, H.VECTOR_F, a, 1.0)
+        same(lh, lo, [H.VECTOR_U], interior_only=True)
+        # and again from the new iterate (the second call starts from ghost zones the first one left as scratch)
+        assert hip.lib.hpgmg_smooth_in_cycle(lh.ptr, H.VECTOR_U, H.VECTOR_F, a, 1.0) == 1
+        lo.b.lib.smooth(lo.ptr, H.VECTOR_U, H.VECTOR_F, a, 1.0)
+        same(lh, lo, [H.VECTOR_U], interior_only=True)
+        # the right-hand side and the coefficients are inputs only
+        same(lh, lo, [H.VECTOR_F, H.VECTOR_DINV, H.VECTOR_BETA_I, H.VECTOR_BETA_J, H.VECTOR_BETA_K], interior_only=True)
+    finally:
+        lh.destroy(); lo.destroy()
+
+
 @pytest.mark.parametrize("variant,geom", [("27pt-cheby", (2, 8)), ("27pt-gsrb", (1, 4)), ("fv4-gsrb", (2, 8)), ("fv4-gsrb", (2, 16)), ("fv4-cheby", (1, 8)),
                                            ("fv2-cheby", (2, 8)), ("fv4-gsrb", (1, 2)), ("27pt-cheby", (1, 2)), ("fv4-gsrb", (2, 32))])
 def test_other_plugins_operator_by_operator(hip, oracle, variant, geom):
