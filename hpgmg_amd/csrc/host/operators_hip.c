@@ -130,6 +130,7 @@ typedef struct {
   struct { const blockCopy_type *host; int n; blockCopy_type *dev; } lists[MAX_LISTS];
   int num_lists;
   hpgmg_hip_bc_entry *d_bc[STENCIL_MAX_SHAPES]; int n_bc[STENCIL_MAX_SHAPES];   /* boundary-condition blocks with their geometry worked out */
+  int *d_fv4_special; int n_fv4_special;       /* fv4 red + black: cells on internal box faces next to a domain wall (box, i, j, k); n < 0: not built */
   hpgmg_hip_bc_entry *d_bc_k; int n_bc_k, bc_k_local;      /* the blocks of the stencil's shape whose domain normal has a k component (fv4 red + black pre-pass); n_bc_k < 0: not built */
   int bc_sources_local[STENCIL_MAX_SHAPES];    /* 1: every entry reads cells of local boxes' interiors only (no exchange needed before the conditions) */
   int *krylov_pinned;          /* iterations of device-side bottom solves not yet folded into level->Krylov_iterations */
@@ -166,7 +167,7 @@ static void coef32_invalidate(level_type *L);
 static backend_t *backend_of(level_type *L) {
   hpgmg_level_ext *X = hpgmg_level_ext_get(L);
   backend_t *B = (backend_t *)X->backend;
-  if (!B) { B = (backend_t *)calloc(1, sizeof(*B)); X->backend = B; B->lexicographic = -1; B->n_bc_k = -1; }
+  if (!B) { B = (backend_t *)calloc(1, sizeof(*B)); X->backend = B; B->lexicographic = -1; B->n_bc_k = -1; B->n_fv4_special = -1; }
   double *v0 = L->num_my_boxes ? L->my_boxes[0].vectors[0] : NULL;
   if (B->seen_v0 != v0 || B->seen_nv != L->numVectors || B->seen_boxes != L->num_my_boxes || !B->d_box_low) {
     int b, n = L->num_my_boxes > 0 ? L->num_my_boxes : 1;
@@ -258,6 +259,7 @@ void hpgmg_level_release(level_type *L) {
   for (s = 0; s < B->num_lists; s++) hpgmg_hip_free(B->lists[s].dev);
   for (s = 0; s < STENCIL_MAX_SHAPES; s++) if (B->d_bc[s]) hpgmg_hip_free(B->d_bc[s]);
   if (B->d_bc_k) hpgmg_hip_free(B->d_bc_k);
+  if (B->d_fv4_special) hpgmg_hip_free(B->d_fv4_special);
   if (B->d_box_base) hpgmg_hip_free(B->d_box_base);
   if (B->d_box_low) hpgmg_hip_free(B->d_box_low);
   if (B->d_box_nbr) hpgmg_hip_free(B->d_box_nbr);
@@ -1168,6 +1170,40 @@ static void fv4_rb_bcs(level_type *L, backend_t *B, int scratch, int id) {      
   HIP_OK(hpgmg_hip_exchange_and_bc(&Ls, id, NULL, 0, e, n, 4));
   TOCK();
 }
+/* The cells whose intermediate value the one-pass kernel must not recompute: a cell next to a tile of ANOTHER box (= on an internal box face) whose
+ * stencil reaches outside the domain (= within one cell of a wall in another direction).  The coefficient ghost cells outside the domain are
+ * extrapolated with box-relative normals (boundary_fv.c:573-681), so two boxes hold different values for the same place there. */
+static const int *fv4_special_cells(level_type *L, backend_t *B, int *n_out) {
+  if (B->n_fv4_special < 0) {
+    int cap = 1024, n = 0, b, ax, side, u, v;
+    int *h = (int *)malloc((size_t)cap * 4 * sizeof(int));
+    const int dim = L->box_dim, N[3] = { L->dim.i, L->dim.j, L->dim.k }, nb[3] = { L->boxes_in.i, L->boxes_in.j, L->boxes_in.k };
+    if (L->boundary_condition.type != BC_PERIODIC)
+    for (b = 0; b < L->num_my_boxes; b++) {
+      const int low[3] = { L->my_boxes[b].low.i, L->my_boxes[b].low.j, L->my_boxes[b].low.k };
+      for (ax = 0; ax < 3; ax++) for (side = 0; side < 2; side++) {
+        const int bpos = low[ax] / dim + (side ? 1 : -1);
+        if (bpos < 0 || bpos >= nb[ax]) continue;                          /* a domain wall, not an internal face */
+        const int a1 = (ax + 1) % 3, a2 = (ax + 2) % 3;
+        for (v = 0; v < dim; v++) for (u = 0; u < dim; u++) {
+          const int g1 = low[a1] + u, g2 = low[a2] + v;
+          if (!(g1 == 0 || g1 == N[a1] - 1 || g2 == 0 || g2 == N[a2] - 1)) continue;
+          int c[3];
+          c[ax] = side ? dim - 1 : 0; c[a1] = u; c[a2] = v;
+          if (n == cap) { cap *= 2; h = (int *)realloc(h, (size_t)cap * 4 * sizeof(int)); }
+          h[4 * n] = b; h[4 * n + 1] = c[0]; h[4 * n + 2] = c[1]; h[4 * n + 3] = c[2]; n++;
+        }
+      }
+    }
+    B->d_fv4_special = (int *)hpgmg_hip_malloc((size_t)(n > 0 ? n : 1) * 4 * sizeof(int));
+    if (!B->d_fv4_special) { fprintf(stderr, "hpgmg: device allocation failed: %s\n", hpgmg_hip_last_error()); abort(); }
+    if (n > 0) HIP_OK(hpgmg_hip_memcpy_h2d(B->d_fv4_special, h, (size_t)n * 4 * sizeof(int)));
+    free(h);
+    B->n_fv4_special = n;
+  }
+  *n_out = B->n_fv4_special;
+  return B->d_fv4_special;
+}
 static int smooth_fv4_rb(level_type *L, int x_id, int rhs_id, double a, double b, int sweeps) {
   hpgmg_config cfg;
   hpgmg_get_config(&cfg);
@@ -1186,6 +1222,8 @@ static int smooth_fv4_rb(level_type *L, int x_id, int rhs_id, double a, double b
   ensure_pair_scratch(L, B);
   hpgmg_hip_set_tile_ghost_free(1);
   const double h2inv = 1.0 / (L->h * L->h);
+  int n_sp = 0;
+  const int *sp_cells = fv4_special_cells(L, B, &n_sp);
   /* (scratch, id) of the iterate before pass p: x, then TEMP / x alternately; an odd count routes its second pass through private vector 0 */
   int src_s = 0, src_id = x_id;
   for (p = 0; p < passes; p++) {
@@ -1197,7 +1235,7 @@ static int smooth_fv4_rb(level_type *L, int x_id, int rhs_id, double a, double b
     if (left == 2 && src_s == 0 && src_id == x_id) dst_id = VECTOR_TEMP;
     fv4_rb_bcs(L, B, src_s, src_id);
     TICK(L, smooth, "smooth (fv4 GSRB, red + black half sweeps in one pass)");
-    HIP_OK(hpgmg_hip_fv4_rb_prepass(&B->dev, v, (double *const *)B->d_pair_base, src_s, src_id, 1, rhs_id, a, b, h2inv, 2 * p, e_k, n_k));
+    HIP_OK(hpgmg_hip_fv4_rb_prepass(&B->dev, v, (double *const *)B->d_pair_base, src_s, src_id, 1, rhs_id, a, b, h2inv, 2 * p, e_k, n_k, sp_cells, n_sp));
     HIP_OK(hpgmg_hip_smooth_gsrb_fv4_rb(&B->dev, v, (double *const *)B->d_pair_base, src_s, src_id, dst_s, dst_id, 1, rhs_id, a, b, h2inv, 2 * p));
     TOCK();
     src_s = dst_s; src_id = dst_id;

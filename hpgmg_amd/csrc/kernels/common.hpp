@@ -31,6 +31,20 @@ inline int grid_for(int logical_blocks, int *per_xcd) {
   return *per_xcd * kXcds;
 }
 
+// A box pointer read from a table in memory has no known address space, so every access through it is a FLAT instruction, which counts
+// against lgkmcnt as well as vmcnt: a wave waiting for its LDS reads then also waits for every prefetch still in flight from HBM.
+// Kernels that depend on that overlap address device memory through these types (global_load / global_store).
+typedef double __attribute__((address_space(1))) gdouble;
+typedef const gdouble *gcptr;
+typedef gdouble *gptr;
+__device__ __forceinline__ gcptr as_global(const double *p) { return (gcptr)p; }
+__device__ __forceinline__ gptr as_global(double *p) { return (gptr)p; }
+// load / store at a base that is the same for every lane (a scalar register pair) plus an unsigned 32-bit BYTE offset per lane: the
+// "scalar base + vector offset" form of global_load / global_store, no 64-bit address arithmetic per lane
+typedef const char __attribute__((address_space(1))) *gcbytes;
+typedef char __attribute__((address_space(1))) *gbytes;
+__device__ __forceinline__ double gld(gcptr base, unsigned byte_off) { return *(gcptr)((gcbytes)base + byte_off); }
+__device__ __forceinline__ void gst(gptr base, unsigned byte_off, double v) { *(gptr)((gbytes)base + byte_off) = v; }
 // pointer to cell (0,0,0) (first interior cell) of vector `id` in box `box`
 __device__ __forceinline__ double *vec_origin(const hpgmg_hip_level &L, int box, int id) {
   return L.box_base[box] + (size_t)id * (size_t)L.volume + (size_t)L.ghosts * (size_t)(1 + L.jStride + L.kStride);

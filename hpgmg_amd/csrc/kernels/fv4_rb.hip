@@ -1,0 +1,95 @@
+// fv4_rb.hip -- launchers of the one-pass red + black GSRB sweep of the 4th-order operator (fv4_rb.hpp) and of its pre-pass.
+// A translation unit of its own: the kernel lives at the edge of the 256 registers two waves per SIMD leave it, and is compiled with the
+// register-minimising scheduler (Makefile: FLAGS_fv4_rb) without changing how the other kernels are scheduled.
+#include <stdlib.h>
+#include "common.hpp"
+#include "fv4_tile.hpp"
+#include "fv4_rb.hpp"
+
+namespace hpgmg {
+int  profile_begin(long long cells);          // stencil.hip: hipEvent pair around a smoother launch (bench.py's roofline)
+void profile_end(int p, long long cells);
+static int env_int(const char *name, int dflt) { const char *e = getenv(name); return (e && *e) ? atoi(e) : dflt; }
+}
+using namespace hpgmg;
+
+extern "C" {
+
+// Both coloured half sweeps (sweep, sweep + 1; sweep even) of an out-of-place GSRB sweep of the 4th-order operator in one pass
+// (fv4_rb.hpp).  Vectors are (scratch?, id) pairs: scratch ids address the plugin-private vectors behind scr_base.  Boxes of side 64 m,
+// all of them local, two ghost cells; apply_BCs_v4 done on the input; on Dirichlet levels hpgmg_hip_fv4_rb_prepass run before.
+static long long g_rb4_launches = 0;
+long long hpgmg_hip_rb_fv4_launch_count(void) { return g_rb4_launches; }
+int hpgmg_hip_smooth_gsrb_fv4_rb_supported(const hpgmg_hip_level *L, int variant) {
+  static const int off = env_int("HPGMG_TUNE_FV4_NO_RB", 0);
+  if (variant != HPGMG_HIP_FV4_VC_HELMHOLTZ && variant != HPGMG_HIP_FV4_VC_POISSON) return 0;
+  return !off && L->num_boxes > 0 && L->dim % 64 == 0 && L->box_nbr != nullptr && L->ghosts == 2;
+}
+static VecSel vec_sel(const hpgmg_hip_level *L, double *const *scr_base, int scratch, int id) { return VecSel{scratch ? scr_base : L->box_base, id}; }
+// The ghost planes of the intermediate vector t below / above the domain, into the k ghost zone of scratch vector tg_id: a red half sweep
+// of x on the four planes next to each k wall (the tiled kernel, restricted to those planes and boxes) into tg's interior, then
+// apply_BCs_v4 of tg over the boundary blocks whose domain normal has a k component (faces and the i-k / j-k edges; entries: the
+// host-computed geometry of exactly those blocks, sources read from the box that owns them).
+int hpgmg_hip_fv4_rb_prepass(const hpgmg_hip_level *L, int variant, double *const *scr_base, int x_scratch, int x_id, int tg_id, int rhs_id,
+                             double a, double b, double h2inv, int sweep, const hpgmg_hip_bc_entry *entries_k, int n_k, const int *special_cells, int n_special) {
+  HPGMG_SKIP_IF_REPLAY();
+  if (!hpgmg_hip_smooth_gsrb_fv4_rb_supported(L, variant) || (sweep & 1) || !scr_base) return record_error(hipErrorInvalidValue, "fv4_rb_prepass: level / arguments not supported");
+  if (n_special > 0) {                                     // the cells of internal box faces next to a domain wall: their t with the owning box's coefficients
+    Fv4SpecialArgs S = {};
+    S.x = vec_sel(L, scr_base, x_scratch, x_id); S.tg = vec_sel(L, scr_base, 1, tg_id); S.rhs_id = rhs_id; S.a = a; S.b = b; S.h2inv = h2inv; S.sweep = sweep;
+    S.cells = special_cells; S.n = n_special;
+    if (variant == HPGMG_HIP_FV4_VC_HELMHOLTZ) hipLaunchKernelGGL((fv4_special_kernel<HPGMG_HIP_FV4_VC_HELMHOLTZ>), dim3((n_special + 255) / 256), dim3(256), 0, g_stream, *L, S);
+    else hipLaunchKernelGGL((fv4_special_kernel<HPGMG_HIP_FV4_VC_POISSON>), dim3((n_special + 255) / 256), dim3(256), 0, g_stream, *L, S);
+    HPGMG_LAUNCH_CHECK("fv4_special_kernel");
+  }
+  if (n_k <= 0) return 0;                                  // no k wall on this rank's boxes (periodic)
+  constexpr int TJ = 8, TI = 64;
+  Fv4TileArgs P = {};
+  P.xn_id = x_id; P.xout_id = tg_id; P.rhs_id = rhs_id; P.a = a; P.b = b; P.h2inv = h2inv; P.sweep = sweep; P.copy_other_colour = 1; P.ghost_free = 1;
+  P.x_base = x_scratch ? scr_base : nullptr; P.out_base = scr_base;
+  P.tiles_i = L->dim / TI; P.tiles_j = L->dim / TJ; P.kchunk = 4; P.chunks_k = 2; P.k_origin = 0; P.k_step = L->dim - 4; P.wall_only = 1;
+  P.total_blocks = L->num_boxes * P.chunks_k * P.tiles_j * P.tiles_i;
+  const int grid = grid_for(P.total_blocks, &P.per_xcd);
+  const size_t lds = (size_t)11 * (TI + 4) * (TJ + 4) * sizeof(double);
+#define FV4_PRE_CASE(VAR) { \
+    static bool once = false; if (!once) { HPGMG_CHECK(hipFuncSetAttribute((const void *)fv4_tile_kernel<VAR, FV4_GSRB, TJ, TI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once = true; } \
+    hipLaunchKernelGGL((fv4_tile_kernel<VAR, FV4_GSRB, TJ, TI>), dim3(grid), dim3(TI, TJ), lds, g_stream, *L, P); }
+  if (variant == HPGMG_HIP_FV4_VC_HELMHOLTZ) FV4_PRE_CASE(HPGMG_HIP_FV4_VC_HELMHOLTZ)
+  else FV4_PRE_CASE(HPGMG_HIP_FV4_VC_POISSON)
+#undef FV4_PRE_CASE
+  HPGMG_LAUNCH_CHECK("fv4_tile_kernel (red + black pre-pass)");
+  hpgmg_hip_level Ls = *L;
+  Ls.box_base = scr_base;
+  return hpgmg_hip_exchange_and_bc(&Ls, tg_id, nullptr, 0, entries_k, n_k, 4);
+}
+int hpgmg_hip_smooth_gsrb_fv4_rb(const hpgmg_hip_level *L, int variant, double *const *scr_base, int x_scratch, int x_id, int out_scratch, int out_id,
+                                 int tg_id, int rhs_id, double a, double b, double h2inv, int sweep) {
+  HPGMG_SKIP_IF_REPLAY();
+  if (!hpgmg_hip_smooth_gsrb_fv4_rb_supported(L, variant) || (x_scratch == out_scratch && x_id == out_id) || (sweep & 1) || !scr_base)
+    return record_error(hipErrorInvalidValue, "smooth_gsrb_fv4_rb: level / arguments not supported");
+  Fv4RbArgs A = {};
+  A.x = vec_sel(L, scr_base, x_scratch, x_id); A.out = vec_sel(L, scr_base, out_scratch, out_id); A.tg = vec_sel(L, scr_base, 1, tg_id);
+  A.rhs_id = rhs_id; A.a = a; A.b = b; A.h2inv = h2inv; A.sweep = sweep;
+  A.tiles_i = L->dim / fv4rb::TI; A.tiles_j = L->dim / fv4rb::TJ;
+  int kchunk = L->dim;                                   // one workgroup per CU: 256 fill the chip; every k chunk costs four extra planes of loads and two red stages
+  while (kchunk > 16 && (long long)L->num_boxes * A.tiles_i * A.tiles_j * (L->dim / kchunk) < 256) kchunk /= 2;
+  static const int tune_kc = env_int("HPGMG_TUNE_FV4_RB_KCHUNK", 0);
+  if (tune_kc > 0 && L->dim % tune_kc == 0) kchunk = tune_kc;
+  A.kchunk = kchunk; A.chunks_k = (L->dim + kchunk - 1) / kchunk;
+  A.total_blocks = L->num_boxes * A.chunks_k * A.tiles_j * A.tiles_i;
+  const int grid = grid_for(A.total_blocks, &A.per_xcd);
+  const long long cells = (long long)L->num_boxes * L->dim * L->dim * L->dim;
+  const int prof = profile_begin(cells);
+#define FV4_RB_CASE(VAR) { \
+    static bool once = false; if (!once) { HPGMG_CHECK(hipFuncSetAttribute((const void *)fv4_rb_kernel<VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fv4rb::LDS_BYTES)); once = true; } \
+    hipLaunchKernelGGL((fv4_rb_kernel<VAR>), dim3(grid), dim3(64, 8), fv4rb::LDS_BYTES, g_stream, *L, A); }
+  if (variant == HPGMG_HIP_FV4_VC_HELMHOLTZ) FV4_RB_CASE(HPGMG_HIP_FV4_VC_HELMHOLTZ)
+  else FV4_RB_CASE(HPGMG_HIP_FV4_VC_POISSON)
+#undef FV4_RB_CASE
+  g_rb4_launches++;
+  profile_end(prof, 2 * cells);                         // one launch = two half sweeps over every cell
+  HPGMG_LAUNCH_CHECK("fv4_rb_kernel");
+  return 0;
+}
+
+}  // extern "C"

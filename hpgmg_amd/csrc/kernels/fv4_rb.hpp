@@ -23,8 +23,11 @@
 //   * in k they are read from the ghost planes of vector P.tg, which a small pre-pass has filled: the existing tiled kernel forms t on
 //     the four planes next to the bottom / top of the domain and the existing boundary kernel extrapolates them (faces and the i-k /
 //     j-k edges).  Registers and LDS positions of black parity on those planes take the value of P.tg, red-parity ones that of x.
-// Cells outside the box but inside the domain are read from the box that owns them (common.hpp gf_column) -- coefficients too: a ring
-// cell belongs to the neighbouring box, whose ghost coefficients differ from this box's where a third direction leaves the domain.
+// Cells outside the box but inside the domain are read from the box that owns them (common.hpp gf_column).  Coefficients come from the own
+// box's ghost zone, as in the reference; outside the DOMAIN that is this box's own extrapolation, which differs from what a neighbouring box
+// holds for the same place (extrapolate_betas works with box-relative normals).  So a recomputed cell that belongs to ANOTHER box and whose
+// stencil reaches outside the domain ("special": the lines where an internal box face meets a domain wall) is not recomputed here: its t is
+// read from the interior of P.tg, where fv4_special_kernel (below) has formed it with the owning box's coefficients.
 // Every update is the expression tree of fv4_tile.hpp (= the reference macro), so x' is bit-identical to the two separate half sweeps;
 // the intermediate vector is never materialised: 56 B per cell per SWEEP.  x' must not alias x.
 #pragma once
@@ -35,8 +38,8 @@
 namespace hpgmg {
 
 struct VecSel { double *const *base; int id; };      // vector `id` behind a table of box bases: a level vector or a plugin-private scratch vector
-__device__ __forceinline__ double *sel_origin(const hpgmg_hip_level &L, const VecSel &S, int box) {
-  return S.base[box] + (size_t)S.id * (size_t)L.volume + (size_t)L.ghosts * (size_t)(1 + L.jStride + L.kStride);
+__device__ __forceinline__ gptr sel_origin(const hpgmg_hip_level &L, const VecSel &S, int box) {
+  return as_global(S.base[box]) + (size_t)S.id * (size_t)L.volume + (size_t)L.ghosts * (size_t)(1 + L.jStride + L.kStride);
 }
 
 struct Fv4RbArgs {
@@ -52,7 +55,8 @@ constexpr int TI = 64, TJ = 16, NT = 512;
 constexpr int WX = TI + 6, HX = TJ + 6, PX = WX * HX;          // x planes: three-cell halo
 constexpr int WB = TI + 4, HB = TJ + 4, PB = WB * HB;          // coefficient planes: two-cell halo
 constexpr int ST = 34, HT = TJ + 2, PT = ST * HT;              // red cells of t on the tile + 1: column c = i + 1 -> c >> 1
-constexpr int LDS_DOUBLES = 4 * PX + 8 * PB + 3 * PT;
+constexpr int NRING = 80;                                      // lanes that own a pair of ring cells
+constexpr int LDS_DOUBLES = 4 * PX + 8 * PB + 3 * PT + NT + 4 * NRING;     // + per-lane pointers parked in LDS (see the kernel)
 constexpr size_t LDS_BYTES = (size_t)LDS_DOUBLES * sizeof(double);
 __device__ __forceinline__ constexpr int posX(int ci, int cj) { return (cj + 3) * WX + (ci + 3); }
 __device__ __forceinline__ constexpr int posB(int ci, int cj) { return (cj + 2) * WB + (ci + 2); }
@@ -75,8 +79,8 @@ __device__ __forceinline__ void beta18(B18 &o, const double *I0, const double *I
   o.d[10] = K1[1] - K1[-1];        o.d[11] = K1[W] - K1[-W];
 }
 // the same read at a cell of a box's own arrays in memory (p: the cell in the box's level vectors): what the reference reads for a cell of that box
-__device__ __forceinline__ void beta18_global(B18 &o, const double *p, size_t vol, int jS, int kS) {
-  const double *I = p + (size_t)VECTOR_BETA_I * vol, *J = p + (size_t)VECTOR_BETA_J * vol, *K = p + (size_t)VECTOR_BETA_K * vol;
+__device__ __forceinline__ void beta18_global(B18 &o, gcptr p, size_t vol, int jS, int kS) {
+  gcptr I = p + (size_t)VECTOR_BETA_I * vol, J = p + (size_t)VECTOR_BETA_J * vol, K = p + (size_t)VECTOR_BETA_K * vol;
   o.f[0] = I[0]; o.f[1] = I[1]; o.f[2] = J[0]; o.f[3] = J[jS]; o.f[4] = K[0]; o.f[5] = K[kS];
   o.d[0] = I[jS] - I[-jS];          o.d[1] = I[kS] - I[-kS];
   o.d[2] = J[1] - J[-1];            o.d[3] = J[kS] - J[-kS];
@@ -118,6 +122,7 @@ __global__ __launch_bounds__(512) void fv4_rb_kernel(const hpgmg_hip_level L, co
   constexpr bool kHelm = (V == HPGMG_HIP_FV4_VC_HELMHOLTZ);
   extern __shared__ double fv4rb_lds[];
   double *sX = fv4rb_lds, *sBI = sX + 4 * PX, *sBJ = sBI + 3 * PB, *sBK = sBJ + 3 * PB, *sT = sBK + 2 * PB;
+  unsigned long long *sPtr = (unsigned long long *)(sT + 3 * PT);
 
   const int logical = xcd_logical_block((int)blockIdx.x, P.per_xcd);
   if (logical >= P.total_blocks) return;
@@ -144,13 +149,19 @@ __global__ __launch_bounds__(512) void fv4_rb_kernel(const hpgmg_hip_level L, co
 
   // ---- (1) the own pair of cells (gi, gj), (gi, gj + 1).  Every vector of the own box is reached from one uniform base with the
   // lane's 32-bit offset own_g; planes p >= dim through the base of the box above (or the own ghost zone)
+  // Addressing: base pointers that are the same for every lane (they stay in scalar registers) + ONE unsigned 32-bit offset per lane,
+  // so a load is "scalar base + lane offset" with no 64-bit address arithmetic per lane: lvb / xb / tgb / outb point at the START of the
+  // box's storage and own_o = (first interior cell) + (the lane's lower cell) is never negative, ghost planes included.
   const int gi = i0 + li, gj = j0 + 2 * lj, own_g = gi + gj * jS;
+  const unsigned own_o = (unsigned)(first + (size_t)own_g), ujS = (unsigned)jS, ukS = (unsigned)kS;
+  const unsigned own_b = own_o * 8u, bjS = ujS * 8u, bkS = ukS * 8u;     // the same in bytes (a box's vector is far smaller than 4 GB)
   const int ownX = posX(li, 2 * lj), ownB = posB(li, 2 * lj), ownT = posT(li, 2 * lj);
-  const double *lvb = L.box_base[box] + first, *lvb_hi = lvb;                       // level vectors: lvb[id * vol + own_g + p * kS (+ jS)]
-  const double *xb = sel_origin(L, P.x, box), *xb_hi = xb;
-  const double *tgb = sel_origin(L, P.tg, box);                                     // its k ghost planes: boundary values of t
-  double *outb = sel_origin(L, P.out, box);
-  if (nb[5] >= 0) { lvb_hi = L.box_base[nb[5]] + first - (long long)dim * kS; xb_hi = sel_origin(L, P.x, nb[5]) - (long long)dim * kS; }
+  gcptr lvb = as_global(L.box_base[box]), lvb_hi = lvb;                     // level vectors: lvb[id * vol + own_o + p * kS (+ jS)]
+  gcptr xb = as_global(P.x.base[box]) + (size_t)P.x.id * vol, xb_hi = xb;
+  gcptr tgb = as_global(P.tg.base[box]) + (size_t)P.tg.id * vol;            // its k ghost planes: boundary values of t
+  gptr outb = as_global(P.out.base[box]) + (size_t)P.out.id * vol;
+  gcptr tgb_hi = (nb[5] >= 0) ? as_global(P.tg.base[nb[5]]) + (size_t)P.tg.id * vol - (long long)dim * kS : tgb;
+  if (nb[5] >= 0) { lvb_hi = as_global(L.box_base[nb[5]]) - (long long)dim * kS; xb_hi = as_global(P.x.base[nb[5]]) + (size_t)P.x.id * vol - (long long)dim * kS; }
 
   // ---- (2) one halo cell of the x planes (the cells within three steps of the tile: 492)
   const bool has_h = tid < 492;
@@ -170,8 +181,11 @@ __global__ __launch_bounds__(512) void fv4_rb_kernel(const hpgmg_hip_level L, co
   if (h_ok) hcol = gf_column(L, box, i0 + hi, j0 + hj);
   // a halo cell face-adjacent to the tile: a position B reads on the planes r - 1, r + 1 (the k ghost planes of t need it)
   const bool h_face = h_ok && ((hi >= 0 && hi < TI && (hj == -1 || hj == TJ)) || (hj >= 0 && hj < TJ && (hi == -1 || hi == TI)));
-  const double *__restrict__ xh = sel_origin(L, P.x, hcol.box) + hcol.off, *__restrict__ xh_hi = xh;
-  { const int m = L.box_nbr[6 * hcol.box + 5]; if (h_ok && m >= 0) xh_hi = sel_origin(L, P.x, m) + hcol.off - (long long)dim * kS; }
+  // per-lane columns in other boxes are followed by MARCHING pointers (xh_c: the halo column at plane q+2, al_c / xe_c below); the base to
+  // continue with above the box (the box above, or the own ghost zone) is needed once per march at most: it waits in LDS, not in registers
+  gcptr xh = sel_origin(L, P.x, hcol.box) + hcol.off;
+  { const int m = L.box_nbr[6 * hcol.box + 5];
+    sPtr[tid] = (unsigned long long)((h_ok && m >= 0) ? sel_origin(L, P.x, m) + hcol.off - (long long)dim * kS : xh); }
 
   // ---- (3) lanes 0 .. 331: one halo cell of the coefficient planes (what the stencils of the tile and of its face-adjacent ring reach), read
   //      from the OWN box's ghost zone like the reference does: inside the domain that is the neighbour's value (rebuild_operator exchanged
@@ -189,26 +203,38 @@ __global__ __launch_bounds__(512) void fv4_rb_kernel(const hpgmg_hip_level L, co
   }
   if (has_e) {
     const int e = tid - 432;
-    if (e < 32)      { ej = -1; ei = 2 * e; edx = 1; }
-    else if (e < 64) { ej = TJ; ei = 2 * (e - 32); edx = 1; }
+    // rows -1 and TJ alternate from lane to lane: their red cells sit at columns of opposite parity, so the 32 lanes of a half wave read
+    // 32 different LDS banks (one row alone reads every second double: a two-way conflict on every access)
+    if (e < 64)      { ej = (e & 1) ? TJ : -1; ei = 2 * (e >> 1); edx = 1; }
     else if (e < 72) { ei = -1; ej = 2 * (e - 64); edy = 1; }
     else             { ei = TI; ej = 2 * (e - 72); edy = 1; }
   }
-  const int bB = posB(bhi, bhj), b_g = (i0 + bhi) + (j0 + bhj) * jS;              // the coefficient halo cell: in LDS, in the own box
+  const int bB = posB(bhi, bhj);                                                  // the coefficient halo cell: in LDS, in the own box
+  const unsigned b_o = (unsigned)((long long)first + (i0 + bhi) + (long long)(j0 + bhj) * jS);
   const bool e_in = has_e && out_i(i0 + ei) == 0 && out_j(j0 + ej) == 0;          // inside the domain: R forms its red cell
   const bool e_other = e_in && (i0 + ei < 0 || i0 + ei >= dim || j0 + ej < 0 || j0 + ej >= dim);     // ... which belongs to another box
   GfColumn acol = {box, 0};
   if (e_in)  acol = gf_column(L, box, i0 + ei, j0 + ej);
   const int e_step = edx + edy * jS;                                              // second cell of the ring pair, in memory (same box: pairs are aligned)
-  const double *__restrict__ al = L.box_base[acol.box] + first + acol.off, *__restrict__ al_hi = al;
-  const double *__restrict__ xe = sel_origin(L, P.x, acol.box) + acol.off, *__restrict__ xe_hi = xe;
+  gcptr al = as_global(L.box_base[acol.box]) + first + acol.off;
+  gcptr xe = sel_origin(L, P.x, acol.box) + acol.off;
   { const int m = L.box_nbr[6 * acol.box + 5];
-    if (e_in && m >= 0) { al_hi = L.box_base[m] + first + acol.off - (long long)dim * kS; xe_hi = sel_origin(L, P.x, m) + acol.off - (long long)dim * kS; } }
+    const bool up_box = e_in && m >= 0;
+    if (has_e) {
+      const int e = tid - 432;
+      sPtr[NT + e] = (unsigned long long)(up_box ? as_global(L.box_base[m]) + first + acol.off - (long long)dim * kS : al);
+      sPtr[NT + NRING + e] = (unsigned long long)(up_box ? sel_origin(L, P.x, m) + acol.off - (long long)dim * kS : xe);
+      // where the ring pair's t is read when it is "special": the same column of P.tg, in its box / in the box above
+      sPtr[NT + 2 * NRING + e] = (unsigned long long)(sel_origin(L, P.tg, acol.box) + acol.off);
+      sPtr[NT + 3 * NRING + e] = (unsigned long long)(up_box ? sel_origin(L, P.tg, m) + acol.off - (long long)dim * kS : sel_origin(L, P.tg, acol.box) + acol.off);
+    } }
+  const int e_id = has_e ? tid - 432 : 0;
 
   // ---- (5) lanes 0 .. 331: one ghost cell of t outside the domain in i and / or j: kind 1 near, 2 far, 3 the k-edge cell diagonal to a tile corner
   const bool tile_wall = t_ilo || t_ihi || t_jlo || t_jhi;
-  int bc_kind = 0, bc_i = 0, bc_j = 0, bc_si = 0, bc_sj = 0;                      // position, inward step(s)
+  int bc_pack = 0;                                                                // kind, position, inward step(s), packed: decoded where it is used
   if (tile_wall) {
+    int bc_kind = 0, bc_i = 0, bc_j = 0, bc_si = 0, bc_sj = 0;
     int n = tid;
     // i walls: near cells of rows -1 .. TJ (a row outside the domain makes it the k-edge cell), far cells of rows 0 .. TJ-1
     for (int side = 0; side < 2 && n >= 0; side++) {
@@ -232,6 +258,7 @@ __global__ __launch_bounds__(512) void fv4_rb_kernel(const hpgmg_hip_level L, co
         n = -1;
       } else n -= 130;
     }
+    bc_pack = bc_kind | ((bc_i + 4) << 2) | ((bc_j + 4) << 9) | ((bc_si + 1) << 14) | ((bc_sj + 1) << 16);
   }
 
   // t on plane q at a tile / ring cell inside the domain: a red cell from the t ring, a black one is the cell of x
@@ -243,16 +270,16 @@ __global__ __launch_bounds__(512) void fv4_rb_kernel(const hpgmg_hip_level L, co
   // >= dim); planes below the box are only met in the prologue of the first chunk and looked up there.
   const int qlo = bottom ? 0 : k0 - 1, qhi = top ? dim - 1 : k1;                  // planes R works on
   auto x_own_any = [&](int cell, int p) -> double {                               // x at the own column, cell 0 / 1 of the pair
-    if (p >= 0) return (p > dim + 1 && wall_khi) ? 0.0 : ((p >= dim) ? xb_hi : xb)[own_g + cell * jS + p * kS];
+    if (p >= 0) return (p > dim + 1 && wall_khi) ? 0.0 : ((p >= dim) ? xb_hi : xb)[own_o + cell * ujS + p * ukS];
     if (nb[4] >= 0) return sel_origin(L, P.x, nb[4])[own_g + cell * jS + (p + dim) * kS];
-    return (p < -2) ? 0.0 : xb[own_g + cell * jS + p * kS];
+    return (p < -2) ? 0.0 : xb[(long long)own_o + cell * jS + (long long)p * kS];
   };
   auto lv_any = [&](int id, int cell, int p) -> double {                          // a level vector at the own column, any plane the box or its k neighbours hold
-    if (p >= 0) return ((p >= dim) ? lvb_hi : lvb)[(size_t)id * vol + own_g + cell * jS + p * kS];
-    if (nb[4] >= 0) return (L.box_base[nb[4]] + first)[(size_t)id * vol + own_g + cell * jS + (p + dim) * kS];
-    return lvb[(size_t)id * vol + own_g + cell * jS + p * kS];
+    if (p >= 0) return (((p >= dim) ? lvb_hi : lvb) + (size_t)id * vol)[own_o + cell * ujS + p * ukS];
+    if (nb[4] >= 0) return (as_global(L.box_base[nb[4]]) + first)[(size_t)id * vol + own_g + cell * jS + (p + dim) * kS];
+    return (lvb + (size_t)id * vol)[(long long)own_o + cell * jS + (long long)p * kS];
   };
-  auto xh_fwd = [&](int p) -> double { return ((p >= dim) ? xh_hi : xh)[p * kS]; };
+  auto xh_fwd = [&](int p) -> double { return ((p >= dim) ? (gcptr)sPtr[tid] : xh)[p * kS]; };
   auto xh_any = [&](int p) -> double {
     if (!h_ok) return 0.0;
     if (p >= 0) return (p > dim + 1 && L.box_nbr[6 * hcol.box + 5] < 0) ? 0.0 : xh_fwd(p);
@@ -260,14 +287,14 @@ __global__ __launch_bounds__(512) void fv4_rb_kernel(const hpgmg_hip_level L, co
     if (m >= 0) return sel_origin(L, P.x, m)[hcol.off + (p + dim) * kS];
     return (p < -2) ? 0.0 : xh[p * kS];
   };
-  auto al_fwd = [&](int id, int cell, int p) -> double { return ((p >= dim) ? al_hi : al)[(size_t)id * vol + cell * e_step + p * kS]; };
+  auto al_fwd = [&](int id, int cell, int p) -> double { return ((p >= dim) ? (gcptr)sPtr[NT + e_id] : al)[(size_t)id * vol + cell * e_step + p * kS]; };
   auto al_any = [&](int id, int cell, int p) -> double {
     if (p >= 0) return al_fwd(id, cell, p);
     const int m = L.box_nbr[6 * acol.box + 4];
-    if (m >= 0) return (L.box_base[m] + first)[(size_t)id * vol + acol.off + cell * e_step + (p + dim) * kS];
+    if (m >= 0) return (as_global(L.box_base[m]) + first)[(size_t)id * vol + acol.off + cell * e_step + (p + dim) * kS];
     return al[(size_t)id * vol + cell * e_step + p * kS];
   };
-  auto xe_fwd = [&](int cell, int p) -> double { return ((p >= dim) ? xe_hi : xe)[cell * e_step + p * kS]; };
+  auto xe_fwd = [&](int cell, int p) -> double { return ((p >= dim) ? (gcptr)sPtr[NT + NRING + e_id] : xe)[cell * e_step + p * kS]; };
   auto e_red = [&](int q) { return is_red(i0 + ei, j0 + ej, q) ? 0 : 1; };         // which cell of the ring pair is red on plane q
 
   // ---- prologue: planes qlo-2 .. qlo+1 of x, planes qlo-1 .. qlo+1 of beta_i / beta_j, faces qlo, qlo+1 of beta_k into LDS; x[qlo+2] of
@@ -279,13 +306,13 @@ __global__ __launch_bounds__(512) void fv4_rb_kernel(const hpgmg_hip_level L, co
   }
   for (int p = qlo - 1; p <= qlo + 1; p++) {
     const int s = slot3(p) * PB;
-    sBI[s + ownB] = lvb[(size_t)VECTOR_BETA_I * vol + own_g + p * kS]; sBI[s + ownB + WB] = lvb[(size_t)VECTOR_BETA_I * vol + own_g + jS + p * kS];
-    sBJ[s + ownB] = lvb[(size_t)VECTOR_BETA_J * vol + own_g + p * kS]; sBJ[s + ownB + WB] = lvb[(size_t)VECTOR_BETA_J * vol + own_g + jS + p * kS];
-    if (has_b) { sBI[s + bB] = lvb[(size_t)VECTOR_BETA_I * vol + b_g + p * kS]; sBJ[s + bB] = lvb[(size_t)VECTOR_BETA_J * vol + b_g + p * kS]; }
+    sBI[s + ownB] = (lvb + (size_t)VECTOR_BETA_I * vol)[(long long)own_o + (long long)p * kS]; sBI[s + ownB + WB] = (lvb + (size_t)VECTOR_BETA_I * vol)[(long long)own_o + jS + (long long)p * kS];
+    sBJ[s + ownB] = (lvb + (size_t)VECTOR_BETA_J * vol)[(long long)own_o + (long long)p * kS]; sBJ[s + ownB + WB] = (lvb + (size_t)VECTOR_BETA_J * vol)[(long long)own_o + jS + (long long)p * kS];
+    if (has_b) { sBI[s + bB] = (lvb + (size_t)VECTOR_BETA_I * vol)[(long long)b_o + (long long)p * kS]; sBJ[s + bB] = (lvb + (size_t)VECTOR_BETA_J * vol)[(long long)b_o + (long long)p * kS]; }
     if (p >= qlo) {
       const int s2 = slot2(p) * PB;
-      sBK[s2 + ownB] = lvb[(size_t)VECTOR_BETA_K * vol + own_g + p * kS]; sBK[s2 + ownB + WB] = lvb[(size_t)VECTOR_BETA_K * vol + own_g + jS + p * kS];
-      if (has_b) sBK[s2 + bB] = lvb[(size_t)VECTOR_BETA_K * vol + b_g + p * kS];
+      sBK[s2 + ownB] = (lvb + (size_t)VECTOR_BETA_K * vol)[(long long)own_o + (long long)p * kS]; sBK[s2 + ownB + WB] = (lvb + (size_t)VECTOR_BETA_K * vol)[(long long)own_o + jS + (long long)p * kS];
+      if (has_b) sBK[s2 + bB] = (lvb + (size_t)VECTOR_BETA_K * vol)[(long long)b_o + (long long)p * kS];
     }
   }
   double kp2_0 = x_own_any(0, qlo + 2), kp2_1 = x_own_any(1, qlo + 2);           // x two planes above the current one, both cells of the pair
@@ -299,38 +326,57 @@ __global__ __launch_bounds__(512) void fv4_rb_kernel(const hpgmg_hip_level L, co
   }
   // what B(q) needs from the coefficient planes that will have left the rings by then (beta_i / beta_j plane q-1, beta_k face q), formed a step early
   double pd1 = 0.0, pd3 = 0.0, pd7 = 0.0, pd9 = 0.0, pf4 = 0.0, pd4 = 0.0, pd5 = 0.0;
-  double b_rhs = 0.0, b_dinv = 0.0, b_al = 0.0, r_prev = 0.0, kmB = 0.0;           // kmB: t three planes below the current one at the cell B works on
+  double b_rhs = 0.0, b_dinv = 0.0, b_al = 0.0, kmB = 0.0;           // kmB: t three planes below the current one at the cell B works on
   const double bh2inv = P.b * P.h2inv, nbh2inv = (-P.b) * P.h2inv;
 
+  // marching pointers: the x halo column at plane q+2, the ring pair's level vectors at plane q+1, its x at plane q+3
+  gcptr xh_c = ((qlo + 2 >= dim) ? (gcptr)sPtr[tid] : xh) + (long long)(qlo + 2) * kS;
+  gcptr al_c = ((qlo + 1 >= dim) ? (gcptr)sPtr[NT + e_id] : al) + (long long)(qlo + 1) * kS;
+  gcptr xe_c = ((qlo + 3 >= dim) ? (gcptr)sPtr[NT + NRING + e_id] : xe) + (long long)(qlo + 3) * kS;
   const int qend = top ? dim : qhi;                                                 // at the top of the domain one more step: B(dim-1) after t's ghost plane
   for (int q = qlo; q <= qend; q++) {
     __syncthreads();                                                                // [A] the planes stored at the end of the previous step are in place
     const bool do_r = q <= qhi, more = q + 1 <= qhi;                                // more: there is an R(q+1)
+    const int up = is_red(gi, gj, q) ? 0 : 1;                                      // the red cell of the own pair on plane q: 0 lower, 1 upper
+    // ---- "special" red cells of this step (see the head of the file): t comes from P.tg's interior.  These loads are the FIRST of the step, so
+    // waiting for them later does not mean waiting for the prefetches issued after them.
+    const bool q_out = q < 0 || q >= dim;
+    const int row_r = 2 * lj + up, ec = e_red(q), eci = ei + ec * edx, ecj = ej + ec * edy;
+    const bool sp_o = do_r && q_out && ((t_ilo && li == 0) || (t_ihi && li == TI - 1) || (t_jlo && row_r == 0) || (t_jhi && row_r == TJ - 1));
+    const bool sp_e = do_r && e_in && (e_other || q_out) &&
+                      (out_i(i0 + eci - 1) || out_i(i0 + eci + 1) || out_j(j0 + ecj - 1) || out_j(j0 + ecj + 1) || (wall_klo && q == 0) || (wall_khi && q == dim - 1));
+    double t_spo = 0.0, t_spe = 0.0;
+    if (__builtin_expect(sp_o, 0)) t_spo = (q >= dim) ? tgb_hi[own_o + up * ujS + (long long)q * kS] : sel_origin(L, P.tg, nb[4])[own_g + up * jS + (q + dim) * kS];
+    if (__builtin_expect(sp_e, 0)) {
+      if (q >= 0) t_spe = ((gcptr)sPtr[NT + (q >= dim ? 3 : 2) * NRING + e_id])[ec * e_step + (long long)q * kS];
+      else { const int m = L.box_nbr[6 * acol.box + 4]; t_spe = (sel_origin(L, P.tg, m) + acol.off)[ec * e_step + (long long)(q + dim) * kS]; }
+    }
     // ---- loads of this step (consumed at its end or in the next step)
-    double n_x0 = 0.0, n_x1 = 0.0, n_hx = 0.0, n_bi0 = 0.0, n_bi1 = 0.0, n_bj0 = 0.0, n_bj1 = 0.0, n_bk0 = 0.0, n_bk1 = 0.0, h_bi = 0.0, h_bj = 0.0, h_bk = 0.0;
-    double n_rhs0 = 0.0, n_rhs1 = 0.0, n_dinv0 = 0.0, n_dinv1 = 0.0, n_al0 = 0.0, n_al1 = 0.0, ne_rhs = 0.0, ne_dinv = 0.0, ne_al = 0.0, ne_xp2 = 0.0;
+    // aux0 .. aux2: the coefficient halo cell (lanes 0 .. 331: beta_i, beta_j, beta_k) or the ring pair's red cell (lanes 432 ..: rhs, Dinv, x two planes up)
+    double n_x0 = 0.0, n_x1 = 0.0, n_hx = 0.0, n_bi0 = 0.0, n_bi1 = 0.0, n_bj0 = 0.0, n_bj1 = 0.0, n_bk0 = 0.0, n_bk1 = 0.0, aux0 = 0.0, aux1 = 0.0, aux2 = 0.0;
+    double n_rhs0 = 0.0, n_rhs1 = 0.0, n_dinv0 = 0.0, n_dinv1 = 0.0, n_al0 = 0.0, n_al1 = 0.0, ne_al = 0.0;
     if (more) {
       const int p2 = q + 2, p3 = q + 3, p1 = q + 1;
-      if (h_ok) n_hx = xh_fwd(p2);
-      { const double *b = lvb + own_g + p2 * kS;                                    // coefficients: always the own box's arrays, ghost planes included
-        n_bi0 = b[(size_t)VECTOR_BETA_I * vol]; n_bi1 = b[(size_t)VECTOR_BETA_I * vol + jS];
-        n_bj0 = b[(size_t)VECTOR_BETA_J * vol]; n_bj1 = b[(size_t)VECTOR_BETA_J * vol + jS];
-        n_bk0 = b[(size_t)VECTOR_BETA_K * vol]; n_bk1 = b[(size_t)VECTOR_BETA_K * vol + jS]; }
-      if (has_b) { const double *b = lvb + b_g + p2 * kS; h_bi = b[(size_t)VECTOR_BETA_I * vol]; h_bj = b[(size_t)VECTOR_BETA_J * vol]; h_bk = b[(size_t)VECTOR_BETA_K * vol]; }
-      if (!(wall_khi && p3 > dim + 1)) { const double *b = ((p3 >= dim) ? xb_hi : xb) + own_g + p3 * kS; n_x0 = b[0]; n_x1 = b[jS]; }
-      { const double *b = ((p1 >= dim) ? lvb_hi : lvb) + own_g + p1 * kS;
-        n_rhs0 = b[(size_t)P.rhs_id * vol]; n_rhs1 = b[(size_t)P.rhs_id * vol + jS];
-        n_dinv0 = b[(size_t)VECTOR_DINV * vol]; n_dinv1 = b[(size_t)VECTOR_DINV * vol + jS];
-        if (kHelm) { n_al0 = b[(size_t)VECTOR_ALPHA * vol]; n_al1 = b[(size_t)VECTOR_ALPHA * vol + jS]; } }
+      if (h_ok) n_hx = xh_c[0];
+      { // coefficients: always the own box's arrays, ghost planes included
+        gcptr bi = lvb + (size_t)VECTOR_BETA_I * vol, bj = lvb + (size_t)VECTOR_BETA_J * vol, bk = lvb + (size_t)VECTOR_BETA_K * vol;
+        const unsigned o = own_b + (unsigned)p2 * bkS;
+        n_bi0 = gld(bi, o); n_bi1 = gld(bi, o + bjS); n_bj0 = gld(bj, o); n_bj1 = gld(bj, o + bjS); n_bk0 = gld(bk, o); n_bk1 = gld(bk, o + bjS);
+        if (has_b) { const unsigned ob = b_o * 8u + (unsigned)p2 * bkS; aux0 = gld(bi, ob); aux1 = gld(bj, ob); aux2 = gld(bk, ob); } }
+      if (!(wall_khi && p3 > dim + 1)) { gcptr b = (p3 >= dim) ? xb_hi : xb; const unsigned o = own_b + (unsigned)p3 * bkS; n_x0 = gld(b, o); n_x1 = gld(b, o + bjS); }
+      { gcptr b = (p1 >= dim) ? lvb_hi : lvb;
+        gcptr br = b + (size_t)P.rhs_id * vol, bd = b + (size_t)VECTOR_DINV * vol;
+        const unsigned o = own_b + (unsigned)p1 * bkS;
+        n_rhs0 = gld(br, o); n_rhs1 = gld(br, o + bjS); n_dinv0 = gld(bd, o); n_dinv1 = gld(bd, o + bjS);
+        if (kHelm) { gcptr ba = b + (size_t)VECTOR_ALPHA * vol; n_al0 = gld(ba, o); n_al1 = gld(ba, o + bjS); } }
       if (e_in) {
         const int c = e_red(p1);
-        ne_rhs = al_fwd(P.rhs_id, c, p1); ne_dinv = al_fwd(VECTOR_DINV, c, p1); if (kHelm) ne_al = al_fwd(VECTOR_ALPHA, c, p1);
-        ne_xp2 = xe_fwd(c, p3);
+        gcptr a = al_c + c * e_step;
+        aux0 = a[(size_t)P.rhs_id * vol]; aux1 = a[(size_t)VECTOR_DINV * vol]; if (kHelm) ne_al = a[(size_t)VECTOR_ALPHA * vol];
+        aux2 = xe_c[c * e_step];
       }
     }
 
-    const int up = is_red(gi, gj, q) ? 0 : 1;                                      // the red cell of the own pair on plane q: 0 lower, 1 upper
-    double r_new = 0.0;
     if (do_r) {
       const double *X0 = sX + slot4(q) * PX, *Xm = sX + slot4(q - 1) * PX, *Xp = sX + slot4(q + 1) * PX, *Xmm = sX + slot4(q - 2) * PX;
       const double *I0 = sBI + slot3(q) * PB, *Im = sBI + slot3(q - 1) * PB, *Ip = sBI + slot3(q + 1) * PB;
@@ -349,45 +395,35 @@ __global__ __launch_bounds__(512) void fv4_rb_kernel(const hpgmg_hip_level L, co
         X25 x; B18 bt;
         const int oX = ownX + up * WX, oB = ownB + up * WB;
         gather(x, oX, up ? kp2_1 : kp2_0);
-        // "special": a cell of ANOTHER box (here: a plane below / above this box) whose stencil reaches outside the domain must see that
-        // box's own extrapolated coefficients there, not this box's: read them where the reference reads them
-        const int row = 2 * lj + up;
-        const bool sp = (q < 0 || q >= dim) && ((t_ilo && li == 0) || (t_ihi && li == TI - 1) || (t_jlo && row == 0) || (t_jhi && row == TJ - 1));
-        if (sp) {
-          const double *pc = (q >= dim) ? lvb_hi + own_g + up * jS + q * kS : L.box_base[nb[4]] + first + own_g + up * jS + (q + dim) * kS;
-          beta18_global(bt, pc, vol, jS, kS);
-        } else beta18(bt, I0 + oB, Im + oB, Ip + oB, J0 + oB, Jm + oB, Jp + oB, K0 + oB, K1 + oB);
+        beta18(bt, I0 + oB, Im + oB, Ip + oB, J0 + oB, Jm + oB, Jp + oB, K0 + oB, K1 + oB);
         const double sum = fv4_sum(x, bt);
         const double alv = up ? c_al1 : c_al0, rhs = up ? c_rhs1 : c_rhs0, dinv = up ? c_dinv1 : c_dinv0;
         const double Ax = kHelm ? (P.a * alv) * x.c - bh2inv * sum : nbh2inv * sum;
-        r_new = x.c + dinv * (rhs - Ax);
+        double r_new = x.c + dinv * (rhs - Ax);
+        if (__builtin_expect(sp_o, 0)) r_new = t_spo;                               // a special cell (a plane of another box next to a wall)
         sT[slot3(q) * PT + ownT + up * ST] = r_new;
+        if (q >= k0 && q < k1) gst(outb, own_b + up * bjS + (unsigned)q * bkS, r_new);      // the pair's red cell on plane q is final: x' = t there
       }
       if (e_in) { // ---- R(q) at the red cell of the ring pair
         X25 x; B18 bt;
-        const int c = e_red(q), ci = ei + c * edx, cj = ej + c * edy;
+        const int ci = eci, cj = ecj;
         const int oX = posX(ci, cj), oB = posB(ci, cj);
         gather(x, oX, e_xp2);
-        const int ci_g = i0 + ci, cj_g = j0 + cj;
-        const bool sp = (e_other || q < 0 || q >= dim) &&
-                        (out_i(ci_g - 1) || out_i(ci_g + 1) || out_j(cj_g - 1) || out_j(cj_g + 1) || (wall_klo && q == 0) || (wall_khi && q == dim - 1));
-        if (sp) {
-          const double *pc;
-          if (q >= 0) pc = ((q >= dim) ? al_hi : al) + c * e_step + q * kS;
-          else { const int m = L.box_nbr[6 * acol.box + 4]; pc = L.box_base[m] + first + acol.off + c * e_step + (q + dim) * kS; }
-          beta18_global(bt, pc, vol, jS, kS);
-        } else beta18(bt, I0 + oB, Im + oB, Ip + oB, J0 + oB, Jm + oB, Jp + oB, K0 + oB, K1 + oB);
+        beta18(bt, I0 + oB, Im + oB, Ip + oB, J0 + oB, Jm + oB, Jp + oB, K0 + oB, K1 + oB);
         const double sum = fv4_sum(x, bt);
         const double Ax = kHelm ? (P.a * e_al) * x.c - bh2inv * sum : nbh2inv * sum;
-        sT[slot3(q) * PT + posT(ci, cj)] = x.c + e_dinv * (e_rhs - Ax);
+        double tv = x.c + e_dinv * (e_rhs - Ax);
+        if (__builtin_expect(sp_e, 0)) tv = t_spe;
+        sT[slot3(q) * PT + posT(ci, cj)] = tv;
       }
     }
     __syncthreads();                                                                // [B] t on plane q is complete inside the domain
     // ghost values of t: in i / j on plane q (tiles at a wall); below the domain after R(0); above it after R(dim-1) (the x ring's part:
     // B(dim-2) reads it in this step) and in the extra step (the t ring's part, whose slot B(dim-2) still needed)
     const int kfill = (bottom && q == 0) ? 1 : ((top && q == dim - 1) ? 2 : ((top && q == dim) ? 3 : 0));
-    if ((tile_wall && do_r) || kfill) {
-      if (tile_wall && do_r && bc_kind) {
+    if (__builtin_expect((tile_wall && do_r) || kfill, 0)) {
+      if (tile_wall && do_r && (bc_pack & 3)) {
+        const int bc_kind = bc_pack & 3, bc_i = ((bc_pack >> 2) & 127) - 4, bc_j = ((bc_pack >> 9) & 31) - 4, bc_si = ((bc_pack >> 14) & 3) - 1, bc_sj = ((bc_pack >> 16) & 3) - 1;
         // ---- ghost cells of t on plane q outside the domain in i / j: apply_BCs_v4 (boundary_fv.c:262-425) from t itself
         const bool red = is_red(i0 + bc_i, j0 + bc_j, q);
         if (bc_kind == 3) {
@@ -408,17 +444,17 @@ __global__ __launch_bounds__(512) void fv4_rb_kernel(const hpgmg_hip_level L, co
           else if (!red)    sX[slot4(q) * PX + posX(bc_i, bc_j)] = v4_far(x1, x2, x3, x4);
         }
       }
-      if (kfill) {
+      if (__builtin_expect(kfill != 0, 0)) {
         // ---- the ghost plane of t below / above the domain (P.tg): red-parity own cells into the t ring, black-parity positions over x's
         const int pg = (kfill == 1) ? -1 : dim;
-        const double t0 = tgb[own_g + pg * kS], t1 = tgb[own_g + jS + pg * kS];
+        const double t0 = tgb[(long long)own_o + (long long)pg * kS], t1 = tgb[(long long)own_o + jS + (long long)pg * kS];
         const bool red0 = is_red(gi, gj, pg);
         if (kfill != 3) {
           sX[slot4(pg) * PX + ownX + (red0 ? WX : 0)] = red0 ? t1 : t0;
           if (h_face && !is_red(i0 + hi, j0 + hj, pg)) sX[slot4(pg) * PX + hX] = (sel_origin(L, P.tg, hcol.box) + hcol.off)[pg * kS];
         }
         if (kfill != 2) sT[slot3(pg) * PT + ownT + (red0 ? 0 : ST)] = red0 ? t0 : t1;
-        if (kfill == 1) sX[slot4(-2) * PX + ownX + (red0 ? 0 : WX)] = tgb[own_g + (red0 ? 0 : jS) - 2 * kS];   // two below: black parity where plane -1 is red
+        if (kfill == 1) sX[slot4(-2) * PX + ownX + (red0 ? 0 : WX)] = tgb[(long long)own_o + (red0 ? 0 : jS) - 2LL * kS];   // two below: black parity where plane -1 is red
       }
       __syncthreads();                                                              // [C]
     }
@@ -434,7 +470,8 @@ __global__ __launch_bounds__(512) void fv4_rb_kernel(const hpgmg_hip_level L, co
       constexpr int W = WX, V2 = WB;
       x.c = X0[o];
       x.km2 = kmB;
-      x.kp2 = (top && q == dim) ? tgb[own_g + up * jS + (dim + 1) * kS] : sX[slot4(q + 1) * PX + o];
+      x.kp2 = sX[slot4(q + 1) * PX + o];
+      if (__builtin_expect(top && q == dim, 0)) x.kp2 = tgb[own_o + up * ujS + (unsigned)(dim + 1) * ukS];
       x.im1 = T0[posT(li - 1, row)]; x.ip1 = T0[posT(li + 1, row)]; x.jm1 = T0[posT(li, row - 1)]; x.jp1 = T0[posT(li, row + 1)];
       x.km1 = Tm[posT(li, row)]; x.kp1 = Tp[posT(li, row)];
       x.im2 = X0[o - 2]; x.ip2 = X0[o + 2]; x.jm2 = X0[o - 2 * W]; x.jp2 = X0[o + 2 * W];
@@ -449,8 +486,8 @@ __global__ __launch_bounds__(512) void fv4_rb_kernel(const hpgmg_hip_level L, co
       bt.d[10] = K1[1] - K1[-1]; bt.d[11] = K1[V2] - K1[-V2];
       const double sum = fv4_sum(x, bt);
       const double Ax = kHelm ? (P.a * b_al) * x.c - bh2inv * sum : nbh2inv * sum;
-      outb[own_g + up * jS + r * kS] = x.c + b_dinv * (b_rhs - Ax);
-      outb[own_g + (1 - up) * jS + r * kS] = r_prev;                                // the pair's red cell on plane r: what R(r) formed
+      gst(outb, own_b + up * bjS + (unsigned)r * bkS, x.c + b_dinv * (b_rhs - Ax));
+                               // the pair's red cell on plane r: what R(r) formed
     }
     if (do_r) {
       // for B(q) in the next step, at the OTHER cell of the pair (black on plane q): the terms whose planes will have left the rings by then
@@ -468,15 +505,72 @@ __global__ __launch_bounds__(512) void fv4_rb_kernel(const hpgmg_hip_level L, co
       sX[s + ownX] = kp2_0; sX[s + ownX + WX] = kp2_1;
       if (has_h) sX[s + hX] = n_hx;
       sBI[sb + ownB] = n_bi0; sBI[sb + ownB + WB] = n_bi1; sBJ[sb + ownB] = n_bj0; sBJ[sb + ownB + WB] = n_bj1; sBK[sk + ownB] = n_bk0; sBK[sk + ownB + WB] = n_bk1;
-      if (has_b) { sBI[sb + bB] = h_bi; sBJ[sb + bB] = h_bj; sBK[sk + bB] = h_bk; }
+      if (has_b) { sBI[sb + bB] = aux0; sBJ[sb + bB] = aux1; sBK[sk + bB] = aux2; }
     }
     // ---- next plane
-    r_prev = r_new;
     b_rhs = up ? c_rhs0 : c_rhs1; b_dinv = up ? c_dinv0 : c_dinv1; b_al = up ? c_al0 : c_al1;      // the black cell of plane q: B(q) in the next step
     kp2_0 = n_x0; kp2_1 = n_x1;
     c_rhs0 = n_rhs0; c_rhs1 = n_rhs1; c_dinv0 = n_dinv0; c_dinv1 = n_dinv1; c_al0 = n_al0; c_al1 = n_al1;
-    e_rhs = ne_rhs; e_dinv = ne_dinv; e_al = ne_al; e_xp2 = ne_xp2;
+    if (has_e) { e_rhs = aux0; e_dinv = aux1; e_xp2 = aux2; }
+    e_al = ne_al;
+    // the marching pointers: one plane up; where a column leaves the top of its box, continue in the box above (parked in LDS)
+    xh_c += kS; al_c += kS; xe_c += kS;
+    if (__builtin_expect(q + 3 == dim, 0)) xh_c = (gcptr)sPtr[tid] + (long long)dim * kS;
+    if (__builtin_expect(q + 2 == dim, 0)) al_c = (gcptr)sPtr[NT + e_id] + (long long)dim * kS;
+    if (__builtin_expect(q + 4 == dim, 0)) xe_c = (gcptr)sPtr[NT + NRING + e_id] + (long long)dim * kS;
   }
+}
+
+// ---- the "special" cells (head of the file): t = the red half sweep of x at the listed cells of this rank's boxes, formed exactly as the
+// reference forms it for a cell of that box (its own coefficient arrays, ghost zones included; x outside the box from the box that owns it),
+// written into the interior of P.tg.  A few thousand cells per level (lines where an internal box face meets a domain wall): one lane per
+// cell, plain global loads.
+struct Fv4SpecialArgs {
+  VecSel x, tg;
+  int rhs_id;
+  double a, b, h2inv;
+  int sweep;
+  const int *cells;      // 4 ints per cell: box, i, j, k
+  int n;
+};
+template <int V>
+__global__ __launch_bounds__(256) void fv4_special_kernel(const hpgmg_hip_level L, const Fv4SpecialArgs P) {
+  using namespace fv4rb;
+  constexpr bool kHelm = (V == HPGMG_HIP_FV4_VC_HELMHOLTZ);
+  const int idx = (int)blockIdx.x * 256 + (int)threadIdx.x;
+  if (idx >= P.n) return;
+  const int box = P.cells[4 * idx], i = P.cells[4 * idx + 1], j = P.cells[4 * idx + 2], k = P.cells[4 * idx + 3];
+  const int dim = L.dim, jS = L.jStride, kS = L.kStride;
+  const size_t vol = (size_t)L.volume, first = (size_t)L.ghosts * (size_t)(1 + jS + kS);
+  // x at (i + di, j + dj, k + dk): in the box that owns the place (one hop per axis), its ghost zone where the domain ends
+  auto xat = [&](int di, int dj, int dk) -> double {
+    int b = box, I = i + di, J = j + dj, K = k + dk;
+    if (I < 0)         { const int n = L.box_nbr[6 * b + 0]; if (n >= 0) { b = n; I += dim; } }
+    else if (I >= dim) { const int n = L.box_nbr[6 * b + 1]; if (n >= 0) { b = n; I -= dim; } }
+    if (J < 0)         { const int n = L.box_nbr[6 * b + 2]; if (n >= 0) { b = n; J += dim; } }
+    else if (J >= dim) { const int n = L.box_nbr[6 * b + 3]; if (n >= 0) { b = n; J -= dim; } }
+    if (K < 0)         { const int n = L.box_nbr[6 * b + 4]; if (n >= 0) { b = n; K += dim; } }
+    else if (K >= dim) { const int n = L.box_nbr[6 * b + 5]; if (n >= 0) { b = n; K -= dim; } }
+    return sel_origin(L, P.x, b)[I + J * jS + K * kS];
+  };
+  X25 x;
+  x.c = xat(0, 0, 0); x.im1 = xat(-1, 0, 0); x.ip1 = xat(1, 0, 0); x.im2 = xat(-2, 0, 0); x.ip2 = xat(2, 0, 0);
+  x.jm1 = xat(0, -1, 0); x.jp1 = xat(0, 1, 0); x.jm2 = xat(0, -2, 0); x.jp2 = xat(0, 2, 0);
+  x.km1 = xat(0, 0, -1); x.kp1 = xat(0, 0, 1); x.km2 = xat(0, 0, -2); x.kp2 = xat(0, 0, 2);
+  x.mm = xat(-1, -1, 0); x.pm = xat(1, -1, 0); x.mp = xat(-1, 1, 0); x.pp = xat(1, 1, 0);
+  x.m_im = xat(-1, 0, -1); x.m_ip = xat(1, 0, -1); x.m_jm = xat(0, -1, -1); x.m_jp = xat(0, 1, -1);
+  x.p_im = xat(-1, 0, 1); x.p_ip = xat(1, 0, 1); x.p_jm = xat(0, -1, 1); x.p_jp = xat(0, 1, 1);
+  gcptr pc = as_global(L.box_base[box]) + first + i + j * jS + (long long)k * kS;
+  double v = x.c;
+  const int par0 = (L.box_low[3 * box] ^ L.box_low[3 * box + 1] ^ L.box_low[3 * box + 2] ^ P.sweep) & 1;
+  if (((i ^ j ^ k ^ par0) & 1) == 0) {
+    B18 bt;
+    beta18_global(bt, pc, vol, jS, kS);
+    const double sum = fv4_sum(x, bt);
+    const double Ax = kHelm ? (P.a * pc[(size_t)VECTOR_ALPHA * vol]) * x.c - (P.b * P.h2inv) * sum : ((-P.b) * P.h2inv) * sum;
+    v = x.c + pc[(size_t)VECTOR_DINV * vol] * (pc[(size_t)P.rhs_id * vol] - Ax);
+  }
+  sel_origin(L, P.tg, box)[i + j * jS + (long long)k * kS] = v;
 }
 
 }  // namespace hpgmg

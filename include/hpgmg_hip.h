@@ -240,10 +240,13 @@ int hpgmg_hip_exchange_and_bc(const hpgmg_hip_level *L, int id, const blockCopy_
  * gsrb.c:24-132 twice, apply_BCs_v4 boundary_fv.c:262-569 in between) in one pass: kernels/fv4_rb.hpp.  Vectors are (scratch, id) pairs;
  * scratch = 1 addresses the plugin-private vectors behind scr_base (same box layout as the level's).  The intermediate vector lives in
  * LDS; its ghost planes below / above the domain are read from the k ghost zone of scratch vector tg_id, which _prepass fills first
- * (entries_k: the geometry of the boundary blocks whose domain normal has a k component).  sweep = number of the first (even) half sweep. */
+ * (entries_k: the geometry of the boundary blocks whose domain normal has a k component; special_cells: the cells on internal box faces that
+ * are next to a domain wall -- their intermediate value is formed by the pre-pass with the owning box's coefficients and read by the main
+ * kernel, which recomputes every other cell next to its tiles itself).  sweep = number of the first (even) half sweep. */
 int  hpgmg_hip_smooth_gsrb_fv4_rb_supported(const hpgmg_hip_level *L, int variant);
 int  hpgmg_hip_fv4_rb_prepass(const hpgmg_hip_level *L, int variant, double *const *scr_base, int x_scratch, int x_id, int tg_id, int rhs_id,
-                              double a, double b, double h2inv, int sweep, const hpgmg_hip_bc_entry *entries_k, int n_k);
+                              double a, double b, double h2inv, int sweep, const hpgmg_hip_bc_entry *entries_k, int n_k,
+                              const int *special_cells /* DEVICE: box, i, j, k per cell */, int n_special);
 int  hpgmg_hip_smooth_gsrb_fv4_rb(const hpgmg_hip_level *L, int variant, double *const *scr_base, int x_scratch, int x_id, int out_scratch, int out_id,
                                   int tg_id, int rhs_id, double a, double b, double h2inv, int sweep);
 long long hpgmg_hip_rb_fv4_launch_count(void);   /* launches of the one-pass kernel so far (tests) */
