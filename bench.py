@@ -18,8 +18,13 @@ the reference CLI's `7 8` with N ranks (256^3, 256^3, 384^3, 512^3).
 value = fine-grid DOF of the whole job / max-over-ranks time.
 
 Extra objects on the JSON line:
-  roofline     fine-level Chebyshev smoother: algorithmic bytes (72 B per cell per sweep x the sweeps a launch performs;
-               the fused kernel does two) / hipEvent-timed launch
+  roofline     the fine-level smoother kernel, timed with hipEvents on the launch stream inside the timed region.
+               achieved / frac = the bytes ONE LAUNCH of that kernel has to move in the form it really has (a kernel that does two
+               sweeps per pass is charged its own stream count once, not twice the single-sweep figure) / launch time / 8 TB/s;
+               unfused_equivalent_GBs = SURVEY 8(d)'s bytes per cell per sweep x the sweeps the launch performs / launch time: what
+               separate sweeps would have had to move in that time (a speed-up figure, not a bandwidth -- it may exceed the peak);
+               traffic = HBM bytes per launch from the rocprofv3 PMC passes (traffic_source names the committed summary file),
+               dram_GBs_from_pmc = traffic / launch time.  frac > 1 is refused.
   cpu_baseline the REFERENCE binary (oracle/_ref, built from /root/reference by oracle/Makefile)
                run on this box's host cores; falls back to the CPU restatement ("port").
 """
@@ -36,7 +41,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-BYTES_PER_CELL_CHEBY_HELMHOLTZ = 72  # x_n, x_nm1, rhs, Dinv, beta_i/j/k, alpha read + x_np1 written
 LOG2_BOX_DIM, BOXES_PER_RANK = 7, 8
 
 
@@ -81,8 +85,9 @@ def cpu_baseline():
 
 
 def pmc_traffic(workload="config2", fine_cells=None):
-    """HBM bytes per fine-level smoother launch from the committed rocprofv3 --pmc summary of this workload, if any (the newest: files sort
-    by round tag).  config 2: the sweep-pair launch with its pre-pass; config 3: the tiled kernel's coloured half sweep at the same size."""
+    """(HBM bytes per fine-level smoother launch, file it comes from): the committed rocprofv3 --pmc summary of this workload, if any (the
+    newest: files sort by round tag).  config 2: the sweep-pair launch with its pre-pass; config 3: the one-pass kernel at the same size.
+    The number was measured on ANOTHER run of the same command (profiles/README.md); it is not a measurement of this run."""
     best = None
     pdir = os.path.join(ROOT, "profiles")
     want = {"config2": ("_pmc_summary.json", "hbm_bytes_per_launch_cheby_fine"), "config3-fv4": ("_fv4_pmc_summary.json", "hbm_bytes_per_launch_smoother_fine"),
@@ -95,10 +100,10 @@ def pmc_traffic(workload="config2", fine_cells=None):
                 d = json.load(open(os.path.join(pdir, f)))
                 got = d.get(want[1])
                 if got and (fine_cells is None or workload == "config2" or d.get("cells") == fine_cells):
-                    best = got
+                    best = (got, "profiles/" + f)
             except Exception:
                 pass
-    return best
+    return best if best else (None, None)
 
 
 def main():
@@ -122,15 +127,15 @@ def main():
     # `python bench.py --gpus N` outside torchrun: start the N ranks ourselves, as a CHILD process (this parent has not touched the
     # GPU and never does), relay the child's JSON line and exit with its code.  Never measure one GPU and call it N.
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        import socket
-        with socket.socket() as sk:
-            sk.bind(("127.0.0.1", 0))
-            port = sk.getsockname()[1]
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
-               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        # --standalone: the launcher's own c10d rendezvous picks its port while holding it (no bind-close-reuse race)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               os.path.abspath(__file__)] + sys.argv[1:]
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
                    OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", str(max(1, host_cores() // args.gpus))))
-        child = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+        try:      # every rank has its own watchdog; the parent waits a little longer than that, never for ever
+            child = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True, timeout=(args.watchdog + 120) if args.watchdog > 0 else None)
+        except subprocess.TimeoutExpired:
+            raise SystemExit(f"bench.py: the {args.gpus}-rank job did not finish within {args.watchdog + 120} s")
         lines = [l for l in child.stdout.splitlines() if l.strip()]
         result = next((l for l in reversed(lines) if l.startswith("{") and '"metric"' in l), None)
         for l in lines:
@@ -175,12 +180,11 @@ def main():
     if world > 1 or args.force_transport:
         import torch.distributed as dist
         if world == 1 and "RANK" not in os.environ:      # --force-transport outside torchrun: a one-rank job on this machine
-            import socket
-            with socket.socket() as sk:
-                sk.bind(("127.0.0.1", 0))
-                free = sk.getsockname()[1]
-            os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free))
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            import tempfile      # a one-rank job needs no network rendezvous at all: a file store
+            store = "file://" + os.path.join(tempfile.mkdtemp(prefix="hpgmg_bench_"), "store")
+            dist.init_process_group(backend="nccl", init_method=store, rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+        if not dist.is_initialized():
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         ident = torch.zeros(128, dtype=torch.uint8, device="cuda")
         if rank == 0:
             buf = ctypes.create_string_buffer(128)
@@ -264,26 +268,35 @@ def main():
     if rank == 0:
         sec_per_step = elapsed / args.steps
         roof = None
-        # SURVEY 8(d) algorithmic bytes per cell per sweep of the fine-level smoother kernel each workload spends most of its time in
-        smoother = {"config1": (40, "7-pt constant-coefficient Chebyshev sweep (stencil7_kernel): x_n, x_nm1, rhs, Dinv read + x_np1 written"),
-                    "config2": (BYTES_PER_CELL_CHEBY_HELMHOLTZ, "hpgmg::cheby_pair_kernel<VC Helmholtz> (+ its edge-column pre-pass): one launch = TWO Chebyshev sweeps"),
-                    "config4": (BYTES_PER_CELL_CHEBY_HELMHOLTZ, "hpgmg::cheby_pair_kernel<VC Helmholtz> (+ its edge-column pre-pass): one launch = TWO Chebyshev sweeps"),
-                    "config5": (52, "hpgmg::cheby_pair_kernel<VC Helmholtz, fp32 coefficient streams> (+ pre-pass): one launch = TWO Chebyshev sweeps"),
-                    "config3-fv4": (56, "hpgmg::fv4_tile_kernel<VC Poisson, GSRB>: one out-of-place coloured half sweep (x, rhs, Dinv, beta_i/j/k read + x written)"),
-                    "config3-27pt": (32, "hpgmg::stencil27_rb_kernel: one launch = BOTH coloured half sweeps of an out-of-place GSRB sweep (each, done separately: x, rhs, Dinv read + x written; the intermediate vector stays in LDS)")}[args.workload]
+        # The fine-level smoother kernel each workload spends most of its time in: (bytes per cell per sweep when every sweep is a pass of its
+        # own -- SURVEY 8(d) --, bytes per cell ONE LAUNCH moves when it performs two sweeps in one pass, description)
+        smoother = {"config1": (40, 40, "7-pt constant-coefficient Chebyshev sweep (stencil7_kernel): x_n, x_nm1, rhs, Dinv read + x_np1 written"),
+                    "config2": (72, 80, "hpgmg::cheby_pair_kernel<VC Helmholtz> (+ its edge-column pre-pass): one launch = TWO Chebyshev sweeps in one pass: x0, x_nm1, rhs, Dinv, alpha, beta_i/j/k read once, x1 and x2 written"),
+                    "config4": (72, 80, "hpgmg::cheby_pair_kernel<VC Helmholtz> (+ its edge-column pre-pass): one launch = TWO Chebyshev sweeps in one pass: x0, x_nm1, rhs, Dinv, alpha, beta_i/j/k read once, x1 and x2 written"),
+                    "config5": (52, 60, "hpgmg::cheby_pair_kernel<VC Helmholtz, fp32 coefficient streams> (+ pre-pass): one launch = TWO Chebyshev sweeps: x0, x_nm1, rhs (fp64), five fp32 coefficient streams read, x1 and x2 written"),
+                    "config3-fv4": (56, 56, "hpgmg::fv4_rb_kernel<VC Poisson> (+ its pre-pass): one launch = BOTH coloured half sweeps of an out-of-place GSRB sweep in one pass: x, rhs, Dinv, beta_i/j/k read once, x' written (the intermediate vector stays in LDS); "
+                                            "with HPGMG_TUNE_FV4_NO_RB=1 hpgmg::fv4_tile_kernel, one half sweep per launch"),
+                    "config3-27pt": (32, 32, "hpgmg::stencil27_rb_kernel: one launch = BOTH coloured half sweeps of an out-of-place GSRB sweep in one pass: x, rhs, Dinv read once, x' written (the intermediate vector stays in LDS)")}[args.workload]
         if launches.value > 0 and ms.value > 0:
             avg_s = ms.value * 1e-3 / launches.value
-            # cells.value counts cell-sweeps: the sweep-pair kernel reports two sweeps per launch
-            bytes_per_launch = smoother[0] * (cells.value / launches.value)
+            # cells.value counts cell-sweeps: a kernel that does two sweeps per pass reports two per launch
+            sweeps_per_launch = cells.value / launches.value / fine_cells
+            fused = sweeps_per_launch > 1.5
+            bytes_per_launch = (smoother[1] if fused else smoother[0] * sweeps_per_launch) * fine_cells
             achieved = bytes_per_launch / avg_s / 1e9
-            traffic = pmc_traffic(args.workload, int(fine_cells)) if world == 1 else None
+            unfused = smoother[0] * sweeps_per_launch * fine_cells / avg_s / 1e9
+            traffic, traffic_source = pmc_traffic(args.workload, int(fine_cells)) if world == 1 else (None, None)
+            if achieved > HBM_PEAK_GBS:
+                raise SystemExit(f"bench.py: roofline fraction {achieved / HBM_PEAK_GBS:.3f} > 1 -- the byte model of this kernel is wrong")
             roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "kernel": smoother[1] + f" over the {my_boxes} finest-level boxes of {box_dim}^3 of this rank",
-                    "sweeps_per_launch": round(cells.value / launches.value / fine_cells, 3),
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
+                    "kernel": smoother[2] + f" over the {my_boxes} finest-level boxes of {box_dim}^3 of this rank",
+                    "sweeps_per_launch": round(sweeps_per_launch, 3),
                     "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_us": round(avg_s * 1e6, 2),
                     "launches_timed": launches.value,
-                    # what the launch really moves (rocprofv3 PMC, profiles/*_pmc_summary.json): DRAM-level rate, next to the algorithmic one above
+                    # what separate sweeps would have had to move in the same time: a speed-up figure, not a bandwidth
+                    "unfused_equivalent_GBs": round(unfused, 1),
+                    # what the launch really moves (rocprofv3 PMC, the file named in traffic_source): DRAM-level rate
                     "dram_GBs_from_pmc": round(traffic / avg_s / 1e9, 1) if traffic else None}
         line = {
             "metric": "DOF/s (fine-grid) for FMG F-cycle", "value": dof / sec_per_step, "unit": "DOF/s",

@@ -80,41 +80,74 @@ double hpgmg_hip_event_elapsed_ms(void *a, void *b) {
 // a hipEvent pair recorded on the launch stream around an operator; the elapsed device time is added to the caller's
 // accumulator (seconds) when the pool is flushed -- at the latest when it is full, normally when the table is printed or
 // reset.  Inside a hipGraph capture nothing is recorded (-1).
-static const int kTimerPool = 8192;
-static hipEvent_t g_tev[2 * kTimerPool];
-static double *g_tacc[kTimerPool];
-static int g_tev_alloc = 0, g_tev_used = 0;
+// A slot is free, open (begin recorded) or closed (end recorded); only closed slots are settled, so a flush that happens while outer
+// ticks are still open (MGVCycle's total around its operators) leaves those alone, and a slot id carries the slot's generation, so an
+// id that outlived its slot is ignored instead of closing somebody else's tick.
+static const int kTimerSettleAt = 8192;          // closed pairs that may pile up before timer_begin settles them
+enum { T_FREE = 0, T_OPEN = 1, T_CLOSED = 2 };
+struct TimerSlot { hipEvent_t ev[2]; double *acc; int state; unsigned gen; bool made; };
+static TimerSlot *g_tslot = nullptr;
+static int g_tcap = 0, g_tn = 0, g_tclosed = 0;   // capacity, slots ever used, closed and not yet settled
+static int *g_tfree = nullptr; static int g_tfree_n = 0;
 int hpgmg_hip_graph_is_open(void);
 int hpgmg_hip_timer_flush(void) {
-  for (int p = 0; p < g_tev_used; p++) {
+  for (int p = 0; p < g_tn; p++) {
+    TimerSlot &t = g_tslot[p];
+    if (t.state != T_CLOSED) continue;
     float ms = 0.f;
-    if (hipEventSynchronize(g_tev[2 * p + 1]) == hipSuccess && hipEventElapsedTime(&ms, g_tev[2 * p], g_tev[2 * p + 1]) == hipSuccess && g_tacc[p]) *g_tacc[p] += 1e-3 * (double)ms;
+    if (hipEventSynchronize(t.ev[1]) == hipSuccess && hipEventElapsedTime(&ms, t.ev[0], t.ev[1]) == hipSuccess && t.acc) *t.acc += 1e-3 * (double)ms;
     else (void)hipGetLastError();
+    t.state = T_FREE; t.gen++; t.acc = nullptr;
+    g_tfree[g_tfree_n++] = p;
   }
-  g_tev_used = 0;
+  g_tclosed = 0;
   return 0;
 }
 int hpgmg_hip_timer_begin(double *acc_seconds) {
   if (hpgmg_hip_graph_is_open()) return -1;
   ensure_stream();
-  if (g_tev_used == kTimerPool) hpgmg_hip_timer_flush();
-  if (g_tev_used == g_tev_alloc) {
-    if (hipEventCreate(&g_tev[2 * g_tev_alloc]) != hipSuccess || hipEventCreate(&g_tev[2 * g_tev_alloc + 1]) != hipSuccess) { (void)hipGetLastError(); return -1; }
-    g_tev_alloc++;
+  if (g_tclosed >= kTimerSettleAt) hpgmg_hip_timer_flush();
+  int p;
+  if (g_tfree_n > 0) p = g_tfree[--g_tfree_n];
+  else {
+    if (g_tn == g_tcap) {
+      const int cap = g_tcap ? 2 * g_tcap : 1024;
+      TimerSlot *ns = (TimerSlot *)realloc(g_tslot, (size_t)cap * sizeof(TimerSlot));
+      int *nf = (int *)realloc(g_tfree, (size_t)cap * sizeof(int));
+      if (ns) g_tslot = ns;
+      if (nf) g_tfree = nf;
+      if (!ns || !nf) return -1;
+      for (int q = g_tcap; q < cap; q++) { g_tslot[q].state = T_FREE; g_tslot[q].gen = 0; g_tslot[q].made = false; g_tslot[q].acc = nullptr; }
+      g_tcap = cap;
+    }
+    p = g_tn++;
   }
-  const int p = g_tev_used++;
-  g_tacc[p] = acc_seconds;
-  (void)hipEventRecord(g_tev[2 * p], g_stream);
-  return p;
+  TimerSlot &t = g_tslot[p];
+  if (!t.made) {
+    if (hipEventCreate(&t.ev[0]) != hipSuccess || hipEventCreate(&t.ev[1]) != hipSuccess) { (void)hipGetLastError(); g_tfree[g_tfree_n++] = p; return -1; }
+    t.made = true;
+  }
+  t.acc = acc_seconds; t.state = T_OPEN;
+  (void)hipEventRecord(t.ev[0], g_stream);
+  return (int)(((t.gen & 0x7ffu) << 20) | (unsigned)p);          // 20 bits of slot, 11 of generation
 }
-void hpgmg_hip_timer_end(int slot) {
-  if (slot < 0 || slot >= g_tev_used) return;
-  if (hipEventRecord(g_tev[2 * slot + 1], g_stream) != hipSuccess) { (void)hipGetLastError(); g_tacc[slot] = nullptr; }
+void hpgmg_hip_timer_end(int id) {
+  if (id < 0) return;
+  const int p = id & 0xfffff;
+  if (p >= g_tn) return;
+  TimerSlot &t = g_tslot[p];
+  if (t.state != T_OPEN || (t.gen & 0x7ffu) != (((unsigned)id >> 20) & 0x7ffu)) return;       // a stale id
+  if (hipEventRecord(t.ev[1], g_stream) != hipSuccess) { (void)hipGetLastError(); t.acc = nullptr; }
+  t.state = T_CLOSED; g_tclosed++;
 }
-// an accumulator is going away (level destroyed): settle what is pending
+// an accumulator is going away (level destroyed): settle what is pending; ticks still open on it are dropped
 void hpgmg_hip_timer_forget(const void *lo, const void *hi) {
   bool any = false;
-  for (int p = 0; p < g_tev_used; p++) if ((const void *)g_tacc[p] >= lo && (const void *)g_tacc[p] < hi) any = true;
+  for (int p = 0; p < g_tn; p++) {
+    TimerSlot &t = g_tslot[p];
+    if (t.state == T_FREE || (const void *)t.acc < lo || (const void *)t.acc >= hi) continue;
+    if (t.state == T_OPEN) t.acc = nullptr; else any = true;
+  }
   if (any) hpgmg_hip_timer_flush();
 }
 

@@ -712,6 +712,13 @@ static int g_tile_last_blocks = 0;       // workgroups of that launch (= partial
 static int g_defer_mode = 0;   // 0: whole boxes; 1: skip the cells next to remote faces; 2: only those cells (stencil7_shell_kernel)
 
 static int env_int(const char *name, int dflt) { const char *e = getenv(name); return (e && *e) ? atoi(e) : dflt; }
+// A fused residual form was requested (g_tile_fused) but the launch is about to take a kernel that cannot honour it -- it would STORE the
+// residual over the vector the caller passed as a dummy output.  Refuse loudly; never leave the request pending for a later launch.
+static int refuse_unfused(const char *kernel) {
+  if (!g_tile_fused.kind) return 0;
+  g_tile_fused = TileFused{};
+  return record_error(hipErrorInvalidValue, kernel);
+}
 
 static void plan(const hpgmg_hip_level *L, StencilArgs &P, dim3 &block, int &grid) {
   static const int tune_ty = env_int("HPGMG_TUNE_TY", 0), tune_kchunk = env_int("HPGMG_TUNE_KCHUNK", 0);   // experiments only
@@ -771,6 +778,7 @@ static int launch27(const hpgmg_hip_level *L, StencilArgs P, bool is_smoother) {
     HPGMG_LAUNCH_CHECK("stencil27_tile_kernel");
     return 0;
   }
+  if (int e = refuse_unfused("fused residual form requested, but this level runs stencil27_kernel")) return e;
   dim3 block; int grid;
   plan(L, P, block, grid);
   const long long cells = (long long)L->num_boxes * L->dim * L->dim * L->dim;
@@ -831,6 +839,7 @@ static int launch_direct(const hpgmg_hip_level *L, int variant, StencilArgs P, b
     static const int no_tile = env_int("HPGMG_TUNE_FV4_DIRECT", 0);
     if (!no_tile && L->dim % fv4_tile_granule() == 0 && L->ghosts >= 2 && P.xn_id != P.xout_id) return launch_fv4_tile<(MODE == MODE_BLACKBOX) ? MODE_APPLY : MODE>(L, variant, P, is_smoother);
   }
+  if (int e = refuse_unfused("fused residual form requested, but this level runs stencil_direct_kernel")) return e;
   dim3 block; int grid;
   plan(L, P, block, grid);
   P.ghost_free = 0;
@@ -860,6 +869,7 @@ static int launch(const hpgmg_hip_level *L, int variant, StencilArgs P, bool is_
   if (L->num_boxes <= 0) return 0;
   if (variant == HPGMG_HIP_27PT_CC) return launch27<MODE>(L, P, is_smoother);
   if (variant == HPGMG_HIP_FV4_VC_HELMHOLTZ || variant == HPGMG_HIP_FV4_VC_POISSON) return launch_direct<MODE>(L, variant, P, is_smoother);
+  if (int e = refuse_unfused("fused residual form requested for a variant without tiled kernels")) return e;
   dim3 block; int grid;
   plan(L, P, block, grid);
   if (g_defer_mode) {
@@ -1063,12 +1073,16 @@ static double g_pair_interp_prescale = 1.0;
 static int smooth_pair(const hpgmg_hip_level *L, int variant, int gsrb, int sweep_a, double *const *scr_base, const float *const *c32_base,
                        int x0_scr, int x0_id, int xm1_scr, int xm1_id, int out1_scr, int out1_id, int out2_scr, int out2_id,
                        int rhs_id, double a, double b, double h2inv, double c1a, double c2a, double c1b, double c2b) {
-  HPGMG_SKIP_IF_REPLAY();
+  // the requests set for THIS launch (hpgmg_hip_pair_set_halo / _discard_x1 / _set_interp) are taken here, before any exit: whatever
+  // happens below, none of them can stay pending and change a later launch
   const bool remote = g_pair_halo_set;
-  g_pair_halo_set = false;
+  const int discard_x1 = g_pair_discard_x1;
+  const hpgmg_hip_level *const interp_level = g_pair_interp_level;
+  g_pair_halo_set = false; g_pair_discard_x1 = 0; g_pair_interp_level = nullptr;
+  HPGMG_SKIP_IF_REPLAY();
   const int Di = remote ? g_pair_brick[0] * L->dim : L->dim_i, Dj = remote ? g_pair_brick[1] * L->dim : L->dim_j, Dk = remote ? g_pair_brick[2] * L->dim : L->dim_k;
   if (!pair_supported_dims(L, variant, Di, Dj, Dk)) return record_error(hipErrorInvalidValue, "smooth_cheby_pair: level not supported");
-  if (remote && (L->dim % 128 != 0 || c32_base || g_pair_interp_level)) return record_error(hipErrorInvalidValue, "smooth_cheby_pair: remote faces need whole-row boxes, fp64 coefficients, no folded interpolation");
+  if (remote && (L->dim % 128 != 0 || c32_base || interp_level)) return record_error(hipErrorInvalidValue, "smooth_cheby_pair: remote faces need whole-row boxes, fp64 coefficients, no folded interpolation");
   static const int tune_kc = env_int("HPGMG_TUNE_PAIR_KC", 0);
   constexpr int nw = 16;
   // k chunk: every workgroup costs KC+2 plane steps and (at 128 VGPRs, 16 waves) one workgroup occupies a CU, so the
@@ -1086,11 +1100,10 @@ static int smooth_pair(const hpgmg_hip_level *L, int variant, int gsrb, int swee
   A.x0 = VecRef{x0_scr, x0_id}; A.xm1 = VecRef{xm1_scr, xm1_id}; A.out1 = VecRef{out1_scr, out1_id}; A.out2 = VecRef{out2_scr, out2_id};
   A.rhs_id = rhs_id; A.a = a; A.b = b; A.h2inv = h2inv; A.c1a = c1a; A.c2a = c2a; A.c1b = c1b; A.c2b = c2b;
   A.scr_base = scr_base; A.c32_base = c32_base; A.sweep_a = sweep_a;
-  A.keep_x1 = g_pair_discard_x1 ? 0 : 1; g_pair_discard_x1 = 0;
-  const bool interp = (g_pair_interp_level != nullptr);
+  A.keep_x1 = discard_x1 ? 0 : 1;
+  const bool interp = (interp_level != nullptr);
   if (interp) {
-    const hpgmg_hip_level *C = g_pair_interp_level;
-    g_pair_interp_level = nullptr;
+    const hpgmg_hip_level *C = interp_level;
     if (L->dim % 128 != 0 || C->num_boxes != L->num_boxes || 2 * C->dim != L->dim) return record_error(hipErrorInvalidValue, "smooth pair with interpolation: level pair not supported");
     A.Lc = *C; A.coarse_id = g_pair_interp_id; A.prescale = g_pair_interp_prescale;
   }
@@ -1371,7 +1384,7 @@ int hpgmg_hip_residual_norm(const hpgmg_hip_level *L, int variant, int res_id, i
   if (tiled_variant(variant)) {
     if (!hpgmg_hip_residual_fused_supported(L, variant) || res_id >= 0) return record_error(hipErrorInvalidValue, "residual_norm: level not supported (27-point / fv4: norm only, res_id < 0)");
     const long long cells = (long long)L->num_boxes * L->dim * L->dim * L->dim;
-    double *part = reduction_scratch((int)(cells / 4096 + 1024));
+    double *part = reduction_scratch((int)(cells / 512 + 1024));      // one per workgroup: tiles of 512 cells, k chunks down to one plane (HPGMG_TUNE_*_KCHUNK)
     if (!part) return record_error(hipErrorOutOfMemory, "residual_norm: scratch");
     g_tile_fused = TileFused{}; g_tile_fused.kind = 1; g_tile_fused.partials = part;
     StencilArgs T = {}; T.xn_id = x_id; T.xout_id = rhs_id; T.rhs_id = rhs_id; T.a = a; T.b = b; T.h2inv = h2inv;

@@ -97,6 +97,9 @@ def test_cli_stdout_has_the_reference_layout(ref_build, variant, flags, args):
     ("7pt-cheby", [], "4 125"), ("7pt-cheby", [], "4 343"), ("7pt-gsrb", ["--smoother", "gsrb"], "4 216"),
     ("7pt-cheby-helm", ["--helmholtz"], "5 27"), ("fv4-gsrb", ["--op", "fv4", "--smoother", "gsrb"], "4 125"), ("27pt-cheby", ["--op", "27pt"], "4 125"),
     ("7pt-cheby", [], "4 2"), ("7pt-cheby", [], "4 7"), ("7pt-cheby", [], "5 1"),
+    # 7^3 boxes with the Helmholtz operator and 6^3 with the 27-point one: non-power-of-two decompositions of these two plugins in place of the
+    # costlier `7pt-cheby-helm 4 729` / `27pt-cheby 4 343` (log2_box_dim cannot go below 4)
+    ("7pt-cheby-helm", ["--helmholtz"], "4 343"), ("27pt-cheby", ["--op", "27pt"], "4 216"),
 ])
 def test_our_host_layer_and_oracle_against_the_reference_binary_on_odd_decompositions(ref_build, variant, flags, args):
     """Beyond the committed golden cases: box counts that are not powers of two (3^3 ... 9^3 boxes; requested counts that are
