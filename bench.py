@@ -121,8 +121,33 @@ def main():
     ap.add_argument("--series", choices=["strong", "weak"], default="strong",
                     help="what N > 1 runs (config2): strong = the north_star series, the SAME 256^3 problem cut over N GPUs (`hpgmg-fv 7 8/N`: 8/4/2/1 boxes of "
                          "128^3 per GPU); weak = the reference CLI's own `7 8` with N ranks (256^3, 256^3, 384^3, 512^3 for N = 1, 2, 4, 8; hpgmg-fv.c:184-197)")
+    ap.add_argument("--route-b", action="store_true",
+                    help="measure INTEGRATION.md Route B instead: the REFERENCE's own driver (mg.c, solvers.c, hpgmg-fv.c, level.c -- oracle/_ref/routeb-7pt-cheby-helm, "
+                         "built from /root/reference by oracle/Makefile) running on this repository's operator plugin, config 2, its own 10 + 10 solve protocol")
     ap.add_argument("--watchdog", type=int, default=900, help="seconds after which a rank that has not finished reports where it is stuck and exits 124 (0 = off)")
     args = ap.parse_args()
+
+    if args.route_b:
+        # Nothing of this repository's driver runs here: the reference's FMGSolve calls the plugin through operators.h only, so none of the
+        # optional fused hooks are used.  The reference times its own solves (hpgmg-fv.c:77-99) and prints DOF/s.
+        binary = os.path.join(ROOT, "oracle", "_ref", "routeb-7pt-cheby-helm")
+        if not os.path.exists(binary):
+            raise SystemExit("bench.py --route-b: oracle/_ref/routeb-7pt-cheby-helm is not built (make -C oracle ref, needs /root/reference)")
+        env = dict(os.environ, OMP_NUM_THREADS=str(min(host_cores(), 8)))
+        out = subprocess.run([binary, str(LOG2_BOX_DIM), str(BOXES_PER_RANK)], capture_output=True, text=True, env=env, timeout=900)
+        m = re.search(r"h=\S+\s+DOF=(\S+)\s+time=(\S+)\s+DOF/s=(\S+)", out.stdout)
+        norm = re.search(r"f-cycle\s+norm=(\S+)", out.stdout)
+        if out.returncode or not m:
+            sys.stderr.write(out.stdout[-2000:] + out.stderr[-2000:])
+            raise SystemExit("bench.py --route-b: the reference driver did not finish")
+        print(json.dumps({"metric": "DOF/s (fine-grid) for FMG F-cycle", "value": float(m.group(3)), "unit": "DOF/s", "n_gpus": 1, "steps": 10, "warmup": 10,
+                          "ms_per_step": float(m.group(2)) * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                          "config": {"workload": f"hpgmg-fv {LOG2_BOX_DIM} {BOXES_PER_RANK}: 256^3 fp64 7-pt variable-coefficient Helmholtz, Chebyshev smoother -- Route B: the reference's "
+                                                 "unmodified mg.c / solvers.c / hpgmg-fv.c (level.c with the storage lines patched) on this repository's operator plugin",
+                                     "route": "B", "fine_grid_dof": float(m.group(1)), "fcycle_residual_norm": float(norm.group(1)) if norm else None,
+                                     "protocol": "the reference's own: 10 warm-up + 10 timed FMGSolve, host clock around each (hpgmg-fv.c:77-99)"},
+                          "roofline": None}), flush=True)
+        return
 
     # `python bench.py --gpus N` outside torchrun: start the N ranks ourselves, as a CHILD process (this parent has not touched the
     # GPU and never does), relay the child's JSON line and exit with its code.  Never measure one GPU and call it N.

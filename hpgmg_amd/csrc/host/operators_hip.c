@@ -74,7 +74,15 @@ void hpgmg_tick_end(hpgmg_tick t) {
 void hpgmg_timers_settle(void) { hpgmg_hip_timer_flush(); }
 #define TICK(L, FIELD, WHAT) const hpgmg_tick tick_ = hpgmg_tick_begin((L), &(L)->timers.FIELD, WHAT)
 #define TOCK() hpgmg_tick_end(tick_)
-#define HIP_OK(call) do { int e_ = (call); if (e_) { fprintf(stderr, "hpgmg: %s failed (%d): %s\n", #call, e_, hpgmg_hip_last_error()); abort(); } } while (0)
+/* every device call of this file goes through HIP_OK: the operators still waiting in the lazy queue (end of the file) are issued first, so
+ * whatever runs next sees the state they leave */
+static void lazy_flush(void);
+static void do_smooth(level_type *L, int x_id, int rhs_id, double a, double b);
+static void do_residual(level_type *L, int res_id, int x_id, int rhs_id, double a, double b);
+static void do_restriction(level_type *Lc, int id_c, level_type *Lf, int id_f, int type);
+static void do_interpolation_vcycle(level_type *Lf, int id_f, double prescale, level_type *Lc, int id_c);
+static void do_zero_vector(level_type *L, int id);
+#define HIP_OK(call) do { lazy_flush(); int e_ = (call); if (e_) { fprintf(stderr, "hpgmg: %s failed (%d): %s\n", #call, e_, hpgmg_hip_last_error()); abort(); } } while (0)
 
 /* ---------------------------------------------------------------- storage hooks */
 const char *hpgmg_backend_name(void) { return "hip"; }
@@ -592,8 +600,8 @@ void rebuild_operator_blackbox(level_type *L, double a, double b, int colors) {
   const int x_id = VECTOR_TEMP, Aii_id = VECTOR_DINV, sum_id = (hpgmg_vectors_reserved() > VECTOR_L1INV) ? VECTOR_L1INV : VECTOR_E;
   const double h2inv = 1.0 / (L->h * L->h);
   int ic, jc, kc;
-  zero_vector(L, Aii_id);
-  zero_vector(L, sum_id);
+  do_zero_vector(L, Aii_id);
+  do_zero_vector(L, sum_id);
   for (kc = 0; kc < colors; kc++) for (jc = 0; jc < colors; jc++) for (ic = 0; ic < colors; ic++) {
     color_vector(L, x_id, colors, ic, jc, kc);
     exchange_boundary(L, x_id, stencil_get_shape());
@@ -645,7 +653,9 @@ void hpgmg_level_sync_counters(level_type *L) {
 /* leg 0/1: the legs around a host-driven bottom solve; leg 2: legs + bottom solve; leg 3: bottom solve only (n == 1);
  * leg 4: the whole F-cycle below levels[0] (right-hand side restricted down the chain, bottom solve, interpolation_fcycle + V-cycle per
  * level upwards); leg 5: only answer whether leg 4 would be accepted */
-int hpgmg_vcycle_legs_fused(level_type **levels, int n, int e_id, int R_id, double a, double b, int leg) {
+static int vcycle_legs_fused(level_type **levels, int n, int e_id, int R_id, double a, double b, int leg);
+int hpgmg_vcycle_legs_fused(level_type **levels, int n, int e_id, int R_id, double a, double b, int leg) { lazy_flush(); return vcycle_legs_fused(levels, n, e_id, R_id, a, b, leg); }
+static int vcycle_legs_fused(level_type **levels, int n, int e_id, int R_id, double a, double b, int leg) {
   static int enabled = -1, bottom_enabled = -1;
   hpgmg_config cfg;
   const hpgmg_hip_level *dev[8];
@@ -1073,7 +1083,10 @@ static int smooth_gsrb_pairs(level_type *L, int x_id, int rhs_id, double a, doub
  * piecewise-constant interpolation folded into the first sweep pair: the interpolated e is never written or re-read.
  * Same iterate (e = x4) as the two separate operators; VECTOR_TEMP (their x3) is left unspecified -- nothing in a cycle reads it
  * (HPGMG_TEMP_SCRATCH=0 stores it as smooth() does).  0 = not applicable. */
-int hpgmg_interp_smooth_fused(level_type *Lf, int e_id, int R_id, level_type *Lc, double a, double b) {
+static int interp_smooth_fused(level_type *Lf, int e_id, int R_id, level_type *Lc, double a, double b, int exact_state);
+int hpgmg_interp_smooth_fused(level_type *Lf, int e_id, int R_id, level_type *Lc, double a, double b) { lazy_flush(); return interp_smooth_fused(Lf, e_id, R_id, Lc, a, b, 0); }
+/* exact_state: VECTOR_TEMP is left as smooth() leaves it (the lazy queue runs behind the reference's own driver, which promises nothing about it) */
+static int interp_smooth_fused(level_type *Lf, int e_id, int R_id, level_type *Lc, double a, double b, int exact_state) {
   hpgmg_config cfg;
   hpgmg_get_config(&cfg);
   const int sweeps = hpgmg_smooth_sweeps();
@@ -1089,7 +1102,7 @@ int hpgmg_interp_smooth_fused(level_type *Lf, int e_id, int R_id, level_type *Lc
   if (cfg.smoother == HPGMG_SMOOTH_CHEBY) {
     double c1[16], c2[16];
     cheby_coefficients(Lf, sweeps, c1, c2);
-    { const char *e = getenv("HPGMG_TEMP_SCRATCH"); temp_is_scratch = !(e && e[0] == '0'); }      /* a cycle-only hook: VECTOR_TEMP is dead afterwards */
+    { const char *e = getenv("HPGMG_TEMP_SCRATCH"); temp_is_scratch = !exact_state && !(e && e[0] == '0'); }      /* the cycle hook: VECTOR_TEMP is dead afterwards */
     const int done = smooth_cheby_pairs(Lf, e_id, R_id, a, b, c1, c2, sweeps);
     temp_is_scratch = 0;
     if (!done) { fprintf(stderr, "hpgmg: fused interpolation+smooth refused after being accepted\n"); abort(); }
@@ -1148,7 +1161,8 @@ int hpgmg_smooth_in_cycle(level_type *L, int x_id, int rhs_id, double a, double 
   static int on = -1;
   if (on < 0) { const char *e = getenv("HPGMG_TEMP_SCRATCH"); on = !(e && e[0] == '0'); }
   temp_is_scratch = on;
-  smooth(L, x_id, rhs_id, a, b);
+  lazy_flush();
+  do_smooth(L, x_id, rhs_id, a, b);
   temp_is_scratch = 0;
   return 1;
 }
@@ -1244,7 +1258,7 @@ static int smooth_fv4_rb(level_type *L, int x_id, int rhs_id, double a, double b
   fv4_rb_smooths++;
   return 1;
 }
-void smooth(level_type *L, int x_id, int rhs_id, double a, double b) {
+static void do_smooth(level_type *L, int x_id, int rhs_id, double a, double b) {
   hpgmg_config cfg;
   hpgmg_get_config(&cfg);
   const int sweeps = hpgmg_smooth_sweeps(), v = variant();
@@ -1296,7 +1310,7 @@ void smooth(level_type *L, int x_id, int rhs_id, double a, double b) {
   }
 }
 
-void residual(level_type *L, int res_id, int x_id, int rhs_id, double a, double b) {   /* residual.c:9-51 */
+static void do_residual(level_type *L, int res_id, int x_id, int rhs_id, double a, double b) {   /* residual.c:9-51 */
   if (small_level_try(L, 3, x_id, rhs_id, res_id, a, b)) return;
   STENCIL_WITH_GHOSTS(L, x_id, res_id, residual, hpgmg_hip_residual(&backend_of(L)->dev, variant(), res_id, x_id, rhs_id, a, b, 1.0 / (L->h * L->h)));
 }
@@ -1306,7 +1320,7 @@ void apply_op(level_type *L, int Ax_id, int x_id, double a, double b) {         
 }
 
 /* ---------------------------------------------------------------- restriction.c:104-212 */
-void restriction(level_type *Lc, int id_c, level_type *Lf, int id_f, int type) {
+static void do_restriction(level_type *Lc, int id_c, level_type *Lf, int id_f, int type) {
   TICK(Lf, restriction_total, "restriction");
   communicator_type *S = &Lf->restriction[type], *R = &Lc->restriction[type];
   backend_t *Bc = backend_of(Lc), *Bf = backend_of(Lf);
@@ -1378,15 +1392,22 @@ static int fused_residual_operand(level_type *L, backend_t *B, int x_id) {
   if (!exchange_and_bcs_one_launch(L, x_id, shape, cfg.op == HPGMG_OP_27PT ? 12 : 4, 0)) apply_BCs(L, x_id, shape);
   return 1;
 }
+static int residual_restrict_zero_fused(level_type *Lc, int id_c, level_type *Lf, int res_id, int x_id, int rhs_id, double a, double b, int zero_id);
 int hpgmg_residual_restrict_zero_fused(level_type *Lc, int id_c, level_type *Lf, int x_id, int rhs_id, double a, double b, int zero_id) {
+  lazy_flush();
+  return residual_restrict_zero_fused(Lc, id_c, Lf, -1, x_id, rhs_id, a, b, zero_id);
+}
+/* res_id >= 0: the residual is stored as well (7-point): the exact state of the three operators */
+static int residual_restrict_zero_fused(level_type *Lc, int id_c, level_type *Lf, int res_id, int x_id, int rhs_id, double a, double b, int zero_id) {
   communicator_type *S = &Lf->restriction[RESTRICT_CELL], *R = &Lc->restriction[RESTRICT_CELL];
   if (!Lf->active || !Lc->active || Lc->num_my_boxes < 1 || Lf->num_my_boxes < 1 || zero_id == id_c) return 0;
   if (S->num_sends || R->num_recvs || S->num_blocks[0] || R->num_blocks[2] || S->num_blocks[1] < 1) return 0;
   backend_t *Bc = backend_of(Lc), *Bf = backend_of(Lf);
   if (!restrict_map_of(Lf, Bf)) return 0;
+  { hpgmg_config cfg; hpgmg_get_config(&cfg); if (res_id >= 0 && (cfg.op != HPGMG_OP_7PT || res_id == x_id || res_id == rhs_id)) return 0; }
   if (!fused_residual_operand(Lf, Bf, x_id)) return 0;
   TICK(Lf, residual, "residual + restriction + zero_vector (fused)");
-  HIP_OK(hpgmg_hip_residual_restrict(&Bf->dev, variant(), x_id, rhs_id, a, b, 1.0 / (Lf->h * Lf->h), &Bc->dev, id_c, Bf->d_restrict_map, zero_id));
+  HIP_OK(hpgmg_hip_residual_restrict_store(&Bf->dev, variant(), res_id, x_id, rhs_id, a, b, 1.0 / (Lf->h * Lf->h), &Bc->dev, id_c, Bf->d_restrict_map, zero_id));
   TOCK();
   return 1;
 }
@@ -1435,7 +1456,7 @@ static void interpolation_lists(level_type *Lf, int id_f, double prescale, level
   HIP_OK(hpgmg_hip_increment_blocks(&Bf->dev, id_f, prescale, mirror(Lf, R->blocks[2], R->num_blocks[2]), R->num_blocks[2]));
   TOCK();
 }
-void interpolation_vcycle(level_type *Lf, int id_f, double prescale, level_type *Lc, int id_c) {
+static void do_interpolation_vcycle(level_type *Lf, int id_f, double prescale, level_type *Lc, int id_c) {
   hpgmg_config c; hpgmg_get_config(&c);
   if (c.op == HPGMG_OP_27PT) {                                  /* interpolation_p2.c:228-230 */
     if (!exchange_and_bcs_one_launch(Lc, id_c, STENCIL_SHAPE_BOX, 12, 1)) { exchange_boundary(Lc, id_c, STENCIL_SHAPE_BOX); apply_BCs_p2(Lc, id_c, STENCIL_SHAPE_BOX); }
@@ -1452,7 +1473,7 @@ void interpolation_vcycle(level_type *Lf, int id_f, double prescale, level_type 
 }
 void interpolation_fcycle(level_type *Lf, int id_f, double prescale, level_type *Lc, int id_c) {
   hpgmg_config c; hpgmg_get_config(&c);
-  if (c.op == HPGMG_OP_27PT || c.op == HPGMG_OP_FV2) { interpolation_vcycle(Lf, id_f, prescale, Lc, id_c); return; } /* operators.27pt.c:150-151, .fv2.c:151-152 */
+  if (c.op == HPGMG_OP_27PT || c.op == HPGMG_OP_FV2) { do_interpolation_vcycle(Lf, id_f, prescale, Lc, id_c); return; } /* operators.27pt.c:150-151, .fv2.c:151-152 */
   if (c.op == HPGMG_OP_FV4) {                                   /* interpolation_v4.c:276-278 */
     if (!exchange_and_bcs_one_launch(Lc, id_c, STENCIL_SHAPE_BOX, 4, 1)) { exchange_boundary(Lc, id_c, STENCIL_SHAPE_BOX); apply_BCs_v4(Lc, id_c, STENCIL_SHAPE_BOX); }
     interpolation_lists(Lf, id_f, prescale, Lc, id_c, 4, 0x7);
@@ -1466,7 +1487,7 @@ void interpolation_fcycle(level_type *Lf, int id_f, double prescale, level_type 
 
 /* ---------------------------------------------------------------- misc.c */
 #define BLAS1(call) do { TICK(L, blas1, "BLAS1"); HIP_OK(call); TOCK(); } while (0)
-void zero_vector(level_type *L, int id) { BLAS1(hpgmg_hip_fill(&backend_of(L)->dev, id, 0.0)); }
+static void do_zero_vector(level_type *L, int id) { BLAS1(hpgmg_hip_fill(&backend_of(L)->dev, id, 0.0)); }
 void init_vector(level_type *L, int id, double s) { BLAS1(hpgmg_hip_fill(&backend_of(L)->dev, id, s)); }
 void add_vectors(level_type *L, int c, double sa, int a, double sb, int b) { BLAS1(hpgmg_hip_axpby(&backend_of(L)->dev, c, sa, a, sb, b)); }
 void mul_vectors(level_type *L, int c, double s, int a, int b) { BLAS1(hpgmg_hip_mul(&backend_of(L)->dev, c, s, a, b)); }
@@ -1485,13 +1506,14 @@ static double allreduce_scalar(level_type *L, double v, int op) {
   return v;
 }
 double dot(level_type *L, int a, int b) { double v; BLAS1(hpgmg_hip_dot(&backend_of(L)->dev, a, b, &v)); return allreduce_scalar(L, v, HPGMG_REDUCE_SUM); }
-double norm(level_type *L, int a) { double v; BLAS1(hpgmg_hip_norm_max(&backend_of(L)->dev, a, &v)); return allreduce_scalar(L, v, HPGMG_REDUCE_MAX); }
+static double do_norm(level_type *L, int a) {
+  double v; BLAS1(hpgmg_hip_norm_max(&backend_of(L)->dev, a, &v)); return allreduce_scalar(L, v, HPGMG_REDUCE_MAX); }
 double mean(level_type *L, int a) {
   double v; BLAS1(hpgmg_hip_sum(&backend_of(L)->dev, a, &v));
   v = allreduce_scalar(L, v, HPGMG_REDUCE_SUM);
   return v / (double)((double)L->dim.i * (double)L->dim.j * (double)L->dim.k);
 }
-double error(level_type *L, int a, int b) { add_vectors(L, VECTOR_TEMP, 1.0, a, -1.0, b); return norm(L, VECTOR_TEMP); }
+double error(level_type *L, int a, int b) { add_vectors(L, VECTOR_TEMP, 1.0, a, -1.0, b); return do_norm(L, VECTOR_TEMP); }
 
 /* ---------------------------------------------------------------- problem.p6.c:79-135
  * Analytic coefficients and right-hand side are evaluated on the host with the
@@ -1618,10 +1640,10 @@ void rebuild_operator(level_type *L, level_type *from, double a, double b) {
   hpgmg_get_config(&cfg);
   if (cfg.op != HPGMG_OP_7PT) {                                 /* operators.27pt.c:96-121, .fv2.c:98-124, .fv4.c:145-172 */
     if (from) {
-      if (cfg.helmholtz) restriction(L, VECTOR_ALPHA, from, VECTOR_ALPHA, RESTRICT_CELL);
-      restriction(L, VECTOR_BETA_I, from, VECTOR_BETA_I, RESTRICT_FACE_I);
-      restriction(L, VECTOR_BETA_J, from, VECTOR_BETA_J, RESTRICT_FACE_J);
-      restriction(L, VECTOR_BETA_K, from, VECTOR_BETA_K, RESTRICT_FACE_K);
+      if (cfg.helmholtz) do_restriction(L, VECTOR_ALPHA, from, VECTOR_ALPHA, RESTRICT_CELL);
+      do_restriction(L, VECTOR_BETA_I, from, VECTOR_BETA_I, RESTRICT_FACE_I);
+      do_restriction(L, VECTOR_BETA_J, from, VECTOR_BETA_J, RESTRICT_FACE_J);
+      do_restriction(L, VECTOR_BETA_K, from, VECTOR_BETA_K, RESTRICT_FACE_K);
     }
     if (cfg.op == HPGMG_OP_FV4) extrapolate_betas(L);           /* mixed-derivative terms read beta in the ghost zone */
     if (cfg.helmholtz) exchange_boundary(L, VECTOR_ALPHA, STENCIL_SHAPE_BOX);
@@ -1635,10 +1657,10 @@ void rebuild_operator(level_type *L, level_type *from, double a, double b) {
   if (cfg.op != HPGMG_OP_7PT) no_kernel("rebuild_operator for this operator");
   if (L->my_rank == 0 && hpgmg_verbose) { fprintf(stdout, "  rebuilding operator for level...  h=%e  ", L->h); fflush(stdout); }
   if (from) {
-    if (cfg.helmholtz) restriction(L, VECTOR_ALPHA, from, VECTOR_ALPHA, RESTRICT_CELL);
-    restriction(L, VECTOR_BETA_I, from, VECTOR_BETA_I, RESTRICT_FACE_I);
-    restriction(L, VECTOR_BETA_J, from, VECTOR_BETA_J, RESTRICT_FACE_J);
-    restriction(L, VECTOR_BETA_K, from, VECTOR_BETA_K, RESTRICT_FACE_K);
+    if (cfg.helmholtz) do_restriction(L, VECTOR_ALPHA, from, VECTOR_ALPHA, RESTRICT_CELL);
+    do_restriction(L, VECTOR_BETA_I, from, VECTOR_BETA_I, RESTRICT_FACE_I);
+    do_restriction(L, VECTOR_BETA_J, from, VECTOR_BETA_J, RESTRICT_FACE_J);
+    do_restriction(L, VECTOR_BETA_K, from, VECTOR_BETA_K, RESTRICT_FACE_K);
   }
   if (cfg.helmholtz) exchange_boundary(L, VECTOR_ALPHA, STENCIL_SHAPE_BOX);
   exchange_boundary(L, VECTOR_BETA_I, STENCIL_SHAPE_BOX);
@@ -1655,4 +1677,160 @@ void rebuild_operator(level_type *L, level_type *from, double a, double b) {
   L->dominant_eigenvalue_of_DinvA = lambda;
   exchange_boundary(L, VECTOR_DINV, STENCIL_SHAPE_BOX);
   if (cfg.helmholtz) exchange_boundary(L, VECTOR_L1INV, STENCIL_SHAPE_BOX);
+}
+
+
+/* ---------------------------------------------------------------- lazy void operators
+ * The reference's own driver (INTEGRATION.md Route B) knows nothing of the fused hooks above: MGVCycle (mg.c:1145-1164) calls
+ *     smooth, residual(TEMP), restriction(from TEMP), zero_vector          on the way down, level after level,
+ *     interpolation_vcycle, smooth                                          on the way up,
+ * and these calls return nothing.  So the plugin may postpone them: a call that continues one of the two patterns is only recorded; the
+ * first call that does not (any other operator, anything that returns a value, a copy to the host -- every device call of this file
+ * passes through HIP_OK, which drains the queue first) makes the recorded operators run, as the fused forms where those apply:
+ *   - a run of whole down-leg / up-leg units over small levels: the single-launch V-cycle legs (kernels/tail.hip);
+ *   - residual + restriction + zero_vector of a large level: one pass (the residual is stored too: exactly the three operators' state);
+ *   - interpolation_vcycle + smooth of a large level: the interpolation folded into the first sweep pair;
+ *   - residual(res) followed by norm(res): one pass (norm() asks the queue).
+ * Every fused form used here leaves exactly the vectors the separate operators leave (VECTOR_TEMP included).  HPGMG_LAZY=0 turns the queue off. */
+enum { LZ_SMOOTH = 1, LZ_RESIDUAL, LZ_RESTRICT, LZ_ZERO, LZ_INTERP };
+enum { LZ_NONE = 0, LZ_DOWN, LZ_UP, LZ_RN };      /* RN: a lone residual() waiting to see whether norm() of its result follows (mg.c:1321-1323) */
+typedef struct { int op; level_type *L, *L2; int i0, i1, i2; double a, b; } lazy_op;
+#define LZ_MAX 80
+static lazy_op lz[LZ_MAX];
+static int lz_n = 0, lz_mode = LZ_NONE, lz_busy = 0, lazy_on = -1;
+static long long lazy_fused_legs = 0, lazy_fused_units = 0;
+long long hpgmg_lazy_fused_legs(void) { return lazy_fused_legs; }      /* single-launch legs / fused large-level units issued by the queue so far (tests) */
+long long hpgmg_lazy_fused_units(void) { return lazy_fused_units; }
+void hpgmg_set_lazy(int on) { lazy_flush(); lazy_on = on ? 1 : 0; }
+/* HPGMG_LAZY_REPORT=1: what the queue did, on stderr when the process ends (tests/test_gpu_route_b.py reads it) */
+__attribute__((destructor)) static void lazy_report(void) {
+  const char *e = getenv("HPGMG_LAZY_REPORT");
+  if (e && e[0] == '1') fprintf(stderr, "hpgmg lazy queue: %lld single-launch legs, %lld fused large-level units\n", lazy_fused_legs, lazy_fused_units);
+}
+static int lazy_enabled(void) {
+  if (lazy_on < 0) { const char *e = getenv("HPGMG_LAZY"); lazy_on = !(e && e[0] == '0'); }
+  return lazy_on && !lz_busy;
+}
+static void lazy_run_one(const lazy_op *o) {
+  switch (o->op) {
+    case LZ_SMOOTH:   do_smooth(o->L, o->i0, o->i1, o->a, o->b); break;
+    case LZ_RESIDUAL: do_residual(o->L, o->i0, o->i1, o->i2, o->a, o->b); break;
+    case LZ_RESTRICT: do_restriction(o->L, o->i0, o->L2, o->i1, o->i2); break;
+    case LZ_ZERO:     do_zero_vector(o->L, o->i0); break;
+    case LZ_INTERP:   do_interpolation_vcycle(o->L, o->i0, o->a, o->L2, o->i1); break;
+  }
+}
+static void lazy_flush(void) {
+  if (lz_busy || lz_n == 0) return;
+  lz_busy = 1;                                            /* the operators below issue device calls themselves */
+  const int n = lz_n, mode = lz_mode;
+  int q = 0;
+  if (mode == LZ_DOWN) {
+    const int units = n / 4;
+    int u = 0;
+    while (u < units) {
+      /* levels lz[4u].L, lz[4(u+1)].L, ... and the coarse level of the last whole unit: one launch when they are small enough */
+      level_type *chain[LZ_MAX / 4 + 2];
+      int m = 0, w;
+      for (w = u; w < units; w++) chain[m++] = lz[4 * w].L;
+      chain[m++] = lz[4 * (units - 1) + 2].L;
+      const lazy_op *s0 = &lz[4 * u];
+      if (m >= 2 && vcycle_legs_fused(chain, m, s0->i0, s0->i1, s0->a, s0->b, 0)) { lazy_fused_legs++; u = units; break; }
+      /* this unit on its own: smooth, then residual + restriction + zero_vector in one pass where the level allows it */
+      lazy_run_one(&lz[4 * u]);
+      const lazy_op *r = &lz[4 * u + 1], *t = &lz[4 * u + 2], *z = &lz[4 * u + 3];
+      if (residual_restrict_zero_fused(t->L, t->i0, r->L, r->i0, r->i1, r->i2, r->a, r->b, z->i0)) lazy_fused_units++;
+      else { lazy_run_one(r); lazy_run_one(t); lazy_run_one(z); }
+      u++;
+    }
+    q = 4 * units;
+  } else if (mode == LZ_UP) {
+    const int units = n / 2;
+    /* units run from the coarsest pair upwards: the longest prefix that fits the single-launch leg, then unit by unit */
+    int done = 0, m;
+    for (m = units; m >= 1 && !done; m--) {
+      level_type *chain[LZ_MAX / 2 + 2];
+      int c = 0, w;
+      for (w = m - 1; w >= 0; w--) chain[c++] = lz[2 * w].L;       /* finest first */
+      chain[c++] = lz[0].L2;                                        /* the level the first interpolation reads */
+      const lazy_op *sm = &lz[1];
+      if (vcycle_legs_fused(chain, c, sm->i0, sm->i1, sm->a, sm->b, 1)) { lazy_fused_legs++; done = m; }
+    }
+    int u;
+    for (u = done; u < units; u++) {
+      const lazy_op *ip = &lz[2 * u], *sm = &lz[2 * u + 1];
+      if (interp_smooth_fused(ip->L, sm->i0, sm->i1, ip->L2, sm->a, sm->b, 1)) lazy_fused_units++;
+      else { lazy_run_one(ip); lazy_run_one(sm); }
+    }
+    q = 2 * units;
+  }
+  for (; q < n; q++) lazy_run_one(&lz[q]);                /* a unit the caller did not finish */
+  lz_n = 0; lz_mode = LZ_NONE;
+  lz_busy = 0;
+}
+/* does this call continue the pattern?  1: recorded, the caller returns; 0: the caller flushes and runs it */
+static int lazy_push(int op, level_type *L, level_type *L2, int i0, int i1, int i2, double a, double b) {
+  if (!lazy_enabled() || lz_n == LZ_MAX) return 0;
+  hpgmg_config cfg;
+  hpgmg_get_config(&cfg);
+  if (cfg.op != HPGMG_OP_7PT) return 0;                   /* the fused forms used by the queue are the 7-point plugin's */
+  int ok = 0;
+  if (lz_n == 0) {
+    if (op == LZ_SMOOTH) { ok = 1; lz_mode = LZ_DOWN; }
+    else if (op == LZ_INTERP && a == 1.0 && i0 == i1) { ok = 1; lz_mode = LZ_UP; }
+    else if (op == LZ_RESIDUAL) { ok = 1; lz_mode = LZ_RN; }
+  } else if (lz_mode == LZ_DOWN) {
+    const int pos = lz_n % 4;
+    const lazy_op *s0 = &lz[lz_n - pos];                  /* this unit's smooth (pos > 0) */
+    if (pos == 0) { const lazy_op *z = &lz[lz_n - 1], *f = &lz[0]; ok = (op == LZ_SMOOTH && L == z->L && i0 == f->i0 && i1 == f->i1 && a == f->a && b == f->b); }
+    else if (pos == 1) ok = (op == LZ_RESIDUAL && L == s0->L && i0 == VECTOR_TEMP && i1 == s0->i0 && i2 == s0->i1 && a == s0->a && b == s0->b);
+    else if (pos == 2) ok = (op == LZ_RESTRICT && L2 == s0->L && i0 == s0->i1 && i1 == VECTOR_TEMP && i2 == RESTRICT_CELL && L != s0->L);
+    else ok = (op == LZ_ZERO && L == lz[lz_n - 1].L && i0 == s0->i0);
+  } else if (lz_mode == LZ_UP) {
+    const int pos = lz_n % 2;
+    if (pos == 0) { const lazy_op *p = &lz[lz_n - 2]; ok = (op == LZ_INTERP && a == 1.0 && i0 == i1 && L2 == p->L && i0 == p->i0); }
+    else { const lazy_op *ip = &lz[lz_n - 1]; ok = (op == LZ_SMOOTH && L == ip->L && i0 == ip->i0 && (lz_n == 1 || (i1 == lz[1].i1 && a == lz[1].a && b == lz[1].b))); }
+  }
+  if (!ok) return 0;
+  lazy_op *o = &lz[lz_n++];
+  o->op = op; o->L = L; o->L2 = L2; o->i0 = i0; o->i1 = i1; o->i2 = i2; o->a = a; o->b = b;
+  return 1;
+}
+/* the five operators of include/hpgmg_operators.h (= operators.h) that take part */
+void smooth(level_type *L, int x_id, int rhs_id, double a, double b) {
+  if (lazy_push(LZ_SMOOTH, L, NULL, x_id, rhs_id, 0, a, b)) return;
+  lazy_flush();
+  if (lazy_push(LZ_SMOOTH, L, NULL, x_id, rhs_id, 0, a, b)) return;      /* it may start the next pattern */
+  do_smooth(L, x_id, rhs_id, a, b);
+}
+void residual(level_type *L, int res_id, int x_id, int rhs_id, double a, double b) {
+  if (lazy_push(LZ_RESIDUAL, L, NULL, res_id, x_id, rhs_id, a, b)) return;
+  lazy_flush();
+  do_residual(L, res_id, x_id, rhs_id, a, b);
+}
+void restriction(level_type *Lc, int id_c, level_type *Lf, int id_f, int type) {
+  if (lazy_push(LZ_RESTRICT, Lc, Lf, id_c, id_f, type, 0.0, 0.0)) return;
+  lazy_flush();
+  do_restriction(Lc, id_c, Lf, id_f, type);
+}
+void zero_vector(level_type *L, int id) {
+  if (lazy_push(LZ_ZERO, L, NULL, id, 0, 0, 0.0, 0.0)) return;
+  lazy_flush();
+  do_zero_vector(L, id);
+}
+void interpolation_vcycle(level_type *Lf, int id_f, double prescale, level_type *Lc, int id_c) {
+  if (lazy_push(LZ_INTERP, Lf, Lc, id_f, id_c, 0, prescale, 0.0)) return;
+  lazy_flush();
+  if (lazy_push(LZ_INTERP, Lf, Lc, id_f, id_c, 0, prescale, 0.0)) return;
+  do_interpolation_vcycle(Lf, id_f, prescale, Lc, id_c);
+}
+double norm(level_type *L, int a) {
+  if (lz_mode == LZ_RN && lz_n == 1 && !lz_busy && lz[0].L == L && lz[0].i0 == a) {       /* residual(a, ...) then norm(a): one pass, the residual stored as usual */
+    const lazy_op o = lz[0];
+    double v = 0.0;
+    lz_n = 0; lz_mode = LZ_NONE;
+    if (hpgmg_residual_norm_fused(L, o.i0, o.i1, o.i2, o.a, o.b, &v)) { lazy_fused_units++; return v; }
+    do_residual(L, o.i0, o.i1, o.i2, o.a, o.b);
+  }
+  return do_norm(L, a);
 }

@@ -46,6 +46,7 @@ struct FusedArgs {
   int zero_chunks_per_box, compute_blocks;
   double *partials;             // MODE_RESIDUAL_NORM: one max per workgroup
   int no_store;                 // MODE_RESIDUAL_NORM: the residual itself is not wanted, only its norm
+  int store_res;                // MODE_RESIDUAL_RESTRICT: ALSO store the residual (to xout_id): the exact state of residual() + restriction()
 };
 
 struct StencilArgs {
@@ -212,7 +213,7 @@ __global__ __launch_bounds__(64 * WJ) void stencil7_wide_kernel(const hpgmg_hip_
   constexpr bool kRestrict = (MODE == MODE_RESIDUAL_RESTRICT), kNorm = (MODE == MODE_RESIDUAL_NORM);
 
   typename src_ptr<MODE == MODE_GSRB>::type x = vec_origin(L, box, P.xn_id);
-  double *out = (kRestrict || (kNorm && F.no_store)) ? nullptr : vec_origin(L, box, P.xout_id);
+  double *out = ((kRestrict && !F.store_res) || (kNorm && F.no_store)) ? nullptr : vec_origin(L, box, P.xout_id);
   const double *__restrict__ rhs = (MODE == MODE_APPLY) ? nullptr : vec_origin(L, box, P.rhs_id);
   const double *__restrict__ dinv = kSmooth ? vec_origin(L, box, VECTOR_DINV) : nullptr;
   const double *__restrict__ alpha = kHelm ? vec_origin(L, box, VECTOR_ALPHA) : nullptr;
@@ -329,7 +330,7 @@ __global__ __launch_bounds__(64 * WJ) void stencil7_wide_kernel(const hpgmg_hip_
           }                                                                                                                 \
         }                                                                                                                   \
         RES = o;                                                                                                            \
-        if (kRestrict || (kNorm && F.no_store)) { }                                                                         \
+        if ((kRestrict && !F.store_res) || (kNorm && F.no_store)) { }                                                       \
         else if (dm == 0) st2(out + IDX, o);                                                                                \
         else { if (!(dm & 1)) out[IDX] = o.x; if (!(dm & 2)) out[IDX + 1] = o.y; }                                          \
       }                                                                                                                     \
@@ -1361,19 +1362,27 @@ int hpgmg_hip_residual_fused_supported(const hpgmg_hip_level *L, int variant) {
 }
 // residual (never stored) -> restriction into vector coarse_id of Lc, plus zero_vector(Lc, zero_id) when zero_id >= 0: the end of
 // MGVCycle's down leg (mg.c:1150-1153) in one pass over the fine level.  map[4 b .. 4 b + 3] = coarse box and coarse (i, j, k) under fine box b's first cell.
+int hpgmg_hip_residual_restrict_store(const hpgmg_hip_level *L, int variant, int res_id, int x_id, int rhs_id, double a, double b, double h2inv,
+                                      const hpgmg_hip_level *Lc, int coarse_id, const int *map, int zero_id);
 int hpgmg_hip_residual_restrict(const hpgmg_hip_level *L, int variant, int x_id, int rhs_id, double a, double b, double h2inv,
                                 const hpgmg_hip_level *Lc, int coarse_id, const int *map, int zero_id) {
+  return hpgmg_hip_residual_restrict_store(L, variant, -1, x_id, rhs_id, a, b, h2inv, Lc, coarse_id, map, zero_id);
+}
+// res_id >= 0 (7-point only): the residual is stored as residual() would store it as well
+int hpgmg_hip_residual_restrict_store(const hpgmg_hip_level *L, int variant, int res_id, int x_id, int rhs_id, double a, double b, double h2inv,
+                                      const hpgmg_hip_level *Lc, int coarse_id, const int *map, int zero_id) {
   HPGMG_SKIP_IF_REPLAY();
   if (tiled_variant(variant)) {
-    if (!hpgmg_hip_residual_fused_supported(L, variant) || Lc->num_boxes <= 0) return record_error(hipErrorInvalidValue, "residual_restrict: level not supported");
+    if (!hpgmg_hip_residual_fused_supported(L, variant) || Lc->num_boxes <= 0 || res_id >= 0) return record_error(hipErrorInvalidValue, "residual_restrict: level not supported");
     g_tile_fused = TileFused{}; g_tile_fused.kind = 2; g_tile_fused.Lc = *Lc; g_tile_fused.coarse_id = coarse_id; g_tile_fused.map = map;
     StencilArgs T = {}; T.xn_id = x_id; T.xout_id = rhs_id; T.rhs_id = rhs_id; T.a = a; T.b = b; T.h2inv = h2inv;    // xout only has to differ from xn: nothing is stored
     if (int e = launch<MODE_RESIDUAL>(L, variant, T, false)) return e;
     return zero_id >= 0 ? hpgmg_hip_fill(Lc, zero_id, 0.0) : 0;
   }
   if (!wide_fused_ok(L, variant) || Lc->num_boxes <= 0) return record_error(hipErrorInvalidValue, "residual_restrict: level not supported");
-  StencilArgs P = {}; P.xn_id = x_id; P.xout_id = x_id; P.rhs_id = rhs_id; P.a = a; P.b = b; P.h2inv = h2inv;
-  FusedArgs F = {}; F.Lc = *Lc; F.coarse_id = coarse_id; F.zero_id = zero_id; F.map = map;
+  if (res_id == x_id || res_id == rhs_id) return record_error(hipErrorInvalidValue, "residual_restrict: the residual may not overwrite its inputs");
+  StencilArgs P = {}; P.xn_id = x_id; P.xout_id = (res_id >= 0) ? res_id : x_id; P.rhs_id = rhs_id; P.a = a; P.b = b; P.h2inv = h2inv;
+  FusedArgs F = {}; F.Lc = *Lc; F.coarse_id = coarse_id; F.zero_id = zero_id; F.map = map; F.store_res = (res_id >= 0);
   F.zero_chunks_per_box = (Lc->volume + 4095) / 4096;
   return launch_wide_fused<MODE_RESIDUAL_RESTRICT>(L, variant, P, F, zero_id >= 0 ? F.zero_chunks_per_box * Lc->num_boxes : 0);
 }

@@ -114,6 +114,9 @@ int hpgmg_hip_residual(const hpgmg_hip_level *L, int variant, int res_id, int x_
 int hpgmg_hip_residual_fused_supported(const hpgmg_hip_level *L, int variant);
 int hpgmg_hip_residual_restrict(const hpgmg_hip_level *L, int variant, int x_id, int rhs_id, double a, double b, double h2inv,
                                 const hpgmg_hip_level *Lc, int coarse_id, const int *map, int zero_id);
+/* the same, and the residual is ALSO stored to vector res_id (>= 0; 7-point kernels): exactly the state residual() + restriction() + zero_vector() leave */
+int hpgmg_hip_residual_restrict_store(const hpgmg_hip_level *L, int variant, int res_id, int x_id, int rhs_id, double a, double b, double h2inv,
+                                      const hpgmg_hip_level *Lc, int coarse_id, const int *map, int zero_id);
 int hpgmg_hip_residual_norm(const hpgmg_hip_level *L, int variant, int res_id, int x_id, int rhs_id, double a, double b, double h2inv, double *norm_out);
 /* Small levels (<= hpgmg_hip_small_level_max_cells() cells, every exchange copy local) of the 27-point / fv2 / fv4 plugins: a whole
  * smooth() -- per sweep exchange_boundary (local copy list), apply_BCs (list + kind: 1 p1, 2 p2, 3 v2, 4 v4; zero_first = clear the

@@ -31,9 +31,12 @@ def test_reference_driver_runs_on_the_hip_plugin(variant, args):
     if not os.path.exists(binary):
         pytest.skip("oracle/_ref/routeb-* not built (needs /root/reference: make -C oracle ref)")
     gold = GOLD[f"{variant} {args}"]
-    env = dict(os.environ, OMP_NUM_THREADS="4")
+    env = dict(os.environ, OMP_NUM_THREADS="4", HPGMG_LAZY_REPORT="1")
     out = subprocess.run([binary] + args.split(), capture_output=True, text=True, env=env, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
+    # the reference's MGVCycle knows none of the fused hooks: the plugin's lazy queue must have recognised its legs and run them fused
+    m = re.search(r"hpgmg lazy queue: (\d+) single-launch legs, (\d+) fused large-level units", out.stderr)
+    assert m and int(m.group(1)) > 0 and (int(m.group(2)) > 0 or args != "7 8"), out.stderr[-500:]      # large-level units only exist at 256^3
     lines = pinned(out.stdout)
     norms = []
     for l in lines:
