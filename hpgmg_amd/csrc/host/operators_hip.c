@@ -1702,6 +1702,7 @@ static long long lazy_fused_legs = 0, lazy_fused_units = 0;
 long long hpgmg_lazy_fused_legs(void) { return lazy_fused_legs; }      /* single-launch legs / fused large-level units issued by the queue so far (tests) */
 long long hpgmg_lazy_fused_units(void) { return lazy_fused_units; }
 void hpgmg_set_lazy(int on) { lazy_flush(); lazy_on = on ? 1 : 0; }
+void hpgmg_operators_flush(void) { lazy_flush(); }      /* issue every postponed operator now (nothing is ever left behind: any other call does the same) */
 /* HPGMG_LAZY_REPORT=1: what the queue did, on stderr when the process ends (tests/test_gpu_route_b.py reads it) */
 __attribute__((destructor)) static void lazy_report(void) {
   const char *e = getenv("HPGMG_LAZY_REPORT");

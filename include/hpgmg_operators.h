@@ -149,6 +149,13 @@ int     hpgmg_norm_scale_restrict_fused(level_type *level, int F_id, int R_id, l
 /* smooth() for callers to whom VECTOR_TEMP is scratch afterwards (MGVCycle: the operator that follows a smooth() overwrites or ignores
  * it): same iterate in phi_id, VECTOR_TEMP unspecified.  Returns 1 when executed, 0 when the caller must call smooth(). */
 int     hpgmg_smooth_in_cycle(level_type *level, int phi_id, int rhs_id, double a, double b);
+/* The operators that return nothing may be postponed by a plugin: the HIP plugin records smooth / residual / restriction / zero_vector /
+ * interpolation_vcycle while they follow the order MGVCycle issues them in (mg.c:1145-1164) and runs them, fused where it can, at the first
+ * call that does not -- so the reference's unmodified driver gets the fused forms too (INTEGRATION.md Route B).  The state every later call
+ * sees is exactly the one the separate operators leave.  hpgmg_operators_flush() issues what is pending (tests that count launches use it),
+ * hpgmg_set_lazy(0) / HPGMG_LAZY=0 turns the queue off.  The CPU oracle implements both as no-ops. */
+void    hpgmg_operators_flush(void);
+void    hpgmg_set_lazy(int on);
 /* bring level->Krylov_iterations up to date with bottom solves the plugin ran asynchronously */
 void    hpgmg_level_sync_counters(level_type *level);
 /* called by destroy_level / MGDestroy so the plugin can drop device mirrors */
