@@ -10,9 +10,12 @@
 //                                              ->  hpgmg_hip_rccl_allreduce over the listed ranks
 // Message sizes are small (a 128^2 face = 128 KiB, 4 faces per neighbour), every neighbour
 // pair has its own xGMI link, so one grouped call per exchange is the right granularity.
-// The scalar reductions involve only the ranks active on that level (the reference's
-// per-level MPI_Comm_split); they are done as an all-to-all of 8-byte messages reduced on
-// the host in rank order, which is deterministic and identical on every rank.
+// The scalar reductions involve only the ranks active on that level (the reference's per-level
+// MPI_Comm_split).  A MAX over every rank of the job -- norm() on a level all ranks share, the
+// only reduction of a Dirichlet solve that crosses ranks once the coarse levels are gathered --
+// is one ncclAllReduce (a maximum is exact in any order).  Sums, and reductions over a subset of
+// the ranks, are an all-to-all of 8-byte messages reduced on the host in rank order: the result
+// is then the same association on every rank and from run to run, which the golden numbers need.
 #include <stdio.h>
 #include <string.h>
 #include <rccl/rccl.h>
@@ -70,12 +73,25 @@ void hpgmg_hip_rccl_sendrecv(void *ctx, int nrecv, double *const *rbuf, const in
   if (r != ncclSuccess) { nccl_fail(r, "grouped ncclSend/ncclRecv"); abort(); }
 }
 
+// MAX of n (<= job size) host doubles over EVERY rank of the communicator, in place: misc.c:324 MPI_Allreduce(MPI_MAX) on a level all ranks share
+int hpgmg_hip_rccl_allreduce_max_world(double *vals, int n) {
+  if (!g_comm || n > g_size || n < 1) return record_error(hipErrorInvalidValue, "rccl_allreduce_max_world");
+  memcpy(g_red_host, vals, (size_t)n * sizeof(double));
+  HPGMG_CHECK(hipMemcpyAsync(g_red_dev, g_red_host, (size_t)n * sizeof(double), hipMemcpyHostToDevice, g_stream));
+  NCCL_OK(ncclAllReduce(g_red_dev, g_red_dev, (size_t)n, ncclDouble, ncclMax, g_comm, g_stream));
+  HPGMG_CHECK(hipMemcpyAsync(g_red_host, g_red_dev, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, g_stream));
+  HPGMG_CHECK(hipStreamSynchronize(g_stream));             // the caller needs the value on the host, as after MPI_Allreduce
+  memcpy(vals, g_red_host, (size_t)n * sizeof(double));
+  return 0;
+}
+
 // signature = hpgmg_transport.allreduce: n host doubles, in place, over `ranks` (sorted, contains me)
 void hpgmg_hip_rccl_allreduce(void *ctx, double *vals, int n, int op, const int *ranks, int nranks) {
   (void)ctx;
   hpgmg_hip_graph_flush();
   if (nranks <= 1) return;
   if (!g_comm) { fprintf(stderr, "hpgmg_hip: RCCL transport used before hpgmg_hip_rccl_init\n"); abort(); }
+  if (op == 0 && nranks == g_size && n <= g_size) { if (hpgmg_hip_rccl_allreduce_max_world(vals, n)) abort(); return; }
   for (int v = 0; v < n; v++) {   // n is 1 everywhere on the path; keep the general form simple
     g_red_host[g_rank] = vals[v];
     hipMemcpyAsync(g_red_dev + g_rank, g_red_host + g_rank, sizeof(double), hipMemcpyHostToDevice, g_stream);

@@ -333,6 +333,9 @@ void hpgmg_hip_rccl_finalize(void);
 void hpgmg_hip_rccl_sendrecv(void *ctx, int nrecv, double *const *rbuf, const int *rsize, const int *rrank,
                              int nsend, double *const *sbuf, const int *ssize, const int *srank, int tag);
 void hpgmg_hip_rccl_allreduce(void *ctx, double *vals, int n, int op, const int *ranks, int nranks);
+/* MAX of n (<= job size) host doubles over every rank of the communicator, in place (one ncclAllReduce; what the transport's allreduce uses for a
+ * whole-job maximum, misc.c:324) */
+int  hpgmg_hip_rccl_allreduce_max_world(double *vals, int n);
 
 #ifdef __cplusplus
 }

@@ -40,6 +40,8 @@ def test_rccl_sendrecv_to_self_and_trivial_allreduce():
         assert np.array_equal(got, src)
         val = (ctypes.c_double * 1)(3.25)
         K.hpgmg_hip_rccl_allreduce(None, val, 1, 0, (c_int * 1)(0), 1)                   # one active rank: identity
+        K.hpgmg_hip_rccl_allreduce_max_world.argtypes = [P(ctypes.c_double), c_int]
+        assert K.hpgmg_hip_rccl_allreduce_max_world(val, 1) == 0                      # the ncclAllReduce(max) the transport issues on levels every rank shares
         assert val[0] == 3.25
         K.hpgmg_hip_free(vp(d_s)); K.hpgmg_hip_free(vp(d_r))
     finally:
