@@ -51,6 +51,8 @@ __device__ __forceinline__ double *vec_origin(const hpgmg_hip_level &L, int box,
 }
 
 
+__device__ __forceinline__ gptr gvec_origin(const hpgmg_hip_level &L, int box, int id) { return as_global(vec_origin(L, box, id)); }   // the same, typed as device memory
+
 // Ghost-free reading on levels whose boxes are all local (L.box_nbr codes >= 0 or -1): a cell up to `ghosts` cells outside box
 // `box` is read where it LIVES -- in the interior of the neighbouring box -- instead of from this box's ghost zone, so no
 // exchange_boundary copy is needed before a stencil launch.  Only directions that leave the DOMAIN stay in a ghost zone: that of the
@@ -69,7 +71,7 @@ __device__ __forceinline__ double gf_load_outside(const hpgmg_hip_level &L, int 
   int box = c.box;
   if (p < 0) { const int n = L.box_nbr[6 * box + 4]; if (n >= 0) { box = n; p += L.dim; } }
   else       { const int n = L.box_nbr[6 * box + 5]; if (n >= 0) { box = n; p -= L.dim; } }
-  return vec_origin(L, box, id)[c.off + p * L.kStride];
+  return gvec_origin(L, box, id)[c.off + p * L.kStride];
 }
 
 
@@ -87,7 +89,7 @@ template <int TI, int TJ>
 struct TileFusedState {
   double lane_max = 0.0, racc = 0.0;
   // called once per plane step AFTER the step's first barrier with the residual of the PREVIOUS plane in sR[(k-1)&1] (k > k0)
-  __device__ __forceinline__ void gather(const TileFused &F, const double *sR, int li, int lj, int kprev, int k0, double *coarse) {
+  __device__ __forceinline__ void gather(const TileFused &F, const double *sR, int li, int lj, int kprev, int k0, gptr coarse) {
     if ((li | lj) & 1) return;
     const double *r = sR + ((kprev & 1) * TJ + lj) * TI + li;
     if (((kprev - k0) & 1) == 0) { racc = r[0] + r[1]; racc = racc + r[TI]; racc = racc + r[TI + 1]; }

@@ -377,6 +377,7 @@ __global__ __launch_bounds__(512) void fv4_rb_kernel(const hpgmg_hip_level L, co
       }
     }
 
+    double r_new = 0.0;                                                             // t at the own pair's red cell of plane q
     if (do_r) {
       const double *X0 = sX + slot4(q) * PX, *Xm = sX + slot4(q - 1) * PX, *Xp = sX + slot4(q + 1) * PX, *Xmm = sX + slot4(q - 2) * PX;
       const double *I0 = sBI + slot3(q) * PB, *Im = sBI + slot3(q - 1) * PB, *Ip = sBI + slot3(q + 1) * PB;
@@ -399,7 +400,7 @@ __global__ __launch_bounds__(512) void fv4_rb_kernel(const hpgmg_hip_level L, co
         const double sum = fv4_sum(x, bt);
         const double alv = up ? c_al1 : c_al0, rhs = up ? c_rhs1 : c_rhs0, dinv = up ? c_dinv1 : c_dinv0;
         const double Ax = kHelm ? (P.a * alv) * x.c - bh2inv * sum : nbh2inv * sum;
-        double r_new = x.c + dinv * (rhs - Ax);
+        r_new = x.c + dinv * (rhs - Ax);
         if (__builtin_expect(sp_o, 0)) r_new = t_spo;                               // a special cell (a plane of another box next to a wall)
         sT[slot3(q) * PT + ownT + up * ST] = r_new;
         if (q >= k0 && q < k1) gst(outb, own_b + up * bjS + (unsigned)q * bkS, r_new);      // the pair's red cell on plane q is final: x' = t there
@@ -417,11 +418,14 @@ __global__ __launch_bounds__(512) void fv4_rb_kernel(const hpgmg_hip_level L, co
         sT[slot3(q) * PT + posT(ci, cj)] = tv;
       }
     }
-    __syncthreads();                                                                // [B] t on plane q is complete inside the domain
+    // B(q-1), next, reads nothing of plane q that ANOTHER lane has just written: from that plane it takes its own column's t (r_new) and
+    // black-parity cells, which are x.  So there is no barrier between R and B -- the waves of the workgroup may drift between the two stages,
+    // one wave's LDS reads under another's arithmetic -- except where the ghost cells of t have to be formed from the neighbours' results:
     // ghost values of t: in i / j on plane q (tiles at a wall); below the domain after R(0); above it after R(dim-1) (the x ring's part:
     // B(dim-2) reads it in this step) and in the extra step (the t ring's part, whose slot B(dim-2) still needed)
     const int kfill = (bottom && q == 0) ? 1 : ((top && q == dim - 1) ? 2 : ((top && q == dim) ? 3 : 0));
     if (__builtin_expect((tile_wall && do_r) || kfill, 0)) {
+      __syncthreads();                                                              // [B] t on plane q is complete inside the domain
       if (tile_wall && do_r && (bc_pack & 3)) {
         const int bc_kind = bc_pack & 3, bc_i = ((bc_pack >> 2) & 127) - 4, bc_j = ((bc_pack >> 9) & 31) - 4, bc_si = ((bc_pack >> 14) & 3) - 1, bc_sj = ((bc_pack >> 16) & 3) - 1;
         // ---- ghost cells of t on plane q outside the domain in i / j: apply_BCs_v4 (boundary_fv.c:262-425) from t itself
@@ -473,7 +477,8 @@ __global__ __launch_bounds__(512) void fv4_rb_kernel(const hpgmg_hip_level L, co
       x.kp2 = sX[slot4(q + 1) * PX + o];
       if (__builtin_expect(top && q == dim, 0)) x.kp2 = tgb[own_o + up * ujS + (unsigned)(dim + 1) * ukS];
       x.im1 = T0[posT(li - 1, row)]; x.ip1 = T0[posT(li + 1, row)]; x.jm1 = T0[posT(li, row - 1)]; x.jp1 = T0[posT(li, row + 1)];
-      x.km1 = Tm[posT(li, row)]; x.kp1 = Tp[posT(li, row)];
+      x.km1 = Tm[posT(li, row)];
+      x.kp1 = do_r ? r_new : Tp[posT(li, row)];                                     // the own column on plane q: what R has just formed (the extra step at the top of the domain: its ghost value)
       x.im2 = X0[o - 2]; x.ip2 = X0[o + 2]; x.jm2 = X0[o - 2 * W]; x.jp2 = X0[o + 2 * W];
       x.mm = X0[o - 1 - W]; x.pm = X0[o + 1 - W]; x.mp = X0[o - 1 + W]; x.pp = X0[o + 1 + W];
       x.m_im = Xm[o - 1]; x.m_ip = Xm[o + 1]; x.m_jm = Xm[o - W]; x.m_jp = Xm[o + W];

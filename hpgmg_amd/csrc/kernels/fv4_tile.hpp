@@ -67,14 +67,15 @@ __global__ __launch_bounds__(TI * TJ) void fv4_tile_kernel(const hpgmg_hip_level
   if (P.x_base) Lx.box_base = P.x_base;
   if (P.out_base) Lo.box_base = P.out_base;
 
-  const double *__restrict__ x = vec_origin(Lx, box, P.xn_id);
-  double *__restrict__ out = vec_origin(Lo, box, P.xout_id);
-  const double *__restrict__ rhs = (MODE == FV4_APPLY) ? nullptr : vec_origin(L, box, P.rhs_id);
-  const double *__restrict__ dinv = kSmooth ? vec_origin(L, box, VECTOR_DINV) : nullptr;
-  const double *__restrict__ alpha = kHelm ? vec_origin(L, box, VECTOR_ALPHA) : nullptr;
-  const double *__restrict__ gbi = vec_origin(L, box, VECTOR_BETA_I);
-  const double *__restrict__ gbj = vec_origin(L, box, VECTOR_BETA_J);
-  const double *__restrict__ gbk = vec_origin(L, box, VECTOR_BETA_K);
+  // device-memory pointers (common.hpp): global_load / global_store, so a wait for LDS data does not also wait for the loads in flight
+  gcptr x = gvec_origin(Lx, box, P.xn_id);
+  gptr out = gvec_origin(Lo, box, P.xout_id);
+  gcptr rhs = (MODE == FV4_APPLY) ? nullptr : gvec_origin(L, box, P.rhs_id);
+  gcptr dinv = kSmooth ? gvec_origin(L, box, VECTOR_DINV) : nullptr;
+  gcptr alpha = kHelm ? gvec_origin(L, box, VECTOR_ALPHA) : nullptr;
+  gcptr gbi = gvec_origin(L, box, VECTOR_BETA_I);
+  gcptr gbj = gvec_origin(L, box, VECTOR_BETA_J);
+  gcptr gbk = gvec_origin(L, box, VECTOR_BETA_K);
   int colour000 = 0;
   if (MODE == FV4_GSRB) colour000 = (L.box_low[3 * box] ^ L.box_low[3 * box + 1] ^ L.box_low[3 * box + 2] ^ P.sweep) & 1;
 
@@ -98,16 +99,16 @@ __global__ __launch_bounds__(TI * TJ) void fv4_tile_kernel(const hpgmg_hip_level
     if (P.ghost_free) hcol = gf_column(L, box, i0 + hi, j0 + hj);
   }
   // x of the own column / the halo column on plane p (any p the stencil reaches): inside the box's k range a plain load
-  const double *__restrict__ xh = (has_halo && P.ghost_free) ? vec_origin(Lx, hcol.box, P.xn_id) + hcol.off : x + halo_g;
+  gcptr xh = (has_halo && P.ghost_free) ? gvec_origin(Lx, hcol.box, P.xn_id) + hcol.off : x + halo_g;
   const bool gf = P.ghost_free != 0;
   const int dim = L.dim;
   // planes below the box (p < 0) are only met in the prologue of the first chunk: looked up there.  Planes above it (p >= dim) are met
   // in the last steps of the last chunk: one alternative base pointer per column, selected by p, keeps the marching loop free of branches
-  const double *__restrict__ xo_hi = x + own_g, *__restrict__ xh_hi = xh;
+  gcptr xo_hi = x + own_g, xh_hi = xh;
   if (gf && k1 == dim) {
     const int n = L.box_nbr[6 * box + 5];
-    if (n >= 0) xo_hi = vec_origin(Lx, n, P.xn_id) + own_g - (long long)dim * kS;
-    if (has_halo) { const int m = L.box_nbr[6 * hcol.box + 5]; if (m >= 0) xh_hi = vec_origin(Lx, m, P.xn_id) + hcol.off - (long long)dim * kS; }
+    if (n >= 0) xo_hi = gvec_origin(Lx, n, P.xn_id) + own_g - (long long)dim * kS;
+    if (has_halo) { const int m = L.box_nbr[6 * hcol.box + 5]; if (m >= 0) xh_hi = gvec_origin(Lx, m, P.xn_id) + hcol.off - (long long)dim * kS; }
   }
   auto x_own = [&](int p) -> double {
     if (gf && p < 0) return gf_load_outside(Lx, P.xn_id, GfColumn{box, own_g}, p);
@@ -142,10 +143,10 @@ __global__ __launch_bounds__(TI * TJ) void fv4_tile_kernel(const hpgmg_hip_level
 
   const TileFused &F = P.fused;
   TileFusedState<TI, TJ> fs;
-  double *coarse = nullptr;
+  gptr coarse = nullptr;
   if (MODE == FV4_RESIDUAL && F.kind == 2) {
     const int *mp = F.map + 4 * box;
-    coarse = vec_origin(F.Lc, mp[0], F.coarse_id) + (mp[1] + (i >> 1)) + (mp[2] + (j >> 1)) * F.Lc.jStride + (mp[3] + (k0 >> 1)) * F.Lc.kStride;
+    coarse = gvec_origin(F.Lc, mp[0], F.coarse_id) + (mp[1] + (i >> 1)) + (mp[2] + (j >> 1)) * F.Lc.jStride + (mp[3] + (k0 >> 1)) * F.Lc.kStride;
   }
 
   for (int k = k0; k < k1; k++) {

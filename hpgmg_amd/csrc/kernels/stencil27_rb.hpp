@@ -78,10 +78,11 @@ __global__ __launch_bounds__(32 * TJ) __attribute__((amdgpu_waves_per_eu(4, 8)))
   const int par0 = (L.box_low[3 * box] ^ L.box_low[3 * box + 1] ^ L.box_low[3 * box + 2] ^ P.sweep) & 1;   // parity offset: cell (i,j,k) of the box is red when ((i^j^k^par0)&1) == 0
   auto is_red = [&](int ci, int cj, int ck2) { return (((ci ^ cj ^ ck2 ^ par0) & 1) == 0); };
 
-  const double *__restrict__ x = vec_origin(L, box, P.xn_id);
-  double *__restrict__ out = vec_origin(L, box, P.xout_id);
-  const double *__restrict__ rhs = vec_origin(L, box, P.rhs_id);
-  const double *__restrict__ dinv = vec_origin(L, box, VECTOR_DINV);
+  // device-memory pointers (common.hpp): global_load / global_store, so a wait for LDS data does not also wait for the loads in flight
+  gcptr x = gvec_origin(L, box, P.xn_id);
+  gptr out = gvec_origin(L, box, P.xout_id);
+  gcptr rhs = gvec_origin(L, box, P.rhs_id);
+  gcptr dinv = gvec_origin(L, box, VECTOR_DINV);
 
   // ---- this lane's cells.  (1) its own two cells (gi, gj) and (gi, gj + 1); (2) at most one halo cell of the x planes; (3) at most one
   // ring cell of the t planes
@@ -117,10 +118,10 @@ __global__ __launch_bounds__(32 * TJ) __attribute__((amdgpu_waves_per_eu(4, 8)))
   auto slot3 = [](int p) { return ((p % 3) + 3) % 3; };
   // x on plane p (box-relative, -2 <= p <= dim+1) of the own columns / the halo column; 0 where nothing is defined
   auto k_ok = [&](int p) { const int s = side(p, wall_klo, wall_khi); return !(s && dist(p) > 1); };
-  const double *__restrict__ xo = x + own_g;
-  const double *__restrict__ xh = (has_h && h_ok) ? vec_origin(L, hcol.box, P.xn_id) + hcol.off : xo;
+  gcptr xo = x + own_g;
+  gcptr xh = (has_h && h_ok) ? gvec_origin(L, hcol.box, P.xn_id) + hcol.off : xo;
   // own column pair on plane p of vector `id` whose in-box pointer (at the lower cell) is `inbox`
-  auto load_own2 = [&](const double *inbox, int id, int p, double &lo, double &hi) {
+  auto load_own2 = [&](gcptr inbox, int id, int p, double &lo, double &hi) {
     if (p >= 0 && p < dim) { lo = inbox[p * kS]; hi = inbox[p * kS + jS]; }
     else { lo = gf_load_outside(L, id, GfColumn{box, own_g}, p); hi = gf_load_outside(L, id, GfColumn{box, own_g + jS}, p); }
   };
@@ -131,9 +132,9 @@ __global__ __launch_bounds__(32 * TJ) __attribute__((amdgpu_waves_per_eu(4, 8)))
     return gf_load_outside(L, P.xn_id, hcol, p);
   };
   // rhs / Dinv of the ring cell on plane p (inside the domain)
-  const double *__restrict__ rhs_e = e_in ? vec_origin(L, ecol.box, P.rhs_id) + ecol.off : rhs;
-  const double *__restrict__ dinv_e = e_in ? vec_origin(L, ecol.box, VECTOR_DINV) + ecol.off : dinv;
-  auto load_e = [&](const double *inbox, int id, int p) -> double {
+  gcptr rhs_e = e_in ? gvec_origin(L, ecol.box, P.rhs_id) + ecol.off : rhs;
+  gcptr dinv_e = e_in ? gvec_origin(L, ecol.box, VECTOR_DINV) + ecol.off : dinv;
+  auto load_e = [&](gcptr inbox, int id, int p) -> double {
     if (p >= 0 && p < dim) return inbox[p * kS];
     return gf_load_outside(L, id, ecol, p);
   };

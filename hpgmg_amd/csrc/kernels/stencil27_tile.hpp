@@ -51,10 +51,10 @@ __global__ __launch_bounds__(TI * TJ) void stencil27_tile_kernel(const hpgmg_hip
   const int k0 = ck * P.kchunk, k1 = (k0 + P.kchunk < L.dim) ? k0 + P.kchunk : L.dim;
   const int jS = L.jStride, kS = L.kStride;
 
-  const double *__restrict__ x = vec_origin(L, box, P.xn_id);
-  double *__restrict__ out = vec_origin(L, box, P.xout_id);      // 27-pt GSRB is out of place, Chebyshev / Jacobi ping-pong: never aliases x
-  const double *__restrict__ rhs = (MODE == 4) ? nullptr : vec_origin(L, box, P.rhs_id);
-  const double *__restrict__ dinv = kSmooth ? vec_origin(L, box, VECTOR_DINV) : nullptr;
+  gcptr x = gvec_origin(L, box, P.xn_id);
+  gptr out = gvec_origin(L, box, P.xout_id);      // 27-pt GSRB is out of place, Chebyshev / Jacobi ping-pong: never aliases x
+  gcptr rhs = (MODE == 4) ? nullptr : gvec_origin(L, box, P.rhs_id);
+  gcptr dinv = kSmooth ? gvec_origin(L, box, VECTOR_DINV) : nullptr;
   int colour000 = 0;
   if (MODE == 1) colour000 = (L.box_low[3 * box] ^ L.box_low[3 * box + 1] ^ L.box_low[3 * box + 2] ^ P.sweep) & 1;
 
@@ -71,16 +71,16 @@ __global__ __launch_bounds__(TI * TJ) void stencil27_tile_kernel(const hpgmg_hip
     halo_s = (hj + 1) * W + (hi + 1);
     if (P.ghost_free) hcol = gf_column(L, box, i0 + hi, j0 + hj);
   }
-  const double *__restrict__ xh = (has_halo && P.ghost_free) ? vec_origin(L, hcol.box, P.xn_id) + hcol.off : x + halo_g;
+  gcptr xh = (has_halo && P.ghost_free) ? gvec_origin(L, hcol.box, P.xn_id) + hcol.off : x + halo_g;
   const bool gf = P.ghost_free != 0;
   const int dim = L.dim;
   // planes below the box (p < 0) are only met in the prologue of the first chunk: looked up there.  Planes above it (p >= dim) are met
   // in the last steps of the last chunk: one alternative base pointer per column, selected by p, keeps the marching loop free of branches
-  const double *__restrict__ xo_hi = x + own_g, *__restrict__ xh_hi = xh;
+  gcptr xo_hi = x + own_g, xh_hi = xh;
   if (gf && k1 == dim) {
     const int n = L.box_nbr[6 * box + 5];
-    if (n >= 0) xo_hi = vec_origin(L, n, P.xn_id) + own_g - (long long)dim * kS;
-    if (has_halo) { const int m = L.box_nbr[6 * hcol.box + 5]; if (m >= 0) xh_hi = vec_origin(L, m, P.xn_id) + hcol.off - (long long)dim * kS; }
+    if (n >= 0) xo_hi = gvec_origin(L, n, P.xn_id) + own_g - (long long)dim * kS;
+    if (has_halo) { const int m = L.box_nbr[6 * hcol.box + 5]; if (m >= 0) xh_hi = gvec_origin(L, m, P.xn_id) + hcol.off - (long long)dim * kS; }
   }
   auto x_own = [&](int p) -> double {
     if (gf && p < 0) return gf_load_outside(L, P.xn_id, GfColumn{box, own_g}, p);
@@ -105,10 +105,10 @@ __global__ __launch_bounds__(TI * TJ) void stencil27_tile_kernel(const hpgmg_hip
   double c_old = (MODE == 0) ? out[own_g + k0 * kS] : 0.0;
   const TileFused &F = P.fused;
   TileFusedState<TI, TJ> fs;
-  double *coarse = nullptr;
+  gptr coarse = nullptr;
   if (MODE == 3 && F.kind == 2) {
     const int *mp = F.map + 4 * box;
-    coarse = vec_origin(F.Lc, mp[0], F.coarse_id) + (mp[1] + (i >> 1)) + (mp[2] + (j >> 1)) * F.Lc.jStride + (mp[3] + (k0 >> 1)) * F.Lc.kStride;
+    coarse = gvec_origin(F.Lc, mp[0], F.coarse_id) + (mp[1] + (i >> 1)) + (mp[2] + (j >> 1)) * F.Lc.jStride + (mp[3] + (k0 >> 1)) * F.Lc.kStride;
   }
 
   for (int k = k0; k < k1; k++) {

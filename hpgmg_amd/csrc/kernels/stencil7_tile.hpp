@@ -44,14 +44,14 @@ __global__ __launch_bounds__(64 * TJ) void stencil7_tile_kernel(const hpgmg_hip_
   const int jS = L.jStride, kS = L.kStride, last = L.dim - 1;
   const bool gf = P.ghost_free != 0;
 
-  const double *x = vec_origin(L, box, P.xn_id);                  // may alias out (in-place GSRB): a swept cell's neighbours all have the other colour
-  double *out = vec_origin(L, box, P.xout_id);
-  const double *__restrict__ rhs = (MODE == 4) ? nullptr : vec_origin(L, box, P.rhs_id);
-  const double *__restrict__ dinv = kSmooth ? vec_origin(L, box, VECTOR_DINV) : nullptr;
-  const double *__restrict__ alpha = kHelm ? vec_origin(L, box, VECTOR_ALPHA) : nullptr;
-  const double *__restrict__ beta_i = kVC ? vec_origin(L, box, VECTOR_BETA_I) : nullptr;
-  const double *__restrict__ beta_j = kVC ? vec_origin(L, box, VECTOR_BETA_J) : nullptr;
-  const double *__restrict__ beta_k = kVC ? vec_origin(L, box, VECTOR_BETA_K) : nullptr;
+  gcptr x = gvec_origin(L, box, P.xn_id);                  // may alias out (in-place GSRB): a swept cell's neighbours all have the other colour
+  gptr out = gvec_origin(L, box, P.xout_id);
+  gcptr rhs = (MODE == 4) ? nullptr : gvec_origin(L, box, P.rhs_id);
+  gcptr dinv = kSmooth ? gvec_origin(L, box, VECTOR_DINV) : nullptr;
+  gcptr alpha = kHelm ? gvec_origin(L, box, VECTOR_ALPHA) : nullptr;
+  gcptr beta_i = kVC ? gvec_origin(L, box, VECTOR_BETA_I) : nullptr;
+  gcptr beta_j = kVC ? gvec_origin(L, box, VECTOR_BETA_J) : nullptr;
+  gcptr beta_k = kVC ? gvec_origin(L, box, VECTOR_BETA_K) : nullptr;
   int colour000 = 0;
   if (MODE == 1) colour000 = (L.box_low[3 * box] ^ L.box_low[3 * box + 1] ^ L.box_low[3 * box + 2] ^ P.sweep) & 1;
 
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(64 * TJ) void stencil7_tile_kernel(const hpgmg_hip_
   //   kind 0: plain load (inside the box, or the ghost zone);  1: from the neighbouring local box;  2: Dirichlet, minus the adjacent interior cell
   const bool has_halo = tid < NH;
   int halo_s = 0, halo_g = 0, halo_kind = 0;
-  const double *halo_x = x;
+  gcptr halo_x = x;
   if (has_halo) {
     int hi, hj;
     if (tid < TI)          { hj = -1; hi = tid; }
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(64 * TJ) void stencil7_tile_kernel(const hpgmg_hip_
     if (ci < 0) dir = 0; else if (ci > last) dir = 1; else if (cj < 0) dir = 2; else if (cj > last) dir = 3;
     if (dir >= 0 && gf) {
       const int nb = L.box_nbr[6 * box + dir];
-      if (nb >= 0) { halo_kind = 1; halo_x = vec_origin(L, nb, P.xn_id); if (dir == 0) ci = last; else if (dir == 1) ci = 0; else if (dir == 2) cj = last; else cj = 0; }
+      if (nb >= 0) { halo_kind = 1; halo_x = gvec_origin(L, nb, P.xn_id); if (dir == 0) ci = last; else if (dir == 1) ci = 0; else if (dir == 2) cj = last; else cj = 0; }
       else if (nb == -1) { halo_kind = 2; if (dir == 0) ci = 0; else if (dir == 1) ci = last; else if (dir == 2) cj = 0; else cj = last; }
     }
     halo_g = ci + cj * jS;
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(64 * TJ) void stencil7_tile_kernel(const hpgmg_hip_
   // value of x just below / above the box on this lane's column (k faces)
   auto outside_k = [&](int dir, double centre, int kk) -> double {
     const int nb = L.box_nbr[6 * box + dir];
-    if (nb >= 0) return vec_origin(L, nb, P.xn_id)[own_g + (dir == 4 ? last : 0) * kS];
+    if (nb >= 0) return gvec_origin(L, nb, P.xn_id)[own_g + (dir == 4 ? last : 0) * kS];
     if (nb == -1) return -centre;
     return x[own_g + kk * kS];
   };

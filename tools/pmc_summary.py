@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Combine two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs as the MI355X guide prescribes)
-into profiles/<tag>_pmc_summary.json: HBM-side bytes per launch of the fine-level kernels next to their
-algorithmic bytes.
+into profiles/<tag>_pmc_summary.json: HBM-side bytes per launch of the fine-level kernels next to the bytes a launch
+has to move in the form it has (a kernel that does two sweeps in one pass: its own stream count, once -- 80 B per cell for
+the Chebyshev sweep pair, 56 for the fv4 and 32 for the 27-point red + black pass).
 
 usage: tools/pmc_summary.py <fetch.db> <write.db> <out.json> [--cells N]
 rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB.  gfx950 correction (MI355X_MICROARCH.md, HBM section):
@@ -37,9 +38,9 @@ def biggest(kern, pattern):
 def main():
     fetch, write, out = per_kernel(sys.argv[1]), per_kernel(sys.argv[2]), sys.argv[3]
     cells = int(sys.argv[sys.argv.index("--cells") + 1]) if "--cells" in sys.argv else 256 ** 3
-    rows = {"cheby_pair_fine": ("cheby_pair_kernel", 144), "cheby_pair_edge_columns": ("cheby_pair_edge_kernel", 0), "cheby_fine": ("stencil7_wide_kernelILi0ELi0", 72), "residual_fine": ("stencil7_wide_kernelILi0ELi3", 56),
+    rows = {"cheby_pair_fine": ("cheby_pair_kernel", 80), "cheby_pair_edge_columns": ("cheby_pair_edge_kernel", 0), "cheby_fine": ("stencil7_wide_kernelILi0ELi0", 72), "residual_fine": ("stencil7_wide_kernelILi0ELi3", 56),
             "residual_restrict_zero_fine": ("stencil7_wide_kernelILi0ELi6", 58), "residual_norm_fine": ("stencil7_wide_kernelILi0ELi7", 56),
-            "norm_copy_restrict_fine": ("norm_copy_restrict_kernel", 17), "fv4_gsrb_fine": ("fv4_tile_kernelILi5ELi1", 56), "stencil27_gsrb_fine": ("stencil27_tile_kernelILi1", 32), "stencil27_rb_fine": ("stencil27_rb_kernel", 64),
+            "norm_copy_restrict_fine": ("norm_copy_restrict_kernel", 17), "fv4_gsrb_fine": ("fv4_tile_kernelILi5ELi1", 56), "fv4_rb_fine": ("fv4_rb_kernel", 56), "fv4_special_cells": ("fv4_special_kernel", 0), "stencil27_gsrb_fine": ("stencil27_tile_kernelILi1", 32), "stencil27_rb_fine": ("stencil27_rb_kernel", 32),
             "scale_fine": ("elementwise_kernelILi3", 16), "interp_p0_fine": ("interp_blocks_kernelILi0", 17),
             "interp_p1_fine": ("interp_blocks_kernelILi1", 17), "restrict_fine": ("restrict_blocks_kernelILi0", 9), "norm_fine": ("absmax_kernel", 8)}
     res = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), MI355X",
@@ -58,6 +59,8 @@ def main():
     if "cheby_pair_fine" in k:      # the smoother launch bench.py times = edge-column pre-pass + pair kernel (two sweeps)
         res["hbm_bytes_per_launch_cheby_fine"] = k["cheby_pair_fine"]["hbm_bytes_per_launch"] + k.get("cheby_pair_edge_columns", {}).get("hbm_bytes_per_launch", 0.0)
         res["sweeps_per_launch"] = 2
+    elif "fv4_rb_fine" in k:            # one launch = both coloured half sweeps in one pass (the pre-pass launches are small and listed separately)
+        res["hbm_bytes_per_launch_smoother_fine"] = k["fv4_rb_fine"]["hbm_bytes_per_launch"]; res["sweeps_per_launch"] = 2
     elif "fv4_gsrb_fine" in k:
         res["hbm_bytes_per_launch_smoother_fine"] = k["fv4_gsrb_fine"]["hbm_bytes_per_launch"]; res["sweeps_per_launch"] = 1
     elif "stencil27_rb_fine" in k:      # one launch = both coloured half sweeps
