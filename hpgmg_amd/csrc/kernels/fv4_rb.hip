@@ -19,11 +19,15 @@ extern "C" {
 // (fv4_rb.hpp).  Vectors are (scratch?, id) pairs: scratch ids address the plugin-private vectors behind scr_base.  Boxes of side 64 m,
 // all of them local, two ghost cells; apply_BCs_v4 done on the input; on Dirichlet levels hpgmg_hip_fv4_rb_prepass run before.
 static long long g_rb4_launches = 0;
+#ifdef HPGMG_EXP_TIMELINE
+static unsigned long long *g_fv4rb_timeline = nullptr;
+void hpgmg_hip_exp_timeline_fv4(void *buf) { g_fv4rb_timeline = (unsigned long long *)buf; }
+#endif
 long long hpgmg_hip_rb_fv4_launch_count(void) { return g_rb4_launches; }
 int hpgmg_hip_smooth_gsrb_fv4_rb_supported(const hpgmg_hip_level *L, int variant) {
   static const int off = env_int("HPGMG_TUNE_FV4_NO_RB", 0);
   if (variant != HPGMG_HIP_FV4_VC_HELMHOLTZ && variant != HPGMG_HIP_FV4_VC_POISSON) return 0;
-  return !off && L->num_boxes > 0 && L->dim % 64 == 0 && L->box_nbr != nullptr && L->ghosts == 2;
+  return !off && L->num_boxes > 0 && L->dim % 32 == 0 && L->box_nbr != nullptr && L->ghosts == 2;
 }
 static VecSel vec_sel(const hpgmg_hip_level *L, double *const *scr_base, int scratch, int id) { return VecSel{scratch ? scr_base : L->box_base, id}; }
 // The ghost planes of the intermediate vector t below / above the domain, into the k ghost zone of scratch vector tg_id: a red half sweep
@@ -43,19 +47,19 @@ int hpgmg_hip_fv4_rb_prepass(const hpgmg_hip_level *L, int variant, double *cons
     HPGMG_LAUNCH_CHECK("fv4_special_kernel");
   }
   if (n_k <= 0) return 0;                                  // no k wall on this rank's boxes (periodic)
-  constexpr int TJ = 8, TI = 64;
   Fv4TileArgs P = {};
   P.xn_id = x_id; P.xout_id = tg_id; P.rhs_id = rhs_id; P.a = a; P.b = b; P.h2inv = h2inv; P.sweep = sweep; P.copy_other_colour = 1; P.ghost_free = 1;
   P.x_base = x_scratch ? scr_base : nullptr; P.out_base = scr_base;
-  P.tiles_i = L->dim / TI; P.tiles_j = L->dim / TJ; P.kchunk = 4; P.chunks_k = 2; P.k_origin = 0; P.k_step = L->dim - 4; P.wall_only = 1;
-  P.total_blocks = L->num_boxes * P.chunks_k * P.tiles_j * P.tiles_i;
-  const int grid = grid_for(P.total_blocks, &P.per_xcd);
-  const size_t lds = (size_t)11 * (TI + 4) * (TJ + 4) * sizeof(double);
-#define FV4_PRE_CASE(VAR) { \
+  P.kchunk = 4; P.chunks_k = 2; P.k_origin = 0; P.k_step = L->dim - 4; P.wall_only = 1;
+#define FV4_PRE_CASE(VAR, TJ, TI) { \
+    P.tiles_i = L->dim / TI; P.tiles_j = L->dim / TJ; P.total_blocks = L->num_boxes * P.chunks_k * P.tiles_j * P.tiles_i; \
+    const int grid = grid_for(P.total_blocks, &P.per_xcd); \
+    const size_t lds = (size_t)11 * (TI + 4) * (TJ + 4) * sizeof(double); \
     static bool once = false; if (!once) { HPGMG_CHECK(hipFuncSetAttribute((const void *)fv4_tile_kernel<VAR, FV4_GSRB, TJ, TI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once = true; } \
     hipLaunchKernelGGL((fv4_tile_kernel<VAR, FV4_GSRB, TJ, TI>), dim3(grid), dim3(TI, TJ), lds, g_stream, *L, P); }
-  if (variant == HPGMG_HIP_FV4_VC_HELMHOLTZ) FV4_PRE_CASE(HPGMG_HIP_FV4_VC_HELMHOLTZ)
-  else FV4_PRE_CASE(HPGMG_HIP_FV4_VC_POISSON)
+  const bool wide = L->dim % 64 == 0;
+  if (variant == HPGMG_HIP_FV4_VC_HELMHOLTZ) { if (wide) FV4_PRE_CASE(HPGMG_HIP_FV4_VC_HELMHOLTZ, 8, 64) else FV4_PRE_CASE(HPGMG_HIP_FV4_VC_HELMHOLTZ, 16, 32) }
+  else                                       { if (wide) FV4_PRE_CASE(HPGMG_HIP_FV4_VC_POISSON, 8, 64) else FV4_PRE_CASE(HPGMG_HIP_FV4_VC_POISSON, 16, 32) }
 #undef FV4_PRE_CASE
   HPGMG_LAUNCH_CHECK("fv4_tile_kernel (red + black pre-pass)");
   hpgmg_hip_level Ls = *L;
@@ -70,21 +74,29 @@ int hpgmg_hip_smooth_gsrb_fv4_rb(const hpgmg_hip_level *L, int variant, double *
   Fv4RbArgs A = {};
   A.x = vec_sel(L, scr_base, x_scratch, x_id); A.out = vec_sel(L, scr_base, out_scratch, out_id); A.tg = vec_sel(L, scr_base, 1, tg_id);
   A.rhs_id = rhs_id; A.a = a; A.b = b; A.h2inv = h2inv; A.sweep = sweep;
-  A.tiles_i = L->dim / fv4rb::TI; A.tiles_j = L->dim / fv4rb::TJ;
-  int kchunk = L->dim;                                   // one workgroup per CU: 256 fill the chip; every k chunk costs four extra planes of loads and two red stages
-  while (kchunk > 16 && (long long)L->num_boxes * A.tiles_i * A.tiles_j * (L->dim / kchunk) < 256) kchunk /= 2;
+  // tile width: 64 (one workgroup of 8 waves per CU) or 32 (two of 4 waves; the only form for boxes of 32^3)
+  const int tune_ti = env_int("HPGMG_TUNE_FV4_RB_TI", 0);      // read per call: the tests switch it
+  int TI = (L->dim % 64 == 0) ? 64 : 32;
+  if (tune_ti == 32 || (tune_ti == 64 && L->dim % 64 == 0)) TI = tune_ti;
+  A.tiles_i = L->dim / TI; A.tiles_j = L->dim / fv4rb::TJ;
+  int kchunk = L->dim;                                   // 256 (512) resident workgroups fill the chip; every k chunk costs four extra planes of loads and two red stages
+  while (kchunk > 16 && (long long)L->num_boxes * A.tiles_i * A.tiles_j * (L->dim / kchunk) < (TI == 64 ? 256 : 512)) kchunk /= 2;
   static const int tune_kc = env_int("HPGMG_TUNE_FV4_RB_KCHUNK", 0);
   if (tune_kc > 0 && L->dim % tune_kc == 0) kchunk = tune_kc;
   A.kchunk = kchunk; A.chunks_k = (L->dim + kchunk - 1) / kchunk;
   A.total_blocks = L->num_boxes * A.chunks_k * A.tiles_j * A.tiles_i;
   const int grid = grid_for(A.total_blocks, &A.per_xcd);
+#ifdef HPGMG_EXP_TIMELINE
+  A.timeline = g_fv4rb_timeline;
+#endif
   const long long cells = (long long)L->num_boxes * L->dim * L->dim * L->dim;
   const int prof = profile_begin(cells);
-#define FV4_RB_CASE(VAR) { \
-    static bool once = false; if (!once) { HPGMG_CHECK(hipFuncSetAttribute((const void *)fv4_rb_kernel<VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fv4rb::LDS_BYTES)); once = true; } \
-    hipLaunchKernelGGL((fv4_rb_kernel<VAR>), dim3(grid), dim3(64, 8), fv4rb::LDS_BYTES, g_stream, *L, A); }
-  if (variant == HPGMG_HIP_FV4_VC_HELMHOLTZ) FV4_RB_CASE(HPGMG_HIP_FV4_VC_HELMHOLTZ)
-  else FV4_RB_CASE(HPGMG_HIP_FV4_VC_POISSON)
+#define FV4_RB_CASE(VAR, TI_) { \
+    constexpr size_t lds = fv4rb::Geom<TI_>::LDS_BYTES; \
+    static bool once = false; if (!once) { HPGMG_CHECK(hipFuncSetAttribute((const void *)fv4_rb_kernel<VAR, TI_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once = true; } \
+    hipLaunchKernelGGL((fv4_rb_kernel<VAR, TI_>), dim3(grid), dim3(TI_, 8), lds, g_stream, *L, A); }
+  if (variant == HPGMG_HIP_FV4_VC_HELMHOLTZ) { if (TI == 64) FV4_RB_CASE(HPGMG_HIP_FV4_VC_HELMHOLTZ, 64) else FV4_RB_CASE(HPGMG_HIP_FV4_VC_HELMHOLTZ, 32) }
+  else                                       { if (TI == 64) FV4_RB_CASE(HPGMG_HIP_FV4_VC_POISSON, 64) else FV4_RB_CASE(HPGMG_HIP_FV4_VC_POISSON, 32) }
 #undef FV4_RB_CASE
   g_rb4_launches++;
   profile_end(prof, 2 * cells);                         // one launch = two half sweeps over every cell

@@ -48,28 +48,57 @@ struct Fv4RbArgs {
   double a, b, h2inv;
   int sweep;                            // number of the first (even) half sweep: its colour is (i ^ j ^ k ^ sweep) & 1 == 0
   int tiles_i, tiles_j, chunks_k, kchunk, per_xcd, total_blocks;
+  unsigned long long *timeline;         // experiment builds (-DHPGMG_EXP_TIMELINE): where two waves of one workgroup record the clock at the stage boundaries
 };
 
 namespace fv4rb {
-constexpr int TI = 64, TJ = 16, NT = 512;
-constexpr int WX = TI + 6, HX = TJ + 6, PX = WX * HX;          // x planes: three-cell halo
-constexpr int WB = TI + 4, HB = TJ + 4, PB = WB * HB;          // coefficient planes: two-cell halo
-constexpr int ST = 34, HT = TJ + 2, PT = ST * HT;              // red cells of t on the tile + 1: column c = i + 1 -> c >> 1
-constexpr int NRING = 80;                                      // lanes that own a pair of ring cells
-constexpr int LDS_DOUBLES = 4 * PX + 8 * PB + 3 * PT + NT + 4 * NRING;     // + per-lane pointers parked in LDS (see the kernel)
-constexpr size_t LDS_BYTES = (size_t)LDS_DOUBLES * sizeof(double);
-__device__ __forceinline__ constexpr int posX(int ci, int cj) { return (cj + 3) * WX + (ci + 3); }
-__device__ __forceinline__ constexpr int posB(int ci, int cj) { return (cj + 2) * WB + (ci + 2); }
-__device__ __forceinline__ int posT(int ci, int cj) { return (cj + 1) * ST + ((ci + 1) >> 1); }
+constexpr int TJ = 16;
+// Tile geometry: TI x 16 cells, TI x 8 lanes.  TI = 64: one workgroup of 8 waves fills a CU's LDS; TI = 32: 80 608 B, so TWO workgroups of 4
+// waves share a CU and one's barriers / LDS phases run under the other's arithmetic and loads (at 1.57 x instead of 1.36 x the minimum
+// traffic); also the form for boxes of 32^3.
+template <int TI_> struct Geom {
+  static constexpr int TI = TI_, NT = TI * 8;
+  static constexpr int WX = TI + 6, HX = TJ + 6, PX = WX * HX;          // x planes: three-cell halo
+  static constexpr int WB = TI + 4, HB = TJ + 4, PB = WB * HB;          // coefficient planes: two-cell halo
+  static constexpr int ST = TI / 2 + 2, HT = TJ + 2, PT = ST * HT;      // red cells of t on the tile + 1: column c = i + 1 -> c >> 1
+  static constexpr int NRING = TI + TJ;                                 // lanes that own a pair of ring cells (the last NRING of the workgroup)
+  static constexpr int NH = 6 * TI + 12 + 6 * TJ;                       // halo cells of an x plane (within three steps of the tile, corners cut)
+  static constexpr int NBH = 4 * TI + 12 + 4 * TJ;                      // halo cells of a coefficient plane
+  static constexpr bool H2 = NH > NT;                                   // lanes 0 .. NH-NT-1 own a second x halo cell
+  static constexpr bool PARK = (TI == 64);                              // per-lane "box above" pointers wait in LDS (there is room) instead of being rebuilt
+  static constexpr int LDS_DOUBLES = 4 * PX + 8 * PB + 3 * PT + NT / 2 + (PARK ? NT + 4 * NRING : 0);       // + the boundary descriptors (one int per lane)
+  static constexpr size_t LDS_BYTES = (size_t)LDS_DOUBLES * sizeof(double);
+  static_assert(NBH <= NT - NRING && NH <= 2 * NT && 68 + 2 * (2 * TI + 2) <= NT, "lane roles");
+  __device__ __forceinline__ static constexpr int posX(int ci, int cj) { return (cj + 3) * WX + (ci + 3); }
+  __device__ __forceinline__ static constexpr int posB(int ci, int cj) { return (cj + 2) * WB + (ci + 2); }
+  __device__ __forceinline__ static int posT(int ci, int cj) { return (cj + 1) * ST + ((ci + 1) >> 1); }
+  // the n-th halo cell of an x plane / of a coefficient plane, relative to the tile
+  __device__ __forceinline__ static void halo_x(int n, int &hi, int &hj) {
+    if (n < TI)              { hj = -3; hi = n; }
+    else if (n < 2 * TI)     { hj = TJ + 2; hi = n - TI; }
+    else if (n < 3 * TI + 2) { hj = -2; hi = -1 + (n - 2 * TI); }
+    else if (n < 4 * TI + 4) { hj = TJ + 1; hi = -1 + (n - (3 * TI + 2)); }
+    else if (n < 5 * TI + 8) { hj = -1; hi = -2 + (n - (4 * TI + 4)); }
+    else if (n < 6 * TI + 12) { hj = TJ; hi = -2 + (n - (5 * TI + 8)); }
+    else                     { const int h = n - (6 * TI + 12), c = h % 6; hj = h / 6; hi = (c < 3) ? c - 3 : TI + (c - 3); }
+  }
+  __device__ __forceinline__ static void halo_b(int n, int &hi, int &hj) {
+    if (n < TI + 2)           { hj = -2; hi = -1 + n; }
+    else if (n < 2 * TI + 4)  { hj = TJ + 1; hi = -1 + (n - (TI + 2)); }
+    else if (n < 3 * TI + 8)  { hj = -1; hi = -2 + (n - (2 * TI + 4)); }
+    else if (n < 4 * TI + 12) { hj = TJ; hi = -2 + (n - (3 * TI + 8)); }
+    else                      { const int h = n - (4 * TI + 12), c = h % 4; hj = h / 4; hi = (c < 2) ? c - 2 : TI + (c - 2); }
+  }
+};
 __device__ __forceinline__ int slot4(int p) { return p & 3; }
 __device__ __forceinline__ int slot3(int p) { return ((p % 3) + 3) % 3; }
 __device__ __forceinline__ int slot2(int p) { return p & 1; }
 
 struct B18 { double f[6], d[12]; };    // what the stencil takes from the coefficients at one cell: six face values, twelve differences
 // operators.fv4.c:87-108 read at a cell of three beta_i / beta_j planes and two beta_k faces (row stride WB)
+template <int W>
 __device__ __forceinline__ void beta18(B18 &o, const double *I0, const double *Im, const double *Ip, const double *J0, const double *Jm, const double *Jp,
                                        const double *K0, const double *K1) {
-  constexpr int W = WB;
   o.f[0] = I0[0]; o.f[1] = I0[1]; o.f[2] = J0[0]; o.f[3] = J0[W]; o.f[4] = K0[0]; o.f[5] = K1[0];
   o.d[0] = I0[W] - I0[-W];         o.d[1] = Ip[0] - Im[0];
   o.d[2] = J0[1] - J0[-1];         o.d[3] = Jp[0] - Jm[0];
@@ -77,6 +106,23 @@ __device__ __forceinline__ void beta18(B18 &o, const double *I0, const double *I
   o.d[6] = I0[1 + W] - I0[1 - W];  o.d[7] = Ip[1] - Im[1];
   o.d[8] = J0[W + 1] - J0[W - 1];  o.d[9] = Jp[W] - Jm[W];
   o.d[10] = K1[1] - K1[-1];        o.d[11] = K1[W] - K1[-W];
+}
+// The same in pieces, so that a stage issues its LDS reads in a few large groups ahead of the arithmetic (the wave has one other wave to hide
+// behind, so every round trip to the LDS that the instruction stream exposes is paid in full) without holding all 55 operands at once:
+// group 1 = what the six face terms and the first five mixed terms take, group 2 = the rest
+struct BG1 { double i00, i01, j00, jw0, k00, k10, i0p, i0m, ip0, im0, j01, j0m, jp0, jm0, k0p, k0m; };
+struct BG2 { double k0w, k0mw, i0pp, i0mp, ip1, im1, jwp, jwm, jpw, jmw, k1p, k1m, k1w, k1mw; };
+template <int W>
+__device__ __forceinline__ void beta_g1(BG1 &r, const double *I0, const double *Im, const double *Ip, const double *J0, const double *Jm, const double *Jp,
+                                        const double *K0, const double *K1) {
+  r.i00 = I0[0]; r.i01 = I0[1]; r.j00 = J0[0]; r.jw0 = J0[W]; r.k00 = K0[0]; r.k10 = K1[0];
+  r.i0p = I0[W]; r.i0m = I0[-W]; r.ip0 = Ip[0]; r.im0 = Im[0]; r.j01 = J0[1]; r.j0m = J0[-1]; r.jp0 = Jp[0]; r.jm0 = Jm[0]; r.k0p = K0[1]; r.k0m = K0[-1];
+}
+template <int W>
+__device__ __forceinline__ void beta_g2(BG2 &r, const double *I0, const double *Im, const double *Ip, const double *J0, const double *Jm, const double *Jp,
+                                        const double *K0, const double *K1) {
+  r.k0w = K0[W]; r.k0mw = K0[-W]; r.i0pp = I0[1 + W]; r.i0mp = I0[1 - W]; r.ip1 = Ip[1]; r.im1 = Im[1];
+  r.jwp = J0[W + 1]; r.jwm = J0[W - 1]; r.jpw = Jp[W]; r.jmw = Jm[W]; r.k1p = K1[1]; r.k1m = K1[-1]; r.k1w = K1[W]; r.k1mw = K1[-W];
 }
 // the same read at a cell of a box's own arrays in memory (p: the cell in the box's level vectors): what the reference reads for a cell of that box
 __device__ __forceinline__ void beta18_global(B18 &o, gcptr p, size_t vol, int jS, int kS) {
@@ -114,15 +160,90 @@ __device__ __forceinline__ double fv4_sum(const X25 &x, const B18 &b) {
   s2 = s2 + b.d[11] * (x.p_jp - x.jp1 - x.p_jm + x.jm1);
   return FV4_TWELFTH * s1 + (0.25 * FV4_TWELFTH) * s2;
 }
+// fv4_sum in two steps (the same expression tree): what depends on the iterate only, then the products with the coefficients
+struct Br18 { double a[6], m[12]; };
+__device__ __forceinline__ void fv4_brackets(Br18 &o, const X25 &x) {
+  o.a[0] = 15.0 * (x.im1 - x.c) - (x.im2 - x.ip1);
+  o.a[1] = 15.0 * (x.ip1 - x.c) - (x.ip2 - x.im1);
+  o.a[2] = 15.0 * (x.jm1 - x.c) - (x.jm2 - x.jp1);
+  o.a[3] = 15.0 * (x.jp1 - x.c) - (x.jp2 - x.jm1);
+  o.a[4] = 15.0 * (x.km1 - x.c) - (x.km2 - x.kp1);
+  o.a[5] = 15.0 * (x.kp1 - x.c) - (x.kp2 - x.km1);
+  o.m[0] = x.mp - x.jp1 - x.mm + x.jm1;
+  o.m[1] = x.p_im - x.kp1 - x.m_im + x.km1;
+  o.m[2] = x.pm - x.ip1 - x.mm + x.im1;
+  o.m[3] = x.p_jm - x.kp1 - x.m_jm + x.km1;
+  o.m[4] = x.m_ip - x.ip1 - x.m_im + x.im1;
+  o.m[5] = x.m_jp - x.jp1 - x.m_jm + x.jm1;
+  o.m[6] = x.pp - x.jp1 - x.pm + x.jm1;
+  o.m[7] = x.p_ip - x.kp1 - x.m_ip + x.km1;
+  o.m[8] = x.pp - x.ip1 - x.mp + x.im1;
+  o.m[9] = x.p_jp - x.kp1 - x.m_jp + x.km1;
+  o.m[10] = x.p_ip - x.ip1 - x.p_im + x.im1;
+  o.m[11] = x.p_jp - x.jp1 - x.p_jm + x.jm1;
+}
+// ... in the two parts the coefficient groups allow: s1 and the first five terms of s2, then the other seven and the total
+__device__ __forceinline__ void fv4_combine_a(double &s1, double &s2, const Br18 &r, const BG1 &g) {
+  s1 = g.i00 * r.a[0];
+  s1 = s1 + g.i01 * r.a[1];
+  s1 = s1 + g.j00 * r.a[2];
+  s1 = s1 + g.jw0 * r.a[3];
+  s1 = s1 + g.k00 * r.a[4];
+  s1 = s1 + g.k10 * r.a[5];
+  s2 = (g.i0p - g.i0m) * r.m[0];
+  s2 = s2 + (g.ip0 - g.im0) * r.m[1];
+  s2 = s2 + (g.j01 - g.j0m) * r.m[2];
+  s2 = s2 + (g.jp0 - g.jm0) * r.m[3];
+  s2 = s2 + (g.k0p - g.k0m) * r.m[4];
+}
+__device__ __forceinline__ double fv4_combine_b(double s1, double s2, const Br18 &r, const BG2 &g) {
+  s2 = s2 + (g.k0w - g.k0mw) * r.m[5];
+  s2 = s2 + (g.i0pp - g.i0mp) * r.m[6];
+  s2 = s2 + (g.ip1 - g.im1) * r.m[7];
+  s2 = s2 + (g.jwp - g.jwm) * r.m[8];
+  s2 = s2 + (g.jpw - g.jmw) * r.m[9];
+  s2 = s2 + (g.k1p - g.k1m) * r.m[10];
+  s2 = s2 + (g.k1w - g.k1mw) * r.m[11];
+  return FV4_TWELFTH * s1 + (0.25 * FV4_TWELFTH) * s2;
+}
+__device__ __forceinline__ double fv4_combine(const Br18 &r, const B18 &b) {
+  double s1 = b.f[0] * r.a[0];
+  s1 = s1 + b.f[1] * r.a[1];
+  s1 = s1 + b.f[2] * r.a[2];
+  s1 = s1 + b.f[3] * r.a[3];
+  s1 = s1 + b.f[4] * r.a[4];
+  s1 = s1 + b.f[5] * r.a[5];
+  double s2 = b.d[0] * r.m[0];
+  s2 = s2 + b.d[1] * r.m[1];
+  s2 = s2 + b.d[2] * r.m[2];
+  s2 = s2 + b.d[3] * r.m[3];
+  s2 = s2 + b.d[4] * r.m[4];
+  s2 = s2 + b.d[5] * r.m[5];
+  s2 = s2 + b.d[6] * r.m[6];
+  s2 = s2 + b.d[7] * r.m[7];
+  s2 = s2 + b.d[8] * r.m[8];
+  s2 = s2 + b.d[9] * r.m[9];
+  s2 = s2 + b.d[10] * r.m[10];
+  s2 = s2 + b.d[11] * r.m[11];
+  return FV4_TWELFTH * s1 + (0.25 * FV4_TWELFTH) * s2;
+}
+#define FV4RB_FENCE() __builtin_amdgcn_sched_barrier(0)      /* nothing is scheduled across: reads stay together, ahead of the arithmetic */
 }  // namespace fv4rb
 
-template <int V>
-__global__ __launch_bounds__(512) void fv4_rb_kernel(const hpgmg_hip_level L, const Fv4RbArgs P) {
+template <int V, int TI_>
+__global__ __launch_bounds__(TI_ * 8, 2) void fv4_rb_kernel(const hpgmg_hip_level L, const Fv4RbArgs P) {      // two waves per SIMD: 256 registers
   using namespace fv4rb;
+  using G = Geom<TI_>;
+  constexpr int TI = G::TI, NT = G::NT, WX = G::WX, PX = G::PX, WB = G::WB, PB = G::PB, ST = G::ST, PT = G::PT, NRING = G::NRING;
+  constexpr bool H2 = G::H2, PARK = G::PARK;
   constexpr bool kHelm = (V == HPGMG_HIP_FV4_VC_HELMHOLTZ);
+  auto posX = [](int ci, int cj) { return G::posX(ci, cj); };
+  auto posB = [](int ci, int cj) { return G::posB(ci, cj); };
+  auto posT = [](int ci, int cj) { return G::posT(ci, cj); };
   extern __shared__ double fv4rb_lds[];
   double *sX = fv4rb_lds, *sBI = sX + 4 * PX, *sBJ = sBI + 3 * PB, *sBK = sBJ + 3 * PB, *sT = sBK + 2 * PB;
-  unsigned long long *sPtr = (unsigned long long *)(sT + 3 * PT);
+  int *sBC = (int *)(sT + 3 * PT);                                             // one boundary-cell descriptor per lane (tiles at a wall)
+  unsigned long long *sPtr = (unsigned long long *)(sT + 3 * PT + NT / 2);     // PARK only
 
   const int logical = xcd_logical_block((int)blockIdx.x, P.per_xcd);
   if (logical >= P.total_blocks) return;
@@ -132,6 +253,9 @@ __global__ __launch_bounds__(512) void fv4_rb_kernel(const hpgmg_hip_level L, co
   const int ck = t % P.chunks_k; t /= P.chunks_k;
   const int box = t;
   const int li = (int)threadIdx.x, lj = (int)threadIdx.y, tid = lj * TI + li;     // lj: the pair of rows 2 lj, 2 lj + 1
+#ifdef HPGMG_EXP_TIMELINE
+  if (P.timeline && tid == 0 && logical < 8192) P.timeline[16384 + 3 * logical] = __builtin_amdgcn_s_memrealtime();     // workgroup start
+#endif
   const int i0 = ti * TI, j0 = tj * TJ;
   const int dim = L.dim, jS = L.jStride, kS = L.kStride;
   const int k0 = ck * P.kchunk, k1 = (k0 + P.kchunk < dim) ? k0 + P.kchunk : dim;
@@ -163,51 +287,48 @@ __global__ __launch_bounds__(512) void fv4_rb_kernel(const hpgmg_hip_level L, co
   gcptr tgb_hi = (nb[5] >= 0) ? as_global(P.tg.base[nb[5]]) + (size_t)P.tg.id * vol - (long long)dim * kS : tgb;
   if (nb[5] >= 0) { lvb_hi = as_global(L.box_base[nb[5]]) - (long long)dim * kS; xb_hi = as_global(P.x.base[nb[5]]) + (size_t)P.x.id * vol - (long long)dim * kS; }
 
-  // ---- (2) one halo cell of the x planes (the cells within three steps of the tile: 492)
-  const bool has_h = tid < 492;
-  int hi = 0, hj = 0;
-  if (has_h) {
-    if (tid < 64)       { hj = -3; hi = tid; }
-    else if (tid < 128) { hj = TJ + 2; hi = tid - 64; }
-    else if (tid < 194) { hj = -2; hi = -1 + (tid - 128); }
-    else if (tid < 260) { hj = TJ + 1; hi = -1 + (tid - 194); }
-    else if (tid < 328) { hj = -1; hi = -2 + (tid - 260); }
-    else if (tid < 396) { hj = TJ; hi = -2 + (tid - 328); }
-    else                { const int h = tid - 396, c = h % 6; hj = h / 6; hi = (c < 3) ? c - 3 : TI + (c - 3); }
-  }
-  const int hX = posX(hi, hj);
+  // ---- (2) one halo cell of the x planes (the cells within three steps of the tile: NH = 492 / 300); with TI = 32 the first 44 lanes own two
+  const bool has_h = tid < G::NH, has_h2 = H2 && tid + NT < G::NH;
+  int hi = 0, hj = 0, h2i = 0, h2j = 0;
+  // in reverse order: the waves at the end of the workgroup also carry the ring cells, so they get the contiguous rows of the halo and the
+  // first waves the columns (one cache line per lane)
+  if (has_h) G::halo_x(G::NH - 1 - tid, hi, hj);
+  if (has_h2) G::halo_x(G::NH - 1 - (tid + NT), h2i, h2j);
+  const int hX = posX(hi, hj), h2X = posX(h2i, h2j);
   const bool h_ok = has_h && out_i(i0 + hi) <= 2 && out_j(j0 + hj) <= 2;          // further out nothing is defined (and nothing is needed)
-  GfColumn hcol = {box, 0};
+  const bool h2_ok = has_h2 && out_i(i0 + h2i) <= 2 && out_j(j0 + h2j) <= 2;
+  GfColumn hcol = {box, 0}, h2col = {box, 0};
   if (h_ok) hcol = gf_column(L, box, i0 + hi, j0 + hj);
+  if (h2_ok) h2col = gf_column(L, box, i0 + h2i, j0 + h2j);
   // a halo cell face-adjacent to the tile: a position B reads on the planes r - 1, r + 1 (the k ghost planes of t need it)
   const bool h_face = h_ok && ((hi >= 0 && hi < TI && (hj == -1 || hj == TJ)) || (hj >= 0 && hj < TJ && (hi == -1 || hi == TI)));
+  const bool h2_face = h2_ok && ((h2i >= 0 && h2i < TI && (h2j == -1 || h2j == TJ)) || (h2j >= 0 && h2j < TJ && (h2i == -1 || h2i == TI)));
   // per-lane columns in other boxes are followed by MARCHING pointers (xh_c: the halo column at plane q+2, al_c / xe_c below); the base to
-  // continue with above the box (the box above, or the own ghost zone) is needed once per march at most: it waits in LDS, not in registers
-  gcptr xh = sel_origin(L, P.x, hcol.box) + hcol.off;
-  { const int m = L.box_nbr[6 * hcol.box + 5];
-    sPtr[tid] = (unsigned long long)((h_ok && m >= 0) ? sel_origin(L, P.x, m) + hcol.off - (long long)dim * kS : xh); }
+  // continue with above the box (the box above, or the own ghost zone) is needed once per march at most: it waits in LDS where there is
+  // room (PARK) and is rebuilt from the column otherwise -- not in registers
+  auto x_col = [&](const GfColumn &c) -> gcptr { return sel_origin(L, P.x, c.box) + c.off; };
+  auto x_col_up = [&](const GfColumn &c, bool ok) -> gcptr {
+    const int m = L.box_nbr[6 * c.box + 5];
+    return (ok && m >= 0) ? sel_origin(L, P.x, m) + c.off - (long long)dim * kS : sel_origin(L, P.x, c.box) + c.off;
+  };
+  if (PARK) sPtr[tid] = (unsigned long long)x_col_up(hcol, h_ok);
+  auto xh_up = [&]() -> gcptr { return PARK ? (gcptr)sPtr[tid] : x_col_up(hcol, h_ok); };
 
   // ---- (3) lanes 0 .. 331: one halo cell of the coefficient planes (what the stencils of the tile and of its face-adjacent ring reach), read
   //      from the OWN box's ghost zone like the reference does: inside the domain that is the neighbour's value (rebuild_operator exchanged
   //      it), outside the domain it is this box's own extrapolation -- which differs from what the neighbouring box holds for the same
   //      place (extrapolate_betas works with box-relative normals), see "special" below
   // ---- (4) lanes 432 .. 511: a red / black pair of ring cells e0 = (ei, ej), e1 = e0 + (edx, edy), in the box that owns them
-  const bool has_b = tid < 332, has_e = tid >= 432;
+  const bool has_b = tid < G::NBH, has_e = tid < NRING;
   int bhi = 0, bhj = 0, ei = 0, ej = 0, edx = 0, edy = 0;
-  if (has_b) {
-    if (tid < 66)       { bhj = -2; bhi = -1 + tid; }
-    else if (tid < 132) { bhj = TJ + 1; bhi = -1 + (tid - 66); }
-    else if (tid < 200) { bhj = -1; bhi = -2 + (tid - 132); }
-    else if (tid < 268) { bhj = TJ; bhi = -2 + (tid - 200); }
-    else                { const int h = tid - 268, c = h % 4; bhj = h / 4; bhi = (c < 2) ? c - 2 : TI + (c - 2); }
-  }
+  if (has_b) G::halo_b(tid, bhi, bhj);
   if (has_e) {
-    const int e = tid - 432;
+    const int e = tid;
     // rows -1 and TJ alternate from lane to lane: their red cells sit at columns of opposite parity, so the 32 lanes of a half wave read
     // 32 different LDS banks (one row alone reads every second double: a two-way conflict on every access)
-    if (e < 64)      { ej = (e & 1) ? TJ : -1; ei = 2 * (e >> 1); edx = 1; }
-    else if (e < 72) { ei = -1; ej = 2 * (e - 64); edy = 1; }
-    else             { ei = TI; ej = 2 * (e - 72); edy = 1; }
+    if (e < TI)          { ej = (e & 1) ? TJ : -1; ei = 2 * (e >> 1); edx = 1; }
+    else if (e < TI + 8) { ei = -1; ej = 2 * (e - TI); edy = 1; }
+    else                 { ei = TI; ej = 2 * (e - TI - 8); edy = 1; }
   }
   const int bB = posB(bhi, bhj);                                                  // the coefficient halo cell: in LDS, in the own box
   const unsigned b_o = (unsigned)((long long)first + (i0 + bhi) + (long long)(j0 + bhj) * jS);
@@ -216,26 +337,32 @@ __global__ __launch_bounds__(512) void fv4_rb_kernel(const hpgmg_hip_level L, co
   GfColumn acol = {box, 0};
   if (e_in)  acol = gf_column(L, box, i0 + ei, j0 + ej);
   const int e_step = edx + edy * jS;                                              // second cell of the ring pair, in memory (same box: pairs are aligned)
-  gcptr al = as_global(L.box_base[acol.box]) + first + acol.off;
-  gcptr xe = sel_origin(L, P.x, acol.box) + acol.off;
-  { const int m = L.box_nbr[6 * acol.box + 5];
-    const bool up_box = e_in && m >= 0;
-    if (has_e) {
-      const int e = tid - 432;
-      sPtr[NT + e] = (unsigned long long)(up_box ? as_global(L.box_base[m]) + first + acol.off - (long long)dim * kS : al);
-      sPtr[NT + NRING + e] = (unsigned long long)(up_box ? sel_origin(L, P.x, m) + acol.off - (long long)dim * kS : xe);
-      // where the ring pair's t is read when it is "special": the same column of P.tg, in its box / in the box above
-      sPtr[NT + 2 * NRING + e] = (unsigned long long)(sel_origin(L, P.tg, acol.box) + acol.off);
-      sPtr[NT + 3 * NRING + e] = (unsigned long long)(up_box ? sel_origin(L, P.tg, m) + acol.off - (long long)dim * kS : sel_origin(L, P.tg, acol.box) + acol.off);
-    } }
-  const int e_id = has_e ? tid - 432 : 0;
+  const int e_id = has_e ? tid : 0;
+  // the ring pair's column: level vectors (al), x (xe), and P.tg, where its t is read when it is "special"; `up`: the base for planes >= dim
+  auto al_col = [&](bool up) -> gcptr {
+    const int m = L.box_nbr[6 * acol.box + 5];
+    return (up && e_in && m >= 0) ? as_global(L.box_base[m]) + first + acol.off - (long long)dim * kS : as_global(L.box_base[acol.box]) + first + acol.off;
+  };
+  auto xe_col = [&](bool up) -> gcptr { return up ? x_col_up(acol, e_in) : x_col(acol); };
+  auto tge_col = [&](bool up) -> gcptr {
+    const int m = L.box_nbr[6 * acol.box + 5];
+    return (up && e_in && m >= 0) ? sel_origin(L, P.tg, m) + acol.off - (long long)dim * kS : sel_origin(L, P.tg, acol.box) + acol.off;
+  };
+  if (PARK && has_e) {
+    sPtr[NT + e_id] = (unsigned long long)al_col(true); sPtr[NT + NRING + e_id] = (unsigned long long)xe_col(true);
+    sPtr[NT + 2 * NRING + e_id] = (unsigned long long)tge_col(false); sPtr[NT + 3 * NRING + e_id] = (unsigned long long)tge_col(true);
+  }
+  auto al_up = [&]() -> gcptr { return PARK ? (gcptr)sPtr[NT + e_id] : al_col(true); };
+  auto xe_up = [&]() -> gcptr { return PARK ? (gcptr)sPtr[NT + NRING + e_id] : xe_col(true); };
 
   // ---- (5) lanes 0 .. 331: one ghost cell of t outside the domain in i and / or j: kind 1 near, 2 far, 3 the k-edge cell diagonal to a tile corner
   const bool tile_wall = t_ilo || t_ihi || t_jlo || t_jhi;
-  int bc_pack = 0;                                                                // kind, position, inward step(s), packed: decoded where it is used
-  if (tile_wall) {
+  // The descriptor (kind, position, inward steps; packed) waits in LDS, not in a register: a value that is live across the loop but used
+  // only in this rarely taken block is what the register allocator spills first, and a reload from scratch is a vector-memory load -- it
+  // returns behind every prefetch in flight, i.e. costs the wall tiles an HBM round trip per step (they took 1.5 x the time of the
+  // others, and with a quarter of the tiles at a wall that set the launch time)
+  auto bc_descr = [&](int n) -> int {
     int bc_kind = 0, bc_i = 0, bc_j = 0, bc_si = 0, bc_sj = 0;
-    int n = tid;
     // i walls: near cells of rows -1 .. TJ (a row outside the domain makes it the k-edge cell), far cells of rows 0 .. TJ-1
     for (int side = 0; side < 2 && n >= 0; side++) {
       if (!(side ? t_ihi : t_ilo)) continue;
@@ -251,16 +378,17 @@ __global__ __launch_bounds__(512) void fv4_rb_kernel(const hpgmg_hip_level L, co
     // j walls: near cells of columns -1 .. TI inside the domain, far cells of columns 0 .. TI-1
     for (int side = 0; side < 2 && n >= 0; side++) {
       if (!(side ? t_jhi : t_jlo)) continue;
-      if (n < 130) {
+      if (n < 2 * TI + 2) {
         const int row = side ? TJ : -1, s = side ? -1 : 1;
-        if (n < 66) { const int c = -1 + n; if (!out_i(i0 + c)) { bc_kind = 1; bc_i = c; bc_j = row; bc_sj = s; } }
-        else        { bc_kind = 2; bc_i = n - 66; bc_j = side ? TJ + 1 : -2; bc_sj = s; }
+        if (n < TI + 2) { const int c = -1 + n; if (!out_i(i0 + c)) { bc_kind = 1; bc_i = c; bc_j = row; bc_sj = s; } }
+        else            { bc_kind = 2; bc_i = n - (TI + 2); bc_j = side ? TJ + 1 : -2; bc_sj = s; }
         n = -1;
-      } else n -= 130;
+      } else n -= 2 * TI + 2;
     }
-    bc_pack = bc_kind | ((bc_i + 4) << 2) | ((bc_j + 4) << 9) | ((bc_si + 1) << 14) | ((bc_sj + 1) << 16);
-  }
+    return bc_kind | ((bc_i + 4) << 2) | ((bc_j + 4) << 9) | ((bc_si + 1) << 14) | ((bc_sj + 1) << 16);
+  };
 
+  if (tile_wall) sBC[tid] = bc_descr(tid);                                        // read after the barriers of the first step
   // t on plane q at a tile / ring cell inside the domain: a red cell from the t ring, a black one is the cell of x
   auto t_at = [&](int ci, int cj, int q) -> double {
     return is_red(i0 + ci, j0 + cj, q) ? sT[slot3(q) * PT + posT(ci, cj)] : sX[slot4(q) * PX + posX(ci, cj)];
@@ -279,22 +407,20 @@ __global__ __launch_bounds__(512) void fv4_rb_kernel(const hpgmg_hip_level L, co
     if (nb[4] >= 0) return (as_global(L.box_base[nb[4]]) + first)[(size_t)id * vol + own_g + cell * jS + (p + dim) * kS];
     return (lvb + (size_t)id * vol)[(long long)own_o + cell * jS + (long long)p * kS];
   };
-  auto xh_fwd = [&](int p) -> double { return ((p >= dim) ? (gcptr)sPtr[tid] : xh)[p * kS]; };
-  auto xh_any = [&](int p) -> double {
-    if (!h_ok) return 0.0;
-    if (p >= 0) return (p > dim + 1 && L.box_nbr[6 * hcol.box + 5] < 0) ? 0.0 : xh_fwd(p);
-    const int m = L.box_nbr[6 * hcol.box + 4];
-    if (m >= 0) return sel_origin(L, P.x, m)[hcol.off + (p + dim) * kS];
-    return (p < -2) ? 0.0 : xh[p * kS];
+  auto xh_any = [&](const GfColumn &c, bool ok, int p) -> double {               // prologue only
+    if (!ok) return 0.0;
+    if (p >= 0) return (p > dim + 1 && L.box_nbr[6 * c.box + 5] < 0) ? 0.0 : ((p >= dim) ? x_col_up(c, ok) : x_col(c))[p * kS];
+    const int m = L.box_nbr[6 * c.box + 4];
+    if (m >= 0) return sel_origin(L, P.x, m)[c.off + (p + dim) * kS];
+    return (p < -2) ? 0.0 : x_col(c)[p * kS];
   };
-  auto al_fwd = [&](int id, int cell, int p) -> double { return ((p >= dim) ? (gcptr)sPtr[NT + e_id] : al)[(size_t)id * vol + cell * e_step + p * kS]; };
-  auto al_any = [&](int id, int cell, int p) -> double {
-    if (p >= 0) return al_fwd(id, cell, p);
+  auto al_any = [&](int id, int cell, int p) -> double {                          // prologue only
+    if (p >= 0) return al_col(p >= dim)[(size_t)id * vol + cell * e_step + p * kS];
     const int m = L.box_nbr[6 * acol.box + 4];
     if (m >= 0) return (as_global(L.box_base[m]) + first)[(size_t)id * vol + acol.off + cell * e_step + (p + dim) * kS];
-    return al[(size_t)id * vol + cell * e_step + p * kS];
+    return al_col(false)[(size_t)id * vol + cell * e_step + p * kS];
   };
-  auto xe_fwd = [&](int cell, int p) -> double { return ((p >= dim) ? (gcptr)sPtr[NT + NRING + e_id] : xe)[cell * e_step + p * kS]; };
+  auto xe_fwd = [&](int cell, int p) -> double { return xe_col(p >= dim)[cell * e_step + p * kS]; };      // prologue only
   auto e_red = [&](int q) { return is_red(i0 + ei, j0 + ej, q) ? 0 : 1; };         // which cell of the ring pair is red on plane q
 
   // ---- prologue: planes qlo-2 .. qlo+1 of x, planes qlo-1 .. qlo+1 of beta_i / beta_j, faces qlo, qlo+1 of beta_k into LDS; x[qlo+2] of
@@ -302,7 +428,8 @@ __global__ __launch_bounds__(512) void fv4_rb_kernel(const hpgmg_hip_level L, co
   for (int p = qlo - 2; p <= qlo + 1; p++) {
     const int s = slot4(p) * PX;
     sX[s + ownX] = x_own_any(0, p); sX[s + ownX + WX] = x_own_any(1, p);
-    if (has_h) sX[s + hX] = xh_any(p);
+    if (has_h) sX[s + hX] = xh_any(hcol, h_ok, p);
+    if (has_h2) sX[s + h2X] = xh_any(h2col, h2_ok, p);
   }
   for (int p = qlo - 1; p <= qlo + 1; p++) {
     const int s = slot3(p) * PB;
@@ -330,12 +457,26 @@ __global__ __launch_bounds__(512) void fv4_rb_kernel(const hpgmg_hip_level L, co
   const double bh2inv = P.b * P.h2inv, nbh2inv = (-P.b) * P.h2inv;
 
   // marching pointers: the x halo column at plane q+2, the ring pair's level vectors at plane q+1, its x at plane q+3
-  gcptr xh_c = ((qlo + 2 >= dim) ? (gcptr)sPtr[tid] : xh) + (long long)(qlo + 2) * kS;
-  gcptr al_c = ((qlo + 1 >= dim) ? (gcptr)sPtr[NT + e_id] : al) + (long long)(qlo + 1) * kS;
-  gcptr xe_c = ((qlo + 3 >= dim) ? (gcptr)sPtr[NT + NRING + e_id] : xe) + (long long)(qlo + 3) * kS;
+  gcptr xh_c = ((qlo + 2 >= dim) ? x_col_up(hcol, h_ok) : x_col(hcol)) + (long long)(qlo + 2) * kS;
+  gcptr xh2_c = H2 ? ((qlo + 2 >= dim) ? x_col_up(h2col, h2_ok) : x_col(h2col)) + (long long)(qlo + 2) * kS : xh_c;
+  gcptr al_c = al_col(qlo + 1 >= dim) + (long long)(qlo + 1) * kS;
+  gcptr xe_c = xe_col(qlo + 3 >= dim) + (long long)(qlo + 3) * kS;
   const int qend = top ? dim : qhi;                                                 // at the top of the domain one more step: B(dim-1) after t's ghost plane
+#ifdef HPGMG_EXP_TIMELINE
+  // wave 0 and the last (ring) wave of one workgroup in the middle of the grid: the 100 MHz clock at nine points of every step
+  const bool probe = P.timeline && logical == P.total_blocks / 2 + 3 && (tid & 63) == 0;
+  unsigned long long *tl = P.timeline + (tid >> 6) * 2048;
+  int tl_n = 0;
+#define TL_MARK() do { if (probe && tl_n < 2040) tl[tl_n++] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define TL_MARK() do { } while (0)
+#endif
+  // the waves that also carry the ring have the longest step and everybody else waits for them at the barriers: they issue first
+  if (tid < ((NRING + 63) / 64) * 64) __builtin_amdgcn_s_setprio(2);
   for (int q = qlo; q <= qend; q++) {
+    TL_MARK();                                                                      // 0
     __syncthreads();                                                                // [A] the planes stored at the end of the previous step are in place
+    TL_MARK();                                                                      // 1
     const bool do_r = q <= qhi, more = q + 1 <= qhi;                                // more: there is an R(q+1)
     const int up = is_red(gi, gj, q) ? 0 : 1;                                      // the red cell of the own pair on plane q: 0 lower, 1 upper
     // ---- "special" red cells of this step (see the head of the file): t comes from P.tg's interior.  These loads are the FIRST of the step, so
@@ -348,16 +489,23 @@ __global__ __launch_bounds__(512) void fv4_rb_kernel(const hpgmg_hip_level L, co
     double t_spo = 0.0, t_spe = 0.0;
     if (__builtin_expect(sp_o, 0)) t_spo = (q >= dim) ? tgb_hi[own_o + up * ujS + (long long)q * kS] : sel_origin(L, P.tg, nb[4])[own_g + up * jS + (q + dim) * kS];
     if (__builtin_expect(sp_e, 0)) {
-      if (q >= 0) t_spe = ((gcptr)sPtr[NT + (q >= dim ? 3 : 2) * NRING + e_id])[ec * e_step + (long long)q * kS];
+      if (q >= 0) t_spe = (PARK ? (gcptr)sPtr[NT + (q >= dim ? 3 : 2) * NRING + e_id] : tge_col(q >= dim))[ec * e_step + (long long)q * kS];
       else { const int m = L.box_nbr[6 * acol.box + 4]; t_spe = (sel_origin(L, P.tg, m) + acol.off)[ec * e_step + (long long)(q + dim) * kS]; }
     }
     // ---- loads of this step (consumed at its end or in the next step)
-    // aux0 .. aux2: the coefficient halo cell (lanes 0 .. 331: beta_i, beta_j, beta_k) or the ring pair's red cell (lanes 432 ..: rhs, Dinv, x two planes up)
-    double n_x0 = 0.0, n_x1 = 0.0, n_hx = 0.0, n_bi0 = 0.0, n_bi1 = 0.0, n_bj0 = 0.0, n_bj1 = 0.0, n_bk0 = 0.0, n_bk1 = 0.0, aux0 = 0.0, aux1 = 0.0, aux2 = 0.0;
-    double n_rhs0 = 0.0, n_rhs1 = 0.0, n_dinv0 = 0.0, n_dinv1 = 0.0, n_al0 = 0.0, n_al1 = 0.0, ne_al = 0.0;
-    if (more) {
+    // aux0 .. aux2: the coefficient halo cell (lanes 0 .. NBH-1: beta_i, beta_j, beta_k); eax0 .. eax2: the ring pair's red cell (the last NRING lanes:
+    // rhs, Dinv, x two planes up).  Separate registers although no lane has both roles: a second load into a register whose first load
+    // may still be in flight makes the wave wait for it -- here the ring waves, at the start of every step, for the prefetches before it
+    double n_x0 = 0.0, n_x1 = 0.0, n_hx = 0.0, n_hx2 = 0.0, n_bi0, n_bi1, n_bj0, n_bj1, n_bk0, n_bk1, aux0, aux1, aux2;      // the rest: defined whenever it is used
+    double eax0, eax1, eax2;
+    double n_rhs0, n_rhs1, n_dinv0, n_dinv1, n_al0 = 0.0, n_al1 = 0.0, ne_al = 0.0;
+    // A CU passes these loads on at about 16 B per clock, so the 80 KB of a step take 2 us to ISSUE and the waves served last sat
+    // in this block while the first ones computed (timeline: 0.7 us for the first, 2.2 us for the last wave).  So the second half of the
+    // workgroup runs its R stage first and issues afterwards, when the first half has moved on: both halves find the path free.
+    auto prefetch = [&]() {
       const int p2 = q + 2, p3 = q + 3, p1 = q + 1;
       if (h_ok) n_hx = xh_c[0];
+      if (H2 && h2_ok) n_hx2 = xh2_c[0];
       { // coefficients: always the own box's arrays, ghost planes included
         gcptr bi = lvb + (size_t)VECTOR_BETA_I * vol, bj = lvb + (size_t)VECTOR_BETA_J * vol, bk = lvb + (size_t)VECTOR_BETA_K * vol;
         const unsigned o = own_b + (unsigned)p2 * bkS;
@@ -372,49 +520,75 @@ __global__ __launch_bounds__(512) void fv4_rb_kernel(const hpgmg_hip_level L, co
       if (e_in) {
         const int c = e_red(p1);
         gcptr a = al_c + c * e_step;
-        aux0 = a[(size_t)P.rhs_id * vol]; aux1 = a[(size_t)VECTOR_DINV * vol]; if (kHelm) ne_al = a[(size_t)VECTOR_ALPHA * vol];
-        aux2 = xe_c[c * e_step];
+        eax0 = a[(size_t)P.rhs_id * vol]; eax1 = a[(size_t)VECTOR_DINV * vol]; if (kHelm) ne_al = a[(size_t)VECTOR_ALPHA * vol];
+        eax2 = xe_c[c * e_step];
       }
-    }
-
+    };
+    const bool late = tid >= NT / 2;                                                // the same for every lane of a wave
     double r_new = 0.0;                                                             // t at the own pair's red cell of plane q
+    const double *X0 = sX + slot4(q) * PX, *Xm = sX + slot4(q - 1) * PX, *Xp = sX + slot4(q + 1) * PX, *Xmm = sX + slot4(q - 2) * PX;
+    const double *I0 = sBI + slot3(q) * PB, *Im = sBI + slot3(q - 1) * PB, *Ip = sBI + slot3(q + 1) * PB;
+    const double *J0 = sBJ + slot3(q) * PB, *Jm = sBJ + slot3(q - 1) * PB, *Jp = sBJ + slot3(q + 1) * PB;
+    const double *K0 = sBK + slot2(q) * PB, *K1 = sBK + slot2(q + 1) * PB;
+    auto gather = [&](X25 &x, int o, double kp2) {                               // the 25 values around position o of the x planes
+      constexpr int W = WX;
+      x.c = X0[o]; x.im1 = X0[o - 1]; x.ip1 = X0[o + 1]; x.im2 = X0[o - 2]; x.ip2 = X0[o + 2];
+      x.jm1 = X0[o - W]; x.jp1 = X0[o + W]; x.jm2 = X0[o - 2 * W]; x.jp2 = X0[o + 2 * W];
+      x.km1 = Xm[o]; x.kp1 = Xp[o]; x.km2 = Xmm[o]; x.kp2 = kp2;
+      x.mm = X0[o - 1 - W]; x.pm = X0[o + 1 - W]; x.mp = X0[o - 1 + W]; x.pp = X0[o + 1 + W];
+      x.m_im = Xm[o - 1]; x.m_ip = Xm[o + 1]; x.m_jm = Xm[o - W]; x.m_jp = Xm[o + W];
+      x.p_im = Xp[o - 1]; x.p_ip = Xp[o + 1]; x.p_jm = Xp[o - W]; x.p_jp = Xp[o + W];
+    };
+    if (more && !late) prefetch();
+    TL_MARK();                                                                      // 2: loads issued (first half of the workgroup)
     if (do_r) {
-      const double *X0 = sX + slot4(q) * PX, *Xm = sX + slot4(q - 1) * PX, *Xp = sX + slot4(q + 1) * PX, *Xmm = sX + slot4(q - 2) * PX;
-      const double *I0 = sBI + slot3(q) * PB, *Im = sBI + slot3(q - 1) * PB, *Ip = sBI + slot3(q + 1) * PB;
-      const double *J0 = sBJ + slot3(q) * PB, *Jm = sBJ + slot3(q - 1) * PB, *Jp = sBJ + slot3(q + 1) * PB;
-      const double *K0 = sBK + slot2(q) * PB, *K1 = sBK + slot2(q + 1) * PB;
-      auto gather = [&](X25 &x, int o, double kp2) {                               // the 25 values around position o of the x planes
-        constexpr int W = WX;
-        x.c = X0[o]; x.im1 = X0[o - 1]; x.ip1 = X0[o + 1]; x.im2 = X0[o - 2]; x.ip2 = X0[o + 2];
-        x.jm1 = X0[o - W]; x.jp1 = X0[o + W]; x.jm2 = X0[o - 2 * W]; x.jp2 = X0[o + 2 * W];
-        x.km1 = Xm[o]; x.kp1 = Xp[o]; x.km2 = Xmm[o]; x.kp2 = kp2;
-        x.mm = X0[o - 1 - W]; x.pm = X0[o + 1 - W]; x.mp = X0[o - 1 + W]; x.pp = X0[o + 1 + W];
-        x.m_im = Xm[o - 1]; x.m_ip = Xm[o + 1]; x.m_jm = Xm[o - W]; x.m_jp = Xm[o + W];
-        x.p_im = Xp[o - 1]; x.p_ip = Xp[o + 1]; x.p_jm = Xp[o - W]; x.p_jp = Xp[o + W];
-      };
       { // ---- R(q) at the red cell of the own pair (gsrb.c:100-104)
-        X25 x; B18 bt;
+        X25 x; BG1 g1; BG2 g2; Br18 br;
         const int oX = ownX + up * WX, oB = ownB + up * WB;
+        FV4RB_FENCE();
         gather(x, oX, up ? kp2_1 : kp2_0);
-        beta18(bt, I0 + oB, Im + oB, Ip + oB, J0 + oB, Jm + oB, Jp + oB, K0 + oB, K1 + oB);
-        const double sum = fv4_sum(x, bt);
+        beta_g1<WB>(g1, I0 + oB, Im + oB, Ip + oB, J0 + oB, Jm + oB, Jp + oB, K0 + oB, K1 + oB);
+        FV4RB_FENCE();
+        fv4_brackets(br, x);                    // under the arrival of group 1
+        FV4RB_FENCE();
+        beta_g2<WB>(g2, I0 + oB, Im + oB, Ip + oB, J0 + oB, Jm + oB, Jp + oB, K0 + oB, K1 + oB);
+        FV4RB_FENCE();
+        double s1, s2;
+        fv4_combine_a(s1, s2, br, g1);          // under the arrival of group 2
+        FV4RB_FENCE();
+        const double sum = fv4_combine_b(s1, s2, br, g2);
         const double alv = up ? c_al1 : c_al0, rhs = up ? c_rhs1 : c_rhs0, dinv = up ? c_dinv1 : c_dinv0;
         const double Ax = kHelm ? (P.a * alv) * x.c - bh2inv * sum : nbh2inv * sum;
         r_new = x.c + dinv * (rhs - Ax);
-        if (__builtin_expect(sp_o, 0)) r_new = t_spo;                               // a special cell (a plane of another box next to a wall)
+        // a special cell (a plane of another box next to a wall).  A real branch (the empty asm keeps it from becoming a select): only there
+        // does anything wait for t_spo, which means waiting for every prefetch issued after it
+        if (__builtin_expect(sp_o, 0)) { asm volatile("" ::: "memory"); r_new = t_spo; }
         sT[slot3(q) * PT + ownT + up * ST] = r_new;
         if (q >= k0 && q < k1) gst(outb, own_b + up * bjS + (unsigned)q * bkS, r_new);      // the pair's red cell on plane q is final: x' = t there
       }
+    }
+    TL_MARK();                                                                      // 3: R own
+    if (more && late) prefetch();
+    if (do_r) {
       if (e_in) { // ---- R(q) at the red cell of the ring pair
-        X25 x; B18 bt;
+        X25 x; BG1 g1; BG2 g2; Br18 br;
         const int ci = eci, cj = ecj;
         const int oX = posX(ci, cj), oB = posB(ci, cj);
+        FV4RB_FENCE();
         gather(x, oX, e_xp2);
-        beta18(bt, I0 + oB, Im + oB, Ip + oB, J0 + oB, Jm + oB, Jp + oB, K0 + oB, K1 + oB);
-        const double sum = fv4_sum(x, bt);
+        beta_g1<WB>(g1, I0 + oB, Im + oB, Ip + oB, J0 + oB, Jm + oB, Jp + oB, K0 + oB, K1 + oB);
+        FV4RB_FENCE();
+        fv4_brackets(br, x);
+        FV4RB_FENCE();
+        beta_g2<WB>(g2, I0 + oB, Im + oB, Ip + oB, J0 + oB, Jm + oB, Jp + oB, K0 + oB, K1 + oB);
+        FV4RB_FENCE();
+        double s1, s2;
+        fv4_combine_a(s1, s2, br, g1);
+        FV4RB_FENCE();
+        const double sum = fv4_combine_b(s1, s2, br, g2);
         const double Ax = kHelm ? (P.a * e_al) * x.c - bh2inv * sum : nbh2inv * sum;
         double tv = x.c + e_dinv * (e_rhs - Ax);
-        if (__builtin_expect(sp_e, 0)) tv = t_spe;
+        if (__builtin_expect(sp_e, 0)) { asm volatile("" ::: "memory"); tv = t_spe; }
         sT[slot3(q) * PT + posT(ci, cj)] = tv;
       }
     }
@@ -423,17 +597,19 @@ __global__ __launch_bounds__(512) void fv4_rb_kernel(const hpgmg_hip_level L, co
     // one wave's LDS reads under another's arithmetic -- except where the ghost cells of t have to be formed from the neighbours' results:
     // ghost values of t: in i / j on plane q (tiles at a wall); below the domain after R(0); above it after R(dim-1) (the x ring's part:
     // B(dim-2) reads it in this step) and in the extra step (the t ring's part, whose slot B(dim-2) still needed)
+    TL_MARK();                                                                      // 4: R ring
     const int kfill = (bottom && q == 0) ? 1 : ((top && q == dim - 1) ? 2 : ((top && q == dim) ? 3 : 0));
     if (__builtin_expect((tile_wall && do_r) || kfill, 0)) {
       __syncthreads();                                                              // [B] t on plane q is complete inside the domain
-      if (tile_wall && do_r && (bc_pack & 3)) {
+      const int bc_pack = (tile_wall && do_r) ? sBC[tid] : 0;
+      if (bc_pack & 3) {
         const int bc_kind = bc_pack & 3, bc_i = ((bc_pack >> 2) & 127) - 4, bc_j = ((bc_pack >> 9) & 31) - 4, bc_si = ((bc_pack >> 14) & 3) - 1, bc_sj = ((bc_pack >> 16) & 3) - 1;
         // ---- ghost cells of t on plane q outside the domain in i / j: apply_BCs_v4 (boundary_fv.c:262-425) from t itself
         const bool red = is_red(i0 + bc_i, j0 + bc_j, q);
         if (bc_kind == 3) {
           if (!red) {                                                               // read by the diagonal black cell only
             double n4[4];
-#pragma unroll
+#pragma unroll 1
             for (int m = 0; m < 4; m++) {
               const int cj = bc_j + (m + 1) * bc_sj;
               n4[m] = v4_near(t_at(bc_i + bc_si, cj, q), t_at(bc_i + 2 * bc_si, cj, q), t_at(bc_i + 3 * bc_si, cj, q), t_at(bc_i + 4 * bc_si, cj, q));
@@ -451,11 +627,13 @@ __global__ __launch_bounds__(512) void fv4_rb_kernel(const hpgmg_hip_level L, co
       if (__builtin_expect(kfill != 0, 0)) {
         // ---- the ghost plane of t below / above the domain (P.tg): red-parity own cells into the t ring, black-parity positions over x's
         const int pg = (kfill == 1) ? -1 : dim;
-        const double t0 = tgb[(long long)own_o + (long long)pg * kS], t1 = tgb[(long long)own_o + jS + (long long)pg * kS];
+        double t0 = tgb[(long long)own_o + (long long)pg * kS], t1 = tgb[(long long)own_o + jS + (long long)pg * kS];
+        asm volatile("" : "+v"(t0), "+v"(t1));             // landed here, on every path: a load still pending at the join would make the common path wait
         const bool red0 = is_red(gi, gj, pg);
         if (kfill != 3) {
           sX[slot4(pg) * PX + ownX + (red0 ? WX : 0)] = red0 ? t1 : t0;
           if (h_face && !is_red(i0 + hi, j0 + hj, pg)) sX[slot4(pg) * PX + hX] = (sel_origin(L, P.tg, hcol.box) + hcol.off)[pg * kS];
+          if (H2 && h2_face && !is_red(i0 + h2i, j0 + h2j, pg)) sX[slot4(pg) * PX + h2X] = (sel_origin(L, P.tg, h2col.box) + h2col.off)[pg * kS];
         }
         if (kfill != 2) sT[slot3(pg) * PT + ownT + (red0 ? 0 : ST)] = red0 ? t0 : t1;
         if (kfill == 1) sX[slot4(-2) * PX + ownX + (red0 ? 0 : WX)] = tgb[(long long)own_o + (red0 ? 0 : jS) - 2LL * kS];   // two below: black parity where plane -1 is red
@@ -467,6 +645,7 @@ __global__ __launch_bounds__(512) void fv4_rb_kernel(const hpgmg_hip_level L, co
     const int r = q - 1;
     if (r >= k0 && r < k1) {
       X25 x; B18 bt;
+      FV4RB_FENCE();
       const double *X0 = sX + slot4(r) * PX, *Xm = sX + slot4(r - 1) * PX, *Xp = sX + slot4(r + 1) * PX;
       const double *T0 = sT + slot3(r) * PT, *Tm = sT + slot3(r - 1) * PT, *Tp = sT + slot3(r + 1) * PT;
       const int row = 2 * lj + up;
@@ -475,7 +654,11 @@ __global__ __launch_bounds__(512) void fv4_rb_kernel(const hpgmg_hip_level L, co
       x.c = X0[o];
       x.km2 = kmB;
       x.kp2 = sX[slot4(q + 1) * PX + o];
-      if (__builtin_expect(top && q == dim, 0)) x.kp2 = tgb[own_o + up * ujS + (unsigned)(dim + 1) * ukS];
+      if (__builtin_expect(top && q == dim, 0)) {                                  // landed before the branch is left: no pending load may reach the common path
+        double v = tgb[own_o + up * ujS + (unsigned)(dim + 1) * ukS];
+        asm volatile("" : "+v"(v));
+        x.kp2 = v;
+      }
       x.im1 = T0[posT(li - 1, row)]; x.ip1 = T0[posT(li + 1, row)]; x.jm1 = T0[posT(li, row - 1)]; x.jp1 = T0[posT(li, row + 1)];
       x.km1 = Tm[posT(li, row)];
       x.kp1 = do_r ? r_new : Tp[posT(li, row)];                                     // the own column on plane q: what R has just formed (the extra step at the top of the domain: its ghost value)
@@ -485,44 +668,73 @@ __global__ __launch_bounds__(512) void fv4_rb_kernel(const hpgmg_hip_level L, co
       x.p_im = Xp[o - 1]; x.p_ip = Xp[o + 1]; x.p_jm = Xp[o - W]; x.p_jp = Xp[o + W];
       // coefficients: beta_i / beta_j plane r and beta_k face r+1 are still in the rings, the rest was formed in the previous step
       const double *I0 = sBI + slot3(r) * PB + oB, *J0 = sBJ + slot3(r) * PB + oB, *K1 = sBK + slot2(r + 1) * PB + oB;
-      bt.f[0] = I0[0]; bt.f[1] = I0[1]; bt.f[2] = J0[0]; bt.f[3] = J0[V2]; bt.f[4] = pf4; bt.f[5] = K1[0];
-      bt.d[0] = I0[V2] - I0[-V2]; bt.d[1] = pd1; bt.d[2] = J0[1] - J0[-1]; bt.d[3] = pd3; bt.d[4] = pd4; bt.d[5] = pd5;
-      bt.d[6] = I0[1 + V2] - I0[1 - V2]; bt.d[7] = pd7; bt.d[8] = J0[V2 + 1] - J0[V2 - 1]; bt.d[9] = pd9;
-      bt.d[10] = K1[1] - K1[-1]; bt.d[11] = K1[V2] - K1[-V2];
-      const double sum = fv4_sum(x, bt);
+      const double i00 = I0[0], i01 = I0[1], j00 = J0[0], jw0 = J0[V2], k10 = K1[0], i0p = I0[V2], i0m = I0[-V2], j01 = J0[1], j0m = J0[-1];
+      FV4RB_FENCE();
+      Br18 br;
+      fv4_brackets(br, x);
+      FV4RB_FENCE();
+      const double i0pp = I0[1 + V2], i0mp = I0[1 - V2], jwp = J0[V2 + 1], jwm = J0[V2 - 1], k1p = K1[1], k1m = K1[-1], k1w = K1[V2], k1mw = K1[-V2];
+      FV4RB_FENCE();
+      bt.f[0] = i00; bt.f[1] = i01; bt.f[2] = j00; bt.f[3] = jw0; bt.f[4] = pf4; bt.f[5] = k10;
+      bt.d[0] = i0p - i0m; bt.d[1] = pd1; bt.d[2] = j01 - j0m; bt.d[3] = pd3; bt.d[4] = pd4; bt.d[5] = pd5;
+      bt.d[6] = i0pp - i0mp; bt.d[7] = pd7; bt.d[8] = jwp - jwm; bt.d[9] = pd9;
+      bt.d[10] = k1p - k1m; bt.d[11] = k1w - k1mw;
+      const double sum = fv4_combine(br, bt);
       const double Ax = kHelm ? (P.a * b_al) * x.c - bh2inv * sum : nbh2inv * sum;
       gst(outb, own_b + up * bjS + (unsigned)r * bkS, x.c + b_dinv * (b_rhs - Ax));
                                // the pair's red cell on plane r: what R(r) formed
     }
+    TL_MARK();                                                                      // 5: B
     if (do_r) {
       // for B(q) in the next step, at the OTHER cell of the pair (black on plane q): the terms whose planes will have left the rings by then
       // (after B(q-1), which has just used the previous set)
       const double *Im = sBI + slot3(q - 1) * PB, *Ip = sBI + slot3(q + 1) * PB, *Jm = sBJ + slot3(q - 1) * PB, *Jp = sBJ + slot3(q + 1) * PB, *K0 = sBK + slot2(q) * PB;
       const int o2 = ownB + (1 - up) * WB;
-      pd1 = Ip[o2] - Im[o2]; pd7 = Ip[o2 + 1] - Im[o2 + 1]; pd3 = Jp[o2] - Jm[o2]; pd9 = Jp[o2 + WB] - Jm[o2 + WB];
-      pf4 = K0[o2]; pd4 = K0[o2 + 1] - K0[o2 - 1]; pd5 = K0[o2 + WB] - K0[o2 - WB];
+      FV4RB_FENCE();
+      const double ip0 = Ip[o2], im0 = Im[o2], ip1 = Ip[o2 + 1], im1 = Im[o2 + 1], jp0 = Jp[o2], jm0 = Jm[o2], jpw = Jp[o2 + WB], jmw = Jm[o2 + WB];
+      const double k00 = K0[o2], k0p = K0[o2 + 1], k0m = K0[o2 - 1], k0w = K0[o2 + WB], k0mw = K0[o2 - WB];
+      FV4RB_FENCE();
+      pd1 = ip0 - im0; pd7 = ip1 - im1; pd3 = jp0 - jm0; pd9 = jpw - jmw;
+      pf4 = k00; pd4 = k0p - k0m; pd5 = k0w - k0mw;
     }
+    TL_MARK();                                                                      // 6: coefficient terms for the next B
     __syncthreads();                                                                // [D] B is done with the plane that is overwritten now
+    TL_MARK();                                                                      // 7
     // t three planes below the NEXT plane at the cell B works on then (the other cell of the pair): still in the x ring, in a slot this lane itself overwrites next
     kmB = sX[slot4(q - 2) * PX + ownX + (1 - up) * WX];
     if (more) {
       const int p2 = q + 2, s = slot4(p2) * PX, sb = slot3(p2) * PB, sk = slot2(p2) * PB;
       sX[s + ownX] = kp2_0; sX[s + ownX + WX] = kp2_1;
       if (has_h) sX[s + hX] = n_hx;
+      if (has_h2) sX[s + h2X] = n_hx2;
       sBI[sb + ownB] = n_bi0; sBI[sb + ownB + WB] = n_bi1; sBJ[sb + ownB] = n_bj0; sBJ[sb + ownB + WB] = n_bj1; sBK[sk + ownB] = n_bk0; sBK[sk + ownB + WB] = n_bk1;
       if (has_b) { sBI[sb + bB] = aux0; sBJ[sb + bB] = aux1; sBK[sk + bB] = aux2; }
     }
+    // t_spo / t_spe stay live to this point, where every load of the step has landed: were their registers reused earlier, the reuse would have
+    // to wait for the (possibly still outstanding) special loads, i.e. for all prefetches, in the middle of the step
+    asm volatile("" :: "v"(t_spo), "v"(t_spe));
+#ifdef HPGMG_EXP_TIMELINE
+    if (probe) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
+    TL_MARK();                                                                      // 8: prefetched planes in LDS
     // ---- next plane
     b_rhs = up ? c_rhs0 : c_rhs1; b_dinv = up ? c_dinv0 : c_dinv1; b_al = up ? c_al0 : c_al1;      // the black cell of plane q: B(q) in the next step
     kp2_0 = n_x0; kp2_1 = n_x1;
     c_rhs0 = n_rhs0; c_rhs1 = n_rhs1; c_dinv0 = n_dinv0; c_dinv1 = n_dinv1; c_al0 = n_al0; c_al1 = n_al1;
-    if (has_e) { e_rhs = aux0; e_dinv = aux1; e_xp2 = aux2; }
+    if (has_e) { e_rhs = eax0; e_dinv = eax1; e_xp2 = eax2; }
     e_al = ne_al;
     // the marching pointers: one plane up; where a column leaves the top of its box, continue in the box above (parked in LDS)
+#ifdef HPGMG_EXP_TIMELINE
+    if (P.timeline && tid == 0 && logical < 8192) {
+      if (q == qlo) P.timeline[16384 + 3 * logical + 1] = __builtin_amdgcn_s_memrealtime();     // first step done (prologue + one step)
+      if (q == qend) P.timeline[16384 + 3 * logical + 2] = __builtin_amdgcn_s_memrealtime();    // last step done
+    }
+#endif
     xh_c += kS; al_c += kS; xe_c += kS;
-    if (__builtin_expect(q + 3 == dim, 0)) xh_c = (gcptr)sPtr[tid] + (long long)dim * kS;
-    if (__builtin_expect(q + 2 == dim, 0)) al_c = (gcptr)sPtr[NT + e_id] + (long long)dim * kS;
-    if (__builtin_expect(q + 4 == dim, 0)) xe_c = (gcptr)sPtr[NT + NRING + e_id] + (long long)dim * kS;
+    if (H2) xh2_c += kS;
+    if (__builtin_expect(q + 3 == dim, 0)) { xh_c = xh_up() + (long long)dim * kS; if (H2) xh2_c = x_col_up(h2col, h2_ok) + (long long)dim * kS; }
+    if (__builtin_expect(q + 2 == dim, 0)) al_c = al_up() + (long long)dim * kS;
+    if (__builtin_expect(q + 4 == dim, 0)) xe_c = xe_up() + (long long)dim * kS;
   }
 }
 

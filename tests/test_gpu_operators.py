@@ -419,14 +419,20 @@ def test_27pt_red_and_black_half_sweeps_in_one_pass(hip, oracle, geom):
         lh.destroy(); lo.destroy()
 
 
+@pytest.mark.parametrize("tile_width", [64, 32])
 @pytest.mark.parametrize("variant,geom", [("fv4-gsrb", (2, 64)), ("fv4-gsrb", (1, 64)), ("fv4-gsrb", (3, 64)), ("fv4-gsrb", (1, 128)), ("fv4-gsrb-helm", (2, 64)),
-                                          ("fv4-gsrb", (1, 64, "periodic")), ("fv4-gsrb", (2, 64, "periodic")), ("fv4-gsrb-helm", (1, 128)), ("fv4-gsrb", (2, 128))])
-def test_fv4_red_and_black_half_sweeps_in_one_pass(hip, oracle, variant, geom):
+                                          ("fv4-gsrb", (1, 64, "periodic")), ("fv4-gsrb", (2, 64, "periodic")), ("fv4-gsrb-helm", (1, 128)), ("fv4-gsrb", (2, 128)),
+                                          ("fv4-gsrb", (1, 32)), ("fv4-gsrb", (2, 32)), ("fv4-gsrb", (3, 32)), ("fv4-gsrb-helm", (2, 32)), ("fv4-gsrb", (2, 32, "periodic"))])
+def test_fv4_red_and_black_half_sweeps_in_one_pass(hip, oracle, variant, geom, tile_width, monkeypatch):
     """Inside a cycle (hpgmg_smooth_in_cycle: VECTOR_TEMP is scratch afterwards) the 4th-order GSRB smoother runs each red + black pair of its
     six half sweeps as ONE pass (fv4_rb.hpp): the intermediate vector lives in LDS, its quartic boundary extrapolation (apply_BCs_v4) is formed
     in LDS in i / j and by a pre-pass in k.  The iterate must equal the oracle's six separate half sweeps bit for bit -- 1, 8 and 27 boxes
     (every combination of domain walls and neighbouring boxes around a tile), Dirichlet and periodic, Poisson and Helmholtz, whole-box and
-    chunked k marches -- and the kernel must really have been the one launched."""
+    chunked k marches -- and the kernel must really have been the one launched.  Both tile widths: 64 x 16 (one workgroup of 8 waves per CU) and
+    32 x 16 (two workgroups of 4 waves; the only form for boxes of 32^3)."""
+    if geom[1] % 64 != 0 and tile_width == 64:
+        pytest.skip("boxes of 32^3 only have the 32-wide tiles")
+    monkeypatch.setenv("HPGMG_TUNE_FV4_RB_TI", str(tile_width))
     set_mode(hip, 1)
     K = H.load_kernels()
     lh, lo = make_pair(hip, oracle, variant, geom[0], geom[1], seed=17, bc=H.BC_PERIODIC if len(geom) > 2 else H.BC_DIRICHLET)
