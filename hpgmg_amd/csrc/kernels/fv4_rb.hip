@@ -27,7 +27,10 @@ long long hpgmg_hip_rb_fv4_launch_count(void) { return g_rb4_launches; }
 int hpgmg_hip_smooth_gsrb_fv4_rb_supported(const hpgmg_hip_level *L, int variant) {
   static const int off = env_int("HPGMG_TUNE_FV4_NO_RB", 0);
   if (variant != HPGMG_HIP_FV4_VC_HELMHOLTZ && variant != HPGMG_HIP_FV4_VC_POISSON) return 0;
-  return !off && L->num_boxes > 0 && L->dim % 32 == 0 && L->box_nbr != nullptr && L->ghosts == 2;
+  // boxes of side 64 m; 32-wide tiles (two workgroups per CU) also take boxes of 32^3, but measured slower there than two half-sweep launches
+  // of the tiled kernel (98 vs 2 x 35 us on a 128^3 level of 64 boxes: the march is too short for its prologue), so only on request
+  const int need = (env_int("HPGMG_TUNE_FV4_RB_TI", 0) == 32) ? 32 : 64;
+  return !off && L->num_boxes > 0 && L->dim % need == 0 && L->box_nbr != nullptr && L->ghosts == 2;
 }
 static VecSel vec_sel(const hpgmg_hip_level *L, double *const *scr_base, int scratch, int id) { return VecSel{scratch ? scr_base : L->box_base, id}; }
 // The ghost planes of the intermediate vector t below / above the domain, into the k ghost zone of scratch vector tg_id: a red half sweep
@@ -87,7 +90,7 @@ int hpgmg_hip_smooth_gsrb_fv4_rb(const hpgmg_hip_level *L, int variant, double *
   A.total_blocks = L->num_boxes * A.chunks_k * A.tiles_j * A.tiles_i;
   const int grid = grid_for(A.total_blocks, &A.per_xcd);
 #ifdef HPGMG_EXP_TIMELINE
-  A.timeline = g_fv4rb_timeline;
+  A.timeline = g_fv4rb_timeline; A.timeline_wg = env_int("HPGMG_EXP_TIMELINE_WG", -1);
 #endif
   const long long cells = (long long)L->num_boxes * L->dim * L->dim * L->dim;
   const int prof = profile_begin(cells);

@@ -48,6 +48,7 @@ struct Fv4RbArgs {
   double a, b, h2inv;
   int sweep;                            // number of the first (even) half sweep: its colour is (i ^ j ^ k ^ sweep) & 1 == 0
   int tiles_i, tiles_j, chunks_k, kchunk, per_xcd, total_blocks;
+  int timeline_wg;                      // ... which workgroup (logical index; < 0: one in the middle of the grid)
   unsigned long long *timeline;         // experiment builds (-DHPGMG_EXP_TIMELINE): where two waves of one workgroup record the clock at the stage boundaries
 };
 
@@ -464,7 +465,7 @@ __global__ __launch_bounds__(TI_ * 8, 2) void fv4_rb_kernel(const hpgmg_hip_leve
   const int qend = top ? dim : qhi;                                                 // at the top of the domain one more step: B(dim-1) after t's ghost plane
 #ifdef HPGMG_EXP_TIMELINE
   // wave 0 and the last (ring) wave of one workgroup in the middle of the grid: the 100 MHz clock at nine points of every step
-  const bool probe = P.timeline && logical == P.total_blocks / 2 + 3 && (tid & 63) == 0;
+  const bool probe = P.timeline && logical == (P.timeline_wg >= 0 ? P.timeline_wg : P.total_blocks / 2 + 3) && (tid & 63) == 0;
   unsigned long long *tl = P.timeline + (tid >> 6) * 2048;
   int tl_n = 0;
 #define TL_MARK() do { if (probe && tl_n < 2040) tl[tl_n++] = __builtin_amdgcn_s_memrealtime(); } while (0)
@@ -601,6 +602,7 @@ __global__ __launch_bounds__(TI_ * 8, 2) void fv4_rb_kernel(const hpgmg_hip_leve
     const int kfill = (bottom && q == 0) ? 1 : ((top && q == dim - 1) ? 2 : ((top && q == dim) ? 3 : 0));
     if (__builtin_expect((tile_wall && do_r) || kfill, 0)) {
       __syncthreads();                                                              // [B] t on plane q is complete inside the domain
+      TL_MARK();
       const int bc_pack = (tile_wall && do_r) ? sBC[tid] : 0;
       if (bc_pack & 3) {
         const int bc_kind = bc_pack & 3, bc_i = ((bc_pack >> 2) & 127) - 4, bc_j = ((bc_pack >> 9) & 31) - 4, bc_si = ((bc_pack >> 14) & 3) - 1, bc_sj = ((bc_pack >> 16) & 3) - 1;
@@ -638,8 +640,10 @@ __global__ __launch_bounds__(TI_ * 8, 2) void fv4_rb_kernel(const hpgmg_hip_leve
         if (kfill != 2) sT[slot3(pg) * PT + ownT + (red0 ? 0 : ST)] = red0 ? t0 : t1;
         if (kfill == 1) sX[slot4(-2) * PX + ownX + (red0 ? 0 : WX)] = tgb[(long long)own_o + (red0 ? 0 : jS) - 2LL * kS];   // two below: black parity where plane -1 is red
       }
+      TL_MARK();
       __syncthreads();                                                              // [C]
-    }
+      TL_MARK();
+    } else { TL_MARK(); TL_MARK(); TL_MARK(); }
 
     // ---- B(r), r = q - 1: the black half sweep at the cell of the own pair that is red on plane q (black on plane r)
     const int r = q - 1;

@@ -26,14 +26,14 @@ K.hpgmg_hip_sync()
 K.hpgmg_hip_exp_timeline_fv4(None)
 host = np.zeros(NB, dtype=np.uint64)
 K.hpgmg_hip_memcpy_d2h(ctypes.c_void_p(host.ctypes.data), ctypes.c_void_p(buf), NB * 8)
-names = ["barrier A", "issue loads", "R own", "R ring", "BC + B", "pd", "barrier D", "wait loads + LDS stores"]
+names = ["barrier A", "issue loads", "R own", "R ring", "barrier B", "BC", "barrier C", "B", "pd", "barrier D", "wait loads + LDS stores"]
 for wsel in range(8):
     label = f"wave {wsel}"
     t = host[wsel * 2048: wsel * 2048 + 2040]
-    n = int(np.count_nonzero(t)); steps = n // 9
+    n = int(np.count_nonzero(t)); steps = n // 12
     if steps < 4:
         print(label, "no record", n); continue
-    tt = t[:steps * 9].astype(np.float64).reshape(steps, 9) * 0.01    # us
+    tt = t[:steps * 12].astype(np.float64).reshape(steps, 12) * 0.01    # us
     d = np.diff(tt, axis=1)[4:-4]                                       # steady state
     tot = (tt[-4, 0] - tt[4, 0]) / (steps - 8)
     print(f"{label}: {steps} steps, {tot:.2f} us per step; " + "  ".join(f"{nm} {v:.2f}" for nm, v in zip(names, d.mean(axis=0))) + f"  loop {tot - d.mean(axis=0).sum():.2f}")
