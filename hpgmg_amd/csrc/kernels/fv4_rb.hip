@@ -2,6 +2,7 @@
 // A translation unit of its own: the kernel lives at the edge of the 256 registers two waves per SIMD leave it, and is compiled with the
 // register-minimising scheduler (Makefile: FLAGS_fv4_rb) without changing how the other kernels are scheduled.
 #include <stdlib.h>
+#include <vector>
 #include "common.hpp"
 #include "fv4_tile.hpp"
 #include "fv4_rb.hpp"
@@ -31,6 +32,40 @@ int hpgmg_hip_smooth_gsrb_fv4_rb_supported(const hpgmg_hip_level *L, int variant
   // of the tiled kernel (98 vs 2 x 35 us on a 128^3 level of 64 boxes: the march is too short for its prologue), so only on request
   const int need = (env_int("HPGMG_TUNE_FV4_RB_TI", 0) == 32) ? 32 : 64;
   return !off && L->num_boxes > 0 && L->dim % need == 0 && L->box_nbr != nullptr && L->ghosts == 2;
+}
+// Dispatch order of the tiles.  A tile at a domain wall in i or j forms the boundary values of the intermediate vector in every step
+// (two more barriers, a short serial stage): its workgroup takes about a quarter longer, and with 4 workgroups per CU in a launch the
+// CUs that drew several of them finish last.  Each XCD keeps its contiguous range of tiles (common.hpp) but starts with the slow ones.
+// Built once per (level geometry, tiling) from the box neighbour table; any order gives the same numbers.
+struct TileOrder { const int *nbr; int num_boxes, dim, ti, kchunk, grid; int *d_order; };
+static std::vector<TileOrder> g_tile_orders;
+static const int *tile_order(const hpgmg_hip_level *L, const Fv4RbArgs &A, int TI, int grid) {
+  static const int on = env_int("HPGMG_TUNE_FV4_RB_ORDER", 1);
+  if (!on || A.total_blocks <= 256) return nullptr;                  // one round: every workgroup starts at once anyway
+  for (const TileOrder &o : g_tile_orders)
+    if (o.nbr == L->box_nbr && o.num_boxes == L->num_boxes && o.dim == L->dim && o.ti == TI && o.kchunk == A.kchunk && o.grid == grid) return o.d_order;
+  std::vector<int> nbr(6 * (size_t)L->num_boxes), order((size_t)grid);
+  if (hipMemcpy(nbr.data(), L->box_nbr, nbr.size() * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return nullptr;
+  for (int x = 0; x < kXcds; x++) {
+    int pos = x * A.per_xcd;
+    for (int pass = 0; pass < 2; pass++)
+      for (int l = x * A.per_xcd; l < (x + 1) * A.per_xcd; l++) {
+        if (l >= A.total_blocks) continue;
+        int t = l;
+        const int ti = t % A.tiles_i; t /= A.tiles_i;
+        const int tj = t % A.tiles_j; t /= A.tiles_j;
+        t /= A.chunks_k;
+        const int *nb = &nbr[6 * (size_t)t];
+        const bool wall = (nb[0] == -1 && ti == 0) || (nb[1] == -1 && ti == A.tiles_i - 1) || (nb[2] == -1 && tj == 0) || (nb[3] == -1 && tj == A.tiles_j - 1);
+        if (wall == (pass == 0)) order[pos++] = l;
+      }
+    while (pos < (x + 1) * A.per_xcd) order[pos++] = A.total_blocks;      // the padding of the grid: nothing to do
+  }
+  int *d = nullptr;
+  if (hipMalloc(&d, order.size() * sizeof(int)) != hipSuccess) return nullptr;
+  if (hipMemcpy(d, order.data(), order.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return nullptr; }
+  g_tile_orders.push_back(TileOrder{L->box_nbr, L->num_boxes, L->dim, TI, A.kchunk, grid, d});
+  return d;
 }
 static VecSel vec_sel(const hpgmg_hip_level *L, double *const *scr_base, int scratch, int id) { return VecSel{scratch ? scr_base : L->box_base, id}; }
 // The ghost planes of the intermediate vector t below / above the domain, into the k ghost zone of scratch vector tg_id: a red half sweep
@@ -89,6 +124,7 @@ int hpgmg_hip_smooth_gsrb_fv4_rb(const hpgmg_hip_level *L, int variant, double *
   A.kchunk = kchunk; A.chunks_k = (L->dim + kchunk - 1) / kchunk;
   A.total_blocks = L->num_boxes * A.chunks_k * A.tiles_j * A.tiles_i;
   const int grid = grid_for(A.total_blocks, &A.per_xcd);
+  A.order = tile_order(L, A, TI, grid);
 #ifdef HPGMG_EXP_TIMELINE
   A.timeline = g_fv4rb_timeline; A.timeline_wg = env_int("HPGMG_EXP_TIMELINE_WG", -1);
 #endif

@@ -48,6 +48,7 @@ struct Fv4RbArgs {
   double a, b, h2inv;
   int sweep;                            // number of the first (even) half sweep: its colour is (i ^ j ^ k ^ sweep) & 1 == 0
   int tiles_i, tiles_j, chunks_k, kchunk, per_xcd, total_blocks;
+  const int *order;                     // dispatch slot -> tile (nullptr: identity): the tiles at a domain wall take longer, so each XCD starts with them
   int timeline_wg;                      // ... which workgroup (logical index; < 0: one in the middle of the grid)
   unsigned long long *timeline;         // experiment builds (-DHPGMG_EXP_TIMELINE): where two waves of one workgroup record the clock at the stage boundaries
 };
@@ -246,7 +247,8 @@ __global__ __launch_bounds__(TI_ * 8, 2) void fv4_rb_kernel(const hpgmg_hip_leve
   int *sBC = (int *)(sT + 3 * PT);                                             // one boundary-cell descriptor per lane (tiles at a wall)
   unsigned long long *sPtr = (unsigned long long *)(sT + 3 * PT + NT / 2);     // PARK only
 
-  const int logical = xcd_logical_block((int)blockIdx.x, P.per_xcd);
+  int logical = xcd_logical_block((int)blockIdx.x, P.per_xcd);
+  if (P.order) logical = P.order[logical];
   if (logical >= P.total_blocks) return;
   int t = logical;
   const int ti = t % P.tiles_i; t /= P.tiles_i;
