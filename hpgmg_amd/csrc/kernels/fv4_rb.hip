@@ -76,10 +76,12 @@ int hpgmg_hip_fv4_rb_prepass(const hpgmg_hip_level *L, int variant, double *cons
                              double a, double b, double h2inv, int sweep, const hpgmg_hip_bc_entry *entries_k, int n_k, const int *special_cells, int n_special) {
   HPGMG_SKIP_IF_REPLAY();
   if (!hpgmg_hip_smooth_gsrb_fv4_rb_supported(L, variant) || (sweep & 1) || !scr_base) return record_error(hipErrorInvalidValue, "fv4_rb_prepass: level / arguments not supported");
-  if (n_special > 0) {                                     // the cells of internal box faces next to a domain wall: their t with the owning box's coefficients
-    Fv4SpecialArgs S = {};
-    S.x = vec_sel(L, scr_base, x_scratch, x_id); S.tg = vec_sel(L, scr_base, 1, tg_id); S.rhs_id = rhs_id; S.a = a; S.b = b; S.h2inv = h2inv; S.sweep = sweep;
-    S.cells = special_cells; S.n = n_special;
+  // the cells of internal box faces next to a domain wall: their t with the owning box's coefficients -- in the same launch as the planes
+  // next to the k walls when there are any
+  Fv4SpecialArgs S = {};
+  S.x = vec_sel(L, scr_base, x_scratch, x_id); S.tg = vec_sel(L, scr_base, 1, tg_id); S.rhs_id = rhs_id; S.a = a; S.b = b; S.h2inv = h2inv; S.sweep = sweep;
+  S.cells = special_cells; S.n = n_special > 0 ? n_special : 0;
+  if (n_special > 0 && n_k <= 0) {
     if (variant == HPGMG_HIP_FV4_VC_HELMHOLTZ) hipLaunchKernelGGL((fv4_special_kernel<HPGMG_HIP_FV4_VC_HELMHOLTZ>), dim3((n_special + 255) / 256), dim3(256), 0, g_stream, *L, S);
     else hipLaunchKernelGGL((fv4_special_kernel<HPGMG_HIP_FV4_VC_POISSON>), dim3((n_special + 255) / 256), dim3(256), 0, g_stream, *L, S);
     HPGMG_LAUNCH_CHECK("fv4_special_kernel");
@@ -93,13 +95,14 @@ int hpgmg_hip_fv4_rb_prepass(const hpgmg_hip_level *L, int variant, double *cons
     P.tiles_i = L->dim / TI; P.tiles_j = L->dim / TJ; P.total_blocks = L->num_boxes * P.chunks_k * P.tiles_j * P.tiles_i; \
     const int grid = grid_for(P.total_blocks, &P.per_xcd); \
     const size_t lds = (size_t)11 * (TI + 4) * (TJ + 4) * sizeof(double); \
-    static bool once = false; if (!once) { HPGMG_CHECK(hipFuncSetAttribute((const void *)fv4_tile_kernel<VAR, FV4_GSRB, TJ, TI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once = true; } \
-    hipLaunchKernelGGL((fv4_tile_kernel<VAR, FV4_GSRB, TJ, TI>), dim3(grid), dim3(TI, TJ), lds, g_stream, *L, P); }
+    const int sp_blocks = (S.n + TI * TJ - 1) / (TI * TJ); \
+    static bool once = false; if (!once) { HPGMG_CHECK(hipFuncSetAttribute((const void *)fv4_rb_prepass_kernel<VAR, TJ, TI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once = true; } \
+    hipLaunchKernelGGL((fv4_rb_prepass_kernel<VAR, TJ, TI>), dim3(grid + sp_blocks), dim3(TI, TJ), lds, g_stream, *L, P, S, sp_blocks); }
   const bool wide = L->dim % 64 == 0;
   if (variant == HPGMG_HIP_FV4_VC_HELMHOLTZ) { if (wide) FV4_PRE_CASE(HPGMG_HIP_FV4_VC_HELMHOLTZ, 8, 64) else FV4_PRE_CASE(HPGMG_HIP_FV4_VC_HELMHOLTZ, 16, 32) }
   else                                       { if (wide) FV4_PRE_CASE(HPGMG_HIP_FV4_VC_POISSON, 8, 64) else FV4_PRE_CASE(HPGMG_HIP_FV4_VC_POISSON, 16, 32) }
 #undef FV4_PRE_CASE
-  HPGMG_LAUNCH_CHECK("fv4_tile_kernel (red + black pre-pass)");
+  HPGMG_LAUNCH_CHECK("fv4_rb_prepass_kernel");
   hpgmg_hip_level Ls = *L;
   Ls.box_base = scr_base;
   return hpgmg_hip_exchange_and_bc(&Ls, tg_id, nullptr, 0, entries_k, n_k, 4);

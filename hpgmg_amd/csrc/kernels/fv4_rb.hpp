@@ -360,6 +360,7 @@ __global__ __launch_bounds__(TI_ * 8, 2) void fv4_rb_kernel(const hpgmg_hip_leve
 
   // ---- (5) lanes 0 .. 331: one ghost cell of t outside the domain in i and / or j: kind 1 near, 2 far, 3 the k-edge cell diagonal to a tile corner
   const bool tile_wall = t_ilo || t_ihi || t_jlo || t_jhi;
+  const bool iwall_only = (t_ilo || t_ihi) && !(t_jlo || t_jhi);
   // The descriptor (kind, position, inward steps; packed) waits in LDS, not in a register: a value that is live across the loop but used
   // only in this rarely taken block is what the register allocator spills first, and a reload from scratch is a vector-memory load -- it
   // returns behind every prefetch in flight, i.e. costs the wall tiles an HBM round trip per step (they took 1.5 x the time of the
@@ -391,7 +392,18 @@ __global__ __launch_bounds__(TI_ * 8, 2) void fv4_rb_kernel(const hpgmg_hip_leve
     return bc_kind | ((bc_i + 4) << 2) | ((bc_j + 4) << 9) | ((bc_si + 1) << 14) | ((bc_sj + 1) << 16);
   };
 
-  if (tile_wall) sBC[tid] = bc_descr(tid);                                        // read after the barriers of the first step
+  // tiles at an i wall only: lanes 0 .. 3 / TI-4 .. TI-1 of every wave take the near and the far cell of its two rows, lanes 4, 5 /
+  // TI-6, TI-5 of the first wave (whose lanes are the ring pairs of rows -1 and TJ) the near cells of those rows
+  auto bc_descr_iwall = [&]() -> int {
+    const bool lft = t_ilo && li < 6, rgt = t_ihi && li >= TI - 6;
+    if (!(lft || rgt)) return 0;
+    const int m = lft ? li : TI - 1 - li;
+    if (m >= 4 && lj != 0) return 0;
+    const int row = (m < 4) ? 2 * lj + (m & 1) : ((m & 1) ? TJ : -1), kind = (m < 2 || m >= 4) ? 1 : 2;
+    const int gc = lft ? -kind : TI - 1 + kind, si = lft ? 1 : -1;
+    return kind | ((gc + 4) << 2) | ((row + 4) << 9) | ((si + 1) << 14) | ((0 + 1) << 16);
+  };
+  if (tile_wall) sBC[tid] = iwall_only ? bc_descr_iwall() : bc_descr(tid);        // read after the barriers of the first step
   // t on plane q at a tile / ring cell inside the domain: a red cell from the t ring, a black one is the cell of x
   auto t_at = [&](int ci, int cj, int q) -> double {
     return is_red(i0 + ci, j0 + cj, q) ? sT[slot3(q) * PT + posT(ci, cj)] : sX[slot4(q) * PX + posX(ci, cj)];
@@ -602,8 +614,14 @@ __global__ __launch_bounds__(TI_ * 8, 2) void fv4_rb_kernel(const hpgmg_hip_leve
     // B(dim-2) reads it in this step) and in the extra step (the t ring's part, whose slot B(dim-2) still needed)
     TL_MARK();                                                                      // 4: R ring
     const int kfill = (bottom && q == 0) ? 1 : ((top && q == dim - 1) ? 2 : ((top && q == dim) ? 3 : 0));
+    // A tile at an i wall only (a quarter of all tiles; j walls: one in sixteen) needs no barriers for this: its ghost cells are dealt to the
+    // lanes so that the four cells one is formed from are results of the SAME wave (bc_descr_iwall; LDS serves a wave's accesses in order);
+    // what B(q-1) reads of plane q outside its own column is the near cell of its own row; every other ghost cell of plane q is first read
+    // in the next step, behind its barriers; and the positions written (black parity in the x ring, the t ring) are none R(q) of another
+    // wave still reads (those have red parity).
+    const bool bc_sync = (tile_wall && !iwall_only && do_r) || kfill;
     if (__builtin_expect((tile_wall && do_r) || kfill, 0)) {
-      __syncthreads();                                                              // [B] t on plane q is complete inside the domain
+      if (bc_sync) __syncthreads();                                                 // [B] t on plane q is complete inside the domain
       TL_MARK();
       const int bc_pack = (tile_wall && do_r) ? sBC[tid] : 0;
       if (bc_pack & 3) {
@@ -643,7 +661,7 @@ __global__ __launch_bounds__(TI_ * 8, 2) void fv4_rb_kernel(const hpgmg_hip_leve
         if (kfill == 1) sX[slot4(-2) * PX + ownX + (red0 ? 0 : WX)] = tgb[(long long)own_o + (red0 ? 0 : jS) - 2LL * kS];   // two below: black parity where plane -1 is red
       }
       TL_MARK();
-      __syncthreads();                                                              // [C]
+      if (bc_sync) __syncthreads();                                                 // [C]
       TL_MARK();
     } else { TL_MARK(); TL_MARK(); TL_MARK(); }
 
@@ -757,23 +775,27 @@ struct Fv4SpecialArgs {
   int n;
 };
 template <int V>
-__global__ __launch_bounds__(256) void fv4_special_kernel(const hpgmg_hip_level L, const Fv4SpecialArgs P) {
+__device__ __forceinline__ void fv4_special_cell(const hpgmg_hip_level &L, const Fv4SpecialArgs &P, int idx) {
   using namespace fv4rb;
   constexpr bool kHelm = (V == HPGMG_HIP_FV4_VC_HELMHOLTZ);
-  const int idx = (int)blockIdx.x * 256 + (int)threadIdx.x;
   if (idx >= P.n) return;
   const int box = P.cells[4 * idx], i = P.cells[4 * idx + 1], j = P.cells[4 * idx + 2], k = P.cells[4 * idx + 3];
   const int dim = L.dim, jS = L.jStride, kS = L.kStride;
   const size_t vol = (size_t)L.volume, first = (size_t)L.ghosts * (size_t)(1 + jS + kS);
   // x at (i + di, j + dj, k + dk): in the box that owns the place (one hop per axis), its ghost zone where the domain ends
+  // the first hop from the cell's own box comes from a copy of its six neighbours read up front (one round trip instead of one per access)
+  int nb0[6];
+#pragma unroll
+  for (int d = 0; d < 6; d++) nb0[d] = L.box_nbr[6 * box + d];
+  auto nbr = [&](int b, int d) -> int { return (b == box) ? nb0[d] : L.box_nbr[6 * b + d]; };
   auto xat = [&](int di, int dj, int dk) -> double {
     int b = box, I = i + di, J = j + dj, K = k + dk;
-    if (I < 0)         { const int n = L.box_nbr[6 * b + 0]; if (n >= 0) { b = n; I += dim; } }
-    else if (I >= dim) { const int n = L.box_nbr[6 * b + 1]; if (n >= 0) { b = n; I -= dim; } }
-    if (J < 0)         { const int n = L.box_nbr[6 * b + 2]; if (n >= 0) { b = n; J += dim; } }
-    else if (J >= dim) { const int n = L.box_nbr[6 * b + 3]; if (n >= 0) { b = n; J -= dim; } }
-    if (K < 0)         { const int n = L.box_nbr[6 * b + 4]; if (n >= 0) { b = n; K += dim; } }
-    else if (K >= dim) { const int n = L.box_nbr[6 * b + 5]; if (n >= 0) { b = n; K -= dim; } }
+    if (I < 0)         { const int n = nbr(b, 0); if (n >= 0) { b = n; I += dim; } }
+    else if (I >= dim) { const int n = nbr(b, 1); if (n >= 0) { b = n; I -= dim; } }
+    if (J < 0)         { const int n = nbr(b, 2); if (n >= 0) { b = n; J += dim; } }
+    else if (J >= dim) { const int n = nbr(b, 3); if (n >= 0) { b = n; J -= dim; } }
+    if (K < 0)         { const int n = nbr(b, 4); if (n >= 0) { b = n; K += dim; } }
+    else if (K >= dim) { const int n = nbr(b, 5); if (n >= 0) { b = n; K -= dim; } }
     return sel_origin(L, P.x, b)[I + J * jS + K * kS];
   };
   X25 x;
@@ -794,6 +816,18 @@ __global__ __launch_bounds__(256) void fv4_special_kernel(const hpgmg_hip_level 
     v = x.c + pc[(size_t)VECTOR_DINV * vol] * (pc[(size_t)P.rhs_id * vol] - Ax);
   }
   sel_origin(L, P.tg, box)[i + j * jS + (long long)k * kS] = v;
+}
+template <int V>
+__global__ __launch_bounds__(256) void fv4_special_kernel(const hpgmg_hip_level L, const Fv4SpecialArgs P) {
+  fv4_special_cell<V>(L, P, (int)blockIdx.x * 256 + (int)threadIdx.x);
+}
+// The pre-pass as one launch: the first sp_blocks workgroups take the special cells (long chains of dependent loads: they start first and
+// finish under the others), the rest run the tiled half sweep on the planes next to the k walls (fv4_tile_body).  Both write the interior of
+// P.tg; where they write the same cell they write the same value.
+template <int V, int TJ, int TI>
+__global__ __launch_bounds__(TI * TJ) void fv4_rb_prepass_kernel(const hpgmg_hip_level L, const Fv4TileArgs T, const Fv4SpecialArgs S, int sp_blocks) {
+  if ((int)blockIdx.x >= sp_blocks) fv4_tile_body<V, FV4_GSRB, TJ, TI>(L, T, (int)blockIdx.x - sp_blocks);
+  else fv4_special_cell<V>(L, S, (int)blockIdx.x * (TI * TJ) + (int)threadIdx.y * TI + (int)threadIdx.x);
 }
 
 }  // namespace hpgmg

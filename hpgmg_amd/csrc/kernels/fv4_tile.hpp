@@ -40,8 +40,9 @@ struct Fv4TileArgs {
 };
 enum { FV4_CHEBY = 0, FV4_GSRB = 1, FV4_JACOBI = 2, FV4_RESIDUAL = 3, FV4_APPLY = 4 };
 
+// the kernel's body; `block` = blockIdx.x (a device function so that the pre-pass of fv4_rb.hpp can run other work in the same launch)
 template <int V, int MODE, int TJ, int TI = 64>
-__global__ __launch_bounds__(TI * TJ) void fv4_tile_kernel(const hpgmg_hip_level L, const Fv4TileArgs P) {
+__device__ __forceinline__ void fv4_tile_body(const hpgmg_hip_level &L, const Fv4TileArgs &P, int block) {
   constexpr int W = TI + 4, H = TJ + 4, NT = TI * TJ, PLANE = W * H;
   constexpr int NH = 4 * W + 4 * TJ;                           // halo cells of one plane tile (two rows above and below, two columns left and right)
   static_assert(NH <= NT, "one halo cell per lane at most");
@@ -51,7 +52,7 @@ __global__ __launch_bounds__(TI * TJ) void fv4_tile_kernel(const hpgmg_hip_level
   __shared__ double sR[(MODE == FV4_RESIDUAL) ? 2 * TJ * TI : 1];   // fused residual forms: a plane of residuals / the workgroup's partial maxima
   double *sX = fv4_lds, *sBI = fv4_lds + 3 * PLANE, *sBJ = fv4_lds + 6 * PLANE, *sBK = fv4_lds + 9 * PLANE;   // rings of 3, 3, 3, 2 plane tiles
 
-  const int logical = xcd_logical_block((int)blockIdx.x, P.per_xcd);
+  const int logical = xcd_logical_block(block, P.per_xcd);
   if (logical >= P.total_blocks) return;
   int t = logical;
   const int ti = t % P.tiles_i; t /= P.tiles_i;
@@ -226,6 +227,10 @@ __global__ __launch_bounds__(TI * TJ) void fv4_tile_kernel(const hpgmg_hip_level
     __syncthreads();
     if (tid == 0) { double m2 = sR[0]; for (int q = 1; q < NT / 64; q++) m2 = (sR[q] > m2) ? sR[q] : m2; F.partials[logical] = m2; }
   }
+}
+template <int V, int MODE, int TJ, int TI = 64>
+__global__ __launch_bounds__(TI * TJ) void fv4_tile_kernel(const hpgmg_hip_level L, const Fv4TileArgs P) {
+  fv4_tile_body<V, MODE, TJ, TI>(L, P, (int)blockIdx.x);
 }
 
 }  // namespace hpgmg
