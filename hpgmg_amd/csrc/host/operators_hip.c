@@ -1121,8 +1121,11 @@ static int small_fused = -1;
 void hpgmg_set_small_fused(int on) { small_fused = on ? 1 : 0; }
 static int small_level_try(level_type *L, int mode, int x_id, int rhs_id, int res_id, double a, double b) {
   hpgmg_config cfg;
-  if (small_fused < 0) { const char *e = getenv("HPGMG_SMALL_FUSED"); small_fused = (e && e[0] == '1'); }
-  const int enabled = small_fused;
+  if (small_fused < 0) { const char *e = getenv("HPGMG_SMALL_FUSED"); small_fused = (e && e[0] == '1') ? 1 : ((e && e[0] == '2') ? 2 : 0); }
+  /* 1: every qualifying level; 2: levels of ONE box only (no copy list, 26 boundary entries) -- round 3: still slower than the launches it
+   * replaces (`7 64`: fv4 37.4 vs 34.2 ms, 27-pt 18.0 vs 13.9 ms per F-cycle): the kernel works out of global memory, and one workgroup pays
+   * every dependent round trip in full */
+  const int enabled = small_fused == 1 || (small_fused == 2 && L->num_my_boxes == 1);
   hpgmg_get_config(&cfg);
   if (!enabled || cfg.op == HPGMG_OP_7PT || L->num_my_boxes < 1) return 0;
   if ((long long)L->dim.i * L->dim.j * L->dim.k > hpgmg_hip_small_level_max_cells()) return 0;
