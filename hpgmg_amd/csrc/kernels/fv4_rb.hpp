@@ -469,6 +469,7 @@ __global__ __launch_bounds__(TI_ * 8, 2) void fv4_rb_kernel(const hpgmg_hip_leve
   // what B(q) needs from the coefficient planes that will have left the rings by then (beta_i / beta_j plane q-1, beta_k face q), formed a step early
   double pd1 = 0.0, pd3 = 0.0, pd7 = 0.0, pd9 = 0.0, pf4 = 0.0, pd4 = 0.0, pd5 = 0.0;
   double b_rhs = 0.0, b_dinv = 0.0, b_al = 0.0, kmB = 0.0;           // kmB: t three planes below the current one at the cell B works on
+  double r_prev = 0.0;                                               // what R formed at the own pair's red cell a step ago
   const double bh2inv = P.b * P.h2inv, nbh2inv = (-P.b) * P.h2inv;
 
   // marching pointers: the x halo column at plane q+2, the ring pair's level vectors at plane q+1, its x at plane q+3
@@ -579,7 +580,7 @@ __global__ __launch_bounds__(TI_ * 8, 2) void fv4_rb_kernel(const hpgmg_hip_leve
         // does anything wait for t_spo, which means waiting for every prefetch issued after it
         if (__builtin_expect(sp_o, 0)) { asm volatile("" ::: "memory"); r_new = t_spo; }
         sT[slot3(q) * PT + ownT + up * ST] = r_new;
-        if (q >= k0 && q < k1) gst(outb, own_b + up * bjS + (unsigned)q * bkS, r_new);      // the pair's red cell on plane q is final: x' = t there
+        // the pair's red cell on plane q is final (x' = t there); it is stored a step later, together with the black cell of its plane
       }
     }
     TL_MARK();                                                                      // 3: R own
@@ -705,7 +706,12 @@ __global__ __launch_bounds__(TI_ * 8, 2) void fv4_rb_kernel(const hpgmg_hip_leve
       bt.d[10] = k1p - k1m; bt.d[11] = k1w - k1mw;
       const double sum = fv4_combine(br, bt);
       const double Ax = kHelm ? (P.a * b_al) * x.c - bh2inv * sum : nbh2inv * sum;
-      gst(outb, own_b + up * bjS + (unsigned)r * bkS, x.c + b_dinv * (b_rhs - Ax));
+      // both cells of the pair on plane r in two stores that each cover a whole row of the tile: the black one just formed, the red one from
+      // R(r) a step ago.  (Stored with its own stage, each colour wrote every second cell of a line, a step apart: the lines went to memory
+      // twice -- WRITE_SIZE was 2.14 GB per 512^3 pass for 1.07 GB of output.)
+      const double bv = x.c + b_dinv * (b_rhs - Ax);
+      gst(outb, own_b + (unsigned)r * bkS, up ? r_prev : bv);
+      gst(outb, own_b + bjS + (unsigned)r * bkS, up ? bv : r_prev);
                                // the pair's red cell on plane r: what R(r) formed
     }
     TL_MARK();                                                                      // 5: B
@@ -744,6 +750,7 @@ __global__ __launch_bounds__(TI_ * 8, 2) void fv4_rb_kernel(const hpgmg_hip_leve
     // ---- next plane
     b_rhs = up ? c_rhs0 : c_rhs1; b_dinv = up ? c_dinv0 : c_dinv1; b_al = up ? c_al0 : c_al1;      // the black cell of plane q: B(q) in the next step
     kp2_0 = n_x0; kp2_1 = n_x1;
+    r_prev = r_new;
     c_rhs0 = n_rhs0; c_rhs1 = n_rhs1; c_dinv0 = n_dinv0; c_dinv1 = n_dinv1; c_al0 = n_al0; c_al1 = n_al1;
     if (has_e) { e_rhs = eax0; e_dinv = eax1; e_xp2 = eax2; }
     e_al = ne_al;
