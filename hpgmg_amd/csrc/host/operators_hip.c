@@ -1118,15 +1118,19 @@ static int interp_smooth_fused(level_type *Lf, int e_id, int R_id, level_type *L
  * ~160 copy / boundary list entries whose dependent load chains run 16 at a time on one CU, while separate launches spread them over
  * the chip; the launch overhead saved (~5 us each) is smaller than that serialisation. */
 static int small_fused = -1;
-void hpgmg_set_small_fused(int on) { small_fused = on ? 1 : 0; }
+void hpgmg_set_small_fused(int mode) { small_fused = (mode == 1 || mode == 2) ? mode : 0; }   /* 0 off, 1 every small level, 2 (default) one-box levels in LDS */
 static int small_level_try(level_type *L, int mode, int x_id, int rhs_id, int res_id, double a, double b) {
   hpgmg_config cfg;
   if (small_fused < 0) { const char *e = getenv("HPGMG_SMALL_FUSED"); small_fused = (e && e[0] == '1') ? 1 : ((e && e[0] == '2') ? 2 : 0); }
-  /* 1: every qualifying level; 2: levels of ONE box only (no copy list, 26 boundary entries) -- round 3: still slower than the launches it
-   * replaces (`7 64`: fv4 37.4 vs 34.2 ms, 27-pt 18.0 vs 13.9 ms per F-cycle): the kernel works out of global memory, and one workgroup pays
-   * every dependent round trip in full */
-  const int enabled = small_fused == 1 || (small_fused == 2 && L->num_my_boxes == 1);
+  /* 0 (default): off.  1: every qualifying level, out of global memory (slower than the launches it replaces, see above).  2: smooth() on
+   * levels of ONE box whose vectors fit the LDS -- the kernel then works on an image of the box there (round 3).  Measured on `7 64`: fv4
+   * 33.4 vs 33.1 ms, i.e. no gain either: a smooth() of such a level is then one ~55 us launch instead of twelve ~5 us ones, the generic
+   * (FLAT) accesses to the image and the single workgroup's serial phases cost what the launches cost.  Off; bit-identical, tested. */
   hpgmg_get_config(&cfg);
+  /* mode 2 takes what it shortens: a smooth() of many launches (fv4 GSRB: 12, Chebyshev: 8; a residual or apply_op is two launches of ~5 us,
+   * the kernel with its copies in and out ~15 us; the 27-point GSRB smoother already runs as two one-workgroup-per-box launches) */
+  const int worth = (mode <= 2) && !(cfg.op == HPGMG_OP_27PT && cfg.smoother == HPGMG_SMOOTH_GSRB);
+  const int enabled = small_fused == 1 || (small_fused == 2 && worth && L->num_my_boxes == 1 && (size_t)9 * (size_t)L->box_volume * sizeof(double) <= (size_t)150 * 1024);
   if (!enabled || cfg.op == HPGMG_OP_7PT || L->num_my_boxes < 1) return 0;
   if ((long long)L->dim.i * L->dim.j * L->dim.k > hpgmg_hip_small_level_max_cells()) return 0;
   if (L->num_my_boxes != L->boxes_in.i * L->boxes_in.j * L->boxes_in.k) return 0;

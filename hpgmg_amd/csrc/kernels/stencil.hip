@@ -618,18 +618,53 @@ struct SmallArgs {
   double a, b, h2inv, c1[8], c2[8];
   const blockCopy_type *copy_list; int n_copy;
   const blockCopy_type *bc_list; int n_bc;
+  int lds_resident;                 // a level of ONE box whose vectors fit the LDS: work on an image of the box there (see the kernel)
 };
+// LDS-resident form (round 3): out of global memory every boundary entry and every stencil read of this one workgroup is a round trip to
+// the L2 that nothing hides (measured: slower than the dozen launches it replaces, even on a level of one box).  For a level of ONE box
+// the vectors the operator touches -- x, VECTOR_TEMP, rhs, Dinv, alpha, beta_i/j/k, the result -- are copied into LDS with the box's own
+// padded layout, the level descriptor is pointed at that image (a one-entry box table in LDS, vector ids renumbered to slots), the very same
+// entry routines and per-cell expressions run on it, and the vectors written go back to memory at the end: bit-identical by construction.
+constexpr int kSmallSlots = 9;
 template <int V>
-__global__ __launch_bounds__(1024) void small_level_kernel(const hpgmg_hip_level L, const SmallArgs A) {
+__global__ __launch_bounds__(1024) void small_level_kernel(const hpgmg_hip_level L0, const SmallArgs A) {
   constexpr bool kFv4 = (V == HPGMG_HIP_FV4_VC_HELMHOLTZ || V == HPGMG_HIP_FV4_VC_POISSON), k27 = (V == HPGMG_HIP_27PT_CC);
   constexpr bool kVC = (V != HPGMG_HIP_7PT_CC && !k27);
   constexpr bool kHelm = (V == HPGMG_HIP_7PT_VC_HELMHOLTZ || V == HPGMG_HIP_FV4_VC_HELMHOLTZ);
+  extern __shared__ double small_lds[];
+  __shared__ double *s_box_table[1];
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = (int)blockDim.x >> 6;
+  hpgmg_hip_level L = L0;
+  // vector ids as the body uses them: the level's, or slots of the LDS image
+  int x_id = A.x_id, rhs_id = A.rhs_id, res_id = A.res_id, temp_id = VECTOR_TEMP, dinv_id = VECTOR_DINV, al_id = VECTOR_ALPHA;
+  int bi_id = VECTOR_BETA_I, bj_id = VECTOR_BETA_J, bk_id = VECTOR_BETA_K;
+  int slot_of[kSmallSlots];                                        // level vector id held in each slot (-1: unused)
+  if (A.lds_resident) {
+    const bool smooth = (A.mode == MODE_CHEBY || A.mode == MODE_JACOBI || A.mode == MODE_GSRB);
+    const bool uses_temp = smooth && !(A.mode == MODE_GSRB && !A.out_of_place);
+    slot_of[0] = A.x_id; slot_of[1] = uses_temp ? VECTOR_TEMP : -1; slot_of[2] = (A.mode == MODE_APPLY) ? -1 : A.rhs_id; slot_of[3] = smooth ? VECTOR_DINV : -1;
+    slot_of[4] = kHelm ? VECTOR_ALPHA : -1; slot_of[5] = kVC ? VECTOR_BETA_I : -1; slot_of[6] = kVC ? VECTOR_BETA_J : -1; slot_of[7] = kVC ? VECTOR_BETA_K : -1;
+    slot_of[8] = smooth ? -1 : A.res_id;
+    const size_t vol = (size_t)L0.volume;
+#pragma unroll
+    for (int q = 0; q < kSmallSlots; q++) {
+      if (slot_of[q] < 0) continue;
+      // a result vector that is written in full needs no load, but its ghost zone must hold what memory holds: copy it all the same
+      const double *g = L0.box_base[0] + (size_t)slot_of[q] * vol;
+#pragma unroll 8
+      for (int t = tid; t < (int)vol; t += (int)blockDim.x) small_lds[(size_t)q * vol + t] = g[t];      // unrolled: eight loads in flight per lane, not one
+    }
+    if (tid == 0) s_box_table[0] = small_lds;
+    L.box_base = s_box_table;
+    x_id = 0; temp_id = 1; rhs_id = 2; dinv_id = 3; al_id = 4; bi_id = 5; bj_id = 6; bk_id = 7; res_id = smooth ? 0 : 8;
+    if (!smooth && A.res_id == A.x_id) res_id = 0;
+    __syncthreads();
+  }
   const int dim = L.dim, jS = L.jStride, kS = L.kStride, per_box = dim * dim * dim, total = per_box * L.num_boxes;
   for (int s = 0; s < A.sweeps; s++) {
-    int src = A.x_id, dst = A.res_id;
-    if (A.mode == MODE_CHEBY || A.mode == MODE_JACOBI || (A.mode == MODE_GSRB && A.out_of_place)) { src = (s & 1) ? VECTOR_TEMP : A.x_id; dst = (s & 1) ? A.x_id : VECTOR_TEMP; }
-    else if (A.mode == MODE_GSRB) { src = A.x_id; dst = A.x_id; }
+    int src = x_id, dst = res_id;
+    if (A.mode == MODE_CHEBY || A.mode == MODE_JACOBI || (A.mode == MODE_GSRB && A.out_of_place)) { src = (s & 1) ? temp_id : x_id; dst = (s & 1) ? x_id : temp_id; }
+    else if (A.mode == MODE_GSRB) { src = x_id; dst = x_id; }
     // exchange_boundary(src): box -> box copies (blockCopy.c:6-105)
     for (int e = wave; e < A.n_copy; e += nwaves) copy_entry<false>(L, src, A.copy_list[e], 0.0, lane, 64);
     __syncthreads();
@@ -657,18 +692,30 @@ __global__ __launch_bounds__(1024) void small_level_kernel(const hpgmg_hip_level
         const plane9 m = load_plane(x + ijk - kS, jS), c = load_plane(x + ijk, jS), p = load_plane(x + ijk + kS, jS);
         Ax = apply_op_27pt(m, c, p, A.a, A.b, A.h2inv);
       } else {
-        Ax = apply_op_direct<V>(x, kHelm ? vec_origin(L, box, VECTOR_ALPHA) : nullptr, kVC ? vec_origin(L, box, VECTOR_BETA_I) : nullptr,
-                                kVC ? vec_origin(L, box, VECTOR_BETA_J) : nullptr, kVC ? vec_origin(L, box, VECTOR_BETA_K) : nullptr, ijk, jS, kS, A.a, A.b, A.h2inv);
+        Ax = apply_op_direct<V>(x, kHelm ? vec_origin(L, box, al_id) : nullptr, kVC ? vec_origin(L, box, bi_id) : nullptr,
+                                kVC ? vec_origin(L, box, bj_id) : nullptr, kVC ? vec_origin(L, box, bk_id) : nullptr, ijk, jS, kS, A.a, A.b, A.h2inv);
       }
       if (A.mode == MODE_APPLY) { out[ijk] = Ax; continue; }
-      const double rhs = vec_origin(L, box, A.rhs_id)[ijk];
+      const double rhs = vec_origin(L, box, rhs_id)[ijk];
       if (A.mode == MODE_RESIDUAL) { out[ijk] = rhs - Ax; continue; }
-      const double dinv = vec_origin(L, box, VECTOR_DINV)[ijk];
+      const double dinv = vec_origin(L, box, dinv_id)[ijk];
       if (A.mode == MODE_CHEBY)      { const double xnm1 = out[ijk]; out[ijk] = xc + A.c1[s] * (xc - xnm1) + A.c2[s] * dinv * (rhs - Ax); }
       else if (A.mode == MODE_GSRB)  { out[ijk] = xc + dinv * (rhs - Ax); }
       else                           { out[ijk] = xc + A.c2[s] * dinv * (rhs - Ax); }
     }
     __syncthreads();
+  }
+  if (A.lds_resident) {                                           // what was written goes back to memory, ghost zones included (the boundary entries filled them)
+    const size_t vol = (size_t)L0.volume;
+    const bool smooth = (A.mode == MODE_CHEBY || A.mode == MODE_JACOBI || A.mode == MODE_GSRB);
+#pragma unroll
+    for (int q = 0; q < kSmallSlots; q++) {
+      const bool written = smooth ? (q == 0 || (q == 1 && slot_of[1] >= 0)) : (q == 0 || q == 8);      // x's ghost zone was filled too
+      if (!written || slot_of[q] < 0) continue;
+      double *g = L0.box_base[0] + (size_t)slot_of[q] * vol;
+#pragma unroll 8
+      for (int t = tid; t < (int)vol; t += (int)blockDim.x) g[t] = small_lds[(size_t)q * vol + t];
+    }
   }
   (void)kFv4;
 }
@@ -1266,15 +1313,25 @@ int hpgmg_hip_small_level_op(const hpgmg_hip_level *L, int variant, int mode, in
   A.copy_list = copy_list; A.n_copy = copy_list ? n_copy : 0; A.bc_list = bc_list; A.n_bc = bc_list ? n_bc : 0;
   const long long cells = (long long)L->num_boxes * L->dim * L->dim * L->dim;
   const int threads = cells >= 1024 ? 1024 : (cells >= 256 ? 256 : 64);
+  // one box whose vectors fit the LDS: work on an image of it there
+  const size_t image = (size_t)kSmallSlots * (size_t)L->volume * sizeof(double);
+  static const int no_lds = env_int("HPGMG_TUNE_SMALL_NO_LDS", 0);
+  A.lds_resident = (!no_lds && L->num_boxes == 1 && A.n_copy == 0 && image <= 150 * 1024) ? 1 : 0;
+  const size_t lds = A.lds_resident ? image : 0;
+  const int threads_used = A.lds_resident ? 1024 : threads;        // the image is copied by every lane there is
+#define SMALL_CASE(VAR) { \
+    static bool once = false; if (!once) { HPGMG_CHECK(hipFuncSetAttribute((const void *)small_level_kernel<VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); once = true; } \
+    hipLaunchKernelGGL((small_level_kernel<VAR>), dim3(1), dim3(threads_used), lds, g_stream, *L, A); }
   switch (variant) {
-    case HPGMG_HIP_27PT_CC:          hipLaunchKernelGGL((small_level_kernel<HPGMG_HIP_27PT_CC>), dim3(1), dim3(threads), 0, g_stream, *L, A); break;
-    case HPGMG_HIP_FV4_VC_HELMHOLTZ: hipLaunchKernelGGL((small_level_kernel<HPGMG_HIP_FV4_VC_HELMHOLTZ>), dim3(1), dim3(threads), 0, g_stream, *L, A); break;
-    case HPGMG_HIP_FV4_VC_POISSON:   hipLaunchKernelGGL((small_level_kernel<HPGMG_HIP_FV4_VC_POISSON>), dim3(1), dim3(threads), 0, g_stream, *L, A); break;
-    case HPGMG_HIP_7PT_VC_HELMHOLTZ: hipLaunchKernelGGL((small_level_kernel<HPGMG_HIP_7PT_VC_HELMHOLTZ>), dim3(1), dim3(threads), 0, g_stream, *L, A); break;
-    case HPGMG_HIP_7PT_VC_POISSON:   hipLaunchKernelGGL((small_level_kernel<HPGMG_HIP_7PT_VC_POISSON>), dim3(1), dim3(threads), 0, g_stream, *L, A); break;
-    case HPGMG_HIP_7PT_CC:           hipLaunchKernelGGL((small_level_kernel<HPGMG_HIP_7PT_CC>), dim3(1), dim3(threads), 0, g_stream, *L, A); break;
+    case HPGMG_HIP_27PT_CC:          SMALL_CASE(HPGMG_HIP_27PT_CC) break;
+    case HPGMG_HIP_FV4_VC_HELMHOLTZ: SMALL_CASE(HPGMG_HIP_FV4_VC_HELMHOLTZ) break;
+    case HPGMG_HIP_FV4_VC_POISSON:   SMALL_CASE(HPGMG_HIP_FV4_VC_POISSON) break;
+    case HPGMG_HIP_7PT_VC_HELMHOLTZ: SMALL_CASE(HPGMG_HIP_7PT_VC_HELMHOLTZ) break;
+    case HPGMG_HIP_7PT_VC_POISSON:   SMALL_CASE(HPGMG_HIP_7PT_VC_POISSON) break;
+    case HPGMG_HIP_7PT_CC:           SMALL_CASE(HPGMG_HIP_7PT_CC) break;
     default: return record_error(hipErrorInvalidValue, "small_level_op: variant");
   }
+#undef SMALL_CASE
   HPGMG_LAUNCH_CHECK("small_level_kernel");
   return 0;
 }

@@ -127,15 +127,17 @@ def test_hipgraph_segments_replay_the_same_numbers(hip):
         hip.lib.hpgmg_set_graphs(0)
 
 
+@pytest.mark.parametrize("mode", [1, 2, 0])
 @pytest.mark.parametrize("variant,args", [("fv4-gsrb", "4 8"), ("27pt-gsrb", "4 8"), ("27pt-cheby", "5 8"), ("fv2-cheby", "4 8"), ("fv4-cheby", "4 8")])
-def test_small_levels_as_single_launches_give_the_same_norms(hip, variant, args):
-    """hpgmg_set_small_fused(1): smooth() / residual() of the non-7-point plugins on levels of <= 16^3 cells as one single-workgroup
-    launch each (exchange copies + boundary conditions + stencil per sweep inside).  Opt-in (measured slower than separate launches),
-    but it must be the same numbers."""
+def test_small_levels_as_single_launches_give_the_same_norms(hip, variant, args, mode):
+    """hpgmg_set_small_fused: smooth() / residual() of the non-7-point plugins on small levels as one single-workgroup launch each (exchange
+    copies + boundary conditions + stencil per sweep inside).  Mode 1: every level of <= 16^3 cells, out of global memory (opt-in: measured
+    slower than separate launches); mode 2: smooth() on levels of ONE box, on an image of the box in LDS (no gain measured either); mode 0 (the default): separate launches.  The same
+    numbers in every mode."""
     import ctypes
     gold = GOLD[f"{variant} {args}"]
     hip.lib.hpgmg_set_small_fused.argtypes = [ctypes.c_int]
-    hip.lib.hpgmg_set_small_fused(1)
+    hip.lib.hpgmg_set_small_fused(mode)
     try:
         hip.configure(**VARIANTS[variant])
         s = hip.solver_cli(*map(int, args.split()))
