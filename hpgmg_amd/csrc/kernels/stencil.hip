@@ -28,7 +28,9 @@
 #include "fv4_tile.hpp"
 #include "stencil27_rb.hpp"
 #include "stencil27_rb_box.hpp"
-#include "stencil7_pair_tile.hpp"
+#ifdef HPGMG_EXPERIMENTS
+#include "stencil7_pair_tile.hpp"      // measured slower than what it replaces: only in builds with EXPERIMENTS=1 (csrc/Makefile)
+#endif
 #include "stencil7_tile.hpp"
 #include "block_ops.hpp"
 
@@ -613,6 +615,7 @@ __global__ __launch_bounds__(256) void stencil_direct_kernel(const hpgmg_hip_lev
 // launch costs more than the work (fv4: 18 launches of ~6 us per smooth()); the arithmetic is the same entry routines and the same
 // per-cell expressions as the streaming kernels, so results stay bit-identical.  (The 7-point plugin has its own, LDS-resident form
 // of this idea: tail.hip.)
+#ifdef HPGMG_EXPERIMENTS
 struct SmallArgs {
   int mode, sweeps, x_id, rhs_id, res_id, out_of_place, bc_kind, zero_first;   // bc_kind: 0 none (periodic), 1 p1, 2 p2, 3 v2, 4 v4
   double a, b, h2inv, c1[8], c2[8];
@@ -719,6 +722,8 @@ __global__ __launch_bounds__(1024) void small_level_kernel(const hpgmg_hip_level
   }
   (void)kFv4;
 }
+
+#endif  // HPGMG_EXPERIMENTS
 
 // ---- smoother-kernel profiling: hipEvent pair around every smoother launch ----
 static bool g_profile = false;
@@ -1219,6 +1224,15 @@ long long hpgmg_hip_pair_tile_launch_count(void) { return g_pair_tile_launches; 
 // HPGMG_TUNE_7PT_PAIR_TILE=1 or hpgmg_hip_set_pair_tile(1) enables it (bit-identical; the tests do).
 static int g_pair_tile_on = -1;
 void hpgmg_hip_set_pair_tile(int on) { g_pair_tile_on = on ? 1 : 0; }
+#ifndef HPGMG_EXPERIMENTS
+int hpgmg_hip_experiments(void) { return 0; }
+int hpgmg_hip_smooth_cheby_pair_tile_supported(const hpgmg_hip_level *, int) { (void)g_pair_tile_on; return 0; }
+int hpgmg_hip_smooth_cheby_pair_tile(const hpgmg_hip_level *, int, double *const *, int, int, int, int, int, int, int, int, int, double, double, double, double, double, double, double, int) {
+  (void)g_pair_tile_launches;
+  return record_error(hipErrorInvalidValue, "smooth_cheby_pair_tile: not in this build (make EXPERIMENTS=1)");
+}
+#else
+int hpgmg_hip_experiments(void) { return 1; }
 int hpgmg_hip_smooth_cheby_pair_tile_supported(const hpgmg_hip_level *L, int variant) {
   if (g_pair_tile_on < 0) g_pair_tile_on = env_int("HPGMG_TUNE_7PT_PAIR_TILE", 0) ? 1 : 0;
   const int off = !g_pair_tile_on;
@@ -1254,6 +1268,7 @@ int hpgmg_hip_smooth_cheby_pair_tile(const hpgmg_hip_level *L, int variant, doub
   HPGMG_LAUNCH_CHECK("stencil7_pair_tile_kernel");
   return 0;
 }
+#endif  // HPGMG_EXPERIMENTS
 void hpgmg_hip_pair_fold_interpolation(const hpgmg_hip_level *Lc, int coarse_id, double prescale) {
   g_pair_interp_level = Lc; g_pair_interp_id = coarse_id; g_pair_interp_prescale = prescale;
 }
@@ -1296,6 +1311,13 @@ int hpgmg_hip_smooth_gsrb_pair(const hpgmg_hip_level *L, int variant, double *co
                                double a, double b, double h2inv, int sweep) {
   return smooth_pair(L, variant, 1, sweep, scr_base, c32_base, x0_scr, x0_id, x0_scr, x0_id, 1, edge_scr_id, out2_scr, out2_id, rhs_id, a, b, h2inv, 0.0, 0.0, 0.0, 0.0);
 }
+#ifndef HPGMG_EXPERIMENTS
+int hpgmg_hip_small_level_max_cells(void) { return 0; }          // no level qualifies: the kernel is not in this build
+int hpgmg_hip_small_level_op(const hpgmg_hip_level *, int, int, int, int, int, int, int, double, double, double, const double *, const double *,
+                             const blockCopy_type *, int, const blockCopy_type *, int, int, int) {
+  return record_error(hipErrorInvalidValue, "small_level_op: not in this build (make EXPERIMENTS=1)");
+}
+#else
 int hpgmg_hip_small_level_max_cells(void) { return 4096; }
 // mode: 0 Chebyshev, 1 GSRB, 2 Jacobi (x_id <-> VECTOR_TEMP ping-pong as smooth() does; GSRB in place unless out_of_place), 3 residual
 // (res_id = rhs - A x), 4 apply_op (res_id = A x); c1 / c2: per-sweep Chebyshev coefficients (Jacobi: c2 = the weight)
@@ -1335,6 +1357,7 @@ int hpgmg_hip_small_level_op(const hpgmg_hip_level *L, int variant, int mode, in
   HPGMG_LAUNCH_CHECK("small_level_kernel");
   return 0;
 }
+#endif  // HPGMG_EXPERIMENTS
 int hpgmg_hip_smooth_gsrb(const hpgmg_hip_level *L, int variant, int xn_id, int xnp1_id, int rhs_id,
                           double a, double b, double h2inv, int sweep) {
   StencilArgs P = {}; P.xn_id = xn_id; P.xout_id = xnp1_id; P.rhs_id = rhs_id; P.a = a; P.b = b; P.h2inv = h2inv; P.sweep = sweep;

@@ -123,6 +123,10 @@ int hpgmg_hip_residual_norm(const hpgmg_hip_level *L, int variant, int res_id, i
  * regions before extrapolating, boundary_fv.c:133-140) and the stencil -- or a residual() / apply_op() in ONE single-workgroup launch.
  * mode: 0 Chebyshev (c1, c2 per sweep), 1 GSRB (in place, or via VECTOR_TEMP when out_of_place), 2 Jacobi (c2 = weight), 3 residual
  * (res_id = rhs - A x), 4 apply_op (res_id = A x).  Same entry routines and per-cell expressions as the streaming kernels. */
+/* 1 when the library was built with EXPERIMENTS=1 (csrc/Makefile): the kernels that measured slower than what they replace -- this one, the
+ * two-sweep tile kernel for cache-resident levels (hpgmg_hip_smooth_cheby_pair_tile), the 32-wide tiles of the fv4 red + black pass -- are
+ * compiled only then; otherwise their entry points exist and decline (supported() = 0, max_cells() = 0). */
+int hpgmg_hip_experiments(void);
 int hpgmg_hip_small_level_max_cells(void);
 int hpgmg_hip_small_level_op(const hpgmg_hip_level *L, int variant, int mode, int sweeps, int x_id, int rhs_id, int res_id, int out_of_place,
                              double a, double b, double h2inv, const double *c1, const double *c2,

@@ -115,6 +115,8 @@ def test_chebyshev_sweep_pairs_on_cache_resident_levels(hip, oracle, variant, ge
     equal the oracle's four separate sweeps bit for bit; the in-cycle form (x3 not stored) must give the same iterate."""
     K = H.load_kernels()
     K.hpgmg_hip_pair_tile_launch_count.restype = ctypes.c_longlong
+    if not K.hpgmg_hip_experiments():
+        pytest.skip("the two-sweep tile kernel is only in builds with EXPERIMENTS=1 (it measured slower than what it replaces)")
     K.hpgmg_hip_set_pair_tile.argtypes = [ctypes.c_int]
     K.hpgmg_hip_set_pair_tile(1)          # opt-in: on the 128^3 level of config 2 it measured slower than two single-sweep launches
     hip.lib.hpgmg_smooth_in_cycle.restype = ctypes.c_int
@@ -432,6 +434,8 @@ def test_fv4_red_and_black_half_sweeps_in_one_pass(hip, oracle, variant, geom, t
     32 x 16 (two workgroups of 4 waves; the only form for boxes of 32^3)."""
     if geom[1] % 64 != 0 and tile_width == 64:
         pytest.skip("boxes of 32^3 only have the 32-wide tiles")
+    if tile_width == 32 and not H.load_kernels().hpgmg_hip_experiments():
+        pytest.skip("the 32-wide tiles are only in builds with EXPERIMENTS=1 (they measured slower)")
     monkeypatch.setenv("HPGMG_TUNE_FV4_RB_TI", str(tile_width))
     set_mode(hip, 1)
     K = H.load_kernels()
