@@ -1814,6 +1814,7 @@ void smooth(level_type *L, int x_id, int rhs_id, double a, double b) {
 void residual(level_type *L, int res_id, int x_id, int rhs_id, double a, double b) {
   if (lazy_push(LZ_RESIDUAL, L, NULL, res_id, x_id, rhs_id, a, b)) return;
   lazy_flush();
+  if (lazy_push(LZ_RESIDUAL, L, NULL, res_id, x_id, rhs_id, a, b)) return;      /* it may start the residual + norm pattern (the convergence check after the last V-cycle) */
   do_residual(L, res_id, x_id, rhs_id, a, b);
 }
 void restriction(level_type *Lc, int id_c, level_type *Lf, int id_f, int type) {

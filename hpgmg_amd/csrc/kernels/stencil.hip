@@ -29,7 +29,7 @@
 #include "stencil27_rb.hpp"
 #include "stencil27_rb_box.hpp"
 #ifdef HPGMG_EXPERIMENTS
-#include "stencil7_pair_tile.hpp"      // measured slower than what it replaces: only in builds with EXPERIMENTS=1 (csrc/Makefile)
+#include "stencil7_pair_tile.hpp"      // measured slower than what it replaces (every tile width): only in builds with EXPERIMENTS=1 (csrc/Makefile)
 #endif
 #include "stencil7_tile.hpp"
 #include "block_ops.hpp"
@@ -1224,31 +1224,46 @@ long long hpgmg_hip_pair_tile_launch_count(void) { return g_pair_tile_launches; 
 // HPGMG_TUNE_7PT_PAIR_TILE=1 or hpgmg_hip_set_pair_tile(1) enables it (bit-identical; the tests do).
 static int g_pair_tile_on = -1;
 void hpgmg_hip_set_pair_tile(int on) { g_pair_tile_on = on ? 1 : 0; }
-#ifndef HPGMG_EXPERIMENTS
+#ifdef HPGMG_EXPERIMENTS
+int hpgmg_hip_experiments(void) { return 1; }
+#else
 int hpgmg_hip_experiments(void) { return 0; }
-int hpgmg_hip_smooth_cheby_pair_tile_supported(const hpgmg_hip_level *, int) { (void)g_pair_tile_on; return 0; }
+#endif
+// which tile the level takes: 64 (boxes of side 64 m: hpgmg_hip_set_pair_tile(1), builds with EXPERIMENTS=1), 32 / 16 (boxes of 32^3 / 16^3:
+// HPGMG_TUNE_7PT_PAIR_SMALL=1 or hpgmg_hip_set_pair_tile(1)), 0: none.  All of them measured SLOWER than single-sweep launches: the march with
+// its barriers is a chain of round trips, a single-sweep launch of a small level issues everything at once (config 2: 4.28 vs 3.34 ms per
+// F-cycle with the small-box form on)
+static int pair_tile_width(const hpgmg_hip_level *L, int variant) {
+  if (variant != HPGMG_HIP_7PT_VC_HELMHOLTZ && variant != HPGMG_HIP_7PT_VC_POISSON && variant != HPGMG_HIP_7PT_CC) return 0;
+  if (!(L->num_boxes > 0 && L->box_nbr != nullptr && !L->periodic && L->ghosts >= 1)) return 0;
+#ifdef HPGMG_EXPERIMENTS
+  static const int small_on = env_int("HPGMG_TUNE_7PT_PAIR_SMALL", 0);
+  if (g_pair_tile_on < 0) g_pair_tile_on = env_int("HPGMG_TUNE_7PT_PAIR_TILE", 0) ? 1 : 0;
+  if ((small_on || g_pair_tile_on) && (L->dim == 32 || L->dim == 16)) return L->dim;
+  if (g_pair_tile_on && L->dim % 64 == 0) return 64;
+#else
+  (void)g_pair_tile_on;
+#endif
+  return 0;
+}
+int hpgmg_hip_smooth_cheby_pair_tile_supported(const hpgmg_hip_level *L, int variant) { return pair_tile_width(L, variant) != 0; }
+#ifndef HPGMG_EXPERIMENTS
 int hpgmg_hip_smooth_cheby_pair_tile(const hpgmg_hip_level *, int, double *const *, int, int, int, int, int, int, int, int, int, double, double, double, double, double, double, double, int) {
   (void)g_pair_tile_launches;
   return record_error(hipErrorInvalidValue, "smooth_cheby_pair_tile: not in this build (make EXPERIMENTS=1)");
 }
 #else
-int hpgmg_hip_experiments(void) { return 1; }
-int hpgmg_hip_smooth_cheby_pair_tile_supported(const hpgmg_hip_level *L, int variant) {
-  if (g_pair_tile_on < 0) g_pair_tile_on = env_int("HPGMG_TUNE_7PT_PAIR_TILE", 0) ? 1 : 0;
-  const int off = !g_pair_tile_on;
-  if (variant != HPGMG_HIP_7PT_VC_HELMHOLTZ && variant != HPGMG_HIP_7PT_VC_POISSON && variant != HPGMG_HIP_7PT_CC) return 0;
-  return !off && L->num_boxes > 0 && L->dim % 64 == 0 && L->box_nbr != nullptr && !L->periodic && L->ghosts >= 1;
-}
 int hpgmg_hip_smooth_cheby_pair_tile(const hpgmg_hip_level *L, int variant, double *const *scr_base,
                                      int x0_scr, int x0_id, int xm1_scr, int xm1_id, int out1_scr, int out1_id, int out2_scr, int out2_id,
                                      int rhs_id, double a, double b, double h2inv, double c1a, double c2a, double c1b, double c2b, int keep_x1) {
   HPGMG_SKIP_IF_REPLAY();
-  if (!hpgmg_hip_smooth_cheby_pair_tile_supported(L, variant)) return record_error(hipErrorInvalidValue, "smooth_cheby_pair_tile: level not supported");
-  constexpr int TJ = 8;
+  const int TI = pair_tile_width(L, variant);
+  if (!TI) return record_error(hipErrorInvalidValue, "smooth_cheby_pair_tile: level not supported");
+  const int TJ = (TI == 16) ? 16 : 8;
   S7PairTileArgs A = {};
   A.x0 = VecRef{x0_scr, x0_id}; A.xm1 = VecRef{xm1_scr, xm1_id}; A.out1 = VecRef{out1_scr, out1_id}; A.out2 = VecRef{out2_scr, out2_id};
   A.rhs_id = rhs_id; A.keep_x1 = keep_x1; A.a = a; A.b = b; A.h2inv = h2inv; A.c1a = c1a; A.c2a = c2a; A.c1b = c1b; A.c2b = c2b; A.scr_base = scr_base;
-  A.tiles_i = L->dim / 64; A.tiles_j = L->dim / TJ;
+  A.tiles_i = L->dim / TI; A.tiles_j = L->dim / TJ;
   static const int tune_kc = env_int("HPGMG_TUNE_7PT_PAIR_TILE_KCHUNK", 0);
   int kchunk = L->dim;
   while (kchunk > 8 && (long long)L->num_boxes * A.tiles_i * A.tiles_j * (L->dim / kchunk) < 512) kchunk /= 2;
@@ -1258,11 +1273,16 @@ int hpgmg_hip_smooth_cheby_pair_tile(const hpgmg_hip_level *L, int variant, doub
   const int grid = grid_for(A.total_blocks, &A.per_xcd);
   const long long cells = (long long)L->num_boxes * L->dim * L->dim * L->dim;
   const int prof = profile_begin(cells);
-  switch (variant) {
-    case HPGMG_HIP_7PT_VC_HELMHOLTZ: hipLaunchKernelGGL((stencil7_pair_tile_kernel<HPGMG_HIP_7PT_VC_HELMHOLTZ, TJ>), dim3(grid), dim3(64, TJ), 0, g_stream, *L, A); break;
-    case HPGMG_HIP_7PT_VC_POISSON:   hipLaunchKernelGGL((stencil7_pair_tile_kernel<HPGMG_HIP_7PT_VC_POISSON, TJ>), dim3(grid), dim3(64, TJ), 0, g_stream, *L, A); break;
-    default:                         hipLaunchKernelGGL((stencil7_pair_tile_kernel<HPGMG_HIP_7PT_CC, TJ>), dim3(grid), dim3(64, TJ), 0, g_stream, *L, A); break;
+#define PAIR_TILE_CASES(TJ_, TI_) \
+  switch (variant) { \
+    case HPGMG_HIP_7PT_VC_HELMHOLTZ: hipLaunchKernelGGL((stencil7_pair_tile_kernel<HPGMG_HIP_7PT_VC_HELMHOLTZ, TJ_, TI_>), dim3(grid), dim3(TI_, TJ_), 0, g_stream, *L, A); break; \
+    case HPGMG_HIP_7PT_VC_POISSON:   hipLaunchKernelGGL((stencil7_pair_tile_kernel<HPGMG_HIP_7PT_VC_POISSON, TJ_, TI_>), dim3(grid), dim3(TI_, TJ_), 0, g_stream, *L, A); break; \
+    default:                         hipLaunchKernelGGL((stencil7_pair_tile_kernel<HPGMG_HIP_7PT_CC, TJ_, TI_>), dim3(grid), dim3(TI_, TJ_), 0, g_stream, *L, A); break; \
   }
+  if (TI == 32) { PAIR_TILE_CASES(8, 32) }
+  else if (TI == 16) { PAIR_TILE_CASES(16, 16) }
+  else { PAIR_TILE_CASES(8, 64) }
+#undef PAIR_TILE_CASES
   g_pair_tile_launches++;
   profile_end(prof, 2 * cells);
   HPGMG_LAUNCH_CHECK("stencil7_pair_tile_kernel");

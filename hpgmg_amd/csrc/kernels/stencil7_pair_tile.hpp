@@ -27,9 +27,11 @@ struct S7PairTileArgs {
 
 template <int V> struct S7Coef { double bi0, bi1, bj0, bj1, bk0, bk1, al, dinv, rhs; };
 
-template <int V, int TJ>
-__global__ __launch_bounds__(64 * TJ) __attribute__((amdgpu_waves_per_eu(4, 8))) void stencil7_pair_tile_kernel(const hpgmg_hip_level L, const S7PairTileArgs P) {
-  constexpr int TI = 64, NT = TI * TJ;
+// TI x TJ tiles: 64 x 8 for boxes of side 64 m; 32 x 8 / 16 x 16 for the levels of boxes of 32^3 / 16^3 (round 3: there a sweep is a launch of
+// ~5 us that is mostly launch, and two sweeps per launch halve the count)
+template <int V, int TJ, int TI = 64>
+__global__ __launch_bounds__(TI * TJ) __attribute__((amdgpu_waves_per_eu(4, 8))) void stencil7_pair_tile_kernel(const hpgmg_hip_level L, const S7PairTileArgs P) {
+  constexpr int NT = TI * TJ;
   constexpr int WO = TI + 4, HO = TJ + 4, PO = WO * HO;          // planes of x0: two-cell halo (the corners are never read: star stencil)
   constexpr int WP = TI + 2, HP = TJ + 2, PP = WP * HP;          // planes of x1: one-cell halo
   constexpr int NHO = 4 * WO + 4 * TJ;

@@ -108,15 +108,18 @@ def test_fused_chebyshev_sweep_pairs(hip, oracle, variant, geom):
 
 
 @pytest.mark.parametrize("variant,geom", [("7pt-cheby-helm", (2, 64)), ("7pt-cheby", (1, 64)), ("7ptcc-cheby", (2, 64)), ("7pt-cheby-helm", (3, 64)),
-                                          ("7pt-cheby-helm", (1, 128)), ("7pt-cheby", (3, 64))])
+                                          ("7pt-cheby-helm", (1, 128)), ("7pt-cheby", (3, 64)),
+                                          ("7pt-cheby-helm", (2, 32)), ("7pt-cheby", (1, 32)), ("7ptcc-cheby", (2, 32)), ("7pt-cheby-helm", (3, 16)),
+                                          ("7pt-cheby", (2, 16)), ("7ptcc-cheby", (1, 16)), ("7pt-cheby-helm", (4, 16))])
 def test_chebyshev_sweep_pairs_on_cache_resident_levels(hip, oracle, variant, geom):
-    """Levels too small for the row-wise sweep-pair kernel (below 4 M cells, or rows that are no multiple of 128 cells) but made of boxes of
-    side 64 m run their Chebyshev smooth() as two launches of two sweeps each in tile form (stencil7_pair_tile.hpp): U and VECTOR_TEMP must
-    equal the oracle's four separate sweeps bit for bit; the in-cycle form (x3 not stored) must give the same iterate."""
+    """Levels too small for the row-wise sweep-pair kernel (below 4 M cells, or rows that are no multiple of 128 cells) run their Chebyshev
+    smooth() as two launches of two sweeps each in tile form (stencil7_pair_tile.hpp): boxes of side 64 m, of 32^3 and of 16^3
+    (opt-in, EXPERIMENTS=1: measured slower than single-sweep launches for every one of them).  U and VECTOR_TEMP must equal the oracle's
+    four separate sweeps bit for bit; the in-cycle form (x3 not stored) must give the same iterate."""
     K = H.load_kernels()
     K.hpgmg_hip_pair_tile_launch_count.restype = ctypes.c_longlong
     if not K.hpgmg_hip_experiments():
-        pytest.skip("the two-sweep tile kernel is only in builds with EXPERIMENTS=1 (it measured slower than what it replaces)")
+        pytest.skip("the two-sweep tile kernel is only in builds with EXPERIMENTS=1 (it measured slower than what it replaces, for every box size)")
     K.hpgmg_hip_set_pair_tile.argtypes = [ctypes.c_int]
     K.hpgmg_hip_set_pair_tile(1)          # opt-in: on the 128^3 level of config 2 it measured slower than two single-sweep launches
     hip.lib.hpgmg_smooth_in_cycle.restype = ctypes.c_int
