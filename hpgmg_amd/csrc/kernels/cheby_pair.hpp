@@ -63,9 +63,16 @@ struct LaneShift { long long lvl, scr, c32; };   // element offsets for level ve
 __device__ __forceinline__ long long shift_of(const LaneShift &s, VecRef r) { return r.scratch ? s.scr : s.lvl; }
 
 struct alignas(16) p2 { double x, y; };
-__device__ __forceinline__ p2 pld(const double *p) { return *reinterpret_cast<const p2 *>(p); }
+// Device memory is addressed as such (address space 1: global_load / global_store), not through generic pointers: a FLAT access counts
+// against lgkmcnt as well as vmcnt, and the box-base pointers these kernels look up per plane are scalar loads -- each wait for one of them
+// (lgkmcnt) was a wait for every FLAT load already in flight, so the eight streams of a step were fetched one round trip after the other.
+typedef double __attribute__((ext_vector_type(2))) d2v;
+typedef const d2v __attribute__((address_space(1))) *gd2cptr;
+typedef d2v __attribute__((address_space(1))) *gd2ptr;
+__device__ __forceinline__ p2 pld(const double *p) { const d2v v = *(gd2cptr)as_global(p); return p2{v.x, v.y}; }
 // (non-temporal stores for x1/x2 were measured: 4.15 vs 3.80 ms per F-cycle -- slower; plain stores stay)
-__device__ __forceinline__ void pst(double *p, p2 v) { *reinterpret_cast<p2 *>(p) = v; }
+__device__ __forceinline__ void pst(double *p, p2 v) { d2v w; w.x = v.x; w.y = v.y; *(gd2ptr)as_global(p) = w; }
+__device__ __forceinline__ double gld1(const double *p) { return *as_global(p); }      // one double of device memory
 __device__ __forceinline__ p2 pneg(p2 v) { return p2{-v.x, -v.y}; }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
@@ -82,10 +89,10 @@ template <bool C32> struct CoefStream {
     else     { p64 = L.box_base[box] + (size_t)vec_id * (size_t)L.volume + first + sh.lvl; p32 = nullptr; }
   }
   __device__ __forceinline__ p2 pair(int off) const {
-    if (C32) { const float2 f = *reinterpret_cast<const float2 *>(p32 + off); return p2{(double)f.x, (double)f.y}; }
+    if (C32) { typedef float __attribute__((ext_vector_type(2))) f2v; const f2v f = *(const f2v __attribute__((address_space(1))) *)(p32 + off); return p2{(double)f.x, (double)f.y}; }
     return pld(p64 + off);
   }
-  __device__ __forceinline__ double one(int off) const { return C32 ? (double)p32[off] : p64[off]; }
+  __device__ __forceinline__ double one(int off) const { return C32 ? (double)*(const float __attribute__((address_space(1))) *)(p32 + off) : gld1(p64 + off); }
 };
 
 // coefficients of one plane for a lane's two cells
@@ -112,8 +119,9 @@ __device__ __forceinline__ p2 pair_update(p2 c, double left, double right, p2 jm
   return o;
 }
 
+constexpr int kPairMaxBoxes = 1024;       // boxes per rank the pair kernel takes (their base-pointer tables are copied into LDS, see below)
 template <int V, int NW, bool C32, int SM, bool NARROW, bool INTERP, bool REMOTE = false>
-__global__ __launch_bounds__(64 * NW) void cheby_pair_kernel(const hpgmg_hip_level L, const PairArgs A) {
+__global__ __launch_bounds__(64 * NW) void cheby_pair_kernel(const hpgmg_hip_level L_in, const PairArgs A_in) {
   static_assert(!(REMOTE && (NARROW || INTERP || C32)), "the multi-rank variant is built for whole-row boxes, fp64 coefficients, no folded interpolation");
   constexpr bool kVC = (V != HPGMG_HIP_7PT_CC);
   constexpr bool kHelm = (V == HPGMG_HIP_7PT_VC_HELMHOLTZ);
@@ -122,6 +130,30 @@ __global__ __launch_bounds__(64 * NW) void cheby_pair_kernel(const hpgmg_hip_lev
   p2 (*slabX0)[NW][64] = reinterpret_cast<p2 (*)[NW][64]>(pair_lds);
   p2 (*slabX1)[NW][64] = reinterpret_cast<p2 (*)[NW][64]>(pair_lds + 2 * NW * 64);
   p2 (*slabBJ)[NW][64] = reinterpret_cast<p2 (*)[NW][64]>(pair_lds + 4 * NW * 64);
+  // The box-base tables (level vectors, scratch vectors, fp32 copies, the coarse level of a folded interpolation) are looked up for every
+  // stream of every plane.  From memory that is a load whose result the stream's own load has to wait for -- and the wait, counting
+  // loads in flight, also waited for every stream issued before it: the eight streams of a step went out one round trip after the
+  // other (timeline: 6 us per step in the load phase).  Copies of the tables in LDS make the lookup a ds_read, which nothing in flight
+  // to memory delays, and the level / argument structs below point at them.
+  __shared__ double *sTabLvl[kPairMaxBoxes];
+  __shared__ double *sTabScr[kPairMaxBoxes];
+  __shared__ const float *sTabC32[C32 ? kPairMaxBoxes : 1];
+  __shared__ double *sTabCrs[INTERP ? kPairMaxBoxes : 1];
+  hpgmg_hip_level L = L_in;
+  PairArgs A = A_in;
+  {
+    const int nt = 64 * NW, tid0 = (int)threadIdx.y * 64 + (int)threadIdx.x;
+    for (int bx = tid0; bx < L_in.num_boxes; bx += nt) {
+      sTabLvl[bx] = L_in.box_base[bx];
+      sTabScr[bx] = A_in.scr_base ? A_in.scr_base[bx] : nullptr;
+      if (C32) sTabC32[bx] = A_in.c32_base[bx];
+      if (INTERP) sTabCrs[bx] = A_in.Lc.box_base[bx];
+    }
+    L.box_base = sTabLvl; A.scr_base = sTabScr;
+    if (C32) A.c32_base = sTabC32;
+    if (INTERP) A.Lc.box_base = sTabCrs;
+    __syncthreads();
+  }
 
   const int logical = xcd_logical_block((int)blockIdx.x, A.per_xcd);
   if (logical >= A.total_blocks) return;
@@ -176,14 +208,14 @@ __global__ __launch_bounds__(64 * NW) void cheby_pair_kernel(const hpgmg_hip_lev
   auto x0_pair = [&](int box, int l_i, int l_j, int gk) -> p2 {
     p2 v = pld(pair_vec(L, A, A.x0, box) + shift_of(sh, A.x0) + l_i + l_j * jS + plane_off(gk));
     if (INTERP) {
-      const double c = vec_origin(A.Lc, box, A.coarse_id)[(l_i >> 1) + (l_j >> 1) * A.Lc.jStride + ((gk % bd) >> 1) * A.Lc.kStride];
+      const double c = gld1(vec_origin(A.Lc, box, A.coarse_id) + ((l_i >> 1) + (l_j >> 1) * A.Lc.jStride + ((gk % bd) >> 1) * A.Lc.kStride));
       v.x = A.prescale * v.x + c; v.y = A.prescale * v.y + c;
     }
     return v;
   };
   auto x0_one = [&](int box, int l_i, int l_j, int gk) -> double {
-    double v = pair_vec(L, A, A.x0, box)[l_i + l_j * jS + plane_off(gk)];
-    if (INTERP) v = A.prescale * v + vec_origin(A.Lc, box, A.coarse_id)[(l_i >> 1) + (l_j >> 1) * A.Lc.jStride + ((gk % bd) >> 1) * A.Lc.kStride];
+    double v = gld1(pair_vec(L, A, A.x0, box) + (l_i + l_j * jS + plane_off(gk)));
+    if (INTERP) v = A.prescale * v + gld1(vec_origin(A.Lc, box, A.coarse_id) + ((l_i >> 1) + (l_j >> 1) * A.Lc.jStride + ((gk % bd) >> 1) * A.Lc.kStride));
     return v;
   };
   // REMOTE: the same pair on ANY plane x0 is known on -- inside, ghost (-1, Dk) or deep (-2, Dk+1).  A deep plane of a ghost row
@@ -315,8 +347,8 @@ __global__ __launch_bounds__(64 * NW) void cheby_pair_kernel(const hpgmg_hip_lev
       double left = __shfl_up(x1m1.y, 1, 64), right = __shfl_down(x1m1.x, 1, 64);
       // across a tile edge -- and, REMOTE, across a remote i face -- x1 was written beforehand by cheby_pair_edge_kernel
 #ifndef HPGMG_EXP_NO_X1EDGE
-      if (lane == 0)  left  = (left_dom && !left_ghost)   ? -x1m1.x : pair_vec(L, A, A.out1, box_of(biL, bj_, q))[liL + lj * jS + plane_off(q)];
-      if (lane == 63) right = (right_dom && !right_ghost) ? -x1m1.y : pair_vec(L, A, A.out1, box_of(biR, bj_, q))[liR + lj * jS + plane_off(q)];
+      if (lane == 0)  left  = (left_dom && !left_ghost)   ? -x1m1.x : gld1(pair_vec(L, A, A.out1, box_of(biL, bj_, q)) + (liL + lj * jS + plane_off(q)));
+      if (lane == 63) right = (right_dom && !right_ghost) ? -x1m1.y : gld1(pair_vec(L, A, A.out1, box_of(biR, bj_, q)) + (liR + lj * jS + plane_off(q)));
 #endif
       const p2 x2 = pair_update<V, SM>(x1m1, left, right, jm, jp, km, kp, x0m, qp, A.a, A.b, A.h2inv, A.c1b, A.c2b, ((gj ^ q ^ (A.sweep_a + 1)) & 1) == 0);
       pst(pair_vec(L, A, A.out2, boxq) + shift_of(sh, A.out2) + offq, x2);
@@ -349,8 +381,8 @@ __global__ __launch_bounds__(64 * NW) void cheby_pair_kernel(const hpgmg_hip_lev
       const p2 km = in_dom(q - 1) ? x1m2 : pneg(x1m1);
       const p2 kp = pneg(x1m1);
       double left = __shfl_up(x1m1.y, 1, 64), right = __shfl_down(x1m1.x, 1, 64);
-      if (lane == 0)  left  = (left_dom && !left_ghost)   ? -x1m1.x : pair_vec(L, A, A.out1, box_of(biL, bj_, q))[liL + lj * jS + plane_off(q)];
-      if (lane == 63) right = (right_dom && !right_ghost) ? -x1m1.y : pair_vec(L, A, A.out1, box_of(biR, bj_, q))[liR + lj * jS + plane_off(q)];
+      if (lane == 0)  left  = (left_dom && !left_ghost)   ? -x1m1.x : gld1(pair_vec(L, A, A.out1, box_of(biL, bj_, q)) + (liL + lj * jS + plane_off(q)));
+      if (lane == 63) right = (right_dom && !right_ghost) ? -x1m1.y : gld1(pair_vec(L, A, A.out1, box_of(biR, bj_, q)) + (liR + lj * jS + plane_off(q)));
       const p2 x2 = pair_update<V, SM>(x1m1, left, right, jm, jp, km, kp, x0m, qp, A.a, A.b, A.h2inv, A.c1b, A.c2b, ((gj ^ q ^ (A.sweep_a + 1)) & 1) == 0);
       pst(pair_vec(L, A, A.out2, boxq) + shift_of(sh, A.out2) + offq, x2);
     }
@@ -398,8 +430,8 @@ __global__ __launch_bounds__(256) void cheby_pair_edge_kernel(const hpgmg_hip_le
       }
     }
     int box; const int idx = cell(ci, cj, ck, box);
-    double v = pair_vec(L, A, A.x0, box)[idx];
-    if (INTERP) v = A.prescale * v + vec_origin(A.Lc, box, A.coarse_id)[((ci % bd) >> 1) + ((cj % bd) >> 1) * A.Lc.jStride + ((ck % bd) >> 1) * A.Lc.kStride];
+    double v = gld1(pair_vec(L, A, A.x0, box) + idx);
+    if (INTERP) v = A.prescale * v + gld1(vec_origin(A.Lc, box, A.coarse_id) + (((ci % bd) >> 1) + ((cj % bd) >> 1) * A.Lc.jStride + ((ck % bd) >> 1) * A.Lc.kStride));
     return v;
   };
   int box; const int idx = cell(gi, gj, gk, box);

@@ -1089,7 +1089,7 @@ int hpgmg_hip_smooth_cheby(const hpgmg_hip_level *L, int variant, int xn_id, int
 // no error recorded) when the level does not fit the kernel's assumptions, so the caller can fall back.
 static int pair_supported_dims(const hpgmg_hip_level *L, int variant, int Di, int Dj, int Dk) {
   if (variant != HPGMG_HIP_7PT_VC_HELMHOLTZ && variant != HPGMG_HIP_7PT_VC_POISSON && variant != HPGMG_HIP_7PT_CC) return 0;
-  if (L->num_boxes <= 0 || L->periodic || !(L->flags & 1) || L->ghosts < 1 || Di % 128 != 0) return 0;
+  if (L->num_boxes <= 0 || L->num_boxes > kPairMaxBoxes || L->periodic || !(L->flags & 1) || L->ghosts < 1 || Di % 128 != 0) return 0;
   // a wave owns a 128-cell row: whole multiples of 128 per box, or several boxes (consecutive in one slab) per row
   if (L->dim % 128 != 0 && !(128 % L->dim == 0 && L->dim >= 16 && (L->box_stride > 0 || L->num_boxes == 1))) return 0;
   if (L->jStride % 2 || L->kStride % 2 || L->volume % 2) return 0;
