@@ -1225,6 +1225,7 @@ static const int *fv4_special_cells(level_type *L, backend_t *B, int *n_out) {
   *n_out = B->n_fv4_special;
   return B->d_fv4_special;
 }
+static void do_scale_vector(level_type *L, int c, double s, int a);
 static int smooth_fv4_rb(level_type *L, int x_id, int rhs_id, double a, double b, int sweeps) {
   hpgmg_config cfg;
   hpgmg_get_config(&cfg);
@@ -1261,7 +1262,7 @@ static int smooth_fv4_rb(level_type *L, int x_id, int rhs_id, double a, double b
     TOCK();
     src_s = dst_s; src_id = dst_id;
   }
-  if (passes == 1) scale_vector(L, x_id, 1.0, VECTOR_TEMP);      /* a single pass cannot land on its own input (never the case with the reference's counts) */
+  if (passes == 1) do_scale_vector(L, x_id, 1.0, VECTOR_TEMP);      /* a single pass cannot land on its own input (never the case with the reference's counts) */
   fv4_rb_smooths++;
   return 1;
 }
@@ -1420,7 +1421,7 @@ static int residual_restrict_zero_fused(level_type *Lc, int id_c, level_type *Lf
 }
 /* norm(L, F) ; scale_vector(L, R, 1.0, F) ; restriction(Lc, R, L, R, RESTRICT_CELL) -- how FMGSolve starts (mg.c:1262-1270) -- in one pass over F.
  * Every rank's share of the restriction must be local.  0 = not applicable. */
-int hpgmg_norm_scale_restrict_fused(level_type *L, int F_id, int R_id, level_type *Lc, double *norm_out) {
+static int norm_scale_restrict_fused(level_type *L, int F_id, int R_id, level_type *Lc, double *norm_out) {
   communicator_type *S = &L->restriction[RESTRICT_CELL], *R = &Lc->restriction[RESTRICT_CELL];
   if (!fused_residual_on() || !L->active || !Lc->active || L->num_my_boxes < 1 || Lc->num_my_boxes < 1 || F_id == R_id) return 0;
   if (S->num_sends || R->num_recvs || S->num_blocks[0] || R->num_blocks[2] || S->num_blocks[1] < 1) return 0;
@@ -1428,12 +1429,13 @@ int hpgmg_norm_scale_restrict_fused(level_type *L, int F_id, int R_id, level_typ
   if ((L->box_dim & 1) || !(B->dev.flags & 1) || (L->box_jStride & 1) || (L->box_kStride & 1) || (L->box_volume & 1) || L->box_dim < 16) return 0;
   if (!restrict_map_of(L, B)) return 0;
   double v = 0.0;
-  { TICK(L, blas1, "norm(F) + R = F + restriction (fused)");
-    HIP_OK(hpgmg_hip_norm_copy_restrict(&B->dev, F_id, R_id, &Bc->dev, R_id, B->d_restrict_map, &v));
+  { TICK(L, blas1, norm_out ? "norm(F) + R = F + restriction (fused)" : "R = F + restriction (fused)");
+    HIP_OK(hpgmg_hip_norm_copy_restrict(&B->dev, F_id, R_id, &Bc->dev, R_id, B->d_restrict_map, norm_out ? &v : NULL));
     TOCK(); }
-  *norm_out = allreduce_scalar(L, v, HPGMG_REDUCE_MAX);
+  if (norm_out) *norm_out = allreduce_scalar(L, v, HPGMG_REDUCE_MAX);
   return 1;
 }
+int hpgmg_norm_scale_restrict_fused(level_type *L, int F_id, int R_id, level_type *Lc, double *norm_out) { return norm_scale_restrict_fused(L, F_id, R_id, Lc, norm_out); }
 /* residual(L, res, x, rhs) ; norm(L, res) -- the convergence check of MGSolve / FMGSolve (mg.c:1321-1323) -- in one pass: the residual is
  * stored as usual (res_id < 0: not stored -- the cycle driver's check, after which VECTOR_TEMP is dead) and its max-abs comes out of the
  * same kernel.  0 = not applicable. */
@@ -1499,7 +1501,7 @@ void init_vector(level_type *L, int id, double s) { BLAS1(hpgmg_hip_fill(&backen
 void add_vectors(level_type *L, int c, double sa, int a, double sb, int b) { BLAS1(hpgmg_hip_axpby(&backend_of(L)->dev, c, sa, a, sb, b)); }
 void mul_vectors(level_type *L, int c, double s, int a, int b) { BLAS1(hpgmg_hip_mul(&backend_of(L)->dev, c, s, a, b)); }
 void invert_vector(level_type *L, int c, double s, int a) { BLAS1(hpgmg_hip_invert(&backend_of(L)->dev, c, s, a)); }
-void scale_vector(level_type *L, int c, double s, int a) { BLAS1(hpgmg_hip_scale(&backend_of(L)->dev, c, s, a)); }
+static void do_scale_vector(level_type *L, int c, double s, int a) { BLAS1(hpgmg_hip_scale(&backend_of(L)->dev, c, s, a)); }
 void shift_vector(level_type *L, int c, int a, double shift) { BLAS1(hpgmg_hip_shift(&backend_of(L)->dev, c, a, shift)); }
 void color_vector(level_type *L, int id, int colors, int ic, int jc, int kc) { BLAS1(hpgmg_hip_color(&backend_of(L)->dev, id, colors, ic, jc, kc)); }
 void random_vector(level_type *L, int id) { BLAS1(hpgmg_hip_random(&backend_of(L)->dev, id)); }
@@ -1699,8 +1701,9 @@ void rebuild_operator(level_type *L, level_type *from, double a, double b) {
  *   - interpolation_vcycle + smooth of a large level: the interpolation folded into the first sweep pair;
  *   - residual(res) followed by norm(res): one pass (norm() asks the queue).
  * Every fused form used here leaves exactly the vectors the separate operators leave (VECTOR_TEMP included).  HPGMG_LAZY=0 turns the queue off. */
-enum { LZ_SMOOTH = 1, LZ_RESIDUAL, LZ_RESTRICT, LZ_ZERO, LZ_INTERP };
-enum { LZ_NONE = 0, LZ_DOWN, LZ_UP, LZ_RN };      /* RN: a lone residual() waiting to see whether norm() of its result follows (mg.c:1321-1323) */
+enum { LZ_SMOOTH = 1, LZ_RESIDUAL, LZ_RESTRICT, LZ_ZERO, LZ_INTERP, LZ_SCALE };
+enum { LZ_NONE = 0, LZ_DOWN, LZ_UP, LZ_RN, LZ_SR };      /* RN: a lone residual() waiting to see whether norm() of its result follows (mg.c:1321-1323);
+                                                          * SR: scale_vector(R, 1.0, F) waiting for restriction(coarse R <- R): how FMGSolve starts (mg.c:1266-1277) */
 typedef struct { int op; level_type *L, *L2; int i0, i1, i2; double a, b; } lazy_op;
 #define LZ_MAX 80
 static lazy_op lz[LZ_MAX];
@@ -1726,6 +1729,7 @@ static void lazy_run_one(const lazy_op *o) {
     case LZ_RESTRICT: do_restriction(o->L, o->i0, o->L2, o->i1, o->i2); break;
     case LZ_ZERO:     do_zero_vector(o->L, o->i0); break;
     case LZ_INTERP:   do_interpolation_vcycle(o->L, o->i0, o->a, o->L2, o->i1); break;
+    case LZ_SCALE:    do_scale_vector(o->L, o->i0, o->a, o->i1); break;
   }
 }
 static void lazy_flush(void) {
@@ -1771,6 +1775,8 @@ static void lazy_flush(void) {
       else { lazy_run_one(ip); lazy_run_one(sm); }
     }
     q = 2 * units;
+  } else if (mode == LZ_SR && n == 2) {                   /* R = 1.0 * F, then its restriction: one pass over F (the norm the kernel also forms is not asked for) */
+    if (norm_scale_restrict_fused(lz[0].L, lz[0].i1, lz[0].i0, lz[1].L, NULL)) { lazy_fused_units++; q = 2; }
   }
   for (; q < n; q++) lazy_run_one(&lz[q]);                /* a unit the caller did not finish */
   lz_n = 0; lz_mode = LZ_NONE;
@@ -1778,7 +1784,7 @@ static void lazy_flush(void) {
 }
 /* does this call continue the pattern?  1: recorded, the caller returns; 0: the caller flushes and runs it */
 static int lazy_push(int op, level_type *L, level_type *L2, int i0, int i1, int i2, double a, double b) {
-  if (!lazy_enabled() || lz_n == LZ_MAX) return 0;
+  if (!lazy_enabled() || lz_n == LZ_MAX || lz_busy) return 0;      /* busy: the queue is being issued; what its operators call runs at once */
   hpgmg_config cfg;
   hpgmg_get_config(&cfg);
   if (cfg.op != HPGMG_OP_7PT) return 0;                   /* the fused forms used by the queue are the 7-point plugin's */
@@ -1787,6 +1793,9 @@ static int lazy_push(int op, level_type *L, level_type *L2, int i0, int i1, int 
     if (op == LZ_SMOOTH) { ok = 1; lz_mode = LZ_DOWN; }
     else if (op == LZ_INTERP && a == 1.0 && i0 == i1) { ok = 1; lz_mode = LZ_UP; }
     else if (op == LZ_RESIDUAL) { ok = 1; lz_mode = LZ_RN; }
+    else if (op == LZ_SCALE && a == 1.0 && i0 != i1) { ok = 1; lz_mode = LZ_SR; }
+  } else if (lz_mode == LZ_SR) {
+    ok = (lz_n == 1 && op == LZ_RESTRICT && L2 == lz[0].L && i1 == lz[0].i0 && i0 == lz[0].i0 && i2 == RESTRICT_CELL && L != lz[0].L);
   } else if (lz_mode == LZ_DOWN) {
     const int pos = lz_n % 4;
     const lazy_op *s0 = &lz[lz_n - pos];                  /* this unit's smooth (pos > 0) */
@@ -1821,6 +1830,12 @@ void restriction(level_type *Lc, int id_c, level_type *Lf, int id_f, int type) {
   if (lazy_push(LZ_RESTRICT, Lc, Lf, id_c, id_f, type, 0.0, 0.0)) return;
   lazy_flush();
   do_restriction(Lc, id_c, Lf, id_f, type);
+}
+void scale_vector(level_type *L, int c, double s, int a) {
+  if (lazy_push(LZ_SCALE, L, NULL, c, a, 0, s, 0.0)) return;
+  lazy_flush();
+  if (lazy_push(LZ_SCALE, L, NULL, c, a, 0, s, 0.0)) return;
+  do_scale_vector(L, c, s, a);
 }
 void zero_vector(level_type *L, int id) {
   if (lazy_push(LZ_ZERO, L, NULL, id, 0, 0, 0.0, 0.0)) return;

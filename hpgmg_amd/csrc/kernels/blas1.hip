@@ -392,12 +392,13 @@ int hpgmg_hip_random(const hpgmg_hip_level *L, int id) {
 
 int hpgmg_hip_norm_copy_restrict(const hpgmg_hip_level *L, int f_id, int r_id, const hpgmg_hip_level *Lc, int rc_id, const int *map, double *norm_out) {
   if (int e = hpgmg_hip_graph_flush()) return e;
-  *norm_out = 0.0;
+  if (norm_out) *norm_out = 0.0;
   if (L->num_boxes <= 0 || Lc->num_boxes <= 0 || (L->dim & 1) || !(L->flags & 1) || (L->jStride & 1) || (L->kStride & 1) || (L->volume & 1) || f_id == r_id)
     return record_error(hipErrorInvalidValue, "norm_copy_restrict: level not supported");
   const int nblk = rows_grid(L->num_boxes * (L->dim / 2) * (L->dim / 2));
   if (int e = ensure_scratch(nblk)) return e;
   hipLaunchKernelGGL(norm_copy_restrict_kernel, dim3(nblk), dim3(256), 0, g_stream, *L, f_id, r_id, *Lc, rc_id, map, g_scratch);
+  if (!norm_out) { HPGMG_LAUNCH_CHECK("norm_copy_restrict (copy + restriction only)"); return 0; }     // the norm is not wanted: nothing to reduce, nothing to wait for
   hipLaunchKernelGGL(final_max_kernel, dim3(1), dim3(256), 0, g_stream, (const double *)g_scratch, nblk, 0.0, g_result_dev, ++g_seq);
   HPGMG_LAUNCH_CHECK("norm_copy_restrict");
   return fetch_result(norm_out);
