@@ -17,4 +17,9 @@ f=$(find gpurun_out/prof_${tag}/fetch -name '*.db' | head -1); w=$(find gpurun_o
 python3 tools/rocprof_summary.py "$f" --out gpurun_out/${tag}_pmc_fetch </dev/null > /dev/null
 python3 tools/rocprof_summary.py "$w" --out gpurun_out/${tag}_pmc_write </dev/null > /dev/null
 python3 tools/pmc_summary.py "$f" "$w" gpurun_out/${tag}_pmc_summary.json --cells $cells </dev/null
+# the plain bench line once more, now that this build's counter summary exists: roofline.traffic / traffic_source on the line are then this tag's
+# (the copy under profiles/ lives on this box only; the caller copies gpurun_out/${tag}_* into profiles/ of the repository)
+cp gpurun_out/${tag}_pmc_summary.json profiles/ 2>/dev/null
+timeout 900 python3 bench.py --workload $wl > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err </dev/null
+tail -1 gpurun_out/${tag}_bench.json | cut -c1-200
 find gpurun_out/prof_${tag} -name '*.db' -size +30M -delete
