@@ -1161,6 +1161,36 @@ static int small_level_try(level_type *L, int mode, int x_id, int rhs_id, int re
   return 1;
 }
 
+/* IterativeSolver's BiCGStab on a bottom level of one small box of the 27-point / fv2 / fv4 plugins as ONE launch (kernels/stencil.hip:
+ * bottom_bicgstab_kernel; the 7-point plugin's bottom solve lives in its tail kernel).  Driven from the host, an iteration is ~25 launches and
+ * ~6 host round trips on a level of 8 cells.  HPGMG_FUSED_BOTTOM=0 keeps the host-driven solver. */
+int hpgmg_bottom_solve_fused(level_type *L, int e_id, int R_id, double a, double b, double want) {
+  static int on = -1;
+  hpgmg_config cfg;
+  if (on < 0) { const char *e = getenv("HPGMG_FUSED_BOTTOM"); on = !(e && e[0] == '0'); }
+  hpgmg_get_config(&cfg);
+  if (!on || cfg.op == HPGMG_OP_7PT || !L->active || L->num_my_boxes != 1 || L->boxes_in.i * L->boxes_in.j * L->boxes_in.k != 1) return 0;
+  if (L->boundary_condition.type == BC_PERIODIC || L->must_subtract_mean == 1) return 0;
+  if ((long long)L->dim.i * L->dim.j * L->dim.k > hpgmg_hip_bottom_bicgstab_max_cells()) return 0;
+  const int shape = stencil_get_shape();
+  communicator_type *C = &L->exchange_ghosts[shape];
+  if (C->num_sends + C->num_recvs > 0 || C->num_blocks[0] || C->num_blocks[1] || C->num_blocks[2]) return 0;      /* one box: nothing to exchange */
+  int bc_kind, zero_first = 0;
+  const int n_bc = L->boundary_condition.num_blocks[shape];
+  if (cfg.op == HPGMG_OP_27PT) bc_kind = (L->box_dim < 2) ? 1 : 2;                                    /* as small_level_try / apply_BCs */
+  else if (cfg.op == HPGMG_OP_FV2 || L->box_dim < 4) { bc_kind = (L->box_dim < 2) ? 1 : 3; zero_first = (bc_kind == 3 && L->box_ghosts > 1); }
+  else { bc_kind = 4; zero_first = (L->box_ghosts > 2); }
+  lazy_flush();
+  backend_t *B = backend_of(L);
+  if (!B->krylov_pinned) { B->krylov_pinned = (int *)hpgmg_hip_host_malloc(64); if (B->krylov_pinned) *B->krylov_pinned = 0; }
+  if (!B->krylov_pinned) return 0;
+  hpgmg_tick tk = hpgmg_tick_begin(L, &L->timers.Total, "bottom solve, one launch");
+  HIP_OK(hpgmg_hip_bottom_bicgstab(&B->dev, variant(), e_id, R_id, hpgmg_vectors_reserved(), a, b, 1.0 / (L->h * L->h), want,
+                                   n_bc ? mirror(L, L->boundary_condition.blocks[shape], n_bc) : NULL, n_bc, bc_kind, zero_first, B->krylov_pinned));
+  hpgmg_tick_end(tk);
+  return 1;
+}
+
 /* smooth() as the cycle driver uses it (mg.c:1148,1161): same iterate, but VECTOR_TEMP is left unspecified -- the next operator of a
  * cycle overwrites or ignores it.  Always returns 1 (the hook exists so that the reference's own driver, which never calls it, keeps
  * the exact state of smooth()). */

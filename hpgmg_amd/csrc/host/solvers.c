@@ -82,5 +82,6 @@ void IterativeSolver(level_type *L, int u_id, int f_id, double a, double b, doub
     if (hpgmg_vectors_reserved() > VECTOR_ALPHA) alpha_is_zero = (dot(L, VECTOR_ALPHA, VECTOR_ALPHA) == 0.0);
     if (L->boundary_condition.type == BC_PERIODIC && (a == 0 || alpha_is_zero)) L->must_subtract_mean = 1;
   }
+  if (L->must_subtract_mean != 1 && hpgmg_bottom_solve_fused(L, u_id, f_id, a, b, desired_reduction_in_norm)) return;   /* the same solver as one device launch */
   bicgstab(L, u_id, f_id, a, b, desired_reduction_in_norm);
 }

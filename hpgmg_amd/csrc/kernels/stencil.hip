@@ -725,6 +725,156 @@ __global__ __launch_bounds__(1024) void small_level_kernel(const hpgmg_hip_level
 
 #endif  // HPGMG_EXPERIMENTS
 
+
+// ---------------------------------------------------------------------------------------------
+// Bottom solve of the 27-point / fv2 / fv4 plugins: diagonally preconditioned BiCGStab (solvers/bicgstab.c:14-97) on a bottom level of ONE
+// box as one single-workgroup launch.  Driven from the host it is ~25 launches and ~6 host round trips (the dot products and norms) per
+// iteration on a level of 8 cells: 1.5 ms of a 33 ms fv4 F-cycle at 512^3, a quarter of one at 128^3.  One cell per lane, every vector a
+// register; the vector the operator is applied to passes through an image of the padded box in LDS, on which the boundary entries of the
+// level run (the same entry routines as the streaming kernels) before the stencil (the same per-cell expression).  The operation sequence,
+// the expression of every BLAS-1 step (misc.c: c = sa*a + sb*b, c = s*a*b), the break-down tests and the order of the sums -- one partial
+// per dim x 8 x 8 tile accumulated k, j, i, partials added in tile order (misc.c:261-269) -- are those of host/solvers.c, so the iterates,
+// the iteration count and the coarse correction are bit-identical to the host-driven solve (the 7-point plugin's form of this: tail.hip).
+struct BottomArgs {
+  int e_id, R_id, krylov_base, bc_kind, zero_first, n_bc;
+  double a, b, h2inv, want;
+  const blockCopy_type *bc_list;
+  int *krylov_iterations;
+};
+template <int V>
+__global__ __launch_bounds__(512) void bottom_bicgstab_kernel(const hpgmg_hip_level L, const BottomArgs A) {
+  constexpr bool k27 = (V == HPGMG_HIP_27PT_CC);
+  constexpr bool kVC = (V != HPGMG_HIP_7PT_CC && !k27);
+  constexpr bool kHelm = (V == HPGMG_HIP_7PT_VC_HELMHOLTZ || V == HPGMG_HIP_FV4_VC_HELMHOLTZ);
+  extern __shared__ double bb_lds[];                               // the image of the padded box (L.volume doubles), then the reduction scratch
+  __shared__ double *s_tab[1];
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = (int)blockDim.x >> 6;
+  const int dim = L.dim, jS = L.jStride, kS = L.kStride, total = dim * dim * dim;
+  const bool active = tid < total;
+  const int ci = tid % dim, cj = (tid / dim) % dim, ck = tid / (dim * dim), ijk = ci + cj * jS + ck * kS;
+  double *img = bb_lds, *scr = bb_lds + L.volume;
+  hpgmg_hip_level Li = L;
+  if (tid == 0) s_tab[0] = img;
+  Li.box_base = s_tab;                                             // vector 0 of box 0 of Li = the image
+  for (int t = tid; t < L.volume; t += (int)blockDim.x) img[t] = 0.0;
+  __syncthreads();
+  double *xi = vec_origin(Li, 0, 0);
+  const double *alpha = kHelm ? vec_origin(L, 0, VECTOR_ALPHA) : nullptr;
+  const double *bi = kVC ? vec_origin(L, 0, VECTOR_BETA_I) : nullptr, *bj = kVC ? vec_origin(L, 0, VECTOR_BETA_J) : nullptr, *bk = kVC ? vec_origin(L, 0, VECTOR_BETA_K) : nullptr;
+  const int r0_id = A.krylov_base, r_id = r0_id + 1, p_id = r0_id + 2, q_id = r0_id + 3, s_id = r0_id + 4, t_id = r0_id + 5, Ap_id = r0_id + 6, As_id = r0_id + 7;
+  double x = 0, r0 = 0, r = 0, p = 0, q = 0, sv = 0, tv = 0, Ap = 0, As = 0, tmp = 0, dinv = 0, rhs = 0;
+  if (active) {
+    x = vec_origin(L, 0, A.e_id)[ijk]; rhs = vec_origin(L, 0, A.R_id)[ijk]; dinv = vec_origin(L, 0, VECTOR_DINV)[ijk];
+    r0 = vec_origin(L, 0, r0_id)[ijk]; r = vec_origin(L, 0, r_id)[ijk]; p = vec_origin(L, 0, p_id)[ijk]; q = vec_origin(L, 0, q_id)[ijk];
+    sv = vec_origin(L, 0, s_id)[ijk]; tv = vec_origin(L, 0, t_id)[ijk]; Ap = vec_origin(L, 0, Ap_id)[ijk]; As = vec_origin(L, 0, As_id)[ijk];
+    tmp = vec_origin(L, 0, VECTOR_TEMP)[ijk];
+  }
+  // apply_op(v): exchange_boundary (nothing to exchange: one box) + apply_BCs + the stencil (operators.*.c: apply_op)
+  auto apply = [&](double v) -> double {
+    if (active) xi[ijk] = v;
+    __syncthreads();
+    if (A.bc_kind && A.zero_first) { for (int e = wave; e < A.n_bc; e += nwaves) bc_zero_entry(Li, 0, A.bc_list[e], lane, 64); __syncthreads(); }
+    for (int e = wave; e < A.n_bc; e += nwaves) {
+      if (A.bc_kind == 1) bc_p1_entry(Li, 0, A.bc_list[e], lane, 64);
+      else if (A.bc_kind == 2) bc_p2_entry(Li, 0, A.bc_list[e], lane, 64);
+      else if (A.bc_kind == 3) bc_v2_entry(Li, 0, A.bc_list[e], lane, 64);
+      else if (A.bc_kind == 4) bc_v4_entry(Li, 0, A.bc_list[e], lane, 64);
+    }
+    __syncthreads();
+    double Ax = 0.0;
+    if (active) {
+      if (k27) {
+        const plane9 m = load_plane(xi + ijk - kS, jS), c = load_plane(xi + ijk, jS), pp = load_plane(xi + ijk + kS, jS);
+        Ax = apply_op_27pt(m, c, pp, A.a, A.b, A.h2inv);
+      } else {
+        Ax = apply_op_direct<V>(xi, alpha, bi, bj, bk, ijk, jS, kS, A.a, A.b, A.h2inv);
+      }
+    }
+    __syncthreads();
+    return Ax;
+  };
+  // dot(a, b): misc.c:230-280 -- per tile of 8 x 8 rows a partial accumulated k, j, i; the partials added in tile order
+  const int tiles_side = (dim + BLOCKCOPY_TILE_J - 1) / BLOCKCOPY_TILE_J, ntiles = tiles_side * ((dim + BLOCKCOPY_TILE_K - 1) / BLOCKCOPY_TILE_K);
+  auto dot = [&](double va, double vb) -> double {
+    if (active) scr[tid] = va * vb;
+    __syncthreads();
+    if (tid < ntiles) {
+      const int k0 = (tid / tiles_side) * BLOCKCOPY_TILE_K, j0 = (tid % tiles_side) * BLOCKCOPY_TILE_J;
+      const int k1 = min(k0 + BLOCKCOPY_TILE_K, dim), j1 = min(j0 + BLOCKCOPY_TILE_J, dim);
+      double acc = 0.0;
+      for (int k = k0; k < k1; k++) for (int j = j0; j < j1; j++) { const double *row = scr + dim * (j + dim * k); for (int i = 0; i < dim; i++) acc += row[i]; }
+      scr[512 + tid] = acc;
+    }
+    __syncthreads();
+    if (tid == 0) { double sum = 0.0; for (int t = 0; t < ntiles; t++) sum += scr[512 + t]; scr[1024] = sum; }
+    __syncthreads();
+    const double v = scr[1024];
+    __syncthreads();
+    return v;
+  };
+  auto norm = [&](double v) -> double {                            // max |v| (misc.c:303-349): exact under any order
+    double m = 0.0;
+    if (active) { const double f = fabs(v); m = (f > m) ? f : m; }
+    for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_down(m, off, 64); m = (o > m) ? o : m; }
+    if (lane == 0) scr[1032 + wave] = m;
+    __syncthreads();
+    m = scr[1032];
+    for (int w = 1; w < nwaves; w++) m = (scr[1032 + w] > m) ? scr[1032 + w] : m;
+    __syncthreads();
+    return m;
+  };
+  const double want = A.want;
+  int it = 0;
+  // host/solvers.c bicgstab(), Dirichlet (no mean to remove)
+  r0 = rhs - apply(x);
+  r = 1.0 * r0;
+  p = 1.0 * r0;
+  {
+    double rho = dot(r, r0);
+    const double r0_norm = norm(r);
+    if (!(rho == 0.0 || r0_norm == 0.0)) {
+      while (it < 200) {
+        it++;
+        q = 1.0 * dinv * p;
+        Ap = apply(q);
+        const double Ap_r0 = dot(Ap, r0);
+        if (Ap_r0 == 0.0) break;
+        const double al = rho / Ap_r0;
+        if (__builtin_isinf(al)) break;
+        x = 1.0 * x + al * q;
+        sv = 1.0 * r + (-al) * Ap;
+        const double s_norm = norm(sv);
+        if (s_norm == 0.0 || s_norm < want * r0_norm) break;
+        tv = 1.0 * dinv * sv;
+        As = apply(tv);
+        const double As_As = dot(As, As);
+        const double As_s = dot(As, sv);
+        if (As_As == 0.0) break;
+        const double omega = As_s / As_As;
+        if (omega == 0.0 || __builtin_isinf(omega)) break;
+        x = 1.0 * x + omega * tv;
+        r = 1.0 * sv + (-omega) * As;
+        const double r_norm = norm(r);
+        if (r_norm == 0.0 || r_norm < want * r0_norm) break;
+        const double rho_new = dot(r, r0);
+        if (rho_new == 0.0) break;
+        const double beta = (rho_new / rho) * (al / omega);
+        if (__builtin_isinf(beta)) break;
+        tmp = 1.0 * p + (-omega) * Ap;
+        p = 1.0 * r + beta * tmp;
+        rho = rho_new;
+      }
+    }
+  }
+  if (active) {
+    vec_origin(L, 0, A.e_id)[ijk] = x;
+    vec_origin(L, 0, r0_id)[ijk] = r0; vec_origin(L, 0, r_id)[ijk] = r; vec_origin(L, 0, p_id)[ijk] = p; vec_origin(L, 0, q_id)[ijk] = q;
+    vec_origin(L, 0, s_id)[ijk] = sv; vec_origin(L, 0, t_id)[ijk] = tv; vec_origin(L, 0, Ap_id)[ijk] = Ap; vec_origin(L, 0, As_id)[ijk] = As;
+    vec_origin(L, 0, VECTOR_TEMP)[ijk] = tmp;
+  }
+  if (tid == 0 && A.krylov_iterations) *A.krylov_iterations += it;
+}
+
 // ---- smoother-kernel profiling: hipEvent pair around every smoother launch ----
 static bool g_profile = false;
 static long long g_profile_min_cells = 0;   // only launches covering at least this many cells are timed
@@ -1378,6 +1528,38 @@ int hpgmg_hip_small_level_op(const hpgmg_hip_level *L, int variant, int mode, in
   return 0;
 }
 #endif  // HPGMG_EXPERIMENTS
+
+// BiCGStab bottom solve of the 27-point / fv2 / fv4 plugins on a level of one box (bottom_bicgstab_kernel): x_id holds the initial guess and
+// receives the solution; the eight work vectors start at krylov_base; bc_list / bc_kind / zero_first as for hpgmg_hip_small_level_op;
+// krylov_iterations: device-visible host counter the kernel adds its iteration count to, or NULL.  Dirichlet only.
+int hpgmg_hip_bottom_bicgstab_max_cells(void) { return 512; }
+int hpgmg_hip_bottom_bicgstab(const hpgmg_hip_level *L, int variant, int x_id, int rhs_id, int krylov_base, double a, double b, double h2inv, double want,
+                              const blockCopy_type *bc_list, int n_bc, int bc_kind, int zero_first, int *krylov_iterations) {
+  HPGMG_SKIP_IF_REPLAY();
+  const long long cells = (long long)L->dim * L->dim * L->dim;
+  if (L->num_boxes != 1 || cells > 512 || L->periodic) return record_error(hipErrorInvalidValue, "bottom_bicgstab: a level of one box of at most 512 cells, Dirichlet");
+  BottomArgs A = {};
+  A.e_id = x_id; A.R_id = rhs_id; A.krylov_base = krylov_base; A.a = a; A.b = b; A.h2inv = h2inv; A.want = want;
+  A.bc_list = bc_list; A.n_bc = bc_list ? n_bc : 0; A.bc_kind = A.n_bc > 0 ? bc_kind : 0; A.zero_first = zero_first; A.krylov_iterations = krylov_iterations;
+  const int threads = cells > 256 ? 512 : (cells > 64 ? 256 : 64);
+  const size_t lds = ((size_t)L->volume + 1100) * sizeof(double);
+  if (lds > 150 * 1024) return record_error(hipErrorInvalidValue, "bottom_bicgstab: box too large for the LDS image");
+#define BOTTOM_CASE(VAR) { \
+    static bool once = false; if (!once) { HPGMG_CHECK(hipFuncSetAttribute((const void *)bottom_bicgstab_kernel<VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); once = true; } \
+    hipLaunchKernelGGL((bottom_bicgstab_kernel<VAR>), dim3(1), dim3(threads), lds, g_stream, *L, A); }
+  switch (variant) {
+    case HPGMG_HIP_27PT_CC:          BOTTOM_CASE(HPGMG_HIP_27PT_CC) break;
+    case HPGMG_HIP_FV4_VC_HELMHOLTZ: BOTTOM_CASE(HPGMG_HIP_FV4_VC_HELMHOLTZ) break;
+    case HPGMG_HIP_FV4_VC_POISSON:   BOTTOM_CASE(HPGMG_HIP_FV4_VC_POISSON) break;
+    case HPGMG_HIP_7PT_VC_HELMHOLTZ: BOTTOM_CASE(HPGMG_HIP_7PT_VC_HELMHOLTZ) break;
+    case HPGMG_HIP_7PT_VC_POISSON:   BOTTOM_CASE(HPGMG_HIP_7PT_VC_POISSON) break;
+    case HPGMG_HIP_7PT_CC:           BOTTOM_CASE(HPGMG_HIP_7PT_CC) break;
+    default: return record_error(hipErrorInvalidValue, "bottom_bicgstab: variant");
+  }
+#undef BOTTOM_CASE
+  HPGMG_LAUNCH_CHECK("bottom_bicgstab_kernel");
+  return 0;
+}
 int hpgmg_hip_smooth_gsrb(const hpgmg_hip_level *L, int variant, int xn_id, int xnp1_id, int rhs_id,
                           double a, double b, double h2inv, int sweep) {
   StencilArgs P = {}; P.xn_id = xn_id; P.xout_id = xnp1_id; P.rhs_id = rhs_id; P.a = a; P.b = b; P.h2inv = h2inv; P.sweep = sweep;

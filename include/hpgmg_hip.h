@@ -134,6 +134,13 @@ int hpgmg_hip_small_level_op(const hpgmg_hip_level *L, int variant, int mode, in
 /* Overlap of the halo exchange with the stencil launches below (ghost-free 7-point path only): mode 1 = the next
  * launches leave the cells next to a face owned by another rank (box_nbr == -2) untouched, mode 2 = the next launches
  * compute exactly those cells (one lane per cell), mode 0 = whole boxes. */
+/* Bottom solve of the 27-point / fv2 / fv4 plugins: diagonally preconditioned BiCGStab (solvers/bicgstab.c:14-97, as host/solvers.c drives
+ * it) on a bottom level of ONE box of at most max_cells() cells, Dirichlet, in one single-workgroup launch: x_id = initial guess and
+ * solution, eight work vectors from krylov_base, boundary list / kind / zero_first as for hpgmg_hip_small_level_op, krylov_iterations =
+ * device-visible host counter the kernel adds its iteration count to (or NULL).  Bit-identical to the host-driven solve. */
+int hpgmg_hip_bottom_bicgstab_max_cells(void);
+int hpgmg_hip_bottom_bicgstab(const hpgmg_hip_level *L, int variant, int x_id, int rhs_id, int krylov_base, double a, double b, double h2inv, double want,
+                              const blockCopy_type *bc_list, int n_bc, int bc_kind, int zero_first, int *krylov_iterations);
 void hpgmg_hip_set_defer_mode(int mode);
 /* The LDS-tiled 27-point and fv4 kernels (boxes whose side is a multiple of 64, out of place) can read x outside a box from the
  * neighbouring box itself when every box of the level is local: the caller then runs only apply_BCs before the launch, not

@@ -120,6 +120,10 @@ void    hpgmg_segment_end(void);
  * executed it (bit-identical to the per-operator sequence), 0 when it cannot -- the driver then
  * issues the operators one by one. */
 int     hpgmg_vcycle_legs_fused(level_type **levels, int n, int e_id, int R_id, double a, double b, int leg);
+/* The whole bottom solve -- IterativeSolver's BiCGStab (solvers/bicgstab.c:14-97) on level L: e_id = initial guess and solution -- as one device
+ * launch where the plugin has one (27-point / fv2 / fv4: a bottom level of one small box, Dirichlet); 0 = not taken, the caller runs the
+ * host-driven solver.  Same iterates, same iteration count (folded into L->Krylov_iterations by hpgmg_level_sync_counters). */
+int     hpgmg_bottom_solve_fused(level_type *L, int e_id, int R_id, double a, double b, double desired_reduction_in_norm);
 /* Optional fused form of  interpolation_vcycle(fine, e, 1.0, coarse, e); smooth(fine, e, R)  (mg.c:1160-1161): returns 1 when the
  * plugin executed both (same iterate; VECTOR_TEMP unspecified, as with hpgmg_smooth_in_cycle), 0 when the driver must call the two operators. */
 int     hpgmg_interp_smooth_fused(level_type *fine, int e_id, int R_id, level_type *coarse, double a, double b);

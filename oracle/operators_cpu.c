@@ -71,6 +71,8 @@ void hpgmg_segment_begin(long long key) { (void)key; }
 void hpgmg_segment_end(void) {}
 int hpgmg_vcycle_legs_fused(level_type **levels, int n, int e_id, int R_id, double a, double b, int leg) {
   (void)levels; (void)n; (void)e_id; (void)R_id; (void)a; (void)b; (void)leg; return 0; }
+int hpgmg_bottom_solve_fused(level_type *L, int e_id, int R_id, double a, double b, double want) {
+  (void)L; (void)e_id; (void)R_id; (void)a; (void)b; (void)want; return 0; }
 
 /* interior-origin pointer of vector id in box b */
 static inline double *vec(const level_type *L, int box, int id) {
