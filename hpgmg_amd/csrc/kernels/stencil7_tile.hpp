@@ -78,9 +78,12 @@ __global__ __launch_bounds__(64 * TJ) void stencil7_tile_kernel(const hpgmg_hip_
     halo_g = ci + cj * jS;
   }
   auto halo_at = [&](int k) -> double { const double v = halo_x[halo_g + k * kS]; return halo_kind == 2 ? -v : v; };
-  // value of x just below / above the box on this lane's column (k faces)
+  // value of x just below / above the box on this lane's column (k faces).  The two neighbour numbers are read HERE, once: looked up inside
+  // the march, the load was hoisted above its (rarely taken) branch and its wait -- vmcnt(0), in front of the prefetches just issued for the
+  // next plane -- made every step a full round trip to memory.
+  const int nb_k[2] = { L.box_nbr ? L.box_nbr[6 * box + 4] : -3, L.box_nbr ? L.box_nbr[6 * box + 5] : -3 };
   auto outside_k = [&](int dir, double centre, int kk) -> double {
-    const int nb = L.box_nbr[6 * box + dir];
+    const int nb = nb_k[dir - 4];
     if (nb >= 0) return gvec_origin(L, nb, P.xn_id)[own_g + (dir == 4 ? last : 0) * kS];
     if (nb == -1) return -centre;
     return x[own_g + kk * kS];
