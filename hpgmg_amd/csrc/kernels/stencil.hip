@@ -1373,7 +1373,7 @@ long long hpgmg_hip_pair_tile_launch_count(void) { return g_pair_tile_launches; 
 // resident and latency bound, and a pair step issues twice the loads of a single-sweep step before its first barrier.
 // HPGMG_TUNE_7PT_PAIR_TILE=1 or hpgmg_hip_set_pair_tile(1) enables it (bit-identical; the tests do).
 static int g_pair_tile_on = -1;
-void hpgmg_hip_set_pair_tile(int on) { g_pair_tile_on = on ? 1 : 0; }
+void hpgmg_hip_set_pair_tile(int on) { g_pair_tile_on = on ? 3 : 0; }
 #ifdef HPGMG_EXPERIMENTS
 int hpgmg_hip_experiments(void) { return 1; }
 #else
@@ -1387,10 +1387,10 @@ static int pair_tile_width(const hpgmg_hip_level *L, int variant) {
   if (variant != HPGMG_HIP_7PT_VC_HELMHOLTZ && variant != HPGMG_HIP_7PT_VC_POISSON && variant != HPGMG_HIP_7PT_CC) return 0;
   if (!(L->num_boxes > 0 && L->box_nbr != nullptr && !L->periodic && L->ghosts >= 1)) return 0;
 #ifdef HPGMG_EXPERIMENTS
-  static const int small_on = env_int("HPGMG_TUNE_7PT_PAIR_SMALL", 0);
-  if (g_pair_tile_on < 0) g_pair_tile_on = env_int("HPGMG_TUNE_7PT_PAIR_TILE", 0) ? 1 : 0;
-  if ((small_on || g_pair_tile_on) && (L->dim == 32 || L->dim == 16)) return L->dim;
-  if (g_pair_tile_on && L->dim % 64 == 0) return 64;
+  // bit 0: boxes of side 64 m (HPGMG_TUNE_7PT_PAIR_TILE=1), bit 1: boxes of 32^3 / 16^3 (HPGMG_TUNE_7PT_PAIR_SMALL=1); set_pair_tile(1): both
+  if (g_pair_tile_on < 0) g_pair_tile_on = (env_int("HPGMG_TUNE_7PT_PAIR_TILE", 0) ? 1 : 0) | (env_int("HPGMG_TUNE_7PT_PAIR_SMALL", 0) ? 2 : 0);
+  if ((g_pair_tile_on & 2) && (L->dim == 32 || L->dim == 16)) return L->dim;
+  if ((g_pair_tile_on & 1) && L->dim % 64 == 0) return 64;
 #else
   (void)g_pair_tile_on;
 #endif
