@@ -1121,15 +1121,19 @@ static int small_fused = -1;
 void hpgmg_set_small_fused(int mode) { small_fused = (mode == 1 || mode == 2) ? mode : 0; }   /* 0 off, 1 every small level, 2 (default) one-box levels in LDS */
 static int small_level_try(level_type *L, int mode, int x_id, int rhs_id, int res_id, double a, double b) {
   hpgmg_config cfg;
-  if (small_fused < 0) { const char *e = getenv("HPGMG_SMALL_FUSED"); small_fused = (e && e[0] == '1') ? 1 : ((e && e[0] == '2') ? 2 : 0); }
-  /* 0 (default): off.  1: every qualifying level, out of global memory (slower than the launches it replaces, see above).  2: smooth() on
-   * levels of ONE box whose vectors fit the LDS -- the kernel then works on an image of the box there (round 3).  Measured on `7 64`: fv4
-   * 33.4 vs 33.1 ms, i.e. no gain either: a smooth() of such a level is then one ~55 us launch instead of twelve ~5 us ones, the generic
-   * (FLAT) accesses to the image and the single workgroup's serial phases cost what the launches cost.  Off; bit-identical, tested. */
+  if (small_fused < 0) { const char *e = getenv("HPGMG_SMALL_FUSED"); small_fused = (e && e[0] == '1') ? 1 : ((e && e[0] == '0') ? 0 : 2); }
+  if (small_fused == 1 && !hpgmg_hip_experiments()) small_fused = 2;
+  /* 0: off.  1 (experiment builds): every qualifying level, out of global memory (slower than the launches it replaces, see above).  2
+   * (default): smooth() on levels of ONE box whose vectors fit the LDS -- the kernel then works on an image of the box there (round 3).  With
+   * generic (FLAT) accesses to the image a smooth() was one ~60 us launch instead of twelve ~5 us ones: no gain.  With LDS-typed pointers, the
+   * boundary descriptors built without scratch memory and the corner / edge extrapolations of apply_BCs_v4 spread over the lanes of a wave it
+   * is 27 us (fv4, 8^3): `7 8` fv4 9.45 -> 9.2 ms, fv2 7.05 -> 6.45 ms per F-cycle.  Bit-identical, tested in all three modes. */
   hpgmg_get_config(&cfg);
   /* mode 2 takes what it shortens: a smooth() of many launches (fv4 GSRB: 12, Chebyshev: 8; a residual or apply_op is two launches of ~5 us,
    * the kernel with its copies in and out ~15 us; the 27-point GSRB smoother already runs as two one-workgroup-per-box launches) */
-  const int worth = (mode <= 2) && !(cfg.op == HPGMG_OP_27PT && cfg.smoother == HPGMG_SMOOTH_GSRB);
+  static int small_27 = -1;
+  if (small_27 < 0) { const char *e = getenv("HPGMG_TUNE_SMALL_27PT_GSRB"); small_27 = (e && e[0] == '1'); }
+  const int worth = (mode <= 2) && (small_27 || !(cfg.op == HPGMG_OP_27PT && cfg.smoother == HPGMG_SMOOTH_GSRB));
   const int enabled = small_fused == 1 || (small_fused == 2 && worth && L->num_my_boxes == 1 && (size_t)9 * (size_t)L->box_volume * sizeof(double) <= (size_t)150 * 1024);
   if (!enabled || cfg.op == HPGMG_OP_7PT || L->num_my_boxes < 1) return 0;
   if ((long long)L->dim.i * L->dim.j * L->dim.k > hpgmg_hip_small_level_max_cells()) return 0;

@@ -439,7 +439,8 @@ __global__ __launch_bounds__(256) void stencil7_shell_kernel(const hpgmg_hip_lev
 #include "stencil27_tile.hpp"   // C27_* constants + the LDS-staged kernel for boxes of side 64 m
 namespace hpgmg {
 struct plane9 { double v[3][3]; };   // [dj+1][di+1]
-__device__ __forceinline__ plane9 load_plane(const double *p, int jS) {
+template <typename P>
+__device__ __forceinline__ plane9 load_plane(P p, int jS) {
   plane9 q;
 #pragma unroll
   for (int jj = 0; jj < 3; jj++) {
@@ -515,8 +516,9 @@ __global__ __launch_bounds__(256) void stencil27_kernel(const hpgmg_hip_level L,
 // Expression order is the macro's: T*(six face terms) + (0.25*T)*(twelve mixed terms), each
 // group summed left to right; a mixed term is (beta+ - beta-) * (((x1 - x2) - x3) + x4).
 #define FV4_TWELFTH ( 0.0833333333333333333)
-template <int V>
-__device__ __forceinline__ double apply_op_direct(const double *x, const double *alpha, const double *bi, const double *bj, const double *bk,
+// (pointer types are template parameters: the single-workgroup kernels pass LDS pointers for the vectors they hold an image of)
+template <int V, typename XP, typename CP>
+__device__ __forceinline__ double apply_op_direct(XP x, CP alpha, CP bi, CP bj, CP bk,
                                                   int ijk, int jS, int kS, double a, double b, double h2inv) {
   const double xc = x[ijk];
   if (V == HPGMG_HIP_FV4_VC_HELMHOLTZ || V == HPGMG_HIP_FV4_VC_POISSON) {
@@ -615,13 +617,13 @@ __global__ __launch_bounds__(256) void stencil_direct_kernel(const hpgmg_hip_lev
 // launch costs more than the work (fv4: 18 launches of ~6 us per smooth()); the arithmetic is the same entry routines and the same
 // per-cell expressions as the streaming kernels, so results stay bit-identical.  (The 7-point plugin has its own, LDS-resident form
 // of this idea: tail.hip.)
-#ifdef HPGMG_EXPERIMENTS
 struct SmallArgs {
   int mode, sweeps, x_id, rhs_id, res_id, out_of_place, bc_kind, zero_first;   // bc_kind: 0 none (periodic), 1 p1, 2 p2, 3 v2, 4 v4
   double a, b, h2inv, c1[8], c2[8];
   const blockCopy_type *copy_list; int n_copy;
   const blockCopy_type *bc_list; int n_bc;
   int lds_resident;                 // a level of ONE box whose vectors fit the LDS: work on an image of the box there (see the kernel)
+  unsigned long long *timeline;     // experiment builds (-DHPGMG_EXP_TIMELINE): lane 0 records the clock at the phase boundaries
 };
 // LDS-resident form (round 3): out of global memory every boundary entry and every stencil read of this one workgroup is a round trip to
 // the L2 that nothing hides (measured: slower than the dozen launches it replaces, even on a level of one box).  For a level of ONE box
@@ -629,101 +631,167 @@ struct SmallArgs {
 // padded layout, the level descriptor is pointed at that image (a one-entry box table in LDS, vector ids renumbered to slots), the very same
 // entry routines and per-cell expressions run on it, and the vectors written go back to memory at the end: bit-identical by construction.
 constexpr int kSmallSlots = 9;
-template <int V>
-__global__ __launch_bounds__(1024) void small_level_kernel(const hpgmg_hip_level L0, const SmallArgs A) {
-  constexpr bool kFv4 = (V == HPGMG_HIP_FV4_VC_HELMHOLTZ || V == HPGMG_HIP_FV4_VC_POISSON), k27 = (V == HPGMG_HIP_27PT_CC);
+typedef double __attribute__((address_space(3))) *lds_dptr;       // a pointer into LDS, typed as such: ds_read / ds_write, not FLAT
+typedef const int __attribute__((address_space(3))) *lds_iptr;
+// the eight words of a boundary entry that the entry routines read (subtype, dim, read.box / i / j / k), kept in LDS by the single-workgroup
+// kernels: read from the level's list in memory, the descriptor was a round trip per entry and half sweep
+__device__ __forceinline__ void lds_bc_words_fill(int *words, const blockCopy_type *list, int n, int tid, int nth) {
+  for (int t = tid; t < 8 * n; t += nth) {
+    const blockCopy_type &g = list[t >> 3];
+    const int f = t & 7;
+    words[t] = f == 0 ? g.subtype : f == 1 ? g.dim.i : f == 2 ? g.dim.j : f == 3 ? g.dim.k : f == 4 ? g.read.box : f == 5 ? g.read.i : f == 6 ? g.read.j : g.read.k;
+  }
+}
+__device__ __forceinline__ blockCopy_type lds_bc_entry(const int *words, int e) {
+  const lds_iptr w = (lds_iptr)words + 8 * e;
+  blockCopy_type en;
+  en.subtype = w[0]; en.dim.i = w[1]; en.dim.j = w[2]; en.dim.k = w[3]; en.read.box = w[4]; en.read.i = w[5]; en.read.j = w[6]; en.read.k = w[7];
+  return en;
+}
+// The sweeps of one launch.  RES: the vectors live in the LDS image (`image`; vector "ids" are slots of it, the only box is box 0) and every
+// access to them is an LDS instruction -- through generic pointers each was a FLAT access, and a corner entry of apply_BCs_v4 (64 dependent
+// reads by one lane) or the 55 reads of a stencil took microseconds: 6.1 + 3.8 us per half sweep of an 8^3 level, 66 us per smooth().
+template <int V, bool RES>
+__device__ __forceinline__ void small_level_run(const hpgmg_hip_level &L, const SmallArgs &A, double *image, const blockCopy_type *bc_entries, const int *bc_words, const int *ids, unsigned long long *tl, int &tl_n) {
+  constexpr bool k27 = (V == HPGMG_HIP_27PT_CC);
   constexpr bool kVC = (V != HPGMG_HIP_7PT_CC && !k27);
   constexpr bool kHelm = (V == HPGMG_HIP_7PT_VC_HELMHOLTZ || V == HPGMG_HIP_FV4_VC_HELMHOLTZ);
-  extern __shared__ double small_lds[];
-  __shared__ double *s_box_table[1];
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = (int)blockDim.x >> 6;
-  hpgmg_hip_level L = L0;
-  // vector ids as the body uses them: the level's, or slots of the LDS image
-  int x_id = A.x_id, rhs_id = A.rhs_id, res_id = A.res_id, temp_id = VECTOR_TEMP, dinv_id = VECTOR_DINV, al_id = VECTOR_ALPHA;
-  int bi_id = VECTOR_BETA_I, bj_id = VECTOR_BETA_J, bk_id = VECTOR_BETA_K;
-  int slot_of[kSmallSlots];                                        // level vector id held in each slot (-1: unused)
-  if (A.lds_resident) {
-    const bool smooth = (A.mode == MODE_CHEBY || A.mode == MODE_JACOBI || A.mode == MODE_GSRB);
-    const bool uses_temp = smooth && !(A.mode == MODE_GSRB && !A.out_of_place);
-    slot_of[0] = A.x_id; slot_of[1] = uses_temp ? VECTOR_TEMP : -1; slot_of[2] = (A.mode == MODE_APPLY) ? -1 : A.rhs_id; slot_of[3] = smooth ? VECTOR_DINV : -1;
-    slot_of[4] = kHelm ? VECTOR_ALPHA : -1; slot_of[5] = kVC ? VECTOR_BETA_I : -1; slot_of[6] = kVC ? VECTOR_BETA_J : -1; slot_of[7] = kVC ? VECTOR_BETA_K : -1;
-    slot_of[8] = smooth ? -1 : A.res_id;
-    const size_t vol = (size_t)L0.volume;
-#pragma unroll
-    for (int q = 0; q < kSmallSlots; q++) {
-      if (slot_of[q] < 0) continue;
-      // a result vector that is written in full needs no load, but its ghost zone must hold what memory holds: copy it all the same
-      const double *g = L0.box_base[0] + (size_t)slot_of[q] * vol;
-#pragma unroll 8
-      for (int t = tid; t < (int)vol; t += (int)blockDim.x) small_lds[(size_t)q * vol + t] = g[t];      // unrolled: eight loads in flight per lane, not one
-    }
-    if (tid == 0) s_box_table[0] = small_lds;
-    L.box_base = s_box_table;
-    x_id = 0; temp_id = 1; rhs_id = 2; dinv_id = 3; al_id = 4; bi_id = 5; bj_id = 6; bk_id = 7; res_id = smooth ? 0 : 8;
-    if (!smooth && A.res_id == A.x_id) res_id = 0;
-    __syncthreads();
-  }
   const int dim = L.dim, jS = L.jStride, kS = L.kStride, per_box = dim * dim * dim, total = per_box * L.num_boxes;
+  const size_t vol = (size_t)L.volume, first = (size_t)L.ghosts * (size_t)(1 + jS + kS);
+  // origin of vector `id` of box `box`: a slot of the image (LDS) or the level's own storage
+  auto vo = [&](int box, int id) {
+    if constexpr (RES) { (void)box; return (lds_dptr)image + ((size_t)id * vol + first); }
+    else return vec_origin(L, box, id);
+  };
+  // boundary entry e: from the level's list, or (RES, bc_words != 0) from the eight words of it that the entry routines read, kept in LDS
+  auto entry = [&](int e) {
+    if constexpr (RES) {
+      if (bc_words) return lds_bc_entry(bc_words, e);
+    }
+    return bc_entries[e];
+  };
+  // the colour of cell (0,0,0) of the one box of an image (read once: every cell of every sweep asked the level for it)
+  int low_parity = 0;
+  if constexpr (RES) low_parity = L.box_low[0] ^ L.box_low[1] ^ L.box_low[2];
+  const int x_id = ids[0], temp_id = ids[1], rhs_id = ids[2], dinv_id = ids[3], al_id = ids[4], bi_id = ids[5], bj_id = ids[6], bk_id = ids[7], res_id = ids[8];
+#ifdef HPGMG_EXP_TIMELINE
+#define SL_MARK() do { if (tl && threadIdx.x == 0 && tl_n < 250) tl[tl_n++] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define SL_MARK() do { (void)tl; (void)tl_n; } while (0)
+#endif
   for (int s = 0; s < A.sweeps; s++) {
     int src = x_id, dst = res_id;
     if (A.mode == MODE_CHEBY || A.mode == MODE_JACOBI || (A.mode == MODE_GSRB && A.out_of_place)) { src = (s & 1) ? temp_id : x_id; dst = (s & 1) ? x_id : temp_id; }
     else if (A.mode == MODE_GSRB) { src = x_id; dst = x_id; }
-    // exchange_boundary(src): box -> box copies (blockCopy.c:6-105)
-    for (int e = wave; e < A.n_copy; e += nwaves) copy_entry<false>(L, src, A.copy_list[e], 0.0, lane, 64);
-    __syncthreads();
+    // exchange_boundary(src): box -> box copies (blockCopy.c:6-105); an image is one box: nothing to copy
+    if (!RES) { for (int e = wave; e < A.n_copy; e += nwaves) copy_entry<false>(L, src, A.copy_list[e], 0.0, lane, 64); __syncthreads(); }
+    SL_MARK();
     // apply_BCs(src)
-    if (A.bc_kind && A.zero_first) { for (int e = wave; e < A.n_bc; e += nwaves) bc_zero_entry(L, src, A.bc_list[e], lane, 64); __syncthreads(); }
+    if (A.bc_kind && A.zero_first) { for (int e = wave; e < A.n_bc; e += nwaves) { const blockCopy_type en = entry(e); bc_zero_entry_at(vo(en.read.box, src), L, en, lane, 64); } __syncthreads(); }
     for (int e = wave; e < A.n_bc; e += nwaves) {
-      if (A.bc_kind == 1) bc_p1_entry(L, src, A.bc_list[e], lane, 64);
-      else if (A.bc_kind == 2) bc_p2_entry(L, src, A.bc_list[e], lane, 64);
-      else if (A.bc_kind == 3) bc_v2_entry(L, src, A.bc_list[e], lane, 64);
-      else if (A.bc_kind == 4) bc_v4_entry(L, src, A.bc_list[e], lane, 64);
+      const blockCopy_type en = entry(e);
+      if (A.bc_kind == 1) bc_p1_entry_at(vo(en.read.box, src), L, en, lane, 64);
+      else if (A.bc_kind == 2) bc_p2_entry_at(vo(en.read.box, src), L, en, lane, 64);
+      else if (A.bc_kind == 3) bc_v2_entry_at(vo(en.read.box, src), L, en, lane, 64);
+      else if (A.bc_kind == 4) bc_v4_entry_at(vo(en.read.box, src), L, en, lane, 64);
     }
     __syncthreads();
+    SL_MARK();
     // the stencil over every cell (same expressions as stencil_direct_kernel / stencil27_kernel)
     for (int t = tid; t < total; t += (int)blockDim.x) {
       const int box = t / per_box, r = t - box * per_box, k = r / (dim * dim), j = (r / dim) % dim, i = r % dim;
       const int ijk = i + j * jS + k * kS;
-      const double *x = vec_origin(L, box, src);
-      double *out = vec_origin(L, box, dst);
+      auto x = vo(box, src);
+      auto out = vo(box, dst);
       const double xc = x[ijk];
       bool update = true;
-      if (A.mode == MODE_GSRB) update = (((i ^ j ^ k ^ L.box_low[3 * box] ^ L.box_low[3 * box + 1] ^ L.box_low[3 * box + 2] ^ s) & 1) == 0);
+      if (A.mode == MODE_GSRB) {
+        const int lp = RES ? low_parity : (L.box_low[3 * box] ^ L.box_low[3 * box + 1] ^ L.box_low[3 * box + 2]);
+        update = (((i ^ j ^ k ^ lp ^ s) & 1) == 0);
+      }
       if (!update) { if (A.out_of_place) out[ijk] = xc; continue; }
       double Ax;
       if (k27) {
-        const plane9 m = load_plane(x + ijk - kS, jS), c = load_plane(x + ijk, jS), p = load_plane(x + ijk + kS, jS);
+        const plane9 m = load_plane(x + (ijk - kS), jS), c = load_plane(x + ijk, jS), p = load_plane(x + (ijk + kS), jS);
         Ax = apply_op_27pt(m, c, p, A.a, A.b, A.h2inv);
       } else {
-        Ax = apply_op_direct<V>(x, kHelm ? vec_origin(L, box, al_id) : nullptr, kVC ? vec_origin(L, box, bi_id) : nullptr,
-                                kVC ? vec_origin(L, box, bj_id) : nullptr, kVC ? vec_origin(L, box, bk_id) : nullptr, ijk, jS, kS, A.a, A.b, A.h2inv);
+        auto none = vo(box, src); none = nullptr;
+        Ax = apply_op_direct<V>(x, kHelm ? vo(box, al_id) : none, kVC ? vo(box, bi_id) : none, kVC ? vo(box, bj_id) : none, kVC ? vo(box, bk_id) : none,
+                                ijk, jS, kS, A.a, A.b, A.h2inv);
       }
       if (A.mode == MODE_APPLY) { out[ijk] = Ax; continue; }
-      const double rhs = vec_origin(L, box, rhs_id)[ijk];
+      const double rhs = vo(box, rhs_id)[ijk];
       if (A.mode == MODE_RESIDUAL) { out[ijk] = rhs - Ax; continue; }
-      const double dinv = vec_origin(L, box, dinv_id)[ijk];
+      const double dinv = vo(box, dinv_id)[ijk];
       if (A.mode == MODE_CHEBY)      { const double xnm1 = out[ijk]; out[ijk] = xc + A.c1[s] * (xc - xnm1) + A.c2[s] * dinv * (rhs - Ax); }
       else if (A.mode == MODE_GSRB)  { out[ijk] = xc + dinv * (rhs - Ax); }
       else                           { out[ijk] = xc + A.c2[s] * dinv * (rhs - Ax); }
     }
     __syncthreads();
+    SL_MARK();
   }
-  if (A.lds_resident) {                                           // what was written goes back to memory, ghost zones included (the boundary entries filled them)
-    const size_t vol = (size_t)L0.volume;
-    const bool smooth = (A.mode == MODE_CHEBY || A.mode == MODE_JACOBI || A.mode == MODE_GSRB);
-#pragma unroll
-    for (int q = 0; q < kSmallSlots; q++) {
-      const bool written = smooth ? (q == 0 || (q == 1 && slot_of[1] >= 0)) : (q == 0 || q == 8);      // x's ghost zone was filled too
-      if (!written || slot_of[q] < 0) continue;
-      double *g = L0.box_base[0] + (size_t)slot_of[q] * vol;
-#pragma unroll 8
-      for (int t = tid; t < (int)vol; t += (int)blockDim.x) g[t] = small_lds[(size_t)q * vol + t];
-    }
-  }
-  (void)kFv4;
+#undef SL_MARK
 }
-
-#endif  // HPGMG_EXPERIMENTS
+template <int V>
+__global__ __launch_bounds__(1024) void small_level_kernel(const hpgmg_hip_level L, const SmallArgs A) {
+  constexpr bool k27 = (V == HPGMG_HIP_27PT_CC);
+  constexpr bool kVC = (V != HPGMG_HIP_7PT_CC && !k27);
+  constexpr bool kHelm = (V == HPGMG_HIP_7PT_VC_HELMHOLTZ || V == HPGMG_HIP_FV4_VC_HELMHOLTZ);
+  extern __shared__ double small_lds[];
+  const int tid = (int)threadIdx.x;
+  int tl_n = 0;
+  unsigned long long *tl = nullptr;
+#ifdef HPGMG_EXP_TIMELINE
+  tl = A.timeline;
+  if (tl && tid == 0) tl[tl_n++] = __builtin_amdgcn_s_memrealtime();
+#endif
+  if (!A.lds_resident) {                                          // out of global memory: measured slower than the launches it replaces (experiments)
+#ifdef HPGMG_EXPERIMENTS
+    const int ids[kSmallSlots] = { A.x_id, VECTOR_TEMP, A.rhs_id, VECTOR_DINV, VECTOR_ALPHA, VECTOR_BETA_I, VECTOR_BETA_J, VECTOR_BETA_K, A.res_id };
+    small_level_run<V, false>(L, A, nullptr, A.bc_list, nullptr, ids, tl, tl_n);
+#endif
+    return;
+  }
+  // ---- one box, its vectors in LDS: copy in, run, copy what was written back (ghost zones included: the boundary entries filled them)
+  const bool smooth = (A.mode == MODE_CHEBY || A.mode == MODE_JACOBI || A.mode == MODE_GSRB);
+  const bool uses_temp = smooth && !(A.mode == MODE_GSRB && !A.out_of_place);
+  int slot_of[kSmallSlots];                                        // level vector id held in each slot (-1: unused)
+  slot_of[0] = A.x_id; slot_of[1] = uses_temp ? VECTOR_TEMP : -1; slot_of[2] = (A.mode == MODE_APPLY) ? -1 : A.rhs_id; slot_of[3] = smooth ? VECTOR_DINV : -1;
+  slot_of[4] = kHelm ? VECTOR_ALPHA : -1; slot_of[5] = kVC ? VECTOR_BETA_I : -1; slot_of[6] = kVC ? VECTOR_BETA_J : -1; slot_of[7] = kVC ? VECTOR_BETA_K : -1;
+  slot_of[8] = (smooth || A.res_id == A.x_id) ? -1 : A.res_id;
+  const size_t vol = (size_t)L.volume;
+  lds_dptr img = (lds_dptr)small_lds;
+  // the boundary entries of the box (26 at most) wait in LDS too: read from memory, the descriptor was a round trip per entry and half sweep
+  __shared__ int s_bc[32 * 8];
+  const bool bc_in_lds = A.n_bc <= 32;
+  if (bc_in_lds) lds_bc_words_fill(s_bc, A.bc_list, A.n_bc, tid, (int)blockDim.x);
+#pragma unroll
+  for (int q = 0; q < kSmallSlots; q++) {
+    if (slot_of[q] < 0) continue;
+    // (a result vector that is written in full needs no load, but its ghost zone must come back as it was: copy it all the same)
+    const double *g = L.box_base[0] + (size_t)slot_of[q] * vol;
+#pragma unroll 8
+    for (int t = tid; t < (int)vol; t += (int)blockDim.x) img[(size_t)q * vol + t] = g[t];      // unrolled: eight loads in flight per lane, not one
+  }
+  __syncthreads();
+#ifdef HPGMG_EXP_TIMELINE
+  if (tl && tid == 0) tl[tl_n++] = __builtin_amdgcn_s_memrealtime();
+#endif
+  const int ids[kSmallSlots] = { 0, 1, 2, 3, 4, 5, 6, 7, (smooth || A.res_id == A.x_id) ? 0 : 8 };
+  small_level_run<V, true>(L, A, small_lds, A.bc_list, bc_in_lds ? (const int *)s_bc : nullptr, ids, tl, tl_n);
+#pragma unroll
+  for (int q = 0; q < kSmallSlots; q++) {
+    const bool written = smooth ? (q == 0 || (q == 1 && slot_of[1] >= 0)) : (q == 0 || q == 8);      // x's ghost zone was filled too
+    if (!written || slot_of[q] < 0) continue;
+    double *g = L.box_base[0] + (size_t)slot_of[q] * vol;
+#pragma unroll 8
+    for (int t = tid; t < (int)vol; t += (int)blockDim.x) g[t] = img[(size_t)q * vol + t];
+  }
+#ifdef HPGMG_EXP_TIMELINE
+  if (tl && tid == 0) { tl[tl_n++] = __builtin_amdgcn_s_memrealtime(); tl[255] = (unsigned long long)tl_n; }
+#endif
+}
 
 
 // ---------------------------------------------------------------------------------------------
@@ -746,21 +814,31 @@ __global__ __launch_bounds__(512) void bottom_bicgstab_kernel(const hpgmg_hip_le
   constexpr bool k27 = (V == HPGMG_HIP_27PT_CC);
   constexpr bool kVC = (V != HPGMG_HIP_7PT_CC && !k27);
   constexpr bool kHelm = (V == HPGMG_HIP_7PT_VC_HELMHOLTZ || V == HPGMG_HIP_FV4_VC_HELMHOLTZ);
-  extern __shared__ double bb_lds[];                               // the image of the padded box (L.volume doubles), then the reduction scratch
-  __shared__ double *s_tab[1];
+  extern __shared__ double bb_lds[];                               // images of the padded box (5 x L.volume doubles: v, alpha, beta_i/j/k), then the reduction scratch
+  __shared__ int s_bc[32 * 8];
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = (int)blockDim.x >> 6;
   const int dim = L.dim, jS = L.jStride, kS = L.kStride, total = dim * dim * dim;
   const bool active = tid < total;
   const int ci = tid % dim, cj = (tid / dim) % dim, ck = tid / (dim * dim), ijk = ci + cj * jS + ck * kS;
-  double *img = bb_lds, *scr = bb_lds + L.volume;
-  hpgmg_hip_level Li = L;
-  if (tid == 0) s_tab[0] = img;
-  Li.box_base = s_tab;                                             // vector 0 of box 0 of Li = the image
-  for (int t = tid; t < L.volume; t += (int)blockDim.x) img[t] = 0.0;
+  // Every access to the images is an LDS instruction (pointers typed as such; through generic pointers each was a FLAT access), the
+  // coefficients wait there too (read from memory they were a round trip to the L2 per apply), and so do the boundary entries.
+  const int vol = L.volume, first = L.ghosts * (1 + jS + kS);
+  const lds_dptr img = (lds_dptr)bb_lds;
+  const lds_dptr xi = img + first;
+  const lds_dptr alpha = img + (vol + first), bi = img + (2 * vol + first), bj = img + (3 * vol + first), bk = img + (4 * vol + first);
+  const lds_dptr scr = img + 5 * vol;
+  const bool bc_in_lds = A.n_bc <= 32;
+  if (bc_in_lds) lds_bc_words_fill(s_bc, A.bc_list, A.n_bc, tid, (int)blockDim.x);
+  {
+    const double *g_al = L.box_base[0] + (size_t)VECTOR_ALPHA * vol, *g_bi = L.box_base[0] + (size_t)VECTOR_BETA_I * vol;
+    const double *g_bj = L.box_base[0] + (size_t)VECTOR_BETA_J * vol, *g_bk = L.box_base[0] + (size_t)VECTOR_BETA_K * vol;
+    for (int t = tid; t < vol; t += (int)blockDim.x) {
+      img[t] = 0.0;
+      if (kHelm) img[vol + t] = g_al[t];
+      if (kVC) { img[2 * vol + t] = g_bi[t]; img[3 * vol + t] = g_bj[t]; img[4 * vol + t] = g_bk[t]; }
+    }
+  }
   __syncthreads();
-  double *xi = vec_origin(Li, 0, 0);
-  const double *alpha = kHelm ? vec_origin(L, 0, VECTOR_ALPHA) : nullptr;
-  const double *bi = kVC ? vec_origin(L, 0, VECTOR_BETA_I) : nullptr, *bj = kVC ? vec_origin(L, 0, VECTOR_BETA_J) : nullptr, *bk = kVC ? vec_origin(L, 0, VECTOR_BETA_K) : nullptr;
   const int r0_id = A.krylov_base, r_id = r0_id + 1, p_id = r0_id + 2, q_id = r0_id + 3, s_id = r0_id + 4, t_id = r0_id + 5, Ap_id = r0_id + 6, As_id = r0_id + 7;
   double x = 0, r0 = 0, r = 0, p = 0, q = 0, sv = 0, tv = 0, Ap = 0, As = 0, tmp = 0, dinv = 0, rhs = 0;
   if (active) {
@@ -769,22 +847,24 @@ __global__ __launch_bounds__(512) void bottom_bicgstab_kernel(const hpgmg_hip_le
     sv = vec_origin(L, 0, s_id)[ijk]; tv = vec_origin(L, 0, t_id)[ijk]; Ap = vec_origin(L, 0, Ap_id)[ijk]; As = vec_origin(L, 0, As_id)[ijk];
     tmp = vec_origin(L, 0, VECTOR_TEMP)[ijk];
   }
+  auto entry = [&](int e) { if (bc_in_lds) return lds_bc_entry(s_bc, e); return A.bc_list[e]; };
   // apply_op(v): exchange_boundary (nothing to exchange: one box) + apply_BCs + the stencil (operators.*.c: apply_op)
   auto apply = [&](double v) -> double {
     if (active) xi[ijk] = v;
     __syncthreads();
-    if (A.bc_kind && A.zero_first) { for (int e = wave; e < A.n_bc; e += nwaves) bc_zero_entry(Li, 0, A.bc_list[e], lane, 64); __syncthreads(); }
+    if (A.bc_kind && A.zero_first) { for (int e = wave; e < A.n_bc; e += nwaves) bc_zero_entry_at(xi, L, entry(e), lane, 64); __syncthreads(); }
     for (int e = wave; e < A.n_bc; e += nwaves) {
-      if (A.bc_kind == 1) bc_p1_entry(Li, 0, A.bc_list[e], lane, 64);
-      else if (A.bc_kind == 2) bc_p2_entry(Li, 0, A.bc_list[e], lane, 64);
-      else if (A.bc_kind == 3) bc_v2_entry(Li, 0, A.bc_list[e], lane, 64);
-      else if (A.bc_kind == 4) bc_v4_entry(Li, 0, A.bc_list[e], lane, 64);
+      const blockCopy_type en = entry(e);
+      if (A.bc_kind == 1) bc_p1_entry_at(xi, L, en, lane, 64);
+      else if (A.bc_kind == 2) bc_p2_entry_at(xi, L, en, lane, 64);
+      else if (A.bc_kind == 3) bc_v2_entry_at(xi, L, en, lane, 64);
+      else if (A.bc_kind == 4) bc_v4_entry_at(xi, L, en, lane, 64);
     }
     __syncthreads();
     double Ax = 0.0;
     if (active) {
       if (k27) {
-        const plane9 m = load_plane(xi + ijk - kS, jS), c = load_plane(xi + ijk, jS), pp = load_plane(xi + ijk + kS, jS);
+        const plane9 m = load_plane(xi + (ijk - kS), jS), c = load_plane(xi + ijk, jS), pp = load_plane(xi + (ijk + kS), jS);
         Ax = apply_op_27pt(m, c, pp, A.a, A.b, A.h2inv);
       } else {
         Ax = apply_op_direct<V>(xi, alpha, bi, bj, bk, ijk, jS, kS, A.a, A.b, A.h2inv);
@@ -802,7 +882,7 @@ __global__ __launch_bounds__(512) void bottom_bicgstab_kernel(const hpgmg_hip_le
       const int k0 = (tid / tiles_side) * BLOCKCOPY_TILE_K, j0 = (tid % tiles_side) * BLOCKCOPY_TILE_J;
       const int k1 = min(k0 + BLOCKCOPY_TILE_K, dim), j1 = min(j0 + BLOCKCOPY_TILE_J, dim);
       double acc = 0.0;
-      for (int k = k0; k < k1; k++) for (int j = j0; j < j1; j++) { const double *row = scr + dim * (j + dim * k); for (int i = 0; i < dim; i++) acc += row[i]; }
+      for (int k = k0; k < k1; k++) for (int j = j0; j < j1; j++) { const lds_dptr row = scr + dim * (j + dim * k); for (int i = 0; i < dim; i++) acc += row[i]; }
       scr[512 + tid] = acc;
     }
     __syncthreads();
@@ -1003,7 +1083,8 @@ static int launch_fv4_tile_tj(const hpgmg_hip_level *L, int variant, const Stenc
   P.tiles_i = L->dim / TI; P.tiles_j = L->dim / TJ;
   int kchunk = L->dim;                                   // enough workgroups to fill the chip, as few chunk prologues as possible
   const int want = (TJ * TI >= 1024) ? 512 : 1024;
-  while (kchunk > 16 && (long long)L->num_boxes * P.tiles_i * P.tiles_j * (L->dim / kchunk) < want) kchunk /= 2;
+  static const int kc_min = env_int("HPGMG_TUNE_FV4_KCHUNK_MIN", 2);
+  while (kchunk > kc_min && (long long)L->num_boxes * P.tiles_i * P.tiles_j * (L->dim / kchunk) < want) kchunk /= 2;
   static const int tune_kc = env_int("HPGMG_TUNE_FV4_KCHUNK", 0);
   if (tune_kc > 0 && L->dim % tune_kc == 0) kchunk = tune_kc;
   P.kchunk = kchunk; P.chunks_k = (L->dim + kchunk - 1) / kchunk;
@@ -1481,13 +1562,6 @@ int hpgmg_hip_smooth_gsrb_pair(const hpgmg_hip_level *L, int variant, double *co
                                double a, double b, double h2inv, int sweep) {
   return smooth_pair(L, variant, 1, sweep, scr_base, c32_base, x0_scr, x0_id, x0_scr, x0_id, 1, edge_scr_id, out2_scr, out2_id, rhs_id, a, b, h2inv, 0.0, 0.0, 0.0, 0.0);
 }
-#ifndef HPGMG_EXPERIMENTS
-int hpgmg_hip_small_level_max_cells(void) { return 0; }          // no level qualifies: the kernel is not in this build
-int hpgmg_hip_small_level_op(const hpgmg_hip_level *, int, int, int, int, int, int, int, double, double, double, const double *, const double *,
-                             const blockCopy_type *, int, const blockCopy_type *, int, int, int) {
-  return record_error(hipErrorInvalidValue, "small_level_op: not in this build (make EXPERIMENTS=1)");
-}
-#else
 int hpgmg_hip_small_level_max_cells(void) { return 4096; }
 // mode: 0 Chebyshev, 1 GSRB, 2 Jacobi (x_id <-> VECTOR_TEMP ping-pong as smooth() does; GSRB in place unless out_of_place), 3 residual
 // (res_id = rhs - A x), 4 apply_op (res_id = A x); c1 / c2: per-sweep Chebyshev coefficients (Jacobi: c2 = the weight)
@@ -1509,8 +1583,14 @@ int hpgmg_hip_small_level_op(const hpgmg_hip_level *L, int variant, int mode, in
   const size_t image = (size_t)kSmallSlots * (size_t)L->volume * sizeof(double);
   static const int no_lds = env_int("HPGMG_TUNE_SMALL_NO_LDS", 0);
   A.lds_resident = (!no_lds && L->num_boxes == 1 && A.n_copy == 0 && image <= 150 * 1024) ? 1 : 0;
+#ifdef HPGMG_EXP_TIMELINE
+  A.timeline = (unsigned long long *)g_exp_timeline;
+#endif
   const size_t lds = A.lds_resident ? image : 0;
   const int threads_used = A.lds_resident ? 1024 : threads;        // the image is copied by every lane there is
+#ifndef HPGMG_EXPERIMENTS
+  if (!A.lds_resident) return record_error(hipErrorInvalidValue, "small_level_op: only levels of one box that fit the LDS in this build (make EXPERIMENTS=1)");
+#endif
 #define SMALL_CASE(VAR) { \
     static bool once = false; if (!once) { HPGMG_CHECK(hipFuncSetAttribute((const void *)small_level_kernel<VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); once = true; } \
     hipLaunchKernelGGL((small_level_kernel<VAR>), dim3(1), dim3(threads_used), lds, g_stream, *L, A); }
@@ -1527,7 +1607,6 @@ int hpgmg_hip_small_level_op(const hpgmg_hip_level *L, int variant, int mode, in
   HPGMG_LAUNCH_CHECK("small_level_kernel");
   return 0;
 }
-#endif  // HPGMG_EXPERIMENTS
 
 // BiCGStab bottom solve of the 27-point / fv2 / fv4 plugins on a level of one box (bottom_bicgstab_kernel): x_id holds the initial guess and
 // receives the solution; the eight work vectors start at krylov_base; bc_list / bc_kind / zero_first as for hpgmg_hip_small_level_op;
@@ -1541,8 +1620,10 @@ int hpgmg_hip_bottom_bicgstab(const hpgmg_hip_level *L, int variant, int x_id, i
   BottomArgs A = {};
   A.e_id = x_id; A.R_id = rhs_id; A.krylov_base = krylov_base; A.a = a; A.b = b; A.h2inv = h2inv; A.want = want;
   A.bc_list = bc_list; A.n_bc = bc_list ? n_bc : 0; A.bc_kind = A.n_bc > 0 ? bc_kind : 0; A.zero_first = zero_first; A.krylov_iterations = krylov_iterations;
-  const int threads = cells > 256 ? 512 : (cells > 64 ? 256 : 64);
-  const size_t lds = ((size_t)L->volume + 1100) * sizeof(double);
+  // eight waves whatever the level: the boundary entries (26 of them) are a wave's work each
+  static const int tune_threads = env_int("HPGMG_TUNE_BOTTOM_THREADS", 512);
+  const int threads = (cells > 256 || tune_threads >= 512) ? 512 : (cells > 64 || tune_threads >= 256 ? 256 : 64);
+  const size_t lds = ((size_t)5 * L->volume + 1100) * sizeof(double);
   if (lds > 150 * 1024) return record_error(hipErrorInvalidValue, "bottom_bicgstab: box too large for the LDS image");
 #define BOTTOM_CASE(VAR) { \
     static bool once = false; if (!once) { HPGMG_CHECK(hipFuncSetAttribute((const void *)bottom_bicgstab_kernel<VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); once = true; } \

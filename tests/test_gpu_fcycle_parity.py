@@ -131,13 +131,13 @@ def test_hipgraph_segments_replay_the_same_numbers(hip):
 @pytest.mark.parametrize("variant,args", [("fv4-gsrb", "4 8"), ("27pt-gsrb", "4 8"), ("27pt-cheby", "5 8"), ("fv2-cheby", "4 8"), ("fv4-cheby", "4 8")])
 def test_small_levels_as_single_launches_give_the_same_norms(hip, variant, args, mode):
     """hpgmg_set_small_fused: smooth() / residual() of the non-7-point plugins on small levels as one single-workgroup launch each (exchange
-    copies + boundary conditions + stencil per sweep inside).  Mode 1: every level of <= 16^3 cells, out of global memory (opt-in: measured
-    slower than separate launches); mode 2: smooth() on levels of ONE box, on an image of the box in LDS (no gain measured either); mode 0 (the default): separate launches.  The same
-    numbers in every mode."""
+    copies + boundary conditions + stencil per sweep inside).  Mode 1 (EXPERIMENTS=1 builds): every level of <= 16^3 cells, out of global
+    memory (measured slower than separate launches); mode 2 (the default): smooth() on levels of ONE box, on an image of the box in LDS; mode 0:
+    separate launches.  The same numbers in every mode."""
     import ctypes
     import hpgmg_amd as H
-    if mode and not H.load_kernels().hpgmg_hip_experiments():
-        pytest.skip("the one-launch small-level kernel is only in builds with EXPERIMENTS=1 (it measured slower than what it replaces)")
+    if mode == 1 and not H.load_kernels().hpgmg_hip_experiments():
+        pytest.skip("the out-of-global-memory form of the small-level kernel is only in builds with EXPERIMENTS=1 (it measured slower than what it replaces)")
     gold = GOLD[f"{variant} {args}"]
     hip.lib.hpgmg_set_small_fused.argtypes = [ctypes.c_int]
     hip.lib.hpgmg_set_small_fused(mode)
@@ -149,7 +149,7 @@ def test_small_levels_as_single_launches_give_the_same_norms(hip, variant, args,
         assert fmt(err) == gold["richardson_error"]
         s.destroy()
     finally:
-        hip.lib.hpgmg_set_small_fused(0)
+        hip.lib.hpgmg_set_small_fused(2)
 
 
 def test_reference_three_launch_mode_gives_the_same_norms(hip):
