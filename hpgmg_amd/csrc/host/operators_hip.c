@@ -655,8 +655,84 @@ void hpgmg_level_sync_counters(level_type *L) {
  * level upwards); leg 5: only answer whether leg 4 would be accepted */
 static int vcycle_legs_fused(level_type **levels, int n, int e_id, int R_id, double a, double b, int leg);
 int hpgmg_vcycle_legs_fused(level_type **levels, int n, int e_id, int R_id, double a, double b, int leg) { lazy_flush(); return vcycle_legs_fused(levels, n, e_id, R_id, a, b, leg); }
+/* The same for the 27-point / fv2 / fv4 plugins, leg 2 only (smooth ... bottom solve ... smooth as one launch): every level of the chain is ONE
+ * box whose vectors fit the LDS (kernels/stencil.hip: small_vtail_kernel).  `7 8`: the levels of 8^3, 4^3, 2^3 (and 1^3) cells. */
+/* OFF by default (HPGMG_SMALL_VTAIL=1 / hpgmg_set_small_vtail(1) turn it on; bit-identical, tested both ways).  Measured on MI355X, `7 8`
+ * F-cycles with it on / off: fv4 7.93 / 7.79 ms, 27-point 4.18 / 3.92 ms, fv2 6.53 / 6.55 ms.  The launch of 8^3 + 4^3 + 2^3 levels takes
+ * 191 us (fv4 GSRB; tools/exp_vtail_timeline.py): 4 x 22 us of smoothing (a half sweep is a 3.6 us chain of boundary entries, barrier,
+ * stencil, barrier -- the same on 64 cells as on 512), 54 us of bottom solve, 43 us of image traffic; the ~15 launches it replaces are
+ * mostly the same chains and their launch gaps overlap with the host's queue, so nothing is gained, and the 27-point plugin's one-launch
+ * red + black box kernel is faster than two half sweeps here. */
+static long long small_vtails = 0;
+static int small_vtail_on = -1;
+long long hpgmg_small_vtails(void) { return small_vtails; }
+void hpgmg_set_small_vtail(int on) { small_vtail_on = on ? 1 : 0; }
+static int small_vtail_fused(level_type **levels, int n, int e_id, int R_id, double a, double b) {
+  hpgmg_config cfg;
+  hpgmg_hip_small_tail_args T;
+  int l;
+  if (small_vtail_on < 0) { const char *e = getenv("HPGMG_SMALL_VTAIL"); small_vtail_on = (e && e[0] == '1'); }
+  if (!small_vtail_on) return 0;
+  hpgmg_get_config(&cfg);
+  const int sweeps = hpgmg_smooth_sweeps();
+  if (n < 2 || n > HPGMG_HIP_SMALL_TAIL_MAX_LEVELS || sweeps < 1 || sweeps > 8 || (sweeps & 1) || graphs == 1) return 0;      /* (captured segments: the argument block's upload is not capturable) */
+  if (cfg.smoother != HPGMG_SMOOTH_CHEBY && cfg.smoother != HPGMG_SMOOTH_GSRB && cfg.smoother != HPGMG_SMOOTH_JACOBI) return 0;
+  memset(&T, 0, sizeof T);
+  T.n = n; T.mode = (cfg.smoother == HPGMG_SMOOTH_CHEBY) ? 0 : (cfg.smoother == HPGMG_SMOOTH_GSRB ? 1 : 2);
+  T.sweeps = sweeps; T.out_of_place = (T.mode == 1) ? hpgmg_gsrb_out_of_place() : 0;
+  T.e_id = e_id; T.R_id = R_id; T.krylov_base = hpgmg_vectors_reserved(); T.a = a; T.b = b; T.want = MG_DEFAULT_BOTTOM_NORM;
+  const int shape = stencil_get_shape();
+  for (l = 0; l < n; l++) {
+    level_type *L = levels[l];
+    if (!L->active || L->num_my_boxes != 1 || L->boxes_in.i * L->boxes_in.j * L->boxes_in.k != 1) return 0;
+    if (L->boundary_condition.type != BC_DIRICHLET || L->dim.i != L->dim.j || L->dim.i != L->dim.k) return 0;
+    if (l > 0 && 2 * L->dim.i != levels[l - 1]->dim.i) return 0;
+    {
+      communicator_type *C = &L->exchange_ghosts[shape], *CB = &L->exchange_ghosts[STENCIL_SHAPE_BOX];
+      if (C->num_sends + C->num_recvs > 0 || C->num_blocks[0] || C->num_blocks[1] || C->num_blocks[2]) return 0;      /* one box: nothing to exchange */
+      if (CB->num_sends + CB->num_recvs > 0 || CB->num_blocks[0] || CB->num_blocks[1] || CB->num_blocks[2]) return 0;
+    }
+    backend_t *B = backend_of(L);
+    hpgmg_hip_small_tail_level *v = &T.lv[l];
+    v->L = B->dev;
+    v->h2inv = 1.0 / (L->h * L->h);
+    v->n_bc = L->boundary_condition.num_blocks[shape];
+    v->bc_list = v->n_bc ? mirror(L, L->boundary_condition.blocks[shape], v->n_bc) : NULL;
+    if (cfg.op == HPGMG_OP_27PT) v->bc_kind = (L->box_dim < 2) ? 1 : 2;                                   /* as small_level_try / apply_BCs */
+    else if (cfg.op == HPGMG_OP_FV2 || L->box_dim < 4) { v->bc_kind = (L->box_dim < 2) ? 1 : 3; v->zero_first = (v->bc_kind == 3 && L->box_ghosts > 1); }
+    else { v->bc_kind = 4; v->zero_first = (L->box_ghosts > 2); }
+    /* the conditions interpolation_vcycle applies to THIS level's correction before the level above reads it: apply_BCs_p2 (27-point) /
+     * apply_BCs_v2 (fv2, fv4) over STENCIL_SHAPE_BOX */
+    v->n_ibc = L->boundary_condition.num_blocks[STENCIL_SHAPE_BOX];
+    v->ibc_list = v->n_ibc ? mirror(L, L->boundary_condition.blocks[STENCIL_SHAPE_BOX], v->n_ibc) : NULL;
+    if (cfg.op == HPGMG_OP_27PT) v->ibc_kind = (L->box_dim < 2) ? 1 : 2;
+    else { v->ibc_kind = (L->box_dim < 2) ? 1 : 3; v->ibc_zero_first = (v->ibc_kind == 3 && L->box_ghosts > 1); }
+    if (v->n_bc > 32 || v->n_ibc > 32) return 0;
+    if (l + 1 < n) {
+      if (T.mode == 0) { if (L->dominant_eigenvalue_of_DinvA <= 0.0) return 0; cheby_coefficients(L, sweeps, v->c1, v->c2); }
+      if (T.mode == 2) { int q; for (q = 0; q < sweeps; q++) v->c2[q] = 2.0 / 3.0; }
+    } else {
+      /* solvers.c:77-87: the fused solve is the Dirichlet one (no mean to remove); the Krylov vectors must exist */
+      if (L->must_subtract_mean != 0) return 0;
+      if ((long long)L->dim.i * L->dim.j * L->dim.k > hpgmg_hip_bottom_bicgstab_max_cells()) return 0;
+      if (L->numVectors < hpgmg_vectors_reserved() + IterativeSolver_NumVectors()) return 0;
+      if (!B->krylov_pinned) { B->krylov_pinned = (int *)hpgmg_hip_host_malloc(64); if (B->krylov_pinned) *B->krylov_pinned = 0; }
+      if (!B->krylov_pinned) return 0;
+      T.krylov_iterations = B->krylov_pinned;
+    }
+  }
+  if (hpgmg_hip_small_vtail_lds_doubles(&T) > hpgmg_hip_small_vtail_lds_limit()) return 0;
+  TICK(levels[0], smooth, "fused V-cycle tail (levels of one box)");
+  HIP_OK(hpgmg_hip_small_vtail(&T, variant()));
+  TOCK();
+  small_vtails++;
+  return 1;
+}
+static int fused_tail_enabled = -1;
+void hpgmg_set_fused_tail(int on) { fused_tail_enabled = on ? 1 : 0; }      /* tests: 0 = every operator of the small levels as its own launch(es) */
 static int vcycle_legs_fused(level_type **levels, int n, int e_id, int R_id, double a, double b, int leg) {
-  static int enabled = -1, bottom_enabled = -1;
+  static int bottom_enabled = -1;
+#define enabled fused_tail_enabled
   hpgmg_config cfg;
   const hpgmg_hip_level *dev[8];
   int l, s;
@@ -666,6 +742,7 @@ static int vcycle_legs_fused(level_type **levels, int n, int e_id, int R_id, dou
   hpgmg_get_config(&cfg);
   const int sweeps = hpgmg_smooth_sweeps();
   const int with_bottom = (leg >= 2);
+  if (enabled && cfg.op != HPGMG_OP_7PT) return (leg == 2 && bottom_enabled) ? small_vtail_fused(levels, n, e_id, R_id, a, b) : 0;
   if (!enabled || !ghost_free_mode() || cfg.op != HPGMG_OP_7PT || n > 8 || n > hpgmg_hip_tail_max_levels() || sweeps > 8) return 0;
   if (with_bottom && !bottom_enabled) return 0;
   if (n < (leg == 3 ? 1 : 2)) return 0;
@@ -713,6 +790,7 @@ static int vcycle_legs_fused(level_type **levels, int n, int e_id, int R_id, dou
                                hpgmg_vectors_reserved(), MG_DEFAULT_BOTTOM_NORM, with_bottom ? backend_of(levels[n - 1])->krylov_pinned : NULL));
   TOCK();
   return 1;
+#undef enabled
 }
 
 /* every box of the level is local and local box b sits at lexicographic position b (what the kernels that address

@@ -350,4 +350,20 @@ __device__ __forceinline__ void bc_fv_compact_entry(const hpgmg_hip_level &L, in
 }
 
 
+// 1-D rules of the tensor-product interpolations (v[] = coarse line, centre at v[R]):
+//   order 2 = p2 interpolation_p2.c:90-92,150-205;  order 3 = v2 interpolation_v2.c:111-113;  order 4 = v4 interpolation_v4.c:96-97,180-240
+template <int ORDER>
+__device__ __forceinline__ double interp_rule(bool odd, const double *v) {
+  if (ORDER == 2) {
+    const double w0 = 5.0 / 32.0, w1 = 30.0 / 32.0, w2 = -3.0 / 32.0;
+    return odd ? (w1 * v[1] + w2 * v[0] + w0 * v[2]) : (w1 * v[1] + w0 * v[0] + w2 * v[2]);
+  } else if (ORDER == 3) {
+    const double c1 = 1.0 / 8.0;
+    return odd ? (v[1] - c1 * (v[0] - v[2])) : (v[1] + c1 * (v[0] - v[2]));
+  } else {
+    const double c1 = 22.0 / 128.0, c2 = -3.0 / 128.0;
+    return odd ? (v[2] - c1 * (v[1] - v[3]) - c2 * (v[0] - v[4])) : (v[2] + c1 * (v[1] - v[3]) + c2 * (v[0] - v[4]));
+  }
+}
+
 }  // namespace hpgmg

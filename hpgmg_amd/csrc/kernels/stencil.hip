@@ -22,6 +22,7 @@
 //   * logical tiles are ordered box, k, j, i and dealt to XCDs in contiguous ranges (common.hpp) so halo
 //     planes shared by adjacent tiles hit the same L2.
 #include <stdlib.h>
+#include <cstring>
 #include "common.hpp"
 #include "stencil_math.hpp"
 #include "cheby_pair.hpp"
@@ -516,10 +517,70 @@ __global__ __launch_bounds__(256) void stencil27_kernel(const hpgmg_hip_level L,
 // Expression order is the macro's: T*(six face terms) + (0.25*T)*(twelve mixed terms), each
 // group summed left to right; a mixed term is (beta+ - beta-) * (((x1 - x2) - x3) + x4).
 #define FV4_TWELFTH ( 0.0833333333333333333)
-// (pointer types are template parameters: the single-workgroup kernels pass LDS pointers for the vectors they hold an image of)
+// The fv4 expression below with its 55 operands read in batches (a scheduling fence after each) instead of where the
+// expression names them (three batches: 19 + 24 + 12): out of LDS the compiler otherwise issues them one to three at a time, each group a round trip of its own -- ~30 of
+// them per cell, which was the whole stencil phase of the single-workgroup kernels.  Same expression tree, term by term (MIX(B, o, t, d) =
+// (B[o + t] - B[o - t]) * (((x[d + t] - x[t]) - x[d - t]) + x[-t])).
 template <int V, typename XP, typename CP>
+__device__ __forceinline__ double apply_op_fv4_batched(XP x, CP alpha, CP bi, CP bj, CP bk, int ijk, int jS, int kS, double a, double b, double h2inv) {
+  const double xc = x[ijk], xm1 = x[ijk - 1], xp1 = x[ijk + 1], xm2 = x[ijk - 2], xp2 = x[ijk + 2];
+  const double xmj = x[ijk - jS], xpj = x[ijk + jS], xm2j = x[ijk - 2 * jS], xp2j = x[ijk + 2 * jS];
+  const double xmk = x[ijk - kS], xpk = x[ijk + kS], xm2k = x[ijk - 2 * kS], xp2k = x[ijk + 2 * kS];
+  const double bi0 = bi[ijk], bi1 = bi[ijk + 1], bj0 = bj[ijk], bj1 = bj[ijk + jS], bk0 = bk[ijk], bk1 = bk[ijk + kS];
+  const double al = (V == HPGMG_HIP_FV4_VC_HELMHOLTZ) ? alpha[ijk] : 0.0;
+  __builtin_amdgcn_sched_barrier(0);
+  double s1 = bi0 * (15.0 * (xm1 - xc) - (xm2 - xp1));
+  s1 = s1 + bi1 * (15.0 * (xp1 - xc) - (xp2 - xm1));
+  s1 = s1 + bj0 * (15.0 * (xmj - xc) - (xm2j - xpj));
+  s1 = s1 + bj1 * (15.0 * (xpj - xc) - (xp2j - xmj));
+  s1 = s1 + bk0 * (15.0 * (xmk - xc) - (xm2k - xpk));
+  s1 = s1 + bk1 * (15.0 * (xpk - xc) - (xp2k - xmk));
+  __builtin_amdgcn_sched_barrier(0);
+  double xij[2][2], xik[2][2], xjk[2][2];                                   // x[(+-1) + (+-jS)], x[(+-1) + (+-kS)], x[(+-jS) + (+-kS)]: index 0 = minus, 1 = plus
+  double bi_j[2], bi_k[2], bi1_j[2], bi1_k[2], bj_i[2], bj_k[2], bj1_i[2], bj1_k[2], bk_i[2], bk_j[2], bk1_i[2], bk1_j[2];   // B[o +- t]
+#pragma unroll
+  for (int p = 0; p < 2; p++) {
+    const int sp = p ? 1 : -1;
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const int sq = q ? 1 : -1;
+      xij[p][q] = x[ijk + sp + sq * jS]; xik[p][q] = x[ijk + sp + sq * kS]; xjk[p][q] = x[ijk + sp * jS + sq * kS];
+    }
+    bi_j[p] = bi[ijk + sp * jS]; bi_k[p] = bi[ijk + sp * kS];
+    bj_i[p] = bj[ijk + sp]; bj_k[p] = bj[ijk + sp * kS];
+    bk_i[p] = bk[ijk + sp]; bk_j[p] = bk[ijk + sp * jS];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  double s2 = (bi_j[1] - bi_j[0]) * (xij[0][1] - xpj - xij[0][0] + xmj);
+  s2 = s2 + (bi_k[1] - bi_k[0]) * (xik[0][1] - xpk - xik[0][0] + xmk);
+  s2 = s2 + (bj_i[1] - bj_i[0]) * (xij[1][0] - xp1 - xij[0][0] + xm1);
+  s2 = s2 + (bj_k[1] - bj_k[0]) * (xjk[0][1] - xpk - xjk[0][0] + xmk);
+  s2 = s2 + (bk_i[1] - bk_i[0]) * (xik[1][0] - xp1 - xik[0][0] + xm1);
+  s2 = s2 + (bk_j[1] - bk_j[0]) * (xjk[1][0] - xpj - xjk[0][0] + xmj);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int p = 0; p < 2; p++) {                                               // third batch: the coefficients of the far faces (1024 lanes: 128 registers each)
+    const int sp = p ? 1 : -1;
+    bi1_j[p] = bi[ijk + 1 + sp * jS]; bi1_k[p] = bi[ijk + 1 + sp * kS];
+    bj1_i[p] = bj[ijk + jS + sp]; bj1_k[p] = bj[ijk + jS + sp * kS];
+    bk1_i[p] = bk[ijk + kS + sp]; bk1_j[p] = bk[ijk + kS + sp * jS];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  s2 = s2 + (bi1_j[1] - bi1_j[0]) * (xij[1][1] - xpj - xij[1][0] + xmj);
+  s2 = s2 + (bi1_k[1] - bi1_k[0]) * (xik[1][1] - xpk - xik[1][0] + xmk);
+  s2 = s2 + (bj1_i[1] - bj1_i[0]) * (xij[1][1] - xp1 - xij[0][1] + xm1);
+  s2 = s2 + (bj1_k[1] - bj1_k[0]) * (xjk[1][1] - xpk - xjk[1][0] + xmk);
+  s2 = s2 + (bk1_i[1] - bk1_i[0]) * (xik[1][1] - xp1 - xik[0][1] + xm1);
+  s2 = s2 + (bk1_j[1] - bk1_j[0]) * (xjk[1][1] - xpj - xjk[0][1] + xmj);
+  const double sum = FV4_TWELFTH * s1 + (0.25 * FV4_TWELFTH) * s2;
+  if (V == HPGMG_HIP_FV4_VC_HELMHOLTZ) return (a * al) * xc - (b * h2inv) * sum;
+  return ((-b) * h2inv) * sum;
+}
+// (pointer types are template parameters: the single-workgroup kernels pass LDS pointers for the vectors they hold an image of, and BATCH)
+template <int V, typename XP, typename CP, bool BATCH = false>
 __device__ __forceinline__ double apply_op_direct(XP x, CP alpha, CP bi, CP bj, CP bk,
                                                   int ijk, int jS, int kS, double a, double b, double h2inv) {
+  if constexpr (BATCH && (V == HPGMG_HIP_FV4_VC_HELMHOLTZ || V == HPGMG_HIP_FV4_VC_POISSON)) return apply_op_fv4_batched<V>(x, alpha, bi, bj, bk, ijk, jS, kS, a, b, h2inv);
   const double xc = x[ijk];
   if (V == HPGMG_HIP_FV4_VC_HELMHOLTZ || V == HPGMG_HIP_FV4_VC_POISSON) {
     double s1 = bi[ijk] * (15.0 * (x[ijk - 1] - xc) - (x[ijk - 2] - x[ijk + 1]));
@@ -633,6 +694,10 @@ struct SmallArgs {
 constexpr int kSmallSlots = 9;
 typedef double __attribute__((address_space(3))) *lds_dptr;       // a pointer into LDS, typed as such: ds_read / ds_write, not FLAT
 typedef const int __attribute__((address_space(3))) *lds_iptr;
+// a pointer into global memory, typed as such: through a generic pointer a load is a FLAT instruction, which may address LDS -- the compiler
+// then keeps every such load and every LDS store of a copy loop in program order, one round trip to memory per element
+typedef double __attribute__((address_space(1))) *gbl_dptr;
+typedef const double __attribute__((address_space(1))) *gbl_cdptr;
 // the eight words of a boundary entry that the entry routines read (subtype, dim, read.box / i / j / k), kept in LDS by the single-workgroup
 // kernels: read from the level's list in memory, the descriptor was a round trip per entry and half sweep
 __device__ __forceinline__ void lds_bc_words_fill(int *words, const blockCopy_type *list, int n, int tid, int nth) {
@@ -651,8 +716,9 @@ __device__ __forceinline__ blockCopy_type lds_bc_entry(const int *words, int e) 
 // The sweeps of one launch.  RES: the vectors live in the LDS image (`image`; vector "ids" are slots of it, the only box is box 0) and every
 // access to them is an LDS instruction -- through generic pointers each was a FLAT access, and a corner entry of apply_BCs_v4 (64 dependent
 // reads by one lane) or the 55 reads of a stencil took microseconds: 6.1 + 3.8 us per half sweep of an 8^3 level, 66 us per smooth().
-template <int V, bool RES>
-__device__ __forceinline__ void small_level_run(const hpgmg_hip_level &L, const SmallArgs &A, double *image, const blockCopy_type *bc_entries, const int *bc_words, const int *ids, unsigned long long *tl, int &tl_n) {
+// coef(s, c1, c2): the Chebyshev / Jacobi coefficients of sweep s (a functor: the caller knows where they live -- kernel arguments, memory)
+template <int V, bool RES, typename CoefFn>
+__device__ __forceinline__ void small_level_run(const hpgmg_hip_level &L, const SmallArgs &A, double *image, const blockCopy_type *bc_entries, const int *bc_words, const int *ids, unsigned long long *tl, int &tl_n, CoefFn coef) {
   constexpr bool k27 = (V == HPGMG_HIP_27PT_CC);
   constexpr bool kVC = (V != HPGMG_HIP_7PT_CC && !k27);
   constexpr bool kHelm = (V == HPGMG_HIP_7PT_VC_HELMHOLTZ || V == HPGMG_HIP_FV4_VC_HELMHOLTZ);
@@ -680,7 +746,11 @@ __device__ __forceinline__ void small_level_run(const hpgmg_hip_level &L, const 
 #else
 #define SL_MARK() do { (void)tl; (void)tl_n; } while (0)
 #endif
+  // (an image is one box of at most 512 cells, a cell per lane: its coordinates are worked out once, not per sweep -- four integer divisions)
+  const int own_k = tid / (dim * dim), own_j = (tid / dim) % dim, own_i = tid % dim;
   for (int s = 0; s < A.sweeps; s++) {
+    double cs1 = 0.0, cs2 = 0.0;
+    coef(s, cs1, cs2);
     int src = x_id, dst = res_id;
     if (A.mode == MODE_CHEBY || A.mode == MODE_JACOBI || (A.mode == MODE_GSRB && A.out_of_place)) { src = (s & 1) ? temp_id : x_id; dst = (s & 1) ? x_id : temp_id; }
     else if (A.mode == MODE_GSRB) { src = x_id; dst = x_id; }
@@ -700,7 +770,8 @@ __device__ __forceinline__ void small_level_run(const hpgmg_hip_level &L, const 
     SL_MARK();
     // the stencil over every cell (same expressions as stencil_direct_kernel / stencil27_kernel)
     for (int t = tid; t < total; t += (int)blockDim.x) {
-      const int box = t / per_box, r = t - box * per_box, k = r / (dim * dim), j = (r / dim) % dim, i = r % dim;
+      int box = 0, i = own_i, j = own_j, k = own_k;
+      if (!RES || total > (int)blockDim.x) { box = t / per_box; const int r = t - box * per_box; k = r / (dim * dim); j = (r / dim) % dim; i = r % dim; }
       const int ijk = i + j * jS + k * kS;
       auto x = vo(box, src);
       auto out = vo(box, dst);
@@ -717,16 +788,16 @@ __device__ __forceinline__ void small_level_run(const hpgmg_hip_level &L, const 
         Ax = apply_op_27pt(m, c, p, A.a, A.b, A.h2inv);
       } else {
         auto none = vo(box, src); none = nullptr;
-        Ax = apply_op_direct<V>(x, kHelm ? vo(box, al_id) : none, kVC ? vo(box, bi_id) : none, kVC ? vo(box, bj_id) : none, kVC ? vo(box, bk_id) : none,
-                                ijk, jS, kS, A.a, A.b, A.h2inv);
+        Ax = apply_op_direct<V, decltype(x), decltype(none), RES>(x, kHelm ? vo(box, al_id) : none, kVC ? vo(box, bi_id) : none, kVC ? vo(box, bj_id) : none, kVC ? vo(box, bk_id) : none,
+                                                                   ijk, jS, kS, A.a, A.b, A.h2inv);
       }
       if (A.mode == MODE_APPLY) { out[ijk] = Ax; continue; }
       const double rhs = vo(box, rhs_id)[ijk];
       if (A.mode == MODE_RESIDUAL) { out[ijk] = rhs - Ax; continue; }
       const double dinv = vo(box, dinv_id)[ijk];
-      if (A.mode == MODE_CHEBY)      { const double xnm1 = out[ijk]; out[ijk] = xc + A.c1[s] * (xc - xnm1) + A.c2[s] * dinv * (rhs - Ax); }
+      if (A.mode == MODE_CHEBY)      { const double xnm1 = out[ijk]; out[ijk] = xc + cs1 * (xc - xnm1) + cs2 * dinv * (rhs - Ax); }
       else if (A.mode == MODE_GSRB)  { out[ijk] = xc + dinv * (rhs - Ax); }
-      else                           { out[ijk] = xc + A.c2[s] * dinv * (rhs - Ax); }
+      else                           { out[ijk] = xc + cs2 * dinv * (rhs - Ax); }
     }
     __syncthreads();
     SL_MARK();
@@ -749,7 +820,7 @@ __global__ __launch_bounds__(1024) void small_level_kernel(const hpgmg_hip_level
   if (!A.lds_resident) {                                          // out of global memory: measured slower than the launches it replaces (experiments)
 #ifdef HPGMG_EXPERIMENTS
     const int ids[kSmallSlots] = { A.x_id, VECTOR_TEMP, A.rhs_id, VECTOR_DINV, VECTOR_ALPHA, VECTOR_BETA_I, VECTOR_BETA_J, VECTOR_BETA_K, A.res_id };
-    small_level_run<V, false>(L, A, nullptr, A.bc_list, nullptr, ids, tl, tl_n);
+    small_level_run<V, false>(L, A, nullptr, A.bc_list, nullptr, ids, tl, tl_n, [&](int s, double &c1, double &c2) { c1 = A.c1[s]; c2 = A.c2[s]; });
 #endif
     return;
   }
@@ -770,7 +841,7 @@ __global__ __launch_bounds__(1024) void small_level_kernel(const hpgmg_hip_level
   for (int q = 0; q < kSmallSlots; q++) {
     if (slot_of[q] < 0) continue;
     // (a result vector that is written in full needs no load, but its ghost zone must come back as it was: copy it all the same)
-    const double *g = L.box_base[0] + (size_t)slot_of[q] * vol;
+    const gbl_cdptr g = (gbl_cdptr)(L.box_base[0] + (size_t)slot_of[q] * vol);
 #pragma unroll 8
     for (int t = tid; t < (int)vol; t += (int)blockDim.x) img[(size_t)q * vol + t] = g[t];      // unrolled: eight loads in flight per lane, not one
   }
@@ -779,12 +850,12 @@ __global__ __launch_bounds__(1024) void small_level_kernel(const hpgmg_hip_level
   if (tl && tid == 0) tl[tl_n++] = __builtin_amdgcn_s_memrealtime();
 #endif
   const int ids[kSmallSlots] = { 0, 1, 2, 3, 4, 5, 6, 7, (smooth || A.res_id == A.x_id) ? 0 : 8 };
-  small_level_run<V, true>(L, A, small_lds, A.bc_list, bc_in_lds ? (const int *)s_bc : nullptr, ids, tl, tl_n);
+  small_level_run<V, true>(L, A, small_lds, A.bc_list, bc_in_lds ? (const int *)s_bc : nullptr, ids, tl, tl_n, [&](int s, double &c1, double &c2) { c1 = A.c1[s]; c2 = A.c2[s]; });
 #pragma unroll
   for (int q = 0; q < kSmallSlots; q++) {
     const bool written = smooth ? (q == 0 || (q == 1 && slot_of[1] >= 0)) : (q == 0 || q == 8);      // x's ghost zone was filled too
     if (!written || slot_of[q] < 0) continue;
-    double *g = L.box_base[0] + (size_t)slot_of[q] * vol;
+    const gbl_dptr g = (gbl_dptr)(L.box_base[0] + (size_t)slot_of[q] * vol);
 #pragma unroll 8
     for (int t = tid; t < (int)vol; t += (int)blockDim.x) g[t] = img[(size_t)q * vol + t];
   }
@@ -810,7 +881,7 @@ struct BottomArgs {
   int *krylov_iterations;
 };
 template <int V>
-__global__ __launch_bounds__(512) void bottom_bicgstab_kernel(const hpgmg_hip_level L, const BottomArgs A) {
+__device__ __forceinline__ void bottom_bicgstab_body(const hpgmg_hip_level &L, const BottomArgs &A) {
   constexpr bool k27 = (V == HPGMG_HIP_27PT_CC);
   constexpr bool kVC = (V != HPGMG_HIP_7PT_CC && !k27);
   constexpr bool kHelm = (V == HPGMG_HIP_7PT_VC_HELMHOLTZ || V == HPGMG_HIP_FV4_VC_HELMHOLTZ);
@@ -830,8 +901,8 @@ __global__ __launch_bounds__(512) void bottom_bicgstab_kernel(const hpgmg_hip_le
   const bool bc_in_lds = A.n_bc <= 32;
   if (bc_in_lds) lds_bc_words_fill(s_bc, A.bc_list, A.n_bc, tid, (int)blockDim.x);
   {
-    const double *g_al = L.box_base[0] + (size_t)VECTOR_ALPHA * vol, *g_bi = L.box_base[0] + (size_t)VECTOR_BETA_I * vol;
-    const double *g_bj = L.box_base[0] + (size_t)VECTOR_BETA_J * vol, *g_bk = L.box_base[0] + (size_t)VECTOR_BETA_K * vol;
+    const gbl_cdptr g_al = (gbl_cdptr)(L.box_base[0] + (size_t)VECTOR_ALPHA * vol), g_bi = (gbl_cdptr)(L.box_base[0] + (size_t)VECTOR_BETA_I * vol);
+    const gbl_cdptr g_bj = (gbl_cdptr)(L.box_base[0] + (size_t)VECTOR_BETA_J * vol), g_bk = (gbl_cdptr)(L.box_base[0] + (size_t)VECTOR_BETA_K * vol);
     for (int t = tid; t < vol; t += (int)blockDim.x) {
       img[t] = 0.0;
       if (kHelm) img[vol + t] = g_al[t];
@@ -867,7 +938,7 @@ __global__ __launch_bounds__(512) void bottom_bicgstab_kernel(const hpgmg_hip_le
         const plane9 m = load_plane(xi + (ijk - kS), jS), c = load_plane(xi + ijk, jS), pp = load_plane(xi + (ijk + kS), jS);
         Ax = apply_op_27pt(m, c, pp, A.a, A.b, A.h2inv);
       } else {
-        Ax = apply_op_direct<V>(xi, alpha, bi, bj, bk, ijk, jS, kS, A.a, A.b, A.h2inv);
+        Ax = apply_op_direct<V, lds_dptr, lds_dptr, true>(xi, alpha, bi, bj, bk, ijk, jS, kS, A.a, A.b, A.h2inv);
       }
     }
     __syncthreads();
@@ -953,6 +1024,157 @@ __global__ __launch_bounds__(512) void bottom_bicgstab_kernel(const hpgmg_hip_le
     vec_origin(L, 0, VECTOR_TEMP)[ijk] = tmp;
   }
   if (tid == 0 && A.krylov_iterations) *A.krylov_iterations += it;
+}
+template <int V>
+__global__ __launch_bounds__(512) void bottom_bicgstab_kernel(const hpgmg_hip_level L, const BottomArgs A) { bottom_bicgstab_body<V>(L, A); }
+
+// ---------------------------------------------------------------------------------------------
+// The rest of a V-cycle below a level of ONE box, 27-point / fv2 / fv4 plugins (mg.c:1133-1166), as one single-workgroup launch.  Driven
+// operator by operator a visit of such a level is 4 launches on the way down (smooth -- itself one launch, above --, the boundary fill and
+// the stencil of residual(), restriction + zero_vector) and 3 on the way up, ~5 us each for work of a microsecond.  Here the levels of
+// the chain take turns in LDS: an image of the level's box (nine vectors, padded layout) is loaded, small_level_run() smooths it and
+// forms the residual, the restriction goes straight from the image to the coarse level's right-hand side in memory, the written vectors go
+// back; the bottom solve is bottom_bicgstab_body(); on the way up the coarse correction is staged behind the image, its boundary
+// conditions are applied there and the tensor rule adds it to the image's x before the smoother runs.  Every per-cell expression is the one
+// of the per-operator kernels (restrict_entry / interp_tensor_kernel in blocks.hip), so the result is bit-identical to the launches it
+// replaces (the coarse correction's ghost zone in MEMORY is left as it was: every reader fills it first).
+template <int V>
+__global__ __launch_bounds__(1024) void small_vtail_kernel(const hpgmg_hip_small_tail_args *__restrict__ Tp, unsigned long long *tl) {
+#ifdef HPGMG_EXP_TIMELINE
+  int tl_n = 0;
+#define VT_MARK() do { if (tl && threadIdx.x == 0 && tl_n < 250) tl[tl_n++] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define VT_MARK() do { (void)tl; } while (0)
+#endif
+  VT_MARK();
+#ifdef HPGMG_EXP_TIMELINE
+  if (tl && threadIdx.x == 0) tl[253] = __builtin_amdgcn_s_memtime();      // shader clock against the 100 MHz real-time marks
+#endif
+  constexpr bool k27 = (V == HPGMG_HIP_27PT_CC);
+  constexpr bool kVC = (V != HPGMG_HIP_7PT_CC && !k27);
+  constexpr bool kHelm = (V == HPGMG_HIP_7PT_VC_HELMHOLTZ || V == HPGMG_HIP_FV4_VC_HELMHOLTZ);
+  constexpr int ORDER = k27 ? 2 : 3;                               // interpolation_p2.c (27-point) / interpolation_v2.c (fv2, fv4)
+  extern __shared__ double vt_lds[];
+  __shared__ int s_bc[32 * 8];
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = (int)blockDim.x >> 6, nth = (int)blockDim.x;
+  const int n = Tp->n, e_id = Tp->e_id, R_id = Tp->R_id;
+  const lds_dptr img = (lds_dptr)vt_lds;
+  // slots of an image: x, VECTOR_TEMP, rhs, Dinv, alpha, beta_i, beta_j, beta_k (small_level_run addresses them by slot number)
+  const int slot_vec[8] = { e_id, VECTOR_TEMP, R_id, VECTOR_DINV, kHelm ? VECTOR_ALPHA : -1, kVC ? VECTOR_BETA_I : -1, kVC ? VECTOR_BETA_J : -1, kVC ? VECTOR_BETA_K : -1 };
+  int unused_n = 0;
+  for (int ph = 0; ph < 2 * n - 1; ph++) {
+    if (ph == n - 1) {                                             // ---- the bottom solve (solvers.c IterativeSolver -> BiCGStab)
+      const hpgmg_hip_small_tail_level &lb = Tp->lv[n - 1];
+      const hpgmg_hip_level Lb = lb.L;
+      BottomArgs B;
+      B.e_id = e_id; B.R_id = R_id; B.krylov_base = Tp->krylov_base; B.bc_kind = lb.n_bc > 0 ? lb.bc_kind : 0; B.zero_first = lb.zero_first; B.n_bc = lb.n_bc;
+      B.a = Tp->a; B.b = Tp->b; B.h2inv = lb.h2inv; B.want = Tp->want; B.bc_list = lb.bc_list; B.krylov_iterations = Tp->krylov_iterations;
+      bottom_bicgstab_body<V>(Lb, B);
+      __threadfence(); __syncthreads();
+      VT_MARK();
+      continue;
+    }
+    const bool down = ph < n - 1;
+    const int l = down ? ph : (2 * (n - 1) - ph);
+    const hpgmg_hip_small_tail_level &lv = Tp->lv[l];
+    const hpgmg_hip_level L = lv.L;
+    const int vol = L.volume, jS = L.jStride, kS = L.kStride, dim = L.dim, first = L.ghosts * (1 + jS + kS);
+    // ---- the image of level l
+    {
+      const double *base = L.box_base[0];
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        if (slot_vec[q] < 0) continue;
+        const gbl_cdptr g = (gbl_cdptr)(base + (size_t)slot_vec[q] * vol);
+#pragma unroll 4
+        for (int t = tid; t < vol; t += nth) img[q * vol + t] = g[t];
+      }
+    }
+    VT_MARK();
+    if (!down) {
+      // ---- interpolation_vcycle(level l, e, 1.0, level l + 1, e): the coarse correction behind the image, its boundary conditions, the rule
+      const hpgmg_hip_small_tail_level &lc = Tp->lv[l + 1];
+      const hpgmg_hip_level Lc = lc.L;
+      const int cvol = Lc.volume, cj = Lc.jStride, ck = Lc.kStride, cfirst = Lc.ghosts * (1 + cj + ck);
+      const lds_dptr stage = img + 8 * vol;
+      const gbl_cdptr gx = (gbl_cdptr)(Lc.box_base[0] + (size_t)e_id * cvol);
+      for (int t = tid; t < cvol; t += nth) stage[t] = gx[t];
+      lds_bc_words_fill(s_bc, lc.ibc_list, lc.n_ibc, tid, nth);
+      __syncthreads();
+      const lds_dptr cx = stage + cfirst;
+      if (lc.ibc_kind && lc.ibc_zero_first) { for (int e = wave; e < lc.n_ibc; e += nwaves) bc_zero_entry_at(cx, Lc, lds_bc_entry(s_bc, e), lane, 64); __syncthreads(); }
+      for (int e = wave; e < lc.n_ibc; e += nwaves) {
+        const blockCopy_type en = lds_bc_entry(s_bc, e);
+        if (lc.ibc_kind == 1) bc_p1_entry_at(cx, Lc, en, lane, 64);
+        else if (lc.ibc_kind == 2) bc_p2_entry_at(cx, Lc, en, lane, 64);
+        else if (lc.ibc_kind == 3) bc_v2_entry_at(cx, Lc, en, lane, 64);
+      }
+      __syncthreads();
+      const lds_dptr xf = img + first;
+      for (int t = tid; t < dim * dim * dim; t += nth) {
+        const int i = t % dim, j = (t / dim) % dim, k = t / (dim * dim);
+        const lds_dptr c = cx + ((i >> 1) + (j >> 1) * cj + (k >> 1) * ck);
+        double tk[3];
+#pragma unroll
+        for (int kk = 0; kk < 3; kk++) {
+          double tj[3];
+#pragma unroll
+          for (int jj = 0; jj < 3; jj++) {
+            double line[3];
+#pragma unroll
+            for (int ii = 0; ii < 3; ii++) line[ii] = c[(ii - 1) + (jj - 1) * cj + (kk - 1) * ck];
+            tj[jj] = interp_rule<ORDER>((i & 1) != 0, line);
+          }
+          tk[kk] = interp_rule<ORDER>((j & 1) != 0, tj);
+        }
+        const double add = interp_rule<ORDER>((k & 1) != 0, tk);
+        const int ijk = i + j * jS + k * kS;
+        xf[ijk] = 1.0 * xf[ijk] + add;
+      }
+    }
+    lds_bc_words_fill(s_bc, lv.bc_list, lv.n_bc, tid, nth);
+    __syncthreads();
+    VT_MARK();
+    // ---- smooth(level l), and on the way down residual(level l, VECTOR_TEMP, e, R)
+    for (int pass = 0; pass < (down ? 2 : 1); pass++) {
+      SmallArgs A;
+      A.mode = pass ? MODE_RESIDUAL : Tp->mode; A.sweeps = pass ? 1 : Tp->sweeps; A.out_of_place = pass ? 0 : Tp->out_of_place;
+      A.x_id = 0; A.rhs_id = 2; A.res_id = 1; A.bc_kind = lv.n_bc > 0 ? lv.bc_kind : 0; A.zero_first = lv.zero_first;
+      A.a = Tp->a; A.b = Tp->b; A.h2inv = lv.h2inv; A.copy_list = nullptr; A.n_copy = 0; A.bc_list = lv.bc_list; A.n_bc = lv.n_bc; A.lds_resident = 1; A.timeline = nullptr;
+      const int ids[kSmallSlots] = { 0, 1, 2, 3, 4, 5, 6, 7, pass ? 1 : 0 };
+      small_level_run<V, true>(L, A, vt_lds, lv.bc_list, lv.n_bc <= 32 ? (const int *)s_bc : nullptr, ids, nullptr, unused_n,
+                               [&](int s, double &c1, double &c2) { c1 = lv.c1[s]; c2 = lv.c2[s]; });
+      VT_MARK();
+    }
+    if (down) {
+      // ---- restriction(level l + 1, R, level l, VECTOR_TEMP, RESTRICT_CELL) and zero_vector(level l + 1, e)
+      const hpgmg_hip_level Lc = Tp->lv[l + 1].L;
+      const int cdim = Lc.dim, cj = Lc.jStride, ck = Lc.kStride, cvol = Lc.volume;
+      const lds_dptr tf = img + (vol + first);
+      const gbl_dptr rc = (gbl_dptr)(Lc.box_base[0] + (size_t)R_id * cvol + (size_t)Lc.ghosts * (1 + cj + ck));
+      for (int t = tid; t < cdim * cdim * cdim; t += nth) {
+        const int i = t % cdim, j = (t / cdim) % cdim, k = t / (cdim * cdim);
+        const lds_dptr f = tf + (2 * i + 2 * j * jS + 2 * k * kS);
+        double v = f[0] + f[1]; v = v + f[jS]; v = v + f[1 + jS]; v = v + f[kS]; v = v + f[1 + kS]; v = v + f[jS + kS]; v = v + f[1 + jS + kS];
+        rc[i + j * cj + k * ck] = v * 0.125;
+      }
+      const gbl_dptr zc = (gbl_dptr)(Lc.box_base[0] + (size_t)e_id * cvol);
+      for (int t = tid; t < cvol; t += nth) zc[t] = 0.0;
+    }
+    // ---- what was written goes back: x and VECTOR_TEMP, ghost zones included (the boundary entries filled them)
+    {
+      double *base = L.box_base[0];
+      const gbl_dptr gx = (gbl_dptr)(base + (size_t)e_id * vol), gt = (gbl_dptr)(base + (size_t)VECTOR_TEMP * vol);
+#pragma unroll 4
+      for (int t = tid; t < vol; t += nth) { gx[t] = img[t]; gt[t] = img[vol + t]; }
+    }
+    __threadfence(); __syncthreads();
+    VT_MARK();
+  }
+#ifdef HPGMG_EXP_TIMELINE
+  if (tl && threadIdx.x == 0) { tl[254] = __builtin_amdgcn_s_memtime(); tl[255] = (unsigned long long)tl_n; }
+#endif
+#undef VT_MARK
 }
 
 // ---- smoother-kernel profiling: hipEvent pair around every smoother launch ----
@@ -1639,6 +1861,61 @@ int hpgmg_hip_bottom_bicgstab(const hpgmg_hip_level *L, int variant, int x_id, i
   }
 #undef BOTTOM_CASE
   HPGMG_LAUNCH_CHECK("bottom_bicgstab_kernel");
+  return 0;
+}
+// V-cycle tail below a level of one box (small_vtail_kernel).  The argument block lives in device memory: it is the same for every visit of
+// a chain in a solve, so a few of them are kept and uploaded only when their contents change.
+long long hpgmg_hip_small_vtail_lds_limit(void) { return 150 * 1024 / (long long)sizeof(double); }
+long long hpgmg_hip_small_vtail_lds_doubles(const hpgmg_hip_small_tail_args *T) {
+  long long need = 0;
+  for (int l = 0; l + 1 < T->n; l++) { const long long v = 8LL * T->lv[l].L.volume + T->lv[l + 1].L.volume; if (v > need) need = v; }
+  const long long bottom = 5LL * T->lv[T->n - 1].L.volume + 1100;
+  return bottom > need ? bottom : need;
+}
+static long long g_small_vtail_launches = 0;
+long long hpgmg_hip_small_vtail_launch_count(void) { return g_small_vtail_launches; }
+int hpgmg_hip_small_vtail(const hpgmg_hip_small_tail_args *T, int variant) {
+  HPGMG_SKIP_IF_REPLAY();
+  if (!T || T->n < 2 || T->n > HPGMG_HIP_SMALL_TAIL_MAX_LEVELS || T->sweeps < 1 || T->sweeps > 8 || T->mode < MODE_CHEBY || T->mode > MODE_JACOBI)
+    return record_error(hipErrorInvalidValue, "small_vtail: arguments");
+  for (int l = 0; l < T->n; l++) {
+    const hpgmg_hip_level &L = T->lv[l].L;
+    if (L.num_boxes != 1 || L.periodic || (l > 0 && 2 * L.dim != T->lv[l - 1].L.dim)) return record_error(hipErrorInvalidValue, "small_vtail: a chain of levels of one box, halving, Dirichlet");
+  }
+  if ((long long)T->lv[T->n - 1].L.dim * T->lv[T->n - 1].L.dim * T->lv[T->n - 1].L.dim > 512) return record_error(hipErrorInvalidValue, "small_vtail: bottom level too large");
+  const long long need = hpgmg_hip_small_vtail_lds_doubles(T);
+  if (need > hpgmg_hip_small_vtail_lds_limit()) return record_error(hipErrorInvalidValue, "small_vtail: the chain does not fit the LDS");
+  constexpr int kSlots = 8;
+  static hpgmg_hip_small_tail_args host_copy[kSlots];
+  static hpgmg_hip_small_tail_args *dev_copy[kSlots];
+  static int used = 0, next = 0;
+  int slot = -1;
+  for (int q = 0; q < used; q++) if (memcmp(&host_copy[q], T, sizeof *T) == 0) { slot = q; break; }
+  if (slot < 0) {
+    slot = (used < kSlots) ? used++ : (next++ % kSlots);
+    if (!dev_copy[slot]) HPGMG_CHECK(hipMalloc((void **)&dev_copy[slot], sizeof *T));
+    host_copy[slot] = *T;
+    HPGMG_CHECK(hipMemcpyAsync(dev_copy[slot], &host_copy[slot], sizeof *T, hipMemcpyHostToDevice, g_stream));   // stream order: after every launch that reads the slot
+  }
+  const size_t lds = (size_t)need * sizeof(double);
+  unsigned long long *tl = nullptr;
+#ifdef HPGMG_EXP_TIMELINE
+  tl = (unsigned long long *)g_exp_timeline;
+#endif
+#define VTAIL_CASE(VAR) { \
+    static bool once = false; if (!once) { HPGMG_CHECK(hipFuncSetAttribute((const void *)small_vtail_kernel<VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); once = true; } \
+    hipLaunchKernelGGL((small_vtail_kernel<VAR>), dim3(1), dim3(1024), lds, g_stream, (const hpgmg_hip_small_tail_args *)dev_copy[slot], tl); }
+  switch (variant) {
+    case HPGMG_HIP_27PT_CC:          VTAIL_CASE(HPGMG_HIP_27PT_CC) break;
+    case HPGMG_HIP_FV4_VC_HELMHOLTZ: VTAIL_CASE(HPGMG_HIP_FV4_VC_HELMHOLTZ) break;
+    case HPGMG_HIP_FV4_VC_POISSON:   VTAIL_CASE(HPGMG_HIP_FV4_VC_POISSON) break;
+    case HPGMG_HIP_7PT_VC_HELMHOLTZ: VTAIL_CASE(HPGMG_HIP_7PT_VC_HELMHOLTZ) break;
+    case HPGMG_HIP_7PT_VC_POISSON:   VTAIL_CASE(HPGMG_HIP_7PT_VC_POISSON) break;
+    default: return record_error(hipErrorInvalidValue, "small_vtail: variant");
+  }
+#undef VTAIL_CASE
+  g_small_vtail_launches++;
+  HPGMG_LAUNCH_CHECK("small_vtail_kernel");
   return 0;
 }
 int hpgmg_hip_smooth_gsrb(const hpgmg_hip_level *L, int variant, int xn_id, int xnp1_id, int rhs_id,

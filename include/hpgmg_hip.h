@@ -141,6 +141,29 @@ int hpgmg_hip_small_level_op(const hpgmg_hip_level *L, int variant, int mode, in
 int hpgmg_hip_bottom_bicgstab_max_cells(void);
 int hpgmg_hip_bottom_bicgstab(const hpgmg_hip_level *L, int variant, int x_id, int rhs_id, int krylov_base, double a, double b, double h2inv, double want,
                               const blockCopy_type *bc_list, int n_bc, int bc_kind, int zero_first, int *krylov_iterations);
+/* The rest of a V-cycle (mg.c:1133-1166 MGVCycle) of the 27-point / fv2 / fv4 plugins below a level of ONE box, as one single-workgroup
+ * launch: per level smooth, residual, restriction (restriction.c:49-60), zero_vector of the coarse correction; the BiCGStab bottom solve
+ * (as hpgmg_hip_bottom_bicgstab); then per level upwards interpolation_vcycle (interpolation_p2.c / _v2.c: apply_BCs of the coarse
+ * correction over STENCIL_SHAPE_BOX, then fine += tensor rule) and smooth.  lv[0] is the finest level of the chain, lv[n-1] the bottom.  Every
+ * level is one box whose nine vectors fit the LDS (lds_doubles() tells how much a chain needs); Dirichlet.  mode: 0 Chebyshev, 1 GSRB,
+ * 2 Jacobi (as hpgmg_hip_small_level_op).  The same entry routines and per-cell expressions as the per-operator kernels: bit-identical. */
+#define HPGMG_HIP_SMALL_TAIL_MAX_LEVELS 4
+typedef struct {
+  hpgmg_hip_level L;
+  const blockCopy_type *bc_list, *ibc_list;   /* DEVICE lists: boundary blocks of the operator's stencil shape / of STENCIL_SHAPE_BOX (interpolation FROM this level) */
+  int n_bc, bc_kind, zero_first, n_ibc, ibc_kind, ibc_zero_first;   /* kinds: 1 p1, 2 p2, 3 v2, 4 v4; zero_first: clear the blocks before the condition fills its layers */
+  double h2inv, c1[8], c2[8];                  /* Chebyshev coefficients per sweep (Jacobi: c2 = the weight) */
+} hpgmg_hip_small_tail_level;
+typedef struct {
+  int n, mode, sweeps, out_of_place, e_id, R_id, krylov_base, pad_;
+  double a, b, want;
+  int *krylov_iterations;                      /* device-visible host counter the bottom solve adds its iteration count to, or NULL */
+  hpgmg_hip_small_tail_level lv[HPGMG_HIP_SMALL_TAIL_MAX_LEVELS];
+} hpgmg_hip_small_tail_args;
+long long hpgmg_hip_small_vtail_lds_doubles(const hpgmg_hip_small_tail_args *args);   /* > what a workgroup has: the chain does not qualify */
+long long hpgmg_hip_small_vtail_lds_limit(void);
+int hpgmg_hip_small_vtail(const hpgmg_hip_small_tail_args *args, int variant);
+long long hpgmg_hip_small_vtail_launch_count(void);   /* launches so far (tests) */
 void hpgmg_hip_set_defer_mode(int mode);
 /* The LDS-tiled 27-point and fv4 kernels (boxes whose side is a multiple of 64, out of place) can read x outside a box from the
  * neighbouring box itself when every box of the level is local: the caller then runs only apply_BCs before the launch, not

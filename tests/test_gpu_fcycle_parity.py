@@ -152,6 +152,34 @@ def test_small_levels_as_single_launches_give_the_same_norms(hip, variant, args,
         hip.lib.hpgmg_set_small_fused(2)
 
 
+@pytest.mark.parametrize("variant,args", [("fv4-gsrb", "4 8"), ("27pt-gsrb", "4 8"), ("27pt-cheby", "5 8"), ("fv2-cheby", "4 8"), ("fv4-cheby", "4 8")])
+def test_vcycle_tail_below_a_one_box_level_is_one_launch_and_gives_the_same_norms(hip, variant, args):
+    """27-point / fv2 / fv4: the rest of a V-cycle below a level of ONE box (smooth, residual, restriction, zero_vector per level, the BiCGStab
+    bottom solve, interpolation_vcycle and smooth per level upwards) can run as one single-workgroup launch (small_vtail_kernel; opt-in,
+    hpgmg_set_small_vtail(1): it measured no faster than the launches it replaces).  When on it must be taken (launch counter), and the norms are
+    the golden ones with it and without it."""
+    import ctypes
+    import hpgmg_amd as H
+    gold = GOLD[f"{variant} {args}"]
+    k = H.load_kernels()
+    k.hpgmg_hip_small_vtail_launch_count.restype = ctypes.c_longlong
+    hip.lib.hpgmg_set_small_vtail.argtypes = [ctypes.c_int]
+    try:
+        for on in (1, 0):
+            hip.lib.hpgmg_set_small_vtail(on)
+            hip.configure(**VARIANTS[variant])
+            before = k.hpgmg_hip_small_vtail_launch_count()
+            s = hip.solver_cli(*map(int, args.split()))
+            assert [fmt(v) for v in s.three_sizes()] == gold["norms"]
+            err, order = s.richardson()
+            assert fmt(err) == gold["richardson_error"]
+            s.destroy()
+            taken = k.hpgmg_hip_small_vtail_launch_count() - before
+            assert (taken > 0) if on else (taken == 0), (on, taken)
+    finally:
+        hip.lib.hpgmg_set_small_vtail(0)
+
+
 def test_reference_three_launch_mode_gives_the_same_norms(hip):
     """HPGMG_GHOST_FREE=0 path (exchange_boundary + apply_BCs + stencil, as the reference sequences them)."""
     import ctypes
