@@ -657,23 +657,24 @@ static int vcycle_legs_fused(level_type **levels, int n, int e_id, int R_id, dou
 int hpgmg_vcycle_legs_fused(level_type **levels, int n, int e_id, int R_id, double a, double b, int leg) { lazy_flush(); return vcycle_legs_fused(levels, n, e_id, R_id, a, b, leg); }
 /* The same for the 27-point / fv2 / fv4 plugins, leg 2 only (smooth ... bottom solve ... smooth as one launch): every level of the chain is ONE
  * box whose vectors fit the LDS (kernels/stencil.hip: small_vtail_kernel).  `7 8`: the levels of 8^3, 4^3, 2^3 (and 1^3) cells. */
-/* OFF by default (HPGMG_SMALL_VTAIL=1 / hpgmg_set_small_vtail(1) turn it on; bit-identical, tested both ways).  Measured on MI355X, `7 8`
- * F-cycles with it on / off: fv4 7.93 / 7.79 ms, 27-point 4.18 / 3.92 ms, fv2 6.53 / 6.55 ms.  The launch of 8^3 + 4^3 + 2^3 levels takes
- * 191 us (fv4 GSRB; tools/exp_vtail_timeline.py): 4 x 22 us of smoothing (a half sweep is a 3.6 us chain of boundary entries, barrier,
- * stencil, barrier -- the same on 64 cells as on 512), 54 us of bottom solve, 43 us of image traffic; the ~15 launches it replaces are
- * mostly the same chains and their launch gaps overlap with the host's queue, so nothing is gained, and the 27-point plugin's one-launch
- * red + black box kernel is faster than two half sweeps here. */
+/* On by default except for the 27-point plugin with GSRB (HPGMG_SMALL_VTAIL=0 / 1, hpgmg_set_small_vtail(); bit-identical, tested both ways).
+ * Measured on MI355X, `7 8` F-cycles with it on / off: fv4 GSRB 7.72 / 7.77 ms, fv4 Chebyshev 8.13 / 8.23, fv2 GSRB 6.35 / 6.56, fv2 Chebyshev
+ * 6.65 / 6.91, 27-point Chebyshev 4.72 / 4.84 -- and 27-point GSRB 4.04 / 3.94: that plugin's one-launch red + black box kernel beats two half
+ * sweeps of the generic form.  The first version (1024 lanes) was slower everywhere: the bottom solve's 240 registers per lane spilled into
+ * scratch memory under the 128-register cap; with 512 lanes the launch of 8^3 + 4^3 + 2^3 levels takes 169 instead of 191 us (fv4 GSRB;
+ * tools/exp_vtail_timeline.py): 4 x 24 us of smoothing, 28 us of bottom solve, the rest image traffic and interpolation. */
 static long long small_vtails = 0;
 static int small_vtail_on = -1;
 long long hpgmg_small_vtails(void) { return small_vtails; }
-void hpgmg_set_small_vtail(int on) { small_vtail_on = on ? 1 : 0; }
+void hpgmg_set_small_vtail(int on) { small_vtail_on = (on == 2) ? 2 : (on ? 1 : 0); }      /* 0 off, 1 on for every plugin, 2 the default (not for 27-point GSRB) */
 static int small_vtail_fused(level_type **levels, int n, int e_id, int R_id, double a, double b) {
   hpgmg_config cfg;
   hpgmg_hip_small_tail_args T;
   int l;
-  if (small_vtail_on < 0) { const char *e = getenv("HPGMG_SMALL_VTAIL"); small_vtail_on = (e && e[0] == '1'); }
+  if (small_vtail_on < 0) { const char *e = getenv("HPGMG_SMALL_VTAIL"); small_vtail_on = (e && e[0] == '0') ? 0 : ((e && e[0] == '1') ? 1 : 2); }   /* 2: the default */
   if (!small_vtail_on) return 0;
   hpgmg_get_config(&cfg);
+  if (small_vtail_on == 2 && cfg.op == HPGMG_OP_27PT && cfg.smoother == HPGMG_SMOOTH_GSRB) return 0;
   const int sweeps = hpgmg_smooth_sweeps();
   if (n < 2 || n > HPGMG_HIP_SMALL_TAIL_MAX_LEVELS || sweeps < 1 || sweeps > 8 || (sweeps & 1) || graphs == 1) return 0;      /* (captured segments: the argument block's upload is not capturable) */
   if (cfg.smoother != HPGMG_SMOOTH_CHEBY && cfg.smoother != HPGMG_SMOOTH_GSRB && cfg.smoother != HPGMG_SMOOTH_JACOBI) return 0;

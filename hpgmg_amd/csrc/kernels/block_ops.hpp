@@ -246,22 +246,23 @@ __device__ __forceinline__ void bc_v4_cell(CP x, WP xw, int ijk, int s0, int s1,
 // A corner (NN = 3) formed by a whole WAVE: the 64 reads and 84 extrapolations of bc_v4_cell<3> are a chain of ~5000 cycles for one lane -- on
 // a level of one box, where a wave has an entry to itself, the eight corners set the time of the boundary stage.  Lane l takes row
 // (m, p) = (l & 3, (l >> 2) & 3) of the 4 x 4 rows along i, the rows of a p are gathered by shuffles, then the four p: the same
-// expression tree, evaluated by every lane (lanes >= 16 mirror the first sixteen), written by lane 0.
+// expression tree.  A corner is the work of SIXTEEN lanes: each aligned group of 16 lanes of the wave forms the corner its lanes were given (all
+// four groups the same one when the wave has a single entry: the duplicate stores write the same values), the group's first lane writes.
 template <typename CP, typename WP>
 __device__ __forceinline__ void bc_v4_corner_wave(CP x, WP xw, int ijk, int di, int dj, int dk, int lane) {
-  const int m = lane & 3, p = (lane >> 2) & 3;
+  const int m = lane & 3, p = (lane >> 2) & 3, base = lane & 48;
   const int o = ijk + (m + 1) * dj + (p + 1) * dk;
   const double a1 = x[o + di], a2 = x[o + 2 * di], a3 = x[o + 3 * di], a4 = x[o + 4 * di];
   const double njv = v4_near(a1, a2, a3, a4), fjv = v4_far(a1, a2, a3, a4);
   double nj[4], fj[4];
 #pragma unroll
-  for (int q = 0; q < 4; q++) { nj[q] = __shfl(njv, (p << 2) | q, 64); fj[q] = __shfl(fjv, (p << 2) | q, 64); }
+  for (int q = 0; q < 4; q++) { nj[q] = __shfl(njv, base | (p << 2) | q, 64); fj[q] = __shfl(fjv, base | (p << 2) | q, 64); }
   const double nnv = v4_near(nj[0], nj[1], nj[2], nj[3]), nfv = v4_far(nj[0], nj[1], nj[2], nj[3]);
   const double fnv = v4_near(fj[0], fj[1], fj[2], fj[3]), ffv = v4_far(fj[0], fj[1], fj[2], fj[3]);
   double nn[4], nf[4], fn[4], ff[4];
 #pragma unroll
-  for (int q = 0; q < 4; q++) { nn[q] = __shfl(nnv, q << 2, 64); nf[q] = __shfl(nfv, q << 2, 64); fn[q] = __shfl(fnv, q << 2, 64); ff[q] = __shfl(ffv, q << 2, 64); }
-  if (lane == 0) {
+  for (int q = 0; q < 4; q++) { nn[q] = __shfl(nnv, base | (q << 2), 64); nf[q] = __shfl(nfv, base | (q << 2), 64); fn[q] = __shfl(fnv, base | (q << 2), 64); ff[q] = __shfl(ffv, base | (q << 2), 64); }
+  if ((lane & 15) == 0) {
     xw[ijk]                = v4_near(nn[0], nn[1], nn[2], nn[3]);
     xw[ijk - dk]           = v4_far(nn[0], nn[1], nn[2], nn[3]);
     xw[ijk - dj]           = v4_near(nf[0], nf[1], nf[2], nf[3]);
@@ -306,6 +307,28 @@ __device__ __forceinline__ void bc_v4_entry_at(P x, const hpgmg_hip_level &L, co
     if (g.nn == 1)      bc_v4_cell<1>(x, x, ijk + g.pos[0], g.step[0], 0, 0);
     else if (g.nn == 2) bc_v4_cell<2>(x, x, ijk + g.pos[0] + g.pos[1], g.step[0], g.step[1], 0);
     else                bc_v4_cell<3>(x, x, ijk + g.pos[0] + g.pos[1] + g.pos[2], g.step[0], g.step[1], g.step[2]);
+  }
+}
+// The same entry for a GROUP of lanes of a wave -- 16 for a corner, 32 for an edge (eight cells at a time), 64 for a face -- so that the entries of a
+// box (8 corners, 12 edges, 6 faces) fill the lanes of a workgroup instead of taking a wave each: `sub` = the lane's index in its group, `lane`
+// = its index in the wave (groups are aligned to their size).
+template <typename P>
+__device__ __forceinline__ void bc_v4_entry_packed(P x, const hpgmg_hip_level &L, const blockCopy_type &e, int sub, int lane) {
+  const BcGeom g = bc_geometry(L, e);
+  const int n = g.len[0] * g.len[1];
+  if (g.nn == 3) {
+    bc_v4_corner_wave(x, x, g.lo[0] * g.fstride[0] + g.lo[1] * g.fstride[1] + g.pos[0] + g.pos[1] + g.pos[2], g.step[0], g.step[1], g.step[2], lane);
+  } else if (g.nn == 2) {
+    for (int tb = 0; tb < n; tb += 8) {
+      const int tc = tb + (sub >> 2), t = min(tc, n - 1);
+      const int ijk = (t % g.len[0] + g.lo[0]) * g.fstride[0] + (t / g.len[0] + g.lo[1]) * g.fstride[1];
+      bc_v4_edge_wave(x, x, ijk + g.pos[0] + g.pos[1], g.step[0], g.step[1], lane, tc < n);
+    }
+  } else {
+    for (int t = sub; t < n; t += 64) {
+      const int r = t % g.len[0], q = t / g.len[0];
+      bc_v4_cell<1>(x, x, (r + g.lo[0]) * g.fstride[0] + (q + g.lo[1]) * g.fstride[1] + g.pos[0], g.step[0], 0, 0);
+    }
   }
 }
 __device__ __forceinline__ void bc_v4_entry(const hpgmg_hip_level &L, int id, const blockCopy_type &e, int tid, int nth) {

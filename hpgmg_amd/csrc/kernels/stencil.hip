@@ -700,12 +700,35 @@ typedef double __attribute__((address_space(1))) *gbl_dptr;
 typedef const double __attribute__((address_space(1))) *gbl_cdptr;
 // the eight words of a boundary entry that the entry routines read (subtype, dim, read.box / i / j / k), kept in LDS by the single-workgroup
 // kernels: read from the level's list in memory, the descriptor was a round trip per entry and half sweep
-__device__ __forceinline__ void lds_bc_words_fill(int *words, const blockCopy_type *list, int n, int tid, int nth) {
-  for (int t = tid; t < 8 * n; t += nth) {
-    const blockCopy_type &g = list[t >> 3];
-    const int f = t & 7;
-    words[t] = f == 0 ? g.subtype : f == 1 ? g.dim.i : f == 2 ? g.dim.j : f == 3 ? g.dim.k : f == 4 ? g.read.box : f == 5 ? g.read.i : f == 6 ? g.read.j : g.read.k;
+// (n <= 32.)  The entries are stored SORTED by kind -- corners, edges, faces; their order is immaterial, every entry reads the interior and writes
+// ghost cells of its own -- and words[256..258] hold the three counts: the packed dispatch of apply_BCs_v4 below hands out lanes by kind.
+constexpr int kBcWords = 32 * 8 + 4;
+__device__ __forceinline__ void lds_bc_words_fill(int *words, const blockCopy_type *list, int n, int tid, int nth, bool sorted) {
+  if (!sorted) {                                                  // every lane fetches a word (the sorted form is a wave's serial work: only where it pays)
+    for (int t = tid; t < 8 * n; t += nth) {
+      const blockCopy_type &g = list[t >> 3];
+      const int f = t & 7;
+      words[t] = f == 0 ? g.subtype : f == 1 ? g.dim.i : f == 2 ? g.dim.j : f == 3 ? g.dim.k : f == 4 ? g.read.box : f == 5 ? g.read.i : f == 6 ? g.read.j : g.read.k;
+    }
+    return;
   }
+  if (tid >= 64) return;                                          // the first wave: a lane per entry, the positions by ballot
+  const bool have = tid < n;
+  int w[8] = {0, 0, 0, 0, 0, 0, 0, 0}, nn = 0;
+  if (have) {
+    const blockCopy_type &g = list[tid];
+    w[0] = g.subtype; w[1] = g.dim.i; w[2] = g.dim.j; w[3] = g.dim.k; w[4] = g.read.box; w[5] = g.read.i; w[6] = g.read.j; w[7] = g.read.k;
+    nn = (w[0] % 3 != 1) + ((w[0] % 9) / 3 != 1) + (w[0] / 9 != 1);
+  }
+  const unsigned long long m3 = __ballot(have && nn == 3), m2 = __ballot(have && nn == 2), m1 = __ballot(have && nn < 2);
+  const unsigned long long below = (1ull << tid) - 1ull;
+  const int n3 = __popcll(m3), n2 = __popcll(m2);
+  const int pos = (nn == 3) ? __popcll(m3 & below) : (nn == 2) ? n3 + __popcll(m2 & below) : n3 + n2 + __popcll(m1 & below);
+  if (have) {
+#pragma unroll
+    for (int f = 0; f < 8; f++) words[8 * pos + f] = w[f];
+  }
+  if (tid == 0) { words[256] = n3; words[257] = n2; words[258] = __popcll(m1); }
 }
 __device__ __forceinline__ blockCopy_type lds_bc_entry(const int *words, int e) {
   const lds_iptr w = (lds_iptr)words + 8 * e;
@@ -759,7 +782,21 @@ __device__ __forceinline__ void small_level_run(const hpgmg_hip_level &L, const 
     SL_MARK();
     // apply_BCs(src)
     if (A.bc_kind && A.zero_first) { for (int e = wave; e < A.n_bc; e += nwaves) { const blockCopy_type en = entry(e); bc_zero_entry_at(vo(en.read.box, src), L, en, lane, 64); } __syncthreads(); }
-    for (int e = wave; e < A.n_bc; e += nwaves) {
+    bool packed = false;
+    if constexpr (RES) packed = (bc_words != nullptr && A.bc_kind == 4);
+    if (packed) {
+      // apply_BCs_v4 with the lanes handed out by kind: 16 per corner, 32 per edge, 64 per face -- the 26 entries of a box are 896 lanes of
+      // work, one round of a 1024-lane workgroup (two of a 512-lane one) instead of a wave per entry (two / four rounds)
+      const lds_iptr cnt = (lds_iptr)bc_words + 256;
+      const int n3 = cnt[0], n2 = cnt[1], n1 = cnt[2], lim3 = n3 * 16, lim2 = lim3 + n2 * 32, demand = lim2 + n1 * 64;
+      for (int g0 = 0; g0 < demand; g0 += (int)blockDim.x) {
+        const int g = g0 + tid;
+        if (g < lim3)        bc_v4_entry_packed(vo(0, src), L, lds_bc_entry(bc_words, g >> 4), g & 15, lane);
+        else if (g < lim2)   bc_v4_entry_packed(vo(0, src), L, lds_bc_entry(bc_words, n3 + ((g - lim3) >> 5)), (g - lim3) & 31, lane);
+        else if (g < demand) bc_v4_entry_packed(vo(0, src), L, lds_bc_entry(bc_words, n3 + n2 + ((g - lim2) >> 6)), (g - lim2) & 63, lane);
+      }
+    }
+    for (int e = wave; e < A.n_bc && !packed; e += nwaves) {
       const blockCopy_type en = entry(e);
       if (A.bc_kind == 1) bc_p1_entry_at(vo(en.read.box, src), L, en, lane, 64);
       else if (A.bc_kind == 2) bc_p2_entry_at(vo(en.read.box, src), L, en, lane, 64);
@@ -788,7 +825,9 @@ __device__ __forceinline__ void small_level_run(const hpgmg_hip_level &L, const 
         Ax = apply_op_27pt(m, c, p, A.a, A.b, A.h2inv);
       } else {
         auto none = vo(box, src); none = nullptr;
-        Ax = apply_op_direct<V, decltype(x), decltype(none), RES>(x, kHelm ? vo(box, al_id) : none, kVC ? vo(box, bi_id) : none, kVC ? vo(box, bj_id) : none, kVC ? vo(box, bk_id) : none,
+        // (not the batched form here: with 1024 lanes a lane has 128 registers, the batches then spill, and what the stencil phase gains the
+        // boundary phase loses to the reloads -- measured 1.44 + 1.9 us against 1.8 + 1.7 us per half sweep)
+        Ax = apply_op_direct<V, decltype(x), decltype(none), false>(x, kHelm ? vo(box, al_id) : none, kVC ? vo(box, bi_id) : none, kVC ? vo(box, bj_id) : none, kVC ? vo(box, bk_id) : none,
                                                                    ijk, jS, kS, A.a, A.b, A.h2inv);
       }
       if (A.mode == MODE_APPLY) { out[ijk] = Ax; continue; }
@@ -834,9 +873,9 @@ __global__ __launch_bounds__(1024) void small_level_kernel(const hpgmg_hip_level
   const size_t vol = (size_t)L.volume;
   lds_dptr img = (lds_dptr)small_lds;
   // the boundary entries of the box (26 at most) wait in LDS too: read from memory, the descriptor was a round trip per entry and half sweep
-  __shared__ int s_bc[32 * 8];
+  __shared__ int s_bc[kBcWords];
   const bool bc_in_lds = A.n_bc <= 32;
-  if (bc_in_lds) lds_bc_words_fill(s_bc, A.bc_list, A.n_bc, tid, (int)blockDim.x);
+  if (bc_in_lds) lds_bc_words_fill(s_bc, A.bc_list, A.n_bc, tid, (int)blockDim.x, A.bc_kind == 4);
 #pragma unroll
   for (int q = 0; q < kSmallSlots; q++) {
     if (slot_of[q] < 0) continue;
@@ -886,7 +925,7 @@ __device__ __forceinline__ void bottom_bicgstab_body(const hpgmg_hip_level &L, c
   constexpr bool kVC = (V != HPGMG_HIP_7PT_CC && !k27);
   constexpr bool kHelm = (V == HPGMG_HIP_7PT_VC_HELMHOLTZ || V == HPGMG_HIP_FV4_VC_HELMHOLTZ);
   extern __shared__ double bb_lds[];                               // images of the padded box (5 x L.volume doubles: v, alpha, beta_i/j/k), then the reduction scratch
-  __shared__ int s_bc[32 * 8];
+  __shared__ int s_bc[kBcWords];
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = (int)blockDim.x >> 6;
   const int dim = L.dim, jS = L.jStride, kS = L.kStride, total = dim * dim * dim;
   const bool active = tid < total;
@@ -899,7 +938,7 @@ __device__ __forceinline__ void bottom_bicgstab_body(const hpgmg_hip_level &L, c
   const lds_dptr alpha = img + (vol + first), bi = img + (2 * vol + first), bj = img + (3 * vol + first), bk = img + (4 * vol + first);
   const lds_dptr scr = img + 5 * vol;
   const bool bc_in_lds = A.n_bc <= 32;
-  if (bc_in_lds) lds_bc_words_fill(s_bc, A.bc_list, A.n_bc, tid, (int)blockDim.x);
+  if (bc_in_lds) lds_bc_words_fill(s_bc, A.bc_list, A.n_bc, tid, (int)blockDim.x, false);
   {
     const gbl_cdptr g_al = (gbl_cdptr)(L.box_base[0] + (size_t)VECTOR_ALPHA * vol), g_bi = (gbl_cdptr)(L.box_base[0] + (size_t)VECTOR_BETA_I * vol);
     const gbl_cdptr g_bj = (gbl_cdptr)(L.box_base[0] + (size_t)VECTOR_BETA_J * vol), g_bk = (gbl_cdptr)(L.box_base[0] + (size_t)VECTOR_BETA_K * vol);
@@ -1039,7 +1078,7 @@ __global__ __launch_bounds__(512) void bottom_bicgstab_kernel(const hpgmg_hip_le
 // of the per-operator kernels (restrict_entry / interp_tensor_kernel in blocks.hip), so the result is bit-identical to the launches it
 // replaces (the coarse correction's ghost zone in MEMORY is left as it was: every reader fills it first).
 template <int V>
-__global__ __launch_bounds__(1024) void small_vtail_kernel(const hpgmg_hip_small_tail_args *__restrict__ Tp, unsigned long long *tl) {
+__global__ __launch_bounds__(512) void small_vtail_kernel(const hpgmg_hip_small_tail_args *__restrict__ Tp, unsigned long long *tl) {
 #ifdef HPGMG_EXP_TIMELINE
   int tl_n = 0;
 #define VT_MARK() do { if (tl && threadIdx.x == 0 && tl_n < 250) tl[tl_n++] = __builtin_amdgcn_s_memrealtime(); } while (0)
@@ -1055,7 +1094,7 @@ __global__ __launch_bounds__(1024) void small_vtail_kernel(const hpgmg_hip_small
   constexpr bool kHelm = (V == HPGMG_HIP_7PT_VC_HELMHOLTZ || V == HPGMG_HIP_FV4_VC_HELMHOLTZ);
   constexpr int ORDER = k27 ? 2 : 3;                               // interpolation_p2.c (27-point) / interpolation_v2.c (fv2, fv4)
   extern __shared__ double vt_lds[];
-  __shared__ int s_bc[32 * 8];
+  __shared__ int s_bc[kBcWords];
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = (int)blockDim.x >> 6, nth = (int)blockDim.x;
   const int n = Tp->n, e_id = Tp->e_id, R_id = Tp->R_id;
   const lds_dptr img = (lds_dptr)vt_lds;
@@ -1099,7 +1138,7 @@ __global__ __launch_bounds__(1024) void small_vtail_kernel(const hpgmg_hip_small
       const lds_dptr stage = img + 8 * vol;
       const gbl_cdptr gx = (gbl_cdptr)(Lc.box_base[0] + (size_t)e_id * cvol);
       for (int t = tid; t < cvol; t += nth) stage[t] = gx[t];
-      lds_bc_words_fill(s_bc, lc.ibc_list, lc.n_ibc, tid, nth);
+      lds_bc_words_fill(s_bc, lc.ibc_list, lc.n_ibc, tid, nth, false);
       __syncthreads();
       const lds_dptr cx = stage + cfirst;
       if (lc.ibc_kind && lc.ibc_zero_first) { for (int e = wave; e < lc.n_ibc; e += nwaves) bc_zero_entry_at(cx, Lc, lds_bc_entry(s_bc, e), lane, 64); __syncthreads(); }
@@ -1132,7 +1171,7 @@ __global__ __launch_bounds__(1024) void small_vtail_kernel(const hpgmg_hip_small
         xf[ijk] = 1.0 * xf[ijk] + add;
       }
     }
-    lds_bc_words_fill(s_bc, lv.bc_list, lv.n_bc, tid, nth);
+    lds_bc_words_fill(s_bc, lv.bc_list, lv.n_bc, tid, nth, lv.bc_kind == 4);
     __syncthreads();
     VT_MARK();
     // ---- smooth(level l), and on the way down residual(level l, VECTOR_TEMP, e, R)
@@ -1904,7 +1943,7 @@ int hpgmg_hip_small_vtail(const hpgmg_hip_small_tail_args *T, int variant) {
 #endif
 #define VTAIL_CASE(VAR) { \
     static bool once = false; if (!once) { HPGMG_CHECK(hipFuncSetAttribute((const void *)small_vtail_kernel<VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); once = true; } \
-    hipLaunchKernelGGL((small_vtail_kernel<VAR>), dim3(1), dim3(1024), lds, g_stream, (const hpgmg_hip_small_tail_args *)dev_copy[slot], tl); }
+    hipLaunchKernelGGL((small_vtail_kernel<VAR>), dim3(1), dim3(512), lds, g_stream, (const hpgmg_hip_small_tail_args *)dev_copy[slot], tl); }
   switch (variant) {
     case HPGMG_HIP_27PT_CC:          VTAIL_CASE(HPGMG_HIP_27PT_CC) break;
     case HPGMG_HIP_FV4_VC_HELMHOLTZ: VTAIL_CASE(HPGMG_HIP_FV4_VC_HELMHOLTZ) break;

@@ -81,7 +81,7 @@ int         hpgmg_transport_init_rccl(const char *id128, int rank, int size);
 void        hpgmg_transport_finalize_rccl(void);
 void        hpgmg_set_sync_timers(int on);
 void        hpgmg_set_small_fused(int mode);   /* 27-pt / fv2 / fv4: 2 (default) smooth() on levels of ONE box as one single-workgroup launch on an image of the box in LDS; 0 off; 1 (EXPERIMENTS=1 builds) every level of <= 4096 cells, out of global memory (measured slower) */
-void        hpgmg_set_small_vtail(int on);     /* 27-pt / fv2 / fv4: 1 = the rest of a V-cycle below a level of one box as ONE launch (default 0: measured no faster; bit-identical) */
+void        hpgmg_set_small_vtail(int on);     /* 27-pt / fv2 / fv4: the rest of a V-cycle below a level of one box as ONE launch: 2 (default) on except for 27-pt GSRB, 1 on, 0 off; bit-identical */
 void        hpgmg_set_fused_tail(int on);      /* 0: no single-launch V-/F-cycle tails (7-pt: kernels/tail.hip; tests) */
 long long   hpgmg_pair_remote_smooths(void);   /* smooth() calls executed as sweep pairs with faces owned by other ranks (tests) */
 /* level->timers after settling pending device timers: smooth, residual, apply_op, blas1, boundary_conditions, restriction_total,

@@ -155,9 +155,9 @@ def test_small_levels_as_single_launches_give_the_same_norms(hip, variant, args,
 @pytest.mark.parametrize("variant,args", [("fv4-gsrb", "4 8"), ("27pt-gsrb", "4 8"), ("27pt-cheby", "5 8"), ("fv2-cheby", "4 8"), ("fv4-cheby", "4 8")])
 def test_vcycle_tail_below_a_one_box_level_is_one_launch_and_gives_the_same_norms(hip, variant, args):
     """27-point / fv2 / fv4: the rest of a V-cycle below a level of ONE box (smooth, residual, restriction, zero_vector per level, the BiCGStab
-    bottom solve, interpolation_vcycle and smooth per level upwards) can run as one single-workgroup launch (small_vtail_kernel; opt-in,
-    hpgmg_set_small_vtail(1): it measured no faster than the launches it replaces).  When on it must be taken (launch counter), and the norms are
-    the golden ones with it and without it."""
+    bottom solve, interpolation_vcycle and smooth per level upwards) runs as one single-workgroup launch (small_vtail_kernel; the default except for 27-point GSRB,
+    hpgmg_set_small_vtail(1) = on for every plugin).  When on it must be taken (launch counter), and the norms are the golden ones with it and
+    without it."""
     import ctypes
     import hpgmg_amd as H
     gold = GOLD[f"{variant} {args}"]
@@ -177,7 +177,7 @@ def test_vcycle_tail_below_a_one_box_level_is_one_launch_and_gives_the_same_norm
             taken = k.hpgmg_hip_small_vtail_launch_count() - before
             assert (taken > 0) if on else (taken == 0), (on, taken)
     finally:
-        hip.lib.hpgmg_set_small_vtail(0)
+        hip.lib.hpgmg_set_small_vtail(2)
 
 
 def test_reference_three_launch_mode_gives_the_same_norms(hip):
