@@ -729,10 +729,11 @@ static int small_vtail_fused(level_type **levels, int n, int e_id, int R_id, dou
   small_vtails++;
   return 1;
 }
-static int fused_tail_enabled = -1;
+static int fused_tail_enabled = -1, fused_bottom_enabled = -1;
 void hpgmg_set_fused_tail(int on) { fused_tail_enabled = on ? 1 : 0; }      /* tests: 0 = every operator of the small levels as its own launch(es) */
+void hpgmg_set_fused_bottom(int on) { fused_bottom_enabled = on ? 1 : 0; }  /* tests: 0 = the bottom solve driven from the host (host/solvers.c BiCGStab through the operators) */
 static int vcycle_legs_fused(level_type **levels, int n, int e_id, int R_id, double a, double b, int leg) {
-  static int bottom_enabled = -1;
+#define bottom_enabled fused_bottom_enabled
 #define enabled fused_tail_enabled
   hpgmg_config cfg;
   const hpgmg_hip_level *dev[8];
@@ -792,6 +793,7 @@ static int vcycle_legs_fused(level_type **levels, int n, int e_id, int R_id, dou
   TOCK();
   return 1;
 #undef enabled
+#undef bottom_enabled
 }
 
 /* every box of the level is local and local box b sits at lexicographic position b (what the kernels that address
@@ -1248,9 +1250,9 @@ static int small_level_try(level_type *L, int mode, int x_id, int rhs_id, int re
  * bottom_bicgstab_kernel; the 7-point plugin's bottom solve lives in its tail kernel).  Driven from the host, an iteration is ~25 launches and
  * ~6 host round trips on a level of 8 cells.  HPGMG_FUSED_BOTTOM=0 keeps the host-driven solver. */
 int hpgmg_bottom_solve_fused(level_type *L, int e_id, int R_id, double a, double b, double want) {
-  static int on = -1;
   hpgmg_config cfg;
-  if (on < 0) { const char *e = getenv("HPGMG_FUSED_BOTTOM"); on = !(e && e[0] == '0'); }
+  if (fused_bottom_enabled < 0) { const char *e = getenv("HPGMG_FUSED_BOTTOM"); fused_bottom_enabled = !(e && e[0] == '0'); }
+  const int on = fused_bottom_enabled;
   hpgmg_get_config(&cfg);
   if (!on || cfg.op == HPGMG_OP_7PT || !L->active || L->num_my_boxes != 1 || L->boxes_in.i * L->boxes_in.j * L->boxes_in.k != 1) return 0;
   if (L->boundary_condition.type == BC_PERIODIC || L->must_subtract_mean == 1) return 0;
@@ -1435,7 +1437,7 @@ static void do_residual(level_type *L, int res_id, int x_id, int rhs_id, double 
   if (small_level_try(L, 3, x_id, rhs_id, res_id, a, b)) return;
   STENCIL_WITH_GHOSTS(L, x_id, res_id, residual, hpgmg_hip_residual(&backend_of(L)->dev, variant(), res_id, x_id, rhs_id, a, b, 1.0 / (L->h * L->h)));
 }
-void apply_op(level_type *L, int Ax_id, int x_id, double a, double b) {               /* apply_op.c:9-48 */
+static void do_apply_op(level_type *L, int Ax_id, int x_id, double a, double b) {               /* apply_op.c:9-48 */
   if (small_level_try(L, 4, x_id, -1, Ax_id, a, b)) return;
   STENCIL_WITH_GHOSTS(L, x_id, Ax_id, apply_op, hpgmg_hip_residual(&backend_of(L)->dev, variant(), Ax_id, x_id, -1, a, b, 1.0 / (L->h * L->h)));
 }
@@ -1611,8 +1613,8 @@ void interpolation_fcycle(level_type *Lf, int id_f, double prescale, level_type 
 #define BLAS1(call) do { TICK(L, blas1, "BLAS1"); HIP_OK(call); TOCK(); } while (0)
 static void do_zero_vector(level_type *L, int id) { BLAS1(hpgmg_hip_fill(&backend_of(L)->dev, id, 0.0)); }
 void init_vector(level_type *L, int id, double s) { BLAS1(hpgmg_hip_fill(&backend_of(L)->dev, id, s)); }
-void add_vectors(level_type *L, int c, double sa, int a, double sb, int b) { BLAS1(hpgmg_hip_axpby(&backend_of(L)->dev, c, sa, a, sb, b)); }
-void mul_vectors(level_type *L, int c, double s, int a, int b) { BLAS1(hpgmg_hip_mul(&backend_of(L)->dev, c, s, a, b)); }
+static void do_add_vectors(level_type *L, int c, double sa, int a, double sb, int b) { BLAS1(hpgmg_hip_axpby(&backend_of(L)->dev, c, sa, a, sb, b)); }
+static void do_mul_vectors(level_type *L, int c, double s, int a, int b) { BLAS1(hpgmg_hip_mul(&backend_of(L)->dev, c, s, a, b)); }
 void invert_vector(level_type *L, int c, double s, int a) { BLAS1(hpgmg_hip_invert(&backend_of(L)->dev, c, s, a)); }
 static void do_scale_vector(level_type *L, int c, double s, int a) { BLAS1(hpgmg_hip_scale(&backend_of(L)->dev, c, s, a)); }
 void shift_vector(level_type *L, int c, int a, double shift) { BLAS1(hpgmg_hip_shift(&backend_of(L)->dev, c, a, shift)); }
@@ -1627,7 +1629,7 @@ static double allreduce_scalar(level_type *L, double v, int op) {
   }
   return v;
 }
-double dot(level_type *L, int a, int b) { double v; BLAS1(hpgmg_hip_dot(&backend_of(L)->dev, a, b, &v)); return allreduce_scalar(L, v, HPGMG_REDUCE_SUM); }
+static double do_dot(level_type *L, int a, int b) { double v; BLAS1(hpgmg_hip_dot(&backend_of(L)->dev, a, b, &v)); return allreduce_scalar(L, v, HPGMG_REDUCE_SUM); }
 static double do_norm(level_type *L, int a) {
   double v; BLAS1(hpgmg_hip_norm_max(&backend_of(L)->dev, a, &v)); return allreduce_scalar(L, v, HPGMG_REDUCE_MAX); }
 double mean(level_type *L, int a) {
@@ -1635,7 +1637,7 @@ double mean(level_type *L, int a) {
   v = allreduce_scalar(L, v, HPGMG_REDUCE_SUM);
   return v / (double)((double)L->dim.i * (double)L->dim.j * (double)L->dim.k);
 }
-double error(level_type *L, int a, int b) { add_vectors(L, VECTOR_TEMP, 1.0, a, -1.0, b); return do_norm(L, VECTOR_TEMP); }
+double error(level_type *L, int a, int b) { add_vectors(L, VECTOR_TEMP, 1.0, a, -1.0, b); return norm(L, VECTOR_TEMP); }
 
 /* ---------------------------------------------------------------- problem.p6.c:79-135
  * Analytic coefficients and right-hand side are evaluated on the host with the
@@ -1814,8 +1816,8 @@ void rebuild_operator(level_type *L, level_type *from, double a, double b) {
  *   - interpolation_vcycle + smooth of a large level: the interpolation folded into the first sweep pair;
  *   - residual(res) followed by norm(res): one pass (norm() asks the queue).
  * Every fused form used here leaves exactly the vectors the separate operators leave (VECTOR_TEMP included).  HPGMG_LAZY=0 turns the queue off. */
-enum { LZ_SMOOTH = 1, LZ_RESIDUAL, LZ_RESTRICT, LZ_ZERO, LZ_INTERP, LZ_SCALE };
-enum { LZ_NONE = 0, LZ_DOWN, LZ_UP, LZ_RN, LZ_SR };      /* RN: a lone residual() waiting to see whether norm() of its result follows (mg.c:1321-1323);
+enum { LZ_SMOOTH = 1, LZ_RESIDUAL, LZ_RESTRICT, LZ_ZERO, LZ_INTERP, LZ_SCALE, LZ_ADD, LZ_MUL, LZ_APPLY };
+enum { LZ_NONE = 0, LZ_DOWN, LZ_UP, LZ_RN, LZ_SR, LZ_SMALL };      /* RN: a lone residual() waiting to see whether norm() of its result follows (mg.c:1321-1323);
                                                           * SR: scale_vector(R, 1.0, F) waiting for restriction(coarse R <- R): how FMGSolve starts (mg.c:1266-1277) */
 typedef struct { int op; level_type *L, *L2; int i0, i1, i2; double a, b; } lazy_op;
 #define LZ_MAX 80
@@ -1834,6 +1836,55 @@ __attribute__((destructor)) static void lazy_report(void) {
 static int lazy_enabled(void) {
   if (lazy_on < 0) { const char *e = getenv("HPGMG_LAZY"); lazy_on = !(e && e[0] == '0'); }
   return lazy_on && !lz_busy;
+}
+/* LZ_SMALL: BLAS-1 calls, apply_op and residual on a level of ONE box of side <= 8 wait for the dot product or norm that follows them -- what a
+ * host-driven Krylov solver on the bottom level issues between two scalars it needs (the reference's solvers/bicgstab.c, "Route B"; host/solvers.c
+ * with HPGMG_FUSED_BOTTOM=0) -- and go out with it as ONE launch (kernels/stencil.hip: small_ops_kernel): 6 launches per BiCGStab iteration
+ * instead of ~18.  HPGMG_SMALL_OPS=0 / hpgmg_set_small_ops(0) turn it off. */
+static int small_ops_on = -1;
+static long long small_ops_groups = 0;
+void hpgmg_set_small_ops(int on) { lazy_flush(); small_ops_on = on ? 1 : 0; }
+long long hpgmg_small_ops_groups(void) { return small_ops_groups; }
+static int small_ops_kind(int op) { return op == LZ_ADD ? 1 : op == LZ_MUL ? 2 : op == LZ_SCALE ? 3 : op == LZ_APPLY ? 4 : op == LZ_RESIDUAL ? 5 : 0; }
+static int small_ops_level_ok(level_type *L) {
+  if (small_ops_on < 0) { const char *e = getenv("HPGMG_SMALL_OPS"); small_ops_on = !(e && e[0] == '0'); }
+  if (!small_ops_on || !L->active || L->num_my_boxes != 1 || L->boxes_in.i * L->boxes_in.j * L->boxes_in.k != 1 || L->box_dim > 8) return 0;
+  if (L->boundary_condition.type != BC_DIRICHLET) return 0;
+  communicator_type *C = &L->exchange_ghosts[stencil_get_shape()];
+  if (C->num_sends + C->num_recvs > 0 || C->num_blocks[0] || C->num_blocks[1] || C->num_blocks[2]) return 0;      /* one box: nothing to exchange */
+  { const hpgmg_transport *T = hpgmg_get_transport(); if (T && T->size > 1) { hpgmg_level_ext *X = hpgmg_level_ext_get(L); if (X->num_active_ranks > 1) return 0; } }
+  return L->boundary_condition.num_blocks[stencil_get_shape()] <= 64;
+}
+/* issue the queue (mode LZ_SMALL) as one launch; value_kind 6 / 7: ending in dot(va, vb) / norm(va), whose value is returned */
+static double small_ops_issue(int value_kind, int va, int vb) {
+  level_type *L = lz[0].L;
+  backend_t *B = backend_of(L);
+  hpgmg_config cfg;
+  int kinds[16], c[16], a[16], b[16], q, n = 0, bc_kind, zero_first = 0;
+  double sa[16], sb[16], op_a = 0.0, op_b = 0.0, v = 0.0;
+  hpgmg_get_config(&cfg);
+  for (q = 0; q < lz_n; q++, n++) {
+    const lazy_op *o = &lz[q];
+    kinds[n] = small_ops_kind(o->op); c[n] = o->i0; a[n] = o->i1; b[n] = o->i2; sa[n] = o->a; sb[n] = o->b;
+    if (o->op == LZ_APPLY || o->op == LZ_RESIDUAL) { op_a = o->a; op_b = o->b; sa[n] = sb[n] = 0.0; }
+  }
+  if (value_kind) { kinds[n] = value_kind; c[n] = 0; a[n] = va; b[n] = vb; sa[n] = sb[n] = 0.0; n++; }
+  lz_n = 0; lz_mode = LZ_NONE;
+  const int shape = stencil_get_shape(), n_bc = L->boundary_condition.num_blocks[shape];
+  if (cfg.op == HPGMG_OP_7PT) bc_kind = 1;                                                              /* apply_BCs, as the operators themselves choose */
+  else if (cfg.op == HPGMG_OP_27PT) bc_kind = (L->box_dim < 2) ? 1 : 2;
+  else if (cfg.op == HPGMG_OP_FV2 || L->box_dim < 4) { bc_kind = (L->box_dim < 2) ? 1 : 3; zero_first = (bc_kind == 3 && L->box_ghosts > 1); }
+  else { bc_kind = 4; zero_first = (L->box_ghosts > 2); }
+  lz_busy = 1;
+  {
+    TICK(L, blas1, "queued small-level operators, one launch");
+    HIP_OK(hpgmg_hip_small_ops(&B->dev, variant(), n, kinds, c, a, b, sa, sb, n_bc ? mirror(L, L->boundary_condition.blocks[shape], n_bc) : NULL, n_bc, bc_kind, zero_first,
+                               op_a, op_b, 1.0 / (L->h * L->h), value_kind ? &v : NULL));
+    TOCK();
+  }
+  lz_busy = 0;
+  small_ops_groups++;
+  return v;
 }
 static void lazy_run_one(const lazy_op *o) {
   switch (o->op) {
@@ -1888,6 +1939,10 @@ static void lazy_flush(void) {
       else { lazy_run_one(ip); lazy_run_one(sm); }
     }
     q = 2 * units;
+  } else if (mode == LZ_SMALL) {                          /* no dot product / norm came: the queue as one launch all the same */
+    lz_busy = 0;
+    (void)small_ops_issue(0, 0, 0);
+    return;
   } else if (mode == LZ_SR && n == 2) {                   /* R = 1.0 * F, then its restriction: one pass over F (the norm the kernel also forms is not asked for) */
     if (norm_scale_restrict_fused(lz[0].L, lz[0].i1, lz[0].i0, lz[1].L, NULL)) { lazy_fused_units++; q = 2; }
   }
@@ -1900,8 +1955,19 @@ static int lazy_push(int op, level_type *L, level_type *L2, int i0, int i1, int 
   if (!lazy_enabled() || lz_n == LZ_MAX || lz_busy) return 0;      /* busy: the queue is being issued; what its operators call runs at once */
   hpgmg_config cfg;
   hpgmg_get_config(&cfg);
-  if (cfg.op != HPGMG_OP_7PT) return 0;                   /* the fused forms used by the queue are the 7-point plugin's */
   int ok = 0;
+  if (small_ops_kind(op) && (lz_n == 0 || lz_mode == LZ_SMALL) && small_ops_level_ok(L)) {     /* any plugin */
+    if (lz_n == 0) { ok = 1; lz_mode = LZ_SMALL; }
+    else if (L == lz[0].L && lz_n < hpgmg_hip_small_ops_max() - 1) {
+      ok = 1;
+      if (op == LZ_APPLY || op == LZ_RESIDUAL) { int q; for (q = 0; q < lz_n; q++) if ((lz[q].op == LZ_APPLY || lz[q].op == LZ_RESIDUAL) && (lz[q].a != a || lz[q].b != b)) ok = 0; }   /* one (a, b) per launch */
+    }
+    if (ok) { lazy_op *o = &lz[lz_n++]; o->op = op; o->L = L; o->L2 = L2; o->i0 = i0; o->i1 = i1; o->i2 = i2; o->a = a; o->b = b; return 1; }
+    return 0;
+  }
+  if (lz_mode == LZ_SMALL) return 0;
+  if (cfg.op != HPGMG_OP_7PT) return 0;                   /* the other fused forms used by the queue are the 7-point plugin's */
+  if (op == LZ_ADD || op == LZ_MUL || op == LZ_APPLY) return 0;
   if (lz_n == 0) {
     if (op == LZ_SMOOTH) { ok = 1; lz_mode = LZ_DOWN; }
     else if (op == LZ_INTERP && a == 1.0 && i0 == i1) { ok = 1; lz_mode = LZ_UP; }
@@ -1955,6 +2021,28 @@ void zero_vector(level_type *L, int id) {
   lazy_flush();
   do_zero_vector(L, id);
 }
+void add_vectors(level_type *L, int c, double sa, int a, double sb, int b) {
+  if (lazy_push(LZ_ADD, L, NULL, c, a, b, sa, sb)) return;
+  lazy_flush();
+  if (lazy_push(LZ_ADD, L, NULL, c, a, b, sa, sb)) return;
+  do_add_vectors(L, c, sa, a, sb, b);
+}
+void mul_vectors(level_type *L, int c, double s, int a, int b) {
+  if (lazy_push(LZ_MUL, L, NULL, c, a, b, s, 0.0)) return;
+  lazy_flush();
+  if (lazy_push(LZ_MUL, L, NULL, c, a, b, s, 0.0)) return;
+  do_mul_vectors(L, c, s, a, b);
+}
+void apply_op(level_type *L, int Ax_id, int x_id, double a, double b) {
+  if (lazy_push(LZ_APPLY, L, NULL, Ax_id, x_id, 0, a, b)) return;
+  lazy_flush();
+  if (lazy_push(LZ_APPLY, L, NULL, Ax_id, x_id, 0, a, b)) return;
+  do_apply_op(L, Ax_id, x_id, a, b);
+}
+double dot(level_type *L, int a, int b) {
+  if (lz_mode == LZ_SMALL && lz_n > 0 && !lz_busy && lz[0].L == L) return allreduce_scalar(L, small_ops_issue(6, a, b), HPGMG_REDUCE_SUM);
+  return do_dot(L, a, b);
+}
 void interpolation_vcycle(level_type *Lf, int id_f, double prescale, level_type *Lc, int id_c) {
   if (lazy_push(LZ_INTERP, Lf, Lc, id_f, id_c, 0, prescale, 0.0)) return;
   lazy_flush();
@@ -1962,6 +2050,7 @@ void interpolation_vcycle(level_type *Lf, int id_f, double prescale, level_type 
   do_interpolation_vcycle(Lf, id_f, prescale, Lc, id_c);
 }
 double norm(level_type *L, int a) {
+  if (lz_mode == LZ_SMALL && lz_n > 0 && !lz_busy && lz[0].L == L) return allreduce_scalar(L, small_ops_issue(7, a, 0), HPGMG_REDUCE_MAX);
   if (lz_mode == LZ_RN && lz_n == 1 && !lz_busy && lz[0].L == L && lz[0].i0 == a) {       /* residual(a, ...) then norm(a): one pass, the residual stored as usual */
     const lazy_op o = lz[0];
     double v = 0.0;

@@ -130,12 +130,7 @@ __device__ __forceinline__ double absmax_rows(const hpgmg_hip_level &L, int id) 
 // Scalar results go straight to a pinned host slot {value, sequence}: the last lane stores the value,
 // fences at system scope, then stores the launch's sequence number; the host polls the sequence
 // instead of paying a full stream synchronisation (reductions gate the host-driven BiCGStab).
-struct ResultSlot { double value; unsigned long long seq; };
-__device__ __forceinline__ void publish(ResultSlot *slot, double v, unsigned long long seq) {
-  slot->value = v;
-  __threadfence_system();
-  __hip_atomic_store(&slot->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
+// (ResultSlot and publish(): common.hpp)
 
 // small levels: one workgroup walks every row and stores the final max itself
 __global__ __launch_bounds__(256) void absmax_small_kernel(const hpgmg_hip_level L, int id, ResultSlot *result, unsigned long long seq) {
@@ -336,6 +331,9 @@ static int fetch_result(double *out) {
   return 0;
 }
 
+// for kernels of other translation units that publish a scalar themselves (stencil.hip: small_ops_kernel)
+ResultSlot *reduction_slot_next(unsigned long long *seq_out) { if (ensure_scratch(1)) return nullptr; *seq_out = ++g_seq; return g_result_dev; }
+int reduction_fetch(double *out) { return fetch_result(out); }
 // for kernels of other translation units that leave one partial maximum per workgroup (stencil.hip: residual + norm fused)
 double *reduction_scratch(int n) { return ensure_scratch(n) ? nullptr : g_scratch; }
 int finish_max_reduction(int n, double init, double *out) {

@@ -16,6 +16,11 @@ int  record_error(hipError_t e, const char *where);
 
 double *reduction_scratch(int n);                       // blas1.hip: device scratch of >= n doubles for per-workgroup partial results
 int finish_max_reduction(int n, double init, double *out);   // blas1.hip: fold n partial maxima, publish to the host, wait for the value
+// Scalar results go straight to a pinned host slot {value, sequence}: the last lane stores the value, fences at system scope, then stores the
+// launch's sequence number; the host polls the sequence instead of paying a full stream synchronisation (blas1.hip owns the slot).
+struct ResultSlot { double value; unsigned long long seq; };
+ResultSlot *reduction_slot_next(unsigned long long *seq_out);   // blas1.hip: the slot and the sequence number the next publishing launch must use
+int reduction_fetch(double *out);                               // blas1.hip: wait for that launch's value
 
 constexpr int kXcds = 8;              // MI355X: 8 XCDs, workgroup b is placed on XCD b % 8
 
@@ -45,6 +50,11 @@ typedef const char __attribute__((address_space(1))) *gcbytes;
 typedef char __attribute__((address_space(1))) *gbytes;
 __device__ __forceinline__ double gld(gcptr base, unsigned byte_off) { return *(gcptr)((gcbytes)base + byte_off); }
 __device__ __forceinline__ void gst(gptr base, unsigned byte_off, double v) { *(gptr)((gbytes)base + byte_off) = v; }
+__device__ __forceinline__ void publish(ResultSlot *slot, double v, unsigned long long seq) {
+  slot->value = v;
+  __threadfence_system();
+  __hip_atomic_store(&slot->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 // pointer to cell (0,0,0) (first interior cell) of vector `id` in box `box`
 __device__ __forceinline__ double *vec_origin(const hpgmg_hip_level &L, int box, int id) {
   return L.box_base[box] + (size_t)id * (size_t)L.volume + (size_t)L.ghosts * (size_t)(1 + L.jStride + L.kStride);

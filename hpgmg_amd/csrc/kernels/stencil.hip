@@ -1068,6 +1068,80 @@ template <int V>
 __global__ __launch_bounds__(512) void bottom_bicgstab_kernel(const hpgmg_hip_level L, const BottomArgs A) { bottom_bicgstab_body<V>(L, A); }
 
 // ---------------------------------------------------------------------------------------------
+// A queue of BLAS-1 / operator calls on a level of ONE small box (<= 512 cells) as one single-workgroup launch, ending -- if the caller
+// wants a value -- in the dot product or norm that made the host ask.  This is what a host-driven Krylov solver does on the bottom level
+// (the reference's solvers/bicgstab.c through operators.h, "Route B"): per iteration ~18 launches of an 8-cell kernel and 6 scalars fetched;
+// the plugin postpones the void operators and issues them together with the value-returning one: 6 launches.  Every operation is the
+// expression of its own kernel: misc.c add_vectors c = sa*a + sb*b, mul_vectors c = s*a*b, scale_vector c = s*a (blas1.hip
+// elementwise_kernel); apply_op / residual = apply_BCs on the operand with the level's own boundary entries, then the stencil; dot = the
+// products summed k, j, i (one dim x 8 x 8 tile: the order of misc.c:261-269 and tile_sum_kernel); norm = max |a|.
+enum { SO_ADD = 1, SO_MUL, SO_SCALE, SO_APPLY, SO_RESIDUAL, SO_DOT, SO_NORM };
+constexpr int kSmallOpsMax = 12;
+struct SmallOp { int kind, c, a, b; double sa, sb; };
+struct SmallOpsArgs {
+  int n, bc_kind, zero_first, n_bc;
+  const blockCopy_type *bc_list;
+  double a, b, h2inv;
+  ResultSlot *result; unsigned long long seq;
+  SmallOp op[kSmallOpsMax];
+};
+template <int V>
+__global__ __launch_bounds__(512) void small_ops_kernel(const hpgmg_hip_level L, const SmallOpsArgs A) {
+  constexpr bool k27 = (V == HPGMG_HIP_27PT_CC);
+  constexpr bool kVC = (V != HPGMG_HIP_7PT_CC && !k27);
+  constexpr bool kHelm = (V == HPGMG_HIP_7PT_VC_HELMHOLTZ || V == HPGMG_HIP_FV4_VC_HELMHOLTZ);
+  __shared__ double part[512 + 8];
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = (int)blockDim.x >> 6;
+  const int dim = L.dim, jS = L.jStride, kS = L.kStride, total = dim * dim * dim;
+  const bool active = tid < total;
+  const int ci = tid % dim, cj = (tid / dim) % dim, ck = tid / (dim * dim), ijk = ci + cj * jS + ck * kS;
+  for (int q = 0; q < A.n; q++) {
+    const int kind = A.op[q].kind, idc = A.op[q].c, ida = A.op[q].a, idb = A.op[q].b;
+    const double sa = A.op[q].sa, sb = A.op[q].sb;
+    if (kind == SO_ADD)        { if (active) vec_origin(L, 0, idc)[ijk] = sa * vec_origin(L, 0, ida)[ijk] + sb * vec_origin(L, 0, idb)[ijk]; }
+    else if (kind == SO_MUL)   { if (active) vec_origin(L, 0, idc)[ijk] = sa * vec_origin(L, 0, ida)[ijk] * vec_origin(L, 0, idb)[ijk]; }
+    else if (kind == SO_SCALE) { if (active) vec_origin(L, 0, idc)[ijk] = sa * vec_origin(L, 0, ida)[ijk]; }
+    else if (kind == SO_APPLY || kind == SO_RESIDUAL) {
+      // exchange_boundary: one box, nothing to copy; apply_BCs on the operand, then the stencil (operators.*.c apply_op / residual)
+      if (A.bc_kind && A.zero_first) { for (int e = wave; e < A.n_bc; e += nwaves) bc_zero_entry(L, ida, A.bc_list[e], lane, 64); __syncthreads(); }
+      for (int e = wave; e < A.n_bc; e += nwaves) {
+        if (A.bc_kind == 1) bc_p1_entry(L, ida, A.bc_list[e], lane, 64);
+        else if (A.bc_kind == 2) bc_p2_entry(L, ida, A.bc_list[e], lane, 64);
+        else if (A.bc_kind == 3) bc_v2_entry(L, ida, A.bc_list[e], lane, 64);
+        else if (A.bc_kind == 4) bc_v4_entry(L, ida, A.bc_list[e], lane, 64);
+      }
+      __syncthreads();
+      if (active) {
+        const double *x = vec_origin(L, 0, ida);
+        double Ax;
+        if (k27) {
+          const plane9 m = load_plane(x + (ijk - kS), jS), c = load_plane(x + ijk, jS), pp = load_plane(x + (ijk + kS), jS);
+          Ax = apply_op_27pt(m, c, pp, A.a, A.b, A.h2inv);
+        } else {
+          const double *none = nullptr;
+          Ax = apply_op_direct<V>(x, kHelm ? (const double *)vec_origin(L, 0, VECTOR_ALPHA) : none, kVC ? (const double *)vec_origin(L, 0, VECTOR_BETA_I) : none,
+                                  kVC ? (const double *)vec_origin(L, 0, VECTOR_BETA_J) : none, kVC ? (const double *)vec_origin(L, 0, VECTOR_BETA_K) : none, ijk, jS, kS, A.a, A.b, A.h2inv);
+        }
+        vec_origin(L, 0, idc)[ijk] = (kind == SO_RESIDUAL) ? vec_origin(L, 0, idb)[ijk] - Ax : Ax;
+      }
+    } else if (kind == SO_DOT) {
+      if (active) part[tid] = vec_origin(L, 0, ida)[ijk] * vec_origin(L, 0, idb)[ijk];
+      __syncthreads();
+      if (tid == 0) { double acc = 0.0; for (int t = 0; t < total; t++) acc += part[t]; publish(A.result, 0.0 + acc, A.seq); }   // (one tile: its partial added to 0.0, as tile_sum_kernel does)
+    } else if (kind == SO_NORM) {
+      double m = 0.0;
+      if (active) { const double f = fabs(vec_origin(L, 0, ida)[ijk]); m = (f > m) ? f : m; }
+      for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_down(m, off, 64); m = (o > m) ? o : m; }
+      if (lane == 0) part[512 + wave] = m;
+      __syncthreads();
+      if (tid == 0) { for (int w = 1; w < nwaves; w++) m = (part[512 + w] > m) ? part[512 + w] : m; publish(A.result, m, A.seq); }
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // The rest of a V-cycle below a level of ONE box, 27-point / fv2 / fv4 plugins (mg.c:1133-1166), as one single-workgroup launch.  Driven
 // operator by operator a visit of such a level is 4 launches on the way down (smooth -- itself one launch, above --, the boundary fill and
 // the stencil of residual(), restriction + zero_vector) and 3 on the way up, ~5 us each for work of a microsecond.  Here the levels of
@@ -1900,6 +1974,44 @@ int hpgmg_hip_bottom_bicgstab(const hpgmg_hip_level *L, int variant, int x_id, i
   }
 #undef BOTTOM_CASE
   HPGMG_LAUNCH_CHECK("bottom_bicgstab_kernel");
+  return 0;
+}
+// A queue of BLAS-1 / operator calls on a level of one box of <= 512 cells as one launch (small_ops_kernel).  kinds: 1 add (c = sa*a + sb*b),
+// 2 mul (c = sa*a*b), 3 scale (c = sa*a), 4 apply_op (c = A a), 5 residual (c = b - A a), 6 dot (a, b), 7 norm (a); a value-returning
+// operation may only come last, its value goes to *value_out (the call then waits for it).
+static long long g_small_ops_launches = 0;
+long long hpgmg_hip_small_ops_launch_count(void) { return g_small_ops_launches; }
+int hpgmg_hip_small_ops_max(void) { return kSmallOpsMax; }
+int hpgmg_hip_small_ops(const hpgmg_hip_level *L, int variant, int n, const int *kinds, const int *c, const int *a, const int *b, const double *sa, const double *sb,
+                        const blockCopy_type *bc_list, int n_bc, int bc_kind, int zero_first, double op_a, double op_b, double h2inv, double *value_out) {
+  if (int e = hpgmg_hip_graph_flush()) return e;
+  if (n < 1 || n > kSmallOpsMax || L->num_boxes != 1 || L->dim > 8 || L->periodic) return record_error(hipErrorInvalidValue, "small_ops: one Dirichlet box of side <= 8, 1..12 operations");
+  SmallOpsArgs A = {};
+  A.n = n; A.bc_list = bc_list; A.n_bc = bc_list ? n_bc : 0; A.bc_kind = A.n_bc > 0 ? bc_kind : 0; A.zero_first = zero_first; A.a = op_a; A.b = op_b; A.h2inv = h2inv;
+  bool wants = false;
+  for (int q = 0; q < n; q++) {
+    if (kinds[q] < SO_ADD || kinds[q] > SO_NORM || ((kinds[q] == SO_DOT || kinds[q] == SO_NORM) && q != n - 1)) return record_error(hipErrorInvalidValue, "small_ops: operation list");
+    A.op[q].kind = kinds[q]; A.op[q].c = c[q]; A.op[q].a = a[q]; A.op[q].b = b[q]; A.op[q].sa = sa[q]; A.op[q].sb = sb[q];
+    wants = (kinds[q] == SO_DOT || kinds[q] == SO_NORM);
+  }
+  if (wants != (value_out != nullptr)) return record_error(hipErrorInvalidValue, "small_ops: value_out must be given exactly when the list ends in a dot product or norm");
+  if (wants) { A.result = reduction_slot_next(&A.seq); if (!A.result) return record_error(hipErrorOutOfMemory, "small_ops: result slot"); }
+  const int cells = L->dim * L->dim * L->dim;
+  const int threads = cells > 256 ? 512 : (A.n_bc > 4 ? 512 : 64);          // the boundary entries are a wave's work each
+#define SMALL_OPS_CASE(VAR) hipLaunchKernelGGL((small_ops_kernel<VAR>), dim3(1), dim3(threads), 0, g_stream, *L, A);
+  switch (variant) {
+    case HPGMG_HIP_27PT_CC:          SMALL_OPS_CASE(HPGMG_HIP_27PT_CC) break;
+    case HPGMG_HIP_FV4_VC_HELMHOLTZ: SMALL_OPS_CASE(HPGMG_HIP_FV4_VC_HELMHOLTZ) break;
+    case HPGMG_HIP_FV4_VC_POISSON:   SMALL_OPS_CASE(HPGMG_HIP_FV4_VC_POISSON) break;
+    case HPGMG_HIP_7PT_VC_HELMHOLTZ: SMALL_OPS_CASE(HPGMG_HIP_7PT_VC_HELMHOLTZ) break;
+    case HPGMG_HIP_7PT_VC_POISSON:   SMALL_OPS_CASE(HPGMG_HIP_7PT_VC_POISSON) break;
+    case HPGMG_HIP_7PT_CC:           SMALL_OPS_CASE(HPGMG_HIP_7PT_CC) break;
+    default: return record_error(hipErrorInvalidValue, "small_ops: variant");
+  }
+#undef SMALL_OPS_CASE
+  g_small_ops_launches++;
+  HPGMG_LAUNCH_CHECK("small_ops_kernel");
+  if (wants) return reduction_fetch(value_out);
   return 0;
 }
 // V-cycle tail below a level of one box (small_vtail_kernel).  The argument block lives in device memory: it is the same for every visit of

@@ -180,6 +180,36 @@ def test_vcycle_tail_below_a_one_box_level_is_one_launch_and_gives_the_same_norm
         hip.lib.hpgmg_set_small_vtail(2)
 
 
+@pytest.mark.parametrize("variant,args", [("7pt-cheby", "4 8"), ("7pt-gsrb", "5 8"), ("fv4-gsrb", "4 8"), ("27pt-cheby", "5 8"), ("fv2-cheby", "4 8")])
+def test_host_driven_bottom_solve_through_the_small_operator_queue(hip, variant, args):
+    """The bottom solve driven from the host (hpgmg_set_fused_bottom(0): host/solvers.c BiCGStab calling mul_vectors, apply_op, dot, add_vectors,
+    norm ... as the reference's solvers/bicgstab.c does through operators.h).  On a level of one small box the void operators wait for the dot product
+    or norm that follows them and go out with it as ONE launch (small_ops_kernel): the queue must be used (group counter), and the norms are the golden
+    ones with it and with every operator a launch of its own (hpgmg_set_small_ops(0))."""
+    import ctypes
+    gold = GOLD[f"{variant} {args}"]
+    lib = hip.lib
+    lib.hpgmg_set_fused_bottom.argtypes = [ctypes.c_int]
+    lib.hpgmg_set_small_ops.argtypes = [ctypes.c_int]
+    lib.hpgmg_small_ops_groups.restype = ctypes.c_longlong
+    try:
+        lib.hpgmg_set_fused_bottom(0)
+        for on in (1, 0):
+            lib.hpgmg_set_small_ops(on)
+            hip.configure(**VARIANTS[variant])
+            before = lib.hpgmg_small_ops_groups()
+            s = hip.solver_cli(*map(int, args.split()))
+            assert [fmt(v) for v in s.three_sizes()] == gold["norms"]
+            err, order = s.richardson()
+            assert fmt(err) == gold["richardson_error"]
+            s.destroy()
+            groups = lib.hpgmg_small_ops_groups() - before
+            assert (groups > 0) if on else (groups == 0), (on, groups)
+    finally:
+        lib.hpgmg_set_fused_bottom(1)
+        lib.hpgmg_set_small_ops(1)
+
+
 def test_reference_three_launch_mode_gives_the_same_norms(hip):
     """HPGMG_GHOST_FREE=0 path (exchange_boundary + apply_BCs + stencil, as the reference sequences them)."""
     import ctypes
