@@ -258,6 +258,7 @@ static const blockCopy_type *mirror(level_type *owner, const blockCopy_type *hos
 }
 
 void hpgmg_level_release(level_type *L) {
+  lazy_flush();                                  /* postponed operators hold a pointer to their level */
   hpgmg_hip_graph_reset();                       /* cached graphs hold pointers into this level */
   hpgmg_hip_timer_forget(&L->timers, &L->timers + 1);   /* pending device timers point into this level */
   hpgmg_level_ext *X = hpgmg_level_ext_get(L);
@@ -1858,6 +1859,7 @@ static int small_ops_level_ok(level_type *L) {
 /* issue the queue (mode LZ_SMALL) as one launch; value_kind 6 / 7: ending in dot(va, vb) / norm(va), whose value is returned */
 static double small_ops_issue(int value_kind, int va, int vb) {
   level_type *L = lz[0].L;
+  lz_busy = 1;                                            /* from here on every device call (the first backend_of() of a level uploads its tables) runs at once */
   backend_t *B = backend_of(L);
   hpgmg_config cfg;
   int kinds[16], c[16], a[16], b[16], q, n = 0, bc_kind, zero_first = 0;
@@ -1875,7 +1877,6 @@ static double small_ops_issue(int value_kind, int va, int vb) {
   else if (cfg.op == HPGMG_OP_27PT) bc_kind = (L->box_dim < 2) ? 1 : 2;
   else if (cfg.op == HPGMG_OP_FV2 || L->box_dim < 4) { bc_kind = (L->box_dim < 2) ? 1 : 3; zero_first = (bc_kind == 3 && L->box_ghosts > 1); }
   else { bc_kind = 4; zero_first = (L->box_ghosts > 2); }
-  lz_busy = 1;
   {
     TICK(L, blas1, "queued small-level operators, one launch");
     HIP_OK(hpgmg_hip_small_ops(&B->dev, variant(), n, kinds, c, a, b, sa, sb, n_bc ? mirror(L, L->boundary_condition.blocks[shape], n_bc) : NULL, n_bc, bc_kind, zero_first,
@@ -1940,8 +1941,7 @@ static void lazy_flush(void) {
     }
     q = 2 * units;
   } else if (mode == LZ_SMALL) {                          /* no dot product / norm came: the queue as one launch all the same */
-    lz_busy = 0;
-    (void)small_ops_issue(0, 0, 0);
+    (void)small_ops_issue(0, 0, 0);                       /* (clears the queue and lz_busy) */
     return;
   } else if (mode == LZ_SR && n == 2) {                   /* R = 1.0 * F, then its restriction: one pass over F (the norm the kernel also forms is not asked for) */
     if (norm_scale_restrict_fused(lz[0].L, lz[0].i1, lz[0].i0, lz[1].L, NULL)) { lazy_fused_units++; q = 2; }
