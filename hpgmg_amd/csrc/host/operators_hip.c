@@ -1856,9 +1856,21 @@ static int small_ops_level_ok(level_type *L) {
   { const hpgmg_transport *T = hpgmg_get_transport(); if (T && T->size > 1) { hpgmg_level_ext *X = hpgmg_level_ext_get(L); if (X->num_active_ranks > 1) return 0; } }
   return L->boundary_condition.num_blocks[stencil_get_shape()] <= 64;
 }
-/* issue the queue (mode LZ_SMALL) as one launch; value_kind 6 / 7: ending in dot(va, vb) / norm(va), whose value is returned */
-static double small_ops_issue(int value_kind, int va, int vb) {
-  level_type *L = lz[0].L;
+/* A scalar the host asks for is often followed by another one with no operator in between (BiCGStab: dot(As, As) then dot(As, s); norm(r) then
+ * dot(r, r0)).  The queue remembers which request followed which, lets the launch that answers the first form the second as well, and answers
+ * the second from that value if it comes -- as long as nothing else was issued or queued in between.  (Forming a reduction nobody asks for
+ * changes no vector.) */
+typedef struct { level_type *L; int kind, a, b; } so_request;
+static so_request so_last, so_pred_key[8], so_pred_val[8], so_cached;
+static int so_npred = 0, so_last_fresh = 0, so_cache_valid = 0;
+static double so_cache_value = 0.0;
+static long long small_ops_answers = 0;
+long long hpgmg_small_ops_prefetched(void) { return small_ops_answers; }      /* scalars answered without a launch (tests) */
+static int so_same(const so_request *r, level_type *L, int kind, int a, int b) { return r->L == L && r->kind == kind && r->a == a && r->b == b; }
+static void so_touch(void) { so_last_fresh = 0; so_cache_valid = 0; }          /* something was issued or queued: what is remembered about the last scalar is stale */
+/* issue the queue (mode LZ_SMALL, or nothing) on level L as one launch; value_kind 6 / 7: ending in dot(va, vb) / norm(va), whose value is returned;
+ * p_kind: a second, predicted request formed by the same launch (its value to *p_out) */
+static double small_ops_issue(level_type *L, int value_kind, int va, int vb, int p_kind, int pa, int pb, double *p_out) {
   lz_busy = 1;                                            /* from here on every device call (the first backend_of() of a level uploads its tables) runs at once */
   backend_t *B = backend_of(L);
   hpgmg_config cfg;
@@ -1871,6 +1883,7 @@ static double small_ops_issue(int value_kind, int va, int vb) {
     if (o->op == LZ_APPLY || o->op == LZ_RESIDUAL) { op_a = o->a; op_b = o->b; sa[n] = sb[n] = 0.0; }
   }
   if (value_kind) { kinds[n] = value_kind; c[n] = 0; a[n] = va; b[n] = vb; sa[n] = sb[n] = 0.0; n++; }
+  if (value_kind && p_kind) { kinds[n] = p_kind; c[n] = 0; a[n] = pa; b[n] = pb; sa[n] = sb[n] = 0.0; n++; }
   lz_n = 0; lz_mode = LZ_NONE;
   const int shape = stencil_get_shape(), n_bc = L->boundary_condition.num_blocks[shape];
   if (cfg.op == HPGMG_OP_7PT) bc_kind = 1;                                                              /* apply_BCs, as the operators themselves choose */
@@ -1880,7 +1893,7 @@ static double small_ops_issue(int value_kind, int va, int vb) {
   {
     TICK(L, blas1, "queued small-level operators, one launch");
     HIP_OK(hpgmg_hip_small_ops(&B->dev, variant(), n, kinds, c, a, b, sa, sb, n_bc ? mirror(L, L->boundary_condition.blocks[shape], n_bc) : NULL, n_bc, bc_kind, zero_first,
-                               op_a, op_b, 1.0 / (L->h * L->h), value_kind ? &v : NULL));
+                               op_a, op_b, 1.0 / (L->h * L->h), value_kind ? &v : NULL, (value_kind && p_kind) ? p_out : NULL));
     TOCK();
   }
   lz_busy = 0;
@@ -1898,6 +1911,7 @@ static void lazy_run_one(const lazy_op *o) {
   }
 }
 static void lazy_flush(void) {
+  if (!lz_busy) so_touch();                               /* every device call of the plugin passes here first */
   if (lz_busy || lz_n == 0) return;
   lz_busy = 1;                                            /* the operators below issue device calls themselves */
   const int n = lz_n, mode = lz_mode;
@@ -1941,7 +1955,7 @@ static void lazy_flush(void) {
     }
     q = 2 * units;
   } else if (mode == LZ_SMALL) {                          /* no dot product / norm came: the queue as one launch all the same */
-    (void)small_ops_issue(0, 0, 0);                       /* (clears the queue and lz_busy) */
+    (void)small_ops_issue(lz[0].L, 0, 0, 0, 0, 0, 0, NULL);   /* (clears the queue and lz_busy) */
     return;
   } else if (mode == LZ_SR && n == 2) {                   /* R = 1.0 * F, then its restriction: one pass over F (the norm the kernel also forms is not asked for) */
     if (norm_scale_restrict_fused(lz[0].L, lz[0].i1, lz[0].i0, lz[1].L, NULL)) { lazy_fused_units++; q = 2; }
@@ -1962,7 +1976,7 @@ static int lazy_push(int op, level_type *L, level_type *L2, int i0, int i1, int 
       ok = 1;
       if (op == LZ_APPLY || op == LZ_RESIDUAL) { int q; for (q = 0; q < lz_n; q++) if ((lz[q].op == LZ_APPLY || lz[q].op == LZ_RESIDUAL) && (lz[q].a != a || lz[q].b != b)) ok = 0; }   /* one (a, b) per launch */
     }
-    if (ok) { lazy_op *o = &lz[lz_n++]; o->op = op; o->L = L; o->L2 = L2; o->i0 = i0; o->i1 = i1; o->i2 = i2; o->a = a; o->b = b; return 1; }
+    if (ok) { lazy_op *o = &lz[lz_n++]; o->op = op; o->L = L; o->L2 = L2; o->i0 = i0; o->i1 = i1; o->i2 = i2; o->a = a; o->b = b; so_touch(); return 1; }
     return 0;
   }
   if (lz_mode == LZ_SMALL) return 0;
@@ -2039,8 +2053,9 @@ void apply_op(level_type *L, int Ax_id, int x_id, double a, double b) {
   if (lazy_push(LZ_APPLY, L, NULL, Ax_id, x_id, 0, a, b)) return;
   do_apply_op(L, Ax_id, x_id, a, b);
 }
+static int small_value_request(level_type *L, int kind, int a, int b, double *out);
 double dot(level_type *L, int a, int b) {
-  if (lz_mode == LZ_SMALL && lz_n > 0 && !lz_busy && lz[0].L == L) return allreduce_scalar(L, small_ops_issue(6, a, b), HPGMG_REDUCE_SUM);
+  { double v; if (small_value_request(L, 6, a, b, &v)) return allreduce_scalar(L, v, HPGMG_REDUCE_SUM); }
   return do_dot(L, a, b);
 }
 void interpolation_vcycle(level_type *Lf, int id_f, double prescale, level_type *Lc, int id_c) {
@@ -2049,8 +2064,34 @@ void interpolation_vcycle(level_type *Lf, int id_f, double prescale, level_type 
   if (lazy_push(LZ_INTERP, Lf, Lc, id_f, id_c, 0, prescale, 0.0)) return;
   do_interpolation_vcycle(Lf, id_f, prescale, Lc, id_c);
 }
+/* dot() / norm() on a level of one small box: with what is queued for that level, with the request that usually follows, or from the value a
+ * previous launch formed in advance.  0: not such a level (the caller takes the ordinary path). */
+static int small_value_request(level_type *L, int kind, int a, int b, double *out) {
+  int q;
+  if (lz_busy || !lazy_enabled() || !small_ops_level_ok(L)) return 0;
+  if (lz_n > 0 && !(lz_mode == LZ_SMALL && lz[0].L == L)) return 0;                       /* something else is queued: the ordinary path flushes it */
+  const int was_fresh = so_last_fresh && so_last.L == L && lz_n == 0;
+  if (was_fresh) {                                         /* learn: this request follows the last one with nothing in between */
+    for (q = 0; q < so_npred; q++) if (so_same(&so_pred_key[q], so_last.L, so_last.kind, so_last.a, so_last.b)) break;
+    if (q == so_npred && so_npred < 8) so_npred++;
+    if (q < 8) { so_pred_key[q] = so_last; so_pred_val[q].L = L; so_pred_val[q].kind = kind; so_pred_val[q].a = a; so_pred_val[q].b = b; }
+  }
+  if (was_fresh && so_cache_valid && so_same(&so_cached, L, kind, a, b)) {
+    *out = so_cache_value; small_ops_answers++;
+    so_cache_valid = 0; so_last.L = L; so_last.kind = kind; so_last.a = a; so_last.b = b; so_last_fresh = 1;
+    return 1;
+  }
+  int p_kind = 0, pa = 0, pb = 0;
+  for (q = 0; q < so_npred; q++) if (so_same(&so_pred_key[q], L, kind, a, b)) { p_kind = so_pred_val[q].kind; pa = so_pred_val[q].a; pb = so_pred_val[q].b; }
+  if (p_kind && lz_n >= hpgmg_hip_small_ops_max() - 2) p_kind = 0;
+  double pv = 0.0;
+  *out = small_ops_issue(L, kind, a, b, p_kind, pa, pb, &pv);
+  so_last.L = L; so_last.kind = kind; so_last.a = a; so_last.b = b; so_last_fresh = 1;
+  so_cache_valid = p_kind != 0; so_cached.L = L; so_cached.kind = p_kind; so_cached.a = pa; so_cached.b = pb; so_cache_value = pv;
+  return 1;
+}
 double norm(level_type *L, int a) {
-  if (lz_mode == LZ_SMALL && lz_n > 0 && !lz_busy && lz[0].L == L) return allreduce_scalar(L, small_ops_issue(7, a, 0), HPGMG_REDUCE_MAX);
+  { double v; if (small_value_request(L, 7, a, 0, &v)) return allreduce_scalar(L, v, HPGMG_REDUCE_MAX); }
   if (lz_mode == LZ_RN && lz_n == 1 && !lz_busy && lz[0].L == L && lz[0].i0 == a) {       /* residual(a, ...) then norm(a): one pass, the residual stored as usual */
     const lazy_op o = lz[0];
     double v = 0.0;

@@ -334,6 +334,7 @@ static int fetch_result(double *out) {
 // for kernels of other translation units that publish a scalar themselves (stencil.hip: small_ops_kernel)
 ResultSlot *reduction_slot_next(unsigned long long *seq_out) { if (ensure_scratch(1)) return nullptr; *seq_out = ++g_seq; return g_result_dev; }
 int reduction_fetch(double *out) { return fetch_result(out); }
+double reduction_second_value(void) { return reinterpret_cast<volatile double *>(g_result_dev)[2]; }
 // for kernels of other translation units that leave one partial maximum per workgroup (stencil.hip: residual + norm fused)
 double *reduction_scratch(int n) { return ensure_scratch(n) ? nullptr : g_scratch; }
 int finish_max_reduction(int n, double init, double *out) {

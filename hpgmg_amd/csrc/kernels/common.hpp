@@ -21,6 +21,7 @@ int finish_max_reduction(int n, double init, double *out);   // blas1.hip: fold 
 struct ResultSlot { double value; unsigned long long seq; };
 ResultSlot *reduction_slot_next(unsigned long long *seq_out);   // blas1.hip: the slot and the sequence number the next publishing launch must use
 int reduction_fetch(double *out);                               // blas1.hip: wait for that launch's value
+double reduction_second_value(void);                            // blas1.hip: the word behind the slot's sequence number (a launch that publishes two values), after reduction_fetch()
 
 constexpr int kXcds = 8;              // MI355X: 8 XCDs, workgroup b is placed on XCD b % 8
 

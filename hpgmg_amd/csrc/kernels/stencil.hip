@@ -1085,6 +1085,13 @@ struct SmallOpsArgs {
   ResultSlot *result; unsigned long long seq;
   SmallOp op[kSmallOpsMax];
 };
+// a launch may end in TWO value-returning operations (the second one a guess of what the host asks next): value k goes to the k-th double of
+// the slot's payload (value, then the word behind the sequence number), the LAST operation of the list publishes the sequence number
+__device__ __forceinline__ void small_ops_value(ResultSlot *slot, int k, double v, bool last, unsigned long long seq) {
+  double *second = reinterpret_cast<double *>(slot) + 2;
+  if (k == 0) slot->value = v; else *second = v;
+  if (last) { __threadfence_system(); __hip_atomic_store(&slot->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+}
 template <int V>
 __global__ __launch_bounds__(512) void small_ops_kernel(const hpgmg_hip_level L, const SmallOpsArgs A) {
   constexpr bool k27 = (V == HPGMG_HIP_27PT_CC);
@@ -1095,6 +1102,7 @@ __global__ __launch_bounds__(512) void small_ops_kernel(const hpgmg_hip_level L,
   const int dim = L.dim, jS = L.jStride, kS = L.kStride, total = dim * dim * dim;
   const bool active = tid < total;
   const int ci = tid % dim, cj = (tid / dim) % dim, ck = tid / (dim * dim), ijk = ci + cj * jS + ck * kS;
+  int nvalues = 0;                                                 // value-returning operations so far: the first goes to result->value, the second behind it
   for (int q = 0; q < A.n; q++) {
     const int kind = A.op[q].kind, idc = A.op[q].c, ida = A.op[q].a, idb = A.op[q].b;
     const double sa = A.op[q].sa, sb = A.op[q].sb;
@@ -1127,14 +1135,16 @@ __global__ __launch_bounds__(512) void small_ops_kernel(const hpgmg_hip_level L,
     } else if (kind == SO_DOT) {
       if (active) part[tid] = vec_origin(L, 0, ida)[ijk] * vec_origin(L, 0, idb)[ijk];
       __syncthreads();
-      if (tid == 0) { double acc = 0.0; for (int t = 0; t < total; t++) acc += part[t]; publish(A.result, 0.0 + acc, A.seq); }   // (one tile: its partial added to 0.0, as tile_sum_kernel does)
+      if (tid == 0) { double acc = 0.0; for (int t = 0; t < total; t++) acc += part[t]; small_ops_value(A.result, nvalues, 0.0 + acc, q == A.n - 1, A.seq); }   // (one tile: its partial added to 0.0, as tile_sum_kernel does)
+      nvalues++;
     } else if (kind == SO_NORM) {
       double m = 0.0;
       if (active) { const double f = fabs(vec_origin(L, 0, ida)[ijk]); m = (f > m) ? f : m; }
       for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_down(m, off, 64); m = (o > m) ? o : m; }
       if (lane == 0) part[512 + wave] = m;
       __syncthreads();
-      if (tid == 0) { for (int w = 1; w < nwaves; w++) m = (part[512 + w] > m) ? part[512 + w] : m; publish(A.result, m, A.seq); }
+      if (tid == 0) { for (int w = 1; w < nwaves; w++) m = (part[512 + w] > m) ? part[512 + w] : m; small_ops_value(A.result, nvalues, m, q == A.n - 1, A.seq); }
+      nvalues++;
     }
     __threadfence_block();
     __syncthreads();
@@ -1983,18 +1993,21 @@ static long long g_small_ops_launches = 0;
 long long hpgmg_hip_small_ops_launch_count(void) { return g_small_ops_launches; }
 int hpgmg_hip_small_ops_max(void) { return kSmallOpsMax; }
 int hpgmg_hip_small_ops(const hpgmg_hip_level *L, int variant, int n, const int *kinds, const int *c, const int *a, const int *b, const double *sa, const double *sb,
-                        const blockCopy_type *bc_list, int n_bc, int bc_kind, int zero_first, double op_a, double op_b, double h2inv, double *value_out) {
+                        const blockCopy_type *bc_list, int n_bc, int bc_kind, int zero_first, double op_a, double op_b, double h2inv, double *value_out, double *value2_out) {
   if (int e = hpgmg_hip_graph_flush()) return e;
   if (n < 1 || n > kSmallOpsMax || L->num_boxes != 1 || L->dim > 8 || L->periodic) return record_error(hipErrorInvalidValue, "small_ops: one Dirichlet box of side <= 8, 1..12 operations");
   SmallOpsArgs A = {};
   A.n = n; A.bc_list = bc_list; A.n_bc = bc_list ? n_bc : 0; A.bc_kind = A.n_bc > 0 ? bc_kind : 0; A.zero_first = zero_first; A.a = op_a; A.b = op_b; A.h2inv = h2inv;
-  bool wants = false;
+  int nvalues = 0;
   for (int q = 0; q < n; q++) {
-    if (kinds[q] < SO_ADD || kinds[q] > SO_NORM || ((kinds[q] == SO_DOT || kinds[q] == SO_NORM) && q != n - 1)) return record_error(hipErrorInvalidValue, "small_ops: operation list");
+    const bool is_value = (kinds[q] == SO_DOT || kinds[q] == SO_NORM);
+    if (kinds[q] < SO_ADD || kinds[q] > SO_NORM || (is_value && q < n - 2) || (is_value && q == n - 2 && !(kinds[n - 1] == SO_DOT || kinds[n - 1] == SO_NORM)))
+      return record_error(hipErrorInvalidValue, "small_ops: operation list (value-returning operations only as the last one or two entries)");
     A.op[q].kind = kinds[q]; A.op[q].c = c[q]; A.op[q].a = a[q]; A.op[q].b = b[q]; A.op[q].sa = sa[q]; A.op[q].sb = sb[q];
-    wants = (kinds[q] == SO_DOT || kinds[q] == SO_NORM);
+    nvalues += is_value ? 1 : 0;
   }
-  if (wants != (value_out != nullptr)) return record_error(hipErrorInvalidValue, "small_ops: value_out must be given exactly when the list ends in a dot product or norm");
+  const bool wants = nvalues > 0;
+  if ((nvalues >= 1) != (value_out != nullptr) || (nvalues == 2) != (value2_out != nullptr)) return record_error(hipErrorInvalidValue, "small_ops: one output pointer per value-returning operation");
   if (wants) { A.result = reduction_slot_next(&A.seq); if (!A.result) return record_error(hipErrorOutOfMemory, "small_ops: result slot"); }
   const int cells = L->dim * L->dim * L->dim;
   const int threads = cells > 256 ? 512 : (A.n_bc > 4 ? 512 : 64);          // the boundary entries are a wave's work each
@@ -2011,7 +2024,7 @@ int hpgmg_hip_small_ops(const hpgmg_hip_level *L, int variant, int n, const int 
 #undef SMALL_OPS_CASE
   g_small_ops_launches++;
   HPGMG_LAUNCH_CHECK("small_ops_kernel");
-  if (wants) return reduction_fetch(value_out);
+  if (wants) { if (int e = reduction_fetch(value_out)) return e; if (value2_out) *value2_out = reduction_second_value(); }
   return 0;
 }
 // V-cycle tail below a level of one box (small_vtail_kernel).  The argument block lives in device memory: it is the same for every visit of

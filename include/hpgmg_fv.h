@@ -84,6 +84,7 @@ void        hpgmg_set_small_fused(int mode);   /* 27-pt / fv2 / fv4: 2 (default)
 void        hpgmg_set_small_vtail(int on);     /* 27-pt / fv2 / fv4: the rest of a V-cycle below a level of one box as ONE launch: 2 (default) on except for 27-pt GSRB, 1 on, 0 off; bit-identical */
 void        hpgmg_set_small_ops(int on);       /* 1 (default): BLAS-1 calls / apply_op / residual on a level of one small box wait for the dot product or norm that follows and go out with it as one launch (host-driven Krylov solvers); 0: a launch each */
 long long   hpgmg_small_ops_groups(void);      /* such launches so far (tests) */
+long long   hpgmg_small_ops_prefetched(void);  /* scalars answered from a value the previous launch formed in advance (tests) */
 void        hpgmg_set_fused_bottom(int on);    /* 0: the bottom solve driven from the host (BiCGStab of host/solvers.c through the operators; tests) */
 void        hpgmg_set_fused_tail(int on);      /* 0: no single-launch V-/F-cycle tails (7-pt: kernels/tail.hip; tests) */
 long long   hpgmg_pair_remote_smooths(void);   /* smooth() calls executed as sweep pairs with faces owned by other ranks (tests) */

@@ -150,11 +150,11 @@ int hpgmg_hip_bottom_bicgstab(const hpgmg_hip_level *L, int variant, int x_id, i
 /* A queue of BLAS-1 / operator calls on a level of ONE box of side <= 8 (Dirichlet) as one single-workgroup launch: what a host-driven Krylov
  * solver issues between two scalars it needs (solvers/bicgstab.c through operators.h).  kinds[q]: 1 add_vectors c = sa*a + sb*b, 2 mul_vectors
  * c = sa*a*b, 3 scale_vector c = sa*a, 4 apply_op c = A a, 5 residual c = b - A a (operators' a, b, h2inv; boundary list / kind / zero_first as for
- * hpgmg_hip_small_level_op), 6 dot(a, b), 7 norm(a) -- the last two only as the last entry, their value goes to *value_out (non-NULL exactly
- * then; the call waits for it).  At most hpgmg_hip_small_ops_max() entries.  Same expressions and summation order as the per-operator kernels. */
+ * hpgmg_hip_small_level_op), 6 dot(a, b), 7 norm(a) -- the last two only as the last entry or the last TWO entries (the second: a value the caller expects to be asked for
+ * next), their values go to *value_out / *value2_out (non-NULL exactly then; the call waits for them).  At most hpgmg_hip_small_ops_max() entries.  Same expressions and summation order as the per-operator kernels. */
 int hpgmg_hip_small_ops_max(void);
 int hpgmg_hip_small_ops(const hpgmg_hip_level *L, int variant, int n, const int *kinds, const int *c, const int *a, const int *b, const double *sa, const double *sb,
-                        const blockCopy_type *bc_list, int n_bc, int bc_kind, int zero_first, double op_a, double op_b, double h2inv, double *value_out);
+                        const blockCopy_type *bc_list, int n_bc, int bc_kind, int zero_first, double op_a, double op_b, double h2inv, double *value_out, double *value2_out);
 long long hpgmg_hip_small_ops_launch_count(void);   /* launches so far (tests) */
 #define HPGMG_HIP_SMALL_TAIL_MAX_LEVELS 4
 typedef struct {

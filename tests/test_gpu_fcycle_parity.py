@@ -192,12 +192,13 @@ def test_host_driven_bottom_solve_through_the_small_operator_queue(hip, variant,
     lib.hpgmg_set_fused_bottom.argtypes = [ctypes.c_int]
     lib.hpgmg_set_small_ops.argtypes = [ctypes.c_int]
     lib.hpgmg_small_ops_groups.restype = ctypes.c_longlong
+    lib.hpgmg_small_ops_prefetched.restype = ctypes.c_longlong
     try:
         lib.hpgmg_set_fused_bottom(0)
         for on in (1, 0):
             lib.hpgmg_set_small_ops(on)
             hip.configure(**VARIANTS[variant])
-            before = lib.hpgmg_small_ops_groups()
+            before, answered = lib.hpgmg_small_ops_groups(), lib.hpgmg_small_ops_prefetched()
             s = hip.solver_cli(*map(int, args.split()))
             assert [fmt(v) for v in s.three_sizes()] == gold["norms"]
             err, order = s.richardson()
@@ -205,6 +206,10 @@ def test_host_driven_bottom_solve_through_the_small_operator_queue(hip, variant,
             s.destroy()
             groups = lib.hpgmg_small_ops_groups() - before
             assert (groups > 0) if on else (groups == 0), (on, groups)
+            # dot(As, As) is followed by dot(As, s), norm(r) by dot(r, r0) with no operator in between: the second scalar of each pair comes from the
+            # launch that answered the first
+            answered = lib.hpgmg_small_ops_prefetched() - answered
+            assert (answered > 0) if on else (answered == 0), (on, answered)
     finally:
         lib.hpgmg_set_fused_bottom(1)
         lib.hpgmg_set_small_ops(1)
