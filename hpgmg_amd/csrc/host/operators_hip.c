@@ -138,6 +138,7 @@ typedef struct {
   struct { const blockCopy_type *host; int n; blockCopy_type *dev; } lists[MAX_LISTS];
   int num_lists;
   hpgmg_hip_bc_entry *d_bc[STENCIL_MAX_SHAPES]; int n_bc[STENCIL_MAX_SHAPES];   /* boundary-condition blocks with their geometry worked out */
+  blockCopy_type *h_bc_by_box[STENCIL_MAX_SHAPES]; int *d_bc_start[STENCIL_MAX_SHAPES];   /* boundary blocks sorted by box + the range of each box (fv4 box kernel) */
   int *d_fv4_special; int n_fv4_special;       /* fv4 red + black: cells on internal box faces next to a domain wall (box, i, j, k); n < 0: not built */
   hpgmg_hip_bc_entry *d_bc_k; int n_bc_k, bc_k_local;      /* the blocks of the stencil's shape whose domain normal has a k component (fv4 red + black pre-pass); n_bc_k < 0: not built */
   int bc_sources_local[STENCIL_MAX_SHAPES];    /* 1: every entry reads cells of local boxes' interiors only (no exchange needed before the conditions) */
@@ -269,6 +270,7 @@ void hpgmg_level_release(level_type *L) {
   for (s = 0; s < STENCIL_MAX_SHAPES; s++) if (B->d_bc[s]) hpgmg_hip_free(B->d_bc[s]);
   if (B->d_bc_k) hpgmg_hip_free(B->d_bc_k);
   if (B->d_fv4_special) hpgmg_hip_free(B->d_fv4_special);
+  for (s = 0; s < STENCIL_MAX_SHAPES; s++) { if (B->d_bc_start[s]) hpgmg_hip_free(B->d_bc_start[s]); free(B->h_bc_by_box[s]); }
   if (B->d_box_base) hpgmg_hip_free(B->d_box_base);
   if (B->d_box_low) hpgmg_hip_free(B->d_box_low);
   if (B->d_box_nbr) hpgmg_hip_free(B->d_box_nbr);
@@ -1422,6 +1424,34 @@ static void do_smooth(level_type *L, int x_id, int rhs_id, double a, double b) {
       }
     }
     if (smooth_fv4_rb(L, x_id, rhs_id, a, b, sweeps)) return;
+    /* fv4 on a level of small boxes (4^3 ... 16^3, all local): a half sweep as ONE launch -- x outside a box read where it lives, the boundary
+     * conditions of the result applied by the same launch (kernels/stencil.hip: fv4_box_gsrb_kernel) -- instead of two */
+    if (cfg.op == HPGMG_OP_FV4 && oop && !(sweeps & 1) && ghost_free_mode() && B->all_faces_local && L->box_dim >= 4 && x_id != VECTOR_TEMP && rhs_id != VECTOR_TEMP &&
+        L->boundary_condition.type == BC_DIRICHLET && hpgmg_hip_smooth_gsrb_fv4_box_supported(&B->dev, v)) {
+      const int shape = stencil_get_shape(), n_bc = L->boundary_condition.num_blocks[shape];
+      if (!B->d_bc_start[shape]) {
+        int *start = (int *)calloc((size_t)L->num_my_boxes + 1, sizeof(int)), q, bx, m = 0;
+        B->h_bc_by_box[shape] = (blockCopy_type *)malloc((size_t)(n_bc > 0 ? n_bc : 1) * sizeof(blockCopy_type));
+        for (bx = 0; bx < L->num_my_boxes; bx++) {
+          start[bx] = m;
+          for (q = 0; q < n_bc; q++) if (L->boundary_condition.blocks[shape][q].read.box == bx) B->h_bc_by_box[shape][m++] = L->boundary_condition.blocks[shape][q];
+        }
+        start[L->num_my_boxes] = m;
+        B->d_bc_start[shape] = (int *)hpgmg_hip_malloc(((size_t)L->num_my_boxes + 1) * sizeof(int));
+        if (!B->d_bc_start[shape] || m != n_bc) { fprintf(stderr, "hpgmg: boundary blocks by box: allocation failed or a block without a box\n"); abort(); }
+        HIP_OK(hpgmg_hip_memcpy_h2d(B->d_bc_start[shape], start, ((size_t)L->num_my_boxes + 1) * sizeof(int)));
+        free(start);
+      }
+      const blockCopy_type *by_box = n_bc ? mirror(L, B->h_bc_by_box[shape], n_bc) : NULL;
+      if (!exchange_and_bcs_one_launch(L, x_id, shape, 4, 0)) apply_BCs(L, x_id, shape);      /* the domain-boundary ghost cells the first half sweep reads */
+      for (s = 0; s < sweeps; s++) {
+        const int src = (s & 1) ? VECTOR_TEMP : x_id, dst = (s & 1) ? x_id : VECTOR_TEMP;
+        TICK(L, smooth, "smooth (fv4 GSRB half sweep, small boxes: one launch)");
+        HIP_OK(hpgmg_hip_smooth_gsrb_fv4_box(&B->dev, v, src, dst, rhs_id, a, b, h2inv, s, by_box, B->d_bc_start[shape]));
+        TOCK();
+      }
+      return;
+    }
     for (s = 0; s < sweeps; s++) {
       const int src = (oop && (s & 1)) ? VECTOR_TEMP : x_id, dst = oop ? ((s & 1) ? x_id : VECTOR_TEMP) : x_id;
       STENCIL_WITH_GHOSTS(L, src, dst, smooth, hpgmg_hip_smooth_gsrb(&B->dev, v, src, dst, rhs_id, a, b, h2inv, s));

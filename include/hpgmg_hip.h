@@ -99,6 +99,15 @@ int hpgmg_hip_smooth_cheby(const hpgmg_hip_level *L, int variant, int xn_id, int
                            double a, double b, double h2inv, double c1, double c2);
 int hpgmg_hip_smooth_gsrb(const hpgmg_hip_level *L, int variant, int xn_id, int xnp1_id, int rhs_id,
                           double a, double b, double h2inv, int sweep);
+/* One coloured half sweep of the fv4 GSRB smoother (out of place) on a level of small boxes (side 4, 8 or 16, all local, Dirichlet) as ONE launch:
+ * x outside a box is read where it lives (no exchange_boundary before), and apply_BCs_v4 of the RESULT runs in the same launch, each box applying
+ * its own entries -- bc_by_box = the level's boundary blocks of the stencil's shape sorted by box, bc_start[box] .. bc_start[box + 1] the range of a
+ * box (DEVICE arrays).  xn_id must carry valid domain-boundary ghost cells (an earlier launch of this kernel, or apply_BCs). */
+int hpgmg_hip_smooth_gsrb_fv4_box_supported(const hpgmg_hip_level *L, int variant);   /* 0 in product builds and unless switched on */
+int hpgmg_hip_smooth_gsrb_fv4_box(const hpgmg_hip_level *L, int variant, int xn_id, int xout_id, int rhs_id, double a, double b, double h2inv, int sweep,
+                                  const blockCopy_type *bc_by_box, const int *bc_start);
+long long hpgmg_hip_fv4_box_launch_count(void);
+void hpgmg_hip_set_fv4_box(int on);   /* EXPERIMENTS=1 builds: 1 = use it (default 0 / HPGMG_TUNE_FV4_BOX: it measured slower than the two launches it replaces) */
 int hpgmg_hip_smooth_jacobi(const hpgmg_hip_level *L, int variant, int xn_id, int xnp1_id, int rhs_id,
                             double a, double b, double h2inv, double weight);
 /* operators/residual.c:9-51 (rhs_id >= 0: res = rhs - A x) and operators/apply_op.c:9-48 (rhs_id < 0: res = A x) */

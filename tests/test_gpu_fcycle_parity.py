@@ -215,6 +215,31 @@ def test_host_driven_bottom_solve_through_the_small_operator_queue(hip, variant,
         lib.hpgmg_set_small_ops(1)
 
 
+def test_fv4_half_sweep_of_small_boxes_as_one_launch(hip):
+    """EXPERIMENTS=1 builds: one coloured half sweep of fv4 GSRB on a level of small boxes as ONE launch (x outside a box read where it lives, the
+    boundary conditions of the result applied by the same launch) instead of exchange + conditions and stencil: opt-in (measured slower), the same norms."""
+    import ctypes
+    import hpgmg_amd as H
+    k = H.load_kernels()
+    if not k.hpgmg_hip_experiments():
+        pytest.skip("fv4_box_gsrb_kernel is only in builds with EXPERIMENTS=1 (it measured slower than what it replaces)")
+    gold = GOLD["fv4-gsrb 4 8"]
+    k.hpgmg_hip_set_fv4_box.argtypes = [ctypes.c_int]
+    k.hpgmg_hip_fv4_box_launch_count.restype = ctypes.c_longlong
+    try:
+        k.hpgmg_hip_set_fv4_box(1)
+        before = k.hpgmg_hip_fv4_box_launch_count()
+        hip.configure(**VARIANTS["fv4-gsrb"])
+        s = hip.solver_cli(4, 8)
+        assert [fmt(v) for v in s.three_sizes()] == gold["norms"]
+        err, order = s.richardson()
+        assert fmt(err) == gold["richardson_error"]
+        s.destroy()
+        assert k.hpgmg_hip_fv4_box_launch_count() > before
+    finally:
+        k.hpgmg_hip_set_fv4_box(0)
+
+
 def test_reference_three_launch_mode_gives_the_same_norms(hip):
     """HPGMG_GHOST_FREE=0 path (exchange_boundary + apply_BCs + stencil, as the reference sequences them)."""
     import ctypes
