@@ -1424,9 +1424,22 @@ static void do_smooth(level_type *L, int x_id, int rhs_id, double a, double b) {
       }
     }
     if (smooth_fv4_rb(L, x_id, rhs_id, a, b, sweeps)) return;
+    /* The exported smooth() (VECTOR_TEMP must be left as the separate half sweeps leave it: the iterate before the last one) -- what the
+     * reference's own driver calls (Route B): all sweeps but the last as red + black passes x -> TEMP -> x, the last sweep as its two half
+     * sweeps x -> TEMP -> x.  The same iterates, the same final x and VECTOR_TEMP; 2 passes + 2 half sweeps instead of 6 half sweeps. */
+    int first_half_sweep = 0;
+    if (cfg.op == HPGMG_OP_FV4 && oop && !temp_is_scratch && sweeps >= 6 && !(sweeps & 1) && (((sweeps - 2) / 2) & 1) == 0) {
+      static int exact_rb = -1;
+      if (exact_rb < 0) { const char *e = getenv("HPGMG_TUNE_FV4_NO_EXACT_RB"); exact_rb = !(e && e[0] == '1'); }
+      if (exact_rb) {
+        temp_is_scratch = 1;
+        if (smooth_fv4_rb(L, x_id, rhs_id, a, b, sweeps - 2)) first_half_sweep = sweeps - 2;      /* an even number of passes: they end on x */
+        temp_is_scratch = 0;
+      }
+    }
     /* fv4 on a level of small boxes (4^3 ... 16^3, all local): a half sweep as ONE launch -- x outside a box read where it lives, the boundary
      * conditions of the result applied by the same launch (kernels/stencil.hip: fv4_box_gsrb_kernel) -- instead of two */
-    if (cfg.op == HPGMG_OP_FV4 && oop && !(sweeps & 1) && ghost_free_mode() && B->all_faces_local && L->box_dim >= 4 && x_id != VECTOR_TEMP && rhs_id != VECTOR_TEMP &&
+    if (!first_half_sweep && cfg.op == HPGMG_OP_FV4 && oop && !(sweeps & 1) && ghost_free_mode() && B->all_faces_local && L->box_dim >= 4 && x_id != VECTOR_TEMP && rhs_id != VECTOR_TEMP &&
         L->boundary_condition.type == BC_DIRICHLET && hpgmg_hip_smooth_gsrb_fv4_box_supported(&B->dev, v)) {
       const int shape = stencil_get_shape(), n_bc = L->boundary_condition.num_blocks[shape];
       if (!B->d_bc_start[shape]) {
@@ -1452,7 +1465,7 @@ static void do_smooth(level_type *L, int x_id, int rhs_id, double a, double b) {
       }
       return;
     }
-    for (s = 0; s < sweeps; s++) {
+    for (s = first_half_sweep; s < sweeps; s++) {
       const int src = (oop && (s & 1)) ? VECTOR_TEMP : x_id, dst = oop ? ((s & 1) ? x_id : VECTOR_TEMP) : x_id;
       STENCIL_WITH_GHOSTS(L, src, dst, smooth, hpgmg_hip_smooth_gsrb(&B->dev, v, src, dst, rhs_id, a, b, h2inv, s));
     }
