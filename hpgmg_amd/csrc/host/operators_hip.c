@@ -670,7 +670,7 @@ static long long small_vtails = 0;
 static int small_vtail_on = -1;
 long long hpgmg_small_vtails(void) { return small_vtails; }
 void hpgmg_set_small_vtail(int on) { small_vtail_on = (on == 2) ? 2 : (on ? 1 : 0); }      /* 0 off, 1 on for every plugin, 2 the default (not for 27-point GSRB) */
-static int small_vtail_fused(level_type **levels, int n, int e_id, int R_id, double a, double b) {
+static int small_vtail_fused(level_type **levels, int n, int e_id, int R_id, double a, double b, int legs) {
   hpgmg_config cfg;
   hpgmg_hip_small_tail_args T;
   int l;
@@ -682,7 +682,7 @@ static int small_vtail_fused(level_type **levels, int n, int e_id, int R_id, dou
   if (n < 2 || n > HPGMG_HIP_SMALL_TAIL_MAX_LEVELS || sweeps < 1 || sweeps > 8 || (sweeps & 1) || graphs == 1) return 0;      /* (captured segments: the argument block's upload is not capturable) */
   if (cfg.smoother != HPGMG_SMOOTH_CHEBY && cfg.smoother != HPGMG_SMOOTH_GSRB && cfg.smoother != HPGMG_SMOOTH_JACOBI) return 0;
   memset(&T, 0, sizeof T);
-  T.n = n; T.mode = (cfg.smoother == HPGMG_SMOOTH_CHEBY) ? 0 : (cfg.smoother == HPGMG_SMOOTH_GSRB ? 1 : 2);
+  T.n = n; T.legs = legs; T.mode = (cfg.smoother == HPGMG_SMOOTH_CHEBY) ? 0 : (cfg.smoother == HPGMG_SMOOTH_GSRB ? 1 : 2);
   T.sweeps = sweeps; T.out_of_place = (T.mode == 1) ? hpgmg_gsrb_out_of_place() : 0;
   T.e_id = e_id; T.R_id = R_id; T.krylov_base = hpgmg_vectors_reserved(); T.a = a; T.b = b; T.want = MG_DEFAULT_BOTTOM_NORM;
   const int shape = stencil_get_shape();
@@ -715,7 +715,7 @@ static int small_vtail_fused(level_type **levels, int n, int e_id, int R_id, dou
     if (l + 1 < n) {
       if (T.mode == 0) { if (L->dominant_eigenvalue_of_DinvA <= 0.0) return 0; cheby_coefficients(L, sweeps, v->c1, v->c2); }
       if (T.mode == 2) { int q; for (q = 0; q < sweeps; q++) v->c2[q] = 2.0 / 3.0; }
-    } else {
+    } else if (legs & 2) {
       /* solvers.c:77-87: the fused solve is the Dirichlet one (no mean to remove); the Krylov vectors must exist */
       if (L->must_subtract_mean != 0) return 0;
       if ((long long)L->dim.i * L->dim.j * L->dim.k > hpgmg_hip_bottom_bicgstab_max_cells()) return 0;
@@ -747,7 +747,11 @@ static int vcycle_legs_fused(level_type **levels, int n, int e_id, int R_id, dou
   hpgmg_get_config(&cfg);
   const int sweeps = hpgmg_smooth_sweeps();
   const int with_bottom = (leg >= 2);
-  if (enabled && cfg.op != HPGMG_OP_7PT) return (leg == 2 && bottom_enabled) ? small_vtail_fused(levels, n, e_id, R_id, a, b) : 0;
+  if (enabled && cfg.op != HPGMG_OP_7PT) {      /* leg 0 / 1: the way down / up around a bottom solve somebody else runs (the reference's driver, through the queue below) */
+    if (leg == 2) return bottom_enabled ? small_vtail_fused(levels, n, e_id, R_id, a, b, 7) : 0;
+    if (leg == 0 || leg == 1) return small_vtail_fused(levels, n, e_id, R_id, a, b, leg == 0 ? 1 : 4);
+    return 0;
+  }
   if (!enabled || !ghost_free_mode() || cfg.op != HPGMG_OP_7PT || n > 8 || n > hpgmg_hip_tail_max_levels() || sweeps > 8) return 0;
   if (with_bottom && !bottom_enabled) return 0;
   if (n < (leg == 3 ? 1 : 2)) return 0;
@@ -2023,8 +2027,10 @@ static int lazy_push(int op, level_type *L, level_type *L2, int i0, int i1, int 
     return 0;
   }
   if (lz_mode == LZ_SMALL) return 0;
-  if (cfg.op != HPGMG_OP_7PT) return 0;                   /* the other fused forms used by the queue are the 7-point plugin's */
   if (op == LZ_ADD || op == LZ_MUL || op == LZ_APPLY) return 0;
+  /* the legs of MGVCycle are recognised for every plugin (the levels of one box at their end go out as one launch: small_vtail_kernel);
+   * the large-level fused forms and the residual + norm / copy + restriction pairs are the 7-point plugin's */
+  if (cfg.op != HPGMG_OP_7PT && !(op == LZ_SMOOTH || op == LZ_INTERP || lz_mode == LZ_DOWN || lz_mode == LZ_UP)) return 0;
   if (lz_n == 0) {
     if (op == LZ_SMOOTH) { ok = 1; lz_mode = LZ_DOWN; }
     else if (op == LZ_INTERP && a == 1.0 && i0 == i1) { ok = 1; lz_mode = LZ_UP; }

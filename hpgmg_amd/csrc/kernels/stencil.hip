@@ -1250,7 +1250,9 @@ __global__ __launch_bounds__(512) void small_vtail_kernel(const hpgmg_hip_small_
   // slots of an image: x, VECTOR_TEMP, rhs, Dinv, alpha, beta_i, beta_j, beta_k (small_level_run addresses them by slot number)
   const int slot_vec[8] = { e_id, VECTOR_TEMP, R_id, VECTOR_DINV, kHelm ? VECTOR_ALPHA : -1, kVC ? VECTOR_BETA_I : -1, kVC ? VECTOR_BETA_J : -1, kVC ? VECTOR_BETA_K : -1 };
   int unused_n = 0;
+  const int legs = Tp->legs;                                       // bit 0: the way down, bit 1: the bottom solve, bit 2: the way up
   for (int ph = 0; ph < 2 * n - 1; ph++) {
+    if (ph < n - 1 ? !(legs & 1) : (ph == n - 1 ? !(legs & 2) : !(legs & 4))) continue;
     if (ph == n - 1) {                                             // ---- the bottom solve (solvers.c IterativeSolver -> BiCGStab)
       const hpgmg_hip_small_tail_level &lb = Tp->lv[n - 1];
       const hpgmg_hip_level Lb = lb.L;
@@ -2141,13 +2143,13 @@ static long long g_small_vtail_launches = 0;
 long long hpgmg_hip_small_vtail_launch_count(void) { return g_small_vtail_launches; }
 int hpgmg_hip_small_vtail(const hpgmg_hip_small_tail_args *T, int variant) {
   HPGMG_SKIP_IF_REPLAY();
-  if (!T || T->n < 2 || T->n > HPGMG_HIP_SMALL_TAIL_MAX_LEVELS || T->sweeps < 1 || T->sweeps > 8 || T->mode < MODE_CHEBY || T->mode > MODE_JACOBI)
+  if (!T || T->n < 2 || T->n > HPGMG_HIP_SMALL_TAIL_MAX_LEVELS || T->legs < 1 || T->legs > 7 || T->sweeps < 1 || T->sweeps > 8 || T->mode < MODE_CHEBY || T->mode > MODE_JACOBI)
     return record_error(hipErrorInvalidValue, "small_vtail: arguments");
   for (int l = 0; l < T->n; l++) {
     const hpgmg_hip_level &L = T->lv[l].L;
     if (L.num_boxes != 1 || L.periodic || (l > 0 && 2 * L.dim != T->lv[l - 1].L.dim)) return record_error(hipErrorInvalidValue, "small_vtail: a chain of levels of one box, halving, Dirichlet");
   }
-  if ((long long)T->lv[T->n - 1].L.dim * T->lv[T->n - 1].L.dim * T->lv[T->n - 1].L.dim > 512) return record_error(hipErrorInvalidValue, "small_vtail: bottom level too large");
+  if ((T->legs & 2) && (long long)T->lv[T->n - 1].L.dim * T->lv[T->n - 1].L.dim * T->lv[T->n - 1].L.dim > 512) return record_error(hipErrorInvalidValue, "small_vtail: bottom level too large");
   const long long need = hpgmg_hip_small_vtail_lds_doubles(T);
   if (need > hpgmg_hip_small_vtail_lds_limit()) return record_error(hipErrorInvalidValue, "small_vtail: the chain does not fit the LDS");
   constexpr int kSlots = 8;

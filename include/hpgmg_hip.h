@@ -173,7 +173,7 @@ typedef struct {
   double h2inv, c1[8], c2[8];                  /* Chebyshev coefficients per sweep (Jacobi: c2 = the weight) */
 } hpgmg_hip_small_tail_level;
 typedef struct {
-  int n, mode, sweeps, out_of_place, e_id, R_id, krylov_base, pad_;
+  int n, mode, sweeps, out_of_place, e_id, R_id, krylov_base, legs;   /* legs: bit 0 the way down, bit 1 the bottom solve, bit 2 the way up (7 = the whole tail) */
   double a, b, want;
   int *krylov_iterations;                      /* device-visible host counter the bottom solve adds its iteration count to, or NULL */
   hpgmg_hip_small_tail_level lv[HPGMG_HIP_SMALL_TAIL_MAX_LEVELS];

@@ -38,8 +38,10 @@ def test_reference_driver_runs_on_the_hip_plugin(variant, args):
     assert out.returncode == 0, out.stderr[-2000:]
     # the reference's MGVCycle knows none of the fused hooks: the plugin's lazy queue must have recognised its legs and run them fused
     m = re.search(r"hpgmg lazy queue: (\d+) single-launch legs, (\d+) fused large-level units", out.stderr)
-    if variant.startswith("7pt"):        # (the fused legs are the 7-point plugin's; the other plugins are checked for their numbers)
+    if variant.startswith("7pt"):
         assert m and int(m.group(1)) > 0 and (int(m.group(2)) > 0 or args != "7 8"), out.stderr[-500:]      # large-level units only exist at 256^3
+    elif variant != "27pt-gsrb":         # fv4 / fv2: the legs over their levels of one box (small_vtail_kernel); 27-point GSRB keeps its box kernel
+        assert m and int(m.group(1)) > 0, out.stderr[-500:]
     lines = pinned(out.stdout)
     norms = []
     for l in lines:
