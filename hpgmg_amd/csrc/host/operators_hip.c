@@ -12,29 +12,8 @@
  * Host-side structure of each routine follows the reference routine named in
  * its comment (exchange -> BC -> kernel, pack -> send/recv -> local -> unpack).
  */
-#include <stdio.h>
-#include <stdlib.h>
-#include <string.h>
-#include <math.h>
-#include <time.h>
-#include <stdint.h>
-#include "hpgmg_level.h"
-#include "hpgmg_operators.h"
-#include "hpgmg_mg.h"
-#include "hpgmg_hip.h"
+#include "plugin_internal.h"
 
-int hpgmg_smooth_sweeps(void);
-int hpgmg_gsrb_out_of_place(void);
-
-/* Timers of level->timers (reference level.h:162-196; printed by MGPrintTiming, mg.c:54-161).  Launches are asynchronous, so
- * there are three ways to fill them:
- *   HPGMG_TIMERS=host   (default for library users / bench.py) host clock around the launch calls: costs nothing, but the rows only
- *                       say where the HOST thread spent its time;
- *   HPGMG_TIMERS=device (default of the hpgmg-fv executable, hpgmg_set_timer_mode(1)) a hipEvent pair on the launch stream around
- *                       every operator: device time per operator class and level, settled when the table is printed or reset;
- *   HPGMG_TIMERS=sync   (or HPGMG_SYNC_TIMERS=1) synchronise around every operator: exact wall time, serialises host and device.
- * With HPGMG_ROCTX=1 every timed operator is also a roctx range "<dim>^3 <operator>" (rocprofv3 --marker-trace). */
-enum { TIMERS_HOST = 0, TIMERS_DEVICE = 1, TIMERS_SYNC = 2 };
 static int timer_mode = -1;
 void hpgmg_set_timer_mode(int mode) { timer_mode = (mode >= 0 && mode <= 2) ? mode : 0; }
 void hpgmg_set_sync_timers(int on) { timer_mode = on ? TIMERS_SYNC : TIMERS_HOST; }
@@ -72,17 +51,11 @@ void hpgmg_tick_end(hpgmg_tick t) {
   if (t.range) hpgmg_hip_range_pop();
 }
 void hpgmg_timers_settle(void) { hpgmg_hip_timer_flush(); }
-#define TICK(L, FIELD, WHAT) const hpgmg_tick tick_ = hpgmg_tick_begin((L), &(L)->timers.FIELD, WHAT)
-#define TOCK() hpgmg_tick_end(tick_)
-/* every device call of this file goes through HIP_OK: the operators still waiting in the lazy queue (end of the file) are issued first, so
- * whatever runs next sees the state they leave */
-static void lazy_flush(void);
 static void do_smooth(level_type *L, int x_id, int rhs_id, double a, double b);
 static void do_residual(level_type *L, int res_id, int x_id, int rhs_id, double a, double b);
 static void do_restriction(level_type *Lc, int id_c, level_type *Lf, int id_f, int type);
 static void do_interpolation_vcycle(level_type *Lf, int id_f, double prescale, level_type *Lc, int id_c);
 static void do_zero_vector(level_type *L, int id);
-#define HIP_OK(call) do { lazy_flush(); int e_ = (call); if (e_) { fprintf(stderr, "hpgmg: %s failed (%d): %s\n", #call, e_, hpgmg_hip_last_error()); abort(); } } while (0)
 
 /* ---------------------------------------------------------------- storage hooks */
 const char *hpgmg_backend_name(void) { return "hip"; }
@@ -129,51 +102,9 @@ void hpgmg_segment_begin(long long key) {
 }
 void hpgmg_segment_end(void) { HIP_OK(hpgmg_hip_graph_end()); }
 
-/* ---------------------------------------------------------------- per-level device record */
-#define MAX_LISTS 32
-typedef struct {
-  hpgmg_hip_level dev;         /* what the kernels receive */
-  double **d_box_base;  int *d_box_low;  int *d_box_nbr;  int all_faces_local;
-  double  *seen_v0;     int seen_nv, seen_boxes;  /* detects create_vectors() re-allocation */
-  struct { const blockCopy_type *host; int n; blockCopy_type *dev; } lists[MAX_LISTS];
-  int num_lists;
-  hpgmg_hip_bc_entry *d_bc[STENCIL_MAX_SHAPES]; int n_bc[STENCIL_MAX_SHAPES];   /* boundary-condition blocks with their geometry worked out */
-  blockCopy_type *h_bc_by_box[STENCIL_MAX_SHAPES]; int *d_bc_start[STENCIL_MAX_SHAPES];   /* boundary blocks sorted by box + the range of each box (fv4 box kernel) */
-  int *d_fv4_special; int n_fv4_special;       /* fv4 red + black: cells on internal box faces next to a domain wall (box, i, j, k); n < 0: not built */
-  hpgmg_hip_bc_entry *d_bc_k; int n_bc_k, bc_k_local;      /* the blocks of the stencil's shape whose domain normal has a k component (fv4 red + black pre-pass); n_bc_k < 0: not built */
-  int bc_sources_local[STENCIL_MAX_SHAPES];    /* 1: every entry reads cells of local boxes' interiors only (no exchange needed before the conditions) */
-  int *krylov_pinned;          /* iterations of device-side bottom solves not yet folded into level->Krylov_iterations */
-  double *pair_scratch; double **d_pair_base;   /* two private vectors per box for the fused Chebyshev sweep pairs */
-  float *coef32; float **d_coef32_base; int coef32_valid;   /* fp32 copies of Dinv, alpha, beta_* for the mixed-precision smoother */
-  int lexicographic;           /* -1 unknown, else whether local box b sits at (b % nb, (b / nb) % nb, b / nb^2) and all boxes are local */
-  int *d_restrict_map;         /* fused residual + restriction: per fine box the coarse box and the coarse cell under its first cell (device) */
-  struct pair_halo *halo;      /* sweep pairs across rank boundaries: brick shape, message plans, deep halos (NULL: not built / not applicable) */
-  int halo_state;              /* 0 not examined, 1 usable, -1 this level cannot use it */
-} backend_t;
-
-/* ---- halo of a sweep pair (kernels/cheby_pair.hpp, REMOTE variants) ----------------------------------------------------------
- * One message per neighbouring rank per sweep PAIR instead of one per sweep (reference: exchange_boundary before every sweep,
- * chebyshev.c:45-46).  Plan FIRST (first pair of a smooth()): x0 two cells deep on faces + one cell on the brick's edges, xm1 and the
- * right-hand side one cell deep; plan NEXT: the same without the right-hand side; plan COEF (once per operator rebuild): the normal
- * beta component one index beyond the ghost zone on the high faces.  Inside a message regions are ordered by the sender's global box
- * id, then the direction seen from the sender, then the item -- both sides derive that order independently, like level.c does. */
-enum { HALO_FIRST = 0, HALO_NEXT = 1, HALO_COEF = 2, HALO_PLANS = 3 };
-typedef struct {
-  int n_send, n_recv;                           /* regions */
-  hpgmg_hip_halo_entry *d_send, *d_recv;        /* device copies of the region lists */
-  int n_sp, n_rp;                               /* messages: peers this rank sends to / receives from */
-  int *sp_rank, *rp_rank, *sp_size, *rp_size;   /* doubles per message */
-  double **sp_ptr, **rp_ptr;                    /* start of each message inside the rank's send / receive buffer */
-} halo_plan;
-typedef struct pair_halo {
-  int brick[3], rem[6];
-  halo_plan plan[HALO_PLANS];
-  double *sendbuf, *recvbuf, *deep, *deep_beta;
-  int coef_valid;
-} pair_halo;
 
 static void coef32_invalidate(level_type *L);
-static backend_t *backend_of(level_type *L) {
+backend_t *hp_backend_of(level_type *L) {
   hpgmg_level_ext *X = hpgmg_level_ext_get(L);
   backend_t *B = (backend_t *)X->backend;
   if (!B) { B = (backend_t *)calloc(1, sizeof(*B)); X->backend = B; B->lexicographic = -1; B->n_bc_k = -1; B->n_fv4_special = -1; }
@@ -244,10 +175,10 @@ static backend_t *backend_of(level_type *L) {
 }
 
 /* device mirror of one immutable host list (uploaded on first use) */
-static const blockCopy_type *mirror(level_type *owner, const blockCopy_type *host, int n) {
+const blockCopy_type *hp_mirror(level_type *owner, const blockCopy_type *host, int n) {
   int s;
   if (n <= 0 || !host) return NULL;
-  backend_t *B = backend_of(owner);
+  backend_t *B = hp_backend_of(owner);
   for (s = 0; s < B->num_lists; s++) if (B->lists[s].host == host && B->lists[s].n == n) return B->lists[s].dev;
   if (B->num_lists == MAX_LISTS) { fprintf(stderr, "hpgmg: too many block lists on one level\n"); abort(); }
   blockCopy_type *d = (blockCopy_type *)hpgmg_hip_malloc((size_t)n * sizeof(blockCopy_type));
@@ -259,13 +190,14 @@ static const blockCopy_type *mirror(level_type *owner, const blockCopy_type *hos
 }
 
 void hpgmg_level_release(level_type *L) {
-  lazy_flush();                                  /* postponed operators hold a pointer to their level */
+  hp_lazy_flush();                                  /* postponed operators hold a pointer to their level */
   hpgmg_hip_graph_reset();                       /* cached graphs hold pointers into this level */
   hpgmg_hip_timer_forget(&L->timers, &L->timers + 1);   /* pending device timers point into this level */
   hpgmg_level_ext *X = hpgmg_level_ext_get(L);
   backend_t *B = (backend_t *)X->backend;
   int s;
   if (!B) return;
+  hp_images_release(B);
   for (s = 0; s < B->num_lists; s++) hpgmg_hip_free(B->lists[s].dev);
   for (s = 0; s < STENCIL_MAX_SHAPES; s++) if (B->d_bc[s]) hpgmg_hip_free(B->d_bc[s]);
   if (B->d_bc_k) hpgmg_hip_free(B->d_bc_k);
@@ -298,7 +230,7 @@ void hpgmg_level_release(level_type *L) {
   X->backend = NULL;
 }
 
-static int variant(void) {
+int hp_variant(void) {
   hpgmg_config c;
   hpgmg_get_config(&c);
   if (c.op == HPGMG_OP_7PT || c.op == HPGMG_OP_FV2)   /* operators.fv2.c: the 7-pt stencil with finite-volume BCs/interpolation */
@@ -323,11 +255,11 @@ void exchange_boundary(level_type *L, int id, int shape) {
   TICK(L, ghostZone_total, "exchange_boundary");
   if (shape >= STENCIL_MAX_SHAPES) shape = STENCIL_SHAPE_BOX;
   communicator_type *C = &L->exchange_ghosts[shape];
-  backend_t *B = backend_of(L);
-  HIP_OK(hpgmg_hip_copy_blocks(&B->dev, id, mirror(L, C->blocks[0], C->num_blocks[0]), C->num_blocks[0]));   /* pack */
+  backend_t *B = hp_backend_of(L);
+  HIP_OK(hpgmg_hip_copy_blocks(&B->dev, id, hp_mirror(L, C->blocks[0], C->num_blocks[0]), C->num_blocks[0]));   /* pack */
   transport_phase(C, C, (L->tag << 4) | shape);
-  HIP_OK(hpgmg_hip_copy_blocks(&B->dev, id, mirror(L, C->blocks[1], C->num_blocks[1]), C->num_blocks[1]));   /* box -> box */
-  HIP_OK(hpgmg_hip_copy_blocks(&B->dev, id, mirror(L, C->blocks[2], C->num_blocks[2]), C->num_blocks[2]));   /* unpack */
+  HIP_OK(hpgmg_hip_copy_blocks(&B->dev, id, hp_mirror(L, C->blocks[1], C->num_blocks[1]), C->num_blocks[1]));   /* box -> box */
+  HIP_OK(hpgmg_hip_copy_blocks(&B->dev, id, hp_mirror(L, C->blocks[2], C->num_blocks[2]), C->num_blocks[2]));   /* unpack */
   TOCK();
 }
 
@@ -337,7 +269,7 @@ void exchange_boundary(level_type *L, int id, int shape) {
  * neighbours and the Dirichlet condition itself, so only messages from other ranks still go
  * through the ghost zone: pack -> send/recv -> unpack, no local copies, no BC launch. */
 static int ghost_free = -1;
-static int ghost_free_mode(void) {
+int hp_ghost_free_mode(void) {
   if (ghost_free < 0) { const char *e = getenv("HPGMG_GHOST_FREE"); ghost_free = (e && e[0] == '0') ? 0 : 1; hpgmg_hip_set_ghost_free(ghost_free); }
   return ghost_free;
 }
@@ -350,48 +282,53 @@ static const hpgmg_hip_bc_entry *bc_entries(level_type *L, int shape, int *n_out
 static int exchange_and_bcs_one_launch(level_type *L, int id, int shape, int order, int with_copies) {
   static int merge = -1;
   if (merge < 0) { const char *e = getenv("HPGMG_ONE_LAUNCH_GHOSTS"); merge = !(e && e[0] == '0'); }
-  if (!merge || !ghost_free_mode() || L->num_my_boxes < 1 || L->boundary_condition.type == BC_PERIODIC) return 0;
+  if (!merge || !hp_ghost_free_mode() || L->num_my_boxes < 1 || L->boundary_condition.type == BC_PERIODIC) return 0;
   if (order == 12 && !(L->box_dim >= 2 && L->box_ghosts == 1)) return 0;      /* the fall-backs of apply_BCs_p2 / v2 / v4 for tiny boxes stay separate launches */
   if (order == 2 && !(L->box_dim >= 2)) return 0;
   if (order == 4 && !(L->box_dim >= 4)) return 0;
   communicator_type *C = &L->exchange_ghosts[shape];
   if (C->num_sends + C->num_recvs > 0 || C->num_blocks[0] || C->num_blocks[2]) return 0;
-  backend_t *B = backend_of(L);
+  backend_t *B = hp_backend_of(L);
   int n = 0;
   const hpgmg_hip_bc_entry *e = bc_entries(L, shape, &n);
   if (!B->bc_sources_local[shape]) return 0;
   TICK(L, ghostZone_total, "exchange_boundary + apply_BCs (one launch)");
-  HIP_OK(hpgmg_hip_exchange_and_bc(&B->dev, id, with_copies ? mirror(L, C->blocks[1], C->num_blocks[1]) : NULL, with_copies ? C->num_blocks[1] : 0, e, n, order));
+  HIP_OK(hpgmg_hip_exchange_and_bc(&B->dev, id, with_copies ? hp_mirror(L, C->blocks[1], C->num_blocks[1]) : NULL, with_copies ? C->num_blocks[1] : 0, e, n, order));
   TOCK();
   return 1;
 }
-static int variant(void);
 static void ghosts_for_stencil(level_type *L, int id, int out_id) {
   const int shape = stencil_get_shape();
   hpgmg_config c;
   hpgmg_get_config(&c);
-  const int fuse = ghost_free_mode() && c.op == HPGMG_OP_7PT && shape == STENCIL_SHAPE_STAR;
+  const int fuse = hp_ghost_free_mode() && c.op == HPGMG_OP_7PT && shape == STENCIL_SHAPE_STAR;
   hpgmg_hip_set_ghost_free(fuse);   /* the in-kernel -x(centre) rule IS apply_BCs_p1; other plugins (fv2: v2 BCs) need real ghosts */
   hpgmg_hip_set_tile_ghost_free(0);
   if (fuse) {
     communicator_type *C = &L->exchange_ghosts[shape];
     if (C->num_sends + C->num_recvs > 0) {
       TICK(L, ghostZone_total, "exchange_boundary (remote faces)");
-      backend_t *B = backend_of(L);
-      HIP_OK(hpgmg_hip_copy_blocks(&B->dev, id, mirror(L, C->blocks[0], C->num_blocks[0]), C->num_blocks[0]));
+      backend_t *B = hp_backend_of(L);
+      HIP_OK(hpgmg_hip_copy_blocks(&B->dev, id, hp_mirror(L, C->blocks[0], C->num_blocks[0]), C->num_blocks[0]));
       transport_phase(C, C, (L->tag << 4) | shape);
-      HIP_OK(hpgmg_hip_copy_blocks(&B->dev, id, mirror(L, C->blocks[2], C->num_blocks[2]), C->num_blocks[2]));
+      HIP_OK(hpgmg_hip_copy_blocks(&B->dev, id, hp_mirror(L, C->blocks[2], C->num_blocks[2]), C->num_blocks[2]));
       TOCK();
     }
     return;
   }
   /* 27-point and fv4 on a level whose boxes are all local, about to run the LDS-tiled kernel: it reads a neighbouring box's cells
    * where they live, so only the domain-boundary ghost cells are needed (each box's own, from its own interior) */
-  if (ghost_free_mode() && (c.op == HPGMG_OP_27PT || c.op == HPGMG_OP_FV4) && L->num_my_boxes > 0) {
-    backend_t *B = backend_of(L);
-    if (B->all_faces_local && hpgmg_hip_tile_kernel_applies(&B->dev, variant(), id != out_id)) {
+  if (hp_ghost_free_mode() && (c.op == HPGMG_OP_27PT || c.op == HPGMG_OP_FV4) && L->num_my_boxes > 0) {
+    backend_t *B = hp_backend_of(L);
+    if (B->all_faces_local && hpgmg_hip_tile_kernel_applies(&B->dev, hp_variant(), id != out_id)) {
       hpgmg_hip_set_tile_ghost_free(1);
       if (!exchange_and_bcs_one_launch(L, id, shape, c.op == HPGMG_OP_27PT ? 12 : 4, 0)) apply_BCs(L, id, shape);
+      return;
+    }
+    /* boxes on other ranks: the same kernel on the table with their images -- one message per neighbouring rank carries the cells it reads there */
+    if (!B->all_faces_local && hp_images_ready(L, B) && hpgmg_hip_tile_kernel_applies(&B->img->dev, hp_variant(), id != out_id)) {
+      hpgmg_hip_set_tile_ghost_free(1);
+      hp_images_refresh(L, B, 0, id, stencil_get_radius(), -1, c.op == HPGMG_OP_27PT ? 12 : 4);
       return;
     }
   }
@@ -422,7 +359,7 @@ static int overlap_begin(level_type *L, int id) {
   if (overlap_mode < 0) { const char *e = getenv("HPGMG_OVERLAP"); overlap_mode = (e && e[0] == '0') ? 0 : 1; }
   if (!overlap_mode || !T || T->size < 2) return 0;
   hpgmg_get_config(&c);
-  if (!(ghost_free_mode() && c.op == HPGMG_OP_7PT && shape == STENCIL_SHAPE_STAR) || L->box_dim < 8) return 0;
+  if (!(hp_ghost_free_mode() && c.op == HPGMG_OP_7PT && shape == STENCIL_SHAPE_STAR) || L->box_dim < 8) return 0;
   communicator_type *C = &L->exchange_ghosts[shape];
   if (C->num_sends + C->num_recvs == 0 || L->num_my_boxes < 1) return 0;
   if (!comm_stream) {
@@ -430,11 +367,11 @@ static int overlap_begin(level_type *L, int id) {
     if (!comm_stream || !ev_packed || !ev_landed) { fprintf(stderr, "hpgmg: cannot create the exchange stream\n"); abort(); }
   }
   const double t0 = (hpgmg_get_timer_mode() == TIMERS_DEVICE) ? 0.0 : now();   /* two streams: the exchange is hidden behind the stencil launch by design, only the host modes time it */
-  backend_t *B = backend_of(L);
+  backend_t *B = hp_backend_of(L);
   void *launch_stream = hpgmg_hip_get_stream();
   hpgmg_hip_set_ghost_free(1);
-  HIP_OK(hpgmg_hip_copy_blocks(&B->dev, id, mirror(L, C->blocks[0], C->num_blocks[0]), C->num_blocks[0]));          /* pack */
-  const blockCopy_type *unpack = mirror(L, C->blocks[2], C->num_blocks[2]);
+  HIP_OK(hpgmg_hip_copy_blocks(&B->dev, id, hp_mirror(L, C->blocks[0], C->num_blocks[0]), C->num_blocks[0]));          /* pack */
+  const blockCopy_type *unpack = hp_mirror(L, C->blocks[2], C->num_blocks[2]);
   HIP_OK(hpgmg_hip_event_record(ev_packed));
   hpgmg_hip_set_stream(comm_stream);
   HIP_OK(hpgmg_hip_stream_wait_event(ev_packed));
@@ -449,6 +386,7 @@ static int overlap_begin(level_type *L, int id) {
 static void overlap_end(void) { HIP_OK(hpgmg_hip_stream_wait_event(ev_landed)); }
 /* run a stencil launch with its operand's ghost zones: overlapped (two launches: all but the shell, then the shell) or plain */
 #define STENCIL_WITH_GHOSTS(L, id, out_id, TIMER, CALL) do {                                                     \
+    hp_backend_of(L)->img_active = 0;                                                                    \
     if (overlap_begin(L, id)) {                                                                          \
       TICK(L, TIMER, #TIMER " (overlapped with the halo exchange)");                                     \
       hpgmg_hip_set_defer_mode(1); HIP_OK(CALL);                                                         \
@@ -467,9 +405,9 @@ void apply_BCs_p1(level_type *L, int x_id, int shape) {
   if (shape >= STENCIL_MAX_SHAPES) shape = STENCIL_SHAPE_BOX;
   if (L->boundary_condition.type == BC_PERIODIC) return;
   TICK(L, boundary_conditions, "apply_BCs_p1");
-  backend_t *B = backend_of(L);
+  backend_t *B = hp_backend_of(L);
   const int n = L->boundary_condition.num_blocks[shape];
-  HIP_OK(hpgmg_hip_apply_bc_p1(&B->dev, x_id, mirror(L, L->boundary_condition.blocks[shape], n), n));
+  HIP_OK(hpgmg_hip_apply_bc_p1(&B->dev, x_id, hp_mirror(L, L->boundary_condition.blocks[shape], n), n));
   TOCK();
 }
 static void no_kernel(const char *what) { fprintf(stderr, "hpgmg: %s has no HIP kernel yet\n", what); abort(); }
@@ -479,22 +417,55 @@ void apply_BCs_p2(level_type *L, int x_id, int shape) {                         
   if (L->boundary_condition.type == BC_PERIODIC) return;
   if (L->box_dim < 2) { apply_BCs_p1(L, x_id, shape); return; }
   TICK(L, boundary_conditions, "apply_BCs_p2");
-  backend_t *B = backend_of(L);
+  backend_t *B = hp_backend_of(L);
   int n = L->boundary_condition.num_blocks[shape];
   if (L->box_ghosts == 1) { const hpgmg_hip_bc_entry *e = bc_entries(L, shape, &n); HIP_OK(hpgmg_hip_apply_bc_fv(&B->dev, x_id, e, n, 12)); }
-  else HIP_OK(hpgmg_hip_apply_bc_p2(&B->dev, x_id, mirror(L, L->boundary_condition.blocks[shape], n), n));
+  else HIP_OK(hpgmg_hip_apply_bc_p2(&B->dev, x_id, hp_mirror(L, L->boundary_condition.blocks[shape], n), n));
   TOCK();
 }
 void apply_BCs_v1(level_type *L, int x_id, int shape) { apply_BCs_p1(L, x_id, shape); }   /* boundary_fv.c:6-90: same one-point formula */
 /* The finite-volume conditions work on a block's DOMAIN normal (its subtype): the axes leaving the domain sit at ghost index -1 / dim and
  * step inward, the others run over the block's extent.  That geometry is fixed per block, so it is worked out here once; the kernel
  * then only loads it (faces first: they are the long entries). */
+int hp_bc_entry_from_block(const level_type *L, int box, const int bpos[3], const int lo[3], const int len[3], int subtype,
+                           int (*find)(void *, int), void *ctx, hpgmg_hip_bc_entry *o) {
+  const int strides[3] = {1, L->box_jStride, L->box_kStride};
+  const int d[3] = {subtype % 3 - 1, (subtype % 9) / 3 - 1, subtype / 9 - 1};
+  int ax, nf = 0, local = 1;
+  o->box = box; o->nn = 0; o->base = 0; o->len0 = o->len1 = 1; o->fs0 = o->fs1 = 0;
+  o->zbase = lo[0] * strides[0] + lo[1] * strides[1] + lo[2] * strides[2]; o->zi = len[0]; o->zj = len[1]; o->zk = len[2];
+  int nbr[3] = {0, 0, 0};                  /* in-face axes whose range lies in the ghost zone: the block runs along that neighbour's face */
+  for (ax = 0; ax < 3; ax++) {
+    if (d[ax]) { o->base += (d[ax] < 0 ? -1 : L->box_dim) * strides[ax]; o->step[o->nn++] = -d[ax] * strides[ax]; }
+    else {
+      if (nf == 0) { o->base += lo[ax] * strides[ax]; o->len0 = len[ax]; o->fs0 = strides[ax]; nf++; }
+      else if (nf == 1) { o->base += lo[ax] * strides[ax]; o->len1 = len[ax]; o->fs1 = strides[ax]; nf++; }
+      if (lo[ax] < 0) nbr[ax] = -1; else if (lo[ax] >= L->box_dim) nbr[ax] = 1;
+    }
+  }
+  /* read the cells the condition is formed from where they live: the box that owns them (same offsets, shifted by a box length) */
+  o->src_box = o->box; o->src_base = o->base;
+  if (nbr[0] || nbr[1] || nbr[2]) {
+    const int ni = bpos[0] + nbr[0], nj = bpos[1] + nbr[1], nk = bpos[2] + nbr[2];
+    int src = -1;
+    if (ni >= 0 && nj >= 0 && nk >= 0 && ni < L->boxes_in.i && nj < L->boxes_in.j && nk < L->boxes_in.k) src = find(ctx, ni + L->boxes_in.i * (nj + L->boxes_in.j * nk));
+    if (src >= 0) { o->src_box = src; for (ax = 0; ax < 3; ax++) o->src_base -= nbr[ax] * L->box_dim * strides[ax]; }
+    else local = 0;                        /* not in the table (another rank's): that block keeps reading the ghost zone an exchange has filled */
+  }
+  return local;
+}
+static int find_own_box(void *ctx, int gid) {
+  const level_type *L = (const level_type *)ctx;
+  int q;
+  if (L->rank_of_box[gid] != L->my_rank) return -1;
+  for (q = 0; q < L->num_my_boxes; q++) if (L->my_boxes[q].global_box_id == gid) return q;
+  return -1;
+}
 /* host list of the entries of boundary_condition.blocks[shape] (k_only: only those whose domain normal has a k component) */
 static hpgmg_hip_bc_entry *bc_entries_host(level_type *L, int shape, int k_only, int *n_out, int *all_local_out) {
   const int n = L->boundary_condition.num_blocks[shape];
   const blockCopy_type *blocks = L->boundary_condition.blocks[shape];
   hpgmg_hip_bc_entry *h = (hpgmg_hip_bc_entry *)calloc((size_t)(n > 0 ? n : 1), sizeof *h);
-  const int strides[3] = {1, L->my_boxes[0].jStride, L->my_boxes[0].kStride};
   int kind, q, m = 0, all_local = 1, skipped = 0;
   for (kind = 1; kind <= 3; kind++) for (q = 0; q < n; q++) {
     const blockCopy_type *e = &blocks[q];
@@ -502,32 +473,9 @@ static hpgmg_hip_bc_entry *bc_entries_host(level_type *L, int shape, int k_only,
     const int lo[3] = {e->read.i, e->read.j, e->read.k}, len[3] = {e->dim.i, e->dim.j, e->dim.k};
     if ((d[0] != 0) + (d[1] != 0) + (d[2] != 0) != kind) continue;
     if (k_only && !d[2]) { skipped++; continue; }
-    hpgmg_hip_bc_entry *o = &h[m++];
-    int ax, nf = 0;
-    o->box = e->read.box; o->nn = 0; o->base = 0; o->len0 = o->len1 = 1; o->fs0 = o->fs1 = 0;
-    o->zbase = lo[0] * strides[0] + lo[1] * strides[1] + lo[2] * strides[2]; o->zi = len[0]; o->zj = len[1]; o->zk = len[2];
-    int nbr[3] = {0, 0, 0};                  /* in-face axes whose range lies in the ghost zone: the block runs along that neighbour's face */
-    for (ax = 0; ax < 3; ax++) {
-      if (d[ax]) { o->base += (d[ax] < 0 ? -1 : L->box_dim) * strides[ax]; o->step[o->nn++] = -d[ax] * strides[ax]; }
-      else {
-        if (nf == 0) { o->base += lo[ax] * strides[ax]; o->len0 = len[ax]; o->fs0 = strides[ax]; nf++; }
-        else if (nf == 1) { o->base += lo[ax] * strides[ax]; o->len1 = len[ax]; o->fs1 = strides[ax]; nf++; }
-        if (lo[ax] < 0) nbr[ax] = -1; else if (lo[ax] >= L->box_dim) nbr[ax] = 1;
-      }
-    }
-    /* read the cells the condition is formed from where they live: the box that owns them (same offsets, shifted by a box length) */
-    o->src_box = o->box; o->src_base = o->base;
-    if (nbr[0] || nbr[1] || nbr[2]) {
-      const box_type *bx = &L->my_boxes[o->box];
-      const int ni = bx->low.i / L->box_dim + nbr[0], nj = bx->low.j / L->box_dim + nbr[1], nk = bx->low.k / L->box_dim + nbr[2];
-      int src = -1, q2;
-      if (ni >= 0 && nj >= 0 && nk >= 0 && ni < L->boxes_in.i && nj < L->boxes_in.j && nk < L->boxes_in.k) {
-        const int gid = ni + L->boxes_in.i * (nj + L->boxes_in.j * nk);
-        if (L->rank_of_box[gid] == L->my_rank) for (q2 = 0; q2 < L->num_my_boxes; q2++) if (L->my_boxes[q2].global_box_id == gid) src = q2;
-      }
-      if (src >= 0) { o->src_box = src; for (ax = 0; ax < 3; ax++) o->src_base -= nbr[ax] * L->box_dim * strides[ax]; }
-      else all_local = 0;                    /* owned by another rank: that block keeps reading the ghost zone an exchange has filled */
-    }
+    const box_type *bx = &L->my_boxes[e->read.box];
+    const int bpos[3] = { bx->low.i / L->box_dim, bx->low.j / L->box_dim, bx->low.k / L->box_dim };
+    if (!hp_bc_entry_from_block(L, e->read.box, bpos, lo, len, e->subtype, find_own_box, L, &h[m++])) all_local = 0;
   }
   if (m + skipped != n) { fprintf(stderr, "hpgmg: boundary-condition block without a domain normal\n"); abort(); }
   *n_out = m; *all_local_out = all_local;
@@ -541,7 +489,7 @@ static hpgmg_hip_bc_entry *bc_entries_upload(hpgmg_hip_bc_entry *h, int n) {
   return d;
 }
 static const hpgmg_hip_bc_entry *bc_entries(level_type *L, int shape, int *n_out) {
-  backend_t *B = backend_of(L);
+  backend_t *B = hp_backend_of(L);
   const int n = L->boundary_condition.num_blocks[shape];
   *n_out = n;
   if (n <= 0) return NULL;
@@ -556,7 +504,7 @@ static const hpgmg_hip_bc_entry *bc_entries(level_type *L, int shape, int *n_out
 }
 /* the blocks of the stencil's shape whose domain normal has a k component (faces below / above the domain, i-k and j-k edges) */
 static const hpgmg_hip_bc_entry *bc_entries_k(level_type *L, int *n_out, int *all_local_out) {
-  backend_t *B = backend_of(L);
+  backend_t *B = hp_backend_of(L);
   if (B->n_bc_k < 0) {
     int m = 0;
     hpgmg_hip_bc_entry *h = bc_entries_host(L, stencil_get_shape(), 1, &m, &B->bc_k_local);
@@ -572,7 +520,7 @@ void apply_BCs_v2(level_type *L, int x_id, int shape) {                         
   if (L->box_dim < 2) { apply_BCs_v1(L, x_id, shape); return; }
   TICK(L, boundary_conditions, "apply_BCs_v2");
   int n = L->boundary_condition.num_blocks[shape];
-  { const hpgmg_hip_bc_entry *e = bc_entries(L, shape, &n); HIP_OK(hpgmg_hip_apply_bc_fv(&backend_of(L)->dev, x_id, e, n, 2)); }   /* clears the deeper layers first when there are any */
+  { const hpgmg_hip_bc_entry *e = bc_entries(L, shape, &n); HIP_OK(hpgmg_hip_apply_bc_fv(&hp_backend_of(L)->dev, x_id, e, n, 2)); }   /* clears the deeper layers first when there are any */
   TOCK();
 }
 void apply_BCs_v4(level_type *L, int x_id, int shape) {                                   /* boundary_fv.c:262-569 */
@@ -582,17 +530,16 @@ void apply_BCs_v4(level_type *L, int x_id, int shape) {                         
   if (L->box_dim < 4) { apply_BCs_v2(L, x_id, shape); return; }
   TICK(L, boundary_conditions, "apply_BCs_v4");
   int n = L->boundary_condition.num_blocks[shape];
-  { const hpgmg_hip_bc_entry *e = bc_entries(L, shape, &n); HIP_OK(hpgmg_hip_apply_bc_fv(&backend_of(L)->dev, x_id, e, n, 4)); }   /* clears the deeper layers first when there are any */
+  { const hpgmg_hip_bc_entry *e = bc_entries(L, shape, &n); HIP_OK(hpgmg_hip_apply_bc_fv(&hp_backend_of(L)->dev, x_id, e, n, 4)); }   /* clears the deeper layers first when there are any */
   TOCK();
 }
 void extrapolate_betas(level_type *L) {                                                    /* boundary_fv.c:573-681 */
   if (L->boundary_condition.type == BC_PERIODIC) return;
   TICK(L, boundary_conditions, "extrapolate_betas");
   const int n = L->boundary_condition.num_blocks[STENCIL_SHAPE_BOX];
-  HIP_OK(hpgmg_hip_extrapolate_betas(&backend_of(L)->dev, mirror(L, L->boundary_condition.blocks[STENCIL_SHAPE_BOX], n), n));
+  HIP_OK(hpgmg_hip_extrapolate_betas(&hp_backend_of(L)->dev, hp_mirror(L, L->boundary_condition.blocks[STENCIL_SHAPE_BOX], n), n));
   TOCK();
 }
-static int variant(void);
 /* operators/rebuild.c:47-208: probe with colors^3 0/1 colourings (exchange + BCs each time), accumulate on the device */
 void rebuild_operator_blackbox(level_type *L, double a, double b, int colors) {
   coef32_invalidate(L);
@@ -609,10 +556,10 @@ void rebuild_operator_blackbox(level_type *L, double a, double b, int colors) {
     color_vector(L, x_id, colors, ic, jc, kc);
     exchange_boundary(L, x_id, stencil_get_shape());
     apply_BCs(L, x_id, stencil_get_shape());
-    HIP_OK(hpgmg_hip_blackbox_accumulate(&backend_of(L)->dev, variant(), x_id, Aii_id, sum_id, a, b, h2inv));
+    HIP_OK(hpgmg_hip_blackbox_accumulate(&hp_backend_of(L)->dev, hp_variant(), x_id, Aii_id, sum_id, a, b, h2inv));
   }
   double lambda = -1e9;
-  HIP_OK(hpgmg_hip_blackbox_finalize(&backend_of(L)->dev, Aii_id, sum_id, a, b, h2inv, &lambda));
+  HIP_OK(hpgmg_hip_blackbox_finalize(&hp_backend_of(L)->dev, Aii_id, sum_id, a, b, h2inv, &lambda));
   if (L->my_rank == 0 && hpgmg_verbose) fprintf(stdout, "done\n");
   { const hpgmg_transport *T = hpgmg_get_transport();
     if (T && T->size > 1) { int r, *all = (int *)malloc((size_t)T->size * sizeof(int)); for (r = 0; r < T->size; r++) all[r] = r;
@@ -657,7 +604,7 @@ void hpgmg_level_sync_counters(level_type *L) {
  * leg 4: the whole F-cycle below levels[0] (right-hand side restricted down the chain, bottom solve, interpolation_fcycle + V-cycle per
  * level upwards); leg 5: only answer whether leg 4 would be accepted */
 static int vcycle_legs_fused(level_type **levels, int n, int e_id, int R_id, double a, double b, int leg);
-int hpgmg_vcycle_legs_fused(level_type **levels, int n, int e_id, int R_id, double a, double b, int leg) { lazy_flush(); return vcycle_legs_fused(levels, n, e_id, R_id, a, b, leg); }
+int hpgmg_vcycle_legs_fused(level_type **levels, int n, int e_id, int R_id, double a, double b, int leg) { hp_lazy_flush(); return vcycle_legs_fused(levels, n, e_id, R_id, a, b, leg); }
 /* The same for the 27-point / fv2 / fv4 plugins, leg 2 only (smooth ... bottom solve ... smooth as one launch): every level of the chain is ONE
  * box whose vectors fit the LDS (kernels/stencil.hip: small_vtail_kernel).  `7 8`: the levels of 8^3, 4^3, 2^3 (and 1^3) cells. */
 /* On by default except for the 27-point plugin with GSRB (HPGMG_SMALL_VTAIL=0 / 1, hpgmg_set_small_vtail(); bit-identical, tested both ways).
@@ -696,19 +643,19 @@ static int small_vtail_fused(level_type **levels, int n, int e_id, int R_id, dou
       if (C->num_sends + C->num_recvs > 0 || C->num_blocks[0] || C->num_blocks[1] || C->num_blocks[2]) return 0;      /* one box: nothing to exchange */
       if (CB->num_sends + CB->num_recvs > 0 || CB->num_blocks[0] || CB->num_blocks[1] || CB->num_blocks[2]) return 0;
     }
-    backend_t *B = backend_of(L);
+    backend_t *B = hp_backend_of(L);
     hpgmg_hip_small_tail_level *v = &T.lv[l];
     v->L = B->dev;
     v->h2inv = 1.0 / (L->h * L->h);
     v->n_bc = L->boundary_condition.num_blocks[shape];
-    v->bc_list = v->n_bc ? mirror(L, L->boundary_condition.blocks[shape], v->n_bc) : NULL;
+    v->bc_list = v->n_bc ? hp_mirror(L, L->boundary_condition.blocks[shape], v->n_bc) : NULL;
     if (cfg.op == HPGMG_OP_27PT) v->bc_kind = (L->box_dim < 2) ? 1 : 2;                                   /* as small_level_try / apply_BCs */
     else if (cfg.op == HPGMG_OP_FV2 || L->box_dim < 4) { v->bc_kind = (L->box_dim < 2) ? 1 : 3; v->zero_first = (v->bc_kind == 3 && L->box_ghosts > 1); }
     else { v->bc_kind = 4; v->zero_first = (L->box_ghosts > 2); }
     /* the conditions interpolation_vcycle applies to THIS level's correction before the level above reads it: apply_BCs_p2 (27-point) /
      * apply_BCs_v2 (fv2, fv4) over STENCIL_SHAPE_BOX */
     v->n_ibc = L->boundary_condition.num_blocks[STENCIL_SHAPE_BOX];
-    v->ibc_list = v->n_ibc ? mirror(L, L->boundary_condition.blocks[STENCIL_SHAPE_BOX], v->n_ibc) : NULL;
+    v->ibc_list = v->n_ibc ? hp_mirror(L, L->boundary_condition.blocks[STENCIL_SHAPE_BOX], v->n_ibc) : NULL;
     if (cfg.op == HPGMG_OP_27PT) v->ibc_kind = (L->box_dim < 2) ? 1 : 2;
     else { v->ibc_kind = (L->box_dim < 2) ? 1 : 3; v->ibc_zero_first = (v->ibc_kind == 3 && L->box_ghosts > 1); }
     if (v->n_bc > 32 || v->n_ibc > 32) return 0;
@@ -727,7 +674,7 @@ static int small_vtail_fused(level_type **levels, int n, int e_id, int R_id, dou
   }
   if (hpgmg_hip_small_vtail_lds_doubles(&T) > hpgmg_hip_small_vtail_lds_limit()) return 0;
   TICK(levels[0], smooth, "fused V-cycle tail (levels of one box)");
-  HIP_OK(hpgmg_hip_small_vtail(&T, variant()));
+  HIP_OK(hpgmg_hip_small_vtail(&T, hp_variant()));
   TOCK();
   small_vtails++;
   return 1;
@@ -752,7 +699,7 @@ static int vcycle_legs_fused(level_type **levels, int n, int e_id, int R_id, dou
     if (leg == 0 || leg == 1) return small_vtail_fused(levels, n, e_id, R_id, a, b, leg == 0 ? 1 : 4);
     return 0;
   }
-  if (!enabled || !ghost_free_mode() || cfg.op != HPGMG_OP_7PT || n > 8 || n > hpgmg_hip_tail_max_levels() || sweeps > 8) return 0;
+  if (!enabled || !hp_ghost_free_mode() || cfg.op != HPGMG_OP_7PT || n > 8 || n > hpgmg_hip_tail_max_levels() || sweeps > 8) return 0;
   if (with_bottom && !bottom_enabled) return 0;
   if (n < (leg == 3 ? 1 : 2)) return 0;
   if (leg >= 4) { static int ftail = -1; if (ftail < 0) { const char *e = getenv("HPGMG_FUSED_FTAIL"); ftail = !(e && e[0] == '0'); } if (!ftail) return 0; }
@@ -760,7 +707,7 @@ static int vcycle_legs_fused(level_type **levels, int n, int e_id, int R_id, dou
    * how the coarse levels end up after agglomeration onto rank 0 -- no message and no all-reduce is needed then */
   for (l = 0; l < n; l++) {
     level_type *L = levels[l];
-    backend_t *B = backend_of(L);
+    backend_t *B = hp_backend_of(L);
     const long long cells = (long long)L->dim.i * L->dim.j * L->dim.k;
     if (!L->active || L->num_my_boxes < 1 || !B->all_faces_local) return 0;
     /* the kernel addresses cells by global coordinate: cubic Dirichlet domain, boxes in lexicographic order, halving per level */
@@ -795,8 +742,8 @@ static int vcycle_legs_fused(level_type **levels, int n, int e_id, int R_id, dou
   }
   if (leg == 5) return 1;
   TICK(levels[0], smooth, leg == 3 ? "bottom solve (device BiCGStab)" : (leg == 4 ? "fused F-cycle tail" : "fused V-cycle tail"));
-  HIP_OK(hpgmg_hip_vcycle_tail(n, dev, h2inv, c1, c2, sweeps, variant(), cfg.smoother, e_id, R_id, a, b, leg,
-                               hpgmg_vectors_reserved(), MG_DEFAULT_BOTTOM_NORM, with_bottom ? backend_of(levels[n - 1])->krylov_pinned : NULL));
+  HIP_OK(hpgmg_hip_vcycle_tail(n, dev, h2inv, c1, c2, sweeps, hp_variant(), cfg.smoother, e_id, R_id, a, b, leg,
+                               hpgmg_vectors_reserved(), MG_DEFAULT_BOTTOM_NORM, with_bottom ? hp_backend_of(levels[n - 1])->krylov_pinned : NULL));
   TOCK();
   return 1;
 #undef enabled
@@ -806,7 +753,7 @@ static int vcycle_legs_fused(level_type **levels, int n, int e_id, int R_id, dou
 /* every box of the level is local and local box b sits at lexicographic position b (what the kernels that address
  * cells by global coordinate assume) */
 static int boxes_lexicographic(level_type *L) {
-  backend_t *B = backend_of(L);
+  backend_t *B = hp_backend_of(L);
   if (B->lexicographic < 0) {
     int bx, ok = (L->num_my_boxes == L->boxes_in.i * L->boxes_in.j * L->boxes_in.k);
     for (bx = 0; ok && bx < L->num_my_boxes; bx++) {
@@ -829,7 +776,7 @@ int hpgmg_get_smoother_precision(void) {
   return smoother_bits;
 }
 static const float *const *coef32_of(level_type *L) {
-  backend_t *B = backend_of(L);
+  backend_t *B = hp_backend_of(L);
   if (hpgmg_get_smoother_precision() != 32) return NULL;
   if (!B->coef32) {
     int bx;
@@ -847,7 +794,7 @@ static const float *const *coef32_of(level_type *L) {
   if (!B->coef32_valid) { HIP_OK(hpgmg_hip_coef32_refresh(&B->dev, (float *const *)B->d_coef32_base, L->numVectors)); B->coef32_valid = 1; }
   return (const float *const *)B->d_coef32_base;
 }
-static void coef32_invalidate(level_type *L) { backend_t *B = backend_of(L); B->coef32_valid = 0; if (B->halo) B->halo->coef_valid = 0; }
+static void coef32_invalidate(level_type *L) { backend_t *B = hp_backend_of(L); B->coef32_valid = 0; if (B->halo) B->halo->coef_valid = 0; hp_images_invalidate_coefficients(B); }
 
 /* ---------------------------------------------------------------- sweep pairs across rank boundaries: halo plans */
 static int pair_remote_enabled(void) {
@@ -855,7 +802,7 @@ static int pair_remote_enabled(void) {
   if (on < 0) { const char *e = getenv("HPGMG_PAIR_REMOTE"); on = !(e && e[0] == '0'); }
   return on;
 }
-static int box_rank_at(const level_type *L, int bi, int bj, int bk) {           /* -1 outside the (non-periodic) domain */
+int hp_box_rank_at(const level_type *L, int bi, int bj, int bk) {           /* -1 outside the (non-periodic) domain */
   if (bi < 0 || bj < 0 || bk < 0 || bi >= L->boxes_in.i || bj >= L->boxes_in.j || bk >= L->boxes_in.k) return -1;
   return L->rank_of_box[bi + L->boxes_in.i * (bj + L->boxes_in.j * bk)];
 }
@@ -870,7 +817,7 @@ static int every_rank_owns_a_brick(const level_type *L, int lo[3], int n[3]) {
   for (bk = 0; bk < L->boxes_in.k; bk++) for (bj = 0; bj < L->boxes_in.j; bj++) for (bi = 0; bi < L->boxes_in.i; bi++) {
     const int c[3] = { bi, bj, bk };
     int a;
-    r = box_rank_at(L, bi, bj, bk);
+    r = hp_box_rank_at(L, bi, bj, bk);
     if (r < 0 || r >= nr) { ok = 0; continue; }
     cnt[r]++;
     for (a = 0; a < 3; a++) { if (c[a] < mn[3 * r + a]) mn[3 * r + a] = c[a]; if (c[a] > mx[3 * r + a]) mx[3 * r + a] = c[a]; }
@@ -940,11 +887,11 @@ static pair_halo *pair_halo_build(level_type *L, const int lo[3], const int n[3]
       const int order = (d[0] != 0) + (d[1] != 0) + (d[2] != 0);
       if (order != 1 && order != 2) continue;
       if (which == HALO_COEF && order != 1) continue;
-      const int M = box_rank_at(L, bi, bj, bk), S = box_rank_at(L, bi + d[0], bj + d[1], bk + d[2]);
+      const int M = hp_box_rank_at(L, bi, bj, bk), S = hp_box_rank_at(L, bi + d[0], bj + d[1], bk + d[2]);
       if (M < 0 || S < 0 || M == S || (M != me && S != me)) continue;
       if (order == 2) {   /* an edge value is read only where BOTH faces it touches belong to other ranks (a Dirichlet face overrides it) */
         int need = 1;
-        for (a = 0; a < 3; a++) if (d[a]) { const int r = box_rank_at(L, bi + (a == 0 ? d[0] : 0), bj + (a == 1 ? d[1] : 0), bk + (a == 2 ? d[2] : 0)); if (r < 0 || r == M) need = 0; }
+        for (a = 0; a < 3; a++) if (d[a]) { const int r = hp_box_rank_at(L, bi + (a == 0 ? d[0] : 0), bj + (a == 1 ? d[1] : 0), bk + (a == 2 ? d[2] : 0)); if (r < 0 || r == M) need = 0; }
         if (!need) continue;
       }
       const int recv_id = bi + L->boxes_in.i * (bj + L->boxes_in.j * bk);
@@ -1037,7 +984,7 @@ static int pair_halo_ready(level_type *L, backend_t *B) {
       const int ci = X->low.i / L->box_dim - lo[0], cj = X->low.j / L->box_dim - lo[1], ck = X->low.k / L->box_dim - lo[2];
       if (ci + n[0] * (cj + n[1] * ck) != b) ok = 0;
     }
-    if (ok && !hpgmg_hip_smooth_cheby_pair_supported_brick(&B->dev, variant(), n[0], n[1], n[2])) ok = 0;
+    if (ok && !hpgmg_hip_smooth_cheby_pair_supported_brick(&B->dev, hp_variant(), n[0], n[1], n[2])) ok = 0;
     if (ok) { B->halo = pair_halo_build(L, lo, n); B->halo_state = 1; }
   }
   return B->halo_state > 0;
@@ -1064,7 +1011,7 @@ static long long pair_remote_smooths = 0;
 long long hpgmg_pair_remote_smooths(void) { return pair_remote_smooths; }   /* smooth() calls done as sweep pairs with remote faces (tests) */
 
 /* the two plugin-private vectors per box that hold x1, x2 of the first sweep pair of a smooth() */
-static void ensure_pair_scratch(level_type *L, backend_t *B) {
+void hp_ensure_pair_scratch(level_type *L, backend_t *B) {
   if (!B->pair_scratch) {
     int bx;
     double **base = (double **)calloc((size_t)L->num_my_boxes, sizeof(double *));
@@ -1085,10 +1032,10 @@ static int pair_kernel_ready(level_type *L, int x_id, int rhs_id, int sweeps) {
   if (fused_sweeps < 0) { const char *e = getenv("HPGMG_FUSED_SWEEPS"); fused_sweeps = !(e && e[0] == '0'); }
   hpgmg_config cfg;
   hpgmg_get_config(&cfg);
-  backend_t *B = backend_of(L);
-  if (!fused_sweeps || sweeps != 4 || cfg.op != HPGMG_OP_7PT || !ghost_free_mode() || stencil_get_shape() != STENCIL_SHAPE_STAR) return 0;
+  backend_t *B = hp_backend_of(L);
+  if (!fused_sweeps || sweeps != 4 || cfg.op != HPGMG_OP_7PT || !hp_ghost_free_mode() || stencil_get_shape() != STENCIL_SHAPE_STAR) return 0;
   if (L->boundary_condition.type != BC_DIRICHLET || x_id == VECTOR_TEMP || rhs_id == VECTOR_TEMP) return 0;
-  if (B->all_faces_local) { if (!hpgmg_hip_smooth_cheby_pair_supported(&B->dev, variant()) || !boxes_lexicographic(L)) return 0; }
+  if (B->all_faces_local) { if (!hpgmg_hip_smooth_cheby_pair_supported(&B->dev, hp_variant()) || !boxes_lexicographic(L)) return 0; }
   else if (!pair_halo_ready(L, B)) return 0;          /* faces owned by other ranks: two-deep halo, one exchange per pair */
   { /* the pass structure pays when the level is bandwidth bound; a cache-resident level (128^3 and smaller) is latency
      * bound and faster with many small single-sweep workgroups (measured: 128^3 pair 80 us vs 2 x 27 us) */
@@ -1096,7 +1043,7 @@ static int pair_kernel_ready(level_type *L, int x_id, int rhs_id, int sweeps) {
     if (min_cells < 0) { const char *e = getenv("HPGMG_PAIR_MIN_CELLS"); min_cells = (e && *e) ? atoll(e) : 4000000; }
     if ((long long)L->dim.i * L->dim.j * L->dim.k < min_cells) return 0;
   }
-  ensure_pair_scratch(L, B);
+  hp_ensure_pair_scratch(L, B);
   hpgmg_hip_set_ghost_free(1);
   return 1;
 }
@@ -1108,14 +1055,14 @@ static int smooth_cheby_tile_pairs(level_type *L, int x_id, int rhs_id, double a
   hpgmg_config cfg;
   hpgmg_get_config(&cfg);
   if (fused_sweeps < 0) { const char *e = getenv("HPGMG_FUSED_SWEEPS"); fused_sweeps = !(e && e[0] == '0'); }
-  if (!fused_sweeps || sweeps != 4 || cfg.op != HPGMG_OP_7PT || !ghost_free_mode() || stencil_get_shape() != STENCIL_SHAPE_STAR) return 0;
+  if (!fused_sweeps || sweeps != 4 || cfg.op != HPGMG_OP_7PT || !hp_ghost_free_mode() || stencil_get_shape() != STENCIL_SHAPE_STAR) return 0;
   if (L->boundary_condition.type != BC_DIRICHLET || x_id == VECTOR_TEMP || rhs_id == VECTOR_TEMP || L->num_my_boxes < 1) return 0;
-  backend_t *B = backend_of(L);
-  if (!B->all_faces_local || !hpgmg_hip_smooth_cheby_pair_tile_supported(&B->dev, variant())) return 0;
-  ensure_pair_scratch(L, B);
+  backend_t *B = hp_backend_of(L);
+  if (!B->all_faces_local || !hpgmg_hip_smooth_cheby_pair_tile_supported(&B->dev, hp_variant())) return 0;
+  hp_ensure_pair_scratch(L, B);
   hpgmg_hip_set_ghost_free(1);
   const double h2inv = 1.0 / (L->h * L->h);
-  const int v = variant();
+  const int v = hp_variant();
   { TICK(L, smooth, "smooth (Chebyshev sweeps 1+2, tiles)");
     HIP_OK(hpgmg_hip_smooth_cheby_pair_tile(&B->dev, v, (double *const *)B->d_pair_base, 0, x_id, 0, VECTOR_TEMP, 1, 0, 1, 1, rhs_id, a, b, h2inv, c1[0], c2[0], c1[1], c2[1], 1));
     TOCK(); }
@@ -1132,9 +1079,9 @@ static int smooth_cheby_tile_pairs(level_type *L, int x_id, int rhs_id, double a
  * pair does not store it */
 static int smooth_cheby_pairs(level_type *L, int x_id, int rhs_id, double a, double b, const double *c1, const double *c2, int sweeps) {
   if (!pair_kernel_ready(L, x_id, rhs_id, sweeps)) return 0;
-  backend_t *B = backend_of(L);
+  backend_t *B = hp_backend_of(L);
   const double h2inv = 1.0 / (L->h * L->h);
-  const int v = variant();
+  const int v = hp_variant();
   const int remote = !B->all_faces_local;
   const float *const *c32 = remote ? NULL : coef32_of(L);      /* across ranks the coefficient streams stay fp64 */
   if (remote) { pair_remote_smooths++; pair_halo_before_launch(L, B, 1, 0, x_id, 0, VECTOR_TEMP, rhs_id); }
@@ -1152,9 +1099,9 @@ static int smooth_cheby_pairs(level_type *L, int x_id, int rhs_id, double a, dou
  * x_id -> private vector -> x_id; VECTOR_TEMP is not touched, as in the reference's in-place form */
 static int smooth_gsrb_pairs(level_type *L, int x_id, int rhs_id, double a, double b, int sweeps) {
   if (hpgmg_gsrb_out_of_place() || !pair_kernel_ready(L, x_id, rhs_id, sweeps)) return 0;
-  backend_t *B = backend_of(L);
+  backend_t *B = hp_backend_of(L);
   const double h2inv = 1.0 / (L->h * L->h);
-  const int v = variant();
+  const int v = hp_variant();
   const int remote = !B->all_faces_local;
   if (remote) { pair_remote_smooths++; pair_halo_before_launch(L, B, 1, 0, x_id, 0, x_id, rhs_id); }
   { TICK(L, smooth, "smooth (GSRB half sweeps 1+2)");
@@ -1172,7 +1119,7 @@ static int smooth_gsrb_pairs(level_type *L, int x_id, int rhs_id, double a, doub
  * Same iterate (e = x4) as the two separate operators; VECTOR_TEMP (their x3) is left unspecified -- nothing in a cycle reads it
  * (HPGMG_TEMP_SCRATCH=0 stores it as smooth() does).  0 = not applicable. */
 static int interp_smooth_fused(level_type *Lf, int e_id, int R_id, level_type *Lc, double a, double b, int exact_state);
-int hpgmg_interp_smooth_fused(level_type *Lf, int e_id, int R_id, level_type *Lc, double a, double b) { lazy_flush(); return interp_smooth_fused(Lf, e_id, R_id, Lc, a, b, 0); }
+int hpgmg_interp_smooth_fused(level_type *Lf, int e_id, int R_id, level_type *Lc, double a, double b) { hp_lazy_flush(); return interp_smooth_fused(Lf, e_id, R_id, Lc, a, b, 0); }
 /* exact_state: VECTOR_TEMP is left as smooth() leaves it (the lazy queue runs behind the reference's own driver, which promises nothing about it) */
 static int interp_smooth_fused(level_type *Lf, int e_id, int R_id, level_type *Lc, double a, double b, int exact_state) {
   hpgmg_config cfg;
@@ -1183,10 +1130,10 @@ static int interp_smooth_fused(level_type *Lf, int e_id, int R_id, level_type *L
   if (cfg.smoother != HPGMG_SMOOTH_CHEBY && !(cfg.smoother == HPGMG_SMOOTH_GSRB && !hpgmg_gsrb_out_of_place())) return 0;
   if (S->num_sends || S->num_recvs || Rv->num_sends || Rv->num_recvs || S->num_blocks[0] || Rv->num_blocks[2]) return 0;   /* all parents local */
   if (Lf->box_dim % 128 != 0 || Lc->box_dim * 2 != Lf->box_dim || Lc->num_my_boxes != Lf->num_my_boxes || !boxes_lexicographic(Lc)) return 0;
-  if (!backend_of(Lf)->all_faces_local) return 0;       /* across ranks the pair kernel takes x0 as stored (interpolation stays its own launch) */
+  if (!hp_backend_of(Lf)->all_faces_local) return 0;       /* across ranks the pair kernel takes x0 as stored (interpolation stays its own launch) */
   if (!pair_kernel_ready(Lf, e_id, R_id, sweeps)) return 0;
   if (cfg.smoother == HPGMG_SMOOTH_CHEBY && Lf->dominant_eigenvalue_of_DinvA <= 0.0) return 0;
-  hpgmg_hip_pair_fold_interpolation(&backend_of(Lc)->dev, e_id, 1.0);
+  hpgmg_hip_pair_fold_interpolation(&hp_backend_of(Lc)->dev, e_id, 1.0);
   if (cfg.smoother == HPGMG_SMOOTH_CHEBY) {
     double c1[16], c2[16];
     cheby_coefficients(Lf, sweeps, c1, c2);
@@ -1243,12 +1190,12 @@ static int small_level_try(level_type *L, int mode, int x_id, int rhs_id, int re
   if (mode == 0) cheby_coefficients(L, sweeps, c1, c2);
   if (mode == 2) for (q = 0; q < sweeps; q++) c2[q] = 2.0 / 3.0;
   if (sweeps > 8) return 0;
-  backend_t *B = backend_of(L);
+  backend_t *B = hp_backend_of(L);
   const double t_h2inv = 1.0 / (L->h * L->h);
   hpgmg_tick tk = hpgmg_tick_begin(L, mode <= 2 ? &L->timers.smooth : (mode == 3 ? &L->timers.residual : &L->timers.apply_op), "small level, one launch");
-  HIP_OK(hpgmg_hip_small_level_op(&B->dev, variant(), mode, sweeps, x_id, rhs_id, res_id, mode == 1 ? hpgmg_gsrb_out_of_place() : 0, a, b, t_h2inv, c1, c2,
-                                  mirror(L, C->blocks[1], C->num_blocks[1]), C->num_blocks[1],
-                                  n_bc ? mirror(L, L->boundary_condition.blocks[shape], n_bc) : NULL, n_bc, bc_kind, zero_first));
+  HIP_OK(hpgmg_hip_small_level_op(&B->dev, hp_variant(), mode, sweeps, x_id, rhs_id, res_id, mode == 1 ? hpgmg_gsrb_out_of_place() : 0, a, b, t_h2inv, c1, c2,
+                                  hp_mirror(L, C->blocks[1], C->num_blocks[1]), C->num_blocks[1],
+                                  n_bc ? hp_mirror(L, L->boundary_condition.blocks[shape], n_bc) : NULL, n_bc, bc_kind, zero_first));
   hpgmg_tick_end(tk);
   return 1;
 }
@@ -1272,13 +1219,13 @@ int hpgmg_bottom_solve_fused(level_type *L, int e_id, int R_id, double a, double
   if (cfg.op == HPGMG_OP_27PT) bc_kind = (L->box_dim < 2) ? 1 : 2;                                    /* as small_level_try / apply_BCs */
   else if (cfg.op == HPGMG_OP_FV2 || L->box_dim < 4) { bc_kind = (L->box_dim < 2) ? 1 : 3; zero_first = (bc_kind == 3 && L->box_ghosts > 1); }
   else { bc_kind = 4; zero_first = (L->box_ghosts > 2); }
-  lazy_flush();
-  backend_t *B = backend_of(L);
+  hp_lazy_flush();
+  backend_t *B = hp_backend_of(L);
   if (!B->krylov_pinned) { B->krylov_pinned = (int *)hpgmg_hip_host_malloc(64); if (B->krylov_pinned) *B->krylov_pinned = 0; }
   if (!B->krylov_pinned) return 0;
   hpgmg_tick tk = hpgmg_tick_begin(L, &L->timers.Total, "bottom solve, one launch");
-  HIP_OK(hpgmg_hip_bottom_bicgstab(&B->dev, variant(), e_id, R_id, hpgmg_vectors_reserved(), a, b, 1.0 / (L->h * L->h), want,
-                                   n_bc ? mirror(L, L->boundary_condition.blocks[shape], n_bc) : NULL, n_bc, bc_kind, zero_first, B->krylov_pinned));
+  HIP_OK(hpgmg_hip_bottom_bicgstab(&B->dev, hp_variant(), e_id, R_id, hpgmg_vectors_reserved(), a, b, 1.0 / (L->h * L->h), want,
+                                   n_bc ? hp_mirror(L, L->boundary_condition.blocks[shape], n_bc) : NULL, n_bc, bc_kind, zero_first, B->krylov_pinned));
   hpgmg_tick_end(tk);
   return 1;
 }
@@ -1290,7 +1237,7 @@ int hpgmg_smooth_in_cycle(level_type *L, int x_id, int rhs_id, double a, double 
   static int on = -1;
   if (on < 0) { const char *e = getenv("HPGMG_TEMP_SCRATCH"); on = !(e && e[0] == '0'); }
   temp_is_scratch = on;
-  lazy_flush();
+  hp_lazy_flush();
   do_smooth(L, x_id, rhs_id, a, b);
   temp_is_scratch = 0;
   return 1;
@@ -1299,7 +1246,8 @@ int hpgmg_smooth_in_cycle(level_type *L, int x_id, int rhs_id, double a, double 
  * (kernels/fv4_rb.hpp) instead of gsrb.c:24-132's two.  The passes go x -> TEMP -> private vector 0 -> x (an odd number of passes cannot
  * ping-pong between two vectors); private vector 1 lends its k ghost planes to the intermediate vector's boundary values (the pre-pass).
  * 0 = not applicable, the caller runs the half sweeps one by one. */
-static long long fv4_rb_smooths = 0;
+static long long fv4_rb_smooths = 0, rb27_smooth_passes = 0;
+long long hpgmg_rb27_passes(void) { return rb27_smooth_passes; }      /* red + black passes of the 27-point GSRB smoother so far (tests) */
 long long hpgmg_fv4_rb_smooths(void) { return fv4_rb_smooths; }
 static void fv4_rb_bcs(level_type *L, backend_t *B, int scratch, int id) {           /* apply_BCs_v4 on the pass's input (neighbouring boxes are read where they live) */
   const int shape = stencil_get_shape();
@@ -1351,23 +1299,30 @@ static void do_scale_vector(level_type *L, int c, double s, int a);
 static int smooth_fv4_rb(level_type *L, int x_id, int rhs_id, double a, double b, int sweeps) {
   hpgmg_config cfg;
   hpgmg_get_config(&cfg);
-  backend_t *B = backend_of(L);
-  const int passes = sweeps / 2, v = variant();
-  if (cfg.op != HPGMG_OP_FV4 || !hpgmg_gsrb_out_of_place() || !temp_is_scratch || !ghost_free_mode() || (sweeps & 1) || passes < 1) return 0;
-  if (L->num_my_boxes < 1 || !B->all_faces_local || x_id == VECTOR_TEMP || rhs_id == VECTOR_TEMP || L->box_dim < 8) return 0;
-  if (!hpgmg_hip_smooth_gsrb_fv4_rb_supported(&B->dev, v)) return 0;
+  backend_t *B = hp_backend_of(L);
+  const int passes = sweeps / 2, v = hp_variant();
+  if (cfg.op != HPGMG_OP_FV4 || !hpgmg_gsrb_out_of_place() || !temp_is_scratch || !hp_ghost_free_mode() || (sweeps & 1) || passes < 1) return 0;
+  if (L->num_my_boxes < 1 || x_id == VECTOR_TEMP || rhs_id == VECTOR_TEMP || L->box_dim < 8) return 0;
+  /* boxes on other ranks: the same passes on the table with their images (halo_images.c) -- x three cells deep once per PASS, i.e. one
+   * exchange per sweep where the reference has two (gsrb.c:30-33), the cells next to the faces recomputed from the owner's inputs */
+  const int images = !B->all_faces_local;
+  if (images && !hp_images_ready(L, B)) return 0;
+  const hpgmg_hip_level *dev = images ? &B->img->dev : &B->dev;
+  if (!hpgmg_hip_smooth_gsrb_fv4_rb_supported(dev, v)) return 0;
   int n_k = 0, k_local = 1, n_all = 0, p;
   const hpgmg_hip_bc_entry *e_k = NULL;
-  if (L->boundary_condition.type != BC_PERIODIC) {
+  if (images) e_k = hp_images_bc_k(L, B, &n_k);
+  else if (L->boundary_condition.type != BC_PERIODIC) {
     e_k = bc_entries_k(L, &n_k, &k_local);
     (void)bc_entries(L, stencil_get_shape(), &n_all);
     if (!k_local || !B->bc_sources_local[stencil_get_shape()]) return 0;
   }
-  ensure_pair_scratch(L, B);
+  hp_ensure_pair_scratch(L, B);
+  double *const *pair_base = images ? (double *const *)B->img->d_pair_base : (double *const *)B->d_pair_base;
   hpgmg_hip_set_tile_ghost_free(1);
   const double h2inv = 1.0 / (L->h * L->h);
   int n_sp = 0;
-  const int *sp_cells = fv4_special_cells(L, B, &n_sp);
+  const int *sp_cells = images ? hp_images_fv4_special(L, B, &n_sp) : fv4_special_cells(L, B, &n_sp);
   /* (scratch, id) of the iterate before pass p: x, then TEMP / x alternately; an odd count routes its second pass through private vector 0 */
   int src_s = 0, src_id = x_id;
   for (p = 0; p < passes; p++) {
@@ -1377,10 +1332,12 @@ static int smooth_fv4_rb(level_type *L, int x_id, int rhs_id, double a, double b
     else if (left == 2 && !(src_s == 0 && src_id == x_id)) { dst_s = 1; dst_id = 0; }    /* two to go and not standing on x: step aside so that the last pass can land on x */
     else dst_id = (src_s == 0 && src_id == VECTOR_TEMP) ? x_id : VECTOR_TEMP;
     if (left == 2 && src_s == 0 && src_id == x_id) dst_id = VECTOR_TEMP;
-    fv4_rb_bcs(L, B, src_s, src_id);
+    if (images) hp_images_refresh(L, B, src_s, src_id, 3, p == 0 ? rhs_id : -1, 4);
+    else fv4_rb_bcs(L, B, src_s, src_id);
     TICK(L, smooth, "smooth (fv4 GSRB, red + black half sweeps in one pass)");
-    HIP_OK(hpgmg_hip_fv4_rb_prepass(&B->dev, v, (double *const *)B->d_pair_base, src_s, src_id, 1, rhs_id, a, b, h2inv, 2 * p, e_k, n_k, sp_cells, n_sp));
-    HIP_OK(hpgmg_hip_smooth_gsrb_fv4_rb(&B->dev, v, (double *const *)B->d_pair_base, src_s, src_id, dst_s, dst_id, 1, rhs_id, a, b, h2inv, 2 * p));
+    /* the pre-pass also works on the images next to the k walls: the main kernel reads the intermediate vector's ghost planes in their columns */
+    HIP_OK(hpgmg_hip_fv4_rb_prepass(images ? &B->img->dev_all : dev, v, pair_base, src_s, src_id, 1, rhs_id, a, b, h2inv, 2 * p, e_k, n_k, sp_cells, n_sp));
+    HIP_OK(hpgmg_hip_smooth_gsrb_fv4_rb(dev, v, pair_base, src_s, src_id, dst_s, dst_id, 1, rhs_id, a, b, h2inv, 2 * p));
     TOCK();
     src_s = dst_s; src_id = dst_id;
   }
@@ -1391,9 +1348,9 @@ static int smooth_fv4_rb(level_type *L, int x_id, int rhs_id, double a, double b
 static void do_smooth(level_type *L, int x_id, int rhs_id, double a, double b) {
   hpgmg_config cfg;
   hpgmg_get_config(&cfg);
-  const int sweeps = hpgmg_smooth_sweeps(), v = variant();
+  const int sweeps = hpgmg_smooth_sweeps(), v = hp_variant();
   const double h2inv = 1.0 / (L->h * L->h);
-  backend_t *B = backend_of(L);
+  backend_t *B = hp_backend_of(L);
   int s;
   if (cfg.op != HPGMG_OP_7PT && small_level_try(L, cfg.smoother == HPGMG_SMOOTH_CHEBY ? 0 : (cfg.smoother == HPGMG_SMOOTH_GSRB ? 1 : 2), x_id, rhs_id, x_id, a, b)) return;
   if (cfg.smoother == HPGMG_SMOOTH_CHEBY) {          /* chebyshev.c:8-100 */
@@ -1404,25 +1361,31 @@ static void do_smooth(level_type *L, int x_id, int rhs_id, double a, double b) {
     if (smooth_cheby_tile_pairs(L, x_id, rhs_id, a, b, c1, c2, sweeps)) return;
     for (s = 0; s < sweeps; s++) {
       const int src = (s & 1) ? VECTOR_TEMP : x_id, dst = (s & 1) ? x_id : VECTOR_TEMP;
-      STENCIL_WITH_GHOSTS(L, src, dst, smooth, hpgmg_hip_smooth_cheby(&B->dev, v, src, dst, rhs_id, a, b, h2inv, c1[s], c2[s]));
+      STENCIL_WITH_GHOSTS(L, src, dst, smooth, hpgmg_hip_smooth_cheby(hp_stencil_dev(B), v, src, dst, rhs_id, a, b, h2inv, c1[s], c2[s]));
     }
   } else if (cfg.smoother == HPGMG_SMOOTH_GSRB) {    /* gsrb.c:24-132 */
     const int oop = hpgmg_gsrb_out_of_place();
     if (smooth_gsrb_pairs(L, x_id, rhs_id, a, b, sweeps)) return;
     /* 27-point, inside a cycle (VECTOR_TEMP is scratch afterwards): each red + black pair of half sweeps as one pass, x -> TEMP -> x.
      * The state the exported smooth() must leave in VECTOR_TEMP (the iterate before the last half sweep) never exists in this form. */
-    if (cfg.op == HPGMG_OP_27PT && oop && temp_is_scratch && ghost_free_mode() && sweeps % 4 == 0 && L->num_my_boxes > 0 && B->all_faces_local &&
-        x_id != VECTOR_TEMP && rhs_id != VECTOR_TEMP) {
-      const int tiled = hpgmg_hip_smooth_gsrb27_rb_supported(&B->dev);                          /* boxes of side 64 m: marching tiles */
-      const int boxed = !tiled && hpgmg_hip_smooth_gsrb27_rb_box_supported(&B->dev);   /* boxes of 2^3 ... 16^3: one workgroup per box */
+    if (cfg.op == HPGMG_OP_27PT && oop && temp_is_scratch && hp_ghost_free_mode() && sweeps % 4 == 0 && L->num_my_boxes > 0 &&
+        (B->all_faces_local || hp_images_ready(L, B)) && x_id != VECTOR_TEMP && rhs_id != VECTOR_TEMP) {
+      /* boxes on other ranks: the same pass on the table with their images -- x two cells deep once per pass (one exchange per sweep instead of
+       * gsrb.c:30-33's two), the intermediate vector on the cells around a box recomputed from the owner's x, right-hand side and D^{-1} */
+      const int images = !B->all_faces_local;
+      const hpgmg_hip_level *dev = images ? &B->img->dev : &B->dev;
+      const int tiled = hpgmg_hip_smooth_gsrb27_rb_supported(dev);                          /* boxes of side 64 m: marching tiles */
+      const int boxed = !tiled && hpgmg_hip_smooth_gsrb27_rb_box_supported(dev);   /* boxes of 2^3 ... 16^3: one workgroup per box */
       if (tiled || boxed) {
         for (s = 0; s < sweeps; s += 2) {
           const int src = (s & 2) ? VECTOR_TEMP : x_id, dst = (s & 2) ? x_id : VECTOR_TEMP;
-          if (tiled && !exchange_and_bcs_one_launch(L, src, stencil_get_shape(), 12, 0)) apply_BCs(L, src, stencil_get_shape());
+          if (images) hp_images_refresh(L, B, 0, src, 2, s == 0 ? rhs_id : -1, 12);
+          else if (tiled && !exchange_and_bcs_one_launch(L, src, stencil_get_shape(), 12, 0)) apply_BCs(L, src, stencil_get_shape());
           TICK(L, smooth, "smooth (27-point GSRB, red + black half sweeps in one pass)");
-          if (tiled) HIP_OK(hpgmg_hip_smooth_gsrb27_rb(&B->dev, src, dst, rhs_id, a, b, h2inv, s));
-          else       HIP_OK(hpgmg_hip_smooth_gsrb27_rb_box(&B->dev, src, dst, rhs_id, a, b, h2inv, s));
+          if (tiled) HIP_OK(hpgmg_hip_smooth_gsrb27_rb(dev, src, dst, rhs_id, a, b, h2inv, s));
+          else       HIP_OK(hpgmg_hip_smooth_gsrb27_rb_box(dev, src, dst, rhs_id, a, b, h2inv, s));
           TOCK();
+          rb27_smooth_passes++;
         }
         return;
       }
@@ -1443,7 +1406,7 @@ static void do_smooth(level_type *L, int x_id, int rhs_id, double a, double b) {
     }
     /* fv4 on a level of small boxes (4^3 ... 16^3, all local): a half sweep as ONE launch -- x outside a box read where it lives, the boundary
      * conditions of the result applied by the same launch (kernels/stencil.hip: fv4_box_gsrb_kernel) -- instead of two */
-    if (!first_half_sweep && cfg.op == HPGMG_OP_FV4 && oop && !(sweeps & 1) && ghost_free_mode() && B->all_faces_local && L->box_dim >= 4 && x_id != VECTOR_TEMP && rhs_id != VECTOR_TEMP &&
+    if (!first_half_sweep && cfg.op == HPGMG_OP_FV4 && oop && !(sweeps & 1) && hp_ghost_free_mode() && B->all_faces_local && L->box_dim >= 4 && x_id != VECTOR_TEMP && rhs_id != VECTOR_TEMP &&
         L->boundary_condition.type == BC_DIRICHLET && hpgmg_hip_smooth_gsrb_fv4_box_supported(&B->dev, v)) {
       const int shape = stencil_get_shape(), n_bc = L->boundary_condition.num_blocks[shape];
       if (!B->d_bc_start[shape]) {
@@ -1459,7 +1422,7 @@ static void do_smooth(level_type *L, int x_id, int rhs_id, double a, double b) {
         HIP_OK(hpgmg_hip_memcpy_h2d(B->d_bc_start[shape], start, ((size_t)L->num_my_boxes + 1) * sizeof(int)));
         free(start);
       }
-      const blockCopy_type *by_box = n_bc ? mirror(L, B->h_bc_by_box[shape], n_bc) : NULL;
+      const blockCopy_type *by_box = n_bc ? hp_mirror(L, B->h_bc_by_box[shape], n_bc) : NULL;
       if (!exchange_and_bcs_one_launch(L, x_id, shape, 4, 0)) apply_BCs(L, x_id, shape);      /* the domain-boundary ghost cells the first half sweep reads */
       for (s = 0; s < sweeps; s++) {
         const int src = (s & 1) ? VECTOR_TEMP : x_id, dst = (s & 1) ? x_id : VECTOR_TEMP;
@@ -1471,34 +1434,34 @@ static void do_smooth(level_type *L, int x_id, int rhs_id, double a, double b) {
     }
     for (s = first_half_sweep; s < sweeps; s++) {
       const int src = (oop && (s & 1)) ? VECTOR_TEMP : x_id, dst = oop ? ((s & 1) ? x_id : VECTOR_TEMP) : x_id;
-      STENCIL_WITH_GHOSTS(L, src, dst, smooth, hpgmg_hip_smooth_gsrb(&B->dev, v, src, dst, rhs_id, a, b, h2inv, s));
+      STENCIL_WITH_GHOSTS(L, src, dst, smooth, hpgmg_hip_smooth_gsrb(hp_stencil_dev(B), v, src, dst, rhs_id, a, b, h2inv, s));
     }
   } else {                                           /* jacobi.c:8-65 */
     for (s = 0; s < sweeps; s++) {
       const int src = (s & 1) ? VECTOR_TEMP : x_id, dst = (s & 1) ? x_id : VECTOR_TEMP;
-      STENCIL_WITH_GHOSTS(L, src, dst, smooth, hpgmg_hip_smooth_jacobi(&B->dev, v, src, dst, rhs_id, a, b, h2inv, 2.0 / 3.0));
+      STENCIL_WITH_GHOSTS(L, src, dst, smooth, hpgmg_hip_smooth_jacobi(hp_stencil_dev(B), v, src, dst, rhs_id, a, b, h2inv, 2.0 / 3.0));
     }
   }
 }
 
 static void do_residual(level_type *L, int res_id, int x_id, int rhs_id, double a, double b) {   /* residual.c:9-51 */
   if (small_level_try(L, 3, x_id, rhs_id, res_id, a, b)) return;
-  STENCIL_WITH_GHOSTS(L, x_id, res_id, residual, hpgmg_hip_residual(&backend_of(L)->dev, variant(), res_id, x_id, rhs_id, a, b, 1.0 / (L->h * L->h)));
+  STENCIL_WITH_GHOSTS(L, x_id, res_id, residual, hpgmg_hip_residual(hp_stencil_dev(hp_backend_of(L)), hp_variant(), res_id, x_id, rhs_id, a, b, 1.0 / (L->h * L->h)));
 }
 static void do_apply_op(level_type *L, int Ax_id, int x_id, double a, double b) {               /* apply_op.c:9-48 */
   if (small_level_try(L, 4, x_id, -1, Ax_id, a, b)) return;
-  STENCIL_WITH_GHOSTS(L, x_id, Ax_id, apply_op, hpgmg_hip_residual(&backend_of(L)->dev, variant(), Ax_id, x_id, -1, a, b, 1.0 / (L->h * L->h)));
+  STENCIL_WITH_GHOSTS(L, x_id, Ax_id, apply_op, hpgmg_hip_residual(hp_stencil_dev(hp_backend_of(L)), hp_variant(), Ax_id, x_id, -1, a, b, 1.0 / (L->h * L->h)));
 }
 
 /* ---------------------------------------------------------------- restriction.c:104-212 */
 static void do_restriction(level_type *Lc, int id_c, level_type *Lf, int id_f, int type) {
   TICK(Lf, restriction_total, "restriction");
   communicator_type *S = &Lf->restriction[type], *R = &Lc->restriction[type];
-  backend_t *Bc = backend_of(Lc), *Bf = backend_of(Lf);
-  HIP_OK(hpgmg_hip_restrict_blocks(&Bc->dev, id_c, &Bf->dev, id_f, mirror(Lf, S->blocks[0], S->num_blocks[0]), S->num_blocks[0], type));
+  backend_t *Bc = hp_backend_of(Lc), *Bf = hp_backend_of(Lf);
+  HIP_OK(hpgmg_hip_restrict_blocks(&Bc->dev, id_c, &Bf->dev, id_f, hp_mirror(Lf, S->blocks[0], S->num_blocks[0]), S->num_blocks[0], type));
   transport_phase(R, S, (Lf->tag << 4) | 0x5);
-  HIP_OK(hpgmg_hip_restrict_blocks(&Bc->dev, id_c, &Bf->dev, id_f, mirror(Lf, S->blocks[1], S->num_blocks[1]), S->num_blocks[1], type));
-  HIP_OK(hpgmg_hip_copy_blocks(&Bc->dev, id_c, mirror(Lc, R->blocks[2], R->num_blocks[2]), R->num_blocks[2]));
+  HIP_OK(hpgmg_hip_restrict_blocks(&Bc->dev, id_c, &Bf->dev, id_f, hp_mirror(Lf, S->blocks[1], S->num_blocks[1]), S->num_blocks[1], type));
+  HIP_OK(hpgmg_hip_copy_blocks(&Bc->dev, id_c, hp_mirror(Lc, R->blocks[2], R->num_blocks[2]), R->num_blocks[2]));
   TOCK();
 }
 
@@ -1509,8 +1472,8 @@ int hpgmg_restrict_zero_fused(level_type *Lc, int id_c, level_type *Lf, int id_f
   if (!Lf->active || !Lc->active || Lc->num_my_boxes < 1 || zero_id == id_c) return 0;
   if (S->num_sends || R->num_recvs || S->num_blocks[0] || R->num_blocks[2] || S->num_blocks[1] < 1) return 0;
   TICK(Lf, restriction_total, "restriction + zero_vector");
-  backend_t *Bc = backend_of(Lc), *Bf = backend_of(Lf);
-  HIP_OK(hpgmg_hip_restrict_cell_and_zero(&Bc->dev, id_c, &Bf->dev, id_f, mirror(Lf, S->blocks[1], S->num_blocks[1]), S->num_blocks[1], zero_id));
+  backend_t *Bc = hp_backend_of(Lc), *Bf = hp_backend_of(Lf);
+  HIP_OK(hpgmg_hip_restrict_cell_and_zero(&Bc->dev, id_c, &Bf->dev, id_f, hp_mirror(Lf, S->blocks[1], S->num_blocks[1]), S->num_blocks[1], zero_id));
   TOCK();
   return 1;
 }
@@ -1550,14 +1513,22 @@ static int fused_residual_operand(level_type *L, backend_t *B, int x_id) {
   hpgmg_config cfg;
   hpgmg_get_config(&cfg);
   const int shape = stencil_get_shape();
-  if (!fused_residual_on() || !ghost_free_mode() || !L->active || L->num_my_boxes < 1 || L->boundary_condition.type == BC_PERIODIC || !B->all_faces_local) return 0;
+  if (!fused_residual_on() || !hp_ghost_free_mode() || !L->active || L->num_my_boxes < 1 || L->boundary_condition.type == BC_PERIODIC) return 0;
+  B->img_active = 0;
+  if (!B->all_faces_local) {           /* 27-point / fv4 with boxes on other ranks: the same pass on the table with their images */
+    if ((cfg.op != HPGMG_OP_27PT && cfg.op != HPGMG_OP_FV4) || !hp_images_ready(L, B) || !hpgmg_hip_residual_fused_supported(&B->img->dev, hp_variant())) return 0;
+    hpgmg_hip_set_ghost_free(0);
+    hpgmg_hip_set_tile_ghost_free(1);
+    hp_images_refresh(L, B, 0, x_id, stencil_get_radius(), -1, cfg.op == HPGMG_OP_27PT ? 12 : 4);
+    return 1;
+  }
   if (cfg.op == HPGMG_OP_7PT) {
     if (shape != STENCIL_SHAPE_STAR) return 0;
     hpgmg_hip_set_ghost_free(1);
-    return hpgmg_hip_residual_fused_supported(&B->dev, variant());
+    return hpgmg_hip_residual_fused_supported(&B->dev, hp_variant());
   }
   if (cfg.op != HPGMG_OP_27PT && cfg.op != HPGMG_OP_FV4) return 0;
-  if (!hpgmg_hip_residual_fused_supported(&B->dev, variant())) return 0;
+  if (!hpgmg_hip_residual_fused_supported(&B->dev, hp_variant())) return 0;
   hpgmg_hip_set_ghost_free(0);
   hpgmg_hip_set_tile_ghost_free(1);
   if (!exchange_and_bcs_one_launch(L, x_id, shape, cfg.op == HPGMG_OP_27PT ? 12 : 4, 0)) apply_BCs(L, x_id, shape);
@@ -1565,7 +1536,7 @@ static int fused_residual_operand(level_type *L, backend_t *B, int x_id) {
 }
 static int residual_restrict_zero_fused(level_type *Lc, int id_c, level_type *Lf, int res_id, int x_id, int rhs_id, double a, double b, int zero_id);
 int hpgmg_residual_restrict_zero_fused(level_type *Lc, int id_c, level_type *Lf, int x_id, int rhs_id, double a, double b, int zero_id) {
-  lazy_flush();
+  hp_lazy_flush();
   return residual_restrict_zero_fused(Lc, id_c, Lf, -1, x_id, rhs_id, a, b, zero_id);
 }
 /* res_id >= 0: the residual is stored as well (7-point): the exact state of the three operators */
@@ -1573,12 +1544,12 @@ static int residual_restrict_zero_fused(level_type *Lc, int id_c, level_type *Lf
   communicator_type *S = &Lf->restriction[RESTRICT_CELL], *R = &Lc->restriction[RESTRICT_CELL];
   if (!Lf->active || !Lc->active || Lc->num_my_boxes < 1 || Lf->num_my_boxes < 1 || zero_id == id_c) return 0;
   if (S->num_sends || R->num_recvs || S->num_blocks[0] || R->num_blocks[2] || S->num_blocks[1] < 1) return 0;
-  backend_t *Bc = backend_of(Lc), *Bf = backend_of(Lf);
+  backend_t *Bc = hp_backend_of(Lc), *Bf = hp_backend_of(Lf);
   if (!restrict_map_of(Lf, Bf)) return 0;
   { hpgmg_config cfg; hpgmg_get_config(&cfg); if (res_id >= 0 && (cfg.op != HPGMG_OP_7PT || res_id == x_id || res_id == rhs_id)) return 0; }
   if (!fused_residual_operand(Lf, Bf, x_id)) return 0;
   TICK(Lf, residual, "residual + restriction + zero_vector (fused)");
-  HIP_OK(hpgmg_hip_residual_restrict_store(&Bf->dev, variant(), res_id, x_id, rhs_id, a, b, 1.0 / (Lf->h * Lf->h), &Bc->dev, id_c, Bf->d_restrict_map, zero_id));
+  HIP_OK(hpgmg_hip_residual_restrict_store(hp_stencil_dev(Bf), hp_variant(), res_id, x_id, rhs_id, a, b, 1.0 / (Lf->h * Lf->h), &Bc->dev, id_c, Bf->d_restrict_map, zero_id));
   TOCK();
   return 1;
 }
@@ -1588,7 +1559,7 @@ static int norm_scale_restrict_fused(level_type *L, int F_id, int R_id, level_ty
   communicator_type *S = &L->restriction[RESTRICT_CELL], *R = &Lc->restriction[RESTRICT_CELL];
   if (!fused_residual_on() || !L->active || !Lc->active || L->num_my_boxes < 1 || Lc->num_my_boxes < 1 || F_id == R_id) return 0;
   if (S->num_sends || R->num_recvs || S->num_blocks[0] || R->num_blocks[2] || S->num_blocks[1] < 1) return 0;
-  backend_t *Bc = backend_of(Lc), *B = backend_of(L);
+  backend_t *Bc = hp_backend_of(Lc), *B = hp_backend_of(L);
   if ((L->box_dim & 1) || !(B->dev.flags & 1) || (L->box_jStride & 1) || (L->box_kStride & 1) || (L->box_volume & 1) || L->box_dim < 16) return 0;
   if (!restrict_map_of(L, B)) return 0;
   double v = 0.0;
@@ -1607,11 +1578,11 @@ int hpgmg_residual_norm_fused(level_type *L, int res_id, int x_id, int rhs_id, d
   hpgmg_get_config(&cfg);
   if (cfg.op != HPGMG_OP_7PT && res_id >= 0) return 0;          /* the tiled kernels of the other plugins only carry the norm-only form */
   if (!L->active || L->num_my_boxes < 1) return 0;
-  backend_t *B = backend_of(L);
+  backend_t *B = hp_backend_of(L);
   if (!fused_residual_operand(L, B, x_id)) return 0;
   double v = 0.0;
   { TICK(L, residual, "residual + norm (fused)");
-    HIP_OK(hpgmg_hip_residual_norm(&B->dev, variant(), res_id, x_id, rhs_id, a, b, 1.0 / (L->h * L->h), &v));
+    HIP_OK(hpgmg_hip_residual_norm(hp_stencil_dev(B), hp_variant(), res_id, x_id, rhs_id, a, b, 1.0 / (L->h * L->h), &v));
     TOCK(); }
   *norm_out = allreduce_scalar(L, v, HPGMG_REDUCE_MAX);
   return 1;
@@ -1621,11 +1592,11 @@ int hpgmg_residual_norm_fused(level_type *L, int res_id, int x_id, int rhs_id, d
 static void interpolation_lists(level_type *Lf, int id_f, double prescale, level_type *Lc, int id_c, int order, int tagbits) {
   TICK(Lf, interpolation_total, "interpolation");
   communicator_type *S = &Lc->interpolation, *R = &Lf->interpolation;
-  backend_t *Bc = backend_of(Lc), *Bf = backend_of(Lf);
-  HIP_OK(hpgmg_hip_interpolate_blocks(&Bf->dev, id_f, 0.0, &Bc->dev, id_c, mirror(Lc, S->blocks[0], S->num_blocks[0]), S->num_blocks[0], order));
+  backend_t *Bc = hp_backend_of(Lc), *Bf = hp_backend_of(Lf);
+  HIP_OK(hpgmg_hip_interpolate_blocks(&Bf->dev, id_f, 0.0, &Bc->dev, id_c, hp_mirror(Lc, S->blocks[0], S->num_blocks[0]), S->num_blocks[0], order));
   transport_phase(R, S, (Lf->tag << 4) | tagbits);
-  HIP_OK(hpgmg_hip_interpolate_blocks(&Bf->dev, id_f, prescale, &Bc->dev, id_c, mirror(Lc, S->blocks[1], S->num_blocks[1]), S->num_blocks[1], order));
-  HIP_OK(hpgmg_hip_increment_blocks(&Bf->dev, id_f, prescale, mirror(Lf, R->blocks[2], R->num_blocks[2]), R->num_blocks[2]));
+  HIP_OK(hpgmg_hip_interpolate_blocks(&Bf->dev, id_f, prescale, &Bc->dev, id_c, hp_mirror(Lc, S->blocks[1], S->num_blocks[1]), S->num_blocks[1], order));
+  HIP_OK(hpgmg_hip_increment_blocks(&Bf->dev, id_f, prescale, hp_mirror(Lf, R->blocks[2], R->num_blocks[2]), R->num_blocks[2]));
   TOCK();
 }
 static void do_interpolation_vcycle(level_type *Lf, int id_f, double prescale, level_type *Lc, int id_c) {
@@ -1659,15 +1630,15 @@ void interpolation_fcycle(level_type *Lf, int id_f, double prescale, level_type 
 
 /* ---------------------------------------------------------------- misc.c */
 #define BLAS1(call) do { TICK(L, blas1, "BLAS1"); HIP_OK(call); TOCK(); } while (0)
-static void do_zero_vector(level_type *L, int id) { BLAS1(hpgmg_hip_fill(&backend_of(L)->dev, id, 0.0)); }
-void init_vector(level_type *L, int id, double s) { BLAS1(hpgmg_hip_fill(&backend_of(L)->dev, id, s)); }
-static void do_add_vectors(level_type *L, int c, double sa, int a, double sb, int b) { BLAS1(hpgmg_hip_axpby(&backend_of(L)->dev, c, sa, a, sb, b)); }
-static void do_mul_vectors(level_type *L, int c, double s, int a, int b) { BLAS1(hpgmg_hip_mul(&backend_of(L)->dev, c, s, a, b)); }
-void invert_vector(level_type *L, int c, double s, int a) { BLAS1(hpgmg_hip_invert(&backend_of(L)->dev, c, s, a)); }
-static void do_scale_vector(level_type *L, int c, double s, int a) { BLAS1(hpgmg_hip_scale(&backend_of(L)->dev, c, s, a)); }
-void shift_vector(level_type *L, int c, int a, double shift) { BLAS1(hpgmg_hip_shift(&backend_of(L)->dev, c, a, shift)); }
-void color_vector(level_type *L, int id, int colors, int ic, int jc, int kc) { BLAS1(hpgmg_hip_color(&backend_of(L)->dev, id, colors, ic, jc, kc)); }
-void random_vector(level_type *L, int id) { BLAS1(hpgmg_hip_random(&backend_of(L)->dev, id)); }
+static void do_zero_vector(level_type *L, int id) { BLAS1(hpgmg_hip_fill(&hp_backend_of(L)->dev, id, 0.0)); }
+void init_vector(level_type *L, int id, double s) { BLAS1(hpgmg_hip_fill(&hp_backend_of(L)->dev, id, s)); }
+static void do_add_vectors(level_type *L, int c, double sa, int a, double sb, int b) { BLAS1(hpgmg_hip_axpby(&hp_backend_of(L)->dev, c, sa, a, sb, b)); }
+static void do_mul_vectors(level_type *L, int c, double s, int a, int b) { BLAS1(hpgmg_hip_mul(&hp_backend_of(L)->dev, c, s, a, b)); }
+void invert_vector(level_type *L, int c, double s, int a) { BLAS1(hpgmg_hip_invert(&hp_backend_of(L)->dev, c, s, a)); }
+static void do_scale_vector(level_type *L, int c, double s, int a) { BLAS1(hpgmg_hip_scale(&hp_backend_of(L)->dev, c, s, a)); }
+void shift_vector(level_type *L, int c, int a, double shift) { BLAS1(hpgmg_hip_shift(&hp_backend_of(L)->dev, c, a, shift)); }
+void color_vector(level_type *L, int id, int colors, int ic, int jc, int kc) { BLAS1(hpgmg_hip_color(&hp_backend_of(L)->dev, id, colors, ic, jc, kc)); }
+void random_vector(level_type *L, int id) { BLAS1(hpgmg_hip_random(&hp_backend_of(L)->dev, id)); }
 
 static double allreduce_scalar(level_type *L, double v, int op) {
   const hpgmg_transport *T = hpgmg_get_transport();
@@ -1677,11 +1648,11 @@ static double allreduce_scalar(level_type *L, double v, int op) {
   }
   return v;
 }
-static double do_dot(level_type *L, int a, int b) { double v; BLAS1(hpgmg_hip_dot(&backend_of(L)->dev, a, b, &v)); return allreduce_scalar(L, v, HPGMG_REDUCE_SUM); }
+static double do_dot(level_type *L, int a, int b) { double v; BLAS1(hpgmg_hip_dot(&hp_backend_of(L)->dev, a, b, &v)); return allreduce_scalar(L, v, HPGMG_REDUCE_SUM); }
 static double do_norm(level_type *L, int a) {
-  double v; BLAS1(hpgmg_hip_norm_max(&backend_of(L)->dev, a, &v)); return allreduce_scalar(L, v, HPGMG_REDUCE_MAX); }
+  double v; BLAS1(hpgmg_hip_norm_max(&hp_backend_of(L)->dev, a, &v)); return allreduce_scalar(L, v, HPGMG_REDUCE_MAX); }
 double mean(level_type *L, int a) {
-  double v; BLAS1(hpgmg_hip_sum(&backend_of(L)->dev, a, &v));
+  double v; BLAS1(hpgmg_hip_sum(&hp_backend_of(L)->dev, a, &v));
   v = allreduce_scalar(L, v, HPGMG_REDUCE_SUM);
   return v / (double)((double)L->dim.i * (double)L->dim.j * (double)L->dim.k);
 }
@@ -1840,7 +1811,7 @@ void rebuild_operator(level_type *L, level_type *from, double a, double b) {
   exchange_boundary(L, VECTOR_BETA_K, STENCIL_SHAPE_BOX);
 
   double lambda = -1e9;
-  BLAS1(hpgmg_hip_rebuild_7pt(&backend_of(L)->dev, cfg.variable_coeff, cfg.helmholtz ? VECTOR_ALPHA : -1,
+  BLAS1(hpgmg_hip_rebuild_7pt(&hp_backend_of(L)->dev, cfg.variable_coeff, cfg.helmholtz ? VECTOR_ALPHA : -1,
                               cfg.helmholtz ? VECTOR_L1INV : -1, a, b, 1.0 / (L->h * L->h), &lambda));
   { const hpgmg_transport *T = hpgmg_get_transport();
     if (T && T->size > 1) { int r, *all = (int *)malloc((size_t)T->size * sizeof(int)); for (r = 0; r < T->size; r++) all[r] = r;
@@ -1874,8 +1845,8 @@ static int lz_n = 0, lz_mode = LZ_NONE, lz_busy = 0, lazy_on = -1;
 static long long lazy_fused_legs = 0, lazy_fused_units = 0;
 long long hpgmg_lazy_fused_legs(void) { return lazy_fused_legs; }      /* single-launch legs / fused large-level units issued by the queue so far (tests) */
 long long hpgmg_lazy_fused_units(void) { return lazy_fused_units; }
-void hpgmg_set_lazy(int on) { lazy_flush(); lazy_on = on ? 1 : 0; }
-void hpgmg_operators_flush(void) { lazy_flush(); }      /* issue every postponed operator now (nothing is ever left behind: any other call does the same) */
+void hpgmg_set_lazy(int on) { hp_lazy_flush(); lazy_on = on ? 1 : 0; }
+void hpgmg_operators_flush(void) { hp_lazy_flush(); }      /* issue every postponed operator now (nothing is ever left behind: any other call does the same) */
 /* HPGMG_LAZY_REPORT=1: what the queue did, on stderr when the process ends (tests/test_gpu_route_b.py reads it) */
 __attribute__((destructor)) static void lazy_report(void) {
   const char *e = getenv("HPGMG_LAZY_REPORT");
@@ -1891,7 +1862,7 @@ static int lazy_enabled(void) {
  * instead of ~18.  HPGMG_SMALL_OPS=0 / hpgmg_set_small_ops(0) turn it off. */
 static int small_ops_on = -1;
 static long long small_ops_groups = 0;
-void hpgmg_set_small_ops(int on) { lazy_flush(); small_ops_on = on ? 1 : 0; }
+void hpgmg_set_small_ops(int on) { hp_lazy_flush(); small_ops_on = on ? 1 : 0; }
 long long hpgmg_small_ops_groups(void) { return small_ops_groups; }
 static int small_ops_kind(int op) { return op == LZ_ADD ? 1 : op == LZ_MUL ? 2 : op == LZ_SCALE ? 3 : op == LZ_APPLY ? 4 : op == LZ_RESIDUAL ? 5 : 0; }
 static int small_ops_level_ok(level_type *L) {
@@ -1918,8 +1889,8 @@ static void so_touch(void) { so_last_fresh = 0; so_cache_valid = 0; }          /
 /* issue the queue (mode LZ_SMALL, or nothing) on level L as one launch; value_kind 6 / 7: ending in dot(va, vb) / norm(va), whose value is returned;
  * p_kind: a second, predicted request formed by the same launch (its value to *p_out) */
 static double small_ops_issue(level_type *L, int value_kind, int va, int vb, int p_kind, int pa, int pb, double *p_out) {
-  lz_busy = 1;                                            /* from here on every device call (the first backend_of() of a level uploads its tables) runs at once */
-  backend_t *B = backend_of(L);
+  lz_busy = 1;                                            /* from here on every device call (the first hp_backend_of() of a level uploads its tables) runs at once */
+  backend_t *B = hp_backend_of(L);
   hpgmg_config cfg;
   int kinds[16], c[16], a[16], b[16], q, n = 0, bc_kind, zero_first = 0;
   double sa[16], sb[16], op_a = 0.0, op_b = 0.0, v = 0.0;
@@ -1939,7 +1910,7 @@ static double small_ops_issue(level_type *L, int value_kind, int va, int vb, int
   else { bc_kind = 4; zero_first = (L->box_ghosts > 2); }
   {
     TICK(L, blas1, "queued small-level operators, one launch");
-    HIP_OK(hpgmg_hip_small_ops(&B->dev, variant(), n, kinds, c, a, b, sa, sb, n_bc ? mirror(L, L->boundary_condition.blocks[shape], n_bc) : NULL, n_bc, bc_kind, zero_first,
+    HIP_OK(hpgmg_hip_small_ops(&B->dev, hp_variant(), n, kinds, c, a, b, sa, sb, n_bc ? hp_mirror(L, L->boundary_condition.blocks[shape], n_bc) : NULL, n_bc, bc_kind, zero_first,
                                op_a, op_b, 1.0 / (L->h * L->h), value_kind ? &v : NULL, (value_kind && p_kind) ? p_out : NULL));
     TOCK();
   }
@@ -1957,7 +1928,7 @@ static void lazy_run_one(const lazy_op *o) {
     case LZ_SCALE:    do_scale_vector(o->L, o->i0, o->a, o->i1); break;
   }
 }
-static void lazy_flush(void) {
+void hp_lazy_flush(void) {
   if (!lz_busy) so_touch();                               /* every device call of the plugin passes here first */
   if (lz_busy || lz_n == 0) return;
   lz_busy = 1;                                            /* the operators below issue device calls themselves */
@@ -2058,47 +2029,47 @@ static int lazy_push(int op, level_type *L, level_type *L2, int i0, int i1, int 
 /* the five operators of include/hpgmg_operators.h (= operators.h) that take part */
 void smooth(level_type *L, int x_id, int rhs_id, double a, double b) {
   if (lazy_push(LZ_SMOOTH, L, NULL, x_id, rhs_id, 0, a, b)) return;
-  lazy_flush();
+  hp_lazy_flush();
   if (lazy_push(LZ_SMOOTH, L, NULL, x_id, rhs_id, 0, a, b)) return;      /* it may start the next pattern */
   do_smooth(L, x_id, rhs_id, a, b);
 }
 void residual(level_type *L, int res_id, int x_id, int rhs_id, double a, double b) {
   if (lazy_push(LZ_RESIDUAL, L, NULL, res_id, x_id, rhs_id, a, b)) return;
-  lazy_flush();
+  hp_lazy_flush();
   if (lazy_push(LZ_RESIDUAL, L, NULL, res_id, x_id, rhs_id, a, b)) return;      /* it may start the residual + norm pattern (the convergence check after the last V-cycle) */
   do_residual(L, res_id, x_id, rhs_id, a, b);
 }
 void restriction(level_type *Lc, int id_c, level_type *Lf, int id_f, int type) {
   if (lazy_push(LZ_RESTRICT, Lc, Lf, id_c, id_f, type, 0.0, 0.0)) return;
-  lazy_flush();
+  hp_lazy_flush();
   do_restriction(Lc, id_c, Lf, id_f, type);
 }
 void scale_vector(level_type *L, int c, double s, int a) {
   if (lazy_push(LZ_SCALE, L, NULL, c, a, 0, s, 0.0)) return;
-  lazy_flush();
+  hp_lazy_flush();
   if (lazy_push(LZ_SCALE, L, NULL, c, a, 0, s, 0.0)) return;
   do_scale_vector(L, c, s, a);
 }
 void zero_vector(level_type *L, int id) {
   if (lazy_push(LZ_ZERO, L, NULL, id, 0, 0, 0.0, 0.0)) return;
-  lazy_flush();
+  hp_lazy_flush();
   do_zero_vector(L, id);
 }
 void add_vectors(level_type *L, int c, double sa, int a, double sb, int b) {
   if (lazy_push(LZ_ADD, L, NULL, c, a, b, sa, sb)) return;
-  lazy_flush();
+  hp_lazy_flush();
   if (lazy_push(LZ_ADD, L, NULL, c, a, b, sa, sb)) return;
   do_add_vectors(L, c, sa, a, sb, b);
 }
 void mul_vectors(level_type *L, int c, double s, int a, int b) {
   if (lazy_push(LZ_MUL, L, NULL, c, a, b, s, 0.0)) return;
-  lazy_flush();
+  hp_lazy_flush();
   if (lazy_push(LZ_MUL, L, NULL, c, a, b, s, 0.0)) return;
   do_mul_vectors(L, c, s, a, b);
 }
 void apply_op(level_type *L, int Ax_id, int x_id, double a, double b) {
   if (lazy_push(LZ_APPLY, L, NULL, Ax_id, x_id, 0, a, b)) return;
-  lazy_flush();
+  hp_lazy_flush();
   if (lazy_push(LZ_APPLY, L, NULL, Ax_id, x_id, 0, a, b)) return;
   do_apply_op(L, Ax_id, x_id, a, b);
 }
@@ -2109,7 +2080,7 @@ double dot(level_type *L, int a, int b) {
 }
 void interpolation_vcycle(level_type *Lf, int id_f, double prescale, level_type *Lc, int id_c) {
   if (lazy_push(LZ_INTERP, Lf, Lc, id_f, id_c, 0, prescale, 0.0)) return;
-  lazy_flush();
+  hp_lazy_flush();
   if (lazy_push(LZ_INTERP, Lf, Lc, id_f, id_c, 0, prescale, 0.0)) return;
   do_interpolation_vcycle(Lf, id_f, prescale, Lc, id_c);
 }

@@ -108,6 +108,9 @@ def main():
         counts = (ctypes.c_longlong * 2)()
         K.hpgmg_hip_pair_launch_counts(counts)
         stats["pair_launches"], stats["pair_remote_launches"] = counts[0], counts[1]
+        for name, fn in (("fv4_rb_smooths", be.lib.hpgmg_fv4_rb_smooths), ("rb27_passes", be.lib.hpgmg_rb27_passes), ("image_exchanges", be.lib.hpgmg_image_exchanges)):
+            fn.restype = ctypes.c_longlong          # one-pass red + black smoothers, refreshes of the images of neighbouring ranks' boxes
+            stats[name] = fn()
     s.destroy()
     print("RESULT " + json.dumps({"rank": rank, "norms": ["%1.15e" % v for v in norms], "err": "%1.15e" % err,
                                   "order": "%0.3f" % order, "levels": levels, "stats": stats, "repeat": repeat}), flush=True)

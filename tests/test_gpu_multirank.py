@@ -65,6 +65,35 @@ def test_sweep_pairs_across_rank_boundaries(world, variant, log2, per_rank, gold
         assert r["stats"]["pair_remote_launches"] == 2 * r["stats"]["pair_remote_smooths"], r["stats"]
 
 
+@pytest.mark.parametrize("world,variant,log2,per_rank,gold_key", [
+    (2, "fv4-gsrb", 7, 4, "fv4-gsrb 7 8"),        # bricks of 2 x 2 x 1 boxes of 128^3: one remote k face
+    (2, "27pt-gsrb", 7, 4, "27pt-gsrb 7 8"),
+    (4, "fv4-gsrb", 7, 2, "fv4-gsrb 7 8"),        # bricks of 2 x 1 x 1: remote j and k faces and the edge between them
+    (8, "27pt-gsrb", 7, 1, "27pt-gsrb 7 8"),      # one box per rank: three remote faces, three edges, a corner
+    (8, "fv4-gsrb", 7, 8, "fv4-gsrb 7 64"),       # BASELINE config 3 as stated: 512^3, eight ranks of 2 x 2 x 2 boxes
+    (2, "fv4-cheby", 5, 4, "fv4-cheby 5 8"),      # the tiled kernels (Chebyshev sweeps, residual) on the images, reference rank map down to boxes of 8^3
+    (2, "27pt-cheby", 7, 4, "27pt-cheby 7 8"),
+])
+def test_config3_kernels_across_rank_boundaries(world, variant, log2, per_rank, gold_key):
+    """BASELINE config 3 is an 8-rank configuration: the one-pass red + black kernels of the fv4 and 27-point GSRB smoothers, the LDS-tiled
+    kernels and the fused residual passes must keep running when faces belong to other ranks -- on images of the neighbouring ranks' boxes,
+    refreshed by ONE message per neighbour and sweep (gsrb.c:30-33 exchanges twice per sweep) -- and reproduce the single-rank reference
+    numbers to the last digit."""
+    if gold_key not in GOLD:
+        pytest.skip("no golden record for " + gold_key)
+    gold = GOLD[gold_key]
+    res = run_job(world, variant, log2, per_rank, backend="hip")
+    assert res[0]["norms"] == gold["norms"], res[0]
+    assert res[0]["err"] == gold["richardson_error"] and res[0]["order"] == gold["order"]
+    assert res[0]["repeat"] == [gold["norms"][0]] * 3, res[0]["repeat"]
+    for r in res:
+        assert r["stats"]["image_exchanges"] > 20, r["stats"]
+        if variant == "fv4-gsrb":
+            assert r["stats"]["fv4_rb_smooths"] >= 8, r["stats"]
+        if variant == "27pt-gsrb":
+            assert r["stats"]["rb27_passes"] >= 16, r["stats"]
+
+
 @pytest.mark.parametrize("world,variant,log2,per_rank,gold_key,gather", [
     (2, "7pt-cheby-helm", 4, 4, "7pt-cheby-helm 4 8", 16),
     (4, "7pt-cheby", 4, 8, "7pt-cheby 4 27", 24),
