@@ -404,3 +404,35 @@ void hp_images_refresh(level_type *L, backend_t *B, int scr, int id, int depth, 
   B->img_active = 1;
   hp_images_exchanges++;
 }
+
+/* The same with the message hidden behind computation (north_star: "ghost-zone exchange on RCCL over xGMI overlapped with interior smoothing";
+ * the reference overlaps only its local copies with the messages, exchange_boundary.c:81-90):
+ *     launch stream:    own boxes' boundary conditions | part 1 of the stencil launch: tiles that read no image | wait | part 2
+ *     exchange stream:  wait for the vector | pack, grouped send / receive, unpack, the images' boundary conditions |
+ * Returns 1 when set up that way -- the caller issues part 1, hp_images_refresh_end(), part 2 (hpgmg_hip_set_tile_part) -- and 0 when the
+ * refresh was done in line (HPGMG_OVERLAP=0): one whole launch. */
+static void *img_stream = NULL, *ev_ready = NULL, *ev_landed = NULL;
+int hp_images_refresh_begin(level_type *L, backend_t *B, int scr, int id, int depth, int rhs_id, int bc_order) {
+  halo_images *I = B->img;
+  if (!hp_overlap_enabled() || hpgmg_get_timer_mode() == TIMERS_SYNC) { hp_images_refresh(L, B, scr, id, depth, rhs_id, bc_order); return 0; }
+  if (depth < 1 || depth > I->depth_max) { fprintf(stderr, "hpgmg: images hold %d cells, %d asked for\n", I->depth_max, depth); abort(); }
+  if (!img_stream) {
+    img_stream = hpgmg_hip_stream_create(); ev_ready = hpgmg_hip_event_create(); ev_landed = hpgmg_hip_event_create();
+    if (!img_stream || !ev_ready || !ev_landed) { fprintf(stderr, "hpgmg: cannot create the exchange stream\n"); abort(); }
+  }
+  void *launch_stream = hpgmg_hip_get_stream();
+  HIP_OK(hpgmg_hip_event_record(ev_ready));                    /* the vector to be sent is complete once everything issued so far has run */
+  hp_images_bcs(L, B, scr, id, bc_order, 1);
+  hpgmg_hip_set_stream(img_stream);
+  HIP_OK(hpgmg_hip_stream_wait_event(ev_ready));
+  if (!I->coef_valid) { plan_exchange(L, I, IMG_PLAN_COEF, 0, 0, 0); I->coef_valid = 1; }
+  plan_exchange(L, I, depth - 1 + (rhs_id >= 0 ? 3 : 0), scr, id, rhs_id >= 0 ? rhs_id : 0);
+  hp_images_bcs(L, B, scr, id, bc_order, 2);
+  HIP_OK(hpgmg_hip_event_record(ev_landed));
+  hpgmg_hip_set_stream(launch_stream);
+  B->img_active = 1;
+  hp_images_exchanges++;
+  hp_overlap_counted();
+  return 1;
+}
+void hp_images_refresh_end(void) { HIP_OK(hpgmg_hip_stream_wait_event(ev_landed)); }

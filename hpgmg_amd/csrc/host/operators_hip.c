@@ -352,6 +352,11 @@ static int overlap_mode = -1;
 static long long overlap_count = 0;
 long long hpgmg_overlap_count(void) { return overlap_count; }   /* overlapped exchanges so far (tests) */
 void hpgmg_set_overlap(int on) { overlap_mode = on ? 1 : 0; }
+int hp_overlap_enabled(void) {
+  if (overlap_mode < 0) { const char *e = getenv("HPGMG_OVERLAP"); overlap_mode = (e && e[0] == '0') ? 0 : 1; }
+  return overlap_mode;
+}
+void hp_overlap_counted(void) { overlap_count++; }
 static int overlap_begin(level_type *L, int id) {
   const int shape = stencil_get_shape();
   const hpgmg_transport *T = hpgmg_get_transport();
@@ -1332,12 +1337,22 @@ static int smooth_fv4_rb(level_type *L, int x_id, int rhs_id, double a, double b
     else if (left == 2 && !(src_s == 0 && src_id == x_id)) { dst_s = 1; dst_id = 0; }    /* two to go and not standing on x: step aside so that the last pass can land on x */
     else dst_id = (src_s == 0 && src_id == VECTOR_TEMP) ? x_id : VECTOR_TEMP;
     if (left == 2 && src_s == 0 && src_id == x_id) dst_id = VECTOR_TEMP;
-    if (images) hp_images_refresh(L, B, src_s, src_id, 3, p == 0 ? rhs_id : -1, 4);
+    /* images: the message and the images' boundary conditions go to the exchange stream; under them the launch stream runs the tiles that
+     * read neither an image nor anything the pre-pass forms (part 1), then waits, runs the pre-pass and the other tiles (part 2) */
+    int overlapped = 0;
+    if (images) overlapped = hp_images_refresh_begin(L, B, src_s, src_id, 3, p == 0 ? rhs_id : -1, 4);
     else fv4_rb_bcs(L, B, src_s, src_id);
     TICK(L, smooth, "smooth (fv4 GSRB, red + black half sweeps in one pass)");
+    if (overlapped) {
+      hpgmg_hip_set_tile_part(1);
+      HIP_OK(hpgmg_hip_smooth_gsrb_fv4_rb(dev, v, pair_base, src_s, src_id, dst_s, dst_id, 1, rhs_id, a, b, h2inv, 2 * p));
+      hp_images_refresh_end();
+      hpgmg_hip_set_tile_part(2);
+    }
     /* the pre-pass also works on the images next to the k walls: the main kernel reads the intermediate vector's ghost planes in their columns */
     HIP_OK(hpgmg_hip_fv4_rb_prepass(images ? &B->img->dev_all : dev, v, pair_base, src_s, src_id, 1, rhs_id, a, b, h2inv, 2 * p, e_k, n_k, sp_cells, n_sp));
     HIP_OK(hpgmg_hip_smooth_gsrb_fv4_rb(dev, v, pair_base, src_s, src_id, dst_s, dst_id, 1, rhs_id, a, b, h2inv, 2 * p));
+    if (overlapped) hpgmg_hip_set_tile_part(0);
     TOCK();
     src_s = dst_s; src_id = dst_id;
   }
@@ -1379,9 +1394,17 @@ static void do_smooth(level_type *L, int x_id, int rhs_id, double a, double b) {
       if (tiled || boxed) {
         for (s = 0; s < sweeps; s += 2) {
           const int src = (s & 2) ? VECTOR_TEMP : x_id, dst = (s & 2) ? x_id : VECTOR_TEMP;
-          if (images) hp_images_refresh(L, B, 0, src, 2, s == 0 ? rhs_id : -1, 12);
+          int overlapped = 0;
+          if (images && tiled) overlapped = hp_images_refresh_begin(L, B, 0, src, 2, s == 0 ? rhs_id : -1, 12);     /* the tiles that read no image run under the exchange */
+          else if (images) hp_images_refresh(L, B, 0, src, 2, s == 0 ? rhs_id : -1, 12);
           else if (tiled && !exchange_and_bcs_one_launch(L, src, stencil_get_shape(), 12, 0)) apply_BCs(L, src, stencil_get_shape());
           TICK(L, smooth, "smooth (27-point GSRB, red + black half sweeps in one pass)");
+          if (overlapped) {
+            hpgmg_hip_set_tile_part(1); HIP_OK(hpgmg_hip_smooth_gsrb27_rb(dev, src, dst, rhs_id, a, b, h2inv, s));
+            hp_images_refresh_end();
+            hpgmg_hip_set_tile_part(2); HIP_OK(hpgmg_hip_smooth_gsrb27_rb(dev, src, dst, rhs_id, a, b, h2inv, s));
+            hpgmg_hip_set_tile_part(0);
+          } else
           if (tiled) HIP_OK(hpgmg_hip_smooth_gsrb27_rb(dev, src, dst, rhs_id, a, b, h2inv, s));
           else       HIP_OK(hpgmg_hip_smooth_gsrb27_rb_box(dev, src, dst, rhs_id, a, b, h2inv, s));
           TOCK();

@@ -135,6 +135,10 @@ HP_INTERNAL int  hp_bc_entry_from_block(const level_type *L, int box, const int 
                                         int (*find)(void *, int), void *ctx, hpgmg_hip_bc_entry *o);
 HP_INTERNAL int  hp_images_ready(level_type *L, backend_t *B);
 HP_INTERNAL void hp_images_refresh(level_type *L, backend_t *B, int scr, int id, int depth, int rhs_id, int bc_order);
+HP_INTERNAL int  hp_images_refresh_begin(level_type *L, backend_t *B, int scr, int id, int depth, int rhs_id, int bc_order);
+HP_INTERNAL void hp_images_refresh_end(void);
+HP_INTERNAL int  hp_overlap_enabled(void);
+HP_INTERNAL void hp_overlap_counted(void);
 HP_INTERNAL void hp_images_bcs(level_type *L, backend_t *B, int scr, int id, int bc_order, int part);
 HP_INTERNAL const int *hp_images_fv4_special(level_type *L, backend_t *B, int *n_out);
 HP_INTERNAL const hpgmg_hip_bc_entry *hp_images_bc_k(level_type *L, backend_t *B, int *n_out);

@@ -37,6 +37,13 @@ inline int grid_for(int logical_blocks, int *per_xcd) {
   return *per_xcd * kXcds;
 }
 
+// Launching a tiled kernel in two parts (multi-rank: the halo exchange runs on another stream under part 1).  A tile = (box, k chunk, tj, ti)
+// numbered ti + tiles_i * (tj + tiles_j * (ck + chunks_k * box)).  Part 1: the tiles whose halo reaches no IMAGE of another rank's box (a
+// neighbour index >= L->num_boxes in box_nbr; include/hpgmg_hip.h) -- and, with walls_to_part2, no domain wall either; part 2: the others.
+// Returns the dispatch list (slot -> tile, padded with `total`) for a grid of *grid workgroups with *per_xcd per XCD; *grid = 0: nothing to launch.
+extern int g_tile_part;               // 0: whole launches; 1 / 2: the next tiled launches run that part only
+const int *tile_part_order(const hpgmg_hip_level *L, int tiles_i, int tiles_j, int chunks_k, int part, bool walls_to_part2, int *grid, int *per_xcd, int *count);
+
 // A box pointer read from a table in memory has no known address space, so every access through it is a FLAT instruction, which counts
 // against lgkmcnt as well as vmcnt: a wave waiting for its LDS reads then also waits for every prefetch still in flight from HBM.
 // Kernels that depend on that overlap address device memory through these types (global_load / global_store).

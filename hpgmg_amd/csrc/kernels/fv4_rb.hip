@@ -134,12 +134,18 @@ int hpgmg_hip_smooth_gsrb_fv4_rb(const hpgmg_hip_level *L, int variant, double *
   if (tune_kc > 0 && L->dim % tune_kc == 0) kchunk = tune_kc;
   A.kchunk = kchunk; A.chunks_k = (L->dim + kchunk - 1) / kchunk;
   A.total_blocks = L->num_boxes * A.chunks_k * A.tiles_j * A.tiles_i;
-  const int grid = grid_for(A.total_blocks, &A.per_xcd);
-  A.order = tile_order(L, A, TI, grid);
+  int grid = grid_for(A.total_blocks, &A.per_xcd);
+  long long cells = (long long)L->num_boxes * L->dim * L->dim * L->dim;
+  if (g_tile_part) {      // one part of the launch: part 1 = tiles that read neither an image of another rank's box nor anything the pre-pass forms (no wall)
+    int count = 0;
+    A.order = tile_part_order(L, A.tiles_i, A.tiles_j, A.chunks_k, g_tile_part, true, &grid, &A.per_xcd, &count);
+    if (grid == 0) return 0;
+    if (!A.order) return record_error(hipErrorOutOfMemory, "smooth_gsrb_fv4_rb: dispatch list of a partial launch");
+    cells = cells * count / A.total_blocks;
+  } else A.order = tile_order(L, A, TI, grid);
 #ifdef HPGMG_EXP_TIMELINE
   A.timeline = g_fv4rb_timeline; A.timeline_wg = env_int("HPGMG_EXP_TIMELINE_WG", -1);
 #endif
-  const long long cells = (long long)L->num_boxes * L->dim * L->dim * L->dim;
   const int prof = profile_begin(cells);
 #define FV4_RB_CASE(VAR, TI_) { \
     constexpr size_t lds = fv4rb::Geom<TI_>::LDS_BYTES; \

@@ -5,6 +5,7 @@
 #include <string.h>
 #include <stdlib.h>
 #include <dlfcn.h>
+#include <vector>
 #include "common.hpp"
 
 namespace hpgmg {
@@ -177,3 +178,42 @@ void hpgmg_hip_range_push(const char *name) { if (roctx_ready()) g_roctx_push(na
 void hpgmg_hip_range_pop(void) { if (roctx_ready()) g_roctx_pop(); }
 
 }  // extern "C"
+
+// ---- two-part launches of the tiled kernels (common.hpp) ----
+namespace hpgmg {
+int g_tile_part = 0;
+struct PartOrder { const int *nbr; int num_boxes, ti, tj, ck, part, walls; int *d_order; int grid, per_xcd, count; };
+static std::vector<PartOrder> g_part_orders;
+const int *tile_part_order(const hpgmg_hip_level *L, int tiles_i, int tiles_j, int chunks_k, int part, bool walls_to_part2, int *grid, int *per_xcd, int *count) {
+  for (const PartOrder &o : g_part_orders)
+    if (o.nbr == L->box_nbr && o.num_boxes == L->num_boxes && o.ti == tiles_i && o.tj == tiles_j && o.ck == chunks_k && o.part == part && o.walls == (int)walls_to_part2) {
+      *grid = o.grid; *per_xcd = o.per_xcd; *count = o.count; return o.d_order;
+    }
+  const int total = L->num_boxes * chunks_k * tiles_j * tiles_i;
+  std::vector<int> nbr(6 * (size_t)L->num_boxes), sel;
+  *grid = 0; *per_xcd = 0; *count = 0;
+  if (!L->box_nbr || hipMemcpy(nbr.data(), L->box_nbr, nbr.size() * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return nullptr;
+  for (int l = 0; l < total; l++) {
+    int t = l;
+    const int ti = t % tiles_i; t /= tiles_i;
+    const int tj = t % tiles_j; t /= tiles_j;
+    const int ck = t % chunks_k; t /= chunks_k;
+    const int *nb = &nbr[6 * (size_t)t];
+    const bool at[6] = { ti == 0, ti == tiles_i - 1, tj == 0, tj == tiles_j - 1, ck == 0, ck == chunks_k - 1 };
+    bool later = false;
+    for (int d = 0; d < 6; d++) if (at[d] && (nb[d] >= L->num_boxes || nb[d] == -2 || (walls_to_part2 && nb[d] == -1))) later = true;
+    if (later == (part == 2)) sel.push_back(l);
+  }
+  PartOrder o = { L->box_nbr, L->num_boxes, tiles_i, tiles_j, chunks_k, part, (int)walls_to_part2, nullptr, 0, 0, (int)sel.size() };
+  if (!sel.empty()) {
+    o.per_xcd = ((int)sel.size() + kXcds - 1) / kXcds; o.grid = o.per_xcd * kXcds;
+    sel.resize((size_t)o.grid, total);                                     // the padding of the grid: nothing to do
+    if (hipMalloc(&o.d_order, sel.size() * sizeof(int)) != hipSuccess) return nullptr;
+    if (hipMemcpy(o.d_order, sel.data(), sel.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(o.d_order); return nullptr; }
+  }
+  g_part_orders.push_back(o);
+  *grid = o.grid; *per_xcd = o.per_xcd; *count = o.count;
+  return o.d_order;
+}
+}  // namespace hpgmg
+extern "C" void hpgmg_hip_set_tile_part(int part) { hpgmg::g_tile_part = (part == 1 || part == 2) ? part : 0; }

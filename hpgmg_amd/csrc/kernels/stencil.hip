@@ -2214,8 +2214,15 @@ int hpgmg_hip_smooth_gsrb27_rb(const hpgmg_hip_level *L, int x_id, int out_id, i
   if (tune_kc > 0 && L->dim % tune_kc == 0) kchunk = tune_kc;
   A.kchunk = kchunk; A.chunks_k = (L->dim + kchunk - 1) / kchunk;
   A.total_blocks = L->num_boxes * A.chunks_k * A.tiles_j * A.tiles_i;
-  const int grid = grid_for(A.total_blocks, &A.per_xcd);
-  const long long cells = (long long)L->num_boxes * L->dim * L->dim * L->dim;
+  int grid = grid_for(A.total_blocks, &A.per_xcd);
+  long long cells = (long long)L->num_boxes * L->dim * L->dim * L->dim;
+  if (g_tile_part) {      // one part of the launch: part 1 = the tiles that read nothing of an image of another rank's box
+    int count = 0;
+    A.order = tile_part_order(L, A.tiles_i, A.tiles_j, A.chunks_k, g_tile_part, false, &grid, &A.per_xcd, &count);
+    if (grid == 0) return 0;
+    if (!A.order) return record_error(hipErrorOutOfMemory, "smooth_gsrb27_rb: dispatch list of a partial launch");
+    cells = cells * count / A.total_blocks;
+  }
   const int prof = profile_begin(cells);
   hipLaunchKernelGGL((stencil27_rb_kernel<TJ>), dim3(grid), dim3(64, TJ / 2), 0, g_stream, *L, A);
   g_rb27_launches++;

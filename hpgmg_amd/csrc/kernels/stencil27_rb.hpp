@@ -28,6 +28,7 @@ struct S27RbArgs {
   double a, b, h2inv;
   int sweep;                            // number of the first (even) half sweep: its colour is (i ^ j ^ k ^ sweep) & 1 == 0
   int tiles_i, tiles_j, chunks_k, kchunk, per_xcd, total_blocks;
+  const int *order;                     // dispatch slot -> tile (nullptr: identity); partial launches (common.hpp tile_part_order)
 };
 
 // A x at the centre of three LDS planes (row stride W): operators.27pt.c:60-91 in apply_op_27pt's order -- 8 corners, 12 edges, 6 faces, centre
@@ -56,7 +57,8 @@ __global__ __launch_bounds__(32 * TJ) __attribute__((amdgpu_waves_per_eu(4, 8)))
   __shared__ double sO[3 * PO];
   __shared__ double sP[3 * PP];
 
-  const int logical = xcd_logical_block((int)blockIdx.x, P.per_xcd);
+  int logical = xcd_logical_block((int)blockIdx.x, P.per_xcd);
+  if (P.order) logical = P.order[logical];
   if (logical >= P.total_blocks) return;
   int t = logical;
   const int ti = t % P.tiles_i; t /= P.tiles_i;

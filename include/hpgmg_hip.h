@@ -183,6 +183,13 @@ long long hpgmg_hip_small_vtail_lds_limit(void);
 int hpgmg_hip_small_vtail(const hpgmg_hip_small_tail_args *args, int variant);
 long long hpgmg_hip_small_vtail_launch_count(void);   /* launches so far (tests) */
 void hpgmg_hip_set_defer_mode(int mode);
+/* Two-part launches of the tiled kernels that read neighbouring ranks' cells from images (boxes listed in box_base / box_low / box_nbr
+ * BEHIND the num_boxes own ones, reached through box_nbr like any neighbour): part 1 = the tiles whose halo reaches no image (for the fv4
+ * red + black pass also no domain wall: nothing its pre-pass forms), part 2 = the others, 0 = whole launches.  Lets the caller run the
+ * exchange that refreshes the images on a second stream under part 1 (north_star: "ghost-zone exchange ... overlapped with interior
+ * smoothing"; reference operators/exchange_boundary.c:81-90 only overlaps the local copies).  Applies to hpgmg_hip_smooth_gsrb_fv4_rb and
+ * hpgmg_hip_smooth_gsrb27_rb. */
+void hpgmg_hip_set_tile_part(int part);
 /* The LDS-tiled 27-point and fv4 kernels (boxes whose side is a multiple of 64, out of place) can read x outside a box from the
  * neighbouring box itself when every box of the level is local: the caller then runs only apply_BCs before the launch, not
  * exchange_boundary.  applies() tells whether the next smooth / residual / apply_op launch of `variant` would be such a kernel. */

@@ -92,6 +92,25 @@ def test_config3_kernels_across_rank_boundaries(world, variant, log2, per_rank, 
             assert r["stats"]["fv4_rb_smooths"] >= 8, r["stats"]
         if variant == "27pt-gsrb":
             assert r["stats"]["rb27_passes"] >= 16, r["stats"]
+        if variant.endswith("gsrb") and os.environ.get("HPGMG_OVERLAP", "1") != "0":     # the refresh of a red + black pass runs under the tiles that read no image
+            assert r["stats"]["overlapped_exchanges"] > 20, r["stats"]
+
+
+@pytest.mark.parametrize("variant,gold_key,env", [
+    ("fv4-gsrb", "fv4-gsrb 7 8", {"HPGMG_OVERLAP": "0"}),       # the refresh in line with the launch stream: one whole launch per pass
+    ("27pt-gsrb", "27pt-gsrb 7 8", {"HPGMG_OVERLAP": "0"}),
+    ("fv4-gsrb", "fv4-gsrb 7 8", {"HPGMG_IMAGES": "0"}),        # without the images: exchange_boundary + two half sweeps, what round 3 ran
+])
+def test_config3_multirank_switches(variant, gold_key, env):
+    gold = GOLD[gold_key]
+    res = run_job(2, variant, 7, 4, backend="hip", extra_env=env)
+    assert res[0]["norms"] == gold["norms"], res[0]
+    assert res[0]["repeat"] == [gold["norms"][0]] * 3, res[0]["repeat"]
+    for r in res:
+        if env.get("HPGMG_IMAGES") == "0":
+            assert r["stats"]["image_exchanges"] == 0 and r["stats"]["fv4_rb_smooths"] == 0, r["stats"]
+        else:
+            assert r["stats"]["image_exchanges"] > 20 and r["stats"]["overlapped_exchanges"] == 0, r["stats"]
 
 
 @pytest.mark.parametrize("world,variant,log2,per_rank,gold_key,gather", [

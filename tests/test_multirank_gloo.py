@@ -18,11 +18,12 @@ def free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def run_job(world, variant, log2, per_rank, backend="oracle", gather_dim=0):
+def run_job(world, variant, log2, per_rank, backend="oracle", gather_dim=0, extra_env=None):
     """gather_dim=0: the reference's rank map on every level; > 0: levels of <= gather_dim^3 cells on rank 0 (the product default is 64)."""
     if backend == "oracle":
         build_oracle()
     env = dict(os.environ, OMP_NUM_THREADS="2", MASTER_ADDR="127.0.0.1", HPGMG_GATHER_DIM=str(gather_dim), HPGMG_GRAPH="1")   # graphs on: capture / replay / empty-capture paths get exercised
+    env.update(extra_env or {})
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), os.path.join(ROOT, "tests", "multirank_worker.py"), variant, str(log2), str(per_rank), backend]
     out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
