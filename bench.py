@@ -288,11 +288,12 @@ def main():
         elapsed = float(t.item())
 
     ctypes.CDLL(None).fflush(None)
+    exit_code = 0
     if dist is not None:
         dist.barrier()                       # every rank has flushed its C-level output before rank 0 prints the result
     if rank == 0:
         sec_per_step = elapsed / args.steps
-        roof = None
+        roof, roof_error = None, None
         # The fine-level smoother kernel each workload spends most of its time in: (bytes per cell per sweep when every sweep is a pass of its
         # own -- SURVEY 8(d) --, bytes per cell ONE LAUNCH moves when it performs two sweeps in one pass, description)
         smoother = {"config1": (40, 40, "7-pt constant-coefficient Chebyshev sweep (stencil7_kernel): x_n, x_nm1, rhs, Dinv read + x_np1 written"),
@@ -311,18 +312,20 @@ def main():
             achieved = bytes_per_launch / avg_s / 1e9
             unfused = smoother[0] * sweeps_per_launch * fine_cells / avg_s / 1e9
             traffic, traffic_source = pmc_traffic(args.workload, int(fine_cells)) if world == 1 else (None, None)
-            if achieved > HBM_PEAK_GBS:
-                raise SystemExit(f"bench.py: roofline fraction {achieved / HBM_PEAK_GBS:.3f} > 1 -- the byte model of this kernel is wrong")
-            roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
-                    "kernel": smoother[2] + f" over the {my_boxes} finest-level boxes of {box_dim}^3 of this rank",
-                    "sweeps_per_launch": round(sweeps_per_launch, 3),
-                    "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_us": round(avg_s * 1e6, 2),
-                    "launches_timed": launches.value,
-                    # what separate sweeps would have had to move in the same time: a speed-up figure, not a bandwidth
-                    "unfused_equivalent_GBs": round(unfused, 1),
-                    # what the launch really moves (rocprofv3 PMC, the file named in traffic_source): DRAM-level rate
-                    "dram_GBs_from_pmc": round(traffic / avg_s / 1e9, 1) if traffic else None}
+            if achieved > HBM_PEAK_GBS:      # the line is still printed (the measurement is done), with roofline null and an error field; exit code 3
+                roof_error = f"roofline fraction {achieved / HBM_PEAK_GBS:.3f} > 1 -- the byte model of this kernel is wrong"
+            else:
+              roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
+                      "traffic_note": "PMC bytes per launch from the committed summary named in traffic_source: ANOTHER run (and possibly build) of the same command, not this one" if traffic else None,
+                      "kernel": smoother[2] + f" over the {my_boxes} finest-level boxes of {box_dim}^3 of this rank",
+                      "sweeps_per_launch": round(sweeps_per_launch, 3),
+                      "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_us": round(avg_s * 1e6, 2),
+                      "launches_timed": launches.value,
+                      # what separate sweeps would have had to move in the same time: a speed-up figure, not a bandwidth
+                      "unfused_equivalent_GBs": round(unfused, 1),
+                      # what the launch really moves (rocprofv3 PMC, the file named in traffic_source): DRAM-level rate
+                      "dram_GBs_from_pmc": round(traffic / avg_s / 1e9, 1) if traffic else None}
         line = {
             "metric": "DOF/s (fine-grid) for FMG F-cycle", "value": dof / sec_per_step, "unit": "DOF/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": sec_per_step * 1e3,
@@ -339,15 +342,21 @@ def main():
                        "fine_grid_dof": dof, "fcycle_residual_norm": norm, "parallelism": f"boxes over {world} GPU(s), RCCL halo exchange"},
             "roofline": roof,
         }
+        if roof_error:
+            line["error"] = roof_error
         if world == 1 and not args.no_cpu_baseline and args.workload in ("config2", "config5"):
             line["cpu_baseline"] = cpu_baseline()
         ctypes.CDLL(None).fflush(None)      # anything C code buffered on stdout goes first: the JSON line is the last line
         print(json.dumps(line), flush=True)
+        if roof_error:
+            exit_code = 3
 
     lib.hpgmg_solver_destroy(solver)
     if dist is not None:
         lib.hpgmg_transport_finalize_rccl()
         dist.destroy_process_group()
+    if exit_code:
+        sys.exit(exit_code)
 
 
 if __name__ == "__main__":

@@ -64,7 +64,7 @@ double *hpgmg_vector_alloc(size_t n) {
   if (!p) { fprintf(stderr, "hpgmg: device allocation of %zu doubles failed: %s\n", n, hpgmg_hip_last_error()); abort(); }
   return p;
 }
-void hpgmg_vector_free(double *p) { hpgmg_hip_free(p); }
+void hpgmg_vector_free(double *p) { hp_lazy_flush(); hpgmg_hip_free(p); }      /* a postponed operator may still hold this storage */
 void hpgmg_vector_copy(double *d, const double *s, size_t n) { HIP_OK(hpgmg_hip_memcpy_d2d(d, s, n * sizeof(double))); }
 void hpgmg_vector_upload(double *d, const double *s, size_t n) { HIP_OK(hpgmg_hip_memcpy_h2d(d, s, n * sizeof(double))); }
 void hpgmg_vector_download(double *d, const double *s, size_t n) { HIP_OK(hpgmg_hip_memcpy_d2h(d, s, n * sizeof(double))); }
@@ -93,6 +93,7 @@ void hpgmg_transport_finalize_rccl(void) { hpgmg_set_transport(NULL); hpgmg_hip_
 static int graphs = -1;
 void hpgmg_set_graphs(int on) { graphs = on ? 1 : 0; }
 void hpgmg_segment_begin(long long key) {
+  hp_lazy_flush();                                                     /* nothing postponed may slip into (or past) the captured stretch */
   if (graphs < 0) { const char *e = getenv("HPGMG_GRAPH"); graphs = (e && e[0] == '1'); }
   if (!graphs || hpgmg_get_timer_mode() == TIMERS_SYNC) return;       /* per-operator synchronisation: stay eager */
   /* multi-rank: segments cover levels of <= 64^3 cells; they are message-free (capturable) only when the rank map
@@ -189,8 +190,10 @@ const blockCopy_type *hp_mirror(level_type *owner, const blockCopy_type *host, i
   return d;
 }
 
+static void small_ops_forget(void);
 void hpgmg_level_release(level_type *L) {
   hp_lazy_flush();                                  /* postponed operators hold a pointer to their level */
+  small_ops_forget();                            /* ... and so do the remembered scalar requests */
   hpgmg_hip_graph_reset();                       /* cached graphs hold pointers into this level */
   hpgmg_hip_timer_forget(&L->timers, &L->timers + 1);   /* pending device timers point into this level */
   hpgmg_level_ext *X = hpgmg_level_ext_get(L);
@@ -1228,10 +1231,9 @@ int hpgmg_bottom_solve_fused(level_type *L, int e_id, int R_id, double a, double
   backend_t *B = hp_backend_of(L);
   if (!B->krylov_pinned) { B->krylov_pinned = (int *)hpgmg_hip_host_malloc(64); if (B->krylov_pinned) *B->krylov_pinned = 0; }
   if (!B->krylov_pinned) return 0;
-  hpgmg_tick tk = hpgmg_tick_begin(L, &L->timers.Total, "bottom solve, one launch");
+  /* no tick of its own: the caller (MGVCycle -> IterativeSolver) already charges the bottom solve to L->timers.Total */
   HIP_OK(hpgmg_hip_bottom_bicgstab(&B->dev, hp_variant(), e_id, R_id, hpgmg_vectors_reserved(), a, b, 1.0 / (L->h * L->h), want,
                                    n_bc ? hp_mirror(L, L->boundary_condition.blocks[shape], n_bc) : NULL, n_bc, bc_kind, zero_first, B->krylov_pinned));
-  hpgmg_tick_end(tk);
   return 1;
 }
 
@@ -1908,6 +1910,7 @@ static double so_cache_value = 0.0;
 static long long small_ops_answers = 0;
 long long hpgmg_small_ops_prefetched(void) { return small_ops_answers; }      /* scalars answered without a launch (tests) */
 static int so_same(const so_request *r, level_type *L, int kind, int a, int b) { return r->L == L && r->kind == kind && r->a == a && r->b == b; }
+static void small_ops_forget(void) { so_npred = 0; so_last_fresh = 0; so_cache_valid = 0; }      /* a level is going away: the remembered requests name it */
 static void so_touch(void) { so_last_fresh = 0; so_cache_valid = 0; }          /* something was issued or queued: what is remembered about the last scalar is stale */
 /* issue the queue (mode LZ_SMALL, or nothing) on level L as one launch; value_kind 6 / 7: ending in dot(va, vb) / norm(va), whose value is returned;
  * p_kind: a second, predicted request formed by the same launch (its value to *p_out) */
@@ -2127,6 +2130,7 @@ static int small_value_request(level_type *L, int kind, int a, int b, double *ou
   int p_kind = 0, pa = 0, pb = 0;
   for (q = 0; q < so_npred; q++) if (so_same(&so_pred_key[q], L, kind, a, b)) { p_kind = so_pred_val[q].kind; pa = so_pred_val[q].a; pb = so_pred_val[q].b; }
   if (p_kind && lz_n >= hpgmg_hip_small_ops_max() - 2) p_kind = 0;
+  if (p_kind && (pa < 0 || pa >= L->numVectors || pb < 0 || pb >= L->numVectors)) p_kind = 0;      /* a remembered request must name vectors this level has */
   double pv = 0.0;
   *out = small_ops_issue(L, kind, a, b, p_kind, pa, pb, &pv);
   so_last.L = L; so_last.kind = kind; so_last.a = a; so_last.b = b; so_last_fresh = 1;

@@ -51,7 +51,10 @@ __global__ __launch_bounds__(256) void ghost_fill_kernel(const hpgmg_hip_level L
 // deeper ghost cell may see a shallower one already (high side) or not yet (low side) updated.  One lane per
 // list entry walks its block in exactly that order; entries run in parallel like the reference's OpenMP tasks.
 // Setup only (called from rebuild_operator), never in the timed cycle.
-__global__ __launch_bounds__(64) void extrapolate_betas_kernel(const hpgmg_hip_level L, const blockCopy_type *__restrict__ list, int n) {
+// Blocks of one box depend on each other (the deeper layer of an edge block reads the shallower layer of a face block), and the reference
+// with one thread runs them in list order: per box the 26 directions in the order of level.c:377-379.  The launcher therefore runs one
+// launch per direction `phase` (blocks of the same direction never read each other's cells), in that order.
+__global__ __launch_bounds__(64) void extrapolate_betas_kernel(const hpgmg_hip_level L, const blockCopy_type *__restrict__ list, int n, int phase) {
   const int b = blockIdx.x * 64 + threadIdx.x;
   if (b >= n) return;
   const blockCopy_type &e = list[b];
@@ -63,6 +66,7 @@ __global__ __launch_bounds__(64) void extrapolate_betas_kernel(const hpgmg_hip_l
   if (ilo >= L.dim) subtype += 1;
   if (jlo >= L.dim) subtype += 3;
   if (klo >= L.dim) subtype += 9;
+  if (subtype != phase) return;
   const int normal = 26 - subtype, di = normal % 3 - 1, dj = (normal % 9) / 3 - 1, dk = normal / 9 - 1;
   const int bs[3] = { dj * jS + dk * kS, di + dk * kS, di + dj * jS };
   const int skip_lo[3] = {12, 10, 4}, skip_hi[3] = {14, 16, 22};
@@ -351,7 +355,8 @@ int hpgmg_hip_exchange_and_bc(const hpgmg_hip_level *L, int id, const blockCopy_
 int hpgmg_hip_extrapolate_betas(const hpgmg_hip_level *L, const blockCopy_type *blocks, int n) {
   HPGMG_SKIP_IF_REPLAY();
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(extrapolate_betas_kernel, dim3((n + 63) / 64), dim3(64), 0, g_stream, *L, blocks, n);
+  for (int phase = 0; phase < 27; phase++)
+    if (phase != 13) hipLaunchKernelGGL(extrapolate_betas_kernel, dim3((n + 63) / 64), dim3(64), 0, g_stream, *L, blocks, n, phase);
   HPGMG_LAUNCH_CHECK("extrapolate_betas_kernel");
   return 0;
 }

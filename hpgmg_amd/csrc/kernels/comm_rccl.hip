@@ -13,9 +13,11 @@
 // The scalar reductions involve only the ranks active on that level (the reference's per-level
 // MPI_Comm_split).  A MAX over every rank of the job -- norm() on a level all ranks share, the
 // only reduction of a Dirichlet solve that crosses ranks once the coarse levels are gathered --
-// is one ncclAllReduce (a maximum is exact in any order).  Sums, and reductions over a subset of
-// the ranks, are an all-to-all of 8-byte messages reduced on the host in rank order: the result
-// is then the same association on every rank and from run to run, which the golden numbers need.
+// is one ncclAllReduce (a maximum is exact in any order).  A SUM over every rank of the job (dot() and mean() on a level all ranks
+// share: ten per iteration of a host-driven BiCGStab, solvers/bicgstab.c:14-97) is ONE ncclAllGather of the partials followed by an
+// addition in rank order on the host: one collective, and the same association on every rank and from run to run, which the golden
+// numbers need (ncclAllReduce(ncclSum) would add in whatever order the ring or tree RCCL picked).  Only reductions over a SUBSET of
+// the ranks (levels below the agglomeration point) remain an all-to-all of 8-byte messages, reduced the same way.
 #include <stdio.h>
 #include <string.h>
 #include <rccl/rccl.h>
@@ -24,8 +26,10 @@
 namespace hpgmg {
 static ncclComm_t g_comm = nullptr;
 static int g_rank = 0, g_size = 1;
-static double *g_red_dev = nullptr;   // [g_size] staging for the scalar all-to-all
-static double *g_red_host = nullptr;  // pinned
+constexpr int kRedMax = 16;           // values per reduction call (the path reduces one)
+static double *g_red_dev = nullptr;   // [(g_size + 1) * kRedMax] staging: every rank's partials, then my own
+static double *g_red_host = nullptr;  // pinned, same size
+static long long g_allgathers = 0;
 static int nccl_fail(ncclResult_t r, const char *where) {
   fprintf(stderr, "hpgmg_hip: %s: %s\n", where, ncclGetErrorString(r));
   return 1000 + (int)r;
@@ -49,8 +53,8 @@ int hpgmg_hip_rccl_init(const char *id128, int rank, int size) {
   memcpy(id.internal, id128, NCCL_UNIQUE_ID_BYTES);
   NCCL_OK(ncclCommInitRank(&g_comm, size, id, rank));
   g_rank = rank; g_size = size;
-  HPGMG_CHECK(hipMalloc((void **)&g_red_dev, (size_t)size * sizeof(double)));
-  HPGMG_CHECK(hipHostMalloc((void **)&g_red_host, (size_t)size * sizeof(double), hipHostMallocDefault));
+  HPGMG_CHECK(hipMalloc((void **)&g_red_dev, (size_t)(size + 1) * kRedMax * sizeof(double)));
+  HPGMG_CHECK(hipHostMalloc((void **)&g_red_host, (size_t)(size + 1) * kRedMax * sizeof(double), hipHostMallocDefault));
   return 0;
 }
 
@@ -75,7 +79,7 @@ void hpgmg_hip_rccl_sendrecv(void *ctx, int nrecv, double *const *rbuf, const in
 
 // MAX of n (<= job size) host doubles over EVERY rank of the communicator, in place: misc.c:324 MPI_Allreduce(MPI_MAX) on a level all ranks share
 int hpgmg_hip_rccl_allreduce_max_world(double *vals, int n) {
-  if (!g_comm || n > g_size || n < 1) return record_error(hipErrorInvalidValue, "rccl_allreduce_max_world");
+  if (!g_comm || n > kRedMax || n < 1) return record_error(hipErrorInvalidValue, "rccl_allreduce_max_world");
   memcpy(g_red_host, vals, (size_t)n * sizeof(double));
   HPGMG_CHECK(hipMemcpyAsync(g_red_dev, g_red_host, (size_t)n * sizeof(double), hipMemcpyHostToDevice, g_stream));
   NCCL_OK(ncclAllReduce(g_red_dev, g_red_dev, (size_t)n, ncclDouble, ncclMax, g_comm, g_stream));
@@ -85,13 +89,33 @@ int hpgmg_hip_rccl_allreduce_max_world(double *vals, int n) {
   return 0;
 }
 
+// SUM (or MAX) of n host doubles over EVERY rank, in place, as one ncclAllGather + a reduction in rank order on the host (misc.c:276,373)
+long long hpgmg_hip_rccl_allgather_count(void) { return g_allgathers; }
+int hpgmg_hip_rccl_allreduce_ordered_world(double *vals, int n, int op) {
+  if (!g_comm || n > kRedMax || n < 1) return record_error(hipErrorInvalidValue, "rccl_allreduce_ordered_world");
+  double *mine_dev = g_red_dev + (size_t)g_size * kRedMax, *mine_host = g_red_host + (size_t)g_size * kRedMax;
+  memcpy(mine_host, vals, (size_t)n * sizeof(double));
+  HPGMG_CHECK(hipMemcpyAsync(mine_dev, mine_host, (size_t)n * sizeof(double), hipMemcpyHostToDevice, g_stream));
+  NCCL_OK(ncclAllGather(mine_dev, g_red_dev, (size_t)n, ncclDouble, g_comm, g_stream));       // rank r's values land at [r * n, (r + 1) * n)
+  HPGMG_CHECK(hipMemcpyAsync(g_red_host, g_red_dev, (size_t)g_size * n * sizeof(double), hipMemcpyDeviceToHost, g_stream));
+  HPGMG_CHECK(hipStreamSynchronize(g_stream));             // the caller needs the value on the host, as after MPI_Allreduce
+  for (int v = 0; v < n; v++) {
+    double acc = g_red_host[v];
+    for (int r = 1; r < g_size; r++) { const double x = g_red_host[(size_t)r * n + v]; if (op == 0) acc = (x > acc) ? x : acc; else acc += x; }
+    vals[v] = acc;
+  }
+  g_allgathers++;
+  return 0;
+}
+
 // signature = hpgmg_transport.allreduce: n host doubles, in place, over `ranks` (sorted, contains me)
 void hpgmg_hip_rccl_allreduce(void *ctx, double *vals, int n, int op, const int *ranks, int nranks) {
   (void)ctx;
   hpgmg_hip_graph_flush();
   if (nranks <= 1) return;
   if (!g_comm) { fprintf(stderr, "hpgmg_hip: RCCL transport used before hpgmg_hip_rccl_init\n"); abort(); }
-  if (op == 0 && nranks == g_size && n <= g_size) { if (hpgmg_hip_rccl_allreduce_max_world(vals, n)) abort(); return; }
+  if (op == 0 && nranks == g_size && n <= kRedMax) { if (hpgmg_hip_rccl_allreduce_max_world(vals, n)) abort(); return; }
+  if (nranks == g_size && n <= kRedMax) { if (hpgmg_hip_rccl_allreduce_ordered_world(vals, n, op)) abort(); return; }      // sums: one collective, rank-ordered association
   for (int v = 0; v < n; v++) {   // n is 1 everywhere on the path; keep the general form simple
     g_red_host[g_rank] = vals[v];
     hipMemcpyAsync(g_red_dev + g_rank, g_red_host + g_rank, sizeof(double), hipMemcpyHostToDevice, g_stream);

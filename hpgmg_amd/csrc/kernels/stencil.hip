@@ -2113,7 +2113,7 @@ int hpgmg_hip_small_ops(const hpgmg_hip_level *L, int variant, int n, const int 
   if ((nvalues >= 1) != (value_out != nullptr) || (nvalues == 2) != (value2_out != nullptr)) return record_error(hipErrorInvalidValue, "small_ops: one output pointer per value-returning operation");
   if (wants) { A.result = reduction_slot_next(&A.seq); if (!A.result) return record_error(hipErrorOutOfMemory, "small_ops: result slot"); }
   const int cells = L->dim * L->dim * L->dim;
-  const int threads = cells > 256 ? 512 : (A.n_bc > 4 ? 512 : 64);          // the boundary entries are a wave's work each
+  const int threads = cells > 64 ? 512 : (A.n_bc > 4 ? 512 : 64);           // one cell per lane (no striding); the boundary entries are a wave's work each
 #define SMALL_OPS_CASE(VAR) hipLaunchKernelGGL((small_ops_kernel<VAR>), dim3(1), dim3(threads), 0, g_stream, *L, A);
   switch (variant) {
     case HPGMG_HIP_27PT_CC:          SMALL_OPS_CASE(HPGMG_HIP_27PT_CC) break;

@@ -395,6 +395,11 @@ void hpgmg_hip_rccl_allreduce(void *ctx, double *vals, int n, int op, const int 
 /* MAX of n (<= job size) host doubles over every rank of the communicator, in place (one ncclAllReduce; what the transport's allreduce uses for a
  * whole-job maximum, misc.c:324) */
 int  hpgmg_hip_rccl_allreduce_max_world(double *vals, int n);
+/* SUM (op 1) or MAX (op 0) of n (<= 16) host doubles over every rank, in place, as ONE ncclAllGather of the partials followed by a reduction in
+ * rank order on the host: the association of misc.c:276,373's MPI_Allreduce(MPI_SUM) made deterministic (what the transport's allreduce uses
+ * for a whole-job sum); _allgather_count = how many have run (tests) */
+int  hpgmg_hip_rccl_allreduce_ordered_world(double *vals, int n, int op);
+long long hpgmg_hip_rccl_allgather_count(void);
 
 #ifdef __cplusplus
 }

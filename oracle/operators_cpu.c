@@ -426,13 +426,17 @@ void apply_BCs_v4(level_type *L, int x_id, int shape) {
 /* boundary_fv.c:573-681: fill the ghost cells of the face coefficients by polynomial extrapolation along the
  * direction pointing back into the box (the coefficient normal to a face keeps its face value).  The
  * reference walks each block in k,j,i order IN PLACE, so a deeper ghost cell may read a shallower one that
- * was (high side) or was not yet (low side) updated; the same order is kept here. */
+ * was (high side) or was not yet (low side) updated; the same order is kept here.
+ * BLOCKS depend on each other too: the deeper cells of an edge block are formed from the shallower layer of a FACE block of the same box
+ * (one step along the edge's diagonal), so their values depend on which block ran first.  The reference threads this loop over the blocks
+ * (PRAGMA_THREAD_ACROSS_BLOCKS), i.e. with several threads those cells -- which no stencil reads: apply_op_ijk only takes coefficient
+ * differences along the axes -- are a race; with ONE thread the blocks run in list order, which is what this restatement does and what the
+ * per-operator fixtures (tests/golden/ops_golden.json, generated with OMP_NUM_THREADS=1) pin. */
 void extrapolate_betas(level_type *L) {
   if (L->boundary_condition.type == BC_PERIODIC) return;
   const double t0 = now();
   const int shape = 0;
   int n;
-  _Pragma("omp parallel for schedule(static,1)")
   for (n = 0; n < L->boundary_condition.num_blocks[shape]; n++) {
     const blockCopy_type *blk = &L->boundary_condition.blocks[shape][n];
     const box_type *B = &L->my_boxes[blk->read.box];

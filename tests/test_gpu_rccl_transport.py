@@ -43,6 +43,11 @@ def test_rccl_sendrecv_to_self_and_trivial_allreduce():
         K.hpgmg_hip_rccl_allreduce_max_world.argtypes = [P(ctypes.c_double), c_int]
         assert K.hpgmg_hip_rccl_allreduce_max_world(val, 1) == 0                      # the ncclAllReduce(max) the transport issues on levels every rank shares
         assert val[0] == 3.25
+        K.hpgmg_hip_rccl_allreduce_ordered_world.argtypes = [P(ctypes.c_double), c_int, c_int]
+        K.hpgmg_hip_rccl_allgather_count.restype = ctypes.c_longlong
+        pair = (ctypes.c_double * 2)(0.1, -2.5)
+        assert K.hpgmg_hip_rccl_allreduce_ordered_world(pair, 2, 1) == 0               # the ncclAllGather + rank-ordered sum of a whole-job dot() / mean()
+        assert (pair[0], pair[1]) == (0.1, -2.5) and K.hpgmg_hip_rccl_allgather_count() == 1
         K.hpgmg_hip_free(vp(d_s)); K.hpgmg_hip_free(vp(d_r))
     finally:
         K.hpgmg_hip_rccl_finalize()
