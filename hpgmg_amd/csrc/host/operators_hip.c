@@ -1867,7 +1867,8 @@ typedef struct { int op; level_type *L, *L2; int i0, i1, i2; double a, b; } lazy
 #define LZ_MAX 80
 static lazy_op lz[LZ_MAX];
 static int lz_n = 0, lz_mode = LZ_NONE, lz_busy = 0, lazy_on = -1;
-static long long lazy_fused_legs = 0, lazy_fused_units = 0;
+static long long lazy_fused_legs = 0, lazy_fused_units = 0, lazy_temp_proved_dead = 0;
+long long hpgmg_lazy_temp_proved_dead(void) { return lazy_temp_proved_dead; }      /* smooth() calls run in the in-cycle form because the queue saw VECTOR_TEMP overwritten next (tests) */
 long long hpgmg_lazy_fused_legs(void) { return lazy_fused_legs; }      /* single-launch legs / fused large-level units issued by the queue so far (tests) */
 long long hpgmg_lazy_fused_units(void) { return lazy_fused_units; }
 void hpgmg_set_lazy(int on) { hp_lazy_flush(); lazy_on = on ? 1 : 0; }
@@ -1875,7 +1876,7 @@ void hpgmg_operators_flush(void) { hp_lazy_flush(); }      /* issue every postpo
 /* HPGMG_LAZY_REPORT=1: what the queue did, on stderr when the process ends (tests/test_gpu_route_b.py reads it) */
 __attribute__((destructor)) static void lazy_report(void) {
   const char *e = getenv("HPGMG_LAZY_REPORT");
-  if (e && e[0] == '1') fprintf(stderr, "hpgmg lazy queue: %lld single-launch legs, %lld fused large-level units\n", lazy_fused_legs, lazy_fused_units);
+  if (e && e[0] == '1') fprintf(stderr, "hpgmg lazy queue: %lld single-launch legs, %lld fused large-level units, %lld smooths with VECTOR_TEMP proved dead\n", lazy_fused_legs, lazy_fused_units, lazy_temp_proved_dead);
 }
 static int lazy_enabled(void) {
   if (lazy_on < 0) { const char *e = getenv("HPGMG_LAZY"); lazy_on = !(e && e[0] == '0'); }
@@ -1971,8 +1972,15 @@ void hp_lazy_flush(void) {
       chain[m++] = lz[4 * (units - 1) + 2].L;
       const lazy_op *s0 = &lz[4 * u];
       if (m >= 2 && vcycle_legs_fused(chain, m, s0->i0, s0->i1, s0->a, s0->b, 0)) { lazy_fused_legs++; u = units; break; }
-      /* this unit on its own: smooth, then residual + restriction + zero_vector in one pass where the level allows it */
-      lazy_run_one(&lz[4 * u]);
+      /* this unit on its own: smooth, then residual + restriction + zero_vector in one pass where the level allows it.  The unit's next
+       * operator is residual(VECTOR_TEMP, ...) (mg.c:1150), which overwrites what smooth() leaves in VECTOR_TEMP before anything can read it:
+       * the queue has PROVED the vector dead, so the smoother may run in its in-cycle form (hpgmg_smooth_in_cycle: the sweep pair without the
+       * x3 store, the 27-point / fv4 red + black passes) although the reference's driver never says so.  HPGMG_TEMP_SCRATCH=0 keeps the exact form. */
+      { static int dead_ok = -1;
+        if (dead_ok < 0) { const char *e = getenv("HPGMG_TEMP_SCRATCH"); dead_ok = !(e && e[0] == '0'); }
+        const lazy_op *sm = &lz[4 * u];
+        if (dead_ok && sm->i0 != VECTOR_TEMP && sm->i1 != VECTOR_TEMP) { temp_is_scratch = 1; lazy_run_one(sm); temp_is_scratch = 0; lazy_temp_proved_dead++; }
+        else lazy_run_one(sm); }
       const lazy_op *r = &lz[4 * u + 1], *t = &lz[4 * u + 2], *z = &lz[4 * u + 3];
       if (residual_restrict_zero_fused(t->L, t->i0, r->L, r->i0, r->i1, r->i2, r->a, r->b, z->i0)) lazy_fused_units++;
       else { lazy_run_one(r); lazy_run_one(t); lazy_run_one(z); }

@@ -1,0 +1,43 @@
+"""The parity sweep of tools/parity_sweep.sh as part of the GPU suite: the HIP executable and the CPU-oracle executable (same host layer, same
+CLI as the reference's hpgmg-fv) run the same arguments, and every pinned line -- f-cycle norms at h / 2h / 4h (mg.c:1328), eigenvalue bounds of
+rebuild_operator, Richardson error and order (mg.c:1128,1130) -- must be identical.  Every plugin and smoother, non-power-of-two decompositions
+(27, 125, 216 boxes: 3^3 ... 6^3 bottoms where BiCGStab really iterates, agglomerating ladders) and the periodic builds.  The oracle side of
+these odd decompositions is pinned to the reference binary by tests/test_oracle_vs_reference.py."""
+import os
+import re
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PINNED = re.compile(r"f-cycle|\|\|error\|\||order=|eigenvalue")
+
+CASES = [
+    ("", "4 27"), ("--smoother gsrb", "4 125"), ("--helmholtz", "5 216"), ("--const-coeff", "4 27"), ("--smoother jacobi", "4 27"),
+    ("--op 27pt", "4 27"), ("--op 27pt --smoother gsrb", "4 125"), ("--op 27pt --smoother gsrb", "6 27"),
+    ("--op fv4 --smoother gsrb", "4 27"), ("--op fv4 --smoother gsrb", "4 125"), ("--op fv4 --smoother gsrb", "5 216"), ("--op fv4", "4 27"),
+    ("--op fv2", "4 125"), ("--op fv2", "5 27"),
+    ("--periodic", "4 27"), ("--periodic --smoother gsrb --helmholtz", "4 64"), ("--smoother gsrb", "4 343"),
+]
+
+
+def pinned_lines(exe, flags, size):
+    cmd = [exe, "--warmup", "1", "--solves", "2"] + flags.split() + size.split()
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, OMP_WAIT_POLICY="passive"))
+    assert out.returncode == 0, (cmd, out.stdout[-800:], out.stderr[-800:])
+    lines = []
+    for line in out.stdout.splitlines():
+        if PINNED.search(line):
+            line = re.sub(r"  done \(.*", "", line)
+            line = re.sub(r".*(eigenvalue_max.*)", r"\1", line)
+            lines.append(line.strip())
+    return lines
+
+
+@pytest.mark.parametrize("flags,size", CASES)
+def test_hip_executable_prints_what_the_oracle_executable_prints(flags, size):
+    hip = pinned_lines(os.path.join(ROOT, "hpgmg_amd", "bin", "hpgmg-fv"), flags, size)
+    cpu = pinned_lines(os.path.join(ROOT, "oracle", "hpgmg-fv-oracle"), flags, size)
+    assert len(hip) >= 10 and any("f-cycle" in l for l in hip)
+    assert hip == cpu

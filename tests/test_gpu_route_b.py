@@ -38,6 +38,8 @@ def test_reference_driver_runs_on_the_hip_plugin(variant, args):
     assert out.returncode == 0, out.stderr[-2000:]
     # the reference's MGVCycle knows none of the fused hooks: the plugin's lazy queue must have recognised its legs and run them fused
     m = re.search(r"hpgmg lazy queue: (\d+) single-launch legs, (\d+) fused large-level units", out.stderr)
+    if args == "7 8":       # the pre-smooth of a level too large for the single-launch legs: the queue sees residual(VECTOR_TEMP) next and runs the in-cycle form
+        assert int(re.search(r"(\d+) smooths with VECTOR_TEMP proved dead", out.stderr).group(1)) > 0, out.stderr[-500:]
     if variant.startswith("7pt"):
         assert m and int(m.group(1)) > 0 and (int(m.group(2)) > 0 or args != "7 8"), out.stderr[-500:]      # large-level units only exist at 256^3
     elif variant != "27pt-gsrb":         # fv4 / fv2: the legs over their levels of one box (small_vtail_kernel); 27-point GSRB keeps its box kernel
@@ -54,3 +56,25 @@ def test_reference_driver_runs_on_the_hip_plugin(variant, args):
     assert [l for l in lines if l.startswith("||error||")] == ["||error||=" + gold["richardson_error"]]
     assert [l for l in lines if l.startswith("order=")] == ["order=" + gold["order"]]
     assert "DOF/s=" in out.stdout
+
+
+@pytest.mark.parametrize("variant,args", [("7pt-cheby-vcycle", "5 8"), ("7pt-cheby-vcycle", "7 8"), ("fv4-gsrb-vcycle", "5 8")])
+def test_reference_mgsolve_runs_on_the_hip_plugin(variant, args):
+    """The reference's OTHER driver of the same plugin: built without -DUSE_FCYCLES its benchmark calls MGSolve (mg.c:1168-1233: V-cycles until
+    the residual has dropped by 1e-10, a residual() + norm() after every cycle).  That is a second caller of the lazy operator queue with its own
+    call order; every printed norm must equal what the reference binary itself prints for the same arguments (run here, on the host cores)."""
+    routeb = os.path.join(ROOT, "oracle", "_ref", "routeb-" + variant)
+    ref = os.path.join(ROOT, "oracle", "_ref", "hpgmg-" + variant)
+    if not (os.path.exists(routeb) and os.path.exists(ref)):
+        pytest.skip("oracle/_ref/*-vcycle not built (needs /root/reference: make -C oracle ref)")
+    env = dict(os.environ, OMP_NUM_THREADS="8", HPGMG_LAZY_REPORT="1")
+    outs = []
+    for exe in (routeb, ref):
+        out = subprocess.run([exe] + args.split(), capture_output=True, text=True, env=env, timeout=900)
+        assert out.returncode == 0, out.stderr[-2000:]
+        outs.append(out)
+    keep = lambda o: re.findall(r"(v-cycle=\s*\d+\s+norm=\S+\s+rel=\S+|\|\|error\|\|=\S+|order=\S+|eigenvalue_max<\S+)", o.stdout)
+    a, b = keep(outs[0]), keep(outs[1])
+    assert len(a) > 50 and a == b, [x for x in zip(a, b) if x[0] != x[1]][:4]
+    m = re.search(r"hpgmg lazy queue: (\d+) single-launch legs, (\d+) fused large-level units, (\d+) smooths with VECTOR_TEMP proved dead", outs[0].stderr)
+    assert m and int(m.group(1)) > 0 and int(m.group(3)) > 0, outs[0].stderr[-500:]
