@@ -84,6 +84,18 @@ int hpgmg_transport_init_rccl(const char *id128, int rank, int size) {
   return 0;
 }
 void hpgmg_transport_finalize_rccl(void) { hpgmg_set_transport(NULL); hpgmg_hip_rccl_finalize(); }
+/* The node-local alternative: direct peer copies between the ranks' device buffers (kernels/comm_ipc.hip). */
+int hpgmg_transport_init_ipc(const char *name, int rank, int size) {
+  hpgmg_transport t;
+  int e = hpgmg_hip_ipc_init(name, rank, size);
+  if (e) return e;
+  t.rank = rank; t.size = size; t.ctx = NULL;
+  t.sendrecv = hpgmg_hip_ipc_sendrecv;
+  t.allreduce = hpgmg_hip_ipc_allreduce;
+  hpgmg_set_transport(&t);
+  return 0;
+}
+void hpgmg_transport_finalize_ipc(void) { hpgmg_set_transport(NULL); hpgmg_hip_ipc_finalize(); }
 
 /* ---------------------------------------------------------------- hipGraph segments (see hpgmg_operators.h) */
 /* hipGraph capture/replay of the launch-bound segments is available but OFF by default: with the launch stream
@@ -200,6 +212,7 @@ void hpgmg_level_release(level_type *L) {
   backend_t *B = (backend_t *)X->backend;
   int s;
   if (!B) return;
+  hpgmg_hip_pair_packed_forget(&B->dev);
   hp_images_release(B);
   for (s = 0; s < B->num_lists; s++) hpgmg_hip_free(B->lists[s].dev);
   for (s = 0; s < STENCIL_MAX_SHAPES; s++) if (B->d_bc[s]) hpgmg_hip_free(B->d_bc[s]);
@@ -802,7 +815,7 @@ static const float *const *coef32_of(level_type *L) {
   if (!B->coef32_valid) { HIP_OK(hpgmg_hip_coef32_refresh(&B->dev, (float *const *)B->d_coef32_base, L->numVectors)); B->coef32_valid = 1; }
   return (const float *const *)B->d_coef32_base;
 }
-static void coef32_invalidate(level_type *L) { backend_t *B = hp_backend_of(L); B->coef32_valid = 0; if (B->halo) B->halo->coef_valid = 0; hp_images_invalidate_coefficients(B); }
+static void coef32_invalidate(level_type *L) { backend_t *B = hp_backend_of(L); B->coef32_valid = 0; if (B->halo) B->halo->coef_valid = 0; hp_images_invalidate_coefficients(B); hpgmg_hip_pair_packed_invalidate(&B->dev); }
 
 /* ---------------------------------------------------------------- sweep pairs across rank boundaries: halo plans */
 static int pair_remote_enabled(void) {

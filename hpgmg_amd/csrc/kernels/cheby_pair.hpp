@@ -51,6 +51,9 @@ struct PairArgs {
   const double *deep_beta;                          // [box][face 1,3,5 -> 0..2][v][u]: beta_i / beta_j / beta_k at local index dim+1
   int tiles_i, slabs_j, chunks_k, KC, per_xcd, total_blocks;
   int edge_blocks, edge_per_xcd;                    // the pre-pass grid (cheby_pair_edge_kernel)
+  // the eight coefficient values of every pre-pass cell (beta_i low / high face, beta_j, beta_k, alpha, Dinv), packed [column][k][j][8] once per
+  // operator rebuild: the pre-pass walks COLUMNS of the boxes, where each value read in place costs a 64-byte sector of its own (null: read in place)
+  double *edge_coef;
 };
 
 __device__ __forceinline__ double *pair_vec(const hpgmg_hip_level &L, const PairArgs &A, VecRef r, int box) {
@@ -393,7 +396,8 @@ __global__ __launch_bounds__(64 * NW) void cheby_pair_kernel(const hpgmg_hip_lev
 // reads as i neighbours of the second sweep.  One lane per cell of those columns (0.8 % of the level), lanes along j.
 // REMOTE: also on the ghost columns gi = -1 / Di of remote i faces (columns 2 (tiles_i - 1) and + 1), formed from the ghost
 // zone and the deep halo exactly as the owning rank forms its own cells; neighbours across remote j / k faces come from the ghost zone.
-template <int V, bool C32, int SM, bool INTERP, bool REMOTE = false>
+// PACK: instead of forming x1, store the cell's eight coefficient values to A.edge_coef (once per operator rebuild); later launches read them there.
+template <int V, bool C32, int SM, bool INTERP, bool REMOTE = false, bool PACK = false>
 __global__ __launch_bounds__(256) void cheby_pair_edge_kernel(const hpgmg_hip_level L, const PairArgs A) {
   constexpr bool kVC = (V != HPGMG_HIP_7PT_CC);
   constexpr bool kHelm = (V == HPGMG_HIP_7PT_VC_HELMHOLTZ);
@@ -435,19 +439,30 @@ __global__ __launch_bounds__(256) void cheby_pair_edge_kernel(const hpgmg_hip_le
     return v;
   };
   int box; const int idx = cell(gi, gj, gk, box);
-  const double xc = x0_at(gi, gj, gk, 0.0);
-  double bi0 = 0, bi1 = 0, bj0 = 0, bj1 = 0, bk0 = 0, bk1 = 0, al = 0;
-  if (kVC) {
+  double bi0 = 0, bi1 = 0, bj0 = 0, bj1 = 0, bk0 = 0, bk1 = 0, al = 0, dinv = 0;
+  const bool packed = !PACK && !REMOTE && !C32 && kVC && A.edge_coef != nullptr;
+  double *const pk = (!REMOTE && !C32 && kVC && A.edge_coef) ? A.edge_coef + ((size_t)(col * A.Dk + gk) * A.Dj + gj) * 8 : nullptr;
+  if (packed) {                                               // one 64-byte line per cell, consecutive lanes consecutive lines
+    const d2v v0 = *(gd2cptr)as_global(pk), v1 = *(gd2cptr)as_global(pk + 2), v2 = *(gd2cptr)as_global(pk + 4), v3 = *(gd2cptr)as_global(pk + 6);
+    bi0 = v0.x; bi1 = v0.y; bj0 = v1.x; bj1 = v1.y; bk0 = v2.x; bk1 = v2.y; al = v3.x; dinv = v3.y;
+  }
+  const double xc = PACK ? 0.0 : x0_at(gi, gj, gk, 0.0);
+  if (kVC && !packed) {
     const CoefStream<C32> bi(L, A, box, VECTOR_BETA_I, C32_BETA_I), bj(L, A, box, VECTOR_BETA_J, C32_BETA_J), bk(L, A, box, VECTOR_BETA_K, C32_BETA_K);
     bi0 = bi.one(idx); bj0 = bj.one(idx); bj1 = bj.one(idx + jS); bk0 = bk.one(idx); bk1 = bk.one(idx + kS);
     // the far face of a ghost cell beyond the high i face is one index past the ghost zone: deep coefficient halo
     if (REMOTE && gi >= A.Di) bi1 = A.deep_beta[(((size_t)box * 3 + 0) * bd + (gk % bd)) * bd + (gj % bd)];
     else bi1 = bi.one(idx + 1);
   }
-  if (kHelm) al = CoefStream<C32>(L, A, box, VECTOR_ALPHA, C32_ALPHA).one(idx);
+  if (kHelm && !packed) al = CoefStream<C32>(L, A, box, VECTOR_ALPHA, C32_ALPHA).one(idx);
+  if (!packed) dinv = CoefStream<C32>(L, A, box, VECTOR_DINV, C32_DINV).one(idx);
+  if (PACK) {
+    if (pk) { pk[0] = bi0; pk[1] = bi1; pk[2] = bj0; pk[3] = bj1; pk[4] = bk0; pk[5] = bk1; pk[6] = al; pk[7] = dinv; }
+    return;
+  }
   const double Ax = apply_op_7pt<V>(xc, x0_at(gi - 1, gj, gk, xc), x0_at(gi + 1, gj, gk, xc), x0_at(gi, gj - 1, gk, xc), x0_at(gi, gj + 1, gk, xc),
                                     x0_at(gi, gj, gk - 1, xc), x0_at(gi, gj, gk + 1, xc), bi0, bi1, bj0, bj1, bk0, bk1, al, A.a, A.b, A.h2inv);
-  const double dinv = CoefStream<C32>(L, A, box, VECTOR_DINV, C32_DINV).one(idx), rhs = vec_origin(L, box, A.rhs_id)[idx];
+  const double rhs = vec_origin(L, box, A.rhs_id)[idx];
   if (SM == PAIR_CHEBY) {
     const double xnm1 = (A.c1a != 0.0) ? pair_vec(L, A, A.xm1, box)[idx] : xc;     // as in the main kernel: not read when its coefficient is 0
     pair_vec(L, A, A.out1, box)[idx] = xc + A.c1a * (xc - xnm1) + A.c2a * dinv * (rhs - Ax);

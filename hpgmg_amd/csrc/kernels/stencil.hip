@@ -1766,6 +1766,27 @@ static int g_pair_discard_x1 = 0;     // consumed by the next Chebyshev pair lau
 static const hpgmg_hip_level *g_pair_interp_level = nullptr;
 static int g_pair_interp_id = 0;
 static double g_pair_interp_prescale = 1.0;
+// The pre-pass's coefficient values, packed once per operator rebuild (cheby_pair.hpp: PairArgs.edge_coef).  Keyed by the level's box table;
+// hpgmg_hip_pair_packed_invalidate() when the coefficients change, _forget() when the level goes away.  HPGMG_TUNE_PAIR_PACKED=0: read in place.
+struct EdgePack { const void *key; int variant, Di, Dj, Dk; double *buf; bool valid; };
+static std::vector<EdgePack> g_edge_packs;
+extern "C" void hpgmg_hip_pair_packed_invalidate(const hpgmg_hip_level *L) { for (EdgePack &e : g_edge_packs) if (!L || e.key == (const void *)L->box_base) e.valid = false; }
+extern "C" void hpgmg_hip_pair_packed_forget(const hpgmg_hip_level *L) {
+  for (size_t q = 0; q < g_edge_packs.size();) {
+    if (!L || g_edge_packs[q].key == (const void *)L->box_base) { (void)hipStreamSynchronize(g_stream); (void)hipFree(g_edge_packs[q].buf); g_edge_packs.erase(g_edge_packs.begin() + (long)q); }
+    else q++;
+  }
+}
+static EdgePack *edge_pack_slot(const hpgmg_hip_level *L, int variant, const PairArgs &A) {
+  static const int on = env_int("HPGMG_TUNE_PAIR_PACKED", 1);
+  if (!on || A.tiles_i < 2 || variant == HPGMG_HIP_7PT_CC) return nullptr;
+  for (EdgePack &e : g_edge_packs) if (e.key == (const void *)L->box_base && e.variant == variant && e.Di == A.Di && e.Dj == A.Dj && e.Dk == A.Dk) return &e;
+  EdgePack e = { (const void *)L->box_base, variant, A.Di, A.Dj, A.Dk, nullptr, false };
+  const size_t n = (size_t)2 * (A.tiles_i - 1) * A.Dk * A.Dj * 8;
+  if (hipMalloc((void **)&e.buf, n * sizeof(double)) != hipSuccess) return nullptr;
+  g_edge_packs.push_back(e);
+  return &g_edge_packs.back();
+}
 static int smooth_pair(const hpgmg_hip_level *L, int variant, int gsrb, int sweep_a, double *const *scr_base, const float *const *c32_base,
                        int x0_scr, int x0_id, int xm1_scr, int xm1_id, int out1_scr, int out1_id, int out2_scr, int out2_id,
                        int rhs_id, double a, double b, double h2inv, double c1a, double c2a, double c1b, double c2b) {
@@ -1814,6 +1835,20 @@ static int smooth_pair(const hpgmg_hip_level *L, int variant, int gsrb, int swee
   const int grid = grid_for(A.total_blocks, &A.per_xcd);
   const long long cells = (long long)A.Di * A.Dj * A.Dk;
   const size_t lds = (size_t)nw * 6 * 64 * sizeof(p2);
+  if (!remote && !c32_base) {        // the pre-pass reads its coefficient values packed; (re)pack them after an operator rebuild
+    EdgePack *pk = edge_pack_slot(L, variant, A);
+    if (pk) {
+      A.edge_coef = pk->buf;
+      if (!pk->valid) {
+        A.edge_blocks = ((A.Dj + 63) / 64) * A.Dk * 2 * (A.tiles_i - 1);
+        const dim3 pgrid(grid_for(A.edge_blocks, &A.edge_per_xcd));
+        if (variant == HPGMG_HIP_7PT_VC_HELMHOLTZ) hipLaunchKernelGGL((cheby_pair_edge_kernel<HPGMG_HIP_7PT_VC_HELMHOLTZ, false, PAIR_CHEBY, false, false, true>), pgrid, dim3(64), 0, g_stream, *L, A);
+        else hipLaunchKernelGGL((cheby_pair_edge_kernel<HPGMG_HIP_7PT_VC_POISSON, false, PAIR_CHEBY, false, false, true>), pgrid, dim3(64), 0, g_stream, *L, A);
+        HPGMG_LAUNCH_CHECK("cheby_pair_edge_kernel (packing)");
+        pk->valid = true;
+      }
+    }
+  }
   const int prof = profile_begin(cells);
 #define PAIR_LAUNCH2(VAR, C32, SM, NARROW, INTERP) { \
       static bool once = false; if (!once) { HPGMG_CHECK(hipFuncSetAttribute((const void *)cheby_pair_kernel<VAR, nw, C32, SM, NARROW, INTERP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once = true; } \

@@ -79,6 +79,10 @@ void        hpgmg_set_verbose(int v);
 /* HIP build only: install the RCCL transport (id from hpgmg_hip_rccl_unique_id on rank 0) */
 int         hpgmg_transport_init_rccl(const char *id128, int rank, int size);
 void        hpgmg_transport_finalize_rccl(void);
+/* the node-local peer-copy transport (hipIpc memory handles + stream-ordered host functions on shared counters, include/hpgmg_hip.h): `name` = a POSIX shared-memory
+ * name ("/...") every rank of the job passes; rank 0 creates the segment */
+int         hpgmg_transport_init_ipc(const char *name, int rank, int size);
+void        hpgmg_transport_finalize_ipc(void);
 void        hpgmg_set_sync_timers(int on);
 void        hpgmg_set_small_fused(int mode);   /* 27-pt / fv2 / fv4: 2 (default) smooth() on levels of ONE box as one single-workgroup launch on an image of the box in LDS; 0 off; 1 (EXPERIMENTS=1 builds) every level of <= 4096 cells, out of global memory (measured slower) */
 void        hpgmg_set_small_vtail(int on);     /* 27-pt / fv2 / fv4: the rest of a V-cycle below a level of one box as ONE launch: 2 (default) on except for 27-pt GSRB, 1 on, 0 off; bit-identical */

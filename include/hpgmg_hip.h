@@ -242,6 +242,11 @@ void hpgmg_hip_pair_set_halo(const int brick_boxes[3], const int remote_face[6],
 /* The NEXT hpgmg_hip_smooth_cheby_pair launch need not store x1: its out1 vector is scratch to the caller (the cycle driver's
  * smooth(): nothing reads VECTOR_TEMP after it).  Saves one of the launch's ten streams; x2 (out2) is unaffected. */
 void hpgmg_hip_pair_discard_x1(void);
+/* The sweep-pair launches keep a packed copy of the coefficient values their pre-pass reads (eight per cell of the columns next to interior tile
+ * edges; built on the first launch of a level): _invalidate(L) after its coefficient vectors changed (rebuild_operator / initialize_problem),
+ * _forget(L) before the level's storage is freed; L = NULL: every level. */
+void hpgmg_hip_pair_packed_invalidate(const hpgmg_hip_level *L);
+void hpgmg_hip_pair_packed_forget(const hpgmg_hip_level *L);
 void hpgmg_hip_pair_launch_counts(long long out[2]);      /* sweep-pair launches so far: all, and those with remote faces (tests) */
 /* One region of a sweep-pair halo message.  vec: 0 = the pair's x0, 1 = its xm1, 2 = its right-hand side, 16 + id = level vector id.
  * Pack copies the region (i fastest) to sendbuf + off; unpack copies recvbuf + off into the region (deep = -1: ghost cells at
@@ -400,6 +405,17 @@ int  hpgmg_hip_rccl_allreduce_max_world(double *vals, int n);
  * for a whole-job sum); _allgather_count = how many have run (tests) */
 int  hpgmg_hip_rccl_allreduce_ordered_world(double *vals, int n, int op);
 long long hpgmg_hip_rccl_allgather_count(void);
+
+/* ---- a second transport for ONE node: peer copies between the ranks' device buffers through hipIpc memory handles, ordered against both ranks'
+ *      streams by host functions on counters in a small POSIX shared-memory segment (no collective library, nothing staged through the host, no
+ *      stream synchronisation); scalars through the same segment, reduced in rank order.  `name` = a shared-memory name ("/...") the ranks of a job agree on; rank 0 creates the segment.  Same callback signatures as
+ *      the RCCL transport.  Works between GPUs of a node (xGMI) and between processes that share a GPU. ---- */
+int  hpgmg_hip_ipc_init(const char *name, int rank, int size);
+void hpgmg_hip_ipc_finalize(void);
+void hpgmg_hip_ipc_sendrecv(void *ctx, int nrecv, double *const *rbuf, const int *rsize, const int *rrank,
+                            int nsend, double *const *sbuf, const int *ssize, const int *srank, int tag);
+void hpgmg_hip_ipc_allreduce(void *ctx, double *vals, int n, int op, const int *ranks, int nranks);
+long long hpgmg_hip_ipc_message_count(void);
 
 #ifdef __cplusplus
 }

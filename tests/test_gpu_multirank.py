@@ -127,3 +127,27 @@ def test_hip_gathered_coarse_levels(world, variant, log2, per_rank, gold_key, ga
     assert res[0]["norms"] == gold["norms"], res[0]
     assert res[0]["err"] == gold["richardson_error"] and res[0]["order"] == gold["order"]
     assert res[0]["repeat"] == [gold["norms"][0]] * 3, res[0]["repeat"]
+
+
+@pytest.mark.parametrize("world,variant,log2,per_rank,gold_key,gather", [
+    (2, "7pt-cheby-helm", 7, 4, "7pt-cheby-helm 7 8", 64),     # sweep pairs with a two-deep halo + overlapped shell launches, product rank map
+    (4, "7pt-cheby", 4, 8, "7pt-cheby 4 27", 0),               # 27 boxes over 4 ranks (7/7/7/6): uneven message plans, reference rank map on every level
+    (8, "7pt-cheby-helm", 7, 1, "7pt-cheby-helm 7 8", 64),     # one box per rank: three remote faces and their edges
+    (2, "7pt-gsrb", 5, 4, "7pt-gsrb 5 8", 0),
+    (2, "fv4-gsrb", 7, 4, "fv4-gsrb 7 8", 64),                 # images of the neighbouring boxes, refreshed on the exchange stream
+    (8, "27pt-gsrb", 7, 1, "27pt-gsrb 7 8", 64),
+    (8, "fv4-gsrb", 7, 8, "fv4-gsrb 7 64", 64),                # BASELINE config 3 as stated
+])
+def test_ipc_peer_copy_transport(world, variant, log2, per_rank, gold_key, gather):
+    """The node-local transport of the product (kernels/comm_ipc.hip): every message is a device-to-device copy from the sender's buffer into the
+    receiver's (hipIpc memory handles), ordered against both ranks' launch streams by stream-ordered host functions on shared counters -- nothing
+    staged through the host, no stream synchronisation -- and every scalar reduction goes through shared memory in rank order.  Unlike RCCL it runs with several ranks on ONE
+    GPU, so here the multi-rank product path runs end to end on device-ordered messages; the numbers must be the single-rank reference's."""
+    gold = GOLD[gold_key]
+    res = run_job(world, variant, log2, per_rank, backend="hip", gather_dim=gather, extra_env={"HPGMG_TEST_TRANSPORT": "ipc"})
+    assert res[0]["norms"] == gold["norms"], res[0]
+    assert res[0]["err"] == gold["richardson_error"] and res[0]["order"] == gold["order"]
+    assert res[0]["repeat"] == [gold["norms"][0]] * 3, res[0]["repeat"]
+    for r in res:
+        assert r["stats"].get("transport") == "ipc" and r["stats"]["messages"] > 50, r["stats"]
+        assert r["stats"]["overlapped_exchanges"] > 0, r["stats"]
