@@ -115,6 +115,12 @@ def main():
     ap.add_argument("--workload", choices=["config1", "config2", "config3-fv4", "config3-27pt", "config4", "config5"], default="config2",
                     help="BASELINE.json configs; default config2 = the one the metric is quoted on.  config3 (`7 64`) and config4 (`8 8`) are the 8-GPU "
                          "configurations: with --gpus 1 they run their single-rank reading (512^3 on one GPU).  config5 = config2 with --precision fp32")
+    ap.add_argument("--transport", choices=["rccl", "ipc"], default="rccl",
+                    help="N > 1: rccl = grouped ncclSend / ncclRecv over xGMI (default, what the driver measures); ipc = the node-local peer-copy transport "
+                         "(hipIpc handles, stream-ordered host functions: hpgmg_amd/csrc/kernels/comm_ipc.hip)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="with --transport ipc: every rank on device 0 (several ranks on ONE GPU).  Exercises and times the N > 1 code path where only one GPU "
+                         "exists; the line says so and is NOT a scaling measurement")
     ap.add_argument("--force-transport", action="store_true", help="initialise torch.distributed + the RCCL transport even with one rank (smoke test of the N>1 bootstrap)")
     ap.add_argument("--precision", choices=["fp64", "fp32"], default="fp64",
                     help="fp32 = BASELINE.json config 5: mixed-precision Chebyshev smoother (fp32 coefficient streams), tolerance-gated; default fp64 = config 2, bit-exact")
@@ -188,10 +194,14 @@ def main():
         dog.start()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a {world}-rank run as {args.gpus} GPUs")
-    if world > 1 and torch.cuda.device_count() < world:
+    if args.share_gpu and args.transport != "ipc":
+        raise SystemExit("--share-gpu needs --transport ipc (RCCL refuses two ranks on one device)")
+    if world > 1 and torch.cuda.device_count() < world and not args.share_gpu:
         raise SystemExit(f"--gpus {world} but only {torch.cuda.device_count()} device(s) visible")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP operator path has no CPU fallback")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
 
     import hpgmg_amd as H
@@ -208,17 +218,26 @@ def main():
             import tempfile      # a one-rank job needs no network rendezvous at all: a file store
             store = "file://" + os.path.join(tempfile.mkdtemp(prefix="hpgmg_bench_"), "store")
             dist.init_process_group(backend="nccl", init_method=store, rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
-        if not dist.is_initialized():
+        if args.transport == "ipc":      # torch.distributed only starts the job and carries the barriers (gloo); every message of the solver is a peer copy
+            if not dist.is_initialized():
+                dist.init_process_group(backend="gloo")
+            token = [("/hpgmg_bench_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getpid())) if rank == 0 else None]
+            dist.broadcast_object_list(token, src=0)
+            lib.hpgmg_transport_init_ipc.restype = ctypes.c_int
+            lib.hpgmg_transport_init_ipc.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int]
+            assert lib.hpgmg_transport_init_ipc(token[0].encode(), rank, world) == 0
+        if args.transport == "rccl" and not dist.is_initialized():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         ident = torch.zeros(128, dtype=torch.uint8, device="cuda")
-        if rank == 0:
-            buf = ctypes.create_string_buffer(128)
-            assert K.hpgmg_hip_rccl_unique_id(buf) == 0
-            ident = torch.tensor(list(buf.raw), dtype=torch.uint8, device="cuda")
-        dist.broadcast(ident, src=0)
-        lib.hpgmg_transport_init_rccl.restype = ctypes.c_int
-        lib.hpgmg_transport_init_rccl.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int]
-        assert lib.hpgmg_transport_init_rccl(bytes(ident.cpu().tolist()), rank, world) == 0
+        if args.transport == "rccl":
+            if rank == 0:
+                buf = ctypes.create_string_buffer(128)
+                assert K.hpgmg_hip_rccl_unique_id(buf) == 0
+                ident = torch.tensor(list(buf.raw), dtype=torch.uint8, device="cuda")
+            dist.broadcast(ident, src=0)
+            lib.hpgmg_transport_init_rccl.restype = ctypes.c_int
+            lib.hpgmg_transport_init_rccl.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int]
+            assert lib.hpgmg_transport_init_rccl(bytes(ident.cpu().tolist()), rank, world) == 0
         ctypes.CDLL(None).fflush(None)      # RCCL prints a version banner through C stdio: get it out now, not after the JSON line
 
     if args.workload == "config5":
@@ -281,9 +300,11 @@ def main():
     lib.hpgmg_pair_remote_smooths.restype = ctypes.c_longlong
     lib.hpgmg_overlap_count.restype = ctypes.c_longlong
     remote_smooths, overlapped = lib.hpgmg_pair_remote_smooths(), lib.hpgmg_overlap_count()
+    lib.hpgmg_image_exchanges.restype = ctypes.c_longlong
+    image_refreshes = lib.hpgmg_image_exchanges()
     stage[0] = "result reduction"
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.transport == "rccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -334,9 +355,10 @@ def main():
             "config": {"workload": f"hpgmg-fv {w_log2} {boxes_per_rank}{f' x {world} ranks' if world > 1 else ''}: {dim}^3 fp64 {w_text} smoother"
                                    f"{' (mixed precision, BASELINE config 5)' if mixed else ''}, {my_boxes} boxes of {box_dim}^3 per GPU, BiCGStab bottom, Dirichlet",
                        "series": (f"{args.series} scaling: " + ("same problem on every N (north_star series)" if args.series == "strong" else "reference CLI `7 8` with N ranks (domain grows with N)")) if world > 1 else "single GPU",
-                       "rccl_ranks": world if dist is not None else 0,
-                       "halo": ({"smooths_as_sweep_pairs_with_remote_faces": remote_smooths, "exchanges_overlapped_with_stencil_launches": overlapped,
-                                 "note": "fine-level smoother: ONE two-cell-deep halo exchange per sweep pair; residual and coarser sweeps: exchange overlapped with the interior launch"}
+                       "rccl_ranks": world if (dist is not None and args.transport == "rccl") else 0,
+                       "transport": (args.transport + (": ALL RANKS SHARE ONE GPU -- a functional run of the N > 1 path, not a scaling measurement" if args.share_gpu else "")) if dist is not None else None,
+                       "halo": ({"smooths_as_sweep_pairs_with_remote_faces": remote_smooths, "exchanges_overlapped_with_stencil_launches": overlapped, "refreshes_of_neighbour_box_images": image_refreshes,
+                                 "note": "7-point: ONE two-cell-deep halo exchange per sweep pair, residual and coarser sweeps overlapped with the interior launch; 27-point / fv4: images of the neighbouring ranks' boxes, one refresh per red + black pass, run on the exchange stream under the tiles that read no image"}
                                 if world > 1 else None),
                        "baseline_config": args.workload,
                        "fine_grid_dof": dof, "fcycle_residual_norm": norm, "parallelism": f"boxes over {world} GPU(s), RCCL halo exchange"},
@@ -353,7 +375,11 @@ def main():
 
     lib.hpgmg_solver_destroy(solver)
     if dist is not None:
-        lib.hpgmg_transport_finalize_rccl()
+        if args.transport == "ipc":
+            dist.barrier()
+            lib.hpgmg_transport_finalize_ipc()
+        else:
+            lib.hpgmg_transport_finalize_rccl()
         dist.destroy_process_group()
     if exit_code:
         sys.exit(exit_code)
