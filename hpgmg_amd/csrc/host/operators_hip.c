@@ -1021,13 +1021,48 @@ static void pair_halo_exchange(level_type *L, backend_t *B, int which, int x0_sc
   HIP_OK(hpgmg_hip_pair_halo_unpack(&B->dev, (double *const *)B->d_pair_base, x0_scr, x0_id, xm1_scr, xm1_id, rhs_id, P->d_recv, P->n_recv, H->recvbuf, H->deep, H->deep_beta));
   TOCK();
 }
-/* everything a remote sweep pair needs before its launch: (once per operator rebuild) the deep coefficient planes, then the halo of this pair */
-static void pair_halo_before_launch(level_type *L, backend_t *B, int first, int x0_scr, int x0_id, int xm1_scr, int xm1_id, int rhs_id) {
+/* The same with the message hidden behind computation: the exchange goes to the exchange stream, the launch stream runs the workgroups of the pair
+ * launch that touch no face of another rank (part 1: hpgmg_hip_set_tile_part), waits, and runs the others (part 2).  Returns 1 when set up that way
+ * -- the caller issues part 1, overlap_end(), part 2, each after hpgmg_hip_pair_set_halo() (consumed per launch) -- and 0 when the exchange was done
+ * in line (HPGMG_OVERLAP=0): one whole launch. */
+static int pair_halo_begin(level_type *L, backend_t *B, int first, int x0_scr, int x0_id, int xm1_scr, int xm1_id, int rhs_id) {
   pair_halo *H = B->halo;
   if (!H->coef_valid) { pair_halo_exchange(L, B, HALO_COEF, 0, 0, 0, 0, 0); H->coef_valid = 1; }
+  if (!hp_overlap_enabled() || hpgmg_get_timer_mode() == TIMERS_SYNC) {
+    pair_halo_exchange(L, B, first ? HALO_FIRST : HALO_NEXT, x0_scr, x0_id, xm1_scr, xm1_id, rhs_id);
+    return 0;
+  }
+  if (!comm_stream) {
+    comm_stream = hpgmg_hip_stream_create(); ev_packed = hpgmg_hip_event_create(); ev_landed = hpgmg_hip_event_create();
+    if (!comm_stream || !ev_packed || !ev_landed) { fprintf(stderr, "hpgmg: cannot create the exchange stream\n"); abort(); }
+  }
+  void *launch_stream = hpgmg_hip_get_stream();
+  HIP_OK(hpgmg_hip_event_record(ev_packed));                   /* the vectors to be sent are complete once everything issued so far has run */
+  hpgmg_hip_set_stream(comm_stream);
+  HIP_OK(hpgmg_hip_stream_wait_event(ev_packed));
   pair_halo_exchange(L, B, first ? HALO_FIRST : HALO_NEXT, x0_scr, x0_id, xm1_scr, xm1_id, rhs_id);
-  hpgmg_hip_pair_set_halo(H->brick, H->rem, H->deep, H->deep_beta);
+  HIP_OK(hpgmg_hip_event_record(ev_landed));
+  hpgmg_hip_set_stream(launch_stream);
+  overlap_count++;
+  return 1;
 }
+/* one sweep-pair launch of a level with faces on other ranks: whole, or as its two parts around the arrival of the halo */
+#define PAIR_REMOTE_LAUNCH(OVERLAPPED, DISCARD_X1, CALL) do {                                                   \
+    pair_halo *H_ = B->halo;                                                                                   \
+    if (OVERLAPPED) {                                                                                          \
+      hpgmg_hip_pair_set_halo(H_->brick, H_->rem, H_->deep, H_->deep_beta); hpgmg_hip_set_tile_part(1);        \
+      if (DISCARD_X1) hpgmg_hip_pair_discard_x1();                                                             \
+      HIP_OK(CALL);                                                                                            \
+      overlap_end();                                                                                           \
+      hpgmg_hip_pair_set_halo(H_->brick, H_->rem, H_->deep, H_->deep_beta); hpgmg_hip_set_tile_part(2);        \
+      if (DISCARD_X1) hpgmg_hip_pair_discard_x1();                                                             \
+      HIP_OK(CALL);                                                                                            \
+      hpgmg_hip_set_tile_part(0);                                                                              \
+    } else {                                                                                                   \
+      hpgmg_hip_pair_set_halo(H_->brick, H_->rem, H_->deep, H_->deep_beta);                                    \
+      if (DISCARD_X1) hpgmg_hip_pair_discard_x1();                                                             \
+      HIP_OK(CALL);                                                                                            \
+    } } while (0)
 static long long pair_remote_smooths = 0;
 long long hpgmg_pair_remote_smooths(void) { return pair_remote_smooths; }   /* smooth() calls done as sweep pairs with remote faces (tests) */
 
@@ -1105,14 +1140,19 @@ static int smooth_cheby_pairs(level_type *L, int x_id, int rhs_id, double a, dou
   const int v = hp_variant();
   const int remote = !B->all_faces_local;
   const float *const *c32 = remote ? NULL : coef32_of(L);      /* across ranks the coefficient streams stay fp64 */
-  if (remote) { pair_remote_smooths++; pair_halo_before_launch(L, B, 1, 0, x_id, 0, VECTOR_TEMP, rhs_id); }
+  int over = 0;
+  if (remote) { pair_remote_smooths++; over = pair_halo_begin(L, B, 1, 0, x_id, 0, VECTOR_TEMP, rhs_id); }
   { TICK(L, smooth, "smooth (Chebyshev sweeps 1+2)");
-    HIP_OK(hpgmg_hip_smooth_cheby_pair(&B->dev, v, (double *const *)B->d_pair_base, c32, 0, x_id, 0, VECTOR_TEMP, 1, 0, 1, 1, rhs_id, a, b, h2inv, c1[0], c2[0], c1[1], c2[1]));
+    if (remote) PAIR_REMOTE_LAUNCH(over, 0, hpgmg_hip_smooth_cheby_pair(&B->dev, v, (double *const *)B->d_pair_base, c32, 0, x_id, 0, VECTOR_TEMP, 1, 0, 1, 1, rhs_id, a, b, h2inv, c1[0], c2[0], c1[1], c2[1]));
+    else HIP_OK(hpgmg_hip_smooth_cheby_pair(&B->dev, v, (double *const *)B->d_pair_base, c32, 0, x_id, 0, VECTOR_TEMP, 1, 0, 1, 1, rhs_id, a, b, h2inv, c1[0], c2[0], c1[1], c2[1]));
     TOCK(); }
-  if (remote) pair_halo_before_launch(L, B, 0, 1, 1, 1, 0, rhs_id);
+  if (remote) over = pair_halo_begin(L, B, 0, 1, 1, 1, 0, rhs_id);
   { TICK(L, smooth, "smooth (Chebyshev sweeps 3+4)");
-    if (temp_is_scratch) hpgmg_hip_pair_discard_x1();
-    HIP_OK(hpgmg_hip_smooth_cheby_pair(&B->dev, v, (double *const *)B->d_pair_base, c32, 1, 1, 1, 0, 0, VECTOR_TEMP, 0, x_id, rhs_id, a, b, h2inv, c1[2], c2[2], c1[3], c2[3]));
+    if (remote) PAIR_REMOTE_LAUNCH(over, temp_is_scratch, hpgmg_hip_smooth_cheby_pair(&B->dev, v, (double *const *)B->d_pair_base, c32, 1, 1, 1, 0, 0, VECTOR_TEMP, 0, x_id, rhs_id, a, b, h2inv, c1[2], c2[2], c1[3], c2[3]));
+    else {
+      if (temp_is_scratch) hpgmg_hip_pair_discard_x1();
+      HIP_OK(hpgmg_hip_smooth_cheby_pair(&B->dev, v, (double *const *)B->d_pair_base, c32, 1, 1, 1, 0, 0, VECTOR_TEMP, 0, x_id, rhs_id, a, b, h2inv, c1[2], c2[2], c1[3], c2[3]));
+    }
     TOCK(); }
   return 1;
 }
@@ -1124,13 +1164,16 @@ static int smooth_gsrb_pairs(level_type *L, int x_id, int rhs_id, double a, doub
   const double h2inv = 1.0 / (L->h * L->h);
   const int v = hp_variant();
   const int remote = !B->all_faces_local;
-  if (remote) { pair_remote_smooths++; pair_halo_before_launch(L, B, 1, 0, x_id, 0, x_id, rhs_id); }
+  int over = 0;
+  if (remote) { pair_remote_smooths++; over = pair_halo_begin(L, B, 1, 0, x_id, 0, x_id, rhs_id); }
   { TICK(L, smooth, "smooth (GSRB half sweeps 1+2)");
-    HIP_OK(hpgmg_hip_smooth_gsrb_pair(&B->dev, v, (double *const *)B->d_pair_base, NULL, 0, x_id, 0, 1, 1, rhs_id, a, b, h2inv, 0));
+    if (remote) PAIR_REMOTE_LAUNCH(over, 0, hpgmg_hip_smooth_gsrb_pair(&B->dev, v, (double *const *)B->d_pair_base, NULL, 0, x_id, 0, 1, 1, rhs_id, a, b, h2inv, 0));
+    else HIP_OK(hpgmg_hip_smooth_gsrb_pair(&B->dev, v, (double *const *)B->d_pair_base, NULL, 0, x_id, 0, 1, 1, rhs_id, a, b, h2inv, 0));
     TOCK(); }
-  if (remote) pair_halo_before_launch(L, B, 0, 1, 1, 1, 1, rhs_id);
+  if (remote) over = pair_halo_begin(L, B, 0, 1, 1, 1, 1, rhs_id);
   { TICK(L, smooth, "smooth (GSRB half sweeps 3+4)");
-    HIP_OK(hpgmg_hip_smooth_gsrb_pair(&B->dev, v, (double *const *)B->d_pair_base, NULL, 1, 1, 0, 0, x_id, rhs_id, a, b, h2inv, 2));
+    if (remote) PAIR_REMOTE_LAUNCH(over, 0, hpgmg_hip_smooth_gsrb_pair(&B->dev, v, (double *const *)B->d_pair_base, NULL, 1, 1, 0, 0, x_id, rhs_id, a, b, h2inv, 2));
+    else HIP_OK(hpgmg_hip_smooth_gsrb_pair(&B->dev, v, (double *const *)B->d_pair_base, NULL, 1, 1, 0, 0, x_id, rhs_id, a, b, h2inv, 2));
     TOCK(); }
   return 1;
 }

@@ -54,6 +54,8 @@ struct PairArgs {
   // the eight coefficient values of every pre-pass cell (beta_i low / high face, beta_j, beta_k, alpha, Dinv), packed [column][k][j][8] once per
   // operator rebuild: the pre-pass walks COLUMNS of the boxes, where each value read in place costs a 64-byte sector of its own (null: read in place)
   double *edge_coef;
+  // REMOTE, two-part launches (the halo exchange runs on another stream under part 1): dispatch slot -> workgroup, padded with total_blocks (null: identity)
+  const int *order;
 };
 
 __device__ __forceinline__ double *pair_vec(const hpgmg_hip_level &L, const PairArgs &A, VecRef r, int box) {
@@ -158,7 +160,8 @@ __global__ __launch_bounds__(64 * NW) void cheby_pair_kernel(const hpgmg_hip_lev
     __syncthreads();
   }
 
-  const int logical = xcd_logical_block((int)blockIdx.x, A.per_xcd);
+  int logical = xcd_logical_block((int)blockIdx.x, A.per_xcd);
+  if (REMOTE && A.order) logical = A.order[logical];
   if (logical >= A.total_blocks) return;
   int t = logical;
   const int ti = t % A.tiles_i; t /= A.tiles_i;

@@ -1787,6 +1787,35 @@ static EdgePack *edge_pack_slot(const hpgmg_hip_level *L, int variant, const Pai
   g_edge_packs.push_back(e);
   return &g_edge_packs.back();
 }
+// Two-part launches of the sweep pair across rank boundaries (hpgmg_hip_set_tile_part): part 1 = the workgroups whose slab / chunk / tile touches
+// no face another rank owns -- they read nothing the halo exchange delivers (ghost zones, deep planes, ghost columns of the pre-pass) --, part 2 the
+// others.  Each part runs the (cheap) pre-pass in full: before the exchange its cells next to remote faces are formed from stale ghost values and
+// read by nobody, the second run overwrites them.
+struct PairOrder { int ti, sj, ck, rem[6], part; int *d_order; int grid, per_xcd, count; };
+static std::vector<PairOrder> g_pair_orders;
+static const PairOrder *pair_part_order(const PairArgs &A, int part) {
+  for (const PairOrder &o : g_pair_orders)
+    if (o.ti == A.tiles_i && o.sj == A.slabs_j && o.ck == A.chunks_k && o.part == part && memcmp(o.rem, A.rem, sizeof o.rem) == 0) return &o;
+  PairOrder o = {}; o.ti = A.tiles_i; o.sj = A.slabs_j; o.ck = A.chunks_k; o.part = part; memcpy(o.rem, A.rem, sizeof o.rem);
+  std::vector<int> sel;
+  for (int l = 0; l < A.total_blocks; l++) {
+    int t = l;
+    const int ti = t % A.tiles_i; t /= A.tiles_i;
+    const int sj = t % A.slabs_j; t /= A.slabs_j;
+    const int ck = t;
+    const bool later = (ti == 0 && A.rem[0]) || (ti == A.tiles_i - 1 && A.rem[1]) || (sj == 0 && A.rem[2]) || (sj == A.slabs_j - 1 && A.rem[3]) || (ck == 0 && A.rem[4]) || (ck == A.chunks_k - 1 && A.rem[5]);
+    if (later == (part == 2)) sel.push_back(l);
+  }
+  o.count = (int)sel.size();
+  if (o.count > 0) {
+    o.per_xcd = (o.count + kXcds - 1) / kXcds; o.grid = o.per_xcd * kXcds;
+    sel.resize((size_t)o.grid, A.total_blocks);
+    if (hipMalloc((void **)&o.d_order, sel.size() * sizeof(int)) != hipSuccess) return nullptr;
+    if (hipMemcpy(o.d_order, sel.data(), sel.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(o.d_order); return nullptr; }
+  }
+  g_pair_orders.push_back(o);
+  return &g_pair_orders.back();
+}
 static int smooth_pair(const hpgmg_hip_level *L, int variant, int gsrb, int sweep_a, double *const *scr_base, const float *const *c32_base,
                        int x0_scr, int x0_id, int xm1_scr, int xm1_id, int out1_scr, int out1_id, int out2_scr, int out2_id,
                        int rhs_id, double a, double b, double h2inv, double c1a, double c2a, double c1b, double c2b) {
@@ -1832,8 +1861,16 @@ static int smooth_pair(const hpgmg_hip_level *L, int variant, int gsrb, int swee
 #endif
   A.tiles_i = A.Di / 128; A.slabs_j = (A.Dj + (nw - 2) - 1) / (nw - 2); A.KC = kc; A.chunks_k = (A.Dk + kc - 1) / kc;
   A.total_blocks = A.tiles_i * A.slabs_j * A.chunks_k;
-  const int grid = grid_for(A.total_blocks, &A.per_xcd);
-  const long long cells = (long long)A.Di * A.Dj * A.Dk;
+  int grid = grid_for(A.total_blocks, &A.per_xcd);
+  long long cells = (long long)A.Di * A.Dj * A.Dk;
+  const int part = remote ? g_tile_part : 0;
+  if (part) {
+    const PairOrder *o = pair_part_order(A, part);
+    if (!o) return record_error(hipErrorOutOfMemory, "smooth pair: dispatch list of a partial launch");
+    if (o->count == 0) return 0;
+    A.order = o->d_order; grid = o->grid; A.per_xcd = o->per_xcd;
+    cells = cells * o->count / A.total_blocks;
+  }
   const size_t lds = (size_t)nw * 6 * 64 * sizeof(p2);
   if (!remote && !c32_base) {        // the pre-pass reads its coefficient values packed; (re)pack them after an operator rebuild
     EdgePack *pk = edge_pack_slot(L, variant, A);
@@ -1882,7 +1919,7 @@ static int smooth_pair(const hpgmg_hip_level *L, int variant, int gsrb, int swee
 #undef PAIR_LAUNCH
 #undef PAIR_LAUNCH2
 #undef PAIR_LAUNCH_REMOTE
-  g_pair_launches++; if (remote) g_pair_remote_launches++;
+  if (part != 1) { g_pair_launches++; if (remote) g_pair_remote_launches++; }      // the two parts of a launch count once (part 2 is never empty: it holds the workgroups at the remote faces)
   profile_end(prof, 2 * cells);                      // one launch = two sweeps over every cell
   HPGMG_LAUNCH_CHECK("cheby_pair_kernel");
   return 0;

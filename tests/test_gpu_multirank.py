@@ -63,6 +63,8 @@ def test_sweep_pairs_across_rank_boundaries(world, variant, log2, per_rank, gold
         # 4 timed f-cycles at h (three_sizes, richardson, 3 repeats - 1) x 2 smooth() calls on the fine level, at least
         assert r["stats"]["pair_remote_smooths"] >= 8, r["stats"]
         assert r["stats"]["pair_remote_launches"] == 2 * r["stats"]["pair_remote_smooths"], r["stats"]
+        if os.environ.get("HPGMG_OVERLAP", "1") != "0":       # each pair's halo exchange runs on the exchange stream under the workgroups that touch no remote face
+            assert r["stats"]["overlapped_exchanges"] >= 2 * r["stats"]["pair_remote_smooths"], r["stats"]
 
 
 @pytest.mark.parametrize("world,variant,log2,per_rank,gold_key", [
