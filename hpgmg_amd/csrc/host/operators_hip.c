@@ -218,7 +218,6 @@ void hpgmg_level_release(level_type *L) {
   for (s = 0; s < STENCIL_MAX_SHAPES; s++) if (B->d_bc[s]) hpgmg_hip_free(B->d_bc[s]);
   if (B->d_bc_k) hpgmg_hip_free(B->d_bc_k);
   if (B->d_fv4_special) hpgmg_hip_free(B->d_fv4_special);
-  for (s = 0; s < STENCIL_MAX_SHAPES; s++) { if (B->d_bc_start[s]) hpgmg_hip_free(B->d_bc_start[s]); free(B->h_bc_by_box[s]); }
   if (B->d_box_base) hpgmg_hip_free(B->d_box_base);
   if (B->d_box_low) hpgmg_hip_free(B->d_box_low);
   if (B->d_box_nbr) hpgmg_hip_free(B->d_box_nbr);
@@ -1104,29 +1103,7 @@ static int pair_kernel_ready(level_type *L, int x_id, int rhs_id, int sweeps) {
   return 1;
 }
 
-/* The same two-sweeps-per-launch scheme on cache-resident levels (boxes of side 64 m on one rank; kernels/stencil7_pair_tile.hpp): small
- * tiles that recompute x1 on a one-cell rim.  Vector traffic and states as in smooth_cheby_pairs() below.  0 = not applicable. */
 static int temp_is_scratch = 0;
-static int smooth_cheby_tile_pairs(level_type *L, int x_id, int rhs_id, double a, double b, const double *c1, const double *c2, int sweeps) {
-  hpgmg_config cfg;
-  hpgmg_get_config(&cfg);
-  if (fused_sweeps < 0) { const char *e = getenv("HPGMG_FUSED_SWEEPS"); fused_sweeps = !(e && e[0] == '0'); }
-  if (!fused_sweeps || sweeps != 4 || cfg.op != HPGMG_OP_7PT || !hp_ghost_free_mode() || stencil_get_shape() != STENCIL_SHAPE_STAR) return 0;
-  if (L->boundary_condition.type != BC_DIRICHLET || x_id == VECTOR_TEMP || rhs_id == VECTOR_TEMP || L->num_my_boxes < 1) return 0;
-  backend_t *B = hp_backend_of(L);
-  if (!B->all_faces_local || !hpgmg_hip_smooth_cheby_pair_tile_supported(&B->dev, hp_variant())) return 0;
-  hp_ensure_pair_scratch(L, B);
-  hpgmg_hip_set_ghost_free(1);
-  const double h2inv = 1.0 / (L->h * L->h);
-  const int v = hp_variant();
-  { TICK(L, smooth, "smooth (Chebyshev sweeps 1+2, tiles)");
-    HIP_OK(hpgmg_hip_smooth_cheby_pair_tile(&B->dev, v, (double *const *)B->d_pair_base, 0, x_id, 0, VECTOR_TEMP, 1, 0, 1, 1, rhs_id, a, b, h2inv, c1[0], c2[0], c1[1], c2[1], 1));
-    TOCK(); }
-  { TICK(L, smooth, "smooth (Chebyshev sweeps 3+4, tiles)");
-    HIP_OK(hpgmg_hip_smooth_cheby_pair_tile(&B->dev, v, (double *const *)B->d_pair_base, 1, 1, 1, 0, 0, VECTOR_TEMP, 0, x_id, rhs_id, a, b, h2inv, c1[2], c2[2], c1[3], c2[3], temp_is_scratch ? 0 : 1));
-    TOCK(); }
-  return 1;
-}
 
 /* Chebyshev smooth() as fused sweep pairs (kernels/cheby_pair.hpp): 4 sweeps = 2 passes of 10 streams instead of
  * 4 x 9.  x1,x2 of the first pair go to two plugin-private vectors, the second pair brings x3 -> VECTOR_TEMP and
@@ -1221,7 +1198,7 @@ void hpgmg_set_small_fused(int mode) { small_fused = (mode == 1 || mode == 2) ? 
 static int small_level_try(level_type *L, int mode, int x_id, int rhs_id, int res_id, double a, double b) {
   hpgmg_config cfg;
   if (small_fused < 0) { const char *e = getenv("HPGMG_SMALL_FUSED"); small_fused = (e && e[0] == '1') ? 1 : ((e && e[0] == '0') ? 0 : 2); }
-  if (small_fused == 1 && !hpgmg_hip_experiments()) small_fused = 2;
+  if (small_fused == 1) small_fused = 2;                /* (mode 1, every small level out of global memory, measured slower in two rounds: removed) */
   /* 0: off.  1 (experiment builds): every qualifying level, out of global memory (slower than the launches it replaces, see above).  2
    * (default): smooth() on levels of ONE box whose vectors fit the LDS -- the kernel then works on an image of the box there (round 3).  With
    * generic (FLAT) accesses to the image a smooth() was one ~60 us launch instead of twelve ~5 us ones: no gain.  With LDS-typed pointers, the
@@ -1431,7 +1408,6 @@ static void do_smooth(level_type *L, int x_id, int rhs_id, double a, double b) {
     if (L->dominant_eigenvalue_of_DinvA <= 0.0 && L->my_rank == 0) fprintf(stderr, "dominant_eigenvalue_of_DinvA <= 0.0 !\n");
     cheby_coefficients(L, sweeps, c1, c2);
     if (smooth_cheby_pairs(L, x_id, rhs_id, a, b, c1, c2, sweeps)) return;
-    if (smooth_cheby_tile_pairs(L, x_id, rhs_id, a, b, c1, c2, sweeps)) return;
     for (s = 0; s < sweeps; s++) {
       const int src = (s & 1) ? VECTOR_TEMP : x_id, dst = (s & 1) ? x_id : VECTOR_TEMP;
       STENCIL_WITH_GHOSTS(L, src, dst, smooth, hpgmg_hip_smooth_cheby(hp_stencil_dev(B), v, src, dst, rhs_id, a, b, h2inv, c1[s], c2[s]));
@@ -1484,34 +1460,6 @@ static void do_smooth(level_type *L, int x_id, int rhs_id, double a, double b) {
         if (smooth_fv4_rb(L, x_id, rhs_id, a, b, sweeps - 2)) first_half_sweep = sweeps - 2;      /* an even number of passes: they end on x */
         temp_is_scratch = 0;
       }
-    }
-    /* fv4 on a level of small boxes (4^3 ... 16^3, all local): a half sweep as ONE launch -- x outside a box read where it lives, the boundary
-     * conditions of the result applied by the same launch (kernels/stencil.hip: fv4_box_gsrb_kernel) -- instead of two */
-    if (!first_half_sweep && cfg.op == HPGMG_OP_FV4 && oop && !(sweeps & 1) && hp_ghost_free_mode() && B->all_faces_local && L->box_dim >= 4 && x_id != VECTOR_TEMP && rhs_id != VECTOR_TEMP &&
-        L->boundary_condition.type == BC_DIRICHLET && hpgmg_hip_smooth_gsrb_fv4_box_supported(&B->dev, v)) {
-      const int shape = stencil_get_shape(), n_bc = L->boundary_condition.num_blocks[shape];
-      if (!B->d_bc_start[shape]) {
-        int *start = (int *)calloc((size_t)L->num_my_boxes + 1, sizeof(int)), q, bx, m = 0;
-        B->h_bc_by_box[shape] = (blockCopy_type *)malloc((size_t)(n_bc > 0 ? n_bc : 1) * sizeof(blockCopy_type));
-        for (bx = 0; bx < L->num_my_boxes; bx++) {
-          start[bx] = m;
-          for (q = 0; q < n_bc; q++) if (L->boundary_condition.blocks[shape][q].read.box == bx) B->h_bc_by_box[shape][m++] = L->boundary_condition.blocks[shape][q];
-        }
-        start[L->num_my_boxes] = m;
-        B->d_bc_start[shape] = (int *)hpgmg_hip_malloc(((size_t)L->num_my_boxes + 1) * sizeof(int));
-        if (!B->d_bc_start[shape] || m != n_bc) { fprintf(stderr, "hpgmg: boundary blocks by box: allocation failed or a block without a box\n"); abort(); }
-        HIP_OK(hpgmg_hip_memcpy_h2d(B->d_bc_start[shape], start, ((size_t)L->num_my_boxes + 1) * sizeof(int)));
-        free(start);
-      }
-      const blockCopy_type *by_box = n_bc ? hp_mirror(L, B->h_bc_by_box[shape], n_bc) : NULL;
-      if (!exchange_and_bcs_one_launch(L, x_id, shape, 4, 0)) apply_BCs(L, x_id, shape);      /* the domain-boundary ghost cells the first half sweep reads */
-      for (s = 0; s < sweeps; s++) {
-        const int src = (s & 1) ? VECTOR_TEMP : x_id, dst = (s & 1) ? x_id : VECTOR_TEMP;
-        TICK(L, smooth, "smooth (fv4 GSRB half sweep, small boxes: one launch)");
-        HIP_OK(hpgmg_hip_smooth_gsrb_fv4_box(&B->dev, v, src, dst, rhs_id, a, b, h2inv, s, by_box, B->d_bc_start[shape]));
-        TOCK();
-      }
-      return;
     }
     for (s = first_half_sweep; s < sweeps; s++) {
       const int src = (oop && (s & 1)) ? VECTOR_TEMP : x_id, dst = oop ? ((s & 1) ? x_id : VECTOR_TEMP) : x_id;

@@ -46,7 +46,6 @@ typedef struct {
   struct { const blockCopy_type *host; int n; blockCopy_type *dev; } lists[MAX_LISTS];
   int num_lists;
   hpgmg_hip_bc_entry *d_bc[STENCIL_MAX_SHAPES]; int n_bc[STENCIL_MAX_SHAPES];   /* boundary-condition blocks with their geometry worked out */
-  blockCopy_type *h_bc_by_box[STENCIL_MAX_SHAPES]; int *d_bc_start[STENCIL_MAX_SHAPES];   /* boundary blocks sorted by box + the range of each box (fv4 box kernel) */
   int *d_fv4_special; int n_fv4_special;       /* fv4 red + black: cells on internal box faces next to a domain wall (box, i, j, k); n < 0: not built */
   hpgmg_hip_bc_entry *d_bc_k; int n_bc_k, bc_k_local;      /* the blocks of the stencil's shape whose domain normal has a k component (fv4 red + black pre-pass); n_bc_k < 0: not built */
   int bc_sources_local[STENCIL_MAX_SHAPES];    /* 1: every entry reads cells of local boxes' interiors only (no exchange needed before the conditions) */

@@ -30,11 +30,7 @@ int hpgmg_hip_smooth_gsrb_fv4_rb_supported(const hpgmg_hip_level *L, int variant
   if (variant != HPGMG_HIP_FV4_VC_HELMHOLTZ && variant != HPGMG_HIP_FV4_VC_POISSON) return 0;
   // boxes of side 64 m; 32-wide tiles (two workgroups per CU) also take boxes of 32^3, but measured slower there than two half-sweep launches
   // of the tiled kernel (98 vs 2 x 35 us on a 128^3 level of 64 boxes: the march is too short for its prologue), so only on request
-#ifdef HPGMG_EXPERIMENTS
-  const int need = (env_int("HPGMG_TUNE_FV4_RB_TI", 0) == 32) ? 32 : 64;
-#else
-  const int need = 64;                                    // the 32-wide tiles are only in builds with EXPERIMENTS=1
-#endif
+  const int need = 64;                                    // (32-wide tiles, two workgroups per CU, measured slower in two rounds: removed)
   return !off && L->num_boxes > 0 && L->dim % need == 0 && L->box_nbr != nullptr && L->ghosts == 2;
 }
 // Dispatch order of the tiles.  A tile at a domain wall in i or j forms the boundary values of the intermediate vector in every step
@@ -119,14 +115,7 @@ int hpgmg_hip_smooth_gsrb_fv4_rb(const hpgmg_hip_level *L, int variant, double *
   Fv4RbArgs A = {};
   A.x = vec_sel(L, scr_base, x_scratch, x_id); A.out = vec_sel(L, scr_base, out_scratch, out_id); A.tg = vec_sel(L, scr_base, 1, tg_id);
   A.rhs_id = rhs_id; A.a = a; A.b = b; A.h2inv = h2inv; A.sweep = sweep;
-  // tile width: 64 (one workgroup of 8 waves per CU) or 32 (two of 4 waves; the only form for boxes of 32^3)
-  const int tune_ti = env_int("HPGMG_TUNE_FV4_RB_TI", 0);      // read per call: the tests switch it
-  int TI = (L->dim % 64 == 0) ? 64 : 32;
-#ifdef HPGMG_EXPERIMENTS
-  if (tune_ti == 32 || (tune_ti == 64 && L->dim % 64 == 0)) TI = tune_ti;
-#else
-  (void)tune_ti;
-#endif
+  const int TI = 64;                                      // one workgroup of 8 waves per CU
   A.tiles_i = L->dim / TI; A.tiles_j = L->dim / fv4rb::TJ;
   int kchunk = L->dim;                                   // 256 (512) resident workgroups fill the chip; every k chunk costs four extra planes of loads and two red stages
   while (kchunk > 16 && (long long)L->num_boxes * A.tiles_i * A.tiles_j * (L->dim / kchunk) < (TI == 64 ? 256 : 512)) kchunk /= 2;
@@ -151,12 +140,7 @@ int hpgmg_hip_smooth_gsrb_fv4_rb(const hpgmg_hip_level *L, int variant, double *
     constexpr size_t lds = fv4rb::Geom<TI_>::LDS_BYTES; \
     static bool once = false; if (!once) { HPGMG_CHECK(hipFuncSetAttribute((const void *)fv4_rb_kernel<VAR, TI_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once = true; } \
     hipLaunchKernelGGL((fv4_rb_kernel<VAR, TI_>), dim3(grid), dim3(TI_, 8), lds, g_stream, *L, A); }
-#ifdef HPGMG_EXPERIMENTS
-  if (variant == HPGMG_HIP_FV4_VC_HELMHOLTZ) { if (TI == 64) FV4_RB_CASE(HPGMG_HIP_FV4_VC_HELMHOLTZ, 64) else FV4_RB_CASE(HPGMG_HIP_FV4_VC_HELMHOLTZ, 32) }
-  else                                       { if (TI == 64) FV4_RB_CASE(HPGMG_HIP_FV4_VC_POISSON, 64) else FV4_RB_CASE(HPGMG_HIP_FV4_VC_POISSON, 32) }
-#else
   if (variant == HPGMG_HIP_FV4_VC_HELMHOLTZ) FV4_RB_CASE(HPGMG_HIP_FV4_VC_HELMHOLTZ, 64) else FV4_RB_CASE(HPGMG_HIP_FV4_VC_POISSON, 64)
-#endif
 #undef FV4_RB_CASE
   g_rb4_launches++;
   profile_end(prof, 2 * cells);                         // one launch = two half sweeps over every cell

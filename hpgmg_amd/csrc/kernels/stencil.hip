@@ -29,9 +29,6 @@
 #include "fv4_tile.hpp"
 #include "stencil27_rb.hpp"
 #include "stencil27_rb_box.hpp"
-#ifdef HPGMG_EXPERIMENTS
-#include "stencil7_pair_tile.hpp"      // measured slower than what it replaces (every tile width): only in builds with EXPERIMENTS=1 (csrc/Makefile)
-#endif
 #include "stencil7_tile.hpp"
 #include "block_ops.hpp"
 
@@ -856,13 +853,7 @@ __global__ __launch_bounds__(1024) void small_level_kernel(const hpgmg_hip_level
   tl = A.timeline;
   if (tl && tid == 0) tl[tl_n++] = __builtin_amdgcn_s_memrealtime();
 #endif
-  if (!A.lds_resident) {                                          // out of global memory: measured slower than the launches it replaces (experiments)
-#ifdef HPGMG_EXPERIMENTS
-    const int ids[kSmallSlots] = { A.x_id, VECTOR_TEMP, A.rhs_id, VECTOR_DINV, VECTOR_ALPHA, VECTOR_BETA_I, VECTOR_BETA_J, VECTOR_BETA_K, A.res_id };
-    small_level_run<V, false>(L, A, nullptr, A.bc_list, nullptr, ids, tl, tl_n, [&](int s, double &c1, double &c2) { c1 = A.c1[s]; c2 = A.c2[s]; });
-#endif
-    return;
-  }
+  if (!A.lds_resident) return;                                    // (the launcher only starts it on one box whose vectors fit the LDS)
   // ---- one box, its vectors in LDS: copy in, run, copy what was written back (ghost zones included: the boundary entries filled them)
   const bool smooth = (A.mode == MODE_CHEBY || A.mode == MODE_JACOBI || A.mode == MODE_GSRB);
   const bool uses_temp = smooth && !(A.mode == MODE_GSRB && !A.out_of_place);
@@ -1066,71 +1057,6 @@ __device__ __forceinline__ void bottom_bicgstab_body(const hpgmg_hip_level &L, c
 }
 template <int V>
 __global__ __launch_bounds__(512) void bottom_bicgstab_kernel(const hpgmg_hip_level L, const BottomArgs A) { bottom_bicgstab_body<V>(L, A); }
-
-// ---------------------------------------------------------------------------------------------
-// One coloured half sweep of the fv4 GSRB smoother (gsrb.c:24-132, out of place) on a level of SMALL boxes (side 4 ... 16, all local) as ONE launch
-// instead of two (exchange + boundary conditions, then the stencil).  A workgroup owns a box: it gathers x on the box and its two-cell rim into
-// an LDS image with the box's own padded layout -- every cell read where it LIVES (common.hpp: gf_column; the neighbouring box's interior, or,
-// outside the domain, the ghost zone of the box reached through the in-domain directions) --, sweeps the box out of the image (the same
-// per-cell expression as stencil_direct_kernel) and then, after a barrier, applies the boundary entries of ITS box to the result: the ghost cells
-// the next half sweep will look for there are exactly the ones formed from this box's own interior (an entry whose inputs lie in an in-domain
-// ghost zone writes cells no ghost-free reader ever visits).  The entries arrive sorted by box (bc_start[box] .. bc_start[box + 1]).
-// EXPERIMENTS=1 builds only, opt-in (HPGMG_TUNE_FV4_BOX=1): bit-identical, but MEASURED SLOWER than the two launches it replaces -- `7 8` 8.73 vs
-// 7.77 ms, `7 64` 32.1 vs 31.3 ms per F-cycle: one workgroup per box is ~18 us (gather of the 20^3 image, four cells per lane swept one after the
-// other, boundary entries on global memory), while exchange + boundary conditions and the stencil, spread over the chip, are ~5 us each.
-#ifdef HPGMG_EXPERIMENTS
-struct Fv4BoxArgs { int xn_id, xout_id, rhs_id, sweep; double a, b, h2inv; const blockCopy_type *bc_list; const int *bc_start; };
-template <int V>
-__global__ __launch_bounds__(1024) void fv4_box_gsrb_kernel(const hpgmg_hip_level L, const Fv4BoxArgs A) {
-  constexpr bool kHelm = (V == HPGMG_HIP_FV4_VC_HELMHOLTZ);
-  extern __shared__ double fb_lds[];
-  const int box = (int)blockIdx.x, tid = (int)threadIdx.x, nth = (int)blockDim.x, lane = tid & 63, wave = tid >> 6, nwaves = nth >> 6;
-  const int dim = L.dim, jS = L.jStride, kS = L.kStride, first = L.ghosts * (1 + jS + kS);
-  const lds_dptr x = (lds_dptr)fb_lds + first;
-  const int w = dim + 4, nreg = w * w * w;
-  // where the 27 regions of the image (the box and its rim, by the sign of each coordinate's excursion) live: the box to read and the shift of
-  // each coordinate, found once by following the face links as gf_column / gf_load_outside do (i, then j, then k) -- every cell of the image is
-  // then ONE load from a known place, and the loads of a lane are independent of each other
-  __shared__ int s_src_box[27], s_src_off[27];
-  if (tid < 27) {
-    const int di = tid % 3 - 1, dj = (tid / 3) % 3 - 1, dk = tid / 9 - 1;
-    int bx = box, off = 0;
-    if (di) { const int n = L.box_nbr[6 * bx + (di < 0 ? 0 : 1)]; if (n >= 0) { bx = n; off -= di * dim; } }
-    if (dj) { const int n = L.box_nbr[6 * bx + (dj < 0 ? 2 : 3)]; if (n >= 0) { bx = n; off -= dj * dim * jS; } }
-    if (dk) { const int n = L.box_nbr[6 * bx + (dk < 0 ? 4 : 5)]; if (n >= 0) { bx = n; off -= dk * dim * kS; } }
-    s_src_box[tid] = bx; s_src_off[tid] = off;
-  }
-  __syncthreads();
-  const size_t vec_off = (size_t)A.xn_id * (size_t)L.volume + (size_t)first;
-#pragma unroll 4
-  for (int t = tid; t < nreg; t += nth) {
-    const int ri = t % w - 2, rj = (t / w) % w - 2, rk = t / (w * w) - 2;
-    const int di = ri < 0 ? -1 : (ri >= dim ? 1 : 0), dj = rj < 0 ? -1 : (rj >= dim ? 1 : 0), dk = rk < 0 ? -1 : (rk >= dim ? 1 : 0);
-    const int r = (di + 1) + 3 * (dj + 1) + 9 * (dk + 1), ijk = ri + rj * jS + rk * kS;
-    const gbl_cdptr src = (gbl_cdptr)(L.box_base[s_src_box[r]] + vec_off);
-    // (the corners of the rim -- di, dj, dk all non-zero -- are no neighbours of the stencil; loaded like the rest, never read)
-    x[ijk] = src[ijk + s_src_off[r]];
-  }
-  __syncthreads();
-  const double *alpha = kHelm ? vec_origin(L, box, VECTOR_ALPHA) : nullptr;
-  const double *bi = vec_origin(L, box, VECTOR_BETA_I), *bj = vec_origin(L, box, VECTOR_BETA_J), *bk = vec_origin(L, box, VECTOR_BETA_K);
-  const double *rhs = vec_origin(L, box, A.rhs_id), *dinv = vec_origin(L, box, VECTOR_DINV);
-  double *out = vec_origin(L, box, A.xout_id);
-  const int colour000 = (L.box_low[3 * box] ^ L.box_low[3 * box + 1] ^ L.box_low[3 * box + 2] ^ A.sweep) & 1;
-  for (int t = tid; t < dim * dim * dim; t += nth) {
-    const int i = t % dim, j = (t / dim) % dim, k = t / (dim * dim), ijk = i + j * jS + k * kS;
-    const double xc = x[ijk];
-    if (((i ^ j ^ k ^ colour000) & 1) == 0) {
-      const double Ax = apply_op_direct<V>(x, alpha, bi, bj, bk, ijk, jS, kS, A.a, A.b, A.h2inv);
-      out[ijk] = xc + dinv[ijk] * (rhs[ijk] - Ax);
-    } else out[ijk] = xc;                                          // out of place: the other colour is carried over
-  }
-  __threadfence_block();
-  __syncthreads();
-  // apply_BCs_v4 (boundary_fv.c:262-569) on the result, this box's entries
-  for (int e = A.bc_start[box] + wave; e < A.bc_start[box + 1]; e += nwaves) bc_v4_entry(L, A.xout_id, A.bc_list[e], lane, 64);
-}
-#endif  // HPGMG_EXPERIMENTS
 
 // ---------------------------------------------------------------------------------------------
 // A queue of BLAS-1 / operator calls on a level of ONE small box (<= 512 cells) as one single-workgroup launch, ending -- if the caller
@@ -1929,81 +1855,6 @@ int hpgmg_hip_smooth_cheby_pair(const hpgmg_hip_level *L, int variant, double *c
                                 int rhs_id, double a, double b, double h2inv, double c1a, double c2a, double c1b, double c2b) {
   return smooth_pair(L, variant, 0, 0, scr_base, c32_base, x0_scr, x0_id, xm1_scr, xm1_id, out1_scr, out1_id, out2_scr, out2_id, rhs_id, a, b, h2inv, c1a, c2a, c1b, c2b);
 }
-// Two Chebyshev sweeps in one launch on a cache-resident level (stencil7_pair_tile.hpp): boxes of side 64 m, every box local, Dirichlet.
-// Same arguments as hpgmg_hip_smooth_cheby_pair (fp64 coefficients); keep_x1 = 0 when the caller declared out1 scratch.
-static long long g_pair_tile_launches = 0;
-long long hpgmg_hip_pair_tile_launch_count(void) { return g_pair_tile_launches; }
-// OFF by default: measured on the 128^3 level of config 2 a pair launch takes 63 us against 2 x 26 us for the single-sweep tiled kernel
-// (3.45 vs 3.32 ms per F-cycle; longer k chunks are worse still: 3.65 / 4.19 / 5.26 ms at 16 / 32 / 64 planes) -- that level is cache
-// resident and latency bound, and a pair step issues twice the loads of a single-sweep step before its first barrier.
-// HPGMG_TUNE_7PT_PAIR_TILE=1 or hpgmg_hip_set_pair_tile(1) enables it (bit-identical; the tests do).
-static int g_pair_tile_on = -1;
-void hpgmg_hip_set_pair_tile(int on) { g_pair_tile_on = on ? 3 : 0; }
-#ifdef HPGMG_EXPERIMENTS
-int hpgmg_hip_experiments(void) { return 1; }
-#else
-int hpgmg_hip_experiments(void) { return 0; }
-#endif
-// which tile the level takes: 64 (boxes of side 64 m: hpgmg_hip_set_pair_tile(1), builds with EXPERIMENTS=1), 32 / 16 (boxes of 32^3 / 16^3:
-// HPGMG_TUNE_7PT_PAIR_SMALL=1 or hpgmg_hip_set_pair_tile(1)), 0: none.  All of them measured SLOWER than single-sweep launches: the march with
-// its barriers is a chain of round trips, a single-sweep launch of a small level issues everything at once (config 2: 4.28 vs 3.34 ms per
-// F-cycle with the small-box form on)
-static int pair_tile_width(const hpgmg_hip_level *L, int variant) {
-  if (variant != HPGMG_HIP_7PT_VC_HELMHOLTZ && variant != HPGMG_HIP_7PT_VC_POISSON && variant != HPGMG_HIP_7PT_CC) return 0;
-  if (!(L->num_boxes > 0 && L->box_nbr != nullptr && !L->periodic && L->ghosts >= 1)) return 0;
-#ifdef HPGMG_EXPERIMENTS
-  // bit 0: boxes of side 64 m (HPGMG_TUNE_7PT_PAIR_TILE=1), bit 1: boxes of 32^3 / 16^3 (HPGMG_TUNE_7PT_PAIR_SMALL=1); set_pair_tile(1): both
-  if (g_pair_tile_on < 0) g_pair_tile_on = (env_int("HPGMG_TUNE_7PT_PAIR_TILE", 0) ? 1 : 0) | (env_int("HPGMG_TUNE_7PT_PAIR_SMALL", 0) ? 2 : 0);
-  if ((g_pair_tile_on & 2) && (L->dim == 32 || L->dim == 16)) return L->dim;
-  if ((g_pair_tile_on & 1) && L->dim % 64 == 0) return 64;
-#else
-  (void)g_pair_tile_on;
-#endif
-  return 0;
-}
-int hpgmg_hip_smooth_cheby_pair_tile_supported(const hpgmg_hip_level *L, int variant) { return pair_tile_width(L, variant) != 0; }
-#ifndef HPGMG_EXPERIMENTS
-int hpgmg_hip_smooth_cheby_pair_tile(const hpgmg_hip_level *, int, double *const *, int, int, int, int, int, int, int, int, int, double, double, double, double, double, double, double, int) {
-  (void)g_pair_tile_launches;
-  return record_error(hipErrorInvalidValue, "smooth_cheby_pair_tile: not in this build (make EXPERIMENTS=1)");
-}
-#else
-int hpgmg_hip_smooth_cheby_pair_tile(const hpgmg_hip_level *L, int variant, double *const *scr_base,
-                                     int x0_scr, int x0_id, int xm1_scr, int xm1_id, int out1_scr, int out1_id, int out2_scr, int out2_id,
-                                     int rhs_id, double a, double b, double h2inv, double c1a, double c2a, double c1b, double c2b, int keep_x1) {
-  HPGMG_SKIP_IF_REPLAY();
-  const int TI = pair_tile_width(L, variant);
-  if (!TI) return record_error(hipErrorInvalidValue, "smooth_cheby_pair_tile: level not supported");
-  const int TJ = (TI == 16) ? 16 : 8;
-  S7PairTileArgs A = {};
-  A.x0 = VecRef{x0_scr, x0_id}; A.xm1 = VecRef{xm1_scr, xm1_id}; A.out1 = VecRef{out1_scr, out1_id}; A.out2 = VecRef{out2_scr, out2_id};
-  A.rhs_id = rhs_id; A.keep_x1 = keep_x1; A.a = a; A.b = b; A.h2inv = h2inv; A.c1a = c1a; A.c2a = c2a; A.c1b = c1b; A.c2b = c2b; A.scr_base = scr_base;
-  A.tiles_i = L->dim / TI; A.tiles_j = L->dim / TJ;
-  static const int tune_kc = env_int("HPGMG_TUNE_7PT_PAIR_TILE_KCHUNK", 0);
-  int kchunk = L->dim;
-  while (kchunk > 8 && (long long)L->num_boxes * A.tiles_i * A.tiles_j * (L->dim / kchunk) < 512) kchunk /= 2;
-  if (tune_kc > 0 && L->dim % tune_kc == 0) kchunk = tune_kc;
-  A.kchunk = kchunk; A.chunks_k = (L->dim + kchunk - 1) / kchunk;
-  A.total_blocks = L->num_boxes * A.chunks_k * A.tiles_j * A.tiles_i;
-  const int grid = grid_for(A.total_blocks, &A.per_xcd);
-  const long long cells = (long long)L->num_boxes * L->dim * L->dim * L->dim;
-  const int prof = profile_begin(cells);
-#define PAIR_TILE_CASES(TJ_, TI_) \
-  switch (variant) { \
-    case HPGMG_HIP_7PT_VC_HELMHOLTZ: hipLaunchKernelGGL((stencil7_pair_tile_kernel<HPGMG_HIP_7PT_VC_HELMHOLTZ, TJ_, TI_>), dim3(grid), dim3(TI_, TJ_), 0, g_stream, *L, A); break; \
-    case HPGMG_HIP_7PT_VC_POISSON:   hipLaunchKernelGGL((stencil7_pair_tile_kernel<HPGMG_HIP_7PT_VC_POISSON, TJ_, TI_>), dim3(grid), dim3(TI_, TJ_), 0, g_stream, *L, A); break; \
-    default:                         hipLaunchKernelGGL((stencil7_pair_tile_kernel<HPGMG_HIP_7PT_CC, TJ_, TI_>), dim3(grid), dim3(TI_, TJ_), 0, g_stream, *L, A); break; \
-  }
-  if (TI == 32) { PAIR_TILE_CASES(8, 32) }
-  else if (TI == 16) { PAIR_TILE_CASES(16, 16) }
-  else { PAIR_TILE_CASES(8, 64) }
-#undef PAIR_TILE_CASES
-  g_pair_tile_launches++;
-  profile_end(prof, 2 * cells);
-  HPGMG_LAUNCH_CHECK("stencil7_pair_tile_kernel");
-  return 0;
-}
-#endif  // HPGMG_EXPERIMENTS
 void hpgmg_hip_pair_fold_interpolation(const hpgmg_hip_level *Lc, int coarse_id, double prescale) {
   g_pair_interp_level = Lc; g_pair_interp_id = coarse_id; g_pair_interp_prescale = prescale;
 }
@@ -2072,9 +1923,7 @@ int hpgmg_hip_small_level_op(const hpgmg_hip_level *L, int variant, int mode, in
 #endif
   const size_t lds = A.lds_resident ? image : 0;
   const int threads_used = A.lds_resident ? 1024 : threads;        // the image is copied by every lane there is
-#ifndef HPGMG_EXPERIMENTS
-  if (!A.lds_resident) return record_error(hipErrorInvalidValue, "small_level_op: only levels of one box that fit the LDS in this build (make EXPERIMENTS=1)");
-#endif
+  if (!A.lds_resident) return record_error(hipErrorInvalidValue, "small_level_op: a level of one box whose vectors fit the LDS");
 #define SMALL_CASE(VAR) { \
     static bool once = false; if (!once) { HPGMG_CHECK(hipFuncSetAttribute((const void *)small_level_kernel<VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); once = true; } \
     hipLaunchKernelGGL((small_level_kernel<VAR>), dim3(1), dim3(threads_used), lds, g_stream, *L, A); }
@@ -2123,42 +1972,6 @@ int hpgmg_hip_bottom_bicgstab(const hpgmg_hip_level *L, int variant, int x_id, i
   }
 #undef BOTTOM_CASE
   HPGMG_LAUNCH_CHECK("bottom_bicgstab_kernel");
-  return 0;
-}
-// One coloured half sweep of fv4 GSRB on a level of small boxes, ghost handling and boundary conditions of the result included (fv4_box_gsrb_kernel)
-static long long g_fv4_box_launches = 0;
-long long hpgmg_hip_fv4_box_launch_count(void) { return g_fv4_box_launches; }
-static int g_fv4_box_on = -1;
-void hpgmg_hip_set_fv4_box(int on) { g_fv4_box_on = on ? 1 : 0; }
-int hpgmg_hip_smooth_gsrb_fv4_box_supported(const hpgmg_hip_level *L, int variant) {
-#ifndef HPGMG_EXPERIMENTS
-  (void)L; (void)variant; (void)g_fv4_box_on;
-  return 0;                                                        // measured slower than what it replaces: not in this build (make EXPERIMENTS=1)
-#else
-  if (g_fv4_box_on < 0) g_fv4_box_on = env_int("HPGMG_TUNE_FV4_BOX", 0);
-  const int off = !g_fv4_box_on;
-  if (off || !(variant == HPGMG_HIP_FV4_VC_HELMHOLTZ || variant == HPGMG_HIP_FV4_VC_POISSON)) return 0;
-  return L->num_boxes > 0 && L->box_nbr != nullptr && L->ghosts == 2 && !L->periodic && (L->dim == 4 || L->dim == 8 || L->dim == 16) && (size_t)L->volume * sizeof(double) <= 150 * 1024;
-#endif
-}
-int hpgmg_hip_smooth_gsrb_fv4_box(const hpgmg_hip_level *L, int variant, int xn_id, int xout_id, int rhs_id, double a, double b, double h2inv, int sweep,
-                                  const blockCopy_type *bc_by_box, const int *bc_start) {
-  HPGMG_SKIP_IF_REPLAY();
-  if (!hpgmg_hip_smooth_gsrb_fv4_box_supported(L, variant) || xn_id == xout_id || !bc_start) return record_error(hipErrorInvalidValue, "smooth_gsrb_fv4_box: level / arguments not supported (EXPERIMENTS=1 builds, HPGMG_TUNE_FV4_BOX=1)");
-#ifdef HPGMG_EXPERIMENTS
-  Fv4BoxArgs A = {}; A.xn_id = xn_id; A.xout_id = xout_id; A.rhs_id = rhs_id; A.sweep = sweep; A.a = a; A.b = b; A.h2inv = h2inv; A.bc_list = bc_by_box; A.bc_start = bc_start;
-  const size_t lds = (size_t)L->volume * sizeof(double);
-  const int cells = L->dim * L->dim * L->dim, threads = cells >= 1024 ? 1024 : (cells >= 512 ? 512 : 256);
-#define FV4_BOX_CASE(VAR) { \
-    static bool once = false; if (!once) { HPGMG_CHECK(hipFuncSetAttribute((const void *)fv4_box_gsrb_kernel<VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); once = true; } \
-    hipLaunchKernelGGL((fv4_box_gsrb_kernel<VAR>), dim3(L->num_boxes), dim3(threads), lds, g_stream, *L, A); }
-  if (variant == HPGMG_HIP_FV4_VC_HELMHOLTZ) FV4_BOX_CASE(HPGMG_HIP_FV4_VC_HELMHOLTZ) else FV4_BOX_CASE(HPGMG_HIP_FV4_VC_POISSON)
-#undef FV4_BOX_CASE
-  g_fv4_box_launches++;
-  HPGMG_LAUNCH_CHECK("fv4_box_gsrb_kernel");
-#else
-  (void)rhs_id; (void)a; (void)b; (void)h2inv; (void)sweep; (void)bc_by_box;
-#endif
   return 0;
 }
 // A queue of BLAS-1 / operator calls on a level of one box of <= 512 cells as one launch (small_ops_kernel).  kinds: 1 add (c = sa*a + sb*b),

@@ -99,15 +99,6 @@ int hpgmg_hip_smooth_cheby(const hpgmg_hip_level *L, int variant, int xn_id, int
                            double a, double b, double h2inv, double c1, double c2);
 int hpgmg_hip_smooth_gsrb(const hpgmg_hip_level *L, int variant, int xn_id, int xnp1_id, int rhs_id,
                           double a, double b, double h2inv, int sweep);
-/* One coloured half sweep of the fv4 GSRB smoother (out of place) on a level of small boxes (side 4, 8 or 16, all local, Dirichlet) as ONE launch:
- * x outside a box is read where it lives (no exchange_boundary before), and apply_BCs_v4 of the RESULT runs in the same launch, each box applying
- * its own entries -- bc_by_box = the level's boundary blocks of the stencil's shape sorted by box, bc_start[box] .. bc_start[box + 1] the range of a
- * box (DEVICE arrays).  xn_id must carry valid domain-boundary ghost cells (an earlier launch of this kernel, or apply_BCs). */
-int hpgmg_hip_smooth_gsrb_fv4_box_supported(const hpgmg_hip_level *L, int variant);   /* 0 in product builds and unless switched on */
-int hpgmg_hip_smooth_gsrb_fv4_box(const hpgmg_hip_level *L, int variant, int xn_id, int xout_id, int rhs_id, double a, double b, double h2inv, int sweep,
-                                  const blockCopy_type *bc_by_box, const int *bc_start);
-long long hpgmg_hip_fv4_box_launch_count(void);
-void hpgmg_hip_set_fv4_box(int on);   /* EXPERIMENTS=1 builds: 1 = use it (default 0 / HPGMG_TUNE_FV4_BOX: it measured slower than the two launches it replaces) */
 int hpgmg_hip_smooth_jacobi(const hpgmg_hip_level *L, int variant, int xn_id, int xnp1_id, int rhs_id,
                             double a, double b, double h2inv, double weight);
 /* operators/residual.c:9-51 (rhs_id >= 0: res = rhs - A x) and operators/apply_op.c:9-48 (rhs_id < 0: res = A x) */
@@ -132,10 +123,6 @@ int hpgmg_hip_residual_norm(const hpgmg_hip_level *L, int variant, int res_id, i
  * regions before extrapolating, boundary_fv.c:133-140) and the stencil -- or a residual() / apply_op() in ONE single-workgroup launch.
  * mode: 0 Chebyshev (c1, c2 per sweep), 1 GSRB (in place, or via VECTOR_TEMP when out_of_place), 2 Jacobi (c2 = weight), 3 residual
  * (res_id = rhs - A x), 4 apply_op (res_id = A x).  Same entry routines and per-cell expressions as the streaming kernels. */
-/* 1 when the library was built with EXPERIMENTS=1 (csrc/Makefile): the kernels that measured slower than what they replace -- this one, the
- * two-sweep tile kernel for cache-resident levels (hpgmg_hip_smooth_cheby_pair_tile), the 32-wide tiles of the fv4 red + black pass -- are
- * compiled only then; otherwise their entry points exist and decline (supported() = 0, max_cells() = 0). */
-int hpgmg_hip_experiments(void);
 int hpgmg_hip_small_level_max_cells(void);
 int hpgmg_hip_small_level_op(const hpgmg_hip_level *L, int variant, int mode, int sweeps, int x_id, int rhs_id, int res_id, int out_of_place,
                              double a, double b, double h2inv, const double *c1, const double *c2,
@@ -219,15 +206,6 @@ int hpgmg_hip_smooth_cheby_pair_supported(const hpgmg_hip_level *L, int variant)
 int hpgmg_hip_smooth_cheby_pair(const hpgmg_hip_level *L, int variant, double *const *scr_base, const float *const *c32_base,
                                 int x0_scr, int x0_id, int xm1_scr, int xm1_id, int out1_scr, int out1_id, int out2_scr, int out2_id,
                                 int rhs_id, double a, double b, double h2inv, double c1a, double c2a, double c1b, double c2b);
-/* The same two sweeps for cache-resident levels (boxes of side 64 m, every box local, Dirichlet; kernels/stencil7_pair_tile.hpp): small
- * tiles that recompute x1 on a one-cell rim instead of exchanging it.  keep_x1 = 0: out1 is scratch, x1 is not stored.  Off by default
- * (slower than two single-sweep launches on the 128^3 level it was written for); supported() is 0 until set_pair_tile(1). */
-void hpgmg_hip_set_pair_tile(int on);
-int hpgmg_hip_smooth_cheby_pair_tile_supported(const hpgmg_hip_level *L, int variant);
-int hpgmg_hip_smooth_cheby_pair_tile(const hpgmg_hip_level *L, int variant, double *const *scr_base,
-                                     int x0_scr, int x0_id, int xm1_scr, int xm1_id, int out1_scr, int out1_id, int out2_scr, int out2_id,
-                                     int rhs_id, double a, double b, double h2inv, double c1a, double c2a, double c1b, double c2b, int keep_x1);
-long long hpgmg_hip_pair_tile_launch_count(void);   /* launches of that kernel so far (tests) */
 /* Sweep pairs across rank boundaries (boxes over the GPUs of a node, halo exchange over RCCL).  This rank's boxes form a
  * brick of brick_boxes[0..2] boxes (numbered lexicographically inside it); remote_face[f] (f = -i,+i,-j,+j,-k,+k) is 1 where the
  * brick face belongs to another rank, 0 where it is the (Dirichlet) domain boundary.  Before the launch the caller must have

@@ -127,17 +127,13 @@ def test_hipgraph_segments_replay_the_same_numbers(hip):
         hip.lib.hpgmg_set_graphs(0)
 
 
-@pytest.mark.parametrize("mode", [1, 2, 0])
+@pytest.mark.parametrize("mode", [2, 0])
 @pytest.mark.parametrize("variant,args", [("fv4-gsrb", "4 8"), ("27pt-gsrb", "4 8"), ("27pt-cheby", "5 8"), ("fv2-cheby", "4 8"), ("fv4-cheby", "4 8")])
 def test_small_levels_as_single_launches_give_the_same_norms(hip, variant, args, mode):
     """hpgmg_set_small_fused: smooth() / residual() of the non-7-point plugins on small levels as one single-workgroup launch each (exchange
-    copies + boundary conditions + stencil per sweep inside).  Mode 1 (EXPERIMENTS=1 builds): every level of <= 16^3 cells, out of global
-    memory (measured slower than separate launches); mode 2 (the default): smooth() on levels of ONE box, on an image of the box in LDS; mode 0:
-    separate launches.  The same numbers in every mode."""
+    copies + boundary conditions + stencil per sweep inside).  Mode 2 (the default): smooth() on levels of ONE box, on an image of the box in LDS;
+    mode 0: separate launches.  The same numbers in both."""
     import ctypes
-    import hpgmg_amd as H
-    if mode == 1 and not H.load_kernels().hpgmg_hip_experiments():
-        pytest.skip("the out-of-global-memory form of the small-level kernel is only in builds with EXPERIMENTS=1 (it measured slower than what it replaces)")
     gold = GOLD[f"{variant} {args}"]
     hip.lib.hpgmg_set_small_fused.argtypes = [ctypes.c_int]
     hip.lib.hpgmg_set_small_fused(mode)
@@ -213,31 +209,6 @@ def test_host_driven_bottom_solve_through_the_small_operator_queue(hip, variant,
     finally:
         lib.hpgmg_set_fused_bottom(1)
         lib.hpgmg_set_small_ops(1)
-
-
-def test_fv4_half_sweep_of_small_boxes_as_one_launch(hip):
-    """EXPERIMENTS=1 builds: one coloured half sweep of fv4 GSRB on a level of small boxes as ONE launch (x outside a box read where it lives, the
-    boundary conditions of the result applied by the same launch) instead of exchange + conditions and stencil: opt-in (measured slower), the same norms."""
-    import ctypes
-    import hpgmg_amd as H
-    k = H.load_kernels()
-    if not k.hpgmg_hip_experiments():
-        pytest.skip("fv4_box_gsrb_kernel is only in builds with EXPERIMENTS=1 (it measured slower than what it replaces)")
-    gold = GOLD["fv4-gsrb 4 8"]
-    k.hpgmg_hip_set_fv4_box.argtypes = [ctypes.c_int]
-    k.hpgmg_hip_fv4_box_launch_count.restype = ctypes.c_longlong
-    try:
-        k.hpgmg_hip_set_fv4_box(1)
-        before = k.hpgmg_hip_fv4_box_launch_count()
-        hip.configure(**VARIANTS["fv4-gsrb"])
-        s = hip.solver_cli(4, 8)
-        assert [fmt(v) for v in s.three_sizes()] == gold["norms"]
-        err, order = s.richardson()
-        assert fmt(err) == gold["richardson_error"]
-        s.destroy()
-        assert k.hpgmg_hip_fv4_box_launch_count() > before
-    finally:
-        k.hpgmg_hip_set_fv4_box(0)
 
 
 def test_reference_three_launch_mode_gives_the_same_norms(hip):

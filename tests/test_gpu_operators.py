@@ -107,42 +107,6 @@ def test_fused_chebyshev_sweep_pairs(hip, oracle, variant, geom):
         lh.destroy(); lo.destroy()
 
 
-@pytest.mark.parametrize("variant,geom", [("7pt-cheby-helm", (2, 64)), ("7pt-cheby", (1, 64)), ("7ptcc-cheby", (2, 64)), ("7pt-cheby-helm", (3, 64)),
-                                          ("7pt-cheby-helm", (1, 128)), ("7pt-cheby", (3, 64)),
-                                          ("7pt-cheby-helm", (2, 32)), ("7pt-cheby", (1, 32)), ("7ptcc-cheby", (2, 32)), ("7pt-cheby-helm", (3, 16)),
-                                          ("7pt-cheby", (2, 16)), ("7ptcc-cheby", (1, 16)), ("7pt-cheby-helm", (4, 16))])
-def test_chebyshev_sweep_pairs_on_cache_resident_levels(hip, oracle, variant, geom):
-    """Levels too small for the row-wise sweep-pair kernel (below 4 M cells, or rows that are no multiple of 128 cells) run their Chebyshev
-    smooth() as two launches of two sweeps each in tile form (stencil7_pair_tile.hpp): boxes of side 64 m, of 32^3 and of 16^3
-    (opt-in, EXPERIMENTS=1: measured slower than single-sweep launches for every one of them).  U and VECTOR_TEMP must equal the oracle's
-    four separate sweeps bit for bit; the in-cycle form (x3 not stored) must give the same iterate."""
-    K = H.load_kernels()
-    K.hpgmg_hip_pair_tile_launch_count.restype = ctypes.c_longlong
-    if not K.hpgmg_hip_experiments():
-        pytest.skip("the two-sweep tile kernel is only in builds with EXPERIMENTS=1 (it measured slower than what it replaces, for every box size)")
-    K.hpgmg_hip_set_pair_tile.argtypes = [ctypes.c_int]
-    K.hpgmg_hip_set_pair_tile(1)          # opt-in: on the 128^3 level of config 2 it measured slower than two single-sweep launches
-    hip.lib.hpgmg_smooth_in_cycle.restype = ctypes.c_int
-    hip.lib.hpgmg_smooth_in_cycle.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double]
-    lh, lo = make_pair(hip, oracle, variant, *geom, seed=17)
-    try:
-        a, b = (1.0, 1.0) if "helm" in variant else (0.0, 1.0)
-        for lv in (lh, lo):
-            lv.b.lib.rebuild_operator(lv.ptr, None, a, b)
-        n0 = K.hpgmg_hip_pair_tile_launch_count()
-        for lv in (lh, lo):
-            lv.b.lib.smooth(lv.ptr, H.VECTOR_U, H.VECTOR_F, a, b)
-        hip.lib.hpgmg_operators_flush()      # smooth() returns nothing, so the plugin may still hold it back: issue it before counting launches
-        assert K.hpgmg_hip_pair_tile_launch_count() - n0 == 2
-        same(lh, lo, [H.VECTOR_U, H.VECTOR_TEMP], interior_only=True)
-        assert hip.lib.hpgmg_smooth_in_cycle(lh.ptr, H.VECTOR_U, H.VECTOR_F, a, b) == 1
-        lo.b.lib.smooth(lo.ptr, H.VECTOR_U, H.VECTOR_F, a, b)
-        same(lh, lo, [H.VECTOR_U], interior_only=True)
-    finally:
-        K.hpgmg_hip_set_pair_tile(0)
-        lh.destroy(); lo.destroy()
-
-
 @pytest.mark.parametrize("geom", GEOMS)
 @pytest.mark.parametrize("shape", [H.STENCIL_SHAPE_BOX, H.STENCIL_SHAPE_STAR, H.STENCIL_SHAPE_NO_CORNERS])
 def test_exchange_and_boundary_conditions(hip, oracle, geom, shape):
@@ -424,22 +388,14 @@ def test_27pt_red_and_black_half_sweeps_in_one_pass(hip, oracle, geom):
         lh.destroy(); lo.destroy()
 
 
-@pytest.mark.parametrize("tile_width", [64, 32])
 @pytest.mark.parametrize("variant,geom", [("fv4-gsrb", (2, 64)), ("fv4-gsrb", (1, 64)), ("fv4-gsrb", (3, 64)), ("fv4-gsrb", (1, 128)), ("fv4-gsrb-helm", (2, 64)),
-                                          ("fv4-gsrb", (1, 64, "periodic")), ("fv4-gsrb", (2, 64, "periodic")), ("fv4-gsrb-helm", (1, 128)), ("fv4-gsrb", (2, 128)),
-                                          ("fv4-gsrb", (1, 32)), ("fv4-gsrb", (2, 32)), ("fv4-gsrb", (3, 32)), ("fv4-gsrb-helm", (2, 32)), ("fv4-gsrb", (2, 32, "periodic"))])
-def test_fv4_red_and_black_half_sweeps_in_one_pass(hip, oracle, variant, geom, tile_width, monkeypatch):
+                                          ("fv4-gsrb", (1, 64, "periodic")), ("fv4-gsrb", (2, 64, "periodic")), ("fv4-gsrb-helm", (1, 128)), ("fv4-gsrb", (2, 128))])
+def test_fv4_red_and_black_half_sweeps_in_one_pass(hip, oracle, variant, geom):
     """Inside a cycle (hpgmg_smooth_in_cycle: VECTOR_TEMP is scratch afterwards) the 4th-order GSRB smoother runs each red + black pair of its
     six half sweeps as ONE pass (fv4_rb.hpp): the intermediate vector lives in LDS, its quartic boundary extrapolation (apply_BCs_v4) is formed
     in LDS in i / j and by a pre-pass in k.  The iterate must equal the oracle's six separate half sweeps bit for bit -- 1, 8 and 27 boxes
     (every combination of domain walls and neighbouring boxes around a tile), Dirichlet and periodic, Poisson and Helmholtz, whole-box and
-    chunked k marches -- and the kernel must really have been the one launched.  Both tile widths: 64 x 16 (one workgroup of 8 waves per CU) and
-    32 x 16 (two workgroups of 4 waves; the only form for boxes of 32^3)."""
-    if geom[1] % 64 != 0 and tile_width == 64:
-        pytest.skip("boxes of 32^3 only have the 32-wide tiles")
-    if tile_width == 32 and not H.load_kernels().hpgmg_hip_experiments():
-        pytest.skip("the 32-wide tiles are only in builds with EXPERIMENTS=1 (they measured slower)")
-    monkeypatch.setenv("HPGMG_TUNE_FV4_RB_TI", str(tile_width))
+    chunked k marches -- and the kernel must really have been the one launched (64 x 16 tiles, one workgroup of 8 waves per CU)."""
     set_mode(hip, 1)
     K = H.load_kernels()
     lh, lo = make_pair(hip, oracle, variant, geom[0], geom[1], seed=17, bc=H.BC_PERIODIC if len(geom) > 2 else H.BC_DIRICHLET)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Experiment (library built with EXPERIMENTS=1 EXTRA_HIPFLAGS=-DHPGMG_EXP_TIMELINE): where one launch of the one-box small-level smooth
+"""Experiment (library built with EXTRA_HIPFLAGS=-DHPGMG_EXP_TIMELINE): where one launch of the one-box small-level smooth
 (HPGMG_SMALL_FUSED=2: fv4 GSRB on an 8^3 level, image of the box in LDS) spends its time."""
 import ctypes, os, sys
 import numpy as np
