@@ -10,8 +10,7 @@
 #include "plugin_internal.h"
 
 long long hp_images_exchanges = 0;
-static int images_on = -1;
-void hpgmg_set_images(int on) { images_on = on ? 1 : 0; }             /* tests: 0 = the exchange_boundary path on every level */
+void hpgmg_set_images(int on) { hp_switch_set(SW_IMAGES, on ? 1 : 0); }             /* tests: 0 = the exchange_boundary path on every level */
 long long hpgmg_image_exchanges(void) { return hp_images_exchanges; }
 
 static int table_find(void *ctx, int gid) {
@@ -378,9 +377,8 @@ int hp_images_ready(level_type *L, backend_t *B) {
     const hpgmg_transport *T = hpgmg_get_transport();
     hpgmg_config cfg;
     hpgmg_get_config(&cfg);
-    if (images_on < 0) { const char *e = getenv("HPGMG_IMAGES"); images_on = !(e && e[0] == '0'); }
     B->img_state = -1;
-    int ok = images_on && T && T->size > 1 && hp_ghost_free_mode() && (cfg.op == HPGMG_OP_27PT || cfg.op == HPGMG_OP_FV4) &&
+    int ok = hp_switch(SW_IMAGES) && T && T->size > 1 && hp_ghost_free_mode() && (cfg.op == HPGMG_OP_27PT || cfg.op == HPGMG_OP_FV4) &&
              L->boundary_condition.type == BC_DIRICHLET && L->num_my_boxes > 0 && !B->all_faces_local &&
              L->box_dim >= 8 && stencil_get_radius() + 1 + L->box_ghosts <= L->box_dim;
     if (ok) {

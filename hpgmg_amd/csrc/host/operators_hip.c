@@ -51,7 +51,7 @@ void hpgmg_tick_end(hpgmg_tick t) {
   if (t.range) hpgmg_hip_range_pop();
 }
 void hpgmg_timers_settle(void) { hpgmg_hip_timer_flush(); }
-static void do_smooth(level_type *L, int x_id, int rhs_id, double a, double b);
+static void do_smooth(level_type *L, int x_id, int rhs_id, double a, double b, int temp_dead);
 static void do_residual(level_type *L, int res_id, int x_id, int rhs_id, double a, double b);
 static void do_restriction(level_type *Lc, int id_c, level_type *Lf, int id_f, int type);
 static void do_interpolation_vcycle(level_type *Lf, int id_f, double prescale, level_type *Lc, int id_c);
@@ -102,12 +102,10 @@ void hpgmg_transport_finalize_ipc(void) { hpgmg_set_transport(NULL); hpgmg_hip_i
  * kept full by asynchronous eager launches the GPU is already 99 % busy, and on ROCm 7 replaying the segments as graphs
  * measured 2-5 % slower (3.88 vs 3.81 ms per 256^3 F-cycle, 0.574 vs 0.548 ms at 64^3).  HPGMG_GRAPH=1 or
  * hpgmg_set_graphs(1) turns it on (useful when the host thread is the bottleneck). */
-static int graphs = -1;
-void hpgmg_set_graphs(int on) { graphs = on ? 1 : 0; }
+void hpgmg_set_graphs(int on) { hp_switch_set(SW_GRAPH, on ? 1 : 0); }
 void hpgmg_segment_begin(long long key) {
   hp_lazy_flush();                                                     /* nothing postponed may slip into (or past) the captured stretch */
-  if (graphs < 0) { const char *e = getenv("HPGMG_GRAPH"); graphs = (e && e[0] == '1'); }
-  if (!graphs || hpgmg_get_timer_mode() == TIMERS_SYNC) return;       /* per-operator synchronisation: stay eager */
+  if (!hp_switch(SW_GRAPH) || hpgmg_get_timer_mode() == TIMERS_SYNC) return;       /* per-operator synchronisation: stay eager */
   /* multi-rank: segments cover levels of <= 64^3 cells; they are message-free (capturable) only when the rank map
    * gathers those levels on rank 0 (mg.c: hpgmg_gather_dim, the default) */
   { extern int hpgmg_gather_dim; const hpgmg_transport *T = hpgmg_get_transport(); if (T && T->size > 1 && hpgmg_gather_dim < 64) return; }
@@ -283,21 +281,15 @@ void exchange_boundary(level_type *L, int id, int shape) {
  * stencil; HPGMG_GHOST_FREE=0 restores the reference's three-step form) the kernel reads local
  * neighbours and the Dirichlet condition itself, so only messages from other ranks still go
  * through the ghost zone: pack -> send/recv -> unpack, no local copies, no BC launch. */
-static int ghost_free = -1;
-int hp_ghost_free_mode(void) {
-  if (ghost_free < 0) { const char *e = getenv("HPGMG_GHOST_FREE"); ghost_free = (e && e[0] == '0') ? 0 : 1; hpgmg_hip_set_ghost_free(ghost_free); }
-  return ghost_free;
-}
-void hpgmg_set_ghost_free(int on) { ghost_free = on ? 1 : 0; hpgmg_hip_set_ghost_free(ghost_free); }
+int hp_ghost_free_mode(void) { return (int)hp_switch(SW_GHOST_FREE); }
+void hpgmg_set_ghost_free(int on) { hp_switch_set(SW_GHOST_FREE, on ? 1 : 0); hpgmg_hip_set_ghost_free(on ? 1 : 0); }
 /* exchange_boundary(L, id, shape) + apply_BCs_p2 / v2 / v4 (order 12 / 2 / 4) as ONE launch, when the level has no messages and every
  * boundary-condition block can read its sources from the box that owns them (then the box-to-box copies and the conditions are
  * independent of each other).  with_copies = 0: only the conditions (the caller's kernel reads neighbouring boxes itself).  Returns 0 when the
  * caller must issue the two operators. */
 static const hpgmg_hip_bc_entry *bc_entries(level_type *L, int shape, int *n_out);
 static int exchange_and_bcs_one_launch(level_type *L, int id, int shape, int order, int with_copies) {
-  static int merge = -1;
-  if (merge < 0) { const char *e = getenv("HPGMG_ONE_LAUNCH_GHOSTS"); merge = !(e && e[0] == '0'); }
-  if (!merge || !hp_ghost_free_mode() || L->num_my_boxes < 1 || L->boundary_condition.type == BC_PERIODIC) return 0;
+  if (!hp_switch(SW_ONE_LAUNCH_GHOSTS) || !hp_ghost_free_mode() || L->num_my_boxes < 1 || L->boundary_condition.type == BC_PERIODIC) return 0;
   if (order == 12 && !(L->box_dim >= 2 && L->box_ghosts == 1)) return 0;      /* the fall-backs of apply_BCs_p2 / v2 / v4 for tiny boxes stay separate launches */
   if (order == 2 && !(L->box_dim >= 2)) return 0;
   if (order == 4 && !(L->box_dim >= 4)) return 0;
@@ -363,21 +355,16 @@ static void ghosts_for_stencil(level_type *L, int id, int out_id) {
  *     comm stream:         | wait pack, grouped ncclSend/ncclRecv, unpack into ghost zones |
  * overlap_begin() returns 0 when the level does not qualify (then the caller uses ghosts_for_stencil()). */
 static void *comm_stream = NULL, *ev_packed = NULL, *ev_landed = NULL;
-static int overlap_mode = -1;
 static long long overlap_count = 0;
 long long hpgmg_overlap_count(void) { return overlap_count; }   /* overlapped exchanges so far (tests) */
-void hpgmg_set_overlap(int on) { overlap_mode = on ? 1 : 0; }
-int hp_overlap_enabled(void) {
-  if (overlap_mode < 0) { const char *e = getenv("HPGMG_OVERLAP"); overlap_mode = (e && e[0] == '0') ? 0 : 1; }
-  return overlap_mode;
-}
+void hpgmg_set_overlap(int on) { hp_switch_set(SW_OVERLAP, on ? 1 : 0); }
+int hp_overlap_enabled(void) { return (int)hp_switch(SW_OVERLAP); }
 void hp_overlap_counted(void) { overlap_count++; }
 static int overlap_begin(level_type *L, int id) {
   const int shape = stencil_get_shape();
   const hpgmg_transport *T = hpgmg_get_transport();
   hpgmg_config c;
-  if (overlap_mode < 0) { const char *e = getenv("HPGMG_OVERLAP"); overlap_mode = (e && e[0] == '0') ? 0 : 1; }
-  if (!overlap_mode || !T || T->size < 2) return 0;
+  if (!hp_overlap_enabled() || !T || T->size < 2) return 0;
   hpgmg_get_config(&c);
   if (!(hp_ghost_free_mode() && c.op == HPGMG_OP_7PT && shape == STENCIL_SHAPE_STAR) || L->box_dim < 8) return 0;
   communicator_type *C = &L->exchange_ghosts[shape];
@@ -634,19 +621,18 @@ int hpgmg_vcycle_legs_fused(level_type **levels, int n, int e_id, int R_id, doub
  * scratch memory under the 128-register cap; with 512 lanes the launch of 8^3 + 4^3 + 2^3 levels takes 169 instead of 191 us (fv4 GSRB;
  * tools/exp_vtail_timeline.py): 4 x 24 us of smoothing, 28 us of bottom solve, the rest image traffic and interpolation. */
 static long long small_vtails = 0;
-static int small_vtail_on = -1;
 long long hpgmg_small_vtails(void) { return small_vtails; }
-void hpgmg_set_small_vtail(int on) { small_vtail_on = (on == 2) ? 2 : (on ? 1 : 0); }      /* 0 off, 1 on for every plugin, 2 the default (not for 27-point GSRB) */
+void hpgmg_set_small_vtail(int on) { hp_switch_set(SW_SMALL_VTAIL, (on == 2) ? 2 : (on ? 1 : 0)); }      /* 0 off, 1 on for every plugin, 2 the default (not for 27-point GSRB) */
 static int small_vtail_fused(level_type **levels, int n, int e_id, int R_id, double a, double b, int legs) {
   hpgmg_config cfg;
   hpgmg_hip_small_tail_args T;
   int l;
-  if (small_vtail_on < 0) { const char *e = getenv("HPGMG_SMALL_VTAIL"); small_vtail_on = (e && e[0] == '0') ? 0 : ((e && e[0] == '1') ? 1 : 2); }   /* 2: the default */
+  const int small_vtail_on = (int)hp_switch(SW_SMALL_VTAIL);      /* 2: the default */
   if (!small_vtail_on) return 0;
   hpgmg_get_config(&cfg);
   if (small_vtail_on == 2 && cfg.op == HPGMG_OP_27PT && cfg.smoother == HPGMG_SMOOTH_GSRB) return 0;
   const int sweeps = hpgmg_smooth_sweeps();
-  if (n < 2 || n > HPGMG_HIP_SMALL_TAIL_MAX_LEVELS || sweeps < 1 || sweeps > 8 || (sweeps & 1) || graphs == 1) return 0;      /* (captured segments: the argument block's upload is not capturable) */
+  if (n < 2 || n > HPGMG_HIP_SMALL_TAIL_MAX_LEVELS || sweeps < 1 || sweeps > 8 || (sweeps & 1) || hp_switch(SW_GRAPH)) return 0;      /* (captured segments: the argument block's upload is not capturable) */
   if (cfg.smoother != HPGMG_SMOOTH_CHEBY && cfg.smoother != HPGMG_SMOOTH_GSRB && cfg.smoother != HPGMG_SMOOTH_JACOBI) return 0;
   memset(&T, 0, sizeof T);
   T.n = n; T.legs = legs; T.mode = (cfg.smoother == HPGMG_SMOOTH_CHEBY) ? 0 : (cfg.smoother == HPGMG_SMOOTH_GSRB ? 1 : 2);
@@ -699,18 +685,14 @@ static int small_vtail_fused(level_type **levels, int n, int e_id, int R_id, dou
   small_vtails++;
   return 1;
 }
-static int fused_tail_enabled = -1, fused_bottom_enabled = -1;
-void hpgmg_set_fused_tail(int on) { fused_tail_enabled = on ? 1 : 0; }      /* tests: 0 = every operator of the small levels as its own launch(es) */
-void hpgmg_set_fused_bottom(int on) { fused_bottom_enabled = on ? 1 : 0; }  /* tests: 0 = the bottom solve driven from the host (host/solvers.c BiCGStab through the operators) */
+void hpgmg_set_fused_tail(int on) { hp_switch_set(SW_FUSED_TAIL, on ? 1 : 0); }      /* tests: 0 = every operator of the small levels as its own launch(es) */
+void hpgmg_set_fused_bottom(int on) { hp_switch_set(SW_FUSED_BOTTOM, on ? 1 : 0); }  /* tests: 0 = the bottom solve driven from the host (host/solvers.c BiCGStab through the operators) */
 static int vcycle_legs_fused(level_type **levels, int n, int e_id, int R_id, double a, double b, int leg) {
-#define bottom_enabled fused_bottom_enabled
-#define enabled fused_tail_enabled
   hpgmg_config cfg;
   const hpgmg_hip_level *dev[8];
   int l, s;
   double h2inv[8], c1[64], c2[64];
-  if (enabled < 0) { const char *e = getenv("HPGMG_FUSED_TAIL"); enabled = !(e && e[0] == '0'); }
-  if (bottom_enabled < 0) { const char *e = getenv("HPGMG_FUSED_BOTTOM"); bottom_enabled = !(e && e[0] == '0'); }
+  const int enabled = (int)hp_switch(SW_FUSED_TAIL), bottom_enabled = (int)hp_switch(SW_FUSED_BOTTOM);
   hpgmg_get_config(&cfg);
   const int sweeps = hpgmg_smooth_sweeps();
   const int with_bottom = (leg >= 2);
@@ -722,7 +704,7 @@ static int vcycle_legs_fused(level_type **levels, int n, int e_id, int R_id, dou
   if (!enabled || !hp_ghost_free_mode() || cfg.op != HPGMG_OP_7PT || n > 8 || n > hpgmg_hip_tail_max_levels() || sweeps > 8) return 0;
   if (with_bottom && !bottom_enabled) return 0;
   if (n < (leg == 3 ? 1 : 2)) return 0;
-  if (leg >= 4) { static int ftail = -1; if (ftail < 0) { const char *e = getenv("HPGMG_FUSED_FTAIL"); ftail = !(e && e[0] == '0'); } if (!ftail) return 0; }
+  if (leg >= 4 && !hp_switch(SW_FUSED_FTAIL)) return 0;
   /* multi-rank jobs: the chain qualifies when this rank owns every box of every level in it (checked below), which is
    * how the coarse levels end up after agglomeration onto rank 0 -- no message and no all-reduce is needed then */
   for (l = 0; l < n; l++) {
@@ -766,8 +748,6 @@ static int vcycle_legs_fused(level_type **levels, int n, int e_id, int R_id, dou
                                hpgmg_vectors_reserved(), MG_DEFAULT_BOTTOM_NORM, with_bottom ? hp_backend_of(levels[n - 1])->krylov_pinned : NULL));
   TOCK();
   return 1;
-#undef enabled
-#undef bottom_enabled
 }
 
 /* every box of the level is local and local box b sits at lexicographic position b (what the kernels that address
@@ -789,11 +769,9 @@ static int boxes_lexicographic(level_type *L) {
 /* BASELINE config 5: mixed-precision Chebyshev smoother.  32 = the fused sweep pairs read fp32 copies of the five
  * coefficient vectors (the iterate, the right-hand side and all arithmetic stay fp64; residual, restriction,
  * interpolation and every level the pair kernel does not cover are unchanged).  64 (default) = bit-exact fp64. */
-static int smoother_bits = 0;
-void hpgmg_set_smoother_precision(int bits) { smoother_bits = (bits == 32) ? 32 : 64; }
+void hpgmg_set_smoother_precision(int bits) { hp_switch_set(SW_SMOOTHER_PRECISION, (bits == 32) ? 32 : 64); }
 int hpgmg_get_smoother_precision(void) {
-  if (!smoother_bits) { const char *e = getenv("HPGMG_SMOOTHER_PRECISION"); smoother_bits = (e && atoi(e) == 32) ? 32 : 64; }
-  return smoother_bits;
+  return hp_switch(SW_SMOOTHER_PRECISION) == 32 ? 32 : 64;
 }
 static const float *const *coef32_of(level_type *L) {
   backend_t *B = hp_backend_of(L);
@@ -817,11 +795,7 @@ static const float *const *coef32_of(level_type *L) {
 static void coef32_invalidate(level_type *L) { backend_t *B = hp_backend_of(L); B->coef32_valid = 0; if (B->halo) B->halo->coef_valid = 0; hp_images_invalidate_coefficients(B); hpgmg_hip_pair_packed_invalidate(&B->dev); }
 
 /* ---------------------------------------------------------------- sweep pairs across rank boundaries: halo plans */
-static int pair_remote_enabled(void) {
-  static int on = -1;
-  if (on < 0) { const char *e = getenv("HPGMG_PAIR_REMOTE"); on = !(e && e[0] == '0'); }
-  return on;
-}
+static int pair_remote_enabled(void) { return (int)hp_switch(SW_PAIR_REMOTE); }
 int hp_box_rank_at(const level_type *L, int bi, int bj, int bk) {           /* -1 outside the (non-periodic) domain */
   if (bi < 0 || bj < 0 || bk < 0 || bi >= L->boxes_in.i || bj >= L->boxes_in.j || bk >= L->boxes_in.k) return -1;
   return L->rank_of_box[bi + L->boxes_in.i * (bj + L->boxes_in.j * bk)];
@@ -1080,37 +1054,32 @@ void hp_ensure_pair_scratch(level_type *L, backend_t *B) {
     free(base);
   }
 }
-static int fused_sweeps = -1;
-void hpgmg_set_fused_sweeps(int on) { fused_sweeps = on ? 1 : 0; }
+void hpgmg_set_fused_sweeps(int on) { hp_switch_set(SW_FUSED_SWEEPS, on ? 1 : 0); }
 /* common part: does the level qualify for the sweep-pair kernel, and are its two private vectors there? */
 static int pair_kernel_ready(level_type *L, int x_id, int rhs_id, int sweeps) {
-  if (fused_sweeps < 0) { const char *e = getenv("HPGMG_FUSED_SWEEPS"); fused_sweeps = !(e && e[0] == '0'); }
   hpgmg_config cfg;
   hpgmg_get_config(&cfg);
   backend_t *B = hp_backend_of(L);
-  if (!fused_sweeps || sweeps != 4 || cfg.op != HPGMG_OP_7PT || !hp_ghost_free_mode() || stencil_get_shape() != STENCIL_SHAPE_STAR) return 0;
+  if (!hp_switch(SW_FUSED_SWEEPS) || sweeps != 4 || cfg.op != HPGMG_OP_7PT || !hp_ghost_free_mode() || stencil_get_shape() != STENCIL_SHAPE_STAR) return 0;
   if (L->boundary_condition.type != BC_DIRICHLET || x_id == VECTOR_TEMP || rhs_id == VECTOR_TEMP) return 0;
   if (B->all_faces_local) { if (!hpgmg_hip_smooth_cheby_pair_supported(&B->dev, hp_variant()) || !boxes_lexicographic(L)) return 0; }
   else if (!pair_halo_ready(L, B)) return 0;          /* faces owned by other ranks: two-deep halo, one exchange per pair */
   { /* the pass structure pays when the level is bandwidth bound; a cache-resident level (128^3 and smaller) is latency
      * bound and faster with many small single-sweep workgroups (measured: 128^3 pair 80 us vs 2 x 27 us) */
-    static long long min_cells = -1;
-    if (min_cells < 0) { const char *e = getenv("HPGMG_PAIR_MIN_CELLS"); min_cells = (e && *e) ? atoll(e) : 4000000; }
-    if ((long long)L->dim.i * L->dim.j * L->dim.k < min_cells) return 0;
+    if ((long long)L->dim.i * L->dim.j * L->dim.k < hp_switch(SW_PAIR_MIN_CELLS)) return 0;
   }
   hp_ensure_pair_scratch(L, B);
   hpgmg_hip_set_ghost_free(1);
   return 1;
 }
 
-static int temp_is_scratch = 0;
 
 /* Chebyshev smooth() as fused sweep pairs (kernels/cheby_pair.hpp): 4 sweeps = 2 passes of 10 streams instead of
  * 4 x 9.  x1,x2 of the first pair go to two plugin-private vectors, the second pair brings x3 -> VECTOR_TEMP and
  * x4 -> x_id, i.e. exactly the state chebyshev.c:43-99 leaves.  Returns 0 when the level does not qualify. */
 /* smooth() called by the cycle driver through hpgmg_smooth_in_cycle(): VECTOR_TEMP (x3 of the four sweeps) is dead after it, so the second
  * pair does not store it */
-static int smooth_cheby_pairs(level_type *L, int x_id, int rhs_id, double a, double b, const double *c1, const double *c2, int sweeps) {
+static int smooth_cheby_pairs(level_type *L, int x_id, int rhs_id, double a, double b, const double *c1, const double *c2, int sweeps, int temp_dead) {
   if (!pair_kernel_ready(L, x_id, rhs_id, sweeps)) return 0;
   backend_t *B = hp_backend_of(L);
   const double h2inv = 1.0 / (L->h * L->h);
@@ -1125,9 +1094,9 @@ static int smooth_cheby_pairs(level_type *L, int x_id, int rhs_id, double a, dou
     TOCK(); }
   if (remote) over = pair_halo_begin(L, B, 0, 1, 1, 1, 0, rhs_id);
   { TICK(L, smooth, "smooth (Chebyshev sweeps 3+4)");
-    if (remote) PAIR_REMOTE_LAUNCH(over, temp_is_scratch, hpgmg_hip_smooth_cheby_pair(&B->dev, v, (double *const *)B->d_pair_base, c32, 1, 1, 1, 0, 0, VECTOR_TEMP, 0, x_id, rhs_id, a, b, h2inv, c1[2], c2[2], c1[3], c2[3]));
+    if (remote) PAIR_REMOTE_LAUNCH(over, temp_dead, hpgmg_hip_smooth_cheby_pair(&B->dev, v, (double *const *)B->d_pair_base, c32, 1, 1, 1, 0, 0, VECTOR_TEMP, 0, x_id, rhs_id, a, b, h2inv, c1[2], c2[2], c1[3], c2[3]));
     else {
-      if (temp_is_scratch) hpgmg_hip_pair_discard_x1();
+      if (temp_dead) hpgmg_hip_pair_discard_x1();
       HIP_OK(hpgmg_hip_smooth_cheby_pair(&B->dev, v, (double *const *)B->d_pair_base, c32, 1, 1, 1, 0, 0, VECTOR_TEMP, 0, x_id, rhs_id, a, b, h2inv, c1[2], c2[2], c1[3], c2[3]));
     }
     TOCK(); }
@@ -1178,9 +1147,7 @@ static int interp_smooth_fused(level_type *Lf, int e_id, int R_id, level_type *L
   if (cfg.smoother == HPGMG_SMOOTH_CHEBY) {
     double c1[16], c2[16];
     cheby_coefficients(Lf, sweeps, c1, c2);
-    { const char *e = getenv("HPGMG_TEMP_SCRATCH"); temp_is_scratch = !exact_state && !(e && e[0] == '0'); }      /* the cycle hook: VECTOR_TEMP is dead afterwards */
-    const int done = smooth_cheby_pairs(Lf, e_id, R_id, a, b, c1, c2, sweeps);
-    temp_is_scratch = 0;
+    const int done = smooth_cheby_pairs(Lf, e_id, R_id, a, b, c1, c2, sweeps, !exact_state && hp_switch(SW_TEMP_SCRATCH));      /* the cycle hook: VECTOR_TEMP is dead afterwards */
     if (!done) { fprintf(stderr, "hpgmg: fused interpolation+smooth refused after being accepted\n"); abort(); }
   } else if (!smooth_gsrb_pairs(Lf, e_id, R_id, a, b, sweeps)) { fprintf(stderr, "hpgmg: fused interpolation+smooth refused after being accepted\n"); abort(); }
   return 1;
@@ -1193,12 +1160,10 @@ static int interp_smooth_fused(level_type *Lf, int e_id, int R_id, level_type *L
  * launches it replaces -- fv4 GSRB `7 8` 17.1 vs 12.7 ms, 27-pt GSRB 9.9 vs 6.2 ms per F-cycle -- because a 16^3 level in 8 boxes has
  * ~160 copy / boundary list entries whose dependent load chains run 16 at a time on one CU, while separate launches spread them over
  * the chip; the launch overhead saved (~5 us each) is smaller than that serialisation. */
-static int small_fused = -1;
-void hpgmg_set_small_fused(int mode) { small_fused = (mode == 1 || mode == 2) ? mode : 0; }   /* 0 off, 1 every small level, 2 (default) one-box levels in LDS */
+void hpgmg_set_small_fused(int mode) { hp_switch_set(SW_SMALL_FUSED, (mode == 1 || mode == 2) ? 2 : 0); }   /* 0 off, 1 every small level, 2 (default) one-box levels in LDS */
 static int small_level_try(level_type *L, int mode, int x_id, int rhs_id, int res_id, double a, double b) {
   hpgmg_config cfg;
-  if (small_fused < 0) { const char *e = getenv("HPGMG_SMALL_FUSED"); small_fused = (e && e[0] == '1') ? 1 : ((e && e[0] == '0') ? 0 : 2); }
-  if (small_fused == 1) small_fused = 2;                /* (mode 1, every small level out of global memory, measured slower in two rounds: removed) */
+  const int small_fused = hp_switch(SW_SMALL_FUSED) ? 2 : 0;      /* (mode 1, every small level out of global memory, measured slower in two rounds: removed) */
   /* 0: off.  1 (experiment builds): every qualifying level, out of global memory (slower than the launches it replaces, see above).  2
    * (default): smooth() on levels of ONE box whose vectors fit the LDS -- the kernel then works on an image of the box there (round 3).  With
    * generic (FLAT) accesses to the image a smooth() was one ~60 us launch instead of twelve ~5 us ones: no gain.  With LDS-typed pointers, the
@@ -1207,10 +1172,9 @@ static int small_level_try(level_type *L, int mode, int x_id, int rhs_id, int re
   hpgmg_get_config(&cfg);
   /* mode 2 takes what it shortens: a smooth() of many launches (fv4 GSRB: 12, Chebyshev: 8; a residual or apply_op is two launches of ~5 us,
    * the kernel with its copies in and out ~15 us; the 27-point GSRB smoother already runs as two one-workgroup-per-box launches) */
-  static int small_27 = -1;
-  if (small_27 < 0) { const char *e = getenv("HPGMG_TUNE_SMALL_27PT_GSRB"); small_27 = (e && e[0] == '1'); }
+  const int small_27 = (int)hp_switch(SW_SMALL_27PT_GSRB);
   const int worth = (mode <= 2) && (small_27 || !(cfg.op == HPGMG_OP_27PT && cfg.smoother == HPGMG_SMOOTH_GSRB));
-  const int enabled = small_fused == 1 || (small_fused == 2 && worth && L->num_my_boxes == 1 && (size_t)9 * (size_t)L->box_volume * sizeof(double) <= (size_t)150 * 1024);
+  const int enabled = (small_fused == 2 && worth && L->num_my_boxes == 1 && (size_t)9 * (size_t)L->box_volume * sizeof(double) <= (size_t)150 * 1024);
   if (!enabled || cfg.op == HPGMG_OP_7PT || L->num_my_boxes < 1) return 0;
   if ((long long)L->dim.i * L->dim.j * L->dim.k > hpgmg_hip_small_level_max_cells()) return 0;
   if (L->num_my_boxes != L->boxes_in.i * L->boxes_in.j * L->boxes_in.k) return 0;
@@ -1246,8 +1210,7 @@ static int small_level_try(level_type *L, int mode, int x_id, int rhs_id, int re
  * ~6 host round trips on a level of 8 cells.  HPGMG_FUSED_BOTTOM=0 keeps the host-driven solver. */
 int hpgmg_bottom_solve_fused(level_type *L, int e_id, int R_id, double a, double b, double want) {
   hpgmg_config cfg;
-  if (fused_bottom_enabled < 0) { const char *e = getenv("HPGMG_FUSED_BOTTOM"); fused_bottom_enabled = !(e && e[0] == '0'); }
-  const int on = fused_bottom_enabled;
+  const int on = (int)hp_switch(SW_FUSED_BOTTOM);
   hpgmg_get_config(&cfg);
   if (!on || cfg.op == HPGMG_OP_7PT || !L->active || L->num_my_boxes != 1 || L->boxes_in.i * L->boxes_in.j * L->boxes_in.k != 1) return 0;
   if (L->boundary_condition.type == BC_PERIODIC || L->must_subtract_mean == 1) return 0;
@@ -1274,12 +1237,8 @@ int hpgmg_bottom_solve_fused(level_type *L, int e_id, int R_id, double a, double
  * cycle overwrites or ignores it.  Always returns 1 (the hook exists so that the reference's own driver, which never calls it, keeps
  * the exact state of smooth()). */
 int hpgmg_smooth_in_cycle(level_type *L, int x_id, int rhs_id, double a, double b) {
-  static int on = -1;
-  if (on < 0) { const char *e = getenv("HPGMG_TEMP_SCRATCH"); on = !(e && e[0] == '0'); }
-  temp_is_scratch = on;
   hp_lazy_flush();
-  do_smooth(L, x_id, rhs_id, a, b);
-  temp_is_scratch = 0;
+  do_smooth(L, x_id, rhs_id, a, b, (int)hp_switch(SW_TEMP_SCRATCH));
   return 1;
 }
 /* 4th-order operator, GSRB, inside a cycle (VECTOR_TEMP is scratch afterwards): each red + black pair of half sweeps as ONE pass
@@ -1336,12 +1295,12 @@ static const int *fv4_special_cells(level_type *L, backend_t *B, int *n_out) {
   return B->d_fv4_special;
 }
 static void do_scale_vector(level_type *L, int c, double s, int a);
-static int smooth_fv4_rb(level_type *L, int x_id, int rhs_id, double a, double b, int sweeps) {
+static int smooth_fv4_rb(level_type *L, int x_id, int rhs_id, double a, double b, int sweeps, int temp_dead) {
   hpgmg_config cfg;
   hpgmg_get_config(&cfg);
   backend_t *B = hp_backend_of(L);
   const int passes = sweeps / 2, v = hp_variant();
-  if (cfg.op != HPGMG_OP_FV4 || !hpgmg_gsrb_out_of_place() || !temp_is_scratch || !hp_ghost_free_mode() || (sweeps & 1) || passes < 1) return 0;
+  if (cfg.op != HPGMG_OP_FV4 || !hpgmg_gsrb_out_of_place() || !temp_dead || !hp_ghost_free_mode() || (sweeps & 1) || passes < 1) return 0;
   if (L->num_my_boxes < 1 || x_id == VECTOR_TEMP || rhs_id == VECTOR_TEMP || L->box_dim < 8) return 0;
   /* boxes on other ranks: the same passes on the table with their images (halo_images.c) -- x three cells deep once per PASS, i.e. one
    * exchange per sweep where the reference has two (gsrb.c:30-33), the cells next to the faces recomputed from the owner's inputs */
@@ -1395,7 +1354,9 @@ static int smooth_fv4_rb(level_type *L, int x_id, int rhs_id, double a, double b
   fv4_rb_smooths++;
   return 1;
 }
-static void do_smooth(level_type *L, int x_id, int rhs_id, double a, double b) {
+/* temp_dead: the caller declares VECTOR_TEMP scratch after this smooth() (inside a cycle: hpgmg_smooth_in_cycle, or the operator queue saw it
+ * overwritten next) -- the in-cycle forms may run: the sweep pair without the x3 store, the red + black passes of the 27-point / fv4 GSRB smoothers */
+static void do_smooth(level_type *L, int x_id, int rhs_id, double a, double b, int temp_dead) {
   hpgmg_config cfg;
   hpgmg_get_config(&cfg);
   const int sweeps = hpgmg_smooth_sweeps(), v = hp_variant();
@@ -1407,7 +1368,7 @@ static void do_smooth(level_type *L, int x_id, int rhs_id, double a, double b) {
     double c1[16], c2[16];
     if (L->dominant_eigenvalue_of_DinvA <= 0.0 && L->my_rank == 0) fprintf(stderr, "dominant_eigenvalue_of_DinvA <= 0.0 !\n");
     cheby_coefficients(L, sweeps, c1, c2);
-    if (smooth_cheby_pairs(L, x_id, rhs_id, a, b, c1, c2, sweeps)) return;
+    if (smooth_cheby_pairs(L, x_id, rhs_id, a, b, c1, c2, sweeps, temp_dead)) return;
     for (s = 0; s < sweeps; s++) {
       const int src = (s & 1) ? VECTOR_TEMP : x_id, dst = (s & 1) ? x_id : VECTOR_TEMP;
       STENCIL_WITH_GHOSTS(L, src, dst, smooth, hpgmg_hip_smooth_cheby(hp_stencil_dev(B), v, src, dst, rhs_id, a, b, h2inv, c1[s], c2[s]));
@@ -1417,7 +1378,7 @@ static void do_smooth(level_type *L, int x_id, int rhs_id, double a, double b) {
     if (smooth_gsrb_pairs(L, x_id, rhs_id, a, b, sweeps)) return;
     /* 27-point, inside a cycle (VECTOR_TEMP is scratch afterwards): each red + black pair of half sweeps as one pass, x -> TEMP -> x.
      * The state the exported smooth() must leave in VECTOR_TEMP (the iterate before the last half sweep) never exists in this form. */
-    if (cfg.op == HPGMG_OP_27PT && oop && temp_is_scratch && hp_ghost_free_mode() && sweeps % 4 == 0 && L->num_my_boxes > 0 &&
+    if (cfg.op == HPGMG_OP_27PT && oop && temp_dead && hp_ghost_free_mode() && sweeps % 4 == 0 && L->num_my_boxes > 0 &&
         (B->all_faces_local || hp_images_ready(L, B)) && x_id != VECTOR_TEMP && rhs_id != VECTOR_TEMP) {
       /* boxes on other ranks: the same pass on the table with their images -- x two cells deep once per pass (one exchange per sweep instead of
        * gsrb.c:30-33's two), the intermediate vector on the cells around a box recomputed from the owner's x, right-hand side and D^{-1} */
@@ -1447,19 +1408,13 @@ static void do_smooth(level_type *L, int x_id, int rhs_id, double a, double b) {
         return;
       }
     }
-    if (smooth_fv4_rb(L, x_id, rhs_id, a, b, sweeps)) return;
+    if (smooth_fv4_rb(L, x_id, rhs_id, a, b, sweeps, temp_dead)) return;
     /* The exported smooth() (VECTOR_TEMP must be left as the separate half sweeps leave it: the iterate before the last one) -- what the
      * reference's own driver calls (Route B): all sweeps but the last as red + black passes x -> TEMP -> x, the last sweep as its two half
      * sweeps x -> TEMP -> x.  The same iterates, the same final x and VECTOR_TEMP; 2 passes + 2 half sweeps instead of 6 half sweeps. */
     int first_half_sweep = 0;
-    if (cfg.op == HPGMG_OP_FV4 && oop && !temp_is_scratch && sweeps >= 6 && !(sweeps & 1) && (((sweeps - 2) / 2) & 1) == 0) {
-      static int exact_rb = -1;
-      if (exact_rb < 0) { const char *e = getenv("HPGMG_TUNE_FV4_NO_EXACT_RB"); exact_rb = !(e && e[0] == '1'); }
-      if (exact_rb) {
-        temp_is_scratch = 1;
-        if (smooth_fv4_rb(L, x_id, rhs_id, a, b, sweeps - 2)) first_half_sweep = sweeps - 2;      /* an even number of passes: they end on x */
-        temp_is_scratch = 0;
-      }
+    if (cfg.op == HPGMG_OP_FV4 && oop && !temp_dead && sweeps >= 6 && !(sweeps & 1) && (((sweeps - 2) / 2) & 1) == 0 && !hp_switch(SW_FV4_NO_EXACT_RB)) {
+      if (smooth_fv4_rb(L, x_id, rhs_id, a, b, sweeps - 2, 1)) first_half_sweep = sweeps - 2;      /* VECTOR_TEMP is scratch to THESE passes (the half sweeps after them rewrite it); an even number of passes: they end on x */
     }
     for (s = first_half_sweep; s < sweeps; s++) {
       const int src = (oop && (s & 1)) ? VECTOR_TEMP : x_id, dst = oop ? ((s & 1) ? x_id : VECTOR_TEMP) : x_id;
@@ -1531,10 +1486,8 @@ static const int *restrict_map_of(level_type *Lf, backend_t *Bf) {
   }
   return Bf->d_restrict_map;
 }
-static int fused_residual = -1;
 static int fused_residual_on(void) {
-  if (fused_residual < 0) { const char *e = getenv("HPGMG_FUSED_RESIDUAL"); fused_residual = !(e && e[0] == '0'); }
-  return fused_residual;
+  return (int)hp_switch(SW_FUSED_RESIDUAL);
 }
 /* the operand of a fused residual form is made ready: 7-point -- nothing (the kernel applies the Dirichlet rule and reads neighbouring boxes);
  * 27-point / fv4 -- the domain-boundary ghost cells (the tiled kernel reads neighbouring boxes itself).  0 = the level does not qualify. */
@@ -1870,34 +1823,30 @@ enum { LZ_NONE = 0, LZ_DOWN, LZ_UP, LZ_RN, LZ_SR, LZ_SMALL };      /* RN: a lone
 typedef struct { int op; level_type *L, *L2; int i0, i1, i2; double a, b; } lazy_op;
 #define LZ_MAX 80
 static lazy_op lz[LZ_MAX];
-static int lz_n = 0, lz_mode = LZ_NONE, lz_busy = 0, lazy_on = -1;
+static int lz_n = 0, lz_mode = LZ_NONE, lz_busy = 0;
 static long long lazy_fused_legs = 0, lazy_fused_units = 0, lazy_temp_proved_dead = 0;
 long long hpgmg_lazy_temp_proved_dead(void) { return lazy_temp_proved_dead; }      /* smooth() calls run in the in-cycle form because the queue saw VECTOR_TEMP overwritten next (tests) */
 long long hpgmg_lazy_fused_legs(void) { return lazy_fused_legs; }      /* single-launch legs / fused large-level units issued by the queue so far (tests) */
 long long hpgmg_lazy_fused_units(void) { return lazy_fused_units; }
-void hpgmg_set_lazy(int on) { hp_lazy_flush(); lazy_on = on ? 1 : 0; }
+void hpgmg_set_lazy(int on) { hp_lazy_flush(); hp_switch_set(SW_LAZY, on ? 1 : 0); }
 void hpgmg_operators_flush(void) { hp_lazy_flush(); }      /* issue every postponed operator now (nothing is ever left behind: any other call does the same) */
 /* HPGMG_LAZY_REPORT=1: what the queue did, on stderr when the process ends (tests/test_gpu_route_b.py reads it) */
 __attribute__((destructor)) static void lazy_report(void) {
-  const char *e = getenv("HPGMG_LAZY_REPORT");
-  if (e && e[0] == '1') fprintf(stderr, "hpgmg lazy queue: %lld single-launch legs, %lld fused large-level units, %lld smooths with VECTOR_TEMP proved dead\n", lazy_fused_legs, lazy_fused_units, lazy_temp_proved_dead);
+  if (hp_switch(SW_LAZY_REPORT)) fprintf(stderr, "hpgmg lazy queue: %lld single-launch legs, %lld fused large-level units, %lld smooths with VECTOR_TEMP proved dead\n", lazy_fused_legs, lazy_fused_units, lazy_temp_proved_dead);
 }
 static int lazy_enabled(void) {
-  if (lazy_on < 0) { const char *e = getenv("HPGMG_LAZY"); lazy_on = !(e && e[0] == '0'); }
-  return lazy_on && !lz_busy;
+  return hp_switch(SW_LAZY) && !lz_busy;
 }
 /* LZ_SMALL: BLAS-1 calls, apply_op and residual on a level of ONE box of side <= 8 wait for the dot product or norm that follows them -- what a
  * host-driven Krylov solver on the bottom level issues between two scalars it needs (the reference's solvers/bicgstab.c, "Route B"; host/solvers.c
  * with HPGMG_FUSED_BOTTOM=0) -- and go out with it as ONE launch (kernels/stencil.hip: small_ops_kernel): 6 launches per BiCGStab iteration
  * instead of ~18.  HPGMG_SMALL_OPS=0 / hpgmg_set_small_ops(0) turn it off. */
-static int small_ops_on = -1;
 static long long small_ops_groups = 0;
-void hpgmg_set_small_ops(int on) { hp_lazy_flush(); small_ops_on = on ? 1 : 0; }
+void hpgmg_set_small_ops(int on) { hp_lazy_flush(); hp_switch_set(SW_SMALL_OPS, on ? 1 : 0); }
 long long hpgmg_small_ops_groups(void) { return small_ops_groups; }
 static int small_ops_kind(int op) { return op == LZ_ADD ? 1 : op == LZ_MUL ? 2 : op == LZ_SCALE ? 3 : op == LZ_APPLY ? 4 : op == LZ_RESIDUAL ? 5 : 0; }
 static int small_ops_level_ok(level_type *L) {
-  if (small_ops_on < 0) { const char *e = getenv("HPGMG_SMALL_OPS"); small_ops_on = !(e && e[0] == '0'); }
-  if (!small_ops_on || !L->active || L->num_my_boxes != 1 || L->boxes_in.i * L->boxes_in.j * L->boxes_in.k != 1 || L->box_dim > 8) return 0;
+  if (!hp_switch(SW_SMALL_OPS) || !L->active || L->num_my_boxes != 1 || L->boxes_in.i * L->boxes_in.j * L->boxes_in.k != 1 || L->box_dim > 8) return 0;
   if (L->boundary_condition.type != BC_DIRICHLET) return 0;
   communicator_type *C = &L->exchange_ghosts[stencil_get_shape()];
   if (C->num_sends + C->num_recvs > 0 || C->num_blocks[0] || C->num_blocks[1] || C->num_blocks[2]) return 0;      /* one box: nothing to exchange */
@@ -1951,7 +1900,7 @@ static double small_ops_issue(level_type *L, int value_kind, int va, int vb, int
 }
 static void lazy_run_one(const lazy_op *o) {
   switch (o->op) {
-    case LZ_SMOOTH:   do_smooth(o->L, o->i0, o->i1, o->a, o->b); break;
+    case LZ_SMOOTH:   do_smooth(o->L, o->i0, o->i1, o->a, o->b, 0); break;
     case LZ_RESIDUAL: do_residual(o->L, o->i0, o->i1, o->i2, o->a, o->b); break;
     case LZ_RESTRICT: do_restriction(o->L, o->i0, o->L2, o->i1, o->i2); break;
     case LZ_ZERO:     do_zero_vector(o->L, o->i0); break;
@@ -1980,10 +1929,8 @@ void hp_lazy_flush(void) {
        * operator is residual(VECTOR_TEMP, ...) (mg.c:1150), which overwrites what smooth() leaves in VECTOR_TEMP before anything can read it:
        * the queue has PROVED the vector dead, so the smoother may run in its in-cycle form (hpgmg_smooth_in_cycle: the sweep pair without the
        * x3 store, the 27-point / fv4 red + black passes) although the reference's driver never says so.  HPGMG_TEMP_SCRATCH=0 keeps the exact form. */
-      { static int dead_ok = -1;
-        if (dead_ok < 0) { const char *e = getenv("HPGMG_TEMP_SCRATCH"); dead_ok = !(e && e[0] == '0'); }
-        const lazy_op *sm = &lz[4 * u];
-        if (dead_ok && sm->i0 != VECTOR_TEMP && sm->i1 != VECTOR_TEMP) { temp_is_scratch = 1; lazy_run_one(sm); temp_is_scratch = 0; lazy_temp_proved_dead++; }
+      { const lazy_op *sm = &lz[4 * u];
+        if (hp_switch(SW_TEMP_SCRATCH) && sm->i0 != VECTOR_TEMP && sm->i1 != VECTOR_TEMP) { do_smooth(sm->L, sm->i0, sm->i1, sm->a, sm->b, 1); lazy_temp_proved_dead++; }
         else lazy_run_one(sm); }
       const lazy_op *r = &lz[4 * u + 1], *t = &lz[4 * u + 2], *z = &lz[4 * u + 3];
       if (residual_restrict_zero_fused(t->L, t->i0, r->L, r->i0, r->i1, r->i2, r->a, r->b, z->i0)) lazy_fused_units++;
@@ -2069,7 +2016,7 @@ void smooth(level_type *L, int x_id, int rhs_id, double a, double b) {
   if (lazy_push(LZ_SMOOTH, L, NULL, x_id, rhs_id, 0, a, b)) return;
   hp_lazy_flush();
   if (lazy_push(LZ_SMOOTH, L, NULL, x_id, rhs_id, 0, a, b)) return;      /* it may start the next pattern */
-  do_smooth(L, x_id, rhs_id, a, b);
+  do_smooth(L, x_id, rhs_id, a, b, 0);
 }
 void residual(level_type *L, int res_id, int x_id, int rhs_id, double a, double b) {
   if (lazy_push(LZ_RESIDUAL, L, NULL, res_id, x_id, rhs_id, a, b)) return;
