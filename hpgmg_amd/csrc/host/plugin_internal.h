@@ -153,4 +153,70 @@ HP_INTERNAL void hp_images_invalidate_coefficients(backend_t *B);
 extern HP_INTERNAL long long hp_images_exchanges;      /* image refreshes so far (tests) */
 static inline const hpgmg_hip_level *hp_stencil_dev(backend_t *B) { return (B->img && B->img_active) ? &B->img->dev : &B->dev; }
 
+
+/* ---- what the translation units of the plugin share (operators_hip.c was one file until round 4) ---- */
+extern HP_INTERNAL void *hp_comm_stream, *hp_ev_packed, *hp_ev_landed;
+extern HP_INTERNAL long long hp_overlap_count;
+HP_INTERNAL double hp_now(void);
+HP_INTERNAL void hp_transport_phase(const communicator_type *recv_side, const communicator_type *send_side, int tag);
+HP_INTERNAL int hp_exchange_and_bcs_one_launch(level_type *L, int id, int shape, int order, int with_copies);
+HP_INTERNAL void hp_ghosts_for_stencil(level_type *L, int id, int out_id);
+HP_INTERNAL int hp_overlap_begin(level_type *L, int id);
+HP_INTERNAL void hp_overlap_end(void);
+HP_INTERNAL void hp_no_kernel(const char *what);
+HP_INTERNAL const hpgmg_hip_bc_entry *hp_bc_entries(level_type *L, int shape, int *n_out);
+HP_INTERNAL const hpgmg_hip_bc_entry *hp_bc_entries_k(level_type *L, int *n_out, int *all_local_out);
+HP_INTERNAL int hp_vcycle_legs_fused(level_type **levels, int n, int e_id, int R_id, double a, double b, int leg);
+HP_INTERNAL void hp_coef32_invalidate(level_type *L);
+HP_INTERNAL int hp_interp_smooth_fused(level_type *Lf, int e_id, int R_id, level_type *Lc, double a, double b, int exact_state);
+HP_INTERNAL void hp_do_smooth(level_type *L, int x_id, int rhs_id, double a, double b, int temp_dead);
+HP_INTERNAL void hp_do_residual(level_type *L, int res_id, int x_id, int rhs_id, double a, double b);
+HP_INTERNAL void hp_do_apply_op(level_type *L, int Ax_id, int x_id, double a, double b);
+HP_INTERNAL int hp_pair_halo_ready(level_type *L, backend_t *B);
+HP_INTERNAL int hp_pair_halo_begin(level_type *L, backend_t *B, int first, int x0_scr, int x0_id, int xm1_scr, int xm1_id, int rhs_id);
+HP_INTERNAL void hp_do_restriction(level_type *Lc, int id_c, level_type *Lf, int id_f, int type);
+HP_INTERNAL int hp_residual_restrict_zero_fused(level_type *Lc, int id_c, level_type *Lf, int res_id, int x_id, int rhs_id, double a, double b, int zero_id);
+HP_INTERNAL int hp_norm_scale_restrict_fused(level_type *L, int F_id, int R_id, level_type *Lc, double *norm_out);
+HP_INTERNAL void hp_do_interpolation_vcycle(level_type *Lf, int id_f, double prescale, level_type *Lc, int id_c);
+HP_INTERNAL void hp_do_zero_vector(level_type *L, int id);
+HP_INTERNAL void hp_do_add_vectors(level_type *L, int c, double sa, int a, double sb, int b);
+HP_INTERNAL void hp_do_mul_vectors(level_type *L, int c, double s, int a, int b);
+HP_INTERNAL void hp_do_scale_vector(level_type *L, int c, double s, int a);
+HP_INTERNAL double hp_allreduce_scalar(level_type *L, double v, int op);
+HP_INTERNAL double hp_do_dot(level_type *L, int a, int b);
+HP_INTERNAL double hp_do_norm(level_type *L, int a);
+HP_INTERNAL void hp_small_ops_forget(void);
+
+#define BLAS1(call) do { TICK(L, blas1, "BLAS1"); HIP_OK(call); TOCK(); } while (0)
+#define STENCIL_WITH_GHOSTS(L, id, out_id, TIMER, CALL) do {                                                     \
+    hp_backend_of(L)->img_active = 0;                                                                    \
+    if (hp_overlap_begin(L, id)) {                                                                          \
+      TICK(L, TIMER, #TIMER " (overlapped with the halo exchange)");                                     \
+      hpgmg_hip_set_defer_mode(1); HIP_OK(CALL);                                                         \
+      hp_overlap_end();                                                                                     \
+      hpgmg_hip_set_defer_mode(2); HIP_OK(CALL); hpgmg_hip_set_defer_mode(0);                            \
+      TOCK();                                                                                            \
+    } else {                                                                                             \
+      hp_ghosts_for_stencil(L, id, out_id);                                                                 \
+      TICK(L, TIMER, #TIMER);                                                                            \
+      HIP_OK(CALL);                                                                                      \
+      TOCK();                                                                                            \
+    } } while (0)
+#define PAIR_REMOTE_LAUNCH(OVERLAPPED, DISCARD_X1, CALL) do {                                                   \
+    pair_halo *H_ = B->halo;                                                                                   \
+    if (OVERLAPPED) {                                                                                          \
+      hpgmg_hip_pair_set_halo(H_->brick, H_->rem, H_->deep, H_->deep_beta); hpgmg_hip_set_tile_part(1);        \
+      if (DISCARD_X1) hpgmg_hip_pair_discard_x1();                                                             \
+      HIP_OK(CALL);                                                                                            \
+      hp_overlap_end();                                                                                           \
+      hpgmg_hip_pair_set_halo(H_->brick, H_->rem, H_->deep, H_->deep_beta); hpgmg_hip_set_tile_part(2);        \
+      if (DISCARD_X1) hpgmg_hip_pair_discard_x1();                                                             \
+      HIP_OK(CALL);                                                                                            \
+      hpgmg_hip_set_tile_part(0);                                                                              \
+    } else {                                                                                                   \
+      hpgmg_hip_pair_set_halo(H_->brick, H_->rem, H_->deep, H_->deep_beta);                                    \
+      if (DISCARD_X1) hpgmg_hip_pair_discard_x1();                                                             \
+      HIP_OK(CALL);                                                                                            \
+    } } while (0)
+
 #endif

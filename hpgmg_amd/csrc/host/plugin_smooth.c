@@ -1,0 +1,611 @@
+/*
+ * plugin_smooth.c -- smooth() (operators/chebyshev.c, gsrb.c, jacobi.c) in all its forms: single sweeps, sweep pairs, red + black passes, the single-launch legs of the small levels; residual() / apply_op().
+ * Part of the operator plugin (see operators_hip.c); no arithmetic on vector data happens here.
+ */
+#include "plugin_internal.h"
+
+/* ---------------------------------------------------------------- smoothers */
+static void cheby_coefficients(const level_type *L, int degree, double *c1, double *c2) { /* chebyshev.c:22-40 */
+  double beta = 1.000 * L->dominant_eigenvalue_of_DinvA, alpha = 0.125000 * beta;
+  double theta = 0.5 * (beta + alpha), delta = 0.5 * (beta - alpha), sigma = theta / delta, rho_n = 1 / sigma;
+  int s;
+  c1[0] = 0.0; c2[0] = 1 / theta;
+  for (s = 1; s < degree; s++) { double rho_nm1 = rho_n; rho_n = 1.0 / (2.0 * sigma - rho_nm1); c1[s] = rho_n * rho_nm1; c2[s] = rho_n * 2.0 / delta; }
+}
+
+/* Both legs of a V-cycle over a chain of tiny levels in one launch each (kernels/tail.hip). */
+/* fold the iteration counts of device-side bottom solves into level->Krylov_iterations (mg.c:156 prints it) */
+void hpgmg_level_sync_counters(level_type *L) {
+  hpgmg_hip_timer_flush();                       /* pending device timers land in level->timers before they are read or reset */
+  hpgmg_level_ext *X = hpgmg_level_ext_get(L);
+  backend_t *B = (backend_t *)X->backend;
+  if (!B || !B->krylov_pinned) return;
+  HIP_OK(hpgmg_hip_sync());
+  L->Krylov_iterations += *B->krylov_pinned;
+  *B->krylov_pinned = 0;
+}
+
+/* leg 0/1: the legs around a host-driven bottom solve; leg 2: legs + bottom solve; leg 3: bottom solve only (n == 1);
+ * leg 4: the whole F-cycle below levels[0] (right-hand side restricted down the chain, bottom solve, interpolation_fcycle + V-cycle per
+ * level upwards); leg 5: only answer whether leg 4 would be accepted */
+int hpgmg_vcycle_legs_fused(level_type **levels, int n, int e_id, int R_id, double a, double b, int leg) { hp_lazy_flush(); return hp_vcycle_legs_fused(levels, n, e_id, R_id, a, b, leg); }
+/* The same for the 27-point / fv2 / fv4 plugins, leg 2 only (smooth ... bottom solve ... smooth as one launch): every level of the chain is ONE
+ * box whose vectors fit the LDS (kernels/stencil.hip: small_vtail_kernel).  `7 8`: the levels of 8^3, 4^3, 2^3 (and 1^3) cells. */
+/* On by default except for the 27-point plugin with GSRB (HPGMG_SMALL_VTAIL=0 / 1, hpgmg_set_small_vtail(); bit-identical, tested both ways).
+ * Measured on MI355X, `7 8` F-cycles with it on / off: fv4 GSRB 7.72 / 7.77 ms, fv4 Chebyshev 8.13 / 8.23, fv2 GSRB 6.35 / 6.56, fv2 Chebyshev
+ * 6.65 / 6.91, 27-point Chebyshev 4.72 / 4.84 -- and 27-point GSRB 4.04 / 3.94: that plugin's one-launch red + black box kernel beats two half
+ * sweeps of the generic form.  The first version (1024 lanes) was slower everywhere: the bottom solve's 240 registers per lane spilled into
+ * scratch memory under the 128-register cap; with 512 lanes the launch of 8^3 + 4^3 + 2^3 levels takes 169 instead of 191 us (fv4 GSRB;
+ * tools/exp_vtail_timeline.py): 4 x 24 us of smoothing, 28 us of bottom solve, the rest image traffic and interpolation. */
+static long long small_vtails = 0;
+long long hpgmg_small_vtails(void) { return small_vtails; }
+void hpgmg_set_small_vtail(int on) { hp_switch_set(SW_SMALL_VTAIL, (on == 2) ? 2 : (on ? 1 : 0)); }      /* 0 off, 1 on for every plugin, 2 the default (not for 27-point GSRB) */
+static int small_vtail_fused(level_type **levels, int n, int e_id, int R_id, double a, double b, int legs) {
+  hpgmg_config cfg;
+  hpgmg_hip_small_tail_args T;
+  int l;
+  const int small_vtail_on = (int)hp_switch(SW_SMALL_VTAIL);      /* 2: the default */
+  if (!small_vtail_on) return 0;
+  hpgmg_get_config(&cfg);
+  if (small_vtail_on == 2 && cfg.op == HPGMG_OP_27PT && cfg.smoother == HPGMG_SMOOTH_GSRB) return 0;
+  const int sweeps = hpgmg_smooth_sweeps();
+  if (n < 2 || n > HPGMG_HIP_SMALL_TAIL_MAX_LEVELS || sweeps < 1 || sweeps > 8 || (sweeps & 1) || hp_switch(SW_GRAPH)) return 0;      /* (captured segments: the argument block's upload is not capturable) */
+  if (cfg.smoother != HPGMG_SMOOTH_CHEBY && cfg.smoother != HPGMG_SMOOTH_GSRB && cfg.smoother != HPGMG_SMOOTH_JACOBI) return 0;
+  memset(&T, 0, sizeof T);
+  T.n = n; T.legs = legs; T.mode = (cfg.smoother == HPGMG_SMOOTH_CHEBY) ? 0 : (cfg.smoother == HPGMG_SMOOTH_GSRB ? 1 : 2);
+  T.sweeps = sweeps; T.out_of_place = (T.mode == 1) ? hpgmg_gsrb_out_of_place() : 0;
+  T.e_id = e_id; T.R_id = R_id; T.krylov_base = hpgmg_vectors_reserved(); T.a = a; T.b = b; T.want = MG_DEFAULT_BOTTOM_NORM;
+  const int shape = stencil_get_shape();
+  for (l = 0; l < n; l++) {
+    level_type *L = levels[l];
+    if (!L->active || L->num_my_boxes != 1 || L->boxes_in.i * L->boxes_in.j * L->boxes_in.k != 1) return 0;
+    if (L->boundary_condition.type != BC_DIRICHLET || L->dim.i != L->dim.j || L->dim.i != L->dim.k) return 0;
+    if (l > 0 && 2 * L->dim.i != levels[l - 1]->dim.i) return 0;
+    {
+      communicator_type *C = &L->exchange_ghosts[shape], *CB = &L->exchange_ghosts[STENCIL_SHAPE_BOX];
+      if (C->num_sends + C->num_recvs > 0 || C->num_blocks[0] || C->num_blocks[1] || C->num_blocks[2]) return 0;      /* one box: nothing to exchange */
+      if (CB->num_sends + CB->num_recvs > 0 || CB->num_blocks[0] || CB->num_blocks[1] || CB->num_blocks[2]) return 0;
+    }
+    backend_t *B = hp_backend_of(L);
+    hpgmg_hip_small_tail_level *v = &T.lv[l];
+    v->L = B->dev;
+    v->h2inv = 1.0 / (L->h * L->h);
+    v->n_bc = L->boundary_condition.num_blocks[shape];
+    v->bc_list = v->n_bc ? hp_mirror(L, L->boundary_condition.blocks[shape], v->n_bc) : NULL;
+    if (cfg.op == HPGMG_OP_27PT) v->bc_kind = (L->box_dim < 2) ? 1 : 2;                                   /* as small_level_try / apply_BCs */
+    else if (cfg.op == HPGMG_OP_FV2 || L->box_dim < 4) { v->bc_kind = (L->box_dim < 2) ? 1 : 3; v->zero_first = (v->bc_kind == 3 && L->box_ghosts > 1); }
+    else { v->bc_kind = 4; v->zero_first = (L->box_ghosts > 2); }
+    /* the conditions interpolation_vcycle applies to THIS level's correction before the level above reads it: apply_BCs_p2 (27-point) /
+     * apply_BCs_v2 (fv2, fv4) over STENCIL_SHAPE_BOX */
+    v->n_ibc = L->boundary_condition.num_blocks[STENCIL_SHAPE_BOX];
+    v->ibc_list = v->n_ibc ? hp_mirror(L, L->boundary_condition.blocks[STENCIL_SHAPE_BOX], v->n_ibc) : NULL;
+    if (cfg.op == HPGMG_OP_27PT) v->ibc_kind = (L->box_dim < 2) ? 1 : 2;
+    else { v->ibc_kind = (L->box_dim < 2) ? 1 : 3; v->ibc_zero_first = (v->ibc_kind == 3 && L->box_ghosts > 1); }
+    if (v->n_bc > 32 || v->n_ibc > 32) return 0;
+    if (l + 1 < n) {
+      if (T.mode == 0) { if (L->dominant_eigenvalue_of_DinvA <= 0.0) return 0; cheby_coefficients(L, sweeps, v->c1, v->c2); }
+      if (T.mode == 2) { int q; for (q = 0; q < sweeps; q++) v->c2[q] = 2.0 / 3.0; }
+    } else if (legs & 2) {
+      /* solvers.c:77-87: the fused solve is the Dirichlet one (no mean to remove); the Krylov vectors must exist */
+      if (L->must_subtract_mean != 0) return 0;
+      if ((long long)L->dim.i * L->dim.j * L->dim.k > hpgmg_hip_bottom_bicgstab_max_cells()) return 0;
+      if (L->numVectors < hpgmg_vectors_reserved() + IterativeSolver_NumVectors()) return 0;
+      if (!B->krylov_pinned) { B->krylov_pinned = (int *)hpgmg_hip_host_malloc(64); if (B->krylov_pinned) *B->krylov_pinned = 0; }
+      if (!B->krylov_pinned) return 0;
+      T.krylov_iterations = B->krylov_pinned;
+    }
+  }
+  if (hpgmg_hip_small_vtail_lds_doubles(&T) > hpgmg_hip_small_vtail_lds_limit()) return 0;
+  TICK(levels[0], smooth, "fused V-cycle tail (levels of one box)");
+  HIP_OK(hpgmg_hip_small_vtail(&T, hp_variant()));
+  TOCK();
+  small_vtails++;
+  return 1;
+}
+void hpgmg_set_fused_tail(int on) { hp_switch_set(SW_FUSED_TAIL, on ? 1 : 0); }      /* tests: 0 = every operator of the small levels as its own launch(es) */
+void hpgmg_set_fused_bottom(int on) { hp_switch_set(SW_FUSED_BOTTOM, on ? 1 : 0); }  /* tests: 0 = the bottom solve driven from the host (host/solvers.c BiCGStab through the operators) */
+int hp_vcycle_legs_fused(level_type **levels, int n, int e_id, int R_id, double a, double b, int leg) {
+  hpgmg_config cfg;
+  const hpgmg_hip_level *dev[8];
+  int l, s;
+  double h2inv[8], c1[64], c2[64];
+  const int enabled = (int)hp_switch(SW_FUSED_TAIL), bottom_enabled = (int)hp_switch(SW_FUSED_BOTTOM);
+  hpgmg_get_config(&cfg);
+  const int sweeps = hpgmg_smooth_sweeps();
+  const int with_bottom = (leg >= 2);
+  if (enabled && cfg.op != HPGMG_OP_7PT) {      /* leg 0 / 1: the way down / up around a bottom solve somebody else runs (the reference's driver, through the queue below) */
+    if (leg == 2) return bottom_enabled ? small_vtail_fused(levels, n, e_id, R_id, a, b, 7) : 0;
+    if (leg == 0 || leg == 1) return small_vtail_fused(levels, n, e_id, R_id, a, b, leg == 0 ? 1 : 4);
+    return 0;
+  }
+  if (!enabled || !hp_ghost_free_mode() || cfg.op != HPGMG_OP_7PT || n > 8 || n > hpgmg_hip_tail_max_levels() || sweeps > 8) return 0;
+  if (with_bottom && !bottom_enabled) return 0;
+  if (n < (leg == 3 ? 1 : 2)) return 0;
+  if (leg >= 4 && !hp_switch(SW_FUSED_FTAIL)) return 0;
+  /* multi-rank jobs: the chain qualifies when this rank owns every box of every level in it (checked below), which is
+   * how the coarse levels end up after agglomeration onto rank 0 -- no message and no all-reduce is needed then */
+  for (l = 0; l < n; l++) {
+    level_type *L = levels[l];
+    backend_t *B = hp_backend_of(L);
+    const long long cells = (long long)L->dim.i * L->dim.j * L->dim.k;
+    if (!L->active || L->num_my_boxes < 1 || !B->all_faces_local) return 0;
+    /* the kernel addresses cells by global coordinate: cubic Dirichlet domain, boxes in lexicographic order, halving per level */
+    if (L->boundary_condition.type != BC_DIRICHLET || L->dim.i != L->dim.j || L->dim.i != L->dim.k || (sweeps & 1)) return 0;
+    if (l > 0 && 2 * L->dim.i != levels[l - 1]->dim.i) return 0;
+    {
+      const int nb = L->dim.i / L->box_dim;
+      int bx;
+      if (L->num_my_boxes != nb * nb * nb) return 0;
+      for (bx = 0; bx < L->num_my_boxes; bx++) {
+        const box_type *X = &L->my_boxes[bx];
+        if (X->low.i != (bx % nb) * L->box_dim || X->low.j != ((bx / nb) % nb) * L->box_dim || X->low.k != (bx / (nb * nb)) * L->box_dim) return 0;
+      }
+    }
+    if (l + 1 < n) {
+      if (cells > hpgmg_hip_tail_max_cells()) return 0;
+      if (L->dominant_eigenvalue_of_DinvA <= 0.0 && cfg.smoother == HPGMG_SMOOTH_CHEBY) return 0;
+      cheby_coefficients(L, sweeps, c1 + l * sweeps, c2 + l * sweeps);
+    } else {
+      for (s = 0; s < sweeps; s++) c1[l * sweeps + s] = c2[l * sweeps + s] = 0.0;
+      if (with_bottom) {
+        /* solvers.c:27-95: Dirichlet never subtracts the mean; the Krylov vectors must exist */
+        if (cells > hpgmg_hip_tail_bottom_max_cells() || L->must_subtract_mean == 1) return 0;
+        if (L->numVectors < hpgmg_vectors_reserved() + IterativeSolver_NumVectors()) return 0;
+        L->must_subtract_mean = 0;
+        if (!B->krylov_pinned) B->krylov_pinned = (int *)hpgmg_hip_host_malloc(64);
+        if (!B->krylov_pinned) return 0;
+      }
+    }
+    dev[l] = &B->dev;
+    h2inv[l] = 1.0 / (L->h * L->h);
+  }
+  if (leg == 5) return 1;
+  TICK(levels[0], smooth, leg == 3 ? "bottom solve (device BiCGStab)" : (leg == 4 ? "fused F-cycle tail" : "fused V-cycle tail"));
+  HIP_OK(hpgmg_hip_vcycle_tail(n, dev, h2inv, c1, c2, sweeps, hp_variant(), cfg.smoother, e_id, R_id, a, b, leg,
+                               hpgmg_vectors_reserved(), MG_DEFAULT_BOTTOM_NORM, with_bottom ? hp_backend_of(levels[n - 1])->krylov_pinned : NULL));
+  TOCK();
+  return 1;
+}
+
+/* every box of the level is local and local box b sits at lexicographic position b (what the kernels that address
+ * cells by global coordinate assume) */
+static int boxes_lexicographic(level_type *L) {
+  backend_t *B = hp_backend_of(L);
+  if (B->lexicographic < 0) {
+    int bx, ok = (L->num_my_boxes == L->boxes_in.i * L->boxes_in.j * L->boxes_in.k);
+    for (bx = 0; ok && bx < L->num_my_boxes; bx++) {
+      const box_type *X = &L->my_boxes[bx];
+      if (X->low.i != (bx % L->boxes_in.i) * L->box_dim || X->low.j != ((bx / L->boxes_in.i) % L->boxes_in.j) * L->box_dim ||
+          X->low.k != (bx / (L->boxes_in.i * L->boxes_in.j)) * L->box_dim) ok = 0;
+    }
+    B->lexicographic = ok;
+  }
+  return B->lexicographic;
+}
+
+/* BASELINE config 5: mixed-precision Chebyshev smoother.  32 = the fused sweep pairs read fp32 copies of the five
+ * coefficient vectors (the iterate, the right-hand side and all arithmetic stay fp64; residual, restriction,
+ * interpolation and every level the pair kernel does not cover are unchanged).  64 (default) = bit-exact fp64. */
+void hpgmg_set_smoother_precision(int bits) { hp_switch_set(SW_SMOOTHER_PRECISION, (bits == 32) ? 32 : 64); }
+int hpgmg_get_smoother_precision(void) {
+  return hp_switch(SW_SMOOTHER_PRECISION) == 32 ? 32 : 64;
+}
+static const float *const *coef32_of(level_type *L) {
+  backend_t *B = hp_backend_of(L);
+  if (hpgmg_get_smoother_precision() != 32) return NULL;
+  if (!B->coef32) {
+    int bx;
+    float **base = (float **)calloc((size_t)L->num_my_boxes, sizeof(float *));
+    B->coef32 = (float *)hpgmg_hip_malloc(((size_t)L->num_my_boxes * 5 * (size_t)L->box_volume + 4) * sizeof(float));
+    B->d_coef32_base = (float **)hpgmg_hip_malloc((size_t)L->num_my_boxes * sizeof(float *));
+    if (!B->coef32 || !B->d_coef32_base) { fprintf(stderr, "hpgmg: no memory for the fp32 coefficient copies\n"); abort(); }
+    /* pairs (2 floats) must be 8-byte aligned where the fp64 pairs are 16-byte aligned: same parity of the first interior cell */
+    const size_t pad = ((uintptr_t)L->my_boxes[0].vectors[0] % 16) / sizeof(double);
+    for (bx = 0; bx < L->num_my_boxes; bx++) base[bx] = B->coef32 + pad + (size_t)bx * 5 * (size_t)L->box_volume;
+    HIP_OK(hpgmg_hip_memcpy_h2d(B->d_coef32_base, base, (size_t)L->num_my_boxes * sizeof(float *)));
+    free(base);
+    B->coef32_valid = 0;
+  }
+  if (!B->coef32_valid) { HIP_OK(hpgmg_hip_coef32_refresh(&B->dev, (float *const *)B->d_coef32_base, L->numVectors)); B->coef32_valid = 1; }
+  return (const float *const *)B->d_coef32_base;
+}
+void hp_coef32_invalidate(level_type *L) { backend_t *B = hp_backend_of(L); B->coef32_valid = 0; if (B->halo) B->halo->coef_valid = 0; hp_images_invalidate_coefficients(B); hpgmg_hip_pair_packed_invalidate(&B->dev); }
+
+static long long pair_remote_smooths = 0;
+long long hpgmg_pair_remote_smooths(void) { return pair_remote_smooths; }   /* smooth() calls done as sweep pairs with remote faces (tests) */
+
+/* the two plugin-private vectors per box that hold x1, x2 of the first sweep pair of a smooth() */
+void hp_ensure_pair_scratch(level_type *L, backend_t *B) {
+  if (!B->pair_scratch) {
+    int bx;
+    double **base = (double **)calloc((size_t)L->num_my_boxes, sizeof(double *));
+    B->pair_scratch = (double *)hpgmg_hip_malloc(((size_t)L->num_my_boxes * 2 * (size_t)L->box_volume + 2) * sizeof(double));
+    B->d_pair_base = (double **)hpgmg_hip_malloc((size_t)L->num_my_boxes * sizeof(double *));
+    if (!B->pair_scratch || !B->d_pair_base) { fprintf(stderr, "hpgmg: no memory for the sweep-pair scratch vectors\n"); abort(); }
+    /* the vector bases share the level's alignment class so the first interior cell is 16-byte aligned here too */
+    const size_t pad = ((uintptr_t)L->my_boxes[0].vectors[0] % 16) / sizeof(double);
+    for (bx = 0; bx < L->num_my_boxes; bx++) base[bx] = B->pair_scratch + pad + (size_t)bx * 2 * (size_t)L->box_volume;
+    HIP_OK(hpgmg_hip_memcpy_h2d(B->d_pair_base, base, (size_t)L->num_my_boxes * sizeof(double *)));
+    free(base);
+  }
+}
+void hpgmg_set_fused_sweeps(int on) { hp_switch_set(SW_FUSED_SWEEPS, on ? 1 : 0); }
+/* common part: does the level qualify for the sweep-pair kernel, and are its two private vectors there? */
+static int pair_kernel_ready(level_type *L, int x_id, int rhs_id, int sweeps) {
+  hpgmg_config cfg;
+  hpgmg_get_config(&cfg);
+  backend_t *B = hp_backend_of(L);
+  if (!hp_switch(SW_FUSED_SWEEPS) || sweeps != 4 || cfg.op != HPGMG_OP_7PT || !hp_ghost_free_mode() || stencil_get_shape() != STENCIL_SHAPE_STAR) return 0;
+  if (L->boundary_condition.type != BC_DIRICHLET || x_id == VECTOR_TEMP || rhs_id == VECTOR_TEMP) return 0;
+  if (B->all_faces_local) { if (!hpgmg_hip_smooth_cheby_pair_supported(&B->dev, hp_variant()) || !boxes_lexicographic(L)) return 0; }
+  else if (!hp_pair_halo_ready(L, B)) return 0;          /* faces owned by other ranks: two-deep halo, one exchange per pair */
+  { /* the pass structure pays when the level is bandwidth bound; a cache-resident level (128^3 and smaller) is latency
+     * bound and faster with many small single-sweep workgroups (measured: 128^3 pair 80 us vs 2 x 27 us) */
+    if ((long long)L->dim.i * L->dim.j * L->dim.k < hp_switch(SW_PAIR_MIN_CELLS)) return 0;
+  }
+  hp_ensure_pair_scratch(L, B);
+  hpgmg_hip_set_ghost_free(1);
+  return 1;
+}
+
+
+/* Chebyshev smooth() as fused sweep pairs (kernels/cheby_pair.hpp): 4 sweeps = 2 passes of 10 streams instead of
+ * 4 x 9.  x1,x2 of the first pair go to two plugin-private vectors, the second pair brings x3 -> VECTOR_TEMP and
+ * x4 -> x_id, i.e. exactly the state chebyshev.c:43-99 leaves.  Returns 0 when the level does not qualify. */
+/* smooth() called by the cycle driver through hpgmg_smooth_in_cycle(): VECTOR_TEMP (x3 of the four sweeps) is dead after it, so the second
+ * pair does not store it */
+static int smooth_cheby_pairs(level_type *L, int x_id, int rhs_id, double a, double b, const double *c1, const double *c2, int sweeps, int temp_dead) {
+  if (!pair_kernel_ready(L, x_id, rhs_id, sweeps)) return 0;
+  backend_t *B = hp_backend_of(L);
+  const double h2inv = 1.0 / (L->h * L->h);
+  const int v = hp_variant();
+  const int remote = !B->all_faces_local;
+  const float *const *c32 = remote ? NULL : coef32_of(L);      /* across ranks the coefficient streams stay fp64 */
+  int over = 0;
+  if (remote) { pair_remote_smooths++; over = hp_pair_halo_begin(L, B, 1, 0, x_id, 0, VECTOR_TEMP, rhs_id); }
+  { TICK(L, smooth, "smooth (Chebyshev sweeps 1+2)");
+    if (remote) PAIR_REMOTE_LAUNCH(over, 0, hpgmg_hip_smooth_cheby_pair(&B->dev, v, (double *const *)B->d_pair_base, c32, 0, x_id, 0, VECTOR_TEMP, 1, 0, 1, 1, rhs_id, a, b, h2inv, c1[0], c2[0], c1[1], c2[1]));
+    else HIP_OK(hpgmg_hip_smooth_cheby_pair(&B->dev, v, (double *const *)B->d_pair_base, c32, 0, x_id, 0, VECTOR_TEMP, 1, 0, 1, 1, rhs_id, a, b, h2inv, c1[0], c2[0], c1[1], c2[1]));
+    TOCK(); }
+  if (remote) over = hp_pair_halo_begin(L, B, 0, 1, 1, 1, 0, rhs_id);
+  { TICK(L, smooth, "smooth (Chebyshev sweeps 3+4)");
+    if (remote) PAIR_REMOTE_LAUNCH(over, temp_dead, hpgmg_hip_smooth_cheby_pair(&B->dev, v, (double *const *)B->d_pair_base, c32, 1, 1, 1, 0, 0, VECTOR_TEMP, 0, x_id, rhs_id, a, b, h2inv, c1[2], c2[2], c1[3], c2[3]));
+    else {
+      if (temp_dead) hpgmg_hip_pair_discard_x1();
+      HIP_OK(hpgmg_hip_smooth_cheby_pair(&B->dev, v, (double *const *)B->d_pair_base, c32, 1, 1, 1, 0, 0, VECTOR_TEMP, 0, x_id, rhs_id, a, b, h2inv, c1[2], c2[2], c1[3], c2[3]));
+    }
+    TOCK(); }
+  return 1;
+}
+/* in-place GSRB smooth() (gsrb.c:24-132, 4 coloured half sweeps) as two passes of two half sweeps each:
+ * x_id -> private vector -> x_id; VECTOR_TEMP is not touched, as in the reference's in-place form */
+static int smooth_gsrb_pairs(level_type *L, int x_id, int rhs_id, double a, double b, int sweeps) {
+  if (hpgmg_gsrb_out_of_place() || !pair_kernel_ready(L, x_id, rhs_id, sweeps)) return 0;
+  backend_t *B = hp_backend_of(L);
+  const double h2inv = 1.0 / (L->h * L->h);
+  const int v = hp_variant();
+  const int remote = !B->all_faces_local;
+  int over = 0;
+  if (remote) { pair_remote_smooths++; over = hp_pair_halo_begin(L, B, 1, 0, x_id, 0, x_id, rhs_id); }
+  { TICK(L, smooth, "smooth (GSRB half sweeps 1+2)");
+    if (remote) PAIR_REMOTE_LAUNCH(over, 0, hpgmg_hip_smooth_gsrb_pair(&B->dev, v, (double *const *)B->d_pair_base, NULL, 0, x_id, 0, 1, 1, rhs_id, a, b, h2inv, 0));
+    else HIP_OK(hpgmg_hip_smooth_gsrb_pair(&B->dev, v, (double *const *)B->d_pair_base, NULL, 0, x_id, 0, 1, 1, rhs_id, a, b, h2inv, 0));
+    TOCK(); }
+  if (remote) over = hp_pair_halo_begin(L, B, 0, 1, 1, 1, 1, rhs_id);
+  { TICK(L, smooth, "smooth (GSRB half sweeps 3+4)");
+    if (remote) PAIR_REMOTE_LAUNCH(over, 0, hpgmg_hip_smooth_gsrb_pair(&B->dev, v, (double *const *)B->d_pair_base, NULL, 1, 1, 0, 0, x_id, rhs_id, a, b, h2inv, 2));
+    else HIP_OK(hpgmg_hip_smooth_gsrb_pair(&B->dev, v, (double *const *)B->d_pair_base, NULL, 1, 1, 0, 0, x_id, rhs_id, a, b, h2inv, 2));
+    TOCK(); }
+  return 1;
+}
+
+/* interpolation_vcycle(Lf, e, 1.0, Lc, e) followed by smooth(Lf, e, R) -- the up-leg of MGVCycle (mg.c:1160-1161) -- with the
+ * piecewise-constant interpolation folded into the first sweep pair: the interpolated e is never written or re-read.
+ * Same iterate (e = x4) as the two separate operators; VECTOR_TEMP (their x3) is left unspecified -- nothing in a cycle reads it
+ * (HPGMG_TEMP_SCRATCH=0 stores it as smooth() does).  0 = not applicable. */
+int hpgmg_interp_smooth_fused(level_type *Lf, int e_id, int R_id, level_type *Lc, double a, double b) { hp_lazy_flush(); return hp_interp_smooth_fused(Lf, e_id, R_id, Lc, a, b, 0); }
+/* exact_state: VECTOR_TEMP is left as smooth() leaves it (the lazy queue runs behind the reference's own driver, which promises nothing about it) */
+int hp_interp_smooth_fused(level_type *Lf, int e_id, int R_id, level_type *Lc, double a, double b, int exact_state) {
+  hpgmg_config cfg;
+  hpgmg_get_config(&cfg);
+  const int sweeps = hpgmg_smooth_sweeps();
+  communicator_type *S = &Lc->interpolation, *Rv = &Lf->interpolation;
+  if (cfg.op != HPGMG_OP_7PT || !Lf->active || !Lc->active) return 0;
+  if (cfg.smoother != HPGMG_SMOOTH_CHEBY && !(cfg.smoother == HPGMG_SMOOTH_GSRB && !hpgmg_gsrb_out_of_place())) return 0;
+  if (S->num_sends || S->num_recvs || Rv->num_sends || Rv->num_recvs || S->num_blocks[0] || Rv->num_blocks[2]) return 0;   /* all parents local */
+  if (Lf->box_dim % 128 != 0 || Lc->box_dim * 2 != Lf->box_dim || Lc->num_my_boxes != Lf->num_my_boxes || !boxes_lexicographic(Lc)) return 0;
+  if (!hp_backend_of(Lf)->all_faces_local) return 0;       /* across ranks the pair kernel takes x0 as stored (interpolation stays its own launch) */
+  if (!pair_kernel_ready(Lf, e_id, R_id, sweeps)) return 0;
+  if (cfg.smoother == HPGMG_SMOOTH_CHEBY && Lf->dominant_eigenvalue_of_DinvA <= 0.0) return 0;
+  hpgmg_hip_pair_fold_interpolation(&hp_backend_of(Lc)->dev, e_id, 1.0);
+  if (cfg.smoother == HPGMG_SMOOTH_CHEBY) {
+    double c1[16], c2[16];
+    cheby_coefficients(Lf, sweeps, c1, c2);
+    const int done = smooth_cheby_pairs(Lf, e_id, R_id, a, b, c1, c2, sweeps, !exact_state && hp_switch(SW_TEMP_SCRATCH));      /* the cycle hook: VECTOR_TEMP is dead afterwards */
+    if (!done) { fprintf(stderr, "hpgmg: fused interpolation+smooth refused after being accepted\n"); abort(); }
+  } else if (!smooth_gsrb_pairs(Lf, e_id, R_id, a, b, sweeps)) { fprintf(stderr, "hpgmg: fused interpolation+smooth refused after being accepted\n"); abort(); }
+  return 1;
+}
+
+/* Small levels of the 27-point / fv2 / fv4 plugins: smooth(), residual() or apply_op() with their exchange_boundary + apply_BCs steps as
+ * ONE single-workgroup launch (kernels/stencil.hip: small_level_kernel).  mode: 0 Chebyshev, 1 GSRB, 2 Jacobi, 3 residual, 4 apply_op.
+ * Returns 0 when the level does not qualify (too large, messages needed, 7-point plugin: that one has the LDS-resident tail kernel).
+ * OFF by default (HPGMG_SMALL_FUSED=1 enables; bit-identical, covered by the GPU tests): measured on MI355X it is SLOWER than the
+ * launches it replaces -- fv4 GSRB `7 8` 17.1 vs 12.7 ms, 27-pt GSRB 9.9 vs 6.2 ms per F-cycle -- because a 16^3 level in 8 boxes has
+ * ~160 copy / boundary list entries whose dependent load chains run 16 at a time on one CU, while separate launches spread them over
+ * the chip; the launch overhead saved (~5 us each) is smaller than that serialisation. */
+void hpgmg_set_small_fused(int mode) { hp_switch_set(SW_SMALL_FUSED, (mode == 1 || mode == 2) ? 2 : 0); }   /* 0 off, 1 every small level, 2 (default) one-box levels in LDS */
+static int small_level_try(level_type *L, int mode, int x_id, int rhs_id, int res_id, double a, double b) {
+  hpgmg_config cfg;
+  const int small_fused = hp_switch(SW_SMALL_FUSED) ? 2 : 0;      /* (mode 1, every small level out of global memory, measured slower in two rounds: removed) */
+  /* 0: off.  1 (experiment builds): every qualifying level, out of global memory (slower than the launches it replaces, see above).  2
+   * (default): smooth() on levels of ONE box whose vectors fit the LDS -- the kernel then works on an image of the box there (round 3).  With
+   * generic (FLAT) accesses to the image a smooth() was one ~60 us launch instead of twelve ~5 us ones: no gain.  With LDS-typed pointers, the
+   * boundary descriptors built without scratch memory and the corner / edge extrapolations of apply_BCs_v4 spread over the lanes of a wave it
+   * is 27 us (fv4, 8^3): `7 8` fv4 9.45 -> 9.2 ms, fv2 7.05 -> 6.45 ms per F-cycle.  Bit-identical, tested in all three modes. */
+  hpgmg_get_config(&cfg);
+  /* mode 2 takes what it shortens: a smooth() of many launches (fv4 GSRB: 12, Chebyshev: 8; a residual or apply_op is two launches of ~5 us,
+   * the kernel with its copies in and out ~15 us; the 27-point GSRB smoother already runs as two one-workgroup-per-box launches) */
+  const int small_27 = (int)hp_switch(SW_SMALL_27PT_GSRB);
+  const int worth = (mode <= 2) && (small_27 || !(cfg.op == HPGMG_OP_27PT && cfg.smoother == HPGMG_SMOOTH_GSRB));
+  const int enabled = (small_fused == 2 && worth && L->num_my_boxes == 1 && (size_t)9 * (size_t)L->box_volume * sizeof(double) <= (size_t)150 * 1024);
+  if (!enabled || cfg.op == HPGMG_OP_7PT || L->num_my_boxes < 1) return 0;
+  if ((long long)L->dim.i * L->dim.j * L->dim.k > hpgmg_hip_small_level_max_cells()) return 0;
+  if (L->num_my_boxes != L->boxes_in.i * L->boxes_in.j * L->boxes_in.k) return 0;
+  const int shape = stencil_get_shape();
+  communicator_type *C = &L->exchange_ghosts[shape];
+  if (C->num_sends + C->num_recvs > 0 || C->num_blocks[0] || C->num_blocks[2]) return 0;
+  int bc_kind = 0, zero_first = 0, n_bc = 0;
+  if (L->boundary_condition.type != BC_PERIODIC) {
+    n_bc = L->boundary_condition.num_blocks[shape];
+    if (cfg.op == HPGMG_OP_27PT) bc_kind = (L->box_dim < 2) ? 1 : 2;                                    /* apply_BCs_p2, boundary_fd.c:93-205 */
+    else if (cfg.op == HPGMG_OP_FV2 || L->box_dim < 4) { bc_kind = (L->box_dim < 2) ? 1 : 3; zero_first = (bc_kind == 3 && L->box_ghosts > 1); }   /* apply_BCs_v2 (v4 falls back to it below 4^3) */
+    else { bc_kind = 4; zero_first = (L->box_ghosts > 2); }                                            /* apply_BCs_v4 */
+  }
+  const int sweeps = (mode <= 2) ? hpgmg_smooth_sweeps() : 1;
+  double c1[16], c2[16];
+  int q;
+  for (q = 0; q < 16; q++) c1[q] = c2[q] = 0.0;
+  if (mode == 0) cheby_coefficients(L, sweeps, c1, c2);
+  if (mode == 2) for (q = 0; q < sweeps; q++) c2[q] = 2.0 / 3.0;
+  if (sweeps > 8) return 0;
+  backend_t *B = hp_backend_of(L);
+  const double t_h2inv = 1.0 / (L->h * L->h);
+  hpgmg_tick tk = hpgmg_tick_begin(L, mode <= 2 ? &L->timers.smooth : (mode == 3 ? &L->timers.residual : &L->timers.apply_op), "small level, one launch");
+  HIP_OK(hpgmg_hip_small_level_op(&B->dev, hp_variant(), mode, sweeps, x_id, rhs_id, res_id, mode == 1 ? hpgmg_gsrb_out_of_place() : 0, a, b, t_h2inv, c1, c2,
+                                  hp_mirror(L, C->blocks[1], C->num_blocks[1]), C->num_blocks[1],
+                                  n_bc ? hp_mirror(L, L->boundary_condition.blocks[shape], n_bc) : NULL, n_bc, bc_kind, zero_first));
+  hpgmg_tick_end(tk);
+  return 1;
+}
+
+/* IterativeSolver's BiCGStab on a bottom level of one small box of the 27-point / fv2 / fv4 plugins as ONE launch (kernels/stencil.hip:
+ * bottom_bicgstab_kernel; the 7-point plugin's bottom solve lives in its tail kernel).  Driven from the host, an iteration is ~25 launches and
+ * ~6 host round trips on a level of 8 cells.  HPGMG_FUSED_BOTTOM=0 keeps the host-driven solver. */
+int hpgmg_bottom_solve_fused(level_type *L, int e_id, int R_id, double a, double b, double want) {
+  hpgmg_config cfg;
+  const int on = (int)hp_switch(SW_FUSED_BOTTOM);
+  hpgmg_get_config(&cfg);
+  if (!on || cfg.op == HPGMG_OP_7PT || !L->active || L->num_my_boxes != 1 || L->boxes_in.i * L->boxes_in.j * L->boxes_in.k != 1) return 0;
+  if (L->boundary_condition.type == BC_PERIODIC || L->must_subtract_mean == 1) return 0;
+  if ((long long)L->dim.i * L->dim.j * L->dim.k > hpgmg_hip_bottom_bicgstab_max_cells()) return 0;
+  const int shape = stencil_get_shape();
+  communicator_type *C = &L->exchange_ghosts[shape];
+  if (C->num_sends + C->num_recvs > 0 || C->num_blocks[0] || C->num_blocks[1] || C->num_blocks[2]) return 0;      /* one box: nothing to exchange */
+  int bc_kind, zero_first = 0;
+  const int n_bc = L->boundary_condition.num_blocks[shape];
+  if (cfg.op == HPGMG_OP_27PT) bc_kind = (L->box_dim < 2) ? 1 : 2;                                    /* as small_level_try / apply_BCs */
+  else if (cfg.op == HPGMG_OP_FV2 || L->box_dim < 4) { bc_kind = (L->box_dim < 2) ? 1 : 3; zero_first = (bc_kind == 3 && L->box_ghosts > 1); }
+  else { bc_kind = 4; zero_first = (L->box_ghosts > 2); }
+  hp_lazy_flush();
+  backend_t *B = hp_backend_of(L);
+  if (!B->krylov_pinned) { B->krylov_pinned = (int *)hpgmg_hip_host_malloc(64); if (B->krylov_pinned) *B->krylov_pinned = 0; }
+  if (!B->krylov_pinned) return 0;
+  /* no tick of its own: the caller (MGVCycle -> IterativeSolver) already charges the bottom solve to L->timers.Total */
+  HIP_OK(hpgmg_hip_bottom_bicgstab(&B->dev, hp_variant(), e_id, R_id, hpgmg_vectors_reserved(), a, b, 1.0 / (L->h * L->h), want,
+                                   n_bc ? hp_mirror(L, L->boundary_condition.blocks[shape], n_bc) : NULL, n_bc, bc_kind, zero_first, B->krylov_pinned));
+  return 1;
+}
+
+/* smooth() as the cycle driver uses it (mg.c:1148,1161): same iterate, but VECTOR_TEMP is left unspecified -- the next operator of a
+ * cycle overwrites or ignores it.  Always returns 1 (the hook exists so that the reference's own driver, which never calls it, keeps
+ * the exact state of smooth()). */
+int hpgmg_smooth_in_cycle(level_type *L, int x_id, int rhs_id, double a, double b) {
+  hp_lazy_flush();
+  hp_do_smooth(L, x_id, rhs_id, a, b, (int)hp_switch(SW_TEMP_SCRATCH));
+  return 1;
+}
+/* 4th-order operator, GSRB, inside a cycle (VECTOR_TEMP is scratch afterwards): each red + black pair of half sweeps as ONE pass
+ * (kernels/fv4_rb.hpp) instead of gsrb.c:24-132's two.  The passes go x -> TEMP -> private vector 0 -> x (an odd number of passes cannot
+ * ping-pong between two vectors); private vector 1 lends its k ghost planes to the intermediate vector's boundary values (the pre-pass).
+ * 0 = not applicable, the caller runs the half sweeps one by one. */
+static long long fv4_rb_smooths = 0, rb27_smooth_passes = 0;
+long long hpgmg_rb27_passes(void) { return rb27_smooth_passes; }      /* red + black passes of the 27-point GSRB smoother so far (tests) */
+long long hpgmg_fv4_rb_smooths(void) { return fv4_rb_smooths; }
+static void fv4_rb_bcs(level_type *L, backend_t *B, int scratch, int id) {           /* apply_BCs_v4 on the pass's input (neighbouring boxes are read where they live) */
+  const int shape = stencil_get_shape();
+  if (L->boundary_condition.type == BC_PERIODIC) return;
+  if (!scratch) { if (!hp_exchange_and_bcs_one_launch(L, id, shape, 4, 0)) apply_BCs(L, id, shape); return; }
+  int n = 0;
+  const hpgmg_hip_bc_entry *e = hp_bc_entries(L, shape, &n);
+  hpgmg_hip_level Ls = B->dev;
+  Ls.box_base = (double *const *)B->d_pair_base;
+  TICK(L, boundary_conditions, "apply_BCs_v4 (private vector)");
+  HIP_OK(hpgmg_hip_exchange_and_bc(&Ls, id, NULL, 0, e, n, 4));
+  TOCK();
+}
+/* The cells whose intermediate value the one-pass kernel must not recompute: a cell next to a tile of ANOTHER box (= on an internal box face) whose
+ * stencil reaches outside the domain (= within one cell of a wall in another direction).  The coefficient ghost cells outside the domain are
+ * extrapolated with box-relative normals (boundary_fv.c:573-681), so two boxes hold different values for the same place there. */
+static const int *fv4_special_cells(level_type *L, backend_t *B, int *n_out) {
+  if (B->n_fv4_special < 0) {
+    int cap = 1024, n = 0, b, ax, side, u, v;
+    int *h = (int *)malloc((size_t)cap * 4 * sizeof(int));
+    const int dim = L->box_dim, N[3] = { L->dim.i, L->dim.j, L->dim.k }, nb[3] = { L->boxes_in.i, L->boxes_in.j, L->boxes_in.k };
+    if (L->boundary_condition.type != BC_PERIODIC)
+    for (b = 0; b < L->num_my_boxes; b++) {
+      const int low[3] = { L->my_boxes[b].low.i, L->my_boxes[b].low.j, L->my_boxes[b].low.k };
+      for (ax = 0; ax < 3; ax++) for (side = 0; side < 2; side++) {
+        const int bpos = low[ax] / dim + (side ? 1 : -1);
+        if (bpos < 0 || bpos >= nb[ax]) continue;                          /* a domain wall, not an internal face */
+        const int a1 = (ax + 1) % 3, a2 = (ax + 2) % 3;
+        for (v = 0; v < dim; v++) for (u = 0; u < dim; u++) {
+          const int g1 = low[a1] + u, g2 = low[a2] + v;
+          if (!(g1 == 0 || g1 == N[a1] - 1 || g2 == 0 || g2 == N[a2] - 1)) continue;
+          int c[3];
+          c[ax] = side ? dim - 1 : 0; c[a1] = u; c[a2] = v;
+          if (n == cap) { cap *= 2; h = (int *)realloc(h, (size_t)cap * 4 * sizeof(int)); }
+          h[4 * n] = b; h[4 * n + 1] = c[0]; h[4 * n + 2] = c[1]; h[4 * n + 3] = c[2]; n++;
+        }
+      }
+    }
+    B->d_fv4_special = (int *)hpgmg_hip_malloc((size_t)(n > 0 ? n : 1) * 4 * sizeof(int));
+    if (!B->d_fv4_special) { fprintf(stderr, "hpgmg: device allocation failed: %s\n", hpgmg_hip_last_error()); abort(); }
+    if (n > 0) HIP_OK(hpgmg_hip_memcpy_h2d(B->d_fv4_special, h, (size_t)n * 4 * sizeof(int)));
+    free(h);
+    B->n_fv4_special = n;
+  }
+  *n_out = B->n_fv4_special;
+  return B->d_fv4_special;
+}
+static int smooth_fv4_rb(level_type *L, int x_id, int rhs_id, double a, double b, int sweeps, int temp_dead) {
+  hpgmg_config cfg;
+  hpgmg_get_config(&cfg);
+  backend_t *B = hp_backend_of(L);
+  const int passes = sweeps / 2, v = hp_variant();
+  if (cfg.op != HPGMG_OP_FV4 || !hpgmg_gsrb_out_of_place() || !temp_dead || !hp_ghost_free_mode() || (sweeps & 1) || passes < 1) return 0;
+  if (L->num_my_boxes < 1 || x_id == VECTOR_TEMP || rhs_id == VECTOR_TEMP || L->box_dim < 8) return 0;
+  /* boxes on other ranks: the same passes on the table with their images (halo_images.c) -- x three cells deep once per PASS, i.e. one
+   * exchange per sweep where the reference has two (gsrb.c:30-33), the cells next to the faces recomputed from the owner's inputs */
+  const int images = !B->all_faces_local;
+  if (images && !hp_images_ready(L, B)) return 0;
+  const hpgmg_hip_level *dev = images ? &B->img->dev : &B->dev;
+  if (!hpgmg_hip_smooth_gsrb_fv4_rb_supported(dev, v)) return 0;
+  int n_k = 0, k_local = 1, n_all = 0, p;
+  const hpgmg_hip_bc_entry *e_k = NULL;
+  if (images) e_k = hp_images_bc_k(L, B, &n_k);
+  else if (L->boundary_condition.type != BC_PERIODIC) {
+    e_k = hp_bc_entries_k(L, &n_k, &k_local);
+    (void)hp_bc_entries(L, stencil_get_shape(), &n_all);
+    if (!k_local || !B->bc_sources_local[stencil_get_shape()]) return 0;
+  }
+  hp_ensure_pair_scratch(L, B);
+  double *const *pair_base = images ? (double *const *)B->img->d_pair_base : (double *const *)B->d_pair_base;
+  hpgmg_hip_set_tile_ghost_free(1);
+  const double h2inv = 1.0 / (L->h * L->h);
+  int n_sp = 0;
+  const int *sp_cells = images ? hp_images_fv4_special(L, B, &n_sp) : fv4_special_cells(L, B, &n_sp);
+  /* (scratch, id) of the iterate before pass p: x, then TEMP / x alternately; an odd count routes its second pass through private vector 0 */
+  int src_s = 0, src_id = x_id;
+  for (p = 0; p < passes; p++) {
+    int dst_s = 0, dst_id;
+    const int left = passes - p;                   /* passes still to do, this one included */
+    if (left == 1) dst_id = (passes == 1) ? VECTOR_TEMP : x_id;
+    else if (left == 2 && !(src_s == 0 && src_id == x_id)) { dst_s = 1; dst_id = 0; }    /* two to go and not standing on x: step aside so that the last pass can land on x */
+    else dst_id = (src_s == 0 && src_id == VECTOR_TEMP) ? x_id : VECTOR_TEMP;
+    if (left == 2 && src_s == 0 && src_id == x_id) dst_id = VECTOR_TEMP;
+    /* images: the message and the images' boundary conditions go to the exchange stream; under them the launch stream runs the tiles that
+     * read neither an image nor anything the pre-pass forms (part 1), then waits, runs the pre-pass and the other tiles (part 2) */
+    int overlapped = 0;
+    if (images) overlapped = hp_images_refresh_begin(L, B, src_s, src_id, 3, p == 0 ? rhs_id : -1, 4);
+    else fv4_rb_bcs(L, B, src_s, src_id);
+    TICK(L, smooth, "smooth (fv4 GSRB, red + black half sweeps in one pass)");
+    if (overlapped) {
+      hpgmg_hip_set_tile_part(1);
+      HIP_OK(hpgmg_hip_smooth_gsrb_fv4_rb(dev, v, pair_base, src_s, src_id, dst_s, dst_id, 1, rhs_id, a, b, h2inv, 2 * p));
+      hp_images_refresh_end();
+      hpgmg_hip_set_tile_part(2);
+    }
+    /* the pre-pass also works on the images next to the k walls: the main kernel reads the intermediate vector's ghost planes in their columns */
+    HIP_OK(hpgmg_hip_fv4_rb_prepass(images ? &B->img->dev_all : dev, v, pair_base, src_s, src_id, 1, rhs_id, a, b, h2inv, 2 * p, e_k, n_k, sp_cells, n_sp));
+    HIP_OK(hpgmg_hip_smooth_gsrb_fv4_rb(dev, v, pair_base, src_s, src_id, dst_s, dst_id, 1, rhs_id, a, b, h2inv, 2 * p));
+    if (overlapped) hpgmg_hip_set_tile_part(0);
+    TOCK();
+    src_s = dst_s; src_id = dst_id;
+  }
+  if (passes == 1) hp_do_scale_vector(L, x_id, 1.0, VECTOR_TEMP);      /* a single pass cannot land on its own input (never the case with the reference's counts) */
+  fv4_rb_smooths++;
+  return 1;
+}
+/* temp_dead: the caller declares VECTOR_TEMP scratch after this smooth() (inside a cycle: hpgmg_smooth_in_cycle, or the operator queue saw it
+ * overwritten next) -- the in-cycle forms may run: the sweep pair without the x3 store, the red + black passes of the 27-point / fv4 GSRB smoothers */
+void hp_do_smooth(level_type *L, int x_id, int rhs_id, double a, double b, int temp_dead) {
+  hpgmg_config cfg;
+  hpgmg_get_config(&cfg);
+  const int sweeps = hpgmg_smooth_sweeps(), v = hp_variant();
+  const double h2inv = 1.0 / (L->h * L->h);
+  backend_t *B = hp_backend_of(L);
+  int s;
+  if (cfg.op != HPGMG_OP_7PT && small_level_try(L, cfg.smoother == HPGMG_SMOOTH_CHEBY ? 0 : (cfg.smoother == HPGMG_SMOOTH_GSRB ? 1 : 2), x_id, rhs_id, x_id, a, b)) return;
+  if (cfg.smoother == HPGMG_SMOOTH_CHEBY) {          /* chebyshev.c:8-100 */
+    double c1[16], c2[16];
+    if (L->dominant_eigenvalue_of_DinvA <= 0.0 && L->my_rank == 0) fprintf(stderr, "dominant_eigenvalue_of_DinvA <= 0.0 !\n");
+    cheby_coefficients(L, sweeps, c1, c2);
+    if (smooth_cheby_pairs(L, x_id, rhs_id, a, b, c1, c2, sweeps, temp_dead)) return;
+    for (s = 0; s < sweeps; s++) {
+      const int src = (s & 1) ? VECTOR_TEMP : x_id, dst = (s & 1) ? x_id : VECTOR_TEMP;
+      STENCIL_WITH_GHOSTS(L, src, dst, smooth, hpgmg_hip_smooth_cheby(hp_stencil_dev(B), v, src, dst, rhs_id, a, b, h2inv, c1[s], c2[s]));
+    }
+  } else if (cfg.smoother == HPGMG_SMOOTH_GSRB) {    /* gsrb.c:24-132 */
+    const int oop = hpgmg_gsrb_out_of_place();
+    if (smooth_gsrb_pairs(L, x_id, rhs_id, a, b, sweeps)) return;
+    /* 27-point, inside a cycle (VECTOR_TEMP is scratch afterwards): each red + black pair of half sweeps as one pass, x -> TEMP -> x.
+     * The state the exported smooth() must leave in VECTOR_TEMP (the iterate before the last half sweep) never exists in this form. */
+    if (cfg.op == HPGMG_OP_27PT && oop && temp_dead && hp_ghost_free_mode() && sweeps % 4 == 0 && L->num_my_boxes > 0 &&
+        (B->all_faces_local || hp_images_ready(L, B)) && x_id != VECTOR_TEMP && rhs_id != VECTOR_TEMP) {
+      /* boxes on other ranks: the same pass on the table with their images -- x two cells deep once per pass (one exchange per sweep instead of
+       * gsrb.c:30-33's two), the intermediate vector on the cells around a box recomputed from the owner's x, right-hand side and D^{-1} */
+      const int images = !B->all_faces_local;
+      const hpgmg_hip_level *dev = images ? &B->img->dev : &B->dev;
+      const int tiled = hpgmg_hip_smooth_gsrb27_rb_supported(dev);                          /* boxes of side 64 m: marching tiles */
+      const int boxed = !tiled && hpgmg_hip_smooth_gsrb27_rb_box_supported(dev);   /* boxes of 2^3 ... 16^3: one workgroup per box */
+      if (tiled || boxed) {
+        for (s = 0; s < sweeps; s += 2) {
+          const int src = (s & 2) ? VECTOR_TEMP : x_id, dst = (s & 2) ? x_id : VECTOR_TEMP;
+          int overlapped = 0;
+          if (images && tiled) overlapped = hp_images_refresh_begin(L, B, 0, src, 2, s == 0 ? rhs_id : -1, 12);     /* the tiles that read no image run under the exchange */
+          else if (images) hp_images_refresh(L, B, 0, src, 2, s == 0 ? rhs_id : -1, 12);
+          else if (tiled && !hp_exchange_and_bcs_one_launch(L, src, stencil_get_shape(), 12, 0)) apply_BCs(L, src, stencil_get_shape());
+          TICK(L, smooth, "smooth (27-point GSRB, red + black half sweeps in one pass)");
+          if (overlapped) {
+            hpgmg_hip_set_tile_part(1); HIP_OK(hpgmg_hip_smooth_gsrb27_rb(dev, src, dst, rhs_id, a, b, h2inv, s));
+            hp_images_refresh_end();
+            hpgmg_hip_set_tile_part(2); HIP_OK(hpgmg_hip_smooth_gsrb27_rb(dev, src, dst, rhs_id, a, b, h2inv, s));
+            hpgmg_hip_set_tile_part(0);
+          } else
+          if (tiled) HIP_OK(hpgmg_hip_smooth_gsrb27_rb(dev, src, dst, rhs_id, a, b, h2inv, s));
+          else       HIP_OK(hpgmg_hip_smooth_gsrb27_rb_box(dev, src, dst, rhs_id, a, b, h2inv, s));
+          TOCK();
+          rb27_smooth_passes++;
+        }
+        return;
+      }
+    }
+    if (smooth_fv4_rb(L, x_id, rhs_id, a, b, sweeps, temp_dead)) return;
+    /* The exported smooth() (VECTOR_TEMP must be left as the separate half sweeps leave it: the iterate before the last one) -- what the
+     * reference's own driver calls (Route B): all sweeps but the last as red + black passes x -> TEMP -> x, the last sweep as its two half
+     * sweeps x -> TEMP -> x.  The same iterates, the same final x and VECTOR_TEMP; 2 passes + 2 half sweeps instead of 6 half sweeps. */
+    int first_half_sweep = 0;
+    if (cfg.op == HPGMG_OP_FV4 && oop && !temp_dead && sweeps >= 6 && !(sweeps & 1) && (((sweeps - 2) / 2) & 1) == 0 && !hp_switch(SW_FV4_NO_EXACT_RB)) {
+      if (smooth_fv4_rb(L, x_id, rhs_id, a, b, sweeps - 2, 1)) first_half_sweep = sweeps - 2;      /* VECTOR_TEMP is scratch to THESE passes (the half sweeps after them rewrite it); an even number of passes: they end on x */
+    }
+    for (s = first_half_sweep; s < sweeps; s++) {
+      const int src = (oop && (s & 1)) ? VECTOR_TEMP : x_id, dst = oop ? ((s & 1) ? x_id : VECTOR_TEMP) : x_id;
+      STENCIL_WITH_GHOSTS(L, src, dst, smooth, hpgmg_hip_smooth_gsrb(hp_stencil_dev(B), v, src, dst, rhs_id, a, b, h2inv, s));
+    }
+  } else {                                           /* jacobi.c:8-65 */
+    for (s = 0; s < sweeps; s++) {
+      const int src = (s & 1) ? VECTOR_TEMP : x_id, dst = (s & 1) ? x_id : VECTOR_TEMP;
+      STENCIL_WITH_GHOSTS(L, src, dst, smooth, hpgmg_hip_smooth_jacobi(hp_stencil_dev(B), v, src, dst, rhs_id, a, b, h2inv, 2.0 / 3.0));
+    }
+  }
+}
+
+void hp_do_residual(level_type *L, int res_id, int x_id, int rhs_id, double a, double b) {   /* residual.c:9-51 */
+  if (small_level_try(L, 3, x_id, rhs_id, res_id, a, b)) return;
+  STENCIL_WITH_GHOSTS(L, x_id, res_id, residual, hpgmg_hip_residual(hp_stencil_dev(hp_backend_of(L)), hp_variant(), res_id, x_id, rhs_id, a, b, 1.0 / (L->h * L->h)));
+}
+void hp_do_apply_op(level_type *L, int Ax_id, int x_id, double a, double b) {               /* apply_op.c:9-48 */
+  if (small_level_try(L, 4, x_id, -1, Ax_id, a, b)) return;
+  STENCIL_WITH_GHOSTS(L, x_id, Ax_id, apply_op, hpgmg_hip_residual(hp_stencil_dev(hp_backend_of(L)), hp_variant(), Ax_id, x_id, -1, a, b, 1.0 / (L->h * L->h)));
+}

@@ -72,7 +72,7 @@ def test_sweep_pairs_across_rank_boundaries(world, variant, log2, per_rank, gold
     (2, "27pt-gsrb", 7, 4, "27pt-gsrb 7 8"),
     (4, "fv4-gsrb", 7, 2, "fv4-gsrb 7 8"),        # bricks of 2 x 1 x 1: remote j and k faces and the edge between them
     (8, "27pt-gsrb", 7, 1, "27pt-gsrb 7 8"),      # one box per rank: three remote faces, three edges, a corner
-    (8, "fv4-gsrb", 7, 8, "fv4-gsrb 7 64"),       # BASELINE config 3 as stated: 512^3, eight ranks of 2 x 2 x 2 boxes
+    # (BASELINE config 3 as stated -- 512^3, eight ranks of 2 x 2 x 2 boxes, `(8, fv4-gsrb, 7, 8)` -- runs in test_ipc_peer_copy_transport below, on device-ordered messages)
     (2, "fv4-cheby", 5, 4, "fv4-cheby 5 8"),      # the tiled kernels (Chebyshev sweeps, residual) on the images, reference rank map down to boxes of 8^3
     (2, "27pt-cheby", 7, 4, "27pt-cheby 7 8"),
 ])
