@@ -153,3 +153,7 @@ def test_ipc_peer_copy_transport(world, variant, log2, per_rank, gold_key, gathe
     for r in res:
         assert r["stats"].get("transport") == "ipc" and r["stats"]["messages"] > 50, r["stats"]
         assert r["stats"]["overlapped_exchanges"] > 0, r["stats"]
+        if variant == "fv4-gsrb":            # the one-pass red + black kernel on the images, every rank
+            assert r["stats"]["fv4_rb_smooths"] >= 8 and r["stats"]["image_exchanges"] > 20, r["stats"]
+        if variant == "27pt-gsrb":
+            assert r["stats"]["rb27_passes"] >= 16 and r["stats"]["image_exchanges"] > 20, r["stats"]
