@@ -53,7 +53,9 @@ int hp_exchange_and_bcs_one_launch(level_type *L, int id, int shape, int order, 
   TOCK();
   return 1;
 }
-void hp_ghosts_for_stencil(level_type *L, int id, int out_id) {
+/* Returns 1 when the operand's images are being refreshed on the exchange stream: the caller then issues the stencil launch in its two parts
+ * (hpgmg_hip_set_tile_part 1, hp_images_refresh_end(), 2) -- STENCIL_WITH_GHOSTS does; 0: the ghost data is in place (in stream order), one whole launch. */
+int hp_ghosts_for_stencil(level_type *L, int id, int out_id) {
   const int shape = stencil_get_shape();
   hpgmg_config c;
   hpgmg_get_config(&c);
@@ -70,7 +72,7 @@ void hp_ghosts_for_stencil(level_type *L, int id, int out_id) {
       HIP_OK(hpgmg_hip_copy_blocks(&B->dev, id, hp_mirror(L, C->blocks[2], C->num_blocks[2]), C->num_blocks[2]));
       TOCK();
     }
-    return;
+    return 0;
   }
   /* 27-point and fv4 on a level whose boxes are all local, about to run the LDS-tiled kernel: it reads a neighbouring box's cells
    * where they live, so only the domain-boundary ghost cells are needed (each box's own, from its own interior) */
@@ -79,22 +81,22 @@ void hp_ghosts_for_stencil(level_type *L, int id, int out_id) {
     if (B->all_faces_local && hpgmg_hip_tile_kernel_applies(&B->dev, hp_variant(), id != out_id)) {
       hpgmg_hip_set_tile_ghost_free(1);
       if (!hp_exchange_and_bcs_one_launch(L, id, shape, c.op == HPGMG_OP_27PT ? 12 : 4, 0)) apply_BCs(L, id, shape);
-      return;
+      return 0;
     }
     /* boxes on other ranks: the same kernel on the table with their images -- one message per neighbouring rank carries the cells it reads there */
     if (!B->all_faces_local && hp_images_ready(L, B) && hpgmg_hip_tile_kernel_applies(&B->img->dev, hp_variant(), id != out_id)) {
       hpgmg_hip_set_tile_ghost_free(1);
-      hp_images_refresh(L, B, 0, id, stencil_get_radius(), -1, c.op == HPGMG_OP_27PT ? 12 : 4);
-      return;
+      return hp_images_refresh_begin(L, B, 0, id, stencil_get_radius(), -1, c.op == HPGMG_OP_27PT ? 12 : 4);
     }
   }
   {
     int order = 0;
     if (c.op == HPGMG_OP_27PT) order = 12; else if (c.op == HPGMG_OP_FV2) order = 2; else if (c.op == HPGMG_OP_FV4) order = 4;
-    if (order && hp_exchange_and_bcs_one_launch(L, id, shape, order, 1)) return;
+    if (order && hp_exchange_and_bcs_one_launch(L, id, shape, order, 1)) return 0;
   }
   exchange_boundary(L, id, shape);
   apply_BCs(L, id, shape);
+  return 0;
 }
 
 /* Halo exchange overlapped with the stencil launch that consumes it (north_star: "ghost-zone exchange on RCCL over

@@ -160,7 +160,7 @@ extern HP_INTERNAL long long hp_overlap_count;
 HP_INTERNAL double hp_now(void);
 HP_INTERNAL void hp_transport_phase(const communicator_type *recv_side, const communicator_type *send_side, int tag);
 HP_INTERNAL int hp_exchange_and_bcs_one_launch(level_type *L, int id, int shape, int order, int with_copies);
-HP_INTERNAL void hp_ghosts_for_stencil(level_type *L, int id, int out_id);
+HP_INTERNAL int hp_ghosts_for_stencil(level_type *L, int id, int out_id);
 HP_INTERNAL int hp_overlap_begin(level_type *L, int id);
 HP_INTERNAL void hp_overlap_end(void);
 HP_INTERNAL void hp_no_kernel(const char *what);
@@ -197,9 +197,13 @@ HP_INTERNAL void hp_small_ops_forget(void);
       hpgmg_hip_set_defer_mode(2); HIP_OK(CALL); hpgmg_hip_set_defer_mode(0);                            \
       TOCK();                                                                                            \
     } else {                                                                                             \
-      hp_ghosts_for_stencil(L, id, out_id);                                                                 \
+      const int two_parts_ = hp_ghosts_for_stencil(L, id, out_id);   /* 1: the images' refresh runs on the exchange stream */ \
       TICK(L, TIMER, #TIMER);                                                                            \
-      HIP_OK(CALL);                                                                                      \
+      if (two_parts_) {                                                                                  \
+        hpgmg_hip_set_tile_part(1); HIP_OK(CALL);                                                        \
+        hp_images_refresh_end();                                                                         \
+        hpgmg_hip_set_tile_part(2); HIP_OK(CALL); hpgmg_hip_set_tile_part(0);                            \
+      } else HIP_OK(CALL);                                                                               \
       TOCK();                                                                                            \
     } } while (0)
 #define PAIR_REMOTE_LAUNCH(OVERLAPPED, DISCARD_X1, CALL) do {                                                   \

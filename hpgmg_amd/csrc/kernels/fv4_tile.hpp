@@ -37,6 +37,7 @@ struct Fv4TileArgs {
   // x_base / out_base: box-base tables of the vectors xn_id / xout_id when they are plugin-private scratch vectors (NULL: level vectors)
   int k_origin, k_step, wall_only;
   double *const *x_base, *const *out_base;
+  const int *order;                     // dispatch slot -> tile (nullptr: identity): two-part launches across rank boundaries (common.hpp tile_part_order)
 };
 enum { FV4_CHEBY = 0, FV4_GSRB = 1, FV4_JACOBI = 2, FV4_RESIDUAL = 3, FV4_APPLY = 4 };
 
@@ -52,7 +53,8 @@ __device__ __forceinline__ void fv4_tile_body(const hpgmg_hip_level &L, const Fv
   __shared__ double sR[(MODE == FV4_RESIDUAL) ? 2 * TJ * TI : 1];   // fused residual forms: a plane of residuals / the workgroup's partial maxima
   double *sX = fv4_lds, *sBI = fv4_lds + 3 * PLANE, *sBJ = fv4_lds + 6 * PLANE, *sBK = fv4_lds + 9 * PLANE;   // rings of 3, 3, 3, 2 plane tiles
 
-  const int logical = xcd_logical_block(block, P.per_xcd);
+  int logical = xcd_logical_block(block, P.per_xcd);
+  if (P.order) logical = P.order[logical];
   if (logical >= P.total_blocks) return;
   int t = logical;
   const int ti = t % P.tiles_i; t /= P.tiles_i;

@@ -595,8 +595,15 @@ static int launch27(const hpgmg_hip_level *L, StencilArgs P, bool is_smoother) {
     A.kchunk = kchunk; A.chunks_k = (L->dim + kchunk - 1) / kchunk;
     A.total_blocks = L->num_boxes * A.chunks_k * A.tiles_j * A.tiles_i;
     g_tile_last_blocks = A.total_blocks;
-    const int tgrid = grid_for(A.total_blocks, &A.per_xcd);
-    const long long tcells = (long long)L->num_boxes * L->dim * L->dim * L->dim;
+    int tgrid = grid_for(A.total_blocks, &A.per_xcd);
+    long long tcells = (long long)L->num_boxes * L->dim * L->dim * L->dim;
+    if (g_tile_part && A.fused.kind == 0) {      // one part of the launch (hpgmg_hip_set_tile_part): part 1 = the tiles that read nothing of an image of another rank's box
+      int count = 0;
+      A.order = tile_part_order(L, A.tiles_i, A.tiles_j, A.chunks_k, g_tile_part, false, &tgrid, &A.per_xcd, &count);
+      if (tgrid == 0) return 0;
+      if (!A.order) return record_error(hipErrorOutOfMemory, "stencil27_tile: dispatch list of a partial launch");
+      tcells = tcells * count / A.total_blocks;
+    }
     const int tprof = is_smoother ? profile_begin(tcells) : -1;
     if (narrow) hipLaunchKernelGGL((stencil27_tile_kernel<TM, 16, 32>), dim3(tgrid), dim3(32, 16), 0, g_stream, *L, A);
     else        hipLaunchKernelGGL((stencil27_tile_kernel<TM, 8, 64>), dim3(tgrid), dim3(64, 8), 0, g_stream, *L, A);
@@ -633,9 +640,16 @@ static int launch_fv4_tile_tj(const hpgmg_hip_level *L, int variant, const Stenc
   P.kchunk = kchunk; P.chunks_k = (L->dim + kchunk - 1) / kchunk;
   P.total_blocks = L->num_boxes * P.chunks_k * P.tiles_j * P.tiles_i;
   g_tile_last_blocks = P.total_blocks;
-  const int grid = grid_for(P.total_blocks, &P.per_xcd);
+  int grid = grid_for(P.total_blocks, &P.per_xcd);
   const size_t lds = (size_t)11 * (TI + 4) * (TJ + 4) * sizeof(double);
-  const long long cells = (long long)L->num_boxes * L->dim * L->dim * L->dim;
+  long long cells = (long long)L->num_boxes * L->dim * L->dim * L->dim;
+  if (g_tile_part && P.fused.kind == 0) {        // one part of the launch (hpgmg_hip_set_tile_part): part 1 = the tiles that read nothing of an image of another rank's box
+    int count = 0;
+    P.order = tile_part_order(L, P.tiles_i, P.tiles_j, P.chunks_k, g_tile_part, false, &grid, &P.per_xcd, &count);
+    if (grid == 0) return 0;
+    if (!P.order) return record_error(hipErrorOutOfMemory, "fv4_tile: dispatch list of a partial launch");
+    cells = cells * count / P.total_blocks;
+  }
   const int prof = is_smoother ? profile_begin(cells) : -1;
 #define FV4_TILE_CASE(VAR) { \
     static bool once = false; if (!once) { HPGMG_CHECK(hipFuncSetAttribute((const void *)fv4_tile_kernel<VAR, MODE, TJ, TI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once = true; } \

@@ -28,6 +28,7 @@ struct S27TileArgs {
   int sweep, ghost_free;
   TileFused fused;                      // MODE 3 only: what becomes of the residual (common.hpp)
   int tiles_i, tiles_j, chunks_k, kchunk, per_xcd, total_blocks;
+  const int *order;                     // dispatch slot -> tile (nullptr: identity): two-part launches across rank boundaries (common.hpp tile_part_order)
 };
 
 template <int MODE, int TJ, int TI = 64>
@@ -39,7 +40,8 @@ __global__ __launch_bounds__(TI * TJ) void stencil27_tile_kernel(const hpgmg_hip
   __shared__ double sX[3 * PLANE];
   __shared__ double sR[(MODE == 3) ? 2 * TJ * TI : 1];           // fused residual forms: a plane of residuals / the workgroup's partial maxima
 
-  const int logical = xcd_logical_block((int)blockIdx.x, P.per_xcd);
+  int logical = xcd_logical_block((int)blockIdx.x, P.per_xcd);
+  if (P.order) logical = P.order[logical];
   if (logical >= P.total_blocks) return;
   int t = logical;
   const int ti = t % P.tiles_i; t /= P.tiles_i;

@@ -174,8 +174,9 @@ void hpgmg_hip_set_defer_mode(int mode);
  * BEHIND the num_boxes own ones, reached through box_nbr like any neighbour): part 1 = the tiles whose halo reaches no image (for the fv4
  * red + black pass also no domain wall: nothing its pre-pass forms), part 2 = the others, 0 = whole launches.  Lets the caller run the
  * exchange that refreshes the images on a second stream under part 1 (north_star: "ghost-zone exchange ... overlapped with interior
- * smoothing"; reference operators/exchange_boundary.c:81-90 only overlaps the local copies).  Applies to hpgmg_hip_smooth_gsrb_fv4_rb and
- * hpgmg_hip_smooth_gsrb27_rb. */
+ * smoothing"; reference operators/exchange_boundary.c:81-90 only overlaps the local copies).  Applies to hpgmg_hip_smooth_gsrb_fv4_rb,
+ * hpgmg_hip_smooth_gsrb27_rb, the sweep-pair launches with remote faces, and the LDS-tiled 27-point / fv4 kernels behind hpgmg_hip_smooth_* /
+ * hpgmg_hip_residual (plain forms; the fused residual forms always run whole). */
 void hpgmg_hip_set_tile_part(int part);
 /* The LDS-tiled 27-point and fv4 kernels (boxes whose side is a multiple of 64, out of place) can read x outside a box from the
  * neighbouring box itself when every box of the level is local: the caller then runs only apply_BCs before the launch, not

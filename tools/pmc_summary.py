@@ -32,7 +32,8 @@ def biggest(kern, pattern):
         if pattern in name:
             g = max(x[0] for x in lst)
             vals = [v for gg, v in lst if gg == g]
-            if best is None or g > best[0]: best = (g, sum(vals) / len(vals), len(vals), name)
+            # same grid for two instantiations (e.g. the pre-pass and its once-per-rebuild packing form): the one launched more often
+            if best is None or (g, len(vals)) > (best[0], best[2]): best = (g, sum(vals) / len(vals), len(vals), name)
     return best
 
 def main():
