@@ -333,12 +333,19 @@ def main():
             achieved = bytes_per_launch / avg_s / 1e9
             unfused = smoother[0] * sweeps_per_launch * fine_cells / avg_s / 1e9
             traffic, traffic_source = pmc_traffic(args.workload, int(fine_cells)) if world == 1 else (None, None)
+            if world > 1:      # the single-GPU counter summary of the same kernel, scaled to the cells this rank owns (the launch has the same structure per cell)
+                whole, traffic_source = pmc_traffic(args.workload, None)
+                one_gpu_cells = {"config2": 256 ** 3, "config5": 256 ** 3, "config3-fv4": 512 ** 3, "config3-27pt": 512 ** 3}.get(args.workload)
+                traffic = whole * fine_cells / one_gpu_cells if (whole and one_gpu_cells) else None
+                if traffic is None:
+                    traffic_source = None
             if achieved > HBM_PEAK_GBS:      # the line is still printed (the measurement is done), with roofline null and an error field; exit code 3
                 roof_error = f"roofline fraction {achieved / HBM_PEAK_GBS:.3f} > 1 -- the byte model of this kernel is wrong"
             else:
               roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                       "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
-                      "traffic_note": "PMC bytes per launch from the committed summary named in traffic_source: ANOTHER run (and possibly build) of the same command, not this one" if traffic else None,
+                      "traffic_note": ("PMC bytes per launch from the committed summary named in traffic_source: ANOTHER run (and possibly build) of the same command, not this one"
+                                       + ("; a single-GPU figure scaled to the cells this rank owns" if world > 1 else "")) if traffic else None,
                       "kernel": smoother[2] + f" over the {my_boxes} finest-level boxes of {box_dim}^3 of this rank",
                       "sweeps_per_launch": round(sweeps_per_launch, 3),
                       "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_us": round(avg_s * 1e6, 2),

@@ -9,7 +9,7 @@
 
 namespace hpgmg {
 int  profile_begin(long long cells);          // stencil.hip: hipEvent pair around a smoother launch (bench.py's roofline)
-void profile_end(int p, long long cells);
+void profile_end(int p, long long cells, bool first_part = false);
 static int env_int(const char *name, int dflt) { const char *e = getenv(name); return (e && *e) ? atoi(e) : dflt; }
 }
 using namespace hpgmg;
@@ -125,6 +125,7 @@ int hpgmg_hip_smooth_gsrb_fv4_rb(const hpgmg_hip_level *L, int variant, double *
   A.total_blocks = L->num_boxes * A.chunks_k * A.tiles_j * A.tiles_i;
   int grid = grid_for(A.total_blocks, &A.per_xcd);
   long long cells = (long long)L->num_boxes * L->dim * L->dim * L->dim;
+  const long long whole_cells = cells;
   if (g_tile_part) {      // one part of the launch: part 1 = tiles that read neither an image of another rank's box nor anything the pre-pass forms (no wall)
     int count = 0;
     A.order = tile_part_order(L, A.tiles_i, A.tiles_j, A.chunks_k, g_tile_part, true, &grid, &A.per_xcd, &count);
@@ -135,7 +136,7 @@ int hpgmg_hip_smooth_gsrb_fv4_rb(const hpgmg_hip_level *L, int variant, double *
 #ifdef HPGMG_EXP_TIMELINE
   A.timeline = g_fv4rb_timeline; A.timeline_wg = env_int("HPGMG_EXP_TIMELINE_WG", -1);
 #endif
-  const int prof = profile_begin(cells);
+  const int prof = profile_begin(whole_cells);               // (the caller's size threshold is on the whole launch; a part reports its share of the cells)
 #define FV4_RB_CASE(VAR, TI_) { \
     constexpr size_t lds = fv4rb::Geom<TI_>::LDS_BYTES; \
     static bool once = false; if (!once) { HPGMG_CHECK(hipFuncSetAttribute((const void *)fv4_rb_kernel<VAR, TI_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once = true; } \
@@ -143,7 +144,7 @@ int hpgmg_hip_smooth_gsrb_fv4_rb(const hpgmg_hip_level *L, int variant, double *
   if (variant == HPGMG_HIP_FV4_VC_HELMHOLTZ) FV4_RB_CASE(HPGMG_HIP_FV4_VC_HELMHOLTZ, 64) else FV4_RB_CASE(HPGMG_HIP_FV4_VC_POISSON, 64)
 #undef FV4_RB_CASE
   g_rb4_launches++;
-  profile_end(prof, 2 * cells);                         // one launch = two half sweeps over every cell
+  profile_end(prof, 2 * cells, g_tile_part == 1);       // one launch = two half sweeps over every cell
   HPGMG_LAUNCH_CHECK("fv4_rb_kernel");
   return 0;
 }

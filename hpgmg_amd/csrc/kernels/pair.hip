@@ -176,6 +176,7 @@ static int smooth_pair(const hpgmg_hip_level *L, int variant, int gsrb, int swee
   A.total_blocks = A.tiles_i * A.slabs_j * A.chunks_k;
   int grid = grid_for(A.total_blocks, &A.per_xcd);
   long long cells = (long long)A.Di * A.Dj * A.Dk;
+  const long long whole_cells = cells;
   const int part = remote ? g_tile_part : 0;
   if (part) {
     const PairOrder *o = pair_part_order(A, part);
@@ -199,7 +200,7 @@ static int smooth_pair(const hpgmg_hip_level *L, int variant, int gsrb, int swee
       }
     }
   }
-  const int prof = profile_begin(cells);
+  const int prof = profile_begin(whole_cells);
 #define PAIR_LAUNCH2(VAR, C32, SM, NARROW, INTERP) { \
       static bool once = false; if (!once) { HPGMG_CHECK(hipFuncSetAttribute((const void *)cheby_pair_kernel<VAR, nw, C32, SM, NARROW, INTERP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once = true; } \
       hipLaunchKernelGGL((cheby_pair_kernel<VAR, nw, C32, SM, NARROW, INTERP>), dim3(grid), dim3(64, nw), lds, g_stream, *L, A); }
@@ -233,7 +234,7 @@ static int smooth_pair(const hpgmg_hip_level *L, int variant, int gsrb, int swee
 #undef PAIR_LAUNCH2
 #undef PAIR_LAUNCH_REMOTE
   if (part != 1) { g_pair_launches++; if (remote) g_pair_remote_launches++; }      // the two parts of a launch count once (part 2 is never empty: it holds the workgroups at the remote faces)
-  profile_end(prof, 2 * cells);                      // one launch = two sweeps over every cell
+  profile_end(prof, 2 * cells, part == 1);           // one launch = two sweeps over every cell
   HPGMG_LAUNCH_CHECK("cheby_pair_kernel");
   return 0;
 }

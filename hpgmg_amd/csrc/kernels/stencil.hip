@@ -526,10 +526,12 @@ int profile_begin(long long cells) {
   hipEventRecord(g_ev[2 * p], g_stream);
   return p;
 }
-void profile_end(int p, long long cells) {
+// first_part: part 1 of a two-part launch (hpgmg_hip_set_tile_part): its time and cells are added to the launch that part 2 completes
+void profile_end(int p, long long cells, bool first_part) {
   if (p < 0) return;
   hipEventRecord(g_ev[2 * p + 1], g_stream);
-  g_prof_cells += cells; g_prof_launches++;
+  g_prof_cells += cells;
+  if (!first_part) g_prof_launches++;
 }
 
 static int g_ghost_free = 0;
@@ -597,6 +599,8 @@ static int launch27(const hpgmg_hip_level *L, StencilArgs P, bool is_smoother) {
     g_tile_last_blocks = A.total_blocks;
     int tgrid = grid_for(A.total_blocks, &A.per_xcd);
     long long tcells = (long long)L->num_boxes * L->dim * L->dim * L->dim;
+    const long long whole_cells = tcells;
+    const bool first_part = g_tile_part == 1 && A.fused.kind == 0;
     if (g_tile_part && A.fused.kind == 0) {      // one part of the launch (hpgmg_hip_set_tile_part): part 1 = the tiles that read nothing of an image of another rank's box
       int count = 0;
       A.order = tile_part_order(L, A.tiles_i, A.tiles_j, A.chunks_k, g_tile_part, false, &tgrid, &A.per_xcd, &count);
@@ -604,10 +608,10 @@ static int launch27(const hpgmg_hip_level *L, StencilArgs P, bool is_smoother) {
       if (!A.order) return record_error(hipErrorOutOfMemory, "stencil27_tile: dispatch list of a partial launch");
       tcells = tcells * count / A.total_blocks;
     }
-    const int tprof = is_smoother ? profile_begin(tcells) : -1;
+    const int tprof = is_smoother ? profile_begin(whole_cells) : -1;
     if (narrow) hipLaunchKernelGGL((stencil27_tile_kernel<TM, 16, 32>), dim3(tgrid), dim3(32, 16), 0, g_stream, *L, A);
     else        hipLaunchKernelGGL((stencil27_tile_kernel<TM, 8, 64>), dim3(tgrid), dim3(64, 8), 0, g_stream, *L, A);
-    profile_end(tprof, tcells);
+    profile_end(tprof, tcells, first_part);
     HPGMG_LAUNCH_CHECK("stencil27_tile_kernel");
     return 0;
   }
@@ -643,6 +647,8 @@ static int launch_fv4_tile_tj(const hpgmg_hip_level *L, int variant, const Stenc
   int grid = grid_for(P.total_blocks, &P.per_xcd);
   const size_t lds = (size_t)11 * (TI + 4) * (TJ + 4) * sizeof(double);
   long long cells = (long long)L->num_boxes * L->dim * L->dim * L->dim;
+  const long long whole_cells = cells;
+  const bool first_part = g_tile_part == 1 && P.fused.kind == 0;
   if (g_tile_part && P.fused.kind == 0) {        // one part of the launch (hpgmg_hip_set_tile_part): part 1 = the tiles that read nothing of an image of another rank's box
     int count = 0;
     P.order = tile_part_order(L, P.tiles_i, P.tiles_j, P.chunks_k, g_tile_part, false, &grid, &P.per_xcd, &count);
@@ -650,14 +656,14 @@ static int launch_fv4_tile_tj(const hpgmg_hip_level *L, int variant, const Stenc
     if (!P.order) return record_error(hipErrorOutOfMemory, "fv4_tile: dispatch list of a partial launch");
     cells = cells * count / P.total_blocks;
   }
-  const int prof = is_smoother ? profile_begin(cells) : -1;
+  const int prof = is_smoother ? profile_begin(whole_cells) : -1;
 #define FV4_TILE_CASE(VAR) { \
     static bool once = false; if (!once) { HPGMG_CHECK(hipFuncSetAttribute((const void *)fv4_tile_kernel<VAR, MODE, TJ, TI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once = true; } \
     hipLaunchKernelGGL((fv4_tile_kernel<VAR, MODE, TJ, TI>), dim3(grid), dim3(TI, TJ), lds, g_stream, *L, P); }
   if (variant == HPGMG_HIP_FV4_VC_HELMHOLTZ) FV4_TILE_CASE(HPGMG_HIP_FV4_VC_HELMHOLTZ)
   else FV4_TILE_CASE(HPGMG_HIP_FV4_VC_POISSON)
 #undef FV4_TILE_CASE
-  profile_end(prof, cells);
+  profile_end(prof, cells, first_part);
   HPGMG_LAUNCH_CHECK("fv4_tile_kernel");
   return 0;
 }
@@ -880,6 +886,7 @@ int hpgmg_hip_smooth_gsrb27_rb(const hpgmg_hip_level *L, int x_id, int out_id, i
   A.total_blocks = L->num_boxes * A.chunks_k * A.tiles_j * A.tiles_i;
   int grid = grid_for(A.total_blocks, &A.per_xcd);
   long long cells = (long long)L->num_boxes * L->dim * L->dim * L->dim;
+  const long long whole_cells = cells;
   if (g_tile_part) {      // one part of the launch: part 1 = the tiles that read nothing of an image of another rank's box
     int count = 0;
     A.order = tile_part_order(L, A.tiles_i, A.tiles_j, A.chunks_k, g_tile_part, false, &grid, &A.per_xcd, &count);
@@ -887,10 +894,10 @@ int hpgmg_hip_smooth_gsrb27_rb(const hpgmg_hip_level *L, int x_id, int out_id, i
     if (!A.order) return record_error(hipErrorOutOfMemory, "smooth_gsrb27_rb: dispatch list of a partial launch");
     cells = cells * count / A.total_blocks;
   }
-  const int prof = profile_begin(cells);
+  const int prof = profile_begin(whole_cells);
   hipLaunchKernelGGL((stencil27_rb_kernel<TJ>), dim3(grid), dim3(64, TJ / 2), 0, g_stream, *L, A);
   g_rb27_launches++;
-  profile_end(prof, 2 * cells);                       // one launch = two half sweeps over every cell
+  profile_end(prof, 2 * cells, g_tile_part == 1);     // one launch = two half sweeps over every cell
   HPGMG_LAUNCH_CHECK("stencil27_rb_kernel");
   return 0;
 }

@@ -46,7 +46,7 @@ template <bool kMayAlias> struct src_ptr { typedef const double *__restrict__ ty
 template <> struct src_ptr<true> { typedef const double *type; };
 
 int  profile_begin(long long cells);          // stencil.hip: hipEvent pair around a smoother launch (bench.py's roofline)
-void profile_end(int p, long long cells);
+void profile_end(int p, long long cells, bool first_part = false);
 static inline int env_int(const char *name, int dflt) { const char *e = getenv(name); return (e && *e) ? atoi(e) : dflt; }
 #ifdef HPGMG_EXP_TIMELINE
 extern double *g_exp_timeline;     // experiment build: where a kernel's chosen workgroup records its step timeline (pair.hip)
