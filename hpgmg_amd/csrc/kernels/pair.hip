@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void pair_halo_kernel(const hpgmg_hip_level L,
   }
 }
 #ifdef HPGMG_EXP_TIMELINE
-double *g_exp_timeline = nullptr;
+double *g_exp_timeline = nullptr;     // experiment build: where a kernel's chosen workgroup records its step timeline
 #endif
 }  // namespace hpgmg
 using namespace hpgmg;
@@ -72,9 +72,6 @@ static bool g_pair_halo_set = false;
 static int g_pair_rem[6], g_pair_brick[3];
 static const double *g_pair_deep = nullptr, *g_pair_deep_beta = nullptr;
 static long long g_pair_launches = 0, g_pair_remote_launches = 0;
-#ifdef HPGMG_EXP_TIMELINE
-static double *g_exp_timeline = nullptr;     // experiment build: where the pair kernel's first workgroup records its step timeline
-#endif
 static int g_pair_discard_x1 = 0;     // consumed by the next Chebyshev pair launch: its out1 vector is scratch, do not store x1
 static const hpgmg_hip_level *g_pair_interp_level = nullptr;
 static int g_pair_interp_id = 0;
