@@ -65,6 +65,9 @@ def test_sweep_pairs_across_rank_boundaries(world, variant, log2, per_rank, gold
         assert r["stats"]["pair_remote_launches"] == 2 * r["stats"]["pair_remote_smooths"], r["stats"]
         if os.environ.get("HPGMG_OVERLAP", "1") != "0":       # each pair's halo exchange runs on the exchange stream under the workgroups that touch no remote face
             assert r["stats"]["overlapped_exchanges"] >= 2 * r["stats"]["pair_remote_smooths"], r["stats"]
+        # residual + restriction and residual + norm stay ONE pass each on a bandwidth-bound level with faces on other ranks (x crosses them first)
+        if per_rank * 128 ** 3 >= 4000000:
+            assert r["stats"]["fused_residuals_remote"] >= 8, r["stats"]
 
 
 @pytest.mark.parametrize("world,variant,log2,per_rank,gold_key", [
