@@ -32,8 +32,9 @@ struct S27RbArgs {
 };
 
 // A x at the centre of three LDS planes (row stride W): operators.27pt.c:60-91 in apply_op_27pt's order -- 8 corners, 12 edges, 6 faces, centre
+// (LDS reads through lds27r, stencil27_tile.hpp: one ds_read_b64 each)
 template <int W>
-__device__ __forceinline__ double apply27_lds(const double *m, const double *c, const double *p, double a, double bh2inv) {
+__device__ __forceinline__ double apply27_lds(lds27r m, lds27r c, lds27r p, double a, double bh2inv) {
   double s8 = m[-W - 1] + m[-W + 1]; s8 = s8 + m[W - 1]; s8 = s8 + m[W + 1];
   s8 = s8 + p[-W - 1]; s8 = s8 + p[-W + 1]; s8 = s8 + p[W - 1]; s8 = s8 + p[W + 1];
   double s12 = m[-W] + m[-1]; s12 = s12 + m[1]; s12 = s12 + m[W];
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(32 * TJ) __attribute__((amdgpu_waves_per_eu(4, 8)))
     // ---- R(q): t on plane q -- the red cell of the own pair updated (gsrb.c:90-105), the black one copied -- and the ring cell
     const int up = is_red(gi, gj, q) ? 0 : 1;                     // 0: the lower cell of the pair is the red one, 1: the upper
     {
-      const double *c = sO + slot3(q) * PO, *m = sO + slot3(q - 1) * PO, *pp = sO + slot3(q + 1) * PO;
+      lds27r c = (lds27r)(sO + slot3(q) * PO), m = (lds27r)(sO + slot3(q - 1) * PO), pp = (lds27r)(sO + slot3(q + 1) * PO);
       const int oR = ownO + up * WO, oB = ownO + (1 - up) * WO;
       const double r_rhs = up ? c_rhs_hi : c_rhs_lo, r_dinv = up ? c_dinv_hi : c_dinv_lo;
       const double v = c[oR] + r_dinv * (r_rhs - apply27_lds<WO>(m + oR, c + oR, pp + oR, P.a, bh2inv));
@@ -222,7 +223,7 @@ __global__ __launch_bounds__(32 * TJ) __attribute__((amdgpu_waves_per_eu(4, 8)))
 
     // ---- B(r): the black half sweep on the tile proper, from planes r-1, r, r+1 of t: the black cell of the pair updated, the red one stored as it is
     auto black = [&](int r, double k_rhs, double k_dinv) {
-      const double *c = sP + slot3(r) * PP, *m = sP + slot3(r - 1) * PP, *pp = sP + slot3(r + 1) * PP;
+      lds27r c = (lds27r)(sP + slot3(r) * PP), m = (lds27r)(sP + slot3(r - 1) * PP), pp = (lds27r)(sP + slot3(r + 1) * PP);
       const int upb = is_red(gi, gj, r) ? 1 : 0;                  // 1: the upper cell of the pair is the black one
       const int oB = ownP + upb * WP, oR = ownP + (1 - upb) * WP;
       const double v = c[oB] + k_dinv * (k_rhs - apply27_lds<WP>(m + oB, c + oB, pp + oB, P.a, bh2inv));

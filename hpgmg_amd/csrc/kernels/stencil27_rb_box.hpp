@@ -94,7 +94,7 @@ __global__ __launch_bounds__(NT) void stencil27_rb_box_kernel(const hpgmg_hip_le
     const int cx = (li + 2) + (lj + 2) * WX + (lk + 2) * WX * WX;
     double v = sX[cx];
     if (is_red(i, j, k)) {
-      const double Ax = apply27_lds<WX>(sX + cx - WX * WX, sX + cx, sX + cx + WX * WX, P.a, bh2inv);
+      const double Ax = apply27_lds<WX>((lds27r)(sX + cx - WX * WX), (lds27r)(sX + cx), (lds27r)(sX + cx + WX * WX), P.a, bh2inv);
       v = v + at(VECTOR_DINV, i, j, k) * (at(P.rhs_id, i, j, k) - Ax);
     }
     sT[c] = v;
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(NT) void stencil27_rb_box_kernel(const hpgmg_hip_le
     const int ct = (li + 1) + (lj + 1) * WT + (lk + 1) * WT * WT, g = i + j * jS + k * kS;
     double v = sT[ct];
     if (!is_red(i, j, k)) {
-      const double Ax = apply27_lds<WT>(sT + ct - WT * WT, sT + ct, sT + ct + WT * WT, P.a, bh2inv);
+      const double Ax = apply27_lds<WT>((lds27r)(sT + ct - WT * WT), (lds27r)(sT + ct), (lds27r)(sT + ct + WT * WT), P.a, bh2inv);
       v = v + dinv[g] * (rhs[g] - Ax);
     }
     out[g] = v;

@@ -21,6 +21,8 @@
 #endif
 
 namespace hpgmg {
+// LDS reads of the 27-point stencils: volatile, so that the backend issues ds_read_b64 and does not merge pairs of them into ds_read2_b64 (half the bytes per LDS cycle on gfx950)
+typedef const volatile double __attribute__((address_space(3))) *lds27r;
 
 struct S27TileArgs {
   int xn_id, xout_id, rhs_id, mode;     // mode: MODE_* of stencil.hip (Chebyshev, GSRB, Jacobi, residual, apply_op)
@@ -129,7 +131,7 @@ __global__ __launch_bounds__(TI * TJ) void stencil27_tile_kernel(const hpgmg_hip
     }
     __syncthreads();
 
-    const double *c = sX + slot3(k) * PLANE + own_s, *m = sX + slot3(k - 1) * PLANE + own_s, *p = sX + slot3(k + 1) * PLANE + own_s;
+    lds27r c = (lds27r)(sX + slot3(k) * PLANE + own_s), m = (lds27r)(sX + slot3(k - 1) * PLANE + own_s), p = (lds27r)(sX + slot3(k + 1) * PLANE + own_s);      // each of the 27 values is read once
     const double xc = c[0];
     bool update = true;
     if (MODE == 1) update = (((i ^ j ^ k ^ colour000) & 1) == 0);
