@@ -723,7 +723,7 @@ __global__ __launch_bounds__(256) void fv4_special_kernel(const hpgmg_hip_level 
 // P.tg; where they write the same cell they write the same value.
 template <int V, int TJ, int TI>
 __global__ __launch_bounds__(TI * TJ) void fv4_rb_prepass_kernel(const hpgmg_hip_level L, const Fv4TileArgs T, const Fv4SpecialArgs S, int sp_blocks) {
-  if ((int)blockIdx.x >= sp_blocks) fv4_tile_body<V, FV4_GSRB, TJ, TI>(L, T, (int)blockIdx.x - sp_blocks);
+  if ((int)blockIdx.x >= sp_blocks) fv4_tile_body<V, FV4_GSRB, TJ, TI, false>(L, T, (int)blockIdx.x - sp_blocks);
   else fv4_special_cell<V>(L, S, (int)blockIdx.x * (TI * TJ) + (int)threadIdx.y * TI + (int)threadIdx.x);
 }
 

@@ -43,7 +43,8 @@ struct Fv4TileArgs {
 enum { FV4_CHEBY = 0, FV4_GSRB = 1, FV4_JACOBI = 2, FV4_RESIDUAL = 3, FV4_APPLY = 4 };
 
 // the kernel's body; `block` = blockIdx.x (a device function so that the pre-pass of fv4_rb.hpp can run other work in the same launch)
-template <int V, int MODE, int TJ, int TI = 64>
+// GATHER: every operand of the bracket read up front with ds_read_b64 (fv4_math.hpp); false: named where the expression uses them (fewer registers)
+template <int V, int MODE, int TJ, int TI = 64, bool GATHER = (MODE != FV4_RESIDUAL)>
 __device__ __forceinline__ void fv4_tile_body(const hpgmg_hip_level &L, const Fv4TileArgs &P, int block) {
   constexpr int W = TI + 4, H = TJ + 4, NT = TI * TJ, PLANE = W * H;
   constexpr int NH = 4 * W + 4 * TJ;                           // halo cells of one plane tile (two rows above and below, two columns left and right)
@@ -180,25 +181,57 @@ __device__ __forceinline__ void fv4_tile_body(const hpgmg_hip_level &L, const Fv
     bool update = true;
     if (MODE == FV4_GSRB) update = (((i ^ j ^ k ^ colour000) & 1) == 0);
     if (update) {
-      using namespace fv4rb;
-      ldsr X0 = (ldsr)(sX + slot3(k) * PLANE + own_s), Xm = (ldsr)(sX + slot3(k - 1) * PLANE + own_s), Xp = (ldsr)(sX + slot3(k + 1) * PLANE + own_s);
-      ldsr I0 = (ldsr)(sBI + slot3(k) * PLANE + own_s), Im = (ldsr)(sBI + slot3(k - 1) * PLANE + own_s), Ip = (ldsr)(sBI + slot3(k + 1) * PLANE + own_s);
-      ldsr J0 = (ldsr)(sBJ + slot3(k) * PLANE + own_s), Jm = (ldsr)(sBJ + slot3(k - 1) * PLANE + own_s), Jp = (ldsr)(sBJ + slot3(k + 1) * PLANE + own_s);
-      ldsr K0 = (ldsr)(sBK + (k & 1) * PLANE + own_s), K1 = (ldsr)(sBK + ((k + 1) & 1) * PLANE + own_s);
-      // operators.fv4.c:87-108 (fv4_math.hpp): every operand read once, then the reference's expression tree
-      X25 x; BG1 g1; BG2 g2; Br18 br;
-      x.c = xc; x.im1 = X0[-1]; x.ip1 = X0[1]; x.im2 = X0[-2]; x.ip2 = X0[2];
-      x.jm1 = X0[-W]; x.jp1 = X0[W]; x.jm2 = X0[-2 * W]; x.jp2 = X0[2 * W];
-      x.km1 = xm1; x.kp1 = xp1; x.km2 = xm2; x.kp2 = xp2;
-      x.mm = X0[-1 - W]; x.pm = X0[1 - W]; x.mp = X0[-1 + W]; x.pp = X0[1 + W];
-      x.m_im = Xm[-1]; x.m_ip = Xm[1]; x.m_jm = Xm[-W]; x.m_jp = Xm[W];
-      x.p_im = Xp[-1]; x.p_ip = Xp[1]; x.p_jm = Xp[-W]; x.p_jp = Xp[W];
-      beta_g1<W>(g1, I0, Im, Ip, J0, Jm, Jp, K0, K1);
-      fv4_brackets(br, x);
-      beta_g2<W>(g2, I0, Im, Ip, J0, Jm, Jp, K0, K1);
-      double s1, s2;
-      fv4_combine_a(s1, s2, br, g1);
-      const double sum = fv4_combine_b(s1, s2, br, g2);
+      double sum;
+      if constexpr (GATHER) {
+        using namespace fv4rb;
+        ldsr X0 = (ldsr)(sX + slot3(k) * PLANE + own_s), Xm = (ldsr)(sX + slot3(k - 1) * PLANE + own_s), Xp = (ldsr)(sX + slot3(k + 1) * PLANE + own_s);
+        ldsr I0 = (ldsr)(sBI + slot3(k) * PLANE + own_s), Im = (ldsr)(sBI + slot3(k - 1) * PLANE + own_s), Ip = (ldsr)(sBI + slot3(k + 1) * PLANE + own_s);
+        ldsr J0 = (ldsr)(sBJ + slot3(k) * PLANE + own_s), Jm = (ldsr)(sBJ + slot3(k - 1) * PLANE + own_s), Jp = (ldsr)(sBJ + slot3(k + 1) * PLANE + own_s);
+        ldsr K0 = (ldsr)(sBK + (k & 1) * PLANE + own_s), K1 = (ldsr)(sBK + ((k + 1) & 1) * PLANE + own_s);
+        // operators.fv4.c:87-108 (fv4_math.hpp): every operand read once, then the reference's expression tree
+        X25 x; BG1 g1; BG2 g2; Br18 br;
+        x.c = xc; x.im1 = X0[-1]; x.ip1 = X0[1]; x.im2 = X0[-2]; x.ip2 = X0[2];
+        x.jm1 = X0[-W]; x.jp1 = X0[W]; x.jm2 = X0[-2 * W]; x.jp2 = X0[2 * W];
+        x.km1 = xm1; x.kp1 = xp1; x.km2 = xm2; x.kp2 = xp2;
+        x.mm = X0[-1 - W]; x.pm = X0[1 - W]; x.mp = X0[-1 + W]; x.pp = X0[1 + W];
+        x.m_im = Xm[-1]; x.m_ip = Xm[1]; x.m_jm = Xm[-W]; x.m_jp = Xm[W];
+        x.p_im = Xp[-1]; x.p_ip = Xp[1]; x.p_jm = Xp[-W]; x.p_jp = Xp[W];
+        beta_g1<W>(g1, I0, Im, Ip, J0, Jm, Jp, K0, K1);
+        fv4_brackets(br, x);
+        beta_g2<W>(g2, I0, Im, Ip, J0, Jm, Jp, K0, K1);
+        double s1, s2;
+        fv4_combine_a(s1, s2, br, g1);
+        sum = fv4_combine_b(s1, s2, br, g2);
+      } else {
+        // the residual forms carry the restriction / norm state as well, the pre-pass of the one-pass kernel the special-cell branch: with every operand
+        // read up front they need 170 / 132 registers (fewer waves per CU: measured 17 % / 27 % slower), so here the operands are named where the
+        // expression uses them, as in the first version (the same tree)
+        const double *X0 = sX + slot3(k) * PLANE + own_s, *Xm = sX + slot3(k - 1) * PLANE + own_s, *Xp = sX + slot3(k + 1) * PLANE + own_s;
+        const double *I0 = sBI + slot3(k) * PLANE + own_s, *Im = sBI + slot3(k - 1) * PLANE + own_s, *Ip = sBI + slot3(k + 1) * PLANE + own_s;
+        const double *J0 = sBJ + slot3(k) * PLANE + own_s, *Jm = sBJ + slot3(k - 1) * PLANE + own_s, *Jp = sBJ + slot3(k + 1) * PLANE + own_s;
+        const double *K0 = sBK + (k & 1) * PLANE + own_s, *K1 = sBK + ((k + 1) & 1) * PLANE + own_s;
+        // operators.fv4.c:87-93: six face terms
+        double s1 = I0[0] * (15.0 * (X0[-1] - xc) - (X0[-2] - X0[1]));
+        s1 = s1 + I0[1] * (15.0 * (X0[1] - xc) - (X0[2] - X0[-1]));
+        s1 = s1 + J0[0] * (15.0 * (X0[-W] - xc) - (X0[-2 * W] - X0[W]));
+        s1 = s1 + J0[W] * (15.0 * (X0[W] - xc) - (X0[2 * W] - X0[-W]));
+        s1 = s1 + K0[0] * (15.0 * (xm1 - xc) - (xm2 - xp1));
+        s1 = s1 + K1[0] * (15.0 * (xp1 - xc) - (xp2 - xm1));
+        // operators.fv4.c:95-108: twelve mixed terms, (beta+ - beta-) * (((x1 - x2) - x3) + x4)
+        double s2 = (I0[W] - I0[-W]) * (X0[-1 + W] - X0[W] - X0[-1 - W] + X0[-W]);
+        s2 = s2 + (Ip[0] - Im[0]) * (Xp[-1] - xp1 - Xm[-1] + xm1);
+        s2 = s2 + (J0[1] - J0[-1]) * (X0[-W + 1] - X0[1] - X0[-W - 1] + X0[-1]);
+        s2 = s2 + (Jp[0] - Jm[0]) * (Xp[-W] - xp1 - Xm[-W] + xm1);
+        s2 = s2 + (K0[1] - K0[-1]) * (Xm[1] - X0[1] - Xm[-1] + X0[-1]);
+        s2 = s2 + (K0[W] - K0[-W]) * (Xm[W] - X0[W] - Xm[-W] + X0[-W]);
+        s2 = s2 + (I0[1 + W] - I0[1 - W]) * (X0[1 + W] - X0[W] - X0[1 - W] + X0[-W]);
+        s2 = s2 + (Ip[1] - Im[1]) * (Xp[1] - xp1 - Xm[1] + xm1);
+        s2 = s2 + (J0[W + 1] - J0[W - 1]) * (X0[W + 1] - X0[1] - X0[W - 1] + X0[-1]);
+        s2 = s2 + (Jp[W] - Jm[W]) * (Xp[W] - xp1 - Xm[W] + xm1);
+        s2 = s2 + (K1[1] - K1[-1]) * (Xp[1] - X0[1] - Xp[-1] + X0[-1]);
+        s2 = s2 + (K1[W] - K1[-W]) * (Xp[W] - X0[W] - Xp[-W] + X0[-W]);
+        sum = FV4_TWELFTH * s1 + (0.25 * FV4_TWELFTH) * s2;
+      }
       const double Ax = kHelm ? (P.a * c_al) * xc - (P.b * P.h2inv) * sum : ((-P.b) * P.h2inv) * sum;
       double o;
       if (MODE == FV4_CHEBY)         o = xc + P.c1 * (xc - c_old) + P.c2 * c_dinv * (c_rhs - Ax);
