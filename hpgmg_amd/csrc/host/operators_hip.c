@@ -79,7 +79,12 @@ static int fused_residual_on(void) {
   return (int)hp_switch(SW_FUSED_RESIDUAL);
 }
 /* the operand of a fused residual form is made ready: 7-point -- nothing (the kernel applies the Dirichlet rule and reads neighbouring boxes);
- * 27-point / fv4 -- the domain-boundary ghost cells (the tiled kernel reads neighbouring boxes itself).  0 = the level does not qualify. */
+ * 27-point / fv4 -- the domain-boundary ghost cells (the tiled kernel reads neighbouring boxes itself).  0 = the level does not qualify;
+ * 2 = x is crossing faces to other ranks on the exchange stream: FUSED_LAUNCH issues the pass as the tiles that touch no such face, the wait, the others. */
+#define FUSED_LAUNCH(READY, CALL) do {                                                                          \
+    if ((READY) == 2) {                                                                                          \
+      hpgmg_hip_set_tile_part(1); HIP_OK(CALL); hp_overlap_end(); hpgmg_hip_set_tile_part(2); HIP_OK(CALL); hpgmg_hip_set_tile_part(0); \
+    } else HIP_OK(CALL); } while (0)
 static int fused_residual_operand(level_type *L, backend_t *B, int x_id) {
   hpgmg_config cfg;
   hpgmg_get_config(&cfg);
@@ -93,8 +98,9 @@ static int fused_residual_operand(level_type *L, backend_t *B, int x_id) {
     if (shape != STENCIL_SHAPE_STAR || (long long)L->num_my_boxes * L->box_dim * L->box_dim * L->box_dim < hp_switch(SW_PAIR_MIN_CELLS)) return 0;
     hpgmg_hip_set_ghost_free(1);
     if (!hpgmg_hip_residual_fused_supported(&B->dev, hp_variant())) return 0;
-    hp_ghosts_for_stencil(L, x_id, -1);
     fused_residuals_remote++;
+    if (hp_overlap_begin(L, x_id)) return 2;      /* the exchange runs on the second stream: the caller launches the pass in its two parts */
+    hp_ghosts_for_stencil(L, x_id, -1);
     return 1;
   }
   if (!B->all_faces_local) {           /* 27-point / fv4 with boxes on other ranks: the same pass on the table with their images */
@@ -128,9 +134,10 @@ int hp_residual_restrict_zero_fused(level_type *Lc, int id_c, level_type *Lf, in
   backend_t *Bc = hp_backend_of(Lc), *Bf = hp_backend_of(Lf);
   if (!restrict_map_of(Lf, Bf)) return 0;
   { hpgmg_config cfg; hpgmg_get_config(&cfg); if (res_id >= 0 && (cfg.op != HPGMG_OP_7PT || res_id == x_id || res_id == rhs_id)) return 0; }
-  if (!fused_residual_operand(Lf, Bf, x_id)) return 0;
+  const int ready = fused_residual_operand(Lf, Bf, x_id);
+  if (!ready) return 0;
   TICK(Lf, residual, "residual + restriction + zero_vector (fused)");
-  HIP_OK(hpgmg_hip_residual_restrict_store(hp_stencil_dev(Bf), hp_variant(), res_id, x_id, rhs_id, a, b, 1.0 / (Lf->h * Lf->h), &Bc->dev, id_c, Bf->d_restrict_map, zero_id));
+  FUSED_LAUNCH(ready, hpgmg_hip_residual_restrict_store(hp_stencil_dev(Bf), hp_variant(), res_id, x_id, rhs_id, a, b, 1.0 / (Lf->h * Lf->h), &Bc->dev, id_c, Bf->d_restrict_map, zero_id));
   TOCK();
   return 1;
 }
@@ -160,10 +167,11 @@ int hpgmg_residual_norm_fused(level_type *L, int res_id, int x_id, int rhs_id, d
   if (cfg.op != HPGMG_OP_7PT && res_id >= 0) return 0;          /* the tiled kernels of the other plugins only carry the norm-only form */
   if (!L->active || L->num_my_boxes < 1) return 0;
   backend_t *B = hp_backend_of(L);
-  if (!fused_residual_operand(L, B, x_id)) return 0;
+  const int ready = fused_residual_operand(L, B, x_id);
+  if (!ready) return 0;
   double v = 0.0;
   { TICK(L, residual, "residual + norm (fused)");
-    HIP_OK(hpgmg_hip_residual_norm(hp_stencil_dev(B), hp_variant(), res_id, x_id, rhs_id, a, b, 1.0 / (L->h * L->h), &v));
+    FUSED_LAUNCH(ready, hpgmg_hip_residual_norm(hp_stencil_dev(B), hp_variant(), res_id, x_id, rhs_id, a, b, 1.0 / (L->h * L->h), &v));
     TOCK(); }
   *norm_out = hp_allreduce_scalar(L, v, HPGMG_REDUCE_MAX);
   return 1;

@@ -156,7 +156,8 @@ __global__ __launch_bounds__(64 * WJ) void stencil7_wide_kernel(const hpgmg_hip_
     for (int q = lo + (int)(threadIdx.y * 64 + threadIdx.x); q < hi; q += 64 * WJ) v[q] = 0.0;
     return;
   }
-  const int logical = xcd_logical_block((int)blockIdx.x, P.per_xcd);
+  int logical = xcd_logical_block((int)blockIdx.x, P.per_xcd);
+  if (P.order) logical = P.order[logical];
   if (logical >= P.total_blocks) return;
   int t = logical;
   const int ti = t % P.tiles_i; t /= P.tiles_i;
@@ -806,7 +807,15 @@ static int launch_wide_fused(const hpgmg_hip_level *L, int variant, StencilArgs 
   P.tiles_i = L->dim / 128; P.tiles_j = L->dim / (2 * wj); P.kchunk = 16; P.chunks_k = (L->dim + 15) / 16;
   F.compute_blocks = L->num_boxes * P.chunks_k * P.tiles_j * P.tiles_i;
   P.total_blocks = F.compute_blocks;
-  const int grid = grid_for(P.total_blocks, &P.per_xcd) + extra_blocks;      // the extra (zeroing) workgroups follow the stencil grid
+  int grid = grid_for(P.total_blocks, &P.per_xcd);
+  if (g_tile_part) {       // one part of the launch (faces on other ranks): part 1 = the tiles at no remote face, under the exchange; part 2 = the others, and the zeroing
+    int count = 0;
+    P.order = tile_part_order(L, P.tiles_i, P.tiles_j, P.chunks_k, g_tile_part, false, &grid, &P.per_xcd, &count);
+    if (g_tile_part == 1) extra_blocks = 0;
+    if (grid == 0 && extra_blocks == 0) return 0;
+    if (grid > 0 && !P.order) return record_error(hipErrorOutOfMemory, "fused residual: dispatch list of a partial launch");
+  }
+  grid += extra_blocks;                                                      // the extra (zeroing) workgroups follow the stencil grid
   switch (variant) {
     case HPGMG_HIP_7PT_VC_HELMHOLTZ: hipLaunchKernelGGL((stencil7_wide_kernel<HPGMG_HIP_7PT_VC_HELMHOLTZ, MODE, wj>), dim3(grid), dim3(64, wj), 0, g_stream, *L, P, F); break;
     case HPGMG_HIP_7PT_VC_POISSON:   hipLaunchKernelGGL((stencil7_wide_kernel<HPGMG_HIP_7PT_VC_POISSON, MODE, wj>), dim3(grid), dim3(64, wj), 0, g_stream, *L, P, F); break;
@@ -992,6 +1001,7 @@ int hpgmg_hip_residual_norm(const hpgmg_hip_level *L, int variant, int res_id, i
   if (res_id < 0) P.xout_id = x_id;
   if (!F.partials) return record_error(hipErrorOutOfMemory, "residual_norm: scratch");
   if (int e = launch_wide_fused<MODE_RESIDUAL_NORM>(L, variant, P, F, 0)) return e;
+  if (g_tile_part == 1) return 0;                 // the first part of a two-part launch: the tiles of the second part have not written their maxima yet
   return finish_max_reduction(blocks, 0.0, norm_out);
 }
 

@@ -38,6 +38,8 @@ struct StencilArgs {
   int ghost_free;               // read face neighbours from the adjacent box / apply the Dirichlet BC in registers
   int defer;                    // 1: leave the cells next to a face owned by another rank untouched (their ghost values are still
                                 //    in flight); stencil7_shell_kernel computes them once the exchange has landed
+  const int *order;             // stencil7_wide_kernel, fused residual forms across rank boundaries: dispatch slot -> tile (nullptr: identity) of a
+                                //    two-part launch (common.hpp tile_part_order): the tiles at a remote face run after the exchange has landed
 };
 
 // x may alias the output only for in-place GSRB; everywhere else it is restrict-qualified
