@@ -118,6 +118,17 @@ def test_config3_multirank_switches(variant, gold_key, env):
             assert r["stats"]["image_exchanges"] > 20 and r["stats"]["overlapped_exchanges"] == 0, r["stats"]
 
 
+def test_7pt_multirank_without_overlap():
+    """HPGMG_OVERLAP=0 on the 7-point path: the sweep pairs' two-deep exchange and the exchange in front of the fused residual passes run in line on the
+    launch stream (whole launches instead of two parts) -- the same numbers, and no exchange may have been counted as overlapped."""
+    gold = GOLD["7pt-cheby-helm 7 8"]
+    res = run_job(2, "7pt-cheby-helm", 7, 4, backend="hip", extra_env={"HPGMG_OVERLAP": "0"})
+    assert res[0]["norms"] == gold["norms"], res[0]
+    assert res[0]["err"] == gold["richardson_error"] and res[0]["order"] == gold["order"]
+    for r in res:
+        assert r["stats"]["pair_remote_smooths"] >= 8 and r["stats"]["fused_residuals_remote"] >= 8 and r["stats"]["overlapped_exchanges"] == 0, r["stats"]
+
+
 @pytest.mark.parametrize("world,variant,log2,per_rank,gold_key,gather", [
     (2, "7pt-cheby-helm", 4, 4, "7pt-cheby-helm 4 8", 16),
     (4, "7pt-cheby", 4, 8, "7pt-cheby 4 27", 24),
