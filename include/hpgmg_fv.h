@@ -93,6 +93,10 @@ long long   hpgmg_small_ops_prefetched(void);  /* scalars answered from a value 
 void        hpgmg_set_fused_bottom(int on);    /* 0: the bottom solve driven from the host (BiCGStab of host/solvers.c through the operators; tests) */
 void        hpgmg_set_fused_tail(int on);      /* 0: no single-launch V-/F-cycle tails (7-pt: kernels/tail.hip; tests) */
 long long   hpgmg_pair_remote_smooths(void);   /* smooth() calls executed as sweep pairs with faces owned by other ranks (tests) */
+long long   hpgmg_fused_residuals_remote(void); /* 7-point: fused residual passes (residual + restriction, residual + norm) run on levels with faces owned by other ranks (tests) */
+long long   hpgmg_fv4_rb_smooths(void);        /* fv4: smooth() calls run as one-pass red + black sweeps; hpgmg_rb27_passes(): such passes of the 27-point smoother (tests) */
+long long   hpgmg_rb27_passes(void);
+long long   hpgmg_image_exchanges(void);       /* 27-point / fv4 across ranks: refreshes of the images of the neighbouring ranks' boxes (tests) */
 /* level->timers after settling pending device timers: smooth, residual, apply_op, blas1, boundary_conditions, restriction_total,
  * interpolation_total, ghostZone_total, Total (seconds since MGResetTimers; reference level.h:162-196) */
 void        hpgmg_level_timers(level_type *level, double out[9]);
