@@ -332,10 +332,11 @@ def main():
             bytes_per_launch = (smoother[1] if fused else smoother[0] * sweeps_per_launch) * fine_cells
             achieved = bytes_per_launch / avg_s / 1e9
             unfused = smoother[0] * sweeps_per_launch * fine_cells / avg_s / 1e9
-            traffic, traffic_source = pmc_traffic(args.workload, int(fine_cells)) if world == 1 else (None, None)
-            if world > 1:      # the single-GPU counter summary of the same kernel, scaled to the cells this rank owns (the launch has the same structure per cell)
-                whole, traffic_source = pmc_traffic(args.workload, None)
-                one_gpu_cells = {"config2": 256 ** 3, "config5": 256 ** 3, "config3-fv4": 512 ** 3, "config3-27pt": 512 ** 3}.get(args.workload)
+            scaled = world > 1 or args.workload == "config4"
+            traffic, traffic_source = pmc_traffic(args.workload, int(fine_cells)) if not scaled else (None, None)
+            if scaled:         # the single-GPU counter summary of the same kernel, scaled to the cells this launch covers (the launch has the same structure per cell): N > 1, and config 4 = config 2's kernel on 512^3
+                whole, traffic_source = pmc_traffic("config2" if args.workload == "config4" else args.workload, None)
+                one_gpu_cells = {"config2": 256 ** 3, "config4": 256 ** 3, "config5": 256 ** 3, "config3-fv4": 512 ** 3, "config3-27pt": 512 ** 3}.get(args.workload)
                 traffic = whole * fine_cells / one_gpu_cells if (whole and one_gpu_cells) else None
                 if traffic is None:
                     traffic_source = None
@@ -345,7 +346,8 @@ def main():
               roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                       "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                       "traffic_note": ("PMC bytes per launch from the committed summary named in traffic_source: ANOTHER run (and possibly build) of the same command, not this one"
-                                       + ("; a single-GPU figure scaled to the cells this rank owns" if world > 1 else "")) if traffic else None,
+                                       + ("; a single-GPU figure scaled to the cells this rank owns" if world > 1 else "")
+                                       + ("; the 256^3 figure of the same kernel scaled to 512^3" if (world == 1 and args.workload == "config4") else "")) if traffic else None,
                       "kernel": smoother[2] + f" over the {my_boxes} finest-level boxes of {box_dim}^3 of this rank",
                       "sweeps_per_launch": round(sweeps_per_launch, 3),
                       "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_us": round(avg_s * 1e6, 2),
