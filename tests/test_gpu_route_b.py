@@ -78,3 +78,27 @@ def test_reference_mgsolve_runs_on_the_hip_plugin(variant, args):
     assert len(a) > 50 and a == b, [x for x in zip(a, b) if x[0] != x[1]][:4]
     m = re.search(r"hpgmg lazy queue: (\d+) single-launch legs, (\d+) fused large-level units, (\d+) smooths with VECTOR_TEMP proved dead", outs[0].stderr)
     assert m and int(m.group(1)) > 0 and int(m.group(3)) > 0, outs[0].stderr[-500:]
+
+
+@pytest.mark.parametrize("variant,args", [("7pt-cheby-helm-mgpcg", "5 8"), ("7pt-cheby-helm-mgpcg", "6 8"), ("27pt-gsrb-mgpcg", "5 8")])
+def test_reference_mgpcg_runs_on_the_hip_plugin(variant, args):
+    """The reference's THIRD driver of the plugin, which its own main() never calls: MGPCG (mg.c:1500-1605), conjugate gradients preconditioned by
+    one V-cycle per iteration.  oracle/mgpcg_harness.c is our main() around it; built once with the reference's operators (the reference itself) and
+    once with the reference's mg.c / solvers.c on the product plugin.  It asks things of a plugin the F-cycle never does: every level grows by three
+    vectors after MGBuild (create_vectors through the storage hooks), MGVCycle runs on vector ids beyond VECTORS_RESERVED, and dot() on the FINE
+    level decides alpha and beta -- so every printed digit depends on the plugin summing in the reference's order (its single-thread order:
+    OMP_NUM_THREADS=1 for the reference binary)."""
+    routeb = os.path.join(ROOT, "oracle", "_ref", "routeb-" + variant)
+    ref = os.path.join(ROOT, "oracle", "_ref", "hpgmg-" + variant)
+    if not (os.path.exists(routeb) and os.path.exists(ref)):
+        pytest.skip("oracle/_ref/*-mgpcg not built (needs /root/reference: make -C oracle ref)")
+    outs = []
+    for exe, threads in ((routeb, "8"), (ref, "1")):
+        out = subprocess.run([exe] + args.split(), capture_output=True, text=True, env=dict(os.environ, OMP_NUM_THREADS=threads, HPGMG_LAZY_REPORT="1"), timeout=900)
+        assert out.returncode == 0, out.stderr[-2000:]
+        outs.append(out)
+    keep = lambda o: re.findall(r"(iter=\s*\d+\s+norm=\S+\s+rel=\S+|MGPCG solve \d: norm\(u\)=\S+\s+Krylov iterations on the fine level so far=\d+|MGPCG dot\(u,f\)=\S+\s+mean\(u\)=\S+)", o.stdout)
+    a, b = keep(outs[0]), keep(outs[1])
+    assert len(a) >= 10 and a == b, [x for x in zip(a, b) if x[0] != x[1]][:4]
+    m = re.search(r"hpgmg lazy queue: (\d+) single-launch legs, (\d+) fused large-level units, (\d+) smooths with VECTOR_TEMP proved dead", outs[0].stderr)
+    assert m and int(m.group(1)) + int(m.group(2)) + int(m.group(3)) > 0, outs[0].stderr[-500:]      # the V-cycles inside still went through the operator queue
