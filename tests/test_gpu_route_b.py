@@ -102,3 +102,23 @@ def test_reference_mgpcg_runs_on_the_hip_plugin(variant, args):
     assert len(a) >= 10 and a == b, [x for x in zip(a, b) if x[0] != x[1]][:4]
     m = re.search(r"hpgmg lazy queue: (\d+) single-launch legs, (\d+) fused large-level units, (\d+) smooths with VECTOR_TEMP proved dead", outs[0].stderr)
     assert m and int(m.group(1)) + int(m.group(2)) + int(m.group(3)) > 0, outs[0].stderr[-500:]      # the V-cycles inside still went through the operator queue
+
+
+@pytest.mark.parametrize("variant,args", [("7pt-cheby-cgbottom", "4 27"), ("7pt-cheby-cgbottom", "5 8"), ("27pt-gsrb-cgbottom", "4 27")])
+def test_reference_cg_bottom_solver_runs_on_the_hip_plugin(variant, args):
+    """The reference built with -DUSE_CG instead of -DUSE_BICGSTAB: its other host-driven bottom solver (solvers/cg.c: diagonally preconditioned
+    CG, five extra vectors, a different sequence of residual / mul_vectors / dot / add_vectors / apply_op calls through the plugin's small-operator
+    queue).  `4 27` has a 3^3-cell bottom level, so the solver really iterates.  Every pinned line must equal the reference binary's (one OpenMP
+    thread there: the bottom level's dot products are sums of a few cells, but the fine-level ones of other paths are not)."""
+    routeb = os.path.join(ROOT, "oracle", "_ref", "routeb-" + variant)
+    ref = os.path.join(ROOT, "oracle", "_ref", "hpgmg-" + variant)
+    if not (os.path.exists(routeb) and os.path.exists(ref)):
+        pytest.skip("oracle/_ref/*-cgbottom not built (needs /root/reference: make -C oracle ref)")
+    outs = []
+    for exe, threads in ((routeb, "8"), (ref, "1")):
+        out = subprocess.run([exe] + args.split(), capture_output=True, text=True, env=dict(os.environ, OMP_NUM_THREADS=threads), timeout=900)
+        assert out.returncode == 0, out.stderr[-2000:]
+        outs.append(out)
+    keep = lambda o: re.findall(r"(f-cycle\s+norm=\S+\s+rel=\S+|\|\|error\|\|=\S+|order=\S+|eigenvalue_max<\S+|Bottom solver iterations\s+\d+)", o.stdout)
+    a, b = keep(outs[0]), keep(outs[1])
+    assert len(a) > 60 and a == b, [x for x in zip(a, b) if x[0] != x[1]][:4]
