@@ -122,3 +122,21 @@ def test_reference_cg_bottom_solver_runs_on_the_hip_plugin(variant, args):
     keep = lambda o: re.findall(r"(f-cycle\s+norm=\S+\s+rel=\S+|\|\|error\|\|=\S+|order=\S+|eigenvalue_max<\S+|Bottom solver iterations\s+\d+)", o.stdout)
     a, b = keep(outs[0]), keep(outs[1])
     assert len(a) > 60 and a == b, [x for x in zip(a, b) if x[0] != x[1]][:4]
+
+
+@pytest.mark.parametrize("variant,args", [("7pt-cheby-periodic", "5 8"), ("7pt-gsrb-periodic", "5 8"), ("7pt-cheby-periodic", "4 27")])
+def test_reference_periodic_build_runs_on_the_hip_plugin(variant, args):
+    """The reference built with -DUSE_PERIODIC_BC (its driver then removes the mean of f and of every iterate: mean() / shift_vector() inside the
+    cycle, hpgmg-fv.c:296-302, mg.c:1176) on the plugin: the same pinned lines as the reference binary (one OpenMP thread there: mean() is a sum
+    over the fine level)."""
+    routeb = os.path.join(ROOT, "oracle", "_ref", "routeb-" + variant)
+    ref = os.path.join(ROOT, "oracle", "_ref", "hpgmg-" + variant)
+    if not (os.path.exists(routeb) and os.path.exists(ref)):
+        pytest.skip("oracle/_ref/*-periodic not built (needs /root/reference: make -C oracle ref)")
+    outs = []
+    for exe, threads in ((routeb, "8"), (ref, "1")):
+        out = subprocess.run([exe] + args.split(), capture_output=True, text=True, env=dict(os.environ, OMP_NUM_THREADS=threads), timeout=900)
+        assert out.returncode == 0, out.stderr[-2000:]
+        outs.append(out)
+    a, b = pinned(outs[0].stdout), pinned(outs[1].stdout)
+    assert len(a) > 60 and a == b, [x for x in zip(a, b) if x[0] != x[1]][:4]
