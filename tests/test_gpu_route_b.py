@@ -140,3 +140,20 @@ def test_reference_periodic_build_runs_on_the_hip_plugin(variant, args):
         outs.append(out)
     a, b = pinned(outs[0].stdout), pinned(outs[1].stdout)
     assert len(a) > 60 and a == b, [x for x in zip(a, b) if x[0] != x[1]][:4]
+
+
+@pytest.mark.parametrize("variant,args", [("7pt-jacobi", "5 8"), ("fv4-cheby", "5 8"), ("27pt-cheby", "5 8"), ("7pt-jacobi", "4 27")])
+def test_reference_other_smoothers_run_on_the_hip_plugin(variant, args):
+    """The remaining smoother / operator pairs the reference can be built with (-DUSE_JACOBI on the 7-point operator, -DUSE_CHEBY on the 4th-order
+    and the 27-point ones) through the reference's own driver on the plugin: the pinned lines of the reference binary."""
+    routeb = os.path.join(ROOT, "oracle", "_ref", "routeb-" + variant)
+    ref = os.path.join(ROOT, "oracle", "_ref", "hpgmg-" + variant)
+    if not (os.path.exists(routeb) and os.path.exists(ref)):
+        pytest.skip("oracle/_ref/routeb-" + variant + " not built (needs /root/reference: make -C oracle ref)")
+    outs = []
+    for exe, threads in ((routeb, "8"), (ref, "1")):
+        out = subprocess.run([exe] + args.split(), capture_output=True, text=True, env=dict(os.environ, OMP_NUM_THREADS=threads), timeout=900)
+        assert out.returncode == 0, out.stderr[-2000:]
+        outs.append(out)
+    a, b = pinned(outs[0].stdout), pinned(outs[1].stdout)
+    assert len(a) > 60 and a == b, [x for x in zip(a, b) if x[0] != x[1]][:4]
