@@ -18,7 +18,7 @@ GOLD = load_golden("fcycle_norms.json")
 def pinned(out):
     keep = []
     for line in out.splitlines():
-        m = re.search(r"(f-cycle\s+norm=\S+\s+rel=\S+|\|\|error\|\|=\S+|order=\S+|eigenvalue_max<\S+)", line)
+        m = re.search(r"(f-cycle\s+norm=\S+\s+rel=\S+|v-cycle=\s*\d+\s+norm=\S+\s+rel=\S+|\|\|error\|\|=\S+|order=\S+|eigenvalue_max<\S+)", line)
         if m:
             keep.append(m.group(1))
     return keep
@@ -142,7 +142,8 @@ def test_reference_periodic_build_runs_on_the_hip_plugin(variant, args):
     assert len(a) > 60 and a == b, [x for x in zip(a, b) if x[0] != x[1]][:4]
 
 
-@pytest.mark.parametrize("variant,args", [("7pt-jacobi", "5 8"), ("fv4-cheby", "5 8"), ("27pt-cheby", "5 8"), ("7pt-jacobi", "4 27")])
+@pytest.mark.parametrize("variant,args", [("7pt-jacobi", "5 8"), ("fv4-cheby", "5 8"), ("27pt-cheby", "5 8"), ("7pt-jacobi", "4 27"),
+                                          ("7pt-cheby-unlimit", "5 8")])      # -DUNLIMIT_FMG_ITERATIONS: the F-cycle followed by V-cycles until converged (mg.c:1239-1247)
 def test_reference_other_smoothers_run_on_the_hip_plugin(variant, args):
     """The remaining smoother / operator pairs the reference can be built with (-DUSE_JACOBI on the 7-point operator, -DUSE_CHEBY on the 4th-order
     and the 27-point ones) through the reference's own driver on the plugin: the pinned lines of the reference binary."""
