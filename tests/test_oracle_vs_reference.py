@@ -60,6 +60,20 @@ def test_reference_driver_with_our_operators_prints_reference_numbers(ref_build,
     assert ref == hyb
 
 
+@pytest.mark.parametrize("variant,args", [("7pt-cheby-helm-mgpcg", "4 8"), ("27pt-gsrb-mgpcg", "4 8"), ("7pt-cheby-cgbottom", "4 27"), ("7pt-cheby-periodic", "4 8"),
+                                          ("7pt-cheby-vcycle", "4 8"), ("7pt-cheby-unlimit", "4 8")])
+def test_the_reference_s_other_drivers_with_our_operators(ref_build, variant, args):
+    """The restatement under the callers the F-cycle build never reaches: MGPCG (oracle/mgpcg_harness.c around mg.c:1500: fine-level dot
+    products decide every digit), the CG bottom solver (-DUSE_CG), the periodic build (mean / shift_vector in the cycle), MGSolve (no
+    -DUSE_FCYCLES) and -DUNLIMIT_FMG_ITERATIONS.  One OpenMP thread on both sides: the reference's sums move with its thread count."""
+    def lines(binary):
+        out = subprocess.run([binary] + args.split(), capture_output=True, text=True, env=cli_env("1"), check=True).stdout
+        return re.findall(r"(f-cycle\s+norm=\S+\s+rel=\S+|v-cycle=\s*\d+\s+norm=\S+\s+rel=\S+|iter=\s*\d+\s+norm=\S+\s+rel=\S+|MGPCG solve \d: \S+.*|MGPCG dot.*|"
+                          r"\|\|error\|\|=\S+|order=\S+|eigenvalue_max<\S+|Bottom solver iterations\s+\d+)", out)
+    ref, hyb = lines(os.path.join(ref_build, "hpgmg-" + variant)), lines(os.path.join(ref_build, "hybrid-" + variant))
+    assert len(ref) >= 10 and ref == hyb, [x for x in zip(ref, hyb) if x[0] != x[1]][:4]
+
+
 def _masked(text):
     """stdout with every timing figure (and the one line naming threads / backend) replaced: what a log parser keys on stays"""
     import re
