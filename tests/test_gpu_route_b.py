@@ -143,7 +143,8 @@ def test_reference_periodic_build_runs_on_the_hip_plugin(variant, args):
 
 
 @pytest.mark.parametrize("variant,args", [("7pt-jacobi", "5 8"), ("fv4-cheby", "5 8"), ("27pt-cheby", "5 8"), ("7pt-jacobi", "4 27"),
-                                          ("7pt-cheby-unlimit", "5 8")])      # -DUNLIMIT_FMG_ITERATIONS: the F-cycle followed by V-cycles until converged (mg.c:1239-1247)
+                                          ("7pt-cheby-unlimit", "5 8"),       # -DUNLIMIT_FMG_ITERATIONS: the F-cycle followed by V-cycles until converged (mg.c:1239-1247)
+                                          ("7pt-cheby-ucycle", "5 8"), ("fv4-gsrb-ucycle", "5 8")])      # -DUSE_UCYCLES: MGBuild does not agglomerate, the host-driven bottom solver runs on a level of eight boxes (mg.c:878-893)
 def test_reference_other_smoothers_run_on_the_hip_plugin(variant, args):
     """The remaining smoother / operator pairs the reference can be built with (-DUSE_JACOBI on the 7-point operator, -DUSE_CHEBY on the 4th-order
     and the 27-point ones) through the reference's own driver on the plugin: the pinned lines of the reference binary."""

@@ -61,11 +61,11 @@ def test_reference_driver_with_our_operators_prints_reference_numbers(ref_build,
 
 
 @pytest.mark.parametrize("variant,args", [("7pt-cheby-helm-mgpcg", "4 8"), ("27pt-gsrb-mgpcg", "4 8"), ("7pt-cheby-cgbottom", "4 27"), ("7pt-cheby-periodic", "4 8"),
-                                          ("7pt-cheby-vcycle", "4 8"), ("7pt-cheby-unlimit", "4 8")])
+                                          ("7pt-cheby-vcycle", "4 8"), ("7pt-cheby-unlimit", "4 8"), ("7pt-cheby-ucycle", "4 8"), ("fv4-gsrb-ucycle", "4 8")])
 def test_the_reference_s_other_drivers_with_our_operators(ref_build, variant, args):
     """The restatement under the callers the F-cycle build never reaches: MGPCG (oracle/mgpcg_harness.c around mg.c:1500: fine-level dot
     products decide every digit), the CG bottom solver (-DUSE_CG), the periodic build (mean / shift_vector in the cycle), MGSolve (no
-    -DUSE_FCYCLES) and -DUNLIMIT_FMG_ITERATIONS.  One OpenMP thread on both sides: the reference's sums move with its thread count."""
+    -DUSE_FCYCLES), -DUNLIMIT_FMG_ITERATIONS and -DUSE_UCYCLES (no agglomeration: the bottom solver works on a level of eight boxes).  One OpenMP thread on both sides: the reference's sums move with its thread count."""
     def lines(binary):
         out = subprocess.run([binary] + args.split(), capture_output=True, text=True, env=cli_env("1"), check=True).stdout
         return re.findall(r"(f-cycle\s+norm=\S+\s+rel=\S+|v-cycle=\s*\d+\s+norm=\S+\s+rel=\S+|iter=\s*\d+\s+norm=\S+\s+rel=\S+|MGPCG solve \d: \S+.*|MGPCG dot.*|"
