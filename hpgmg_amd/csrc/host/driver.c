@@ -153,7 +153,7 @@ void hpgmg_solver_richardson(hpgmg_solver *s, double out[2]) {
 /* ------------------------------------------------------------------ CLI */
 static int usage(int rank) {
   if (rank == 0) fprintf(stderr,
-    "usage: hpgmg-fv [--op 7pt|27pt|fv4|fv2] [--smoother cheby|gsrb|jacobi] [--helmholtz] [--const-coeff] [--fp32-smoother] [--periodic]\n"
+    "usage: hpgmg-fv [--op 7pt|27pt|fv4|fv2] [--smoother cheby|gsrb|jacobi] [--helmholtz] [--const-coeff] [--fp32-smoother] [--periodic] [--mgpcg]\n"
     "                [--warmup N] [--solves N] [--rank R --ranks N]  log2_box_dim  target_boxes_per_rank\n");
   return 0;
 }
@@ -161,7 +161,7 @@ static int usage(int rank) {
 int hpgmg_fv_main(int argc, char **argv) {
   hpgmg_config cfg = { HPGMG_OP_7PT, HPGMG_SMOOTH_CHEBY, 0, 1 };
   int bc = BC_DIRICHLET;
-  int pos[2], npos = 0, a, my_rank = 0, num_ranks = 1, warmup = 10, solves = 10, test_error_only = 0;
+  int pos[2], npos = 0, a, my_rank = 0, num_ranks = 1, warmup = 10, solves = 10, test_error_only = 0, mgpcg = 0;
   const hpgmg_transport *T = hpgmg_get_transport();
   if (T) { my_rank = T->rank; num_ranks = T->size; }
   for (a = 1; a < argc; a++) {
@@ -176,6 +176,7 @@ int hpgmg_fv_main(int argc, char **argv) {
     else if (!strcmp(argv[a], "--fp32-smoother")) hpgmg_set_smoother_precision(32);
     else if (!strcmp(argv[a], "--periodic")) bc = BC_PERIODIC;                       /* the reference's -DUSE_PERIODIC_BC */
     else if (!strcmp(argv[a], "--test-error")) test_error_only = 1;
+    else if (!strcmp(argv[a], "--mgpcg")) mgpcg = 1;                                 /* the reference's third driver (mg.c:1500), which its main() never calls: two solves, then exit */
     else if (!strcmp(argv[a], "--warmup") && a + 1 < argc) warmup = atoi(argv[++a]);
     else if (!strcmp(argv[a], "--solves") && a + 1 < argc) solves = atoi(argv[++a]);
     else if (npos < 2 && argv[a][0] != '-') pos[npos++] = atoi(argv[a]);
@@ -199,6 +200,17 @@ int hpgmg_fv_main(int argc, char **argv) {
   enum { DYNAMIC_RANGE = 3 };
   double avg[DYNAMIC_RANGE];
   int l, n;
+  if (mgpcg) {                     /* what oracle/mgpcg_harness.c prints around the reference's MGPCG */
+    level_type *L0 = s->mg.levels[0];
+    for (n = 0; n < 2; n++) {
+      MGPCG(&s->mg, 0, VECTOR_U, VECTOR_F, s->a, s->b, 1e-10);
+      SAY(my_rank, "MGPCG solve %d: norm(u)=%1.15e  Krylov iterations on the fine level so far=%d\n", n, norm(L0, VECTOR_U), L0->Krylov_iterations);
+    }
+    const double uf = dot(L0, VECTOR_U, VECTOR_F), mu = mean(L0, VECTOR_U);
+    SAY(my_rank, "MGPCG dot(u,f)=%1.15e  mean(u)=%1.15e\n", uf, mu);
+    hpgmg_solver_destroy(s);
+    return 0;
+  }
   if (!test_error_only) {
     for (l = 0; l < DYNAMIC_RANGE; l++) {
       hpgmg_solver_restrict_rhs(s, l);

@@ -525,6 +525,63 @@ void MGSolve(mg_type *G, int onLevel, int u_id, int F_id, double a, double b, do
   SAY(L->my_rank, "done (%f seconds)\n", now() - t0);
 }
 
+/* Conjugate gradients preconditioned with one V-cycle per iteration (reference mg.c:1500-1605; Saad, Iterative Methods for Sparse Linear
+ * Systems, algorithm 9.1 with M^-1 = MGVCycle).  Every level gets three more vectors (p, Ap, z) the first time; the residual test uses the
+ * TRUE residual F - A x after every update (mg.c:1579-1580), what is printed is what the reference prints.  The operator calls and their
+ * order are the reference's, so the iterates -- which hang on dot products over the fine level -- are too. */
+void MGPCG(mg_type *G, int onLevel, int x_id, int F_id, double a, double b, double rtol) {
+  level_type *L = G->levels[onLevel];
+  const int r_id = VECTOR_R, p_id = hpgmg_vectors_reserved(), Ap_id = p_id + 1, z_id = p_id + 2, jMax = 20;
+  int l, j = 0, failed = 0, converged = 0;
+  if (!L->active) return;
+  for (l = 0; l < G->num_levels; l++) create_vectors(G->levels[l], hpgmg_vectors_reserved() + 3);
+  SAY(L->my_rank, "MGPCG...  ");
+  const double t0 = now();
+  seg_reset(G, onLevel + 128, x_id, F_id, a, b);
+  G->MGSolves_performed++;
+  zero_vector(L, x_id);
+  residual(L, r_id, x_id, F_id, a, b);
+  if (L->must_subtract_mean == 1) { const double m = mean(L, r_id); shift_vector(L, r_id, r_id, -m); }
+  const double norm_of_r0 = norm(L, r_id);
+  if (norm_of_r0 == 0.0) converged = 1;                                   /* entered with the exact solution */
+  L->vcycles_from_this_level++;
+  zero_vector(L, z_id);
+  MGVCycle(G, z_id, r_id, a, b, onLevel);                                 /* z = M^-1 r */
+  seg_close();
+  scale_vector(L, p_id, 1.0, z_id);
+  double r_dot_z = dot(L, r_id, z_id);
+  while (j < jMax && !failed && !converged) {
+    j++; L->Krylov_iterations++;
+    apply_op(L, Ap_id, p_id, a, b);
+    const double Ap_dot_p = dot(L, Ap_id, p_id);
+    if (Ap_dot_p == 0.0) { failed = 1; break; }                           /* pivot breakdown */
+    const double alpha = r_dot_z / Ap_dot_p;
+    if (isinf(alpha)) { failed = 1; break; }
+    add_vectors(L, x_id, 1.0, x_id, alpha, p_id);
+    add_vectors(L, r_id, 1.0, r_id, -alpha, Ap_id);
+    if (L->must_subtract_mean == 1) { const double m = mean(L, r_id); shift_vector(L, r_id, r_id, -m); }
+    residual(L, VECTOR_TEMP, x_id, F_id, a, b);                           /* the true residual decides */
+    const double norm_of_r = norm(L, VECTOR_TEMP);
+    if (norm_of_r == 0.0) { converged = 1; break; }
+    if (j > 1) SAY(L->my_rank, "\n          ");
+    SAY(L->my_rank, "iter=%3d  norm=%1.15e  rel=%1.15e  ", j, norm_of_r, norm_of_r / norm_of_r0);
+    hpgmg_last_solve.norm_of_F = norm_of_r0; hpgmg_last_solve.norm_of_residual = norm_of_r; hpgmg_last_solve.vcycles = j;
+    if (norm_of_r / norm_of_r0 < rtol) break;
+    L->vcycles_from_this_level++;
+    zero_vector(L, z_id);
+    MGVCycle(G, z_id, r_id, a, b, onLevel);
+    seg_close();
+    const double r_dot_z_new = dot(L, r_id, z_id);
+    if (r_dot_z_new == 0.0) { failed = 1; break; }                        /* Lanczos breakdown */
+    const double beta = r_dot_z_new / r_dot_z;
+    if (isinf(beta)) { failed = 1; break; }
+    add_vectors(L, p_id, 1.0, z_id, beta, p_id);
+    r_dot_z = r_dot_z_new;
+  }
+  G->timers.MGSolve += now() - t0;
+  SAY(L->my_rank, "done (%f seconds)\n", now() - t0);
+}
+
 void FMGSolve(mg_type *G, int onLevel, int u_id, int F_id, double a, double b, double rtol) {
   /* one F-cycle; the reference only iterates further V-cycles when built with
    * -DUNLIMIT_FMG_ITERATIONS (mg.c:1243-1247), so none are done here */

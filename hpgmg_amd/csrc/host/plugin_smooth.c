@@ -111,6 +111,11 @@ int hp_vcycle_legs_fused(level_type **levels, int n, int e_id, int R_id, double 
   double h2inv[8], c1[64], c2[64];
   const int enabled = (int)hp_switch(SW_FUSED_TAIL), bottom_enabled = (int)hp_switch(SW_FUSED_BOTTOM);
   hpgmg_get_config(&cfg);
+  /* A correction or right-hand side that lives among the work vectors of the host-driven Krylov solver (ids >= VECTORS_RESERVED: MGPCG's z,
+   * mg.c:1530) ALIASES them on the bottom level -- z is BiCGStab's p there (solvers/bicgstab.c:14-19) -- and the reference's numbers include that.
+   * The fused bottom solve keeps the solver's vectors to itself, so the forms that contain it step aside: the legs run without it and the host-driven
+   * solver goes through the operators, aliasing included. */
+  if (leg >= 2 && (e_id >= hpgmg_vectors_reserved() || R_id >= hpgmg_vectors_reserved())) return 0;
   const int sweeps = hpgmg_smooth_sweeps();
   const int with_bottom = (leg >= 2);
   if (enabled && cfg.op != HPGMG_OP_7PT) {      /* leg 0 / 1: the way down / up around a bottom solve somebody else runs (the reference's driver, through the queue below) */
@@ -387,6 +392,7 @@ int hpgmg_bottom_solve_fused(level_type *L, int e_id, int R_id, double a, double
   const int on = (int)hp_switch(SW_FUSED_BOTTOM);
   hpgmg_get_config(&cfg);
   if (!on || cfg.op == HPGMG_OP_7PT || !L->active || L->num_my_boxes != 1 || L->boxes_in.i * L->boxes_in.j * L->boxes_in.k != 1) return 0;
+  if (e_id >= hpgmg_vectors_reserved() || R_id >= hpgmg_vectors_reserved()) return 0;       /* they alias the host solver's work vectors (hp_vcycle_legs_fused) */
   if (L->boundary_condition.type == BC_PERIODIC || L->must_subtract_mean == 1) return 0;
   if ((long long)L->dim.i * L->dim.j * L->dim.k > hpgmg_hip_bottom_bicgstab_max_cells()) return 0;
   const int shape = stencil_get_shape();

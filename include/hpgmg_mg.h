@@ -31,6 +31,7 @@ void MGDestroy(mg_type *all_grids);
 void MGVCycle(mg_type *all_grids, int e_id, int R_id, double a, double b, int level);
 void MGSolve(mg_type *all_grids, int onLevel, int u_id, int F_id, double a, double b, double rtol);
 void FMGSolve(mg_type *all_grids, int onLevel, int u_id, int F_id, double a, double b, double rtol);
+void MGPCG(mg_type *all_grids, int onLevel, int x_id, int F_id, double a, double b, double rtol);   /* mg.c:1500-1605: CG preconditioned with one V-cycle per iteration; grows every level by three vectors */
 void MGPrintTiming(mg_type *all_grids, int fromLevel);
 void MGResetTimers(mg_type *all_grids);
 void richardson_error(mg_type *all_grids, int levelh, int u_id);

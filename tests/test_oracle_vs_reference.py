@@ -74,6 +74,16 @@ def test_the_reference_s_other_drivers_with_our_operators(ref_build, variant, ar
     assert len(ref) >= 10 and ref == hyb, [x for x in zip(ref, hyb) if x[0] != x[1]][:4]
 
 
+@pytest.mark.parametrize("variant,flags,args", [("7pt-cheby-helm-mgpcg", ["--helmholtz"], "4 8"), ("27pt-gsrb-mgpcg", ["--op", "27pt", "--smoother", "gsrb"], "4 8")])
+def test_our_mgpcg_prints_what_the_reference_s_mgpcg_prints(ref_build, variant, flags, args):
+    """MGPCG of OUR host layer (host/mg.c, `hpgmg-fv-oracle --mgpcg`) against the reference's MGPCG (mg.c:1500-1605 under oracle/mgpcg_harness.c),
+    one OpenMP thread each: the same iterates to the last digit, the same iteration counts."""
+    pat = r"(iter=\s*\d+\s+norm=\S+\s+rel=\S+|MGPCG solve \d: norm\(u\)=\S+\s+Krylov iterations on the fine level so far=\d+|MGPCG dot\(u,f\)=\S+\s+mean\(u\)=\S+)"
+    ref = re.findall(pat, subprocess.run([os.path.join(ref_build, "hpgmg-" + variant)] + args.split(), capture_output=True, text=True, env=cli_env("1"), check=True).stdout)
+    ours = re.findall(pat, subprocess.run([os.path.join(ROOT, "oracle", "hpgmg-fv-oracle"), "--mgpcg"] + flags + args.split(), capture_output=True, text=True, env=cli_env("1"), check=True).stdout)
+    assert len(ref) >= 10 and ref == ours, [x for x in zip(ref, ours) if x[0] != x[1]][:4]
+
+
 def _masked(text):
     """stdout with every timing figure (and the one line naming threads / backend) replaced: what a log parser keys on stays"""
     import re
