@@ -124,9 +124,11 @@ void hpgmg_solver_restrict_rhs(hpgmg_solver *s, int l) {
   if (l > 0) restriction(s->mg.levels[l], VECTOR_F, s->mg.levels[l - 1], VECTOR_F, RESTRICT_CELL);
 }
 
+static int solve_with_vcycles = 0;      /* --vcycles: the benchmark solves with MGSolve (V-cycles until converged), as the reference built without -DUSE_FCYCLES does (hpgmg-fv.c:79-83) */
 double hpgmg_solver_fmg(hpgmg_solver *s, int l) {
   zero_vector(s->mg.levels[l], VECTOR_U);
-  FMGSolve(&s->mg, l, VECTOR_U, VECTOR_F, s->a, s->b, 1e-10);
+  if (solve_with_vcycles) MGSolve(&s->mg, l, VECTOR_U, VECTOR_F, s->a, s->b, 1e-10);
+  else FMGSolve(&s->mg, l, VECTOR_U, VECTOR_F, s->a, s->b, 1e-10);
   return hpgmg_last_solve.norm_of_residual;
 }
 
@@ -153,7 +155,7 @@ void hpgmg_solver_richardson(hpgmg_solver *s, double out[2]) {
 /* ------------------------------------------------------------------ CLI */
 static int usage(int rank) {
   if (rank == 0) fprintf(stderr,
-    "usage: hpgmg-fv [--op 7pt|27pt|fv4|fv2] [--smoother cheby|gsrb|jacobi] [--helmholtz] [--const-coeff] [--fp32-smoother] [--periodic] [--mgpcg]\n"
+    "usage: hpgmg-fv [--op 7pt|27pt|fv4|fv2] [--smoother cheby|gsrb|jacobi] [--helmholtz] [--const-coeff] [--fp32-smoother] [--periodic] [--vcycles] [--mgpcg]\n"
     "                [--warmup N] [--solves N] [--rank R --ranks N]  log2_box_dim  target_boxes_per_rank\n");
   return 0;
 }
@@ -176,6 +178,7 @@ int hpgmg_fv_main(int argc, char **argv) {
     else if (!strcmp(argv[a], "--fp32-smoother")) hpgmg_set_smoother_precision(32);
     else if (!strcmp(argv[a], "--periodic")) bc = BC_PERIODIC;                       /* the reference's -DUSE_PERIODIC_BC */
     else if (!strcmp(argv[a], "--test-error")) test_error_only = 1;
+    else if (!strcmp(argv[a], "--vcycles")) solve_with_vcycles = 1;
     else if (!strcmp(argv[a], "--mgpcg")) mgpcg = 1;                                 /* the reference's third driver (mg.c:1500), which its main() never calls: two solves, then exit */
     else if (!strcmp(argv[a], "--warmup") && a + 1 < argc) warmup = atoi(argv[++a]);
     else if (!strcmp(argv[a], "--solves") && a + 1 < argc) solves = atoi(argv[++a]);

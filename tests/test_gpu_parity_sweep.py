@@ -58,3 +58,17 @@ def test_mgpcg_of_this_host_layer_on_the_gpu(flags, size):
         assert out.returncode == 0, (out.stdout[-800:], out.stderr[-800:])
         outs.append(MGPCG_LINES.findall(out.stdout))
     assert len(outs[0]) >= 8 and outs[0] == outs[1], [x for x in zip(outs[0], outs[1]) if x[0] != x[1]][:4]
+
+
+@pytest.mark.parametrize("flags,size", [("--helmholtz", "5 8"), ("", "4 27"), ("--op 27pt --smoother gsrb", "5 8"), ("--op fv4 --smoother gsrb", "5 8"), ("--op fv2", "4 8"), ("--periodic", "4 8"), ("--helmholtz", "7 8")])
+def test_mgsolve_of_this_host_layer_on_the_gpu(flags, size):
+    """`hpgmg-fv --vcycles`: the benchmark solving with MGSolve (V-cycles until the residual has dropped by 1e-10, a residual + norm after every cycle;
+    the reference built without -DUSE_FCYCLES) on the HIP plugin against the CPU oracle: every v-cycle line of the three problem sizes and the
+    Richardson estimate (the oracle side is pinned to the reference by tests/test_oracle_vs_reference.py)."""
+    pat = re.compile(r"(v-cycle=\s*\d+\s+norm=\S+\s+rel=\S+|\|\|error\|\|=\S+|order=\S+)")
+    outs = []
+    for exe in (os.path.join(ROOT, "hpgmg_amd", "bin", "hpgmg-fv"), os.path.join(ROOT, "oracle", "hpgmg-fv-oracle")):
+        out = subprocess.run([exe, "--vcycles", "--warmup", "1", "--solves", "1"] + flags.split() + size.split(), capture_output=True, text=True, timeout=900, env=dict(os.environ, OMP_WAIT_POLICY="passive"))
+        assert out.returncode == 0, (out.stdout[-800:], out.stderr[-800:])
+        outs.append(pat.findall(out.stdout))
+    assert len(outs[0]) >= 20 and outs[0] == outs[1], [x for x in zip(outs[0], outs[1]) if x[0] != x[1]][:4]

@@ -84,6 +84,16 @@ def test_our_mgpcg_prints_what_the_reference_s_mgpcg_prints(ref_build, variant, 
     assert len(ref) >= 10 and ref == ours, [x for x in zip(ref, ours) if x[0] != x[1]][:4]
 
 
+@pytest.mark.parametrize("variant,flags,args", [("7pt-cheby-vcycle", [], "4 8"), ("fv4-gsrb-vcycle", ["--op", "fv4", "--smoother", "gsrb"], "4 8")])
+def test_our_mgsolve_prints_what_the_reference_s_mgsolve_prints(ref_build, variant, flags, args):
+    """`hpgmg-fv-oracle --vcycles` (this repository's MGSolve, host/mg.c) against the reference built without -DUSE_FCYCLES (mg.c:1168-1233): every
+    v-cycle line of the three problem sizes, the Richardson estimate."""
+    pat = r"(v-cycle=\s*\d+\s+norm=\S+\s+rel=\S+|\|\|error\|\|=\S+|order=\S+)"
+    ref = re.findall(pat, subprocess.run([os.path.join(ref_build, "hpgmg-" + variant)] + args.split(), capture_output=True, text=True, env=cli_env(), check=True).stdout)
+    ours = re.findall(pat, subprocess.run([os.path.join(ROOT, "oracle", "hpgmg-fv-oracle"), "--vcycles"] + flags + args.split(), capture_output=True, text=True, env=cli_env(), check=True).stdout)
+    assert len(ref) > 50 and ref == ours, [x for x in zip(ref, ours) if x[0] != x[1]][:4]
+
+
 def _masked(text):
     """stdout with every timing figure (and the one line naming threads / backend) replaced: what a log parser keys on stays"""
     import re
