@@ -262,7 +262,16 @@ static int plan_next_reference(const plan_t *f, int coarsest_dim, plan_t *c);
  * millisecond with no messages (hipGraph segments, fused tail kernel).  0 = the reference's rank map. */
 int hpgmg_gather_dim = -1;
 void hpgmg_set_gather_dim(int dim) { hpgmg_gather_dim = dim; }
+/* The reference's -DUSE_UCYCLES ladder (mg.c:878-893): boxes are halved as long as they can be and never merged, so the bottom level keeps
+ * every box (a truncated V-cycle; the bottom solver then works on a level of many small boxes). */
+static int hpgmg_ucycles = 0;
+void hpgmg_set_ucycles(int on) { hpgmg_ucycles = on ? 1 : 0; }
 static int plan_next(const plan_t *f, int coarsest_dim, plan_t *c) {
+  if (hpgmg_ucycles) {
+    if (f->box_dim % 2) return 0;
+    *c = *f; c->dim = f->dim / 2; c->box_dim = f->box_dim / 2;
+    return c->box_dim >= c->ghosts;
+  }
   if (hpgmg_gather_dim < 0) { const char *e = getenv("HPGMG_GATHER_DIM"); hpgmg_gather_dim = (e && *e) ? atoi(e) : 64; }
   if (!plan_next_reference(f, coarsest_dim, c)) return 0;
   if (f->procs == 1) c->procs = 1;                       /* once gathered, stay gathered */
@@ -582,10 +591,12 @@ void MGPCG(mg_type *G, int onLevel, int x_id, int F_id, double a, double b, doub
   SAY(L->my_rank, "done (%f seconds)\n", now() - t0);
 }
 
+/* V-cycles FMGSolve may add after its F-cycle until the residual has dropped by rtol: 0, or 20 = the reference built with -DUNLIMIT_FMG_ITERATIONS (mg.c:1239-1247) */
+static int hpgmg_fmg_vcycles = 0;
+void hpgmg_set_fmg_vcycles(int n) { hpgmg_fmg_vcycles = n > 0 ? n : 0; }
 void FMGSolve(mg_type *G, int onLevel, int u_id, int F_id, double a, double b, double rtol) {
-  /* one F-cycle; the reference only iterates further V-cycles when built with
-   * -DUNLIMIT_FMG_ITERATIONS (mg.c:1243-1247), so none are done here */
-  const int e_id = u_id, R_id = VECTOR_R, maxVCycles = 0;
+  /* one F-cycle; further V-cycles only on request (hpgmg_set_fmg_vcycles) */
+  const int e_id = u_id, R_id = VECTOR_R, maxVCycles = hpgmg_fmg_vcycles;
   const int bottom = G->num_levels - 1;
   level_type *L = G->levels[onLevel];
   char label[64];

@@ -31,6 +31,8 @@ void MGDestroy(mg_type *all_grids);
 void MGVCycle(mg_type *all_grids, int e_id, int R_id, double a, double b, int level);
 void MGSolve(mg_type *all_grids, int onLevel, int u_id, int F_id, double a, double b, double rtol);
 void FMGSolve(mg_type *all_grids, int onLevel, int u_id, int F_id, double a, double b, double rtol);
+void hpgmg_set_ucycles(int on);        /* before MGBuild: 1 = the reference's -DUSE_UCYCLES ladder (boxes halved, never merged; mg.c:878-893) */
+void hpgmg_set_fmg_vcycles(int n);     /* V-cycles FMGSolve may add after its F-cycle: 0 (default) or 20 = -DUNLIMIT_FMG_ITERATIONS (mg.c:1239-1247) */
 void MGPCG(mg_type *all_grids, int onLevel, int x_id, int F_id, double a, double b, double rtol);   /* mg.c:1500-1605: CG preconditioned with one V-cycle per iteration; grows every level by three vectors */
 void MGPrintTiming(mg_type *all_grids, int fromLevel);
 void MGResetTimers(mg_type *all_grids);

@@ -72,3 +72,20 @@ def test_mgsolve_of_this_host_layer_on_the_gpu(flags, size):
         assert out.returncode == 0, (out.stdout[-800:], out.stderr[-800:])
         outs.append(pat.findall(out.stdout))
     assert len(outs[0]) >= 20 and outs[0] == outs[1], [x for x in zip(outs[0], outs[1]) if x[0] != x[1]][:4]
+
+
+@pytest.mark.parametrize("flags,size", [("--ucycles", "5 8"), ("--ucycles --op fv4 --smoother gsrb", "5 8"), ("--ucycles --op 27pt --smoother gsrb", "4 8"), ("--ucycles --helmholtz", "6 8"),
+                                        ("--unlimit", "5 8"), ("--unlimit --op fv4 --smoother gsrb", "4 8"), ("--unlimit --helmholtz", "7 8")])
+def test_other_cycle_shapes_of_this_host_layer_on_the_gpu(flags, size):
+    """`--ucycles` (the reference's -DUSE_UCYCLES ladder: boxes halved, never merged, so the small levels and the bottom solve run on EIGHT boxes and none
+    of the one-box forms applies) and `--unlimit` (V-cycles after the F-cycle until converged) on the HIP plugin against the CPU oracle, every pinned line."""
+    pat = re.compile(r"(f-cycle\s+norm=\S+\s+rel=\S+|v-cycle=\s*\d+\s+norm=\S+\s+rel=\S+|\|\|error\|\|=\S+|order=\S+|eigenvalue_max<\S+)")
+    outs = []
+    for exe in (os.path.join(ROOT, "hpgmg_amd", "bin", "hpgmg-fv"), os.path.join(ROOT, "oracle", "hpgmg-fv-oracle")):
+        env = dict(os.environ, OMP_WAIT_POLICY="passive")
+        if "--ucycles" in flags:
+            env["OMP_NUM_THREADS"] = "1"        # the bottom solver's dot products run over eight boxes: the plugin sums them in the reference's one-thread order
+        out = subprocess.run([exe, "--warmup", "1", "--solves", "1"] + flags.split() + size.split(), capture_output=True, text=True, timeout=900, env=env)
+        assert out.returncode == 0, (out.stdout[-800:], out.stderr[-800:])
+        outs.append(pat.findall(out.stdout))
+    assert len(outs[0]) >= 10 and outs[0] == outs[1], [x for x in zip(outs[0], outs[1]) if x[0] != x[1]][:4]

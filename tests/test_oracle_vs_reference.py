@@ -84,6 +84,19 @@ def test_our_mgpcg_prints_what_the_reference_s_mgpcg_prints(ref_build, variant, 
     assert len(ref) >= 10 and ref == ours, [x for x in zip(ref, ours) if x[0] != x[1]][:4]
 
 
+@pytest.mark.parametrize("variant,flags,args", [("7pt-cheby-ucycle", ["--ucycles"], "4 8"), ("fv4-gsrb-ucycle", ["--ucycles", "--op", "fv4", "--smoother", "gsrb"], "4 8"),
+                                                ("7pt-cheby-unlimit", ["--unlimit"], "4 8"), ("7pt-cheby-ucycle", ["--ucycles"], "5 8")])
+def test_our_host_layer_with_the_reference_s_other_cycle_flags(ref_build, variant, flags, args):
+    """`hpgmg-fv-oracle --ucycles` (MGBuild without agglomeration: the reference's -DUSE_UCYCLES ladder, mg.c:878-893) and `--unlimit` (V-cycles after the
+    F-cycle until converged: -DUNLIMIT_FMG_ITERATIONS, mg.c:1239-1247) against the reference binaries built with those flags: the level table, every
+    f-cycle / v-cycle line, the Richardson estimate."""
+    pat = r"(attempting to create a \S+ level from .* boxes|f-cycle\s+norm=\S+\s+rel=\S+|v-cycle=\s*\d+\s+norm=\S+\s+rel=\S+|\|\|error\|\|=\S+|order=\S+|eigenvalue_max<\S+)"
+    # one OpenMP thread: with U-cycles the bottom solver's dot products run over eight boxes, and the reference's sum then moves with its thread count
+    ref = re.findall(pat, subprocess.run([os.path.join(ref_build, "hpgmg-" + variant)] + args.split(), capture_output=True, text=True, env=cli_env("1"), check=True).stdout)
+    ours = re.findall(pat, subprocess.run([os.path.join(ROOT, "oracle", "hpgmg-fv-oracle")] + flags + args.split(), capture_output=True, text=True, env=cli_env("1"), check=True).stdout)
+    assert len(ref) > 60 and ref == ours, [x for x in zip(ref, ours) if x[0] != x[1]][:4]
+
+
 @pytest.mark.parametrize("variant,flags,args", [("7pt-cheby-vcycle", [], "4 8"), ("fv4-gsrb-vcycle", ["--op", "fv4", "--smoother", "gsrb"], "4 8")])
 def test_our_mgsolve_prints_what_the_reference_s_mgsolve_prints(ref_build, variant, flags, args):
     """`hpgmg-fv-oracle --vcycles` (this repository's MGSolve, host/mg.c) against the reference built without -DUSE_FCYCLES (mg.c:1168-1233): every
