@@ -49,3 +49,8 @@ int hpgmg_smooth_sweeps(void) {
 /* GSRB must read the previous iterate when the stencil couples same-colour cells
  * (operators.27pt.c:126, operators.fv4.c:178: #define GSRB_OOP) */
 int hpgmg_gsrb_out_of_place(void) { return the_cfg.op == HPGMG_OP_27PT || the_cfg.op == HPGMG_OP_FV4; }
+
+/* the host-driven bottom solver: the reference picks it with -DUSE_BICGSTAB (its default here) or -DUSE_CG (solvers.c:17-24) */
+static int bottom_solver = HPGMG_BOTTOM_BICGSTAB;
+void hpgmg_set_bottom_solver(int which) { bottom_solver = (which == HPGMG_BOTTOM_CG) ? HPGMG_BOTTOM_CG : HPGMG_BOTTOM_BICGSTAB; }   /* before MGBuild: it sets the number of work vectors */
+int hpgmg_get_bottom_solver(void) { return bottom_solver; }

@@ -155,7 +155,8 @@ void hpgmg_solver_richardson(hpgmg_solver *s, double out[2]) {
 /* ------------------------------------------------------------------ CLI */
 static int usage(int rank) {
   if (rank == 0) fprintf(stderr,
-    "usage: hpgmg-fv [--op 7pt|27pt|fv4|fv2] [--smoother cheby|gsrb|jacobi] [--helmholtz] [--const-coeff] [--fp32-smoother] [--periodic] [--vcycles] [--ucycles] [--unlimit] [--mgpcg]\n"
+    "usage: hpgmg-fv [--op 7pt|27pt|fv4|fv2] [--smoother cheby|gsrb|jacobi] [--helmholtz] [--const-coeff] [--fp32-smoother] [--periodic] [--bottom-solver bicgstab|cg]\n"
+    "                [--vcycles] [--ucycles] [--unlimit] [--mgpcg]\n"
     "                [--warmup N] [--solves N] [--rank R --ranks N]  log2_box_dim  target_boxes_per_rank\n");
   return 0;
 }
@@ -178,6 +179,9 @@ int hpgmg_fv_main(int argc, char **argv) {
     else if (!strcmp(argv[a], "--fp32-smoother")) hpgmg_set_smoother_precision(32);
     else if (!strcmp(argv[a], "--periodic")) bc = BC_PERIODIC;                       /* the reference's -DUSE_PERIODIC_BC */
     else if (!strcmp(argv[a], "--test-error")) test_error_only = 1;
+    else if (!strcmp(argv[a], "--bottom-solver") && a + 1 < argc) { a++;              /* the reference's -DUSE_BICGSTAB (default) / -DUSE_CG */
+      if (!strcmp(argv[a], "cg")) hpgmg_set_bottom_solver(HPGMG_BOTTOM_CG); else if (!strcmp(argv[a], "bicgstab")) hpgmg_set_bottom_solver(HPGMG_BOTTOM_BICGSTAB); else return usage(my_rank);
+    }
     else if (!strcmp(argv[a], "--vcycles")) solve_with_vcycles = 1;
     else if (!strcmp(argv[a], "--ucycles")) hpgmg_set_ucycles(1);                    /* the reference's -DUSE_UCYCLES: no agglomeration */
     else if (!strcmp(argv[a], "--unlimit")) hpgmg_set_fmg_vcycles(20);               /* the reference's -DUNLIMIT_FMG_ITERATIONS */

@@ -116,6 +116,7 @@ int hp_vcycle_legs_fused(level_type **levels, int n, int e_id, int R_id, double 
    * The fused bottom solve keeps the solver's vectors to itself, so the forms that contain it step aside: the legs run without it and the host-driven
    * solver goes through the operators, aliasing included. */
   if (leg >= 2 && (e_id >= hpgmg_vectors_reserved() || R_id >= hpgmg_vectors_reserved())) return 0;
+  if (leg >= 2 && hpgmg_get_bottom_solver() != HPGMG_BOTTOM_BICGSTAB) return 0;        /* the device bottom solve is BiCGStab: another host solver runs through the operators */
   const int sweeps = hpgmg_smooth_sweeps();
   const int with_bottom = (leg >= 2);
   if (enabled && cfg.op != HPGMG_OP_7PT) {      /* leg 0 / 1: the way down / up around a bottom solve somebody else runs (the reference's driver, through the queue below) */

@@ -1,6 +1,6 @@
 /*
  * solvers.c -- bottom (coarsest level) solver: diagonally preconditioned
- * BiCGStab, driven from the host through operators.h only.
+ * BiCGStab (default) or CG, driven from the host through operators.h only.
  *
  * Behavioural reference: finite-volume/source/solvers.c:27-95 and
  * solvers/bicgstab.c:14-97 (Saad, Iterative Methods, Alg. 7.7 with a right
@@ -15,7 +15,7 @@
 #include "hpgmg_operators.h"
 #include "hpgmg_mg.h"
 
-int IterativeSolver_NumVectors(void) { return 8; } /* r0, r, p, q, s, t, Ap, As */
+int IterativeSolver_NumVectors(void) { return hpgmg_get_bottom_solver() == HPGMG_BOTTOM_CG ? 5 : 8; } /* BiCGStab: r0, r, p, q, s, t, Ap, As; CG: r0, r, p, Ap, z (solvers.c:92-104) */
 
 static void remove_mean(level_type *L, int id) {
   if (L->must_subtract_mean == 1) {
@@ -74,6 +74,44 @@ static void bicgstab(level_type *L, int x_id, int R_id, double a, double b, doub
   }
 }
 
+/* The reference's other host-driven choice, -DUSE_CG (solvers/cg.c:14-77; Saad, algorithm 9.1 with the diagonal as preconditioner): same calls,
+ * same order, same break-down tests -- the iteration count and the correction feed the pinned norms exactly as BiCGStab's do. */
+static void cg(level_type *L, int x_id, int R_id, double a, double b, double want) {
+  const int base = hpgmg_vectors_reserved();
+  const int r0 = base + 0, r = base + 1, p = base + 2, Ap = base + 3, z = base + 4;
+  const int max_iters = 200;
+  int it = 0;
+  residual(L, r0, x_id, R_id, a, b);
+  remove_mean(L, r0);
+  scale_vector(L, r, 1.0, r0);
+  mul_vectors(L, z, 1.0, VECTOR_DINV, r0);               /* z = D^-1 r0 */
+  scale_vector(L, p, 1.0, z);
+  const double r0_norm = norm(L, r);
+  if (r0_norm == 0.0) return;                             /* entered with the exact solution */
+  double r_dot_z = dot(L, r, z);
+  while (it < max_iters) {
+    it++;
+    L->Krylov_iterations++;
+    apply_op(L, Ap, p, a, b);
+    const double Ap_p = dot(L, Ap, p);
+    if (Ap_p == 0.0) break;                               /* pivot breakdown */
+    const double alpha = r_dot_z / Ap_p;
+    if (isinf(alpha)) break;
+    add_vectors(L, x_id, 1.0, x_id, alpha, p);
+    add_vectors(L, r, 1.0, r, -alpha, Ap);
+    remove_mean(L, r);
+    const double r_norm = norm(L, r);
+    if (r_norm == 0.0 || r_norm < want * r0_norm) break;
+    mul_vectors(L, z, 1.0, VECTOR_DINV, r);
+    const double r_dot_z_new = dot(L, r, z);
+    if (r_dot_z_new == 0.0) break;                        /* Lanczos breakdown */
+    const double beta = r_dot_z_new / r_dot_z;
+    if (isinf(beta)) break;
+    add_vectors(L, p, 1.0, z, beta, p);
+    r_dot_z = r_dot_z_new;
+  }
+}
+
 void IterativeSolver(level_type *L, int u_id, int f_id, double a, double b, double desired_reduction_in_norm) {
   if (!L->active) return;
   if (L->must_subtract_mean == -1) {
@@ -82,6 +120,7 @@ void IterativeSolver(level_type *L, int u_id, int f_id, double a, double b, doub
     if (hpgmg_vectors_reserved() > VECTOR_ALPHA) alpha_is_zero = (dot(L, VECTOR_ALPHA, VECTOR_ALPHA) == 0.0);
     if (L->boundary_condition.type == BC_PERIODIC && (a == 0 || alpha_is_zero)) L->must_subtract_mean = 1;
   }
+  if (hpgmg_get_bottom_solver() == HPGMG_BOTTOM_CG) { cg(L, u_id, f_id, a, b, desired_reduction_in_norm); return; }
   if (L->must_subtract_mean != 1 && hpgmg_bottom_solve_fused(L, u_id, f_id, a, b, desired_reduction_in_norm)) return;   /* the same solver as one device launch */
   bicgstab(L, u_id, f_id, a, b, desired_reduction_in_norm);
 }

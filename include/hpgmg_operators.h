@@ -53,6 +53,9 @@ typedef struct {
 int  hpgmg_configure(const hpgmg_config *cfg);
 void hpgmg_get_config(hpgmg_config *cfg);
 int  hpgmg_vectors_reserved(void); /* VECTORS_RESERVED: 9, or 11 for Helmholtz */
+enum { HPGMG_BOTTOM_BICGSTAB = 0, HPGMG_BOTTOM_CG = 1 };      /* the reference's -DUSE_BICGSTAB / -DUSE_CG (solvers.c:17-24): host loops over the operators */
+void hpgmg_set_bottom_solver(int which);   /* before MGBuild (the solver's work vectors are created there: 8 / 5) */
+int  hpgmg_get_bottom_solver(void);
 
 /* ---- operators.h:14-15 ---- */
 int stencil_get_radius(void);

@@ -89,3 +89,16 @@ def test_other_cycle_shapes_of_this_host_layer_on_the_gpu(flags, size):
         assert out.returncode == 0, (out.stdout[-800:], out.stderr[-800:])
         outs.append(pat.findall(out.stdout))
     assert len(outs[0]) >= 10 and outs[0] == outs[1], [x for x in zip(outs[0], outs[1]) if x[0] != x[1]][:4]
+
+
+@pytest.mark.parametrize("flags,size", [("", "4 27"), ("--op 27pt --smoother gsrb", "4 27"), ("--op fv4 --smoother gsrb", "4 27"), ("--helmholtz", "5 8"), ("--op fv2", "4 125")])
+def test_cg_bottom_solver_of_this_host_layer_on_the_gpu(flags, size):
+    """`--bottom-solver cg`: the reference's other host-driven bottom solver (-DUSE_CG, solvers/cg.c) in this repository's host layer, on the HIP plugin
+    against the CPU oracle -- the device bottom solve (BiCGStab) steps aside and the solver's operator calls go through the small-operator queue."""
+    pat = re.compile(r"(f-cycle\s+norm=\S+\s+rel=\S+|\|\|error\|\|=\S+|order=\S+|eigenvalue_max<\S+|Bottom solver iterations\s+\d+)")
+    outs = []
+    for exe in (os.path.join(ROOT, "hpgmg_amd", "bin", "hpgmg-fv"), os.path.join(ROOT, "oracle", "hpgmg-fv-oracle")):
+        out = subprocess.run([exe, "--bottom-solver", "cg", "--warmup", "1", "--solves", "2"] + flags.split() + size.split(), capture_output=True, text=True, timeout=900, env=dict(os.environ, OMP_WAIT_POLICY="passive"))
+        assert out.returncode == 0, (out.stdout[-800:], out.stderr[-800:])
+        outs.append(pat.findall(out.stdout))
+    assert len(outs[0]) >= 10 and any(l.startswith("Bottom") for l in outs[0]) and outs[0] == outs[1], [x for x in zip(outs[0], outs[1]) if x[0] != x[1]][:4]

@@ -97,6 +97,16 @@ def test_our_host_layer_with_the_reference_s_other_cycle_flags(ref_build, varian
     assert len(ref) > 60 and ref == ours, [x for x in zip(ref, ours) if x[0] != x[1]][:4]
 
 
+@pytest.mark.parametrize("variant,flags,args", [("7pt-cheby-cgbottom", [], "4 27"), ("27pt-gsrb-cgbottom", ["--op", "27pt", "--smoother", "gsrb"], "4 27"), ("7pt-cheby-cgbottom", [], "4 8")])
+def test_our_cg_bottom_solver_against_the_reference_s(ref_build, variant, flags, args):
+    """`hpgmg-fv-oracle --bottom-solver cg` (host/solvers.c: the reference's -DUSE_CG choice, solvers/cg.c) against the reference built with -DUSE_CG:
+    the pinned lines and the bottom solver's iteration counts of the timing tables (`4 27`: a 3^3-cell bottom level, the solver iterates)."""
+    pat = r"(f-cycle\s+norm=\S+\s+rel=\S+|\|\|error\|\|=\S+|order=\S+|eigenvalue_max<\S+|Bottom solver iterations\s+\d+)"
+    ref = re.findall(pat, subprocess.run([os.path.join(ref_build, "hpgmg-" + variant)] + args.split(), capture_output=True, text=True, env=cli_env("1"), check=True).stdout)
+    ours = re.findall(pat, subprocess.run([os.path.join(ROOT, "oracle", "hpgmg-fv-oracle"), "--bottom-solver", "cg"] + flags + args.split(), capture_output=True, text=True, env=cli_env("1"), check=True).stdout)
+    assert len(ref) > 60 and any(l.startswith("Bottom") for l in ref) and ref == ours, [x for x in zip(ref, ours) if x[0] != x[1]][:4]
+
+
 @pytest.mark.parametrize("variant,flags,args", [("7pt-cheby-vcycle", [], "4 8"), ("fv4-gsrb-vcycle", ["--op", "fv4", "--smoother", "gsrb"], "4 8")])
 def test_our_mgsolve_prints_what_the_reference_s_mgsolve_prints(ref_build, variant, flags, args):
     """`hpgmg-fv-oracle --vcycles` (this repository's MGSolve, host/mg.c) against the reference built without -DUSE_FCYCLES (mg.c:1168-1233): every
