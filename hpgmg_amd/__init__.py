@@ -84,6 +84,14 @@ def _declare_driver_api(lib):
         "hpgmg_mg_level": (vp, [vp, c_int]),
         "hpgmg_mg_num_levels": (c_int, [vp]),
         "hpgmg_set_transport": (None, [vp]),
+        # the reference's compile-time choices of mg.c / solvers.c as run-time setters (call before hpgmg_solver_create / MGBuild) and its other drivers
+        "hpgmg_set_bottom_solver": (None, [c_int]), "hpgmg_get_bottom_solver": (c_int, []),      # 0 BiCGStab (-DUSE_BICGSTAB), 1 CG (-DUSE_CG)
+        "hpgmg_set_ucycles": (None, [c_int]),                                                   # -DUSE_UCYCLES
+        "hpgmg_set_fmg_vcycles": (None, [c_int]),                                               # -DUNLIMIT_FMG_ITERATIONS: 20
+        "MGSolve": (None, [vp, c_int, c_int, c_int, c_dbl, c_dbl, c_dbl]),
+        "FMGSolve": (None, [vp, c_int, c_int, c_int, c_dbl, c_dbl, c_dbl]),
+        "MGPCG": (None, [vp, c_int, c_int, c_int, c_dbl, c_dbl, c_dbl]),
+        "hpgmg_solver_mg": (vp, [vp]),
         # operators.h, same names as the reference
         "stencil_get_radius": (c_int, []), "stencil_get_shape": (c_int, []),
         "apply_op": (None, [vp, c_int, c_int, c_dbl, c_dbl]),
