@@ -75,7 +75,10 @@ template <class F> static void spin_until(F done, const char *what) {
 }
 static int ipc_hip_fail(hipError_t e, const char *where) { fprintf(stderr, "hpgmg_hip (ipc transport, rank %d): %s: %s\n", g_irank, where, hipGetErrorString(e)); return (int)e; }
 static int ipc_debug(void) { static int d = -1; if (d < 0) { const char *e = getenv("HPGMG_IPC_DEBUG"); d = (e && e[0] == '1'); } return d; }
-#define IPC_OK(call) do { hipError_t e_ = (call); if (ipc_debug()) { fprintf(stderr, "[ipc %d] %s -> %s (stream %p)\n", g_irank, #call, hipGetErrorString(e_), (void *)g_stream); fflush(stderr); } if (e_ != hipSuccess) { ipc_hip_fail(e_, #call); abort(); } } while (0)
+#define IPC_OK(call) do {                                                                                                                    \
+    hipError_t e_ = (call);                                                                                                                  \
+    if (ipc_debug()) { fprintf(stderr, "[ipc %d] %s -> %s (stream %p)\n", g_irank, #call, hipGetErrorString(e_), (void *)g_stream); fflush(stderr); } \
+    if (e_ != hipSuccess) { ipc_hip_fail(e_, #call); abort(); } } while (0)
 
 // stream-ordered "set counter" / "wait for counter": host functions (they run on the runtime's callback thread, in stream order)
 struct FlagOp { std::atomic<unsigned long long> *flag; unsigned long long value; };
@@ -192,7 +195,10 @@ void hpgmg_hip_ipc_sendrecv(void *ctx, int nrecv, double *const *rbuf, const int
       IpcChannel &c = g_seg->ch[d][g_irank];
       if (s_state[n] != 0 || (n > 0 && srank[n - 1] == d && s_state[n - 1] == 0)) continue;      // messages to one rank go in order
       if (c.posted.load(std::memory_order_acquire) != g_n_sent[d] + 1) continue;                 // the receiver has not posted this one yet
-      if (c.desc.size != (long long)ssize[n] || c.desc.tag != tag) { fprintf(stderr, "hpgmg_hip (ipc transport): rank %d sends %d doubles (tag %d) to rank %d, which expects %lld (tag %d)\n", g_irank, ssize[n], tag, d, c.desc.size, c.desc.tag); abort(); }
+      if (c.desc.size != (long long)ssize[n] || c.desc.tag != tag) {
+        fprintf(stderr, "hpgmg_hip (ipc transport): rank %d sends %d doubles (tag %d) to rank %d, which expects %lld (tag %d)\n", g_irank, ssize[n], tag, d, c.desc.size, c.desc.tag);
+        abort();
+      }
       double *peer = (double *)((char *)map_peer(d, c.desc.mem) + c.desc.offset);
       IPC_OK(hipLaunchHostFunc(g_stream, host_wait_flag, flag_op(&c.ready_done, g_n_sent[d] + 1)));      // the receiver is done with the buffer's previous content
       IPC_OK(hipMemcpyAsync(peer, sbuf[n], (size_t)ssize[n] * sizeof(double), hipMemcpyDeviceToDevice, g_stream));

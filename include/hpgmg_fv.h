@@ -87,7 +87,8 @@ void        hpgmg_set_sync_timers(int on);
 void        hpgmg_print_switches(void);        /* every run-time switch of the plugin (environment variable, value in force, default, meaning) on stderr; HPGMG_SWITCHES=1 prints it at load time */
 void        hpgmg_set_small_fused(int mode);   /* 27-pt / fv2 / fv4: 2 (default) smooth() on levels of ONE box as one single-workgroup launch on an image of the box in LDS; 0 off */
 void        hpgmg_set_small_vtail(int on);     /* 27-pt / fv2 / fv4: the rest of a V-cycle below a level of one box as ONE launch: 2 (default) on except for 27-pt GSRB, 1 on, 0 off; bit-identical */
-void        hpgmg_set_small_ops(int on);       /* 1 (default): BLAS-1 calls / apply_op / residual on a level of one small box wait for the dot product or norm that follows and go out with it as one launch (host-driven Krylov solvers); 0: a launch each */
+void        hpgmg_set_small_ops(int on);       /* 1 (default): BLAS-1 calls / apply_op / residual on a level of one small box wait for the dot product or norm that
+                                                  follows and go out with it as one launch (host-driven Krylov solvers); 0: a launch each */
 long long   hpgmg_small_ops_groups(void);      /* such launches so far (tests) */
 long long   hpgmg_small_ops_prefetched(void);  /* scalars answered from a value the previous launch formed in advance (tests) */
 void        hpgmg_set_fused_bottom(int on);    /* 0: the bottom solve driven from the host (BiCGStab of host/solvers.c through the operators; tests) */
