@@ -6,6 +6,7 @@ vector ids, repeated and interleaved levels, scalars in between -- once with the
 is called), on two identical hierarchies, and requires every scalar and, after every sequence, the interior of EVERY vector of EVERY level to be
 equal byte for byte.  200 sequences per plugin."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -98,8 +99,9 @@ def test_random_operator_sequences_with_and_without_the_queue(hip, variant, geom
             for vid in (T, U, E, R):
                 data = seeded_field(la[l], 1000 * l + vid, scale=0.01)
                 la[l].write_all(vid, data); lb[l].write_all(vid, data)
-        rng = np.random.default_rng(20260 + len(variant))
-        for n in range(12 if big else 200):
+        # HPGMG_FUZZ_SEED / HPGMG_FUZZ_SEQUENCES: longer hunts with other seeds (the suite runs seed 0, 200 sequences)
+        rng = np.random.default_rng(20260 + len(variant) + 7919 * int(os.environ.get("HPGMG_FUZZ_SEED", "0")))
+        for n in range(12 if big else int(os.environ.get("HPGMG_FUZZ_SEQUENCES", "200"))):
             seq = random_sequence(rng, nlev)
             lib.hpgmg_set_lazy(1)
             va = run(lib, la, seq)
