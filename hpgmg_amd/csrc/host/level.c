@@ -65,6 +65,70 @@ void hpgmg_set_transport(const hpgmg_transport *t) {
 }
 const hpgmg_transport *hpgmg_get_transport(void) { return have_transport ? &the_transport : NULL; }
 
+/* First contact of a multi-rank job, before any level exists: every rank sends a known pattern to every other rank and receives one from it
+ * (an 8-byte message and a 2 x 128 x 128 one -- the two-deep face of a 128^3 box -- in ONE phase each, the way exchange_boundary.c:33-97 posts
+ * all its MPI_Irecv / MPI_Isend before the MPI_Waitall), then one maximum and one sum over all ranks and, with three or more ranks, a sum over
+ * ranks {0, 1} only (the sub-communicator reductions of misc.c:276,324,373).  Everything is compared with what it must be; the sum with the
+ * additions done in rank order, bit for bit.  Returns 0, or -1 with `msg` naming the rank pair / reduction that failed.  Every rank calls it. */
+static double selftest_value(int src, int dst, int i, int round) { return 1000003.0 * (double)src + 1009.0 * (double)dst + (double)i + 0.25 * (double)round; }
+int hpgmg_transport_selftest(char *msg, int msglen) {
+  const hpgmg_transport *T = hpgmg_get_transport();
+  if (msg && msglen > 0) msg[0] = 0;
+  if (!T || T->size < 2) return 0;
+  const int me = T->rank, size = T->size, peers = size - 1, sizes[2] = { 1, 2 * 128 * 128 };
+  int round, p, i, bad = 0;
+  for (round = 0; round < 2 && !bad; round++) {
+    const int n = sizes[round];
+    double *dev = hpgmg_vector_alloc((size_t)2 * peers * n + 2), *host = (double *)malloc((size_t)2 * peers * n * sizeof(double));
+    double **sb = (double **)malloc((size_t)2 * peers * sizeof(double *)), **rb = sb + peers;
+    int *cnt = (int *)malloc((size_t)2 * peers * sizeof(int)), *who = cnt + peers;
+    for (p = 0; p < peers; p++) {
+      const int r = (p < me) ? p : p + 1;
+      sb[p] = dev + (size_t)p * n; rb[p] = dev + (size_t)(peers + p) * n; cnt[p] = n; who[p] = r;
+      for (i = 0; i < n; i++) { host[(size_t)p * n + i] = selftest_value(me, r, i, round); host[(size_t)(peers + p) * n + i] = -1.0; }
+    }
+    hpgmg_vector_upload(dev, host, (size_t)2 * peers * n);
+    T->sendrecv(T->ctx, peers, rb, cnt, who, peers, sb, cnt, who, 4242 + round);
+    hpgmg_vector_download(host, dev, (size_t)2 * peers * n);
+    for (p = 0; p < peers && !bad; p++)
+      for (i = 0; i < n; i++)
+        if (host[(size_t)(peers + p) * n + i] != selftest_value(who[p], me, i, round)) {
+          if (msg) snprintf(msg, (size_t)msglen, "transport self-test: message of %d doubles from rank %d to rank %d: element %d is %.17g, expected %.17g",
+                            n, who[p], me, i, host[(size_t)(peers + p) * n + i], selftest_value(who[p], me, i, round));
+          bad = 1; break;
+        }
+    hpgmg_vector_free(dev); free(host); free(sb); free(cnt);
+  }
+  { /* every rank learns whether ANY rank saw a wrong message (nobody is left waiting in the reductions below for a rank that gave up) */
+    int *all = (int *)malloc((size_t)size * sizeof(int));
+    double any = bad ? 1.0 : 0.0;
+    for (p = 0; p < size; p++) all[p] = p;
+    T->allreduce(T->ctx, &any, 1, HPGMG_REDUCE_MAX, all, size);
+    free(all);
+    if (any != 0.0 && !bad) { if (msg) snprintf(msg, (size_t)msglen, "transport self-test: another rank received a damaged message (rank %d's own messages were intact)", me); return -2; }
+  }
+  if (!bad) {
+    int *all = (int *)malloc((size_t)size * sizeof(int));
+    double v, expect = 0.0;
+    for (p = 0; p < size; p++) all[p] = p;
+    v = (double)me + 1.5;
+    T->allreduce(T->ctx, &v, 1, HPGMG_REDUCE_MAX, all, size);
+    if (v != (double)size + 0.5) { if (msg) snprintf(msg, (size_t)msglen, "transport self-test: maximum over %d ranks on rank %d is %.17g, expected %.17g", size, me, v, (double)size + 0.5); bad = 1; }
+    v = 0.1 * (double)(me + 1);
+    for (p = 0; p < size; p++) expect = (p == 0) ? 0.1 * (double)(p + 1) : expect + 0.1 * (double)(p + 1);
+    if (!bad) T->allreduce(T->ctx, &v, 1, HPGMG_REDUCE_SUM, all, size);
+    if (!bad && v != expect) { if (msg) snprintf(msg, (size_t)msglen, "transport self-test: rank-ordered sum over %d ranks on rank %d is %.17g, expected %.17g", size, me, v, expect); bad = 1; }
+    if (!bad && size >= 3 && me < 2) {
+      v = 0.3 * (double)(me + 1);
+      expect = 0.3 * 1.0 + 0.3 * 2.0;
+      T->allreduce(T->ctx, &v, 1, HPGMG_REDUCE_SUM, all, 2);
+      if (v != expect) { if (msg) snprintf(msg, (size_t)msglen, "transport self-test: sum over ranks {0, 1} on rank %d is %.17g, expected %.17g", me, v, expect); bad = 1; }
+    }
+    free(all);
+  }
+  return bad ? -1 : 0;
+}
+
 /* ------------------------------------------------------------------ box -> rank
  * Z-Morton walk over the (possibly non power-of-two) box grid; box n along the
  * curve goes to rank floor(ranks*n/curve_length).  Octants are visited i fastest,
@@ -351,6 +415,9 @@ static int round_up(int x, int m) { return (m > 1) ? ((x + m - 1) / m) * m : x; 
 void create_vectors(level_type *L, int numVectors) {
   if (numVectors <= L->numVectors) return;
   const int old_nv = L->numVectors, width = L->box_dim + 2 * L->box_ghosts;
+  /* the boxes are about to move: whatever the plugin has postponed still names the old storage and must run first (the plugin's
+   * hpgmg_vector_free also drops its captured launch graphs, which hold pointers into the slab that goes away) */
+  if (old_nv > 0) hpgmg_operators_flush();
   L->box_jStride = round_up(width, hpgmg_box_align_jstride);
   L->box_kStride = round_up(L->box_jStride * width, hpgmg_box_align_kstride);
   L->box_volume  = round_up(L->box_kStride * width, hpgmg_box_align_volume);

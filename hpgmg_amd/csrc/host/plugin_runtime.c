@@ -49,7 +49,9 @@ double *hpgmg_vector_alloc(size_t n) {
   if (!p) { fprintf(stderr, "hpgmg: device allocation of %zu doubles failed: %s\n", n, hpgmg_hip_last_error()); abort(); }
   return p;
 }
-void hpgmg_vector_free(double *p) { hp_lazy_flush(); hpgmg_hip_free(p); }      /* a postponed operator may still hold this storage */
+/* a postponed operator may still hold this storage, and so may a captured launch graph (create_vectors() growing a level after solves have run:
+ * FMGSolve -> MGPCG -> FMGSolve would otherwise replay graphs over the freed slab) */
+void hpgmg_vector_free(double *p) { hp_lazy_flush(); hpgmg_hip_graph_reset(); hpgmg_hip_free(p); }
 void hpgmg_vector_copy(double *d, const double *s, size_t n) { HIP_OK(hpgmg_hip_memcpy_d2d(d, s, n * sizeof(double))); }
 void hpgmg_vector_upload(double *d, const double *s, size_t n) { HIP_OK(hpgmg_hip_memcpy_h2d(d, s, n * sizeof(double))); }
 void hpgmg_vector_download(double *d, const double *s, size_t n) { HIP_OK(hpgmg_hip_memcpy_d2h(d, s, n * sizeof(double))); }

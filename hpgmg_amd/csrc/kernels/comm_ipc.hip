@@ -34,7 +34,7 @@
 
 namespace hpgmg {
 constexpr int kIpcMaxRanks = 16, kIpcMaxVals = 16;
-struct IpcDesc { hipIpcMemHandle_t mem; long long offset, size; int tag, pad; };
+struct IpcDesc { hipIpcMemHandle_t mem; long long offset, size; int tag, pad; unsigned long long gen; };      // gen: which export of the receiver's this handle is (a freed allocation's address may come back)
 struct IpcChannel {                                  // data flows sender -> receiver; lives at [receiver][sender]
   std::atomic<unsigned long long> posted, sent;
   std::atomic<unsigned long long> ready_done, sent_done;      // set in STREAM order: the receiver's stream has reached receive n / the sender's copy n has landed
@@ -57,8 +57,9 @@ static char g_seg_name[128];
 static int g_irank = 0, g_isize = 1;
 static unsigned long long g_n_posted[kIpcMaxRanks], g_n_sent[kIpcMaxRanks], g_red_out[kIpcMaxRanks], g_red_in[kIpcMaxRanks];
 static long long g_ipc_messages = 0, g_ipc_doubles = 0;
-struct ExportedMem { void *base; size_t size; hipIpcMemHandle_t h; };
-struct MappedMem { int peer; hipIpcMemHandle_t h; void *base; };
+struct ExportedMem { void *base; size_t size; hipIpcMemHandle_t h; unsigned long long gen; };
+struct MappedMem { int peer; hipIpcMemHandle_t h; void *base; unsigned long long gen; };
+static unsigned long long g_export_gen = 0;
 static std::vector<ExportedMem> g_exported;
 static std::vector<MappedMem> g_mapped;
 
@@ -81,15 +82,15 @@ static int ipc_debug(void) { static int d = -1; if (d < 0) { const char *e = get
     if (e_ != hipSuccess) { ipc_hip_fail(e_, #call); abort(); } } while (0)
 
 // stream-ordered "set counter" / "wait for counter": host functions (they run on the runtime's callback thread, in stream order)
+// Their arguments live on the heap from the enqueue to the end of the callback: a host thread may run a whole F-cycle of messages ahead of its
+// stream, so no fixed ring of slots is safe to reuse.
 struct FlagOp { std::atomic<unsigned long long> *flag; unsigned long long value; };
-static FlagOp g_flag_ops[4096];
-static unsigned g_flag_next = 0;
 static FlagOp *flag_op(std::atomic<unsigned long long> *flag, unsigned long long value) {
-  FlagOp *f = &g_flag_ops[g_flag_next++ % 4096];      // far more slots than a stream ever has host functions in flight
+  FlagOp *f = new FlagOp;
   f->flag = flag; f->value = value;
   return f;
 }
-static void host_set_flag(void *p) { const FlagOp *f = (const FlagOp *)p; f->flag->store(f->value, std::memory_order_release); }
+static void host_set_flag(void *p) { const FlagOp *f = (const FlagOp *)p; f->flag->store(f->value, std::memory_order_release); delete f; }
 static void host_wait_flag(void *p) {
   const FlagOp *f = (const FlagOp *)p;
   const double t0 = wall();
@@ -97,20 +98,29 @@ static void host_wait_flag(void *p) {
     if ((n & 0xfff) == 0xfff && wall() - t0 > ipc_timeout()) { fprintf(stderr, "hpgmg_hip (ipc transport, rank %d): a peer's stream never reached the point this stream waits for\n", g_irank); fflush(stderr); abort(); }
     __builtin_ia32_pause();
   }
+  delete f;
 }
-static const hipIpcMemHandle_t &export_handle(const void *p, long long *offset) {
+static const ExportedMem &export_handle(const void *p, long long *offset) {
   void *base = nullptr; size_t size = 0;
   IPC_OK(hipMemGetAddressRange((hipDeviceptr_t *)&base, &size, (hipDeviceptr_t)p));
   *offset = (long long)((const char *)p - (const char *)base);
-  for (const ExportedMem &e : g_exported) if (e.base == base && e.size == size) return e.h;
-  ExportedMem e; e.base = base; e.size = size;
+  for (const ExportedMem &e : g_exported) if (e.base == base && e.size == size) return e;
+  ExportedMem e; e.base = base; e.size = size; e.gen = ++g_export_gen;
   IPC_OK(hipIpcGetMemHandle(&e.h, base));
   g_exported.push_back(e);
-  return g_exported.back().h;
+  return g_exported.back();
 }
-static void *map_peer(int peer, const hipIpcMemHandle_t &h) {
-  for (const MappedMem &m : g_mapped) if (m.peer == peer && memcmp(&m.h, &h, sizeof h) == 0) return m.base;
-  MappedMem m; m.peer = peer; m.h = h; m.base = nullptr;
+// (peer, gen) names one allocation of the peer's for as long as it lives; a mapping of the same handle bytes under an older generation is of an
+// allocation the peer has freed since (hpgmg_hip_ipc_forget on its side): closed before the new one is opened
+static void *map_peer(int peer, const hipIpcMemHandle_t &h, unsigned long long gen) {
+  for (const MappedMem &m : g_mapped) if (m.peer == peer && m.gen == gen) return m.base;
+  for (size_t n = 0; n < g_mapped.size();) {
+    if (g_mapped[n].peer != peer || memcmp(&g_mapped[n].h, &h, sizeof h) != 0) { n++; continue; }
+    IPC_OK(hipStreamSynchronize(g_stream));               // copies of mine into the stale mapping have drained
+    (void)hipIpcCloseMemHandle(g_mapped[n].base);
+    g_mapped[n] = g_mapped.back(); g_mapped.pop_back();
+  }
+  MappedMem m; m.peer = peer; m.h = h; m.base = nullptr; m.gen = gen;
   IPC_OK(hipIpcOpenMemHandle(&m.base, h, hipIpcMemLazyEnablePeerAccess));
   g_mapped.push_back(m);
   return m.base;
@@ -161,6 +171,13 @@ void hpgmg_hip_ipc_finalize(void) {
   if (g_irank == 0) shm_unlink(g_seg_name);
 }
 long long hpgmg_hip_ipc_message_count(void) { return g_ipc_messages; }
+// an allocation is being freed (hpgmg_hip_free): its exported handle must not be handed out for whatever lands on that address next
+void hpgmg_hip_ipc_forget(const void *p) {
+  for (size_t n = 0; n < g_exported.size();) {
+    if (g_exported[n].base != p) { n++; continue; }
+    g_exported[n] = g_exported.back(); g_exported.pop_back();
+  }
+}
 
 // signature = hpgmg_transport.sendrecv (include/hpgmg_mg.h); buffers are device memory
 void hpgmg_hip_ipc_sendrecv(void *ctx, int nrecv, double *const *rbuf, const int *rsize, const int *rrank,
@@ -178,9 +195,11 @@ void hpgmg_hip_ipc_sendrecv(void *ctx, int nrecv, double *const *rbuf, const int
     for (int n = 0; n < nrecv; n++) {
       const int s = rrank[n];
       IpcChannel &c = g_seg->ch[g_irank][s];
+      if (r_state[n] == 0 && n > 0 && rrank[n - 1] == s && r_state[n - 1] != 2) continue;      // receives from one rank are posted in plan order, like the sends
       if (r_state[n] == 0 && c.sent.load(std::memory_order_acquire) == g_n_posted[s]) {       // the previous receive on this channel has been served: post this one
         long long off = 0;
-        c.desc.mem = export_handle(rbuf[n], &off); c.desc.offset = off; c.desc.size = rsize[n]; c.desc.tag = tag;
+        const ExportedMem &ex = export_handle(rbuf[n], &off);
+        c.desc.mem = ex.h; c.desc.gen = ex.gen; c.desc.offset = off; c.desc.size = rsize[n]; c.desc.tag = tag;
         // READY: whatever this rank issued so far -- in particular the kernels that still read the receive buffer -- precedes the incoming copy
         IPC_OK(hipLaunchHostFunc(g_stream, host_set_flag, flag_op(&c.ready_done, g_n_posted[s] + 1)));
         c.posted.store(++g_n_posted[s], std::memory_order_release);
@@ -199,7 +218,7 @@ void hpgmg_hip_ipc_sendrecv(void *ctx, int nrecv, double *const *rbuf, const int
         fprintf(stderr, "hpgmg_hip (ipc transport): rank %d sends %d doubles (tag %d) to rank %d, which expects %lld (tag %d)\n", g_irank, ssize[n], tag, d, c.desc.size, c.desc.tag);
         abort();
       }
-      double *peer = (double *)((char *)map_peer(d, c.desc.mem) + c.desc.offset);
+      double *peer = (double *)((char *)map_peer(d, c.desc.mem, c.desc.gen) + c.desc.offset);
       IPC_OK(hipLaunchHostFunc(g_stream, host_wait_flag, flag_op(&c.ready_done, g_n_sent[d] + 1)));      // the receiver is done with the buffer's previous content
       IPC_OK(hipMemcpyAsync(peer, sbuf[n], (size_t)ssize[n] * sizeof(double), hipMemcpyDeviceToDevice, g_stream));
       IPC_OK(hipLaunchHostFunc(g_stream, host_set_flag, flag_op(&c.sent_done, g_n_sent[d] + 1)));

@@ -49,7 +49,19 @@ void *hpgmg_hip_malloc(size_t bytes) {
   if (hipMemsetAsync(p, 0, bytes, g_stream) != hipSuccess) { record_error(hipGetLastError(), "hipMemsetAsync"); }
   return p;
 }
-void hpgmg_hip_free(void *p) { hpgmg_hip_graph_flush(); if (p) { hipStreamSynchronize(g_stream); (void)hipFree(p); } }
+// Every cache in this library that is keyed on a device address is told when that address goes away: a later allocation may land on the same
+// address with other content (the tile orders of two-part launches keyed on a neighbour table, the hipIpc handles / peer mappings of the
+// node-local transport keyed on an allocation).
+void hpgmg_hip_tile_part_forget(const void *p);
+void hpgmg_hip_ipc_forget(const void *p);
+void hpgmg_hip_free(void *p) {
+  hpgmg_hip_graph_flush();
+  if (!p) return;
+  hipStreamSynchronize(g_stream);
+  hpgmg_hip_tile_part_forget(p);
+  hpgmg_hip_ipc_forget(p);
+  (void)hipFree(p);
+}
 void *hpgmg_hip_host_malloc(size_t bytes) {
   void *p = nullptr;
   if (hipHostMalloc(&p, bytes ? bytes : 8, hipHostMallocDefault) != hipSuccess) { record_error(hipErrorOutOfMemory, "hpgmg_hip_host_malloc"); return nullptr; }
@@ -216,4 +228,13 @@ const int *tile_part_order(const hpgmg_hip_level *L, int tiles_i, int tiles_j, i
   return o.d_order;
 }
 }  // namespace hpgmg
+// the neighbour table a cached order was derived from is being freed (hpgmg_hip_free): drop the orders and their device copies
+extern "C" void hpgmg_hip_tile_part_forget(const void *p) {
+  using hpgmg::g_part_orders;
+  for (size_t n = 0; n < g_part_orders.size();) {
+    if ((const void *)g_part_orders[n].nbr != p) { n++; continue; }
+    if (g_part_orders[n].d_order) (void)hipFree(g_part_orders[n].d_order);
+    g_part_orders[n] = g_part_orders.back(); g_part_orders.pop_back();
+  }
+}
 extern "C" void hpgmg_hip_set_tile_part(int part) { hpgmg::g_tile_part = (part == 1 || part == 2) ? part : 0; }

@@ -83,6 +83,9 @@ void        hpgmg_transport_finalize_rccl(void);
  * name ("/...") every rank of the job passes; rank 0 creates the segment */
 int         hpgmg_transport_init_ipc(const char *name, int rank, int size);
 void        hpgmg_transport_finalize_ipc(void);
+/* first contact of a multi-rank job (every rank calls it once the transport is installed, before creating levels): a known pattern to and from every
+ * other rank, one maximum, one rank-ordered sum, one sum over a rank subset, all checked; 0, -1 with the failing rank pair / reduction in msg, or -2 when only another rank saw a failure */
+int         hpgmg_transport_selftest(char *msg, int msglen);
 void        hpgmg_set_sync_timers(int on);
 void        hpgmg_print_switches(void);        /* every run-time switch of the plugin (environment variable, value in force, default, meaning) on stderr; HPGMG_SWITCHES=1 prints it at load time */
 void        hpgmg_set_small_fused(int mode);   /* 27-pt / fv2 / fv4: 2 (default) smooth() on levels of ONE box as one single-workgroup launch on an image of the box in LDS; 0 off */

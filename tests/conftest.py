@@ -34,6 +34,20 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "modes: solver modes SURVEY.md section 2 marks OUT OF SCOPE (MGPCG, CG bottom solver, U-/V-cycle shapes, MGSolve of this host "
+                                       "layer); deselected unless the -m expression names them: -m 'gpu and modes'")
+
+
+def pytest_collection_modifyitems(config, items):
+    """`-m gpu` is the hot path's suite; the out-of-scope solver modes only run when asked for by name."""
+    if "modes" in (config.getoption("-m") or ""):
+        return
+    keep, drop = [], []
+    for it in items:
+        (drop if it.get_closest_marker("modes") else keep).append(it)
+    if drop:
+        config.hook.pytest_deselected(items=drop)
+        items[:] = keep
 
 
 @pytest.fixture(scope="session")

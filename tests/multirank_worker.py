@@ -63,6 +63,11 @@ def main():
             stats["messages"] += 1; stats["doubles"] += ssize[n]
         for r in reqs:
             r.wait()
+        bad = os.environ.get("HPGMG_TEST_CORRUPT_FROM")      # negative test of the self-test: what rank `bad` sent arrives with one wrong element
+        if bad is not None and K is None:
+            for n in range(nrecv):
+                if rrank[n] == int(bad) and rsize[n] > 3:
+                    rbuf[n][3] += 1.0
         for dev, host in staged:
             assert K.hpgmg_hip_memcpy_h2d(dev, vp(host.data_ptr()), host.numel() * 8) == 0
 
@@ -92,10 +97,24 @@ def main():
     ipc = backend == "hip" and os.environ.get("HPGMG_TEST_TRANSPORT") == "ipc"
     if ipc:     # the product's node-local transport: peer copies through hipIpc handles ordered by interprocess events (kernels/comm_ipc.hip); gloo only starts the job
         be.lib.hpgmg_transport_init_ipc.argtypes = [ctypes.c_char_p, c_int, c_int]
-        assert be.lib.hpgmg_transport_init_ipc(("/hpgmg_test_%s" % os.environ.get("MASTER_PORT", "0")).encode(), rank, size) == 0
+        nonce = [os.getpid() if rank == 0 else None]      # one segment per JOB: a crashed earlier run with the same port may have left its segment in /dev/shm
+        dist.broadcast_object_list(nonce, src=0)
+        assert be.lib.hpgmg_transport_init_ipc(("/hpgmg_test_%s_%d" % (os.environ.get("MASTER_PORT", "0"), nonce[0])).encode(), rank, size) == 0
     else:
         cb = Transport(rank, size, None, SENDRECV(sendrecv), ALLREDUCE(allreduce))
         be.lib.hpgmg_set_transport(ctypes.byref(cb))
+    # first contact, as bench.py does it: a known pattern to and from every rank, a maximum, a rank-ordered sum, a sum over ranks {0, 1}
+    msg = ctypes.create_string_buffer(512)
+    be.lib.hpgmg_transport_selftest.restype = c_int
+    be.lib.hpgmg_transport_selftest.argtypes = [ctypes.c_char_p, c_int]
+    stats["selftest"] = be.lib.hpgmg_transport_selftest(msg, 512)
+    stats["selftest_message"] = msg.value.decode()
+    if os.environ.get("HPGMG_TEST_CORRUPT_FROM") is not None:      # the negative test stops here: the damaged message must have been noticed
+        print("RESULT " + json.dumps({"rank": rank, "stats": stats}), flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
+    assert stats["selftest"] == 0, stats["selftest_message"]
     be.configure(**VARIANTS[variant])
     s = be.solver_cli(log2, per_rank, rank=rank, ranks=size)
     norms = s.three_sizes()

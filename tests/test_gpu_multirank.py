@@ -4,11 +4,14 @@ and moves them with gloo (RCCL refuses two ranks on one device); everything else
 ghost-free stencils reading remote faces from the ghost zone, active-rank sets on coarse levels, host-driven
 BiCGStab with all-reduced dot products -- is the code the RCCL transport drives on a multi-GPU node.
 Results must equal the single-rank reference golden numbers."""
+import json
 import os
+import subprocess
+import sys
 
 import pytest
 
-from hpgmg_testlib import load_golden
+from hpgmg_testlib import ROOT, load_golden
 from test_multirank_gloo import run_job
 
 pytestmark = pytest.mark.gpu
@@ -171,3 +174,35 @@ def test_ipc_peer_copy_transport(world, variant, log2, per_rank, gold_key, gathe
             assert r["stats"]["fv4_rb_smooths"] >= 8 and r["stats"]["image_exchanges"] > 20, r["stats"]
         if variant == "27pt-gsrb":
             assert r["stats"]["rb27_passes"] >= 16 and r["stats"]["image_exchanges"] > 20, r["stats"]
+
+
+def bench_line(argv, extra_env=None, expect_code=0):
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    env.update(extra_env or {})
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == expect_code, (out.returncode, out.stderr[-3000:])
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, (out.stdout[-1000:], out.stderr[-2000:])
+    return json.loads(lines[0]), out.stderr
+
+
+def test_bench_two_ranks_end_to_end_on_the_ipc_transport():
+    """`bench.py --gpus 2` as the driver will call it, on the one GPU of this box: supervisors -> rank processes -> transport self-test -> the strong-scaling
+    problem (2 x 4 boxes of 128^3) -> ONE JSON line whose norm is the reference's string."""
+    d, _ = bench_line(["--gpus", "2", "--transport", "ipc", "--share-gpu", "--steps", "3", "--warmup", "2"])
+    assert d["n_gpus"] == 2 and d["config"]["transport"].startswith("ipc") and "fallback" not in d["config"]["transport"], d["config"]
+    assert d["config"]["transport_selftest"] == "passed" and d["config"]["parity_ok"] is True, d["config"]
+    assert "%1.15e" % d["config"]["fcycle_residual_norm"] == GOLD["7pt-cheby-helm 7 8"]["norms"][0]
+    assert d["config"]["halo"]["smooths_as_sweep_pairs_with_remote_faces"] > 0 and d["roofline"]["frac"] < 1
+
+
+@pytest.mark.parametrize("how", ["rccl", "rccl:hang"])
+def test_bench_falls_back_to_fresh_ipc_ranks_when_the_first_transport_fails(how):
+    """The first transport is made to fail (every rank of the rccl attempt exits 97) or to hang (every rank sleeps until its watchdog): the supervisors end the
+    attempt and start FRESH rank processes with the ipc transport; the line of that attempt says what happened."""
+    d, err = bench_line(["--gpus", "2", "--share-gpu", "--steps", "2", "--warmup", "1", "--watchdog", "40" if how.endswith("hang") else "300"],
+                        extra_env={"HPGMG_TEST_FAIL_TRANSPORT": how})
+    assert d["config"]["transport"].startswith("ipc (fallback: rccl attempt: "), d["config"]["transport"]
+    assert ("exited with code 124" if how.endswith("hang") else "exited with code 97") in d["config"]["transport"], d["config"]["transport"]
+    assert d["config"]["rccl_ranks"] == 0 and d["config"]["parity_ok"] is True and d["n_gpus"] == 2
+    assert "starting fresh rank processes with the ipc transport" in err

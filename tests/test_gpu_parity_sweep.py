@@ -46,6 +46,7 @@ def test_hip_executable_prints_what_the_oracle_executable_prints(flags, size):
 MGPCG_LINES = re.compile(r"(iter=\s*\d+\s+norm=\S+\s+rel=\S+|MGPCG solve \d: norm\(u\)=\S+\s+Krylov iterations on the fine level so far=\d+|MGPCG dot\(u,f\)=\S+\s+mean\(u\)=\S+)")
 
 
+@pytest.mark.modes
 @pytest.mark.parametrize("flags,size", [("--helmholtz", "5 8"), ("", "4 27"), ("--op 27pt --smoother gsrb", "5 8"), ("--op fv4 --smoother gsrb", "4 8"), ("--periodic", "4 8")])
 def test_mgpcg_of_this_host_layer_on_the_gpu(flags, size):
     """MGPCG of this repository's host layer (host/mg.c, restating the reference's mg.c:1500-1605: conjugate gradients preconditioned with one
@@ -60,6 +61,7 @@ def test_mgpcg_of_this_host_layer_on_the_gpu(flags, size):
     assert len(outs[0]) >= 8 and outs[0] == outs[1], [x for x in zip(outs[0], outs[1]) if x[0] != x[1]][:4]
 
 
+@pytest.mark.modes
 @pytest.mark.parametrize("flags,size", [("--helmholtz", "5 8"), ("", "4 27"), ("--op 27pt --smoother gsrb", "5 8"), ("--op fv4 --smoother gsrb", "5 8"), ("--op fv2", "4 8"), ("--periodic", "4 8"), ("--helmholtz", "7 8")])
 def test_mgsolve_of_this_host_layer_on_the_gpu(flags, size):
     """`hpgmg-fv --vcycles`: the benchmark solving with MGSolve (V-cycles until the residual has dropped by 1e-10, a residual + norm after every cycle;
@@ -74,6 +76,7 @@ def test_mgsolve_of_this_host_layer_on_the_gpu(flags, size):
     assert len(outs[0]) >= 20 and outs[0] == outs[1], [x for x in zip(outs[0], outs[1]) if x[0] != x[1]][:4]
 
 
+@pytest.mark.modes
 @pytest.mark.parametrize("flags,size", [("--ucycles", "5 8"), ("--ucycles --op fv4 --smoother gsrb", "5 8"), ("--ucycles --op 27pt --smoother gsrb", "4 8"), ("--ucycles --helmholtz", "6 8"),
                                         ("--unlimit", "5 8"), ("--unlimit --op fv4 --smoother gsrb", "4 8"), ("--unlimit --helmholtz", "7 8")])
 def test_other_cycle_shapes_of_this_host_layer_on_the_gpu(flags, size):
@@ -91,6 +94,7 @@ def test_other_cycle_shapes_of_this_host_layer_on_the_gpu(flags, size):
     assert len(outs[0]) >= 10 and outs[0] == outs[1], [x for x in zip(outs[0], outs[1]) if x[0] != x[1]][:4]
 
 
+@pytest.mark.modes
 @pytest.mark.parametrize("flags,size", [("", "4 27"), ("--op 27pt --smoother gsrb", "4 27"), ("--op fv4 --smoother gsrb", "4 27"), ("--helmholtz", "5 8"), ("--op fv2", "4 125")])
 def test_cg_bottom_solver_of_this_host_layer_on_the_gpu(flags, size):
     """`--bottom-solver cg`: the reference's other host-driven bottom solver (-DUSE_CG, solvers/cg.c) in this repository's host layer, on the HIP plugin

@@ -58,6 +58,7 @@ def test_reference_driver_runs_on_the_hip_plugin(variant, args):
     assert "DOF/s=" in out.stdout
 
 
+@pytest.mark.modes
 @pytest.mark.parametrize("variant,args", [("7pt-cheby-vcycle", "5 8"), ("7pt-cheby-vcycle", "6 8"), ("fv4-gsrb-vcycle", "5 8")])
 def test_reference_mgsolve_runs_on_the_hip_plugin(variant, args):
     """The reference's OTHER driver of the same plugin: built without -DUSE_FCYCLES its benchmark calls MGSolve (mg.c:1168-1233: V-cycles until
@@ -80,6 +81,7 @@ def test_reference_mgsolve_runs_on_the_hip_plugin(variant, args):
     assert m and int(m.group(1)) > 0 and int(m.group(3)) > 0, outs[0].stderr[-500:]
 
 
+@pytest.mark.modes
 @pytest.mark.parametrize("variant,args", [("7pt-cheby-helm-mgpcg", "5 8"), ("7pt-cheby-helm-mgpcg", "6 8"), ("27pt-gsrb-mgpcg", "5 8")])
 def test_reference_mgpcg_runs_on_the_hip_plugin(variant, args):
     """The reference's THIRD driver of the plugin, which its own main() never calls: MGPCG (mg.c:1500-1605), conjugate gradients preconditioned by
@@ -104,6 +106,7 @@ def test_reference_mgpcg_runs_on_the_hip_plugin(variant, args):
     assert m and int(m.group(1)) + int(m.group(2)) + int(m.group(3)) > 0, outs[0].stderr[-500:]      # the V-cycles inside still went through the operator queue
 
 
+@pytest.mark.modes
 @pytest.mark.parametrize("variant,args", [("7pt-cheby-cgbottom", "4 27"), ("7pt-cheby-cgbottom", "5 8"), ("27pt-gsrb-cgbottom", "4 27")])
 def test_reference_cg_bottom_solver_runs_on_the_hip_plugin(variant, args):
     """The reference built with -DUSE_CG instead of -DUSE_BICGSTAB: its other host-driven bottom solver (solvers/cg.c: diagonally preconditioned
@@ -142,9 +145,14 @@ def test_reference_periodic_build_runs_on_the_hip_plugin(variant, args):
     assert len(a) > 60 and a == b, [x for x in zip(a, b) if x[0] != x[1]][:4]
 
 
-@pytest.mark.parametrize("variant,args", [("7pt-jacobi", "5 8"), ("fv4-cheby", "5 8"), ("27pt-cheby", "5 8"), ("7pt-jacobi", "4 27"),
-                                          ("7pt-cheby-unlimit", "5 8"),       # -DUNLIMIT_FMG_ITERATIONS: the F-cycle followed by V-cycles until converged (mg.c:1239-1247)
-                                          ("7pt-cheby-ucycle", "5 8"), ("fv4-gsrb-ucycle", "5 8")])      # -DUSE_UCYCLES: MGBuild does not agglomerate, the host-driven bottom solver runs on a level of eight boxes (mg.c:878-893)
+_MODES = pytest.mark.modes      # SURVEY section 2 OUT OF SCOPE: only with -m "gpu and modes"
+
+
+@pytest.mark.parametrize("variant,args", [("fv4-cheby", "5 8"), ("27pt-cheby", "5 8"),
+                                          pytest.param("7pt-jacobi", "5 8", marks=_MODES), pytest.param("7pt-jacobi", "4 27", marks=_MODES),
+                                          pytest.param("7pt-cheby-unlimit", "5 8", marks=_MODES),       # -DUNLIMIT_FMG_ITERATIONS: the F-cycle followed by V-cycles until converged (mg.c:1239-1247)
+                                          pytest.param("7pt-cheby-ucycle", "5 8", marks=_MODES),       # -DUSE_UCYCLES: MGBuild does not agglomerate, the host-driven bottom solver runs on a level of eight boxes (mg.c:878-893)
+                                          pytest.param("fv4-gsrb-ucycle", "5 8", marks=_MODES)])
 def test_reference_other_smoothers_run_on_the_hip_plugin(variant, args):
     """The remaining smoother / operator pairs the reference can be built with (-DUSE_JACOBI on the 7-point operator, -DUSE_CHEBY on the 4th-order
     and the 27-point ones) through the reference's own driver on the plugin: the pinned lines of the reference binary."""

@@ -82,3 +82,24 @@ def test_gathered_coarse_levels(world, variant, log2, per_rank, gold_key, gather
         if res[0]["levels"][lv]["dim"] <= gather:
             assert all(n == 0 for n in owners[1:]) and owners[0] > 0, (lv, owners)
     assert all(r["levels"][0]["my_boxes"] > 0 for r in res)
+
+
+def test_transport_selftest_names_the_rank_pair_of_a_damaged_message():
+    """bench.py's first contact (hpgmg_transport_selftest, host/level.c): every multi-rank test above runs it and needs 0; here rank 1's messages
+    arrive with one wrong element, and every receiver must say which pair failed."""
+    res = run_job(3, "7pt-cheby", 4, 1, extra_env={"HPGMG_TEST_CORRUPT_FROM": "1"})
+    assert res[1]["stats"]["selftest"] == -2 and "another rank" in res[1]["stats"]["selftest_message"], res[1]      # its own messages were intact; it learns of the others' through the first reduction
+    for r in (res[0], res[2]):
+        assert r["stats"]["selftest"] == -1 and ("from rank 1 to rank %d" % r["rank"]) in r["stats"]["selftest_message"], r
+
+
+def test_bench_supervisor_starts_fresh_ranks_with_the_other_transport_when_the_first_fails():
+    """bench.py --gpus 2 on a machine without a GPU: both attempts must fail, but in the right way -- the supervisors (torch.distributed.run workers that
+    never touch the GPU) notice the failed rccl ranks, end the attempt, start FRESH rank processes with the ipc transport, and report that no attempt
+    produced a result (exit code 1, no JSON line).  The GPU suite runs the same flow to a result (tests/test_gpu_multirank.py)."""
+    env = dict(os.environ, OMP_NUM_THREADS="1", HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--watchdog", "60"], capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode != 0
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")], out.stdout[-500:]
+    assert "rccl attempt: rank 0 exited with code" in out.stderr and "starting fresh rank processes with the ipc transport" in out.stderr, out.stderr[-2000:]
+    assert "ipc attempt: rank 0 exited with code" in out.stderr and "no attempt produced a result" in out.stderr, out.stderr[-2000:]
