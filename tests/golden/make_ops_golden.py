@@ -12,18 +12,15 @@ import json, os, subprocess, sys, tempfile
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-from ops_script import GEOMETRIES, HARNESS_VARIANTS, parse_harness_file  # noqa: E402
+from ops_script import GEOMETRIES, HARNESS_VARIANTS, LARGE_CASES, parse_harness_file  # noqa: E402
 
 
 def run_harness(variant, boxes_in_i, box_dim, keep_data=False):
     exe = os.path.join(ROOT, "oracle", "_ref", "opharness-" + variant)
-    with tempfile.TemporaryDirectory() as tmp:
+    with tempfile.TemporaryDirectory(dir=os.environ.get("HPGMG_HARNESS_TMP")) as tmp:      # a dump of the 256^3 problem is 4.4 GB
         path = os.path.join(tmp, "dump.bin")
         subprocess.run([exe, str(boxes_in_i), str(box_dim), path], check=True, stdout=subprocess.DEVNULL, env=dict(os.environ, OMP_NUM_THREADS="1"))
-        config, geoms, records, scalars = parse_harness_file(path)
-    if not keep_data:
-        for r in records:
-            r.pop("data")
+        config, geoms, records, scalars = parse_harness_file(path, keep_data)
     return {"config": config, "geoms": {str(k): v for k, v in geoms.items()}, "records": records, "scalars": scalars}
 
 
@@ -33,6 +30,9 @@ def main():
         for bi, bd in GEOMETRIES:
             out["%s %d %d" % (variant, bi, bd)] = run_harness(variant, bi, bd)
             print(variant, bi, bd, len(out["%s %d %d" % (variant, bi, bd)]["records"]), "vectors")
+    for variant, bi, bd in LARGE_CASES:      # the sizes the bandwidth-bound kernels run at (tests/ops_script.py)
+        out["%s %d %d" % (variant, bi, bd)] = run_harness(variant, bi, bd)
+        print(variant, bi, bd, len(out["%s %d %d" % (variant, bi, bd)]["records"]), "vectors")
     with open(os.path.join(HERE, "ops_golden.json"), "w") as f:
         json.dump(out, f, indent=0, sort_keys=True)
         f.write("\n")

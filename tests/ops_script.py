@@ -22,6 +22,10 @@ RESTRICT_CELL, RESTRICT_FACE_I, RESTRICT_FACE_J, RESTRICT_FACE_K = 0, 1, 2, 3
 SHAPE_BOX = 0
 
 GEOMETRIES = [(1, 16), (2, 8)]           # the 16^3 problem as one box and as 2 x 2 x 2 boxes of 8^3
+# The sizes at which the BANDWIDTH-BOUND kernels run (they only take boxes of side 128 m resp. 64 m): 2 x 2 x 2 boxes of 128^3 = BASELINE config 2's level for
+# the sweep-pair / wide / fused-residual kernels of the 7-point plugin, 2 x 2 x 2 boxes of 64^3 for the one-pass red + black and the LDS-tiled kernels of the
+# fv4 and 27-point plugins.  Hashes only, so the fixture stays small; the reference harness needs seconds of CPU for them.
+LARGE_CASES = [("7pt-cheby-helm", 2, 128), ("7pt-gsrb", 2, 128), ("fv4-gsrb", 2, 64), ("27pt-gsrb", 2, 64), ("fv4-cheby", 2, 64), ("27pt-cheby", 2, 64)]
 HARNESS_VARIANTS = ["7pt-cheby", "7pt-gsrb", "7pt-cheby-helm", "7ptcc-cheby", "7pt-jacobi", "27pt-cheby", "27pt-gsrb", "fv4-gsrb", "fv4-cheby", "fv2-cheby"]
 
 
@@ -41,33 +45,32 @@ def record_of(name, level, vid, arr, geom):
             "absmax": "%.17g" % float(np.max(np.abs(inner)))}
 
 
-def parse_harness_file(path):
-    """What oracle/op_harness.c wrote -> (config, geoms, records, scalars); records keep their arrays under 'data'."""
-    raw = open(path, "rb").read()
-    pos, config, geoms, records, scalars = 0, None, {}, [], {}
-    while True:
-        end = raw.index(b"\n", pos)
-        line = raw[pos:end].decode()
-        pos = end + 1
-        if line == "END":
-            break
-        tok = line.split()
-        if tok[0] == "CONFIG":
-            config = {"boxes_in_i": int(tok[1]), "box_dim": int(tok[2]), "a": float(tok[3]), "b": float(tok[4]), "radius": int(tok[5]), "shape": int(tok[6]), "vectors": int(tok[7])}
-        elif tok[0] == "GEOM":
-            geoms[int(tok[1])] = {"dim": int(tok[2]), "box_dim": int(tok[3]), "ghosts": int(tok[4]), "jStride": int(tok[5]), "kStride": int(tok[6]), "volume": int(tok[7]), "boxes": int(tok[8])}
-        elif tok[0] == "SCALAR":
-            scalars[tok[1]] = tok[2]
-        elif tok[0] == "DUMP":
-            name, level, vid, nb, vol = tok[1], int(tok[2]), int(tok[3]), int(tok[4]), int(tok[5])
-            n = nb * vol * 8
-            arr = np.frombuffer(raw[pos:pos + n], dtype=np.float64).reshape(nb, vol).copy()
-            pos += n + 1
-            rec = record_of(name, level, vid, arr, geoms[level])
-            rec["data"] = arr
-            records.append(rec)
-        else:
-            raise ValueError("unexpected line in harness output: " + line[:60])
+def parse_harness_file(path, keep_data=True):
+    """What oracle/op_harness.c wrote -> (config, geoms, records, scalars); records keep their arrays under 'data' (keep_data).  Streamed: a dump of the
+    256^3 problem is several GB."""
+    config, geoms, records, scalars = None, {}, [], {}
+    with open(path, "rb") as f:
+        while True:
+            line = f.readline().decode().rstrip("\n")
+            if line == "END":
+                break
+            tok = line.split()
+            if tok[0] == "CONFIG":
+                config = {"boxes_in_i": int(tok[1]), "box_dim": int(tok[2]), "a": float(tok[3]), "b": float(tok[4]), "radius": int(tok[5]), "shape": int(tok[6]), "vectors": int(tok[7])}
+            elif tok[0] == "GEOM":
+                geoms[int(tok[1])] = {"dim": int(tok[2]), "box_dim": int(tok[3]), "ghosts": int(tok[4]), "jStride": int(tok[5]), "kStride": int(tok[6]), "volume": int(tok[7]), "boxes": int(tok[8])}
+            elif tok[0] == "SCALAR":
+                scalars[tok[1]] = tok[2]
+            elif tok[0] == "DUMP":
+                name, level, vid, nb, vol = tok[1], int(tok[2]), int(tok[3]), int(tok[4]), int(tok[5])
+                arr = np.fromfile(f, dtype=np.float64, count=nb * vol).reshape(nb, vol)
+                f.read(1)
+                rec = record_of(name, level, vid, arr, geoms[level])
+                if keep_data:
+                    rec["data"] = arr
+                records.append(rec)
+            else:
+                raise ValueError("unexpected line in harness output: " + line[:60])
     return config, geoms, records, scalars
 
 
@@ -159,3 +162,43 @@ def replay(be, variant, boxes_in_i, box_dim, keep_data=False):
     dump("coarse.smooth.u", 1, V["U"])
     s.destroy()
     return geoms, records, scalars
+
+
+def replay_cycle_forms(be, variant, boxes_in_i, box_dim):
+    """HIP plugin only: what the CYCLE uses instead of the exported operators -- smooth() in its in-cycle form (sweep pairs without the x3 store, the one-pass
+    red + black kernels), residual + norm and residual + restriction + zero_vector as single passes -- on the inputs of the harness script, recorded under the
+    names of the reference's records they must equal (interiors: these forms do not refresh ghost zones, and leave VECTOR_TEMP unspecified)."""
+    import ctypes
+    from hpgmg_testlib import VARIANTS
+    cfg = VARIANTS[variant]
+    be.configure(**cfg)
+    a, b = (1.0, 1.0) if cfg["helmholtz"] else (0.0, 1.0)
+    s = be.solver(boxes_in_i, box_dim)
+    lib = be.lib
+    L0, L1 = s.level(0), s.level(1)
+    geoms = {l: {"dim": x.dim, "box_dim": x.box_dim, "ghosts": x.ghosts, "jStride": x.jStride, "kStride": x.kStride, "volume": x.volume, "boxes": x.num_boxes} for l, x in {0: L0, 1: L1}.items()}
+    vp, c_int, c_dbl = ctypes.c_void_p, ctypes.c_int, ctypes.c_double
+    lib.hpgmg_smooth_in_cycle.restype = c_int
+    lib.hpgmg_smooth_in_cycle.argtypes = [vp, c_int, c_int, c_dbl, c_dbl]
+    lib.hpgmg_residual_restrict_zero_fused.restype = c_int
+    lib.hpgmg_residual_restrict_zero_fused.argtypes = [vp, c_int, vp, c_int, c_int, c_dbl, c_dbl, c_int]
+    lib.hpgmg_residual_norm_fused.restype = c_int
+    lib.hpgmg_residual_norm_fused.argtypes = [vp, c_int, c_int, c_int, c_dbl, c_dbl, ctypes.POINTER(c_dbl)]
+    p0, p1 = L0.ptr, L1.ptr
+    records, scalars, taken = [], {}, {}
+    lib.random_vector(p0, V["U"])
+    lib.scale_vector(p0, V["U"], 0.001, V["U"])
+    lib.add_vectors(p0, V["U"], 1.0, V["U"], 0.0001, V["F"])
+    taken["smooth_in_cycle"] = lib.hpgmg_smooth_in_cycle(p0, V["U"], V["F"], a, b)
+    if not taken["smooth_in_cycle"]:
+        lib.smooth(p0, V["U"], V["F"], a, b)
+    records.append(record_of("smooth.u", 0, V["U"], L0.read_all(V["U"]), geoms[0]))
+    out = c_dbl(0.0)
+    taken["residual_norm_fused"] = lib.hpgmg_residual_norm_fused(p0, -1, V["U"], V["F"], a, b, ctypes.byref(out))
+    if taken["residual_norm_fused"]:
+        scalars["norm_r"] = "%.17g" % out.value
+    taken["residual_restrict_zero_fused"] = lib.hpgmg_residual_restrict_zero_fused(p1, V["R"], p0, V["U"], V["F"], a, b, V["U"])
+    if taken["residual_restrict_zero_fused"]:
+        records.append(record_of("restrict.cell", 1, V["R"], L1.read_all(V["R"]), geoms[1]))
+    s.destroy()
+    return records, scalars, taken

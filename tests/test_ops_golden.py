@@ -16,10 +16,10 @@ import pytest
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from hpgmg_testlib import Backend, have_reference, load_golden  # noqa: E402
-from ops_script import GEOMETRIES, HARNESS_VARIANTS, replay  # noqa: E402
+from ops_script import GEOMETRIES, HARNESS_VARIANTS, LARGE_CASES, replay, replay_cycle_forms  # noqa: E402
 
 GOLD = load_golden("ops_golden.json")
-CASES = [(v, bi, bd) for v in HARNESS_VARIANTS for bi, bd in GEOMETRIES]
+CASES = [(v, bi, bd) for v in HARNESS_VARIANTS for bi, bd in GEOMETRIES] + LARGE_CASES      # LARGE_CASES: the sizes the bandwidth-bound kernels run at
 
 
 def compare(gold, records, scalars, key):
@@ -70,3 +70,18 @@ def test_hip_equals_the_reference_operator_by_operator(variant, boxes_in_i, box_
     finally:
         hip.lib.hpgmg_set_ghost_free(1)
     compare(gold, records, scalars, "sha_interior" if ghost_free else "sha_full")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant,boxes_in_i,box_dim", LARGE_CASES)
+def test_hip_cycle_forms_equal_the_reference_operators(variant, boxes_in_i, box_dim):
+    """What an F-cycle really launches on its bandwidth-bound levels -- smooth() in its in-cycle form (sweep pairs without the next-to-last iterate's store,
+    red + black half sweeps in one pass), residual + norm and residual + restriction + zero_vector as single passes -- against the bytes the REFERENCE's separate
+    operators leave on the same inputs (chebyshev.c:8-100 / gsrb.c:24-132, residual.c:9-51, restriction.c:104-212, misc.c:287-329)."""
+    gold = GOLD["%s %d %d" % (variant, boxes_in_i, box_dim)]
+    records, scalars, taken = replay_cycle_forms(Backend.hip(), variant, boxes_in_i, box_dim)
+    assert taken["smooth_in_cycle"] == 1 and taken["residual_norm_fused"] == 1 and taken["residual_restrict_zero_fused"] == 1, taken
+    want = {g["name"]: g for g in gold["records"]}
+    bad = [(r["name"], r["absmax"], want[r["name"]]["absmax"]) for r in records if r["sha_interior"] != want[r["name"]]["sha_interior"]]
+    assert len(records) == 2 and not bad, bad
+    assert scalars["norm_r"] == gold["scalars"]["norm_r"], (scalars, gold["scalars"]["norm_r"])
