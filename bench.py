@@ -25,7 +25,8 @@ the reference CLI's `7 8` with N ranks (256^3, 256^3, 384^3, 512^3).
 value = fine-grid DOF of the whole job / max-over-ranks time.
 
 Extra objects on the JSON line:
-  roofline     the fine-level smoother kernel, timed with hipEvents on the launch stream inside the timed region.
+  roofline     the fine-level smoother kernel, timed with hipEvents on the launch stream inside the timed region (every 5th launch: an
+               event pair idles the GPU ~10 us, launches_timed says how many were timed).
                achieved / frac = the bytes ONE LAUNCH of that kernel has to move in the form it really has (a kernel that does two
                sweeps per pass is charged its own stream count once, not twice the single-sweep figure) / launch time / 8 TB/s;
                unfused_equivalent_GBs = SURVEY 8(d)'s bytes per cell per sweep x the sweeps the launch performs / launch time: what
@@ -431,6 +432,9 @@ def run_workload(J, workload, steps, warmup, precision="fp64"):
     # time only the fine-level smoother launches with hipEvents on the launch stream
     fine_cells = my_boxes * box_dim ** 3
     K.hpgmg_hip_profile_smoother_min_cells(max(fine_cells, 1))
+    # an event pair idles the GPU ~10 us per timed launch (1.2 % of a config-2 solve when every launch is timed): every 5th fine-level smoother launch of the
+    # timed region is timed -- 5 is coprime with the 4 / 6 / 8 launches per solve, so every position of the cycle is visited in turn
+    K.hpgmg_hip_profile_smoother_stride(5)
     K.hpgmg_hip_profile_smoother(1)
     barrier(J)
     t0 = time.perf_counter()

@@ -139,6 +139,7 @@ def _declare_kernel_api(lib):
         "hpgmg_hip_event_record": (c_int, [vp]), "hpgmg_hip_event_elapsed_ms": (c_dbl, [vp, vp]),
         "hpgmg_hip_profile_smoother": (None, [c_int]),
         "hpgmg_hip_profile_smoother_min_cells": (None, [ctypes.c_longlong]),
+        "hpgmg_hip_profile_smoother_stride": (None, [c_int]),
         "hpgmg_hip_profile_smoother_read": (c_int, [P(c_dbl), P(ctypes.c_longlong), P(ctypes.c_longlong)]),
         "hpgmg_hip_smooth_cheby": (c_int, [L, c_int, c_int, c_int, c_int, c_dbl, c_dbl, c_dbl, c_dbl, c_dbl]),
         "hpgmg_hip_smooth_gsrb": (c_int, [L, c_int, c_int, c_int, c_int, c_dbl, c_dbl, c_dbl, c_int]),

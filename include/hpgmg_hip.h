@@ -79,6 +79,8 @@ void   hpgmg_hip_range_pop(void);
 /* accumulate the GPU time of every smoother-kernel launch between begin/end (hipEvents around each launch) */
 void   hpgmg_hip_profile_smoother(int enable);
 void   hpgmg_hip_profile_smoother_min_cells(long long min_cells); /* time only launches over >= this many cells */
+/* time only every stride-th eligible launch (an event pair idles the GPU ~10 us per timed launch); 1 = all */
+void hpgmg_hip_profile_smoother_stride(int stride);
 int    hpgmg_hip_profile_smoother_read(double *total_ms, long long *launches, long long *cells);
 
 /* Ghost-free mode of the 7-pt stencil launchers below.  When `on` and L->box_nbr is given, a face
