@@ -126,9 +126,8 @@ void hpgmg_solver_restrict_rhs(hpgmg_solver *s, int l) {
 
 static int solve_with_vcycles = 0;      /* --vcycles: the benchmark solves with MGSolve (V-cycles until converged), as the reference built without -DUSE_FCYCLES does (hpgmg-fv.c:79-83) */
 double hpgmg_solver_fmg(hpgmg_solver *s, int l) {
-  zero_vector(s->mg.levels[l], VECTOR_U);
-  if (solve_with_vcycles) MGSolve(&s->mg, l, VECTOR_U, VECTOR_F, s->a, s->b, 1e-10);
-  else FMGSolve(&s->mg, l, VECTOR_U, VECTOR_F, s->a, s->b, 1e-10);
+  if (solve_with_vcycles) { zero_vector(s->mg.levels[l], VECTOR_U); MGSolve(&s->mg, l, VECTOR_U, VECTOR_F, s->a, s->b, 1e-10); }
+  else { hpgmg_fmg_zero_u_first(); FMGSolve(&s->mg, l, VECTOR_U, VECTOR_F, s->a, s->b, 1e-10); }      /* zero_vector(u) + FMGSolve: u is zeroed where FMGSolve first touches it */
   return hpgmg_last_solve.norm_of_residual;
 }
 

@@ -594,6 +594,11 @@ void MGPCG(mg_type *G, int onLevel, int x_id, int F_id, double a, double b, doub
 /* V-cycles FMGSolve may add after its F-cycle until the residual has dropped by rtol: 0, or 20 = the reference built with -DUNLIMIT_FMG_ITERATIONS (mg.c:1239-1247) */
 static int hpgmg_fmg_vcycles = 0;
 void hpgmg_set_fmg_vcycles(int n) { hpgmg_fmg_vcycles = n > 0 ? n : 0; }
+/* The benchmark step is zero_vector(u) followed by FMGSolve (hpgmg-fv.c:77-85).  FMGSolve's first access to u on its level is the write of
+ * interpolation_fcycle (mg.c:1295), so the zeroing may wait until then and go out WITH it (hpgmg_zero_interpolation_fcycle_fused): the caller
+ * says "u is to be zeroed first" instead of calling zero_vector, and FMGSolve zeroes it where it would first be touched. */
+static int fmg_zero_u_first = 0;
+void hpgmg_fmg_zero_u_first(void) { fmg_zero_u_first = 1; }
 void FMGSolve(mg_type *G, int onLevel, int u_id, int F_id, double a, double b, double rtol) {
   /* one F-cycle; further V-cycles only on request (hpgmg_set_fmg_vcycles) */
   const int e_id = u_id, R_id = VECTOR_R, maxVCycles = hpgmg_fmg_vcycles;
@@ -601,7 +606,9 @@ void FMGSolve(mg_type *G, int onLevel, int u_id, int F_id, double a, double b, d
   level_type *L = G->levels[onLevel];
   char label[64];
   int l, v;
+  int u_to_zero = fmg_zero_u_first;
   hpgmg_tick t;
+  fmg_zero_u_first = 0;
   G->MGSolves_performed++;
   if (!L->active) return;
   SAY(L->my_rank, "FMGSolve... ");
@@ -623,6 +630,7 @@ void FMGSolve(mg_type *G, int onLevel, int u_id, int F_id, double a, double b, d
   int ftail = bottom;
   for (l = onLevel; l < bottom; l++) if (is_small(G, l) && hpgmg_vcycle_legs_fused(&G->levels[l], G->num_levels - l, e_id, R_id, a, b, 5)) { ftail = l; break; }
 
+  if (u_to_zero && ftail <= onLevel) { zero_vector(L, u_id); u_to_zero = 0; }      /* no interpolation onto this level will come: zero it now, as the caller would have */
   for (l = first_restriction; l < ftail; l++) {           /* carry the right-hand side down */
     if (is_small(G, l)) seg_open();
     t = hpgmg_tick_begin(G->levels[l], &G->levels[l]->timers.Total, "restrict R");
@@ -646,7 +654,10 @@ void FMGSolve(mg_type *G, int onLevel, int u_id, int F_id, double a, double b, d
   for (l = ftail - 1; l >= onLevel; l--) {       /* climb: prolong the solution, then one V-cycle */
     if (is_small(G, l)) seg_open();
     t = hpgmg_tick_begin(G->levels[l], &G->levels[l]->timers.Total, "interpolation_fcycle");
-    interpolation_fcycle(G->levels[l], e_id, 0.0, G->levels[l + 1], e_id);
+    if (l == onLevel && u_to_zero) {
+      if (!hpgmg_zero_interpolation_fcycle_fused(G->levels[l], e_id, G->levels[l + 1], e_id)) { zero_vector(G->levels[l], e_id); interpolation_fcycle(G->levels[l], e_id, 0.0, G->levels[l + 1], e_id); }
+      u_to_zero = 0;
+    } else interpolation_fcycle(G->levels[l], e_id, 0.0, G->levels[l + 1], e_id);
     hpgmg_tick_end(t);
     G->levels[l]->vcycles_from_this_level++;
     MGVCycle(G, e_id, R_id, a, b, l);

@@ -54,6 +54,8 @@ int hpgmg_restrict_zero_fused(level_type *Lc, int id_c, level_type *Lf, int id_f
  * leg (mg.c:1150-1153) -- as ONE pass over the fine level: the residual is restricted on the fly and never stored (VECTOR_TEMP of the
  * fine level keeps its previous content; nothing reads it before the up leg's smooth() overwrites it).  0 = not applicable. */
 /* per fine box: the coarse box it restricts into and the coarse cell under its first cell -- read off the local restriction list */
+static const int *restrict_map_of(level_type *Lf, backend_t *Bf);
+const int *hp_restrict_map_of(level_type *Lf, backend_t *Bf) { return restrict_map_of(Lf, Bf); }
 static const int *restrict_map_of(level_type *Lf, backend_t *Bf) {
   communicator_type *S = &Lf->restriction[RESTRICT_CELL];
   if (!Bf->d_restrict_map) {
@@ -178,6 +180,7 @@ int hpgmg_residual_norm_fused(level_type *L, int res_id, int x_id, int rhs_id, d
 }
 
 /* ---------------------------------------------------------------- interpolation_p0.c:52-159, interpolation_p1.c:70-180 */
+
 static void interpolation_lists(level_type *Lf, int id_f, double prescale, level_type *Lc, int id_c, int order, int tagbits) {
   TICK(Lf, interpolation_total, "interpolation");
   communicator_type *S = &Lc->interpolation, *R = &Lf->interpolation;
@@ -203,6 +206,31 @@ void hp_do_interpolation_vcycle(level_type *Lf, int id_f, double prescale, level
   if (c.op != HPGMG_OP_7PT) hp_no_kernel("interpolation_vcycle for this operator");
   interpolation_lists(Lf, id_f, prescale, Lc, id_c, 0, 0x6);
 }
+/* every parent of the fine level's cells is a local box-to-box entry (what the one-launch forms below need) */
+static int interp_all_local(level_type *Lf, level_type *Lc) {
+  communicator_type *S = &Lc->interpolation, *R = &Lf->interpolation;
+  int n;
+  if (Lc->num_my_boxes < 1 || S->num_sends || R->num_recvs || S->num_blocks[0] || R->num_blocks[2] || S->num_blocks[1] < 1) return 0;
+  for (n = 0; n < S->num_blocks[1]; n++) if (S->blocks[1][n].read.box < 0 || S->blocks[1][n].write.box < 0) return 0;
+  return 1;
+}
+/* zero_vector(Lf, id_f) ; interpolation_fcycle(Lf, id_f, 0.0, Lc, id_c) -- how the benchmark's step reaches the fine level: zero_vector(u) before
+ * FMGSolve (hpgmg-fv.c:77-85), whose first write of u on that level is this interpolation (mg.c:1295) -- with the fine vector neither zeroed nor read
+ * (0.0 * 0.0 + y): one pass over the fine level less.  7-point, ghost-free mode, every box local: the interior is exactly what the two operators leave;
+ * the ghost zones, which zero_vector would clear, keep their content -- nothing reads them before a launch that needs them fills them.
+ * 0 = the caller issues both. */
+static long long zero_interp_fused = 0;
+long long hpgmg_zero_interp_fused(void) { return zero_interp_fused; }
+int hpgmg_zero_interpolation_fcycle_fused(level_type *Lf, int id_f, level_type *Lc, int id_c) {
+  hpgmg_config c; hpgmg_get_config(&c);
+  if (c.op != HPGMG_OP_7PT || !hp_switch(SW_FUSED_RESIDUAL) || !hp_ghost_free_mode() || !Lf->active || !Lc->active || Lf->num_my_boxes < 1) return 0;
+  if (!interp_all_local(Lf, Lc) || !hp_backend_of(Lf)->all_faces_local) return 0;
+  zero_interp_fused++;
+  exchange_boundary(Lc, id_c, STENCIL_SHAPE_BOX);              /* interpolation_p1.c:71-72 */
+  apply_BCs_p1(Lc, id_c, STENCIL_SHAPE_BOX);
+  interpolation_lists(Lf, id_f, 0.0, Lc, id_c, 6, 0x7);
+  return 1;
+}
 void interpolation_fcycle(level_type *Lf, int id_f, double prescale, level_type *Lc, int id_c) {
   hpgmg_config c; hpgmg_get_config(&c);
   if (c.op == HPGMG_OP_27PT || c.op == HPGMG_OP_FV2) { hp_do_interpolation_vcycle(Lf, id_f, prescale, Lc, id_c); return; } /* operators.27pt.c:150-151, .fv2.c:151-152 */
@@ -212,6 +240,8 @@ void interpolation_fcycle(level_type *Lf, int id_f, double prescale, level_type 
     return;
   }
   if (c.op != HPGMG_OP_7PT) hp_no_kernel("interpolation_fcycle for this operator");
+  /* ghost-free form (interpolation_p1.c:71-72 without its two launches): every coarse box local, Dirichlet, box-to-box entries only -- the kernel reads a
+   * coarse neighbour where it lives and applies apply_BCs_p1's rule in registers, as the 7-point stencils do (HPGMG_GHOST_FREE=0: the three-step form) */
   exchange_boundary(Lc, id_c, STENCIL_SHAPE_BOX);
   apply_BCs_p1(Lc, id_c, STENCIL_SHAPE_BOX);
   interpolation_lists(Lf, id_f, prescale, Lc, id_c, 1, 0x7);

@@ -186,6 +186,7 @@ HP_INTERNAL double hp_allreduce_scalar(level_type *L, double v, int op);
 HP_INTERNAL double hp_do_dot(level_type *L, int a, int b);
 HP_INTERNAL double hp_do_norm(level_type *L, int a);
 HP_INTERNAL void hp_small_ops_forget(void);
+HP_INTERNAL const int *hp_restrict_map_of(level_type *Lf, backend_t *Bf);      /* device table: per fine box the coarse box and the coarse cell under its first cell; NULL when a parent is not local */
 
 #define BLAS1(call) do { TICK(L, blas1, "BLAS1"); HIP_OK(call); TOCK(); } while (0)
 #define STENCIL_WITH_GHOSTS(L, id, out_id, TIMER, CALL) do {                                                     \

@@ -311,6 +311,41 @@ static int smooth_gsrb_pairs(level_type *L, int x_id, int rhs_id, double a, doub
  * (HPGMG_TEMP_SCRATCH=0 stores it as smooth() does).  0 = not applicable. */
 int hpgmg_interp_smooth_fused(level_type *Lf, int e_id, int R_id, level_type *Lc, double a, double b) { hp_lazy_flush(); return hp_interp_smooth_fused(Lf, e_id, R_id, Lc, a, b, 0); }
 /* exact_state: VECTOR_TEMP is left as smooth() leaves it (the lazy queue runs behind the reference's own driver, which promises nothing about it) */
+/* The same fold on the levels the sweep-pair kernel does not take (the cache-resident 128^3 ... 32^3 levels of config 2: single Chebyshev sweeps): sweep 0
+ * reads x_n and sweep 1 reads x_{n-1} as stored + the coarse value above the cell (kernels/stencil_direct.hpp: InterpFold), so interpolation_vcycle is no
+ * launch of its own.  The same iterates; the interpolated vector itself never exists, and VECTOR_TEMP ends as smooth() leaves it (x3). */
+static long long interp_folded_single = 0;
+long long hpgmg_interp_folded_single(void) { return interp_folded_single; }      /* (tests) */
+static int interp_smooth_fused_single(level_type *Lf, int e_id, int R_id, level_type *Lc, double a, double b) {
+  hpgmg_config cfg;
+  hpgmg_get_config(&cfg);
+  const int sweeps = hpgmg_smooth_sweeps(), v = hp_variant();
+  communicator_type *S = &Lc->interpolation, *Rv = &Lf->interpolation;
+  if (!hp_switch(SW_FUSED_RESIDUAL) || cfg.op != HPGMG_OP_7PT || cfg.smoother != HPGMG_SMOOTH_CHEBY || !Lf->active || !Lc->active || sweeps < 2) return 0;
+  if (Lf->num_my_boxes < 1 || Lc->num_my_boxes < 1 || !hp_ghost_free_mode() || Lf->boundary_condition.type != BC_DIRICHLET) return 0;
+  if (S->num_sends || S->num_recvs || Rv->num_sends || Rv->num_recvs || S->num_blocks[0] || Rv->num_blocks[2]) return 0;   /* all parents local */
+  if (e_id == VECTOR_TEMP || R_id == VECTOR_TEMP || Lf->dominant_eigenvalue_of_DinvA <= 0.0) return 0;
+  backend_t *B = hp_backend_of(Lf), *Bc = hp_backend_of(Lc);
+  if (!B->all_faces_local || stencil_get_shape() != STENCIL_SHAPE_STAR) return 0;
+  hpgmg_hip_set_ghost_free(1);
+  if (!hpgmg_hip_smooth_cheby_fold_supported(&B->dev, v)) return 0;
+  const int *map = hp_restrict_map_of(Lf, B);
+  if (!map) return 0;
+  double c1[16], c2[16];
+  const double h2inv = 1.0 / (Lf->h * Lf->h);
+  int s;
+  cheby_coefficients(Lf, sweeps, c1, c2);
+  B->img_active = 0;
+  for (s = 0; s < sweeps; s++) {
+    const int src = (s & 1) ? VECTOR_TEMP : e_id, dst = (s & 1) ? e_id : VECTOR_TEMP;
+    TICK(Lf, smooth, s < 2 ? "smooth (Chebyshev sweep, interpolation folded in)" : "smooth");
+    if (s < 2) hpgmg_hip_stencil_fold_interpolation(&Bc->dev, e_id, map, s + 1);
+    HIP_OK(hpgmg_hip_smooth_cheby(&B->dev, v, src, dst, R_id, a, b, h2inv, c1[s], c2[s]));
+    TOCK();
+  }
+  interp_folded_single++;
+  return 1;
+}
 int hp_interp_smooth_fused(level_type *Lf, int e_id, int R_id, level_type *Lc, double a, double b, int exact_state) {
   hpgmg_config cfg;
   hpgmg_get_config(&cfg);
@@ -319,9 +354,10 @@ int hp_interp_smooth_fused(level_type *Lf, int e_id, int R_id, level_type *Lc, d
   if (cfg.op != HPGMG_OP_7PT || !Lf->active || !Lc->active) return 0;
   if (cfg.smoother != HPGMG_SMOOTH_CHEBY && !(cfg.smoother == HPGMG_SMOOTH_GSRB && !hpgmg_gsrb_out_of_place())) return 0;
   if (S->num_sends || S->num_recvs || Rv->num_sends || Rv->num_recvs || S->num_blocks[0] || Rv->num_blocks[2]) return 0;   /* all parents local */
-  if (Lf->box_dim % 128 != 0 || Lc->box_dim * 2 != Lf->box_dim || Lc->num_my_boxes != Lf->num_my_boxes || !boxes_lexicographic(Lc)) return 0;
-  if (!hp_backend_of(Lf)->all_faces_local) return 0;       /* across ranks the pair kernel takes x0 as stored (interpolation stays its own launch) */
-  if (!pair_kernel_ready(Lf, e_id, R_id, sweeps)) return 0;
+  if (Lf->box_dim % 128 != 0 || Lc->box_dim * 2 != Lf->box_dim || Lc->num_my_boxes != Lf->num_my_boxes || !boxes_lexicographic(Lc) ||
+      !hp_backend_of(Lf)->all_faces_local ||        /* across ranks the pair kernel takes x0 as stored (interpolation stays its own launch) */
+      !pair_kernel_ready(Lf, e_id, R_id, sweeps))
+    return interp_smooth_fused_single(Lf, e_id, R_id, Lc, a, b);      /* (VECTOR_TEMP ends as smooth() leaves it: also for the queue) not a sweep-pair level: the fold of the single sweeps, if it is one of those */
   if (cfg.smoother == HPGMG_SMOOTH_CHEBY && Lf->dominant_eigenvalue_of_DinvA <= 0.0) return 0;
   hpgmg_hip_pair_fold_interpolation(&hp_backend_of(Lc)->dev, e_id, 1.0);
   if (cfg.smoother == HPGMG_SMOOTH_CHEBY) {

@@ -206,7 +206,9 @@ __global__ __launch_bounds__(256) void restrict_cell_zero_kernel(const hpgmg_hip
 // One wave per COARSE row of an entry (grid.y strides over the rows), one coarse cell per lane: the lane
 // produces the cell's 2x2x2 children, each fine row as one 16-byte read-modify-write when the layout allows.
 // The per-child expression (prescale*fine + weighted coarse neighbours, in the reference's order) is unchanged.
-template <int ORDER>
+// ZEROED (with prescale == 0): the fine vector counts as holding +0.0 everywhere -- zero_vector() followed by interpolation_fcycle() with the fine
+// vector neither zeroed nor read (0.0 * 0.0 + y).
+template <int ORDER, bool ZEROED = false>
 __global__ __launch_bounds__(256) void interp_blocks_kernel(const hpgmg_hip_level Lf, int id_f, double prescale, const hpgmg_hip_level Lc, int id_c,
                                                             const blockCopy_type *__restrict__ list) {
   const blockCopy_type &e = list[blockIdx.x];
@@ -262,7 +264,7 @@ __global__ __launch_bounds__(256) void interp_blocks_kernel(const hpgmg_hip_leve
           double f0 = 0.0, f1 = 0.0;
           if (prescale != 0.0) load_fine(f0, f1);
           blend(f0, f1);
-          if (prescale == 0.0 && (v[0] == 0.0 || v[1] == 0.0)) { load_fine(f0, f1); blend(f0, f1); }
+          if (!ZEROED && prescale == 0.0 && (v[0] == 0.0 || v[1] == 0.0)) { load_fine(f0, f1); blend(f0, f1); }
           if (pairs) *reinterpret_cast<double2 *>(fw) = make_double2(v[0], v[1]);
           else { fw[0] = v[0]; fw[1] = v[1]; }
         }
@@ -391,6 +393,10 @@ int hpgmg_hip_interpolate_blocks(const hpgmg_hip_level *Lf, int id_f, double pre
   const int slabs = n >= 4096 ? 1 : (4096 / n > 64 ? 64 : 4096 / n);
   if (order == 0) hipLaunchKernelGGL((interp_blocks_kernel<0>), dim3(n, slabs), dim3(256), 0, g_stream, *Lf, id_f, prescale, *Lc, id_c, blocks);
   else if (order == 1) hipLaunchKernelGGL((interp_blocks_kernel<1>), dim3(n, slabs), dim3(256), 0, g_stream, *Lf, id_f, prescale, *Lc, id_c, blocks);
+  else if (order == 6) {      // trilinear onto a fine vector that counts as zeroed (zero_vector + interpolation_fcycle, the fine level touched once)
+    if (prescale != 0.0) return record_error(hipErrorInvalidValue, "interpolation onto a zeroed vector: prescale 0");
+    hipLaunchKernelGGL((interp_blocks_kernel<1, true>), dim3(n, slabs), dim3(256), 0, g_stream, *Lf, id_f, prescale, *Lc, id_c, blocks);
+  }
   else if (order == 2) hipLaunchKernelGGL((interp_tensor_kernel<2>), dim3(n, slabs), dim3(256), 0, g_stream, *Lf, id_f, prescale, *Lc, id_c, blocks);
   else if (order == 3) hipLaunchKernelGGL((interp_tensor_kernel<3>), dim3(n, slabs), dim3(256), 0, g_stream, *Lf, id_f, prescale, *Lc, id_c, blocks);
   else if (order == 4) hipLaunchKernelGGL((interp_tensor_kernel<4>), dim3(n, slabs), dim3(256), 0, g_stream, *Lf, id_f, prescale, *Lc, id_c, blocks);

@@ -29,8 +29,8 @@
 
 namespace hpgmg {
 
-template <int V, int MODE>
-__global__ __launch_bounds__(256) void stencil7_kernel(const hpgmg_hip_level L, const StencilArgs P) {
+template <int V, int MODE, bool IP = false>
+__global__ __launch_bounds__(256) void stencil7_kernel(const hpgmg_hip_level L, const StencilArgs P, const InterpFold F = InterpFold{}) {
   const int logical = xcd_logical_block((int)blockIdx.x, P.per_xcd);
   if (logical >= P.total_blocks) return;
   // logical id -> (box, k chunk, j tile, i tile), i fastest
@@ -81,28 +81,49 @@ __global__ __launch_bounds__(256) void stencil7_kernel(const hpgmg_hip_level L, 
     defer_klo = (nb[4] == -2); defer_khi = (nb[5] == -2);
   }
 
+  // IP, sweep 0 of a smooth() with the interpolation folded in: cell (ii, jj, kk) of box bx as stored + the coarse value above it; one step across a
+  // face of the box lands in the neighbouring box (every box local) or on the Dirichlet rule applied to the folded centre
+  const bool fold_x = IP && F.which == 1;
+  auto folded = [&](int bx, int ii, int jj, int kk) -> double { return vec_origin(L, bx, P.xn_id)[ii + jj * jS + kk * kS] + fold_coarse(F, bx, ii, jj, kk); };
+  auto folded_step = [&](int dir, int ii, int jj, int kk, double centre) -> double {      // (ii, jj, kk): one step outside this box across face dir
+    const int nb = L.box_nbr[6 * box + dir];
+    if (nb < 0) return -centre;
+    if (dir == 0) ii = last; else if (dir == 1) ii = 0; else if (dir == 2) jj = last; else if (dir == 3) jj = 0; else if (dir == 4) kk = last; else kk = 0;
+    return folded(nb, ii, jj, kk);
+  };
   int ijk = i + j * jS + k0 * kS;
-  double xc = x[ijk];
-  double xm = (gf && k0 == 0) ? outside(4, i + j * jS + last * kS, ijk - kS, xc) : x[ijk - kS];
+  double xc = fold_x ? folded(box, i, j, k0) : x[ijk];
+  double xm = fold_x ? (k0 == 0 ? folded_step(4, i, j, -1, xc) : folded(box, i, j, k0 - 1))
+                     : ((gf && k0 == 0) ? outside(4, i + j * jS + last * kS, ijk - kS, xc) : x[ijk - kS]);
   double bk0 = kVC ? beta_k[ijk] : 0.0;
 
   for (int k = k0; k < k1; k++, ijk += kS) {
-    const double xp = (gf && k == last) ? outside(5, i + j * jS, ijk + kS, xc) : x[ijk + kS];
+    const double xp = fold_x ? (k == last ? folded_step(5, i, j, k + 1, xc) : folded(box, i, j, k + 1))
+                             : ((gf && k == last) ? outside(5, i + j * jS, ijk + kS, xc) : x[ijk + kS]);
     const double bk1 = kVC ? beta_k[ijk + kS] : 0.0;
     bool update = true;
     if (MODE == MODE_GSRB) update = (((i ^ j ^ k ^ colour000) & 1) == 0);
     if (P.defer && (defer_ij || (k == 0 && defer_klo) || (k == last && defer_khi))) update = false;
     if (update) {
-      const double xim = (gf && i == 0)    ? outside(0, last + j * jS + k * kS, ijk - 1, xc)  : x[ijk - 1];
-      const double xip = (gf && i == last) ? outside(1, j * jS + k * kS, ijk + 1, xc)          : x[ijk + 1];
-      const double xjm = (gf && j == 0)    ? outside(2, i + last * jS + k * kS, ijk - jS, xc) : x[ijk - jS];
-      const double xjp = (gf && j == last) ? outside(3, i + k * kS, ijk + jS, xc)              : x[ijk + jS];
+      double xim, xip, xjm, xjp;
+      if (fold_x) {
+        xim = (i == 0)    ? folded_step(0, i - 1, j, k, xc) : folded(box, i - 1, j, k);
+        xip = (i == last) ? folded_step(1, i + 1, j, k, xc) : folded(box, i + 1, j, k);
+        xjm = (j == 0)    ? folded_step(2, i, j - 1, k, xc) : folded(box, i, j - 1, k);
+        xjp = (j == last) ? folded_step(3, i, j + 1, k, xc) : folded(box, i, j + 1, k);
+      } else {
+        xim = (gf && i == 0)    ? outside(0, last + j * jS + k * kS, ijk - 1, xc)  : x[ijk - 1];
+        xip = (gf && i == last) ? outside(1, j * jS + k * kS, ijk + 1, xc)          : x[ijk + 1];
+        xjm = (gf && j == 0)    ? outside(2, i + last * jS + k * kS, ijk - jS, xc) : x[ijk - jS];
+        xjp = (gf && j == last) ? outside(3, i + k * kS, ijk + jS, xc)              : x[ijk + jS];
+      }
       double bi0 = 0.0, bi1 = 0.0, bj0 = 0.0, bj1 = 0.0, al = 0.0;
       if (kVC) { bi0 = beta_i[ijk]; bi1 = beta_i[ijk + 1]; bj0 = beta_j[ijk]; bj1 = beta_j[ijk + jS]; }
       if (kHelm) al = alpha[ijk];
       const double Ax = apply_op_7pt<V>(xc, xim, xip, xjm, xjp, xm, xp, bi0, bi1, bj0, bj1, bk0, bk1, al, P.a, P.b, P.h2inv);
       if (MODE == MODE_CHEBY) {
-        const double xnm1 = out[ijk];
+        double xnm1 = out[ijk];
+        if (IP && F.which == 2) xnm1 = xnm1 + fold_coarse(F, box, i, j, k);
         out[ijk] = xc + P.c1 * (xc - xnm1) + P.c2 * dinv[ijk] * (rhs[ijk] - Ax);
       } else if (MODE == MODE_GSRB) {
         out[ijk] = xc + dinv[ijk] * (rhs[ijk] - Ax);
@@ -542,6 +563,8 @@ void profile_end(int p, long long cells, bool first_part) {
   if (!first_part) g_prof_launches++;
 }
 
+static InterpFold g_fold = {};            // set by hpgmg_hip_stencil_fold_interpolation for the NEXT hpgmg_hip_smooth_cheby call, which moves it to g_fold_now whatever path it takes
+static InterpFold g_fold_now = {};        // the fold of the hpgmg_hip_smooth_cheby call in progress
 static int g_ghost_free = 0;
 static int g_tile_ghost_free = 0;
 static TileFused g_tile_fused = {};      // consumed by the next tiled residual launch (27-point / fv4): what becomes of the residual
@@ -747,6 +770,7 @@ static int launch(const hpgmg_hip_level *L, int variant, StencilArgs P, bool is_
   int prof = is_smoother ? profile_begin(cells) : -1;
   static const int no_wide = env_int("HPGMG_TUNE_NO_WIDE", 0);
   // wide kernel: side a multiple of 128, 16-byte aligned interior rows (even strides; the box bases are checked by the host)
+  if (g_fold_now.which && L->dim % 128 == 0) { return record_error(hipErrorInvalidValue, "folded interpolation: not in the wide kernel (hpgmg_hip_smooth_cheby_fold_supported)"); }
   if (!no_wide && L->dim % 128 == 0 && L->jStride % 2 == 0 && L->kStride % 2 == 0 && L->volume % 2 == 0 && (L->flags & 1)) {
     static const int wj = env_int("HPGMG_TUNE_WIDE_WJ", 8), tune_kc = env_int("HPGMG_TUNE_KCHUNK", 0);
     block = dim3(64, wj, 1);
@@ -781,6 +805,19 @@ static int launch(const hpgmg_hip_level *L, int variant, StencilArgs P, bool is_
     A.kchunk = (tile7_kc > 0 && L->dim % tile7_kc == 0) ? tile7_kc : 8; A.chunks_k = L->dim / A.kchunk;
     A.total_blocks = L->num_boxes * A.chunks_k * A.tiles_j * A.tiles_i;
     const int tgrid = grid_for(A.total_blocks, &A.per_xcd);
+    if (MODE == MODE_CHEBY && g_fold_now.which) {
+      const InterpFold F = g_fold_now;
+      if (!P.ghost_free) return record_error(hipErrorInvalidValue, "folded interpolation needs the ghost-free path");
+      switch (variant) {
+        case HPGMG_HIP_7PT_VC_HELMHOLTZ: hipLaunchKernelGGL((stencil7_tile_kernel<HPGMG_HIP_7PT_VC_HELMHOLTZ, MODE_CHEBY, TJ, true>), dim3(tgrid), dim3(64, TJ), 0, g_stream, *L, A, F); break;
+        case HPGMG_HIP_7PT_VC_POISSON:   hipLaunchKernelGGL((stencil7_tile_kernel<HPGMG_HIP_7PT_VC_POISSON, MODE_CHEBY, TJ, true>), dim3(tgrid), dim3(64, TJ), 0, g_stream, *L, A, F); break;
+        case HPGMG_HIP_7PT_CC:           hipLaunchKernelGGL((stencil7_tile_kernel<HPGMG_HIP_7PT_CC, MODE_CHEBY, TJ, true>), dim3(tgrid), dim3(64, TJ), 0, g_stream, *L, A, F); break;
+        default: return record_error(hipErrorInvalidValue, "stencil variant not implemented");
+      }
+      profile_end(prof, cells);
+      HPGMG_LAUNCH_CHECK("stencil7_tile_kernel (interpolation folded in)");
+      return 0;
+    }
     switch (variant) {
       case HPGMG_HIP_7PT_VC_HELMHOLTZ: hipLaunchKernelGGL((stencil7_tile_kernel<HPGMG_HIP_7PT_VC_HELMHOLTZ, TM, TJ>), dim3(tgrid), dim3(64, TJ), 0, g_stream, *L, A); break;
       case HPGMG_HIP_7PT_VC_POISSON:   hipLaunchKernelGGL((stencil7_tile_kernel<HPGMG_HIP_7PT_VC_POISSON, TM, TJ>), dim3(tgrid), dim3(64, TJ), 0, g_stream, *L, A); break;
@@ -789,6 +826,19 @@ static int launch(const hpgmg_hip_level *L, int variant, StencilArgs P, bool is_
     }
     profile_end(prof, cells);
     HPGMG_LAUNCH_CHECK("stencil7_tile_kernel");
+    return 0;
+  }
+  if (MODE == MODE_CHEBY && g_fold_now.which) {
+    const InterpFold F = g_fold_now;
+    if (!P.ghost_free || P.defer) return record_error(hipErrorInvalidValue, "folded interpolation needs the ghost-free path with every box local");
+    switch (variant) {
+      case HPGMG_HIP_7PT_VC_HELMHOLTZ: hipLaunchKernelGGL((stencil7_kernel<HPGMG_HIP_7PT_VC_HELMHOLTZ, MODE_CHEBY, true>), dim3(grid), block, 0, g_stream, *L, P, F); break;
+      case HPGMG_HIP_7PT_VC_POISSON:   hipLaunchKernelGGL((stencil7_kernel<HPGMG_HIP_7PT_VC_POISSON, MODE_CHEBY, true>), dim3(grid), block, 0, g_stream, *L, P, F); break;
+      case HPGMG_HIP_7PT_CC:           hipLaunchKernelGGL((stencil7_kernel<HPGMG_HIP_7PT_CC, MODE_CHEBY, true>), dim3(grid), block, 0, g_stream, *L, P, F); break;
+      default: return record_error(hipErrorInvalidValue, "stencil variant not implemented");
+    }
+    profile_end(prof, cells);
+    HPGMG_LAUNCH_CHECK("stencil7_kernel (interpolation folded in)");
     return 0;
   }
   switch (variant) {
@@ -864,10 +914,21 @@ int hpgmg_hip_profile_smoother_read(double *total_ms, long long *launches, long 
   return 0;
 }
 
+// the NEXT hpgmg_hip_smooth_cheby launch reads its operand with the piecewise-constant interpolation from (Lc, coarse_id) folded in (InterpFold)
+int hpgmg_hip_smooth_cheby_fold_supported(const hpgmg_hip_level *L, int variant) {
+  return (variant == HPGMG_HIP_7PT_VC_HELMHOLTZ || variant == HPGMG_HIP_7PT_VC_POISSON || variant == HPGMG_HIP_7PT_CC) && L->box_nbr && L->dim % 128 != 0 && L->dim % 2 == 0 && !g_defer_mode;
+}
+void hpgmg_hip_stencil_fold_interpolation(const hpgmg_hip_level *Lc, int coarse_id, const int *map, int which) {
+  g_fold = InterpFold{}; if (Lc && which) { g_fold.which = which; g_fold.Lc = *Lc; g_fold.coarse_id = coarse_id; g_fold.map = map; }
+}
 int hpgmg_hip_smooth_cheby(const hpgmg_hip_level *L, int variant, int xn_id, int xnp1_id, int rhs_id,
                            double a, double b, double h2inv, double c1, double c2) {
   StencilArgs P = {}; P.xn_id = xn_id; P.xout_id = xnp1_id; P.rhs_id = rhs_id; P.a = a; P.b = b; P.h2inv = h2inv; P.c1 = c1; P.c2 = c2;
-  return launch<MODE_CHEBY>(L, variant, P, true);
+  g_fold_now = g_fold; g_fold = InterpFold{};            // a requested fold belongs to THIS call, also when the launch is skipped (graph replay)
+  if (g_fold_now.which && variant != HPGMG_HIP_7PT_VC_HELMHOLTZ && variant != HPGMG_HIP_7PT_VC_POISSON && variant != HPGMG_HIP_7PT_CC) { g_fold_now = InterpFold{}; return record_error(hipErrorInvalidValue, "folded interpolation: 7-point variants only"); }
+  const int e = launch<MODE_CHEBY>(L, variant, P, true);
+  g_fold_now = InterpFold{};
+  return e;
 }
 // Two Chebyshev sweeps in one pass (cheby_pair.hpp).  Vector references are (scratch?, id) pairs: scratch ids 0/1
 // address the two plugin-private vectors behind scr_base.  Returns hipErrorNotSupported-like status 1 (no launch,

@@ -11,6 +11,7 @@
 #pragma once
 #include "common.hpp"
 #include "stencil_math.hpp"
+#include "stencil_direct.hpp"      // InterpFold
 
 namespace hpgmg {
 
@@ -21,8 +22,9 @@ struct S7TileArgs {
   int tiles_i, tiles_j, chunks_k, kchunk, per_xcd, total_blocks;
 };
 
-template <int V, int MODE, int TJ>
-__global__ __launch_bounds__(64 * TJ) void stencil7_tile_kernel(const hpgmg_hip_level L, const S7TileArgs P) {
+// IP: the piecewise-constant interpolation folded into the first two sweeps of a smooth() (InterpFold, stencil_direct.hpp); every box local.
+template <int V, int MODE, int TJ, bool IP = false>
+__global__ __launch_bounds__(64 * TJ) void stencil7_tile_kernel(const hpgmg_hip_level L, const S7TileArgs P, const InterpFold F = InterpFold{}) {
   constexpr int TI = 64, W = TI + 2, H = TJ + 2, NT = 64 * TJ, PLANE = W * H;
   constexpr int NH = 2 * TI + 2 * TJ;                           // halo cells of a plane tile: a row above and below, a column left and right (no corners: star stencil)
   static_assert(NH <= NT, "one halo cell per lane at most");
@@ -59,7 +61,8 @@ __global__ __launch_bounds__(64 * TJ) void stencil7_tile_kernel(const hpgmg_hip_
   // this lane's halo cell (if any): where it sits in the tile, and how its value is obtained on plane k:
   //   kind 0: plain load (inside the box, or the ghost zone);  1: from the neighbouring local box;  2: Dirichlet, minus the adjacent interior cell
   const bool has_halo = tid < NH;
-  int halo_s = 0, halo_g = 0, halo_kind = 0;
+  int halo_s = 0, halo_g = 0, halo_kind = 0, halo_box = box, halo_i = 0, halo_j = 0;
+  const bool fold_x = IP && F.which == 1, fold_old = IP && F.which == 2;
   gcptr halo_x = x;
   if (has_halo) {
     int hi, hj;
@@ -72,27 +75,32 @@ __global__ __launch_bounds__(64 * TJ) void stencil7_tile_kernel(const hpgmg_hip_
     if (ci < 0) dir = 0; else if (ci > last) dir = 1; else if (cj < 0) dir = 2; else if (cj > last) dir = 3;
     if (dir >= 0 && gf) {
       const int nb = L.box_nbr[6 * box + dir];
-      if (nb >= 0) { halo_kind = 1; halo_x = gvec_origin(L, nb, P.xn_id); if (dir == 0) ci = last; else if (dir == 1) ci = 0; else if (dir == 2) cj = last; else cj = 0; }
+      if (nb >= 0) { halo_kind = 1; halo_box = nb; halo_x = gvec_origin(L, nb, P.xn_id); if (dir == 0) ci = last; else if (dir == 1) ci = 0; else if (dir == 2) cj = last; else cj = 0; }
       else if (nb == -1) { halo_kind = 2; if (dir == 0) ci = 0; else if (dir == 1) ci = last; else if (dir == 2) cj = 0; else cj = last; }
     }
-    halo_g = ci + cj * jS;
+    halo_g = ci + cj * jS; halo_i = ci; halo_j = cj;
   }
-  auto halo_at = [&](int k) -> double { const double v = halo_x[halo_g + k * kS]; return halo_kind == 2 ? -v : v; };
+  auto halo_at = [&](int k) -> double {
+    double v = halo_x[halo_g + k * kS];
+    if (fold_x) v = v + fold_coarse(F, halo_box, halo_i, halo_j, k);
+    return halo_kind == 2 ? -v : v;
+  };
+  auto own_at = [&](int kk) -> double { const double v = x[own_g + kk * kS]; return fold_x ? v + fold_coarse(F, box, i, j, kk) : v; };
   // value of x just below / above the box on this lane's column (k faces).  The two neighbour numbers are read HERE, once: looked up inside
   // the march, the load was hoisted above its (rarely taken) branch and its wait -- vmcnt(0), in front of the prefetches just issued for the
   // next plane -- made every step a full round trip to memory.
   const int nb_k[2] = { L.box_nbr ? L.box_nbr[6 * box + 4] : -3, L.box_nbr ? L.box_nbr[6 * box + 5] : -3 };
   auto outside_k = [&](int dir, double centre, int kk) -> double {
     const int nb = nb_k[dir - 4];
-    if (nb >= 0) return gvec_origin(L, nb, P.xn_id)[own_g + (dir == 4 ? last : 0) * kS];
+    if (nb >= 0) { const double v = gvec_origin(L, nb, P.xn_id)[own_g + (dir == 4 ? last : 0) * kS]; return fold_x ? v + fold_coarse(F, nb, i, j, dir == 4 ? last : 0) : v; }
     if (nb == -1) return -centre;
     return x[own_g + kk * kS];
   };
 
   // registers: x[k-1], x[k], x[k+1] of the own column, the halo value of plane k, beta_k[k]; the streams of plane k in flight
-  double xc = x[own_g + k0 * kS];
-  double xm = (gf && k0 == 0) ? outside_k(4, xc, -1) : x[own_g + (k0 - 1) * kS];
-  double xp = (gf && k0 == last) ? outside_k(5, xc, k0 + 1) : x[own_g + (k0 + 1) * kS];
+  double xc = own_at(k0);
+  double xm = (gf && k0 == 0) ? outside_k(4, xc, -1) : own_at(k0 - 1);
+  double xp = (gf && k0 == last) ? outside_k(5, xc, k0 + 1) : own_at(k0 + 1);
   double h_c = has_halo ? halo_at(k0) : 0.0;
   double bk0 = kVC ? beta_k[own_g + k0 * kS] : 0.0;
   double c_bi = 0, c_bir = 0, c_bj0 = 0, c_bj1 = 0, c_bk1 = 0, c_al = 0, c_dinv = 0, c_rhs = 0, c_old = 0;
@@ -102,7 +110,7 @@ __global__ __launch_bounds__(64 * TJ) void stencil7_tile_kernel(const hpgmg_hip_
     if (kHelm) al = alpha[g];
     if (kSmooth) dv = dinv[g];
     if (MODE != 4) rh = rhs[g];
-    if (MODE == 0) old = out[g];
+    if (MODE == 0) { old = out[g]; if (fold_old) old = old + fold_coarse(F, box, i, j, k); }
   };
   load_streams(k0, c_bi, c_bir, c_bj0, c_bj1, c_bk1, c_al, c_dinv, c_rhs, c_old);
 
@@ -113,7 +121,7 @@ __global__ __launch_bounds__(64 * TJ) void stencil7_tile_kernel(const hpgmg_hip_
     // next step's loads (their latency overlaps this step's barrier and arithmetic)
     double n_xp = 0, n_h = 0, n_bi = 0, n_bir = 0, n_bj0 = 0, n_bj1 = 0, n_bk1 = 0, n_al = 0, n_dinv = 0, n_rhs = 0, n_old = 0;
     if (k + 1 < k1) {
-      n_xp = (gf && k + 1 == last) ? 0.0 : x[own_g + (k + 2) * kS];
+      n_xp = (gf && k + 1 == last) ? 0.0 : own_at(k + 2);
       if (has_halo) n_h = halo_at(k + 1);
       load_streams(k + 1, n_bi, n_bir, n_bj0, n_bj1, n_bk1, n_al, n_dinv, n_rhs, n_old);
     }

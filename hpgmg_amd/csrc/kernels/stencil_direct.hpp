@@ -42,6 +42,21 @@ struct StencilArgs {
                                 //    two-part launch (common.hpp tile_part_order): the tiles at a remote face run after the exchange has landed
 };
 
+// The piecewise-constant interpolation_vcycle that precedes a smooth() on the up leg of a V-cycle (mg.c:1160-1161, interpolation_p0.c:43:
+// f = 1.0 * f + c[i>>1, j>>1, k>>1]) folded into the first two SINGLE Chebyshev sweeps of that smooth() (the sweep-pair kernel has its own fold):
+// which == 1 (sweep 0): every value of x_n the stencil reads is taken as stored + the coarse value above it; which == 2 (sweep 1): x_{n-1}, the old
+// value of the cell being written, is.  After sweep 1 the vector holds x2 and nothing remembers that the interpolated vector never existed.
+struct InterpFold {
+  int which;                       // 0: none
+  hpgmg_hip_level Lc; int coarse_id;
+  const int *map;                  // map[4 b .. 4 b + 3] = coarse box and coarse (i, j, k) under fine box b's first cell (as the fused restriction uses)
+};
+__device__ __forceinline__ double fold_coarse(const InterpFold &F, int box, int i, int j, int k) {
+  const int *m = F.map + 4 * box;
+  return F.Lc.box_base[m[0]][(size_t)F.coarse_id * (size_t)F.Lc.volume + (size_t)F.Lc.ghosts * (size_t)(1 + F.Lc.jStride + F.Lc.kStride)
+                            + (size_t)((m[1] + (i >> 1)) + (m[2] + (j >> 1)) * F.Lc.jStride + (m[3] + (k >> 1)) * F.Lc.kStride)];
+}
+
 // x may alias the output only for in-place GSRB; everywhere else it is restrict-qualified
 // so the loads of plane k+1 can be issued ahead of the store of plane k.
 template <bool kMayAlias> struct src_ptr { typedef const double *__restrict__ type; };

@@ -97,6 +97,11 @@ int  hpgmg_hip_get_ghost_free(void);
  * Jacobi read x_n and write x_np1 (x_np1 doubles as x_{n-1} for Chebyshev);
  * GSRB updates the cells whose global parity (i+j+k+sweep) is even, in place
  * when xn_id == xnp1_id, otherwise copying the other colour. */
+/* interpolation_vcycle (piecewise constant, prescale 1.0; interpolation_p0.c:43) folded into the first two SINGLE Chebyshev sweeps of the smooth() that follows it
+ * (mg.c:1160-1161) on levels the sweep-pair kernel does not take: the NEXT hpgmg_hip_smooth_cheby launch reads x_n (which = 1, sweep 0) resp. x_{n-1} (which = 2, sweep 1)
+ * as stored + the coarse value above the cell; map = per fine box the coarse box and the coarse cell under its first cell (device memory).  Ghost-free path, every box local. */
+int  hpgmg_hip_smooth_cheby_fold_supported(const hpgmg_hip_level *L, int variant);
+void hpgmg_hip_stencil_fold_interpolation(const hpgmg_hip_level *Lc, int coarse_id, const int *map, int which);
 int hpgmg_hip_smooth_cheby(const hpgmg_hip_level *L, int variant, int xn_id, int xnp1_id, int rhs_id,
                            double a, double b, double h2inv, double c1, double c2);
 int hpgmg_hip_smooth_gsrb(const hpgmg_hip_level *L, int variant, int xn_id, int xnp1_id, int rhs_id,

@@ -32,6 +32,7 @@ void MGVCycle(mg_type *all_grids, int e_id, int R_id, double a, double b, int le
 void MGSolve(mg_type *all_grids, int onLevel, int u_id, int F_id, double a, double b, double rtol);
 void FMGSolve(mg_type *all_grids, int onLevel, int u_id, int F_id, double a, double b, double rtol);
 void hpgmg_set_ucycles(int on);        /* before MGBuild: 1 = the reference's -DUSE_UCYCLES ladder (boxes halved, never merged; mg.c:878-893) */
+void hpgmg_fmg_zero_u_first(void);  /* the NEXT FMGSolve starts from u = 0: it zeroes u itself, where it first touches it (the benchmark step's zero_vector(u), hpgmg-fv.c:77-85) */
 void hpgmg_set_fmg_vcycles(int n);     /* V-cycles FMGSolve may add after its F-cycle: 0 (default) or 20 = -DUNLIMIT_FMG_ITERATIONS (mg.c:1239-1247) */
 void MGPCG(mg_type *all_grids, int onLevel, int x_id, int F_id, double a, double b, double rtol);   /* mg.c:1500-1605: CG preconditioned with one V-cycle per iteration; grows every level by three vectors */
 void MGPrintTiming(mg_type *all_grids, int fromLevel);

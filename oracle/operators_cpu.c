@@ -59,6 +59,7 @@ void hpgmg_level_sync_counters(level_type *level) { (void)level; }
 int hpgmg_restrict_zero_fused(level_type *c, int ic, level_type *f, int i_f, int z) { (void)c; (void)ic; (void)f; (void)i_f; (void)z; return 0; }
 int hpgmg_residual_restrict_zero_fused(level_type *c, int ic, level_type *f, int x, int r, double a, double b, int z) { (void)c; (void)ic; (void)f; (void)x; (void)r; (void)a; (void)b; (void)z; return 0; }
 void hpgmg_operators_flush(void) { }
+int  hpgmg_zero_interpolation_fcycle_fused(level_type *fine, int id_f, level_type *coarse, int id_c) { (void)fine; (void)id_f; (void)coarse; (void)id_c; return 0; }
 void hpgmg_set_lazy(int on) { (void)on; }
 int hpgmg_smooth_in_cycle(level_type *l, int p, int r, double a, double b) { (void)l; (void)p; (void)r; (void)a; (void)b; return 0; }
 int hpgmg_norm_scale_restrict_fused(level_type *l, int f, int r, level_type *c, double *o) { (void)l; (void)f; (void)r; (void)c; (void)o; return 0; }

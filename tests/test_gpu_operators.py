@@ -154,6 +154,15 @@ def test_restriction_and_interpolation(hip, oracle, geom):
             be.lib.interpolation_fcycle(f.ptr, H.VECTOR_E, 0.0, c, H.VECTOR_R)     # p1, overwrite
         same(ch, co, [H.VECTOR_R])
         same(fh, fo, [H.VECTOR_U, H.VECTOR_E])
+        # zero_vector + interpolation_fcycle as one launch (the benchmark step's zero_vector(u) and FMGSolve's first write of u): same interior, from any old content
+        bh.lib.hpgmg_zero_interpolation_fcycle_fused.restype = ctypes.c_int
+        bh.lib.hpgmg_zero_interpolation_fcycle_fused.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+        junk = seeded_field(fh, 4242) * 1e3
+        fh.write_all(H.VECTOR_E, junk)
+        assert bh.lib.hpgmg_zero_interpolation_fcycle_fused(fh.ptr, H.VECTOR_E, ch.ptr, H.VECTOR_R) == 1
+        bo.lib.zero_vector(fo.ptr, H.VECTOR_E)
+        bo.lib.interpolation_fcycle(fo.ptr, H.VECTOR_E, 0.0, co.ptr, H.VECTOR_R)
+        same(fh, fo, [H.VECTOR_E], interior_only=True)
     finally:
         for be, f, m in pairs:
             be.lib.hpgmg_mg_destroy(m); f.destroy()
@@ -190,6 +199,47 @@ def test_interpolation_folded_into_the_first_sweep_pair(hip, oracle, variant, ge
         bo.lib.interpolation_vcycle(fo.ptr, H.VECTOR_U, 1.0, co.ptr, H.VECTOR_U)
         bo.lib.smooth(fo.ptr, H.VECTOR_U, H.VECTOR_F, a, b)
         same(fh, fo, [H.VECTOR_U], interior_only=True)      # VECTOR_TEMP is scratch to this cycle-only hook (the second pair does not store x3)
+    finally:
+        for be, f, m, _, _ in pairs:
+            be.lib.hpgmg_mg_destroy(m); f.destroy()
+
+
+@pytest.mark.parametrize("variant,geom", [("7pt-cheby-helm", (2, 64)), ("7pt-cheby-helm", (2, 32)), ("7pt-cheby", (2, 16)), ("7ptcc-cheby", (3, 16)), ("7pt-cheby-helm", (1, 64)),
+                                          ("7pt-cheby", (4, 8)), ("7pt-cheby-helm", (2, 2)), ("7pt-cheby", (1, 32))])
+def test_interpolation_folded_into_single_chebyshev_sweeps(hip, oracle, variant, geom):
+    """The same hook on the levels the sweep-pair kernel does not take (config 2's 128^3 ... 32^3 levels): sweep 0 reads x_n and sweep 1 reads x_{n-1} as stored +
+    the coarse value above the cell (InterpFold: the LDS-tiled kernel for boxes of 64^3, the plain one below), interpolation_vcycle is no launch of its own.
+    The iterate AND VECTOR_TEMP must equal what the oracle's interpolation_vcycle + smooth() leave (mg.c:1160-1161, interpolation_p0.c:43, chebyshev.c:8-100)."""
+    pairs = []
+    for be in (hip, oracle):
+        be.configure(**VARIANTS[variant])
+        fine = be.level(*geom)
+        for vid in range(fine.num_vectors):
+            d = seeded_field(fine, 900 + vid)
+            if vid >= H.VECTOR_DINV:
+                d = np.abs(d) + 0.5
+            fine.write_all(vid, d)
+        for vid in range(H.VECTOR_DINV, fine.num_vectors):
+            be.lib.exchange_boundary(fine.ptr, vid, H.STENCIL_SHAPE_BOX)
+        a, b = (1.0, 1.0) if "helm" in variant else (0.0, 1.0)
+        mg = be.lib.hpgmg_mg_create(fine.ptr, a, b, 1)
+        be.lib.rebuild_operator(fine.ptr, None, a, b)
+        pairs.append((be, fine, mg, a, b))
+    try:
+        from hpgmg_testlib import Level
+        (bh, fh, mh, a, b), (bo, fo, mo, _, _) = pairs
+        hip.lib.hpgmg_interp_smooth_fused.restype = ctypes.c_int
+        hip.lib.hpgmg_interp_smooth_fused.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_double, ctypes.c_double]
+        hip.lib.hpgmg_interp_folded_single.restype = ctypes.c_longlong
+        ch, co = Level(bh, bh.lib.hpgmg_mg_level(mh, 1)), Level(bo, bo.lib.hpgmg_mg_level(mo, 1))
+        coarse_e = seeded_field(ch, 977)
+        ch.write_all(H.VECTOR_U, coarse_e); co.write_all(H.VECTOR_U, coarse_e)
+        before = hip.lib.hpgmg_interp_folded_single()
+        assert hip.lib.hpgmg_interp_smooth_fused(fh.ptr, H.VECTOR_U, H.VECTOR_F, ch.ptr, a, b) == 1
+        assert hip.lib.hpgmg_interp_folded_single() == before + 1
+        bo.lib.interpolation_vcycle(fo.ptr, H.VECTOR_U, 1.0, co.ptr, H.VECTOR_U)
+        bo.lib.smooth(fo.ptr, H.VECTOR_U, H.VECTOR_F, a, b)
+        same(fh, fo, [H.VECTOR_U, H.VECTOR_TEMP], interior_only=True)
     finally:
         for be, f, m, _, _ in pairs:
             be.lib.hpgmg_mg_destroy(m); f.destroy()
