@@ -618,7 +618,9 @@ void FMGSolve(mg_type *G, int onLevel, int u_id, int F_id, double a, double b, d
   t = hpgmg_tick_begin(L, &L->timers.Total, "norm(F), R = F");
   double norm_of_F = 0.0;
   int first_restriction = onLevel;               /* the plugin may do norm, copy and the first restriction in one pass over F */
-  if (onLevel < bottom && hpgmg_norm_scale_restrict_fused(L, F_id, R_id, G->levels[onLevel + 1], &norm_of_F)) first_restriction = onLevel + 1;
+  int norm_deferred = 0;                         /* norm(F) is used only by the check at the end: the plugin may let the host run on and hand it over there */
+  if (onLevel < bottom && hpgmg_norm_scale_restrict_fused_deferred(L, F_id, R_id, G->levels[onLevel + 1])) { first_restriction = onLevel + 1; norm_deferred = 1; }
+  else if (onLevel < bottom && hpgmg_norm_scale_restrict_fused(L, F_id, R_id, G->levels[onLevel + 1], &norm_of_F)) first_restriction = onLevel + 1;
   else {
     norm_of_F = norm(L, F_id);
     scale_vector(L, R_id, 1.0, F_id);
@@ -664,6 +666,7 @@ void FMGSolve(mg_type *G, int onLevel, int u_id, int F_id, double a, double b, d
     seg_close();
   }
 
+  if (norm_deferred) norm_of_F = hpgmg_norm_deferred_fetch(L);
   hpgmg_last_solve.vcycles = 0;
   for (v = -1; v < maxVCycles; v++) {
     if (v >= 0) { L->vcycles_from_this_level++; MGVCycle(G, e_id, R_id, a, b, onLevel); hpgmg_last_solve.vcycles = v + 1; }

@@ -160,6 +160,29 @@ int hp_norm_scale_restrict_fused(level_type *L, int F_id, int R_id, level_type *
   return 1;
 }
 int hpgmg_norm_scale_restrict_fused(level_type *L, int F_id, int R_id, level_type *Lc, double *norm_out) { return hp_norm_scale_restrict_fused(L, F_id, R_id, Lc, norm_out); }
+/* the same, the norm collected later by hpgmg_norm_deferred_fetch(L): FMGSolve needs norm(F) only for the convergence check at its end (mg.c:1262,1323), so the
+ * host does not wait for this pass and keeps the stream full behind it */
+static level_type *deferred_norm_level = NULL;
+int hpgmg_norm_scale_restrict_fused_deferred(level_type *L, int F_id, int R_id, level_type *Lc) {
+  communicator_type *S = &L->restriction[RESTRICT_CELL], *R = &Lc->restriction[RESTRICT_CELL];
+  if (!fused_residual_on() || !hp_switch(SW_DEFER_NORM) || !L->active || !Lc->active || L->num_my_boxes < 1 || Lc->num_my_boxes < 1 || F_id == R_id) return 0;
+  if (S->num_sends || R->num_recvs || S->num_blocks[0] || R->num_blocks[2] || S->num_blocks[1] < 1) return 0;
+  backend_t *Bc = hp_backend_of(Lc), *B = hp_backend_of(L);
+  if ((L->box_dim & 1) || !(B->dev.flags & 1) || (L->box_jStride & 1) || (L->box_kStride & 1) || (L->box_volume & 1) || L->box_dim < 16) return 0;
+  if (!restrict_map_of(L, B)) return 0;
+  { TICK(L, blas1, "norm(F) + R = F + restriction (fused, norm deferred)");
+    HIP_OK(hpgmg_hip_norm_copy_restrict_deferred(&B->dev, F_id, R_id, &Bc->dev, R_id, B->d_restrict_map));
+    TOCK(); }
+  deferred_norm_level = L;
+  return 1;
+}
+double hpgmg_norm_deferred_fetch(level_type *L) {
+  double v = 0.0;
+  if (deferred_norm_level != L) { fprintf(stderr, "hpgmg: no deferred norm is pending on this level\n"); abort(); }
+  deferred_norm_level = NULL;
+  HIP_OK(hpgmg_hip_deferred_fetch(&v));
+  return hp_allreduce_scalar(L, v, HPGMG_REDUCE_MAX);
+}
 /* residual(L, res, x, rhs) ; norm(L, res) -- the convergence check of MGSolve / FMGSolve (mg.c:1321-1323) -- in one pass: the residual is
  * stored as usual (res_id < 0: not stored -- the cycle driver's check, after which VECTOR_TEMP is dead) and its max-abs comes out of the
  * same kernel.  0 = not applicable. */
@@ -223,12 +246,24 @@ static long long zero_interp_fused = 0;
 long long hpgmg_zero_interp_fused(void) { return zero_interp_fused; }
 int hpgmg_zero_interpolation_fcycle_fused(level_type *Lf, int id_f, level_type *Lc, int id_c) {
   hpgmg_config c; hpgmg_get_config(&c);
-  if (c.op != HPGMG_OP_7PT || !hp_switch(SW_FUSED_RESIDUAL) || !hp_ghost_free_mode() || !Lf->active || !Lc->active || Lf->num_my_boxes < 1) return 0;
+  if (!hp_switch(SW_FUSED_RESIDUAL) || !hp_ghost_free_mode() || !Lf->active || !Lc->active || Lf->num_my_boxes < 1) return 0;
   if (!interp_all_local(Lf, Lc) || !hp_backend_of(Lf)->all_faces_local) return 0;
   zero_interp_fused++;
-  exchange_boundary(Lc, id_c, STENCIL_SHAPE_BOX);              /* interpolation_p1.c:71-72 */
-  apply_BCs_p1(Lc, id_c, STENCIL_SHAPE_BOX);
-  interpolation_lists(Lf, id_f, 0.0, Lc, id_c, 6, 0x7);
+  /* the coarse operand's ghost zones as interpolation_fcycle() fills them, then the interpolation in its "onto zeros" form (order + 16) */
+  if (c.op == HPGMG_OP_7PT) {                                   /* interpolation_p1.c:71-72 */
+    exchange_boundary(Lc, id_c, STENCIL_SHAPE_BOX);
+    apply_BCs_p1(Lc, id_c, STENCIL_SHAPE_BOX);
+    interpolation_lists(Lf, id_f, 0.0, Lc, id_c, 17, 0x7);
+  } else if (c.op == HPGMG_OP_27PT) {                           /* operators.27pt.c:150-151 -> interpolation_p2.c:228-230 */
+    if (!hp_exchange_and_bcs_one_launch(Lc, id_c, STENCIL_SHAPE_BOX, 12, 1)) { exchange_boundary(Lc, id_c, STENCIL_SHAPE_BOX); apply_BCs_p2(Lc, id_c, STENCIL_SHAPE_BOX); }
+    interpolation_lists(Lf, id_f, 0.0, Lc, id_c, 18, 0x7);
+  } else if (c.op == HPGMG_OP_FV2) {                            /* operators.fv2.c:151-152 -> interpolation_v2.c:210-212 */
+    if (!hp_exchange_and_bcs_one_launch(Lc, id_c, STENCIL_SHAPE_BOX, 2, 1)) { exchange_boundary(Lc, id_c, STENCIL_SHAPE_BOX); apply_BCs_v2(Lc, id_c, STENCIL_SHAPE_BOX); }
+    interpolation_lists(Lf, id_f, 0.0, Lc, id_c, 19, 0x7);
+  } else {                                                      /* interpolation_v4.c:276-278 */
+    if (!hp_exchange_and_bcs_one_launch(Lc, id_c, STENCIL_SHAPE_BOX, 4, 1)) { exchange_boundary(Lc, id_c, STENCIL_SHAPE_BOX); apply_BCs_v4(Lc, id_c, STENCIL_SHAPE_BOX); }
+    interpolation_lists(Lf, id_f, 0.0, Lc, id_c, 20, 0x7);
+  }
   return 1;
 }
 void interpolation_fcycle(level_type *Lf, int id_f, double prescale, level_type *Lc, int id_c) {

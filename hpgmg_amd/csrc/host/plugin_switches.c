@@ -30,6 +30,7 @@ static struct { const char *env; int kind; long long dflt; const char *what; lon
   [SW_TEMP_SCRATCH]      = { "HPGMG_TEMP_SCRATCH", K_ON, 1, "inside a cycle VECTOR_TEMP is scratch after smooth(): in-cycle smoother forms; 0: the exact state of smooth() everywhere" },
   [SW_FV4_NO_EXACT_RB]   = { "HPGMG_TUNE_FV4_NO_EXACT_RB", K_OFF, 0, "fv4: the exported smooth() as six half sweeps (no red + black passes)" },
   [SW_GRAPH]             = { "HPGMG_GRAPH", K_OFF, 0, "capture / replay the launch-bound segments as hipGraphs (measured slower with a full stream)" },
+  [SW_DEFER_NORM]        = { "HPGMG_DEFER_NORM", K_ON, 1, "FMGSolve: norm(F) of the opening pass is collected at the end, where it is used, instead of waited for at the start" },
   [SW_SMOOTHER_PRECISION]= { "HPGMG_SMOOTHER_PRECISION", K_INT, 64, "32: fp32 coefficient streams in the Chebyshev sweep pairs (BASELINE config 5, tolerance-gated); 64: bit-exact" },
 };
 

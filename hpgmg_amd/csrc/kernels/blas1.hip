@@ -311,7 +311,7 @@ static double *g_scratch = nullptr;  static int g_scratch_len = 0;
 static ResultSlot *g_result_dev = nullptr;   // pinned, device-visible host slot: kernels publish the scalar here directly
 static unsigned long long g_seq = 0;
 static int ensure_scratch(int n) {
-  if (!g_result_dev) { HPGMG_CHECK(hipHostMalloc((void **)&g_result_dev, 64, hipHostMallocDefault)); g_result_dev->seq = 0; g_result_dev->value = 0.0; }
+  if (!g_result_dev) { HPGMG_CHECK(hipHostMalloc((void **)&g_result_dev, 64, hipHostMallocDefault)); for (int q_ = 0; q_ < 4; q_++) { g_result_dev[q_].value = 0.0; g_result_dev[q_].seq = 0; } }      // [0]: the slot (+ a second value behind it); [2]: the slot of a deferred scalar
   if (n > g_scratch_len) {
     if (g_scratch) { hipStreamSynchronize(g_stream); (void)hipFree(g_scratch); }
     int want = n < 65536 ? 65536 : n;
@@ -389,7 +389,29 @@ int hpgmg_hip_random(const hpgmg_hip_level *L, int id) {
   EwArgs A = {}; A.id_c = id; return launch_ew<OP_RANDOM>(L, A);
 }
 
+// A scalar the caller needs only LATER (norm(F) at the start of FMGSolve is used in the convergence check at its end, mg.c:1262,1323) goes to a slot of
+// its own, so the host does not wait for the pass that forms it and keeps the stream full behind it; hpgmg_hip_deferred_fetch() collects it.
+static unsigned long long g_seq_deferred = 0;
+static int norm_copy_restrict(const hpgmg_hip_level *L, int f_id, int r_id, const hpgmg_hip_level *Lc, int rc_id, const int *map, double *norm_out, bool deferred);
+int hpgmg_hip_norm_copy_restrict_deferred(const hpgmg_hip_level *L, int f_id, int r_id, const hpgmg_hip_level *Lc, int rc_id, const int *map) {
+  double unused = 0.0;
+  return norm_copy_restrict(L, f_id, r_id, Lc, rc_id, map, &unused, true);
+}
+int hpgmg_hip_deferred_fetch(double *out) {
+  if (!g_result_dev || g_seq_deferred == 0) return record_error(hipErrorInvalidValue, "deferred_fetch: nothing was deferred");
+  volatile ResultSlot *slot = g_result_dev + 2;
+  for (long spins = 0; slot->seq != g_seq_deferred; spins++) {
+    __builtin_ia32_pause();
+    if (spins > 20000000L) { HPGMG_CHECK(hipStreamSynchronize(g_stream)); if (slot->seq != g_seq_deferred) return record_error(hipErrorUnknown, "deferred reduction result never arrived"); }
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  *out = slot->value;
+  return 0;
+}
 int hpgmg_hip_norm_copy_restrict(const hpgmg_hip_level *L, int f_id, int r_id, const hpgmg_hip_level *Lc, int rc_id, const int *map, double *norm_out) {
+  return norm_copy_restrict(L, f_id, r_id, Lc, rc_id, map, norm_out, false);
+}
+static int norm_copy_restrict(const hpgmg_hip_level *L, int f_id, int r_id, const hpgmg_hip_level *Lc, int rc_id, const int *map, double *norm_out, bool deferred) {
   if (int e = hpgmg_hip_graph_flush()) return e;
   if (norm_out) *norm_out = 0.0;
   if (L->num_boxes <= 0 || Lc->num_boxes <= 0 || (L->dim & 1) || !(L->flags & 1) || (L->jStride & 1) || (L->kStride & 1) || (L->volume & 1) || f_id == r_id)
@@ -398,6 +420,11 @@ int hpgmg_hip_norm_copy_restrict(const hpgmg_hip_level *L, int f_id, int r_id, c
   if (int e = ensure_scratch(nblk)) return e;
   hipLaunchKernelGGL(norm_copy_restrict_kernel, dim3(nblk), dim3(256), 0, g_stream, *L, f_id, r_id, *Lc, rc_id, map, g_scratch);
   if (!norm_out) { HPGMG_LAUNCH_CHECK("norm_copy_restrict (copy + restriction only)"); return 0; }     // the norm is not wanted: nothing to reduce, nothing to wait for
+  if (deferred) {
+    hipLaunchKernelGGL(final_max_kernel, dim3(1), dim3(256), 0, g_stream, (const double *)g_scratch, nblk, 0.0, g_result_dev + 2, ++g_seq_deferred);
+    HPGMG_LAUNCH_CHECK("norm_copy_restrict (norm deferred)");
+    return 0;
+  }
   hipLaunchKernelGGL(final_max_kernel, dim3(1), dim3(256), 0, g_stream, (const double *)g_scratch, nblk, 0.0, g_result_dev, ++g_seq);
   HPGMG_LAUNCH_CHECK("norm_copy_restrict");
   return fetch_result(norm_out);

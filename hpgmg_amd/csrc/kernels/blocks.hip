@@ -96,7 +96,7 @@ __global__ __launch_bounds__(64) void extrapolate_betas_kernel(const hpgmg_hip_l
 // cell's 8 children.  (2R+1)^2 loads per coarse cell instead of (2R+1)^3 (the first version was bound by the L1 at 125 loads per
 // cell); each child is the same expression tree rule_k(rule_j(rule_i(coarse))) as in the reference.  Children are written as
 // 16-byte pairs when the layout allows.
-template <int ORDER>
+template <int ORDER, bool ZEROED = false>      // ZEROED: as in interp_blocks_kernel -- the fine vector counts as +0.0 (prescale == 0), never read
 __global__ __launch_bounds__(256) void interp_tensor_kernel(const hpgmg_hip_level Lf, int id_f, double prescale, const hpgmg_hip_level Lc, int id_c,
                                                             const blockCopy_type *__restrict__ list) {
   constexpr int R = (ORDER == 4) ? 2 : 1, W = 2 * R + 1, KC = 8;
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void interp_tensor_kernel(const hpgmg_hip_leve
             // follows old's -- the old value is fetched only for results that are zeros
             if (prescale != 0.0) load_fine();
             double v0 = prescale * f0 + a0, v1 = prescale * f1 + a1;
-            if (prescale == 0.0 && (v0 == 0.0 || v1 == 0.0)) { load_fine(); v0 = prescale * f0 + a0; v1 = prescale * f1 + a1; }
+            if (!ZEROED && prescale == 0.0 && (v0 == 0.0 || v1 == 0.0)) { load_fine(); v0 = prescale * f0 + a0; v1 = prescale * f1 + a1; }
             if (pairs) *reinterpret_cast<double2 *>(fw) = make_double2(v0, v1);
             else { fw[0] = v0; fw[1] = v1; }
           }
@@ -393,9 +393,12 @@ int hpgmg_hip_interpolate_blocks(const hpgmg_hip_level *Lf, int id_f, double pre
   const int slabs = n >= 4096 ? 1 : (4096 / n > 64 ? 64 : 4096 / n);
   if (order == 0) hipLaunchKernelGGL((interp_blocks_kernel<0>), dim3(n, slabs), dim3(256), 0, g_stream, *Lf, id_f, prescale, *Lc, id_c, blocks);
   else if (order == 1) hipLaunchKernelGGL((interp_blocks_kernel<1>), dim3(n, slabs), dim3(256), 0, g_stream, *Lf, id_f, prescale, *Lc, id_c, blocks);
-  else if (order == 6) {      // trilinear onto a fine vector that counts as zeroed (zero_vector + interpolation_fcycle, the fine level touched once)
+  else if (order >= 17 && order <= 20) {      // order - 16 onto a fine vector that counts as zeroed (zero_vector + interpolation_fcycle, the fine level touched once)
     if (prescale != 0.0) return record_error(hipErrorInvalidValue, "interpolation onto a zeroed vector: prescale 0");
-    hipLaunchKernelGGL((interp_blocks_kernel<1, true>), dim3(n, slabs), dim3(256), 0, g_stream, *Lf, id_f, prescale, *Lc, id_c, blocks);
+    if (order == 17)      hipLaunchKernelGGL((interp_blocks_kernel<1, true>), dim3(n, slabs), dim3(256), 0, g_stream, *Lf, id_f, prescale, *Lc, id_c, blocks);
+    else if (order == 18) hipLaunchKernelGGL((interp_tensor_kernel<2, true>), dim3(n, slabs), dim3(256), 0, g_stream, *Lf, id_f, prescale, *Lc, id_c, blocks);
+    else if (order == 19) hipLaunchKernelGGL((interp_tensor_kernel<3, true>), dim3(n, slabs), dim3(256), 0, g_stream, *Lf, id_f, prescale, *Lc, id_c, blocks);
+    else                  hipLaunchKernelGGL((interp_tensor_kernel<4, true>), dim3(n, slabs), dim3(256), 0, g_stream, *Lf, id_f, prescale, *Lc, id_c, blocks);
   }
   else if (order == 2) hipLaunchKernelGGL((interp_tensor_kernel<2>), dim3(n, slabs), dim3(256), 0, g_stream, *Lf, id_f, prescale, *Lc, id_c, blocks);
   else if (order == 3) hipLaunchKernelGGL((interp_tensor_kernel<3>), dim3(n, slabs), dim3(256), 0, g_stream, *Lf, id_f, prescale, *Lc, id_c, blocks);

@@ -331,6 +331,10 @@ int hpgmg_hip_dot(const hpgmg_hip_level *L, int id_a, int id_b, double *out);   
 /* norm(F), scale_vector(R, 1.0, F) and restriction(coarse rc_id <- R, RESTRICT_CELL) -- the opening of FMGSolve, mg.c:1262-1270 -- in one pass
  * over F (even box side, 16-byte aligned rows; map as for hpgmg_hip_residual_restrict): 25 instead of 41 B per fine cell */
 int hpgmg_hip_norm_copy_restrict(const hpgmg_hip_level *L, int f_id, int r_id, const hpgmg_hip_level *Lc, int rc_id, const int *map, double *norm_out);
+/* the same pass, but the maximum is NOT waited for: it lands in a slot of its own and hpgmg_hip_deferred_fetch() collects it when the caller needs it
+ * (FMGSolve uses norm(F) only in the convergence check at its end, mg.c:1262,1323: the host keeps launching behind the pass) */
+int  hpgmg_hip_norm_copy_restrict_deferred(const hpgmg_hip_level *L, int f_id, int r_id, const hpgmg_hip_level *Lc, int rc_id, const int *restrict_map);
+int  hpgmg_hip_deferred_fetch(double *out);
 int hpgmg_hip_sum(const hpgmg_hip_level *L, int id, double *out);                     /* mean :336 (before the divide) */
 
 /* ---- operators/rebuild.c:47-208 black-box rebuild: accumulate one colouring (x = 0/1 pattern, ghosts

@@ -153,6 +153,9 @@ int     hpgmg_residual_restrict_zero_fused(level_type *coarse, int id_c, level_t
 int     hpgmg_residual_norm_fused(level_type *level, int res_id, int x_id, int rhs_id, double a, double b, double *norm_out);
 /*   *norm_out = norm(level, F); scale_vector(level, R, 1.0, F); restriction(coarse, R, level, R, RESTRICT_CELL)                        (mg.c:1262-1270) */
 int     hpgmg_norm_scale_restrict_fused(level_type *level, int F_id, int R_id, level_type *coarse, double *norm_out);
+/*   the same with the norm collected LATER by hpgmg_norm_deferred_fetch(level) (once, before anything else defers): FMGSolve uses norm(F) only in the check at its end */
+int     hpgmg_norm_scale_restrict_fused_deferred(level_type *level, int F_id, int R_id, level_type *coarse);
+double  hpgmg_norm_deferred_fetch(level_type *level);
 /*   zero_vector(fine, id_f); interpolation_fcycle(fine, id_f, 0.0, coarse, id_c) -- the benchmark step's zero_vector(u) (hpgmg-fv.c:77-85) and the F-cycle's
  *   first write of u on that level (mg.c:1295) -- as one launch: same interior; the ghost zones zero_vector would clear may keep their content */
 int     hpgmg_zero_interpolation_fcycle_fused(level_type *fine, int id_f, level_type *coarse, int id_c);

@@ -59,6 +59,8 @@ void hpgmg_level_sync_counters(level_type *level) { (void)level; }
 int hpgmg_restrict_zero_fused(level_type *c, int ic, level_type *f, int i_f, int z) { (void)c; (void)ic; (void)f; (void)i_f; (void)z; return 0; }
 int hpgmg_residual_restrict_zero_fused(level_type *c, int ic, level_type *f, int x, int r, double a, double b, int z) { (void)c; (void)ic; (void)f; (void)x; (void)r; (void)a; (void)b; (void)z; return 0; }
 void hpgmg_operators_flush(void) { }
+int  hpgmg_norm_scale_restrict_fused_deferred(level_type *level, int F_id, int R_id, level_type *coarse) { (void)level; (void)F_id; (void)R_id; (void)coarse; return 0; }
+double hpgmg_norm_deferred_fetch(level_type *level) { (void)level; return 0.0; }
 int  hpgmg_zero_interpolation_fcycle_fused(level_type *fine, int id_f, level_type *coarse, int id_c) { (void)fine; (void)id_f; (void)coarse; (void)id_c; return 0; }
 void hpgmg_set_lazy(int on) { (void)on; }
 int hpgmg_smooth_in_cycle(level_type *l, int p, int r, double a, double b) { (void)l; (void)p; (void)r; (void)a; (void)b; return 0; }
