@@ -49,7 +49,7 @@ def test_hip_multirank_matches_single_rank_reference(world, variant, log2, per_r
 @pytest.mark.parametrize("world,variant,log2,per_rank,gold_key", [
     (2, "7pt-cheby-helm", 7, 4, "7pt-cheby-helm 7 8"),     # bench.py --gpus 2: bricks of 2 x 2 x 1 boxes, one remote k face
     (4, "7pt-cheby-helm", 7, 2, "7pt-cheby-helm 7 8"),     # bench.py --gpus 4: bricks of 2 x 1 x 1 boxes, remote j and k faces + the edge between them
-    (8, "7pt-cheby-helm", 7, 1, "7pt-cheby-helm 7 8"),     # bench.py --gpus 8: one box per rank, three remote faces and three edges each
+    # (bench.py --gpus 8 -- one box per rank, three remote faces and three edges each -- runs in test_ipc_peer_copy_transport, on device-ordered messages, with the same assertions)
     (2, "7pt-gsrb", 7, 4, "7pt-gsrb 7 8"),
     (4, "7pt-cheby", 7, 2, "7pt-cheby 7 8"),
 ])
@@ -77,8 +77,8 @@ def test_sweep_pairs_across_rank_boundaries(world, variant, log2, per_rank, gold
     (2, "fv4-gsrb", 7, 4, "fv4-gsrb 7 8"),        # bricks of 2 x 2 x 1 boxes of 128^3: one remote k face
     (2, "27pt-gsrb", 7, 4, "27pt-gsrb 7 8"),
     (4, "fv4-gsrb", 7, 2, "fv4-gsrb 7 8"),        # bricks of 2 x 1 x 1: remote j and k faces and the edge between them
-    (8, "27pt-gsrb", 7, 1, "27pt-gsrb 7 8"),      # one box per rank: three remote faces, three edges, a corner
-    # (BASELINE config 3 as stated -- 512^3, eight ranks of 2 x 2 x 2 boxes, `(8, fv4-gsrb, 7, 8)` -- runs in test_ipc_peer_copy_transport below, on device-ordered messages)
+    # (one box per rank -- three remote faces, three edges, a corner: `(8, 27pt-gsrb, 7, 1)` -- and
+    # (BASELINE config 3 as stated -- 512^3, eight ranks of 2 x 2 x 2 boxes, `(8, fv4-gsrb, 7, 8)` -- run in test_ipc_peer_copy_transport below, on device-ordered messages)
     (2, "fv4-cheby", 5, 4, "fv4-cheby 5 8"),      # the tiled kernels (Chebyshev sweeps, residual) on the images, reference rank map down to boxes of 8^3
     (2, "27pt-cheby", 7, 4, "27pt-cheby 7 8"),
 ])
@@ -174,6 +174,8 @@ def test_ipc_peer_copy_transport(world, variant, log2, per_rank, gold_key, gathe
             assert r["stats"]["fv4_rb_smooths"] >= 8 and r["stats"]["image_exchanges"] > 20, r["stats"]
         if variant == "27pt-gsrb":
             assert r["stats"]["rb27_passes"] >= 16 and r["stats"]["image_exchanges"] > 20, r["stats"]
+        if variant.startswith("7pt-cheby") and log2 == 7:       # the fine-level smoother stays the sweep-pair kernel across rank boundaries, one exchange per pair
+            assert r["stats"]["pair_remote_smooths"] >= 8 and r["stats"]["pair_remote_launches"] == 2 * r["stats"]["pair_remote_smooths"], r["stats"]
 
 
 def bench_line(argv, extra_env=None, expect_code=0):
@@ -200,7 +202,7 @@ def test_bench_two_ranks_end_to_end_on_the_ipc_transport():
 def test_bench_falls_back_to_fresh_ipc_ranks_when_the_first_transport_fails(how):
     """The first transport is made to fail (every rank of the rccl attempt exits 97) or to hang (every rank sleeps until its watchdog): the supervisors end the
     attempt and start FRESH rank processes with the ipc transport; the line of that attempt says what happened."""
-    d, err = bench_line(["--gpus", "2", "--share-gpu", "--steps", "2", "--warmup", "1", "--watchdog", "40" if how.endswith("hang") else "300"],
+    d, err = bench_line(["--gpus", "2", "--share-gpu", "--steps", "2", "--warmup", "1", "--watchdog", "25" if how.endswith("hang") else "300"],
                         extra_env={"HPGMG_TEST_FAIL_TRANSPORT": how})
     assert d["config"]["transport"].startswith("ipc (fallback: rccl attempt: "), d["config"]["transport"]
     assert ("exited with code 124" if how.endswith("hang") else "exited with code 97") in d["config"]["transport"], d["config"]["transport"]
