@@ -260,7 +260,17 @@ static int pair_kernel_ready(level_type *L, int x_id, int rhs_id, int sweeps) {
  * x4 -> x_id, i.e. exactly the state chebyshev.c:43-99 leaves.  Returns 0 when the level does not qualify. */
 /* smooth() called by the cycle driver through hpgmg_smooth_in_cycle(): VECTOR_TEMP (x3 of the four sweeps) is dead after it, so the second
  * pair does not store it */
-static int smooth_cheby_pairs(level_type *L, int x_id, int rhs_id, double a, double b, const double *c1, const double *c2, int sweeps, int temp_dead) {
+/* fold_Lc: interpolation_vcycle(L, x_id, 1.0, fold_Lc, x_id) is folded into the first pair (hp_interp_smooth_fused).  One rank: the caller has already told the
+ * kernel library (hpgmg_hip_pair_fold_interpolation, consumed by the first pair launch).  Faces on other ranks: every owner adds the parents of the cells it
+ * SENDS while packing the pair's halo, and the kernel adds them inside the brick only -- set here, once per part of the two-part launch. */
+static long long interp_folded_remote = 0;
+long long hpgmg_interp_folded_remote(void) { return interp_folded_remote; }      /* smooth() calls across rank boundaries whose interpolation was folded in (tests) */
+/* the first pair of a smooth() with the fold requested first: the request is consumed per launch, and a two-part launch is two launches */
+static int first_pair_folded(const hpgmg_hip_level *fold_Lc, backend_t *B, int v, int x_id, int rhs_id, double a, double b, double h2inv, const double *c1, const double *c2) {
+  hpgmg_hip_pair_fold_interpolation(fold_Lc, x_id, 1.0);
+  return hpgmg_hip_smooth_cheby_pair(&B->dev, v, (double *const *)B->d_pair_base, NULL, 0, x_id, 0, VECTOR_TEMP, 1, 0, 1, 1, rhs_id, a, b, h2inv, c1[0], c2[0], c1[1], c2[1]);
+}
+static int smooth_cheby_pairs_fold(level_type *L, int x_id, int rhs_id, double a, double b, const double *c1, const double *c2, int sweeps, int temp_dead, const hpgmg_hip_level *fold_Lc) {
   if (!pair_kernel_ready(L, x_id, rhs_id, sweeps)) return 0;
   backend_t *B = hp_backend_of(L);
   const double h2inv = 1.0 / (L->h * L->h);
@@ -268,9 +278,14 @@ static int smooth_cheby_pairs(level_type *L, int x_id, int rhs_id, double a, dou
   const int remote = !B->all_faces_local;
   const float *const *c32 = remote ? NULL : coef32_of(L);      /* across ranks the coefficient streams stay fp64 */
   int over = 0;
-  if (remote) { pair_remote_smooths++; over = hp_pair_halo_begin(L, B, 1, 0, x_id, 0, VECTOR_TEMP, rhs_id); }
+  if (remote) {
+    pair_remote_smooths++;
+    if (fold_Lc) { hpgmg_hip_pair_halo_fold_interpolation(fold_Lc, x_id, 1.0); interp_folded_remote++; }
+    over = hp_pair_halo_begin(L, B, 1, 0, x_id, 0, VECTOR_TEMP, rhs_id);
+  }
   { TICK(L, smooth, "smooth (Chebyshev sweeps 1+2)");
-    if (remote) PAIR_REMOTE_LAUNCH(over, 0, hpgmg_hip_smooth_cheby_pair(&B->dev, v, (double *const *)B->d_pair_base, c32, 0, x_id, 0, VECTOR_TEMP, 1, 0, 1, 1, rhs_id, a, b, h2inv, c1[0], c2[0], c1[1], c2[1]));
+    if (remote && fold_Lc) PAIR_REMOTE_LAUNCH(over, 0, first_pair_folded(fold_Lc, B, v, x_id, rhs_id, a, b, h2inv, c1, c2));
+    else if (remote) PAIR_REMOTE_LAUNCH(over, 0, hpgmg_hip_smooth_cheby_pair(&B->dev, v, (double *const *)B->d_pair_base, c32, 0, x_id, 0, VECTOR_TEMP, 1, 0, 1, 1, rhs_id, a, b, h2inv, c1[0], c2[0], c1[1], c2[1]));
     else HIP_OK(hpgmg_hip_smooth_cheby_pair(&B->dev, v, (double *const *)B->d_pair_base, c32, 0, x_id, 0, VECTOR_TEMP, 1, 0, 1, 1, rhs_id, a, b, h2inv, c1[0], c2[0], c1[1], c2[1]));
     TOCK(); }
   if (remote) over = hp_pair_halo_begin(L, B, 0, 1, 1, 1, 0, rhs_id);
@@ -282,6 +297,9 @@ static int smooth_cheby_pairs(level_type *L, int x_id, int rhs_id, double a, dou
     }
     TOCK(); }
   return 1;
+}
+static int smooth_cheby_pairs(level_type *L, int x_id, int rhs_id, double a, double b, const double *c1, const double *c2, int sweeps, int temp_dead) {
+  return smooth_cheby_pairs_fold(L, x_id, rhs_id, a, b, c1, c2, sweeps, temp_dead, NULL);
 }
 /* in-place GSRB smooth() (gsrb.c:24-132, 4 coloured half sweeps) as two passes of two half sweeps each:
  * x_id -> private vector -> x_id; VECTOR_TEMP is not touched, as in the reference's in-place form */
@@ -323,7 +341,7 @@ static int interp_smooth_fused_single(level_type *Lf, int e_id, int R_id, level_
   communicator_type *S = &Lc->interpolation, *Rv = &Lf->interpolation;
   if (!hp_switch(SW_FUSED_RESIDUAL) || cfg.op != HPGMG_OP_7PT || cfg.smoother != HPGMG_SMOOTH_CHEBY || !Lf->active || !Lc->active || sweeps < 2) return 0;
   if (Lf->num_my_boxes < 1 || Lc->num_my_boxes < 1 || !hp_ghost_free_mode() || Lf->boundary_condition.type != BC_DIRICHLET) return 0;
-  if (S->num_sends || S->num_recvs || Rv->num_sends || Rv->num_recvs || S->num_blocks[0] || Rv->num_blocks[2]) return 0;   /* all parents local */
+  if (S->num_sends || Rv->num_recvs || S->num_blocks[0] || Rv->num_blocks[2]) return 0;   /* all parents local (the coarse level's send side, the fine level's receive side; their other sides belong to other level pairs) */
   if (e_id == VECTOR_TEMP || R_id == VECTOR_TEMP || Lf->dominant_eigenvalue_of_DinvA <= 0.0) return 0;
   backend_t *B = hp_backend_of(Lf), *Bc = hp_backend_of(Lc);
   if (!B->all_faces_local || stencil_get_shape() != STENCIL_SHAPE_STAR) return 0;
@@ -353,17 +371,21 @@ int hp_interp_smooth_fused(level_type *Lf, int e_id, int R_id, level_type *Lc, d
   communicator_type *S = &Lc->interpolation, *Rv = &Lf->interpolation;
   if (cfg.op != HPGMG_OP_7PT || !Lf->active || !Lc->active) return 0;
   if (cfg.smoother != HPGMG_SMOOTH_CHEBY && !(cfg.smoother == HPGMG_SMOOTH_GSRB && !hpgmg_gsrb_out_of_place())) return 0;
-  if (S->num_sends || S->num_recvs || Rv->num_sends || Rv->num_recvs || S->num_blocks[0] || Rv->num_blocks[2]) return 0;   /* all parents local */
-  if (Lf->box_dim % 128 != 0 || Lc->box_dim * 2 != Lf->box_dim || Lc->num_my_boxes != Lf->num_my_boxes || !boxes_lexicographic(Lc) ||
-      !hp_backend_of(Lf)->all_faces_local ||        /* across ranks the pair kernel takes x0 as stored (interpolation stays its own launch) */
+  if (S->num_sends || Rv->num_recvs || S->num_blocks[0] || Rv->num_blocks[2]) return 0;   /* all parents local (the coarse level's send side, the fine level's receive side; their other sides belong to other level pairs) */
+  const int remote = !hp_backend_of(Lf)->all_faces_local;      /* across ranks: Chebyshev pairs only (every owner adds the parents to the halo cells it sends) */
+  int parents_in_place = (Lc->num_my_boxes == Lf->num_my_boxes), bx;      /* the kernel finds the parent of a cell of fine box b in coarse box b */
+  for (bx = 0; parents_in_place && bx < Lf->num_my_boxes; bx++)
+    parents_in_place = (2 * Lc->my_boxes[bx].low.i == Lf->my_boxes[bx].low.i && 2 * Lc->my_boxes[bx].low.j == Lf->my_boxes[bx].low.j && 2 * Lc->my_boxes[bx].low.k == Lf->my_boxes[bx].low.k);
+  if (Lf->box_dim % 128 != 0 || Lc->box_dim * 2 != Lf->box_dim || !parents_in_place || (!remote && !boxes_lexicographic(Lc)) ||
+      (remote && (cfg.smoother != HPGMG_SMOOTH_CHEBY || !hp_switch(SW_PAIR_REMOTE))) ||
       !pair_kernel_ready(Lf, e_id, R_id, sweeps))
     return interp_smooth_fused_single(Lf, e_id, R_id, Lc, a, b);      /* (VECTOR_TEMP ends as smooth() leaves it: also for the queue) not a sweep-pair level: the fold of the single sweeps, if it is one of those */
   if (cfg.smoother == HPGMG_SMOOTH_CHEBY && Lf->dominant_eigenvalue_of_DinvA <= 0.0) return 0;
-  hpgmg_hip_pair_fold_interpolation(&hp_backend_of(Lc)->dev, e_id, 1.0);
+  if (!remote) hpgmg_hip_pair_fold_interpolation(&hp_backend_of(Lc)->dev, e_id, 1.0);
   if (cfg.smoother == HPGMG_SMOOTH_CHEBY) {
     double c1[16], c2[16];
     cheby_coefficients(Lf, sweeps, c1, c2);
-    const int done = smooth_cheby_pairs(Lf, e_id, R_id, a, b, c1, c2, sweeps, !exact_state && hp_switch(SW_TEMP_SCRATCH));      /* the cycle hook: VECTOR_TEMP is dead afterwards */
+    const int done = smooth_cheby_pairs_fold(Lf, e_id, R_id, a, b, c1, c2, sweeps, !exact_state && hp_switch(SW_TEMP_SCRATCH), remote ? &hp_backend_of(Lc)->dev : NULL);      /* the cycle hook: VECTOR_TEMP is dead afterwards */
     if (!done) { fprintf(stderr, "hpgmg: fused interpolation+smooth refused after being accepted\n"); abort(); }
   } else if (!smooth_gsrb_pairs(Lf, e_id, R_id, a, b, sweeps)) { fprintf(stderr, "hpgmg: fused interpolation+smooth refused after being accepted\n"); abort(); }
   return 1;

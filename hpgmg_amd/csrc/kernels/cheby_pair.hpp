@@ -127,7 +127,8 @@ __device__ __forceinline__ p2 pair_update(p2 c, double left, double right, p2 jm
 constexpr int kPairMaxBoxes = 1024;       // boxes per rank the pair kernel takes (their base-pointer tables are copied into LDS, see below)
 template <int V, int NW, bool C32, int SM, bool NARROW, bool INTERP, bool REMOTE = false>
 __global__ __launch_bounds__(64 * NW) void cheby_pair_kernel(const hpgmg_hip_level L_in, const PairArgs A_in) {
-  static_assert(!(REMOTE && (NARROW || INTERP || C32)), "the multi-rank variant is built for whole-row boxes, fp64 coefficients, no folded interpolation");
+  static_assert(!(REMOTE && (NARROW || C32)), "the multi-rank variant is built for whole-row boxes and fp64 coefficients");
+  // REMOTE + INTERP: the parent is added to the cells of the brick only -- what arrives in ghost zones and deep planes was packed by its owner with ITS parents already added (pair_halo_kernel)
   constexpr bool kVC = (V != HPGMG_HIP_7PT_CC);
   constexpr bool kHelm = (V == HPGMG_HIP_7PT_VC_HELMHOLTZ);
   constexpr int NR = NW - 2;
@@ -213,15 +214,19 @@ __global__ __launch_bounds__(64 * NW) void cheby_pair_kernel(const hpgmg_hip_lev
   // cells of a pair share), and for a single cell
   auto x0_pair = [&](int box, int l_i, int l_j, int gk) -> p2 {
     p2 v = pld(pair_vec(L, A, A.x0, box) + shift_of(sh, A.x0) + l_i + l_j * jS + plane_off(gk));
-    if (INTERP) {
-      const double c = gld1(vec_origin(A.Lc, box, A.coarse_id) + ((l_i >> 1) + (l_j >> 1) * A.Lc.jStride + ((gk % bd) >> 1) * A.Lc.kStride));
+    if (INTERP && (!REMOTE || (l_j >= 0 && l_j < bd && gk >= 0 && gk < A.Dk))) {
+      const int lk = REMOTE ? gk - kbox(gk) * bd : gk % bd;
+      const double c = gld1(vec_origin(A.Lc, box, A.coarse_id) + ((l_i >> 1) + (l_j >> 1) * A.Lc.jStride + (lk >> 1) * A.Lc.kStride));
       v.x = A.prescale * v.x + c; v.y = A.prescale * v.y + c;
     }
     return v;
   };
   auto x0_one = [&](int box, int l_i, int l_j, int gk) -> double {
     double v = gld1(pair_vec(L, A, A.x0, box) + (l_i + l_j * jS + plane_off(gk)));
-    if (INTERP) v = A.prescale * v + gld1(vec_origin(A.Lc, box, A.coarse_id) + ((l_i >> 1) + (l_j >> 1) * A.Lc.jStride + ((gk % bd) >> 1) * A.Lc.kStride));
+    if (INTERP && (!REMOTE || (l_i >= 0 && l_i < bd && l_j >= 0 && l_j < bd && gk >= 0 && gk < A.Dk))) {
+      const int lk = REMOTE ? gk - kbox(gk) * bd : gk % bd;
+      v = A.prescale * v + gld1(vec_origin(A.Lc, box, A.coarse_id) + ((l_i >> 1) + (l_j >> 1) * A.Lc.jStride + (lk >> 1) * A.Lc.kStride));
+    }
     return v;
   };
   // REMOTE: the same pair on ANY plane x0 is known on -- inside, ghost (-1, Dk) or deep (-2, Dk+1).  A deep plane of a ghost row
@@ -438,7 +443,9 @@ __global__ __launch_bounds__(256) void cheby_pair_edge_kernel(const hpgmg_hip_le
     }
     int box; const int idx = cell(ci, cj, ck, box);
     double v = gld1(pair_vec(L, A, A.x0, box) + idx);
-    if (INTERP) v = A.prescale * v + gld1(vec_origin(A.Lc, box, A.coarse_id) + (((ci % bd) >> 1) + ((cj % bd) >> 1) * A.Lc.jStride + ((ck % bd) >> 1) * A.Lc.kStride));
+    // (REMOTE: a cell outside the brick was packed by its owner with its parent already added)
+    if (INTERP && (!REMOTE || (ci >= 0 && ci < A.Di && cj >= 0 && cj < A.Dj && ck >= 0 && ck < A.Dk)))
+      v = A.prescale * v + gld1(vec_origin(A.Lc, box, A.coarse_id) + (((ci % bd) >> 1) + ((cj % bd) >> 1) * A.Lc.jStride + ((ck % bd) >> 1) * A.Lc.kStride));
     return v;
   };
   int box; const int idx = cell(gi, gj, gk, box);

@@ -6,7 +6,9 @@
 
 namespace hpgmg {
 // ---- halo of a sweep pair across rank boundaries: regions of x0 / xm1 / rhs (or a level vector) <-> one message buffer ----
-struct HaloRefs { VecRef x0, xm1; int rhs_id; double *const *scr_base; };
+// fold: packing x0 (vec 0) of a smooth() whose interpolation_vcycle is folded into its first sweep pair -- the owner adds the coarse parent
+// (interpolation_p0.c:43: prescale * f + c[i>>1, j>>1, k>>1]) while packing, so the receiver's ghost zones and deep planes hold the interpolated x0
+struct HaloRefs { VecRef x0, xm1; int rhs_id; double *const *scr_base; int fold; hpgmg_hip_level Lc; int coarse_id; double prescale; };
 __device__ __forceinline__ double *halo_vec(const hpgmg_hip_level &L, const HaloRefs &R, int vec, int box) {
   const size_t first = (size_t)L.ghosts * (size_t)(1 + L.jStride + L.kStride);
   if (vec >= 16) return L.box_base[box] + (size_t)(vec - 16) * (size_t)L.volume + first;
@@ -26,7 +28,14 @@ __global__ __launch_bounds__(256) void pair_halo_kernel(const hpgmg_hip_level L,
   else if (kUnpack && e.deep >= 0) plane = deep + ((size_t)e.box * 6 + e.deep) * (size_t)L.dim * L.dim;
   for (int t = blockIdx.y * 256 + threadIdx.x; t < n; t += gridDim.y * 256) {
     const int ti = t % e.ni, tj = (t / e.ni) % e.nj, tk = t / (e.ni * e.nj);
-    if (!kUnpack) b[t] = v[ti + tj * jS + tk * kS];
+    if (!kUnpack) {
+      double val = v[ti + tj * jS + tk * kS];
+      if (R.fold && e.vec == 0) {
+        const int ci = e.i + ti, cj = e.j + tj, ck = e.k + tk;              // a cell of the sender's interior
+        val = R.prescale * val + vec_origin(R.Lc, e.box, R.coarse_id)[(ci >> 1) + (cj >> 1) * R.Lc.jStride + (ck >> 1) * R.Lc.kStride];
+      }
+      b[t] = val;
+    }
     else if (plane) plane[t] = b[t];
     else v[ti + tj * jS + tk * kS] = b[t];
   }
@@ -138,7 +147,7 @@ static int smooth_pair(const hpgmg_hip_level *L, int variant, int gsrb, int swee
   HPGMG_SKIP_IF_REPLAY();
   const int Di = remote ? g_pair_brick[0] * L->dim : L->dim_i, Dj = remote ? g_pair_brick[1] * L->dim : L->dim_j, Dk = remote ? g_pair_brick[2] * L->dim : L->dim_k;
   if (!pair_supported_dims(L, variant, Di, Dj, Dk)) return record_error(hipErrorInvalidValue, "smooth_cheby_pair: level not supported");
-  if (remote && (L->dim % 128 != 0 || c32_base || interp_level)) return record_error(hipErrorInvalidValue, "smooth_cheby_pair: remote faces need whole-row boxes, fp64 coefficients, no folded interpolation");
+  if (remote && (L->dim % 128 != 0 || c32_base)) return record_error(hipErrorInvalidValue, "smooth_cheby_pair: remote faces need whole-row boxes and fp64 coefficients");
   static const int tune_kc = env_int("HPGMG_TUNE_PAIR_KC", 0);
   constexpr int nw = 16;
   // k chunk: every workgroup costs KC+2 plane steps and (at 128 VGPRs, 16 waves) one workgroup occupies a CU, so the
@@ -201,12 +210,13 @@ static int smooth_pair(const hpgmg_hip_level *L, int variant, int gsrb, int swee
 #define PAIR_LAUNCH2(VAR, C32, SM, NARROW, INTERP) { \
       static bool once = false; if (!once) { HPGMG_CHECK(hipFuncSetAttribute((const void *)cheby_pair_kernel<VAR, nw, C32, SM, NARROW, INTERP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once = true; } \
       hipLaunchKernelGGL((cheby_pair_kernel<VAR, nw, C32, SM, NARROW, INTERP>), dim3(grid), dim3(64, nw), lds, g_stream, *L, A); }
-#define PAIR_LAUNCH_REMOTE(VAR, SM) { \
-      static bool once = false; if (!once) { HPGMG_CHECK(hipFuncSetAttribute((const void *)cheby_pair_kernel<VAR, nw, false, SM, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once = true; } \
+#define PAIR_LAUNCH_REMOTE_IP(VAR, SM, IP) { \
+      static bool once = false; if (!once) { HPGMG_CHECK(hipFuncSetAttribute((const void *)cheby_pair_kernel<VAR, nw, false, SM, false, IP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once = true; } \
       const int ecols = 2 * (A.tiles_i - 1) + (A.rem[0] ? 1 : 0) + (A.rem[1] ? 1 : 0); \
       A.edge_blocks = ((A.Dj + 63) / 64) * A.Dk * ecols; const int egrid_r = grid_for(A.edge_blocks, &A.edge_per_xcd); \
-      if (ecols > 0) hipLaunchKernelGGL((cheby_pair_edge_kernel<VAR, false, SM, false, true>), dim3(egrid_r), dim3(64), 0, g_stream, *L, A); \
-      hipLaunchKernelGGL((cheby_pair_kernel<VAR, nw, false, SM, false, false, true>), dim3(grid), dim3(64, nw), lds, g_stream, *L, A); }
+      if (ecols > 0) hipLaunchKernelGGL((cheby_pair_edge_kernel<VAR, false, SM, IP, true>), dim3(egrid_r), dim3(64), 0, g_stream, *L, A); \
+      hipLaunchKernelGGL((cheby_pair_kernel<VAR, nw, false, SM, false, IP, true>), dim3(grid), dim3(64, nw), lds, g_stream, *L, A); }
+#define PAIR_LAUNCH_REMOTE(VAR, SM) { if (interp) PAIR_LAUNCH_REMOTE_IP(VAR, SM, true) else PAIR_LAUNCH_REMOTE_IP(VAR, SM, false) }
 #define PAIR_LAUNCH(VAR, C32, SM) { \
       A.edge_blocks = ((A.Dj + 63) / 64) * A.Dk * 2 * (A.tiles_i - 1); const dim3 egrid(A.edge_blocks > 0 ? grid_for(A.edge_blocks, &A.edge_per_xcd) : 1); \
       if (remote) PAIR_LAUNCH_REMOTE(VAR, SM) \
@@ -230,6 +240,7 @@ static int smooth_pair(const hpgmg_hip_level *L, int variant, int gsrb, int swee
 #undef PAIR_LAUNCH
 #undef PAIR_LAUNCH2
 #undef PAIR_LAUNCH_REMOTE
+#undef PAIR_LAUNCH_REMOTE_IP
   if (part != 1) { g_pair_launches++; if (remote) g_pair_remote_launches++; }      // the two parts of a launch count once (part 2 is never empty: it holds the workgroups at the remote faces)
   profile_end(prof, 2 * cells, part == 1);           // one launch = two sweeps over every cell
   HPGMG_LAUNCH_CHECK("cheby_pair_kernel");
@@ -255,17 +266,25 @@ void hpgmg_hip_exp_timeline(void *buf) { g_exp_timeline = (double *)buf; }
 void hpgmg_hip_pair_launch_counts(long long out[2]) { out[0] = g_pair_launches; out[1] = g_pair_remote_launches; }
 
 // ---- the halo of a sweep pair across rank boundaries: one pack launch, one grouped send/recv, one unpack launch ----
+static const hpgmg_hip_level *g_halo_fold_level = nullptr;      // consumed by the next pack (hpgmg_hip_pair_halo_fold_interpolation)
+static int g_halo_fold_id = 0;
+static double g_halo_fold_prescale = 1.0;
 static int pair_halo_move(bool unpack, const hpgmg_hip_level *L, double *const *scr_base, int x0_scr, int x0_id, int xm1_scr, int xm1_id, int rhs_id,
                           const hpgmg_hip_halo_entry *entries, int n, double *buf, double *deep, double *deep_beta) {
+  const hpgmg_hip_level *fold = unpack ? nullptr : g_halo_fold_level;
+  if (!unpack) g_halo_fold_level = nullptr;
   HPGMG_SKIP_IF_REPLAY();
   if (n <= 0) return 0;
-  HaloRefs R; R.x0 = VecRef{x0_scr, x0_id}; R.xm1 = VecRef{xm1_scr, xm1_id}; R.rhs_id = rhs_id; R.scr_base = scr_base;
+  HaloRefs R = {}; R.x0 = VecRef{x0_scr, x0_id}; R.xm1 = VecRef{xm1_scr, xm1_id}; R.rhs_id = rhs_id; R.scr_base = scr_base;
+  if (fold) { R.fold = 1; R.Lc = *fold; R.coarse_id = g_halo_fold_id; R.prescale = g_halo_fold_prescale; }
   const int slabs = (L->dim * L->dim + 4095) / 4096;                 // a face of dim^2 values: 16 values per lane
   if (unpack) hipLaunchKernelGGL((pair_halo_kernel<true>), dim3(n, slabs), dim3(256), 0, g_stream, *L, R, entries, buf, deep, deep_beta);
   else        hipLaunchKernelGGL((pair_halo_kernel<false>), dim3(n, slabs), dim3(256), 0, g_stream, *L, R, entries, buf, deep, deep_beta);
   HPGMG_LAUNCH_CHECK("pair_halo_kernel");
   return 0;
 }
+// the NEXT hpgmg_hip_pair_halo_pack adds the coarse parent to the x0 values it packs (a smooth() with interpolation_vcycle folded into its first sweep pair)
+void hpgmg_hip_pair_halo_fold_interpolation(const hpgmg_hip_level *Lc, int coarse_id, double prescale) { g_halo_fold_level = Lc; g_halo_fold_id = coarse_id; g_halo_fold_prescale = prescale; }
 int hpgmg_hip_pair_halo_pack(const hpgmg_hip_level *L, double *const *scr_base, int x0_scr, int x0_id, int xm1_scr, int xm1_id, int rhs_id,
                              const hpgmg_hip_halo_entry *entries, int n, double *sendbuf) {
   return pair_halo_move(false, L, scr_base, x0_scr, x0_id, xm1_scr, xm1_id, rhs_id, entries, n, sendbuf, nullptr, nullptr);

@@ -238,6 +238,9 @@ void hpgmg_hip_pair_launch_counts(long long out[2]);      /* sweep-pair launches
  * Pack copies the region (i fastest) to sendbuf + off; unpack copies recvbuf + off into the region (deep = -1: ghost cells at
  * (i,j,k)), into deep plane `deep` (0..5) or into deep_beta plane deep - 8 (8..10) of the box. */
 typedef struct { int box, vec, i, j, k, ni, nj, nk, deep, pad_; long long off; } hpgmg_hip_halo_entry;
+/* the NEXT hpgmg_hip_pair_halo_pack adds the coarse parent (interpolation_p0.c:43) to the x0 values it packs: across ranks the folded interpolation of
+ * hpgmg_hip_pair_fold_interpolation is applied by each cell's OWNER, so ghost zones and deep planes arrive interpolated */
+void hpgmg_hip_pair_halo_fold_interpolation(const hpgmg_hip_level *Lc, int coarse_id, double prescale);
 int  hpgmg_hip_pair_halo_pack(const hpgmg_hip_level *L, double *const *scr_base, int x0_scr, int x0_id, int xm1_scr, int xm1_id, int rhs_id,
                               const hpgmg_hip_halo_entry *entries, int n, double *sendbuf);
 int  hpgmg_hip_pair_halo_unpack(const hpgmg_hip_level *L, double *const *scr_base, int x0_scr, int x0_id, int xm1_scr, int xm1_id, int rhs_id,

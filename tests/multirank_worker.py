@@ -133,7 +133,7 @@ def main():
         K.hpgmg_hip_pair_launch_counts(counts)
         stats["pair_launches"], stats["pair_remote_launches"] = counts[0], counts[1]
         for name, fn in (("fv4_rb_smooths", be.lib.hpgmg_fv4_rb_smooths), ("rb27_passes", be.lib.hpgmg_rb27_passes), ("image_exchanges", be.lib.hpgmg_image_exchanges),
-                         ("fused_residuals_remote", be.lib.hpgmg_fused_residuals_remote)):
+                         ("fused_residuals_remote", be.lib.hpgmg_fused_residuals_remote), ("interp_folded_remote", be.lib.hpgmg_interp_folded_remote)):
             fn.restype = ctypes.c_longlong          # one-pass red + black smoothers, refreshes of the images of neighbouring ranks' boxes
             stats[name] = fn()
     s.destroy()

@@ -68,6 +68,8 @@ def test_sweep_pairs_across_rank_boundaries(world, variant, log2, per_rank, gold
         assert r["stats"]["pair_remote_launches"] == 2 * r["stats"]["pair_remote_smooths"], r["stats"]
         if os.environ.get("HPGMG_OVERLAP", "1") != "0":       # each pair's halo exchange runs on the exchange stream under the workgroups that touch no remote face
             assert r["stats"]["overlapped_exchanges"] >= 2 * r["stats"]["pair_remote_smooths"], r["stats"]
+        if variant.startswith("7pt-cheby"):      # the up leg's interpolation_vcycle is folded into the first pair across rank boundaries too (each owner adds the parents to what it sends)
+            assert r["stats"]["interp_folded_remote"] >= 4, r["stats"]
         # residual + restriction and residual + norm stay ONE pass each on a bandwidth-bound level with faces on other ranks (x crosses them first)
         if per_rank * 128 ** 3 >= 4000000:
             assert r["stats"]["fused_residuals_remote"] >= 8, r["stats"]
@@ -176,6 +178,7 @@ def test_ipc_peer_copy_transport(world, variant, log2, per_rank, gold_key, gathe
             assert r["stats"]["rb27_passes"] >= 16 and r["stats"]["image_exchanges"] > 20, r["stats"]
         if variant.startswith("7pt-cheby") and log2 == 7:       # the fine-level smoother stays the sweep-pair kernel across rank boundaries, one exchange per pair
             assert r["stats"]["pair_remote_smooths"] >= 8 and r["stats"]["pair_remote_launches"] == 2 * r["stats"]["pair_remote_smooths"], r["stats"]
+            assert r["stats"]["interp_folded_remote"] >= 4, r["stats"]
 
 
 def bench_line(argv, extra_env=None, expect_code=0):
