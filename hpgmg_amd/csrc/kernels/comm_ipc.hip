@@ -96,6 +96,7 @@ static void host_wait_flag(void *p) {
   const double t0 = wall();
   for (unsigned long long n = 0; f->flag->load(std::memory_order_acquire) < f->value; n++) {
     if ((n & 0xfff) == 0xfff && wall() - t0 > ipc_timeout()) { fprintf(stderr, "hpgmg_hip (ipc transport, rank %d): a peer's stream never reached the point this stream waits for\n", g_irank); fflush(stderr); abort(); }
+    if ((n & 0xff) == 0xff) sched_yield();      // several ranks on one GPU share the host cores: the peer this callback waits for may need this one
     __builtin_ia32_pause();
   }
   delete f;
