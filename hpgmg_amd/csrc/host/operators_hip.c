@@ -251,8 +251,7 @@ int hpgmg_zero_interpolation_fcycle_fused(level_type *Lf, int id_f, level_type *
   zero_interp_fused++;
   /* the coarse operand's ghost zones as interpolation_fcycle() fills them, then the interpolation in its "onto zeros" form (order + 16) */
   if (c.op == HPGMG_OP_7PT) {                                   /* interpolation_p1.c:71-72 */
-    exchange_boundary(Lc, id_c, STENCIL_SHAPE_BOX);
-    apply_BCs_p1(Lc, id_c, STENCIL_SHAPE_BOX);
+    if (!hp_exchange_and_bcs_one_launch(Lc, id_c, STENCIL_SHAPE_BOX, 1, 1)) { exchange_boundary(Lc, id_c, STENCIL_SHAPE_BOX); apply_BCs_p1(Lc, id_c, STENCIL_SHAPE_BOX); }
     interpolation_lists(Lf, id_f, 0.0, Lc, id_c, 17, 0x7);
   } else if (c.op == HPGMG_OP_27PT) {                           /* operators.27pt.c:150-151 -> interpolation_p2.c:228-230 */
     if (!hp_exchange_and_bcs_one_launch(Lc, id_c, STENCIL_SHAPE_BOX, 12, 1)) { exchange_boundary(Lc, id_c, STENCIL_SHAPE_BOX); apply_BCs_p2(Lc, id_c, STENCIL_SHAPE_BOX); }
@@ -277,8 +276,7 @@ void interpolation_fcycle(level_type *Lf, int id_f, double prescale, level_type 
   if (c.op != HPGMG_OP_7PT) hp_no_kernel("interpolation_fcycle for this operator");
   /* ghost-free form (interpolation_p1.c:71-72 without its two launches): every coarse box local, Dirichlet, box-to-box entries only -- the kernel reads a
    * coarse neighbour where it lives and applies apply_BCs_p1's rule in registers, as the 7-point stencils do (HPGMG_GHOST_FREE=0: the three-step form) */
-  exchange_boundary(Lc, id_c, STENCIL_SHAPE_BOX);
-  apply_BCs_p1(Lc, id_c, STENCIL_SHAPE_BOX);
+  if (!hp_exchange_and_bcs_one_launch(Lc, id_c, STENCIL_SHAPE_BOX, 1, 1)) { exchange_boundary(Lc, id_c, STENCIL_SHAPE_BOX); apply_BCs_p1(Lc, id_c, STENCIL_SHAPE_BOX); }
   interpolation_lists(Lf, id_f, prescale, Lc, id_c, 1, 0x7);
 }
 

@@ -33,12 +33,13 @@ void exchange_boundary(level_type *L, int id, int shape) {
  * through the ghost zone: pack -> send/recv -> unpack, no local copies, no BC launch. */
 int hp_ghost_free_mode(void) { return (int)hp_switch(SW_GHOST_FREE); }
 void hpgmg_set_ghost_free(int on) { hp_switch_set(SW_GHOST_FREE, on ? 1 : 0); hpgmg_hip_set_ghost_free(on ? 1 : 0); }
-/* exchange_boundary(L, id, shape) + apply_BCs_p2 / v2 / v4 (order 12 / 2 / 4) as ONE launch, when the level has no messages and every
+/* exchange_boundary(L, id, shape) + apply_BCs_p1 / p2 / v2 / v4 (order 1 / 12 / 2 / 4) as ONE launch, when the level has no messages and every
  * boundary-condition block can read its sources from the box that owns them (then the box-to-box copies and the conditions are
  * independent of each other).  with_copies = 0: only the conditions (the caller's kernel reads neighbouring boxes itself).  Returns 0 when the
  * caller must issue the two operators. */
 int hp_exchange_and_bcs_one_launch(level_type *L, int id, int shape, int order, int with_copies) {
   if (!hp_switch(SW_ONE_LAUNCH_GHOSTS) || !hp_ghost_free_mode() || L->num_my_boxes < 1 || L->boundary_condition.type == BC_PERIODIC) return 0;
+  if (order == 1 && L->box_ghosts != 1) return 0;
   if (order == 12 && !(L->box_dim >= 2 && L->box_ghosts == 1)) return 0;      /* the fall-backs of apply_BCs_p2 / v2 / v4 for tiny boxes stay separate launches */
   if (order == 2 && !(L->box_dim >= 2)) return 0;
   if (order == 4 && !(L->box_dim >= 4)) return 0;

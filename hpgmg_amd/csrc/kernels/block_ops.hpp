@@ -337,9 +337,16 @@ __device__ __forceinline__ void bc_v4_entry(const hpgmg_hip_level &L, int id, co
 
 // the same conditions over entries whose geometry the host worked out (hpgmg_hip_bc_entry): one loop per kind, so the
 // instructions a workgroup executes are few and contiguous.  ORDER: 2 = v2, 4 = v4, 12 = p2
+// ORDER 1 = apply_BCs_p1 (boundary_fd.c:35-65): scale * x[ghost + inward normal], scale -1 / +1 / -1 for a face / an edge / a corner
+template <int NN, typename CP, typename WP>
+__device__ __forceinline__ void bc_p1_compact_cell(CP x, WP xw, int ijk, int s0, int s1, int s2) {
+  const double scale = (NN == 2) ? 1.0 : -1.0;
+  xw[ijk] = scale * x[ijk + s0 + (NN >= 2 ? s1 : 0) + (NN == 3 ? s2 : 0)];
+}
 template <int ORDER, int NN, typename CP, typename WP>
 __device__ __forceinline__ void bc_compact_cell(CP x, WP xw, int ijk, int s0, int s1, int s2) {
-  if (ORDER == 4) bc_v4_cell<NN>(x, xw, ijk, s0, s1, s2); else if (ORDER == 2) bc_v2_cell<NN>(x, xw, ijk, s0, s1, s2); else bc_p2_cell<NN>(x, xw, ijk, s0, s1, s2);
+  if (ORDER == 4) bc_v4_cell<NN>(x, xw, ijk, s0, s1, s2); else if (ORDER == 2) bc_v2_cell<NN>(x, xw, ijk, s0, s1, s2);
+  else if (ORDER == 1) bc_p1_compact_cell<NN>(x, xw, ijk, s0, s1, s2); else bc_p2_cell<NN>(x, xw, ijk, s0, s1, s2);
 }
 template <int ORDER, bool REDIRECT, bool CLEAR = false>
 __device__ __forceinline__ void bc_fv_compact_entry(const hpgmg_hip_level &L, int id, const hpgmg_hip_bc_entry &e, int tid, int nth) {

@@ -322,10 +322,10 @@ int hpgmg_hip_apply_bc_v4(const hpgmg_hip_level *L, int id, const blockCopy_type
 }
 // 0: launch without clearing, 1: with, -1: not supported (p2 is defined for one ghost layer only)
 static int bc_fv_clear_mode(const hpgmg_hip_level *L, int order) {
-  if (order != 2 && order != 4 && order != 12) return -1;
+  if (order != 1 && order != 2 && order != 4 && order != 12) return -1;
   const int fills = (order == 4) ? 2 : 1;
   if (L->ghosts <= fills) return 0;
-  return (order == 12) ? -1 : 1;
+  return (order == 12 || order == 1) ? -1 : 1;
 }
 int hpgmg_hip_apply_bc_fv(const hpgmg_hip_level *L, int id, const hpgmg_hip_bc_entry *entries, int n, int order) {
   HPGMG_SKIP_IF_REPLAY();
@@ -336,6 +336,7 @@ int hpgmg_hip_apply_bc_fv(const hpgmg_hip_level *L, int id, const hpgmg_hip_bc_e
   else if (order == 4)          hipLaunchKernelGGL((bc_fv_kernel<4, false>), dim3(n), dim3(256), 0, g_stream, *L, id, entries);
   else if (order == 2 && clear) hipLaunchKernelGGL((bc_fv_kernel<2, true>), dim3(n), dim3(256), 0, g_stream, *L, id, entries);
   else if (order == 2)          hipLaunchKernelGGL((bc_fv_kernel<2, false>), dim3(n), dim3(256), 0, g_stream, *L, id, entries);
+  else if (order == 1)          hipLaunchKernelGGL((bc_fv_kernel<1, false>), dim3(n), dim3(256), 0, g_stream, *L, id, entries);
   else                          hipLaunchKernelGGL((bc_fv_kernel<12, false>), dim3(n), dim3(256), 0, g_stream, *L, id, entries);
   HPGMG_LAUNCH_CHECK("bc_fv_kernel");
   return 0;
@@ -350,6 +351,7 @@ int hpgmg_hip_exchange_and_bc(const hpgmg_hip_level *L, int id, const blockCopy_
   else if (order == 4)          hipLaunchKernelGGL((ghost_fill_kernel<4, false>), grid, dim3(256), 0, g_stream, *L, id, copies, n_copy, entries);
   else if (order == 2 && clear) hipLaunchKernelGGL((ghost_fill_kernel<2, true>), grid, dim3(256), 0, g_stream, *L, id, copies, n_copy, entries);
   else if (order == 2)          hipLaunchKernelGGL((ghost_fill_kernel<2, false>), grid, dim3(256), 0, g_stream, *L, id, copies, n_copy, entries);
+  else if (order == 1)          hipLaunchKernelGGL((ghost_fill_kernel<1, false>), grid, dim3(256), 0, g_stream, *L, id, copies, n_copy, entries);
   else                          hipLaunchKernelGGL((ghost_fill_kernel<12, false>), grid, dim3(256), 0, g_stream, *L, id, copies, n_copy, entries);
   HPGMG_LAUNCH_CHECK("ghost_fill_kernel");
   return 0;
