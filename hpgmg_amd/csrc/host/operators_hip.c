@@ -87,7 +87,10 @@ static int fused_residual_on(void) {
     if ((READY) == 2) {                                                                                          \
       hpgmg_hip_set_tile_part(1); HIP_OK(CALL); hp_overlap_end(); hpgmg_hip_set_tile_part(2); HIP_OK(CALL); hpgmg_hip_set_tile_part(0); \
     } else HIP_OK(CALL); } while (0)
-static int fused_residual_operand(level_type *L, backend_t *B, int x_id) {
+static int fused_residual_operand_form(level_type *L, backend_t *B, int x_id, int restrict_form);
+static int fused_residual_operand(level_type *L, backend_t *B, int x_id) { return fused_residual_operand_form(L, B, x_id, 0); }
+/* restrict_form: residual + restriction + zero_vector, which the 7-point plugin also has for the launch-bound levels of small boxes (one launch instead of two) */
+static int fused_residual_operand_form(level_type *L, backend_t *B, int x_id, int restrict_form) {
   hpgmg_config cfg;
   hpgmg_get_config(&cfg);
   const int shape = stencil_get_shape();
@@ -115,7 +118,7 @@ static int fused_residual_operand(level_type *L, backend_t *B, int x_id) {
   if (cfg.op == HPGMG_OP_7PT) {
     if (shape != STENCIL_SHAPE_STAR) return 0;
     hpgmg_hip_set_ghost_free(1);
-    return hpgmg_hip_residual_fused_supported(&B->dev, hp_variant());
+    return restrict_form ? hpgmg_hip_residual_restrict_supported(&B->dev, hp_variant()) : hpgmg_hip_residual_fused_supported(&B->dev, hp_variant());
   }
   if (cfg.op != HPGMG_OP_27PT && cfg.op != HPGMG_OP_FV4) return 0;
   if (!hpgmg_hip_residual_fused_supported(&B->dev, hp_variant())) return 0;
@@ -136,7 +139,7 @@ int hp_residual_restrict_zero_fused(level_type *Lc, int id_c, level_type *Lf, in
   backend_t *Bc = hp_backend_of(Lc), *Bf = hp_backend_of(Lf);
   if (!restrict_map_of(Lf, Bf)) return 0;
   { hpgmg_config cfg; hpgmg_get_config(&cfg); if (res_id >= 0 && (cfg.op != HPGMG_OP_7PT || res_id == x_id || res_id == rhs_id)) return 0; }
-  const int ready = fused_residual_operand(Lf, Bf, x_id);
+  const int ready = fused_residual_operand_form(Lf, Bf, x_id, 1);
   if (!ready) return 0;
   TICK(Lf, residual, "residual + restriction + zero_vector (fused)");
   FUSED_LAUNCH(ready, hpgmg_hip_residual_restrict_store(hp_stencil_dev(Bf), hp_variant(), res_id, x_id, rhs_id, a, b, 1.0 / (Lf->h * Lf->h), &Bc->dev, id_c, Bf->d_restrict_map, zero_id));

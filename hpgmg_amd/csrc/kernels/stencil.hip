@@ -29,8 +29,20 @@
 
 namespace hpgmg {
 
-template <int V, int MODE, bool IP = false>
-__global__ __launch_bounds__(256) void stencil7_kernel(const hpgmg_hip_level L, const StencilArgs P, const InterpFold F = InterpFold{}) {
+// RR (MODE_RESIDUAL on the launch-bound levels, boxes of side <= 32): residual + restriction + zero_vector of MGVCycle's down leg (mg.c:1150-1153) in
+// ONE launch -- a wave holds whole PAIRS of rows (blockDim.x <= 32), so the lane of an even (i, j) gathers its 2 x 2 patch of residuals from its
+// neighbours' registers, sums it in restriction.c:54-57's order and carries the sum over the plane pair; the coarse zero_vector rides along as
+// extra workgroups; the residual itself is stored only when asked for (FA.store_res: the exact state of the three operators).
+template <int V, int MODE, bool IP = false, bool RR = false>
+__global__ __launch_bounds__(256) void stencil7_kernel(const hpgmg_hip_level L, const StencilArgs P, const InterpFold F = InterpFold{}, const FusedArgs FA = FusedArgs{}) {
+  if (RR && (int)blockIdx.x >= kXcds * P.per_xcd) {      // zero_vector(coarse, zero_id): whole padded boxes, ghosts included
+    const int z = (int)blockIdx.x - kXcds * P.per_xcd, zbox = z / FA.zero_chunks_per_box, chunk = z - zbox * FA.zero_chunks_per_box;
+    if (zbox >= FA.Lc.num_boxes) return;
+    double *v = FA.Lc.box_base[zbox] + (size_t)FA.zero_id * (size_t)FA.Lc.volume;
+    const int lo = chunk * 4096, hi = (lo + 4096 < FA.Lc.volume) ? lo + 4096 : FA.Lc.volume, nth = (int)(blockDim.x * blockDim.y);
+    for (int q = lo + (int)(threadIdx.y * blockDim.x + threadIdx.x); q < hi; q += nth) v[q] = 0.0;
+    return;
+  }
   const int logical = xcd_logical_block((int)blockIdx.x, P.per_xcd);
   if (logical >= P.total_blocks) return;
   // logical id -> (box, k chunk, j tile, i tile), i fastest
@@ -91,6 +103,11 @@ __global__ __launch_bounds__(256) void stencil7_kernel(const hpgmg_hip_level L, 
     if (dir == 0) ii = last; else if (dir == 1) ii = 0; else if (dir == 2) jj = last; else if (dir == 3) jj = 0; else if (dir == 4) kk = last; else kk = 0;
     return folded(nb, ii, jj, kk);
   };
+  double *coarse = nullptr; double racc = 0.0;
+  if (RR) {
+    const int *m = FA.map + 4 * box;
+    coarse = vec_origin(FA.Lc, m[0], FA.coarse_id) + (m[1] + (i >> 1)) + (m[2] + (j >> 1)) * FA.Lc.jStride + (m[3] + (k0 >> 1)) * FA.Lc.kStride;
+  }
   int ijk = i + j * jS + k0 * kS;
   double xc = fold_x ? folded(box, i, j, k0) : x[ijk];
   double xm = fold_x ? (k0 == 0 ? folded_step(4, i, j, -1, xc) : folded(box, i, j, k0 - 1))
@@ -130,7 +147,17 @@ __global__ __launch_bounds__(256) void stencil7_kernel(const hpgmg_hip_level L, 
       } else if (MODE == MODE_JACOBI) {
         out[ijk] = xc + P.c2 * dinv[ijk] * (rhs[ijk] - Ax);
       } else if (MODE == MODE_RESIDUAL) {
-        out[ijk] = rhs[ijk] - Ax;
+        const double r = rhs[ijk] - Ax;
+        if (!RR || FA.store_res) out[ijk] = r;
+        if (RR) {      // the children (i, i+1) of rows j, j+1 of plane k, then of plane k+1; times 0.125 (restriction.c:54-57)
+          const int w = (int)blockDim.x;
+          const double r10 = __shfl_down(r, 1, 64), r01 = __shfl_down(r, w, 64), r11 = __shfl_down(r, w + 1, 64);
+          if (((k - k0) & 1) == 0) { racc = r + r10; racc = racc + r01; racc = racc + r11; }
+          else {
+            racc = racc + r; racc = racc + r10; racc = racc + r01; racc = racc + r11;
+            if (((i | j) & 1) == 0) coarse[((k - k0) >> 1) * FA.Lc.kStride] = racc * 0.125;
+          }
+        }
       } else {
         out[ijk] = Ax;
       }
@@ -853,6 +880,31 @@ static int launch(const hpgmg_hip_level *L, int variant, StencilArgs P, bool is_
 }
 
 // ---- fused forms of residual() on the bandwidth-bound fine level (stencil7_wide_kernel, ghost-free, every face local) ----
+// residual + restriction + zero_vector on the launch-bound levels (boxes of an even side <= 32, every box local): stencil7_kernel<.., RR>
+static int small_fused_ok(const hpgmg_hip_level *L, int variant) {
+  if (variant != HPGMG_HIP_7PT_VC_HELMHOLTZ && variant != HPGMG_HIP_7PT_VC_POISSON && variant != HPGMG_HIP_7PT_CC) return 0;
+  static const int on = env_int("HPGMG_TUNE_SMALL_RR", 1);      // 0: the two launches (experiments)
+  return on && L->num_boxes > 0 && g_ghost_free && L->box_nbr && !g_defer_mode && !g_tile_part && L->dim % 2 == 0 && L->dim <= 32;
+}
+static int launch_small_fused(const hpgmg_hip_level *L, int variant, StencilArgs P, FusedArgs FA, int extra_blocks) {
+  dim3 block; int grid;
+  plan(L, P, block, grid);
+  if (!P.ghost_free || block.x > 32) return record_error(hipErrorInvalidValue, "fused residual on a small level: ghost-free path, boxes of side <= 32");
+  if (P.kchunk < 2 || (P.kchunk & 1)) {          // plane PAIRS stay inside a chunk
+    P.kchunk = (P.kchunk < 2) ? 2 : P.kchunk + 1;
+    P.chunks_k = (L->dim + P.kchunk - 1) / P.kchunk;
+    P.total_blocks = L->num_boxes * P.chunks_k * P.tiles_j * P.tiles_i;
+    grid = grid_for(P.total_blocks, &P.per_xcd);
+  }
+  grid += extra_blocks;
+  switch (variant) {
+    case HPGMG_HIP_7PT_VC_HELMHOLTZ: hipLaunchKernelGGL((stencil7_kernel<HPGMG_HIP_7PT_VC_HELMHOLTZ, MODE_RESIDUAL, false, true>), dim3(grid), block, 0, g_stream, *L, P, InterpFold{}, FA); break;
+    case HPGMG_HIP_7PT_VC_POISSON:   hipLaunchKernelGGL((stencil7_kernel<HPGMG_HIP_7PT_VC_POISSON, MODE_RESIDUAL, false, true>), dim3(grid), block, 0, g_stream, *L, P, InterpFold{}, FA); break;
+    default:                         hipLaunchKernelGGL((stencil7_kernel<HPGMG_HIP_7PT_CC, MODE_RESIDUAL, false, true>), dim3(grid), block, 0, g_stream, *L, P, InterpFold{}, FA); break;
+  }
+  HPGMG_LAUNCH_CHECK("stencil7_kernel (residual + restriction + zero_vector)");
+  return 0;
+}
 static int wide_fused_ok(const hpgmg_hip_level *L, int variant) {
   if (variant != HPGMG_HIP_7PT_VC_HELMHOLTZ && variant != HPGMG_HIP_7PT_VC_POISSON && variant != HPGMG_HIP_7PT_CC) return 0;
   return L->num_boxes > 0 && g_ghost_free && L->box_nbr && !g_defer_mode && L->dim % 128 == 0 && L->jStride % 2 == 0 && L->kStride % 2 == 0 && L->volume % 2 == 0 && (L->flags & 1);
@@ -1023,6 +1075,10 @@ int hpgmg_hip_residual_fused_supported(const hpgmg_hip_level *L, int variant) {
   if (tiled_variant(variant)) return hpgmg_hip_tile_kernel_applies(L, variant, 1) && L->dim % 2 == 0;   // the tiled kernels carry the fused forms (27-point, fv4)
   return wide_fused_ok(L, variant);
 }
+// residual + restriction + zero_vector only (not residual + norm): also the launch-bound levels of small boxes
+int hpgmg_hip_residual_restrict_supported(const hpgmg_hip_level *L, int variant) {
+  return hpgmg_hip_residual_fused_supported(L, variant) || (!tiled_variant(variant) && small_fused_ok(L, variant));
+}
 // residual (never stored) -> restriction into vector coarse_id of Lc, plus zero_vector(Lc, zero_id) when zero_id >= 0: the end of
 // MGVCycle's down leg (mg.c:1150-1153) in one pass over the fine level.  map[4 b .. 4 b + 3] = coarse box and coarse (i, j, k) under fine box b's first cell.
 int hpgmg_hip_residual_restrict_store(const hpgmg_hip_level *L, int variant, int res_id, int x_id, int rhs_id, double a, double b, double h2inv,
@@ -1042,11 +1098,12 @@ int hpgmg_hip_residual_restrict_store(const hpgmg_hip_level *L, int variant, int
     if (int e = launch<MODE_RESIDUAL>(L, variant, T, false)) return e;
     return zero_id >= 0 ? hpgmg_hip_fill(Lc, zero_id, 0.0) : 0;
   }
-  if (!wide_fused_ok(L, variant) || Lc->num_boxes <= 0) return record_error(hipErrorInvalidValue, "residual_restrict: level not supported");
+  if ((!wide_fused_ok(L, variant) && !small_fused_ok(L, variant)) || Lc->num_boxes <= 0) return record_error(hipErrorInvalidValue, "residual_restrict: level not supported");
   if (res_id == x_id || res_id == rhs_id) return record_error(hipErrorInvalidValue, "residual_restrict: the residual may not overwrite its inputs");
   StencilArgs P = {}; P.xn_id = x_id; P.xout_id = (res_id >= 0) ? res_id : x_id; P.rhs_id = rhs_id; P.a = a; P.b = b; P.h2inv = h2inv;
   FusedArgs F = {}; F.Lc = *Lc; F.coarse_id = coarse_id; F.zero_id = zero_id; F.map = map; F.store_res = (res_id >= 0);
   F.zero_chunks_per_box = (Lc->volume + 4095) / 4096;
+  if (!wide_fused_ok(L, variant)) return launch_small_fused(L, variant, P, F, zero_id >= 0 ? F.zero_chunks_per_box * Lc->num_boxes : 0);
   return launch_wide_fused<MODE_RESIDUAL_RESTRICT>(L, variant, P, F, zero_id >= 0 ? F.zero_chunks_per_box * Lc->num_boxes : 0);
 }
 // residual stored to res_id (not stored when res_id < 0) AND its max-abs: residual() + norm() of the convergence check (mg.c:1321-1323) in one pass

@@ -119,6 +119,8 @@ int hpgmg_hip_residual(const hpgmg_hip_level *L, int variant, int res_id, int x_
  *              box: coarse box index and the coarse (i, j, k) under the fine box's first cell.
  *   _norm:     res is stored AND max |res| is returned (residual + norm of the convergence check, mg.c:1321-1323). */
 int hpgmg_hip_residual_fused_supported(const hpgmg_hip_level *L, int variant);
+/* the restriction form alone (hpgmg_hip_residual_restrict / _store) also takes the launch-bound 7-point levels of boxes of an even side <= 32 */
+int  hpgmg_hip_residual_restrict_supported(const hpgmg_hip_level *L, int variant);
 int hpgmg_hip_residual_restrict(const hpgmg_hip_level *L, int variant, int x_id, int rhs_id, double a, double b, double h2inv,
                                 const hpgmg_hip_level *Lc, int coarse_id, const int *map, int zero_id);
 /* the same, and the residual is ALSO stored to vector res_id (>= 0; 7-point kernels): exactly the state residual() + restriction() + zero_vector() leave */

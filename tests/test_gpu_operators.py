@@ -245,6 +245,68 @@ def test_interpolation_folded_into_single_chebyshev_sweeps(hip, oracle, variant,
             be.lib.hpgmg_mg_destroy(m); f.destroy()
 
 
+@pytest.mark.parametrize("variant,geom", [("7pt-cheby-helm", (2, 32)), ("7pt-cheby", (2, 16)), ("7ptcc-cheby", (3, 16)), ("7pt-gsrb", (4, 8)), ("7pt-cheby-helm", (1, 32)),
+                                          ("7pt-cheby", (2, 2)), ("7pt-cheby-helm", (3, 6)), ("7pt-cheby", (1, 24))])
+def test_residual_restriction_zero_as_one_launch_on_small_boxes(hip, oracle, variant, geom):
+    """MGVCycle's down leg (mg.c:1150-1153) on the launch-bound levels (boxes of an even side <= 32): residual + restriction + zero_vector in ONE launch of
+    stencil7_kernel<.., RR> -- the 2 x 2 patch of residuals gathered from the neighbouring lanes' registers, summed in restriction.c:54-57's order.  Both forms:
+    the cycle hook (the residual never stored) and the operator queue's (residual(VECTOR_TEMP) stored too: exactly the state of the three operators)."""
+    set_mode(hip, 1)
+    pairs = []
+    for be in (hip, oracle):
+        be.configure(**VARIANTS[variant])
+        fine = be.level(*geom)
+        for vid in range(fine.num_vectors):
+            d = seeded_field(fine, 1300 + vid)
+            if vid >= H.VECTOR_DINV:
+                d = np.abs(d) + 0.5
+            fine.write_all(vid, d)
+        for vid in range(H.VECTOR_DINV, fine.num_vectors):
+            be.lib.exchange_boundary(fine.ptr, vid, H.STENCIL_SHAPE_BOX)
+        a, b = (1.0, 1.0) if "helm" in variant else (0.0, 1.0)
+        mg = be.lib.hpgmg_mg_create(fine.ptr, a, b, 1)
+        pairs.append((be, fine, mg, a, b))
+    try:
+        from hpgmg_testlib import Level
+        (bh, fh, mh, a, b), (bo, fo, mo, _, _) = pairs
+        c_int, c_dbl, vp = ctypes.c_int, ctypes.c_double, ctypes.c_void_p
+        L = hip.lib
+        L.hpgmg_residual_restrict_zero_fused.restype = c_int
+        L.hpgmg_residual_restrict_zero_fused.argtypes = [vp, c_int, vp, c_int, c_int, c_dbl, c_dbl, c_int]
+        ch, co = Level(bh, bh.lib.hpgmg_mg_level(mh, 1)), Level(bo, bo.lib.hpgmg_mg_level(mo, 1))
+        junk = seeded_field(ch, 1301)
+        for c in (ch, co):
+            c.write_all(H.VECTOR_U, junk); c.write_all(H.VECTOR_R, junk)
+        assert L.hpgmg_residual_restrict_zero_fused(ch.ptr, H.VECTOR_R, fh.ptr, H.VECTOR_U, H.VECTOR_F, a, b, H.VECTOR_U) == 1
+        bo.lib.residual(fo.ptr, H.VECTOR_TEMP, H.VECTOR_U, H.VECTOR_F, a, b)
+        bo.lib.restriction(co.ptr, H.VECTOR_R, fo.ptr, H.VECTOR_TEMP, H.RESTRICT_CELL)
+        bo.lib.zero_vector(co.ptr, H.VECTOR_U)
+        same(ch, co, [H.VECTOR_R])
+        w = ch.box_dim + 2 * ch.ghosts
+        cells = lambda x: x[:, : w * ch.kStride].reshape(-1, w, ch.kStride)[:, :, : w * ch.jStride].reshape(-1, w, w, ch.jStride)[:, :, :, :w]
+        assert np.array_equal(cells(ch.read_all(H.VECTOR_U)), cells(co.read_all(H.VECTOR_U)))
+        # the same three operators through the queue (what the reference's own driver issues): the residual is stored as well
+        for c in (ch, co):
+            c.write_all(H.VECTOR_U, junk); c.write_all(H.VECTOR_F, junk)
+        L.hpgmg_lazy_fused_units.restype = ctypes.c_longlong
+        L.hpgmg_lazy_fused_legs.restype = ctypes.c_longlong
+        before = L.hpgmg_lazy_fused_units() + L.hpgmg_lazy_fused_legs()
+        for be, f, c in ((bh, fh, ch), (bo, fo, co)):
+            be.lib.rebuild_operator(f.ptr, None, a, b)          # D^-1 and the eigenvalue bound smooth() needs
+            be.lib.smooth(f.ptr, H.VECTOR_U, H.VECTOR_F, a, b)
+            be.lib.residual(f.ptr, H.VECTOR_TEMP, H.VECTOR_U, H.VECTOR_F, a, b)
+            be.lib.restriction(c.ptr, H.VECTOR_F, f.ptr, H.VECTOR_TEMP, H.RESTRICT_CELL)      # (MGVCycle restricts into the vector it smooths against, mg.c:1152: what the queue recognises)
+            be.lib.zero_vector(c.ptr, H.VECTOR_U)
+            be.lib.hpgmg_operators_flush()
+        assert L.hpgmg_lazy_fused_units() + L.hpgmg_lazy_fused_legs() > before      # (a level pair small enough for the single-launch leg goes out as that)
+        same(fh, fo, [H.VECTOR_U, H.VECTOR_TEMP], interior_only=True)
+        same(ch, co, [H.VECTOR_F])
+        assert np.array_equal(cells(ch.read_all(H.VECTOR_U)), cells(co.read_all(H.VECTOR_U)))
+    finally:
+        for be, f, m, _, _ in pairs:
+            be.lib.hpgmg_mg_destroy(m); f.destroy()
+
+
 @pytest.mark.parametrize("variant,geom", [("7pt-cheby-helm", (2, 128)), ("7pt-gsrb", (1, 128)), ("7ptcc-cheby", (1, 256)),
                                           ("27pt-gsrb", (2, 64)), ("fv4-gsrb", (2, 64)), ("fv4-gsrb", (3, 32)), ("27pt-cheby", (1, 128))])
 def test_fused_residual_forms(hip, oracle, variant, geom):
