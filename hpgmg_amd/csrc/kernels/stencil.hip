@@ -884,11 +884,26 @@ static int launch(const hpgmg_hip_level *L, int variant, StencilArgs P, bool is_
 static int small_fused_ok(const hpgmg_hip_level *L, int variant) {
   if (variant != HPGMG_HIP_7PT_VC_HELMHOLTZ && variant != HPGMG_HIP_7PT_VC_POISSON && variant != HPGMG_HIP_7PT_CC) return 0;
   static const int on = env_int("HPGMG_TUNE_SMALL_RR", 1);      // 0: the two launches (experiments)
-  return on && L->num_boxes > 0 && g_ghost_free && L->box_nbr && !g_defer_mode && !g_tile_part && L->dim % 2 == 0 && L->dim <= 32;
+  return on && L->num_boxes > 0 && g_ghost_free && L->box_nbr && !g_defer_mode && !g_tile_part && L->dim % 2 == 0 && (L->dim <= 32 || (L->dim % 64 == 0 && L->dim % 128 != 0));
 }
 static int launch_small_fused(const hpgmg_hip_level *L, int variant, StencilArgs P, FusedArgs FA, int extra_blocks) {
   dim3 block; int grid;
   plan(L, P, block, grid);
+  if (L->dim % 64 == 0) {      // boxes of 64^3 (config 2's 128^3 level): the LDS-staged tile kernel carries the form
+    constexpr int TJ = 8;
+    S7TileArgs A = {};
+    A.xn_id = P.xn_id; A.xout_id = P.xout_id; A.rhs_id = P.rhs_id; A.a = P.a; A.b = P.b; A.h2inv = P.h2inv; A.ghost_free = 1;
+    A.tiles_i = L->dim / 64; A.tiles_j = L->dim / TJ; A.kchunk = 8; A.chunks_k = L->dim / A.kchunk;
+    A.total_blocks = L->num_boxes * A.chunks_k * A.tiles_j * A.tiles_i;
+    const int tgrid = grid_for(A.total_blocks, &A.per_xcd) + extra_blocks;
+    switch (variant) {
+      case HPGMG_HIP_7PT_VC_HELMHOLTZ: hipLaunchKernelGGL((stencil7_tile_kernel<HPGMG_HIP_7PT_VC_HELMHOLTZ, MODE_RESIDUAL, TJ, false, true>), dim3(tgrid), dim3(64, TJ), 0, g_stream, *L, A, InterpFold{}, FA); break;
+      case HPGMG_HIP_7PT_VC_POISSON:   hipLaunchKernelGGL((stencil7_tile_kernel<HPGMG_HIP_7PT_VC_POISSON, MODE_RESIDUAL, TJ, false, true>), dim3(tgrid), dim3(64, TJ), 0, g_stream, *L, A, InterpFold{}, FA); break;
+      default:                         hipLaunchKernelGGL((stencil7_tile_kernel<HPGMG_HIP_7PT_CC, MODE_RESIDUAL, TJ, false, true>), dim3(tgrid), dim3(64, TJ), 0, g_stream, *L, A, InterpFold{}, FA); break;
+    }
+    HPGMG_LAUNCH_CHECK("stencil7_tile_kernel (residual + restriction + zero_vector)");
+    return 0;
+  }
   if (!P.ghost_free || block.x > 32) return record_error(hipErrorInvalidValue, "fused residual on a small level: ghost-free path, boxes of side <= 32");
   if (P.kchunk < 2 || (P.kchunk & 1)) {          // plane PAIRS stay inside a chunk
     P.kchunk = (P.kchunk < 2) ? 2 : P.kchunk + 1;

@@ -23,8 +23,11 @@ struct S7TileArgs {
 };
 
 // IP: the piecewise-constant interpolation folded into the first two sweeps of a smooth() (InterpFold, stencil_direct.hpp); every box local.
-template <int V, int MODE, int TJ, bool IP = false>
-__global__ __launch_bounds__(64 * TJ) void stencil7_tile_kernel(const hpgmg_hip_level L, const S7TileArgs P, const InterpFold F = InterpFold{}) {
+// RR (MODE 3): residual + restriction + zero_vector of MGVCycle's down leg (mg.c:1150-1153) in one launch -- a plane of residuals passes through an LDS
+// tile, the lane of an even (i, j) sums its 2 x 2 patch a step later in restriction.c:54-57's order and carries it over the plane pair (TileFusedState,
+// common.hpp); the coarse zero_vector rides along as extra workgroups; the residual itself is stored only when FA.store_res says so.
+template <int V, int MODE, int TJ, bool IP = false, bool RR = false>
+__global__ __launch_bounds__(64 * TJ) void stencil7_tile_kernel(const hpgmg_hip_level L, const S7TileArgs P, const InterpFold F = InterpFold{}, const FusedArgs FA = FusedArgs{}) {
   constexpr int TI = 64, W = TI + 2, H = TJ + 2, NT = 64 * TJ, PLANE = W * H;
   constexpr int NH = 2 * TI + 2 * TJ;                           // halo cells of a plane tile: a row above and below, a column left and right (no corners: star stencil)
   static_assert(NH <= NT, "one halo cell per lane at most");
@@ -32,7 +35,16 @@ __global__ __launch_bounds__(64 * TJ) void stencil7_tile_kernel(const hpgmg_hip_
   constexpr bool kHelm = (V == HPGMG_HIP_7PT_VC_HELMHOLTZ);
   constexpr bool kSmooth = (MODE == 0 || MODE == 1 || MODE == 2);  // Chebyshev, GSRB, Jacobi | 3 residual, 4 apply_op
   __shared__ double sX[2 * PLANE];
+  __shared__ double sR[RR ? 2 * TJ * TI : 1];
 
+  if (RR && (int)blockIdx.x >= kXcds * P.per_xcd) {      // zero_vector(coarse, zero_id): whole padded boxes, ghosts included
+    const int z = (int)blockIdx.x - kXcds * P.per_xcd, zbox = z / FA.zero_chunks_per_box, chunk = z - zbox * FA.zero_chunks_per_box;
+    if (zbox >= FA.Lc.num_boxes) return;
+    double *v = FA.Lc.box_base[zbox] + (size_t)FA.zero_id * (size_t)FA.Lc.volume;
+    const int lo = chunk * 4096, hi = (lo + 4096 < FA.Lc.volume) ? lo + 4096 : FA.Lc.volume;
+    for (int q = lo + (int)(threadIdx.y * 64 + threadIdx.x); q < hi; q += NT) v[q] = 0.0;
+    return;
+  }
   const int logical = xcd_logical_block((int)blockIdx.x, P.per_xcd);
   if (logical >= P.total_blocks) return;
   int t = logical;
@@ -113,6 +125,12 @@ __global__ __launch_bounds__(64 * TJ) void stencil7_tile_kernel(const hpgmg_hip_
     if (MODE == 0) { old = out[g]; if (fold_old) old = old + fold_coarse(F, box, i, j, k); }
   };
   load_streams(k0, c_bi, c_bir, c_bj0, c_bj1, c_bk1, c_al, c_dinv, c_rhs, c_old);
+  TileFused TF = {}; TileFusedState<TI, TJ> fs; gptr coarse = nullptr;
+  if (RR) {
+    const int *mp = FA.map + 4 * box;
+    TF.kind = 2; TF.Lc = FA.Lc;
+    coarse = gvec_origin(FA.Lc, mp[0], FA.coarse_id) + (mp[1] + (i >> 1)) + (mp[2] + (j >> 1)) * FA.Lc.jStride + (mp[3] + (k0 >> 1)) * FA.Lc.kStride;
+  }
 
   for (int k = k0; k < k1; k++) {
     double *s = sX + (k & 1) * PLANE;
@@ -126,6 +144,7 @@ __global__ __launch_bounds__(64 * TJ) void stencil7_tile_kernel(const hpgmg_hip_
       load_streams(k + 1, n_bi, n_bir, n_bj0, n_bj1, n_bk1, n_al, n_dinv, n_rhs, n_old);
     }
     __syncthreads();
+    if (RR && k > k0) fs.gather(TF, sR, li, lj, k - 1, k0, coarse);      // the residuals of plane k-1 are all in sR (stored before this barrier)
     bool update = true;
     if (MODE == 1) update = (((i ^ j ^ k ^ colour000) & 1) == 0);
     // beta_i's high face = the next lane's low face (lane 63 loaded it)
@@ -140,7 +159,8 @@ __global__ __launch_bounds__(64 * TJ) void stencil7_tile_kernel(const hpgmg_hip_
       else if (MODE == 2) o = xc + P.c2 * c_dinv * (c_rhs - Ax);
       else if (MODE == 3) o = c_rhs - Ax;
       else                o = Ax;
-      out[own_g + k * kS] = o;
+      if (!RR || FA.store_res) out[own_g + k * kS] = o;
+      if (RR) sR[((k & 1) * TJ + lj) * TI + li] = o;
     }
     // rotate; at the top of the box the plane above is the face rule applied to the new centre
     xm = xc; xc = xp;
@@ -148,6 +168,7 @@ __global__ __launch_bounds__(64 * TJ) void stencil7_tile_kernel(const hpgmg_hip_
     h_c = n_h; bk0 = c_bk1;
     c_bi = n_bi; c_bir = n_bir; c_bj0 = n_bj0; c_bj1 = n_bj1; c_bk1 = n_bk1; c_al = n_al; c_dinv = n_dinv; c_rhs = n_rhs; c_old = n_old;
   }
+  if (RR) { __syncthreads(); fs.gather(TF, sR, li, lj, k1 - 1, k0, coarse); }
 }
 
 }  // namespace hpgmg

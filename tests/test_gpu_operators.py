@@ -246,7 +246,8 @@ def test_interpolation_folded_into_single_chebyshev_sweeps(hip, oracle, variant,
 
 
 @pytest.mark.parametrize("variant,geom", [("7pt-cheby-helm", (2, 32)), ("7pt-cheby", (2, 16)), ("7ptcc-cheby", (3, 16)), ("7pt-gsrb", (4, 8)), ("7pt-cheby-helm", (1, 32)),
-                                          ("7pt-cheby", (2, 2)), ("7pt-cheby-helm", (3, 6)), ("7pt-cheby", (1, 24))])
+                                          ("7pt-cheby", (2, 2)), ("7pt-cheby-helm", (3, 6)), ("7pt-cheby", (1, 24)),
+                                          ("7pt-cheby-helm", (2, 64)), ("7ptcc-cheby", (1, 64)), ("7pt-gsrb", (3, 64))])      # boxes of 64^3: the LDS-staged tile kernel carries the form
 def test_residual_restriction_zero_as_one_launch_on_small_boxes(hip, oracle, variant, geom):
     """MGVCycle's down leg (mg.c:1150-1153) on the launch-bound levels (boxes of an even side <= 32): residual + restriction + zero_vector in ONE launch of
     stencil7_kernel<.., RR> -- the 2 x 2 patch of residuals gathered from the neighbouring lanes' registers, summed in restriction.c:54-57's order.  Both forms:
