@@ -158,7 +158,15 @@ __global__ __launch_bounds__(256) void absmax_kernel(const hpgmg_hip_level L, in
 __global__ __launch_bounds__(256) void final_max_kernel(const double *partials, int n, double init, ResultSlot *result, unsigned long long seq) {
   __shared__ double smem[4];
   double m = init;
-  for (int t = threadIdx.x; t < n; t += 256) m = (partials[t] > m) ? partials[t] : m;
+  // four loads in flight per lane: the chain of one load per iteration made 8192 partials a 10 us launch (a maximum is exact under any order)
+  double m1 = init, m2 = init, m3 = init;
+  int t = threadIdx.x;
+  for (; t + 768 < n; t += 1024) {
+    const double a0 = partials[t], a1 = partials[t + 256], a2 = partials[t + 512], a3 = partials[t + 768];
+    m = (a0 > m) ? a0 : m; m1 = (a1 > m1) ? a1 : m1; m2 = (a2 > m2) ? a2 : m2; m3 = (a3 > m3) ? a3 : m3;
+  }
+  for (; t < n; t += 256) m = (partials[t] > m) ? partials[t] : m;
+  m = (m1 > m) ? m1 : m; m2 = (m3 > m2) ? m3 : m2; m = (m2 > m) ? m2 : m;
   m = wave_max(m);
   if (threadIdx.x % 64 == 0) smem[threadIdx.x / 64] = m;
   __syncthreads();
