@@ -85,12 +85,12 @@ def run(lib, levels, seq):
 
 
 @pytest.mark.parametrize("variant,geom", [("7pt-cheby-helm", (2, 16)), ("7pt-gsrb", (2, 16)), ("fv4-gsrb", (1, 16)), ("27pt-gsrb", (2, 8)), ("fv2-cheby", (1, 16)),
-                                          ("7pt-cheby", (2, 128))])
+                                          ("7pt-cheby", (2, 128)), ("7pt-cheby-helm", (2, 64))])      # (2, 64): the tile-kernel forms (interpolation fold, one-launch down leg) and the plain ones below
 def test_random_operator_sequences_with_and_without_the_queue(hip, variant, geom):
     lib = hip.lib
     lib.hpgmg_set_lazy.argtypes = [ctypes.c_int]
     hip.configure(**VARIANTS[variant])
-    big = geom[1] >= 128
+    big, mid = geom[1] >= 128, geom[1] == 64
     sa, sb = hip.solver(*geom), hip.solver(*geom)
     try:
         nlev = sa.num_levels()
@@ -101,7 +101,7 @@ def test_random_operator_sequences_with_and_without_the_queue(hip, variant, geom
                 la[l].write_all(vid, data); lb[l].write_all(vid, data)
         # HPGMG_FUZZ_SEED / HPGMG_FUZZ_SEQUENCES: longer hunts with other seeds (the suite runs seed 0, 200 sequences)
         rng = np.random.default_rng(20260 + len(variant) + 7919 * int(os.environ.get("HPGMG_FUZZ_SEED", "0")))
-        for n in range(12 if big else int(os.environ.get("HPGMG_FUZZ_SEQUENCES", "200"))):
+        for n in range(12 if big else (int(os.environ.get("HPGMG_FUZZ_SEQUENCES", "200")) // (5 if mid else 1))):
             seq = random_sequence(rng, nlev)
             lib.hpgmg_set_lazy(1)
             va = run(lib, la, seq)
