@@ -166,24 +166,47 @@ int hpgmg_norm_scale_restrict_fused(level_type *L, int F_id, int R_id, level_typ
 /* the same, the norm collected later by hpgmg_norm_deferred_fetch(L): FMGSolve needs norm(F) only for the convergence check at its end (mg.c:1262,1323), so the
  * host does not wait for this pass and keeps the stream full behind it */
 static level_type *deferred_norm_level = NULL;
+static double deferred_host_value = 0.0;
+static int deferred_on_device = 0;
 int hpgmg_norm_scale_restrict_fused_deferred(level_type *L, int F_id, int R_id, level_type *Lc) {
   communicator_type *S = &L->restriction[RESTRICT_CELL], *R = &Lc->restriction[RESTRICT_CELL];
-  if (!fused_residual_on() || !hp_switch(SW_DEFER_NORM) || !L->active || !Lc->active || L->num_my_boxes < 1 || Lc->num_my_boxes < 1 || F_id == R_id) return 0;
-  if (S->num_sends || R->num_recvs || S->num_blocks[0] || R->num_blocks[2] || S->num_blocks[1] < 1) return 0;
-  backend_t *Bc = hp_backend_of(Lc), *B = hp_backend_of(L);
-  if ((L->box_dim & 1) || !(B->dev.flags & 1) || (L->box_jStride & 1) || (L->box_kStride & 1) || (L->box_volume & 1) || L->box_dim < 16) return 0;
-  if (!restrict_map_of(L, B)) return 0;
-  { TICK(L, blas1, "norm(F) + R = F + restriction (fused, norm deferred)");
+  const hpgmg_transport *T = hpgmg_get_transport();
+  const int many = (T && T->size > 1);
+  if (!fused_residual_on() || !hp_switch(SW_DEFER_NORM) || !L->active || !Lc->active || F_id == R_id) return 0;
+  /* Deferring moves a rank's reduction from the start of the solve to its end, so EVERY rank must take the same decision (a rank that reduced at the
+   * start would pair its collective with another rank's at the end).  With several ranks the decision is therefore taken from what every rank knows:
+   * the same box grid with the same owner for every box on both levels -- then the restriction is local on every rank. */
+  if (many) {
+    const int nb = L->boxes_in.i * L->boxes_in.j * L->boxes_in.k;
+    int q;
+    if (Lc->boxes_in.i != L->boxes_in.i || Lc->boxes_in.j != L->boxes_in.j || Lc->boxes_in.k != L->boxes_in.k) return 0;
+    for (q = 0; q < nb; q++) if (L->rank_of_box[q] != Lc->rank_of_box[q]) return 0;
+  }
+  /* what THIS rank's one-pass kernel needs; a rank of a several-rank job that lacks it still defers: it issues the three operators and keeps its maximum */
+  int local_ok = (L->num_my_boxes >= 1 && Lc->num_my_boxes >= 1 && !S->num_sends && !R->num_recvs && !S->num_blocks[0] && !R->num_blocks[2] && S->num_blocks[1] >= 1);
+  backend_t *Bc = Lc->num_my_boxes >= 1 ? hp_backend_of(Lc) : NULL, *B = L->num_my_boxes >= 1 ? hp_backend_of(L) : NULL;
+  if (local_ok && ((L->box_dim & 1) || !(B->dev.flags & 1) || (L->box_jStride & 1) || (L->box_kStride & 1) || (L->box_volume & 1) || L->box_dim < 16 || !restrict_map_of(L, B))) local_ok = 0;
+  if (!local_ok && !many) return 0;
+  if (local_ok) {
+    TICK(L, blas1, "norm(F) + R = F + restriction (fused, norm deferred)");
     HIP_OK(hpgmg_hip_norm_copy_restrict_deferred(&B->dev, F_id, R_id, &Bc->dev, R_id, B->d_restrict_map));
-    TOCK(); }
+    TOCK();
+    deferred_on_device = 1;
+  } else {
+    double v = 0.0;
+    if (B) { TICK(L, blas1, "norm(F), this rank's part (reduction deferred)"); HIP_OK(hpgmg_hip_norm_max(&B->dev, F_id, &v)); TOCK(); }
+    hp_do_scale_vector(L, R_id, 1.0, F_id);
+    hp_do_restriction(Lc, R_id, L, R_id, RESTRICT_CELL);
+    deferred_host_value = v; deferred_on_device = 0;
+  }
   deferred_norm_level = L;
   return 1;
 }
 double hpgmg_norm_deferred_fetch(level_type *L) {
-  double v = 0.0;
+  double v = deferred_host_value;
   if (deferred_norm_level != L) { fprintf(stderr, "hpgmg: no deferred norm is pending on this level\n"); abort(); }
   deferred_norm_level = NULL;
-  HIP_OK(hpgmg_hip_deferred_fetch(&v));
+  if (deferred_on_device) HIP_OK(hpgmg_hip_deferred_fetch(&v));
   return hp_allreduce_scalar(L, v, HPGMG_REDUCE_MAX);
 }
 /* residual(L, res, x, rhs) ; norm(L, res) -- the convergence check of MGSolve / FMGSolve (mg.c:1321-1323) -- in one pass: the residual is
