@@ -319,6 +319,12 @@ void random_vector(level_type *L, int id) { BLAS1(hpgmg_hip_random(&hp_backend_o
 
 double hp_allreduce_scalar(level_type *L, double v, int op) {
   const hpgmg_transport *T = hpgmg_get_transport();
+  /* every scalar the host waits for passes here: the place to learn that a launch of bricks (kernels/brick_visit.hip) did not get all its workgroups running */
+  if (hpgmg_hip_brick_visit_error()) {
+    fprintf(stderr, "hpgmg: a face exchange inside a brick launch gave up after 2 s -- not all its workgroups were running (other processes' launches of this kind on the same GPU?).  "
+                    "Results since then are void.  HPGMG_BRICK_VISITS=0 runs these levels launch by launch.\n");
+    abort();
+  }
   if (T && T->size > 1) {
     hpgmg_level_ext *X = hpgmg_level_ext_get(L);
     if (X->num_active_ranks > 1) { const double t0 = hp_now(); T->allreduce(T->ctx, &v, 1, op, X->active_ranks, X->num_active_ranks); L->timers.collectives += hp_now() - t0; }   /* host-synchronous by nature: host clock in every mode */

@@ -104,13 +104,75 @@ static int small_vtail_fused(level_type **levels, int n, int e_id, int R_id, dou
 }
 void hpgmg_set_fused_tail(int on) { hp_switch_set(SW_FUSED_TAIL, on ? 1 : 0); }      /* tests: 0 = every operator of the small levels as its own launch(es) */
 void hpgmg_set_fused_bottom(int on) { hp_switch_set(SW_FUSED_BOTTOM, on ? 1 : 0); }  /* tests: 0 = the bottom solve driven from the host (host/solvers.c BiCGStab through the operators) */
+void hpgmg_set_brick_visits(int on) { hp_switch_set(SW_BRICK_VISITS, on ? 1 : 0); if (on == 8 || on == 16) hp_switch_set(SW_BRICK_SIZE, on); }      /* 0 off, 1 on, 8 / 16: on with bricks of that side */
+long long hpgmg_brick_visits(void) { return hpgmg_hip_brick_visits(); }
+/* what the kernels that address cells by global coordinate need of a level (tail.hip, brick_visit.hip): a cubic Dirichlet domain whose boxes are all
+ * here, all faces local, local box b at lexicographic position b */
+static int dense_level_ok(level_type *L) {
+  backend_t *B = hp_backend_of(L);
+  const int nb = L->dim.i / L->box_dim;
+  int bx;
+  if (!L->active || L->num_my_boxes < 1 || !B->all_faces_local) return 0;
+  if (L->boundary_condition.type != BC_DIRICHLET || L->dim.i != L->dim.j || L->dim.i != L->dim.k) return 0;
+  if (L->num_my_boxes != nb * nb * nb) return 0;
+  for (bx = 0; bx < L->num_my_boxes; bx++) {
+    const box_type *X = &L->my_boxes[bx];
+    if (X->low.i != (bx % nb) * L->box_dim || X->low.j != ((bx / nb) % nb) * L->box_dim || X->low.k != (bx / (nb * nb)) * L->box_dim) return 0;
+  }
+  return 1;
+}
+/* How many leading levels of the chain are visited as bricks of 8^3 / 16^3 cells, one launch per visit (kernels/brick_visit.hip): the levels of 64^3 / 32^3
+ * cells above the single-workgroup tail.  0: none. */
+static int brick_prefix(level_type **levels, int n, const hpgmg_config *cfg) {
+  const int sweeps = hpgmg_smooth_sweeps();
+  int k = 0;
+  if (!hp_switch(SW_BRICK_VISITS) || !hp_switch(SW_FUSED_TAIL) || hp_switch(SW_GRAPH) || !hp_ghost_free_mode() || cfg->op != HPGMG_OP_7PT) return 0;
+  if (sweeps < 1 || sweeps > hpgmg_hip_brick_visit_max_sweeps() || (sweeps & 1)) return 0;
+  while (k + 1 < n) {
+    level_type *L = levels[k];
+    const int fits_tail = ((long long)L->dim.i * L->dim.j * L->dim.k <= hpgmg_hip_tail_max_cells());
+    if (L->dim.i < (int)hp_switch(SW_BRICK_MIN_DIM) && fits_tail) break;
+    if (!dense_level_ok(L) || !dense_level_ok(levels[k + 1]) || 2 * levels[k + 1]->dim.i != L->dim.i) return 0;
+    if (!hpgmg_hip_brick_visit_supported(&hp_backend_of(L)->dev, (int)hp_switch(SW_BRICK_SIZE))) { if (fits_tail) break; return 0; }
+    if (L->dominant_eigenvalue_of_DinvA <= 0.0 && cfg->smoother == HPGMG_SMOOTH_CHEBY) return 0;
+    k++;
+  }
+  return k;
+}
+/* `top`: the level whose timers take the launch -- the one whose V-cycle this is, like the tail below it (mg.c books the whole fused cycle on that level's Total) */
+static void brick_visit(level_type *top, level_type *L, level_type *C, const hpgmg_config *cfg, int e_id, int R_id, double a, double b, int leg) {
+  double c1[8], c2[8];
+  const int sweeps = hpgmg_smooth_sweeps();
+  int s;
+  for (s = 0; s < 8; s++) c1[s] = c2[s] = 0.0;
+  if (cfg->smoother == HPGMG_SMOOTH_CHEBY) cheby_coefficients(L, sweeps, c1, c2);
+  TICK(top, smooth, leg == 0 ? "level visit, down (bricks: smooth + residual + restriction in one launch)" : "level visit, up (bricks: interpolation + smooth in one launch)");
+  HIP_OK(hpgmg_hip_brick_visit(&hp_backend_of(L)->dev, &hp_backend_of(C)->dev, 1.0 / (L->h * L->h), c1, c2, sweeps, hp_variant(), cfg->smoother, e_id, R_id, a, b, leg, (int)hp_switch(SW_BRICK_SIZE)));
+  TOCK();
+}
+static level_type *tail_books_on = NULL;      /* the level whose timers take the tail launch when bricks were visited above it (else its own first level) */
+/* leg 16 + x: would leg x be taken?  (nothing is launched) */
 int hp_vcycle_legs_fused(level_type **levels, int n, int e_id, int R_id, double a, double b, int leg) {
   hpgmg_config cfg;
   const hpgmg_hip_level *dev[8];
-  int l, s;
+  int l, s, probe = 0;
   double h2inv[8], c1[64], c2[64];
   const int enabled = (int)hp_switch(SW_FUSED_TAIL), bottom_enabled = (int)hp_switch(SW_FUSED_BOTTOM);
   hpgmg_get_config(&cfg);
+  if (leg >= 16) { probe = 1; leg -= 16; }
+  if (leg <= 2 && !probe) {
+    /* launch-bound levels above the tail: one launch per level visit, then the tail, then one launch per visit on the way up */
+    const int k = brick_prefix(levels, n, &cfg);
+    if (k > 0 && hp_vcycle_legs_fused(levels + k, n - k, e_id, R_id, a, b, 16 + leg)) {
+      if (leg != 1) for (l = 0; l < k; l++) brick_visit(levels[0], levels[l], levels[l + 1], &cfg, e_id, R_id, a, b, 0);
+      tail_books_on = levels[0];
+      const int taken = hp_vcycle_legs_fused(levels + k, n - k, e_id, R_id, a, b, leg);
+      tail_books_on = NULL;
+      if (!taken) { fprintf(stderr, "hpgmg: the V-cycle tail was refused after being accepted\n"); abort(); }
+      if (leg != 0) for (l = k - 1; l >= 0; l--) brick_visit(levels[0], levels[l], levels[l + 1], &cfg, e_id, R_id, a, b, 1);
+      return 1;
+    }
+  }
   /* A correction or right-hand side that lives among the work vectors of the host-driven Krylov solver (ids >= VECTORS_RESERVED: MGPCG's z,
    * mg.c:1530) ALIASES them on the bottom level -- z is BiCGStab's p there (solvers/bicgstab.c:14-19) -- and the reference's numbers include that.
    * The fused bottom solve keeps the solver's vectors to itself, so the forms that contain it step aside: the legs run without it and the host-driven
@@ -165,8 +227,8 @@ int hp_vcycle_legs_fused(level_type **levels, int n, int e_id, int R_id, double 
     dev[l] = &B->dev;
     h2inv[l] = 1.0 / (L->h * L->h);
   }
-  if (leg == 5) return 1;
-  TICK(levels[0], smooth, leg == 3 ? "bottom solve (device BiCGStab)" : (leg == 4 ? "fused F-cycle tail" : "fused V-cycle tail"));
+  if (leg == 5 || probe) return 1;
+  TICK(tail_books_on ? tail_books_on : levels[0], smooth, leg == 3 ? "bottom solve (device BiCGStab)" : (leg == 4 ? "fused F-cycle tail" : "fused V-cycle tail"));
   HIP_OK(hpgmg_hip_vcycle_tail(n, dev, h2inv, c1, c2, sweeps, hp_variant(), cfg.smoother, e_id, R_id, a, b, leg,
                                hpgmg_vectors_reserved(), MG_DEFAULT_BOTTOM_NORM, with_bottom ? hp_backend_of(levels[n - 1])->krylov_pinned : NULL));
   TOCK();

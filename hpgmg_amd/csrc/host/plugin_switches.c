@@ -31,6 +31,9 @@ static struct { const char *env; int kind; long long dflt; const char *what; lon
   [SW_FV4_NO_EXACT_RB]   = { "HPGMG_TUNE_FV4_NO_EXACT_RB", K_OFF, 0, "fv4: the exported smooth() as six half sweeps (no red + black passes)" },
   [SW_GRAPH]             = { "HPGMG_GRAPH", K_OFF, 0, "capture / replay the launch-bound segments as hipGraphs (measured slower with a full stream)" },
   [SW_DEFER_NORM]        = { "HPGMG_DEFER_NORM", K_ON, 1, "FMGSolve: norm(F) of the opening pass is collected at the end, where it is used, instead of waited for at the start" },
+  [SW_BRICK_VISITS]     = { "HPGMG_BRICK_VISITS", K_ON, 1, "7-pt: a visit of the 32^3 / 64^3 level of a V-cycle as one launch of 16^3 bricks that trade faces inside the launch; 0 when other processes run such launches on the same GPU" },
+  [SW_BRICK_SIZE]       = { "HPGMG_TUNE_BRICK", K_INT, 8, "side of those bricks: 8 (512 lanes, one cell each) or 16 (1024 lanes, four cells each)" },
+  [SW_BRICK_MIN_DIM]    = { "HPGMG_TUNE_BRICK_MIN", K_INT, 16, "smallest level (cells per side) visited as bricks; the levels below it are the single-workgroup tail's" },
   [SW_SMOOTHER_PRECISION]= { "HPGMG_SMOOTHER_PRECISION", K_INT, 64, "32: fp32 coefficient streams in the Chebyshev sweep pairs (BASELINE config 5, tolerance-gated); 64: bit-exact" },
 };
 

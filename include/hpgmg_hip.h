@@ -369,6 +369,20 @@ int hpgmg_hip_vcycle_tail(int n, const hpgmg_hip_level *const *levels, const dou
                           int variant, int smoother, int e_id, int R_id, double a, double b, int leg,
                           int krylov_base, double bottom_norm, int *krylov_iterations);
 
+/* ---- brick_visit.hip: one visit of a launch-bound level ABOVE the tail's reach (32^3, 64^3 cells) as ONE launch: the level as bricks of 8^3 or
+ *      16^3 cells, a workgroup each, iterate in LDS, coefficients in registers; between sweeps the bricks trade faces through memory inside the
+ *      launch ({value, sequence number} records, written through and polled: one memory hop, 1.6 us).  Replaces the 5 + 4 launches of
+ *      mg.c:1147-1153 (smooth, residual, restriction, zero_vector) and mg.c:1160-1161 (interpolation_vcycle, smooth).  Every face neighbour local,
+ *      Dirichlet, cubic domain, boxes in lexicographic order (as for the tail).  Not capturable in a hipGraph. ---- */
+int hpgmg_hip_brick_visit_supported(const hpgmg_hip_level *L, int brick);      /* 1: dim_i^3 cells = 2^3 or 4^3 bricks of 16^3 cells (brick = 16), 2^3 .. 8^3 bricks of 8^3 (brick = 8) */
+int hpgmg_hip_brick_visit_max_sweeps(void);
+/* leg 0: smooth, residual -> VECTOR_TEMP, restriction(C.R_id <- TEMP), zero_vector(C.e_id);  leg 1: e += P C.e (piecewise constant), smooth.
+ * c1 / c2: the Chebyshev coefficients of L's `sweeps` sweeps (ignored by the other smoothers). */
+int hpgmg_hip_brick_visit(const hpgmg_hip_level *L, const hpgmg_hip_level *C, double h2inv, const double *c1, const double *c2, int sweeps,
+                          int variant, int smoother, int e_id, int R_id, double a, double b, int leg, int brick);
+long long hpgmg_hip_brick_visits(void);      /* launches so far (tests) */
+int hpgmg_hip_brick_visit_error(void);       /* 1: a face poll of an earlier visit gave up after 2 s (a workgroup of the launch was not running): results are void */
+
 /* ---- hipGraph segments (graph.hip): capture/replay of the launch-bound small-level part of a cycle.
  *      begin(key): first use of a key runs eagerly, second is captured, later ones are replayed
  *      (launchers return immediately while a replay segment is open; end() launches the graph).

@@ -308,6 +308,89 @@ def test_residual_restriction_zero_as_one_launch_on_small_boxes(hip, oracle, var
             be.lib.hpgmg_mg_destroy(m); f.destroy()
 
 
+@pytest.mark.parametrize("variant,geom", [("7pt-cheby-helm", (2, 32)), ("7pt-cheby-helm", (1, 64)), ("7pt-cheby", (4, 16)), ("7ptcc-cheby", (2, 32)), ("7pt-gsrb", (2, 32)),
+                                          ("7pt-jacobi", (1, 64)), ("7pt-cheby-helm", (2, 16)), ("7pt-gsrb", (1, 32)), ("7pt-cheby", (4, 8)), ("7ptcc-cheby", (8, 8)),
+                                          ("7pt-jacobi", (2, 16)), ("7pt-gsrb", (8, 4)), ("7pt-cheby-helm", (2, 8)), ("7pt-gsrb", (1, 16)), ("7ptcc-cheby", (4, 4))])
+@pytest.mark.parametrize("brick", [8, 16])
+def test_level_visits_as_one_launch_of_bricks(hip, oracle, variant, geom, brick):
+    """kernels/brick_visit.hip: MGVCycle (mg.c:1133-1166) from a level of 64^3 or 32^3 cells -- every visit of the levels above the single-workgroup tail
+    is ONE launch (bricks of 16^3 cells, a workgroup each, trading faces inside the launch).  Every vector of every level must be, byte for byte, what the
+    oracle's operator-by-operator cycle leaves: the iterate, the right-hand sides restricted on the way down, VECTOR_TEMP (the residual on the way down,
+    the smoother's partner on the way up) and the zeroed corrections' ghost cells."""
+    from hpgmg_testlib import Level
+    set_mode(hip, 1)
+    pairs = []
+    for be in (hip, oracle):
+        be.configure(**VARIANTS[variant])
+        fine = be.level(*geom)
+        for vid in range(fine.num_vectors):
+            d = seeded_field(fine, 2100 + vid)
+            if vid >= H.VECTOR_DINV:
+                d = np.abs(d) + 0.5
+            fine.write_all(vid, d)
+        for vid in range(H.VECTOR_DINV, fine.num_vectors):
+            be.lib.exchange_boundary(fine.ptr, vid, H.STENCIL_SHAPE_BOX)
+        a, b = (1.0, 1.0) if "helm" in variant else (0.0, 1.0)
+        mg = be.lib.hpgmg_mg_create(fine.ptr, a, b, 1)
+        be.lib.rebuild_operator(fine.ptr, None, a, b)          # D^-1 and the eigenvalue bound of the top level
+        pairs.append((be, fine, mg, a, b))
+    try:
+        (bh, fh, mh, a, b), (bo, fo, mo, _, _) = pairs
+        L = hip.lib
+        L.hpgmg_brick_visits.restype = ctypes.c_longlong
+        L.hpgmg_set_brick_visits.argtypes = [ctypes.c_int]
+        L.hpgmg_set_brick_visits(brick)
+        for be in (bh, bo):
+            be.lib.MGVCycle.restype = None
+            be.lib.MGVCycle.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_int]
+            be.lib.hpgmg_mg_num_levels.restype = ctypes.c_int
+        n = bh.lib.hpgmg_mg_num_levels(mh)
+        assert n == bo.lib.hpgmg_mg_num_levels(mo)
+        lv = lambda be, m, l: Level(be, be.lib.hpgmg_mg_level(m, l))
+        # every level's correction, right-hand side and VECTOR_TEMP start as the same junk on both sides (the cycle overwrites all but the top level's)
+        for l in range(n):
+            for be, m in ((bh, mh), (bo, mo)):
+                x = lv(be, m, l)
+                for vid, seed in ((H.VECTOR_U, 31), (H.VECTOR_F, 32), (H.VECTOR_TEMP, 33)):
+                    x.write_all(vid, seeded_field(x, 2200 + 10 * l + seed))
+        top = geom[0] * geom[1]
+        side_ok = lambda dim: dim >= 16 and 2 <= dim // brick <= (4 if brick == 16 else 8)      # what one launch of bricks covers: 16^3 (bricks of 8^3 only) .. 64^3 cells
+        want = 2 * sum(1 for l in range(n) if side_ok(top >> l))
+        before = L.hpgmg_brick_visits()
+        bh.lib.MGVCycle(mh, H.VECTOR_U, H.VECTOR_F, a, b, 0)
+        bh.lib.hpgmg_operators_flush()
+        assert L.hpgmg_brick_visits() == before + want, "the launch-bound levels were not visited as bricks"
+        bo.lib.MGVCycle(mo, H.VECTOR_U, H.VECTOR_F, a, b, 0)
+        for l in range(n):
+            xh, xo = lv(bh, mh, l), lv(bo, mo, l)
+            same(xh, xo, [H.VECTOR_U, H.VECTOR_F, H.VECTOR_TEMP], interior_only=True)
+            if l > 0 and side_ok(top >> (l - 1)):      # zero_vector by the brick launch of the level above: the whole padded boxes
+                w = xh.box_dim + 2 * xh.ghosts
+                cells = lambda x: x[:, : w * xh.kStride].reshape(-1, w, xh.kStride)[:, :, : w * xh.jStride].reshape(-1, w, w, xh.jStride)[:, :, :, :w]
+                g, d = xh.ghosts, xh.box_dim
+                ah = cells(xh.read_all(H.VECTOR_U)).copy()      # (the oracle's exchange + boundary launches refill them afterwards; here nothing writes them again)
+                ah[:, g:g + d, g:g + d, g:g + d] = 0
+                assert not ah.any(), f"level {l}: ghost cells of the zeroed correction"
+        # the same cycle launch by launch gives the same bytes (and launches no bricks)
+        L.hpgmg_set_brick_visits(0)
+        try:
+            for l in range(n):
+                x = lv(bh, mh, l)
+                for vid, seed in ((H.VECTOR_U, 31), (H.VECTOR_F, 32), (H.VECTOR_TEMP, 33)):
+                    x.write_all(vid, seeded_field(x, 2200 + 10 * l + seed))
+            before = L.hpgmg_brick_visits()
+            bh.lib.MGVCycle(mh, H.VECTOR_U, H.VECTOR_F, a, b, 0)
+            bh.lib.hpgmg_operators_flush()
+            assert L.hpgmg_brick_visits() == before
+            for l in range(n):      # (VECTOR_TEMP is scratch to the in-cycle forms of this path on the way down)
+                same(lv(bh, mh, l), lv(bo, mo, l), [H.VECTOR_U, H.VECTOR_F], interior_only=True)
+        finally:
+            L.hpgmg_set_brick_visits(8)
+    finally:
+        for be, f, m, _, _ in pairs:
+            be.lib.hpgmg_mg_destroy(m); f.destroy()
+
+
 @pytest.mark.parametrize("variant,geom", [("7pt-cheby-helm", (2, 128)), ("7pt-gsrb", (1, 128)), ("7ptcc-cheby", (1, 256)),
                                           ("27pt-gsrb", (2, 64)), ("fv4-gsrb", (2, 64)), ("fv4-gsrb", (3, 32)), ("27pt-cheby", (1, 128))])
 def test_fused_residual_forms(hip, oracle, variant, geom):
