@@ -659,6 +659,11 @@ void FMGSolve(mg_type *G, int onLevel, int u_id, int F_id, double a, double b, d
     if (l == onLevel && u_to_zero) {
       if (!hpgmg_zero_interpolation_fcycle_fused(G->levels[l], e_id, G->levels[l + 1], e_id)) { zero_vector(G->levels[l], e_id); interpolation_fcycle(G->levels[l], e_id, 0.0, G->levels[l + 1], e_id); }
       u_to_zero = 0;
+    } else if (is_small(G, l) && hpgmg_vcycle_legs_fused(&G->levels[l], G->num_levels - l, e_id, R_id, a, b, 6)) {      /* the plugin ran this step whole: interpolation + V-cycle */
+      hpgmg_tick_end(t);
+      G->levels[l]->vcycles_from_this_level++;
+      seg_close();
+      continue;
     } else interpolation_fcycle(G->levels[l], e_id, 0.0, G->levels[l + 1], e_id);
     hpgmg_tick_end(t);
     G->levels[l]->vcycles_from_this_level++;

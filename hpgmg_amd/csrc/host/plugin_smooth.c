@@ -140,14 +140,15 @@ static int brick_prefix(level_type **levels, int n, const hpgmg_config *cfg) {
   return k;
 }
 /* `top`: the level whose timers take the launch -- the one whose V-cycle this is, like the tail below it (mg.c books the whole fused cycle on that level's Total) */
-static void brick_visit(level_type *top, level_type *L, level_type *C, const hpgmg_config *cfg, int e_id, int R_id, double a, double b, int leg) {
+static void brick_visit(level_type *top, level_type *L, level_type *C, const hpgmg_config *cfg, int e_id, int R_id, double a, double b, int leg, int e_zero, int coarse_zero) {
   double c1[8], c2[8];
   const int sweeps = hpgmg_smooth_sweeps();
   int s;
   for (s = 0; s < 8; s++) c1[s] = c2[s] = 0.0;
   if (cfg->smoother == HPGMG_SMOOTH_CHEBY) cheby_coefficients(L, sweeps, c1, c2);
-  TICK(top, smooth, leg == 0 ? "level visit, down (bricks: smooth + residual + restriction in one launch)" : "level visit, up (bricks: interpolation + smooth in one launch)");
-  HIP_OK(hpgmg_hip_brick_visit(&hp_backend_of(L)->dev, &hp_backend_of(C)->dev, 1.0 / (L->h * L->h), c1, c2, sweeps, hp_variant(), cfg->smoother, e_id, R_id, a, b, leg, (int)hp_switch(SW_BRICK_SIZE)));
+  TICK(top, smooth, leg == 1 ? "level visit, up (bricks: interpolation + smooth in one launch)" :
+                    (leg == 0 ? "level visit, down (bricks: smooth + residual + restriction in one launch)" : "interpolation_fcycle + level visit, down (bricks, one launch)"));
+  HIP_OK(hpgmg_hip_brick_visit(&hp_backend_of(L)->dev, &hp_backend_of(C)->dev, 1.0 / (L->h * L->h), c1, c2, sweeps, hp_variant(), cfg->smoother, e_id, R_id, a, b, leg, (int)hp_switch(SW_BRICK_SIZE), e_zero, coarse_zero));
   TOCK();
 }
 static level_type *tail_books_on = NULL;      /* the level whose timers take the tail launch when bricks were visited above it (else its own first level) */
@@ -160,19 +161,26 @@ int hp_vcycle_legs_fused(level_type **levels, int n, int e_id, int R_id, double 
   const int enabled = (int)hp_switch(SW_FUSED_TAIL), bottom_enabled = (int)hp_switch(SW_FUSED_BOTTOM);
   hpgmg_get_config(&cfg);
   if (leg >= 16) { probe = 1; leg -= 16; }
-  if (leg <= 2 && !probe) {
-    /* launch-bound levels above the tail: one launch per level visit, then the tail, then one launch per visit on the way up */
+  if ((leg <= 2 || leg == 6) && !probe) {
+    /* launch-bound levels above the tail: one launch per level visit, then the tail, then one launch per visit on the way up.  leg 6: the step of
+     * FMGSolve's climb (mg.c:1289-1293): interpolation_fcycle(levels[0] <- levels[1]) rides in the first launch of the V-cycle that follows it --
+     * every brick of that launch reads levels[1]'s correction, so its zero_vector is left to the launch that visits levels[1] (a brick level too). */
+    const int fstep = (leg == 6), vleg = fstep ? 2 : leg;
+    if (fstep && !hp_switch(SW_BRICK_FSTEP)) return 0;
     const int k = brick_prefix(levels, n, &cfg);
-    if (k > 0 && hp_vcycle_legs_fused(levels + k, n - k, e_id, R_id, a, b, 16 + leg)) {
-      if (leg != 1) for (l = 0; l < k; l++) brick_visit(levels[0], levels[l], levels[l + 1], &cfg, e_id, R_id, a, b, 0);
+    if (k > (fstep ? 1 : 0) && hp_vcycle_legs_fused(levels + k, n - k, e_id, R_id, a, b, 16 + vleg)) {
+      /* zero_vector of a brick level below the first: by the launch that visits it (which then does not read the vector either) */
+      if (vleg != 1) for (l = 0; l < k; l++) brick_visit(levels[0], levels[l], levels[l + 1], &cfg, e_id, R_id, a, b, (fstep && l == 0) ? 2 : 0, l > 0, l == k - 1);
       tail_books_on = levels[0];
-      const int taken = hp_vcycle_legs_fused(levels + k, n - k, e_id, R_id, a, b, leg);
+      const int taken = hp_vcycle_legs_fused(levels + k, n - k, e_id, R_id, a, b, vleg);
       tail_books_on = NULL;
       if (!taken) { fprintf(stderr, "hpgmg: the V-cycle tail was refused after being accepted\n"); abort(); }
-      if (leg != 0) for (l = k - 1; l >= 0; l--) brick_visit(levels[0], levels[l], levels[l + 1], &cfg, e_id, R_id, a, b, 1);
+      if (vleg != 0) for (l = k - 1; l >= 0; l--) brick_visit(levels[0], levels[l], levels[l + 1], &cfg, e_id, R_id, a, b, 1, 0, 0);
       return 1;
     }
+    if (fstep) return 0;
   }
+  if (leg == 6) return 0;
   /* A correction or right-hand side that lives among the work vectors of the host-driven Krylov solver (ids >= VECTORS_RESERVED: MGPCG's z,
    * mg.c:1530) ALIASES them on the bottom level -- z is BiCGStab's p there (solvers/bicgstab.c:14-19) -- and the reference's numbers include that.
    * The fused bottom solve keeps the solver's vectors to itself, so the forms that contain it step aside: the legs run without it and the host-driven

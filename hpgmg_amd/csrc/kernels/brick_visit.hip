@@ -3,6 +3,8 @@
 // coefficients in registers (4 cells per lane) -- tail.hip's scheme, on more than one CU.
 //   leg 0 (down):  smooth; residual -> TEMP; restriction(coarse.R <- TEMP); zero_vector(coarse.e)
 //   leg 1 (up):    interpolation_vcycle (e += P coarse.e, piecewise constant); smooth
+//   leg 2:         interpolation_fcycle (e = 0.0 e + P1 coarse.e, piecewise linear, the coarse ghost cells of apply_BCs_p1 formed on the fly), then leg 0 -- the
+//                  step of FMGSolve (mg.c:1289-1293) that opens a V-cycle: its exchange + boundary + interpolation launches ride in the load of the visit
 // i.e. the 5 + 4 launches of ~5 us each the per-operator path issues for the visit (4 sweeps of 1.3 MB each are not what they cost: a launch
 // boundary and one memory round trip per sweep are).
 //
@@ -54,6 +56,9 @@ struct BrickArgs {
   double c1[kBrickMaxSweeps], c2[kBrickMaxSweeps];
   int sweeps, e_id, R_id;
   int side;                         // bricks per dimension
+  int e_zero;                       // legs 0: the correction counts as +0.0 (zero_vector came before, mg.c:1153): it is not read, and the cells of its padded boxes that
+                                    // no brick stores at the end (ghost zone, padding) are cleared HERE -- the launch that visited the finer level left it alone
+  int coarse_zero;                  // legs 0, 2: zero_vector(C.e) at the end (0: the launch that visits C does it, see e_zero)
   FaceCell *faces;                  // [2][workgroup][6][B^2]
   u64 epoch;                        // launch number x 64: the first sequence number of this launch is epoch + 1
   unsigned *error;                  // pinned host word: set when a poll gave up
@@ -95,6 +100,7 @@ __global__ __launch_bounds__(BrickGeom<B>::Threads) void brick_visit_kernel(cons
   auto face_cell = [](int f, int u, int v, int depth, int &li, int &lj, int &lk) { BG::face_cell(f, u, v, depth, li, lj, lk); };
   constexpr bool kVC = (V != HPGMG_HIP_7PT_CC);
   constexpr bool kHelm = (V == HPGMG_HIP_7PT_VC_HELMHOLTZ);
+  constexpr bool kUp = (LEG == 1), kDown = (LEG != 1), kFInterp = (LEG == 2);
   extern __shared__ double brick_lds[];
   double *const sx = brick_lds, *const st = brick_lds + kHaloCells;
   const int t = (int)threadIdx.x, wg = (int)blockIdx.x, side = A.side, nwg = side * side * side;
@@ -107,6 +113,38 @@ __global__ __launch_bounds__(BrickGeom<B>::Threads) void brick_visit_kernel(cons
   const u64 t0 = __builtin_amdgcn_s_memrealtime();
   bool gave_up = false;
 
+  // what the first sweep reads at global cell (ci, cj, ck) of this level, given what is stored there
+  auto start_value = [&](double stored, int ci, int cj, int ck) -> double {
+    if (kUp) {               // interpolation_vcycle: e = 1.0*e + (coarse parent), interpolation_p0.c:43
+      const CellRef c = locate(GC, ci >> 1, cj >> 1, ck >> 1);
+      return 1.0 * stored + vec_origin(A.C, c.box, e_id)[c.ijk];
+    }
+    if (kFInterp) {          // interpolation_fcycle, piecewise linear (interpolation_p1.c:40-70): f = 0.0 f + 27/64 c + 9/64 (3 face neighbours) + 3/64 (3 edge
+      // neighbours) + 1/64 corner, an even fine cell leaning on the coarse neighbour behind it, an odd one on the one ahead.  A coarse ghost cell is -, +, -
+      // its mirror image for 1, 2, 3 directions leaving the domain (exchange_boundary + apply_BCs_p1, BOX shape, boundary_fd.c:35-38), formed here.
+      const int Dc = A.C.dim_i;
+      auto coarse = [&](int qi, int qj, int qk) -> double {
+        double sg = 1.0;
+        if (qi < 0) { qi = 0; sg = -sg; } else if (qi >= Dc) { qi = Dc - 1; sg = -sg; }
+        if (qj < 0) { qj = 0; sg = -sg; } else if (qj >= Dc) { qj = Dc - 1; sg = -sg; }
+        if (qk < 0) { qk = 0; sg = -sg; } else if (qk >= Dc) { qk = Dc - 1; sg = -sg; }
+        const CellRef r = locate(GC, qi, qj, qk);
+        return sg * vec_origin(A.C, r.box, e_id)[r.ijk];
+      };
+      const int qi = ci >> 1, qj = cj >> 1, qk = ck >> 1, di = (ci & 1) ? 1 : -1, dj = (cj & 1) ? 1 : -1, dk = (ck & 1) ? 1 : -1;
+      double v = 0.0 * stored;
+      v = v + 0.421875 * coarse(qi, qj, qk);
+      v = v + 0.140625 * coarse(qi, qj, qk + dk);
+      v = v + 0.140625 * coarse(qi, qj + dj, qk);
+      v = v + 0.046875 * coarse(qi, qj + dj, qk + dk);
+      v = v + 0.140625 * coarse(qi + di, qj, qk);
+      v = v + 0.046875 * coarse(qi + di, qj, qk + dk);
+      v = v + 0.046875 * coarse(qi + di, qj + dj, qk);
+      v = v + 0.015625 * coarse(qi + di, qj + dj, qk + dk);
+      return v;
+    }
+    return stored;
+  };
   // a lane's cells: (li, lj) fixed, lk = lk0 + kStepK m -- one LDS position and one global coordinate triple describe all of them
   const int li0 = t % kBrick, lj0 = (t / kBrick) % kBrick, lk0 = t / kFaceCells;
   const int pos0 = hpos(li0, lj0, lk0), gi = o_i + li0, gj = o_j + lj0, gk0 = o_k + lk0;
@@ -118,12 +156,7 @@ __global__ __launch_bounds__(BrickGeom<B>::Threads) void brick_visit_kernel(cons
     const int p = pos0 + m * kStepPos, gk = gk0 + m * kStepK;
     const CellRef w = locate(G, gi, gj, gk);
     const int box = w.box, ijk = w.ijk, jS = A.L.jStride, kS = A.L.kStride;
-    double e = vec_origin(A.L, box, e_id)[ijk];
-    if (LEG == 1) {          // interpolation_vcycle: e = 1.0*e + (coarse parent), interpolation_p0.c:43
-      const CellRef c = locate(GC, gi >> 1, gj >> 1, gk >> 1);
-      e = 1.0 * e + vec_origin(A.C, c.box, e_id)[c.ijk];
-    }
-    sx[p] = e;
+    sx[p] = start_value(A.e_zero ? 0.0 : vec_origin(A.L, box, e_id)[ijk], gi, gj, gk);
     st[p] = vec_origin(A.L, box, VECTOR_TEMP)[ijk];
     q[m].rhs = vec_origin(A.L, box, A.R_id)[ijk];
     q[m].dinv = vec_origin(A.L, box, VECTOR_DINV)[ijk];
@@ -143,9 +176,7 @@ __global__ __launch_bounds__(BrickGeom<B>::Threads) void brick_visit_kernel(cons
     const int hi = o_i + li, hj = o_j + lj, hk = o_k + lk;
     if (hi < 0 || hi >= D || hj < 0 || hj >= D || hk < 0 || hk >= D) continue;      // beyond the domain: the Dirichlet rule, never read
     const CellRef r = locate(G, hi, hj, hk);
-    double e = vec_origin(A.L, r.box, e_id)[r.ijk];
-    if (LEG == 1) { const CellRef c = locate(GC, hi >> 1, hj >> 1, hk >> 1); e = 1.0 * e + vec_origin(A.C, c.box, e_id)[c.ijk]; }
-    sx[hpos(li, lj, lk)] = e;
+    sx[hpos(li, lj, lk)] = start_value(A.e_zero ? 0.0 : vec_origin(A.L, r.box, e_id)[r.ijk], hi, hj, hk);
   }
   __syncthreads();
 
@@ -166,7 +197,7 @@ __global__ __launch_bounds__(BrickGeom<B>::Threads) void brick_visit_kernel(cons
       else                    { dst[p] = xc + (2.0 / 3.0) * q[m].dinv * (q[m].rhs - Ax); }
     }
     __syncthreads();
-    if (LEG == 0 || s + 1 < A.sweeps) {      // (the way down goes on to the residual of the result)
+    if (kDown || s + 1 < A.sweeps) {      // (the way down goes on to the residual of the result)
       // one exchange: the faces of dst go out, the neighbours' faces come into its halo
       const int par = exchange_n & 1;
       const u64 seq = epoch + 1 + (u64)exchange_n;
@@ -200,7 +231,7 @@ __global__ __launch_bounds__(BrickGeom<B>::Threads) void brick_visit_kernel(cons
     }
   }
 
-  if (LEG == 0) {                                     // residual -> TEMP (residual.c:42-48)
+  if (kDown) {                                        // residual -> TEMP (residual.c:42-48)
 #pragma unroll
     for (int m = 0; m < kBrickPerLane; m++) {
       const int p = pos0 + m * kStepPos;
@@ -219,7 +250,7 @@ __global__ __launch_bounds__(BrickGeom<B>::Threads) void brick_visit_kernel(cons
     vec_origin(A.L, w.box, VECTOR_TEMP)[w.ijk] = st[p];
   }
 
-  if (LEG == 0) {
+  if (kDown) {
     // restriction(coarse.R <- TEMP): 0.125 * sum of the 8 children in the reference's order (restriction.c:54-57); this brick's 8^3 coarse cells
     if (t < kBrickCells / 8) {
       constexpr int H = kBrick / 2;
@@ -231,11 +262,23 @@ __global__ __launch_bounds__(BrickGeom<B>::Threads) void brick_visit_kernel(cons
       vec_origin(A.C, c.box, A.R_id)[c.ijk] = v * 0.125;
     }
     // zero_vector(coarse.e): the whole padded boxes, ghosts included (misc.c:6-44), each workgroup a slice of the flat range
-    const int vol = A.C.volume, total = A.C.num_boxes * vol, per = (total + nwg - 1) / nwg;
+    if (A.coarse_zero) {
+      const int vol = A.C.volume, total = A.C.num_boxes * vol, per = (total + nwg - 1) / nwg;
+      const int lo = wg * per, hi = (lo + per < total) ? lo + per : total;
+      for (int z = lo + t; z < hi; z += kBrickThreads) {
+        const int box = z / vol;
+        (A.C.box_base[box] + (size_t)e_id * (size_t)vol)[z - box * vol] = 0.0;
+      }
+    }
+  }
+  if (A.e_zero) {
+    // the part of zero_vector(this level's e) the stores above do not overwrite: every cell of the padded boxes that is not an interior cell
+    const int vol = A.L.volume, total = A.L.num_boxes * vol, per = (total + nwg - 1) / nwg, jS = A.L.jStride, kS = A.L.kStride, g = A.L.ghosts, d = A.L.dim;
     const int lo = wg * per, hi = (lo + per < total) ? lo + per : total;
     for (int z = lo + t; z < hi; z += kBrickThreads) {
-      const int box = z / vol;
-      (A.C.box_base[box] + (size_t)e_id * (size_t)vol)[z - box * vol] = 0.0;
+      const int box = z / vol, off = z - box * vol, k = off / kS, r = off - k * kS, j = r / jS, i = r - j * jS;
+      if (i >= g && i < g + d && j >= g && j < g + d && k >= g && k < g + d) continue;
+      (A.L.box_base[box] + (size_t)e_id * (size_t)vol)[off] = 0.0;
     }
   }
   if (gave_up && A.error) __hip_atomic_store(A.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -256,8 +299,8 @@ static int brick_launch(const BrickArgs &A) {
 }
 template <int V, int SM>
 static int brick_launch_leg(const BrickArgs &A, int leg, int brick) {
-  if (brick == 16) return leg == 0 ? brick_launch<V, SM, 0, 16>(A) : brick_launch<V, SM, 1, 16>(A);
-  return leg == 0 ? brick_launch<V, SM, 0, 8>(A) : brick_launch<V, SM, 1, 8>(A);
+  if (brick == 16) return leg == 0 ? brick_launch<V, SM, 0, 16>(A) : (leg == 1 ? brick_launch<V, SM, 1, 16>(A) : brick_launch<V, SM, 2, 16>(A));
+  return leg == 0 ? brick_launch<V, SM, 0, 8>(A) : (leg == 1 ? brick_launch<V, SM, 1, 8>(A) : brick_launch<V, SM, 2, 8>(A));
 }
 
 }  // namespace hpgmg
@@ -276,11 +319,12 @@ int hpgmg_hip_brick_visit_supported(const hpgmg_hip_level *L, int brick) {
 // 0: fine; 1: a poll of an earlier visit gave up (the results since then are not to be used)
 int hpgmg_hip_brick_visit_error(void) { return (g_error && *(volatile unsigned *)g_error) ? 1 : 0; }
 
-// leg 0: smooth + residual + restriction + zero_vector(coarse e); leg 1: interpolation_vcycle + smooth.  c1 / c2: the level's Chebyshev coefficients.
+// leg 0: smooth + residual + restriction + zero_vector(coarse e); leg 1: interpolation_vcycle + smooth; leg 2: interpolation_fcycle, then leg 0.
+// c1 / c2: the level's Chebyshev coefficients.
 int hpgmg_hip_brick_visit(const hpgmg_hip_level *L, const hpgmg_hip_level *C, double h2inv, const double *c1, const double *c2, int sweeps,
-                          int variant, int smoother, int e_id, int R_id, double a, double b, int leg, int brick) {
+                          int variant, int smoother, int e_id, int R_id, double a, double b, int leg, int brick, int e_zero, int coarse_zero) {
   if (g_skip_launches) return record_error(hipErrorInvalidValue, "brick_visit: not replayable (the launch number is a kernel argument)");
-  if (!hpgmg_hip_brick_visit_supported(L, brick) || sweeps < 1 || sweeps > kBrickMaxSweeps || (sweeps & 1) || leg < 0 || leg > 1 || 2 * C->dim_i != L->dim_i)
+  if (!hpgmg_hip_brick_visit_supported(L, brick) || sweeps < 1 || sweeps > kBrickMaxSweeps || (sweeps & 1) || leg < 0 || leg > 2 || 2 * C->dim_i != L->dim_i)
     return record_error(hipErrorInvalidValue, "brick_visit: level / sweeps / leg");
   if (!g_faces) {
     HPGMG_CHECK(hipMalloc((void **)&g_faces, kFaceRecords * sizeof(FaceCell)));
@@ -293,6 +337,7 @@ int hpgmg_hip_brick_visit(const hpgmg_hip_level *L, const hpgmg_hip_level *C, do
   A.L = *L; A.C = *C; A.h2inv = h2inv; A.a = a; A.b = b; A.sweeps = sweeps; A.e_id = e_id; A.R_id = R_id;
   for (int s = 0; s < sweeps; s++) { A.c1[s] = c1 ? c1[s] : 0.0; A.c2[s] = c2 ? c2[s] : 0.0; }
   A.side = L->dim_i / brick;
+  A.e_zero = (leg == 0 && e_zero) ? 1 : 0; A.coarse_zero = coarse_zero ? 1 : 0;
   A.faces = g_faces; A.error = g_error;
   g_epoch += 64; A.epoch = g_epoch;
   int rc;

@@ -376,10 +376,13 @@ int hpgmg_hip_vcycle_tail(int n, const hpgmg_hip_level *const *levels, const dou
  *      Dirichlet, cubic domain, boxes in lexicographic order (as for the tail).  Not capturable in a hipGraph. ---- */
 int hpgmg_hip_brick_visit_supported(const hpgmg_hip_level *L, int brick);      /* 1: dim_i^3 cells = 2^3 or 4^3 bricks of 16^3 cells (brick = 16), 2^3 .. 8^3 bricks of 8^3 (brick = 8) */
 int hpgmg_hip_brick_visit_max_sweeps(void);
-/* leg 0: smooth, residual -> VECTOR_TEMP, restriction(C.R_id <- TEMP), zero_vector(C.e_id);  leg 1: e += P C.e (piecewise constant), smooth.
- * c1 / c2: the Chebyshev coefficients of L's `sweeps` sweeps (ignored by the other smoothers). */
+/* leg 0: smooth, residual -> VECTOR_TEMP, restriction(C.R_id <- TEMP), zero_vector(C.e_id);  leg 1: e += P C.e (piecewise constant), smooth;
+ * leg 2: interpolation_fcycle (e = 0.0 e + P1 C.e, interpolation_p1.c:40-70 with the coarse ghost cells of apply_BCs_p1 formed on the fly), then leg 0.
+ * c1 / c2: the Chebyshev coefficients of L's `sweeps` sweeps (ignored by the other smoothers).
+ * e_zero (leg 0): e counts as +0.0 and is not read -- zero_vector(L.e) is completed HERE (the ghost zone and padding; the interior is stored at the end anyway);
+ * coarse_zero (legs 0, 2): 1 = zero_vector(C.e) at the end, 0 = left to the launch that visits C with e_zero (leg 2 must: every brick reads C.e). */
 int hpgmg_hip_brick_visit(const hpgmg_hip_level *L, const hpgmg_hip_level *C, double h2inv, const double *c1, const double *c2, int sweeps,
-                          int variant, int smoother, int e_id, int R_id, double a, double b, int leg, int brick);
+                          int variant, int smoother, int e_id, int R_id, double a, double b, int leg, int brick, int e_zero, int coarse_zero);
 long long hpgmg_hip_brick_visits(void);      /* launches so far (tests) */
 int hpgmg_hip_brick_visit_error(void);       /* 1: a face poll of an earlier visit gave up after 2 s (a workgroup of the launch was not running): results are void */
 

@@ -119,7 +119,8 @@ void    hpgmg_segment_end(void);
  * the bottom level between the two); leg 2: leg 0, the bottom solve (solvers.c:27-95, BiCGStab to
  * MG_DEFAULT_BOTTOM_NORM), leg 1; leg 3: the bottom solve alone (n == 1); leg 4: the part of FMGSolve below levels[0]
  * (mg.c:1270-1300: restriction of R down the chain, zero_vector + bottom solve, then per level upwards interpolation_fcycle and
- * MGVCycle, levels[0] included); leg 5: only ask whether leg 4 would be executed.  Returns 1 when the plugin
+ * MGVCycle, levels[0] included); leg 5: only ask whether leg 4 would be executed; leg 6: one step of FMGSolve's climb (mg.c:1289-1293):
+ * interpolation_fcycle(levels[0] <- levels[1]) and the V-cycle from levels[0] (= leg 2) that follows it.  Returns 1 when the plugin
  * executed it (bit-identical to the per-operator sequence), 0 when it cannot -- the driver then
  * issues the operators one by one. */
 int     hpgmg_vcycle_legs_fused(level_type **levels, int n, int e_id, int R_id, double a, double b, int leg);

@@ -371,13 +371,34 @@ def test_level_visits_as_one_launch_of_bricks(hip, oracle, variant, geom, brick)
                 ah = cells(xh.read_all(H.VECTOR_U)).copy()      # (the oracle's exchange + boundary launches refill them afterwards; here nothing writes them again)
                 ah[:, g:g + d, g:g + d, g:g + d] = 0
                 assert not ah.any(), f"level {l}: ghost cells of the zeroed correction"
+        # one step of FMGSolve's climb (mg.c:1289-1293): interpolation_fcycle onto the top level + the V-cycle from it, the interpolation riding in the first
+        # launch of bricks (the plugin takes the step whole when the level below is a brick level too)
+        def junk():
+            for l in range(n):
+                for be, m in ((bh, mh), (bo, mo)):
+                    x = lv(be, m, l)
+                    for vid, seed in ((H.VECTOR_U, 41), (H.VECTOR_F, 42), (H.VECTOR_TEMP, 43)):
+                        x.write_all(vid, seeded_field(x, 2300 + 10 * l + seed))
+        junk()
+        L.hpgmg_vcycle_legs_fused.restype = ctypes.c_int
+        L.hpgmg_vcycle_legs_fused.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_int]
+        chain = (ctypes.c_void_p * n)(*[bh.lib.hpgmg_mg_level(mh, l) for l in range(n)])
+        before = L.hpgmg_brick_visits()
+        took = L.hpgmg_vcycle_legs_fused(chain, n, H.VECTOR_U, H.VECTOR_F, a, b, 6)
+        assert took == (1 if (side_ok(top) and side_ok(top >> 1)) else 0)
+        if took:
+            assert L.hpgmg_brick_visits() == before + want
+            bo.lib.interpolation_fcycle.restype = None
+            bo.lib.interpolation_fcycle.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_void_p, ctypes.c_int]
+            bo.lib.interpolation_fcycle(lv(bo, mo, 0).ptr, H.VECTOR_U, 0.0, lv(bo, mo, 1).ptr, H.VECTOR_U)
+            bo.lib.MGVCycle(mo, H.VECTOR_U, H.VECTOR_F, a, b, 0)
+            for l in range(n):
+                same(lv(bh, mh, l), lv(bo, mo, l), [H.VECTOR_U, H.VECTOR_F, H.VECTOR_TEMP], interior_only=True)
         # the same cycle launch by launch gives the same bytes (and launches no bricks)
+        junk()
+        bo.lib.MGVCycle(mo, H.VECTOR_U, H.VECTOR_F, a, b, 0)
         L.hpgmg_set_brick_visits(0)
         try:
-            for l in range(n):
-                x = lv(bh, mh, l)
-                for vid, seed in ((H.VECTOR_U, 31), (H.VECTOR_F, 32), (H.VECTOR_TEMP, 33)):
-                    x.write_all(vid, seeded_field(x, 2200 + 10 * l + seed))
             before = L.hpgmg_brick_visits()
             bh.lib.MGVCycle(mh, H.VECTOR_U, H.VECTOR_F, a, b, 0)
             bh.lib.hpgmg_operators_flush()
