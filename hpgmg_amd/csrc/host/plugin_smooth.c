@@ -139,17 +139,31 @@ static int brick_prefix(level_type **levels, int n, const hpgmg_config *cfg) {
   }
   return k;
 }
-/* `top`: the level whose timers take the launch -- the one whose V-cycle this is, like the tail below it (mg.c books the whole fused cycle on that level's Total) */
-static void brick_visit(level_type *top, level_type *L, level_type *C, const hpgmg_config *cfg, int e_id, int R_id, double a, double b, int leg, int e_zero, int coarse_zero) {
-  double c1[8], c2[8];
-  const int sweeps = hpgmg_smooth_sweeps();
-  int s;
-  for (s = 0; s < 8; s++) c1[s] = c2[s] = 0.0;
-  if (cfg->smoother == HPGMG_SMOOTH_CHEBY) cheby_coefficients(L, sweeps, c1, c2);
-  TICK(top, smooth, leg == 1 ? "level visit, up (bricks: interpolation + smooth in one launch)" :
-                    (leg == 0 ? "level visit, down (bricks: smooth + residual + restriction in one launch)" : "interpolation_fcycle + level visit, down (bricks, one launch)"));
-  HIP_OK(hpgmg_hip_brick_visit(&hp_backend_of(L)->dev, &hp_backend_of(C)->dev, 1.0 / (L->h * L->h), c1, c2, sweeps, hp_variant(), cfg->smoother, e_id, R_id, a, b, leg, (int)hp_switch(SW_BRICK_SIZE), e_zero, coarse_zero));
-  TOCK();
+/* One launch of bricks for levels[first .. first + count - 1] (dir 0 down, 1 up, 2 interpolation_fcycle + down), or one per level when chains are off.
+ * `top`: the level whose timers take the launches -- the one whose V-cycle this is, like the tail below it (mg.c books the whole fused cycle on that level's Total) */
+static void brick_chain(level_type *top, level_type **levels, int first, int count, const hpgmg_config *cfg, int e_id, int R_id, double a, double b, int dir, int top_e_zero, int below_zero) {
+  const int sweeps = hpgmg_smooth_sweeps(), chain = (int)hp_switch(SW_BRICK_CHAIN), max_n = (chain == 1 || (chain == 2 && dir != 1) || (chain == 3 && dir == 1)) ? hpgmg_hip_brick_chain_max_levels() : 1;
+  int done = 0;
+  while (done < count) {
+    hpgmg_hip_brick_level lv[4];
+    int n = count - done, j, s;
+    if (n > max_n) n = max_n;
+    /* down: the finest levels first; up: the coarsest levels first */
+    const int lo = (dir == 1) ? first + count - done - n : first + done;
+    for (j = 0; j < n; j++) {
+      level_type *L = levels[lo + j];
+      lv[j].L = hp_backend_of(L)->dev; lv[j].h2inv = 1.0 / (L->h * L->h);
+      for (s = 0; s < 8; s++) lv[j].c1[s] = lv[j].c2[s] = 0.0;
+      if (cfg->smoother == HPGMG_SMOOTH_CHEBY) cheby_coefficients(L, sweeps, lv[j].c1, lv[j].c2);
+    }
+    const int is_first_launch = (done == 0), is_last_launch = (done + n == count);
+    TICK(top, smooth, dir == 1 ? "level visits, up (bricks: interpolation + smooth per level, one launch)" :
+                      (dir == 0 ? "level visits, down (bricks: smooth + residual + restriction per level, one launch)" : "interpolation_fcycle + level visit, down (bricks, one launch)"));
+    HIP_OK(hpgmg_hip_brick_chain(n, lv, &hp_backend_of(levels[lo + n])->dev, sweeps, hp_variant(), cfg->smoother, e_id, R_id, a, b, dir, (int)hp_switch(SW_BRICK_SIZE),
+                                 dir == 0 ? (is_first_launch ? top_e_zero : 1) : 0, (dir != 1 && is_last_launch) ? below_zero : 0));
+    TOCK();
+    done += n;
+  }
 }
 static level_type *tail_books_on = NULL;      /* the level whose timers take the tail launch when bricks were visited above it (else its own first level) */
 /* leg 16 + x: would leg x be taken?  (nothing is launched) */
@@ -169,13 +183,16 @@ int hp_vcycle_legs_fused(level_type **levels, int n, int e_id, int R_id, double 
     if (fstep && !hp_switch(SW_BRICK_FSTEP)) return 0;
     const int k = brick_prefix(levels, n, &cfg);
     if (k > (fstep ? 1 : 0) && hp_vcycle_legs_fused(levels + k, n - k, e_id, R_id, a, b, 16 + vleg)) {
-      /* zero_vector of a brick level below the first: by the launch that visits it (which then does not read the vector either) */
-      if (vleg != 1) for (l = 0; l < k; l++) brick_visit(levels[0], levels[l], levels[l + 1], &cfg, e_id, R_id, a, b, (fstep && l == 0) ? 2 : 0, l > 0, l == k - 1);
+      /* zero_vector of a brick level below the first: by the launch that visits it (which then does not read the vector either); the tail's first level: here */
+      if (vleg != 1) {
+        if (fstep) { brick_chain(levels[0], levels, 0, 1, &cfg, e_id, R_id, a, b, 2, 0, 0); brick_chain(levels[0], levels, 1, k - 1, &cfg, e_id, R_id, a, b, 0, 1, 1); }
+        else brick_chain(levels[0], levels, 0, k, &cfg, e_id, R_id, a, b, 0, 0, 1);
+      }
       tail_books_on = levels[0];
       const int taken = hp_vcycle_legs_fused(levels + k, n - k, e_id, R_id, a, b, vleg);
       tail_books_on = NULL;
       if (!taken) { fprintf(stderr, "hpgmg: the V-cycle tail was refused after being accepted\n"); abort(); }
-      if (vleg != 0) for (l = k - 1; l >= 0; l--) brick_visit(levels[0], levels[l], levels[l + 1], &cfg, e_id, R_id, a, b, 1, 0, 0);
+      if (vleg != 0) brick_chain(levels[0], levels, 0, k, &cfg, e_id, R_id, a, b, 1, 0, 0);
       return 1;
     }
     if (fstep) return 0;

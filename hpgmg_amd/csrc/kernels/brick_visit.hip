@@ -46,34 +46,60 @@ template <int B_> struct BrickGeom {
     if (f < 2) { li = w; lj = u; lk = v; } else if (f < 4) { li = u; lj = w; lk = v; } else { li = u; lj = v; lk = w; }
   }
 };
-constexpr int kBrickMaxSweeps = 8;
-constexpr size_t kFaceRecords = (size_t)2 * 512 * 6 * 64;      // both parities of 8^3 bricks of 8^3 cells (= 4^3 bricks of 16^3 take half of it)
+constexpr int kBrickMaxSweeps = 8, kBrickMaxLevels = 3, kBrickMaxWgs = 512;
+// record areas, each per level of a chain: faces [2 parities][workgroup][6][B^2] (8^3 bricks of 8^3 cells fill it; 4^3 bricks of 16^3 take half),
+// one record per cell for what goes down (restricted residuals) and up (corrections), one gate per brick
+constexpr size_t kFaceRecords = (size_t)2 * kBrickMaxWgs * 6 * 64, kCellRecords = (size_t)kBrickMaxWgs * 512;
 constexpr u64 kPollTicks = 200000000ull;            // 2 s of the 100 MHz clock
+// sequence numbers inside a launch (added to its epoch, a multiple of 64): 1 + 12 j + n = exchange n of level j; 40 + j, 48 + j, 56 + j = what level j
+// receives from the finer level / hands to the finer level / its gate
+enum { SEQ_FACES = 1, SEQ_DOWN = 40, SEQ_UP = 48, SEQ_GATE = 56 };
 
+struct BrickLevel {
+  hpgmg_hip_level L;
+  double h2inv, c1[kBrickMaxSweeps], c2[kBrickMaxSweeps];
+  int side, nwg;                    // bricks per dimension, per level
+};
 struct BrickArgs {
-  hpgmg_hip_level L, C;             // the level visited; the next coarser one (restriction target / interpolation source)
-  double h2inv, a, b;
-  double c1[kBrickMaxSweeps], c2[kBrickMaxSweeps];
+  BrickLevel lv[kBrickMaxLevels];   // the levels of the chain, finest first: level j is worked on by workgroups 0 .. lv[j].nwg - 1
+  hpgmg_hip_level C;                // the level below the last one (restriction target / interpolation source): other launches' business
+  int n;
+  double a, b;
   int sweeps, e_id, R_id;
-  int side;                         // bricks per dimension
-  int e_zero;                       // legs 0: the correction counts as +0.0 (zero_vector came before, mg.c:1153): it is not read, and the cells of its padded boxes that
-                                    // no brick stores at the end (ghost zone, padding) are cleared HERE -- the launch that visited the finer level left it alone
-  int coarse_zero;                  // legs 0, 2: zero_vector(C.e) at the end (0: the launch that visits C does it, see e_zero)
-  FaceCell *faces;                  // [2][workgroup][6][B^2]
-  u64 epoch;                        // launch number x 64: the first sequence number of this launch is epoch + 1
+  int top_e_zero;                   // DOWN: the correction of lv[0] counts as +0.0 (zero_vector came before, mg.c:1153) and is not read; the cells of its padded
+                                    // boxes that no brick stores (ghost zone, padding) are cleared here.  (Levels below the first: always.)
+  int below_zero;                   // DOWN: zero_vector(C.e) at the end (0: somebody else's)
+  FaceCell *faces, *down, *up, *gate;
+  u64 epoch;                        // launch number x 64
   unsigned *error;                  // pinned host word: set when a poll gave up
 };
 
 __device__ __forceinline__ void face_store(FaceCell *p, double v, u64 seq) {
   const long long b = __double_as_longlong(v);
   u4v w; w.x = (unsigned)b; w.y = (unsigned)(b >> 32); w.z = (unsigned)seq; w.w = (unsigned)(seq >> 32);
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(w) : "memory");
+  // the s_nop: a VMEM store of more than 8 bytes per lane reads its data registers for a few cycles after issue, and a VALU write to them in that window
+  // corrupts the store.  The compiler pads its own stores against that hazard; it cannot see into this one.  (Found as records with the right sequence
+  // number and the next cell's value: 4 stores per lane back to back, bricks of 16^3.)
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 3" :: "v"(p), "v"(w) : "memory");
 }
 __device__ __forceinline__ FaceCell face_load(const FaceCell *p) {
   u4v w;
   asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(w) : "v"(p) : "memory");
   FaceCell c; c.v = __longlong_as_double((long long)(((u64)w.y << 32) | w.x)); c.seq = ((u64)w.w << 32) | w.z;
   return c;
+}
+// the value of a record once it carries `seq` (nap: s_sleep units between polls)
+__device__ __forceinline__ double record_wait(const FaceCell *p, u64 seq, u64 t0, bool &gave_up, int nap = 1) {
+  FaceCell x = face_load(p);
+  while (x.seq != seq) {
+    if (__builtin_amdgcn_s_memrealtime() - t0 > kPollTicks) { gave_up = true; break; }
+    if (nap > 1) __builtin_amdgcn_s_sleep(8); else __builtin_amdgcn_s_sleep(1);
+    x = face_load(p);
+  }
+#ifdef HPGMG_EXP_REREAD
+  x = face_load(p);
+#endif
+  return x.v;
 }
 
 template <int V, int kHaloW, int kHaloPlane>
@@ -90,9 +116,14 @@ __device__ __forceinline__ double brick_apply(const double *src, int p, int gi, 
 }
 
 enum { BV_CHEBY = 0, BV_GSRB = 1, BV_JACOBI = 2 };
+enum { DIR_DOWN = 0, DIR_UP = 1, DIR_FDOWN = 2 };      // FDOWN: interpolation_fcycle, then DOWN (one level)
 
-template <int V, int SM, int LEG, int B>
-__global__ __launch_bounds__(BrickGeom<B>::Threads) void brick_visit_kernel(const BrickArgs A) {
+// One launch = the visits of a CHAIN of launch-bound levels in one direction.  DOWN: level 0, then (workgroups < lv[1].nwg) level 1 with the residuals
+// level 0 restricted, ...; UP: the last level first, every finer level waiting for the corrections of the one below it.  What passes between two levels
+// of the chain passes as records, like the faces (a level's bricks are not the workgroups that held the cells above / below them).
+template <int V, int SM, int DIR, int B>
+// (B = 8: at least six waves per SIMD = three workgroups per CU = room for 768 -- a level of 64^3 cells needs 512 of them running at once, and not on the last free slot)
+__global__ __launch_bounds__(BrickGeom<B>::Threads, (B == 8) ? 6 : 4) void brick_chain_kernel(const BrickArgs A) {
   using BG = BrickGeom<B>;
   constexpr int kBrick = B, kBrickCells = BG::Cells, kBrickThreads = BG::Threads, kBrickPerLane = BG::PerLane, kHaloW = BG::W, kHaloPlane = BG::Plane, kHaloCells = BG::Halo;
   constexpr int kFaceCells = BG::Face, kStepPos = BG::StepPos, kStepK = BG::StepK;
@@ -100,207 +131,260 @@ __global__ __launch_bounds__(BrickGeom<B>::Threads) void brick_visit_kernel(cons
   auto face_cell = [](int f, int u, int v, int depth, int &li, int &lj, int &lk) { BG::face_cell(f, u, v, depth, li, lj, lk); };
   constexpr bool kVC = (V != HPGMG_HIP_7PT_CC);
   constexpr bool kHelm = (V == HPGMG_HIP_7PT_VC_HELMHOLTZ);
-  constexpr bool kUp = (LEG == 1), kDown = (LEG != 1), kFInterp = (LEG == 2);
+  constexpr bool kUp = (DIR == DIR_UP), kDown = (DIR != DIR_UP), kFInterp = (DIR == DIR_FDOWN);
   extern __shared__ double brick_lds[];
   double *const sx = brick_lds, *const st = brick_lds + kHaloCells;
-  const int t = (int)threadIdx.x, wg = (int)blockIdx.x, side = A.side, nwg = side * side * side;
-  const int bx = wg % side, by = (wg / side) % side, bz = wg / (side * side);
-  const int D = A.L.dim_i, o_i = bx * kBrick, o_j = by * kBrick, o_k = bz * kBrick;
-  const LevelGeom G = geom_of(A.L), GC = geom_of(A.C);
-  FaceCell *const faces = A.faces;
+  const int t = (int)threadIdx.x, wg = (int)blockIdx.x, e_id = A.e_id, R_id = A.R_id, n = A.n;
   const u64 epoch = A.epoch;
-  const int e_id = A.e_id;
   const u64 t0 = __builtin_amdgcn_s_memrealtime();
   bool gave_up = false;
+  const int li0 = t % kBrick, lj0 = (t / kBrick) % kBrick, lk0 = t / kFaceCells, pos0 = hpos(li0, lj0, lk0);
 
-  // what the first sweep reads at global cell (ci, cj, ck) of this level, given what is stored there
-  auto start_value = [&](double stored, int ci, int cj, int ck) -> double {
-    if (kUp) {               // interpolation_vcycle: e = 1.0*e + (coarse parent), interpolation_p0.c:43
-      const CellRef c = locate(GC, ci >> 1, cj >> 1, ck >> 1);
-      return 1.0 * stored + vec_origin(A.C, c.box, e_id)[c.ijk];
-    }
-    if (kFInterp) {          // interpolation_fcycle, piecewise linear (interpolation_p1.c:40-70): f = 0.0 f + 27/64 c + 9/64 (3 face neighbours) + 3/64 (3 edge
-      // neighbours) + 1/64 corner, an even fine cell leaning on the coarse neighbour behind it, an odd one on the one ahead.  A coarse ghost cell is -, +, -
-      // its mirror image for 1, 2, 3 directions leaving the domain (exchange_boundary + apply_BCs_p1, BOX shape, boundary_fd.c:35-38), formed here.
-      const int Dc = A.C.dim_i;
-      auto coarse = [&](int qi, int qj, int qk) -> double {
-        double sg = 1.0;
-        if (qi < 0) { qi = 0; sg = -sg; } else if (qi >= Dc) { qi = Dc - 1; sg = -sg; }
-        if (qj < 0) { qj = 0; sg = -sg; } else if (qj >= Dc) { qj = Dc - 1; sg = -sg; }
-        if (qk < 0) { qk = 0; sg = -sg; } else if (qk >= Dc) { qk = Dc - 1; sg = -sg; }
-        const CellRef r = locate(GC, qi, qj, qk);
-        return sg * vec_origin(A.C, r.box, e_id)[r.ijk];
-      };
-      const int qi = ci >> 1, qj = cj >> 1, qk = ck >> 1, di = (ci & 1) ? 1 : -1, dj = (cj & 1) ? 1 : -1, dk = (ck & 1) ? 1 : -1;
-      double v = 0.0 * stored;
-      v = v + 0.421875 * coarse(qi, qj, qk);
-      v = v + 0.140625 * coarse(qi, qj, qk + dk);
-      v = v + 0.140625 * coarse(qi, qj + dj, qk);
-      v = v + 0.046875 * coarse(qi, qj + dj, qk + dk);
-      v = v + 0.140625 * coarse(qi + di, qj, qk);
-      v = v + 0.046875 * coarse(qi + di, qj, qk + dk);
-      v = v + 0.046875 * coarse(qi + di, qj + dj, qk);
-      v = v + 0.015625 * coarse(qi + di, qj + dj, qk + dk);
-      return v;
-    }
-    return stored;
-  };
-  // a lane's cells: (li, lj) fixed, lk = lk0 + kStepK m -- one LDS position and one global coordinate triple describe all of them
-  const int li0 = t % kBrick, lj0 = (t / kBrick) % kBrick, lk0 = t / kFaceCells;
-  const int pos0 = hpos(li0, lj0, lk0), gi = o_i + li0, gj = o_j + lj0, gk0 = o_k + lk0;
-  CellCoef<V> q[kBrickPerLane];
+  for (int step = 0; step < n; step++) {
+    const int j = kUp ? n - 1 - step : step;
+    const BrickLevel &T = A.lv[j];
+    const int nwg = T.nwg;
+    if (wg >= nwg) { if (kUp) continue; else break; }
+    const bool first = (j == 0), last = (j == n - 1);
+    const hpgmg_hip_level &L = T.L;
+    const hpgmg_hip_level &C = last ? A.C : A.lv[last ? j : j + 1].L;      // the level below this one
+    const int side = T.side, bx = wg % side, by = (wg / side) % side, bz = wg / (side * side);
+    const int D = L.dim_i, o_i = bx * kBrick, o_j = by * kBrick, o_k = bz * kBrick;
+    const LevelGeom G = geom_of(L), GC = geom_of(C);
+    const int gi = o_i + li0, gj = o_j + lj0, gk0 = o_k + lk0;
+    const double a = A.a, b = A.b, h2inv = T.h2inv;
+    FaceCell *const faces = A.faces + (size_t)j * kFaceRecords;
+    const bool e_zero = kDown && !kFInterp && (first ? (A.top_e_zero != 0) : true);
+    const bool rhs_by_record = kDown && !first, parent_by_record = kUp && !last;
+    // the record of cell (ci, cj, ck) of the level BELOW this one (where its owner publishes / expects it): bricks of that level are numbered like ours
+    const int side_c = last ? 1 : A.lv[last ? j : j + 1].side;
+    auto below_record = [&](int ci, int cj, int ck) -> size_t {
+      const int qx = ci / kBrick, qy = cj / kBrick, qz = ck / kBrick;
+      const int owner = qx + side_c * (qy + side_c * qz);
+      return (size_t)owner * kBrickCells + (size_t)((ci - qx * kBrick) + kBrick * ((cj - qy * kBrick) + kBrick * (ck - qz * kBrick)));
+    };
+    const FaceCell *const up_from_below = A.up + (size_t)(last ? j : j + 1) * kCellRecords;      // corrections of the level below (UP, not the last level)
+    const u64 seq_parent = epoch + SEQ_UP + (u64)(j + 1);
 
-  // ---- the brick: iterate (+ the coarse parent on the way up), VECTOR_TEMP, coefficients
-#pragma unroll
-  for (int m = 0; m < kBrickPerLane; m++) {
-    const int p = pos0 + m * kStepPos, gk = gk0 + m * kStepK;
-    const CellRef w = locate(G, gi, gj, gk);
-    const int box = w.box, ijk = w.ijk, jS = A.L.jStride, kS = A.L.kStride;
-    sx[p] = start_value(A.e_zero ? 0.0 : vec_origin(A.L, box, e_id)[ijk], gi, gj, gk);
-    st[p] = vec_origin(A.L, box, VECTOR_TEMP)[ijk];
-    q[m].rhs = vec_origin(A.L, box, A.R_id)[ijk];
-    q[m].dinv = vec_origin(A.L, box, VECTOR_DINV)[ijk];
-    q[m].bi0 = q[m].bi1 = q[m].bj0 = q[m].bj1 = q[m].bk0 = q[m].bk1 = q[m].al = 0.0;
-    if (kVC) {
-      const double *bi = vec_origin(A.L, box, VECTOR_BETA_I), *bj = vec_origin(A.L, box, VECTOR_BETA_J), *bk = vec_origin(A.L, box, VECTOR_BETA_K);
-      q[m].bi0 = bi[ijk]; q[m].bi1 = bi[ijk + 1]; q[m].bj0 = bj[ijk]; q[m].bj1 = bj[ijk + jS]; q[m].bk0 = bk[ijk]; q[m].bk1 = bk[ijk + kS];
-    }
-    if (kHelm) q[m].al = vec_origin(A.L, box, VECTOR_ALPHA)[ijk];
-  }
-  // ---- the halo of the FIRST sweep's input: the neighbouring bricks' cells as earlier launches left them (+ their coarse parents on the way up: the same
-  // expression the owning brick forms).  Lane roles for everything on faces: cell fc = (f B + v) B + u of the 6 B^2 face cells.
-  for (int fc = t; fc < 6 * kFaceCells; fc += kBrickThreads) {
-    const int f = fc / kFaceCells, u = fc % kBrick, v = (fc / kBrick) % kBrick;
-    int li, lj, lk;
-    face_cell(f, u, v, 1, li, lj, lk);
-    const int hi = o_i + li, hj = o_j + lj, hk = o_k + lk;
-    if (hi < 0 || hi >= D || hj < 0 || hj >= D || hk < 0 || hk >= D) continue;      // beyond the domain: the Dirichlet rule, never read
-    const CellRef r = locate(G, hi, hj, hk);
-    sx[hpos(li, lj, lk)] = start_value(A.e_zero ? 0.0 : vec_origin(A.L, r.box, e_id)[r.ijk], hi, hj, hk);
-  }
-  __syncthreads();
+    // what the first sweep reads at global cell (ci, cj, ck) of this level, given what is stored there
+    auto start_value = [&](double stored, int ci, int cj, int ck) -> double {
+      if (kUp) {               // interpolation_vcycle: e = 1.0*e + (coarse parent), interpolation_p0.c:43
+        double parent;
+        if (parent_by_record) parent = record_wait(up_from_below + below_record(ci >> 1, cj >> 1, ck >> 1), seq_parent, t0, gave_up);
+        else { const CellRef c = locate(GC, ci >> 1, cj >> 1, ck >> 1); parent = vec_origin(C, c.box, e_id)[c.ijk]; }
+        return 1.0 * stored + parent;
+      }
+      if (kFInterp) {          // interpolation_fcycle, piecewise linear (interpolation_p1.c:40-70): f = 0.0 f + 27/64 c + 9/64 (3 face neighbours) + 3/64 (3 edge
+        // neighbours) + 1/64 corner, an even fine cell leaning on the coarse neighbour behind it, an odd one on the one ahead.  A coarse ghost cell is -, +, -
+        // its mirror image for 1, 2, 3 directions leaving the domain (exchange_boundary + apply_BCs_p1, BOX shape, boundary_fd.c:35-38), formed here.
+        const int Dc = C.dim_i;
+        auto coarse = [&](int qi, int qj, int qk) -> double {
+          double sg = 1.0;
+          if (qi < 0) { qi = 0; sg = -sg; } else if (qi >= Dc) { qi = Dc - 1; sg = -sg; }
+          if (qj < 0) { qj = 0; sg = -sg; } else if (qj >= Dc) { qj = Dc - 1; sg = -sg; }
+          if (qk < 0) { qk = 0; sg = -sg; } else if (qk >= Dc) { qk = Dc - 1; sg = -sg; }
+          const CellRef r = locate(GC, qi, qj, qk);
+          return sg * vec_origin(C, r.box, e_id)[r.ijk];
+        };
+        const int qi = ci >> 1, qj = cj >> 1, qk = ck >> 1, di = (ci & 1) ? 1 : -1, dj = (cj & 1) ? 1 : -1, dk = (ck & 1) ? 1 : -1;
+        double v = 0.0 * stored;
+        v = v + 0.421875 * coarse(qi, qj, qk);
+        v = v + 0.140625 * coarse(qi, qj, qk + dk);
+        v = v + 0.140625 * coarse(qi, qj + dj, qk);
+        v = v + 0.046875 * coarse(qi, qj + dj, qk + dk);
+        v = v + 0.140625 * coarse(qi + di, qj, qk);
+        v = v + 0.046875 * coarse(qi + di, qj, qk + dk);
+        v = v + 0.046875 * coarse(qi + di, qj + dj, qk);
+        v = v + 0.015625 * coarse(qi + di, qj + dj, qk + dk);
+        return v;
+      }
+      return stored;
+    };
 
-  // ---- smooth(): chebyshev.c:43-99 / gsrb.c:24-132 / jacobi.c:17-62 (an even number of sweeps: the result ends in sx)
-  int exchange_n = 0;
-  for (int s = 0; s < A.sweeps; s++) {
-    const double *src = (SM != BV_GSRB && (s & 1)) ? st : sx;
-    double *dst = (SM == BV_GSRB) ? sx : ((s & 1) ? sx : st);
-    const double c1 = A.c1[s], c2 = A.c2[s];
+    // ---- the brick: what is stored of the iterate, VECTOR_TEMP, coefficients (every load is in flight before anything is waited for)
+    CellCoef<V> q[kBrickPerLane];
+    double e_st[kBrickPerLane];
 #pragma unroll
     for (int m = 0; m < kBrickPerLane; m++) {
       const int p = pos0 + m * kStepPos, gk = gk0 + m * kStepK;
-      if (SM == BV_GSRB && ((gi ^ gj ^ gk ^ s) & 1) != 0) continue;      // global parity: box.low folded in (gsrb.c:55); red cells read black neighbours only
-      const double xc = src[p];
-      const double Ax = brick_apply<V, kHaloW, kHaloPlane>(src, p, gi, gj, gk, D, q[m], A.a, A.b, A.h2inv);
-      if (SM == BV_CHEBY)     { const double xnm1 = dst[p]; dst[p] = xc + c1 * (xc - xnm1) + c2 * q[m].dinv * (q[m].rhs - Ax); }
-      else if (SM == BV_GSRB) { dst[p] = xc + q[m].dinv * (q[m].rhs - Ax); }
-      else                    { dst[p] = xc + (2.0 / 3.0) * q[m].dinv * (q[m].rhs - Ax); }
+      const CellRef w = locate(G, gi, gj, gk);
+      const int box = w.box, ijk = w.ijk, jS = L.jStride, kS = L.kStride;
+      e_st[m] = e_zero ? 0.0 : vec_origin(L, box, e_id)[ijk];
+      st[p] = vec_origin(L, box, VECTOR_TEMP)[ijk];
+      q[m].rhs = rhs_by_record ? 0.0 : vec_origin(L, box, R_id)[ijk];
+      q[m].dinv = vec_origin(L, box, VECTOR_DINV)[ijk];
+      q[m].bi0 = q[m].bi1 = q[m].bj0 = q[m].bj1 = q[m].bk0 = q[m].bk1 = q[m].al = 0.0;
+      if (kVC) {
+        const double *bi = vec_origin(L, box, VECTOR_BETA_I), *bj = vec_origin(L, box, VECTOR_BETA_J), *bk = vec_origin(L, box, VECTOR_BETA_K);
+        q[m].bi0 = bi[ijk]; q[m].bi1 = bi[ijk + 1]; q[m].bj0 = bj[ijk]; q[m].bj1 = bj[ijk + jS]; q[m].bk0 = bk[ijk]; q[m].bk1 = bk[ijk + kS];
+      }
+      if (kHelm) q[m].al = vec_origin(L, box, VECTOR_ALPHA)[ijk];
+    }
+    // the stored iterate beyond the faces (the neighbouring bricks' cells as EARLIER launches left them); lane roles for everything on faces:
+    // cell fc = (f B + v) B + u of the 6 B^2 face cells
+    constexpr int kHaloPerLane = (6 * kFaceCells + kBrickThreads - 1) / kBrickThreads;
+    double h_st[kHaloPerLane];
+#pragma unroll
+    for (int hm = 0; hm < kHaloPerLane; hm++) {
+      const int fc = t + hm * kBrickThreads;
+      h_st[hm] = 0.0;
+      if (fc >= 6 * kFaceCells || e_zero) continue;
+      const int f = fc / kFaceCells, u = fc % kBrick, v = (fc / kBrick) % kBrick;
+      int li, lj, lk;
+      face_cell(f, u, v, 1, li, lj, lk);
+      const int hi = o_i + li, hj = o_j + lj, hk = o_k + lk;
+      if (hi < 0 || hi >= D || hj < 0 || hj >= D || hk < 0 || hk >= D) continue;      // beyond the domain: the Dirichlet rule, never read
+      const CellRef r = locate(G, hi, hj, hk);
+      h_st[hm] = vec_origin(L, r.box, e_id)[r.ijk];
+    }
+    // UP, not the last level: the corrections of the level below are on their way.  One lane watches the gate of the brick that holds this brick's parents
+    // (hundreds of workgroups polling a record per lane for the length of a visit would be in the way of the bricks that work)
+    if (parent_by_record) {
+      if (t == 0) (void)record_wait(A.gate + (size_t)(j + 1) * kBrickMaxWgs + ((bx >> 1) + side_c * ((by >> 1) + side_c * (bz >> 1))), epoch + SEQ_GATE + (u64)(j + 1), t0, gave_up, 8);
+      __syncthreads();
+    }
+#pragma unroll
+    for (int m = 0; m < kBrickPerLane; m++) {
+      const int p = pos0 + m * kStepPos, gk = gk0 + m * kStepK;
+      sx[p] = start_value(e_st[m], gi, gj, gk);
+      if (rhs_by_record) q[m].rhs = record_wait(A.down + (size_t)j * kCellRecords + (size_t)wg * kBrickCells + (size_t)(t + m * kBrickThreads), epoch + SEQ_DOWN + (u64)j, t0, gave_up);
+    }
+#pragma unroll
+    for (int hm = 0; hm < kHaloPerLane; hm++) {
+      const int fc = t + hm * kBrickThreads;
+      if (fc >= 6 * kFaceCells) continue;
+      const int f = fc / kFaceCells, u = fc % kBrick, v = (fc / kBrick) % kBrick;
+      int li, lj, lk;
+      face_cell(f, u, v, 1, li, lj, lk);
+      const int hi = o_i + li, hj = o_j + lj, hk = o_k + lk;
+      if (hi < 0 || hi >= D || hj < 0 || hj >= D || hk < 0 || hk >= D) continue;
+      sx[hpos(li, lj, lk)] = e_zero ? 0.0 : start_value(h_st[hm], hi, hj, hk);
     }
     __syncthreads();
-    if (kDown || s + 1 < A.sweeps) {      // (the way down goes on to the residual of the result)
-      // one exchange: the faces of dst go out, the neighbours' faces come into its halo
-      const int par = exchange_n & 1;
-      const u64 seq = epoch + 1 + (u64)exchange_n;
-      exchange_n++;
-      FaceCell *mine = faces + ((size_t)par * nwg + wg) * 6 * kFaceCells;
-      for (int fc = t; fc < 6 * kFaceCells; fc += kBrickThreads) {
-        const int f = fc / kFaceCells, u = fc % kBrick, v = (fc / kBrick) % kBrick;
-        const int bc = (f < 2) ? bx : ((f < 4) ? by : bz);
-        if ((f & 1) ? (bc == side - 1) : (bc == 0)) continue;                          // no brick beyond this face
-        int li, lj, lk;
-        face_cell(f, u, v, 0, li, lj, lk);
-        face_store(mine + fc, dst[hpos(li, lj, lk)], seq);
+
+    // ---- smooth(): chebyshev.c:43-99 / gsrb.c:24-132 / jacobi.c:17-62 (an even number of sweeps: the result ends in sx)
+    int exchange_n = 0;
+    for (int s = 0; s < A.sweeps; s++) {
+      const double *src = (SM != BV_GSRB && (s & 1)) ? st : sx;
+      double *dst = (SM == BV_GSRB) ? sx : ((s & 1) ? sx : st);
+      const double c1 = T.c1[s], c2 = T.c2[s];
+#pragma unroll
+      for (int m = 0; m < kBrickPerLane; m++) {
+        const int p = pos0 + m * kStepPos, gk = gk0 + m * kStepK;
+        if (SM == BV_GSRB && ((gi ^ gj ^ gk ^ s) & 1) != 0) continue;      // global parity: box.low folded in (gsrb.c:55); red cells read black neighbours only
+        const double xc = src[p];
+        const double Ax = brick_apply<V, kHaloW, kHaloPlane>(src, p, gi, gj, gk, D, q[m], a, b, h2inv);
+        if (SM == BV_CHEBY)     { const double xnm1 = dst[p]; dst[p] = xc + c1 * (xc - xnm1) + c2 * q[m].dinv * (q[m].rhs - Ax); }
+        else if (SM == BV_GSRB) { dst[p] = xc + q[m].dinv * (q[m].rhs - Ax); }
+        else                    { dst[p] = xc + (2.0 / 3.0) * q[m].dinv * (q[m].rhs - Ax); }
       }
-      for (int fc = t; fc < 6 * kFaceCells; fc += kBrickThreads) {
-        const int f = fc / kFaceCells, u = fc % kBrick, v = (fc / kBrick) % kBrick;
-        const int bc = (f < 2) ? bx : ((f < 4) ? by : bz);
-        if ((f & 1) ? (bc == side - 1) : (bc == 0)) continue;
-        const int step = (f < 2) ? 1 : ((f < 4) ? side : side * side), n = wg + ((f & 1) ? step : -step);
-        const FaceCell *theirs = faces + (((size_t)par * nwg + n) * 6 + (f ^ 1)) * kFaceCells + (fc % kFaceCells);
-        FaceCell x = face_load(theirs);
-        while (x.seq != seq) {
-          if (__builtin_amdgcn_s_memrealtime() - t0 > kPollTicks) { gave_up = true; break; }
-          __builtin_amdgcn_s_sleep(1);
-          x = face_load(theirs);
+      __syncthreads();
+      if (kDown || s + 1 < A.sweeps) {      // (the way down goes on to the residual of the result)
+        // one exchange: the faces of dst go out, the neighbours' faces come into its halo
+        const int par = exchange_n & 1;
+        const u64 seq = epoch + SEQ_FACES + (u64)(12 * j + exchange_n);
+        exchange_n++;
+        FaceCell *mine = faces + ((size_t)par * nwg + wg) * 6 * kFaceCells;
+        for (int fc = t; fc < 6 * kFaceCells; fc += kBrickThreads) {
+          const int f = fc / kFaceCells, u = fc % kBrick, v = (fc / kBrick) % kBrick;
+          const int bc = (f < 2) ? bx : ((f < 4) ? by : bz);
+          if ((f & 1) ? (bc == side - 1) : (bc == 0)) continue;                          // no brick beyond this face
+          int li, lj, lk;
+          face_cell(f, u, v, 0, li, lj, lk);
+          face_store(mine + fc, dst[hpos(li, lj, lk)], seq);
         }
-        int li, lj, lk;
-        face_cell(f, u, v, 1, li, lj, lk);
-        dst[hpos(li, lj, lk)] = x.v;
+        for (int fc = t; fc < 6 * kFaceCells; fc += kBrickThreads) {
+          const int f = fc / kFaceCells, u = fc % kBrick, v = (fc / kBrick) % kBrick;
+          const int bc = (f < 2) ? bx : ((f < 4) ? by : bz);
+          if ((f & 1) ? (bc == side - 1) : (bc == 0)) continue;
+          const int stp = (f < 2) ? 1 : ((f < 4) ? side : side * side), nb = wg + ((f & 1) ? stp : -stp);
+          const double xv = record_wait(faces + (((size_t)par * nwg + nb) * 6 + (f ^ 1)) * kFaceCells + (fc % kFaceCells), seq, t0, gave_up);
+          int li, lj, lk;
+          face_cell(f, u, v, 1, li, lj, lk);
+          dst[hpos(li, lj, lk)] = xv;
+        }
+        __syncthreads();
+      }
+    }
+
+    if (kDown) {                                        // residual -> TEMP (residual.c:42-48)
+#pragma unroll
+      for (int m = 0; m < kBrickPerLane; m++) {
+        const int p = pos0 + m * kStepPos;
+        const double Ax = brick_apply<V, kHaloW, kHaloPlane>(sx, p, gi, gj, gk0 + m * kStepK, D, q[m], a, b, h2inv);
+        st[p] = q[m].rhs - Ax;                          // each lane overwrites only its own TEMP cells: no hazard with the reads of sx
       }
       __syncthreads();
     }
-  }
 
-  if (kDown) {                                        // residual -> TEMP (residual.c:42-48)
+    // ---- leave e and TEMP in global memory as the per-operator sequence would; UP: hand the correction to the finer level of the chain
 #pragma unroll
     for (int m = 0; m < kBrickPerLane; m++) {
       const int p = pos0 + m * kStepPos;
-      const double Ax = brick_apply<V, kHaloW, kHaloPlane>(sx, p, gi, gj, gk0 + m * kStepK, D, q[m], A.a, A.b, A.h2inv);
-      st[p] = q[m].rhs - Ax;                          // each lane overwrites only its own TEMP cells: no hazard with the reads of sx
+      const CellRef w = locate(G, gi, gj, gk0 + m * kStepK);
+      vec_origin(L, w.box, e_id)[w.ijk] = sx[p];
+      vec_origin(L, w.box, VECTOR_TEMP)[w.ijk] = st[p];
+      if (kUp && !first) face_store(A.up + (size_t)j * kCellRecords + (size_t)wg * kBrickCells + (size_t)(t + m * kBrickThreads), sx[p], epoch + SEQ_UP + (u64)j);
     }
-    __syncthreads();
-  }
+    if (kUp && !first && t == 0) face_store(A.gate + (size_t)j * kBrickMaxWgs + wg, 0.0, epoch + SEQ_GATE + (u64)j);      // (issued after lane 0's records; the others' may still be on their way: the gate only ends the long wait)
 
-  // ---- leave e and TEMP in global memory as the per-operator sequence would
-#pragma unroll
-  for (int m = 0; m < kBrickPerLane; m++) {
-    const int p = pos0 + m * kStepPos;
-    const CellRef w = locate(G, gi, gj, gk0 + m * kStepK);
-    vec_origin(A.L, w.box, e_id)[w.ijk] = sx[p];
-    vec_origin(A.L, w.box, VECTOR_TEMP)[w.ijk] = st[p];
-  }
-
-  if (kDown) {
-    // restriction(coarse.R <- TEMP): 0.125 * sum of the 8 children in the reference's order (restriction.c:54-57); this brick's 8^3 coarse cells
-    if (t < kBrickCells / 8) {
-      constexpr int H = kBrick / 2;
-      const int ci = t % H, cj = (t / H) % H, ck = t / (H * H);
-      const double *f = st + hpos(2 * ci, 2 * cj, 2 * ck);
-      double v = f[0] + f[1]; v = v + f[kHaloW]; v = v + f[1 + kHaloW]; v = v + f[kHaloPlane]; v = v + f[1 + kHaloPlane]; v = v + f[kHaloW + kHaloPlane];
-      v = v + f[1 + kHaloW + kHaloPlane];
-      const CellRef c = locate(GC, (o_i >> 1) + ci, (o_j >> 1) + cj, (o_k >> 1) + ck);
-      vec_origin(A.C, c.box, A.R_id)[c.ijk] = v * 0.125;
-    }
-    // zero_vector(coarse.e): the whole padded boxes, ghosts included (misc.c:6-44), each workgroup a slice of the flat range
-    if (A.coarse_zero) {
-      const int vol = A.C.volume, total = A.C.num_boxes * vol, per = (total + nwg - 1) / nwg;
-      const int lo = wg * per, hi = (lo + per < total) ? lo + per : total;
-      for (int z = lo + t; z < hi; z += kBrickThreads) {
-        const int box = z / vol;
-        (A.C.box_base[box] + (size_t)e_id * (size_t)vol)[z - box * vol] = 0.0;
+    if (kDown) {
+      // restriction(coarse.R <- TEMP): 0.125 * sum of the 8 children in the reference's order (restriction.c:54-57); this brick's (B/2)^3 coarse cells
+      if (t < kBrickCells / 8) {
+        constexpr int H = kBrick / 2;
+        const int ci = t % H, cj = (t / H) % H, ck = t / (H * H);
+        const double *f = st + hpos(2 * ci, 2 * cj, 2 * ck);
+        double v = f[0] + f[1]; v = v + f[kHaloW]; v = v + f[1 + kHaloW]; v = v + f[kHaloPlane]; v = v + f[1 + kHaloPlane]; v = v + f[kHaloW + kHaloPlane];
+        v = v + f[1 + kHaloW + kHaloPlane];
+        v = v * 0.125;
+        const int qi = (o_i >> 1) + ci, qj = (o_j >> 1) + cj, qk = (o_k >> 1) + ck;
+        const CellRef c = locate(GC, qi, qj, qk);
+        vec_origin(C, c.box, R_id)[c.ijk] = v;
+        if (!last) face_store(A.down + (size_t)(j + 1) * kCellRecords + below_record(qi, qj, qk), v, epoch + SEQ_DOWN + (u64)(j + 1));
+      }
+      // zero_vector(C.e): the whole padded boxes, ghosts included (misc.c:6-44), each workgroup a slice of the flat range.  Not when C is the next level of
+      // this chain (its visit does not read the vector and clears what it does not store itself, below)
+      if (last && A.below_zero) {
+        const int vol = C.volume, total = C.num_boxes * vol, per = (total + nwg - 1) / nwg;
+        const int lo = wg * per, hi = (lo + per < total) ? lo + per : total;
+        for (int z = lo + t; z < hi; z += kBrickThreads) {
+          const int box = z / vol;
+          (C.box_base[box] + (size_t)e_id * (size_t)vol)[z - box * vol] = 0.0;
+        }
+      }
+      if (e_zero) {
+        // the part of zero_vector(this level's e) the stores above do not overwrite: every cell of the padded boxes that is not an interior cell
+        const int vol = L.volume, total = L.num_boxes * vol, per = (total + nwg - 1) / nwg, jS = L.jStride, kS = L.kStride, g = L.ghosts, d = L.dim;
+        const int lo = wg * per, hi = (lo + per < total) ? lo + per : total;
+        for (int z = lo + t; z < hi; z += kBrickThreads) {
+          const int box = z / vol, off = z - box * vol, k = off / kS, r = off - k * kS, jj = r / jS, i = r - jj * jS;
+          if (i >= g && i < g + d && jj >= g && jj < g + d && k >= g && k < g + d) continue;
+          (L.box_base[box] + (size_t)e_id * (size_t)vol)[off] = 0.0;
+        }
       }
     }
-  }
-  if (A.e_zero) {
-    // the part of zero_vector(this level's e) the stores above do not overwrite: every cell of the padded boxes that is not an interior cell
-    const int vol = A.L.volume, total = A.L.num_boxes * vol, per = (total + nwg - 1) / nwg, jS = A.L.jStride, kS = A.L.kStride, g = A.L.ghosts, d = A.L.dim;
-    const int lo = wg * per, hi = (lo + per < total) ? lo + per : total;
-    for (int z = lo + t; z < hi; z += kBrickThreads) {
-      const int box = z / vol, off = z - box * vol, k = off / kS, r = off - k * kS, j = r / jS, i = r - j * jS;
-      if (i >= g && i < g + d && j >= g && j < g + d && k >= g && k < g + d) continue;
-      (A.L.box_base[box] + (size_t)e_id * (size_t)vol)[off] = 0.0;
-    }
+    __syncthreads();                                    // the next level of the chain reuses the LDS arrays
   }
   if (gave_up && A.error) __hip_atomic_store(A.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-static FaceCell *g_faces = nullptr;
+static FaceCell *g_records = nullptr;         // faces | down | up | gate, kBrickMaxLevels of each
 static unsigned *g_error = nullptr;          // pinned host word
 static u64 g_epoch = 0;
 static long long g_visits = 0;
 
-template <int V, int SM, int LEG, int B>
+template <int V, int SM, int DIR, int B>
 static int brick_launch(const BrickArgs &A) {
   static bool once = false;
   const size_t lds = (size_t)2 * BrickGeom<B>::Halo * sizeof(double);
-  if (!once) { HPGMG_CHECK(hipFuncSetAttribute((const void *)brick_visit_kernel<V, SM, LEG, B>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once = true; }
-  hipLaunchKernelGGL((brick_visit_kernel<V, SM, LEG, B>), dim3(A.side * A.side * A.side), dim3(BrickGeom<B>::Threads), lds, g_stream, A);
+  if (!once) { HPGMG_CHECK(hipFuncSetAttribute((const void *)brick_chain_kernel<V, SM, DIR, B>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once = true; }
+  hipLaunchKernelGGL((brick_chain_kernel<V, SM, DIR, B>), dim3(A.lv[0].nwg), dim3(BrickGeom<B>::Threads), lds, g_stream, A);
   return 0;
 }
 template <int V, int SM>
-static int brick_launch_leg(const BrickArgs &A, int leg, int brick) {
-  if (brick == 16) return leg == 0 ? brick_launch<V, SM, 0, 16>(A) : (leg == 1 ? brick_launch<V, SM, 1, 16>(A) : brick_launch<V, SM, 2, 16>(A));
-  return leg == 0 ? brick_launch<V, SM, 0, 8>(A) : (leg == 1 ? brick_launch<V, SM, 1, 8>(A) : brick_launch<V, SM, 2, 8>(A));
+static int brick_launch_dir(const BrickArgs &A, int dir, int brick) {
+  if (brick == 16) return dir == 0 ? brick_launch<V, SM, 0, 16>(A) : (dir == 1 ? brick_launch<V, SM, 1, 16>(A) : brick_launch<V, SM, 2, 16>(A));
+  return dir == 0 ? brick_launch<V, SM, 0, 8>(A) : (dir == 1 ? brick_launch<V, SM, 1, 8>(A) : brick_launch<V, SM, 2, 8>(A));
 }
 
 }  // namespace hpgmg
@@ -309,54 +393,63 @@ using namespace hpgmg;
 extern "C" {
 
 int hpgmg_hip_brick_visit_max_sweeps(void) { return kBrickMaxSweeps; }
-long long hpgmg_hip_brick_visits(void) { return g_visits; }      // launches so far (tests)
+int hpgmg_hip_brick_chain_max_levels(void) { return kBrickMaxLevels; }
+long long hpgmg_hip_brick_visits(void) { return g_visits; }      // level visits so far (tests)
 // 1: a level of dim^3 cells can be visited as bricks of brick^3 cells (brick = 16: 2^3 or 4^3 of them; brick = 8: 2^3 .. 8^3)
 int hpgmg_hip_brick_visit_supported(const hpgmg_hip_level *L, int brick) {
   if (brick != 8 && brick != 16) return 0;
   const int side = L->dim_i / brick, max_side = (brick == 16) ? BrickGeom<16>::MaxSide : BrickGeom<8>::MaxSide;
   return L->dim_i == L->dim_j && L->dim_i == L->dim_k && L->dim_i % brick == 0 && side >= 2 && side <= max_side && L->dim > 0 && L->dim_i % L->dim == 0;
 }
-// 0: fine; 1: a poll of an earlier visit gave up (the results since then are not to be used)
+// 0: fine; 1: a poll of an earlier launch gave up (the results since then are not to be used)
 int hpgmg_hip_brick_visit_error(void) { return (g_error && *(volatile unsigned *)g_error) ? 1 : 0; }
 
-// leg 0: smooth + residual + restriction + zero_vector(coarse e); leg 1: interpolation_vcycle + smooth; leg 2: interpolation_fcycle, then leg 0.
-// c1 / c2: the level's Chebyshev coefficients.
-int hpgmg_hip_brick_visit(const hpgmg_hip_level *L, const hpgmg_hip_level *C, double h2inv, const double *c1, const double *c2, int sweeps,
-                          int variant, int smoother, int e_id, int R_id, double a, double b, int leg, int brick, int e_zero, int coarse_zero) {
-  if (g_skip_launches) return record_error(hipErrorInvalidValue, "brick_visit: not replayable (the launch number is a kernel argument)");
-  if (!hpgmg_hip_brick_visit_supported(L, brick) || sweeps < 1 || sweeps > kBrickMaxSweeps || (sweeps & 1) || leg < 0 || leg > 2 || 2 * C->dim_i != L->dim_i)
-    return record_error(hipErrorInvalidValue, "brick_visit: level / sweeps / leg");
-  if (!g_faces) {
-    HPGMG_CHECK(hipMalloc((void **)&g_faces, kFaceRecords * sizeof(FaceCell)));
-    HPGMG_CHECK(hipMemset(g_faces, 0, kFaceRecords * sizeof(FaceCell)));
+int hpgmg_hip_brick_chain(int n, const hpgmg_hip_brick_level *levels, const hpgmg_hip_level *below, int sweeps, int variant, int smoother,
+                          int e_id, int R_id, double a, double b, int dir, int brick, int top_e_zero, int below_zero) {
+  if (g_skip_launches) return record_error(hipErrorInvalidValue, "brick_chain: not replayable (the launch number is a kernel argument)");
+  if (n < 1 || n > kBrickMaxLevels || sweeps < 1 || sweeps > kBrickMaxSweeps || (sweeps & 1) || dir < 0 || dir > 2 || (dir == 2 && n != 1))
+    return record_error(hipErrorInvalidValue, "brick_chain: levels / sweeps / direction");
+  for (int j = 0; j < n; j++) {
+    const hpgmg_hip_level *next = (j + 1 < n) ? &levels[j + 1].L : below;
+    if (!hpgmg_hip_brick_visit_supported(&levels[j].L, brick) || 2 * next->dim_i != levels[j].L.dim_i) return record_error(hipErrorInvalidValue, "brick_chain: level");
+  }
+  if (!g_records) {
+    const size_t records = (size_t)kBrickMaxLevels * (kFaceRecords + 2 * kCellRecords + kBrickMaxWgs);
+    HPGMG_CHECK(hipMalloc((void **)&g_records, records * sizeof(FaceCell)));
+    HPGMG_CHECK(hipMemset(g_records, 0, records * sizeof(FaceCell)));
     HPGMG_CHECK(hipHostMalloc((void **)&g_error, 64, hipHostMallocDefault));
     *g_error = 0;
     HPGMG_CHECK(hipDeviceSynchronize());
   }
   BrickArgs A = {};
-  A.L = *L; A.C = *C; A.h2inv = h2inv; A.a = a; A.b = b; A.sweeps = sweeps; A.e_id = e_id; A.R_id = R_id;
-  for (int s = 0; s < sweeps; s++) { A.c1[s] = c1 ? c1[s] : 0.0; A.c2[s] = c2 ? c2[s] : 0.0; }
-  A.side = L->dim_i / brick;
-  A.e_zero = (leg == 0 && e_zero) ? 1 : 0; A.coarse_zero = coarse_zero ? 1 : 0;
-  A.faces = g_faces; A.error = g_error;
+  for (int j = 0; j < n; j++) {
+    A.lv[j].L = levels[j].L; A.lv[j].h2inv = levels[j].h2inv;
+    for (int s = 0; s < sweeps; s++) { A.lv[j].c1[s] = levels[j].c1[s]; A.lv[j].c2[s] = levels[j].c2[s]; }
+    A.lv[j].side = levels[j].L.dim_i / brick; A.lv[j].nwg = A.lv[j].side * A.lv[j].side * A.lv[j].side;
+  }
+  A.C = *below; A.n = n; A.a = a; A.b = b; A.sweeps = sweeps; A.e_id = e_id; A.R_id = R_id;
+  A.top_e_zero = (dir == 0 && top_e_zero) ? 1 : 0; A.below_zero = below_zero ? 1 : 0;
+  A.faces = g_records; A.down = A.faces + (size_t)kBrickMaxLevels * kFaceRecords; A.up = A.down + (size_t)kBrickMaxLevels * kCellRecords;
+  A.gate = A.up + (size_t)kBrickMaxLevels * kCellRecords;
+  A.error = g_error;
   g_epoch += 64; A.epoch = g_epoch;
   int rc;
   const int key = variant * 3 + smoother;
   switch (key) {
-    case HPGMG_HIP_7PT_VC_HELMHOLTZ * 3 + BV_CHEBY:  rc = brick_launch_leg<HPGMG_HIP_7PT_VC_HELMHOLTZ, BV_CHEBY>(A, leg, brick); break;
-    case HPGMG_HIP_7PT_VC_HELMHOLTZ * 3 + BV_GSRB:   rc = brick_launch_leg<HPGMG_HIP_7PT_VC_HELMHOLTZ, BV_GSRB>(A, leg, brick); break;
-    case HPGMG_HIP_7PT_VC_HELMHOLTZ * 3 + BV_JACOBI: rc = brick_launch_leg<HPGMG_HIP_7PT_VC_HELMHOLTZ, BV_JACOBI>(A, leg, brick); break;
-    case HPGMG_HIP_7PT_VC_POISSON * 3 + BV_CHEBY:    rc = brick_launch_leg<HPGMG_HIP_7PT_VC_POISSON, BV_CHEBY>(A, leg, brick); break;
-    case HPGMG_HIP_7PT_VC_POISSON * 3 + BV_GSRB:     rc = brick_launch_leg<HPGMG_HIP_7PT_VC_POISSON, BV_GSRB>(A, leg, brick); break;
-    case HPGMG_HIP_7PT_VC_POISSON * 3 + BV_JACOBI:   rc = brick_launch_leg<HPGMG_HIP_7PT_VC_POISSON, BV_JACOBI>(A, leg, brick); break;
-    case HPGMG_HIP_7PT_CC * 3 + BV_CHEBY:            rc = brick_launch_leg<HPGMG_HIP_7PT_CC, BV_CHEBY>(A, leg, brick); break;
-    case HPGMG_HIP_7PT_CC * 3 + BV_GSRB:             rc = brick_launch_leg<HPGMG_HIP_7PT_CC, BV_GSRB>(A, leg, brick); break;
-    case HPGMG_HIP_7PT_CC * 3 + BV_JACOBI:           rc = brick_launch_leg<HPGMG_HIP_7PT_CC, BV_JACOBI>(A, leg, brick); break;
-    default: return record_error(hipErrorInvalidValue, "brick_visit: variant / smoother");
+    case HPGMG_HIP_7PT_VC_HELMHOLTZ * 3 + BV_CHEBY:  rc = brick_launch_dir<HPGMG_HIP_7PT_VC_HELMHOLTZ, BV_CHEBY>(A, dir, brick); break;
+    case HPGMG_HIP_7PT_VC_HELMHOLTZ * 3 + BV_GSRB:   rc = brick_launch_dir<HPGMG_HIP_7PT_VC_HELMHOLTZ, BV_GSRB>(A, dir, brick); break;
+    case HPGMG_HIP_7PT_VC_HELMHOLTZ * 3 + BV_JACOBI: rc = brick_launch_dir<HPGMG_HIP_7PT_VC_HELMHOLTZ, BV_JACOBI>(A, dir, brick); break;
+    case HPGMG_HIP_7PT_VC_POISSON * 3 + BV_CHEBY:    rc = brick_launch_dir<HPGMG_HIP_7PT_VC_POISSON, BV_CHEBY>(A, dir, brick); break;
+    case HPGMG_HIP_7PT_VC_POISSON * 3 + BV_GSRB:     rc = brick_launch_dir<HPGMG_HIP_7PT_VC_POISSON, BV_GSRB>(A, dir, brick); break;
+    case HPGMG_HIP_7PT_VC_POISSON * 3 + BV_JACOBI:   rc = brick_launch_dir<HPGMG_HIP_7PT_VC_POISSON, BV_JACOBI>(A, dir, brick); break;
+    case HPGMG_HIP_7PT_CC * 3 + BV_CHEBY:            rc = brick_launch_dir<HPGMG_HIP_7PT_CC, BV_CHEBY>(A, dir, brick); break;
+    case HPGMG_HIP_7PT_CC * 3 + BV_GSRB:             rc = brick_launch_dir<HPGMG_HIP_7PT_CC, BV_GSRB>(A, dir, brick); break;
+    case HPGMG_HIP_7PT_CC * 3 + BV_JACOBI:           rc = brick_launch_dir<HPGMG_HIP_7PT_CC, BV_JACOBI>(A, dir, brick); break;
+    default: return record_error(hipErrorInvalidValue, "brick_chain: variant / smoother");
   }
   if (rc) return rc;
-  HPGMG_LAUNCH_CHECK("brick_visit_kernel");
-  g_visits++;
+  HPGMG_LAUNCH_CHECK("brick_chain_kernel");
+  g_visits += n;
   return 0;
 }
 

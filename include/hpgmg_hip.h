@@ -369,22 +369,27 @@ int hpgmg_hip_vcycle_tail(int n, const hpgmg_hip_level *const *levels, const dou
                           int variant, int smoother, int e_id, int R_id, double a, double b, int leg,
                           int krylov_base, double bottom_norm, int *krylov_iterations);
 
-/* ---- brick_visit.hip: one visit of a launch-bound level ABOVE the tail's reach (32^3, 64^3 cells) as ONE launch: the level as bricks of 8^3 or
- *      16^3 cells, a workgroup each, iterate in LDS, coefficients in registers; between sweeps the bricks trade faces through memory inside the
- *      launch ({value, sequence number} records, written through and polled: one memory hop, 1.6 us).  Replaces the 5 + 4 launches of
- *      mg.c:1147-1153 (smooth, residual, restriction, zero_vector) and mg.c:1160-1161 (interpolation_vcycle, smooth).  Every face neighbour local,
- *      Dirichlet, cubic domain, boxes in lexicographic order (as for the tail).  Not capturable in a hipGraph. ---- */
+/* ---- brick_visit.hip: the visits of the launch-bound levels ABOVE the tail's reach (16^3 .. 64^3 cells) -- each level as bricks of 8^3 or 16^3 cells, a
+ *      workgroup each, iterate in LDS, coefficients in registers; between sweeps the bricks trade faces through memory inside the launch ({value,
+ *      sequence number} records, written through and polled: one memory hop, 1.6 us), and so do the levels of a chain (restricted residuals on the
+ *      way down, corrections on the way up).  Replaces, per level visit, the 5 + 4 launches of mg.c:1147-1153 (smooth, residual, restriction,
+ *      zero_vector) and mg.c:1160-1161 (interpolation_vcycle, smooth).  Every face neighbour local, Dirichlet, cubic domain, boxes in lexicographic
+ *      order (as for the tail).  Not capturable in a hipGraph. ---- */
+typedef struct { hpgmg_hip_level L; double h2inv, c1[8], c2[8]; } hpgmg_hip_brick_level;      /* c1 / c2: the level's Chebyshev coefficients per sweep */
 int hpgmg_hip_brick_visit_supported(const hpgmg_hip_level *L, int brick);      /* 1: dim_i^3 cells = 2^3 or 4^3 bricks of 16^3 cells (brick = 16), 2^3 .. 8^3 bricks of 8^3 (brick = 8) */
 int hpgmg_hip_brick_visit_max_sweeps(void);
-/* leg 0: smooth, residual -> VECTOR_TEMP, restriction(C.R_id <- TEMP), zero_vector(C.e_id);  leg 1: e += P C.e (piecewise constant), smooth;
- * leg 2: interpolation_fcycle (e = 0.0 e + P1 C.e, interpolation_p1.c:40-70 with the coarse ghost cells of apply_BCs_p1 formed on the fly), then leg 0.
- * c1 / c2: the Chebyshev coefficients of L's `sweeps` sweeps (ignored by the other smoothers).
- * e_zero (leg 0): e counts as +0.0 and is not read -- zero_vector(L.e) is completed HERE (the ghost zone and padding; the interior is stored at the end anyway);
- * coarse_zero (legs 0, 2): 1 = zero_vector(C.e) at the end, 0 = left to the launch that visits C with e_zero (leg 2 must: every brick reads C.e). */
-int hpgmg_hip_brick_visit(const hpgmg_hip_level *L, const hpgmg_hip_level *C, double h2inv, const double *c1, const double *c2, int sweeps,
-                          int variant, int smoother, int e_id, int R_id, double a, double b, int leg, int brick, int e_zero, int coarse_zero);
-long long hpgmg_hip_brick_visits(void);      /* launches so far (tests) */
-int hpgmg_hip_brick_visit_error(void);       /* 1: a face poll of an earlier visit gave up after 2 s (a workgroup of the launch was not running): results are void */
+int hpgmg_hip_brick_chain_max_levels(void);
+/* ONE launch for the chain levels[0 .. n-1] (finest first; `below` = the level under levels[n-1]).
+ * dir 0 (down): per level smooth, residual -> VECTOR_TEMP, restriction(next.R_id <- TEMP); levels[1..] start from a zero correction (mg.c:1153) and get
+ *   their right-hand side from the level above inside the launch.  top_e_zero: levels[0].e counts as +0.0 too and is not read (its zero_vector is completed
+ *   here: ghost zone and padding; the interior is stored at the end anyway); below_zero: zero_vector(below.e) at the end.
+ * dir 1 (up): coarsest level first: e += P next.e (piecewise constant), smooth; levels[n-1] reads `below`, every finer level waits for the one under it.
+ * dir 2 (n == 1): interpolation_fcycle (e = 0.0 e + P1 below.e, interpolation_p1.c:40-70, the ghost cells of apply_BCs_p1 formed on the fly), then dir 0 --
+ *   every brick reads below.e, so below_zero must be 0 and the launch that visits `below` clears it (top_e_zero). */
+int hpgmg_hip_brick_chain(int n, const hpgmg_hip_brick_level *levels, const hpgmg_hip_level *below, int sweeps, int variant, int smoother,
+                          int e_id, int R_id, double a, double b, int dir, int brick, int top_e_zero, int below_zero);
+long long hpgmg_hip_brick_visits(void);      /* level visits so far (tests) */
+int hpgmg_hip_brick_visit_error(void);       /* 1: a poll of an earlier launch gave up after 2 s (a workgroup of the launch was not running): results are void */
 
 /* ---- hipGraph segments (graph.hip): capture/replay of the launch-bound small-level part of a cycle.
  *      begin(key): first use of a key runs eagerly, second is captured, later ones are replayed

@@ -16,7 +16,8 @@ typedef unsigned __attribute__((ext_vector_type(4))) u4;
 
 __device__ __forceinline__ void store16_sc1(Cell *p, double v, u64 seq) {
   u4 w; w.x = (unsigned)__double_as_longlong(v); w.y = (unsigned)(__double_as_longlong(v) >> 32); w.z = (unsigned)seq; w.w = (unsigned)(seq >> 32);
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(w) : "memory");
+  // (s_nop: the data registers of a > 8-byte store must not be written by the VALU in the cycles after issue; the compiler cannot pad an asm store itself)
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 3" :: "v"(p), "v"(w) : "memory");
 }
 __device__ __forceinline__ Cell load16_sc1(const Cell *p) {
   u4 w;
