@@ -134,6 +134,8 @@ __global__ __launch_bounds__(BrickGeom<B>::Threads, (B == 8) ? 6 : 4) void brick
   constexpr bool kUp = (DIR == DIR_UP), kDown = (DIR != DIR_UP), kFInterp = (DIR == DIR_FDOWN);
   extern __shared__ double brick_lds[];
   double *const sx = brick_lds, *const st = brick_lds + kHaloCells;
+  constexpr int kCW = kBrick / 2 + 2;                 // interpolation_fcycle: the brick's coarse cells with a ring of one, (B/2 + 2)^3 doubles behind the two arrays
+  double *const sc = brick_lds + 2 * kHaloCells;
   const int t = (int)threadIdx.x, wg = (int)blockIdx.x, e_id = A.e_id, R_id = A.R_id, n = A.n;
   const u64 epoch = A.epoch;
   const u64 t0 = __builtin_amdgcn_s_memrealtime();
@@ -175,27 +177,19 @@ __global__ __launch_bounds__(BrickGeom<B>::Threads, (B == 8) ? 6 : 4) void brick
         return 1.0 * stored + parent;
       }
       if (kFInterp) {          // interpolation_fcycle, piecewise linear (interpolation_p1.c:40-70): f = 0.0 f + 27/64 c + 9/64 (3 face neighbours) + 3/64 (3 edge
-        // neighbours) + 1/64 corner, an even fine cell leaning on the coarse neighbour behind it, an odd one on the one ahead.  A coarse ghost cell is -, +, -
-        // its mirror image for 1, 2, 3 directions leaving the domain (exchange_boundary + apply_BCs_p1, BOX shape, boundary_fd.c:35-38), formed here.
-        const int Dc = C.dim_i;
-        auto coarse = [&](int qi, int qj, int qk) -> double {
-          double sg = 1.0;
-          if (qi < 0) { qi = 0; sg = -sg; } else if (qi >= Dc) { qi = Dc - 1; sg = -sg; }
-          if (qj < 0) { qj = 0; sg = -sg; } else if (qj >= Dc) { qj = Dc - 1; sg = -sg; }
-          if (qk < 0) { qk = 0; sg = -sg; } else if (qk >= Dc) { qk = Dc - 1; sg = -sg; }
-          const CellRef r = locate(GC, qi, qj, qk);
-          return sg * vec_origin(C, r.box, e_id)[r.ijk];
-        };
-        const int qi = ci >> 1, qj = cj >> 1, qk = ck >> 1, di = (ci & 1) ? 1 : -1, dj = (cj & 1) ? 1 : -1, dk = (ck & 1) ? 1 : -1;
+        // neighbours) + 1/64 corner, an even fine cell leaning on the coarse neighbour behind it, an odd one on the one ahead; the coarse values wait in LDS (sc)
+        const int qi = (ci >> 1) - (o_i >> 1) + 1, qj = (cj >> 1) - (o_j >> 1) + 1, qk = (ck >> 1) - (o_k >> 1) + 1;      // position in sc
+        const int di = (ci & 1) ? 1 : -1, dj = (cj & 1) ? kCW : -kCW, dk = (ck & 1) ? kCW * kCW : -kCW * kCW;
+        const double *c0 = sc + qi + kCW * (qj + kCW * qk);
         double v = 0.0 * stored;
-        v = v + 0.421875 * coarse(qi, qj, qk);
-        v = v + 0.140625 * coarse(qi, qj, qk + dk);
-        v = v + 0.140625 * coarse(qi, qj + dj, qk);
-        v = v + 0.046875 * coarse(qi, qj + dj, qk + dk);
-        v = v + 0.140625 * coarse(qi + di, qj, qk);
-        v = v + 0.046875 * coarse(qi + di, qj, qk + dk);
-        v = v + 0.046875 * coarse(qi + di, qj + dj, qk);
-        v = v + 0.015625 * coarse(qi + di, qj + dj, qk + dk);
+        v = v + 0.421875 * c0[0];
+        v = v + 0.140625 * c0[dk];
+        v = v + 0.140625 * c0[dj];
+        v = v + 0.046875 * c0[dj + dk];
+        v = v + 0.140625 * c0[di];
+        v = v + 0.046875 * c0[di + dk];
+        v = v + 0.046875 * c0[di + dj];
+        v = v + 0.015625 * c0[di + dj + dk];
         return v;
       }
       return stored;
@@ -204,22 +198,44 @@ __global__ __launch_bounds__(BrickGeom<B>::Threads, (B == 8) ? 6 : 4) void brick
     // ---- the brick: what is stored of the iterate, VECTOR_TEMP, coefficients (every load is in flight before anything is waited for)
     CellCoef<V> q[kBrickPerLane];
     double e_st[kBrickPerLane];
+    auto load_coefficients = [&]() {
+#pragma unroll
+      for (int m = 0; m < kBrickPerLane; m++) {
+        const CellRef w = locate(G, gi, gj, gk0 + m * kStepK);
+        const int box = w.box, ijk = w.ijk, jS = L.jStride, kS = L.kStride;
+        q[m].rhs = rhs_by_record ? 0.0 : vec_origin(L, box, R_id)[ijk];
+        q[m].dinv = vec_origin(L, box, VECTOR_DINV)[ijk];
+        q[m].bi0 = q[m].bi1 = q[m].bj0 = q[m].bj1 = q[m].bk0 = q[m].bk1 = q[m].al = 0.0;
+        if (kVC) {
+          const double *bi = vec_origin(L, box, VECTOR_BETA_I), *bj = vec_origin(L, box, VECTOR_BETA_J), *bk = vec_origin(L, box, VECTOR_BETA_K);
+          q[m].bi0 = bi[ijk]; q[m].bi1 = bi[ijk + 1]; q[m].bj0 = bj[ijk]; q[m].bj1 = bj[ijk + jS]; q[m].bk0 = bk[ijk]; q[m].bk1 = bk[ijk + kS];
+        }
+        if (kHelm) q[m].al = vec_origin(L, box, VECTOR_ALPHA)[ijk];
+      }
+    };
 #pragma unroll
     for (int m = 0; m < kBrickPerLane; m++) {
-      const int p = pos0 + m * kStepPos, gk = gk0 + m * kStepK;
-      const CellRef w = locate(G, gi, gj, gk);
-      const int box = w.box, ijk = w.ijk, jS = L.jStride, kS = L.kStride;
-      e_st[m] = e_zero ? 0.0 : vec_origin(L, box, e_id)[ijk];
-      st[p] = vec_origin(L, box, VECTOR_TEMP)[ijk];
-      q[m].rhs = rhs_by_record ? 0.0 : vec_origin(L, box, R_id)[ijk];
-      q[m].dinv = vec_origin(L, box, VECTOR_DINV)[ijk];
-      q[m].bi0 = q[m].bi1 = q[m].bj0 = q[m].bj1 = q[m].bk0 = q[m].bk1 = q[m].al = 0.0;
-      if (kVC) {
-        const double *bi = vec_origin(L, box, VECTOR_BETA_I), *bj = vec_origin(L, box, VECTOR_BETA_J), *bk = vec_origin(L, box, VECTOR_BETA_K);
-        q[m].bi0 = bi[ijk]; q[m].bi1 = bi[ijk + 1]; q[m].bj0 = bj[ijk]; q[m].bj1 = bj[ijk + jS]; q[m].bk0 = bk[ijk]; q[m].bk1 = bk[ijk + kS];
-      }
-      if (kHelm) q[m].al = vec_origin(L, box, VECTOR_ALPHA)[ijk];
+      const int p = pos0 + m * kStepPos;
+      const CellRef w = locate(G, gi, gj, gk0 + m * kStepK);
+      e_st[m] = e_zero ? 0.0 : vec_origin(L, w.box, e_id)[w.ijk];
+      st[p] = vec_origin(L, w.box, VECTOR_TEMP)[w.ijk];
     }
+    if (kFInterp) {
+      // the coarse cells this brick's interpolation reads: its (B/2)^3 parents and a ring of one.  A coarse ghost cell is -, +, - its mirror image for 1, 2, 3
+      // directions leaving the domain (exchange_boundary + apply_BCs_p1, BOX shape, boundary_fd.c:35-38), formed here
+      const int Dc = C.dim_i;
+      for (int idx = t; idx < kCW * kCW * kCW; idx += kBrickThreads) {
+        int qi = (o_i >> 1) - 1 + idx % kCW, qj = (o_j >> 1) - 1 + (idx / kCW) % kCW, qk = (o_k >> 1) - 1 + idx / (kCW * kCW);
+        double sg = 1.0;
+        if (qi < 0) { qi = 0; sg = -sg; } else if (qi >= Dc) { qi = Dc - 1; sg = -sg; }
+        if (qj < 0) { qj = 0; sg = -sg; } else if (qj >= Dc) { qj = Dc - 1; sg = -sg; }
+        if (qk < 0) { qk = 0; sg = -sg; } else if (qk >= Dc) { qk = Dc - 1; sg = -sg; }
+        const CellRef r = locate(GC, qi, qj, qk);
+        sc[idx] = sg * vec_origin(C, r.box, e_id)[r.ijk];
+      }
+      __syncthreads();
+    }
+    if (!kFInterp) load_coefficients();      // (interpolation_fcycle: after the start values -- its eight coarse loads per cell and the coefficients do not fit the registers together)
     // the stored iterate beyond the faces (the neighbouring bricks' cells as EARLIER launches left them); lane roles for everything on faces:
     // cell fc = (f B + v) B + u of the 6 B^2 face cells
     constexpr int kHaloPerLane = (6 * kFaceCells + kBrickThreads - 1) / kBrickThreads;
@@ -249,6 +265,7 @@ __global__ __launch_bounds__(BrickGeom<B>::Threads, (B == 8) ? 6 : 4) void brick
       sx[p] = start_value(e_st[m], gi, gj, gk);
       if (rhs_by_record) q[m].rhs = record_wait(A.down + (size_t)j * kCellRecords + (size_t)wg * kBrickCells + (size_t)(t + m * kBrickThreads), epoch + SEQ_DOWN + (u64)j, t0, gave_up);
     }
+    if (kFInterp) __builtin_amdgcn_sched_barrier(0);      // (the eight coarse loads of a cell's interpolation, twice over, are more than the register budget holds at once)
 #pragma unroll
     for (int hm = 0; hm < kHaloPerLane; hm++) {
       const int fc = t + hm * kBrickThreads;
@@ -260,6 +277,7 @@ __global__ __launch_bounds__(BrickGeom<B>::Threads, (B == 8) ? 6 : 4) void brick
       if (hi < 0 || hi >= D || hj < 0 || hj >= D || hk < 0 || hk >= D) continue;
       sx[hpos(li, lj, lk)] = e_zero ? 0.0 : start_value(h_st[hm], hi, hj, hk);
     }
+    if (kFInterp) { __builtin_amdgcn_sched_barrier(0); load_coefficients(); }
     __syncthreads();
 
     // ---- smooth(): chebyshev.c:43-99 / gsrb.c:24-132 / jacobi.c:17-62 (an even number of sweeps: the result ends in sx)
@@ -376,7 +394,7 @@ static long long g_visits = 0;
 template <int V, int SM, int DIR, int B>
 static int brick_launch(const BrickArgs &A) {
   static bool once = false;
-  const size_t lds = (size_t)2 * BrickGeom<B>::Halo * sizeof(double);
+  const size_t lds = ((size_t)2 * BrickGeom<B>::Halo + (DIR == DIR_FDOWN ? (size_t)(B / 2 + 2) * (B / 2 + 2) * (B / 2 + 2) : 0)) * sizeof(double);
   if (!once) { HPGMG_CHECK(hipFuncSetAttribute((const void *)brick_chain_kernel<V, SM, DIR, B>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once = true; }
   hipLaunchKernelGGL((brick_chain_kernel<V, SM, DIR, B>), dim3(A.lv[0].nwg), dim3(BrickGeom<B>::Threads), lds, g_stream, A);
   return 0;
