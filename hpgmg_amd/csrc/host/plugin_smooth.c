@@ -106,6 +106,7 @@ void hpgmg_set_fused_tail(int on) { hp_switch_set(SW_FUSED_TAIL, on ? 1 : 0); } 
 void hpgmg_set_fused_bottom(int on) { hp_switch_set(SW_FUSED_BOTTOM, on ? 1 : 0); }  /* tests: 0 = the bottom solve driven from the host (host/solvers.c BiCGStab through the operators) */
 void hpgmg_set_brick_visits(int on) { hp_switch_set(SW_BRICK_VISITS, on ? 1 : 0); if (on == 8 || on == 16) hp_switch_set(SW_BRICK_SIZE, on); }      /* 0 off, 1 on, 8 / 16: on with bricks of that side */
 long long hpgmg_brick_visits(void) { return hpgmg_hip_brick_visits(); }
+void hpgmg_set_brick_chains(int on) { hp_switch_set(SW_BRICK_CHAIN, on ? 1 : 0); }      /* 0: one launch per level visit instead of one per V-cycle leg (tests) */
 /* what the kernels that address cells by global coordinate need of a level (tail.hip, brick_visit.hip): a cubic Dirichlet domain whose boxes are all
  * here, all faces local, local box b at lexicographic position b */
 static int dense_level_ok(level_type *L) {

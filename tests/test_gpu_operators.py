@@ -311,10 +311,10 @@ def test_residual_restriction_zero_as_one_launch_on_small_boxes(hip, oracle, var
 @pytest.mark.parametrize("variant,geom", [("7pt-cheby-helm", (2, 32)), ("7pt-cheby-helm", (1, 64)), ("7pt-cheby", (4, 16)), ("7ptcc-cheby", (2, 32)), ("7pt-gsrb", (2, 32)),
                                           ("7pt-jacobi", (1, 64)), ("7pt-cheby-helm", (2, 16)), ("7pt-gsrb", (1, 32)), ("7pt-cheby", (4, 8)), ("7ptcc-cheby", (8, 8)),
                                           ("7pt-jacobi", (2, 16)), ("7pt-gsrb", (8, 4)), ("7pt-cheby-helm", (2, 8)), ("7pt-gsrb", (1, 16)), ("7ptcc-cheby", (4, 4))])
-@pytest.mark.parametrize("brick", [8, 16])
-def test_level_visits_as_one_launch_of_bricks(hip, oracle, variant, geom, brick):
-    """kernels/brick_visit.hip: MGVCycle (mg.c:1133-1166) from a level of 64^3 or 32^3 cells -- every visit of the levels above the single-workgroup tail
-    is ONE launch (bricks of 16^3 cells, a workgroup each, trading faces inside the launch).  Every vector of every level must be, byte for byte, what the
+@pytest.mark.parametrize("brick,chains", [(8, 1), (16, 1), (8, 0)])
+def test_level_visits_as_one_launch_of_bricks(hip, oracle, variant, geom, brick, chains):
+    """kernels/brick_visit.hip: MGVCycle (mg.c:1133-1166) from a level of 64^3, 32^3 or 16^3 cells -- the visits of the levels above the single-workgroup tail
+    are ONE launch per V-cycle leg (bricks of 8^3 / 16^3 cells, a workgroup each, trading faces, restricted residuals and corrections inside the launch).  Every vector of every level must be, byte for byte, what the
     oracle's operator-by-operator cycle leaves: the iterate, the right-hand sides restricted on the way down, VECTOR_TEMP (the residual on the way down,
     the smoother's partner on the way up) and the zeroed corrections' ghost cells."""
     from hpgmg_testlib import Level
@@ -340,6 +340,8 @@ def test_level_visits_as_one_launch_of_bricks(hip, oracle, variant, geom, brick)
         L.hpgmg_brick_visits.restype = ctypes.c_longlong
         L.hpgmg_set_brick_visits.argtypes = [ctypes.c_int]
         L.hpgmg_set_brick_visits(brick)
+        L.hpgmg_set_brick_chains.argtypes = [ctypes.c_int]
+        L.hpgmg_set_brick_chains(chains)          # 1: the levels of a V-cycle leg in ONE launch (what passes between them passes inside it); 0: a launch per level
         for be in (bh, bo):
             be.lib.MGVCycle.restype = None
             be.lib.MGVCycle.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_int]
@@ -407,6 +409,7 @@ def test_level_visits_as_one_launch_of_bricks(hip, oracle, variant, geom, brick)
                 same(lv(bh, mh, l), lv(bo, mo, l), [H.VECTOR_U, H.VECTOR_F], interior_only=True)
         finally:
             L.hpgmg_set_brick_visits(8)
+            L.hpgmg_set_brick_chains(1)
     finally:
         for be, f, m, _, _ in pairs:
             be.lib.hpgmg_mg_destroy(m); f.destroy()
