@@ -415,6 +415,16 @@ def test_level_visits_as_one_launch_of_bricks(hip, oracle, variant, geom, brick,
             be.lib.hpgmg_mg_destroy(m); f.destroy()
 
 
+def test_brick_launches_repeat_bit_for_bit():
+    """tools/stress_bricks.py: the same V-cycle / FMGSolve step from 64^3 and 32^3 levels repeated on the same input -- every repetition must leave the same bytes
+    on every level.  What crosses workgroups inside a brick launch is polled, so a torn, stale or lost record would show here as a difference that depends on timing
+    (the longer hunt: `python tools/stress_bricks.py 300`; profiles/r05h_stress_bricks.log)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_bricks.py"), "12", "7pt-cheby-helm"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "DIFFERENT" not in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 @pytest.mark.parametrize("variant,geom", [("7pt-cheby-helm", (2, 128)), ("7pt-gsrb", (1, 128)), ("7ptcc-cheby", (1, 256)),
                                           ("27pt-gsrb", (2, 64)), ("fv4-gsrb", (2, 64)), ("fv4-gsrb", (3, 32)), ("27pt-cheby", (1, 128))])
 def test_fused_residual_forms(hip, oracle, variant, geom):
