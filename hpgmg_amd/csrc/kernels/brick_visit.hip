@@ -1,27 +1,32 @@
-// brick_visit.hip -- one visit of a LAUNCH-BOUND level of MGVCycle (mg.c:1147-1163) as ONE launch: the level cut into bricks of 16^3 cells, one
-// workgroup of 1024 lanes per brick (64^3: 64 workgroups, 32^3: 8), the brick's iterate and VECTOR_TEMP in LDS with a one-cell halo, its
-// coefficients in registers (4 cells per lane) -- tail.hip's scheme, on more than one CU.
-//   leg 0 (down):  smooth; residual -> TEMP; restriction(coarse.R <- TEMP); zero_vector(coarse.e)
-//   leg 1 (up):    interpolation_vcycle (e += P coarse.e, piecewise constant); smooth
-//   leg 2:         interpolation_fcycle (e = 0.0 e + P1 coarse.e, piecewise linear, the coarse ghost cells of apply_BCs_p1 formed on the fly), then leg 0 -- the
-//                  step of FMGSolve (mg.c:1289-1293) that opens a V-cycle: its exchange + boundary + interpolation launches ride in the load of the visit
-// i.e. the 5 + 4 launches of ~5 us each the per-operator path issues for the visit (4 sweeps of 1.3 MB each are not what they cost: a launch
+// brick_visit.hip -- the visits of the LAUNCH-BOUND levels of MGVCycle (mg.c:1147-1163: 64^3, 32^3, 16^3 cells) as ONE launch per V-cycle leg.
+// A level is cut into bricks of 8^3 cells, one workgroup of 512 lanes per brick (64^3: 512 workgroups, 32^3: 64, 16^3: 8; level j of a chain is worked on
+// by workgroups 0 .. n_j - 1), the brick's iterate and VECTOR_TEMP in LDS with a one-cell halo, its coefficients in registers -- tail.hip's scheme on more
+// than one CU.  (Bricks of 16^3 cells, 1024 lanes, four cells per lane also exist: a sweep of 4096 cells is ~3 us of fp64 issue on ONE CU, so they lose.)
+//   DOWN   per level:  smooth; residual -> TEMP; restriction(next.R <- TEMP); zero_vector(next.e)
+//   UP     per level, coarsest first:  interpolation_vcycle (e += P next.e, piecewise constant); smooth
+//   FDOWN  (one level) interpolation_fcycle (e = 0.0 e + P1 next.e, piecewise linear, the coarse ghost cells of apply_BCs_p1 formed on the fly), then DOWN --
+//          the step of FMGSolve (mg.c:1289-1293) that opens a V-cycle: its exchange + boundary + interpolation launches ride in the load of the visit
+// i.e. per level visit the 5 + 4 launches of ~5 us each that the per-operator path issues (4 sweeps of 1.3 MB each are not what they cost: a launch
 // boundary and one memory round trip per sweep are).
 //
-// Between sweeps the bricks exchange their faces THROUGH MEMORY WITHOUT LEAVING THE KERNEL.  The XCDs' L2 caches are not coherent with each other
-// inside a kernel, so a face cell travels as a 16-byte record {value, sequence number} written through (sc1) by the lane that owns the cell and
-// polled (sc1 loads) by the lane that needs it: the record is its own flag -- one memory hop per exchange, no counter everybody adds to, no
-// fence.  tools/microbench/p2p_flags.hip: 1.6 us per exchange for 8 .. 64 workgroups, against 3.1-3.3 us for a kernel boundary around the
-// same traffic, 2.4-3.2 for data + flag, 5.7-18 for a central counter (what grid.sync() is).  Records are double-buffered by exchange parity: a
-// brick can publish exchange n only after it has read all its neighbours' exchange n-1, which they published after reading n-2 -- the slot of
-// parity n is free.  Sequence numbers never repeat (launch epoch x 64 + exchange), so records of earlier launches never match.
-// Every other global access is of the ordinary kind and obeys one rule: within a launch an address is written by ONE workgroup only and never
-// read by another (the halo of the first sweep comes from what EARLIER launches stored).
-// All workgroups of the launch must be resident at once (<= 64 of 1024 lanes on 256 CUs: they are, unless other processes' launches of this
-// kind fill the GPU -- hpgmg_hip_brick_visit_supported / HPGMG_BRICK_VISITS=0); a poll gives up after 2 s and raises the error flag the host
-// checks at its next synchronisation, so a mistake here ends as an abort with a message, not as a hung GPU.
+// Everything that crosses a workgroup boundary INSIDE the launch -- faces between sweeps, the restricted residuals a level hands to the one below it, the
+// corrections it hands to the one above -- goes THROUGH MEMORY WITHOUT LEAVING THE KERNEL.  The XCDs' L2 caches are not coherent with each other inside a
+// kernel, so a cell travels as a 16-byte record {value, sequence number} written through (sc1) by the lane that owns the cell and polled (sc1 loads) by the
+// lane that needs it: the record is its own flag -- one memory hop, no counter everybody adds to, no fence.  tools/microbench/p2p_flags.hip: 1.6 us per
+// exchange for 8 .. 64 workgroups, 2.4 for 256, against 3.1-3.7 us for a kernel boundary around the same traffic, 2.4-8.3 for data + flag, 5.7-76 for a
+// central counter (what grid.sync() is).  Face records are double-buffered by exchange parity: a brick can publish exchange n only after it has read all
+// its neighbours' exchange n-1, which they published after reading n-2 -- the slot of parity n is free.  Sequence numbers never repeat (launch epoch x 64 +
+// a code for the record's role), so records of earlier launches never match.  A gate record per brick ends the LONG wait of the finer level's workgroups
+// on the way up: one lane watches it, the others poll their own records only afterwards.
+// Every other global access is of the ordinary kind and obeys one rule: within a launch an address is written by ONE workgroup only and never read by
+// another (the halo of a level's first sweep comes from what EARLIER launches stored).  Hence zero_vector of a level below the first of a chain is done
+// by that level's own visit (it then does not read the vector at all), and FDOWN -- every brick of which reads the level below -- is a launch of its own.
+// All workgroups of the launch must be resident at once: at least six waves per SIMD are forced (80 registers), so three workgroups fit a CU and 512 of
+// 768 slots suffice -- they are, unless other processes' launches of this kind fill the GPU (HPGMG_BRICK_VISITS=0 then).  A poll gives up after 2 s and
+// raises the error flag the host checks at its next scalar, so a mistake here ends as an abort with a message, not as a hung GPU.
 // Arithmetic: the expression trees of tail.hip / the streaming kernels (stencil_math.hpp, chebyshev.c:86-95, gsrb.c:100-104, jacobi.c:50-56,
-// residual.c:42-48, restriction.c:54-57, interpolation_p0.c:43): bit-identical to the per-operator path; tests/test_gpu_operators.py runs both.
+// residual.c:42-48, restriction.c:54-57, interpolation_p0.c:43, interpolation_p1.c:40-70): bit-identical to the per-operator path;
+// tests/test_gpu_operators.py runs both, tools/stress_bricks.py repeats a cycle hundreds of times and compares the bytes.
 #include "common.hpp"
 #include "stencil_math.hpp"
 #include "dense_levels.hpp"
