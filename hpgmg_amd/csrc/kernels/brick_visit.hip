@@ -77,6 +77,7 @@ struct BrickArgs {
   FaceCell *faces, *down, *up, *gate;
   u64 epoch;                        // launch number x 64
   unsigned *error;                  // pinned host word: set when a poll gave up
+  int absent_wg;                    // tests (HPGMG_TEST_BRICK_ABSENT): this workgroup leaves at once, as if it had never been given a CU; -1: none
 };
 
 __device__ __forceinline__ void face_store(FaceCell *p, double v, u64 seq) {
@@ -145,6 +146,7 @@ __global__ __launch_bounds__(BrickGeom<B>::Threads, (B == 8) ? 6 : 4) void brick
   const u64 epoch = A.epoch;
   const u64 t0 = __builtin_amdgcn_s_memrealtime();
   bool gave_up = false;
+  if (wg == A.absent_wg) return;
   const int li0 = t % kBrick, lj0 = (t / kBrick) % kBrick, lk0 = t / kFaceCells, pos0 = hpos(li0, lj0, lk0);
 
   for (int step = 0; step < n; step++) {
@@ -430,6 +432,9 @@ int hpgmg_hip_brick_visit_error(void) { return (g_error && *(volatile unsigned *
 int hpgmg_hip_brick_chain(int n, const hpgmg_hip_brick_level *levels, const hpgmg_hip_level *below, int sweeps, int variant, int smoother,
                           int e_id, int R_id, double a, double b, int dir, int brick, int top_e_zero, int below_zero) {
   if (g_skip_launches) return record_error(hipErrorInvalidValue, "brick_chain: not replayable (the launch number is a kernel argument)");
+  if (hpgmg_hip_brick_visit_error())
+    return record_error(hipErrorLaunchFailure, "brick_chain: a poll inside an earlier launch gave up after 2 s -- not all its workgroups were running (other processes' launches "
+                                               "of this kind on the same GPU?); results since then are void.  HPGMG_BRICK_VISITS=0 runs these levels launch by launch");
   if (n < 1 || n > kBrickMaxLevels || sweeps < 1 || sweeps > kBrickMaxSweeps || (sweeps & 1) || dir < 0 || dir > 2 || (dir == 2 && n != 1))
     return record_error(hipErrorInvalidValue, "brick_chain: levels / sweeps / direction");
   for (int j = 0; j < n; j++) {
@@ -456,6 +461,8 @@ int hpgmg_hip_brick_chain(int n, const hpgmg_hip_brick_level *levels, const hpgm
   A.gate = A.up + (size_t)kBrickMaxLevels * kCellRecords;
   A.error = g_error;
   g_epoch += 64; A.epoch = g_epoch;
+  static const int absent = [] { const char *e = getenv("HPGMG_TEST_BRICK_ABSENT"); return (e && *e) ? atoi(e) : -1; }();
+  A.absent_wg = absent;
   int rc;
   const int key = variant * 3 + smoother;
   switch (key) {

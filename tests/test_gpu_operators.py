@@ -415,6 +415,22 @@ def test_level_visits_as_one_launch_of_bricks(hip, oracle, variant, geom, brick,
             be.lib.hpgmg_mg_destroy(m); f.destroy()
 
 
+def test_a_brick_launch_with_a_workgroup_missing_ends_as_an_abort_with_a_message():
+    """A brick launch needs all its workgroups running at once.  HPGMG_TEST_BRICK_ABSENT=1 makes workgroup 1 of every such launch leave at once, as if it had
+    never been given a CU: its neighbours' polls give up after 2 s, the launch ENDS (no hung GPU), and the host aborts at the next scalar it waits for, saying why."""
+    import os, subprocess, sys, time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import ctypes, hpgmg_amd as H; lib = H.load_driver(); lib.hpgmg_set_verbose(0); "
+            "lib.hpgmg_configure(ctypes.byref(H.Config(H.OP_7PT, H.SMOOTH_CHEBY, 1, 1))); s = lib.hpgmg_solver_create(5, 8, H.BC_DIRICHLET, 0, 1); lib.hpgmg_solver_fmg(s, 0); print('SURVIVED')")
+    t0 = time.time()
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, cwd=root, env=dict(os.environ, HPGMG_TEST_BRICK_ABSENT="1"))
+    assert r.returncode != 0 and "SURVIVED" not in r.stdout, r.stdout[-500:]
+    assert "gave up after 2 s" in r.stderr and "HPGMG_BRICK_VISITS=0" in r.stderr, r.stderr[-1500:]
+    assert time.time() - t0 < 60
+    ok = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, cwd=root)      # the GPU is fine afterwards
+    assert ok.returncode == 0 and "SURVIVED" in ok.stdout, ok.stderr[-1500:]
+
+
 def test_brick_launches_repeat_bit_for_bit():
     """tools/stress_bricks.py: the same V-cycle / FMGSolve step from 64^3 and 32^3 levels repeated on the same input -- every repetition must leave the same bytes
     on every level.  What crosses workgroups inside a brick launch is polled, so a torn, stale or lost record would show here as a difference that depends on timing
