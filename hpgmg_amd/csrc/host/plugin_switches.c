@@ -18,7 +18,7 @@ static struct { const char *env; int kind; long long dflt; const char *what; lon
   [SW_FUSED_SWEEPS]      = { "HPGMG_FUSED_SWEEPS", K_ON, 1, "7-pt: two smoother sweeps per pass on bandwidth-bound levels" },
   [SW_PAIR_MIN_CELLS]    = { "HPGMG_PAIR_MIN_CELLS", K_INT, 4000000, "7-pt: smallest level (cells) that takes the sweep-pair kernel" },
   [SW_FUSED_RESIDUAL]    = { "HPGMG_FUSED_RESIDUAL", K_ON, 1, "residual + restriction (+ zero_vector), residual + norm, norm + copy + restriction as one pass each" },
-  [SW_FUSED_TAIL]        = { "HPGMG_FUSED_TAIL", K_ON, 1, "7-pt: the V-cycle below 32^3 as one launch" },
+  [SW_FUSED_TAIL]        = { "HPGMG_FUSED_TAIL", K_ON, 1, "7-pt: the V-cycle below the brick levels (<= 8^3; <= 16^3 without them) as one single-workgroup launch" },
   [SW_FUSED_FTAIL]       = { "HPGMG_FUSED_FTAIL", K_ON, 1, "7-pt: the F-cycle's own work below 32^3 as one launch" },
   [SW_FUSED_BOTTOM]      = { "HPGMG_FUSED_BOTTOM", K_ON, 1, "BiCGStab bottom solve on the device; 0: driven from the host (host/solvers.c) through the operators" },
   [SW_SMALL_FUSED]       = { "HPGMG_SMALL_FUSED", K_TRI, 2, "27-pt / fv2 / fv4: smooth() of a one-box level as one launch on an LDS image (2, default); 0 off" },
@@ -31,7 +31,7 @@ static struct { const char *env; int kind; long long dflt; const char *what; lon
   [SW_FV4_NO_EXACT_RB]   = { "HPGMG_TUNE_FV4_NO_EXACT_RB", K_OFF, 0, "fv4: the exported smooth() as six half sweeps (no red + black passes)" },
   [SW_GRAPH]             = { "HPGMG_GRAPH", K_OFF, 0, "capture / replay the launch-bound segments as hipGraphs (measured slower with a full stream)" },
   [SW_DEFER_NORM]        = { "HPGMG_DEFER_NORM", K_ON, 1, "FMGSolve: norm(F) of the opening pass is collected at the end, where it is used, instead of waited for at the start" },
-  [SW_BRICK_VISITS]     = { "HPGMG_BRICK_VISITS", K_ON, 1, "7-pt: a visit of the 32^3 / 64^3 level of a V-cycle as one launch of 16^3 bricks that trade faces inside the launch; 0 when other processes run such launches on the same GPU" },
+  [SW_BRICK_VISITS]     = { "HPGMG_BRICK_VISITS", K_ON, 1, "7-pt: the 64^3 / 32^3 / 16^3 levels of a V-cycle leg as one launch of 8^3 bricks that trade faces, residuals and corrections inside the launch; 0 when other processes run such launches on the same GPU" },
   [SW_BRICK_SIZE]       = { "HPGMG_TUNE_BRICK", K_INT, 8, "side of those bricks: 8 (512 lanes, one cell each) or 16 (1024 lanes, four cells each)" },
   [SW_BRICK_MIN_DIM]    = { "HPGMG_TUNE_BRICK_MIN", K_INT, 16, "smallest level (cells per side) visited as bricks; the levels below it are the single-workgroup tail's" },
   [SW_BRICK_FSTEP]      = { "HPGMG_TUNE_BRICK_FSTEP", K_ON, 1, "FMGSolve: interpolation_fcycle onto a brick level rides in the first launch of the V-cycle that follows it" },
