@@ -599,7 +599,27 @@ void hpgmg_set_fmg_vcycles(int n) { hpgmg_fmg_vcycles = n > 0 ? n : 0; }
  * says "u is to be zeroed first" instead of calling zero_vector, and FMGSolve zeroes it where it would first be touched. */
 static int fmg_zero_u_first = 0;
 void hpgmg_fmg_zero_u_first(void) { fmg_zero_u_first = 1; }
+static void fmg_solve_once(mg_type *G, int onLevel, int u_id, int F_id, double a, double b, double rtol);
+/* FMGSolve reads F and overwrites u (its first access to u is interpolation_fcycle's write, prescale 0.0): a solve that a plugin reports as failed as a
+ * whole (hpgmg_solve_attempt_end: a fused launch of the HIP plugin did not get all its workgroups running) is repeated from the same inputs -- the
+ * plugin has switched the failing form off, so the second attempt is the launch-by-launch path.  The reference has no such failure mode; its operators
+ * complete (chebyshev.c:9-12 is its only exit). */
 void FMGSolve(mg_type *G, int onLevel, int u_id, int F_id, double a, double b, double rtol) {
+  int attempt, l, booked[64];
+  for (attempt = 0; attempt < 2; attempt++) {
+    for (l = 0; l < G->num_levels && l < 64; l++) booked[l] = G->levels[l]->vcycles_from_this_level;
+    hpgmg_solve_attempt_begin();
+    fmg_solve_once(G, onLevel, u_id, F_id, a, b, rtol);
+    if (!hpgmg_solve_attempt_end()) return;
+    /* what the failed attempt booked: the solve counts once; u is cleared so that 0.0 * u is 0.0 again */
+    G->MGSolves_performed--;
+    for (l = 0; l < G->num_levels && l < 64; l++) G->levels[l]->vcycles_from_this_level = booked[l];
+    if (G->levels[onLevel]->active) zero_vector(G->levels[onLevel], u_id);
+  }
+  fprintf(stderr, "hpgmg: FMGSolve failed twice\n");
+  exit(1);
+}
+static void fmg_solve_once(mg_type *G, int onLevel, int u_id, int F_id, double a, double b, double rtol) {
   /* one F-cycle; further V-cycles only on request (hpgmg_set_fmg_vcycles) */
   const int e_id = u_id, R_id = VECTOR_R, maxVCycles = hpgmg_fmg_vcycles;
   const int bottom = G->num_levels - 1;

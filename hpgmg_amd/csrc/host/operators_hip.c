@@ -317,13 +317,42 @@ void shift_vector(level_type *L, int c, int a, double shift) { BLAS1(hpgmg_hip_s
 void color_vector(level_type *L, int id, int colors, int ic, int jc, int kc) { BLAS1(hpgmg_hip_color(&hp_backend_of(L)->dev, id, colors, ic, jc, kc)); }
 void random_vector(level_type *L, int id) { BLAS1(hpgmg_hip_random(&hp_backend_of(L)->dev, id)); }
 
+/* A launch of bricks (kernels/brick_visit.hip, brick_wide.hip) whose workgroups could not all run gives up after 2 s and raises an error word; every scalar the
+ * host waits for passes hp_allreduce_scalar, which is where it learns of it.  Inside a solve the driver can repeat (hpgmg_solve_attempt_begin / _end, one
+ * rank) the failure is noted, brick launches are switched off for the rest of the process and the driver repeats the solve launch by launch; anywhere else
+ * -- the reference's own driver, several ranks (only rank 0 would know) -- the program stops with a message. */
+static int attempt_open = 0, attempt_failed = 0;
+static long long brick_failures = 0;
+long long hpgmg_brick_failures(void) { return brick_failures; }      /* solves repeated launch by launch after a failed brick launch (tests) */
+static const char *brick_failure_text = "hpgmg: an exchange inside a brick launch gave up after 2 s -- not all its workgroups were running (other processes' launches of this kind on "
+                                        "the same GPU?).  Results since then are void.";
+void hpgmg_solve_attempt_begin(void) {
+  const hpgmg_transport *T = hpgmg_get_transport();
+  attempt_open = !(T && T->size > 1);
+  attempt_failed = 0;
+}
+static void brick_failure_noted(void) {
+  attempt_failed = 1;
+  brick_failures++;
+  hp_switch_set(SW_BRICK_VISITS, 0);
+  if (hpgmg_hip_brick_visit_error_clear()) { fprintf(stderr, "hpgmg: %s\n", hpgmg_hip_last_error()); abort(); }
+}
+int hpgmg_solve_attempt_end(void) {
+  hp_lazy_flush();
+  if (attempt_open && !attempt_failed && hpgmg_hip_brick_visit_error()) { if (hpgmg_hip_sync()) abort(); brick_failure_noted(); }
+  attempt_open = 0;
+  if (attempt_failed) {
+    fprintf(stderr, "%s  Brick launches are off from here on (HPGMG_BRICK_VISITS=0); the solve is repeated launch by launch.\n", brick_failure_text);
+    attempt_failed = 0;
+    return 1;
+  }
+  return 0;
+}
 double hp_allreduce_scalar(level_type *L, double v, int op) {
   const hpgmg_transport *T = hpgmg_get_transport();
-  /* every scalar the host waits for passes here: the place to learn that a launch of bricks (kernels/brick_visit.hip) did not get all its workgroups running */
   if (hpgmg_hip_brick_visit_error()) {
-    fprintf(stderr, "hpgmg: a face exchange inside a brick launch gave up after 2 s -- not all its workgroups were running (other processes' launches of this kind on the same GPU?).  "
-                    "Results since then are void.  HPGMG_BRICK_VISITS=0 runs these levels launch by launch.\n");
-    abort();
+    if (!attempt_open) { fprintf(stderr, "%s  HPGMG_BRICK_VISITS=0 runs these levels launch by launch.\n", brick_failure_text); abort(); }
+    if (!attempt_failed) brick_failure_noted();      /* (the value in hand is void; the driver throws the solve away at hpgmg_solve_attempt_end) */
   }
   if (T && T->size > 1) {
     hpgmg_level_ext *X = hpgmg_level_ext_get(L);

@@ -124,6 +124,8 @@ static int dense_level_ok(level_type *L) {
 }
 /* How many leading levels of the chain are visited as bricks of 8^3 / 16^3 cells, one launch per visit (kernels/brick_visit.hip): the levels of 64^3 / 32^3
  * cells above the single-workgroup tail.  0: none. */
+static long long brick_capacity_refusals = 0;
+long long hpgmg_brick_capacity_refusals(void) { return brick_capacity_refusals; }      /* level visits left to the launch-by-launch path because the device does not hold that many bricks at once (tests) */
 static int brick_prefix(level_type **levels, int n, const hpgmg_config *cfg) {
   const int sweeps = hpgmg_smooth_sweeps();
   int k = 0;
@@ -135,6 +137,10 @@ static int brick_prefix(level_type **levels, int n, const hpgmg_config *cfg) {
     if (L->dim.i < (int)hp_switch(SW_BRICK_MIN_DIM) && fits_tail) break;
     if (!dense_level_ok(L) || !dense_level_ok(levels[k + 1]) || 2 * levels[k + 1]->dim.i != L->dim.i) return 0;
     if (!hpgmg_hip_brick_visit_supported(&hp_backend_of(L)->dev, (int)hp_switch(SW_BRICK_SIZE))) { if (fits_tail) break; return 0; }
+    { /* every brick of a launch must be running at once: more bricks than the device holds of this kernel = the launch-by-launch path (kernels/brick_visit.hip) */
+      const int brick = (int)hp_switch(SW_BRICK_SIZE), side = L->dim.i / brick;
+      if (side * side * side > hpgmg_hip_brick_chain_capacity(hp_variant(), cfg->smoother, brick)) { brick_capacity_refusals++; if (fits_tail) break; return 0; }
+    }
     if (L->dominant_eigenvalue_of_DinvA <= 0.0 && cfg->smoother == HPGMG_SMOOTH_CHEBY) return 0;
     k++;
   }

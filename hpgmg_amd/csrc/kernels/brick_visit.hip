@@ -11,31 +11,31 @@
 //
 // Everything that crosses a workgroup boundary INSIDE the launch -- faces between sweeps, the restricted residuals a level hands to the one below it, the
 // corrections it hands to the one above -- goes THROUGH MEMORY WITHOUT LEAVING THE KERNEL.  The XCDs' L2 caches are not coherent with each other inside a
-// kernel, so a cell travels as a 16-byte record {value, sequence number} written through (sc1) by the lane that owns the cell and polled (sc1 loads) by the
-// lane that needs it: the record is its own flag -- one memory hop, no counter everybody adds to, no fence.  tools/microbench/p2p_flags.hip: 1.6 us per
+// kernel, so a cell travels as a 16-byte record {tag, value, tag} (brick_records.hpp) written through (sc1) by the lane that owns the cell and polled (sc1
+// loads) by the lane that needs it, accepted when BOTH tags carry the expected number (a store observed in two pieces reads as "not yet"): the record is its
+// own flag -- one memory hop, no counter everybody adds to, no fence.  tools/microbench/p2p_flags.hip: 1.6 us per
 // exchange for 8 .. 64 workgroups, 2.4 for 256, against 3.1-3.7 us for a kernel boundary around the same traffic, 2.4-8.3 for data + flag, 5.7-76 for a
 // central counter (what grid.sync() is).  Face records are double-buffered by exchange parity: a brick can publish exchange n only after it has read all
-// its neighbours' exchange n-1, which they published after reading n-2 -- the slot of parity n is free.  Sequence numbers never repeat (launch epoch x 64 +
-// a code for the record's role), so records of earlier launches never match.  A gate record per brick ends the LONG wait of the finer level's workgroups
+// its neighbours' exchange n-1, which they published after reading n-2 -- the slot of parity n is free.  Tags never repeat (launch number x 64 + a code
+// for the record's role; the areas are cleared before the 32-bit number wraps), so records of earlier launches never match.  A gate record per brick ends the LONG wait of the finer level's workgroups
 // on the way up: one lane watches it, the others poll their own records only afterwards.
 // Every other global access is of the ordinary kind and obeys one rule: within a launch an address is written by ONE workgroup only and never read by
 // another (the halo of a level's first sweep comes from what EARLIER launches stored).  Hence zero_vector of a level below the first of a chain is done
 // by that level's own visit (it then does not read the vector at all), and FDOWN -- every brick of which reads the level below -- is a launch of its own.
-// All workgroups of the launch must be resident at once: at least six waves per SIMD are forced (80 registers), so three workgroups fit a CU and 512 of
-// 768 slots suffice -- they are, unless other processes' launches of this kind fill the GPU (HPGMG_BRICK_VISITS=0 then).  A poll gives up after 2 s and
-// raises the error flag the host checks at its next scalar, so a mistake here ends as an abort with a message, not as a hung GPU.
+// All workgroups of the launch must be resident at once: at least six waves per SIMD are forced (80 registers), so three workgroups fit a CU -- 768 slots
+// on 256 CUs for the 512 bricks of a 64^3 level.  The host ASKS (hpgmg_hip_brick_chain_capacity: occupancy x CUs of this device, less an eighth) and takes the
+// launch-by-launch path when a level has more bricks than that (a partitioned or smaller device).  What no query can see -- other processes' launches of this
+// kind filling the slots -- ends a poll after 2 s: it raises the error words, every launch behind it gives up within 100 us, the host learns of it at its next
+// scalar and redoes the solve launch by launch (host/mg.c FMGSolve) or stops with a message (the reference's own driver, multi-rank jobs): never a hung GPU.
 // Arithmetic: the expression trees of tail.hip / the streaming kernels (stencil_math.hpp, chebyshev.c:86-95, gsrb.c:100-104, jacobi.c:50-56,
 // residual.c:42-48, restriction.c:54-57, interpolation_p0.c:43, interpolation_p1.c:40-70): bit-identical to the per-operator path;
 // tests/test_gpu_operators.py runs both, tools/stress_bricks.py repeats a cycle hundreds of times and compares the bytes.
 #include "common.hpp"
 #include "stencil_math.hpp"
 #include "dense_levels.hpp"
+#include "brick_records.hpp"
 
 namespace hpgmg {
-
-typedef unsigned long long u64;
-struct alignas(16) FaceCell { double v; u64 seq; };
-typedef unsigned __attribute__((ext_vector_type(4))) u4v;
 
 // brick geometry: B^3 cells per workgroup.  B = 16: 1024 lanes, 4 cells each; B = 8: 512 lanes, one cell each (eight times the workgroups: a sweep of a
 // 16^3 brick is ~3 us of fp64 issue on ONE CU, which is most of what a launch boundary costs)
@@ -51,15 +51,6 @@ template <int B_> struct BrickGeom {
     if (f < 2) { li = w; lj = u; lk = v; } else if (f < 4) { li = u; lj = w; lk = v; } else { li = u; lj = v; lk = w; }
   }
 };
-constexpr int kBrickMaxSweeps = 8, kBrickMaxLevels = 3, kBrickMaxWgs = 512;
-// record areas, each per level of a chain: faces [2 parities][workgroup][6][B^2] (8^3 bricks of 8^3 cells fill it; 4^3 bricks of 16^3 take half),
-// one record per cell for what goes down (restricted residuals) and up (corrections), one gate per brick
-constexpr size_t kFaceRecords = (size_t)2 * kBrickMaxWgs * 6 * 64, kCellRecords = (size_t)kBrickMaxWgs * 512;
-constexpr u64 kPollTicks = 200000000ull;            // 2 s of the 100 MHz clock
-// sequence numbers inside a launch (added to its epoch, a multiple of 64): 1 + 12 j + n = exchange n of level j; 40 + j, 48 + j, 56 + j = what level j
-// receives from the finer level / hands to the finer level / its gate
-enum { SEQ_FACES = 1, SEQ_DOWN = 40, SEQ_UP = 48, SEQ_GATE = 56 };
-
 struct BrickLevel {
   hpgmg_hip_level L;
   double h2inv, c1[kBrickMaxSweeps], c2[kBrickMaxSweeps];
@@ -74,39 +65,9 @@ struct BrickArgs {
   int top_e_zero;                   // DOWN: the correction of lv[0] counts as +0.0 (zero_vector came before, mg.c:1153) and is not read; the cells of its padded
                                     // boxes that no brick stores (ghost zone, padding) are cleared here.  (Levels below the first: always.)
   int below_zero;                   // DOWN: zero_vector(C.e) at the end (0: somebody else's)
-  FaceCell *faces, *down, *up, *gate;
-  u64 epoch;                        // launch number x 64
-  unsigned *error;                  // pinned host word: set when a poll gave up
+  BrickRecords Rc;                  // record areas, launch epoch, error words (brick_records.hpp)
   int absent_wg;                    // tests (HPGMG_TEST_BRICK_ABSENT): this workgroup leaves at once, as if it had never been given a CU; -1: none
 };
-
-__device__ __forceinline__ void face_store(FaceCell *p, double v, u64 seq) {
-  const long long b = __double_as_longlong(v);
-  u4v w; w.x = (unsigned)b; w.y = (unsigned)(b >> 32); w.z = (unsigned)seq; w.w = (unsigned)(seq >> 32);
-  // the s_nop: a VMEM store of more than 8 bytes per lane reads its data registers for a few cycles after issue, and a VALU write to them in that window
-  // corrupts the store.  The compiler pads its own stores against that hazard; it cannot see into this one.  (Found as records with the right sequence
-  // number and the next cell's value: 4 stores per lane back to back, bricks of 16^3.)
-  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 3" :: "v"(p), "v"(w) : "memory");
-}
-__device__ __forceinline__ FaceCell face_load(const FaceCell *p) {
-  u4v w;
-  asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(w) : "v"(p) : "memory");
-  FaceCell c; c.v = __longlong_as_double((long long)(((u64)w.y << 32) | w.x)); c.seq = ((u64)w.w << 32) | w.z;
-  return c;
-}
-// the value of a record once it carries `seq` (nap: s_sleep units between polls)
-__device__ __forceinline__ double record_wait(const FaceCell *p, u64 seq, u64 t0, bool &gave_up, int nap = 1) {
-  FaceCell x = face_load(p);
-  while (x.seq != seq) {
-    if (__builtin_amdgcn_s_memrealtime() - t0 > kPollTicks) { gave_up = true; break; }
-    if (nap > 1) __builtin_amdgcn_s_sleep(8); else __builtin_amdgcn_s_sleep(1);
-    x = face_load(p);
-  }
-#ifdef HPGMG_EXP_REREAD
-  x = face_load(p);
-#endif
-  return x.v;
-}
 
 template <int V, int kHaloW, int kHaloPlane>
 __device__ __forceinline__ double brick_apply(const double *src, int p, int gi, int gj, int gk, int D, const CellCoef<V> &q, double a, double b, double h2inv) {
@@ -143,7 +104,8 @@ __global__ __launch_bounds__(BrickGeom<B>::Threads, (B == 8) ? 6 : 4) void brick
   constexpr int kCW = kBrick / 2 + 2;                 // interpolation_fcycle: the brick's coarse cells with a ring of one, (B/2 + 2)^3 doubles behind the two arrays
   double *const sc = brick_lds + 2 * kHaloCells;
   const int t = (int)threadIdx.x, wg = (int)blockIdx.x, e_id = A.e_id, R_id = A.R_id, n = A.n;
-  const u64 epoch = A.epoch;
+  const unsigned epoch = A.Rc.epoch;
+  const unsigned *const err_dev = A.Rc.error_dev;
   const u64 t0 = __builtin_amdgcn_s_memrealtime();
   bool gave_up = false;
   if (wg == A.absent_wg) return;
@@ -162,7 +124,7 @@ __global__ __launch_bounds__(BrickGeom<B>::Threads, (B == 8) ? 6 : 4) void brick
     const LevelGeom G = geom_of(L), GC = geom_of(C);
     const int gi = o_i + li0, gj = o_j + lj0, gk0 = o_k + lk0;
     const double a = A.a, b = A.b, h2inv = T.h2inv;
-    FaceCell *const faces = A.faces + (size_t)j * kFaceRecords;
+    FaceCell *const faces = A.Rc.faces + (size_t)j * kFaceRecords;
     const bool e_zero = kDown && !kFInterp && (first ? (A.top_e_zero != 0) : true);
     const bool rhs_by_record = kDown && !first, parent_by_record = kUp && !last;
     // the record of cell (ci, cj, ck) of the level BELOW this one (where its owner publishes / expects it): bricks of that level are numbered like ours
@@ -172,14 +134,14 @@ __global__ __launch_bounds__(BrickGeom<B>::Threads, (B == 8) ? 6 : 4) void brick
       const int owner = qx + side_c * (qy + side_c * qz);
       return (size_t)owner * kBrickCells + (size_t)((ci - qx * kBrick) + kBrick * ((cj - qy * kBrick) + kBrick * (ck - qz * kBrick)));
     };
-    const FaceCell *const up_from_below = A.up + (size_t)(last ? j : j + 1) * kCellRecords;      // corrections of the level below (UP, not the last level)
-    const u64 seq_parent = epoch + SEQ_UP + (u64)(j + 1);
+    const FaceCell *const up_from_below = A.Rc.up + (size_t)(last ? j : j + 1) * kCellRecords;      // corrections of the level below (UP, not the last level)
+    const unsigned seq_parent = epoch + SEQ_UP + (unsigned)(j + 1);
 
     // what the first sweep reads at global cell (ci, cj, ck) of this level, given what is stored there
     auto start_value = [&](double stored, int ci, int cj, int ck) -> double {
       if (kUp) {               // interpolation_vcycle: e = 1.0*e + (coarse parent), interpolation_p0.c:43
         double parent;
-        if (parent_by_record) parent = record_wait(up_from_below + below_record(ci >> 1, cj >> 1, ck >> 1), seq_parent, t0, gave_up);
+        if (parent_by_record) parent = record_wait(up_from_below + below_record(ci >> 1, cj >> 1, ck >> 1), seq_parent, t0, gave_up, err_dev);
         else { const CellRef c = locate(GC, ci >> 1, cj >> 1, ck >> 1); parent = vec_origin(C, c.box, e_id)[c.ijk]; }
         return 1.0 * stored + parent;
       }
@@ -263,14 +225,14 @@ __global__ __launch_bounds__(BrickGeom<B>::Threads, (B == 8) ? 6 : 4) void brick
     // UP, not the last level: the corrections of the level below are on their way.  One lane watches the gate of the brick that holds this brick's parents
     // (hundreds of workgroups polling a record per lane for the length of a visit would be in the way of the bricks that work)
     if (parent_by_record) {
-      if (t == 0) (void)record_wait(A.gate + (size_t)(j + 1) * kBrickMaxWgs + ((bx >> 1) + side_c * ((by >> 1) + side_c * (bz >> 1))), epoch + SEQ_GATE + (u64)(j + 1), t0, gave_up, 8);
+      if (t == 0) (void)record_wait(A.Rc.gate + (size_t)(j + 1) * kBrickMaxWgs + ((bx >> 1) + side_c * ((by >> 1) + side_c * (bz >> 1))), epoch + SEQ_GATE + (unsigned)(j + 1), t0, gave_up, err_dev, 8);
       __syncthreads();
     }
 #pragma unroll
     for (int m = 0; m < kBrickPerLane; m++) {
       const int p = pos0 + m * kStepPos, gk = gk0 + m * kStepK;
       sx[p] = start_value(e_st[m], gi, gj, gk);
-      if (rhs_by_record) q[m].rhs = record_wait(A.down + (size_t)j * kCellRecords + (size_t)wg * kBrickCells + (size_t)(t + m * kBrickThreads), epoch + SEQ_DOWN + (u64)j, t0, gave_up);
+      if (rhs_by_record) q[m].rhs = record_wait(A.Rc.down + (size_t)j * kCellRecords + (size_t)wg * kBrickCells + (size_t)(t + m * kBrickThreads), epoch + SEQ_DOWN + (unsigned)j, t0, gave_up, err_dev);
     }
     if (kFInterp) __builtin_amdgcn_sched_barrier(0);      // (the eight coarse loads of a cell's interpolation, twice over, are more than the register budget holds at once)
 #pragma unroll
@@ -307,7 +269,7 @@ __global__ __launch_bounds__(BrickGeom<B>::Threads, (B == 8) ? 6 : 4) void brick
       if (kDown || s + 1 < A.sweeps) {      // (the way down goes on to the residual of the result)
         // one exchange: the faces of dst go out, the neighbours' faces come into its halo
         const int par = exchange_n & 1;
-        const u64 seq = epoch + SEQ_FACES + (u64)(12 * j + exchange_n);
+        const unsigned seq = epoch + SEQ_FACES + (unsigned)(12 * j + exchange_n);
         exchange_n++;
         FaceCell *mine = faces + ((size_t)par * nwg + wg) * 6 * kFaceCells;
         for (int fc = t; fc < 6 * kFaceCells; fc += kBrickThreads) {
@@ -323,7 +285,7 @@ __global__ __launch_bounds__(BrickGeom<B>::Threads, (B == 8) ? 6 : 4) void brick
           const int bc = (f < 2) ? bx : ((f < 4) ? by : bz);
           if ((f & 1) ? (bc == side - 1) : (bc == 0)) continue;
           const int stp = (f < 2) ? 1 : ((f < 4) ? side : side * side), nb = wg + ((f & 1) ? stp : -stp);
-          const double xv = record_wait(faces + (((size_t)par * nwg + nb) * 6 + (f ^ 1)) * kFaceCells + (fc % kFaceCells), seq, t0, gave_up);
+          const double xv = record_wait(faces + (((size_t)par * nwg + nb) * 6 + (f ^ 1)) * kFaceCells + (fc % kFaceCells), seq, t0, gave_up, err_dev);
           int li, lj, lk;
           face_cell(f, u, v, 1, li, lj, lk);
           dst[hpos(li, lj, lk)] = xv;
@@ -349,9 +311,9 @@ __global__ __launch_bounds__(BrickGeom<B>::Threads, (B == 8) ? 6 : 4) void brick
       const CellRef w = locate(G, gi, gj, gk0 + m * kStepK);
       vec_origin(L, w.box, e_id)[w.ijk] = sx[p];
       vec_origin(L, w.box, VECTOR_TEMP)[w.ijk] = st[p];
-      if (kUp && !first) face_store(A.up + (size_t)j * kCellRecords + (size_t)wg * kBrickCells + (size_t)(t + m * kBrickThreads), sx[p], epoch + SEQ_UP + (u64)j);
+      if (kUp && !first) face_store(A.Rc.up + (size_t)j * kCellRecords + (size_t)wg * kBrickCells + (size_t)(t + m * kBrickThreads), sx[p], epoch + SEQ_UP + (unsigned)j);
     }
-    if (kUp && !first && t == 0) face_store(A.gate + (size_t)j * kBrickMaxWgs + wg, 0.0, epoch + SEQ_GATE + (u64)j);      // (issued after lane 0's records; the others' may still be on their way: the gate only ends the long wait)
+    if (kUp && !first && t == 0) face_store(A.Rc.gate + (size_t)j * kBrickMaxWgs + wg, 0.0, epoch + SEQ_GATE + (unsigned)j);      // (issued after lane 0's records; the others' may still be on their way: the gate only ends the long wait)
 
     if (kDown) {
       // restriction(coarse.R <- TEMP): 0.125 * sum of the 8 children in the reference's order (restriction.c:54-57); this brick's (B/2)^3 coarse cells
@@ -365,7 +327,7 @@ __global__ __launch_bounds__(BrickGeom<B>::Threads, (B == 8) ? 6 : 4) void brick
         const int qi = (o_i >> 1) + ci, qj = (o_j >> 1) + cj, qk = (o_k >> 1) + ck;
         const CellRef c = locate(GC, qi, qj, qk);
         vec_origin(C, c.box, R_id)[c.ijk] = v;
-        if (!last) face_store(A.down + (size_t)(j + 1) * kCellRecords + below_record(qi, qj, qk), v, epoch + SEQ_DOWN + (u64)(j + 1));
+        if (!last) face_store(A.Rc.down + (size_t)(j + 1) * kCellRecords + below_record(qi, qj, qk), v, epoch + SEQ_DOWN + (unsigned)(j + 1));
       }
       // zero_vector(C.e): the whole padded boxes, ghosts included (misc.c:6-44), each workgroup a slice of the flat range.  Not when C is the next level of
       // this chain (its visit does not read the vector and clears what it does not store itself, below)
@@ -390,22 +352,74 @@ __global__ __launch_bounds__(BrickGeom<B>::Threads, (B == 8) ? 6 : 4) void brick
     }
     __syncthreads();                                    // the next level of the chain reuses the LDS arrays
   }
-  if (gave_up && A.error) __hip_atomic_store(A.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (gave_up) brick_raise_error(A.Rc);
 }
 
-static FaceCell *g_records = nullptr;         // faces | down | up | gate, kBrickMaxLevels of each
+static FaceCell *g_records = nullptr;         // faces | down | up | gate, kBrickMaxLevels of each, then the device copy of the error word
 static unsigned *g_error = nullptr;          // pinned host word
-static u64 g_epoch = 0;
+static unsigned *g_error_dev = nullptr;
+static unsigned g_epoch = 0;
 static long long g_visits = 0;
+constexpr size_t kRecordsTotal = (size_t)kBrickMaxLevels * (kFaceRecords + 2 * kCellRecords + kBrickMaxWgs);
 
+int brick_records_for_launch(BrickRecords *R) {
+  if (!g_records) {
+    HPGMG_CHECK(hipMalloc((void **)&g_records, (kRecordsTotal + 4) * sizeof(FaceCell)));
+    HPGMG_CHECK(hipMemset(g_records, 0, (kRecordsTotal + 4) * sizeof(FaceCell)));
+    HPGMG_CHECK(hipHostMalloc((void **)&g_error, 64, hipHostMallocDefault));
+    *g_error = 0;
+    g_error_dev = (unsigned *)(g_records + kRecordsTotal);
+    HPGMG_CHECK(hipDeviceSynchronize());
+  }
+  if (g_epoch > 0xFFFFFFFFu - 256u) {            // the 32-bit tags would repeat: clear every record first (in stream order, behind the launches that use them)
+    HPGMG_CHECK(hipMemsetAsync(g_records, 0, kRecordsTotal * sizeof(FaceCell), g_stream));
+    g_epoch = 0;
+  }
+  g_epoch += 64;
+  R->faces = g_records; R->down = R->faces + (size_t)kBrickMaxLevels * kFaceRecords; R->up = R->down + (size_t)kBrickMaxLevels * kCellRecords;
+  R->gate = R->up + (size_t)kBrickMaxLevels * kCellRecords;
+  R->epoch = g_epoch; R->error = g_error; R->error_dev = g_error_dev;
+  return 0;
+}
+// Every workgroup of a brick launch waits for records of others: all of them must be RESIDENT at once.  What the device holds of a kernel = its occupancy
+// per CU (registers, LDS, waves) x the CUs of this device (a partition in CPX / DPX mode reports its own count).
+int brick_workgroups_resident(const void *kernel, int threads, size_t lds_bytes) {
+  static const int forced = [] { const char *e = getenv("HPGMG_TEST_BRICK_CAPACITY"); return (e && *e) ? atoi(e) : -1; }();
+  if (forced >= 0) return forced;
+  int per_cu = 0, dev = 0, cus = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, lds_bytes) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return per_cu * cus;
+}
+int brick_test_absent_wg(void) {
+  static const int absent = [] { const char *e = getenv("HPGMG_TEST_BRICK_ABSENT"); return (e && *e) ? atoi(e) : -1; }();
+  return absent;
+}
+void brick_count_visits(int n) { g_visits += n; }
+bool brick_error_pending(void) { return g_error && *(volatile unsigned *)g_error; }
+
+template <int DIR, int B> constexpr size_t brick_lds_bytes() { return ((size_t)2 * BrickGeom<B>::Halo + (DIR == DIR_FDOWN ? (size_t)(B / 2 + 2) * (B / 2 + 2) * (B / 2 + 2) : 0)) * sizeof(double); }
 template <int V, int SM, int DIR, int B>
 static int brick_launch(const BrickArgs &A) {
   static bool once = false;
-  const size_t lds = ((size_t)2 * BrickGeom<B>::Halo + (DIR == DIR_FDOWN ? (size_t)(B / 2 + 2) * (B / 2 + 2) * (B / 2 + 2) : 0)) * sizeof(double);
+  const size_t lds = brick_lds_bytes<DIR, B>();
   if (!once) { HPGMG_CHECK(hipFuncSetAttribute((const void *)brick_chain_kernel<V, SM, DIR, B>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once = true; }
   hipLaunchKernelGGL((brick_chain_kernel<V, SM, DIR, B>), dim3(A.lv[0].nwg), dim3(BrickGeom<B>::Threads), lds, g_stream, A);
   return 0;
 }
+// workgroups of the (variant, smoother) kernels the device holds at once: the smallest figure of the three directions
+template <int V, int SM, int B>
+static int brick_capacity() {
+  static int cap = -1;
+  if (cap < 0) {
+    const int c0 = brick_workgroups_resident((const void *)brick_chain_kernel<V, SM, 0, B>, BrickGeom<B>::Threads, brick_lds_bytes<0, B>());
+    const int c1 = brick_workgroups_resident((const void *)brick_chain_kernel<V, SM, 1, B>, BrickGeom<B>::Threads, brick_lds_bytes<1, B>());
+    const int c2 = brick_workgroups_resident((const void *)brick_chain_kernel<V, SM, 2, B>, BrickGeom<B>::Threads, brick_lds_bytes<2, B>());
+    cap = c0 < c1 ? (c0 < c2 ? c0 : c2) : (c1 < c2 ? c1 : c2);
+  }
+  return cap;
+}
+template <int V, int SM> static int brick_capacity_of(int brick) { return brick == 16 ? brick_capacity<V, SM, 16>() : brick_capacity<V, SM, 8>(); }
 template <int V, int SM>
 static int brick_launch_dir(const BrickArgs &A, int dir, int brick) {
   if (brick == 16) return dir == 0 ? brick_launch<V, SM, 0, 16>(A) : (dir == 1 ? brick_launch<V, SM, 1, 16>(A) : brick_launch<V, SM, 2, 16>(A));
@@ -427,27 +441,46 @@ int hpgmg_hip_brick_visit_supported(const hpgmg_hip_level *L, int brick) {
   return L->dim_i == L->dim_j && L->dim_i == L->dim_k && L->dim_i % brick == 0 && side >= 2 && side <= max_side && L->dim > 0 && L->dim_i % L->dim == 0;
 }
 // 0: fine; 1: a poll of an earlier launch gave up (the results since then are not to be used)
-int hpgmg_hip_brick_visit_error(void) { return (g_error && *(volatile unsigned *)g_error) ? 1 : 0; }
+int hpgmg_hip_brick_visit_error(void) { return brick_error_pending() ? 1 : 0; }
+// after the host has dealt with it (every launch behind the failed one has ended: the caller synchronised to learn of it)
+int hpgmg_hip_brick_visit_error_clear(void) {
+  if (!g_error) return 0;
+  HPGMG_CHECK(hipStreamSynchronize(g_stream));
+  HPGMG_CHECK(hipMemsetAsync(g_error_dev, 0, sizeof(unsigned), g_stream));
+  HPGMG_CHECK(hipStreamSynchronize(g_stream));
+  *(volatile unsigned *)g_error = 0;
+  return 0;
+}
+// How many workgroups of the (variant, smoother) brick kernels this device holds at once, less a margin of one eighth for whatever else is running: a launch
+// of more than that many bricks would wait for workgroups that cannot start (the caller then takes the launch-by-launch path).
+int hpgmg_hip_brick_chain_capacity(int variant, int smoother, int brick) {
+  int cap;
+  switch (variant * 3 + smoother) {
+    case HPGMG_HIP_7PT_VC_HELMHOLTZ * 3 + BV_CHEBY:  cap = brick_capacity_of<HPGMG_HIP_7PT_VC_HELMHOLTZ, BV_CHEBY>(brick); break;
+    case HPGMG_HIP_7PT_VC_HELMHOLTZ * 3 + BV_GSRB:   cap = brick_capacity_of<HPGMG_HIP_7PT_VC_HELMHOLTZ, BV_GSRB>(brick); break;
+    case HPGMG_HIP_7PT_VC_HELMHOLTZ * 3 + BV_JACOBI: cap = brick_capacity_of<HPGMG_HIP_7PT_VC_HELMHOLTZ, BV_JACOBI>(brick); break;
+    case HPGMG_HIP_7PT_VC_POISSON * 3 + BV_CHEBY:    cap = brick_capacity_of<HPGMG_HIP_7PT_VC_POISSON, BV_CHEBY>(brick); break;
+    case HPGMG_HIP_7PT_VC_POISSON * 3 + BV_GSRB:     cap = brick_capacity_of<HPGMG_HIP_7PT_VC_POISSON, BV_GSRB>(brick); break;
+    case HPGMG_HIP_7PT_VC_POISSON * 3 + BV_JACOBI:   cap = brick_capacity_of<HPGMG_HIP_7PT_VC_POISSON, BV_JACOBI>(brick); break;
+    case HPGMG_HIP_7PT_CC * 3 + BV_CHEBY:            cap = brick_capacity_of<HPGMG_HIP_7PT_CC, BV_CHEBY>(brick); break;
+    case HPGMG_HIP_7PT_CC * 3 + BV_GSRB:             cap = brick_capacity_of<HPGMG_HIP_7PT_CC, BV_GSRB>(brick); break;
+    case HPGMG_HIP_7PT_CC * 3 + BV_JACOBI:           cap = brick_capacity_of<HPGMG_HIP_7PT_CC, BV_JACOBI>(brick); break;
+    default: return 0;
+  }
+  return cap - cap / 8;
+}
 
 int hpgmg_hip_brick_chain(int n, const hpgmg_hip_brick_level *levels, const hpgmg_hip_level *below, int sweeps, int variant, int smoother,
                           int e_id, int R_id, double a, double b, int dir, int brick, int top_e_zero, int below_zero) {
   if (g_skip_launches) return record_error(hipErrorInvalidValue, "brick_chain: not replayable (the launch number is a kernel argument)");
-  if (hpgmg_hip_brick_visit_error())
-    return record_error(hipErrorLaunchFailure, "brick_chain: a poll inside an earlier launch gave up after 2 s -- not all its workgroups were running (other processes' launches "
-                                               "of this kind on the same GPU?); results since then are void.  HPGMG_BRICK_VISITS=0 runs these levels launch by launch");
+  // a poll inside an earlier launch gave up: the results since then are void whatever is launched now; the host learns of it at its next scalar
+  // (hpgmg_hip_brick_visit_error) and redoes the solve launch by launch or stops
+  if (hpgmg_hip_brick_visit_error()) return 0;
   if (n < 1 || n > kBrickMaxLevels || sweeps < 1 || sweeps > kBrickMaxSweeps || (sweeps & 1) || dir < 0 || dir > 2 || (dir == 2 && n != 1))
     return record_error(hipErrorInvalidValue, "brick_chain: levels / sweeps / direction");
   for (int j = 0; j < n; j++) {
     const hpgmg_hip_level *next = (j + 1 < n) ? &levels[j + 1].L : below;
     if (!hpgmg_hip_brick_visit_supported(&levels[j].L, brick) || 2 * next->dim_i != levels[j].L.dim_i) return record_error(hipErrorInvalidValue, "brick_chain: level");
-  }
-  if (!g_records) {
-    const size_t records = (size_t)kBrickMaxLevels * (kFaceRecords + 2 * kCellRecords + kBrickMaxWgs);
-    HPGMG_CHECK(hipMalloc((void **)&g_records, records * sizeof(FaceCell)));
-    HPGMG_CHECK(hipMemset(g_records, 0, records * sizeof(FaceCell)));
-    HPGMG_CHECK(hipHostMalloc((void **)&g_error, 64, hipHostMallocDefault));
-    *g_error = 0;
-    HPGMG_CHECK(hipDeviceSynchronize());
   }
   BrickArgs A = {};
   for (int j = 0; j < n; j++) {
@@ -457,12 +490,8 @@ int hpgmg_hip_brick_chain(int n, const hpgmg_hip_brick_level *levels, const hpgm
   }
   A.C = *below; A.n = n; A.a = a; A.b = b; A.sweeps = sweeps; A.e_id = e_id; A.R_id = R_id;
   A.top_e_zero = (dir == 0 && top_e_zero) ? 1 : 0; A.below_zero = below_zero ? 1 : 0;
-  A.faces = g_records; A.down = A.faces + (size_t)kBrickMaxLevels * kFaceRecords; A.up = A.down + (size_t)kBrickMaxLevels * kCellRecords;
-  A.gate = A.up + (size_t)kBrickMaxLevels * kCellRecords;
-  A.error = g_error;
-  g_epoch += 64; A.epoch = g_epoch;
-  static const int absent = [] { const char *e = getenv("HPGMG_TEST_BRICK_ABSENT"); return (e && *e) ? atoi(e) : -1; }();
-  A.absent_wg = absent;
+  { const int rc = brick_records_for_launch(&A.Rc); if (rc) return rc; }
+  A.absent_wg = brick_test_absent_wg();
   int rc;
   const int key = variant * 3 + smoother;
   switch (key) {
@@ -479,7 +508,7 @@ int hpgmg_hip_brick_chain(int n, const hpgmg_hip_brick_level *levels, const hpgm
   }
   if (rc) return rc;
   HPGMG_LAUNCH_CHECK("brick_chain_kernel");
-  g_visits += n;
+  brick_count_visits(n);
   return 0;
 }
 

@@ -98,6 +98,8 @@ void        hpgmg_set_fused_bottom(int on);    /* 0: the bottom solve driven fro
 void        hpgmg_set_fused_tail(int on);      /* 0: no single-launch V-/F-cycle tails (7-pt: kernels/tail.hip; tests) */
 void        hpgmg_set_brick_visits(int on);    /* 0: the 32^3 / 64^3 levels of a 7-pt V-cycle launch by launch instead of one launch per visit (kernels/brick_visit.hip); 1: on; 8 / 16: on, bricks of that side (tests) */
 long long   hpgmg_brick_visits(void);          /* level visits done that way so far (tests) */
+long long   hpgmg_brick_failures(void);        /* solves repeated launch by launch because a brick launch did not get all its workgroups running (tests) */
+long long   hpgmg_brick_capacity_refusals(void);      /* level visits left to the launch-by-launch path because the device does not hold that many bricks at once (tests) */
 void        hpgmg_set_brick_chains(int on);    /* 0: one launch per level visit instead of one per V-cycle leg (tests) */
 long long   hpgmg_pair_remote_smooths(void);   /* smooth() calls executed as sweep pairs with faces owned by other ranks (tests) */
 long long   hpgmg_fused_residuals_remote(void); /* 7-point: fused residual passes (residual + restriction, residual + norm) run on levels with faces owned by other ranks (tests) */

@@ -390,6 +390,10 @@ int hpgmg_hip_brick_chain(int n, const hpgmg_hip_brick_level *levels, const hpgm
                           int e_id, int R_id, double a, double b, int dir, int brick, int top_e_zero, int below_zero);
 long long hpgmg_hip_brick_visits(void);      /* level visits so far (tests) */
 int hpgmg_hip_brick_visit_error(void);       /* 1: a poll of an earlier launch gave up after 2 s (a workgroup of the launch was not running): results are void */
+int hpgmg_hip_brick_visit_error_clear(void); /* the host has dealt with it (synchronises) */
+/* workgroups of the (variant, smoother) brick kernels this device holds at once (occupancy x CUs) less an eighth: a level with more bricks than this must not be
+ * launched as bricks -- its workgroups wait for each other (HPGMG_TEST_BRICK_CAPACITY=<n> forces the raw figure: tests) */
+int hpgmg_hip_brick_chain_capacity(int variant, int smoother, int brick);
 
 /* ---- hipGraph segments (graph.hip): capture/replay of the launch-bound small-level part of a cycle.
  *      begin(key): first use of a key runs eagerly, second is captured, later ones are replayed

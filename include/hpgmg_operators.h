@@ -113,17 +113,27 @@ void    hpgmg_vector_download(double *dst_host, const double *src_plugin, size_t
  * such a mechanism implement these as no-ops.  A reduction (norm/dot/mean) ends an open segment. */
 void    hpgmg_segment_begin(long long key);
 void    hpgmg_segment_end(void);
-/* Optional fused form of MGVCycle (mg.c:1147-1163) over the chain levels[0..n-1] (finest first,
- * levels[n-1] = bottom level).  leg 0: smooth, residual, restriction, zero_vector per level going
- * down; leg 1: interpolation_vcycle, smooth per level going up (the driver runs IterativeSolver on
- * the bottom level between the two); leg 2: leg 0, the bottom solve (solvers.c:27-95, BiCGStab to
- * MG_DEFAULT_BOTTOM_NORM), leg 1; leg 3: the bottom solve alone (n == 1); leg 4: the part of FMGSolve below levels[0]
- * (mg.c:1270-1300: restriction of R down the chain, zero_vector + bottom solve, then per level upwards interpolation_fcycle and
- * MGVCycle, levels[0] included); leg 5: only ask whether leg 4 would be executed; leg 6: one step of FMGSolve's climb (mg.c:1289-1293):
- * interpolation_fcycle(levels[0] <- levels[1]) and the V-cycle from levels[0] (= leg 2) that follows it.  Returns 1 when the plugin
- * executed it (bit-identical to the per-operator sequence), 0 when it cannot -- the driver then
- * issues the operators one by one. */
+/* Optional fused form of MGVCycle (mg.c:1147-1163) over the chain levels[0..n-1] (finest first, levels[n-1] = bottom level).  `leg` names the part
+ * (enum hpgmg_leg).  Returns 1 when the plugin executed it (bit-identical to the per-operator sequence), 0 when it cannot -- the driver then issues the
+ * operators one by one. */
+enum hpgmg_leg {
+  HPGMG_LEG_DOWN = 0,              /* smooth, residual, restriction, zero_vector per level going down (the driver runs IterativeSolver on the bottom level afterwards) */
+  HPGMG_LEG_UP = 1,                /* interpolation_vcycle, smooth per level going up */
+  HPGMG_LEG_VCYCLE = 2,            /* DOWN, the bottom solve (solvers.c:27-95, BiCGStab to MG_DEFAULT_BOTTOM_NORM), UP */
+  HPGMG_LEG_BOTTOM = 3,            /* the bottom solve alone (n == 1) */
+  HPGMG_LEG_FCYCLE_TAIL = 4,       /* the part of FMGSolve below levels[0] (mg.c:1270-1300): restriction of R down the chain, zero_vector + bottom solve, then per
+                                      level upwards interpolation_fcycle and MGVCycle, levels[0] included */
+  HPGMG_LEG_FCYCLE_TAIL_ASK = 5,   /* only ask whether HPGMG_LEG_FCYCLE_TAIL would be executed (nothing runs) */
+  HPGMG_LEG_FCYCLE_STEP = 6,       /* one step of FMGSolve's climb (mg.c:1289-1293): interpolation_fcycle(levels[0] <- levels[1]) and the V-cycle from levels[0] */
+  HPGMG_LEG_ASK = 16               /* added to a leg: only ask whether it would be executed */
+};
 int     hpgmg_vcycle_legs_fused(level_type **levels, int n, int e_id, int R_id, double a, double b, int leg);
+/* A plugin whose fused launches can fail AS A WHOLE (the HIP plugin's brick launches, when not all their workgroups get to run: kernels/brick_visit.hip) lets
+ * the cycle driver bracket a solve it is able to repeat from its inputs: begin() = "should such a launch fail from here on, do not stop at the next scalar";
+ * end() returns 1 when one did fail -- the plugin has then switched that form off, and the driver repeats the solve (host/mg.c FMGSolve).  Outside such a
+ * bracket a failure stops the program with a message at the next scalar, as before.  The CPU oracle: no-ops returning 0. */
+void    hpgmg_solve_attempt_begin(void);
+int     hpgmg_solve_attempt_end(void);
 /* The whole bottom solve -- IterativeSolver's BiCGStab (solvers/bicgstab.c:14-97) on level L: e_id = initial guess and solution -- as one device
  * launch where the plugin has one (27-point / fv2 / fv4: a bottom level of one small box, Dirichlet); 0 = not taken, the caller runs the
  * host-driven solver.  Same iterates, same iteration count (folded into L->Krylov_iterations by hpgmg_level_sync_counters). */

@@ -72,6 +72,8 @@ void hpgmg_set_smoother_precision(int bits) { (void)bits; }   /* the oracle is f
 int hpgmg_get_smoother_precision(void) { return 64; }
 void hpgmg_segment_begin(long long key) { (void)key; }
 void hpgmg_segment_end(void) {}
+void hpgmg_solve_attempt_begin(void) {}      /* include/hpgmg_operators.h: no launch of this plugin can fail as a whole */
+int hpgmg_solve_attempt_end(void) { return 0; }
 int hpgmg_vcycle_legs_fused(level_type **levels, int n, int e_id, int R_id, double a, double b, int leg) {
   (void)levels; (void)n; (void)e_id; (void)R_id; (void)a; (void)b; (void)leg; return 0; }
 int hpgmg_bottom_solve_fused(level_type *L, int e_id, int R_id, double a, double b, double want) {

@@ -415,20 +415,69 @@ def test_level_visits_as_one_launch_of_bricks(hip, oracle, variant, geom, brick,
             be.lib.hpgmg_mg_destroy(m); f.destroy()
 
 
-def test_a_brick_launch_with_a_workgroup_missing_ends_as_an_abort_with_a_message():
+_BRICK_SOLVE = ("import ctypes, json, hpgmg_amd as H; lib = H.load_driver(); lib.hpgmg_set_verbose(0); "
+                "lib.hpgmg_brick_visits.restype = ctypes.c_longlong; lib.hpgmg_brick_failures.restype = ctypes.c_longlong; lib.hpgmg_brick_capacity_refusals.restype = ctypes.c_longlong; "
+                "lib.hpgmg_configure(ctypes.byref(H.Config(H.OP_7PT, H.SMOOTH_CHEBY, 1, 1))); s = lib.hpgmg_solver_create(5, 8, H.BC_DIRICHLET, 0, 1); "
+                "n1 = lib.hpgmg_solver_fmg(s, 0); v1 = lib.hpgmg_brick_visits(); n2 = lib.hpgmg_solver_fmg(s, 0); "
+                "print('RESULT ' + json.dumps({'norms': ['%1.15e' % n1, '%1.15e' % n2], 'visits': [v1, lib.hpgmg_brick_visits()], 'failures': lib.hpgmg_brick_failures(), "
+                "'refusals': lib.hpgmg_brick_capacity_refusals()}))")
+
+
+def _brick_solve(env):
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _BRICK_SOLVE], capture_output=True, text=True, timeout=180, cwd=root, env=dict(os.environ, **env))
+    line = next((l for l in r.stdout.splitlines() if l.startswith("RESULT ")), None)
+    return r, (json.loads(line[7:]) if line else None)
+
+
+def test_a_brick_launch_with_a_workgroup_missing_is_repeated_launch_by_launch():
     """A brick launch needs all its workgroups running at once.  HPGMG_TEST_BRICK_ABSENT=1 makes workgroup 1 of every such launch leave at once, as if it had
-    never been given a CU: its neighbours' polls give up after 2 s, the launch ENDS (no hung GPU), and the host aborts at the next scalar it waits for, saying why."""
-    import os, subprocess, sys, time
+    never been given a CU: its neighbours' polls give up after 2 s, the launches behind it within 100 us, the launch ENDS (no hung GPU); FMGSolve learns of it at its
+    next scalar, switches brick launches off and repeats the solve launch by launch -- the reference's number, a message, and no brick launch afterwards."""
+    import json, os, time
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fcycle_norms.json")))["7pt-cheby-helm 5 8"]["norms"][0]
+    t0 = time.time()
+    r, d = _brick_solve({"HPGMG_TEST_BRICK_ABSENT": "1"})
+    assert r.returncode == 0 and d, r.stdout[-500:] + r.stderr[-1500:]
+    assert "gave up after 2 s" in r.stderr and "repeated launch by launch" in r.stderr, r.stderr[-1500:]
+    assert d["norms"] == [gold, gold], d
+    assert d["failures"] == 1 and d["visits"][0] > 0 and d["visits"][1] == d["visits"][0], d      # bricks in the failed attempt only
+    assert time.time() - t0 < 90
+    ok, d = _brick_solve({})      # the GPU is fine afterwards
+    assert ok.returncode == 0 and d["norms"] == [gold, gold] and d["failures"] == 0 and d["visits"][1] > d["visits"][0] > 0, ok.stderr[-1500:]
+
+
+def test_a_failed_brick_launch_outside_a_repeatable_solve_stops_with_a_message():
+    """The same failure under a caller that cannot repeat the solve -- MGVCycle called directly, as the reference's own driver does through operators.h: the host
+    stops at the next scalar it waits for and says why (never a wrong number)."""
+    import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = ("import ctypes, hpgmg_amd as H; lib = H.load_driver(); lib.hpgmg_set_verbose(0); "
-            "lib.hpgmg_configure(ctypes.byref(H.Config(H.OP_7PT, H.SMOOTH_CHEBY, 1, 1))); s = lib.hpgmg_solver_create(5, 8, H.BC_DIRICHLET, 0, 1); lib.hpgmg_solver_fmg(s, 0); print('SURVIVED')")
-    t0 = time.time()
+            "lib.hpgmg_configure(ctypes.byref(H.Config(H.OP_7PT, H.SMOOTH_CHEBY, 1, 1))); s = lib.hpgmg_solver_create(5, 8, H.BC_DIRICHLET, 0, 1); "
+            "lib.hpgmg_solver_mg.restype = ctypes.c_void_p; lib.hpgmg_solver_level.restype = ctypes.c_void_p; lib.norm.restype = ctypes.c_double; "
+            "lib.MGVCycle.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_int]; "
+            "lib.norm.argtypes = [ctypes.c_void_p, ctypes.c_int]; "
+            "lib.MGVCycle(lib.hpgmg_solver_mg(s), H.VECTOR_U, H.VECTOR_F, 1.0, 1.0, 0); print(lib.norm(lib.hpgmg_solver_level(s, 0), H.VECTOR_U)); print('SURVIVED')")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, cwd=root, env=dict(os.environ, HPGMG_TEST_BRICK_ABSENT="1"))
     assert r.returncode != 0 and "SURVIVED" not in r.stdout, r.stdout[-500:]
     assert "gave up after 2 s" in r.stderr and "HPGMG_BRICK_VISITS=0" in r.stderr, r.stderr[-1500:]
-    assert time.time() - t0 < 60
-    ok = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, cwd=root)      # the GPU is fine afterwards
-    assert ok.returncode == 0 and "SURVIVED" in ok.stdout, ok.stderr[-1500:]
+
+
+def test_brick_launches_are_not_attempted_beyond_what_the_device_holds():
+    """Every workgroup of a brick launch must be resident at once.  The plugin asks the runtime (occupancy of the kernel x CUs of the device) and leaves a level with
+    more bricks than that (less an eighth) to the launch-by-launch path.  HPGMG_TEST_BRICK_CAPACITY=100 stands for a partitioned device: 87 usable slots -- the 32^3
+    and 16^3 levels (64 and 8 bricks) still go as bricks, the 64^3 level (512) does not; =8: none does.  Same numbers throughout."""
+    import json, os
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fcycle_norms.json")))["7pt-cheby-helm 5 8"]["norms"][0]
+    full, d_full = _brick_solve({})
+    part, d_part = _brick_solve({"HPGMG_TEST_BRICK_CAPACITY": "100"})
+    none, d_none = _brick_solve({"HPGMG_TEST_BRICK_CAPACITY": "8"})
+    for r, d in ((full, d_full), (part, d_part), (none, d_none)):
+        assert r.returncode == 0 and d and d["norms"] == [gold, gold] and d["failures"] == 0, r.stderr[-1500:]
+    assert d_full["refusals"] == 0 and d_full["visits"][0] > 0
+    assert d_part["refusals"] > 0 and 0 < d_part["visits"][0] < d_full["visits"][0], (d_part, d_full)
+    assert d_none["refusals"] > 0 and d_none["visits"][1] == 0, d_none
 
 
 def test_brick_launches_repeat_bit_for_bit():
