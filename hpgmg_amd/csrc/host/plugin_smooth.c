@@ -37,17 +37,19 @@ int hpgmg_vcycle_legs_fused(level_type **levels, int n, int e_id, int R_id, doub
  * sweeps of the generic form.  The first version (1024 lanes) was slower everywhere: the bottom solve's 240 registers per lane spilled into
  * scratch memory under the 128-register cap; with 512 lanes the launch of 8^3 + 4^3 + 2^3 levels takes 169 instead of 191 us (fv4 GSRB;
  * tools/exp_vtail_timeline.py): 4 x 24 us of smoothing, 28 us of bottom solve, the rest image traffic and interpolation. */
+static level_type *tail_books_on = NULL;      /* the level whose timers take the tail launch when bricks were visited above it (else its own first level) */
+static int tail_follows_bricks = 0;      /* the chain handed to small_vtail_fused is what is left below levels visited as bricks (hp_vcycle_legs_fused) */
 static long long small_vtails = 0;
 long long hpgmg_small_vtails(void) { return small_vtails; }
 void hpgmg_set_small_vtail(int on) { hp_switch_set(SW_SMALL_VTAIL, (on == 2) ? 2 : (on ? 1 : 0)); }      /* 0 off, 1 on for every plugin, 2 the default (not for 27-point GSRB) */
-static int small_vtail_fused(level_type **levels, int n, int e_id, int R_id, double a, double b, int legs) {
+static int small_vtail_fused(level_type **levels, int n, int e_id, int R_id, double a, double b, int legs, int ask_only) {
   hpgmg_config cfg;
   hpgmg_hip_small_tail_args T;
   int l;
   const int small_vtail_on = (int)hp_switch(SW_SMALL_VTAIL);      /* 2: the default */
   if (!small_vtail_on) return 0;
   hpgmg_get_config(&cfg);
-  if (small_vtail_on == 2 && cfg.op == HPGMG_OP_27PT && cfg.smoother == HPGMG_SMOOTH_GSRB) return 0;
+  if (small_vtail_on == 2 && cfg.op == HPGMG_OP_27PT && cfg.smoother == HPGMG_SMOOTH_GSRB && !tail_follows_bricks) return 0;      /* (below brick launches it is the tail: the legs must stay whole) */
   const int sweeps = hpgmg_smooth_sweeps();
   if (n < 2 || n > HPGMG_HIP_SMALL_TAIL_MAX_LEVELS || sweeps < 1 || sweeps > 8 || (sweeps & 1) || hp_switch(SW_GRAPH)) return 0;      /* (captured segments: the argument block's upload is not capturable) */
   if (cfg.smoother != HPGMG_SMOOTH_CHEBY && cfg.smoother != HPGMG_SMOOTH_GSRB && cfg.smoother != HPGMG_SMOOTH_JACOBI) return 0;
@@ -96,7 +98,8 @@ static int small_vtail_fused(level_type **levels, int n, int e_id, int R_id, dou
     }
   }
   if (hpgmg_hip_small_vtail_lds_doubles(&T) > hpgmg_hip_small_vtail_lds_limit()) return 0;
-  TICK(levels[0], smooth, "fused V-cycle tail (levels of one box)");
+  if (ask_only) return 1;
+  TICK(tail_books_on ? tail_books_on : levels[0], smooth, "fused V-cycle tail (levels of one box)");
   HIP_OK(hpgmg_hip_small_vtail(&T, hp_variant()));
   TOCK();
   small_vtails++;
@@ -106,6 +109,7 @@ void hpgmg_set_fused_tail(int on) { hp_switch_set(SW_FUSED_TAIL, on ? 1 : 0); } 
 void hpgmg_set_fused_bottom(int on) { hp_switch_set(SW_FUSED_BOTTOM, on ? 1 : 0); }  /* tests: 0 = the bottom solve driven from the host (host/solvers.c BiCGStab through the operators) */
 void hpgmg_set_brick_visits(int on) { hp_switch_set(SW_BRICK_VISITS, on ? 1 : 0); if (on == 8 || on == 16) hp_switch_set(SW_BRICK_SIZE, on); }      /* 0 off, 1 on, 8 / 16: on with bricks of that side */
 long long hpgmg_brick_visits(void) { return hpgmg_hip_brick_visits(); }
+void hpgmg_set_brick_wide(int on) { hp_switch_set(SW_BRICK_WIDE, on ? 1 : 0); }      /* 0: the 27-point / fv4 plugins visit their launch-bound levels launch by launch (tests) */
 void hpgmg_set_brick_chains(int on) { hp_switch_set(SW_BRICK_CHAIN, on ? 1 : 0); }      /* 0: one launch per level visit instead of one per V-cycle leg (tests) */
 /* what the kernels that address cells by global coordinate need of a level (tail.hip, brick_visit.hip): a cubic Dirichlet domain whose boxes are all
  * here, all faces local, local box b at lexicographic position b */
@@ -124,22 +128,30 @@ static int dense_level_ok(level_type *L) {
 }
 /* How many leading levels of the chain are visited as bricks of 8^3 / 16^3 cells, one launch per visit (kernels/brick_visit.hip): the levels of 64^3 / 32^3
  * cells above the single-workgroup tail.  0: none. */
+static int brick_op_is_wide(const hpgmg_config *cfg) { return cfg->op == HPGMG_OP_27PT || cfg->op == HPGMG_OP_FV4; }
 static long long brick_capacity_refusals = 0;
 long long hpgmg_brick_capacity_refusals(void) { return brick_capacity_refusals; }      /* level visits left to the launch-by-launch path because the device does not hold that many bricks at once (tests) */
 static int brick_prefix(level_type **levels, int n, const hpgmg_config *cfg) {
   const int sweeps = hpgmg_smooth_sweeps();
   int k = 0;
-  if (!hp_switch(SW_BRICK_VISITS) || !hp_switch(SW_FUSED_TAIL) || hp_switch(SW_GRAPH) || !hp_ghost_free_mode() || cfg->op != HPGMG_OP_7PT) return 0;
+  const int wide = brick_op_is_wide(cfg);      /* 27-point / fv4: kernels/brick_wide.hip (bricks of 8^3 only, Chebyshev or out-of-place GSRB) */
+  if (!hp_switch(SW_BRICK_VISITS) || !hp_switch(SW_FUSED_TAIL) || hp_switch(SW_GRAPH)) return 0;
+  if (wide ? (!hp_switch(SW_BRICK_WIDE) || (cfg->smoother != HPGMG_SMOOTH_CHEBY && cfg->smoother != HPGMG_SMOOTH_GSRB) || (cfg->smoother == HPGMG_SMOOTH_GSRB && !hpgmg_gsrb_out_of_place()))
+           : (!hp_ghost_free_mode() || cfg->op != HPGMG_OP_7PT)) return 0;
   if (sweeps < 1 || sweeps > hpgmg_hip_brick_visit_max_sweeps() || (sweeps & 1)) return 0;
   while (k + 1 < n) {
     level_type *L = levels[k];
-    const int fits_tail = ((long long)L->dim.i * L->dim.j * L->dim.k <= hpgmg_hip_tail_max_cells());
+    /* where the single-workgroup tail takes over: the 7-point tail holds levels up to 16^3; the tail of the other plugins starts at the first level of ONE box */
+    const int fits_tail = wide ? (L->num_my_boxes == 1 && L->boxes_in.i * L->boxes_in.j * L->boxes_in.k == 1 && L->dim.i <= 8)
+                               : ((long long)L->dim.i * L->dim.j * L->dim.k <= hpgmg_hip_tail_max_cells());
     if (L->dim.i < (int)hp_switch(SW_BRICK_MIN_DIM) && fits_tail) break;
     if (!dense_level_ok(L) || !dense_level_ok(levels[k + 1]) || 2 * levels[k + 1]->dim.i != L->dim.i) return 0;
-    if (!hpgmg_hip_brick_visit_supported(&hp_backend_of(L)->dev, (int)hp_switch(SW_BRICK_SIZE))) { if (fits_tail) break; return 0; }
+    if (wide ? !hpgmg_hip_brick_wide_supported(&hp_backend_of(L)->dev, hp_variant())
+             : !hpgmg_hip_brick_visit_supported(&hp_backend_of(L)->dev, (int)hp_switch(SW_BRICK_SIZE))) { if (fits_tail) break; return 0; }
     { /* every brick of a launch must be running at once: more bricks than the device holds of this kernel = the launch-by-launch path (kernels/brick_visit.hip) */
-      const int brick = (int)hp_switch(SW_BRICK_SIZE), side = L->dim.i / brick;
-      if (side * side * side > hpgmg_hip_brick_chain_capacity(hp_variant(), cfg->smoother, brick)) { brick_capacity_refusals++; if (fits_tail) break; return 0; }
+      const int brick = wide ? 8 : (int)hp_switch(SW_BRICK_SIZE), side = L->dim.i / brick;
+      const int capacity = wide ? hpgmg_hip_brick_wide_capacity(hp_variant(), cfg->smoother) : hpgmg_hip_brick_chain_capacity(hp_variant(), cfg->smoother, brick);
+      if (side * side * side > capacity) { brick_capacity_refusals++; if (fits_tail) break; return 0; }
     }
     if (L->dominant_eigenvalue_of_DinvA <= 0.0 && cfg->smoother == HPGMG_SMOOTH_CHEBY) return 0;
     k++;
@@ -166,13 +178,16 @@ static void brick_chain(level_type *top, level_type **levels, int first, int cou
     const int is_first_launch = (done == 0), is_last_launch = (done + n == count);
     TICK(top, smooth, dir == 1 ? "level visits, up (bricks: interpolation + smooth per level, one launch)" :
                       (dir == 0 ? "level visits, down (bricks: smooth + residual + restriction per level, one launch)" : "interpolation_fcycle + level visit, down (bricks, one launch)"));
+    if (brick_op_is_wide(cfg))
+      HIP_OK(hpgmg_hip_brick_wide_chain(n, lv, &hp_backend_of(levels[lo + n])->dev, sweeps, hp_variant(), cfg->smoother, e_id, R_id, a, b, dir,
+                                        dir == 0 ? (is_first_launch ? top_e_zero : 1) : 0, (dir != 1 && is_last_launch) ? below_zero : 0));
+    else
     HIP_OK(hpgmg_hip_brick_chain(n, lv, &hp_backend_of(levels[lo + n])->dev, sweeps, hp_variant(), cfg->smoother, e_id, R_id, a, b, dir, (int)hp_switch(SW_BRICK_SIZE),
                                  dir == 0 ? (is_first_launch ? top_e_zero : 1) : 0, (dir != 1 && is_last_launch) ? below_zero : 0));
     TOCK();
     done += n;
   }
 }
-static level_type *tail_books_on = NULL;      /* the level whose timers take the tail launch when bricks were visited above it (else its own first level) */
 /* leg 16 + x: would leg x be taken?  (nothing is launched) */
 int hp_vcycle_legs_fused(level_type **levels, int n, int e_id, int R_id, double a, double b, int leg) {
   hpgmg_config cfg;
@@ -187,17 +202,21 @@ int hp_vcycle_legs_fused(level_type **levels, int n, int e_id, int R_id, double 
      * FMGSolve's climb (mg.c:1289-1293): interpolation_fcycle(levels[0] <- levels[1]) rides in the first launch of the V-cycle that follows it --
      * every brick of that launch reads levels[1]'s correction, so its zero_vector is left to the launch that visits levels[1] (a brick level too). */
     const int fstep = (leg == 6), vleg = fstep ? 2 : leg;
-    if (fstep && !hp_switch(SW_BRICK_FSTEP)) return 0;
+    if (fstep && (!hp_switch(SW_BRICK_FSTEP) || brick_op_is_wide(&cfg))) return 0;      /* (27-point / fv4: interpolation_fcycle stays a launch of its own) */
     const int k = brick_prefix(levels, n, &cfg);
-    if (k > (fstep ? 1 : 0) && hp_vcycle_legs_fused(levels + k, n - k, e_id, R_id, a, b, 16 + vleg)) {
+    const int outer_follows = tail_follows_bricks;      /* (the call for the tail comes through here again, with k == 0) */
+    tail_follows_bricks = outer_follows || (k > 0);
+    const int tail_ok = (k > (fstep ? 1 : 0)) && hp_vcycle_legs_fused(levels + k, n - k, e_id, R_id, a, b, 16 + vleg);
+    tail_follows_bricks = outer_follows;
+    if (tail_ok) {
       /* zero_vector of a brick level below the first: by the launch that visits it (which then does not read the vector either); the tail's first level: here */
       if (vleg != 1) {
         if (fstep) { brick_chain(levels[0], levels, 0, 1, &cfg, e_id, R_id, a, b, 2, 0, 0); brick_chain(levels[0], levels, 1, k - 1, &cfg, e_id, R_id, a, b, 0, 1, 1); }
         else brick_chain(levels[0], levels, 0, k, &cfg, e_id, R_id, a, b, 0, 0, 1);
       }
-      tail_books_on = levels[0];
+      tail_books_on = levels[0]; tail_follows_bricks = 1;
       const int taken = hp_vcycle_legs_fused(levels + k, n - k, e_id, R_id, a, b, vleg);
-      tail_books_on = NULL;
+      tail_books_on = NULL; tail_follows_bricks = outer_follows;
       if (!taken) { fprintf(stderr, "hpgmg: the V-cycle tail was refused after being accepted\n"); abort(); }
       if (vleg != 0) brick_chain(levels[0], levels, 0, k, &cfg, e_id, R_id, a, b, 1, 0, 0);
       return 1;
@@ -214,8 +233,8 @@ int hp_vcycle_legs_fused(level_type **levels, int n, int e_id, int R_id, double 
   const int sweeps = hpgmg_smooth_sweeps();
   const int with_bottom = (leg >= 2);
   if (enabled && cfg.op != HPGMG_OP_7PT) {      /* leg 0 / 1: the way down / up around a bottom solve somebody else runs (the reference's driver, through the queue below) */
-    if (leg == 2) return bottom_enabled ? small_vtail_fused(levels, n, e_id, R_id, a, b, 7) : 0;
-    if (leg == 0 || leg == 1) return small_vtail_fused(levels, n, e_id, R_id, a, b, leg == 0 ? 1 : 4);
+    if (leg == 2) return bottom_enabled ? small_vtail_fused(levels, n, e_id, R_id, a, b, 7, probe) : 0;
+    if (leg == 0 || leg == 1) return small_vtail_fused(levels, n, e_id, R_id, a, b, leg == 0 ? 1 : 4, probe);
     return 0;
   }
   if (!enabled || !hp_ghost_free_mode() || cfg.op != HPGMG_OP_7PT || n > 8 || n > hpgmg_hip_tail_max_levels() || sweeps > 8) return 0;

@@ -36,6 +36,7 @@ static struct { const char *env; int kind; long long dflt; const char *what; lon
   [SW_BRICK_MIN_DIM]    = { "HPGMG_TUNE_BRICK_MIN", K_INT, 16, "smallest level (cells per side) visited as bricks; the levels below it are the single-workgroup tail's" },
   [SW_BRICK_FSTEP]      = { "HPGMG_TUNE_BRICK_FSTEP", K_ON, 1, "FMGSolve: interpolation_fcycle onto a brick level rides in the first launch of the V-cycle that follows it" },
   [SW_BRICK_CHAIN]      = { "HPGMG_TUNE_BRICK_CHAIN", K_INT, 1, "consecutive brick levels of a V-cycle leg in ONE launch (what passes between the levels passes inside it); 0: one launch per level visit" },
+  [SW_BRICK_WIDE]       = { "HPGMG_BRICK_WIDE", K_ON, 1, "27-pt / fv4: the same for the operators with wide stencils (kernels/brick_wide.hip: halo of the stencil's radius, apply_BCs_p2 / _v4 on the LDS image)" },
   [SW_SMOOTHER_PRECISION]= { "HPGMG_SMOOTHER_PRECISION", K_INT, 64, "32: fp32 coefficient streams in the Chebyshev sweep pairs (BASELINE config 5, tolerance-gated); 64: bit-exact" },
 };
 

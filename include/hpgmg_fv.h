@@ -100,6 +100,7 @@ void        hpgmg_set_brick_visits(int on);    /* 0: the 32^3 / 64^3 levels of a
 long long   hpgmg_brick_visits(void);          /* level visits done that way so far (tests) */
 long long   hpgmg_brick_failures(void);        /* solves repeated launch by launch because a brick launch did not get all its workgroups running (tests) */
 long long   hpgmg_brick_capacity_refusals(void);      /* level visits left to the launch-by-launch path because the device does not hold that many bricks at once (tests) */
+void        hpgmg_set_brick_wide(int on);      /* 0: the 27-point / fv4 plugins visit their launch-bound levels launch by launch (kernels/brick_wide.hip off; tests) */
 void        hpgmg_set_brick_chains(int on);    /* 0: one launch per level visit instead of one per V-cycle leg (tests) */
 long long   hpgmg_pair_remote_smooths(void);   /* smooth() calls executed as sweep pairs with faces owned by other ranks (tests) */
 long long   hpgmg_fused_residuals_remote(void); /* 7-point: fused residual passes (residual + restriction, residual + norm) run on levels with faces owned by other ranks (tests) */

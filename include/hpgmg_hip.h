@@ -388,6 +388,15 @@ int hpgmg_hip_brick_chain_max_levels(void);
  *   every brick reads below.e, so below_zero must be 0 and the launch that visits `below` clears it (top_e_zero). */
 int hpgmg_hip_brick_chain(int n, const hpgmg_hip_brick_level *levels, const hpgmg_hip_level *below, int sweeps, int variant, int smoother,
                           int e_id, int R_id, double a, double b, int dir, int brick, int top_e_zero, int below_zero);
+/* ---- brick_wide.hip: the same for the 27-point and 4th-order operators (variants HPGMG_HIP_27PT_CC, HPGMG_HIP_FV4_*): bricks of 8^3 cells with a halo of the stencil's
+ *      radius (faces + edges + corners / faces + edges), every shell cell published once per exchange and fetched by whichever neighbour needs it, apply_BCs_p2 / _v4
+ *      formed on the LDS image after the exchange, interpolation_p2 / _v2 on the way up from an image of the brick's parents; smoother 0 Chebyshev, 1 GSRB (out of
+ *      place, operators.27pt.c:126 / operators.fv4.c:178).  dir 0 / 1 and the two flags as hpgmg_hip_brick_chain.  Replaces per level visit the 13 + 2 + 1 (fv4 GSRB) launches of
+ *      mg.c:1147-1153 with operators/gsrb.c:24-132, boundary_fv.c:262-569, residual.c, restriction.c and the 2 + 12 of mg.c:1160-1161 with interpolation_v2.c. ---- */
+int hpgmg_hip_brick_wide_supported(const hpgmg_hip_level *L, int variant);
+int hpgmg_hip_brick_wide_capacity(int variant, int smoother);
+int hpgmg_hip_brick_wide_chain(int n, const hpgmg_hip_brick_level *levels, const hpgmg_hip_level *below, int sweeps, int variant, int smoother,
+                               int e_id, int R_id, double a, double b, int dir, int top_e_zero, int below_zero);
 long long hpgmg_hip_brick_visits(void);      /* level visits so far (tests) */
 int hpgmg_hip_brick_visit_error(void);       /* 1: a poll of an earlier launch gave up after 2 s (a workgroup of the launch was not running): results are void */
 int hpgmg_hip_brick_visit_error_clear(void); /* the host has dealt with it (synchronises) */

@@ -415,6 +415,85 @@ def test_level_visits_as_one_launch_of_bricks(hip, oracle, variant, geom, brick,
             be.lib.hpgmg_mg_destroy(m); f.destroy()
 
 
+@pytest.mark.parametrize("variant", ["fv4-gsrb", "fv4-cheby", "27pt-gsrb", "27pt-cheby", "fv4-gsrb-helm"])
+@pytest.mark.parametrize("geom,chains", [((4, 16), 1), ((1, 64), 1), ((2, 16), 1), ((2, 8), 1), ((2, 32), 0), ((4, 8), 1)])
+def test_level_visits_as_one_launch_of_bricks_wide_stencils(hip, oracle, variant, geom, chains):
+    """kernels/brick_wide.hip: the same for the 27-point and 4th-order plugins (operators.27pt.c, operators.fv4.c): MGVCycle (mg.c:1133-1166) from a level of 64^3,
+    32^3 or 16^3 cells -- the visits of the levels above the one-box tail are ONE launch per V-cycle leg: bricks of 8^3 cells with a halo of the stencil's radius
+    (faces + edges + corners / two-deep faces + edges), the conditions of apply_BCs_p2 / apply_BCs_v4 formed on the LDS image after every exchange, interpolation_p2 /
+    _v2 on the way up from an image of the brick's parents, out-of-place GSRB as LDS ping-pong.  (4, 16) is the shape of BASELINE config 3's launch-bound levels: 64
+    boxes of 16^3, then 64 of 8^3, then 8 of 8^3.  Every vector of every level must be, byte for byte, what the oracle's operator-by-operator cycle leaves."""
+    from hpgmg_testlib import Level
+    set_mode(hip, 1)
+    pairs = []
+    for be in (hip, oracle):
+        be.configure(**VARIANTS[variant])
+        fine = be.level(*geom)
+        for vid in range(fine.num_vectors):
+            d = seeded_field(fine, 2500 + vid)
+            if vid >= H.VECTOR_DINV:
+                d = np.abs(d) + 0.5
+            fine.write_all(vid, d)
+        for vid in range(H.VECTOR_DINV, fine.num_vectors):
+            be.lib.exchange_boundary(fine.ptr, vid, H.STENCIL_SHAPE_BOX)
+        a, b = (1.0, 1.0) if "helm" in variant else (0.0, 1.0)
+        mg = be.lib.hpgmg_mg_create(fine.ptr, a, b, 1)
+        be.lib.rebuild_operator(fine.ptr, None, a, b)
+        pairs.append((be, fine, mg, a, b))
+    try:
+        (bh, fh, mh, a, b), (bo, fo, mo, _, _) = pairs
+        L = hip.lib
+        L.hpgmg_brick_visits.restype = ctypes.c_longlong
+        L.hpgmg_set_brick_visits.argtypes = [ctypes.c_int]
+        L.hpgmg_set_brick_wide.argtypes = [ctypes.c_int]
+        L.hpgmg_set_brick_chains.argtypes = [ctypes.c_int]
+        L.hpgmg_set_brick_visits(8)
+        L.hpgmg_set_brick_wide(1)
+        L.hpgmg_set_brick_chains(chains)
+        for be in (bh, bo):
+            be.lib.MGVCycle.restype = None
+            be.lib.MGVCycle.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_int]
+            be.lib.hpgmg_mg_num_levels.restype = ctypes.c_int
+        n = bh.lib.hpgmg_mg_num_levels(mh)
+        assert n == bo.lib.hpgmg_mg_num_levels(mo)
+        lv = lambda be, m, l: Level(be, be.lib.hpgmg_mg_level(m, l))
+
+        def junk(base):
+            for l in range(n):
+                for be, m in ((bh, mh), (bo, mo)):
+                    x = lv(be, m, l)
+                    for vid, seed in ((H.VECTOR_U, 31), (H.VECTOR_F, 32), (H.VECTOR_TEMP, 33)):
+                        x.write_all(vid, seeded_field(x, base + 10 * l + seed))
+        junk(2600)
+        top = geom[0] * geom[1]
+        want = 2 * sum(1 for l in range(n) if 16 <= (top >> l) <= 64)
+        assert want > 0
+        before = L.hpgmg_brick_visits()
+        bh.lib.MGVCycle(mh, H.VECTOR_U, H.VECTOR_F, a, b, 0)
+        bh.lib.hpgmg_operators_flush()
+        assert L.hpgmg_brick_visits() == before + want, "the launch-bound levels were not visited as bricks"
+        bo.lib.MGVCycle(mo, H.VECTOR_U, H.VECTOR_F, a, b, 0)
+        for l in range(n):
+            same(lv(bh, mh, l), lv(bo, mo, l), [H.VECTOR_U, H.VECTOR_F, H.VECTOR_TEMP], interior_only=True)
+        # the same cycle launch by launch gives the same bytes (and launches no bricks)
+        junk(2700)
+        bo.lib.MGVCycle(mo, H.VECTOR_U, H.VECTOR_F, a, b, 0)
+        L.hpgmg_set_brick_wide(0)
+        try:
+            before = L.hpgmg_brick_visits()
+            bh.lib.MGVCycle(mh, H.VECTOR_U, H.VECTOR_F, a, b, 0)
+            bh.lib.hpgmg_operators_flush()
+            assert L.hpgmg_brick_visits() == before
+            for l in range(n):
+                same(lv(bh, mh, l), lv(bo, mo, l), [H.VECTOR_U, H.VECTOR_F], interior_only=True)
+        finally:
+            L.hpgmg_set_brick_wide(1)
+            L.hpgmg_set_brick_chains(1)
+    finally:
+        for be, f, m, _, _ in pairs:
+            be.lib.hpgmg_mg_destroy(m); f.destroy()
+
+
 _BRICK_SOLVE = ("import ctypes, json, hpgmg_amd as H; lib = H.load_driver(); lib.hpgmg_set_verbose(0); "
                 "lib.hpgmg_brick_visits.restype = ctypes.c_longlong; lib.hpgmg_brick_failures.restype = ctypes.c_longlong; lib.hpgmg_brick_capacity_refusals.restype = ctypes.c_longlong; "
                 "lib.hpgmg_configure(ctypes.byref(H.Config(H.OP_7PT, H.SMOOTH_CHEBY, 1, 1))); s = lib.hpgmg_solver_create(5, 8, H.BC_DIRICHLET, 0, 1); "
