@@ -145,6 +145,7 @@ static int brick_prefix(level_type **levels, int n, const hpgmg_config *cfg) {
     const int fits_tail = wide ? (L->num_my_boxes == 1 && L->boxes_in.i * L->boxes_in.j * L->boxes_in.k == 1 && L->dim.i <= 8)
                                : ((long long)L->dim.i * L->dim.j * L->dim.k <= hpgmg_hip_tail_max_cells());
     if (L->dim.i < (int)hp_switch(SW_BRICK_MIN_DIM) && fits_tail) break;
+    if (wide && L->dim.i > (int)hp_switch(SW_BRICK_WIDE_MAX_DIM)) return 0;      /* (a tuning switch: all three launch-bound levels pay, profiles/r06d_ab_wide_max.txt) */
     if (!dense_level_ok(L) || !dense_level_ok(levels[k + 1]) || 2 * levels[k + 1]->dim.i != L->dim.i) return 0;
     if (wide ? !hpgmg_hip_brick_wide_supported(&hp_backend_of(L)->dev, hp_variant())
              : !hpgmg_hip_brick_visit_supported(&hp_backend_of(L)->dev, (int)hp_switch(SW_BRICK_SIZE))) { if (fits_tail) break; return 0; }

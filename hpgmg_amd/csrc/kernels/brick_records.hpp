@@ -1,19 +1,20 @@
 // brick_records.hpp -- what the brick launches (brick_visit.hip: 7-point; brick_wide.hip: 27-point / fv4) share: the 16-byte self-flagging record a cell
 // travels in between workgroups of ONE launch, the record areas, the launch epoch, the error word and the co-residency guard.
 //
-// A record is {tag, value low word, value high word, tag}: written through (sc1) with one 16-byte store by the lane that owns the cell, polled (sc1 loads) by
-// the lane that needs it, accepted only when BOTH tags carry the expected number.  The architecture does not promise that a 16-byte store is observed
-// whole; a store that lands in two pieces (of 4 or 8 bytes, in either order) shows a reader one old tag until the second piece is there, i.e. reads as "not
-// yet".  Tags never repeat inside the life of the record areas: tag = launch epoch (launch number x 64, 32 bits) + a code for the record's role; when the
-// 32-bit epoch would wrap, the areas are cleared first (brick_next_epoch).
+// A record is 16 bytes in two 8-byte words, {tag, value low half} and {value high half, tag}: each word is written with ONE 8-byte store and read with ONE 8-byte
+// load (relaxed atomics of agent scope = global_store / global_load ... sc1: written through, read past this XCD's L2 -- the L2s of the eight XCDs are not coherent
+// inside a kernel), by the lane that owns the cell and the lane that needs it.  An aligned 8-byte access is single-copy atomic, so each word is seen whole; a
+// record is accepted when BOTH words carry the expected tag -- a reader that catches the record between the two stores sees one old tag and reads "not yet".  No
+// inline assembly, no store the compiler cannot pad, and the compiler keeps several polls of a lane in flight at once.  Tags never repeat inside the life of
+// the record areas: tag = launch epoch (launch number x 64, 32 bits) + a code for the record's role; when the 32-bit epoch would wrap, the areas are
+// cleared first (brick_records_for_launch).
 #pragma once
 #include "common.hpp"
 
 namespace hpgmg {
 
 typedef unsigned long long u64;
-typedef unsigned __attribute__((ext_vector_type(4))) u4v;
-struct alignas(16) FaceCell { unsigned tag0, lo, hi, tag1; };
+struct alignas(16) FaceCell { u64 w0, w1; };      // w0 = tag | (value bits 0..31) << 32;  w1 = (value bits 32..63) | tag << 32
 
 constexpr int kBrickMaxSweeps = 8, kBrickMaxLevels = 3, kBrickMaxWgs = 512;
 // record areas, each per level of a chain: faces [2 parities][workgroup][6][B^2] (7-point: 8^3 bricks of 8^3 cells fill it; 4^3 bricks of 16^3 take half;
@@ -34,33 +35,55 @@ struct BrickRecords {
 };
 
 __device__ __forceinline__ void face_store(FaceCell *p, double v, unsigned tag) {
-  const long long b = __double_as_longlong(v);
-  u4v w; w.x = tag; w.y = (unsigned)b; w.z = (unsigned)(b >> 32); w.w = tag;
-  // the s_nop: the data registers of a VMEM store of more than 8 bytes are read for some cycles after issue, and a VALU write to them in that window
-  // corrupts the store (the hazard LLVM's GCNHazardRecognizer pads its own stores against: 1 wait state, 2 on gfx940 and later; it cannot see into an asm
-  // statement).  s_nop 3 = 4 wait states inside the same statement, so nothing can be scheduled between the store and the padding.
-  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 3" :: "v"(p), "v"(w) : "memory");
+  const u64 bits = (u64)__double_as_longlong(v);
+  __hip_atomic_store(&p->w0, (u64)tag | (bits << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(&p->w1, (bits >> 32) | ((u64)tag << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ u4v face_load(const FaceCell *p) {
-  u4v w;
-  asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(w) : "v"(p) : "memory");
+struct FaceWords { u64 w0, w1; };
+__device__ __forceinline__ FaceWords face_load(const FaceCell *p) {
+  FaceWords w;
+  w.w0 = __hip_atomic_load(&p->w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  w.w1 = __hip_atomic_load(&p->w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   return w;
 }
-// the value of a record once both its tags carry `tag` (nap: s_sleep units between polls)
+__device__ __forceinline__ bool face_ready(const FaceWords &w, unsigned tag) { return (unsigned)w.w0 == tag && (unsigned)(w.w1 >> 32) == tag; }
+__device__ __forceinline__ double face_value(const FaceWords &w) { return __longlong_as_double((long long)((w.w0 >> 32) | (w.w1 << 32))); }
+// a poll that is not answered yet: give up after 2 s; after 100 us look (once) at the error word -- a launch behind a failed one ends at once
+__device__ __forceinline__ bool poll_expired(u64 t0, bool &looked, const unsigned *error_dev) {
+  const u64 waited = __builtin_amdgcn_s_memrealtime() - t0;
+  if (waited > kPollTicks) return true;
+  if (waited > kPollLookTicks && !looked) {
+    looked = true;
+    if (error_dev && __hip_atomic_load(error_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return true;
+  }
+  return false;
+}
+// the value of a record once both its words carry `tag` (nap: s_sleep units between polls)
 __device__ __forceinline__ double record_wait(const FaceCell *p, unsigned tag, u64 t0, bool &gave_up, const unsigned *error_dev, int nap = 1) {
-  u4v x = face_load(p);
+  FaceWords x = face_load(p);
   bool looked = false;
-  while (x.x != tag || x.w != tag) {
-    const u64 waited = __builtin_amdgcn_s_memrealtime() - t0;
-    if (waited > kPollTicks) { gave_up = true; break; }
-    if (waited > kPollLookTicks && !looked) {
-      looked = true;
-      if (error_dev && __hip_atomic_load(error_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { gave_up = true; break; }
-    }
+  while (!face_ready(x, tag)) {
+    if (poll_expired(t0, looked, error_dev)) { gave_up = true; break; }
     if (nap > 1) __builtin_amdgcn_s_sleep(8); else __builtin_amdgcn_s_sleep(1);
     x = face_load(p);
   }
-  return __longlong_as_double((long long)(((u64)x.z << 32) | x.y));
+  return face_value(x);
+}
+// N records at once: every poll round has all the still-missing ones in flight together (one memory round trip per round, not one per record).
+// pending: bit m set = record p[m] is wanted; out[m] is written for those
+template <int N>
+__device__ __forceinline__ void record_wait_many(const FaceCell *const (&p)[N], unsigned pending, unsigned tag, double (&out)[N], u64 t0, bool &gave_up, const unsigned *error_dev) {
+  bool looked = false;
+  while (pending) {
+    FaceWords x[N];
+#pragma unroll
+    for (int m = 0; m < N; m++) if ((pending >> m) & 1u) x[m] = face_load(p[m]);
+#pragma unroll
+    for (int m = 0; m < N; m++) if (((pending >> m) & 1u) && face_ready(x[m], tag)) { out[m] = face_value(x[m]); pending &= ~(1u << m); }
+    if (!pending) break;
+    if (poll_expired(t0, looked, error_dev)) { gave_up = true; break; }
+    __builtin_amdgcn_s_sleep(1);
+  }
 }
 __device__ __forceinline__ void brick_raise_error(const BrickRecords &R) {
   if (R.error) __hip_atomic_store(R.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

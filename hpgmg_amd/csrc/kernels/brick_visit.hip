@@ -11,9 +11,9 @@
 //
 // Everything that crosses a workgroup boundary INSIDE the launch -- faces between sweeps, the restricted residuals a level hands to the one below it, the
 // corrections it hands to the one above -- goes THROUGH MEMORY WITHOUT LEAVING THE KERNEL.  The XCDs' L2 caches are not coherent with each other inside a
-// kernel, so a cell travels as a 16-byte record {tag, value, tag} (brick_records.hpp) written through (sc1) by the lane that owns the cell and polled (sc1
-// loads) by the lane that needs it, accepted when BOTH tags carry the expected number (a store observed in two pieces reads as "not yet"): the record is its
-// own flag -- one memory hop, no counter everybody adds to, no fence.  tools/microbench/p2p_flags.hip: 1.6 us per
+// kernel, so a cell travels as a 16-byte record of two 8-byte words {tag, value low} {value high, tag} (brick_records.hpp), each written through with one
+// atomic store by the lane that owns the cell and polled with atomic loads by the lane that needs it, accepted when BOTH words carry the expected tag: the
+// record is its own flag -- one memory hop, no counter everybody adds to, no fence.  tools/microbench/p2p_flags.hip: 1.6 us per
 // exchange for 8 .. 64 workgroups, 2.4 for 256, against 3.1-3.7 us for a kernel boundary around the same traffic, 2.4-8.3 for data + flag, 5.7-76 for a
 // central counter (what grid.sync() is).  Face records are double-buffered by exchange parity: a brick can publish exchange n only after it has read all
 // its neighbours' exchange n-1, which they published after reading n-2 -- the slot of parity n is free.  Tags never repeat (launch number x 64 + a code

@@ -193,12 +193,21 @@ __global__ __launch_bounds__(256, 3) void brick_wide_kernel(const WideArgs A) {
 #pragma unroll
       for (int m = 0; m < 2; m++)
         if (own_shell[m] && (colour < 0 || (colour0 ^ m) == colour || own_corner[m])) face_store(faces + ((size_t)par * nwg + wg) * 512 + (2 * t + m), img[pos0 + m], seq);
+      const FaceCell *want[kSlots];
+      double got[kSlots];
+      unsigned pending = 0;
 #pragma unroll
       for (int m = 0; m < kSlots; m++) {
+        want[m] = faces + (size_t)par * nwg * 512 + h_rec[m];
+        got[m] = 0.0;
         if (!(h_state[m] & 1)) continue;
         if (colour >= 0 && ((h_state[m] >> 1) & 1) != colour && !(h_state[m] & 4)) img[h_pos[m]] = from[h_pos[m]];
-        else img[h_pos[m]] = record_wait(faces + (size_t)par * nwg * 512 + h_rec[m], seq, t0, gave_up, err_dev);
+        else pending |= 1u << m;
       }
+      const unsigned polled = pending;
+      record_wait_many<kSlots>(want, pending, seq, got, t0, gave_up, err_dev);      // all of the lane's records in flight together
+#pragma unroll
+      for (int m = 0; m < kSlots; m++) if ((polled >> m) & 1u) img[h_pos[m]] = got[m];
       __syncthreads();
     };
     // apply_BCs on the image: the 488 cells of the one-cell shell around the brick, two per lane; where such a cell lies outside the domain (all its leaving axes
@@ -237,7 +246,10 @@ __global__ __launch_bounds__(256, 3) void brick_wide_kernel(const WideArgs A) {
       const CellRef org = locate(GL, o_i, o_j, o_k);
       const int jS = L.jStride, kS = L.kStride;
       const double *bi = vec_origin(L, org.box, VECTOR_BETA_I) + org.ijk, *bj = vec_origin(L, org.box, VECTOR_BETA_J) + org.ijk, *bk = vec_origin(L, org.box, VECTOR_BETA_K) + org.ijk;
-      for (int idx = t; idx < 2700; idx += kThreads) {
+#pragma unroll
+      for (int idx0 = 0; idx0 < 2700; idx0 += kThreads) {      // (unrolled: all eleven loads of a lane in flight)
+        const int idx = idx0 + t;
+        if (idx >= 2700) break;
         const int arr = idx / 900, r = idx - arr * 900;
         if (arr == 0)      { const int i = r % 9, jj = (r / 9) % 10 - 1, k = r / 90 - 1;  sbi[r] = bi[i + jj * jS + k * kS]; }
         else if (arr == 1) { const int i = r % 10 - 1, jj = (r / 10) % 9, k = r / 90 - 1; sbj[r] = bj[i + jj * jS + k * kS]; }
