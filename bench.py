@@ -18,14 +18,16 @@ children run the node-local hipIpc transport (`"transport": "ipc (fallback: <rea
 attempt begins with a transport self-test (a known pattern to and from every rank, a maximum, a
 rank-ordered sum), and the line carries `parity_ok`: the F-cycle norm equals the reference's string.
 One GPU, default workload: the line also carries `also` -- configs 3 (fv4, 27-pt), 4 and 1 with
-3 timed solves each, under the same clock.
+3 timed solves each, under the same clock, each in a fresh child process (a failure there cannot
+take the headline measurement with it; the headline line is also written to stderr first).
 Default series = north_star's STRONG scaling: the same 256^3 problem on 1, 2, 4, 8 GPUs
 (`hpgmg-fv 7 8/N`, i.e. 8/4/2/1 boxes of 128^3 per GPU; "scaling": "strong").  --series weak =
 the reference CLI's `7 8` with N ranks (256^3, 256^3, 384^3, 512^3).
 value = fine-grid DOF of the whole job / max-over-ranks time.
 
 Extra objects on the JSON line:
-  roofline     the fine-level smoother kernel, timed with hipEvents on the launch stream inside the timed region (every 5th launch: an
+  roofline     (frac = the fused-form reading, frac_survey_8d = SURVEY 8(d)'s bytes per sweep; `basis` says which is which)
+               the fine-level smoother kernel, timed with hipEvents on the launch stream inside the timed region (every 5th launch: an
                event pair idles the GPU ~10 us, launches_timed says how many were timed).
                achieved / frac = the bytes ONE LAUNCH of that kernel has to move in the form it really has (a kernel that does two
                sweeps per pass is charged its own stream count once, not twice the single-sweep figure) / launch time / 8 TB/s;
@@ -222,9 +224,33 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def _die_with_parent():
+    """preexec_fn of a rank child: SIGKILL when the supervisor that started it dies (prctl PR_SET_PDEATHSIG), so no rank outlives a killed job on the GPU."""
+    try:
+        ctypes.CDLL(None, use_errno=True).prctl(1, 9, 0, 0, 0)      # PR_SET_PDEATHSIG = 1, SIGKILL = 9
+    except Exception:
+        pass
+
+
+def _unlink_segment(name):
+    try:
+        os.unlink("/dev/shm" + name)
+    except OSError:
+        pass
+
+
 def supervise(args):
+    import signal
     import tempfile
     import torch.distributed as dist      # gloo between the supervisors only: CPU tensors, no device is touched
+    running = [None]      # the rank child of the attempt in progress
+
+    def _ended(signum, _frame):      # the launcher (or the driver's time-out) ends this supervisor: its rank goes first
+        if running[0] is not None and running[0].poll() is None:
+            running[0].kill()
+        os._exit(128 + signum)
+    signal.signal(signal.SIGTERM, _ended)
+    signal.signal(signal.SIGINT, _ended)
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a {world}-rank run as {args.gpus} GPUs")
@@ -242,13 +268,15 @@ def supervise(args):
                    HPGMG_BENCH_NONCE=nonce, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         out = tempfile.NamedTemporaryFile(prefix="hpgmg_bench_rank%d_" % rank, suffix=".out", delete=False)
         cmd = [sys.executable, os.path.abspath(__file__)] + passthrough + ["--as-rank", "--transport", transport]
-        child = subprocess.Popen(cmd, env=env, stdout=out, stdin=subprocess.DEVNULL)
+        child = subprocess.Popen(cmd, env=env, stdout=out, stdin=subprocess.DEVNULL, preexec_fn=_die_with_parent)
+        running[0] = child
         # lock-step polling: once a second every supervisor says whether its child is running / done / failed; one failure (or the
         # attempt's time limit, which all supervisors reach in the same iteration) ends every child of the attempt
         limit, waited, state = (args.watchdog + 30) if args.watchdog > 0 else 10 ** 9, 0, None
         while True:
             rc = child.poll()
-            t = torch.tensor([1.0 if (rc is not None and rc != 0) else 0.0, 1.0 if rc == 0 else 0.0])
+            # exit code 3 = rank 0 printed its line and flagged it (roofline fraction > 1): a finished measurement, not a transport failure
+            t = torch.tensor([1.0 if (rc is not None and rc not in (0, 3)) else 0.0, 1.0 if rc in (0, 3) else 0.0])
             dist.all_reduce(t)
             if t[0].item() > 0:
                 state = "failed"
@@ -263,6 +291,7 @@ def supervise(args):
         if child.poll() is None:
             child.kill()       # exactly the process this supervisor started
         child.wait()
+        running[0] = None
         codes = [None] * world
         dist.all_gather_object(codes, child.returncode)
         out.close()
@@ -274,9 +303,14 @@ def supervise(args):
             if l is not found:
                 print(l, file=sys.stderr)
         if state == "ok":
-            line, code = found, 0
+            # rank 0's line and rank 0's exit code (0, or 3 with the line's `error` field) are the job's; "ok" without a line is a failure of its own
+            line, code = found, (codes[0] if found is not None else 1)
+            if rank == 0 and found is None:
+                print("bench.py: every rank of the %s attempt ended normally but rank 0 printed no result line" % transport, file=sys.stderr, flush=True)
             break
-        bad = [(r, c) for r, c in enumerate(codes) if c not in (0, -9)]
+        if rank == 0:          # ranks that were killed never reached hpgmg_transport_finalize_ipc: remove the attempt's shared-memory segment
+            _unlink_segment("/hpgmg_bench_%s_%s" % (port, nonce))
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (0, 3, -9)]
         why = (f"{transport} attempt: " + ("no rank finished within %d s" % limit if state == "timeout" else
                                            ", ".join("rank %d exited with code %s" % rc for rc in bad) or "a rank was killed"))
         if rank == 0:
@@ -290,9 +324,11 @@ def supervise(args):
             print(json.dumps(d), flush=True)
         else:
             print("bench.py: no attempt produced a result (" + (why or "?") + ")", file=sys.stderr, flush=True)
+    box = [code]
+    dist.broadcast_object_list(box, src=0)      # every supervisor leaves with rank 0's verdict
     dist.barrier()
     dist.destroy_process_group()
-    sys.exit(code)
+    sys.exit(box[0])
 
 
 # ---------------------------------------------------------------------------------------------------------------- one rank (or the single GPU)
@@ -484,7 +520,13 @@ def run_workload(J, workload, steps, warmup, precision="fp64"):
                 roof_error = f"roofline fraction {achieved / HBM_PEAK_GBS:.3f} > 1 -- the byte model of this kernel is wrong"
             else:
                 roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
+                        "frac": round(achieved / HBM_PEAK_GBS, 4),
+                        # SURVEY 8(d)'s reading: its bytes per cell per sweep x the sweeps the launch performs / the launch time / peak
+                        "frac_survey_8d": round(unfused / HBM_PEAK_GBS, 4),
+                        "basis": (f"frac = the bytes ONE launch has to move in the form it runs in ({smoother[1]} B/cell for {sweeps_per_launch:.0f} sweep(s) in one pass: every stream once) "
+                                  f"/ launch time / peak -- the stricter reading of HBM use; frac_survey_8d = SURVEY.md 8(d)'s {smoother[0]} B/cell per sweep x {sweeps_per_launch:.0f} sweep(s) "
+                                  "/ the same time / peak (= unfused_equivalent_GBs / peak): what separate sweeps would have had to move -- it rewards fusion and may approach or exceed 1"),
+                        "traffic": traffic, "traffic_source": traffic_source,
                         "traffic_note": ("PMC bytes per launch from the committed summary named in traffic_source: ANOTHER run (and possibly build) of the same command, not this one"
                                          + ("; a single-GPU figure scaled to the cells this rank owns" if world > 1 else "")
                                          + ("; the 256^3 figure of the same kernel scaled to 512^3" if (world == 1 and workload == "config4") else "")) if traffic else None,
@@ -532,15 +574,26 @@ def rank_main(args):
         J.dist.barrier()                       # every rank has flushed its C-level output before rank 0 prints the result
     if J.rank == 0:
         if J.world == 1 and args.workload == "config2" and args.precision == "fp64" and not args.no_also:
-            # the other BASELINE configurations under the same clock, in the same process: 1 warm-up + 3 timed solves each (the 8-GPU ones in their single-rank reading)
+            # the other BASELINE configurations under the same clock: 1 warm-up + 3 timed solves each (the 8-GPU ones in their single-rank reading), each in a FRESH
+            # child process (a new process, not a re-exec) with its own time limit -- whatever ends one of them (an abort() from a failed allocation, its watchdog)
+            # cannot take the headline measurement, which is already in hand, with it.  The headline line goes to stderr first, for the same reason.
+            sys.stderr.write("bench.py: headline line before the `also` workloads: " + json.dumps(line) + "\n")
+            sys.stderr.flush()
             also = []
-            for w, k_steps, k_warm in (("config3-fv4", 3, 1), ("config3-27pt", 3, 1), ("config4", 3, 1), ("config1", 10, 3)):      # config 1 is half a millisecond per solve
+            for w, k_steps, k_warm in (("config3-fv4", 3, 1), ("config3-27pt", 3, 1), ("config4", 3, 1), ("config1", 10, 3)):      # config 1 is a third of a millisecond per solve
+                J.stage[0] = f"also: {w} (child process)"
+                cmd = [sys.executable, os.path.abspath(__file__), "--workload", w, "--no-also", "--no-cpu-baseline", "--steps", str(k_steps), "--warmup", str(k_warm), "--watchdog", "150"]
                 try:
-                    l, err = run_workload(J, w, k_steps, k_warm)
+                    child = subprocess.run(cmd, capture_output=True, text=True, timeout=180, stdin=subprocess.DEVNULL)
+                    found = next((x for x in reversed(child.stdout.splitlines()) if x.startswith("{") and '"metric"' in x), None)
+                    if found is None:
+                        also.append({"workload": w, "error": "exit code %s, no result line: %s" % (child.returncode, child.stderr.strip()[-300:])})
+                        continue
+                    l = json.loads(found)
                     also.append({"workload": w, "description": l["config"]["workload"], "steps": k_steps, "warmup": k_warm, "ms_per_step": l["ms_per_step"], "value": l["value"],
                                  "fcycle_residual_norm": l["config"]["fcycle_residual_norm"], "parity_ok": l["config"]["parity_ok"],
-                                 "roofline": ({k: l["roofline"][k] for k in ("frac", "achieved", "avg_launch_us", "sweeps_per_launch", "algorithmic_bytes_per_launch")} if l["roofline"] else None),
-                                 "error": err})
+                                 "roofline": ({k: l["roofline"][k] for k in ("frac", "frac_survey_8d", "achieved", "avg_launch_us", "sweeps_per_launch", "algorithmic_bytes_per_launch", "basis")} if l["roofline"] else None),
+                                 "error": l.get("error")})
                 except Exception as exc:       # the headline measurement is done: report, never drop the line
                     also.append({"workload": w, "error": repr(exc)})
             line["also"] = also

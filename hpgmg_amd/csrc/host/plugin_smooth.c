@@ -142,9 +142,9 @@ static int brick_prefix(level_type **levels, int n, const hpgmg_config *cfg) {
   while (k + 1 < n) {
     level_type *L = levels[k];
     /* where the single-workgroup tail takes over: the 7-point tail holds levels up to 16^3; the tail of the other plugins starts at the first level of ONE box */
-    const int fits_tail = wide ? (L->num_my_boxes == 1 && L->boxes_in.i * L->boxes_in.j * L->boxes_in.k == 1 && L->dim.i <= 8)
+    const int fits_tail = wide ? (L->num_my_boxes == 1 && L->boxes_in.i * L->boxes_in.j * L->boxes_in.k == 1 && L->dim.i <= (int)hp_switch(SW_BRICK_WIDE_TAIL_DIM))
                                : ((long long)L->dim.i * L->dim.j * L->dim.k <= hpgmg_hip_tail_max_cells());
-    if (L->dim.i < (int)hp_switch(SW_BRICK_MIN_DIM) && fits_tail) break;
+    if ((wide || L->dim.i < (int)hp_switch(SW_BRICK_MIN_DIM)) && fits_tail) break;
     if (wide && L->dim.i > (int)hp_switch(SW_BRICK_WIDE_MAX_DIM)) return 0;      /* (a tuning switch: all three launch-bound levels pay, profiles/r06d_ab_wide_max.txt) */
     if (!dense_level_ok(L) || !dense_level_ok(levels[k + 1]) || 2 * levels[k + 1]->dim.i != L->dim.i) return 0;
     if (wide ? !hpgmg_hip_brick_wide_supported(&hp_backend_of(L)->dev, hp_variant())

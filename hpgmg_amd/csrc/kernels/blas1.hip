@@ -233,10 +233,61 @@ __global__ __launch_bounds__(64) void tile_sum_kernel(const hpgmg_hip_level L, i
   __syncthreads();
   if (threadIdx.x == 0) { double s = 0.0; for (int q = 0; q < ntiles; q++) s += part[q]; publish(result, s, seq); }
 }
-__global__ void ordered_sum_kernel(const double *partials, int n, ResultSlot *result, unsigned long long seq) {
+// The same sum on a level of many tiles: ONE WAVE per tile.  A tile's partial is a chain of dim x 8 x 8 dependent additions in k, j, i order (misc.c:261-269)
+// -- that order is the contract, so the chain itself cannot be cut: ~8 cycles per addition, 8192 of them for a tile of a 128^3 box = ~30 us, which with every
+// tile of the level on a wave of its own is also the time of the launch.  What can be taken out of the chain is memory: with a LANE per tile (above) every load
+// of the chain was a 64-byte sector per lane and a round trip per element (1.35 ms at 256^3).  Here the wave's 64 lanes fetch a row (dim cells, coalesced) one row
+// ahead of the chain into LDS -- for a dot product they form the products -- and lane 0 adds the row's values in order from LDS.
+constexpr int kSumMaxChunks = 8;      // rows of up to 512 cells
+__global__ __launch_bounds__(64) void tile_sum_wave_kernel(const hpgmg_hip_level L, int id_a, int id_b, double *partials) {
+  extern __shared__ double sum_rows[];      // [2][dim]
+  const int tiles_side = (L.dim + BLOCKCOPY_TILE_J - 1) / BLOCKCOPY_TILE_J, tiles_per_box = tiles_side * tiles_side;
+  const int t = (int)blockIdx.x, lane = (int)threadIdx.x, dim = L.dim;
+  const int box = t / tiles_per_box, rem = t % tiles_per_box;
+  const int k0 = (rem / tiles_side) * BLOCKCOPY_TILE_K, j0 = (rem % tiles_side) * BLOCKCOPY_TILE_J;
+  const int k1 = min(k0 + BLOCKCOPY_TILE_K, dim), j1 = min(j0 + BLOCKCOPY_TILE_J, dim), nj = j1 - j0, nrows = (k1 - k0) * nj;
+  const gcptr pa = as_global(vec_origin(L, box, id_a));
+  const gcptr pb = (id_b >= 0) ? as_global(vec_origin(L, box, id_b)) : pa;
+  const bool dot = id_b >= 0;
+  double v[kSumMaxChunks];
+  auto fetch = [&](int r) {
+    const int base = (j0 + r % nj) * L.jStride + (k0 + r / nj) * L.kStride;
+#pragma unroll
+    for (int c = 0; c < kSumMaxChunks; c++) {
+      const int i = lane + 64 * c;
+      v[c] = 0.0;
+      if (i < dim) { const double a = pa[base + i]; v[c] = dot ? a * pb[base + i] : a; }
+    }
+  };
+  fetch(0);
+  double acc = 0.0;
+  for (int r = 0; r < nrows; r++) {
+    double *row = sum_rows + (r & 1) * dim;
+#pragma unroll
+    for (int c = 0; c < kSumMaxChunks; c++) { const int i = lane + 64 * c; if (i < dim) row[i] = v[c]; }
+    if (r + 1 < nrows) fetch(r + 1);      // in flight under the chain below
+    __syncthreads();                      // (one wave: orders its LDS writes before lane 0's reads; the buffer written next was read two rows ago)
+    if (lane == 0) { for (int i = 0; i < dim; i++) acc += row[i]; }
+  }
+  if (lane == 0) partials[t] = acc;
+}
+// the partials in tile order: a wave fetches 64 of them at a time, lane 0's chain takes them from the lanes' registers
+__global__ __launch_bounds__(64) void ordered_sum_kernel(const double *partials, int n, ResultSlot *result, unsigned long long seq) {
+  const int lane = (int)threadIdx.x;
   double s = 0.0;
-  for (int t = 0; t < n; t++) s += partials[t];
-  publish(result, s, seq);
+  double next = (lane < n) ? partials[lane] : 0.0;
+  for (int t0 = 0; t0 < n; t0 += 64) {
+    const double cur = next;
+    if (t0 + 64 < n) next = (t0 + 64 + lane < n) ? partials[t0 + 64 + lane] : 0.0;
+    const int m = (n - t0 < 64) ? n - t0 : 64;
+    if (m == 64) {
+#pragma unroll
+      for (int q = 0; q < 64; q++) s += __shfl(cur, q, 64);
+    } else {
+      for (int q = 0; q < m; q++) s += __shfl(cur, q, 64);
+    }
+  }
+  if (lane == 0) publish(result, s, seq);
 }
 
 // ---- operators.7pt.c:158-227 --------------------------------------------------------------
@@ -464,8 +515,9 @@ static int ordered_sum(const hpgmg_hip_level *L, int id_a, int id_b, double *out
   if (ntiles <= 64) {
     hipLaunchKernelGGL((tile_sum_kernel<true>), dim3(1), dim3(64), 0, g_stream, *L, id_a, id_b, g_scratch, g_result_dev, ++g_seq);
   } else {
-    hipLaunchKernelGGL((tile_sum_kernel<false>), dim3((ntiles + 63) / 64), dim3(64), 0, g_stream, *L, id_a, id_b, g_scratch, g_result_dev, 0ULL);
-    hipLaunchKernelGGL(ordered_sum_kernel, dim3(1), dim3(1), 0, g_stream, (const double *)g_scratch, ntiles, g_result_dev, ++g_seq);
+    if (L->dim <= 64 * kSumMaxChunks) hipLaunchKernelGGL(tile_sum_wave_kernel, dim3(ntiles), dim3(64), (size_t)2 * L->dim * sizeof(double), g_stream, *L, id_a, id_b, g_scratch);
+    else hipLaunchKernelGGL((tile_sum_kernel<false>), dim3((ntiles + 63) / 64), dim3(64), 0, g_stream, *L, id_a, id_b, g_scratch, g_result_dev, 0ULL);
+    hipLaunchKernelGGL(ordered_sum_kernel, dim3(1), dim3(64), 0, g_stream, (const double *)g_scratch, ntiles, g_result_dev, ++g_seq);
   }
   HPGMG_LAUNCH_CHECK("ordered_sum");
   return fetch_result(out);

@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256, 3) void brick_wide_kernel(const WideArgs A) {
       exchange_n++;
 #pragma unroll
       for (int m = 0; m < 2; m++)
-        if (own_shell[m] && (colour < 0 || (colour0 ^ m) == colour || own_corner[m])) face_store(faces + ((size_t)par * nwg + wg) * 512 + (2 * t + m), img[pos0 + m], seq);
+        if (side > 1 && own_shell[m] && (colour < 0 || (colour0 ^ m) == colour || own_corner[m])) face_store(faces + ((size_t)par * nwg + wg) * 512 + (2 * t + m), img[pos0 + m], seq);
       const FaceCell *want[kSlots];
       double got[kSlots];
       unsigned pending = 0;
@@ -432,11 +432,12 @@ using namespace hpgmg;
 
 extern "C" {
 
-// 1: a level of dim^3 cells of this operator can be visited as bricks of 8^3 cells: 2^3 .. 8^3 of them, each inside one box, Dirichlet (the caller checks), every box here
+// 1: a level of dim^3 cells of this operator can be visited as bricks of 8^3 cells: 1 .. 8^3 of them (a level of ONE brick has no neighbours: every halo cell is a
+// boundary condition), each inside one box, Dirichlet (the caller checks), every box here
 int hpgmg_hip_brick_wide_supported(const hpgmg_hip_level *L, int variant) {
   if (variant != HPGMG_HIP_27PT_CC && variant != HPGMG_HIP_FV4_VC_HELMHOLTZ && variant != HPGMG_HIP_FV4_VC_POISSON) return 0;
   const int side = L->dim_i / 8, r = (variant == HPGMG_HIP_27PT_CC) ? 1 : 2;
-  return L->dim_i == L->dim_j && L->dim_i == L->dim_k && L->dim_i % 8 == 0 && side >= 2 && side <= 8 && L->dim > 0 && L->dim % 8 == 0 && L->ghosts >= r && !L->periodic;
+  return L->dim_i == L->dim_j && L->dim_i == L->dim_k && L->dim_i % 8 == 0 && side >= 1 && side <= 8 && L->dim > 0 && L->dim % 8 == 0 && L->ghosts >= r && !L->periodic;
 }
 // workgroups of the (variant, smoother) kernels this device holds at once, less an eighth (hpgmg_hip_brick_chain_capacity)
 int hpgmg_hip_brick_wide_capacity(int variant, int smoother) {

@@ -156,10 +156,12 @@ static int smooth_pair(const hpgmg_hip_level *L, int variant, int gsrb, int swee
   if (kc <= 0) {
     const int per_plane = (Di / 128) * ((Dj + (nw - 2) - 1) / (nw - 2)), slots = 256;
     long long best = -1;
-    for (int c = 8; c <= 64 && c <= Dk; c++) {
-      const long long wgs = (long long)per_plane * ((Dk + c - 1) / c), cost = ((wgs + slots - 1) / slots) * (c + 2);
-      if (best < 0 || cost < best) { best = cost; kc = c; }
-    }
+    auto steps = [&](int c) { const long long wgs = (long long)per_plane * ((Dk + c - 1) / c); return ((wgs + slots - 1) / slots) * (c + 2); };
+    for (int c = 8; c <= 64 && c <= Dk; c++) { const long long cost = steps(c); if (best < 0 || cost < best) { best = cost; kc = c; } }
+    // ... and among the chunk lengths within 3 % of that, the LONGEST: two of every KC + 2 planes a workgroup fetches are halo, and the launch is close enough
+    // to the memory system's limit for 5 % fewer bytes to outweigh one more step (256^3: KC 43, one round of 45 steps, 371.8 us per launch against 375.2 for
+    // KC 20, two rounds of 22; tools/ab_pair_kc.sh, profiles/r06e_ab_pair_kc.txt)
+    for (int c = kc + 1; c <= 64 && c <= Dk; c++) if (steps(c) * 100 <= best * 103) kc = c;
   }
   PairArgs A = {};
   A.x0 = VecRef{x0_scr, x0_id}; A.xm1 = VecRef{xm1_scr, xm1_id}; A.out1 = VecRef{out1_scr, out1_id}; A.out2 = VecRef{out2_scr, out2_id};
