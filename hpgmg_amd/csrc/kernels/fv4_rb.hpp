@@ -92,9 +92,15 @@ template <int TI_> struct Geom {
     else                      { const int h = n - (4 * TI + 12), c = h % 4; hj = h / 4; hi = (c < 2) ? c - 2 : TI + (c - 2); }
   }
 };
+#ifdef HPGMG_EXP_STATIC_SLOTS      /* timing experiment only (results are garbage): what the march would cost if every ring slot were a compile-time constant */
+__device__ __forceinline__ int slot4(int p) { (void)p; return 1; }
+__device__ __forceinline__ int slot3(int p) { (void)p; return 1; }
+__device__ __forceinline__ int slot2(int p) { (void)p; return 1; }
+#else
 __device__ __forceinline__ int slot4(int p) { return p & 3; }
 __device__ __forceinline__ int slot3(int p) { return ((p % 3) + 3) % 3; }
 __device__ __forceinline__ int slot2(int p) { return p & 1; }
+#endif
 
 #define FV4RB_FENCE() __builtin_amdgcn_sched_barrier(0)      /* nothing is scheduled across: reads stay together, ahead of the arithmetic */
 }  // namespace fv4rb

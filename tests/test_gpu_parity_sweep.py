@@ -106,3 +106,13 @@ def test_cg_bottom_solver_of_this_host_layer_on_the_gpu(flags, size):
         assert out.returncode == 0, (out.stdout[-800:], out.stderr[-800:])
         outs.append(pat.findall(out.stdout))
     assert len(outs[0]) >= 10 and any(l.startswith("Bottom") for l in outs[0]) and outs[0] == outs[1], [x for x in zip(outs[0], outs[1]) if x[0] != x[1]][:4]
+
+
+@pytest.mark.parametrize("which,flags,size", [("mgsolve", "--helmholtz", "5 8"), ("mgsolve", "--op fv4 --smoother gsrb", "5 8"), ("mgsolve", "--op 27pt --smoother gsrb", "5 8"),
+                                              ("mgpcg", "--helmholtz", "5 8"), ("shapes", "--ucycles", "5 8"), ("shapes", "--unlimit", "5 8"), ("cg", "--helmholtz", "5 8")])
+def test_one_case_of_every_fenced_off_mode_runs_with_the_hot_path_suite(which, flags, size):
+    """The solver modes above are out of scope and only run with -m "gpu and modes" -- but they share MGVCycle's legs with the hot path: brick
+    launches, the tails, the sweep pairs, the ordered sums.  One case of each therefore stays in the default `-m gpu` run (a few seconds together), so that a change
+    to those legs which breaks a mode fails the round, not a log nobody reads."""
+    {"mgsolve": test_mgsolve_of_this_host_layer_on_the_gpu, "mgpcg": test_mgpcg_of_this_host_layer_on_the_gpu,
+     "shapes": test_other_cycle_shapes_of_this_host_layer_on_the_gpu, "cg": test_cg_bottom_solver_of_this_host_layer_on_the_gpu}[which](flags, size)
