@@ -37,6 +37,7 @@ int hpgmg_vcycle_legs_fused(level_type **levels, int n, int e_id, int R_id, doub
  * sweeps of the generic form.  The first version (1024 lanes) was slower everywhere: the bottom solve's 240 registers per lane spilled into
  * scratch memory under the 128-register cap; with 512 lanes the launch of 8^3 + 4^3 + 2^3 levels takes 169 instead of 191 us (fv4 GSRB;
  * tools/exp_vtail_timeline.py): 4 x 24 us of smoothing, 28 us of bottom solve, the rest image traffic and interpolation. */
+static int bottom_solve_fused_impl(level_type *L, int e_id, int R_id, double a, double b, double want, int ask_only);
 static level_type *tail_books_on = NULL;      /* the level whose timers take the tail launch when bricks were visited above it (else its own first level) */
 static int tail_follows_bricks = 0;      /* the chain handed to small_vtail_fused is what is left below levels visited as bricks (hp_vcycle_legs_fused) */
 static long long small_vtails = 0;
@@ -147,10 +148,11 @@ static int brick_prefix(level_type **levels, int n, const hpgmg_config *cfg) {
     if ((wide || L->dim.i < (int)hp_switch(SW_BRICK_MIN_DIM)) && fits_tail) break;
     if (wide && L->dim.i > (int)hp_switch(SW_BRICK_WIDE_MAX_DIM)) return 0;      /* (a tuning switch: all three launch-bound levels pay, profiles/r06d_ab_wide_max.txt) */
     if (!dense_level_ok(L) || !dense_level_ok(levels[k + 1]) || 2 * levels[k + 1]->dim.i != L->dim.i) return 0;
-    if (wide ? !hpgmg_hip_brick_wide_supported(&hp_backend_of(L)->dev, hp_variant())
+    const int wide_brick = wide ? hpgmg_hip_brick_wide_supported(&hp_backend_of(L)->dev, hp_variant()) : 0;      /* 8, 4 (the level of 4^3 cells) or 0 */
+    if (wide ? !wide_brick
              : !hpgmg_hip_brick_visit_supported(&hp_backend_of(L)->dev, (int)hp_switch(SW_BRICK_SIZE))) { if (fits_tail) break; return 0; }
     { /* every brick of a launch must be running at once: more bricks than the device holds of this kernel = the launch-by-launch path (kernels/brick_visit.hip) */
-      const int brick = wide ? 8 : (int)hp_switch(SW_BRICK_SIZE), side = L->dim.i / brick;
+      const int brick = wide ? wide_brick : (int)hp_switch(SW_BRICK_SIZE), side = L->dim.i / brick;
       const int capacity = wide ? hpgmg_hip_brick_wide_capacity(hp_variant(), cfg->smoother) : hpgmg_hip_brick_chain_capacity(hp_variant(), cfg->smoother, brick);
       if (side * side * side > capacity) { brick_capacity_refusals++; if (fits_tail) break; return 0; }
     }
@@ -168,6 +170,14 @@ static void brick_chain(level_type *top, level_type **levels, int first, int cou
     hpgmg_hip_brick_level lv[4];
     int n = count - done, j, s;
     if (n > max_n) n = max_n;
+    if (brick_op_is_wide(cfg)) {
+      /* the levels of one launch are cut into bricks of one size: the level of 4^3 cells (one brick of 4^3) goes on its own */
+      const int v = hp_variant();
+      if (dir == 1) { const int b0 = hpgmg_hip_brick_wide_supported(&hp_backend_of(levels[first + count - done - 1])->dev, v);
+                      int m = 1; while (m < n && hpgmg_hip_brick_wide_supported(&hp_backend_of(levels[first + count - done - 1 - m])->dev, v) == b0) m++; n = m; }
+      else          { const int b0 = hpgmg_hip_brick_wide_supported(&hp_backend_of(levels[first + done])->dev, v);
+                      int m = 1; while (m < n && hpgmg_hip_brick_wide_supported(&hp_backend_of(levels[first + done + m])->dev, v) == b0) m++; n = m; }
+    }
     /* down: the finest levels first; up: the coarsest levels first */
     const int lo = (dir == 1) ? first + count - done - n : first + done;
     for (j = 0; j < n; j++) {
@@ -233,6 +243,12 @@ int hp_vcycle_legs_fused(level_type **levels, int n, int e_id, int R_id, double 
   if (leg >= 2 && hpgmg_get_bottom_solver() != HPGMG_BOTTOM_BICGSTAB) return 0;        /* the device bottom solve is BiCGStab: another host solver runs through the operators */
   const int sweeps = hpgmg_smooth_sweeps();
   const int with_bottom = (leg >= 2);
+  if (enabled && cfg.op != HPGMG_OP_7PT && n == 1 && tail_follows_bricks && leg <= 2) {
+    /* every level above the bottom one was visited as bricks: what is left of the V-cycle is the bottom solve (leg 2) or nothing (the legs around a host-driven one) */
+    if (leg != 2) return 1;
+    if (!bottom_enabled || hpgmg_get_bottom_solver() != HPGMG_BOTTOM_BICGSTAB || e_id >= hpgmg_vectors_reserved() || R_id >= hpgmg_vectors_reserved()) return 0;
+    return bottom_solve_fused_impl(levels[0], e_id, R_id, a, b, MG_DEFAULT_BOTTOM_NORM, probe);
+  }
   if (enabled && cfg.op != HPGMG_OP_7PT) {      /* leg 0 / 1: the way down / up around a bottom solve somebody else runs (the reference's driver, through the queue below) */
     if (leg == 2) return bottom_enabled ? small_vtail_fused(levels, n, e_id, R_id, a, b, 7, probe) : 0;
     if (leg == 0 || leg == 1) return small_vtail_fused(levels, n, e_id, R_id, a, b, leg == 0 ? 1 : 4, probe);
@@ -560,7 +576,9 @@ static int small_level_try(level_type *L, int mode, int x_id, int rhs_id, int re
 /* IterativeSolver's BiCGStab on a bottom level of one small box of the 27-point / fv2 / fv4 plugins as ONE launch (kernels/stencil.hip:
  * bottom_bicgstab_kernel; the 7-point plugin's bottom solve lives in its tail kernel).  Driven from the host, an iteration is ~25 launches and
  * ~6 host round trips on a level of 8 cells.  HPGMG_FUSED_BOTTOM=0 keeps the host-driven solver. */
-int hpgmg_bottom_solve_fused(level_type *L, int e_id, int R_id, double a, double b, double want) {
+static int bottom_solve_fused_impl(level_type *L, int e_id, int R_id, double a, double b, double want, int ask_only);
+int hpgmg_bottom_solve_fused(level_type *L, int e_id, int R_id, double a, double b, double want) { return bottom_solve_fused_impl(L, e_id, R_id, a, b, want, 0); }
+static int bottom_solve_fused_impl(level_type *L, int e_id, int R_id, double a, double b, double want, int ask_only) {
   hpgmg_config cfg;
   const int on = (int)hp_switch(SW_FUSED_BOTTOM);
   hpgmg_get_config(&cfg);
@@ -576,6 +594,8 @@ int hpgmg_bottom_solve_fused(level_type *L, int e_id, int R_id, double a, double
   if (cfg.op == HPGMG_OP_27PT) bc_kind = (L->box_dim < 2) ? 1 : 2;                                    /* as small_level_try / apply_BCs */
   else if (cfg.op == HPGMG_OP_FV2 || L->box_dim < 4) { bc_kind = (L->box_dim < 2) ? 1 : 3; zero_first = (bc_kind == 3 && L->box_ghosts > 1); }
   else { bc_kind = 4; zero_first = (L->box_ghosts > 2); }
+  if (L->numVectors < hpgmg_vectors_reserved() + IterativeSolver_NumVectors()) return 0;      /* (the solver's work vectors must exist) */
+  if (ask_only) return 1;
   hp_lazy_flush();
   backend_t *B = hp_backend_of(L);
   if (!B->krylov_pinned) { B->krylov_pinned = (int *)hpgmg_hip_host_malloc(64); if (B->krylov_pinned) *B->krylov_pinned = 0; }

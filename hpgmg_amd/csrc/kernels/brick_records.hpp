@@ -16,16 +16,17 @@ namespace hpgmg {
 typedef unsigned long long u64;
 struct alignas(16) FaceCell { u64 w0, w1; };      // w0 = tag | (value bits 0..31) << 32;  w1 = (value bits 32..63) | tag << 32
 
-constexpr int kBrickMaxSweeps = 8, kBrickMaxLevels = 3, kBrickMaxWgs = 512;
+constexpr int kBrickMaxSweeps = 8, kBrickMaxLevels = 4, kBrickMaxWgs = 512;
 // record areas, each per level of a chain: faces [2 parities][workgroup][6][B^2] (7-point: 8^3 bricks of 8^3 cells fill it; 4^3 bricks of 16^3 take half;
 // 27-point / fv4: [2 parities][workgroup][512 cells], the same number), one record per cell for what goes down (restricted residuals) and up (corrections),
 // one gate per brick
 constexpr size_t kFaceRecords = (size_t)2 * kBrickMaxWgs * 512, kCellRecords = (size_t)kBrickMaxWgs * 512;
 constexpr u64 kPollTicks = 200000000ull;            // 2 s of the 100 MHz clock
 constexpr u64 kPollLookTicks = 10000ull;            // a poll that has waited 100 us looks at the error word: a launch behind a failed one gives up at once
-// tags inside a launch (added to its epoch, a multiple of 64): 1 + 12 j + n = exchange n of level j (n < 12); 40 + j, 48 + j, 56 + j = what level j
+// tags inside a launch (added to its epoch, a multiple of 64): 1 + 12 j + n = exchange n of level j (j < 4, n < 12: <= 48); 50 + j, 54 + j, 58 + j = what level j
 // receives from the finer level / hands to the finer level / its gate
-enum { SEQ_FACES = 1, SEQ_DOWN = 40, SEQ_UP = 48, SEQ_GATE = 56 };
+enum { SEQ_FACES = 1, SEQ_DOWN = 50, SEQ_UP = 54, SEQ_GATE = 58 };
+static_assert(SEQ_FACES + 12 * kBrickMaxLevels <= SEQ_DOWN && SEQ_GATE + kBrickMaxLevels <= 64, "tag codes");
 
 struct BrickRecords {
   FaceCell *faces, *down, *up, *gate;
