@@ -106,6 +106,7 @@ __global__ __launch_bounds__(BrickGeom<B>::Threads, (B == 8) ? 6 : 4) void brick
   const int t = (int)threadIdx.x, wg = (int)blockIdx.x, e_id = A.e_id, R_id = A.R_id, n = A.n;
   const unsigned epoch = A.Rc.epoch;
   const unsigned *const err_dev = A.Rc.error_dev;
+  const RecordWindow RW = record_window(A.Rc);      // the record areas as a buffer (brick_records.hpp)
   const u64 t0 = __builtin_amdgcn_s_memrealtime();
   bool gave_up = false;
   if (wg == A.absent_wg) return;
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(BrickGeom<B>::Threads, (B == 8) ? 6 : 4) void brick
     auto start_value = [&](double stored, int ci, int cj, int ck) -> double {
       if (kUp) {               // interpolation_vcycle: e = 1.0*e + (coarse parent), interpolation_p0.c:43
         double parent;
-        if (parent_by_record) parent = record_wait(up_from_below + below_record(ci >> 1, cj >> 1, ck >> 1), seq_parent, t0, gave_up, err_dev);
+        if (parent_by_record) parent = record_wait(RW, up_from_below + below_record(ci >> 1, cj >> 1, ck >> 1), seq_parent, t0, gave_up, err_dev);
         else { const CellRef c = locate(GC, ci >> 1, cj >> 1, ck >> 1); parent = vec_origin(C, c.box, e_id)[c.ijk]; }
         return 1.0 * stored + parent;
       }
@@ -225,14 +226,14 @@ __global__ __launch_bounds__(BrickGeom<B>::Threads, (B == 8) ? 6 : 4) void brick
     // UP, not the last level: the corrections of the level below are on their way.  One lane watches the gate of the brick that holds this brick's parents
     // (hundreds of workgroups polling a record per lane for the length of a visit would be in the way of the bricks that work)
     if (parent_by_record) {
-      if (t == 0) (void)record_wait(A.Rc.gate + (size_t)(j + 1) * kBrickMaxWgs + ((bx >> 1) + side_c * ((by >> 1) + side_c * (bz >> 1))), epoch + SEQ_GATE + (unsigned)(j + 1), t0, gave_up, err_dev, 8);
+      if (t == 0) (void)record_wait(RW, A.Rc.gate + (size_t)(j + 1) * kBrickMaxWgs + ((bx >> 1) + side_c * ((by >> 1) + side_c * (bz >> 1))), epoch + SEQ_GATE + (unsigned)(j + 1), t0, gave_up, err_dev, 8);
       __syncthreads();
     }
 #pragma unroll
     for (int m = 0; m < kBrickPerLane; m++) {
       const int p = pos0 + m * kStepPos, gk = gk0 + m * kStepK;
       sx[p] = start_value(e_st[m], gi, gj, gk);
-      if (rhs_by_record) q[m].rhs = record_wait(A.Rc.down + (size_t)j * kCellRecords + (size_t)wg * kBrickCells + (size_t)(t + m * kBrickThreads), epoch + SEQ_DOWN + (unsigned)j, t0, gave_up, err_dev);
+      if (rhs_by_record) q[m].rhs = record_wait(RW, A.Rc.down + (size_t)j * kCellRecords + (size_t)wg * kBrickCells + (size_t)(t + m * kBrickThreads), epoch + SEQ_DOWN + (unsigned)j, t0, gave_up, err_dev);
     }
     if (kFInterp) __builtin_amdgcn_sched_barrier(0);      // (the eight coarse loads of a cell's interpolation, twice over, are more than the register budget holds at once)
 #pragma unroll
@@ -278,14 +279,14 @@ __global__ __launch_bounds__(BrickGeom<B>::Threads, (B == 8) ? 6 : 4) void brick
           if ((f & 1) ? (bc == side - 1) : (bc == 0)) continue;                          // no brick beyond this face
           int li, lj, lk;
           face_cell(f, u, v, 0, li, lj, lk);
-          face_store(mine + fc, dst[hpos(li, lj, lk)], seq);
+          face_store(RW, mine + fc, dst[hpos(li, lj, lk)], seq);
         }
         for (int fc = t; fc < 6 * kFaceCells; fc += kBrickThreads) {
           const int f = fc / kFaceCells, u = fc % kBrick, v = (fc / kBrick) % kBrick;
           const int bc = (f < 2) ? bx : ((f < 4) ? by : bz);
           if ((f & 1) ? (bc == side - 1) : (bc == 0)) continue;
           const int stp = (f < 2) ? 1 : ((f < 4) ? side : side * side), nb = wg + ((f & 1) ? stp : -stp);
-          const double xv = record_wait(faces + (((size_t)par * nwg + nb) * 6 + (f ^ 1)) * kFaceCells + (fc % kFaceCells), seq, t0, gave_up, err_dev);
+          const double xv = record_wait(RW, faces + (((size_t)par * nwg + nb) * 6 + (f ^ 1)) * kFaceCells + (fc % kFaceCells), seq, t0, gave_up, err_dev);
           int li, lj, lk;
           face_cell(f, u, v, 1, li, lj, lk);
           dst[hpos(li, lj, lk)] = xv;
@@ -311,9 +312,9 @@ __global__ __launch_bounds__(BrickGeom<B>::Threads, (B == 8) ? 6 : 4) void brick
       const CellRef w = locate(G, gi, gj, gk0 + m * kStepK);
       vec_origin(L, w.box, e_id)[w.ijk] = sx[p];
       vec_origin(L, w.box, VECTOR_TEMP)[w.ijk] = st[p];
-      if (kUp && !first) face_store(A.Rc.up + (size_t)j * kCellRecords + (size_t)wg * kBrickCells + (size_t)(t + m * kBrickThreads), sx[p], epoch + SEQ_UP + (unsigned)j);
+      if (kUp && !first) face_store(RW, A.Rc.up + (size_t)j * kCellRecords + (size_t)wg * kBrickCells + (size_t)(t + m * kBrickThreads), sx[p], epoch + SEQ_UP + (unsigned)j);
     }
-    if (kUp && !first && t == 0) face_store(A.Rc.gate + (size_t)j * kBrickMaxWgs + wg, 0.0, epoch + SEQ_GATE + (unsigned)j);      // (issued after lane 0's records; the others' may still be on their way: the gate only ends the long wait)
+    if (kUp && !first && t == 0) face_store(RW, A.Rc.gate + (size_t)j * kBrickMaxWgs + wg, 0.0, epoch + SEQ_GATE + (unsigned)j);      // (issued after lane 0's records; the others' may still be on their way: the gate only ends the long wait)
 
     if (kDown) {
       // restriction(coarse.R <- TEMP): 0.125 * sum of the 8 children in the reference's order (restriction.c:54-57); this brick's (B/2)^3 coarse cells
@@ -327,7 +328,7 @@ __global__ __launch_bounds__(BrickGeom<B>::Threads, (B == 8) ? 6 : 4) void brick
         const int qi = (o_i >> 1) + ci, qj = (o_j >> 1) + cj, qk = (o_k >> 1) + ck;
         const CellRef c = locate(GC, qi, qj, qk);
         vec_origin(C, c.box, R_id)[c.ijk] = v;
-        if (!last) face_store(A.Rc.down + (size_t)(j + 1) * kCellRecords + below_record(qi, qj, qk), v, epoch + SEQ_DOWN + (unsigned)(j + 1));
+        if (!last) face_store(RW, A.Rc.down + (size_t)(j + 1) * kCellRecords + below_record(qi, qj, qk), v, epoch + SEQ_DOWN + (unsigned)(j + 1));
       }
       // zero_vector(C.e): the whole padded boxes, ghosts included (misc.c:6-44), each workgroup a slice of the flat range.  Not when C is the next level of
       // this chain (its visit does not read the vector and clears what it does not store itself, below)
@@ -360,7 +361,6 @@ static unsigned *g_error = nullptr;          // pinned host word
 static unsigned *g_error_dev = nullptr;
 static unsigned g_epoch = 0;
 static long long g_visits = 0;
-constexpr size_t kRecordsTotal = (size_t)kBrickMaxLevels * (kFaceRecords + 2 * kCellRecords + kBrickMaxWgs);
 
 int brick_records_for_launch(BrickRecords *R) {
   if (!g_records) {

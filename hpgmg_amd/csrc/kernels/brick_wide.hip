@@ -146,6 +146,7 @@ __global__ __launch_bounds__((WideGeom<V, B>::Threads), (B == 8 ? 3 : 1)) void b
   const int t = (int)threadIdx.x, wg = (int)blockIdx.x, e_id = A.e_id, R_id = A.R_id, n = A.n;
   const unsigned epoch = A.Rc.epoch;
   const unsigned *const err_dev = A.Rc.error_dev;
+  const RecordWindow RW = record_window(A.Rc);      // the record areas as a buffer (brick_records.hpp)
   const u64 t0 = __builtin_amdgcn_s_memrealtime();
   bool gave_up = false;
   if (wg == A.absent_wg) return;
@@ -208,7 +209,7 @@ __global__ __launch_bounds__((WideGeom<V, B>::Threads), (B == 8 ? 3 : 1)) void b
       exchange_n++;
 #pragma unroll
       for (int m = 0; m < 2; m++)
-        if (owner && own_shell[m] && (colour < 0 || (colour0 ^ m) == colour || own_corner[m])) face_store(faces + ((size_t)par * nwg + wg) * kRecordsPerBrick + (cell0 + m), img[pos0 + m], seq);
+        if (owner && own_shell[m] && (colour < 0 || (colour0 ^ m) == colour || own_corner[m])) face_store(RW, faces + ((size_t)par * nwg + wg) * kRecordsPerBrick + (cell0 + m), img[pos0 + m], seq);
       const FaceCell *want[kSlots];
       double got[kSlots];
       unsigned pending = 0;
@@ -221,7 +222,7 @@ __global__ __launch_bounds__((WideGeom<V, B>::Threads), (B == 8 ? 3 : 1)) void b
         else pending |= 1u << m;
       }
       const unsigned polled = pending;
-      record_wait_many<kSlots>(want, pending, seq, got, t0, gave_up, err_dev);      // all of the lane's records in flight together
+      record_wait_many<kSlots>(RW, want, pending, seq, got, t0, gave_up, err_dev);      // all of the lane's records in flight together
 #pragma unroll
       for (int m = 0; m < kSlots; m++) if ((polled >> m) & 1u) img[h_pos[m]] = got[m];
       __syncthreads();
@@ -294,7 +295,7 @@ __global__ __launch_bounds__((WideGeom<V, B>::Threads), (B == 8 ? 3 : 1)) void b
       // sc: in-domain cells from the level below (its bricks' records, or memory below the last level of the chain), the others by apply_BCs_p2 / _v2
       const int Dc = C.dim_i;
       if (parent_by_record) {      // one lane watches the gate of the brick that holds this brick's parents: the long wait
-        if (t == 0) (void)record_wait(A.Rc.gate + (size_t)(j + 1) * kBrickMaxWgs + ((bx >> 1) + side_c * ((by >> 1) + side_c * (bz >> 1))), epoch + SEQ_GATE + (unsigned)(j + 1), t0, gave_up, err_dev, 8);
+        if (t == 0) (void)record_wait(RW, A.Rc.gate + (size_t)(j + 1) * kBrickMaxWgs + ((bx >> 1) + side_c * ((by >> 1) + side_c * (bz >> 1))), epoch + SEQ_GATE + (unsigned)(j + 1), t0, gave_up, err_dev, 8);
         __syncthreads();
       }
       const int cq_i = t % CW, cq_j = (t / CW) % CW, cq_k = t / (CW * CW);
@@ -302,7 +303,7 @@ __global__ __launch_bounds__((WideGeom<V, B>::Threads), (B == 8 ? 3 : 1)) void b
       const bool oi = (ci < 0 || ci >= Dc), oj = (cj < 0 || cj >= Dc), ok = (ck < 0 || ck >= Dc);
       if (t < kCoarseCells && !(oi || oj || ok)) {
         double v;
-        if (parent_by_record) v = record_wait(A.Rc.up + (size_t)(j + 1) * kCellRecords + below_record(ci, cj, ck), epoch + SEQ_UP + (unsigned)(j + 1), t0, gave_up, err_dev);
+        if (parent_by_record) v = record_wait(RW, A.Rc.up + (size_t)(j + 1) * kCellRecords + below_record(ci, cj, ck), epoch + SEQ_UP + (unsigned)(j + 1), t0, gave_up, err_dev);
         else { const CellRef c = locate(GC, ci, cj, ck); v = vec_origin(C, c.box, e_id)[c.ijk]; }
         sc[t] = v;
       }
@@ -339,7 +340,7 @@ __global__ __launch_bounds__((WideGeom<V, B>::Threads), (B == 8 ? 3 : 1)) void b
     }
     if (rhs_by_record && owner) {
 #pragma unroll
-      for (int m = 0; m < 2; m++) rhs[m] = record_wait(A.Rc.down + (size_t)j * kCellRecords + (size_t)wg * kRecordsPerBrick + (size_t)(cell0 + m), epoch + SEQ_DOWN + (unsigned)j, t0, gave_up, err_dev);
+      for (int m = 0; m < 2; m++) rhs[m] = record_wait(RW, A.Rc.down + (size_t)j * kCellRecords + (size_t)wg * kRecordsPerBrick + (size_t)(cell0 + m), epoch + SEQ_DOWN + (unsigned)j, t0, gave_up, err_dev);
     }
     if (e_zero) {
       // zero_vector came before (mg.c:1153): the whole image is +0.0, ghost cells included (the conditions of a zero field are zeros)
@@ -401,10 +402,10 @@ __global__ __launch_bounds__((WideGeom<V, B>::Threads), (B == 8 ? 3 : 1)) void b
         const double xv = sx[pos0 + m];
         vec_origin(L, own.box, e_id)[own.ijk + m] = xv;
         vec_origin(L, own.box, VECTOR_TEMP)[own.ijk + m] = st[pos0 + m];
-        if (kUp && !first) face_store(A.Rc.up + (size_t)j * kCellRecords + (size_t)wg * kRecordsPerBrick + (size_t)(cell0 + m), xv, epoch + SEQ_UP + (unsigned)j);
+        if (kUp && !first) face_store(RW, A.Rc.up + (size_t)j * kCellRecords + (size_t)wg * kRecordsPerBrick + (size_t)(cell0 + m), xv, epoch + SEQ_UP + (unsigned)j);
       }
     }
-    if (kUp && !first && t == 0) face_store(A.Rc.gate + (size_t)j * kBrickMaxWgs + wg, 0.0, epoch + SEQ_GATE + (unsigned)j);
+    if (kUp && !first && t == 0) face_store(RW, A.Rc.gate + (size_t)j * kBrickMaxWgs + wg, 0.0, epoch + SEQ_GATE + (unsigned)j);
 
     if (kDown) {
       // restriction(coarse.R <- TEMP): 0.125 * the 8 children in the reference's order (restriction.c:54-57); this brick's (B/2)^3 coarse cells
@@ -417,7 +418,7 @@ __global__ __launch_bounds__((WideGeom<V, B>::Threads), (B == 8 ? 3 : 1)) void b
         const int qi = (o_i >> 1) + ci, qj = (o_j >> 1) + cj, qk = (o_k >> 1) + ck;
         const CellRef c = locate(GC, qi, qj, qk);
         vec_origin(C, c.box, R_id)[c.ijk] = v;
-        if (!last) face_store(A.Rc.down + (size_t)(j + 1) * kCellRecords + below_record(qi, qj, qk), v, epoch + SEQ_DOWN + (unsigned)(j + 1));
+        if (!last) face_store(RW, A.Rc.down + (size_t)(j + 1) * kCellRecords + below_record(qi, qj, qk), v, epoch + SEQ_DOWN + (unsigned)(j + 1));
       }
       // zero_vector(C.e): whole padded boxes (misc.c:6-44), each workgroup a slice -- not when C is the next level of this chain (its visit clears what it does not store)
       if (last && A.below_zero) {
