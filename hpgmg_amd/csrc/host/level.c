@@ -107,6 +107,11 @@ int hpgmg_transport_selftest(char *msg, int msglen) {
     free(all);
     if (any != 0.0 && !bad) { if (msg) snprintf(msg, (size_t)msglen, "transport self-test: another rank received a damaged message (rank %d's own messages were intact)", me); return -2; }
   }
+  /* HPGMG_SELFTEST_SUBCOMM=1 (the same on every rank): the set {0, 1} is announced like MGBuild announces a level's ranks, so the sum over it below runs on a
+   * sub-communicator where the transport makes one (kernels/comm_rccl.hip: ncclCommSplit).  Off by default: on one node with a power-of-two rank count the
+   * reference's rank map never reduces over a proper subset of two or more ranks, and first contact of the benchmark should not hang on a path it never takes. */
+  const char *sub_env = getenv("HPGMG_SELFTEST_SUBCOMM");
+  if (!bad && size >= 3 && sub_env && sub_env[0] == '1' && T->prepare_subset) { const int pair[2] = { 0, 1 }; T->prepare_subset(T->ctx, pair, 2); }
   if (!bad) {
     int *all = (int *)malloc((size_t)size * sizeof(int));
     double v, expect = 0.0;

@@ -352,6 +352,14 @@ void MGBuild(mg_type *G, level_type *fine, double a, double b, int minCoarseGrid
     free(act);
   }
 
+  { /* sub-communicators for the levels that reduce over a proper subset of the ranks: every rank passes here with the same lists in the same order */
+    const hpgmg_transport *T = hpgmg_get_transport();
+    if (T && T->size > 1 && T->prepare_subset)
+      for (l = 0; l < G->num_levels; l++) {
+        hpgmg_level_ext *X = hpgmg_level_ext_get(G->levels[l]);
+        if (X->num_active_ranks > 1 && X->num_active_ranks < T->size) T->prepare_subset(T->ctx, X->active_ranks, X->num_active_ranks);
+      }
+  }
   SAY(G->my_rank, "\n");
   for (l = 1; l < G->num_levels; l++) rebuild_operator(G->levels[l], G->levels[l - 1], a, b);
   SAY(G->my_rank, "\n");

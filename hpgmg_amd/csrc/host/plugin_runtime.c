@@ -67,6 +67,7 @@ int hpgmg_transport_init_rccl(const char *id128, int rank, int size) {
   t.rank = rank; t.size = size; t.ctx = NULL;
   t.sendrecv = hpgmg_hip_rccl_sendrecv;
   t.allreduce = hpgmg_hip_rccl_allreduce;
+  t.prepare_subset = hpgmg_hip_rccl_prepare_subset;
   hpgmg_set_transport(&t);
   return 0;
 }
@@ -79,6 +80,7 @@ int hpgmg_transport_init_ipc(const char *name, int rank, int size) {
   t.rank = rank; t.size = size; t.ctx = NULL;
   t.sendrecv = hpgmg_hip_ipc_sendrecv;
   t.allreduce = hpgmg_hip_ipc_allreduce;
+  t.prepare_subset = NULL;      /* peer copies: a subset reduction is one round of 8-byte copies among its members already */
   hpgmg_set_transport(&t);
   return 0;
 }

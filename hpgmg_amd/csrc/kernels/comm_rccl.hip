@@ -16,9 +16,13 @@
 // is one ncclAllReduce (a maximum is exact in any order).  A SUM over every rank of the job (dot() and mean() on a level all ranks
 // share: ten per iteration of a host-driven BiCGStab, solvers/bicgstab.c:14-97) is ONE ncclAllGather of the partials followed by an
 // addition in rank order on the host: one collective, and the same association on every rank and from run to run, which the golden
-// numbers need (ncclAllReduce(ncclSum) would add in whatever order the ring or tree RCCL picked).  Only reductions over a SUBSET of
-// the ranks (levels below the agglomeration point) remain an all-to-all of 8-byte messages, reduced the same way.
+// numbers need (ncclAllReduce(ncclSum) would add in whatever order the ring or tree RCCL picked).  Reductions over a SUBSET of the
+// ranks (levels below the agglomeration point; the reference: MPI_Comm_split per level, mg.c:985-993) run the same two ways on a
+// sub-communicator made by ncclCommSplit when MGBuild announces the set (hpgmg_hip_rccl_prepare_subset: collective over the whole
+// job); a set nobody announced, or whose split failed, falls back to an all-to-all of 8-byte messages, reduced the same way.
+// (Written without a multi-GPU node to run it on: the split path has never executed; the fallback is what the one-GPU tests cover.)
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <rccl/rccl.h>
 #include "common.hpp"
@@ -30,6 +34,16 @@ constexpr int kRedMax = 16;           // values per reduction call (the path red
 static double *g_red_dev = nullptr;   // [(g_size + 1) * kRedMax] staging: every rank's partials, then my own
 static double *g_red_host = nullptr;  // pinned, same size
 static long long g_allgathers = 0;
+// sub-communicators: one per distinct set of ranks announced by MGBuild; comm == nullptr: announced, but this rank is no member / the split failed
+struct SubComm { int n; int *ranks; ncclComm_t comm; int ok; };
+constexpr int kMaxSubComms = 64;
+static SubComm g_sub[kMaxSubComms];
+static int g_nsub = 0;
+static long long g_subset_collectives = 0, g_subset_alltoalls = 0;
+static SubComm *find_sub(const int *ranks, int n) {
+  for (int s = 0; s < g_nsub; s++) if (g_sub[s].n == n && memcmp(g_sub[s].ranks, ranks, (size_t)n * sizeof(int)) == 0) return &g_sub[s];
+  return nullptr;
+}
 static int nccl_fail(ncclResult_t r, const char *where) {
   fprintf(stderr, "hpgmg_hip: %s: %s\n", where, ncclGetErrorString(r));
   return 1000 + (int)r;
@@ -58,7 +72,37 @@ int hpgmg_hip_rccl_init(const char *id128, int rank, int size) {
   return 0;
 }
 
+// every rank of the job, same sets in the same order (MGBuild): color = the set's number for its members, no color for the others
+void hpgmg_hip_rccl_prepare_subset(void *ctx, const int *ranks, int nranks) {
+  (void)ctx;
+  if (!g_comm || nranks < 2 || nranks >= g_size || find_sub(ranks, nranks) || g_nsub >= kMaxSubComms) return;
+  SubComm &S = g_sub[g_nsub];
+  S.n = nranks; S.ranks = (int *)malloc((size_t)nranks * sizeof(int)); memcpy(S.ranks, ranks, (size_t)nranks * sizeof(int)); S.comm = nullptr; S.ok = 0;
+  int member = 0;
+  for (int q = 0; q < nranks; q++) if (ranks[q] == g_rank) member = 1;
+  static const int off = [] { const char *e = getenv("HPGMG_RCCL_SUBCOMM"); return (e && e[0] == '0') ? 1 : 0; }();      // 0: keep the all-to-all (every rank must say the same)
+  if (!off) {
+    ncclComm_t sub = nullptr;
+    const ncclResult_t r = ncclCommSplit(g_comm, member ? g_nsub : NCCL_SPLIT_NOCOLOR, g_rank, &sub, nullptr);      // key = my rank: the members keep their order
+    int fine = (r == ncclSuccess && (sub != nullptr || !member)) ? 1 : 0;
+    if (!fine) nccl_fail(r, "ncclCommSplit (subset reductions fall back to the all-to-all)");
+    // every rank learns whether EVERY rank got its part: members that disagreed about the path would wait for each other forever
+    int *flag_host = (int *)g_red_host, *flag_dev = (int *)g_red_dev;
+    *flag_host = fine;
+    if (hipMemcpyAsync(flag_dev, flag_host, sizeof(int), hipMemcpyHostToDevice, g_stream) != hipSuccess ||
+        ncclAllReduce(flag_dev, flag_dev, 1, ncclInt, ncclMin, g_comm, g_stream) != ncclSuccess ||
+        hipMemcpyAsync(flag_host, flag_dev, sizeof(int), hipMemcpyDeviceToHost, g_stream) != hipSuccess || hipStreamSynchronize(g_stream) != hipSuccess) { fprintf(stderr, "hpgmg_hip: agreeing on a sub-communicator failed\n"); abort(); }
+    if (*flag_host) { S.comm = sub; S.ok = member ? 1 : 0; }
+    else { if (sub) ncclCommDestroy(sub); S.comm = nullptr; S.ok = 0; }
+  }
+  g_nsub++;
+}
+long long hpgmg_hip_rccl_subset_collectives(void) { return g_subset_collectives; }      // subset reductions done as ONE collective on a sub-communicator / as an all-to-all
+long long hpgmg_hip_rccl_subset_alltoalls(void) { return g_subset_alltoalls; }
+
 void hpgmg_hip_rccl_finalize(void) {
+  for (int s = 0; s < g_nsub; s++) { if (g_sub[s].comm) { hipStreamSynchronize(g_stream); ncclCommDestroy(g_sub[s].comm); } free(g_sub[s].ranks); }
+  g_nsub = 0;
   if (g_comm) { hipStreamSynchronize(g_stream); ncclCommDestroy(g_comm); g_comm = nullptr; }
   if (g_red_dev) { (void)hipFree(g_red_dev); g_red_dev = nullptr; }
   if (g_red_host) { (void)hipHostFree(g_red_host); g_red_host = nullptr; }
@@ -116,6 +160,27 @@ void hpgmg_hip_rccl_allreduce(void *ctx, double *vals, int n, int op, const int 
   if (!g_comm) { fprintf(stderr, "hpgmg_hip: RCCL transport used before hpgmg_hip_rccl_init\n"); abort(); }
   if (op == 0 && nranks == g_size && n <= kRedMax) { if (hpgmg_hip_rccl_allreduce_max_world(vals, n)) abort(); return; }
   if (nranks == g_size && n <= kRedMax) { if (hpgmg_hip_rccl_allreduce_ordered_world(vals, n, op)) abort(); return; }      // sums: one collective, rank-ordered association
+  if (SubComm *S = find_sub(ranks, nranks)) if (S->ok && S->comm && n <= kRedMax) {
+    // the level's sub-communicator (its ranks are the members in rank order: key = rank): a maximum as ONE ncclAllReduce, a sum as ONE ncclAllGather + the
+    // addition in member order on the host -- what the whole-job forms above do
+    double *mine_dev = g_red_dev + (size_t)g_size * kRedMax, *mine_host = g_red_host + (size_t)g_size * kRedMax;
+    memcpy(mine_host, vals, (size_t)n * sizeof(double));
+    ncclResult_t r = ncclSuccess;
+    if (hipMemcpyAsync(mine_dev, mine_host, (size_t)n * sizeof(double), hipMemcpyHostToDevice, g_stream) != hipSuccess) abort();
+    if (op == 0) r = ncclAllReduce(mine_dev, g_red_dev, (size_t)n, ncclDouble, ncclMax, S->comm, g_stream);
+    else         r = ncclAllGather(mine_dev, g_red_dev, (size_t)n, ncclDouble, S->comm, g_stream);
+    if (r != ncclSuccess) { nccl_fail(r, "subset collective"); abort(); }
+    const size_t back = (op == 0) ? (size_t)n : (size_t)nranks * n;
+    if (hipMemcpyAsync(g_red_host, g_red_dev, back * sizeof(double), hipMemcpyDeviceToHost, g_stream) != hipSuccess || hipStreamSynchronize(g_stream) != hipSuccess) abort();
+    for (int v = 0; v < n; v++) {
+      double acc = g_red_host[v];
+      if (op != 0) for (int q = 1; q < nranks; q++) acc += g_red_host[(size_t)q * n + v];
+      vals[v] = acc;
+    }
+    g_subset_collectives++;
+    return;
+  }
+  g_subset_alltoalls++;
   for (int v = 0; v < n; v++) {   // n is 1 everywhere on the path; keep the general form simple
     g_red_host[g_rank] = vals[v];
     hipMemcpyAsync(g_red_dev + g_rank, g_red_host + g_rank, sizeof(double), hipMemcpyHostToDevice, g_stream);

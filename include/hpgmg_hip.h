@@ -427,6 +427,12 @@ void hpgmg_hip_rccl_finalize(void);
 void hpgmg_hip_rccl_sendrecv(void *ctx, int nrecv, double *const *rbuf, const int *rsize, const int *rrank,
                              int nsend, double *const *sbuf, const int *ssize, const int *srank, int tag);
 void hpgmg_hip_rccl_allreduce(void *ctx, double *vals, int n, int op, const int *ranks, int nranks);
+/* hpgmg_transport.prepare_subset: EVERY rank of the job, same sets in the same order (MGBuild): a sub-communicator for the set by ncclCommSplit (the reference's
+ * MPI_Comm_split per level, mg.c:985-993); reductions over the set are then ONE collective on it.  HPGMG_RCCL_SUBCOMM=0 (on every rank), a failed split on any
+ * rank, or a set never announced: the all-to-all of 8-byte messages. */
+void hpgmg_hip_rccl_prepare_subset(void *ctx, const int *ranks, int nranks);
+long long hpgmg_hip_rccl_subset_collectives(void);      /* subset reductions done as one collective ... */
+long long hpgmg_hip_rccl_subset_alltoalls(void);        /* ... and as an all-to-all (tests, bench.py) */
 /* MAX of n (<= job size) host doubles over every rank of the communicator, in place (one ncclAllReduce; what the transport's allreduce uses for a
  * whole-job maximum, misc.c:324) */
 int  hpgmg_hip_rccl_allreduce_max_world(double *vals, int n);

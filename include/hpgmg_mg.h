@@ -67,6 +67,10 @@ typedef struct {
                    int nsend, double *const *sbuf, const int *ssize, const int *srank, int tag);
   /* in-place allreduce of n host doubles over the listed ranks (sorted, includes caller) */
   void (*allreduce)(void *ctx, double *vals, int n, int op, const int *ranks, int nranks);
+  /* optional (NULL: not wanted).  MGBuild calls it on EVERY rank of the job, in the same order, once per level whose reductions run over a proper
+   * subset of the ranks (the reference's MPI_Comm_split per level, mg.c:985-993): a transport that can make a sub-communicator for the set does it
+   * here -- building one is collective over the whole job (ncclCommSplit), which allreduce(), called by the members only, cannot be. */
+  void (*prepare_subset)(void *ctx, const int *ranks, int nranks);
 } hpgmg_transport;
 void hpgmg_set_transport(const hpgmg_transport *t);
 const hpgmg_transport *hpgmg_get_transport(void);

@@ -22,10 +22,11 @@ c_int, c_dbl, vp = ctypes.c_int, ctypes.c_double, ctypes.c_void_p
 PD, PI = ctypes.POINTER(c_dbl), ctypes.POINTER(c_int)
 SENDRECV = ctypes.CFUNCTYPE(None, vp, c_int, ctypes.POINTER(PD), PI, PI, c_int, ctypes.POINTER(PD), PI, PI, c_int)
 ALLREDUCE = ctypes.CFUNCTYPE(None, vp, PD, c_int, c_int, PI, c_int)
+PREPARE = ctypes.CFUNCTYPE(None, vp, PI, c_int)
 
 
-class Transport(ctypes.Structure):
-    _fields_ = [("rank", c_int), ("size", c_int), ("ctx", vp), ("sendrecv", SENDRECV), ("allreduce", ALLREDUCE)]
+class Transport(ctypes.Structure):      # include/hpgmg_mg.h hpgmg_transport
+    _fields_ = [("rank", c_int), ("size", c_int), ("ctx", vp), ("sendrecv", SENDRECV), ("allreduce", ALLREDUCE), ("prepare_subset", PREPARE)]
 
 
 def view(ptr, n):
@@ -71,10 +72,31 @@ def main():
         for dev, host in staged:
             assert K.hpgmg_hip_memcpy_h2d(dev, vp(host.data_ptr()), host.numel() * 8) == 0
 
+    groups = {}      # sub-communicators announced by MGBuild (every rank, same order): dist.new_group is collective over the job, like ncclCommSplit
+
+    def prepare_subset(ctx, ranks, nranks):
+        members = tuple(ranks[q] for q in range(nranks))
+        stats["subsets_announced"] = stats.get("subsets_announced", 0) + 1
+        if members not in groups and os.environ.get("HPGMG_TEST_SUBCOMM", "1") != "0":
+            groups[members] = dist.new_group(list(members))
+
     def allreduce(ctx, vals, n, op, ranks, nranks):
         stats["allreduces"] += 1
         members = [ranks[q] for q in range(nranks)]
         mine = torch.tensor([vals[v] for v in range(n)], dtype=torch.float64)
+        if tuple(members) in groups:      # ONE collective on the set's sub-communicator, the partials added in member order (what comm_rccl.hip does on a split communicator)
+            stats["subset_collectives"] = stats.get("subset_collectives", 0) + 1
+            parts = [torch.empty(n, dtype=torch.float64) for _ in members]
+            dist.all_gather(parts, mine, group=groups[tuple(members)])
+            for v in range(n):
+                acc = parts[0][v].item()
+                for q in range(1, len(members)):
+                    x = parts[q][v].item()
+                    acc = max(acc, x) if op == 0 else acc + x
+                vals[v] = acc
+            return
+        if nranks < size:
+            stats["subset_alltoalls"] = stats.get("subset_alltoalls", 0) + 1
         got = {rank: mine}
         reqs = []
         for r in members:
@@ -101,7 +123,7 @@ def main():
         dist.broadcast_object_list(nonce, src=0)
         assert be.lib.hpgmg_transport_init_ipc(("/hpgmg_test_%s_%d" % (os.environ.get("MASTER_PORT", "0"), nonce[0])).encode(), rank, size) == 0
     else:
-        cb = Transport(rank, size, None, SENDRECV(sendrecv), ALLREDUCE(allreduce))
+        cb = Transport(rank, size, None, SENDRECV(sendrecv), ALLREDUCE(allreduce), PREPARE(prepare_subset))
         be.lib.hpgmg_set_transport(ctypes.byref(cb))
     # first contact, as bench.py does it: a known pattern to and from every rank, a maximum, a rank-ordered sum, a sum over ranks {0, 1}
     msg = ctypes.create_string_buffer(512)

@@ -103,3 +103,20 @@ def test_bench_supervisor_starts_fresh_ranks_with_the_other_transport_when_the_f
     assert not [l for l in out.stdout.splitlines() if l.startswith("{")], out.stdout[-500:]
     assert "rccl attempt: rank 0 exited with code" in out.stderr and "starting fresh rank processes with the ipc transport" in out.stderr, out.stderr[-2000:]
     assert "ipc attempt: rank 0 exited with code" in out.stderr and "no attempt produced a result" in out.stderr, out.stderr[-2000:]
+
+
+def test_subset_reductions_are_one_collective_on_a_sub_communicator():
+    """The reference reduces on a per-level communicator of the ranks that own boxes there (MPI_Comm_split, mg.c:985-993).  MGBuild announces every such set that is
+    a proper subset of the job on EVERY rank (hpgmg_transport.prepare_subset), the transport builds a sub-communicator -- collective over the whole job, like
+    ncclCommSplit in kernels/comm_rccl.hip; here torch.distributed.new_group -- and a reduction over the set is then ONE collective on it, partials added in member
+    order.  (On one node with the reference's Z-Morton map such sets have one member unless the rank count exceeds the boxes of an agglomerated level, so the set
+    {0, 1} of the transport self-test stands in: HPGMG_SELFTEST_SUBCOMM=1 announces it like a level's.)  Same golden numbers either way."""
+    gold = GOLD["7pt-cheby 4 27"]
+    res = run_job(4, "7pt-cheby", 4, 8, gather_dim=0, extra_env={"HPGMG_SELFTEST_SUBCOMM": "1"})
+    assert res[0]["norms"] == gold["norms"] and res[0]["err"] == gold["richardson_error"], res[0]
+    announced = [r["stats"].get("subsets_announced", 0) for r in res]
+    assert announced[0] > 0 and len(set(announced)) == 1, announced          # every rank was told about the set, members or not
+    assert [r["stats"].get("subset_collectives", 0) for r in res] == [1, 1, 0, 0] and all(r["stats"].get("subset_alltoalls", 0) == 0 for r in res), [r["stats"] for r in res]
+    off = run_job(4, "7pt-cheby", 4, 8, gather_dim=0)                        # not announced: the all-to-all among the members, same sum
+    assert off[0]["norms"] == gold["norms"] and off[0]["err"] == gold["richardson_error"]
+    assert [r["stats"].get("subset_alltoalls", 0) for r in off] == [1, 1, 0, 0] and all(r["stats"].get("subset_collectives", 0) == 0 for r in off)
