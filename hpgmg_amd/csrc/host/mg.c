@@ -443,7 +443,7 @@ void MGVCycle(mg_type *G, int e_id, int R_id, double a, double b, int l) {
   if (!L->active) return;
   if (l == G->num_levels - 1) {
     t = hpgmg_tick_begin(L, &L->timers.Total, "bottom solve");
-    if (!hpgmg_vcycle_legs_fused(&G->levels[l], 1, e_id, R_id, a, b, 3)) {
+    if (!hpgmg_vcycle_legs_fused(&G->levels[l], 1, e_id, R_id, a, b, HPGMG_LEG_BOTTOM)) {
       seg_close();                                 /* the host-driven Krylov solver synchronises */
       IterativeSolver(L, e_id, R_id, a, b, MG_DEFAULT_BOTTOM_NORM);
     }
@@ -455,17 +455,17 @@ void MGVCycle(mg_type *G, int e_id, int R_id, double a, double b, int l) {
   /* tiny levels: the plugin may run the rest of this V-cycle (or each of its legs) as one fused operation */
   const int maybe_tail = is_small(G, l);         /* only small levels can be fused: do not pay for a tick around a refusal on the big ones */
   if (maybe_tail) t = hpgmg_tick_begin(L, &L->timers.Total, "V-cycle tail (fused)");
-  if (maybe_tail && hpgmg_vcycle_legs_fused(&G->levels[l], G->num_levels - l, e_id, R_id, a, b, 2)) {
+  if (maybe_tail && hpgmg_vcycle_legs_fused(&G->levels[l], G->num_levels - l, e_id, R_id, a, b, HPGMG_LEG_VCYCLE)) {
     hpgmg_tick_end(t);
     if (opened_here) seg_close();
     return;
   }
-  if (maybe_tail && hpgmg_vcycle_legs_fused(&G->levels[l], G->num_levels - l, e_id, R_id, a, b, 0)) {
+  if (maybe_tail && hpgmg_vcycle_legs_fused(&G->levels[l], G->num_levels - l, e_id, R_id, a, b, HPGMG_LEG_DOWN)) {
     hpgmg_tick_end(t);
     MGVCycle(G, e_id, R_id, a, b, G->num_levels - 1);          /* bottom solve (closes the segment) */
     seg_open();
     t = hpgmg_tick_begin(L, &L->timers.Total, "V-cycle tail, up leg (fused)");
-    if (!hpgmg_vcycle_legs_fused(&G->levels[l], G->num_levels - l, e_id, R_id, a, b, 1)) { fprintf(stderr, "fused V-cycle leg refused after being accepted\n"); exit(1); }
+    if (!hpgmg_vcycle_legs_fused(&G->levels[l], G->num_levels - l, e_id, R_id, a, b, HPGMG_LEG_UP)) { fprintf(stderr, "fused V-cycle leg refused after being accepted\n"); exit(1); }
     hpgmg_tick_end(t);
     if (opened_here) seg_close();
     return;
@@ -658,7 +658,7 @@ static void fmg_solve_once(mg_type *G, int onLevel, int u_id, int F_id, double a
   /* the plugin may run everything below some small level -- the rest of the restrictions, the bottom solve and the climb back up to
    * that level, interpolation_fcycle + V-cycle per level -- as one fused operation */
   int ftail = bottom;
-  for (l = onLevel; l < bottom; l++) if (is_small(G, l) && hpgmg_vcycle_legs_fused(&G->levels[l], G->num_levels - l, e_id, R_id, a, b, 5)) { ftail = l; break; }
+  for (l = onLevel; l < bottom; l++) if (is_small(G, l) && hpgmg_vcycle_legs_fused(&G->levels[l], G->num_levels - l, e_id, R_id, a, b, HPGMG_LEG_FCYCLE_TAIL_ASK)) { ftail = l; break; }
 
   if (u_to_zero && ftail <= onLevel) { zero_vector(L, u_id); u_to_zero = 0; }      /* no interpolation onto this level will come: zero it now, as the caller would have */
   for (l = first_restriction; l < ftail; l++) {           /* carry the right-hand side down */
@@ -671,7 +671,7 @@ static void fmg_solve_once(mg_type *G, int onLevel, int u_id, int F_id, double a
   if (ftail < bottom) {
     if (is_small(G, ftail)) seg_open();
     t = hpgmg_tick_begin(G->levels[ftail], &G->levels[ftail]->timers.Total, "F-cycle tail (fused)");
-    if (!hpgmg_vcycle_legs_fused(&G->levels[ftail], G->num_levels - ftail, e_id, R_id, a, b, 4)) { fprintf(stderr, "fused F-cycle tail refused after being accepted\n"); exit(1); }
+    if (!hpgmg_vcycle_legs_fused(&G->levels[ftail], G->num_levels - ftail, e_id, R_id, a, b, HPGMG_LEG_FCYCLE_TAIL)) { fprintf(stderr, "fused F-cycle tail refused after being accepted\n"); exit(1); }
     hpgmg_tick_end(t);
     for (l = bottom - 1; l >= ftail; l--) G->levels[l]->vcycles_from_this_level++;
     seg_close();
@@ -687,7 +687,7 @@ static void fmg_solve_once(mg_type *G, int onLevel, int u_id, int F_id, double a
     if (l == onLevel && u_to_zero) {
       if (!hpgmg_zero_interpolation_fcycle_fused(G->levels[l], e_id, G->levels[l + 1], e_id)) { zero_vector(G->levels[l], e_id); interpolation_fcycle(G->levels[l], e_id, 0.0, G->levels[l + 1], e_id); }
       u_to_zero = 0;
-    } else if (is_small(G, l) && hpgmg_vcycle_legs_fused(&G->levels[l], G->num_levels - l, e_id, R_id, a, b, 6)) {      /* the plugin ran this step whole: interpolation + V-cycle */
+    } else if (is_small(G, l) && hpgmg_vcycle_legs_fused(&G->levels[l], G->num_levels - l, e_id, R_id, a, b, HPGMG_LEG_FCYCLE_STEP)) {      /* the plugin ran this step whole: interpolation + V-cycle */
       hpgmg_tick_end(t);
       G->levels[l]->vcycles_from_this_level++;
       seg_close();

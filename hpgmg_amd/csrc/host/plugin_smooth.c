@@ -25,9 +25,7 @@ void hpgmg_level_sync_counters(level_type *L) {
   *B->krylov_pinned = 0;
 }
 
-/* leg 0/1: the legs around a host-driven bottom solve; leg 2: legs + bottom solve; leg 3: bottom solve only (n == 1);
- * leg 4: the whole F-cycle below levels[0] (right-hand side restricted down the chain, bottom solve, interpolation_fcycle + V-cycle per
- * level upwards); leg 5: only answer whether leg 4 would be accepted */
+/* `leg`: enum hpgmg_leg (include/hpgmg_operators.h) -- DOWN 0, UP 1, VCYCLE 2, BOTTOM 3, FCYCLE_TAIL 4, FCYCLE_TAIL_ASK 5, FCYCLE_STEP 6; + HPGMG_LEG_ASK (16): only answer */
 int hpgmg_vcycle_legs_fused(level_type **levels, int n, int e_id, int R_id, double a, double b, int leg) { hp_lazy_flush(); return hp_vcycle_legs_fused(levels, n, e_id, R_id, a, b, leg); }
 /* The same for the 27-point / fv2 / fv4 plugins, leg 2 only (smooth ... bottom solve ... smooth as one launch): every level of the chain is ONE
  * box whose vectors fit the LDS (kernels/stencil.hip: small_vtail_kernel).  `7 8`: the levels of 8^3, 4^3, 2^3 (and 1^3) cells. */
@@ -207,17 +205,17 @@ int hp_vcycle_legs_fused(level_type **levels, int n, int e_id, int R_id, double 
   double h2inv[8], c1[64], c2[64];
   const int enabled = (int)hp_switch(SW_FUSED_TAIL), bottom_enabled = (int)hp_switch(SW_FUSED_BOTTOM);
   hpgmg_get_config(&cfg);
-  if (leg >= 16) { probe = 1; leg -= 16; }
-  if ((leg <= 2 || leg == 6) && !probe) {
+  if (leg >= HPGMG_LEG_ASK) { probe = 1; leg -= HPGMG_LEG_ASK; }
+  if ((leg <= HPGMG_LEG_VCYCLE || leg == HPGMG_LEG_FCYCLE_STEP) && !probe) {
     /* launch-bound levels above the tail: one launch per level visit, then the tail, then one launch per visit on the way up.  leg 6: the step of
      * FMGSolve's climb (mg.c:1289-1293): interpolation_fcycle(levels[0] <- levels[1]) rides in the first launch of the V-cycle that follows it --
      * every brick of that launch reads levels[1]'s correction, so its zero_vector is left to the launch that visits levels[1] (a brick level too). */
-    const int fstep = (leg == 6), vleg = fstep ? 2 : leg;
+    const int fstep = (leg == HPGMG_LEG_FCYCLE_STEP), vleg = fstep ? HPGMG_LEG_VCYCLE : leg;
     if (fstep && (!hp_switch(SW_BRICK_FSTEP) || brick_op_is_wide(&cfg))) return 0;      /* (27-point / fv4: interpolation_fcycle stays a launch of its own) */
     const int k = brick_prefix(levels, n, &cfg);
     const int outer_follows = tail_follows_bricks;      /* (the call for the tail comes through here again, with k == 0) */
     tail_follows_bricks = outer_follows || (k > 0);
-    const int tail_ok = (k > (fstep ? 1 : 0)) && hp_vcycle_legs_fused(levels + k, n - k, e_id, R_id, a, b, 16 + vleg);
+    const int tail_ok = (k > (fstep ? 1 : 0)) && hp_vcycle_legs_fused(levels + k, n - k, e_id, R_id, a, b, HPGMG_LEG_ASK + vleg);
     tail_follows_bricks = outer_follows;
     if (tail_ok) {
       /* zero_vector of a brick level below the first: by the launch that visits it (which then does not read the vector either); the tail's first level: here */
@@ -234,7 +232,7 @@ int hp_vcycle_legs_fused(level_type **levels, int n, int e_id, int R_id, double 
     }
     if (fstep) return 0;
   }
-  if (leg == 6) return 0;
+  if (leg == HPGMG_LEG_FCYCLE_STEP) return 0;
   /* A correction or right-hand side that lives among the work vectors of the host-driven Krylov solver (ids >= VECTORS_RESERVED: MGPCG's z,
    * mg.c:1530) ALIASES them on the bottom level -- z is BiCGStab's p there (solvers/bicgstab.c:14-19) -- and the reference's numbers include that.
    * The fused bottom solve keeps the solver's vectors to itself, so the forms that contain it step aside: the legs run without it and the host-driven
@@ -295,7 +293,7 @@ int hp_vcycle_legs_fused(level_type **levels, int n, int e_id, int R_id, double 
     dev[l] = &B->dev;
     h2inv[l] = 1.0 / (L->h * L->h);
   }
-  if (leg == 5 || probe) return 1;
+  if (leg == HPGMG_LEG_FCYCLE_TAIL_ASK || probe) return 1;
   TICK(tail_books_on ? tail_books_on : levels[0], smooth, leg == 3 ? "bottom solve (device BiCGStab)" : (leg == 4 ? "fused F-cycle tail" : "fused V-cycle tail"));
   HIP_OK(hpgmg_hip_vcycle_tail(n, dev, h2inv, c1, c2, sweeps, hp_variant(), cfg.smoother, e_id, R_id, a, b, leg,
                                hpgmg_vectors_reserved(), MG_DEFAULT_BOTTOM_NORM, with_bottom ? hp_backend_of(levels[n - 1])->krylov_pinned : NULL));

@@ -332,10 +332,8 @@ __global__ __launch_bounds__(64 * NW) void cheby_pair_kernel(const hpgmg_hip_lev
       const p2 km = x0plane(p - 1) ? x0m : pneg(x0c);
       const p2 kp = above_in ? x0p : pneg(x0c);
       double left = __shfl_up(x0c.y, 1, 64), right = __shfl_down(x0c.x, 1, 64);
-#ifndef HPGMG_EXP_NO_X0EDGE
       if (lane == 0)  left  = (left_dom && !left_ghost)   ? -x0c.x : x0_one(box_of(biL, bj_, p), liL, lj, p);
       if (lane == 63) right = (right_dom && !right_ghost) ? -x0c.y : x0_one(box_of(biR, bj_, p), liR, lj, p);
-#endif
       // GSRB: cell (gi, gj, gk) is swept in half sweep s when (gi ^ gj ^ gk ^ s) is even; a pair starts at an even gi
       // (brick origins are multiples of the box size, so brick-local and global parities agree)
       if (!(ghost_row && ghost_plane))                          // a ghost row on a ghost plane is a brick edge: x1 there is never read
@@ -357,10 +355,8 @@ __global__ __launch_bounds__(64 * NW) void cheby_pair_kernel(const hpgmg_hip_lev
       const p2 kp = x1c;                                         // x1 was formed on plane p
       double left = __shfl_up(x1m1.y, 1, 64), right = __shfl_down(x1m1.x, 1, 64);
       // across a tile edge -- and, REMOTE, across a remote i face -- x1 was written beforehand by cheby_pair_edge_kernel
-#ifndef HPGMG_EXP_NO_X1EDGE
       if (lane == 0)  left  = (left_dom && !left_ghost)   ? -x1m1.x : gld1(pair_vec(L, A, A.out1, box_of(biL, bj_, q)) + (liL + lj * jS + plane_off(q)));
       if (lane == 63) right = (right_dom && !right_ghost) ? -x1m1.y : gld1(pair_vec(L, A, A.out1, box_of(biR, bj_, q)) + (liR + lj * jS + plane_off(q)));
-#endif
       const p2 x2 = pair_update<V, SM>(x1m1, left, right, jm, jp, km, kp, x0m, qp, A.a, A.b, A.h2inv, A.c1b, A.c2b, ((gj ^ q ^ (A.sweep_a + 1)) & 1) == 0);
       pst(pair_vec(L, A, A.out2, boxq) + shift_of(sh, A.out2) + offq, x2);
     }
