@@ -125,7 +125,7 @@ typedef struct halo_images {
 /* ---- run-time switches: one table (plugin_switches.c) ---- */
 typedef enum { SW_GHOST_FREE = 0, SW_ONE_LAUNCH_GHOSTS, SW_OVERLAP, SW_PAIR_REMOTE, SW_IMAGES, SW_FUSED_SWEEPS, SW_PAIR_MIN_CELLS, SW_FUSED_RESIDUAL, SW_FUSED_TAIL,
                SW_FUSED_FTAIL, SW_FUSED_BOTTOM, SW_SMALL_FUSED, SW_SMALL_VTAIL, SW_SMALL_27PT_GSRB, SW_SMALL_OPS, SW_LAZY, SW_LAZY_REPORT, SW_TEMP_SCRATCH,
-               SW_FV4_NO_EXACT_RB, SW_GRAPH, SW_SMOOTHER_PRECISION, SW_DEFER_NORM, SW_BRICK_VISITS, SW_BRICK_SIZE, SW_BRICK_MIN_DIM, SW_BRICK_FSTEP, SW_BRICK_CHAIN, SW_BRICK_WIDE, SW_BRICK_WIDE_MAX_DIM, SW_BRICK_WIDE_TAIL_DIM, SW_COUNT } hp_switch_id;
+               SW_FV4_NO_EXACT_RB, SW_GRAPH, SW_SMOOTHER_PRECISION, SW_DEFER_NORM, SW_BRICK_VISITS, SW_BRICK_SIZE, SW_BRICK_MIN_DIM, SW_BRICK_FSTEP, SW_BRICK_CHAIN, SW_BRICK_WIDE, SW_BRICK_WIDE_MAX_DIM, SW_BRICK_WIDE_TAIL_DIM, SW_FTAIL_MAX_DIM, SW_COUNT } hp_switch_id;
 HP_INTERNAL long long hp_switch(hp_switch_id id);                 /* the value in force: the setter's, else the environment's, else the default */
 HP_INTERNAL void hp_switch_set(hp_switch_id id, long long value);
 

@@ -255,7 +255,7 @@ int hp_vcycle_legs_fused(level_type **levels, int n, int e_id, int R_id, double 
   if (!enabled || !hp_ghost_free_mode() || cfg.op != HPGMG_OP_7PT || n > 8 || n > hpgmg_hip_tail_max_levels() || sweeps > 8) return 0;
   if (with_bottom && !bottom_enabled) return 0;
   if (n < (leg == 3 ? 1 : 2)) return 0;
-  if (leg >= 4 && !hp_switch(SW_FUSED_FTAIL)) return 0;
+  if (leg >= 4 && (!hp_switch(SW_FUSED_FTAIL) || levels[0]->dim.i > (int)hp_switch(SW_FTAIL_MAX_DIM))) return 0;
   /* multi-rank jobs: the chain qualifies when this rank owns every box of every level in it (checked below), which is
    * how the coarse levels end up after agglomeration onto rank 0 -- no message and no all-reduce is needed then */
   for (l = 0; l < n; l++) {

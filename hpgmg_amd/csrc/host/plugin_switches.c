@@ -39,6 +39,7 @@ static struct { const char *env; int kind; long long dflt; const char *what; lon
   [SW_BRICK_WIDE]       = { "HPGMG_BRICK_WIDE", K_ON, 1, "27-pt / fv4: the same for the operators with wide stencils (kernels/brick_wide.hip: halo of the stencil's radius, apply_BCs_p2 / _v4 on the LDS image)" },
   [SW_BRICK_WIDE_MAX_DIM] = { "HPGMG_TUNE_BRICK_WIDE_MAX", K_INT, 64, "largest level (cells per side) the 27-pt / fv4 plugins visit as bricks (measured: fv4 `7 64` 29.71 / 29.91 / 30.15 ms with 64 / 32 / 16, 27-pt 12.27 / 12.51 / 12.52)" },
   [SW_BRICK_WIDE_TAIL_DIM] = { "HPGMG_TUNE_BRICK_WIDE_TAIL", K_INT, 1, "27-pt / fv4: the largest one-box level left to the single-workgroup tail (1: the 8^3, 4^3 (and 27-pt: 2^3) levels are visited as ONE brick each and only the bottom solve is left; 2 / 4 / 8: the tail starts there)" },
+  [SW_FTAIL_MAX_DIM]    = { "HPGMG_TUNE_FTAIL_MAX", K_INT, 8, "7-pt: the largest level (cells per side) the single-launch F-cycle tail starts from (8: the 16^3 step of the climb is a brick launch each way, eight CUs instead of one: config 1 0.320 vs 0.328 ms with 16, config 2 the same within noise; profiles/r06i_ab_ftail.txt)" },
   [SW_SMOOTHER_PRECISION]= { "HPGMG_SMOOTHER_PRECISION", K_INT, 64, "32: fp32 coefficient streams in the Chebyshev sweep pairs (BASELINE config 5, tolerance-gated); 64: bit-exact" },
 };
 
