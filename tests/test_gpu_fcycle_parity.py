@@ -153,13 +153,16 @@ def test_vcycle_tail_below_a_one_box_level_is_one_launch_and_gives_the_same_norm
     """27-point / fv2 / fv4: the rest of a V-cycle below a level of ONE box (smooth, residual, restriction, zero_vector per level, the BiCGStab
     bottom solve, interpolation_vcycle and smooth per level upwards) runs as one single-workgroup launch (small_vtail_kernel; the default except for 27-point GSRB,
     hpgmg_set_small_vtail(1) = on for every plugin).  When on it must be taken (launch counter), and the norms are the golden ones with it and
-    without it."""
+    without it.  (Brick launches off: with them the one-box levels of the 27-point / fv4 plugins are bricks too and only the bottom solve is left of the tail --
+    tests/test_gpu_operators.py::test_level_visits_as_one_launch_of_bricks_wide_stencils; this kernel remains the path of fv2 and of HPGMG_BRICK_WIDE=0.)"""
     import ctypes
     import hpgmg_amd as H
     gold = GOLD[f"{variant} {args}"]
     k = H.load_kernels()
     k.hpgmg_hip_small_vtail_launch_count.restype = ctypes.c_longlong
     hip.lib.hpgmg_set_small_vtail.argtypes = [ctypes.c_int]
+    hip.lib.hpgmg_set_brick_wide.argtypes = [ctypes.c_int]
+    hip.lib.hpgmg_set_brick_wide(0)
     try:
         for on in (1, 0):
             hip.lib.hpgmg_set_small_vtail(on)
@@ -174,6 +177,7 @@ def test_vcycle_tail_below_a_one_box_level_is_one_launch_and_gives_the_same_norm
             assert (taken > 0) if on else (taken == 0), (on, taken)
     finally:
         hip.lib.hpgmg_set_small_vtail(2)
+        hip.lib.hpgmg_set_brick_wide(1)
 
 
 @pytest.mark.parametrize("variant,args", [("7pt-cheby", "4 8"), ("7pt-gsrb", "5 8"), ("fv4-gsrb", "4 8"), ("27pt-cheby", "5 8"), ("fv2-cheby", "4 8")])
