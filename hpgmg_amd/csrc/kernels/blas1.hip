@@ -236,11 +236,15 @@ __global__ __launch_bounds__(64) void tile_sum_kernel(const hpgmg_hip_level L, i
 // The same sum on a level of many tiles: ONE WAVE per tile.  A tile's partial is a chain of dim x 8 x 8 dependent additions in k, j, i order (misc.c:261-269)
 // -- that order is the contract, so the chain itself cannot be cut: ~8 cycles per addition, 8192 of them for a tile of a 128^3 box = ~30 us, which with every
 // tile of the level on a wave of its own is also the time of the launch.  What can be taken out of the chain is memory: with a LANE per tile (above) every load
-// of the chain was a 64-byte sector per lane and a round trip per element (1.35 ms at 256^3).  Here the wave's 64 lanes fetch a row (dim cells, coalesced) one row
-// ahead of the chain into LDS -- for a dot product they form the products -- and lane 0 adds the row's values in order from LDS.
+// of the chain was a 64-byte sector per lane and a round trip per element (1.35 ms at 256^3).  Here the wave's 64 lanes fetch EIGHT rows (dim cells each, coalesced)
+// ahead of the chain into LDS -- for a dot product they form the products -- and lane 0 adds the values in order from LDS (one row ahead: 153 us, a memory round
+// trip per row is longer than a row's chain).
 constexpr int kSumMaxChunks = 8;      // rows of up to 512 cells
+constexpr int kSumGroup = 8;          // rows fetched together (one k plane of a tile): enough loads in flight to hide a memory round trip behind a group's chain
+template <int CHUNKS>
 __global__ __launch_bounds__(64) void tile_sum_wave_kernel(const hpgmg_hip_level L, int id_a, int id_b, double *partials) {
-  extern __shared__ double sum_rows[];      // [2][dim]
+  extern __shared__ double sum_rows[];      // [2][kSumGroup][dim]
+  typedef const double __attribute__((address_space(3))) *ldsrow;
   const int tiles_side = (L.dim + BLOCKCOPY_TILE_J - 1) / BLOCKCOPY_TILE_J, tiles_per_box = tiles_side * tiles_side;
   const int t = (int)blockIdx.x, lane = (int)threadIdx.x, dim = L.dim;
   const int box = t / tiles_per_box, rem = t % tiles_per_box;
@@ -249,25 +253,40 @@ __global__ __launch_bounds__(64) void tile_sum_wave_kernel(const hpgmg_hip_level
   const gcptr pa = as_global(vec_origin(L, box, id_a));
   const gcptr pb = (id_b >= 0) ? as_global(vec_origin(L, box, id_b)) : pa;
   const bool dot = id_b >= 0;
-  double v[kSumMaxChunks];
-  auto fetch = [&](int r) {
-    const int base = (j0 + r % nj) * L.jStride + (k0 + r / nj) * L.kStride;
+  const int ngroups = (nrows + kSumGroup - 1) / kSumGroup;
+  double v[kSumGroup][CHUNKS];
+  auto fetch = [&](int g) {      // rows g * 8 .. g * 8 + 7 of the tile (k, j order), a row = dim cells, lane l takes cells l, l + 64, ...
 #pragma unroll
-    for (int c = 0; c < kSumMaxChunks; c++) {
-      const int i = lane + 64 * c;
-      v[c] = 0.0;
-      if (i < dim) { const double a = pa[base + i]; v[c] = dot ? a * pb[base + i] : a; }
+    for (int q = 0; q < kSumGroup; q++) {
+      // (every load is issued, at an address clamped into the tile, and the value discarded where there is no cell: a branch per load made each one a
+      // round trip of its own -- 158 us at 256^3)
+      const int r = g * kSumGroup + q, rc = min(r, nrows - 1);
+      const int base = (j0 + rc % nj) * L.jStride + (k0 + rc / nj) * L.kStride;
+#pragma unroll
+      for (int c = 0; c < CHUNKS; c++) {
+        const int i = lane + 64 * c, ic = min(i, dim - 1);
+        const double a = pa[base + ic], bb = pb[base + ic];
+        const double w = dot ? a * bb : a;
+        v[q][c] = (r < nrows && i < dim) ? w : 0.0;
+      }
     }
   };
   fetch(0);
   double acc = 0.0;
-  for (int r = 0; r < nrows; r++) {
-    double *row = sum_rows + (r & 1) * dim;
+  for (int g = 0; g < ngroups; g++) {
+    double *buf = sum_rows + (size_t)(g & 1) * kSumGroup * dim;
 #pragma unroll
-    for (int c = 0; c < kSumMaxChunks; c++) { const int i = lane + 64 * c; if (i < dim) row[i] = v[c]; }
-    if (r + 1 < nrows) fetch(r + 1);      // in flight under the chain below
-    __syncthreads();                      // (one wave: orders its LDS writes before lane 0's reads; the buffer written next was read two rows ago)
-    if (lane == 0) { for (int i = 0; i < dim; i++) acc += row[i]; }
+    for (int q = 0; q < kSumGroup; q++)
+#pragma unroll
+      for (int c = 0; c < CHUNKS; c++) { const int i = lane + 64 * c; if (i < dim) buf[q * dim + i] = v[q][c]; }
+    if (g + 1 < ngroups) fetch(g + 1);      // in flight under the chain below
+    __syncthreads();                        // (one wave: orders its LDS writes before lane 0's reads; the buffer written next was read two groups ago)
+    if (lane == 0) {
+      const int rows_here = min(kSumGroup, nrows - g * kSumGroup), n = rows_here * dim;
+      const ldsrow rr = (ldsrow)buf;
+#pragma unroll 16
+      for (int i = 0; i < n; i++) acc += rr[i];      // the chain: k, j, i order
+    }
   }
   if (lane == 0) partials[t] = acc;
 }
@@ -515,7 +534,14 @@ static int ordered_sum(const hpgmg_hip_level *L, int id_a, int id_b, double *out
   if (ntiles <= 64) {
     hipLaunchKernelGGL((tile_sum_kernel<true>), dim3(1), dim3(64), 0, g_stream, *L, id_a, id_b, g_scratch, g_result_dev, ++g_seq);
   } else {
-    if (L->dim <= 64 * kSumMaxChunks) hipLaunchKernelGGL(tile_sum_wave_kernel, dim3(ntiles), dim3(64), (size_t)2 * L->dim * sizeof(double), g_stream, *L, id_a, id_b, g_scratch);
+    const size_t lds = (size_t)2 * kSumGroup * L->dim * sizeof(double);
+    if (L->dim <= 128)      hipLaunchKernelGGL((tile_sum_wave_kernel<2>), dim3(ntiles), dim3(64), lds, g_stream, *L, id_a, id_b, g_scratch);
+    else if (L->dim <= 256) hipLaunchKernelGGL((tile_sum_wave_kernel<4>), dim3(ntiles), dim3(64), lds, g_stream, *L, id_a, id_b, g_scratch);
+    else if (L->dim <= 64 * kSumMaxChunks) {
+      static bool once = false;
+      if (!once) { HPGMG_CHECK(hipFuncSetAttribute((const void *)tile_sum_wave_kernel<kSumMaxChunks>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)2 * kSumGroup * 64 * kSumMaxChunks * sizeof(double)))); once = true; }
+      hipLaunchKernelGGL((tile_sum_wave_kernel<kSumMaxChunks>), dim3(ntiles), dim3(64), lds, g_stream, *L, id_a, id_b, g_scratch);
+    }
     else hipLaunchKernelGGL((tile_sum_kernel<false>), dim3((ntiles + 63) / 64), dim3(64), 0, g_stream, *L, id_a, id_b, g_scratch, g_result_dev, 0ULL);
     hipLaunchKernelGGL(ordered_sum_kernel, dim3(1), dim3(64), 0, g_stream, (const double *)g_scratch, ntiles, g_result_dev, ++g_seq);
   }
