@@ -181,7 +181,7 @@ int hp_pair_halo_ready(level_type *L, backend_t *B) {
     const hpgmg_transport *T = hpgmg_get_transport();
     int lo[3], n[3], b, ok;
     B->halo_state = -1;
-    ok = pair_remote_enabled() && T && T->size > 1 && L->boundary_condition.type == BC_DIRICHLET && L->box_dim % 128 == 0 && L->num_my_boxes > 0;
+    ok = pair_remote_enabled() && T && T->size > 1 && L->boundary_condition.type == BC_DIRICHLET && (L->box_dim % 128 == 0 || (128 % L->box_dim == 0 && L->box_dim >= 16)) && L->num_my_boxes > 0;      /* (boxes narrower than a 128-cell row: several per row) */
     if (ok) ok = every_rank_owns_a_brick(L, lo, n);
     for (b = 0; ok && b < L->num_my_boxes; b++) {     /* local numbering = lexicographic inside the brick */
       const box_type *X = &L->my_boxes[b];

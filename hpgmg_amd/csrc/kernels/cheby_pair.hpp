@@ -127,7 +127,7 @@ __device__ __forceinline__ p2 pair_update(p2 c, double left, double right, p2 jm
 constexpr int kPairMaxBoxes = 1024;       // boxes per rank the pair kernel takes (their base-pointer tables are copied into LDS, see below)
 template <int V, int NW, bool C32, int SM, bool NARROW, bool INTERP, bool REMOTE = false>
 __global__ __launch_bounds__(64 * NW) void cheby_pair_kernel(const hpgmg_hip_level L_in, const PairArgs A_in) {
-  static_assert(!(REMOTE && (NARROW || C32)), "the multi-rank variant is built for whole-row boxes and fp64 coefficients");
+  static_assert(!(REMOTE && C32) && !(REMOTE && NARROW && INTERP), "the multi-rank variant is built for fp64 coefficients; with narrow boxes the interpolation is not folded in");
   // REMOTE + INTERP: the parent is added to the cells of the brick only -- what arrives in ghost zones and deep planes was packed by its owner with ITS parents already added (pair_halo_kernel)
   constexpr bool kVC = (V != HPGMG_HIP_7PT_CC);
   constexpr bool kHelm = (V == HPGMG_HIP_7PT_VC_HELMHOLTZ);
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(64 * NW) void cheby_pair_kernel(const hpgmg_hip_lev
   // neighbours in i across the tile edge (lane 0 / lane 63 only)
   const bool left_dom = (gi0 == 0), right_dom = (gi0 + 128 == A.Di);
   const int biL = left_dom ? bi_ : (gi0 - 1) / bd, liL = left_dom ? (REMOTE ? -1 : 0) : (gi0 - 1) - biL * bd;
-  const int biR = right_dom ? bi_ : (gi0 + 128) / bd, liR = right_dom ? (REMOTE ? bd : 0) : (gi0 + 128) - biR * bd;
+  const int biR = right_dom ? (gi0 + 127) / bd : (gi0 + 128) / bd, liR = right_dom ? (REMOTE ? bd : 0) : (gi0 + 128) - biR * bd;      // (right_dom: the row's LAST box -- narrow boxes: not its first)
   const bool left_ghost = REMOTE && left_dom && A.rem[0], right_ghost = REMOTE && right_dom && A.rem[1];   // read the ghost column instead of -centre
   // far rows of x0 the two halo waves need from memory (REMOTE: two rows outside the brick = the deep halo)
   const bool far_lo = row_x1 && (w == 0) && x0row(gj - 1);
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(64 * NW) void cheby_pair_kernel(const hpgmg_hip_lev
   auto x0_row = [&](int bj, int l_j, int gk) -> p2 {
     if (REMOTE && (gk < -1 || gk > A.Dk)) {
       if (l_j < 0 || l_j >= bd) return p2{0, 0};
-      const int box = box_of(bi_, bj, gk);
+      const int box = box_of(bi_, bj, gk) + hop;      // (the lane's own box: the deep planes are stored per box)
       return pld(A.deep + (((size_t)box * 6 + (gk < 0 ? 4 : 5)) * bd + l_j) * bd + li);
     }
     return x0_pair(box_of(bi_, bj, gk), li, l_j, gk);
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(64 * NW) void cheby_pair_kernel(const hpgmg_hip_lev
   auto far_row = [&](int gk) -> p2 {
     if (REMOTE && far_deep) {
       if (gk < 0 || gk >= A.Dk) return p2{0, 0};               // corner again
-      const int box = box_of(bi_, bjf, gk);
+      const int box = box_of(bi_, bjf, gk) + hop;
       return pld(A.deep + (((size_t)box * 6 + (gjf < 0 ? 2 : 3)) * bd + (gk - kbox(gk) * bd)) * bd + li);
     }
     return REMOTE ? x0_row(bjf, ljf, gk) : x0_pair(box_of(bi_, bjf, gk), li, ljf, gk);
@@ -308,10 +308,10 @@ __global__ __launch_bounds__(64 * NW) void cheby_pair_kernel(const hpgmg_hip_lev
         if (p == pstart || (p % bd) == 0) qc.bk0 = bks.pair(off); else qc.bk0 = qp.bk1;
         // the box's own upper face (ghost plane at the box top); REMOTE: the far face of a ghost cell above the brick is one
         // index beyond the ghost zone and comes from the deep coefficient halo
-        if (REMOTE && p >= A.Dk) qc.bk1 = ghost_row ? p2{0, 0} : pld(A.deep_beta + (((size_t)box * 3 + 2) * bd + lj) * bd + li);
+        if (REMOTE && p >= A.Dk) qc.bk1 = ghost_row ? p2{0, 0} : pld(A.deep_beta + (((size_t)(box + hop) * 3 + 2) * bd + lj) * bd + li);
         else qc.bk1 = bks.pair(off + kS);
         qc.bjlo = bj_c;
-        if (REMOTE && gj >= A.Dj) qc.bjhi = ghost_plane ? p2{0, 0} : pld(A.deep_beta + (((size_t)box * 3 + 1) * bd + (p - kbox(p) * bd)) * bd + li);
+        if (REMOTE && gj >= A.Dj) qc.bjhi = ghost_plane ? p2{0, 0} : pld(A.deep_beta + (((size_t)(box + hop) * 3 + 1) * bd + (p - kbox(p) * bd)) * bd + li);
         else if (w == NRs + 1 || gj + 1 >= jhi || ((lj + 1) == bd)) qc.bjhi = CoefStream<C32>(L, A, box, VECTOR_BETA_J, C32_BETA_J, sh).pair(off + jS);
         else qc.bjhi = slabBJ[p & 1][w + 1][lane];
       }

@@ -65,7 +65,6 @@ static int pair_supported_dims(const hpgmg_hip_level *L, int variant, int Di, in
 int hpgmg_hip_smooth_cheby_pair_supported(const hpgmg_hip_level *L, int variant) { return pair_supported_dims(L, variant, L->dim_i, L->dim_j, L->dim_k); }
 // several ranks: this rank's boxes form a brick of nbi x nbj x nbk boxes (numbered lexicographically inside it)
 int hpgmg_hip_smooth_cheby_pair_supported_brick(const hpgmg_hip_level *L, int variant, int nbi, int nbj, int nbk) {
-  if (L->dim % 128 != 0) return 0;
   return pair_supported_dims(L, variant, nbi * L->dim, nbj * L->dim, nbk * L->dim);
 }
 int hpgmg_hip_coef32_refresh(const hpgmg_hip_level *L, float *const *c32_base, int num_vectors) {
@@ -147,7 +146,7 @@ static int smooth_pair(const hpgmg_hip_level *L, int variant, int gsrb, int swee
   HPGMG_SKIP_IF_REPLAY();
   const int Di = remote ? g_pair_brick[0] * L->dim : L->dim_i, Dj = remote ? g_pair_brick[1] * L->dim : L->dim_j, Dk = remote ? g_pair_brick[2] * L->dim : L->dim_k;
   if (!pair_supported_dims(L, variant, Di, Dj, Dk)) return record_error(hipErrorInvalidValue, "smooth_cheby_pair: level not supported");
-  if (remote && (L->dim % 128 != 0 || c32_base)) return record_error(hipErrorInvalidValue, "smooth_cheby_pair: remote faces need whole-row boxes and fp64 coefficients");
+  if (remote && c32_base) return record_error(hipErrorInvalidValue, "smooth_cheby_pair: remote faces need fp64 coefficients");
   static const int tune_kc = env_int("HPGMG_TUNE_PAIR_KC", 0);
   constexpr int nw = 16;
   // k chunk: every workgroup costs KC+2 plane steps and (at 128 VGPRs, 16 waves) one workgroup occupies a CU, so the
@@ -212,13 +211,13 @@ static int smooth_pair(const hpgmg_hip_level *L, int variant, int gsrb, int swee
 #define PAIR_LAUNCH2(VAR, C32, SM, NARROW, INTERP) { \
       static bool once = false; if (!once) { HPGMG_CHECK(hipFuncSetAttribute((const void *)cheby_pair_kernel<VAR, nw, C32, SM, NARROW, INTERP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once = true; } \
       hipLaunchKernelGGL((cheby_pair_kernel<VAR, nw, C32, SM, NARROW, INTERP>), dim3(grid), dim3(64, nw), lds, g_stream, *L, A); }
-#define PAIR_LAUNCH_REMOTE_IP(VAR, SM, IP) { \
-      static bool once = false; if (!once) { HPGMG_CHECK(hipFuncSetAttribute((const void *)cheby_pair_kernel<VAR, nw, false, SM, false, IP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once = true; } \
+#define PAIR_LAUNCH_REMOTE_IP(VAR, SM, NRW, IP) { \
+      static bool once = false; if (!once) { HPGMG_CHECK(hipFuncSetAttribute((const void *)cheby_pair_kernel<VAR, nw, false, SM, NRW, IP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once = true; } \
       const int ecols = 2 * (A.tiles_i - 1) + (A.rem[0] ? 1 : 0) + (A.rem[1] ? 1 : 0); \
       A.edge_blocks = ((A.Dj + 63) / 64) * A.Dk * ecols; const int egrid_r = grid_for(A.edge_blocks, &A.edge_per_xcd); \
       if (ecols > 0) hipLaunchKernelGGL((cheby_pair_edge_kernel<VAR, false, SM, IP, true>), dim3(egrid_r), dim3(64), 0, g_stream, *L, A); \
-      hipLaunchKernelGGL((cheby_pair_kernel<VAR, nw, false, SM, false, IP, true>), dim3(grid), dim3(64, nw), lds, g_stream, *L, A); }
-#define PAIR_LAUNCH_REMOTE(VAR, SM) { if (interp) PAIR_LAUNCH_REMOTE_IP(VAR, SM, true) else PAIR_LAUNCH_REMOTE_IP(VAR, SM, false) }
+      hipLaunchKernelGGL((cheby_pair_kernel<VAR, nw, false, SM, NRW, IP, true>), dim3(grid), dim3(64, nw), lds, g_stream, *L, A); }
+#define PAIR_LAUNCH_REMOTE(VAR, SM) { if (L->dim % 128 != 0) PAIR_LAUNCH_REMOTE_IP(VAR, SM, true, false) else if (interp) PAIR_LAUNCH_REMOTE_IP(VAR, SM, false, true) else PAIR_LAUNCH_REMOTE_IP(VAR, SM, false, false) }
 #define PAIR_LAUNCH(VAR, C32, SM) { \
       A.edge_blocks = ((A.Dj + 63) / 64) * A.Dk * 2 * (A.tiles_i - 1); const dim3 egrid(A.edge_blocks > 0 ? grid_for(A.edge_blocks, &A.edge_per_xcd) : 1); \
       if (remote) PAIR_LAUNCH_REMOTE(VAR, SM) \
