@@ -89,6 +89,15 @@ __global__ __launch_bounds__(64) void extrapolate_betas_kernel(const hpgmg_hip_l
   }
 }
 
+// The two children (2 ci, 2 ci + 1) of a coarse cell as ONE 16-byte store to device memory.  (Written as `*(double2 *)fw = ...` next to the scalar form of the other
+// branch, the compiler merged the two branches into two 8-byte stores per lane: every fine line was written in two half-filled passes -- the interpolations ran at
+// half the device's write rate.  A vector store through a pointer typed as device memory is not something it takes apart.)
+typedef double __attribute__((ext_vector_type(2))) pair_v;
+__device__ __forceinline__ void store_pair(double *p, double a, double b) {
+  pair_v w; w.x = a; w.y = b;
+  *(pair_v __attribute__((address_space(1))) *)as_global(p) = w;
+}
+
 // Tensor-product interpolations (interpolation_p2.c, _v2.c, _v4.c): the 1-D rule is applied along i, then j, then k.
 // One lane per COARSE column, marching in k over a chunk of the entry (a wave per coarse row and chunk; grid.y strides over them):
 // the i- and j-passes of one coarse plane depend only on that plane -- their four results (child i parity x child j parity) are
@@ -103,12 +112,15 @@ __global__ __launch_bounds__(256) void interp_tensor_kernel(const hpgmg_hip_leve
   const blockCopy_type &e = list[blockIdx.x];
   const Side r = resolve_read(Lc, id_c, e), w = resolve_write(Lf, id_f, e);
   const int ci_n = e.dim.i, cj_n = e.dim.j, ck_n = e.dim.k, rj = r.jS, rk = r.kS;
-  const int nkc = (ck_n + KC - 1) / KC, units = cj_n * nkc;
+  // a coarse row shorter than a wave (boxes of 32^3 and smaller below the fine level): the wave takes 64 / wci rows of the tile at once, wci lanes each
+  const int wci = (ci_n > 32) ? 64 : (ci_n > 16 ? 32 : (ci_n > 8 ? 16 : 8)), rpw = 64 / wci, cjg = (cj_n + rpw - 1) / rpw;
+  const int nkc = (ck_n + KC - 1) / KC, units = cjg * nkc;
   const bool pairs = (e.write.box >= 0) && (Lf.flags & 1);
-  const int lane = threadIdx.x % 64;
+  const int lane = threadIdx.x % 64, lane_i = lane % wci, lane_row = lane / wci;
   for (int u = blockIdx.y * 4 + threadIdx.x / 64; u < units; u += gridDim.y * 4) {
-    const int kc = u / cj_n, cj = u - kc * cj_n, k0 = kc * KC, k1 = (k0 + KC < ck_n) ? k0 + KC : ck_n;
-    for (int ci = lane; ci < ci_n; ci += 64) {
+    const int kc = u / cjg, cj = (u - kc * cjg) * rpw + lane_row, k0 = kc * KC, k1 = (k0 + KC < ck_n) ? k0 + KC : ck_n;
+    if (cj >= cj_n) continue;
+    for (int ci = lane_i; ci < ci_n; ci += wci) {
       const double *c = r.p + ci + cj * rj;
       double tk[2][2][W];                                       // [child i parity][child j parity][coarse plane ck-R .. ck+R]
       auto plane = [&](int ck, int slot) {                      // i-pass and j-pass of coarse plane ck
@@ -152,7 +164,7 @@ __global__ __launch_bounds__(256) void interp_tensor_kernel(const hpgmg_hip_leve
             if (prescale != 0.0) load_fine();
             double v0 = prescale * f0 + a0, v1 = prescale * f1 + a1;
             if (!ZEROED && prescale == 0.0 && (v0 == 0.0 || v1 == 0.0)) { load_fine(); v0 = prescale * f0 + a0; v1 = prescale * f1 + a1; }
-            if (pairs) *reinterpret_cast<double2 *>(fw) = make_double2(v0, v1);
+            if (pairs) store_pair(fw, v0, v1);
             else { fw[0] = v0; fw[1] = v1; }
           }
         }
@@ -265,7 +277,7 @@ __global__ __launch_bounds__(256) void interp_blocks_kernel(const hpgmg_hip_leve
           if (prescale != 0.0) load_fine(f0, f1);
           blend(f0, f1);
           if (!ZEROED && prescale == 0.0 && (v[0] == 0.0 || v[1] == 0.0)) { load_fine(f0, f1); blend(f0, f1); }
-          if (pairs) *reinterpret_cast<double2 *>(fw) = make_double2(v[0], v[1]);
+          if (pairs) store_pair(fw, v[0], v[1]);
           else { fw[0] = v[0]; fw[1] = v[1]; }
         }
       }
