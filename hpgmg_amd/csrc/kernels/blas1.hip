@@ -176,6 +176,14 @@ __global__ __launch_bounds__(256) void final_max_kernel(const double *partials, 
 // norm(F) ; scale_vector(R, 1.0, F) ; restriction(coarse R <- R, RESTRICT_CELL) -- the first three operators of FMGSolve (mg.c:1262-1270)
 // -- as one pass over F: a wave owns one COARSE row of a box (its four fine rows, a lane the 2 x 2 x 2 children of a coarse cell,
 // 16-byte accesses), stores R = 1.0 * F, forms the restricted value in the reference's order (restriction.c:54-57) and the maximum of |F|.
+// NT: R is written past the caches (a level larger than the infinity cache: the first reader of R comes a whole cycle later)
+typedef double __attribute__((ext_vector_type(2))) pair_v;
+template <bool NT> __device__ __forceinline__ void store_pair(double *p, double2 v) {
+  pair_v w; w.x = v.x; w.y = v.y;
+  if (NT) __builtin_nontemporal_store(w, (pair_v __attribute__((address_space(1))) *)as_global(p));
+  else *(pair_v __attribute__((address_space(1))) *)as_global(p) = w;
+}
+template <bool NT>
 __global__ __launch_bounds__(256) void norm_copy_restrict_kernel(const hpgmg_hip_level L, int f_id, int r_id, const hpgmg_hip_level Lc, int rc_id,
                                                                  const int *__restrict__ map, double *partials) {
   const int half = L.dim >> 1, rows_per_box = half * half, lane = threadIdx.x % 64;
@@ -193,8 +201,8 @@ __global__ __launch_bounds__(256) void norm_copy_restrict_kernel(const hpgmg_hip
       const double2 cc = *reinterpret_cast<const double2 *>(f + 2 * ci + kS), d = *reinterpret_cast<const double2 *>(f + 2 * ci + jS + kS);
       const double2 ra = make_double2(1.0 * a.x, 1.0 * a.y), rb = make_double2(1.0 * b.x, 1.0 * b.y);
       const double2 rc = make_double2(1.0 * cc.x, 1.0 * cc.y), rd = make_double2(1.0 * d.x, 1.0 * d.y);
-      *reinterpret_cast<double2 *>(r + 2 * ci) = ra; *reinterpret_cast<double2 *>(r + 2 * ci + jS) = rb;
-      *reinterpret_cast<double2 *>(r + 2 * ci + kS) = rc; *reinterpret_cast<double2 *>(r + 2 * ci + jS + kS) = rd;
+      store_pair<NT>(r + 2 * ci, ra); store_pair<NT>(r + 2 * ci + jS, rb);
+      store_pair<NT>(r + 2 * ci + kS, rc); store_pair<NT>(r + 2 * ci + jS + kS, rd);
       double v = ra.x + ra.y; v = v + rb.x; v = v + rb.y; v = v + rc.x; v = v + rc.y; v = v + rd.x; v = v + rd.y;
       c[ci] = v * 0.125;
       double q;
@@ -496,7 +504,10 @@ static int norm_copy_restrict(const hpgmg_hip_level *L, int f_id, int r_id, cons
     return record_error(hipErrorInvalidValue, "norm_copy_restrict: level not supported");
   const int nblk = rows_grid(L->num_boxes * (L->dim / 2) * (L->dim / 2));
   if (int e = ensure_scratch(nblk)) return e;
-  hipLaunchKernelGGL(norm_copy_restrict_kernel, dim3(nblk), dim3(256), 0, g_stream, *L, f_id, r_id, *Lc, rc_id, map, g_scratch);
+  static const bool nt_allowed = [] { const char *e = getenv("HPGMG_TUNE_COPY_NT"); return !(e && *e == '0'); }();
+  if (nt_allowed && (double)L->num_boxes * L->dim * L->dim * L->dim * sizeof(double) > 256e6)
+    hipLaunchKernelGGL(norm_copy_restrict_kernel<true>, dim3(nblk), dim3(256), 0, g_stream, *L, f_id, r_id, *Lc, rc_id, map, g_scratch);
+  else hipLaunchKernelGGL(norm_copy_restrict_kernel<false>, dim3(nblk), dim3(256), 0, g_stream, *L, f_id, r_id, *Lc, rc_id, map, g_scratch);
   if (!norm_out) { HPGMG_LAUNCH_CHECK("norm_copy_restrict (copy + restriction only)"); return 0; }     // the norm is not wanted: nothing to reduce, nothing to wait for
   if (deferred) {
     hipLaunchKernelGGL(final_max_kernel, dim3(1), dim3(256), 0, g_stream, (const double *)g_scratch, nblk, 0.0, g_result_dev + 2, ++g_seq_deferred);

@@ -93,9 +93,11 @@ __global__ __launch_bounds__(64) void extrapolate_betas_kernel(const hpgmg_hip_l
 // branch, the compiler merged the two branches into two 8-byte stores per lane: every fine line was written in two half-filled passes -- the interpolations ran at
 // half the device's write rate.  A vector store through a pointer typed as device memory is not something it takes apart.)
 typedef double __attribute__((ext_vector_type(2))) pair_v;
+template <bool NT>      // NT: non-temporal -- for a vector written once that is larger than the infinity cache (512^3 onto zeros: 478 -> 378 us; read back soon or smaller: slower)
 __device__ __forceinline__ void store_pair(double *p, double a, double b) {
   pair_v w; w.x = a; w.y = b;
-  *(pair_v __attribute__((address_space(1))) *)as_global(p) = w;
+  if (NT) __builtin_nontemporal_store(w, (pair_v __attribute__((address_space(1))) *)as_global(p));
+  else *(pair_v __attribute__((address_space(1))) *)as_global(p) = w;
 }
 
 // Tensor-product interpolations (interpolation_p2.c, _v2.c, _v4.c): the 1-D rule is applied along i, then j, then k.
@@ -105,7 +107,7 @@ __device__ __forceinline__ void store_pair(double *p, double a, double b) {
 // cell's 8 children.  (2R+1)^2 loads per coarse cell instead of (2R+1)^3 (the first version was bound by the L1 at 125 loads per
 // cell); each child is the same expression tree rule_k(rule_j(rule_i(coarse))) as in the reference.  Children are written as
 // 16-byte pairs when the layout allows.
-template <int ORDER, bool ZEROED = false>      // ZEROED: as in interp_blocks_kernel -- the fine vector counts as +0.0 (prescale == 0), never read
+template <int ORDER, bool ZEROED = false, bool NT = false>      // ZEROED: as in interp_blocks_kernel -- the fine vector counts as +0.0 (prescale == 0), never read; NT: store_pair
 __global__ __launch_bounds__(256) void interp_tensor_kernel(const hpgmg_hip_level Lf, int id_f, double prescale, const hpgmg_hip_level Lc, int id_c,
                                                             const blockCopy_type *__restrict__ list) {
   constexpr int R = (ORDER == 4) ? 2 : 1, W = 2 * R + 1, KC = 8;
@@ -164,7 +166,7 @@ __global__ __launch_bounds__(256) void interp_tensor_kernel(const hpgmg_hip_leve
             if (prescale != 0.0) load_fine();
             double v0 = prescale * f0 + a0, v1 = prescale * f1 + a1;
             if (!ZEROED && prescale == 0.0 && (v0 == 0.0 || v1 == 0.0)) { load_fine(); v0 = prescale * f0 + a0; v1 = prescale * f1 + a1; }
-            if (pairs) store_pair(fw, v0, v1);
+            if (pairs) store_pair<NT>(fw, v0, v1);
             else { fw[0] = v0; fw[1] = v1; }
           }
         }
@@ -220,7 +222,7 @@ __global__ __launch_bounds__(256) void restrict_cell_zero_kernel(const hpgmg_hip
 // The per-child expression (prescale*fine + weighted coarse neighbours, in the reference's order) is unchanged.
 // ZEROED (with prescale == 0): the fine vector counts as holding +0.0 everywhere -- zero_vector() followed by interpolation_fcycle() with the fine
 // vector neither zeroed nor read (0.0 * 0.0 + y).
-template <int ORDER, bool ZEROED = false>
+template <int ORDER, bool ZEROED = false, bool NT = false>
 __global__ __launch_bounds__(256) void interp_blocks_kernel(const hpgmg_hip_level Lf, int id_f, double prescale, const hpgmg_hip_level Lc, int id_c,
                                                             const blockCopy_type *__restrict__ list) {
   const blockCopy_type &e = list[blockIdx.x];
@@ -277,7 +279,7 @@ __global__ __launch_bounds__(256) void interp_blocks_kernel(const hpgmg_hip_leve
           if (prescale != 0.0) load_fine(f0, f1);
           blend(f0, f1);
           if (!ZEROED && prescale == 0.0 && (v[0] == 0.0 || v[1] == 0.0)) { load_fine(f0, f1); blend(f0, f1); }
-          if (pairs) store_pair(fw, v[0], v[1]);
+          if (pairs) store_pair<NT>(fw, v[0], v[1]);
           else { fw[0] = v[0]; fw[1] = v[1]; }
         }
       }
@@ -409,10 +411,16 @@ int hpgmg_hip_interpolate_blocks(const hpgmg_hip_level *Lf, int id_f, double pre
   else if (order == 1) hipLaunchKernelGGL((interp_blocks_kernel<1>), dim3(n, slabs), dim3(256), 0, g_stream, *Lf, id_f, prescale, *Lc, id_c, blocks);
   else if (order >= 17 && order <= 20) {      // order - 16 onto a fine vector that counts as zeroed (zero_vector + interpolation_fcycle, the fine level touched once)
     if (prescale != 0.0) return record_error(hipErrorInvalidValue, "interpolation onto a zeroed vector: prescale 0");
-    if (order == 17)      hipLaunchKernelGGL((interp_blocks_kernel<1, true>), dim3(n, slabs), dim3(256), 0, g_stream, *Lf, id_f, prescale, *Lc, id_c, blocks);
-    else if (order == 18) hipLaunchKernelGGL((interp_tensor_kernel<2, true>), dim3(n, slabs), dim3(256), 0, g_stream, *Lf, id_f, prescale, *Lc, id_c, blocks);
-    else if (order == 19) hipLaunchKernelGGL((interp_tensor_kernel<3, true>), dim3(n, slabs), dim3(256), 0, g_stream, *Lf, id_f, prescale, *Lc, id_c, blocks);
-    else                  hipLaunchKernelGGL((interp_tensor_kernel<4, true>), dim3(n, slabs), dim3(256), 0, g_stream, *Lf, id_f, prescale, *Lc, id_c, blocks);
+    // a fine vector beyond the infinity cache (256 MB) is written past the caches: nothing of it would still be there when the next kernel reads it
+    static const bool nt_allowed = [] { const char *e = getenv("HPGMG_TUNE_INTERP_NT"); return !(e && *e == '0'); }();
+    const bool nt = nt_allowed && (double)Lf->num_boxes * Lf->dim * Lf->dim * Lf->dim * sizeof(double) > 256e6;
+#define INTERP_ZEROED(KERNEL, ORD) do { if (nt) hipLaunchKernelGGL((KERNEL<ORD, true, true>), dim3(n, slabs), dim3(256), 0, g_stream, *Lf, id_f, prescale, *Lc, id_c, blocks); \
+                                        else hipLaunchKernelGGL((KERNEL<ORD, true, false>), dim3(n, slabs), dim3(256), 0, g_stream, *Lf, id_f, prescale, *Lc, id_c, blocks); } while (0)
+    if (order == 17)      INTERP_ZEROED(interp_blocks_kernel, 1);
+    else if (order == 18) INTERP_ZEROED(interp_tensor_kernel, 2);
+    else if (order == 19) INTERP_ZEROED(interp_tensor_kernel, 3);
+    else                  INTERP_ZEROED(interp_tensor_kernel, 4);
+#undef INTERP_ZEROED
   }
   else if (order == 2) hipLaunchKernelGGL((interp_tensor_kernel<2>), dim3(n, slabs), dim3(256), 0, g_stream, *Lf, id_f, prescale, *Lc, id_c, blocks);
   else if (order == 3) hipLaunchKernelGGL((interp_tensor_kernel<3>), dim3(n, slabs), dim3(256), 0, g_stream, *Lf, id_f, prescale, *Lc, id_c, blocks);
