@@ -695,7 +695,7 @@ static int launch_fv4_tile_tj(const hpgmg_hip_level *L, int variant, const Stenc
   P.tiles_i = L->dim / TI; P.tiles_j = L->dim / TJ;
   int kchunk = L->dim;                                   // enough workgroups to fill the chip, as few chunk prologues as possible
   const int want = (TJ * TI >= 1024) ? 512 : 1024;
-  static const int kc_min = env_int("HPGMG_TUNE_FV4_KCHUNK_MIN", 2);
+  static const int kc_min = env_int("HPGMG_TUNE_FV4_KCHUNK_MIN", 8);      // (a chunk costs four extra planes of loads: chunks of 4 planes -- what filling 1024 slots asked for on the 128^3 level of 7 64 -- fetch every plane twice; 8: 29 vs 34 us per half sweep there, tools/ab_fv4_kcmin.sh)
   while (kchunk > kc_min && (long long)L->num_boxes * P.tiles_i * P.tiles_j * (L->dim / kchunk) < want) kchunk /= 2;
   static const int tune_kc = env_int("HPGMG_TUNE_FV4_KCHUNK", 0);
   if (tune_kc > 0 && L->dim % tune_kc == 0) kchunk = tune_kc;
