@@ -26,7 +26,9 @@ namespace hpgmg {
 
 constexpr int kTailMaxLevels = 8;
 constexpr int kTailMaxSweeps = 8;
-constexpr int kTailThreads = 1024;
+constexpr int kTailThreads = 1024;                  // lanes of a workgroup that owns up to 4 cells per lane (a chain that starts at 16^3)
+constexpr int kTailThreadsSmall = 512;              // ... of one whose levels have at most 512 cells (from 8^3 down): one cell per lane, half the waves at every barrier
+template <int CPL> constexpr int tail_threads() { return CPL == 1 ? kTailThreadsSmall : kTailThreads; }
 
 struct TailLevel {
   hpgmg_hip_level L;
@@ -47,6 +49,16 @@ struct TailArgs {
 enum { FT_DOWN = 0, FT_UP = 1, FT_BOTTOM = 2, FT_RESTRICT_RHS = 3, FT_ZERO_BOTTOM = 4, FT_INTERP_F = 5 };
 
 enum { SM_CHEBY = 0, SM_GSRB = 1, SM_JACOBI = 2, SM_RESIDUAL = 3 };
+
+// The box-base tables of the chain's levels wait in LDS (CPL == 1 kernels; copied once at the start of the launch): `box_base[box]` read from memory is a
+// round trip of its own in FRONT of every load and store of a visit.
+constexpr int kTailTabBoxes = 64;                   // boxes per level the tables hold (levels of <= 512 cells; more: the 1024-lane kernels, tables in memory)
+template <int CPL>
+__device__ __forceinline__ hpgmg_hip_level tail_lvl(const TailArgs &A, int l, double *const *tab) {
+  hpgmg_hip_level L = A.lv[l].L;
+  if (CPL == 1) L.box_base = tab + l * kTailTabBoxes;
+  return L;
+}
 
 // The level being worked on lives in LDS as two dense D^3 arrays in GLOBAL cell order (box boundaries
 // disappear; a Dirichlet face is the in-register rule ghost = -centre, exactly what apply_BCs_p1 stores):
@@ -73,53 +85,87 @@ __device__ __forceinline__ double tail_apply(const double *src, int c, int gi, i
   return apply_op_7pt<V>(xc, xim, xip, xjm, xjp, xkm, xkp, q.bi0, q.bi1, q.bj0, q.bj1, q.bk0, q.bk1, q.al, a, b, h2inv);
 }
 
-// one visit of a level: load -> (interpolate) -> smooth -> (residual, restrict, zero) -> store
-template <int V, int SM>
-__device__ void tail_level(const TailArgs &A, int l, int leg, double *sx, double *st) {
+#ifdef HPGMG_EXP_TIMELINE      /* experiment builds: lane 0 records the 100 MHz clock at the ends of the routines and at the stages of a visit (tools/exp_tail_timeline.py) */
+__device__ unsigned long long *g_tail_tl = nullptr;
+__device__ int g_tail_tl_n = 0;
+#define TAIL_MARK() do { if (threadIdx.x == 0 && g_tail_tl && g_tail_tl_n < 60) g_tail_tl[g_tail_tl_n++] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define TAIL_MARK() do { } while (0)
+#endif
+// What a visit hands to the NEXT one without a round trip through memory (CPL == 1: chains from 8^3 down, the ones the cycle runs since the 16^3 level went to
+// the brick launches): the restricted residual goes to the next visit through LDS (sr, dense order) as well as to memory, and the correction of the coarser
+// level (or of the bottom solve) is read from sx, where the visit that formed it left it -- the values the per-operator sequence would have read from memory.
+// (Also tried: the next visit's coefficients, VECTOR_TEMP and stored e fetched AHEAD during the current visit -- three tails of config 1 74.6 us instead of
+// 66.2, the F-cycle tail 58.9 instead of 53.2: the address arithmetic and a dozen loads more per visit on the one wave that is the critical path.)
+struct TailCarry {
+  int rhs_level;             // sr holds R of this level, dense order; -1: no
+  int e_level;               // sx holds e of this level, dense order; -1: no
+};
+template <int V>
+__device__ __forceinline__ void tail_fetch_cell(const TailArgs &A, const hpgmg_hip_level &L, const LevelGeom &G, int c, bool want_e, bool want_rhs,
+                                                CellCoef<V> &q, double &temp, double &e, CellRef &where, int &gi, int &gj, int &gk) {
   constexpr bool kVC = (V != HPGMG_HIP_7PT_CC);
   constexpr bool kHelm = (V == HPGMG_HIP_7PT_VC_HELMHOLTZ);
+  { const int cj = c / G.D; gi = c % G.D; gj = cj % G.D; gk = cj / G.D; }
+  where = locate(G, gi, gj, gk);
+  const int box = where.box, ijk = where.ijk, jS = L.jStride, kS = L.kStride;
+  e = want_e ? gvec_origin(L, box, A.e_id)[ijk] : 0.0;
+  temp = gvec_origin(L, box, VECTOR_TEMP)[ijk];
+  q.rhs = want_rhs ? gvec_origin(L, box, A.R_id)[ijk] : 0.0;
+  q.dinv = gvec_origin(L, box, VECTOR_DINV)[ijk];
+  q.bi0 = q.bi1 = q.bj0 = q.bj1 = q.bk0 = q.bk1 = q.al = 0.0;
+  if (kVC) {
+    const gcptr bi = gvec_origin(L, box, VECTOR_BETA_I), bj = gvec_origin(L, box, VECTOR_BETA_J), bk = gvec_origin(L, box, VECTOR_BETA_K);
+    q.bi0 = bi[ijk]; q.bi1 = bi[ijk + 1]; q.bj0 = bj[ijk]; q.bj1 = bj[ijk + jS]; q.bk0 = bk[ijk]; q.bk1 = bk[ijk + kS];
+  }
+  if (kHelm) q.al = gvec_origin(L, box, VECTOR_ALPHA)[ijk];
+}
+// one visit of a level: load -> (interpolate) -> smooth -> (residual, restrict, zero) -> store
+template <int V, int SM, int CPL>
+__device__ void tail_level(const TailArgs &A, double *const *tab, int l, int leg, double *sx, double *st, double *sr, TailCarry &carry) {
+  constexpr int NT = tail_threads<CPL>();
   const TailLevel &T = A.lv[l];
-  const hpgmg_hip_level &L = T.L;
+  const hpgmg_hip_level L = tail_lvl<CPL>(A, l, tab);
   const int D = L.dim_i, total = D * D * D;
   const LevelGeom G = geom_of(L);
-  CellCoef<V> q[kCellsPerLane];
-  int gi[kCellsPerLane], gj[kCellsPerLane], gk[kCellsPerLane];
-  CellRef where[kCellsPerLane];
+  CellCoef<V> q[CPL];
+  int gi[CPL], gj[CPL], gk[CPL];
+  CellRef where[CPL];
+  double e0[CPL], t0[CPL];
+  const bool rhs_here = (CPL == 1) && leg == 0 && carry.rhs_level == l;            // R waits in sr, e is the +0.0 the previous visit stored
+  const bool parent_here = (CPL == 1) && leg == 1 && carry.e_level == l + 1;       // the coarser level's correction waits in sx
 
 #pragma unroll
-  for (int m = 0; m < kCellsPerLane; m++) {
-    const int c = threadIdx.x + m * kTailThreads;
+  for (int m = 0; m < CPL; m++) {
+    const int c = threadIdx.x + m * NT;
     if (c < total) {
-      { const int cj = c / G.D; gi[m] = c % G.D; gj[m] = cj % G.D; gk[m] = cj / G.D; }
-      where[m] = locate(G, gi[m], gj[m], gk[m]);
-      const int box = where[m].box, ijk = where[m].ijk, jS = L.jStride, kS = L.kStride;
-      double e = vec_origin(L, box, A.e_id)[ijk];
+      tail_fetch_cell<V>(A, L, G, c, !rhs_here, !rhs_here, q[m], t0[m], e0[m], where[m], gi[m], gj[m], gk[m]);
+      if (rhs_here) q[m].rhs = sr[c];
       if (leg == 1) {          // interpolation_vcycle: e = 1.0*e + (coarse parent), interpolation_p0.c:43
-        const hpgmg_hip_level &C = A.lv[l + 1].L;
-        const CellRef p = locate(geom_of(C), gi[m] >> 1, gj[m] >> 1, gk[m] >> 1);
-        e = 1.0 * e + vec_origin(C, p.box, A.e_id)[p.ijk];
+        const hpgmg_hip_level C = tail_lvl<CPL>(A, l + 1, tab);
+        double parent;
+        if (parent_here) { const int Dc = C.dim_i; parent = sx[(gi[m] >> 1) + Dc * ((gj[m] >> 1) + Dc * (gk[m] >> 1))]; }
+        else { const CellRef p = locate(geom_of(C), gi[m] >> 1, gj[m] >> 1, gk[m] >> 1); parent = gvec_origin(C, p.box, A.e_id)[p.ijk]; }
+        e0[m] = 1.0 * e0[m] + parent;
       }
-      sx[c] = e;
-      st[c] = vec_origin(L, box, VECTOR_TEMP)[ijk];
-      q[m].rhs = vec_origin(L, box, A.R_id)[ijk];
-      q[m].dinv = vec_origin(L, box, VECTOR_DINV)[ijk];
-      q[m].bi0 = q[m].bi1 = q[m].bj0 = q[m].bj1 = q[m].bk0 = q[m].bk1 = q[m].al = 0.0;
-      if (kVC) {
-        const double *bi = vec_origin(L, box, VECTOR_BETA_I), *bj = vec_origin(L, box, VECTOR_BETA_J), *bk = vec_origin(L, box, VECTOR_BETA_K);
-        q[m].bi0 = bi[ijk]; q[m].bi1 = bi[ijk + 1]; q[m].bj0 = bj[ijk]; q[m].bj1 = bj[ijk + jS]; q[m].bk0 = bk[ijk]; q[m].bk1 = bk[ijk + kS];
-      }
-      if (kHelm) q[m].al = vec_origin(L, box, VECTOR_ALPHA)[ijk];
     }
   }
+  if (parent_here) __syncthreads();                   // every parent has been read: sx may take this level's iterate
+#pragma unroll
+  for (int m = 0; m < CPL; m++) {
+    const int c = threadIdx.x + m * NT;
+    if (c < total) { sx[c] = e0[m]; st[c] = t0[m]; }
+  }
   __syncthreads();
+  TAIL_MARK();
 
   // smooth(): chebyshev.c:43-99 / gsrb.c:24-132 / jacobi.c:17-62 (even number of sweeps: the result ends in sx)
   for (int s = 0; s < A.sweeps; s++) {
     const double *src = (SM != SM_GSRB && (s & 1)) ? st : sx;
     double *dst = (SM == SM_GSRB) ? sx : ((s & 1) ? sx : st);
 #pragma unroll
-    for (int m = 0; m < kCellsPerLane; m++) {
-      const int c = threadIdx.x + m * kTailThreads;
+    for (int m = 0; m < CPL; m++) {
+      const int c = threadIdx.x + m * NT;
       if (c < total) {
         if (SM == SM_GSRB) {
           const int colour = (gi[m] ^ gj[m] ^ gk[m] ^ s) & 1;   // global parity: box.low folded in (gsrb.c:55)
@@ -135,10 +181,11 @@ __device__ void tail_level(const TailArgs &A, int l, int leg, double *sx, double
     __syncthreads();
   }
 
+  TAIL_MARK();
   if (leg == 0) {                                     // residual -> TEMP (residual.c:42-48)
 #pragma unroll
-    for (int m = 0; m < kCellsPerLane; m++) {
-      const int c = threadIdx.x + m * kTailThreads;
+    for (int m = 0; m < CPL; m++) {
+      const int c = threadIdx.x + m * NT;
       if (c < total) {
         const double Ax = tail_apply<V>(sx, c, gi[m], gj[m], gk[m], D, q[m], A.a, A.b, T.h2inv);
         st[c] = q[m].rhs - Ax;                        // each lane overwrites only its own TEMP cells: no hazard with the reads of sx
@@ -147,33 +194,37 @@ __device__ void tail_level(const TailArgs &A, int l, int leg, double *sx, double
     __syncthreads();
   }
 
+  TAIL_MARK();
   // leave e and TEMP in global memory as the per-operator sequence would
 #pragma unroll
-  for (int m = 0; m < kCellsPerLane; m++) {
-    const int c = threadIdx.x + m * kTailThreads;
+  for (int m = 0; m < CPL; m++) {
+    const int c = threadIdx.x + m * NT;
     if (c < total) {
-      vec_origin(L, where[m].box, A.e_id)[where[m].ijk] = sx[c];
-      vec_origin(L, where[m].box, VECTOR_TEMP)[where[m].ijk] = st[c];
+      gvec_origin(L, where[m].box, A.e_id)[where[m].ijk] = sx[c];
+      gvec_origin(L, where[m].box, VECTOR_TEMP)[where[m].ijk] = st[c];
     }
   }
+  carry.e_level = l; carry.rhs_level = -1;
 
   if (leg == 0) {
     // restriction(next.R <- TEMP): 0.125 * sum of the 8 children in the reference's order (restriction.c:54-57)
-    const hpgmg_hip_level &C = A.lv[l + 1].L;
+    const hpgmg_hip_level C = tail_lvl<CPL>(A, l + 1, tab);
     const LevelGeom GC = geom_of(C);
     const int Dc = D / 2, totc = Dc * Dc * Dc;
-    for (int c = threadIdx.x; c < totc; c += kTailThreads) {
+    for (int c = threadIdx.x; c < totc; c += NT) {
       const int cjk = c / GC.D, ci = c % GC.D, cj = cjk % GC.D, ck = cjk / GC.D;
       const double *f = st + 2 * ci + 2 * cj * D + 2 * ck * D * D;
       double v = f[0] + f[1]; v = v + f[D]; v = v + f[1 + D]; v = v + f[D * D]; v = v + f[1 + D * D]; v = v + f[D + D * D]; v = v + f[1 + D + D * D];
       const CellRef p = locate(GC, ci, cj, ck);
-      vec_origin(C, p.box, A.R_id)[p.ijk] = v * 0.125;
+      gvec_origin(C, p.box, A.R_id)[p.ijk] = v * 0.125;
+      if (CPL == 1 && totc <= NT) sr[c] = v * 0.125;
     }
+    if (CPL == 1 && totc <= NT) carry.rhs_level = l + 1;
     // zero_vector(next.e): the whole padded box, ghosts included (misc.c:6-44); the alignment padding between
     // rows is never read and was zero-filled at allocation, so the box's slab is cleared as one contiguous run
     for (int box = 0; box < C.num_boxes; box++) {
-      double *z = C.box_base[box] + (size_t)A.e_id * (size_t)C.volume;
-      for (int c = threadIdx.x; c < C.volume; c += kTailThreads) z[c] = 0.0;
+      const gptr z = as_global(C.box_base[box]) + (size_t)A.e_id * (size_t)C.volume;
+      for (int c = threadIdx.x; c < C.volume; c += NT) z[c] = 0.0;
     }
   }
   __syncthreads();                                    // global writes of this level are visible to the next level's loads
@@ -186,9 +237,10 @@ __device__ void tail_level(const TailArgs &A, int l, int leg, double *sx, double
 // driver (host/solvers.c), and the sums keep the reference's order -- one partial per dim x 8 x 8
 // tile accumulated k,j,i, partials added in tile order (misc.c:261-269) -- so the iterates, the
 // iteration count and the coarse correction are bit-identical to the host-driven solve.
-constexpr int kBottomMaxCells = kTailThreads;
+constexpr int kBottomMaxCells = kTailThreads;      // (NT below: the lanes of the workgroup = the most cells a bottom level may have in it)
 struct BottomGeom { int D, total, c, gi, gj, gk, bd, nb, tiles_side, tiles_per_box, ntiles; bool active; };
 
+template <int NT>
 __device__ double bottom_dot(const BottomGeom &g, double va, double vb, double *scr) {
   if (g.active) scr[g.c] = va * vb;
   __syncthreads();
@@ -203,22 +255,23 @@ __device__ double bottom_dot(const BottomGeom &g, double va, double vb, double *
       const double *row = scr + oi + g.D * ((oj + j) + g.D * (ok + k));
       for (int i = 0; i < g.bd; i++) acc += row[i];
     }
-    scr[kBottomMaxCells + t] = acc;
+    scr[NT + t] = acc;
   }
   __syncthreads();
-  if (t == 0) { double sum = 0.0; for (int q = 0; q < g.ntiles; q++) sum += scr[kBottomMaxCells + q]; scr[2 * kBottomMaxCells] = sum; }
+  if (t == 0) { double sum = 0.0; for (int q = 0; q < g.ntiles; q++) sum += scr[NT + q]; scr[2 * NT] = sum; }
   __syncthreads();
-  return scr[2 * kBottomMaxCells];
+  return scr[2 * NT];
 }
+template <int NT>
 __device__ double bottom_norm(const BottomGeom &g, double v, double *scr) {          // max |v| (misc.c:303-349)
   double m = 0.0;
   if (g.active) { const double f = fabs(v); m = (f > m) ? f : m; }
   for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_down(m, off, 64); m = (o > m) ? o : m; }
-  double *w = scr + 2 * kBottomMaxCells + 8;
+  double *w = scr + 2 * NT + 8;
   if (threadIdx.x % 64 == 0) w[threadIdx.x / 64] = m;
   __syncthreads();
   m = w[0];
-  for (int q = 1; q < kTailThreads / 64; q++) m = (w[q] > m) ? w[q] : m;
+  for (int q = 1; q < NT / 64; q++) m = (w[q] > m) ? w[q] : m;
   __syncthreads();
   return m;
 }
@@ -232,12 +285,12 @@ __device__ double bottom_apply(const BottomGeom &g, double v, const CellCoef<V> 
   return Ax;
 }
 
-template <int V>
-__device__ void tail_bottom(const TailArgs &A, double *sx, double *scr) {
+template <int V, int CPL>
+__device__ void tail_bottom(const TailArgs &A, double *const *tab, double *sx, double *scr, TailCarry &carry) {
   constexpr bool kVC = (V != HPGMG_HIP_7PT_CC);
   constexpr bool kHelm = (V == HPGMG_HIP_7PT_VC_HELMHOLTZ);
   const TailLevel &T = A.lv[A.n - 1];
-  const hpgmg_hip_level &L = T.L;
+  const hpgmg_hip_level L = tail_lvl<CPL>(A, A.n - 1, tab);
   BottomGeom g;
   g.D = L.dim_i; g.total = g.D * g.D * g.D; g.c = threadIdx.x; g.active = g.c < g.total;
   const LevelGeom G = geom_of(L);
@@ -254,18 +307,18 @@ __device__ void tail_bottom(const TailArgs &A, double *sx, double *scr) {
   if (g.active) {
     at = locate(G, g.gi, g.gj, g.gk);
     const int box = at.box, ijk = at.ijk, jS = L.jStride, kS = L.kStride;
-    x = vec_origin(L, box, A.e_id)[ijk];
-    cf.rhs = vec_origin(L, box, A.R_id)[ijk];
-    cf.dinv = vec_origin(L, box, VECTOR_DINV)[ijk];
+    x = gvec_origin(L, box, A.e_id)[ijk];
+    cf.rhs = gvec_origin(L, box, A.R_id)[ijk];
+    cf.dinv = gvec_origin(L, box, VECTOR_DINV)[ijk];
     if (kVC) {
-      const double *bi = vec_origin(L, box, VECTOR_BETA_I), *bj = vec_origin(L, box, VECTOR_BETA_J), *bk = vec_origin(L, box, VECTOR_BETA_K);
+      const gcptr bi = gvec_origin(L, box, VECTOR_BETA_I), bj = gvec_origin(L, box, VECTOR_BETA_J), bk = gvec_origin(L, box, VECTOR_BETA_K);
       cf.bi0 = bi[ijk]; cf.bi1 = bi[ijk + 1]; cf.bj0 = bj[ijk]; cf.bj1 = bj[ijk + jS]; cf.bk0 = bk[ijk]; cf.bk1 = bk[ijk + kS];
     }
-    if (kHelm) cf.al = vec_origin(L, box, VECTOR_ALPHA)[ijk];
+    if (kHelm) cf.al = gvec_origin(L, box, VECTOR_ALPHA)[ijk];
     // work vectors keep whatever an early exit leaves untouched
-    r0 = vec_origin(L, box, r0_id)[ijk]; r = vec_origin(L, box, r_id)[ijk]; p = vec_origin(L, box, p_id)[ijk]; q = vec_origin(L, box, q_id)[ijk];
-    sv = vec_origin(L, box, s_id)[ijk]; tv = vec_origin(L, box, t_id)[ijk]; Ap = vec_origin(L, box, Ap_id)[ijk]; As = vec_origin(L, box, As_id)[ijk];
-    tmp = vec_origin(L, box, VECTOR_TEMP)[ijk];
+    r0 = gvec_origin(L, box, r0_id)[ijk]; r = gvec_origin(L, box, r_id)[ijk]; p = gvec_origin(L, box, p_id)[ijk]; q = gvec_origin(L, box, q_id)[ijk];
+    sv = gvec_origin(L, box, s_id)[ijk]; tv = gvec_origin(L, box, t_id)[ijk]; Ap = gvec_origin(L, box, Ap_id)[ijk]; As = gvec_origin(L, box, As_id)[ijk];
+    tmp = gvec_origin(L, box, VECTOR_TEMP)[ijk];
   }
   const double a = A.a, b = A.b, h2inv = T.h2inv, want = A.bottom_norm;
   int it = 0;
@@ -326,36 +379,39 @@ __device__ void tail_bottom(const TailArgs &A, double *sx, double *scr) {
     }
   } else {
     auto applyN = [&](double v) { return bottom_apply<V>(g, v, cf, a, b, h2inv, sx); };
-    auto dotN = [&](double va, double vb) { return bottom_dot(g, va, vb, scr); };
-    auto normN = [&](double v) { return bottom_norm(g, v, scr); };
+    auto dotN = [&](double va, double vb) { return bottom_dot<tail_threads<CPL>()>(g, va, vb, scr); };
+    auto normN = [&](double v) { return bottom_norm<tail_threads<CPL>()>(g, v, scr); };
     HPGMG_BICGSTAB(applyN, dotN, normN)
   }
 #undef HPGMG_BICGSTAB
   if (g.active) {
     const int box = at.box, ijk = at.ijk;
-    vec_origin(L, box, A.e_id)[ijk] = x;
-    vec_origin(L, box, r0_id)[ijk] = r0; vec_origin(L, box, r_id)[ijk] = r; vec_origin(L, box, p_id)[ijk] = p; vec_origin(L, box, q_id)[ijk] = q;
-    vec_origin(L, box, s_id)[ijk] = sv; vec_origin(L, box, t_id)[ijk] = tv; vec_origin(L, box, Ap_id)[ijk] = Ap; vec_origin(L, box, As_id)[ijk] = As;
-    vec_origin(L, box, VECTOR_TEMP)[ijk] = tmp;
+    gvec_origin(L, box, A.e_id)[ijk] = x;
+    gvec_origin(L, box, r0_id)[ijk] = r0; gvec_origin(L, box, r_id)[ijk] = r; gvec_origin(L, box, p_id)[ijk] = p; gvec_origin(L, box, q_id)[ijk] = q;
+    gvec_origin(L, box, s_id)[ijk] = sv; gvec_origin(L, box, t_id)[ijk] = tv; gvec_origin(L, box, Ap_id)[ijk] = Ap; gvec_origin(L, box, As_id)[ijk] = As;
+    gvec_origin(L, box, VECTOR_TEMP)[ijk] = tmp;
   }
   if (threadIdx.x == 0 && A.krylov_iterations) *A.krylov_iterations += it;
+  if (g.active) sx[g.c] = x;                          // the correction, where the up leg that follows looks for it first
+  carry.e_level = A.n - 1; carry.rhs_level = -1;
   __syncthreads();
 }
 
 // ---- the F-cycle on the chain (leg 4): what FMGSolve does below the chain's first level (mg.c:1270-1300) ----
 // restriction(next.R <- R, RESTRICT_CELL) of the right-hand side, level by level (restriction.c:54-57)
-__device__ void tail_restrict_rhs(const TailArgs &A, int l) {
-  const hpgmg_hip_level &F = A.lv[l].L, &C = A.lv[l + 1].L;
+template <int NT, int CPL>
+__device__ void tail_restrict_rhs(const TailArgs &A, double *const *tab, int l) {
+  const hpgmg_hip_level F = tail_lvl<CPL>(A, l, tab), C = tail_lvl<CPL>(A, l + 1, tab);
   const LevelGeom GF = geom_of(F), GC = geom_of(C);
   const int Dc = C.dim_i, totc = Dc * Dc * Dc;
-  for (int c = threadIdx.x; c < totc; c += kTailThreads) {
+  for (int c = threadIdx.x; c < totc; c += NT) {
     const int cjk = c / GC.D, ci = c % GC.D, cj = cjk % GC.D, ck = cjk / GC.D;
     double f[8];
 #pragma unroll
-    for (int q = 0; q < 8; q++) { const CellRef r = locate(GF, 2 * ci + (q & 1), 2 * cj + ((q >> 1) & 1), 2 * ck + (q >> 2)); f[q] = vec_origin(F, r.box, A.R_id)[r.ijk]; }
+    for (int q = 0; q < 8; q++) { const CellRef r = locate(GF, 2 * ci + (q & 1), 2 * cj + ((q >> 1) & 1), 2 * ck + (q >> 2)); f[q] = gvec_origin(F, r.box, A.R_id)[r.ijk]; }
     double v = f[0] + f[1]; v = v + f[2]; v = v + f[3]; v = v + f[4]; v = v + f[5]; v = v + f[6]; v = v + f[7];
     const CellRef p = locate(GC, ci, cj, ck);
-    vec_origin(C, p.box, A.R_id)[p.ijk] = v * 0.125;
+    gvec_origin(C, p.box, A.R_id)[p.ijk] = v * 0.125;
   }
   __syncthreads();
 }
@@ -363,8 +419,9 @@ __device__ void tail_restrict_rhs(const TailArgs &A, int l) {
 // neighbours) + 3/64 (3 edge neighbours) + 1/64 corner, an even fine cell leaning on the coarse neighbour behind it, an odd one on the
 // one ahead.  The reference first fills the coarse ghost cells (exchange_boundary + apply_BCs_p1, BOX shape: a ghost cell is
 // -, +, - its mirror image for 1, 2, 3 directions leaving the domain, boundary_fd.c:35-38); here the same value is formed on the fly.
-__device__ void tail_interp_fcycle(const TailArgs &A, int l) {
-  const hpgmg_hip_level &F = A.lv[l].L, &C = A.lv[l + 1].L;
+template <int NT, int CPL>
+__device__ void tail_interp_fcycle(const TailArgs &A, double *const *tab, int l) {
+  const hpgmg_hip_level F = tail_lvl<CPL>(A, l, tab), C = tail_lvl<CPL>(A, l + 1, tab);
   const LevelGeom GF = geom_of(F), GC = geom_of(C);
   const int D = F.dim_i, total = D * D * D, Dc = C.dim_i;
   auto coarse = [&](int ci, int cj, int ck) -> double {
@@ -373,13 +430,13 @@ __device__ void tail_interp_fcycle(const TailArgs &A, int l) {
     if (cj < 0) { cj = 0; s = -s; } else if (cj >= Dc) { cj = Dc - 1; s = -s; }
     if (ck < 0) { ck = 0; s = -s; } else if (ck >= Dc) { ck = Dc - 1; s = -s; }
     const CellRef r = locate(GC, ci, cj, ck);
-    return s * vec_origin(C, r.box, A.e_id)[r.ijk];
+    return s * gvec_origin(C, r.box, A.e_id)[r.ijk];
   };
-  for (int c = threadIdx.x; c < total; c += kTailThreads) {
+  for (int c = threadIdx.x; c < total; c += NT) {
     const int cj_ = c / GF.D, gi = c % GF.D, gj = cj_ % GF.D, gk = cj_ / GF.D;
     const int ci = gi >> 1, cj = gj >> 1, ck = gk >> 1, di = (gi & 1) ? 1 : -1, dj = (gj & 1) ? 1 : -1, dk = (gk & 1) ? 1 : -1;
     const CellRef w = locate(GF, gi, gj, gk);
-    double *fp = vec_origin(F, w.box, A.e_id) + w.ijk;
+    const gptr fp = gvec_origin(F, w.box, A.e_id) + w.ijk;
     double v = 0.0 * (*fp);
     v = v + 0.421875 * coarse(ci, cj, ck);
     v = v + 0.140625 * coarse(ci, cj, ck + dk);
@@ -394,45 +451,83 @@ __device__ void tail_interp_fcycle(const TailArgs &A, int l) {
   __syncthreads();
 }
 
-// leg 0: down legs | leg 1: up legs | leg 2: down, bottom solve, up | leg 3: bottom solve only
+// The legs of a V-cycle (0: down legs | 1: up legs | 2: down, bottom solve, up | 3: bottom solve only) and the F-cycle on the chain (leg 4) are both a
+// SEQUENCE of routines the host wrote out (hpgmg_hip_vcycle_tail); interpreting it keeps ONE call site per routine, so everything inlines and TailArgs stays
+// in the kernel-argument segment (several call sites made the compiler copy it to scratch: 3x slower).  CPL: cells per lane -- 1 (512 lanes) for chains from
+// 8^3 down (the usual ones), 4 (1024 lanes) for a chain that starts at 16^3.
+template <int V, int SM, int CPL>
+__global__ __launch_bounds__(tail_threads<CPL>()) void tail_kernel(const TailArgs A) {
+  constexpr int NT = tail_threads<CPL>();
+  __shared__ double sx[CPL * NT];
+  __shared__ double st[(CPL > 3 ? CPL : 3) * NT];      // (the bottom solve's reductions use 2 NT + 24 doubles of it)
+  double *sr = nullptr;                                          // (CPL == 1 only: the 64 KB of static LDS are taken otherwise)
+  if constexpr (CPL == 1) { __shared__ double sr1[NT]; sr = sr1; }
 #ifdef HPGMG_EXP_TIMELINE
-__device__ unsigned long long *g_tail_tl = nullptr;
-#define TAIL_MARK() do { if (threadIdx.x == 0 && g_tail_tl && tl_n < 60) g_tail_tl[tl_n++] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define TAIL_MARK() do { } while (0)
+  if (threadIdx.x == 0) g_tail_tl_n = 0;
 #endif
-template <int V, int SM>
-__global__ __launch_bounds__(kTailThreads) void tail_kernel(const TailArgs A, int leg) {
-  __shared__ double sx[kTailMaxCells];
-  __shared__ double st[kTailMaxCells];
-#ifdef HPGMG_EXP_TIMELINE
-  int tl_n = 0;
-#endif
+  double *const *tab = nullptr;
+  if constexpr (CPL == 1) {
+    // the box-base tables of every level of the chain, and a first touch of every level's descriptor (kernel-argument memory: a scalar-cache miss is ~1 us too)
+    __shared__ double *s_tab[kTailMaxLevels * kTailTabBoxes];
+    double warm = 0.0;
+#pragma unroll
+    for (int l = 0; l < kTailMaxLevels; l++)
+      if (l < A.n) {
+        if ((int)threadIdx.x < A.lv[l].L.num_boxes && (int)threadIdx.x < kTailTabBoxes) s_tab[l * kTailTabBoxes + threadIdx.x] = A.lv[l].L.box_base[threadIdx.x];
+        warm += A.lv[l].h2inv + A.lv[l].c1[kTailMaxSweeps - 1] + A.lv[l].c2[kTailMaxSweeps - 1] + (double)A.lv[l].L.box_stride;
+      }
+    if (warm == 1.2345e300) sx[0] = warm;      // (keeps the touches)
+    tab = s_tab;
+    __syncthreads();
+  }
+  TailCarry carry;
+  carry.rhs_level = -1; carry.e_level = -1;
   TAIL_MARK();
-  if (leg == 0 || leg == 2) { for (int l = 0; l + 1 < A.n; l++) { tail_level<V, SM>(A, l, 0, sx, st); TAIL_MARK(); } }
-  if (leg == 2 || leg == 3) { tail_bottom<V>(A, sx, st); TAIL_MARK(); }
-  if (leg == 1 || leg == 2) { for (int l = A.n - 2; l >= 0; l--) { tail_level<V, SM>(A, l, 1, sx, st); TAIL_MARK(); } }
+  for (int i = 0; i < A.nops; i++) {
+    const int kind = A.ops[i] >> 4, l = A.ops[i] & 15;
+    if (kind == FT_DOWN || kind == FT_UP) tail_level<V, SM, CPL>(A, tab, l, kind, sx, st, sr, carry);
+    else tail_bottom<V, CPL>(A, tab, sx, st, carry);
+    TAIL_MARK();
+  }
 #ifdef HPGMG_EXP_TIMELINE
-  if (threadIdx.x == 0 && g_tail_tl) g_tail_tl[63] = (unsigned long long)tl_n;
+  if (threadIdx.x == 0 && g_tail_tl) g_tail_tl[63] = (unsigned long long)g_tail_tl_n;
 #endif
 }
 // leg 4: the F-cycle on the chain: right-hand side restricted down, bottom solve, then per level upwards interpolation_fcycle + a V-cycle.
 // (Its own kernel: folded into tail_kernel the extra code cost every V-cycle launch registers -- 48 -> 130 us per launch.)
-template <int V, int SM>
-__global__ __launch_bounds__(kTailThreads) void ftail_kernel(const TailArgs A) {
-  __shared__ double sx[kTailMaxCells];
-  __shared__ double st[kTailMaxCells];
-  // the host wrote the sequence out (hpgmg_hip_vcycle_tail); interpreting it keeps ONE call site per routine, so everything inlines
-  // and TailArgs stays in the kernel-argument segment (several call sites made the compiler copy it to scratch: 3x slower)
+template <int V, int SM, int CPL>
+__global__ __launch_bounds__(tail_threads<CPL>()) void ftail_kernel(const TailArgs A) {
+  constexpr int NT = tail_threads<CPL>();
+  __shared__ double sx[CPL * NT];
+  __shared__ double st[(CPL > 3 ? CPL : 3) * NT];      // (the bottom solve's reductions use 2 NT + 24 doubles of it)
+  double *sr = nullptr;                                          // (CPL == 1 only: the 64 KB of static LDS are taken otherwise)
+  if constexpr (CPL == 1) { __shared__ double sr1[NT]; sr = sr1; }
+  double *const *tab = nullptr;
+  if constexpr (CPL == 1) {
+    // the box-base tables of every level of the chain, and a first touch of every level's descriptor (kernel-argument memory: a scalar-cache miss is ~1 us too)
+    __shared__ double *s_tab[kTailMaxLevels * kTailTabBoxes];
+    double warm = 0.0;
+#pragma unroll
+    for (int l = 0; l < kTailMaxLevels; l++)
+      if (l < A.n) {
+        if ((int)threadIdx.x < A.lv[l].L.num_boxes && (int)threadIdx.x < kTailTabBoxes) s_tab[l * kTailTabBoxes + threadIdx.x] = A.lv[l].L.box_base[threadIdx.x];
+        warm += A.lv[l].h2inv + A.lv[l].c1[kTailMaxSweeps - 1] + A.lv[l].c2[kTailMaxSweeps - 1] + (double)A.lv[l].L.box_stride;
+      }
+    if (warm == 1.2345e300) sx[0] = warm;      // (keeps the touches)
+    tab = s_tab;
+    __syncthreads();
+  }
+  TailCarry carry;
+  carry.rhs_level = -1; carry.e_level = -1;
   for (int i = 0; i < A.nops; i++) {
     const int kind = A.ops[i] >> 4, l = A.ops[i] & 15;
-    if (kind == FT_DOWN || kind == FT_UP) tail_level<V, SM>(A, l, kind, sx, st);
-    else if (kind == FT_BOTTOM) tail_bottom<V>(A, sx, st);
-    else if (kind == FT_RESTRICT_RHS) tail_restrict_rhs(A, l);
-    else if (kind == FT_INTERP_F) tail_interp_fcycle(A, l);
+    if (kind == FT_DOWN || kind == FT_UP) tail_level<V, SM, CPL>(A, tab, l, kind, sx, st, sr, carry);
+    else if (kind == FT_BOTTOM) tail_bottom<V, CPL>(A, tab, sx, st, carry);
+    else if (kind == FT_RESTRICT_RHS) tail_restrict_rhs<NT, CPL>(A, tab, l);
+    else if (kind == FT_INTERP_F) tail_interp_fcycle<NT, CPL>(A, tab, l);
     else { // zero_vector(bottom, e): whole padded boxes (misc.c:6-44)
-      const hpgmg_hip_level &B = A.lv[A.n - 1].L;
-      for (int box = 0; box < B.num_boxes; box++) { double *z = B.box_base[box] + (size_t)A.e_id * (size_t)B.volume; for (int c = threadIdx.x; c < B.volume; c += kTailThreads) z[c] = 0.0; }
+      const hpgmg_hip_level B = tail_lvl<CPL>(A, A.n - 1, tab);
+      for (int box = 0; box < B.num_boxes; box++) { const gptr z = as_global(B.box_base[box]) + (size_t)A.e_id * (size_t)B.volume; for (int c = threadIdx.x; c < B.volume; c += NT) z[c] = 0.0; }
       __syncthreads();
     }
   }
@@ -471,6 +566,15 @@ int hpgmg_hip_vcycle_tail(int n, const hpgmg_hip_level *const *levels, const dou
     if (l + 1 < n && cells > kTailMaxCells) return record_error(hipErrorInvalidValue, "vcycle_tail: level too large");
     if (l + 1 == n && leg >= 2 && cells > kBottomMaxCells) return record_error(hipErrorInvalidValue, "vcycle_tail: bottom level too large");
   }
+  int cpl = 1;      // cells per lane: 1 when every level of the chain has at most 512 cells (a workgroup of 512 lanes), else 4 (1024 lanes)
+  for (int l = 0; l < n; l++) if ((long long)levels[l]->dim_i * levels[l]->dim_j * levels[l]->dim_k > kTailThreadsSmall || levels[l]->num_boxes > kTailTabBoxes) cpl = kCellsPerLane;
+  if (leg != 4) {   // the legs of a V-cycle, written out as a sequence
+    int q = 0;
+    if (leg == 0 || leg == 2) for (int l = 0; l + 1 < n; l++) A.ops[q++] = (unsigned char)((FT_DOWN << 4) | l);
+    if (leg == 2 || leg == 3) A.ops[q++] = (unsigned char)(FT_BOTTOM << 4);
+    if (leg == 1 || leg == 2) for (int l = n - 2; l >= 0; l--) A.ops[q++] = (unsigned char)((FT_UP << 4) | l);
+    A.nops = q;
+  }
   if (leg == 4) {   // FMGSolve below levels[0] (mg.c:1270-1300), written out as a sequence
     int q = 0;
     for (int l = 0; l + 1 < n; l++) A.ops[q++] = (unsigned char)((FT_RESTRICT_RHS << 4) | l);
@@ -485,8 +589,10 @@ int hpgmg_hip_vcycle_tail(int n, const hpgmg_hip_level *const *levels, const dou
     if (q > (int)sizeof(A.ops)) return record_error(hipErrorInvalidValue, "vcycle_tail: F-cycle sequence too long");
     A.nops = q;
   }
-#define TAIL_CASE(V, SM) do { if (leg == 4) hipLaunchKernelGGL((ftail_kernel<V, SM>), dim3(1), dim3(kTailThreads), 0, g_stream, A); \
-                              else hipLaunchKernelGGL((tail_kernel<V, SM>), dim3(1), dim3(kTailThreads), 0, g_stream, A, leg); } while (0)
+#define TAIL_CASE(V, SM) do { if (leg == 4) { if (cpl == 1) hipLaunchKernelGGL((ftail_kernel<V, SM, 1>), dim3(1), dim3(kTailThreadsSmall), 0, g_stream, A); \
+                                              else hipLaunchKernelGGL((ftail_kernel<V, SM, kCellsPerLane>), dim3(1), dim3(kTailThreads), 0, g_stream, A); } \
+                              else { if (cpl == 1) hipLaunchKernelGGL((tail_kernel<V, SM, 1>), dim3(1), dim3(kTailThreadsSmall), 0, g_stream, A); \
+                                     else hipLaunchKernelGGL((tail_kernel<V, SM, kCellsPerLane>), dim3(1), dim3(kTailThreads), 0, g_stream, A); } } while (0)
   const int key = variant * 3 + smoother;
   switch (key) {
     case HPGMG_HIP_7PT_VC_HELMHOLTZ * 3 + SM_CHEBY:  TAIL_CASE(HPGMG_HIP_7PT_VC_HELMHOLTZ, SM_CHEBY); break;

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Experiment (library built with EXTRA_HIPFLAGS=-DHPGMG_EXP_TIMELINE): where one V-cycle tail launch (16^3 -> 1^3 and back) spends its time."""
+"""Experiment (library built with EXTRA_HIPFLAGS=-DHPGMG_EXP_TIMELINE): where one V-cycle tail launch (8^3 -> 1^3 and back) spends its time.
+Marks: kernel start; per level visit: loaded (start barrier passed), swept, residual formed, visit done; per bottom solve: done."""
 import ctypes, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -18,4 +19,4 @@ host = np.zeros(64, dtype=np.uint64)
 K.hpgmg_hip_memcpy_d2h(ctypes.c_void_p(host.ctypes.data), ctypes.c_void_p(buf), 64 * 8)
 n = int(host[63]); t = host[:n].astype(np.float64) * 0.01
 print("marks", n, "total us %.1f" % (t[-1] - t[0]))
-print("per routine us (down legs 16,8,4,2 | bottom | up legs 2,4,8,16):", np.round(np.diff(t), 2).tolist())
+print("intervals us:", np.round(np.diff(t), 2).tolist())
