@@ -101,8 +101,10 @@ def test_bench_supervisor_starts_fresh_ranks_with_the_other_transport_when_the_f
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--watchdog", "60"], capture_output=True, text=True, env=env, timeout=600)
     assert out.returncode != 0
     assert not [l for l in out.stdout.splitlines() if l.startswith("{")], out.stdout[-500:]
-    assert "rccl attempt: rank 0 exited with code" in out.stderr and "starting fresh rank processes with the ipc transport" in out.stderr, out.stderr[-2000:]
-    assert "ipc attempt: rank 0 exited with code" in out.stderr and "no attempt produced a result" in out.stderr, out.stderr[-2000:]
+    # (which rank is named depends on timing: a rank still starting up when its peer fails is ended by its supervisor and not listed)
+    import re
+    assert re.search(r"rccl attempt: rank \d exited with code", out.stderr) and "starting fresh rank processes with the ipc transport" in out.stderr, out.stderr[-2000:]
+    assert re.search(r"ipc attempt: rank \d exited with code", out.stderr) and "no attempt produced a result" in out.stderr, out.stderr[-2000:]
 
 
 def test_subset_reductions_are_one_collective_on_a_sub_communicator():
