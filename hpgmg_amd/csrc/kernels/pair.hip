@@ -148,19 +148,33 @@ static int smooth_pair(const hpgmg_hip_level *L, int variant, int gsrb, int swee
   if (!pair_supported_dims(L, variant, Di, Dj, Dk)) return record_error(hipErrorInvalidValue, "smooth_cheby_pair: level not supported");
   if (remote && c32_base) return record_error(hipErrorInvalidValue, "smooth_cheby_pair: remote faces need fp64 coefficients");
   static const int tune_kc = env_int("HPGMG_TUNE_PAIR_KC", 0);
-  constexpr int nw = 16;
-  // k chunk: every workgroup costs KC+2 plane steps and (at 128 VGPRs, 16 waves) one workgroup occupies a CU, so the
-  // launch takes ceil(workgroups / 256) rounds of KC+2 steps: pick the KC that minimises that product
-  int kc = tune_kc;
-  if (kc <= 0) {
-    const int per_plane = (Di / 128) * ((Dj + (nw - 2) - 1) / (nw - 2)), slots = 256;
-    long long best = -1;
-    auto steps = [&](int c) { const long long wgs = (long long)per_plane * ((Dk + c - 1) / c); return ((wgs + slots - 1) / slots) * (c + 2); };
-    for (int c = 8; c <= 64 && c <= Dk; c++) { const long long cost = steps(c); if (best < 0 || cost < best) { best = cost; kc = c; } }
-    // ... and among the chunk lengths within 3 % of that, the LONGEST: two of every KC + 2 planes a workgroup fetches are halo, and the launch is close enough
-    // to the memory system's limit for 5 % fewer bytes to outweigh one more step (256^3: KC 43, one round of 45 steps, 371.8 us per launch against 375.2 for
-    // KC 20, two rounds of 22; tools/ab_pair_kc.sh, profiles/r06e_ab_pair_kc.txt)
-    for (int c = kc + 1; c <= 64 && c <= Dk; c++) if (steps(c) * 100 <= best * 103) kc = c;
+  static const int tune_nw = env_int("HPGMG_TUNE_PAIR_NW", 0);
+  // Waves per workgroup (nw - 2 output rows each) and k chunk.  A workgroup occupies a CU (one fits: LDS, registers), costs KC + 2 plane steps, and a step costs
+  // about in proportion to its waves (the CU's load path is what a step waits for): the launch takes ceil(workgroups / 256) rounds x (KC + 2) steps x nw.  Pick
+  // the pair that minimises that.  What decides is how the grid FITS the 256 CUs: 256^3 with 16 waves is 2 x 19 x 6 = 228 workgroups of 45 steps (338 us);
+  // with 10 waves 2 x 32 x 4 = 256 workgroups of 66 shorter steps (303 us, the kernel at 135 instead of 128 registers: no spills); 512^3 runs best with 12
+  // (5 rounds of 46: 2.67 ms against 2.85).  tools/ab_pair_nw.sh, profiles/r06n_ab_pair_nw.txt.
+  int nw = 16, kc = tune_kc;
+  {
+    const int slots = 256, cand[3] = {10, 12, 16};
+    long long best_cost = -1;
+    for (int ci = 0; ci < 3; ci++) {
+      const int w = cand[ci];
+      if (tune_nw > 0 && w != tune_nw) continue;
+      if (tune_nw <= 0 && c32_base && w == 10) continue;      // (fp32 coefficient streams: the conversions make a step's cost less a matter of its waves; 256^3: 2.92 ms with 10 as with 16, 2.85 with 12)
+      const int per_plane = (Di / 128) * ((Dj + (w - 2) - 1) / (w - 2));
+      auto steps = [&](int c) { const long long wgs = (long long)per_plane * ((Dk + c - 1) / c); return ((wgs + slots - 1) / slots) * (c + 2); };
+      int k = tune_kc;
+      if (k <= 0) {
+        long long best = -1;
+        for (int c = 8; c <= 64 && c <= Dk; c++) { const long long cost = steps(c); if (best < 0 || cost < best) { best = cost; k = c; } }
+        // ... and among the chunk lengths within 3 % of that, the LONGEST: two of every KC + 2 planes a workgroup fetches are halo, and the launch is close enough
+        // to the memory system's limit for 5 % fewer bytes to outweigh one more step (tools/ab_pair_kc.sh, profiles/r06e_ab_pair_kc.txt)
+        for (int c = k + 1; c <= 64 && c <= Dk; c++) if (steps(c) * 100 <= best * 103) k = c;
+      }
+      const long long cost = steps(k) * w;
+      if (best_cost < 0 || cost < best_cost) { best_cost = cost; nw = w; kc = k; }
+    }
   }
   PairArgs A = {};
   A.x0 = VecRef{x0_scr, x0_id}; A.xm1 = VecRef{xm1_scr, xm1_id}; A.out1 = VecRef{out1_scr, out1_id}; A.out2 = VecRef{out2_scr, out2_id};
@@ -208,15 +222,18 @@ static int smooth_pair(const hpgmg_hip_level *L, int variant, int gsrb, int swee
     }
   }
   const int prof = profile_begin(whole_cells);
-#define PAIR_LAUNCH2(VAR, C32, SM, NARROW, INTERP) { \
-      static bool once = false; if (!once) { HPGMG_CHECK(hipFuncSetAttribute((const void *)cheby_pair_kernel<VAR, nw, C32, SM, NARROW, INTERP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once = true; } \
-      hipLaunchKernelGGL((cheby_pair_kernel<VAR, nw, C32, SM, NARROW, INTERP>), dim3(grid), dim3(64, nw), lds, g_stream, *L, A); }
+  // (the waves per workgroup are a template parameter of the kernel: one instance per candidate)
+#define PAIR_NW_SWITCH(...) switch (nw) { case 10: { constexpr int NWC = 10; __VA_ARGS__ } break; case 12: { constexpr int NWC = 12; __VA_ARGS__ } break; default: { constexpr int NWC = 16; __VA_ARGS__ } break; }
+#define PAIR_LAUNCH2(VAR, C32, SM, NARROW, INTERP) PAIR_NW_SWITCH( \
+      static bool once = false; if (!once) { HPGMG_CHECK(hipFuncSetAttribute((const void *)cheby_pair_kernel<VAR, NWC, C32, SM, NARROW, INTERP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)NWC * 6 * 64 * sizeof(p2)))); once = true; } \
+      hipLaunchKernelGGL((cheby_pair_kernel<VAR, NWC, C32, SM, NARROW, INTERP>), dim3(grid), dim3(64, NWC), lds, g_stream, *L, A); )
 #define PAIR_LAUNCH_REMOTE_IP(VAR, SM, NRW, IP) { \
-      static bool once = false; if (!once) { HPGMG_CHECK(hipFuncSetAttribute((const void *)cheby_pair_kernel<VAR, nw, false, SM, NRW, IP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once = true; } \
       const int ecols = 2 * (A.tiles_i - 1) + (A.rem[0] ? 1 : 0) + (A.rem[1] ? 1 : 0); \
       A.edge_blocks = ((A.Dj + 63) / 64) * A.Dk * ecols; const int egrid_r = grid_for(A.edge_blocks, &A.edge_per_xcd); \
       if (ecols > 0) hipLaunchKernelGGL((cheby_pair_edge_kernel<VAR, false, SM, IP, true>), dim3(egrid_r), dim3(64), 0, g_stream, *L, A); \
-      hipLaunchKernelGGL((cheby_pair_kernel<VAR, nw, false, SM, NRW, IP, true>), dim3(grid), dim3(64, nw), lds, g_stream, *L, A); }
+      PAIR_NW_SWITCH( \
+      static bool once = false; if (!once) { HPGMG_CHECK(hipFuncSetAttribute((const void *)cheby_pair_kernel<VAR, NWC, false, SM, NRW, IP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)NWC * 6 * 64 * sizeof(p2)))); once = true; } \
+      hipLaunchKernelGGL((cheby_pair_kernel<VAR, NWC, false, SM, NRW, IP, true>), dim3(grid), dim3(64, NWC), lds, g_stream, *L, A); ) }
 #define PAIR_LAUNCH_REMOTE(VAR, SM) { if (L->dim % 128 != 0) PAIR_LAUNCH_REMOTE_IP(VAR, SM, true, false) else if (interp) PAIR_LAUNCH_REMOTE_IP(VAR, SM, false, true) else PAIR_LAUNCH_REMOTE_IP(VAR, SM, false, false) }
 #define PAIR_LAUNCH(VAR, C32, SM) { \
       A.edge_blocks = ((A.Dj + 63) / 64) * A.Dk * 2 * (A.tiles_i - 1); const dim3 egrid(A.edge_blocks > 0 ? grid_for(A.edge_blocks, &A.edge_per_xcd) : 1); \
@@ -240,6 +257,7 @@ static int smooth_pair(const hpgmg_hip_level *L, int variant, int gsrb, int swee
 #undef PAIR_CASE
 #undef PAIR_LAUNCH
 #undef PAIR_LAUNCH2
+#undef PAIR_NW_SWITCH
 #undef PAIR_LAUNCH_REMOTE
 #undef PAIR_LAUNCH_REMOTE_IP
   if (part != 1) { g_pair_launches++; if (remote) g_pair_remote_launches++; }      // the two parts of a launch count once (part 2 is never empty: it holds the workgroups at the remote faces)
