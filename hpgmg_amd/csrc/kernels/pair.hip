@@ -149,14 +149,15 @@ static int smooth_pair(const hpgmg_hip_level *L, int variant, int gsrb, int swee
   if (remote && c32_base) return record_error(hipErrorInvalidValue, "smooth_cheby_pair: remote faces need fp64 coefficients");
   static const int tune_kc = env_int("HPGMG_TUNE_PAIR_KC", 0);
   static const int tune_nw = env_int("HPGMG_TUNE_PAIR_NW", 0);
-  // Waves per workgroup (nw - 2 output rows each) and k chunk.  A workgroup occupies a CU (one fits: LDS, registers), costs KC + 2 plane steps, and a step costs
-  // about in proportion to its waves (the CU's load path is what a step waits for): the launch takes ceil(workgroups / 256) rounds x (KC + 2) steps x nw.  Pick
-  // the pair that minimises that.  What decides is how the grid FITS the 256 CUs: 256^3 with 16 waves is 2 x 19 x 6 = 228 workgroups of 45 steps (338 us);
-  // with 10 waves 2 x 32 x 4 = 256 workgroups of 66 shorter steps (303 us, the kernel at 135 instead of 128 registers: no spills); 512^3 runs best with 12
-  // (5 rounds of 46: 2.67 ms against 2.85).  tools/ab_pair_nw.sh, profiles/r06n_ab_pair_nw.txt.
+  // Waves per workgroup (nw - 2 output rows each) and k chunk.  A workgroup occupies a CU (one fits: LDS, registers) and costs KC + 2 plane steps; a step
+  // costs about in proportion to its waves (the CU's load path is what a step waits for) -- measured at 256^3: 4.6 / 5.1 / 7.5 us with 10 / 12 / 16 waves (the
+  // 16-wave kernel is held to 128 registers and spills 7).  The launch takes ceil(workgroups / 256) rounds x (KC + 2) steps x that: pick the pair that minimises
+  // it.  What decides is how the grid FITS the 256 CUs: 256^3 with 16 waves is 2 x 19 x 6 = 228 workgroups of 45 steps (338 us); with 10 waves 2 x 32 x 4 = 256
+  // workgroups of 66 shorter steps (303 us); 512^3 runs best with 12 (9 rounds of 49: 2.67 ms against 2.85 with 16).  tools/ab_pair_nw.sh,
+  // profiles/r06n_ab_pair_nw.txt.
   int nw = 16, kc = tune_kc;
   {
-    const int slots = 256, cand[3] = {10, 12, 16};
+    const int slots = 256, cand[3] = {10, 12, 16}, step_cost[3] = {46, 51, 75};      // (tenths of a microsecond per step)
     long long best_cost = -1;
     for (int ci = 0; ci < 3; ci++) {
       const int w = cand[ci];
@@ -172,7 +173,7 @@ static int smooth_pair(const hpgmg_hip_level *L, int variant, int gsrb, int swee
         // to the memory system's limit for 5 % fewer bytes to outweigh one more step (tools/ab_pair_kc.sh, profiles/r06e_ab_pair_kc.txt)
         for (int c = k + 1; c <= 64 && c <= Dk; c++) if (steps(c) * 100 <= best * 103) k = c;
       }
-      const long long cost = steps(k) * w;
+      const long long cost = steps(k) * step_cost[ci];
       if (best_cost < 0 || cost < best_cost) { best_cost = cost; nw = w; kc = k; }
     }
   }
