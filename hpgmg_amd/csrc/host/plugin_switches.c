@@ -16,7 +16,7 @@ static struct { const char *env; int kind; long long dflt; const char *what; lon
   [SW_PAIR_REMOTE]       = { "HPGMG_PAIR_REMOTE", K_ON, 1, "N > 1, 7-pt: sweep pairs across rank boundaries (two-deep halo, one exchange per pair); 0: one exchange per sweep" },
   [SW_IMAGES]            = { "HPGMG_IMAGES", K_ON, 1, "N > 1, 27-pt / fv4: images of the neighbouring ranks' boxes (one-pass red + black kernels keep running); 0: exchange_boundary per half sweep" },
   [SW_FUSED_SWEEPS]      = { "HPGMG_FUSED_SWEEPS", K_ON, 1, "7-pt: two smoother sweeps per pass on bandwidth-bound levels" },
-  [SW_PAIR_MIN_CELLS]    = { "HPGMG_PAIR_MIN_CELLS", K_INT, 4000000, "7-pt: smallest level (cells) that takes the sweep-pair kernel" },
+  [SW_PAIR_MIN_CELLS]    = { "HPGMG_PAIR_MIN_CELLS", K_INT, 2000000, "7-pt: smallest level (cells) that takes the sweep-pair kernel (2 M: the 128^3 level too, since the kernel picks its launch shape per launch -- 16 workgroup rows of 10 waves x 16 chunks = 256 workgroups there: config 2 2.70 vs 2.74 ms; with 16 waves it lost, 3.02 vs 2.92: profiles/r06k_ab_pair_min.txt, r06n_ab_pair_min.txt)" },
   [SW_FUSED_RESIDUAL]    = { "HPGMG_FUSED_RESIDUAL", K_ON, 1, "residual + restriction (+ zero_vector), residual + norm, norm + copy + restriction as one pass each" },
   [SW_FUSED_TAIL]        = { "HPGMG_FUSED_TAIL", K_ON, 1, "7-pt: the V-cycle below the brick levels (<= 8^3; <= 16^3 without them) as one single-workgroup launch" },
   [SW_FUSED_FTAIL]       = { "HPGMG_FUSED_FTAIL", K_ON, 1, "7-pt: the F-cycle's own work below 32^3 as one launch" },

@@ -75,7 +75,8 @@ def test_fp32_smoother_is_tolerance_gated_against_fp64(hip, variant):
         ref = [float(r) for r in gold["norms"]]
         assert abs(got[0] - ref[0]) <= 2e-4 * ref[0], (got[0], ref[0])
         assert got[0] != ref[0] or variant == "7ptcc-cheby"     # the fp32 streams were really used (CC has only Dinv)
-        assert [fmt(v) for v in got[1:]] == gold["norms"][1:]   # 128^3 and 64^3: boxes of 64^3 / 32^3 smooth in fp64
+        assert abs(got[1] - ref[1]) <= 2e-4 * ref[1], (got[1], ref[1])   # 128^3: a sweep-pair level too (>= 2 M cells), fp32 streams there as well
+        assert fmt(got[2]) == gold["norms"][2]                           # 64^3: no sweep-pair level, fp64 throughout
         err, order = s.richardson()
         assert abs(err - float(gold["richardson_error"])) <= 1e-7 * float(gold["richardson_error"])
         assert "%0.3f" % order == gold["order"]
