@@ -364,6 +364,7 @@ void hp_ensure_pair_scratch(level_type *L, backend_t *B) {
   }
 }
 void hpgmg_set_fused_sweeps(int on) { hp_switch_set(SW_FUSED_SWEEPS, on ? 1 : 0); }
+void hpgmg_set_pair_min_cells(long long cells) { hp_switch_set(SW_PAIR_MIN_CELLS, cells > 0 ? cells : 2000000); }
 /* common part: does the level qualify for the sweep-pair kernel, and are its two private vectors there? */
 static int pair_kernel_ready(level_type *L, int x_id, int rhs_id, int sweeps) {
   hpgmg_config cfg;
@@ -504,7 +505,7 @@ int hp_interp_smooth_fused(level_type *Lf, int e_id, int R_id, level_type *Lc, d
   int parents_in_place = (Lc->num_my_boxes == Lf->num_my_boxes), bx;      /* the kernel finds the parent of a cell of fine box b in coarse box b */
   for (bx = 0; parents_in_place && bx < Lf->num_my_boxes; bx++)
     parents_in_place = (2 * Lc->my_boxes[bx].low.i == Lf->my_boxes[bx].low.i && 2 * Lc->my_boxes[bx].low.j == Lf->my_boxes[bx].low.j && 2 * Lc->my_boxes[bx].low.k == Lf->my_boxes[bx].low.k);
-  if (Lf->box_dim % 128 != 0 || Lc->box_dim * 2 != Lf->box_dim || !parents_in_place || (!remote && !boxes_lexicographic(Lc)) ||
+  if ((remote && Lf->box_dim % 128 != 0) || Lc->box_dim * 2 != Lf->box_dim || !parents_in_place ||      /* (narrow boxes across ranks: the fold stays with the single sweeps) */ (!remote && !boxes_lexicographic(Lc)) ||
       (remote && (cfg.smoother != HPGMG_SMOOTH_CHEBY || !hp_switch(SW_PAIR_REMOTE))) ||
       !pair_kernel_ready(Lf, e_id, R_id, sweeps))
     return interp_smooth_fused_single(Lf, e_id, R_id, Lc, a, b);      /* (VECTOR_TEMP ends as smooth() leaves it: also for the queue) not a sweep-pair level: the fold of the single sweeps, if it is one of those */

@@ -216,7 +216,8 @@ __global__ __launch_bounds__(64 * NW) void cheby_pair_kernel(const hpgmg_hip_lev
     p2 v = pld(pair_vec(L, A, A.x0, box) + shift_of(sh, A.x0) + l_i + l_j * jS + plane_off(gk));
     if (INTERP && (!REMOTE || (l_j >= 0 && l_j < bd && gk >= 0 && gk < A.Dk))) {
       const int lk = REMOTE ? gk - kbox(gk) * bd : gk % bd;
-      const double c = gld1(vec_origin(A.Lc, box, A.coarse_id) + ((l_i >> 1) + (l_j >> 1) * A.Lc.jStride + (lk >> 1) * A.Lc.kStride));
+      // (narrow boxes: the lane's own box of the row -- the coarse boxes are numbered like the fine ones)
+      const double c = gld1(vec_origin(A.Lc, NARROW ? box + hop : box, A.coarse_id) + ((l_i >> 1) + (l_j >> 1) * A.Lc.jStride + (lk >> 1) * A.Lc.kStride));
       v.x = A.prescale * v.x + c; v.y = A.prescale * v.y + c;
     }
     return v;

@@ -185,7 +185,7 @@ static int smooth_pair(const hpgmg_hip_level *L, int variant, int gsrb, int swee
   const bool interp = (interp_level != nullptr);
   if (interp) {
     const hpgmg_hip_level *C = interp_level;
-    if (L->dim % 128 != 0 || C->num_boxes != L->num_boxes || 2 * C->dim != L->dim) return record_error(hipErrorInvalidValue, "smooth pair with interpolation: level pair not supported");
+    if ((remote && L->dim % 128 != 0) || C->num_boxes != L->num_boxes || C->num_boxes > kPairMaxBoxes || 2 * C->dim != L->dim) return record_error(hipErrorInvalidValue, "smooth pair with interpolation: level pair not supported");
     A.Lc = *C; A.coarse_id = g_pair_interp_id; A.prescale = g_pair_interp_prescale;
   }
   A.nbi = Di / L->dim; A.nbj = Dj / L->dim;
@@ -241,7 +241,7 @@ static int smooth_pair(const hpgmg_hip_level *L, int variant, int gsrb, int swee
       if (remote) PAIR_LAUNCH_REMOTE(VAR, SM) \
       else if (interp) { \
         if (A.tiles_i > 1) hipLaunchKernelGGL((cheby_pair_edge_kernel<VAR, C32, SM, true>), egrid, dim3(64), 0, g_stream, *L, A); \
-        PAIR_LAUNCH2(VAR, C32, SM, false, true) \
+        if (L->dim % 128 == 0) PAIR_LAUNCH2(VAR, C32, SM, false, true) else PAIR_LAUNCH2(VAR, C32, SM, true, true) \
       } else { \
         if (A.tiles_i > 1) hipLaunchKernelGGL((cheby_pair_edge_kernel<VAR, C32, SM, false>), egrid, dim3(64), 0, g_stream, *L, A); \
         if (L->dim % 128 == 0) PAIR_LAUNCH2(VAR, C32, SM, false, false) else PAIR_LAUNCH2(VAR, C32, SM, true, false) \

@@ -117,6 +117,7 @@ void        hpgmg_set_smoother_precision(int bits); /* 64 (default, bit-exact) o
 int         hpgmg_get_smoother_precision(void);
 void        hpgmg_set_graphs(int on);       /* 1: replay the launch-bound segments of a cycle as hipGraphs (default 0: eager launches measured faster) */
 void        hpgmg_set_fused_sweeps(int on); /* 1 (default): Chebyshev smooth() on boxes of side 128k runs as fused sweep pairs; 0: one launch per sweep */
+void        hpgmg_set_pair_min_cells(long long cells); /* the smallest level (cells) that takes the sweep-pair kernel (default 2 000 000, HPGMG_PAIR_MIN_CELLS); tests */
 void        hpgmg_set_ghost_free(int on);   /* 1 (default): fused ghost handling in the 7-pt stencil launches; 0: exchange + BC + stencil */
 void        hpgmg_set_box_alignment(int jstride, int kstride, int volume, int base_bytes);
 

@@ -168,7 +168,8 @@ def test_restriction_and_interpolation(hip, oracle, geom):
             be.lib.hpgmg_mg_destroy(m); f.destroy()
 
 
-@pytest.mark.parametrize("variant,geom", [("7pt-cheby-helm", (2, 128)), ("7pt-gsrb", (2, 128)), ("7ptcc-cheby", (1, 256))])
+@pytest.mark.parametrize("variant,geom", [("7pt-cheby-helm", (2, 128)), ("7pt-gsrb", (2, 128)), ("7ptcc-cheby", (1, 256)),
+                                          ("7pt-cheby-helm", (2, 64)), ("7pt-gsrb", (2, 64)), ("7pt-cheby", (4, 32))])      # narrow boxes: several per 128-cell row, each lane its own coarse box
 def test_interpolation_folded_into_the_first_sweep_pair(hip, oracle, variant, geom):
     """hpgmg_interp_smooth_fused (the up-leg of MGVCycle on the fine level): interpolation_vcycle + smooth() as sweep pairs whose
     first pass reads e + P(coarse e) without ever storing it.  Must equal the oracle's two separate operators bit for bit."""
@@ -235,7 +236,12 @@ def test_interpolation_folded_into_single_chebyshev_sweeps(hip, oracle, variant,
         coarse_e = seeded_field(ch, 977)
         ch.write_all(H.VECTOR_U, coarse_e); co.write_all(H.VECTOR_U, coarse_e)
         before = hip.lib.hpgmg_interp_folded_single()
-        assert hip.lib.hpgmg_interp_smooth_fused(fh.ptr, H.VECTOR_U, H.VECTOR_F, ch.ptr, a, b) == 1
+        hip.lib.hpgmg_set_pair_min_cells.argtypes = [ctypes.c_longlong]
+        hip.lib.hpgmg_set_pair_min_cells(4000000)      # (a level of 128^3 cells is a sweep-pair level by default: this test is about the single sweeps)
+        try:
+            assert hip.lib.hpgmg_interp_smooth_fused(fh.ptr, H.VECTOR_U, H.VECTOR_F, ch.ptr, a, b) == 1
+        finally:
+            hip.lib.hpgmg_set_pair_min_cells(0)
         assert hip.lib.hpgmg_interp_folded_single() == before + 1
         bo.lib.interpolation_vcycle(fo.ptr, H.VECTOR_U, 1.0, co.ptr, H.VECTOR_U)
         bo.lib.smooth(fo.ptr, H.VECTOR_U, H.VECTOR_F, a, b)
