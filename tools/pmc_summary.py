@@ -26,15 +26,21 @@ def per_kernel(path):
     return out
 
 def biggest(kern, pattern):
-    """average counter value over the launches of the largest grid of the kernels matching pattern"""
-    best = None
+    """average counter value over the launches of the largest grid of the kernels matching pattern.  Several instantiations may share that grid (the sweep-pair
+    kernel runs the 256^3 and the 128^3 level of config 2 as 256 workgroups each; the pre-pass has a once-per-rebuild packing form): of those launched at least
+    a quarter as often as the most frequent one, the one that moves the most bytes = the fine level's."""
+    groups = []
     for name, lst in kern.items():
         if pattern in name:
             g = max(x[0] for x in lst)
             vals = [v for gg, v in lst if gg == g]
-            # same grid for two instantiations (e.g. the pre-pass and its once-per-rebuild packing form): the one launched more often
-            if best is None or (g, len(vals)) > (best[0], best[2]): best = (g, sum(vals) / len(vals), len(vals), name)
-    return best
+            groups.append((g, sum(vals) / len(vals), len(vals), name))
+    if not groups: return None
+    gmax = max(x[0] for x in groups)
+    groups = [x for x in groups if x[0] == gmax]
+    often = max(x[2] for x in groups)
+    groups = [x for x in groups if 4 * x[2] >= often]
+    return max(groups, key=lambda x: x[1])
 
 def main():
     fetch, write, out = per_kernel(sys.argv[1]), per_kernel(sys.argv[2]), sys.argv[3]
