@@ -374,8 +374,8 @@ static int pair_kernel_ready(level_type *L, int x_id, int rhs_id, int sweeps) {
   if (L->boundary_condition.type != BC_DIRICHLET || x_id == VECTOR_TEMP || rhs_id == VECTOR_TEMP) return 0;
   if (B->all_faces_local) { if (!hpgmg_hip_smooth_cheby_pair_supported(&B->dev, hp_variant()) || !boxes_lexicographic(L)) return 0; }
   else if (!hp_pair_halo_ready(L, B)) return 0;          /* faces owned by other ranks: two-deep halo, one exchange per pair */
-  { /* the pass structure pays when the level is bandwidth bound; a cache-resident level (128^3 and smaller) is latency
-     * bound and faster with many small single-sweep workgroups (measured: 128^3 pair 80 us vs 2 x 27 us) */
+  { /* the pass structure pays down to the 128^3 level of config 2 (2 M cells) since the kernel library picks the launch shape per launch: 36-46 us per pair of
+     * sweeps there against 2 x 25 for the tiled single sweeps (with 16 waves per workgroup whatever the level it lost: 80 us) */
     if ((long long)L->dim.i * L->dim.j * L->dim.k < hp_switch(SW_PAIR_MIN_CELLS)) return 0;
   }
   hp_ensure_pair_scratch(L, B);
