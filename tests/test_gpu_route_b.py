@@ -78,8 +78,9 @@ def test_reference_mgsolve_runs_on_the_hip_plugin(variant, args):
     a, b = keep(outs[0]), keep(outs[1])
     assert len(a) > 50 and a == b, [x for x in zip(a, b) if x[0] != x[1]][:4]
     m = re.search(r"hpgmg lazy queue: (\d+) single-launch legs, (\d+) fused large-level units, (\d+) smooths with VECTOR_TEMP proved dead", outs[0].stderr)
-    # (a 7-point problem of 64^3 cells is legs from top to bottom since round 5 -- brick launches above the tail --: no level is left to the unit-by-unit path)
-    all_legs = variant.startswith("7pt") and args == "5 8"
+    # (a problem of 64^3 cells is legs from top to bottom -- 7-point since round 5, fv4 since the wide bricks of round 6; brick launches above the tail --:
+    #  no level is left to the unit-by-unit path)
+    all_legs = args == "5 8"
     assert m and int(m.group(1)) > 0 and (all_legs or int(m.group(3)) > 0), outs[0].stderr[-500:]
 
 
