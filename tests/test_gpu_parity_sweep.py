@@ -22,9 +22,9 @@ CASES = [
 ]
 
 
-def pinned_lines(exe, flags, size):
+def pinned_lines(exe, flags, size, **extra_env):
     cmd = [exe, "--warmup", "1", "--solves", "2"] + flags.split() + size.split()
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, OMP_WAIT_POLICY="passive"))
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, OMP_WAIT_POLICY="passive", **extra_env))
     assert out.returncode == 0, (cmd, out.stdout[-800:], out.stderr[-800:])
     lines = []
     for line in out.stdout.splitlines():
@@ -41,6 +41,28 @@ def test_hip_executable_prints_what_the_oracle_executable_prints(flags, size):
     cpu = pinned_lines(os.path.join(ROOT, "oracle", "hpgmg-fv-oracle"), flags, size)
     assert len(hip) >= 10 and any("f-cycle" in l for l in hip)
     assert hip == cpu
+
+
+_DEFAULT_SHAPE = {}
+
+
+@pytest.mark.parametrize("flags,size,variant", [("--helmholtz", "7 8", "7pt-cheby-helm"), ("--smoother gsrb", "6 8", "7pt-gsrb"), ("", "6 8", "7pt-cheby"), ("--helmholtz", "8 8", "7pt-cheby-helm")])
+@pytest.mark.parametrize("nw,kc", [(10, 0), (12, 0), (16, 0), (10, 16), (12, 32), (16, 8)])
+def test_every_launch_shape_of_the_sweep_pair_kernel_prints_the_same_lines(flags, size, variant, nw, kc):
+    """The sweep-pair kernel exists with 10, 12 and 16 waves per workgroup and marches k chunks of any length; a cost model picks per launch
+    (pair.hip: smooth_pair).  Whatever it picks must not show in the numbers: each shape forced through HPGMG_TUNE_PAIR_NW / HPGMG_TUNE_PAIR_KC
+    prints the lines of the default run, whose f-cycle norms are the reference's (tests/golden/fcycle_norms.json).  512^3, 256^3 and 128^3 fine levels:
+    the levels of two million cells and more are the ones that take the kernel."""
+    import json
+    exe = os.path.join(ROOT, "hpgmg_amd", "bin", "hpgmg-fv")
+    key = (flags, size)
+    if key not in _DEFAULT_SHAPE:
+        _DEFAULT_SHAPE[key] = pinned_lines(exe, flags, size)
+        gold = json.load(open(os.path.join(ROOT, "tests", "golden", "fcycle_norms.json")))[variant + " " + size]["norms"]
+        printed = [re.search(r"norm=(\S+)", l).group(1) for l in _DEFAULT_SHAPE[key] if "f-cycle" in l]
+        assert [g for g in gold if g in printed] == gold, (gold, printed[:6])
+    forced = pinned_lines(exe, flags, size, HPGMG_TUNE_PAIR_NW=str(nw), HPGMG_TUNE_PAIR_KC=str(kc))
+    assert len(forced) >= 10 and forced == _DEFAULT_SHAPE[key]
 
 
 MGPCG_LINES = re.compile(r"(iter=\s*\d+\s+norm=\S+\s+rel=\S+|MGPCG solve \d: norm\(u\)=\S+\s+Krylov iterations on the fine level so far=\d+|MGPCG dot\(u,f\)=\S+\s+mean\(u\)=\S+)")
